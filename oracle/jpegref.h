@@ -1,0 +1,120 @@
+/*
+ * oracle/jpegref.h -- CPU restatement ("oracle") of yigolden/JpegLibrary's Huffman-DCT decode path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as
+ * the checker / CPU baseline.  The product path (jpeglibrary_amd/, libjpgpu.so) never links it.
+ *
+ * Parity pin: this restatement reproduces the reference's own golden PNG dumps
+ * (tests/golden/X.high.png, X.low-diff.png: copied data files of the reference's xunit tests)
+ * with 0 mismatching samples -- see tests/test_oracle_golden.py.
+ *
+ * All "ref:" citations are relative to /root/reference/src/JpegLibrary unless stated.
+ */
+#ifndef JPEGREF_H
+#define JPEGREF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Exception classes of the reference, as status codes. */
+enum {
+    JREF_OK = 0,
+    JREF_INVALID_DATA = 1,      /* System.IO.InvalidDataException           */
+    JREF_INVALID_OPERATION = 2, /* System.InvalidOperationException         */
+    JREF_NOT_SUPPORTED = 3,     /* System.NotSupportedException             */
+    JREF_ARGUMENT = 4           /* System.ArgumentException family          */
+};
+
+typedef struct jref_component {
+    uint8_t identifier, h, v, tq;
+} jref_component;
+
+typedef struct jref_info {
+    int width, height, precision, ncomp;
+    int sof;              /* marker byte of the frame header (0xC0..0xCF)              */
+    int restart_interval; /* value latched by Identify (LAST DRI in the file)          */
+    int consumed;         /* Identify() return value = bytes consumed up to and incl. EOI */
+    jref_component comp[4];
+} jref_info;
+
+/*
+ * The JpegBlockOutputWriter.WriteBlock callback (ref: JpegBlockOutputWriter.cs:17):
+ * 64 int16 row-major, unclamped, at full-resolution pixel coordinates (x, y).
+ */
+typedef void (*jref_write_block_fn)(void *user, const int16_t *block, int component_index, int x, int y);
+
+/* Optional tap: every entropy-decoded baseline block, in decode order, before dequantisation
+ * (64 int16 in zig-zag order).  block_index counts blocks in scan order from 0. */
+typedef void (*jref_coef_tap_fn)(void *user, const int16_t *zigzag_coefs, int component_index, long block_index);
+
+typedef struct jref_decoder jref_decoder;
+
+jref_decoder *jref_create(void);
+void jref_destroy(jref_decoder *d);
+const char *jref_last_error(const jref_decoder *d);
+
+/* ref: JpegDecoder.SetInput (JpegDecoder.cs:56-62): resets frame header and restart interval. */
+void jref_set_input(jref_decoder *d, const uint8_t *data, size_t len);
+/* ref: JpegDecoder.Identify(bool) (JpegDecoder.cs:75-105).  Returns status; info->consumed = return value. */
+int jref_identify(jref_decoder *d, int load_quantization_tables, jref_info *info);
+/* ref: JpegDecoder.TryEstimateQuanlity (JpegDecoder.cs:169-249).  Returns 1 and *quality on success. */
+int jref_try_estimate_quality(jref_decoder *d, float *quality);
+/* ref: JpegDecoder.SetOutputWriter (JpegDecoder.cs:501). */
+void jref_set_output_writer(jref_decoder *d, jref_write_block_fn fn, void *user);
+void jref_set_coef_tap(jref_decoder *d, jref_coef_tap_fn fn, void *user);
+/* ref: JpegDecoder.Decode (JpegDecoder.cs:509-550). */
+int jref_decode(jref_decoder *d);
+/* ref: JpegDecoder.Get/SetRestartInterval (JpegDecoder.cs:656-670), ResetTables etc. */
+int jref_get_restart_interval(const jref_decoder *d);
+
+/* ---- concrete sinks restated from the reference's callers ---- */
+
+/* ref: apps/JpegDecode/JpegBufferOutputWriter8Bit.cs:28-60 ("O2"): out[(y*W+x)*C+comp], signed clamp to [0,255]. */
+typedef struct jref_sink8 {
+    int width, height, component_count;
+    uint8_t *out;
+} jref_sink8;
+void jref_sink8_write(void *sink, const int16_t *block, int component_index, int x, int y);
+
+/* ref: tests/JpegLibrary.Tests/Utils/JpegExtendingOutputWriter.cs:30-112 ("O3"): (ushort) clamp to 2^P-1,
+ * bit-replicated to 16 bits. */
+typedef struct jref_sink16 {
+    int width, height, component_count, precision;
+    uint16_t *out;
+} jref_sink16;
+void jref_sink16_write(void *sink, const int16_t *block, int component_index, int x, int y);
+
+/* Raw sink ("O1x"): full-resolution int16 planes, one per component, plane stride = padded width;
+ * stores exactly what WriteBlock receives (unclamped, chroma already replicated), clipped to the padded plane. */
+typedef struct jref_sink_raw {
+    int padded_width, padded_height, component_count;
+    int16_t *out; /* [component][padded_height][padded_width] */
+} jref_sink_raw;
+void jref_sink_raw_write(void *sink, const int16_t *block, int component_index, int x, int y);
+
+/* ---- one-call helpers used by tests / bench (Identify + Decode, like every caller in the reference) ---- */
+int jref_decode_to_8bit(const uint8_t *data, size_t len, int component_count, uint8_t *out, size_t out_cap,
+                        jref_info *info, char *err, size_t errcap);
+int jref_decode_to_16bit(const uint8_t *data, size_t len, int component_count, uint16_t *out, size_t out_cap,
+                         jref_info *info, char *err, size_t errcap);
+
+/* ---- primitives exported for unit parity tests ---- */
+/* ref: ScanDecoder/JpegScanDecoder.cs:50-73 + FastFloatingPointDCT.cs:54-70: one block, zig-zag int16 in,
+ * spatial int16 out (row-major), unclamped. quant in zig-zag order. */
+void jref_block_dequant_idct_shift(const int16_t *zigzag_coefs, const uint16_t *quant_zigzag, int level_shift,
+                                   int16_t *out64);
+/* ref: JpegHuffmanDecodingTable.cs:249-390: build the decode table from BITS/HUFFVAL. Returns 1 on success.
+ * lookahead: 256 x {size,symbol}; maxcode[18]; valoffset[19]; values[256]. */
+int jref_build_huffman(const uint8_t bits[16], const uint8_t *values, int nvalues, uint8_t lookahead_size[256],
+                       uint8_t lookahead_symbol[256], uint16_t maxcode[18], uint8_t valoffset[19],
+                       uint8_t values_out[256]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

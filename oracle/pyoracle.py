@@ -1,0 +1,205 @@
+"""ctypes binding of oracle/libjpegref.so -- the CPU restatement of the reference decoder.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (jpeglibrary_amd) must never import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libjpegref.so")
+
+JREF_OK, JREF_INVALID_DATA, JREF_INVALID_OPERATION, JREF_NOT_SUPPORTED, JREF_ARGUMENT = range(5)
+STATUS_NAMES = {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException",
+                4: "ArgumentException"}
+
+
+class Component(C.Structure):
+    _fields_ = [("identifier", C.c_uint8), ("h", C.c_uint8), ("v", C.c_uint8), ("tq", C.c_uint8)]
+
+
+class Info(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("precision", C.c_int), ("ncomp", C.c_int),
+                ("sof", C.c_int), ("restart_interval", C.c_int), ("consumed", C.c_int), ("comp", Component * 4)]
+
+
+WRITE_BLOCK_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int)
+COEF_TAP_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int16), C.c_int, C.c_long)
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds). Idempotent."""
+    src = os.path.join(_HERE, "jpegref.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.jref_create.restype = C.c_void_p
+        L.jref_destroy.argtypes = [C.c_void_p]
+        L.jref_last_error.restype = C.c_char_p
+        L.jref_last_error.argtypes = [C.c_void_p]
+        L.jref_set_input.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.jref_identify.argtypes = [C.c_void_p, C.c_int, C.POINTER(Info)]
+        L.jref_try_estimate_quality.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.jref_set_output_writer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.jref_set_coef_tap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.jref_decode.argtypes = [C.c_void_p]
+        L.jref_decode_to_8bit.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Info),
+                                          C.c_char_p, C.c_size_t]
+        L.jref_decode_to_16bit.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Info),
+                                           C.c_char_p, C.c_size_t]
+        L.jref_block_dequant_idct_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.jref_build_huffman.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class OracleError(Exception):
+    def __init__(self, code, message):
+        super().__init__(f"{STATUS_NAMES.get(code, code)}: {message}")
+        self.code = code
+        self.kind = STATUS_NAMES.get(code, str(code))
+        self.message = message
+
+
+def identify(data: bytes, load_quantization_tables=False):
+    """JpegDecoder.SetInput + Identify. Returns (Info, estimated_quality|None)."""
+    L = lib()
+    d = L.jref_create()
+    try:
+        L.jref_set_input(d, data, len(data))
+        info = Info()
+        rc = L.jref_identify(d, int(load_quantization_tables), C.byref(info))
+        if rc != 0:
+            raise OracleError(rc, L.jref_last_error(d).decode())
+        q = None
+        if load_quantization_tables:
+            qf = C.c_float()
+            if L.jref_try_estimate_quality(d, C.byref(qf)):
+                q = qf.value
+        return info, q
+    finally:
+        L.jref_destroy(d)
+
+
+def decode_8bit(data: bytes, component_count=None):
+    """Identify + Decode into the app writer's interleaved u8 buffer (O2). Returns (array[H,W,C], Info)."""
+    L = lib()
+    info, _ = identify(data)
+    cc = component_count or info.ncomp
+    out = np.zeros((info.height, info.width, cc), dtype=np.uint8)
+    err = C.create_string_buffer(256)
+    rc = L.jref_decode_to_8bit(data, len(data), cc, out.ctypes.data, out.size, C.byref(info), err, 256)
+    if rc != 0:
+        raise OracleError(rc, err.value.decode())
+    return out, info
+
+
+def decode_16bit(data: bytes, component_count=4):
+    """Identify + Decode into the xunit test writer's u16 x4 buffer (O3). Returns (array[H,W,C] u16, Info)."""
+    L = lib()
+    info, _ = identify(data)
+    out = np.zeros((info.height, info.width, component_count), dtype=np.uint16)
+    err = C.create_string_buffer(256)
+    rc = L.jref_decode_to_16bit(data, len(data), component_count, out.ctypes.data, out.size, C.byref(info), err, 256)
+    if rc != 0:
+        raise OracleError(rc, err.value.decode())
+    return out, info
+
+
+def decode_with_callbacks(data: bytes, write_block=None, coef_tap=None, call_identify=True):
+    """Run Decode() with Python callbacks.
+
+    write_block(block: np.ndarray[64] int16, component_index, x, y)
+    coef_tap(zigzag: np.ndarray[64] int16, component_index, block_index)
+    Returns Info (from Identify when call_identify, else None).
+    """
+    L = lib()
+    d = L.jref_create()
+    try:
+        L.jref_set_input(d, data, len(data))
+        info = None
+        if call_identify:
+            info = Info()
+            rc = L.jref_identify(d, 0, C.byref(info))
+            if rc != 0:
+                raise OracleError(rc, L.jref_last_error(d).decode())
+
+        def _wb(_user, blk, ci, x, y):
+            if write_block is not None:
+                write_block(np.ctypeslib.as_array(blk, shape=(64,)).copy(), ci, x, y)
+
+        def _tap(_user, blk, ci, bi):
+            coef_tap(np.ctypeslib.as_array(blk, shape=(64,)).copy(), ci, bi)
+
+        wb = WRITE_BLOCK_FN(_wb)
+        L.jref_set_output_writer(d, C.cast(wb, C.c_void_p), None)
+        tap = None
+        if coef_tap is not None:
+            tap = COEF_TAP_FN(_tap)
+            L.jref_set_coef_tap(d, C.cast(tap, C.c_void_p), None)
+        rc = L.jref_decode(d)
+        if rc != 0:
+            raise OracleError(rc, L.jref_last_error(d).decode())
+        return info
+    finally:
+        L.jref_destroy(d)
+
+
+def decode_coefficients(data: bytes):
+    """Baseline only: all entropy-decoded blocks in scan order -> (coefs[nblocks,64] int16 zig-zag, comp[nblocks])."""
+    blocks, comps = [], []
+
+    def tap(z, ci, bi):
+        blocks.append(z)
+        comps.append(ci)
+
+    decode_with_callbacks(data, None, tap)
+    return np.stack(blocks) if blocks else np.zeros((0, 64), np.int16), np.array(comps, dtype=np.int32)
+
+
+def decode_blocks(data: bytes):
+    """All WriteBlock calls in order: list of (component_index, x, y, block[64] int16)."""
+    calls = []
+    info = decode_with_callbacks(data, lambda b, ci, x, y: calls.append((ci, x, y, b)))
+    return calls, info
+
+
+def block_dequant_idct_shift(zigzag_coefs: np.ndarray, quant_zigzag: np.ndarray, level_shift: int) -> np.ndarray:
+    """Vectorised over leading dims: int16[...,64] zig-zag -> int16[...,64] spatial."""
+    L = lib()
+    z = np.ascontiguousarray(zigzag_coefs, dtype=np.int16).reshape(-1, 64)
+    q = np.ascontiguousarray(quant_zigzag, dtype=np.uint16).reshape(64)
+    out = np.empty_like(z)
+    for i in range(z.shape[0]):
+        L.jref_block_dequant_idct_shift(z[i].ctypes.data, q.ctypes.data, level_shift, out[i].ctypes.data)
+    return out.reshape(zigzag_coefs.shape)
+
+
+def build_huffman(bits, values):
+    L = lib()
+    bits = bytes(bits)
+    values = bytes(values)
+    las = np.zeros(256, np.uint8)
+    lasym = np.zeros(256, np.uint8)
+    maxcode = np.zeros(18, np.uint16)
+    valoff = np.zeros(19, np.uint8)
+    vout = np.zeros(256, np.uint8)
+    ok = L.jref_build_huffman(bits, values, len(values), las.ctypes.data, lasym.ctypes.data, maxcode.ctypes.data,
+                              valoff.ctypes.data, vout.ctypes.data)
+    if not ok:
+        raise ValueError("huffman table rejected")
+    return las, lasym, maxcode, valoff, vout
