@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s decoded on the BASELINE.json workload, one process per GPU.
+
+Workload (BASELINE.json configs[1]): a batch of 1024 synthetic 3840x2160 4:2:0 baseline Q75 JPEGs with DRI = 4 MCUs per
+GPU (SURVEY.md 8d recipe, distinct seed per image, > 1 GB of distinct compressed input).  A "step" is one pass of the
+hot path over that batch: marker index -> Huffman MCU decode -> dequantise + float32 IDCT + level shift -> interleaved
+YCbCr8 output (the reference benchmark's sink, tests/JpegLibrary.Benchmarks/DecoderBenchmark.cs:51-73), with the
+compressed bytes already resident in HBM and the pixels left resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--images M] [--workload 4k_dri4|4k_dri0|1080p_q90|512_444]
+
+For N > 1 the driver launches it under torch.distributed.run (one rank per GPU); images shard one-per-GPU
+(embarrassingly parallel: no data-path collective), scaling is weak (per-GPU batch fixed).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (width, height, subsampling, quality, dri, default images per GPU)
+    "4k_dri4": (3840, 2160, "420", 75, 4, 1024),
+    "4k_dri0": (3840, 2160, "420", 75, 0, 1024),
+    "1080p_q90": (1920, 1080, "420", 90, 4, 1024),
+    "512_444": (512, 512, "444", 75, 0, 1),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(buf, sizes, stride, width, height, n_images, max_threads):
+    """Reference-equivalent CPU path (oracle/jpegref.c: Identify + Decode into a JpegBufferOutputWriter8Bit buffer),
+    one independent decoder per host core, on a bounded sample of the same images."""
+    from oracle import pyoracle as po
+
+    L = po.lib()
+    cores = max(1, min(max_threads, os.cpu_count() or 1))
+    # ~15-25 s of CPU work in total at ~0.1 s per 4K image
+    sample = min(n_images, max(cores * 2, int(20.0 / max(0.012 * width * height / 1e6, 1e-3))))
+    sample = max(sample, 1)
+    outs = [np.empty(width * height * 3, np.uint8) for _ in range(cores)]
+
+    def work(tid):
+        err = C.create_string_buffer(256)
+        info = po.Info()
+        n = 0
+        for i in range(tid, sample, cores):
+            rc = L.jref_decode_to_8bit(buf[i * stride:].ctypes.data, int(sizes[i]), 3, outs[tid].ctypes.data, outs[tid].size,
+                                       C.byref(info), err, 256)
+            if rc != 0:
+                raise RuntimeError(err.value.decode())
+            n += 1
+        return n
+
+    # single core
+    t0 = time.perf_counter()
+    n1 = min(sample, 8)
+    for i in range(n1):
+        err = C.create_string_buffer(256)
+        info = po.Info()
+        L.jref_decode_to_8bit(buf[i * stride:].ctypes.data, int(sizes[i]), 3, outs[0].ctypes.data, outs[0].size, C.byref(info), err, 256)
+    t1 = time.perf_counter() - t0
+    single = n1 * width * height / 1e6 / t1
+    with ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        done = sum(ex.map(work, range(cores)))
+        tall = time.perf_counter() - t0
+    return {
+        "value": round(done * width * height / 1e6 / tall, 2),
+        "unit": "Mpixels/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{done} of the benchmark's images, Identify+Decode into an interleaved YCbCr8 buffer, one decoder per core "
+                  f"({tall:.1f} s wall); single core: {single:.1f} Mpixels/s",
+        "single_core_value": round(single, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--images", type=int, default=0, help="images per GPU (default: the workload's batch size)")
+    ap.add_argument("--workload", default="4k_dri4", choices=sorted(WORKLOADS))
+    ap.add_argument("--format", default="interleaved_u8", choices=["interleaved_u8", "planar_u8"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gen-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    n_gpus = world
+
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    import jpeglibrary_amd as jl
+    from tools import jpegsynth
+
+    width, height, ss, quality, dri, default_images = WORKLOADS[args.workload]
+    n_images = args.images or default_images
+    fmt = jl.FMT_INTERLEAVED_U8 if args.format == "interleaved_u8" else jl.FMT_PLANAR_U8
+
+    # ---- synthetic input: distinct seed per image and per rank
+    cpu = os.cpu_count() or 1
+    gen_threads = args.gen_threads or max(1, cpu // max(1, min(world, 8)))
+    t0 = time.perf_counter()
+    buf, sizes, stride = jpegsynth.encode_batch(n_images, width, height, ss, quality, dri, seed0=1 + rank * 1000003, nthreads=gen_threads)
+    t_gen = time.perf_counter() - t0
+    files = [buf[i * stride:i * stride + int(sizes[i])] for i in range(n_images)]
+    log(f"[rank {rank}] generated {n_images} x {width}x{height} {ss} Q{quality} DRI={dri}: {sizes.sum() / 1e6:.1f} MB in {t_gen:.1f} s ({gen_threads} threads)")
+
+    ctx = jl.Context(local_rank)
+    batch = jl.Batch(ctx)
+    t0 = time.perf_counter()
+    batch.upload(files, fmt)
+    t_upload = time.perf_counter() - t0
+    totals = batch.totals()
+    log(f"[rank {rank}] host parse + H2D: {t_upload:.2f} s; {totals}")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        batch.decode()
+    batch.sync()
+    # every image must have decoded cleanly, and a sample must be bit-exact (checked after timing, below)
+    for i in range(n_images):
+        r = batch.result(i)
+        if r.status != 0:
+            raise RuntimeError(f"image {i} failed: status {r.status} detail {r.detail}")
+    if args.warmup:
+        batch.stage_ms()  # drop warm-up events
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.decode()
+    batch.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stage = batch.stage_ms()  # HIP-event averages over exactly the timed steps, on the stream the kernels ran on
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    pixels_per_step = n_images * width * height * n_gpus
+    value = pixels_per_step * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        # dominant kernel: idct_output_kernel.  Algorithmic bytes per launch: 128 B of int16 coefficients
+        # read per 8x8 block + the output bytes written in the chosen layout.
+        idct_bytes = totals["blocks"] * 128 + totals["output_bytes"]
+        idct_s = stage["idct"] / 1e3
+        achieved = idct_bytes / idct_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "idct_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"{args.workload}:{args.format}:{n_images}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpixels/s decoded, 4K 4:2:0 baseline Q75 RST=4, 1 & 8 GPU vs CPU ref",
+            "value": round(value, 1),
+            "unit": "Mpixels/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n_images} x {width}x{height} {ss} baseline Q{quality} DRI={dri} per GPU, output {args.format} resident in HBM",
+                "images_per_gpu": n_images,
+                "compressed_MB_per_gpu": round(totals["compressed_bytes"] / 1e6, 1),
+                "sharding": "image-per-GPU, no collective",
+            },
+            "stage_ms": {k: round(v, 4) for k, v in stage.items()},
+            "roofline": {
+                "kernel": "idct_output_kernel",
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "read_frac": round(totals["blocks"] * 128 / idct_s / 1e9 / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes": idct_bytes,
+                "traffic": traffic,
+            },
+            "host": {"gen_s": round(t_gen, 1), "parse_upload_s": round(t_upload, 2), "cpu_count": cpu},
+        }
+        # spot check after timing: a few images bit-exact against the oracle (checker only)
+        try:
+            from oracle import pyoracle as po
+
+            for i in sorted(set([0, n_images // 2, n_images - 1])):
+                ref, _ = po.decode_8bit(bytes(files[i])) if fmt == jl.FMT_INTERLEAVED_U8 else (None, None)
+                if ref is not None and not np.array_equal(batch.output(i), ref):
+                    raise RuntimeError(f"parity failure on image {i}")
+            out["parity_spot_check"] = "bit-exact vs oracle"
+        except ImportError:
+            out["parity_spot_check"] = "oracle unavailable"
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(buf, sizes, stride, width, height, n_images, cpu)
+        print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,249 @@
+/*
+ * include/jpgpu.h -- C ABI of the MI355X-native baseline-JPEG decode path (libjpgpu.so).
+ *
+ * This is the drop-in boundary for yigolden/JpegLibrary's hot path
+ *     JpegDecoder.Decode() -> JpegHuffmanBaselineScanDecoder.ProcessScan -> JpegBlockOutputWriter.WriteBlock
+ * Every entry point names the reference interface it replaces ("ref:", paths relative to
+ * /root/reference/src/JpegLibrary).  Plain pointers and sizes only; no C++/torch types.
+ * INTEGRATION.md shows the C# P/Invoke stubs that bind these symbols.
+ *
+ * Three levels:
+ *   (1) jpgpu_batch_*    whole-file batch decode with device-resident inputs/outputs (throughput path, bench)
+ *   (2) jpgpu_decode_scan  one scan with pre-parsed tables (what a C# JpegScanDecoder replacement P/Invokes)
+ *   (3) jpgpu_decoder_*  handle-based mirror of the public JpegDecoder API (Identify / SetOutputWriter / Decode)
+ *
+ * Threading: a ctx owns one device + one HIP stream; calls on one ctx (and objects made from it) must be
+ * serialised by the caller; different ctxs are independent (one per GPU / per thread).
+ */
+#ifndef JPGPU_H
+#define JPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JPGPU_VERSION 100
+
+/* ---- status codes.  1..4 mirror the reference's exception classes so a shim can rethrow them. ---- */
+typedef enum jpgpu_status {
+    JPGPU_OK = 0,
+    JPGPU_ERR_INVALID_DATA = 1,      /* System.IO.InvalidDataException   (ref: ScanDecoder/JpegScanDecoder.cs:39-48) */
+    JPGPU_ERR_INVALID_OPERATION = 2, /* System.InvalidOperationException (ref: JpegDecoder.cs:513-518)               */
+    JPGPU_ERR_NOT_SUPPORTED = 3,     /* System.NotSupportedException     (ref: JpegDecoder.cs:629)                   */
+    JPGPU_ERR_ARGUMENT = 4,          /* System.ArgumentException family                                              */
+    JPGPU_ERR_DEVICE = 5,            /* HIP runtime failure (message in jpgpu_last_error)                            */
+    JPGPU_ERR_NO_DEVICE = 6,         /* no MI355X visible: the product has NO CPU fallback                           */
+    JPGPU_ERR_OUT_OF_MEMORY = 7
+} jpgpu_status;
+
+/* Per-image detail codes reported by the device kernels (jpgpu_image_result.detail). */
+typedef enum jpgpu_detail {
+    JPGPU_DETAIL_NONE = 0,
+    JPGPU_DETAIL_INVALID_HUFFMAN_CODE = 1, /* "Invalid Huffman code encountered."  ref: JpegHuffmanDecodingTable.cs:104 */
+    JPGPU_DETAIL_MARKER_IN_DATA = 2,       /* "Expect raw data from bit stream. Yet a marker is encountered." ref: ScanDecoder/JpegHuffmanScanDecoder.cs:107 */
+    JPGPU_DETAIL_STREAM_ENDED = 3,         /* "The bit stream ended prematurely."  ref: ScanDecoder/JpegHuffmanScanDecoder.cs:109 */
+    JPGPU_DETAIL_EXPECT_RESTART = 4,       /* "Expect restart marker."  ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:153 */
+    JPGPU_DETAIL_MISSING_TABLE = 5,        /* Huffman / quantization table not defined. ref: ...BaselineScanDecoder.cs:72-81 */
+    JPGPU_DETAIL_UNSUPPORTED_FRAME = 6,    /* SOF other than SOF0/SOF1 on this path */
+    JPGPU_DETAIL_BAD_HEADER = 7,           /* marker/segment parse failure before the scan */
+    JPGPU_DETAIL_EARLY_EOI = 8             /* not an error: EOI met at a restart boundary, image partially decoded (ref: ...BaselineScanDecoder.cs:145-150) */
+} jpgpu_detail;
+
+/* Output layouts. */
+typedef enum jpgpu_format {
+    /* "O2": interleaved u8, out[(y*W+x)*C + c], signed clamp to [0,255], sub-sampled components replicated,
+     * clipped to W x H.  Byte-identical to apps/JpegDecode/JpegBufferOutputWriter8Bit.cs:28-60 with C = components. */
+    JPGPU_FMT_INTERLEAVED_U8 = 0,
+    /* planar u8 at component-native resolution, planes padded to whole MCUs, signed clamp to [0,255] */
+    JPGPU_FMT_PLANAR_U8 = 1,
+    /* "O1": planar int16 at component-native resolution, planes padded to whole MCUs, UNCLAMPED level-shifted
+     * samples == the blocks JpegBlockOutputWriter.WriteBlock receives before chroma expansion
+     * (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:131-134) */
+    JPGPU_FMT_PLANAR_I16 = 2
+} jpgpu_format;
+
+typedef struct jpgpu_ctx jpgpu_ctx;
+typedef struct jpgpu_batch jpgpu_batch;
+typedef struct jpgpu_decoder jpgpu_decoder;
+
+/* ------------------------------------------------------------------------------------------------ context */
+
+int jpgpu_version(void);
+/* Number of visible HIP devices (0 when none; never initialises a context). */
+int jpgpu_device_count(void);
+/* Creates a context on `device`.  Fails with JPGPU_ERR_NO_DEVICE when no GPU is present. */
+int jpgpu_create(int device, jpgpu_ctx **out);
+void jpgpu_destroy(jpgpu_ctx *ctx);
+/* Last error text of this context (thread-compatible, not thread-safe). ctx may be NULL for create failures. */
+const char *jpgpu_last_error(const jpgpu_ctx *ctx);
+const char *jpgpu_status_string(int status);
+const char *jpgpu_detail_string(int detail);
+
+/* ------------------------------------------------------------------------------------------------ headers */
+
+/* ref: JpegFrameHeader.cs (SOF payload) */
+typedef struct jpgpu_frame_component {
+    uint8_t identifier, h, v, tq;
+} jpgpu_frame_component;
+typedef struct jpgpu_frame {
+    uint16_t width, height; /* SamplesPerLine, NumberOfLines */
+    uint8_t precision, num_components;
+    uint8_t sof; /* marker byte: 0xC0 / 0xC1 */
+    uint8_t reserved;
+    jpgpu_frame_component comp[4];
+} jpgpu_frame;
+
+/* ref: JpegScanHeader.cs (SOS payload) */
+typedef struct jpgpu_scan_component {
+    uint8_t selector, td, ta, reserved;
+} jpgpu_scan_component;
+typedef struct jpgpu_scan {
+    uint8_t num_components, ss, se, ah, al;
+    uint8_t reserved[3];
+    jpgpu_scan_component comp[4];
+} jpgpu_scan;
+
+/* ref: JpegHuffmanDecodingTable.TryParse input: BITS[16] + HUFFVAL (DHT payload without the Tc/Th byte) */
+typedef struct jpgpu_dht {
+    uint8_t present;
+    uint8_t bits[16];
+    uint8_t num_values_minus_0; /* unused, kept for alignment */
+    uint16_t num_values;
+    uint8_t values[256];
+} jpgpu_dht;
+
+/* Geometry of one decoded image inside a batch's output buffer. */
+typedef struct jpgpu_plane_info {
+    uint64_t offset; /* bytes from the image's out_offset */
+    uint32_t width, height, pitch; /* samples; pitch in samples */
+} jpgpu_plane_info;
+typedef struct jpgpu_image_info {
+    int32_t status; /* host-side parse status (jpgpu_status) */
+    int32_t detail;
+    uint16_t width, height;
+    uint8_t precision, num_components, sof, reserved;
+    uint32_t restart_interval;
+    uint32_t mcus_per_line, mcus_per_column, blocks_per_mcu;
+    uint64_t total_blocks;
+    uint64_t out_offset, out_bytes;   /* in the batch output buffer */
+    uint64_t coef_offset;             /* first block index in the batch coefficient buffer */
+    jpgpu_plane_info plane[4];        /* planar formats only */
+} jpgpu_image_info;
+
+typedef struct jpgpu_image_result {
+    int32_t status; /* jpgpu_status */
+    int32_t detail; /* jpgpu_detail */
+    uint32_t error_interval;  /* restart interval index of the first failure */
+    uint32_t decoded_mcus;    /* MCUs actually decoded (== total unless EARLY_EOI) */
+    uint32_t bytes_consumed;  /* entropy bytes up to the terminating marker; same meaning as the reader advance in
+                                 ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:167-176 for well-formed streams */
+    uint32_t terminator;      /* marker byte that ended the entropy segment (0xD9 = EOI), 0 if the data ran out */
+} jpgpu_image_result;
+
+/* ------------------------------------------------------------------------------------------------ (1) batch
+ * Replaces, for a whole set of files at once, the canonical call sequence of every reference caller
+ *   new JpegDecoder(); SetInput; Identify; SetOutputWriter(JpegBufferOutputWriter8Bit); Decode()
+ * (ref: apps/JpegDecode/DecodeAction.cs:26-56, tests/JpegLibrary.Benchmarks/DecoderBenchmark.cs:51-73).
+ */
+int jpgpu_batch_create(jpgpu_ctx *ctx, jpgpu_batch **out);
+void jpgpu_batch_destroy(jpgpu_batch *b);
+
+/* Host side of SetInput+Identify+the marker loop of Decode up to SOS (ref: JpegDecoder.cs:75-162, 509-617):
+ * parses every file's headers/tables, builds device descriptors and uploads the compressed bytes to HBM.
+ * `format` is a jpgpu_format.  Images whose headers fail to parse get a per-image status and are skipped.
+ * Returns JPGPU_OK if the batch is usable (even if some images failed). */
+int jpgpu_batch_upload(jpgpu_batch *b, const uint8_t *const *jpeg, const size_t *len, int n, int format);
+
+/* Launches the device pipeline on the ctx stream (asynchronous):
+ *   marker index -> Huffman MCU decode (ref: ...BaselineScanDecoder.cs:51-222) ->
+ *   dequantise + float32 IDCT + level shift (ref: ScanDecoder/JpegScanDecoder.cs:50-73, FastFloatingPointDCT.cs:54-185) ->
+ *   block output in the batch's format (ref: ...BaselineScanDecoder.cs:225-268 + the sink). */
+int jpgpu_batch_decode(jpgpu_batch *b);
+/* Individual stages, for stage-level parity tests and profiling. */
+int jpgpu_batch_run_entropy(jpgpu_batch *b); /* marker index + Huffman -> coefficient buffer */
+int jpgpu_batch_run_idct(jpgpu_batch *b);    /* coefficient buffer -> output */
+int jpgpu_batch_sync(jpgpu_batch *b);
+
+int jpgpu_batch_size(const jpgpu_batch *b);
+int jpgpu_batch_image_info(const jpgpu_batch *b, int i, jpgpu_image_info *info);
+/* Valid after jpgpu_batch_sync. */
+int jpgpu_batch_result(jpgpu_batch *b, int i, jpgpu_image_result *res);
+
+/* Device pointers (HBM) of the whole-batch buffers; outputs stay resident for downstream GPU consumers. */
+void *jpgpu_batch_output_device(const jpgpu_batch *b, uint64_t *total_bytes);
+void *jpgpu_batch_coefficients_device(const jpgpu_batch *b, uint64_t *total_blocks);
+/* Copies one image's output / coefficient blocks (int16[blocks][64], zig-zag order, MCU scan order) to the host. */
+int jpgpu_batch_download_output(jpgpu_batch *b, int i, void *dst, size_t cap);
+int jpgpu_batch_download_coefficients(jpgpu_batch *b, int i, int16_t *dst, size_t cap_blocks);
+/* Overwrites one image's coefficient blocks from the host (IDCT-stage parity tests; config-5 style accumulate-then-IDCT). */
+int jpgpu_batch_upload_coefficients(jpgpu_batch *b, int i, const int16_t *src, size_t nblocks);
+
+/* hipEvent timings (ms) on the ctx stream, averaged over every jpgpu_batch_decode issued since the previous query
+ * (synchronises): ms[0] marker index, ms[1] Huffman, ms[2] IDCT+output, ms[3] whole pipeline. */
+int jpgpu_batch_stage_ms(jpgpu_batch *b, float ms[4]);
+/* Total entropy-segment bytes / blocks / pixels of the successfully parsed images. */
+int jpgpu_batch_totals(const jpgpu_batch *b, uint64_t *compressed_bytes, uint64_t *blocks, uint64_t *pixels,
+                       uint64_t *output_bytes);
+
+/* ------------------------------------------------------------------------------------------------ (2) per scan
+ * Replaces JpegScanDecoder.ProcessScan(ref JpegReader, JpegScanHeader) for SOF0/SOF1
+ * (ref: ScanDecoder/JpegScanDecoder.cs:12-36, ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:51-177).
+ * The scan decoder's pulled inputs become arguments: GetRestartInterval (JpegDecoder.cs:656),
+ * GetHuffmanTable (:869), GetQuantizationTable (:910).  qt is in zig-zag order like
+ * JpegQuantizationTable.Elements (JpegQuantizationTable.cs:47); qt_present[i] = !IsEmpty.
+ * dht[0][id] are DC tables, dht[1][id] AC tables.  `entropy` points just after the SOS segment
+ * (reader.RemainingBytes); *bytes_consumed is what the reference advances the reader by.
+ * Output is written to host memory `out` (cap bytes) in `format`.
+ */
+int jpgpu_decode_scan(jpgpu_ctx *ctx, const jpgpu_frame *frame, const jpgpu_scan *scan, const uint16_t qt[4][64],
+                      const uint8_t qt_present[4], const jpgpu_dht dht[2][4], uint16_t restart_interval,
+                      const uint8_t *entropy, size_t len, int format, void *out, size_t cap,
+                      jpgpu_image_result *result, size_t *bytes_consumed);
+
+/* ------------------------------------------------------------------------------------------------ (3) decoder
+ * Handle-based mirror of the public JpegDecoder surface (ref: JpegDecoder.cs).  Names follow the reference.
+ */
+/* ref: JpegBlockOutputWriter.WriteBlock (JpegBlockOutputWriter.cs:17): 64 int16 row-major, unclamped,
+ * full-resolution pixel coordinates; same call order as the reference (MCU raster, scan-component order,
+ * block raster in MCU, sub-block raster for expanded chroma). */
+typedef void (*jpgpu_write_block_fn)(void *user, const int16_t *block, int component_index, int x, int y);
+
+/* ctx may be NULL for host-only use (Identify / metadata / tables); Decode then returns JPGPU_ERR_NO_DEVICE. */
+int jpgpu_decoder_create(jpgpu_ctx *ctx, jpgpu_decoder **out);          /* new JpegDecoder()                */
+void jpgpu_decoder_destroy(jpgpu_decoder *d);
+const char *jpgpu_decoder_last_error(const jpgpu_decoder *d);
+int jpgpu_decoder_set_input(jpgpu_decoder *d, const uint8_t *data, size_t len); /* SetInput  :49-62    */
+int jpgpu_decoder_identify(jpgpu_decoder *d, int load_quantization_tables, int *stream_length); /* Identify :75-105 */
+int jpgpu_decoder_try_estimate_quality(jpgpu_decoder *d, float *quality);       /* TryEstimateQuanlity :169-196 */
+int jpgpu_decoder_width(const jpgpu_decoder *d);                                 /* Width  :383 (-1: no frame header) */
+int jpgpu_decoder_height(const jpgpu_decoder *d);                                /* Height :388 */
+int jpgpu_decoder_precision(const jpgpu_decoder *d);                             /* Precision :393 */
+int jpgpu_decoder_number_of_components(const jpgpu_decoder *d);                  /* NumberOfComponents :398 */
+int jpgpu_decoder_start_of_frame(const jpgpu_decoder *d);                        /* StartOfFrame :43 */
+int jpgpu_decoder_get_maximum_horizontal_sampling(jpgpu_decoder *d);             /* :413 */
+int jpgpu_decoder_get_maximum_vertical_sampling(jpgpu_decoder *d);               /* :436 */
+int jpgpu_decoder_get_horizontal_sampling(jpgpu_decoder *d, int component_index); /* :462 */
+int jpgpu_decoder_get_vertical_sampling(jpgpu_decoder *d, int component_index);   /* :481 */
+int jpgpu_decoder_get_restart_interval(const jpgpu_decoder *d);                  /* GetRestartInterval :656 */
+int jpgpu_decoder_set_restart_interval(jpgpu_decoder *d, int restart_interval);  /* SetRestartInterval :662 */
+int jpgpu_decoder_load_tables(jpgpu_decoder *d, const uint8_t *data, size_t len); /* LoadTables :313-363 */
+/* SetOutputWriter :501 -- generic writer: blocks are decoded on the GPU (PLANAR_I16) and replayed on the host. */
+int jpgpu_decoder_set_output_writer(jpgpu_decoder *d, jpgpu_write_block_fn fn, void *user);
+/* SetOutputWriter with the reference's stock 8-bit sink (apps/JpegDecode/JpegBufferOutputWriter8Bit.cs):
+ * the interleaved buffer is produced directly on the GPU (INTERLEAVED_U8) and copied into `out`. */
+int jpgpu_decoder_set_output_buffer8(jpgpu_decoder *d, int width, int height, int component_count, uint8_t *out,
+                                     size_t cap);
+int jpgpu_decoder_decode(jpgpu_decoder *d);                                      /* Decode :509-550 */
+void jpgpu_decoder_reset(jpgpu_decoder *d);                                      /* Reset :930 */
+void jpgpu_decoder_reset_input(jpgpu_decoder *d);                                /* ResetInput :941 */
+void jpgpu_decoder_reset_header(jpgpu_decoder *d);                               /* ResetHeader :949 */
+void jpgpu_decoder_reset_tables(jpgpu_decoder *d);                               /* ResetTables :960 */
+void jpgpu_decoder_reset_output_writer(jpgpu_decoder *d);                        /* ResetOutputWriter :975 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPGPU_H */

@@ -1,0 +1,18 @@
+"""jpeglibrary_amd -- MI355X-native baseline-JPEG decode path behind the JpegLibrary decoder API.
+
+Importing the package loads the in-tree HIP library (libjpgpu.so); it raises if the library is missing.
+There is no CPU fallback: creating a context without a GPU raises NoDeviceError.
+"""
+from . import _capi  # noqa: F401  (loads libjpgpu.so, fails loudly when absent)
+from .batch import FMT_INTERLEAVED_U8, FMT_PLANAR_I16, FMT_PLANAR_U8, Batch, decode_batch
+from .context import Context, default_context, device_count
+from .decoder import JpegBlockOutputWriter, JpegBufferOutputWriter8Bit, JpegDecoder, JpegExtendingOutputWriter
+from .errors import (ArgumentException, DeviceError, InvalidDataException, InvalidOperationException, JpegError,
+                     NoDeviceError, NotSupportedException)
+
+__all__ = [
+    "Batch", "decode_batch", "Context", "default_context", "device_count", "JpegDecoder", "JpegBlockOutputWriter",
+    "JpegBufferOutputWriter8Bit", "JpegExtendingOutputWriter", "FMT_INTERLEAVED_U8", "FMT_PLANAR_U8", "FMT_PLANAR_I16",
+    "JpegError", "InvalidDataException", "InvalidOperationException", "NotSupportedException", "ArgumentException",
+    "DeviceError", "NoDeviceError",
+]

@@ -1,0 +1,133 @@
+"""ctypes binding of libjpgpu.so (the C ABI declared in include/jpgpu.h).
+
+The product has NO CPU fallback: importing this module loads the in-tree HIP library and raises if it is
+missing; creating a context raises if no MI355X is visible.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjpgpu.so")
+
+OK, ERR_INVALID_DATA, ERR_INVALID_OPERATION, ERR_NOT_SUPPORTED, ERR_ARGUMENT, ERR_DEVICE, ERR_NO_DEVICE, ERR_OOM = range(8)
+FMT_INTERLEAVED_U8, FMT_PLANAR_U8, FMT_PLANAR_I16 = 0, 1, 2
+
+DETAIL_NAMES = {0: "NONE", 1: "INVALID_HUFFMAN_CODE", 2: "MARKER_IN_DATA", 3: "STREAM_ENDED", 4: "EXPECT_RESTART",
+                5: "MISSING_TABLE", 6: "UNSUPPORTED_FRAME", 7: "BAD_HEADER", 8: "EARLY_EOI"}
+
+
+class FrameComponent(C.Structure):
+    _fields_ = [("identifier", C.c_uint8), ("h", C.c_uint8), ("v", C.c_uint8), ("tq", C.c_uint8)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("width", C.c_uint16), ("height", C.c_uint16), ("precision", C.c_uint8), ("num_components", C.c_uint8),
+                ("sof", C.c_uint8), ("reserved", C.c_uint8), ("comp", FrameComponent * 4)]
+
+
+class ScanComponent(C.Structure):
+    _fields_ = [("selector", C.c_uint8), ("td", C.c_uint8), ("ta", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class Scan(C.Structure):
+    _fields_ = [("num_components", C.c_uint8), ("ss", C.c_uint8), ("se", C.c_uint8), ("ah", C.c_uint8), ("al", C.c_uint8),
+                ("reserved", C.c_uint8 * 3), ("comp", ScanComponent * 4)]
+
+
+class Dht(C.Structure):
+    _fields_ = [("present", C.c_uint8), ("bits", C.c_uint8 * 16), ("num_values_minus_0", C.c_uint8),
+                ("num_values", C.c_uint16), ("values", C.c_uint8 * 256)]
+
+
+class PlaneInfo(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32), ("pitch", C.c_uint32)]
+
+
+class ImageInfo(C.Structure):
+    _fields_ = [("status", C.c_int32), ("detail", C.c_int32), ("width", C.c_uint16), ("height", C.c_uint16),
+                ("precision", C.c_uint8), ("num_components", C.c_uint8), ("sof", C.c_uint8), ("reserved", C.c_uint8),
+                ("restart_interval", C.c_uint32), ("mcus_per_line", C.c_uint32), ("mcus_per_column", C.c_uint32),
+                ("blocks_per_mcu", C.c_uint32), ("total_blocks", C.c_uint64), ("out_offset", C.c_uint64),
+                ("out_bytes", C.c_uint64), ("coef_offset", C.c_uint64), ("plane", PlaneInfo * 4)]
+
+
+class ImageResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("detail", C.c_int32), ("error_interval", C.c_uint32), ("decoded_mcus", C.c_uint32),
+                ("bytes_consumed", C.c_uint32), ("terminator", C.c_uint32)]
+
+
+WRITE_BLOCK_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int)
+
+# every symbol include/jpgpu.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("jpgpu_version", C.c_int, []),
+    ("jpgpu_device_count", C.c_int, []),
+    ("jpgpu_create", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("jpgpu_destroy", None, [_P]),
+    ("jpgpu_last_error", C.c_char_p, [_P]),
+    ("jpgpu_status_string", C.c_char_p, [C.c_int]),
+    ("jpgpu_detail_string", C.c_char_p, [C.c_int]),
+    ("jpgpu_batch_create", C.c_int, [_P, C.POINTER(_P)]),
+    ("jpgpu_batch_destroy", None, [_P]),
+    ("jpgpu_batch_upload", C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int]),
+    ("jpgpu_batch_decode", C.c_int, [_P]),
+    ("jpgpu_batch_run_entropy", C.c_int, [_P]),
+    ("jpgpu_batch_run_idct", C.c_int, [_P]),
+    ("jpgpu_batch_sync", C.c_int, [_P]),
+    ("jpgpu_batch_size", C.c_int, [_P]),
+    ("jpgpu_batch_image_info", C.c_int, [_P, C.c_int, C.POINTER(ImageInfo)]),
+    ("jpgpu_batch_result", C.c_int, [_P, C.c_int, C.POINTER(ImageResult)]),
+    ("jpgpu_batch_output_device", C.c_void_p, [_P, C.POINTER(C.c_uint64)]),
+    ("jpgpu_batch_coefficients_device", C.c_void_p, [_P, C.POINTER(C.c_uint64)]),
+    ("jpgpu_batch_download_output", C.c_int, [_P, C.c_int, C.c_void_p, C.c_size_t]),
+    ("jpgpu_batch_download_coefficients", C.c_int, [_P, C.c_int, C.c_void_p, C.c_size_t]),
+    ("jpgpu_batch_upload_coefficients", C.c_int, [_P, C.c_int, C.c_void_p, C.c_size_t]),
+    ("jpgpu_batch_stage_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("jpgpu_batch_totals", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("jpgpu_decode_scan", C.c_int, [_P, C.POINTER(Frame), C.POINTER(Scan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint16,
+                                    C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(ImageResult),
+                                    C.POINTER(C.c_size_t)]),
+    ("jpgpu_decoder_create", C.c_int, [_P, C.POINTER(_P)]),
+    ("jpgpu_decoder_destroy", None, [_P]),
+    ("jpgpu_decoder_last_error", C.c_char_p, [_P]),
+    ("jpgpu_decoder_set_input", C.c_int, [_P, C.c_void_p, C.c_size_t]),
+    ("jpgpu_decoder_identify", C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
+    ("jpgpu_decoder_try_estimate_quality", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("jpgpu_decoder_width", C.c_int, [_P]),
+    ("jpgpu_decoder_height", C.c_int, [_P]),
+    ("jpgpu_decoder_precision", C.c_int, [_P]),
+    ("jpgpu_decoder_number_of_components", C.c_int, [_P]),
+    ("jpgpu_decoder_start_of_frame", C.c_int, [_P]),
+    ("jpgpu_decoder_get_maximum_horizontal_sampling", C.c_int, [_P]),
+    ("jpgpu_decoder_get_maximum_vertical_sampling", C.c_int, [_P]),
+    ("jpgpu_decoder_get_horizontal_sampling", C.c_int, [_P, C.c_int]),
+    ("jpgpu_decoder_get_vertical_sampling", C.c_int, [_P, C.c_int]),
+    ("jpgpu_decoder_get_restart_interval", C.c_int, [_P]),
+    ("jpgpu_decoder_set_restart_interval", C.c_int, [_P, C.c_int]),
+    ("jpgpu_decoder_load_tables", C.c_int, [_P, C.c_void_p, C.c_size_t]),
+    ("jpgpu_decoder_set_output_writer", C.c_int, [_P, C.c_void_p, C.c_void_p]),
+    ("jpgpu_decoder_set_output_buffer8", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    ("jpgpu_decoder_decode", C.c_int, [_P]),
+    ("jpgpu_decoder_reset", None, [_P]),
+    ("jpgpu_decoder_reset_input", None, [_P]),
+    ("jpgpu_decoder_reset_header", None, [_P]),
+    ("jpgpu_decoder_reset_tables", None, [_P]),
+    ("jpgpu_decoder_reset_output_writer", None, [_P]),
+]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(jpeglibrary_amd has no CPU fallback; the HIP library is the product)")
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+lib = _load()

@@ -1,0 +1,140 @@
+"""Device-resident batch decode (include/jpgpu.h level 1: jpgpu_batch_*).
+
+Replaces, for a set of files at once, the canonical reference sequence
+    new JpegDecoder(); SetInput; Identify; SetOutputWriter(JpegBufferOutputWriter8Bit); Decode()
+(ref: apps/JpegDecode/DecodeAction.cs:26-56, tests/JpegLibrary.Benchmarks/DecoderBenchmark.cs:51-73).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .context import Context, default_context
+from .errors import raise_for_status
+
+_lib = _capi.lib
+FMT_INTERLEAVED_U8, FMT_PLANAR_U8, FMT_PLANAR_I16 = _capi.FMT_INTERLEAVED_U8, _capi.FMT_PLANAR_U8, _capi.FMT_PLANAR_I16
+
+
+class Batch:
+    def __init__(self, ctx: Context = None):
+        self.ctx = ctx or default_context()
+        self._h = C.c_void_p()
+        raise_for_status(_lib.jpgpu_batch_create(self.ctx._h, C.byref(self._h)), b"jpgpu_batch_create failed")
+        self.format = FMT_INTERLEAVED_U8
+        self._keep = None
+
+    def _check(self, rc):
+        raise_for_status(rc, _lib.jpgpu_last_error(self.ctx._h))
+
+    def upload(self, files, fmt=FMT_INTERLEAVED_U8):
+        """files: list of bytes-like objects or of (numpy uint8 array) views. Host parse + H2D."""
+        n = len(files)
+        ptrs = (C.c_void_p * n)()
+        lens = (C.c_size_t * n)()
+        keep = []
+        for i, f in enumerate(files):
+            a = np.frombuffer(f, dtype=np.uint8) if not isinstance(f, np.ndarray) else f
+            if not a.flags["C_CONTIGUOUS"]:
+                a = np.ascontiguousarray(a)
+            keep.append(a)
+            ptrs[i] = a.ctypes.data
+            lens[i] = a.size
+        self._check(_lib.jpgpu_batch_upload(self._h, ptrs, lens, n, fmt))
+        self.format = fmt
+        return self
+
+    def decode(self):
+        self._check(_lib.jpgpu_batch_decode(self._h))
+        return self
+
+    def run_entropy(self):
+        self._check(_lib.jpgpu_batch_run_entropy(self._h))
+        return self
+
+    def run_idct(self):
+        self._check(_lib.jpgpu_batch_run_idct(self._h))
+        return self
+
+    def sync(self):
+        self._check(_lib.jpgpu_batch_sync(self._h))
+        return self
+
+    def __len__(self):
+        return _lib.jpgpu_batch_size(self._h)
+
+    def image_info(self, i) -> _capi.ImageInfo:
+        info = _capi.ImageInfo()
+        self._check(_lib.jpgpu_batch_image_info(self._h, i, C.byref(info)))
+        return info
+
+    def result(self, i) -> _capi.ImageResult:
+        res = _capi.ImageResult()
+        self._check(_lib.jpgpu_batch_result(self._h, i, C.byref(res)))
+        return res
+
+    def stage_ms(self):
+        ms = (C.c_float * 4)()
+        self._check(_lib.jpgpu_batch_stage_ms(self._h, ms))
+        return {"marker_index": ms[0], "huffman": ms[1], "idct": ms[2], "total": ms[3]}
+
+    def totals(self):
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _lib.jpgpu_batch_totals(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return {"compressed_bytes": a.value, "blocks": b.value, "pixels": c.value, "output_bytes": d.value}
+
+    def output_device_ptr(self):
+        total = C.c_uint64()
+        p = _lib.jpgpu_batch_output_device(self._h, C.byref(total))
+        return p, total.value
+
+    def output(self, i):
+        """Downloads image i. INTERLEAVED_U8 -> uint8[H,W,C]; PLANAR_* -> list of per-component 2-D arrays (padded)."""
+        info = self.image_info(i)
+        raise_for_status(info.status, _lib.jpgpu_last_error(self.ctx._h))
+        raw = np.empty(info.out_bytes, dtype=np.uint8)
+        self._check(_lib.jpgpu_batch_download_output(self._h, i, raw.ctypes.data, raw.size))
+        if self.format == FMT_INTERLEAVED_U8:
+            return raw.reshape(info.height, info.width, info.num_components)
+        dt = np.int16 if self.format == FMT_PLANAR_I16 else np.uint8
+        planes = []
+        for c in range(info.num_components):
+            p = info.plane[c]
+            nbytes = p.pitch * p.height * np.dtype(dt).itemsize
+            planes.append(raw[p.offset:p.offset + nbytes].view(dt).reshape(p.height, p.pitch)[:, :p.width])
+        return planes
+
+    def coefficients(self, i):
+        """int16[blocks, 64] zig-zag order, MCU scan order (the buffer between the Huffman and IDCT stages)."""
+        info = self.image_info(i)
+        raise_for_status(info.status, _lib.jpgpu_last_error(self.ctx._h))
+        out = np.empty((info.total_blocks, 64), dtype=np.int16)
+        self._check(_lib.jpgpu_batch_download_coefficients(self._h, i, out.ctypes.data, info.total_blocks))
+        return out
+
+    def set_coefficients(self, i, coefs):
+        coefs = np.ascontiguousarray(coefs, dtype=np.int16).reshape(-1, 64)
+        self._check(_lib.jpgpu_batch_upload_coefficients(self._h, i, coefs.ctypes.data, coefs.shape[0]))
+
+    def close(self):
+        if self._h:
+            _lib.jpgpu_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decode_batch(files, fmt=FMT_INTERLEAVED_U8, ctx=None):
+    """One-call helper: returns (outputs, results)."""
+    b = Batch(ctx).upload(files, fmt).decode().sync()
+    outs, results = [], []
+    for i in range(len(b)):
+        r = b.result(i)
+        results.append(r)
+        outs.append(b.output(i) if b.image_info(i).status == 0 else None)
+    b.close()
+    return outs, results

@@ -1,0 +1,590 @@
+// jpeglibrary_amd/csrc/capi.cpp -- extern "C" entry points declared in include/jpgpu.h.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <new>
+
+#include "../../include/jpgpu.h"
+#include "device_batch.h"
+#include "host.h"
+
+using namespace jpgpu;
+
+struct jpgpu_batch {
+    jpgpu_ctx *ctx;
+    DeviceBatch impl;
+    explicit jpgpu_batch(jpgpu_ctx *c) : ctx(c), impl(c) {}
+};
+
+static thread_local std::string g_create_error;
+
+extern "C" {
+
+int jpgpu_version(void) { return JPGPU_VERSION; }
+
+int jpgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int jpgpu_create(int device, jpgpu_ctx **out) {
+    if (!out) return JPGPU_ERR_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = "No HIP device is visible (libjpgpu has no CPU fallback).";
+        return JPGPU_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        g_create_error = "Device index out of range.";
+        return JPGPU_ERR_ARGUMENT;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return JPGPU_ERR_DEVICE;
+    }
+    std::unique_ptr<jpgpu_ctx> ctx(new (std::nothrow) jpgpu_ctx());
+    if (!ctx) return JPGPU_ERR_OUT_OF_MEMORY;
+    ctx->device = device;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        return JPGPU_ERR_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    *out = ctx.release();
+    return JPGPU_OK;
+}
+
+void jpgpu_destroy(jpgpu_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *jpgpu_last_error(const jpgpu_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
+
+const char *jpgpu_status_string(int status) {
+    switch (status) {
+    case JPGPU_OK: return "OK";
+    case JPGPU_ERR_INVALID_DATA: return "InvalidDataException";
+    case JPGPU_ERR_INVALID_OPERATION: return "InvalidOperationException";
+    case JPGPU_ERR_NOT_SUPPORTED: return "NotSupportedException";
+    case JPGPU_ERR_ARGUMENT: return "ArgumentException";
+    case JPGPU_ERR_DEVICE: return "HIP device error";
+    case JPGPU_ERR_NO_DEVICE: return "no HIP device";
+    case JPGPU_ERR_OUT_OF_MEMORY: return "out of memory";
+    default: return "unknown status";
+    }
+}
+
+const char *jpgpu_detail_string(int detail) {
+    switch (detail) {
+    case JPGPU_DETAIL_NONE: return "";
+    case JPGPU_DETAIL_INVALID_HUFFMAN_CODE: return "Invalid Huffman code encountered.";
+    case JPGPU_DETAIL_MARKER_IN_DATA: return "Failed to decode JPEG data. Expect raw data from bit stream. Yet a marker is encountered.";
+    case JPGPU_DETAIL_STREAM_ENDED: return "Failed to decode JPEG data. The bit stream ended prematurely.";
+    case JPGPU_DETAIL_EXPECT_RESTART: return "Expect restart marker.";
+    case JPGPU_DETAIL_MISSING_TABLE: return "Failed to decode JPEG data. A Huffman or quantization table is not defined.";
+    case JPGPU_DETAIL_UNSUPPORTED_FRAME: return "This type of JPEG stream is not supported on the GPU path.";
+    case JPGPU_DETAIL_BAD_HEADER: return "Failed to decode JPEG data. Malformed marker segment.";
+    case JPGPU_DETAIL_EARLY_EOI: return "EndOfImage met at a restart boundary; image partially decoded.";
+    default: return "unknown detail";
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ batch
+
+int jpgpu_batch_create(jpgpu_ctx *ctx, jpgpu_batch **out) {
+    if (!ctx || !out) return JPGPU_ERR_ARGUMENT;
+    *out = new (std::nothrow) jpgpu_batch(ctx);
+    return *out ? JPGPU_OK : JPGPU_ERR_OUT_OF_MEMORY;
+}
+void jpgpu_batch_destroy(jpgpu_batch *b) { delete b; }
+
+#define JPGPU_GUARD(b, expr)                                                   \
+    if (!(b)) return JPGPU_ERR_ARGUMENT;                                       \
+    try {                                                                      \
+        return (expr);                                                         \
+    } catch (const DecodeError &e) {                                           \
+        (b)->ctx->last_error = e.what();                                       \
+        return e.status;                                                       \
+    } catch (const std::bad_alloc &) {                                         \
+        (b)->ctx->last_error = "host allocation failed";                       \
+        return JPGPU_ERR_OUT_OF_MEMORY;                                        \
+    } catch (const std::exception &e) {                                        \
+        (b)->ctx->last_error = e.what();                                       \
+        return JPGPU_ERR_DEVICE;                                               \
+    }
+
+int jpgpu_batch_upload(jpgpu_batch *b, const uint8_t *const *jpeg, const size_t *len, int n, int format) {
+    JPGPU_GUARD(b, b->impl.upload_files(jpeg, len, n, format));
+}
+int jpgpu_batch_decode(jpgpu_batch *b) { JPGPU_GUARD(b, b->impl.decode()); }
+int jpgpu_batch_run_entropy(jpgpu_batch *b) {
+    if (!b) return JPGPU_ERR_ARGUMENT;
+    int rc = b->impl.run_marker_index();
+    return rc != JPGPU_OK ? rc : b->impl.run_huffman();
+}
+int jpgpu_batch_run_idct(jpgpu_batch *b) { JPGPU_GUARD(b, b->impl.run_idct()); }
+int jpgpu_batch_sync(jpgpu_batch *b) { JPGPU_GUARD(b, b->impl.sync()); }
+int jpgpu_batch_size(const jpgpu_batch *b) { return b ? b->impl.size() : 0; }
+
+int jpgpu_batch_image_info(const jpgpu_batch *b, int i, jpgpu_image_info *info) {
+    if (!b || !info) return JPGPU_ERR_ARGUMENT;
+    const ImagePlan *img = b->impl.image(i);
+    if (!img) return JPGPU_ERR_ARGUMENT;
+    memset(info, 0, sizeof *info);
+    info->status = img->status;
+    info->detail = img->detail;
+    info->width = img->width;
+    info->height = img->height;
+    info->precision = img->precision;
+    info->num_components = img->num_components;
+    info->sof = img->sof;
+    info->restart_interval = img->restart_interval;
+    info->mcus_per_line = img->mcus_per_line;
+    info->mcus_per_column = img->mcus_per_column;
+    info->blocks_per_mcu = img->blocks_per_mcu;
+    info->total_blocks = img->total_blocks;
+    info->out_offset = img->out_offset;
+    info->out_bytes = img->out_bytes;
+    info->coef_offset = img->coef_offset;
+    memcpy(info->plane, img->plane, sizeof info->plane);
+    if (img->status != JPGPU_OK) b->ctx->last_error = img->error;
+    return JPGPU_OK;
+}
+
+int jpgpu_batch_result(jpgpu_batch *b, int i, jpgpu_image_result *res) { JPGPU_GUARD(b, b->impl.result(i, res)); }
+void *jpgpu_batch_output_device(const jpgpu_batch *b, uint64_t *total_bytes) { return b ? b->impl.output_device(total_bytes) : nullptr; }
+void *jpgpu_batch_coefficients_device(const jpgpu_batch *b, uint64_t *total_blocks) { return b ? b->impl.coefs_device(total_blocks) : nullptr; }
+int jpgpu_batch_download_output(jpgpu_batch *b, int i, void *dst, size_t cap) { JPGPU_GUARD(b, b->impl.download_output(i, dst, cap)); }
+int jpgpu_batch_download_coefficients(jpgpu_batch *b, int i, int16_t *dst, size_t cap_blocks) {
+    JPGPU_GUARD(b, b->impl.download_coefficients(i, dst, cap_blocks));
+}
+int jpgpu_batch_upload_coefficients(jpgpu_batch *b, int i, const int16_t *src, size_t nblocks) {
+    JPGPU_GUARD(b, b->impl.upload_coefficients(i, src, nblocks));
+}
+int jpgpu_batch_stage_ms(jpgpu_batch *b, float ms[4]) { JPGPU_GUARD(b, b->impl.stage_ms(ms)); }
+int jpgpu_batch_totals(const jpgpu_batch *b, uint64_t *compressed_bytes, uint64_t *blocks, uint64_t *pixels, uint64_t *output_bytes) {
+    if (!b) return JPGPU_ERR_ARGUMENT;
+    b->impl.totals(compressed_bytes, blocks, pixels, output_bytes);
+    return JPGPU_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ shared scan runner
+
+namespace {
+
+// Exception the reference throws for a device-reported failure.
+[[noreturn]] void throw_for_result(const jpgpu_image_result &res) {
+    throw DecodeError(res.status, jpgpu_detail_string(res.detail), res.detail);
+}
+
+// WriteBlock + WriteBlockSlow (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:225-268) over one decoded block.
+void write_block_expanded(jpgpu_write_block_fn fn, void *user, const int16_t *block, int component_index, int x, int y, int hs, int vs) {
+    if (hs == 1 && vs == 1) {
+        fn(user, block, component_index, x, y);
+        return;
+    }
+    int16_t temp[64];
+    int hshift = 0, vshift = 0;
+    while ((1 << (hshift + 1)) <= hs) hshift++;
+    while ((1 << (vshift + 1)) <= vs) vshift++;
+    for (int v = 0; v < vs; v++)
+        for (int h = 0; h < hs; h++) {
+            for (int i = 0; i < 8; i++) {
+                const int16_t *row = block + ((8 * v + i) >> vshift) * 8;
+                for (int j = 0; j < 8; j++) temp[8 * i + j] = row[(8 * h + j) >> hshift];
+            }
+            fn(user, temp, component_index, x + 8 * h, y + 8 * v);
+        }
+}
+
+// Replays the WriteBlock call sequence of ProcessScan (:99-134) from PLANAR_I16 planes, for the first `mcus` MCUs.
+void replay_blocks(const ScanJob &job, const ImagePlan &img, const uint8_t *planes, uint32_t mcus, jpgpu_write_block_fn fn, void *user) {
+    const BaselineGeometry &g = job.geo;
+    for (uint32_t m = 0; m < mcus; m++) {
+        const int row_mcu = (int)(m / (uint32_t)g.mcus_per_line), col_mcu = (int)(m % (uint32_t)g.mcus_per_line);
+        const int offset_x = col_mcu * g.max_h, offset_y = row_mcu * g.max_v;
+        for (int c = 0; c < job.scan_components; c++) {
+            const ResolvedScanComponent &rc = job.comp[c];
+            if (rc.component_index >= 4) continue;
+            const jpgpu_plane_info &pl = img.plane[rc.component_index];
+            const int16_t *plane = reinterpret_cast<const int16_t *>(planes + pl.offset);
+            for (int y = 0; y < rc.v; y++)
+                for (int x = 0; x < rc.h; x++) {
+                    int16_t blk[64];
+                    const size_t px = (size_t)(col_mcu * rc.h + x) * 8, py = (size_t)(row_mcu * rc.v + y) * 8;
+                    for (int i = 0; i < 8; i++) memcpy(blk + 8 * i, plane + (py + i) * pl.pitch + px, 16);
+                    write_block_expanded(fn, user, blk, rc.component_index, (offset_x + x) * 8, (offset_y + y) * 8, rc.hs, rc.vs);
+                }
+        }
+    }
+}
+
+// ref: apps/JpegDecode/JpegBufferOutputWriter8Bit.cs:28-60 -- host restatement used when the caller's 8-bit sink
+// geometry differs from the frame (then the GPU's INTERLEAVED_U8 layout cannot be used directly).
+struct HostSink8 {
+    int width, height, component_count;
+    uint8_t *out;
+    static void write(void *user, const int16_t *block, int component_index, int x, int y) {
+        HostSink8 *s = static_cast<HostSink8 *>(user);
+        if (x > s->width || y > s->height) return;
+        const int ww = std::min(s->width - x, 8), wh = std::min(s->height - y, 8);
+        uint8_t *dst = s->out + ((size_t)y * s->width + x) * s->component_count + component_index;
+        for (int dy = 0; dy < wh; dy++) {
+            uint8_t *row = dst + (size_t)dy * s->width * s->component_count;
+            for (int dx = 0; dx < ww; dx++) {
+                const int16_t v = block[dx];
+                row[(size_t)dx * s->component_count] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+            block += 8;
+        }
+    }
+};
+
+struct ScanOutcome {
+    jpgpu_image_result result;
+    size_t reader_advance;  // what ProcessScan advances the outer reader by
+};
+
+// Runs one scan job on the GPU and delivers its output.  `direct8` non-null: INTERLEAVED_U8 straight into that
+// buffer (geometry must equal the frame's); else PLANAR_I16 + replay through (fn, user).
+ScanOutcome run_scan_on_gpu(DeviceBatch &batch, const ScanJob &job, uint8_t *direct8, size_t direct8_bytes, jpgpu_write_block_fn fn,
+                            void *user, std::string *err) {
+    const int format = direct8 ? JPGPU_FMT_INTERLEAVED_U8 : JPGPU_FMT_PLANAR_I16;
+    int rc = batch.upload_single_job(job, format, direct8, direct8_bytes);
+    if (rc == JPGPU_OK) rc = batch.decode();
+    if (rc == JPGPU_OK) rc = batch.sync();
+    ScanOutcome oc;
+    memset(&oc, 0, sizeof oc);
+    if (rc == JPGPU_OK) rc = batch.result(0, &oc.result);
+    if (rc != JPGPU_OK) {
+        if (err) *err = "device failure";
+        throw DecodeError(rc, "GPU scan decode failed (see jpgpu_last_error)");
+    }
+    const ImagePlan &img = *batch.image(0);
+    const uint32_t total = (uint32_t)(job.geo.mcus_per_line * job.geo.mcus_per_column);
+    const uint32_t dri_eff = job.geo.restart_interval ? job.geo.restart_interval : total;
+    uint32_t good_mcus = std::min(oc.result.decoded_mcus, total);
+    if (oc.result.status != JPGPU_OK) good_mcus = std::min<uint64_t>((uint64_t)oc.result.error_interval * dri_eff, total);
+    if (direct8) {
+        if (batch.download_output(0, direct8, direct8_bytes) != JPGPU_OK) throw DecodeError(JPGPU_ERR_DEVICE, "output download failed");
+    } else if (fn) {
+        std::vector<uint8_t> planes(img.out_bytes);
+        if (batch.download_output(0, planes.data(), planes.size()) != JPGPU_OK) throw DecodeError(JPGPU_ERR_DEVICE, "output download failed");
+        replay_blocks(job, img, planes.data(), good_mcus, fn, user);
+    }
+    // where ProcessScan leaves the outer reader (:145-149, :167-176)
+    const uint32_t term = oc.result.terminator;
+    size_t adv = oc.result.bytes_consumed;
+    if (term >= 0xD0 && term <= 0xD7) adv += 2;  // a trailing RSTn is consumed, any other marker is left unread
+    oc.reader_advance = std::min(adv, job.entropy_len);
+    return oc;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ (2) per scan
+
+extern "C" int jpgpu_decode_scan(jpgpu_ctx *ctx, const jpgpu_frame *frame, const jpgpu_scan *scan, const uint16_t qt[4][64],
+                                 const uint8_t qt_present[4], const jpgpu_dht dht[2][4], uint16_t restart_interval,
+                                 const uint8_t *entropy, size_t len, int format, void *out, size_t cap, jpgpu_image_result *result,
+                                 size_t *bytes_consumed) {
+    if (!ctx) return JPGPU_ERR_ARGUMENT;
+    if (!frame || !scan || !qt || !qt_present || !dht || !entropy || !out) {
+        ctx->last_error = "jpgpu_decode_scan: null argument";
+        return JPGPU_ERR_ARGUMENT;
+    }
+    try {
+        if (frame->sof != kSOF0 && frame->sof != kSOF1)
+            throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "This image type is not supported.", kDetailUnsupportedFrame);
+        if (frame->num_components > 4 || scan->num_components > 4)
+            throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "More than 4 components are not supported.", kDetailUnsupportedFrame);
+        HostDecoder dec;
+        FrameHeader fh;
+        fh.precision = frame->precision;
+        fh.lines = frame->height;
+        fh.samples_per_line = frame->width;
+        fh.num_components = frame->num_components;
+        for (int i = 0; i < frame->num_components; i++) fh.components.push_back({frame->comp[i].identifier, frame->comp[i].h, frame->comp[i].v, frame->comp[i].tq});
+        dec.set_frame_header(fh);
+        dec.set_start_of_frame(frame->sof);
+        dec.set_restart_interval(restart_interval);
+        for (int id = 0; id < 4; id++) {
+            if (qt_present[id]) {
+                QuantTable q;
+                q.identifier = (uint8_t)id;
+                memcpy(q.elements, qt[id], sizeof q.elements);
+                dec.set_quantization_table(q);
+            }
+            for (int cls = 0; cls < 2; cls++) {
+                const jpgpu_dht &d = dht[cls][id];
+                if (!d.present) continue;
+                HuffTable t;
+                if (!HuffTable::from_bits_values((uint8_t)cls, (uint8_t)id, d.bits, d.values, d.num_values, &t))
+                    throw_invalid_data("Failed to parse Huffman table.", kDetailBadHeader);
+                dec.set_huffman_table(t);
+            }
+        }
+        ScanHeader sh;
+        sh.num_components = scan->num_components;
+        sh.ss = scan->ss;
+        sh.se = scan->se;
+        sh.ah = scan->ah;
+        sh.al = scan->al;
+        for (int i = 0; i < scan->num_components; i++) sh.components.push_back({scan->comp[i].selector, scan->comp[i].td, scan->comp[i].ta});
+        const BaselineGeometry geo = BaselineGeometry::latch(dec, fh);
+        const ScanJob job = make_scan_job(dec, geo, sh, entropy, len);
+        DeviceBatch batch(ctx);
+        int rc = batch.upload_single_job(job, format, nullptr, 0);
+        if (rc != JPGPU_OK) return rc;
+        if ((rc = batch.decode()) != JPGPU_OK) return rc;
+        if ((rc = batch.sync()) != JPGPU_OK) return rc;
+        jpgpu_image_result res;
+        if ((rc = batch.result(0, &res)) != JPGPU_OK) return rc;
+        if (result) *result = res;
+        if (bytes_consumed) {
+            size_t adv = res.bytes_consumed;
+            if (res.terminator >= 0xD0 && res.terminator <= 0xD7) adv += 2;
+            *bytes_consumed = std::min(adv, len);
+        }
+        if ((rc = batch.download_output(0, out, cap)) != JPGPU_OK) return rc;
+        if (res.status != JPGPU_OK) ctx->last_error = jpgpu_detail_string(res.detail);
+        return res.status;
+    } catch (const DecodeError &e) {
+        ctx->last_error = e.what();
+        if (result) {
+            memset(result, 0, sizeof *result);
+            result->status = e.status;
+            result->detail = e.detail;
+        }
+        return e.status;
+    } catch (const std::exception &e) {
+        ctx->last_error = e.what();
+        return JPGPU_ERR_DEVICE;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ (3) decoder mirror
+
+struct jpgpu_decoder {
+    jpgpu_ctx *ctx = nullptr;
+    HostDecoder host;
+    std::string last_error;
+    enum WriterKind { kNone, kCallback, kBuffer8 } writer = kNone;
+    jpgpu_write_block_fn fn = nullptr;
+    void *user = nullptr;
+    HostSink8 sink8 = {0, 0, 0, nullptr};
+    size_t sink8_cap = 0;
+    std::unique_ptr<DeviceBatch> batch;
+};
+
+namespace {
+
+// What JpegScanDecoder.Create / ProcessScan / Dispose do in the mirror: run every baseline scan on the GPU.
+class GpuScanHandler final : public ScanHandler {
+  public:
+    explicit GpuScanHandler(jpgpu_decoder *d) : d_(d) {}
+    void on_frame(HostDecoder &dec, int sof) override {
+        sof_ = sof;
+        baseline_ = (sof == kSOF0 || sof == kSOF1);
+        if (baseline_) geo_ = BaselineGeometry::latch(dec, dec.frame_header());
+    }
+    void on_scan(HostDecoder &dec, MarkerReader &reader, const ScanHeader &scan) override {
+        if (!baseline_)
+            throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "Only baseline / extended sequential Huffman frames (SOF0, SOF1) run on the GPU path.",
+                              kDetailUnsupportedFrame);
+        if (d_->writer == jpgpu_decoder::kNone) throw_invalid_operation("Output writer is not specified.");
+        if (!d_->ctx) throw DecodeError(JPGPU_ERR_NO_DEVICE, "No HIP device: scans are decoded on the GPU only (no CPU fallback).");
+        const uint8_t *entropy = reader.remaining_bytes();
+        const size_t len = (size_t)reader.remaining_byte_count();
+        const ScanJob job = make_scan_job(dec, geo_, scan, entropy, len);
+        if (!d_->batch) d_->batch.reset(new DeviceBatch(d_->ctx));
+        const FrameHeader &fh = geo_.frame;
+        ScanOutcome oc;
+        const bool direct = d_->writer == jpgpu_decoder::kBuffer8 && d_->sink8.width == fh.samples_per_line && d_->sink8.height == fh.lines &&
+                            d_->sink8.component_count == fh.num_components;
+        if (direct) {
+            oc = run_scan_on_gpu(*d_->batch, job, d_->sink8.out, (size_t)fh.samples_per_line * fh.lines * fh.num_components, nullptr, nullptr, &d_->last_error);
+        } else if (d_->writer == jpgpu_decoder::kBuffer8) {
+            oc = run_scan_on_gpu(*d_->batch, job, nullptr, 0, HostSink8::write, &d_->sink8, &d_->last_error);
+        } else {
+            oc = run_scan_on_gpu(*d_->batch, job, nullptr, 0, d_->fn, d_->user, &d_->last_error);
+        }
+        if (oc.result.status != JPGPU_OK) throw_for_result(oc.result);
+        reader.try_advance((int)oc.reader_advance);
+    }
+    void on_dispose(HostDecoder &) override {}
+
+  private:
+    jpgpu_decoder *d_;
+    BaselineGeometry geo_;
+    bool baseline_ = false;
+    int sof_ = 0;
+};
+
+template <typename F>
+int guarded(jpgpu_decoder *d, F &&f) {
+    if (!d) return JPGPU_ERR_ARGUMENT;
+    try {
+        d->last_error.clear();
+        return f();
+    } catch (const DecodeError &e) {
+        d->last_error = e.what();
+        return e.status;
+    } catch (const std::bad_alloc &) {
+        d->last_error = "host allocation failed";
+        return JPGPU_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception &e) {
+        d->last_error = e.what();
+        return JPGPU_ERR_DEVICE;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int jpgpu_decoder_create(jpgpu_ctx *ctx, jpgpu_decoder **out) {
+    // ctx may be NULL: the host-only calls (SetInput, Identify, metadata, tables) work without a GPU;
+    // Decode then fails with JPGPU_ERR_NO_DEVICE -- there is no CPU decode path.
+    if (!out) return JPGPU_ERR_ARGUMENT;
+    *out = new (std::nothrow) jpgpu_decoder();
+    if (!*out) return JPGPU_ERR_OUT_OF_MEMORY;
+    (*out)->ctx = ctx;
+    return JPGPU_OK;
+}
+void jpgpu_decoder_destroy(jpgpu_decoder *d) { delete d; }
+const char *jpgpu_decoder_last_error(const jpgpu_decoder *d) { return d ? d->last_error.c_str() : ""; }
+
+int jpgpu_decoder_set_input(jpgpu_decoder *d, const uint8_t *data, size_t len) {
+    return guarded(d, [&] {
+        d->host.set_input(data, len);
+        return JPGPU_OK;
+    });
+}
+int jpgpu_decoder_identify(jpgpu_decoder *d, int load_quantization_tables, int *stream_length) {
+    return guarded(d, [&] {
+        const int n = d->host.identify(load_quantization_tables != 0);
+        if (stream_length) *stream_length = n;
+        return JPGPU_OK;
+    });
+}
+int jpgpu_decoder_try_estimate_quality(jpgpu_decoder *d, float *quality) {
+    if (!d || !quality) return 0;
+    return d->host.try_estimate_quality(quality) ? 1 : 0;
+}
+int jpgpu_decoder_width(const jpgpu_decoder *d) { return d && d->host.has_frame_header() ? d->host.frame_header().samples_per_line : -1; }
+int jpgpu_decoder_height(const jpgpu_decoder *d) { return d && d->host.has_frame_header() ? d->host.frame_header().lines : -1; }
+int jpgpu_decoder_precision(const jpgpu_decoder *d) { return d && d->host.has_frame_header() ? d->host.frame_header().precision : -1; }
+int jpgpu_decoder_number_of_components(const jpgpu_decoder *d) { return d && d->host.has_frame_header() ? d->host.frame_header().num_components : -1; }
+int jpgpu_decoder_start_of_frame(const jpgpu_decoder *d) { return d ? d->host.start_of_frame() : 0; }
+int jpgpu_decoder_get_maximum_horizontal_sampling(jpgpu_decoder *d) {
+    int v = -1;
+    guarded(d, [&] {
+        v = d->host.maximum_horizontal_sampling();
+        return JPGPU_OK;
+    });
+    return v;
+}
+int jpgpu_decoder_get_maximum_vertical_sampling(jpgpu_decoder *d) {
+    int v = -1;
+    guarded(d, [&] {
+        v = d->host.maximum_vertical_sampling();
+        return JPGPU_OK;
+    });
+    return v;
+}
+int jpgpu_decoder_get_horizontal_sampling(jpgpu_decoder *d, int component_index) {
+    int v = -1;
+    guarded(d, [&] {
+        const FrameHeader &fh = d->host.frame_header();
+        if ((unsigned)component_index >= fh.components.size()) throw DecodeError(JPGPU_ERR_ARGUMENT, "Specified argument was out of the range of valid values. (Parameter 'componentIndex')");
+        v = fh.components[(size_t)component_index].h;
+        return JPGPU_OK;
+    });
+    return v;
+}
+int jpgpu_decoder_get_vertical_sampling(jpgpu_decoder *d, int component_index) {
+    int v = -1;
+    guarded(d, [&] {
+        const FrameHeader &fh = d->host.frame_header();
+        if ((unsigned)component_index >= fh.components.size()) throw DecodeError(JPGPU_ERR_ARGUMENT, "Specified argument was out of the range of valid values. (Parameter 'componentIndex')");
+        v = fh.components[(size_t)component_index].v;
+        return JPGPU_OK;
+    });
+    return v;
+}
+int jpgpu_decoder_get_restart_interval(const jpgpu_decoder *d) { return d ? d->host.restart_interval() : 0; }
+int jpgpu_decoder_set_restart_interval(jpgpu_decoder *d, int restart_interval) {
+    return guarded(d, [&] {
+        d->host.set_restart_interval(restart_interval);
+        return JPGPU_OK;
+    });
+}
+int jpgpu_decoder_load_tables(jpgpu_decoder *d, const uint8_t *data, size_t len) {
+    return guarded(d, [&] {
+        d->host.load_tables(data, len);
+        return JPGPU_OK;
+    });
+}
+int jpgpu_decoder_set_output_writer(jpgpu_decoder *d, jpgpu_write_block_fn fn, void *user) {
+    return guarded(d, [&] {
+        if (!fn) throw DecodeError(JPGPU_ERR_ARGUMENT, "Value cannot be null. (Parameter 'outputWriter')");
+        d->writer = jpgpu_decoder::kCallback;
+        d->fn = fn;
+        d->user = user;
+        return JPGPU_OK;
+    });
+}
+int jpgpu_decoder_set_output_buffer8(jpgpu_decoder *d, int width, int height, int component_count, uint8_t *out, size_t cap) {
+    return guarded(d, [&] {
+        if (!out) throw DecodeError(JPGPU_ERR_ARGUMENT, "Value cannot be null. (Parameter 'output')");
+        if (width < 0 || height < 0 || component_count <= 0 || cap < (size_t)width * height * component_count)
+            throw DecodeError(JPGPU_ERR_ARGUMENT, "Destination buffer is too small.");  // ref: JpegBufferOutputWriter8Bit.cs:17-20
+        d->writer = jpgpu_decoder::kBuffer8;
+        d->sink8 = {width, height, component_count, out};
+        d->sink8_cap = cap;
+        return JPGPU_OK;
+    });
+}
+int jpgpu_decoder_decode(jpgpu_decoder *d) {
+    return guarded(d, [&] {
+        GpuScanHandler handler(d);
+        d->host.decode(handler, d->writer != jpgpu_decoder::kNone);
+        return JPGPU_OK;
+    });
+}
+void jpgpu_decoder_reset_input(jpgpu_decoder *d) {
+    if (d) d->host.reset_input();
+}
+void jpgpu_decoder_reset_header(jpgpu_decoder *d) {
+    if (d) d->host.reset_header();
+}
+void jpgpu_decoder_reset_tables(jpgpu_decoder *d) {
+    if (d) d->host.reset_tables();
+}
+void jpgpu_decoder_reset_output_writer(jpgpu_decoder *d) {
+    if (d) {
+        d->writer = jpgpu_decoder::kNone;
+        d->fn = nullptr;
+        d->user = nullptr;
+    }
+}
+void jpgpu_decoder_reset(jpgpu_decoder *d) {
+    jpgpu_decoder_reset_input(d);
+    jpgpu_decoder_reset_header(d);
+    jpgpu_decoder_reset_tables(d);
+    jpgpu_decoder_reset_output_writer(d);
+}
+
+}  // extern "C"

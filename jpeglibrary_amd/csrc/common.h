@@ -1,0 +1,107 @@
+// jpeglibrary_amd/csrc/common.h -- structures shared by the host library and the HIP kernels.
+//
+// Vocabulary follows the reference: frame, scan, MCU, restart interval, block (8x8), zig-zag order.
+// A "scan job" is one SOS of one image: the unit JpegScanDecoder.ProcessScan works on
+// (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:51-177).
+#pragma once
+#include <stdint.h>
+
+namespace jpgpu {
+
+constexpr int kMaxScanComponents = 4;
+constexpr int kMaxBlocksPerMcu = 16;  // T.81 allows 10; the reference does not check, we cap at 16
+constexpr int kHuffLutBits = 9;       // first-level lookup width (reference: 8-bit lookahead + maxcode search)
+constexpr int kHuffLutSize = 1 << kHuffLutBits;
+constexpr int kMaxHuffSlots = 8;      // tables staged in LDS per scan job: <=4 DC + <=4 AC
+
+// Device image of JpegHuffmanDecodingTable (ref: JpegHuffmanDecodingTable.cs:33-49, 339-376).
+// lut[i] for the next kHuffLutBits bits: (code_size << 8) | symbol, 0 = take the maxcode search.
+// maxcode / valoffset / values are the reference's arrays verbatim.
+struct alignas(16) DevHuffTable {
+    uint16_t lut[kHuffLutSize];
+    uint16_t maxcode[18];
+    uint8_t valoffset[20];
+    uint8_t values[256];
+    uint8_t pad[8];
+};
+static_assert(sizeof(DevHuffTable) % 16 == 0, "DevHuffTable must be a multiple of 16 bytes");
+
+// Quantization table, zig-zag order like JpegQuantizationTable.Elements (ref: JpegQuantizationTable.cs:47).
+struct alignas(16) DevQuantTable {
+    uint16_t q[64];
+};
+
+struct DevScanComponent {
+    uint8_t component_index;  // index into the frame's component list (WriteBlock's componentIndex)
+    uint8_t h, v;             // sampling factors
+    uint8_t hs, vs;           // subsampling = max / own (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:66-67)
+    uint8_t quant_slot;       // index into DevScan::quant_pool
+    uint8_t dc_slot, ac_slot; // index into DevScan::huff_pool (LDS slot)
+};
+
+enum OutputFormat : int32_t { kFmtInterleavedU8 = 0, kFmtPlanarU8 = 1, kFmtPlanarI16 = 2 };
+
+// One scan job.
+struct alignas(16) DevScan {
+    uint64_t data_off;   // entropy segment start, byte offset into the batch input buffer
+    uint64_t coef_off;   // first block of this scan in the coefficient buffer (block units, 64 x int16 each)
+    uint64_t out_off;    // image base in the output buffer (bytes)
+    uint64_t plane_off[kMaxScanComponents];  // planar formats: byte offset of each scan component's plane from out_off
+    uint32_t plane_pitch[kMaxScanComponents];  // planar formats: pitch in samples
+    uint32_t data_len;   // bytes from data_off to the end of the file
+    uint32_t dri;        // restart interval in MCUs as latched by the scan decoder (0 = none)
+    uint32_t total_mcus, mcus_per_line, mcus_per_column;
+    uint32_t n_intervals;  // dri ? ceil(total_mcus / dri) : 1
+    uint32_t ends_off;     // index of this scan's first slot in the interval-end array (n_intervals slots)
+    uint32_t image_index;
+    uint32_t level_shift;  // 1 << (precision - 1)
+    uint16_t width, height;  // frame SamplesPerLine / NumberOfLines
+    uint8_t precision, frame_components, scan_components, max_h, max_v, blocks_per_mcu;
+    uint8_t restart_check_at_end;  // dri > 0 && total_mcus % dri == 0: the reference runs the restart check after the last MCU
+    uint8_t pad0;
+    DevScanComponent comp[kMaxScanComponents];
+    uint8_t blk_comp[kMaxBlocksPerMcu];  // block-in-MCU -> scan component slot
+    uint8_t blk_x[kMaxBlocksPerMcu];     // block-in-MCU -> x, y inside the component's MCU footprint
+    uint8_t blk_y[kMaxBlocksPerMcu];
+    uint16_t huff_pool[kMaxHuffSlots];   // pool indices of the tables this scan stages (0xFFFF = unused)
+    uint16_t quant_pool[kMaxScanComponents];
+    uint32_t pad1[2];
+};
+static_assert(sizeof(DevScan) % 16 == 0, "DevScan must be a multiple of 16 bytes");
+
+// Device-side result of one scan job.
+struct alignas(16) DevScanStatus {
+    uint32_t n_ends;        // interval ends found by the marker index (<= n_intervals)
+    uint32_t terminator;    // marker byte closing the last indexed interval (RSTn, other), 0 = data ran out
+    uint32_t first_error;   // (interval << 8) | detail of the lowest failing interval, 0xFFFFFFFF = none
+    uint32_t decoded_mcus;  // MCUs decoded (limits the IDCT pass when EOI came early)
+    uint32_t end_pos;       // byte offset (from data_off) of the terminating marker / end of data
+    uint32_t pad[3];
+};
+
+// Work lists: one entry per workgroup.
+struct HuffWork {
+    uint32_t scan;            // scan job index
+    uint32_t first_interval;  // first restart interval handled by this workgroup
+};
+struct IdctWork {
+    uint32_t scan;
+    uint32_t first_mcu;
+};
+
+constexpr uint32_t kNoError = 0xFFFFFFFFu;
+
+// detail codes (mirror jpgpu_detail in include/jpgpu.h)
+enum Detail : uint32_t {
+    kDetailNone = 0,
+    kDetailInvalidHuffmanCode = 1,
+    kDetailMarkerInData = 2,
+    kDetailStreamEnded = 3,
+    kDetailExpectRestart = 4,
+    kDetailMissingTable = 5,
+    kDetailUnsupportedFrame = 6,
+    kDetailBadHeader = 7,
+    kDetailEarlyEoi = 8
+};
+
+}  // namespace jpgpu

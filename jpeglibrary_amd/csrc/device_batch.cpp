@@ -1,0 +1,524 @@
+// jpeglibrary_amd/csrc/device_batch.cpp -- HBM layout, uploads and kernel launches for a batch of scan jobs.
+//
+// HBM layout (all offsets 256-byte aligned unless noted):
+//   input   : the files' bytes back to back (256-byte slots, 256 bytes of slack before the first and after the last)
+//   ends    : uint32 per restart interval: offset of the FF that closes it (written by K1, read by K2)
+//   coefs   : int16[total_blocks][64], zig-zag order, blocks in MCU scan order per scan job (K2 -> K3)
+//   out     : per image, in the batch's format (INTERLEAVED_U8: W*H*C bytes; PLANAR_*: padded planes)
+#include "device_batch.h"
+
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace jpgpu {
+
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+hipError_t DevBuffer::reserve(size_t bytes) {
+    if (bytes <= cap && ptr) return hipSuccess;
+    if (ptr) {
+        hipError_t e = hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        if (e != hipSuccess) return e;
+    }
+    if (bytes == 0) bytes = 256;
+    hipError_t e = hipMalloc(&ptr, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+}
+void DevBuffer::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+}
+
+DeviceBatch::~DeviceBatch() {
+    if (ctx_) (void)hipSetDevice(ctx_->device);
+    for (DevBuffer *b : {&d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
+        b->release();
+    for (hipEvent_t &e : ev_pool_)
+        if (e) (void)hipEventDestroy(e);
+}
+
+int DeviceBatch::fail(int status, const std::string &msg) {
+    ctx_->last_error = msg;
+    return status;
+}
+int DeviceBatch::hip_fail(hipError_t e, const char *what) {
+    return fail(e == hipErrorOutOfMemory ? JPGPU_ERR_OUT_OF_MEMORY : JPGPU_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// Planner: what JpegScanDecoder.Create / ProcessScan become while the batch is being laid out.
+namespace {
+class PlanHandler final : public ScanHandler {
+  public:
+    PlanHandler(std::vector<ScanJob> *jobs) : jobs_(jobs) {}
+    void on_frame(HostDecoder &dec, int sof) override {
+        sof_ = sof;
+        if (sof == kSOF0 || sof == kSOF1) {
+            geo_ = BaselineGeometry::latch(dec, dec.frame_header());  // DRI latched at SOF time
+            baseline_ = true;
+        } else {
+            baseline_ = false;
+        }
+    }
+    void on_scan(HostDecoder &dec, MarkerReader &reader, const ScanHeader &scan) override {
+        if (!baseline_)
+            throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "Only baseline / extended sequential Huffman frames (SOF0, SOF1) run on this path.",
+                              kDetailUnsupportedFrame);
+        const uint8_t *entropy = reader.remaining_bytes();
+        const size_t len = (size_t)reader.remaining_byte_count();
+        jobs_->push_back(make_scan_job(dec, geo_, scan, entropy, len));
+        // leave the reader just before the next non-RST marker, like ProcessScan does (:167-176)
+        reader.try_advance((int)find_scan_end(entropy, len));
+    }
+    void on_dispose(HostDecoder &) override {}
+    const BaselineGeometry &geo() const { return geo_; }
+    int sof() const { return sof_; }
+
+  private:
+    std::vector<ScanJob> *jobs_;
+    BaselineGeometry geo_;
+    bool baseline_ = false;
+    int sof_ = 0;
+};
+}  // namespace
+
+void DeviceBatch::plan_image_geometry(ImagePlan &img, const BaselineGeometry &geo) {
+    const FrameHeader &fh = geo.frame;
+    img.width = fh.samples_per_line;
+    img.height = fh.lines;
+    img.precision = fh.precision;
+    img.num_components = fh.num_components;
+    img.restart_interval = geo.restart_interval;
+    img.mcus_per_line = (uint32_t)geo.mcus_per_line;
+    img.mcus_per_column = (uint32_t)geo.mcus_per_column;
+    if (format_ == JPGPU_FMT_INTERLEAVED_U8) {
+        img.out_bytes = (uint64_t)img.width * img.height * img.num_components;
+    } else {
+        const uint64_t sample_bytes = format_ == JPGPU_FMT_PLANAR_I16 ? 2 : 1;
+        uint64_t off = 0;
+        for (int c = 0; c < fh.num_components && c < 4; c++) {
+            jpgpu_plane_info &p = img.plane[c];
+            p.width = (uint32_t)geo.mcus_per_line * fh.components[c].h * 8;
+            p.height = (uint32_t)geo.mcus_per_column * fh.components[c].v * 8;
+            p.pitch = p.width;
+            p.offset = off;
+            off = align_up(off + (uint64_t)p.pitch * p.height * sample_bytes, 256);
+        }
+        img.out_bytes = off;
+    }
+}
+
+int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int n, int format) {
+    if (n < 0 || (n > 0 && (!jpeg || !len))) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: null argument");
+    if (format < 0 || format > 2) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: unknown format");
+    format_ = format;
+    images_.assign((size_t)n, ImagePlan());
+    jobs_.clear();
+    job_image_.clear();
+    job_entropy_off_.clear();
+    std::vector<const uint8_t *> file_ptr((size_t)n);
+    std::vector<size_t> file_len((size_t)n);
+
+    for (int i = 0; i < n; i++) {
+        ImagePlan &img = images_[i];
+        file_ptr[i] = jpeg[i];
+        file_len[i] = len[i];
+        img.file_len = len[i];
+        const size_t first_job = jobs_.size();
+        try {
+            if (len[i] > 0x7FFFFFF0u) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "JPEG streams of 2 GiB or more are not supported.");
+            HostDecoder dec;
+            dec.set_input(jpeg[i], len[i]);
+            dec.identify(false);  // every reference caller runs Identify before Decode; it latches the LAST DRI (F4)
+            img.sof = (uint8_t)dec.start_of_frame();
+            PlanHandler handler(&jobs_);
+            dec.decode(handler, true);
+            if (jobs_.size() == first_job) {
+                // no scan: Decode() succeeds without writing anything; keep the frame geometry for the caller
+                if (img.sof == kSOF0 || img.sof == kSOF1) plan_image_geometry(img, BaselineGeometry::latch(dec, dec.frame_header()));
+            } else {
+                plan_image_geometry(img, jobs_[first_job].geo);
+                img.blocks_per_mcu = (uint32_t)jobs_[first_job].blocks_per_mcu;
+            }
+            for (size_t j = first_job; j < jobs_.size(); j++) {
+                img.jobs.push_back((int)j);
+                job_image_.push_back(i);
+                job_entropy_off_.push_back((uint64_t)(jobs_[j].entropy - jpeg[i]));
+            }
+        } catch (const DecodeError &e) {
+            jobs_.resize(first_job);
+            job_image_.resize(first_job);
+            job_entropy_off_.resize(first_job);
+            img.jobs.clear();
+            img.status = e.status;
+            img.detail = e.detail;
+            img.error = e.what();
+        }
+    }
+    return layout_and_upload(file_ptr, file_len);
+}
+
+int DeviceBatch::upload_single_job(const ScanJob &job, int format, const void *initial_output, size_t initial_output_bytes) {
+    if (format < 0 || format > 2) return fail(JPGPU_ERR_ARGUMENT, "unknown format");
+    format_ = format;
+    images_.assign(1, ImagePlan());
+    jobs_.assign(1, job);
+    job_image_.assign(1, 0);
+    job_entropy_off_.assign(1, 0);
+    ImagePlan &img = images_[0];
+    img.sof = kSOF0;
+    img.file_len = job.entropy_len;
+    plan_image_geometry(img, job.geo);
+    img.blocks_per_mcu = (uint32_t)job.blocks_per_mcu;
+    img.jobs.push_back(0);
+    std::vector<const uint8_t *> fp(1, job.entropy);
+    std::vector<size_t> fl(1, job.entropy_len);
+    int rc = layout_and_upload(fp, fl);
+    if (rc != JPGPU_OK) return rc;
+    if (initial_output && initial_output_bytes) {
+        const size_t nbytes = std::min<size_t>(initial_output_bytes, img.out_bytes);
+        hipError_t e = hipMemcpyAsync((uint8_t *)d_out_.ptr + img.out_offset, initial_output, nbytes, hipMemcpyHostToDevice, ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(initial output)");
+    }
+    return JPGPU_OK;
+}
+
+int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr, const std::vector<size_t> &file_len) {
+    hipError_t e = hipSetDevice(ctx_->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    status_valid_ = false;
+    ev_used_ = 0;
+
+    // ---- input layout
+    uint64_t in_off = 256;
+    for (size_t i = 0; i < images_.size(); i++) {
+        images_[i].file_offset = in_off;
+        if (images_[i].status == JPGPU_OK && !images_[i].jobs.empty()) in_off = align_up(in_off + file_len[i], 256);
+    }
+    input_bytes_ = in_off + 256;
+
+    // ---- per-image output / coefficient layout, scan descriptors, pools, work lists
+    huff_pool_.clear();
+    quant_pool_.clear();
+    h_scans_.assign(jobs_.size(), DevScan());
+    std::vector<HuffWork> huff_work;
+    std::vector<IdctWork> idct_work;
+    uint64_t out_off = 0, coef_off = 0;
+    uint32_t ends_off = 0;
+    compressed_bytes_ = 0;
+    total_pixels_ = 0;
+    n_huff_slots_ = 1;
+    auto huff_index = [&](const HuffTable &t) -> uint16_t {
+        DevHuffTable d;
+        t.to_device(&d);
+        for (size_t i = 0; i < huff_pool_.size(); i++)
+            if (memcmp(&huff_pool_[i], &d, sizeof d) == 0) return (uint16_t)i;
+        huff_pool_.push_back(d);
+        return (uint16_t)(huff_pool_.size() - 1);
+    };
+    auto quant_index = [&](const QuantTable &t) -> uint16_t {
+        DevQuantTable d;
+        memcpy(d.q, t.elements, sizeof d.q);
+        for (size_t i = 0; i < quant_pool_.size(); i++)
+            if (memcmp(&quant_pool_[i], &d, sizeof d) == 0) return (uint16_t)i;
+        quant_pool_.push_back(d);
+        return (uint16_t)(quant_pool_.size() - 1);
+    };
+
+    for (size_t ii = 0; ii < images_.size(); ii++) {
+        ImagePlan &img = images_[ii];
+        img.out_offset = out_off;
+        img.coef_offset = coef_off;
+        img.total_blocks = 0;
+        if (img.status != JPGPU_OK) continue;
+        out_off = align_up(out_off + img.out_bytes, 256);
+        if (!img.jobs.empty()) total_pixels_ += (uint64_t)img.width * img.height;
+        for (int j : img.jobs) {
+            const ScanJob &job = jobs_[j];
+            DevScan &s = h_scans_[j];
+            memset(&s, 0, sizeof s);
+            const BaselineGeometry &g = job.geo;
+            s.data_off = img.file_offset + job_entropy_off_[j];
+            s.data_len = (uint32_t)(file_len[ii] - job_entropy_off_[j]);
+            s.coef_off = coef_off;
+            s.out_off = img.out_offset;
+            s.dri = g.restart_interval;
+            s.mcus_per_line = (uint32_t)g.mcus_per_line;
+            s.mcus_per_column = (uint32_t)g.mcus_per_column;
+            s.total_mcus = s.mcus_per_line * s.mcus_per_column;
+            s.n_intervals = s.dri ? (s.total_mcus + s.dri - 1) / s.dri : 1;
+            if (s.total_mcus == 0) s.n_intervals = 0;
+            s.ends_off = ends_off;
+            ends_off += s.n_intervals;
+            s.image_index = (uint32_t)ii;
+            s.level_shift = (uint32_t)g.level_shift;
+            s.width = g.frame.samples_per_line;
+            s.height = g.frame.lines;
+            s.precision = g.frame.precision;
+            s.frame_components = g.frame.num_components;
+            s.scan_components = (uint8_t)job.scan_components;
+            s.max_h = (uint8_t)g.max_h;
+            s.max_v = (uint8_t)g.max_v;
+            s.blocks_per_mcu = (uint8_t)job.blocks_per_mcu;
+            s.restart_check_at_end = (s.dri != 0 && s.total_mcus % s.dri == 0) ? 1 : 0;
+            for (int k = 0; k < kMaxHuffSlots; k++) s.huff_pool[k] = 0xFFFF;
+            for (int k = 0; k < job.n_huff; k++) s.huff_pool[k] = huff_index(job.huff_copy[k]);
+            n_huff_slots_ = std::max(n_huff_slots_, job.n_huff);
+            for (int c = 0; c < job.scan_components; c++) {
+                DevScanComponent &dc = s.comp[c];
+                dc.component_index = (uint8_t)job.comp[c].component_index;
+                dc.h = job.comp[c].h;
+                dc.v = job.comp[c].v;
+                dc.hs = (uint8_t)job.comp[c].hs;
+                dc.vs = (uint8_t)job.comp[c].vs;
+                dc.quant_slot = (uint8_t)c;
+                dc.dc_slot = job.dc_slot[c];
+                dc.ac_slot = job.ac_slot[c];
+                s.quant_pool[c] = quant_index(job.quant_copy[c]);
+                const int fc = job.comp[c].component_index;
+                if (fc < 4) {
+                    s.plane_off[c] = img.plane[fc].offset;
+                    s.plane_pitch[c] = img.plane[fc].pitch;
+                }
+            }
+            memcpy(s.blk_comp, job.blk_comp, sizeof s.blk_comp);
+            memcpy(s.blk_x, job.blk_x, sizeof s.blk_x);
+            memcpy(s.blk_y, job.blk_y, sizeof s.blk_y);
+
+            const uint64_t nblocks = (uint64_t)s.total_mcus * s.blocks_per_mcu;
+            coef_off += nblocks;
+            img.total_blocks += nblocks;
+            compressed_bytes_ += s.data_len;
+            for (uint32_t first = 0; first < s.n_intervals; first += kHuffIntervalsPerWg) huff_work.push_back({(uint32_t)j, first});
+            const uint32_t mcus_per_wg = (uint32_t)kIdctBlocksPerWg / s.blocks_per_mcu;
+            for (uint32_t first = 0; first < s.total_mcus; first += mcus_per_wg) idct_work.push_back({(uint32_t)j, first});
+        }
+    }
+    total_blocks_ = coef_off;
+    out_bytes_ = out_off;
+    total_ends_ = ends_off;
+    n_huff_work_ = (int)huff_work.size();
+    n_idct_work_ = (int)idct_work.size();
+
+    h_status_.assign(jobs_.size(), DevScanStatus());
+    for (size_t j = 0; j < jobs_.size(); j++) {
+        DevScanStatus &st = h_status_[j];
+        memset(&st, 0, sizeof st);
+        st.first_error = kNoError;
+        st.decoded_mcus = h_scans_[j].total_mcus;
+    }
+
+    // ---- allocate + H2D
+    struct Up {
+        DevBuffer *buf;
+        const void *src;
+        size_t bytes;
+        size_t reserve;
+    };
+    const Up ups[] = {
+        {&d_scans_, h_scans_.data(), h_scans_.size() * sizeof(DevScan), 0},
+        {&d_status_, h_status_.data(), h_status_.size() * sizeof(DevScanStatus), 0},
+        {&d_huff_pool_, huff_pool_.data(), huff_pool_.size() * sizeof(DevHuffTable), 0},
+        {&d_quant_pool_, quant_pool_.data(), quant_pool_.size() * sizeof(DevQuantTable), 0},
+        {&d_huff_work_, huff_work.data(), huff_work.size() * sizeof(HuffWork), 0},
+        {&d_idct_work_, idct_work.data(), idct_work.size() * sizeof(IdctWork), 0},
+        {&d_ends_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},
+        {&d_coefs_, nullptr, 0, (size_t)total_blocks_ * 128 + 256},
+        {&d_out_, nullptr, 0, (size_t)out_bytes_ + 256},
+        {&d_input_, nullptr, 0, (size_t)input_bytes_},
+    };
+    for (const Up &u : ups) {
+        e = u.buf->reserve(std::max(u.bytes, u.reserve));
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+        if (u.bytes) {
+            e = hipMemcpyAsync(u.buf->ptr, u.src, u.bytes, hipMemcpyHostToDevice, ctx_->stream);
+            if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(descriptors)");
+        }
+    }
+    // slack before the first file and after the last one is read by the kernels' wide loads: keep it defined
+    e = hipMemsetAsync(d_input_.ptr, 0, 256, ctx_->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+    for (size_t i = 0; i < images_.size(); i++) {
+        const ImagePlan &img = images_[i];
+        if (img.status != JPGPU_OK || img.jobs.empty()) continue;
+        e = hipMemcpyAsync((uint8_t *)d_input_.ptr + img.file_offset, file_ptr[i], file_len[i], hipMemcpyHostToDevice, ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(input)");
+        const uint64_t tail = img.file_offset + file_len[i];
+        if (align_up(tail, 256) > tail) {
+            e = hipMemsetAsync((uint8_t *)d_input_.ptr + tail, 0, (size_t)(align_up(tail, 256) - tail), ctx_->stream);
+            if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(tail)");
+        }
+    }
+    e = hipMemsetAsync((uint8_t *)d_input_.ptr + input_bytes_ - 256, 0, 256, ctx_->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(slack)");
+    e = hipStreamSynchronize(ctx_->stream);  // the caller's buffers may be released after upload returns
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(upload)");
+    return JPGPU_OK;
+}
+
+int DeviceBatch::run_marker_index() {
+    status_valid_ = false;
+    hipError_t e = launch_marker_index(ctx_->stream, (const uint8_t *)d_input_.ptr, (const DevScan *)d_scans_.ptr, (int)jobs_.size(),
+                                       (uint32_t *)d_ends_.ptr, (DevScanStatus *)d_status_.ptr);
+    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "marker_index_kernel");
+}
+int DeviceBatch::run_huffman() {
+    status_valid_ = false;
+    hipError_t e = launch_huffman(ctx_->stream, (const uint8_t *)d_input_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_huff_work_.ptr,
+                                  n_huff_work_, (const uint32_t *)d_ends_.ptr, (DevScanStatus *)d_status_.ptr,
+                                  (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_);
+    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "huffman_decode_kernel");
+}
+int DeviceBatch::run_idct() {
+    hipError_t e = launch_idct(ctx_->stream, (const int16_t *)d_coefs_.ptr, (const DevScan *)d_scans_.ptr, (const IdctWork *)d_idct_work_.ptr,
+                               n_idct_work_, (const DevScanStatus *)d_status_.ptr, (const DevQuantTable *)d_quant_pool_.ptr,
+                               (uint8_t *)d_out_.ptr, format_);
+    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "idct_output_kernel");
+}
+
+int DeviceBatch::decode() {
+    hipError_t e = hipSetDevice(ctx_->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    if (ev_used_ + 4 > 4 * 256) ev_used_ = 0;  // bound the pool: keep the most recent decodes only
+    while (ev_pool_.size() < ev_used_ + 4) {
+        hipEvent_t ev = nullptr;
+        e = hipEventCreate(&ev);
+        if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+        ev_pool_.push_back(ev);
+    }
+    hipEvent_t *ev = &ev_pool_[ev_used_];
+    int rc;
+    (void)hipEventRecord(ev[0], ctx_->stream);
+    if ((rc = run_marker_index()) != JPGPU_OK) return rc;
+    (void)hipEventRecord(ev[1], ctx_->stream);
+    if ((rc = run_huffman()) != JPGPU_OK) return rc;
+    (void)hipEventRecord(ev[2], ctx_->stream);
+    if ((rc = run_idct()) != JPGPU_OK) return rc;
+    (void)hipEventRecord(ev[3], ctx_->stream);
+    ev_used_ += 4;
+    return JPGPU_OK;
+}
+
+int DeviceBatch::sync() {
+    hipError_t e = hipStreamSynchronize(ctx_->stream);
+    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "hipStreamSynchronize");
+}
+
+// Average per-stage device time over every decode() issued since the previous query (HIP events on the ctx stream).
+int DeviceBatch::stage_ms(float ms[4]) {
+    if (ev_used_ == 0) return fail(JPGPU_ERR_INVALID_OPERATION, "jpgpu_batch_stage_ms: no decode has run since the last query");
+    int rc = sync();
+    if (rc != JPGPU_OK) return rc;
+    double acc[4] = {0, 0, 0, 0};
+    const size_t n = ev_used_ / 4;
+    for (size_t k = 0; k < n; k++) {
+        hipEvent_t *ev = &ev_pool_[k * 4];
+        float t;
+        for (int i = 0; i < 3; i++) {
+            if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) != hipSuccess) return fail(JPGPU_ERR_DEVICE, "hipEventElapsedTime failed");
+            acc[i] += t;
+        }
+        if (hipEventElapsedTime(&t, ev[0], ev[3]) != hipSuccess) return fail(JPGPU_ERR_DEVICE, "hipEventElapsedTime failed");
+        acc[3] += t;
+    }
+    for (int i = 0; i < 4; i++) ms[i] = (float)(acc[i] / (double)n);
+    ev_used_ = 0;
+    return JPGPU_OK;
+}
+
+int DeviceBatch::fetch_status() {
+    if (status_valid_) return JPGPU_OK;
+    int rc = sync();
+    if (rc != JPGPU_OK) return rc;
+    if (!h_status_.empty()) {
+        hipError_t e = hipMemcpy(h_status_.data(), d_status_.ptr, h_status_.size() * sizeof(DevScanStatus), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpy(status)");
+    }
+    status_valid_ = true;
+    return JPGPU_OK;
+}
+
+int DeviceBatch::result(int i, jpgpu_image_result *res) {
+    const ImagePlan *img = image(i);
+    if (!img || !res) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_result: bad index");
+    memset(res, 0, sizeof *res);
+    if (img->status != JPGPU_OK) {
+        res->status = img->status;
+        res->detail = img->detail;
+        ctx_->last_error = img->error;
+        return JPGPU_OK;
+    }
+    int rc = fetch_status();
+    if (rc != JPGPU_OK) return rc;
+    res->status = JPGPU_OK;
+    for (int j : img->jobs) {
+        const DevScanStatus &st = h_status_[j];
+        res->decoded_mcus = st.decoded_mcus;
+        res->terminator = st.terminator;
+        res->bytes_consumed = st.end_pos;
+        if (st.first_error != kNoError) {
+            const uint32_t detail = st.first_error & 0xFF;
+            res->detail = (int32_t)detail;
+            res->error_interval = st.first_error >> 8;
+            // exception class thrown by the reference for each failure
+            res->status = detail == kDetailExpectRestart ? JPGPU_ERR_INVALID_OPERATION : JPGPU_ERR_INVALID_DATA;
+            break;
+        }
+        if (st.decoded_mcus < h_scans_[j].total_mcus) res->detail = kDetailEarlyEoi;
+    }
+    return JPGPU_OK;
+}
+
+int DeviceBatch::download_output(int i, void *dst, size_t cap) {
+    const ImagePlan *img = image(i);
+    if (!img || !dst) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_download_output: bad argument");
+    if (img->status != JPGPU_OK) return fail(img->status, img->error);
+    if (cap < img->out_bytes) return fail(JPGPU_ERR_ARGUMENT, "Destination buffer is too small.");
+    int rc = sync();
+    if (rc != JPGPU_OK) return rc;
+    hipError_t e = hipMemcpy(dst, (const uint8_t *)d_out_.ptr + img->out_offset, img->out_bytes, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "hipMemcpy(output)");
+}
+
+int DeviceBatch::download_coefficients(int i, int16_t *dst, size_t cap_blocks) {
+    const ImagePlan *img = image(i);
+    if (!img || !dst) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_download_coefficients: bad argument");
+    if (img->status != JPGPU_OK) return fail(img->status, img->error);
+    if (cap_blocks < img->total_blocks) return fail(JPGPU_ERR_ARGUMENT, "Destination buffer is too small.");
+    int rc = sync();
+    if (rc != JPGPU_OK) return rc;
+    hipError_t e = hipMemcpy(dst, (const int16_t *)d_coefs_.ptr + img->coef_offset * 64, img->total_blocks * 128, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "hipMemcpy(coefficients)");
+}
+
+int DeviceBatch::upload_coefficients(int i, const int16_t *src, size_t nblocks) {
+    const ImagePlan *img = image(i);
+    if (!img || !src) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_coefficients: bad argument");
+    if (img->status != JPGPU_OK) return fail(img->status, img->error);
+    if (nblocks != img->total_blocks) return fail(JPGPU_ERR_ARGUMENT, "Block count does not match the image.");
+    int rc = sync();
+    if (rc != JPGPU_OK) return rc;
+    hipError_t e = hipMemcpy((int16_t *)d_coefs_.ptr + img->coef_offset * 64, src, nblocks * 128, hipMemcpyHostToDevice);
+    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "hipMemcpy(coefficients)");
+}
+
+void DeviceBatch::totals(uint64_t *compressed, uint64_t *blocks, uint64_t *pixels, uint64_t *out_bytes) const {
+    if (compressed) *compressed = compressed_bytes_;
+    if (blocks) *blocks = total_blocks_;
+    if (pixels) *pixels = total_pixels_;
+    if (out_bytes) {
+        uint64_t s = 0;
+        for (const ImagePlan &img : images_)
+            if (img.status == JPGPU_OK && !img.jobs.empty()) s += img.out_bytes;
+        *out_bytes = s;
+    }
+}
+
+}  // namespace jpgpu

@@ -1,0 +1,109 @@
+// jpeglibrary_amd/csrc/device_batch.h -- device-resident batch of scan jobs: HBM layout, uploads, kernel launches.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/jpgpu.h"
+#include "common.h"
+#include "host.h"
+
+struct jpgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    int num_cus = 0;
+};
+
+namespace jpgpu {
+
+// grow-only device allocation
+struct DevBuffer {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes);
+    void release();
+};
+
+struct ImagePlan {
+    int status = JPGPU_OK;
+    int detail = 0;
+    std::string error;
+    uint16_t width = 0, height = 0;
+    uint8_t precision = 0, num_components = 0, sof = 0;
+    uint32_t restart_interval = 0;
+    uint32_t mcus_per_line = 0, mcus_per_column = 0, blocks_per_mcu = 0;
+    uint64_t total_blocks = 0;
+    uint64_t out_offset = 0, out_bytes = 0;
+    uint64_t coef_offset = 0;
+    jpgpu_plane_info plane[4] = {};
+    std::vector<int> jobs;     // indices into DeviceBatch::jobs_
+    uint64_t file_offset = 0;  // position of the file inside the device input buffer
+    size_t file_len = 0;
+};
+
+class DeviceBatch {
+  public:
+    explicit DeviceBatch(jpgpu_ctx *ctx) : ctx_(ctx) {}
+    ~DeviceBatch();
+
+    // Whole files: host parse (Identify + Decode's marker loop) -> plans/jobs -> HBM.
+    int upload_files(const uint8_t *const *jpeg, const size_t *len, int n, int format);
+    // One pre-built scan job whose entropy bytes are `entropy` (level-2 API and the JpegDecoder mirror).
+    int upload_single_job(const ScanJob &job, int format, const void *initial_output, size_t initial_output_bytes);
+
+    int run_marker_index();
+    int run_huffman();
+    int run_idct();
+    int decode();  // all three, with stage events
+    int sync();
+
+    int size() const { return (int)images_.size(); }
+    const ImagePlan *image(int i) const { return (i >= 0 && i < (int)images_.size()) ? &images_[i] : nullptr; }
+    int result(int i, jpgpu_image_result *res);
+    void *output_device(uint64_t *total) const {
+        if (total) *total = out_bytes_;
+        return d_out_.ptr;
+    }
+    void *coefs_device(uint64_t *total_blocks) const {
+        if (total_blocks) *total_blocks = total_blocks_;
+        return d_coefs_.ptr;
+    }
+    int download_output(int i, void *dst, size_t cap);
+    int download_coefficients(int i, int16_t *dst, size_t cap_blocks);
+    int upload_coefficients(int i, const int16_t *src, size_t nblocks);
+    int stage_ms(float ms[4]);
+    void totals(uint64_t *compressed, uint64_t *blocks, uint64_t *pixels, uint64_t *out_bytes) const;
+    int format() const { return format_; }
+
+  private:
+    int fail(int status, const std::string &msg);
+    int hip_fail(hipError_t e, const char *what);
+    int layout_and_upload(const std::vector<const uint8_t *> &file_ptr, const std::vector<size_t> &file_len);
+    void plan_image_geometry(ImagePlan &img, const BaselineGeometry &geo);
+    int fetch_status();
+
+    jpgpu_ctx *ctx_;
+    int format_ = JPGPU_FMT_INTERLEAVED_U8;
+    std::vector<ImagePlan> images_;
+    std::vector<ScanJob> jobs_;
+    std::vector<int> job_image_;
+    std::vector<uint64_t> job_entropy_off_;  // offset of the job's entropy segment inside its file
+    std::vector<DevScan> h_scans_;
+    std::vector<DevScanStatus> h_status_;
+    bool status_valid_ = false;
+    std::vector<DevHuffTable> huff_pool_;
+    std::vector<DevQuantTable> quant_pool_;
+    int n_huff_slots_ = 1;
+    int n_huff_work_ = 0, n_idct_work_ = 0;
+    uint64_t total_blocks_ = 0, out_bytes_ = 0, input_bytes_ = 0, compressed_bytes_ = 0, total_pixels_ = 0;
+    uint32_t total_ends_ = 0;
+
+    DevBuffer d_input_, d_scans_, d_status_, d_ends_, d_huff_pool_, d_quant_pool_, d_huff_work_, d_idct_work_, d_coefs_, d_out_;
+    // stage events of every decode() since the last stage_ms() query (4 events per decode)
+    std::vector<hipEvent_t> ev_pool_;
+    size_t ev_used_ = 0;
+};
+
+}  // namespace jpgpu

@@ -1,0 +1,705 @@
+// jpeglibrary_amd/csrc/host_parser.cpp -- host-side marker / table parsing and JpegDecoder state machine.
+// See host.h for the map of reference files this mirrors.  No per-block arithmetic happens here.
+#include <string.h>
+
+#include <algorithm>
+
+#include "../../include/jpgpu.h"
+#include "host.h"
+
+namespace jpgpu {
+
+void throw_invalid_data(const std::string &msg, int detail) { throw DecodeError(JPGPU_ERR_INVALID_DATA, msg, detail); }
+void throw_invalid_data_at(int offset, const std::string &msg, int detail) {
+    // ref: JpegDecoder.cs:371-375
+    throw DecodeError(JPGPU_ERR_INVALID_DATA, "Failed to decode JPEG data at offset " + std::to_string(offset) + ". " + msg, detail);
+}
+void throw_invalid_operation(const std::string &msg, int detail) { throw DecodeError(JPGPU_ERR_INVALID_OPERATION, msg, detail); }
+
+// ------------------------------------------------------------------------------------------------ MarkerReader
+
+bool MarkerReader::try_read_start_of_image() {
+    if (n_ < 2) return false;
+    if (p_[0] == kPadding && p_[1] == kSOI) {
+        p_ += 2;
+        n_ -= 2;
+        return true;
+    }
+    return false;
+}
+
+bool MarkerReader::try_read_marker(int *marker) {
+    while (n_ >= 2) {
+        const uint8_t b1 = p_[0], b2 = p_[1];
+        if (b1 == kPadding) {
+            if (b2 == kPadding) {  // fill byte
+                p_ += 1;
+                n_ -= 1;
+                continue;
+            }
+            if (b2 == 0) {  // stuffed FF inside entropy data
+                p_ += 2;
+                n_ -= 2;
+                continue;
+            }
+            p_ += 2;
+            n_ -= 2;
+            *marker = b2;
+            return true;
+        }
+        const uint8_t *q = static_cast<const uint8_t *>(memchr(p_, kPadding, n_));
+        if (!q) {
+            p_ += n_;
+            n_ = 0;
+            *marker = 0;
+            return false;
+        }
+        n_ -= (size_t)(q - p_);
+        p_ = q;
+    }
+    *marker = 0;
+    return false;
+}
+
+bool MarkerReader::try_read_length(uint16_t *length) {
+    if (n_ < 2) {
+        *length = 0;
+        return false;
+    }
+    // The reference computes (ushort)(b0 << 8 | b1 - 2), which binds as (b0 << 8) | (b1 - 2) (JpegReader.cs:174):
+    // the true payload length only when the low length byte is >= 2.  Kept bit-for-bit so that files the
+    // reference rejects are rejected here too (drop-in behaviour); SURVEY 3.4-10.
+    const int32_t v = ((int32_t)p_[0] << 8) | ((int32_t)p_[1] - 2);
+    *length = (uint16_t)v;
+    p_ += 2;
+    n_ -= 2;
+    return true;
+}
+
+bool MarkerReader::try_read_bytes(int length, const uint8_t **bytes) {
+    if (n_ < (size_t)length) return false;
+    *bytes = p_;
+    p_ += length;
+    n_ -= (size_t)length;
+    return true;
+}
+
+bool MarkerReader::try_advance(int length) {
+    if (length < 0 || n_ < (size_t)length) return false;
+    p_ += length;
+    n_ -= (size_t)length;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ headers
+
+bool FrameHeader::try_parse(const uint8_t *buf, size_t len, bool metadata_only, FrameHeader *out, int *consumed) {
+    *consumed = 0;
+    if (len < 6) return false;
+    FrameHeader fh;
+    fh.num_components = buf[5];
+    fh.samples_per_line = (uint16_t)(buf[4] | (buf[3] << 8));
+    fh.lines = (uint16_t)(buf[2] | (buf[1] << 8));
+    fh.precision = buf[0];
+    buf += 6;
+    len -= 6;
+    *consumed += 6;
+    if (len < (size_t)(3 * fh.num_components)) return false;
+    if (metadata_only) {
+        *consumed += 3 * fh.num_components;
+        *out = fh;
+        return true;
+    }
+    fh.components.resize(fh.num_components);
+    for (int i = 0; i < fh.num_components; i++) {
+        FrameComponent &c = fh.components[i];
+        c.identifier = buf[0];
+        c.h = (uint8_t)(buf[1] >> 4);
+        c.v = (uint8_t)(buf[1] & 0xF);
+        c.tq = buf[2];
+        buf += 3;
+        *consumed += 3;
+    }
+    *out = fh;
+    return true;
+}
+
+bool ScanHeader::try_parse(const uint8_t *buf, size_t len, bool metadata_only, ScanHeader *out, int *consumed) {
+    *consumed = 0;
+    if (len == 0) return false;
+    ScanHeader sh;
+    sh.num_components = buf[0];
+    buf++;
+    len--;
+    (*consumed)++;
+    if (len < (size_t)(2 * sh.num_components + 3)) return false;
+    if (!metadata_only) {
+        sh.components.resize(sh.num_components);
+        for (int i = 0; i < sh.num_components; i++) {
+            sh.components[i].selector = buf[0];
+            sh.components[i].td = (uint8_t)(buf[1] >> 4);
+            sh.components[i].ta = (uint8_t)(buf[1] & 0xF);
+            buf += 2;
+            *consumed += 2;
+        }
+    } else {
+        buf += 2 * sh.num_components;
+        *consumed += 2 * sh.num_components;
+    }
+    sh.ss = buf[0];
+    sh.se = buf[1];
+    sh.ah = (uint8_t)(buf[2] >> 4);
+    sh.al = (uint8_t)(buf[2] & 0xF);
+    *consumed += 3;
+    *out = sh;
+    return true;
+}
+
+bool QuantTable::try_parse(const uint8_t *buf, size_t len, QuantTable *out, int *consumed) {
+    *consumed = 0;
+    if (len == 0) return false;
+    QuantTable t;
+    t.precision = (uint8_t)(buf[0] >> 4);
+    t.identifier = (uint8_t)(buf[0] & 0xF);
+    (*consumed)++;
+    buf++;
+    len--;
+    if (t.precision == 0) {
+        if (len < 64) return false;
+        for (int i = 0; i < 64; i++) t.elements[i] = buf[i];
+        *consumed += 64;
+    } else if (t.precision == 1) {
+        if (len < 128) return false;
+        for (int i = 0; i < 64; i++) t.elements[i] = (uint16_t)(buf[2 * i] << 8 | buf[2 * i + 1]);
+        *consumed += 128;
+    } else {
+        return false;
+    }
+    *out = t;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ Huffman tables
+
+bool HuffTable::from_bits_values(uint8_t table_class, uint8_t identifier, const uint8_t bits[16], const uint8_t *values,
+                                 int num_values, HuffTable *out) {
+    int code_count = 0;
+    for (int i = 15; i >= 0; i--) code_count += bits[i];
+    if (code_count > 256 || num_values < code_count) return false;
+
+    HuffTable t;
+    t.table_class = table_class;
+    t.identifier = identifier;
+    memcpy(t.bits, bits, 16);
+    t.num_values = (uint16_t)code_count;
+    memcpy(t.values, values, (size_t)code_count);
+
+    // GenerateSizeTable / GenerateCodeTable (ref: JpegHuffmanDecodingTable.cs:293-337)
+    uint8_t huffsize[257] = {};
+    uint16_t huffcode[257] = {};
+    int k = 0;
+    for (int len = 1; len <= 16; len++)
+        for (int j = 0; j < bits[len - 1]; j++) huffsize[k++] = (uint8_t)len;
+    huffsize[k] = 0;
+    if (huffsize[0] != 0) {
+        int code = 0, si = huffsize[0];
+        k = 0;
+        for (;;) {
+            do {
+                huffcode[k] = (uint16_t)code;
+                code++;
+                k++;
+            } while (huffsize[k] == si);
+            if (huffsize[k] == 0) break;
+            do {
+                code <<= 1;
+                si++;
+            } while (huffsize[k] != si);
+        }
+    }
+    // Configure (ref: :339-376)
+    int p = 0;
+    for (int l = 1; l <= 16; l++) {
+        if (bits[l - 1] != 0) {
+            t.valoffset[l] = (uint8_t)(p - huffcode[p]);
+            p += bits[l - 1];
+            uint16_t mc = huffcode[p - 1];
+            mc = (uint16_t)(mc << (16 - l));
+            t.maxcode[l] = (uint16_t)(mc | (uint32_t)((1 << (16 - l)) - 1));
+        } else {
+            t.maxcode[l] = 0;
+        }
+    }
+    t.valoffset[18] = 0;
+    t.maxcode[17] = 0xFFFF;
+    // FillByteLookupTable (ref: :378-390)
+    p = 0;
+    for (int l = 1; l <= 8; l++) {
+        for (int i = 0; i < bits[l - 1]; i++, p++) {
+            const int free_bits = 8 - l;
+            const int code = (uint8_t)(huffcode[p] << free_bits);
+            for (int j = 0; j < (1 << free_bits) && code + j < 256; j++) {
+                t.la_size[code + j] = (uint8_t)l;
+                t.la_symbol[code + j] = t.values[p];
+            }
+        }
+    }
+    *out = t;
+    return true;
+}
+
+bool HuffTable::try_parse(const uint8_t *buf, size_t len, HuffTable *out, int *consumed) {
+    *consumed = 0;
+    if (len == 0) return false;
+    const uint8_t tcth = buf[0];
+    (*consumed)++;
+    buf++;
+    len--;
+    if (len < 16) return false;
+    int code_count = 0;
+    for (int i = 15; i >= 0; i--) code_count += buf[i];
+    if (code_count > 256) return false;
+    *consumed += 16;
+    if (len - 16 < (size_t)code_count) return false;
+    *consumed += code_count;
+    return from_bits_values((uint8_t)(tcth >> 4), (uint8_t)(tcth & 0xF), buf, buf + 16, code_count, out);
+}
+
+bool HuffTable::lookup(int code16, int *size, int *symbol) const {
+    const int high8 = code16 >> 8;
+    if (la_size[high8] != 0) {
+        *size = la_size[high8];
+        *symbol = la_symbol[high8];
+        return true;
+    }
+    int s = 9;
+    while (code16 > maxcode[s]) s++;
+    if (s > 16) return false;
+    *size = s;
+    *symbol = values[(valoffset[s] + (code16 >> (16 - s))) & 0xFF];
+    return true;
+}
+
+void HuffTable::to_device(DevHuffTable *out) const {
+    memset(out, 0, sizeof *out);
+    // A code of length <= kHuffLutBits is decided by the top kHuffLutBits bits alone (maxcode[l] has its low 16-l
+    // bits set), so evaluating the reference's Lookup() with the remaining bits all ones gives the entry.
+    for (int i = 0; i < kHuffLutSize; i++) {
+        const int code16 = (i << (16 - kHuffLutBits)) | ((1 << (16 - kHuffLutBits)) - 1);
+        int size = 0, symbol = 0;
+        if (lookup(code16, &size, &symbol) && size <= kHuffLutBits) out->lut[i] = (uint16_t)((size << 8) | symbol);
+    }
+    memcpy(out->maxcode, maxcode, sizeof maxcode);
+    memcpy(out->valoffset, valoffset, sizeof valoffset);
+    memcpy(out->values, values, sizeof values);
+}
+
+// ------------------------------------------------------------------------------------------------ HostDecoder
+
+void HostDecoder::set_input(const uint8_t *data, size_t len) {
+    input_ = data;
+    input_len_ = len;
+    frame_.reset();
+    restart_interval_ = 0;
+}
+
+const FrameHeader &HostDecoder::frame_header() const {
+    if (!frame_) throw_invalid_operation("Call Identify() before this operation.");
+    return *frame_;
+}
+
+void HostDecoder::set_restart_interval(int v) {
+    if ((unsigned)v > 0xFFFFu) throw DecodeError(JPGPU_ERR_ARGUMENT, "Specified argument was out of the range of valid values. (Parameter 'restartInterval')");
+    restart_interval_ = (uint16_t)v;
+}
+
+int HostDecoder::maximum_horizontal_sampling() const {
+    const FrameHeader &fh = frame_header();
+    if (fh.components.empty() && fh.num_components) throw_invalid_operation("Operation is not valid due to the current state of the object.");
+    int m = 1;
+    for (const FrameComponent &c : fh.components) m = std::max(m, (int)c.h);
+    return m;
+}
+int HostDecoder::maximum_vertical_sampling() const {
+    const FrameHeader &fh = frame_header();
+    if (fh.components.empty() && fh.num_components) throw_invalid_operation("Operation is not valid due to the current state of the object.");
+    int m = 1;
+    for (const FrameComponent &c : fh.components) m = std::max(m, (int)c.v);
+    return m;
+}
+
+const HuffTable *HostDecoder::huffman_table(bool is_dc, uint8_t identifier) const {
+    const int cls = is_dc ? 0 : 1;
+    for (const HuffTable &t : huff_)
+        if (t.table_class == cls && t.identifier == identifier) return &t;
+    return nullptr;
+}
+const QuantTable *HostDecoder::quantization_table(uint8_t identifier) const {
+    for (const QuantTable &t : quant_)
+        if (t.identifier == identifier) return &t;
+    return nullptr;
+}
+void HostDecoder::set_huffman_table(const HuffTable &t) {
+    for (HuffTable &e : huff_)
+        if (e.table_class == t.table_class && e.identifier == t.identifier) {
+            e = t;
+            return;
+        }
+    huff_.push_back(t);
+}
+void HostDecoder::set_quantization_table(const QuantTable &t) {
+    for (QuantTable &e : quant_)
+        if (e.identifier == t.identifier) {
+            e = t;
+            return;
+        }
+    quant_.push_back(t);
+}
+
+void HostDecoder::process_other_marker(MarkerReader &r) {
+    uint16_t length;
+    if (!r.try_read_length(&length)) throw_invalid_data_at(r.consumed_byte_count(), "Unexpected end of input data when reading segment length.", kDetailBadHeader);
+    if (!r.try_advance(length)) throw_invalid_data_at(r.consumed_byte_count(), "Unexpected end of input data reached.", kDetailBadHeader);
+}
+
+void HostDecoder::process_frame_header(MarkerReader &r, bool metadata_only, bool override_allowed) {
+    uint16_t length;
+    const uint8_t *buf;
+    if (!r.try_read_length(&length)) throw_invalid_data_at(r.consumed_byte_count(), "Unexpected end of input data when reading segment length.", kDetailBadHeader);
+    if (!r.try_read_bytes(length, &buf)) throw_invalid_data_at(r.consumed_byte_count(), "Unexpected end of input data when reading segment content.", kDetailBadHeader);
+    FrameHeader fh;
+    int consumed;
+    if (!FrameHeader::try_parse(buf, length, metadata_only, &fh, &consumed))
+        throw_invalid_data_at(r.consumed_byte_count() - length + consumed, "Failed to parse frame header.", kDetailBadHeader);
+    if (!override_allowed && frame_) throw_invalid_data_at(r.consumed_byte_count(), "Multiple frame is not supported.", kDetailBadHeader);
+    frame_ = fh;
+}
+
+ScanHeader HostDecoder::process_scan_header(MarkerReader &r, bool metadata_only) {
+    uint16_t length;
+    const uint8_t *buf;
+    if (!r.try_read_length(&length)) throw_invalid_data_at(r.consumed_byte_count(), "Unexpected end of input data when reading segment length.", kDetailBadHeader);
+    if (!r.try_read_bytes(length, &buf)) throw_invalid_data_at(r.consumed_byte_count(), "Unexpected end of input data when reading segment content.", kDetailBadHeader);
+    ScanHeader sh;
+    int consumed;
+    if (!ScanHeader::try_parse(buf, length, metadata_only, &sh, &consumed))
+        throw_invalid_data_at(r.consumed_byte_count() - length + consumed, "Failed to parse scan header.", kDetailBadHeader);
+    return sh;
+}
+
+void HostDecoder::process_dri(MarkerReader &r) {
+    uint16_t length;
+    const uint8_t *buf;
+    if (!r.try_read_length(&length)) throw_invalid_data_at(r.consumed_byte_count(), "Unexpected end of input data when reading segment length.", kDetailBadHeader);
+    if (!r.try_read_bytes(length, &buf) || length < 2)
+        throw_invalid_data_at(r.consumed_byte_count(), "Unexpected end of input data when reading segment content.", kDetailBadHeader);
+    restart_interval_ = (uint16_t)((buf[0] << 8) | buf[1]);
+}
+
+void HostDecoder::process_dht(MarkerReader &r) {
+    uint16_t length;
+    const uint8_t *buf;
+    if (!r.try_read_length(&length)) throw_invalid_data_at(r.consumed_byte_count(), "Unexpected end of input data when reading segment length.", kDetailBadHeader);
+    if (!r.try_read_bytes(length, &buf)) throw_invalid_data_at(r.consumed_byte_count(), "Unexpected end of input data when reading segment content.", kDetailBadHeader);
+    int offset = r.consumed_byte_count() - length;
+    size_t len = length;
+    while (len != 0) {
+        HuffTable t;
+        int consumed;
+        if (!HuffTable::try_parse(buf, len, &t, &consumed)) throw_invalid_data_at(offset, "Failed to parse Huffman table.", kDetailBadHeader);
+        buf += consumed;
+        len -= (size_t)consumed;
+        offset += consumed;
+        set_huffman_table(t);
+    }
+}
+
+void HostDecoder::process_dqt(MarkerReader &r, bool load) {
+    uint16_t length;
+    const uint8_t *buf;
+    if (!r.try_read_length(&length)) throw_invalid_data_at(r.consumed_byte_count(), "Unexpected end of input data when reading segment length.", kDetailBadHeader);
+    if (!r.try_read_bytes(length, &buf)) throw_invalid_data_at(r.consumed_byte_count(), "Unexpected end of input data when reading segment content.", kDetailBadHeader);
+    if (!load) return;
+    int offset = r.consumed_byte_count() - length;
+    size_t len = length;
+    while (len != 0) {
+        QuantTable t;
+        int consumed;
+        if (!QuantTable::try_parse(buf, len, &t, &consumed)) throw_invalid_data_at(offset, "Failed to parse quantization table.", kDetailBadHeader);
+        buf += consumed;
+        len -= (size_t)consumed;
+        offset += consumed;
+        set_quantization_table(t);
+    }
+}
+
+static bool is_any_sof(int m) {
+    switch (m) {
+    case kSOF0: case kSOF1: case kSOF2: case kSOF3: case kSOF5: case kSOF6: case kSOF7:
+    case kSOF9: case kSOF10: case kSOF11: case kSOF13: case kSOF14: case kSOF15:
+        return true;
+    default:
+        return false;
+    }
+}
+
+bool HostDecoder::process_marker_for_identification(int marker, MarkerReader &r, bool load_qt) {
+    if (marker == kSOI) {
+    } else if (is_any_sof(marker)) {
+        start_of_frame_ = marker;
+        process_frame_header(r, false, false);
+    } else if (marker == kSOS) {
+        process_scan_header(r, true);
+    } else if (marker == kDRI) {
+        process_dri(r);
+    } else if (marker == kDQT) {
+        process_dqt(r, load_qt);
+    } else if (is_restart_marker(marker)) {
+    } else if (marker == kEOI) {
+        return false;
+    } else {
+        process_other_marker(r);
+    }
+    return true;
+}
+
+int HostDecoder::identify(bool load_quantization_tables) {
+    if (!input_ || input_len_ == 0) throw_invalid_operation("Input buffer is not specified.");
+    MarkerReader r(input_, input_len_);
+    frame_.reset();
+    bool to_continue = true;
+    while (to_continue && !r.is_empty()) {
+        int marker;
+        if (!r.try_read_marker(&marker)) throw_invalid_data_at(r.consumed_byte_count(), "No marker found.", kDetailBadHeader);
+        to_continue = process_marker_for_identification(marker, r, load_quantization_tables);
+    }
+    if (!frame_) throw_invalid_operation("Frame header was not found.");
+    return r.consumed_byte_count();
+}
+
+// ref: JpegStandardQuantizationTable.cs:12-34 (zig-zag order as stored by the reference)
+static const uint16_t kStdLum[64] = {16, 11, 12, 14, 12, 10, 16, 14, 13, 14, 18, 17, 16, 19, 24, 40, 26, 24, 22, 22, 24, 49,
+                                     35, 37, 29, 40, 58, 51, 61, 60, 57, 51, 56, 55, 64, 72, 92, 78, 64, 68, 87, 69, 55, 56,
+                                     80, 109, 81, 87, 95, 98, 103, 104, 103, 62, 77, 113, 121, 112, 100, 120, 92, 101, 103, 99};
+static const uint16_t kStdChr[64] = {17, 18, 18, 24, 21, 24, 47, 26, 26, 47, 99, 66, 56, 66, 99, 99, 99, 99, 99, 99, 99, 99,
+                                     99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                     99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+
+static float estimate_quality_one(const uint16_t *q, const uint16_t *std_table) {  // ref: JpegDecoder.cs:198-249
+    bool all_ones = true;
+    double sum = 0;
+    for (int i = 0; i < 64; i++) {
+        const double pct = q[i] == 0 ? 999.99 : 100.0 * q[i] / std_table[i];
+        sum += pct;
+        if (q[i] != 1) all_ones = false;
+    }
+    sum /= 64.0;
+    if (all_ones) return 100.0f;
+    if (sum <= 100.0) return (float)((200.0 - sum) / 2.0);
+    return (float)(5000.0 / sum);
+}
+
+bool HostDecoder::try_estimate_quality(float *quality) const {
+    const QuantTable *q0 = quantization_table(0);
+    if (quant_.empty() || !q0) {
+        *quality = 0;
+        return false;
+    }
+    float q = estimate_quality_one(q0->elements, kStdLum);
+    if (const QuantTable *q1 = quantization_table(1)) q = std::min(q, estimate_quality_one(q1->elements, kStdChr));
+    *quality = std::min(std::max(q, 0.0f), 100.0f);
+    return true;
+}
+
+bool HostDecoder::process_marker_for_decode(int marker, MarkerReader &r, ScanHandler &h) {
+    switch (marker) {
+    case kSOF0: case kSOF1: case kSOF2: case kSOF3: case kSOF9: case kSOF10:
+        process_frame_header(r, false, true);
+        h.on_frame(*this, marker);
+        scan_decoder_created_ = true;
+        break;
+    case kSOF5: case kSOF6: case kSOF7: case kSOF11: case kSOF13: case kSOF14: case kSOF15:
+        throw_invalid_data_at(r.consumed_byte_count(), "This type of JPEG stream is not supported.", kDetailUnsupportedFrame);
+    case kDHT:
+        process_dht(r);
+        break;
+    case kDAC:
+        process_other_marker(r);  // arithmetic conditioning: not used by the Huffman path
+        break;
+    case kDQT:
+        process_dqt(r, true);
+        break;
+    case kDRI:
+        process_dri(r);
+        break;
+    case kSOS: {
+        if (!scan_decoder_created_) throw_invalid_data_at(r.consumed_byte_count(), "Scan header appears before frame header.", kDetailBadHeader);
+        const ScanHeader sh = process_scan_header(r, false);
+        h.on_scan(*this, r, sh);
+        break;
+    }
+    case kEOI:
+        return false;
+    default:
+        if (is_restart_marker(marker)) break;
+        process_other_marker(r);
+        break;
+    }
+    return true;
+}
+
+void HostDecoder::decode(ScanHandler &handler, bool have_output_writer) {
+    if (!input_ || input_len_ == 0) throw_invalid_operation("Input buffer is not specified.");
+    if (!have_output_writer) throw_invalid_operation("The output buffer is not specified.");
+    MarkerReader r(input_, input_len_);
+    scan_decoder_created_ = false;
+    if (!r.try_read_start_of_image()) throw_invalid_data_at(r.consumed_byte_count(), "Marker StartOfImage not found.", kDetailBadHeader);
+    try {
+        bool to_continue = true;
+        while (to_continue && !r.is_empty()) {
+            int marker;
+            if (!r.try_read_marker(&marker)) throw_invalid_data_at(r.consumed_byte_count(), "No marker found.", kDetailBadHeader);
+            to_continue = process_marker_for_decode(marker, r, handler);
+        }
+    } catch (...) {
+        handler.on_dispose(*this);  // finally { _scanDecoder?.Dispose(); }
+        scan_decoder_created_ = false;
+        throw;
+    }
+    handler.on_dispose(*this);
+    scan_decoder_created_ = false;
+}
+
+void HostDecoder::load_tables(const uint8_t *data, size_t len) {
+    MarkerReader r(data, len);
+    while (!r.is_empty()) {
+        int marker;
+        if (!r.try_read_marker(&marker)) return;
+        if (marker == kSOI || is_restart_marker(marker)) continue;
+        if (marker == kDHT) process_dht(r);
+        else if (marker == kDAC) process_other_marker(r);
+        else if (marker == kDQT) process_dqt(r, true);
+        else if (marker == kDRI) process_dri(r);
+        else if (marker == kEOI) return;
+        else process_other_marker(r);
+    }
+}
+
+int HostDecoder::resolve_scan(const FrameHeader &fh, const ScanHeader &sh, ResolvedScanComponent out[kMaxScanComponents]) const {
+    int max_h = 1, max_v = 1;
+    for (const FrameComponent &c : fh.components) {
+        max_h = std::max(max_h, (int)c.h);
+        max_v = std::max(max_v, (int)c.v);
+    }
+    if ((int)fh.num_components < (int)sh.num_components) throw_invalid_operation("Operation is not valid due to the current state of the object.");
+    if (sh.num_components > kMaxScanComponents) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "More than 4 components in a scan are not supported.", kDetailUnsupportedFrame);
+    for (int i = 0; i < sh.num_components; i++) {
+        const ScanComponent &sc = sh.components[i];
+        int component_index = 0;
+        const FrameComponent *fc = nullptr;
+        for (int j = 0; j < fh.num_components; j++)
+            if (sc.selector == fh.components[j].identifier) {  // last match wins (no break in the reference)
+                component_index = j;
+                fc = &fh.components[j];
+            }
+        if (!fc) throw_invalid_data("Failed to decode JPEG data. The specified component is missing.", kDetailBadHeader);
+        if (fc->h == 0 || fc->v == 0) throw_invalid_data("Failed to decode JPEG data. Attempted to divide by zero.", kDetailBadHeader);
+        ResolvedScanComponent &c = out[i];
+        c.component_index = component_index;
+        c.h = fc->h;
+        c.v = fc->v;
+        c.dc = huffman_table(true, sc.td);
+        c.ac = huffman_table(false, sc.ta);
+        c.quant = quantization_table(fc->tq);
+        c.hs = max_h / fc->h;
+        c.vs = max_v / fc->v;
+    }
+    return sh.num_components;
+}
+
+// ------------------------------------------------------------------------------------------------ scan jobs
+
+BaselineGeometry BaselineGeometry::latch(const HostDecoder &dec, const FrameHeader &fh) {
+    BaselineGeometry g;
+    g.frame = fh;
+    for (const FrameComponent &c : fh.components) {
+        g.max_h = std::max(g.max_h, (int)c.h);
+        g.max_v = std::max(g.max_v, (int)c.v);
+    }
+    g.restart_interval = dec.restart_interval();  // latched at construction
+    g.mcus_per_line = (fh.samples_per_line + 8 * g.max_h - 1) / (8 * g.max_h);
+    g.mcus_per_column = (fh.lines + 8 * g.max_v - 1) / (8 * g.max_v);
+    g.level_shift = 1 << ((fh.precision - 1) & 31);
+    return g;
+}
+
+ScanJob make_scan_job(const HostDecoder &dec, const BaselineGeometry &geo, const ScanHeader &scan, const uint8_t *entropy,
+                      size_t entropy_len) {
+    ScanJob job;
+    job.geo = geo;
+    job.entropy = entropy;
+    job.entropy_len = entropy_len;
+    if (geo.frame.components.empty() && geo.frame.num_components)
+        throw_invalid_data("Failed to decode JPEG data. Component parameters are missing in JPEG frame header.", kDetailBadHeader);
+    job.scan_components = dec.resolve_scan(geo.frame, scan, job.comp);
+    for (int i = 0; i < job.scan_components; i++) {
+        ResolvedScanComponent &c = job.comp[i];
+        if (!c.dc || !c.ac)
+            throw_invalid_data("Failed to decode JPEG data. Huffman table of component " + std::to_string(c.component_index) + " is not defined.", kDetailMissingTable);
+        if (!c.quant)
+            throw_invalid_data("Failed to decode JPEG data. Quantization table of component " + std::to_string(c.component_index) + " is not defined.", kDetailMissingTable);
+    }
+    // snapshot tables; dedupe by registry pointer
+    const HuffTable *seen[kMaxHuffSlots] = {};
+    auto slot_of = [&](const HuffTable *t) -> uint8_t {
+        for (int i = 0; i < job.n_huff; i++)
+            if (seen[i] == t) return (uint8_t)i;
+        seen[job.n_huff] = t;
+        job.huff_copy[job.n_huff] = *t;
+        return (uint8_t)job.n_huff++;
+    };
+    int nblk = 0;
+    for (int i = 0; i < job.scan_components; i++) {
+        ResolvedScanComponent &c = job.comp[i];
+        job.dc_slot[i] = slot_of(c.dc);
+        job.ac_slot[i] = slot_of(c.ac);
+        job.quant_copy[i] = *c.quant;
+        // block order inside an MCU: scan-component order, then y < v, then x < h (ref: ...BaselineScanDecoder.cs:107-118)
+        for (int y = 0; y < c.v; y++)
+            for (int x = 0; x < c.h; x++) {
+                if (nblk >= kMaxBlocksPerMcu)
+                    throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "More than 16 blocks per MCU are not supported.", kDetailUnsupportedFrame);
+                job.blk_comp[nblk] = (uint8_t)i;
+                job.blk_x[nblk] = (uint8_t)x;
+                job.blk_y[nblk] = (uint8_t)y;
+                nblk++;
+            }
+    }
+    job.blocks_per_mcu = nblk;
+    // the job owns snapshots (huff_copy / quant_copy, addressed by slot); drop the registry pointers so nothing
+    // dangles when the job is moved or the registry changes
+    for (int i = 0; i < job.scan_components; i++) job.comp[i].dc = job.comp[i].ac = nullptr, job.comp[i].quant = nullptr;
+    return job;
+}
+
+size_t find_scan_end(const uint8_t *data, size_t len) {
+    size_t pos = 0;
+    while (pos + 1 < len) {
+        const uint8_t *q = static_cast<const uint8_t *>(memchr(data + pos, 0xFF, len - 1 - pos));
+        if (!q) return len;
+        pos = (size_t)(q - data);
+        const uint8_t nb = data[pos + 1];
+        if (nb == 0x00) {
+            pos += 2;
+        } else if (nb == 0xFF) {
+            pos += 1;
+        } else if (is_restart_marker(nb)) {
+            pos += 2;
+        } else {
+            return pos;
+        }
+    }
+    return len;
+}
+
+}  // namespace jpgpu

@@ -1,0 +1,25 @@
+// jpeglibrary_amd/csrc/kernels.h -- launch wrappers of the HIP kernels (internal C++ API of libjpgpu.so)
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace jpgpu {
+
+constexpr int kHuffWaves = 4;                 // wavefronts per Huffman workgroup
+constexpr int kHuffIntervalsPerWg = 64 * kHuffWaves;  // restart intervals per workgroup (one per lane)
+constexpr int kIdctBlocksPerWg = 256;         // 8x8 blocks per IDCT workgroup (one per lane)
+
+size_t huffman_lds_bytes(int n_slots);
+
+hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const DevScan *scans, int n_scans, uint32_t *ends,
+                               DevScanStatus *status);
+hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
+                          const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
+                          int n_slots);
+hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *scans, const IdctWork *work, int n_work,
+                       const DevScanStatus *status, const DevQuantTable *quant_pool, uint8_t *out, int format);
+
+}  // namespace jpgpu

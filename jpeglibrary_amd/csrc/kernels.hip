@@ -1,0 +1,774 @@
+// jpeglibrary_amd/csrc/kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4, wave64).
+//
+// The reference's hot loop (ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:51-177) is serial:
+//   per MCU, per block: ReadBlockBaseline -> DequantizeBlockAndUnZigZag -> TransformIDCT -> ShiftDataLevel -> WriteBlock.
+// Here it becomes three device stages over a whole batch of scan jobs:
+//   K1 marker_index_kernel    byte-scan of the entropy segment for FF Dn / terminating marker (restart index)
+//   K2 huffman_decode_kernel  one LANE per restart interval, 64 intervals per wavefront; block staged in LDS,
+//                             flushed as whole 128-byte lines to the coefficient buffer (zig-zag int16, MCU order)
+//   K3 idct_output_kernel     one lane per 8x8 block: dequantise + float32 IDCT (strict op order, no FMA) +
+//                             round-half-even + level shift, then block output in the requested layout
+//
+// MUST be compiled with -ffp-contract=off: the reference's Vector4 arithmetic never fuses a*b+c
+// (FastFloatingPointDCT.cs:79-185).  No fast-math.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace jpgpu {
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+__device__ __forceinline__ uint32_t wave_reduce_min(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t t = __shfl_xor(v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_reduce_max_i(int32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int32_t t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return (uint32_t)v;
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    uint32_t l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if (l >= (uint32_t)o) v += t;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: marker index.  One workgroup per scan job.
+//
+// In entropy-coded data 0xFF is always "fresh" (the second byte of FF00 / FFxx is never FF), so
+// "data[p]==FF && data[p+1] not in {00,FF}" identifies a marker without context -- the same rule
+// JpegBitReader.FillBuffer applies byte-serially (ref: JpegBitReader.cs:95-138).
+// ends[k] = offset of the FF that closes restart interval k.  Indexing stops at the first non-RST marker
+// (or at ANY marker when DRI == 0: the reference's bit reader stops feeding bits at every marker).
+// ------------------------------------------------------------------------------------------------
+
+constexpr int kScanThreads = 256;
+constexpr uint32_t kInf = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(kScanThreads) void marker_index_kernel(const uint8_t *__restrict__ data,
+                                                                      const DevScan *__restrict__ scans,
+                                                                      uint32_t *__restrict__ ends,
+                                                                      DevScanStatus *__restrict__ status) {
+    const DevScan &s = scans[blockIdx.x];
+    const uint8_t *p = data + s.data_off;
+    const uint32_t len = s.data_len;
+    const uint32_t cap = s.n_intervals;
+    const bool any_marker_terminates = (s.dri == 0);
+    uint32_t *out = ends + s.ends_off;
+
+    __shared__ uint32_t sh_wave_total[kScanThreads / 64];
+    __shared__ uint32_t sh_term;
+    __shared__ int32_t sh_last;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = tid >> 6;
+    const int32_t misalign = (int32_t)(reinterpret_cast<uintptr_t>(p) & 15);
+    uint32_t found = 0;      // uniform
+    int32_t last_pos = -1;   // uniform: position of the last accepted entry
+    bool done = false;
+
+    for (int64_t tile = -(int64_t)misalign; tile < (int64_t)len && !done; tile += kScanThreads * 16) {
+        if (tid == 0) {
+            sh_term = kInf;
+            sh_last = -1;
+        }
+        __syncthreads();
+        const int64_t off = tile + (int64_t)tid * 16;  // relative to p; 16-byte aligned address
+        uint32_t w[5] = {0, 0, 0, 0, 0};
+        if (off < (int64_t)len) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p + off);  // input buffer is padded: over-read is safe
+            w[0] = v.x;
+            w[1] = v.y;
+            w[2] = v.z;
+            w[3] = v.w;
+            w[4] = *(p + off + 16);
+        }
+        uint32_t rst_mask = 0, term_mask = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t b = (w[j >> 2] >> ((j & 3) * 8)) & 0xFF;
+            const uint32_t nb = (w[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) & 0xFF;
+            const int64_t pos = off + j;
+            const bool in_range = pos >= 0 && pos + 1 < (int64_t)len;
+            const bool is_marker = in_range && b == 0xFF && nb != 0x00 && nb != 0xFF;
+            const bool is_rst = is_marker && ((nb & 0xF8) == 0xD0) && !any_marker_terminates;
+            rst_mask |= (uint32_t)is_rst << j;
+            term_mask |= (uint32_t)(is_marker && !is_rst) << j;
+        }
+        // earliest terminator in the tile
+        uint32_t tpos = term_mask ? (uint32_t)(off + __builtin_ctz(term_mask)) : kInf;
+        tpos = wave_reduce_min(tpos);
+        if (lane_id() == 0 && tpos != kInf) atomicMin(&sh_term, tpos);
+        __syncthreads();
+        const uint32_t term = sh_term;
+        // drop RST markers behind the terminator
+        if (term != kInf) {
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if ((int64_t)(off + j) > (int64_t)term) rst_mask &= ~(1u << j);
+        }
+        const uint32_t cnt = __builtin_popcount(rst_mask);
+        const uint32_t incl = wave_inclusive_scan(cnt);
+        if (lane_id() == 63) sh_wave_total[wave] = incl;
+        __syncthreads();
+        uint32_t base = found;
+        uint32_t tile_total = 0;
+#pragma unroll
+        for (int i = 0; i < kScanThreads / 64; i++) {
+            const uint32_t t = sh_wave_total[i];
+            if ((uint32_t)i < wave) base += t;
+            tile_total += t;
+        }
+        uint32_t idx = base + incl - cnt;
+        int32_t my_last = -1;
+        uint32_t m = rst_mask;
+        while (m) {
+            const int j = __builtin_ctz(m);
+            m &= m - 1;
+            if (idx < cap) {
+                out[idx] = (uint32_t)(off + j);
+                my_last = (int32_t)(off + j);
+            }
+            idx++;
+        }
+        my_last = (int32_t)wave_reduce_max_i(my_last);
+        if (lane_id() == 0 && my_last >= 0) atomicMax(&sh_last, my_last);
+        __syncthreads();
+        if (sh_last >= 0) last_pos = sh_last;
+        found += tile_total;
+        if (found >= cap) {
+            found = cap;
+            done = true;
+        } else if (term != kInf) {
+            if (tid == 0) out[found] = term;
+            last_pos = (int32_t)term;
+            found += 1;
+            done = true;
+        }
+        __syncthreads();
+    }
+    if (!done && found < cap) {
+        // data ran out without a terminating marker: pseudo entry at the end of the data
+        if (tid == 0) out[found] = len;
+        last_pos = (int32_t)len;
+        found += 1;
+    }
+    if (tid == 0) {
+        DevScanStatus st;
+        st.n_ends = found;
+        st.terminator = ((uint32_t)last_pos + 1 < len) ? p[last_pos + 1] : 0;
+        st.first_error = kNoError;
+        st.decoded_mcus = s.total_mcus;
+        st.end_pos = (uint32_t)last_pos;
+        st.pad[0] = st.pad[1] = st.pad[2] = 0;
+        status[blockIdx.x] = st;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: Huffman MCU decode.  One lane per restart interval.
+// ------------------------------------------------------------------------------------------------
+
+// Bit source of one lane == a fresh JpegBitReader positioned at the start of its restart interval
+// (ref: JpegBitReader.cs).  Byte range [pos, end) ends at the FF of the closing marker, so no marker can
+// occur inside; FF00 -> FF, FFFF -> skip one fill byte (ref: :95-138).
+struct LaneBits {
+    const uint8_t *base;  // entropy segment base
+    uint32_t pos, end;    // raw byte offsets
+    uint32_t limit;       // bytes readable in the file (peek bound)
+    uint64_t buf;         // right-justified
+    int32_t bits;
+    uint64_t win;         // 8 raw bytes at [wpos, wpos+8)
+    uint32_t wpos;
+};
+
+__device__ __forceinline__ uint32_t lb_byte(LaneBits &r, uint32_t at) {
+    if (at - r.wpos >= 8u) {
+        r.wpos = at;
+        uint64_t w;
+        __builtin_memcpy(&w, r.base + at, 8);  // unaligned 8-byte global load (buffer is padded)
+        r.win = w;
+    }
+    return (uint32_t)(r.win >> ((at - r.wpos) * 8)) & 0xFFu;
+}
+
+__device__ __forceinline__ void lb_refill(LaneBits &r) {
+    while (r.bits <= 56 && r.pos < r.end) {
+        uint32_t b = lb_byte(r, r.pos);
+        if (b == 0xFF) {
+            if (r.pos + 1 >= r.limit) {  // the stream ended prematurely (ref: :112-116)
+                r.pos = r.end;
+                break;
+            }
+            const uint32_t nb = lb_byte(r, r.pos + 1);
+            if (nb == 0xFF) {  // padding byte, continue reading (ref: :117-121)
+                r.pos += 1;
+                continue;
+            }
+            if (nb != 0) {  // a marker: cannot precede `end` by construction of the index; stop feeding bits
+                r.end = r.pos;
+                break;
+            }
+            r.pos += 2;  // stuffed byte
+        } else {
+            r.pos += 1;
+        }
+        r.buf = (r.buf << 8) | b;
+        r.bits += 8;
+    }
+}
+
+// PeekBits(16): missing low bits are filled with ones (ref: JpegBitReader.cs:157-172)
+__device__ __forceinline__ uint32_t lb_peek16(const LaneBits &r) {
+    if (r.bits >= 16) return (uint32_t)(r.buf >> (r.bits - 16)) & 0xFFFFu;
+    const int miss = 16 - r.bits;
+    return (((uint32_t)r.buf << miss) & 0xFFFFu) | ((1u << miss) - 1u);
+}
+
+// LDS image of a staged DevHuffTable
+struct LdsHuff {
+    const uint16_t *lut;
+    const uint16_t *maxcode;
+    const uint8_t *valoffset;
+    const uint8_t *values;
+};
+
+__device__ __forceinline__ LdsHuff lds_huff(const uint8_t *tabs, uint32_t slot) {
+    const uint8_t *t = tabs + slot * sizeof(DevHuffTable);
+    LdsHuff h;
+    h.lut = reinterpret_cast<const uint16_t *>(t);
+    h.maxcode = reinterpret_cast<const uint16_t *>(t + offsetof(DevHuffTable, maxcode));
+    h.valoffset = t + offsetof(DevHuffTable, valoffset);
+    h.values = t + offsetof(DevHuffTable, values);
+    return h;
+}
+
+// DecodeHuffmanCode (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:81-88, JpegHuffmanDecodingTable.cs:73-113).
+// Returns the symbol, or -1 for "Invalid Huffman code encountered.".
+__device__ __forceinline__ int32_t decode_symbol(LaneBits &r, const LdsHuff &h) {
+    if (r.bits < 16) lb_refill(r);
+    const uint32_t code16 = lb_peek16(r);
+    uint32_t e = h.lut[code16 >> (16 - kHuffLutBits)];
+    uint32_t size = e >> 8, sym = e & 0xFF;
+    if (size == 0) {
+        size = kHuffLutBits + 1;
+        while (code16 > h.maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
+        if (size > 16) return -1;
+        sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
+    }
+    const int32_t adv = (int32_t)size < r.bits ? (int32_t)size : r.bits;  // Math.Min(entry.CodeSize, bitsRead)
+    r.bits -= adv;
+    return (int32_t)sym;
+}
+
+// ReceiveAndExtend (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:100-115).  ok=false when bits are missing.
+__device__ __forceinline__ int32_t receive_extend(LaneBits &r, int32_t n, bool &ok) {
+    if (r.bits < n) {
+        lb_refill(r);
+        if (r.bits < n) {
+            ok = false;
+            return 0;
+        }
+    }
+    r.bits -= n;
+    const int32_t v = (int32_t)((uint32_t)(r.buf >> r.bits) & ((1u << (n & 31)) - 1u));
+    return v - ((((v + v) >> (n & 31)) - 1) & ((1 << (n & 31)) - 1));
+}
+
+// LDS staging of one wave: 64 blocks x 128 B, 16-byte chunks XOR-swizzled so that both the per-lane
+// scattered 2-byte stores and the block-major 16-byte flush reads are (nearly) bank-conflict free.
+__device__ __forceinline__ uint32_t stage_addr(uint32_t blk, uint32_t coef_index) {
+    const uint32_t chunk = (coef_index >> 3) ^ ((blk >> 1) & 7);
+    return blk * 128 + chunk * 16 + (coef_index & 7) * 2;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_t *__restrict__ data,
+                                                                    const DevScan *__restrict__ scans,
+                                                                    const HuffWork *__restrict__ work,
+                                                                    const uint32_t *__restrict__ ends,
+                                                                    DevScanStatus *__restrict__ status,
+                                                                    const DevHuffTable *__restrict__ huff_pool,
+                                                                    int16_t *__restrict__ coefs, int n_slots) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *tabs = smem;                                                  // n_slots * sizeof(DevHuffTable)
+    uint8_t *stage_all = smem + (size_t)n_slots * sizeof(DevHuffTable);   // WAVES * 8192
+
+    const HuffWork wk = work[blockIdx.x];
+    const DevScan &s = scans[wk.scan];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63;
+    const uint32_t wave = tid >> 6;
+
+    // stage this scan's Huffman tables (ref: InitDecodeComponents resolves them per scan, JpegHuffmanScanDecoder.cs:63-64)
+    for (int slot = 0; slot < kMaxHuffSlots && slot < n_slots; slot++) {
+        const uint32_t pi = s.huff_pool[slot];
+        if (pi == 0xFFFF) continue;
+        const uint4 *src = reinterpret_cast<const uint4 *>(&huff_pool[pi]);
+        uint4 *dst = reinterpret_cast<uint4 *>(tabs + slot * sizeof(DevHuffTable));
+        for (uint32_t i = tid; i < sizeof(DevHuffTable) / 16; i += 64 * WAVES) dst[i] = src[i];
+    }
+    uint8_t *stage = stage_all + wave * 8192;
+    // zero the staging area of this wave
+    {
+        uint4 z = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(stage)[i * 64 + lane] = z;
+    }
+    __syncthreads();
+
+    const DevScanStatus st = status[wk.scan];
+    const uint32_t n_ends = st.n_ends;
+    const uint32_t n_intervals = s.n_intervals;
+    const uint32_t total_mcus = s.total_mcus;
+    const uint32_t dri_eff = s.dri ? s.dri : total_mcus;
+    const uint32_t bpm = s.blocks_per_mcu;
+    const uint32_t wave_first = wk.first_interval + wave * 64;
+    const uint32_t interval = wave_first + lane;
+    const bool active = interval < n_ends;
+    const uint32_t *ends_s = ends + s.ends_off;
+
+    LaneBits r;
+    r.base = data + s.data_off;
+    r.limit = s.data_len;
+    r.buf = 0;
+    r.bits = 0;
+    r.win = 0;
+    r.wpos = 0xF0000000u;
+    r.pos = 0;
+    r.end = 0;
+    uint32_t my_mcus = 0;
+    if (active) {
+        r.pos = interval == 0 ? 0u : ends_s[interval - 1] + 2u;
+        r.end = ends_s[interval];
+        my_mcus = (interval == n_intervals - 1) ? total_mcus - interval * dri_eff : dri_eff;
+    }
+    const bool closed_by_marker = active && r.end < s.data_len;
+    // the wave iterates to the largest MCU count among its lanes (only the image's last interval is shorter)
+    uint32_t wave_mcus = 0;
+    {
+        const uint32_t last_in_wave = (wave_first + 63 < n_ends ? wave_first + 63 : n_ends - 1);
+        if (wave_first < n_ends) {
+            wave_mcus = dri_eff;
+            if (wave_first == n_intervals - 1 && last_in_wave == n_intervals - 1) wave_mcus = total_mcus - wave_first * dri_eff;
+        }
+    }
+
+    int32_t pred0 = 0, pred1 = 0, pred2 = 0, pred3 = 0;  // DcPredictor per scan component
+    uint32_t err = 0;
+
+    for (uint32_t mcu = 0; mcu < wave_mcus; mcu++) {
+        for (uint32_t b = 0; b < bpm; b++) {
+            const uint32_t ci = s.blk_comp[b];  // wave-uniform
+            const LdsHuff hdc = lds_huff(tabs, s.comp[ci].dc_slot);
+            const LdsHuff hac = lds_huff(tabs, s.comp[ci].ac_slot);
+            if (active && err == 0 && mcu < my_mcus) {
+                // ReadBlockBaseline (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:179-222)
+                int32_t t = decode_symbol(r, hdc);
+                bool ok = true;
+                if (t < 0) {
+                    err = kDetailInvalidHuffmanCode;
+                } else {
+                    if (t != 0) t = receive_extend(r, t, ok);
+                    if (!ok) {
+                        err = (r.bits == 0 && closed_by_marker) ? kDetailMarkerInData : kDetailStreamEnded;
+                    } else {
+                        int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
+                        t += pred;
+                        if (ci == 0) pred0 = t;
+                        else if (ci == 1) pred1 = t;
+                        else if (ci == 2) pred2 = t;
+                        else pred3 = t;
+                        *reinterpret_cast<int16_t *>(stage + stage_addr(lane, 0)) = (int16_t)t;
+                        for (int32_t i = 1; i < 64;) {
+                            int32_t sy = decode_symbol(r, hac);
+                            if (sy < 0) {
+                                err = kDetailInvalidHuffmanCode;
+                                break;
+                            }
+                            const int32_t rr = sy >> 4;
+                            sy &= 15;
+                            if (sy != 0) {
+                                i += rr;
+                                const int32_t v = receive_extend(r, sy, ok);
+                                if (!ok) {
+                                    err = (r.bits == 0 && closed_by_marker) ? kDetailMarkerInData : kDetailStreamEnded;
+                                    break;
+                                }
+                                const int32_t idx = i < 63 ? i : 63;  // Math.Min(i++, 63)
+                                i++;
+                                *reinterpret_cast<int16_t *>(stage + stage_addr(lane, (uint32_t)idx)) = (int16_t)v;
+                            } else {
+                                if (rr == 0) break;
+                                i += 16;  // ANY r != 0, not only 15 (ref: :212-220)
+                            }
+                        }
+                    }
+                }
+            }
+            // flush 64 blocks of this wave to the coefficient buffer as whole 128-byte lines, re-zero the staging
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const uint32_t blk = it * 8 + (lane >> 3);
+                const uint32_t chunk = lane & 7;
+                uint4 *src = reinterpret_cast<uint4 *>(stage + blk * 128 + ((chunk ^ ((blk >> 1) & 7)) * 16));
+                const uint4 v = *src;
+                const uint4 z = {0, 0, 0, 0};
+                *src = z;
+                const uint32_t owner = wave_first + blk;
+                if (owner < n_ends) {
+                    const uint32_t owner_mcus = (owner == n_intervals - 1) ? total_mcus - owner * dri_eff : dri_eff;
+                    if (mcu < owner_mcus) {
+                        const uint64_t block_index = s.coef_off + ((uint64_t)owner * dri_eff + mcu) * bpm + b;
+                        *reinterpret_cast<uint4 *>(coefs + block_index * 64 + chunk * 8) = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+
+    // Restart check (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:139-163): runs after every completed
+    // interval except a final partial one.  AdvanceAlignByte + TryReadMarker: no whole byte may be left
+    // before the closing marker, and the marker must be RSTn (continue) or EOI (return early).
+    if (active) {
+        uint32_t code = kNoError;
+        if (err != 0) {
+            code = (interval << 8) | err;
+        } else {
+            const bool needs_check = s.dri != 0 && (interval < n_intervals - 1 || s.restart_check_at_end);
+            if (needs_check) {
+                lb_refill(r);
+                const bool leftover = (r.bits - (r.bits & 7)) != 0 || r.pos < r.end;
+                uint32_t closing = 0xD0;  // entries before the last indexed one are RSTn by construction
+                if (interval == n_ends - 1) closing = st.terminator;
+                if (leftover) {
+                    code = (interval << 8) | kDetailExpectRestart;
+                } else if (closing == 0xD9) {
+                    if (interval < n_intervals - 1) atomicMin(&status[wk.scan].decoded_mcus, (interval + 1) * dri_eff);
+                } else if ((closing & 0xF8) != 0xD0) {
+                    code = (interval << 8) | kDetailExpectRestart;
+                }
+            }
+        }
+        if (code != kNoError) atomicMin(&status[wk.scan].first_error, code);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: dequantise + IDCT + level shift + block output.  One lane per block.
+// ------------------------------------------------------------------------------------------------
+
+// ref: JpegZigZag.cs:27-38
+__device__ constexpr uint8_t kNat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                         41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                         30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// The 8-point butterfly of IDCT8x4_LeftPart/RightPart (ref: FastFloatingPointDCT.cs:79-127), one column.
+// Operation order and parenthesisation are normative.
+#define JPGPU_IDCT8(y0, y1, y2, y3, y4, y5, y6, y7)                     \
+    {                                                                   \
+        float mz0 = y1 + y7;                                            \
+        float mz2 = y3 + y7;                                            \
+        float mz1 = y3 + y5;                                            \
+        float mz3 = y1 + y5;                                            \
+        float mz4 = (mz0 + mz1) * 1.175875602f;                         \
+        mz2 = (mz2 * -1.961570560f) + mz4;                              \
+        mz3 = (mz3 * -0.390180644f) + mz4;                              \
+        mz0 = mz0 * -0.899976223f;                                      \
+        mz1 = mz1 * -2.562915447f;                                      \
+        const float mb3 = ((y7 * 0.298631336f) + mz0) + mz2;            \
+        const float mb2 = ((y5 * 2.053119869f) + mz1) + mz3;            \
+        const float mb1 = ((y3 * 3.072711026f) + mz1) + mz2;            \
+        const float mb0 = ((y1 * 1.501321110f) + mz0) + mz3;            \
+        mz4 = (y2 + y6) * 0.541196100f;                                 \
+        mz0 = y0 + y4;                                                  \
+        mz1 = y0 - y4;                                                  \
+        mz2 = mz4 + (y6 * -1.847759065f);                               \
+        mz3 = mz4 + (y2 * 0.765366865f);                                \
+        const float a0 = mz0 + mz3;                                     \
+        const float a3 = mz0 - mz3;                                     \
+        const float a1 = mz1 + mz2;                                     \
+        const float a2 = mz1 - mz2;                                     \
+        y0 = a0 + mb0;                                                  \
+        y7 = a0 - mb0;                                                  \
+        y1 = a1 + mb1;                                                  \
+        y6 = a1 - mb1;                                                  \
+        y2 = a2 + mb2;                                                  \
+        y5 = a2 - mb2;                                                  \
+        y3 = a3 + mb3;                                                  \
+        y4 = a3 - mb3;                                                  \
+    }
+
+// DequantizeBlockAndUnZigZag + TransformIDCT + ShiftDataLevel for one block held in registers.
+// cw: 32 dwords = 64 int16 coefficients (zig-zag), qw: 32 dwords = 64 uint16 quantisers (zig-zag).
+// out: 64 int32 samples, row-major, unclamped (the value the reference casts to short).
+__device__ __forceinline__ void block_idct(const uint32_t (&cw)[32], const uint32_t (&qw)[32], int32_t level_shift,
+                                           int32_t (&out)[64]) {
+    float f[64];
+#pragma unroll
+    for (int k = 0; k < 64; k++) {
+        const uint32_t w = cw[k >> 1], q = qw[k >> 1];
+        const int32_t c = (k & 1) ? ((int32_t)w >> 16) : (int32_t)(int16_t)(w & 0xFFFF);
+        const int32_t qq = (k & 1) ? (int32_t)(q >> 16) : (int32_t)(q & 0xFFFF);
+        f[kNat[k]] = (float)(qq * c);  // ushort * short -> int -> float (ref: ScanDecoder/JpegScanDecoder.cs:58-61)
+    }
+    // pass 1: 1-D IDCT along each ROW (the reference transposes, runs the column butterfly, transposes back)
+#pragma unroll
+    for (int r = 0; r < 8; r++) JPGPU_IDCT8(f[r * 8 + 0], f[r * 8 + 1], f[r * 8 + 2], f[r * 8 + 3], f[r * 8 + 4], f[r * 8 + 5], f[r * 8 + 6], f[r * 8 + 7]);
+    // pass 2: along each COLUMN
+#pragma unroll
+    for (int c = 0; c < 8; c++) JPGPU_IDCT8(f[c], f[8 + c], f[16 + c], f[24 + c], f[32 + c], f[40 + c], f[48 + c], f[56 + c]);
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        const float v = f[i] * 0.1250f;                      // MultiplyInplace(C_0_125)
+        const int32_t rounded = (int32_t)__builtin_rintf(v);  // MathF.Round: half to even (v_rndne_f32)
+        out[i] = (int32_t)(int16_t)(rounded + level_shift);   // (short)(Round + levelShift)
+    }
+}
+
+__device__ __forceinline__ uint32_t clamp_u8(int32_t v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+constexpr int kIdctThreads = 256;
+
+__global__ __launch_bounds__(kIdctThreads) void idct_output_kernel(const int16_t *__restrict__ coefs,
+                                                                    const DevScan *__restrict__ scans,
+                                                                    const IdctWork *__restrict__ work,
+                                                                    const DevScanStatus *__restrict__ status,
+                                                                    const DevQuantTable *__restrict__ quant_pool,
+                                                                    uint8_t *__restrict__ out, int format) {
+    __shared__ __attribute__((aligned(16))) uint8_t sh_in[kIdctThreads * 128];   // swizzled coefficient blocks
+    __shared__ __attribute__((aligned(16))) uint8_t sh_px[kIdctThreads * 64];    // planar u8 samples, [block][64]
+    __shared__ __attribute__((aligned(16))) uint16_t sh_q[kMaxScanComponents][64];
+
+    const IdctWork wk = work[blockIdx.x];
+    const DevScan &s = scans[wk.scan];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bpm = s.blocks_per_mcu;
+    const uint32_t mcus_per_wg = kIdctThreads / bpm;
+    uint32_t decoded = status ? status[wk.scan].decoded_mcus : s.total_mcus;
+    if (decoded > s.total_mcus) decoded = s.total_mcus;
+    if (wk.first_mcu >= decoded) return;
+    const uint32_t n_mcu = (decoded - wk.first_mcu) < mcus_per_wg ? (decoded - wk.first_mcu) : mcus_per_wg;
+    const uint32_t n_blk = n_mcu * bpm;
+
+    // quantisation tables of the scan components
+    if (tid < (uint32_t)s.scan_components * 32) {
+        const uint32_t c = tid >> 5, i = tid & 31;
+        reinterpret_cast<uint32_t *>(sh_q[c])[i] =
+            reinterpret_cast<const uint32_t *>(quant_pool[s.quant_pool[s.comp[c].quant_slot]].q)[i];
+    }
+    // phase A: coalesced 16-byte loads of n_blk consecutive blocks
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(coefs + (s.coef_off + (uint64_t)wk.first_mcu * bpm) * 64);
+        for (uint32_t c = tid; c < n_blk * 8; c += kIdctThreads) {
+            const uint32_t blk = c >> 3, piece = c & 7;
+            *reinterpret_cast<uint4 *>(sh_in + blk * 128 + ((piece ^ ((blk >> 1) & 7)) * 16)) = src[c];
+        }
+    }
+    __syncthreads();
+
+    const uint32_t mcu_local = tid / bpm;
+    const uint32_t b = tid - mcu_local * bpm;
+    const uint32_t mcu = wk.first_mcu + mcu_local;
+    const bool have_block = tid < n_blk;
+    const uint32_t ci = s.blk_comp[b < kMaxBlocksPerMcu ? b : 0];
+    const DevScanComponent comp = s.comp[ci];
+    const uint32_t mcu_x = mcu % s.mcus_per_line, mcu_y = mcu / s.mcus_per_line;
+
+    int32_t px[64];
+    if (have_block) {
+        uint32_t cw[32], qw[32];
+#pragma unroll
+        for (int piece = 0; piece < 8; piece++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(sh_in + tid * 128 + ((piece ^ ((tid >> 1) & 7)) * 16));
+            cw[piece * 4 + 0] = v.x;
+            cw[piece * 4 + 1] = v.y;
+            cw[piece * 4 + 2] = v.z;
+            cw[piece * 4 + 3] = v.w;
+            const uint4 q = reinterpret_cast<const uint4 *>(sh_q[ci])[piece];
+            qw[piece * 4 + 0] = q.x;
+            qw[piece * 4 + 1] = q.y;
+            qw[piece * 4 + 2] = q.z;
+            qw[piece * 4 + 3] = q.w;
+        }
+        block_idct(cw, qw, (int32_t)s.level_shift, px);
+    }
+
+    if (format == kFmtPlanarI16) {
+        // "O1": unclamped int16 at component-native resolution, planes padded to whole MCUs
+        if (have_block) {
+            int16_t *plane = reinterpret_cast<int16_t *>(out + s.out_off + s.plane_off[ci]);
+            const uint32_t pitch = s.plane_pitch[ci];
+            const uint32_t x0 = (mcu_x * comp.h + s.blk_x[b]) * 8, y0 = (mcu_y * comp.v + s.blk_y[b]) * 8;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                uint4 v;
+                v.x = (uint32_t)(px[r * 8 + 0] & 0xFFFF) | ((uint32_t)px[r * 8 + 1] << 16);
+                v.y = (uint32_t)(px[r * 8 + 2] & 0xFFFF) | ((uint32_t)px[r * 8 + 3] << 16);
+                v.z = (uint32_t)(px[r * 8 + 4] & 0xFFFF) | ((uint32_t)px[r * 8 + 5] << 16);
+                v.w = (uint32_t)(px[r * 8 + 6] & 0xFFFF) | ((uint32_t)px[r * 8 + 7] << 16);
+                *reinterpret_cast<uint4 *>(plane + (size_t)(y0 + r) * pitch + x0) = v;
+            }
+        }
+        return;
+    }
+    if (format == kFmtPlanarU8) {
+        if (have_block) {
+            uint8_t *plane = out + s.out_off + s.plane_off[ci];
+            const uint32_t pitch = s.plane_pitch[ci];
+            const uint32_t x0 = (mcu_x * comp.h + s.blk_x[b]) * 8, y0 = (mcu_y * comp.v + s.blk_y[b]) * 8;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                uint2 v;
+                v.x = clamp_u8(px[r * 8 + 0]) | (clamp_u8(px[r * 8 + 1]) << 8) | (clamp_u8(px[r * 8 + 2]) << 16) | (clamp_u8(px[r * 8 + 3]) << 24);
+                v.y = clamp_u8(px[r * 8 + 4]) | (clamp_u8(px[r * 8 + 5]) << 8) | (clamp_u8(px[r * 8 + 6]) << 16) | (clamp_u8(px[r * 8 + 7]) << 24);
+                *reinterpret_cast<uint2 *>(plane + (size_t)(y0 + r) * pitch + x0) = v;
+            }
+        }
+        return;
+    }
+
+    // ---- interleaved u8 ("O2", JpegBufferOutputWriter8Bit semantics) ----
+    const uint32_t W = s.width, H = s.height, C = s.frame_components;
+    // fast path: 3 components in frame order, luma at full sampling, chroma 1x1, row pitch 4-byte aligned
+    const bool fast = (C == 3 && s.scan_components == 3 && s.comp[0].component_index == 0 && s.comp[1].component_index == 1 &&
+                       s.comp[2].component_index == 2 && s.comp[0].hs == 1 && s.comp[0].vs == 1 && s.comp[1].h == 1 &&
+                       s.comp[1].v == 1 && s.comp[2].h == 1 && s.comp[2].v == 1 && s.max_h <= 2 && s.max_v <= 2 &&
+                       (W & 3) == 0 && (s.out_off & 3) == 0 && W % (8u * s.max_h) == 0);
+    if (!fast) {
+        // generic path: every sample stored bytewise with WriteBlockSlow's replication
+        // (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:238-268) and the sink's clipping (x<W, y<H)
+        if (have_block) {
+            uint8_t *img = out + s.out_off;
+            const uint32_t hs = comp.hs, vs = comp.vs;
+            const uint32_t x0 = (mcu_x * s.max_h + s.blk_x[b]) * 8, y0 = (mcu_y * s.max_v + s.blk_y[b]) * 8;
+            const uint32_t hshift = 31 - __builtin_clz(hs | 1), vshift = 31 - __builtin_clz(vs | 1);
+            for (uint32_t v = 0; v < vs; v++)
+                for (uint32_t h = 0; h < hs; h++)
+                    for (uint32_t i = 0; i < 8; i++) {
+                        const uint32_t y = y0 + 8 * v + i;
+                        if (y >= H) continue;
+                        for (uint32_t j = 0; j < 8; j++) {
+                            const uint32_t x = x0 + 8 * h + j;
+                            if (x >= W) continue;
+                            const uint32_t si = (((8 * v + i) >> vshift) * 8) + ((8 * h + j) >> hshift);
+                            int32_t val = 0;
+#pragma unroll
+                            for (int k = 0; k < 64; k++) val = (si == (uint32_t)k) ? px[k] : val;
+                            img[((size_t)y * W + x) * C + comp.component_index] = (uint8_t)clamp_u8(val);
+                        }
+                    }
+        }
+        return;
+    }
+
+    // fast path: clamp to u8 into an LDS tile [block][8 rows][8 B], then assemble 4-pixel groups (12 B) per lane
+    if (have_block) {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(sh_px + tid * 64);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            dst[r * 2 + 0] = clamp_u8(px[r * 8 + 0]) | (clamp_u8(px[r * 8 + 1]) << 8) | (clamp_u8(px[r * 8 + 2]) << 16) | (clamp_u8(px[r * 8 + 3]) << 24);
+            dst[r * 2 + 1] = clamp_u8(px[r * 8 + 4]) | (clamp_u8(px[r * 8 + 5]) << 8) | (clamp_u8(px[r * 8 + 6]) << 16) | (clamp_u8(px[r * 8 + 7]) << 24);
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t max_h = s.max_h, max_v = s.max_v;
+        const uint32_t hshift = max_h >> 1, vshift = max_v >> 1;  // max in {1,2}
+        const uint32_t groups_per_row = 2 * max_h;                 // 4-pixel groups per MCU row
+        const uint32_t rows = 8 * max_v;
+        const uint32_t b_cb = max_h * max_v, b_cr = b_cb + 1;
+        const uint32_t total_groups = rows * n_mcu * groups_per_row;
+        uint8_t *img = out + s.out_off;
+        for (uint32_t g = tid; g < total_groups; g += kIdctThreads) {
+            const uint32_t c4 = g % groups_per_row;
+            const uint32_t t2 = g / groups_per_row;
+            const uint32_t m = t2 % n_mcu;
+            const uint32_t row = t2 / n_mcu;
+            const uint32_t gm = wk.first_mcu + m;
+            const uint32_t gx = gm % s.mcus_per_line, gy = gm / s.mcus_per_line;
+            const uint32_t y = gy * rows + row;
+            if (y >= H) continue;
+            const uint32_t x = gx * 8 * max_h + c4 * 4;
+            const uint32_t xl = c4 * 4;  // x inside the MCU
+            const uint32_t by = row >> 3, bx = xl >> 3;
+            const uint32_t yw = *reinterpret_cast<const uint32_t *>(sh_px + (m * bpm + by * max_h + bx) * 64 + (row & 7) * 8 + (xl & 7));
+            const uint32_t cx = xl >> hshift, cy = row >> vshift;
+            uint32_t cb4, cr4;  // 4 chroma samples for the 4 pixels
+            if (hshift) {
+                const uint32_t cb2 = *reinterpret_cast<const uint16_t *>(sh_px + (m * bpm + b_cb) * 64 + cy * 8 + cx);
+                const uint32_t cr2 = *reinterpret_cast<const uint16_t *>(sh_px + (m * bpm + b_cr) * 64 + cy * 8 + cx);
+                cb4 = (cb2 & 0xFF) * 0x0101u | ((cb2 >> 8) * 0x01010000u);
+                cr4 = (cr2 & 0xFF) * 0x0101u | ((cr2 >> 8) * 0x01010000u);
+            } else {
+                cb4 = *reinterpret_cast<const uint32_t *>(sh_px + (m * bpm + b_cb) * 64 + cy * 8 + cx);
+                cr4 = *reinterpret_cast<const uint32_t *>(sh_px + (m * bpm + b_cr) * 64 + cy * 8 + cx);
+            }
+            const uint32_t y0_ = yw & 0xFF, y1_ = (yw >> 8) & 0xFF, y2_ = (yw >> 16) & 0xFF, y3_ = yw >> 24;
+            const uint32_t b0 = cb4 & 0xFF, b1 = (cb4 >> 8) & 0xFF, b2 = (cb4 >> 16) & 0xFF, b3 = cb4 >> 24;
+            const uint32_t r0 = cr4 & 0xFF, r1 = (cr4 >> 8) & 0xFF, r2 = (cr4 >> 16) & 0xFF, r3 = cr4 >> 24;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(img + ((size_t)y * W + x) * 3);
+            dst[0] = y0_ | (b0 << 8) | (r0 << 16) | (y1_ << 24);
+            dst[1] = b1 | (r1 << 8) | (y2_ << 16) | (b2 << 24);
+            dst[2] = r2 | (y3_ << 8) | (b3 << 16) | (r3 << 24);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+
+hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const DevScan *scans, int n_scans, uint32_t *ends,
+                               DevScanStatus *status) {
+    if (n_scans <= 0) return hipSuccess;
+    hipLaunchKernelGGL(marker_index_kernel, dim3(n_scans), dim3(kScanThreads), 0, stream, data, scans, ends, status);
+    return hipGetLastError();
+}
+
+size_t huffman_lds_bytes(int n_slots) { return (size_t)n_slots * sizeof(DevHuffTable) + (size_t)kHuffWaves * 8192; }
+
+hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
+                          const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
+                          int n_slots) {
+    if (n_work <= 0) return hipSuccess;
+    const size_t lds = huffman_lds_bytes(n_slots);
+    hipLaunchKernelGGL(huffman_decode_kernel<kHuffWaves>, dim3(n_work), dim3(64 * kHuffWaves), lds, stream, data, scans, work,
+                       ends, status, huff_pool, coefs, n_slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *scans, const IdctWork *work, int n_work,
+                       const DevScanStatus *status, const DevQuantTable *quant_pool, uint8_t *out, int format) {
+    if (n_work <= 0) return hipSuccess;
+    hipLaunchKernelGGL(idct_output_kernel, dim3(n_work), dim3(kIdctThreads), 0, stream, coefs, scans, work, status, quant_pool,
+                       out, format);
+    return hipGetLastError();
+}
+
+}  // namespace jpgpu

@@ -1,0 +1,233 @@
+"""Host-side mirror of the reference's public decoder surface, over the C ABI (include/jpgpu.h level 3).
+
+Names, argument meaning and error behaviour follow the reference so that tests read like its own:
+
+    decoder = JpegDecoder()
+    decoder.SetInput(jpeg_bytes)
+    decoder.Identify()
+    writer = JpegExtendingOutputWriter(decoder.Width, decoder.Height, 4, decoder.Precision, buffer)
+    decoder.SetOutputWriter(writer)
+    decoder.Decode()
+
+ref: src/JpegLibrary/JpegDecoder.cs, src/JpegLibrary/JpegBlockOutputWriter.cs,
+     apps/JpegDecode/JpegBufferOutputWriter8Bit.cs, tests/JpegLibrary.Tests/Utils/JpegExtendingOutputWriter.cs
+All block arithmetic (Huffman decode, dequantise, IDCT, level shift) runs in the HIP kernels; this module only
+marshals calls.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .context import Context, default_context
+from .errors import ArgumentException, InvalidOperationException, raise_for_status
+
+_lib = _capi.lib
+
+
+class JpegBlockOutputWriter:
+    """ref: JpegBlockOutputWriter.cs:17 -- abstract sink: one 8x8 int16 block at (componentIndex, x, y)."""
+
+    def WriteBlock(self, blockRef, componentIndex, x, y):  # noqa: N802,N803 (reference names)
+        raise NotImplementedError
+
+
+class JpegBufferOutputWriter8Bit(JpegBlockOutputWriter):
+    """ref: apps/JpegDecode/JpegBufferOutputWriter8Bit.cs -- interleaved u8 buffer, signed clamp to [0,255].
+
+    When its geometry equals the frame's, JpegDecoder produces this layout directly on the GPU
+    (JPGPU_FMT_INTERLEAVED_U8) instead of replaying WriteBlock calls.
+    """
+
+    def __init__(self, width, height, componentCount, output):  # noqa: N803
+        output = np.asarray(output)
+        if output.dtype != np.uint8 or not output.flags["C_CONTIGUOUS"]:
+            raise ArgumentException("output must be a contiguous uint8 array")
+        if output.size < width * height * componentCount:
+            raise ArgumentException("Destination buffer is too small.")
+        self.width, self.height, self.componentCount, self.output = width, height, componentCount, output
+
+    def WriteBlock(self, blockRef, componentIndex, x, y):  # noqa: N802,N803
+        w, h, cc = self.width, self.height, self.componentCount
+        if x > w or y > h:
+            return
+        ww, wh = min(w - x, 8), min(h - y, 8)
+        if ww <= 0 or wh <= 0:
+            return
+        out = self.output.reshape(-1)[:w * h * cc].reshape(h, w, cc)
+        blk = np.asarray(blockRef, dtype=np.int16).reshape(8, 8)[:wh, :ww]
+        out[y:y + wh, x:x + ww, componentIndex] = np.clip(blk, 0, 255).astype(np.uint8)
+
+
+class JpegExtendingOutputWriter(JpegBlockOutputWriter):
+    """ref: tests/JpegLibrary.Tests/Utils/JpegExtendingOutputWriter.cs -- the xunit tests' u16 sink:
+    (ushort) clamp to 2^P-1 (negative samples become max), then bit-replication to 16 bits."""
+
+    def __init__(self, width, height, componentCount, precision, output):  # noqa: N803
+        output = np.asarray(output)
+        if output.dtype != np.uint16 or not output.flags["C_CONTIGUOUS"]:
+            raise ArgumentException("output must be a contiguous uint16 array")
+        if output.size < width * height * componentCount:
+            raise ArgumentException("Destination buffer is too small.")
+        self.width, self.height, self.componentCount, self.precision, self.output = width, height, componentCount, precision, output
+
+    @staticmethod
+    def _fast_expand(bits, bit_count):
+        remaining = 16 - bit_count
+        return (bits << remaining) | (bits & ((1 << remaining) - 1))
+
+    def _expand(self, v):
+        p = self.precision
+        if p >= 8:
+            return self._fast_expand(v, p)
+        bits, cur = v, p
+        while cur < 16:
+            bits = (bits << p) | bits
+            cur += p
+        if cur > 16:
+            bits = bits >> p
+            cur -= p
+            bits = self._fast_expand(bits, cur)
+        return bits
+
+    def WriteBlock(self, blockRef, componentIndex, x, y):  # noqa: N802,N803
+        w, h, cc = self.width, self.height, self.componentCount
+        if x > w or y > h:
+            return
+        ww, wh = min(w - x, 8), min(h - y, 8)
+        if ww <= 0 or wh <= 0:
+            return
+        mx = (1 << self.precision) - 1
+        out = self.output.reshape(-1)[:w * h * cc].reshape(h, w, cc)
+        blk = np.asarray(blockRef, dtype=np.int16).reshape(8, 8)[:wh, :ww]
+        v = np.minimum(blk.astype(np.uint16).astype(np.uint32), mx)
+        out[y:y + wh, x:x + ww, componentIndex] = (self._expand(v) & 0xFFFF).astype(np.uint16)
+
+
+class JpegDecoder:
+    """ref: src/JpegLibrary/JpegDecoder.cs (public surface).  Scans are decoded on the MI355X."""
+
+    def __init__(self, ctx: Context = None, host_only=False):
+        """host_only=True builds a decoder without a device context: SetInput / Identify / metadata / table calls
+        work anywhere, Decode() raises NoDeviceError (scans are decoded on the GPU only)."""
+        self._ctx = None if host_only else (ctx or default_context())
+        self._h = C.c_void_p()
+        raise_for_status(_lib.jpgpu_decoder_create(self._ctx._h if self._ctx else None, C.byref(self._h)), b"jpgpu_decoder_create failed")
+        self._input = None
+        self._writer = None
+        self._cb = None
+
+    # -- helpers
+    def _check(self, rc):
+        raise_for_status(rc, _lib.jpgpu_decoder_last_error(self._h))
+
+    def _need_header(self, v):
+        if v < 0:
+            raise InvalidOperationException("Call Identify() before this operation.")
+        return v
+
+    # -- input / identify
+    def SetInput(self, input):  # noqa: N802,A002
+        a = np.frombuffer(input, dtype=np.uint8) if not isinstance(input, np.ndarray) else np.ascontiguousarray(input, dtype=np.uint8)
+        self._input = a  # the decoder never copies the caller's bytes; keep them alive
+        self._check(_lib.jpgpu_decoder_set_input(self._h, a.ctypes.data if a.size else None, a.size))
+
+    def Identify(self, loadQuantizationTables=False):  # noqa: N802,N803
+        n = C.c_int()
+        self._check(_lib.jpgpu_decoder_identify(self._h, int(bool(loadQuantizationTables)), C.byref(n)))
+        return n.value
+
+    def TryEstimateQuanlity(self):  # noqa: N802  (sic: the reference's spelling)
+        q = C.c_float()
+        ok = _lib.jpgpu_decoder_try_estimate_quality(self._h, C.byref(q))
+        return bool(ok), q.value
+
+    Width = property(lambda self: self._need_header(_lib.jpgpu_decoder_width(self._h)))
+    Height = property(lambda self: self._need_header(_lib.jpgpu_decoder_height(self._h)))
+    Precision = property(lambda self: self._need_header(_lib.jpgpu_decoder_precision(self._h)))
+    NumberOfComponents = property(lambda self: self._need_header(_lib.jpgpu_decoder_number_of_components(self._h)))
+    StartOfFrame = property(lambda self: _lib.jpgpu_decoder_start_of_frame(self._h))
+
+    def GetMaximumHorizontalSampling(self):  # noqa: N802
+        v = _lib.jpgpu_decoder_get_maximum_horizontal_sampling(self._h)
+        if v < 0:
+            self._check(_capi.ERR_INVALID_OPERATION)
+        return v
+
+    def GetMaximumVerticalSampling(self):  # noqa: N802
+        v = _lib.jpgpu_decoder_get_maximum_vertical_sampling(self._h)
+        if v < 0:
+            self._check(_capi.ERR_INVALID_OPERATION)
+        return v
+
+    def GetHorizontalSampling(self, componentIndex):  # noqa: N802,N803
+        v = _lib.jpgpu_decoder_get_horizontal_sampling(self._h, componentIndex)
+        if v < 0:
+            self._check(_capi.ERR_ARGUMENT)
+        return v
+
+    def GetVerticalSampling(self, componentIndex):  # noqa: N802,N803
+        v = _lib.jpgpu_decoder_get_vertical_sampling(self._h, componentIndex)
+        if v < 0:
+            self._check(_capi.ERR_ARGUMENT)
+        return v
+
+    def GetRestartInterval(self):  # noqa: N802
+        return _lib.jpgpu_decoder_get_restart_interval(self._h)
+
+    def SetRestartInterval(self, restartInterval):  # noqa: N802,N803
+        self._check(_lib.jpgpu_decoder_set_restart_interval(self._h, restartInterval))
+
+    def LoadTables(self, content):  # noqa: N802
+        a = np.frombuffer(content, dtype=np.uint8)
+        self._check(_lib.jpgpu_decoder_load_tables(self._h, a.ctypes.data, a.size))
+
+    # -- output / decode
+    def SetOutputWriter(self, outputWriter):  # noqa: N802,N803
+        if outputWriter is None:
+            raise ArgumentException("Value cannot be null. (Parameter 'outputWriter')")
+        self._writer = outputWriter
+        if type(outputWriter) is JpegBufferOutputWriter8Bit:
+            w = outputWriter
+            self._check(_lib.jpgpu_decoder_set_output_buffer8(self._h, w.width, w.height, w.componentCount, w.output.ctypes.data, w.output.size))
+            self._cb = None
+            return
+
+        def _cb(_user, blk, ci, x, y):
+            outputWriter.WriteBlock(np.ctypeslib.as_array(blk, shape=(64,)), ci, x, y)
+
+        self._cb = _capi.WRITE_BLOCK_FN(_cb)
+        self._check(_lib.jpgpu_decoder_set_output_writer(self._h, C.cast(self._cb, C.c_void_p), None))
+
+    def Decode(self):  # noqa: N802
+        self._check(_lib.jpgpu_decoder_decode(self._h))
+
+    # -- resets
+    def Reset(self):  # noqa: N802
+        _lib.jpgpu_decoder_reset(self._h)
+        self._input = self._writer = self._cb = None
+
+    def ResetInput(self):  # noqa: N802
+        _lib.jpgpu_decoder_reset_input(self._h)
+        self._input = None
+
+    def ResetHeader(self):  # noqa: N802
+        _lib.jpgpu_decoder_reset_header(self._h)
+
+    def ResetTables(self):  # noqa: N802
+        _lib.jpgpu_decoder_reset_tables(self._h)
+
+    def ResetOutputWriter(self):  # noqa: N802
+        _lib.jpgpu_decoder_reset_output_writer(self._h)
+        self._writer = self._cb = None
+
+    def close(self):
+        if self._h:
+            _lib.jpgpu_decoder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,375 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the oracle and the reference's golden vectors.
+
+Bit-exact everywhere: coefficients (Huffman stage), samples (IDCT stage), and every output layout.
+Mirrors the reference's own decode tests (tests/JpegLibrary.Tests/Decoder/HuffmanSequentialDecodeTests.cs:23-43).
+"""
+import numpy as np
+import pytest
+
+import jpeglibrary_amd as jl
+from golden_util import load_reference_buffer, read_jpeg
+from oracle import pyoracle as po
+from tools import jpegsynth
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------------ reference goldens
+
+@pytest.mark.parametrize("name", ["cramps.jpg", "lake.jpg", "testorig12.jpg"])
+def test_decode_matches_reference_golden(name):
+    jpeg_bytes = read_jpeg(name)
+    decoder = jl.JpegDecoder()
+    decoder.SetInput(jpeg_bytes)
+    decoder.Identify()
+    buffer = np.zeros(decoder.Width * decoder.Height * 4, dtype=np.uint16)
+    output_writer = jl.JpegExtendingOutputWriter(decoder.Width, decoder.Height, 4, decoder.Precision, buffer)
+    decoder.SetOutputWriter(output_writer)
+    decoder.Decode()
+    reference = load_reference_buffer(name, decoder.Width, decoder.Height, decoder.NumberOfComponents)
+    assert np.array_equal(reference.reshape(-1), buffer)
+
+
+@pytest.mark.parametrize("name", ["cramps.jpg", "lake.jpg", "HETissueSlide.jpg"])
+def test_buffer8_writer_matches_oracle(name):
+    """The app writer (JpegBufferOutputWriter8Bit) fast path: interleaved u8 produced on the GPU."""
+    data = read_jpeg(name)
+    decoder = jl.JpegDecoder()
+    decoder.SetInput(data)
+    decoder.Identify()
+    out = np.zeros(decoder.Width * decoder.Height * decoder.NumberOfComponents, dtype=np.uint8)
+    decoder.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(decoder.Width, decoder.Height, decoder.NumberOfComponents, out))
+    decoder.Decode()
+    ref, _ = po.decode_8bit(data)
+    assert np.array_equal(out.reshape(ref.shape), ref)
+
+
+def test_buffer8_writer_with_foreign_geometry_replays_blocks():
+    """componentCount = 4 for a 3-component image (as the reference's tests do): falls back to WriteBlock replay."""
+    data = read_jpeg("lake.jpg")
+    decoder = jl.JpegDecoder()
+    decoder.SetInput(data)
+    decoder.Identify()
+    out = np.zeros(decoder.Width * decoder.Height * 4, dtype=np.uint8)
+    decoder.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(decoder.Width, decoder.Height, 4, out))
+    decoder.Decode()
+    ref, _ = po.decode_8bit(data, component_count=4)
+    assert np.array_equal(out.reshape(ref.shape), ref)
+
+
+# ------------------------------------------------------------------------------------------------ synthetic matrix
+
+CASES = [
+    # (w, h, subsampling, quality, dri)
+    (512, 512, "444", 75, 0),      # BASELINE config 1
+    (640, 368, "420", 75, 4),      # config-2 shape, small
+    (640, 368, "420", 75, 0),      # config-3 shape, small
+    (480, 272, "420", 90, 4),      # config-4 shape (Q90), height not a multiple of 16
+    (331, 177, "422", 80, 3),      # odd size, 4:2:2
+    (100, 75, "gray", 60, 1),      # grayscale, DRI=1
+    (17, 9, "420", 75, 1),         # tiny, partial MCUs in both directions
+    (341, 486, "420", 50, 22),     # DRI = one MCU row
+    (64, 64, "444", 100, 5),       # Q100: all-ones tables, long codes
+    (1920, 1080, "420", 90, 4),    # one full config-4 image
+]
+
+
+def _decode_gpu(files, fmt):
+    b = jl.Batch().upload(files, fmt).decode().sync()
+    return b
+
+
+@pytest.mark.parametrize("w,h,ss,q,dri", CASES)
+def test_interleaved_u8_matches_oracle(w, h, ss, q, dri):
+    data = jpegsynth.encode(w, h, ss, q, dri, seed=w * 31 + h)
+    b = _decode_gpu([data], jl.FMT_INTERLEAVED_U8)
+    res = b.result(0)
+    assert (res.status, res.detail) == (0, 0)
+    ref, info = po.decode_8bit(data)
+    out = b.output(0)
+    assert out.shape == ref.shape
+    assert np.array_equal(out, ref), f"{(out != ref).sum()} mismatching samples"
+    assert res.terminator == 0xD9 and res.decoded_mcus == b.image_info(0).mcus_per_line * b.image_info(0).mcus_per_column
+
+
+@pytest.mark.parametrize("w,h,ss,q,dri", CASES[:8])
+def test_coefficients_match_oracle(w, h, ss, q, dri):
+    """Huffman stage alone: the coefficient buffer equals the reference's ReadBlockBaseline output, block for block."""
+    data = jpegsynth.encode(w, h, ss, q, dri, seed=7 + w)
+    b = jl.Batch().upload([data], jl.FMT_PLANAR_I16).run_entropy().sync()
+    assert b.result(0).status == 0
+    coefs = b.coefficients(0)
+    ref, _ = po.decode_coefficients(data)
+    assert coefs.shape == ref.shape
+    assert np.array_equal(coefs, ref)
+
+
+@pytest.mark.parametrize("w,h,ss,q,dri", CASES[:8])
+def test_planar_i16_matches_writeblock_arguments(w, h, ss, q, dri):
+    """O1: unclamped int16 planes == the blocks WriteBlock receives (before chroma expansion)."""
+    data = jpegsynth.encode(w, h, ss, q, dri, seed=11 + h)
+    b = _decode_gpu([data], jl.FMT_PLANAR_I16)
+    assert b.result(0).status == 0
+    planes = b.output(0)
+    info = b.image_info(0)
+    # oracle: collect the un-expanded blocks: dequant/IDCT of its own coefficient tap
+    coefs, comps = po.decode_coefficients(data)
+    oinfo, _ = po.identify(data)
+    # rebuild planes from the oracle's WriteBlock calls: for components with hs=vs=1 the calls are the blocks themselves;
+    # for sub-sampled ones the (0,0) sample of each 2x2 (or 2x1) replica group is the native sample.
+    calls, _ = po.decode_blocks(data)
+    max_h = max(oinfo.comp[i].h for i in range(oinfo.ncomp))
+    max_v = max(oinfo.comp[i].v for i in range(oinfo.ncomp))
+    ref_planes = [np.zeros((p.shape[0], p.shape[1]), np.int16) for p in planes]
+    full = [np.zeros((info.mcus_per_column * max_v * 8, info.mcus_per_line * max_h * 8), np.int16) for _ in planes]
+    for ci, x, y, blk in calls:
+        full[ci][y:y + 8, x:x + 8] = blk.reshape(8, 8)
+    for ci in range(oinfo.ncomp):
+        hs, vs = max_h // oinfo.comp[ci].h, max_v // oinfo.comp[ci].v
+        ref_planes[ci] = full[ci][::vs, ::hs]
+    for ci in range(oinfo.ncomp):
+        assert np.array_equal(planes[ci], ref_planes[ci]), ci
+
+
+def test_planar_u8_is_clamped_planar_i16():
+    data = jpegsynth.encode(352, 240, "420", 75, 4, seed=99)
+    p8 = _decode_gpu([data], jl.FMT_PLANAR_U8).output(0)
+    p16 = _decode_gpu([data], jl.FMT_PLANAR_I16).output(0)
+    for a, b in zip(p8, p16):
+        assert np.array_equal(a, np.clip(b, 0, 255).astype(np.uint8))
+
+
+def test_idct_stage_on_random_coefficients():
+    """IDCT kernel alone on adversarial coefficient blocks (full int16 range products, dense blocks)."""
+    data = jpegsynth.encode(256, 256, "444", 75, 0, seed=5)
+    b = jl.Batch().upload([data], jl.FMT_PLANAR_I16)
+    info = b.image_info(0)
+    rng = np.random.default_rng(123)
+    n = info.total_blocks
+    coefs = np.zeros((n, 64), np.int16)
+    coefs[: n // 2] = rng.integers(-1024, 1024, size=(n // 2, 64))
+    coefs[n // 2:, :10] = rng.integers(-2048, 2048, size=(n - n // 2, 10))
+    coefs[0] = 32767
+    coefs[1] = -32768
+    b.set_coefficients(0, coefs)
+    b.run_idct().sync()
+    planes = b.output(0)
+    # oracle per block; quant tables from a reference-side parse of the same file
+    from jpeglibrary_amd import _capi  # noqa: F401
+    qts = _quant_tables(data)
+    bpm = info.blocks_per_mcu
+    for bi in rng.choice(n, size=600, replace=False).tolist() + [0, 1]:
+        mcu, k = divmod(bi, bpm)
+        ci = k  # 4:4:4: block k of the MCU is component k
+        q = qts[0] if ci == 0 else qts[1]
+        ref = po.block_dequant_idct_shift(coefs[bi], q, 128).reshape(8, 8)
+        my, mx = divmod(mcu, info.mcus_per_line)
+        got = planes[ci][my * 8:my * 8 + 8, mx * 8:mx * 8 + 8]
+        assert np.array_equal(got, ref), bi
+
+
+def _quant_tables(data):
+    """DQT payloads (zig-zag order) by table id, read straight from the file."""
+    i, out = 2, {}
+    while i < len(data):
+        m, ln = data[i + 1], (data[i + 2] << 8) | data[i + 3]
+        if m == 0xDB:
+            p = i + 4
+            while p < i + 2 + ln:
+                pq, tq = data[p] >> 4, data[p] & 15
+                if pq == 0:
+                    out[tq] = np.frombuffer(data[p + 1:p + 65], np.uint8).astype(np.uint16)
+                    p += 65
+                else:
+                    out[tq] = np.frombuffer(data[p + 1:p + 129], ">u2").astype(np.uint16)
+                    p += 129
+        if m == 0xDA:
+            break
+        i += 2 + ln
+    return out
+
+
+def test_batch_of_mixed_images():
+    files = [jpegsynth.encode(w, h, ss, q, dri, seed=i) for i, (w, h, ss, q, dri) in enumerate(CASES[:8])]
+    files += [read_jpeg("cramps.jpg"), read_jpeg("lake.jpg")]
+    outs, results = jl.decode_batch(files, jl.FMT_INTERLEAVED_U8)
+    for f, out, res in zip(files, outs, results):
+        assert res.status == 0
+        ref, _ = po.decode_8bit(f)
+        assert np.array_equal(out, ref)
+
+
+def test_pillow_encoded_files_with_restart_markers():
+    """Files from an independent encoder (libjpeg-turbo via Pillow): optimised + standard tables, DRI in blocks/rows."""
+    import io
+
+    from PIL import Image
+
+    rng = np.random.default_rng(1)
+    img = Image.fromarray(rng.integers(0, 255, size=(200, 300, 3), dtype=np.uint8).astype(np.uint8)).resize((301, 203))
+    for kwargs in (dict(quality=75, subsampling=2, restart_marker_blocks=4), dict(quality=85, subsampling=1, restart_marker_rows=1),
+                   dict(quality=60, subsampling=0, optimize=True), dict(quality=90, subsampling=2, optimize=True, restart_marker_blocks=1)):
+        buf = io.BytesIO()
+        img.save(buf, "JPEG", **kwargs)
+        data = buf.getvalue()
+        outs, results = jl.decode_batch([data], jl.FMT_INTERLEAVED_U8)
+        assert results[0].status == 0, kwargs
+        ref, _ = po.decode_8bit(data)
+        assert np.array_equal(outs[0], ref), kwargs
+
+
+# ------------------------------------------------------------------------------------------------ malformed streams
+
+def _status_of_oracle(data):
+    try:
+        po.decode_8bit(data)
+        return "OK"
+    except po.OracleError as e:
+        return e.kind
+
+
+def _status_of_gpu(data):
+    outs, results = jl.decode_batch([data], jl.FMT_INTERLEAVED_U8)
+    return {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException"}[results[0].status], results[0]
+
+
+def test_truncated_and_corrupted_streams_fail_like_the_reference():
+    good = jpegsynth.encode(160, 96, "420", 75, 2, seed=42)
+    sos = good.index(b"\xff\xda")
+    entropy0 = sos + 14
+    rsts = [i for i in range(entropy0, len(good) - 1) if good[i] == 0xFF and 0xD0 <= good[i + 1] <= 0xD7]
+    assert len(rsts) == 29
+    cases = {
+        "truncated_mid_interval": good[:rsts[10] + 9],
+        "truncated_at_restart": good[:rsts[10]] + b"\xff\xd9",   # EOI at a restart boundary: early return, no error
+        "rst_removed": good[:rsts[5]] + good[rsts[5] + 2:],
+        "garbage_before_rst": good[:rsts[7]] + b"\x12\x34" + good[rsts[7]:],
+        "marker_in_data": good[:rsts[3] + 5] + b"\xff\xc4" + good[rsts[3] + 7:],
+        "no_eoi": good[:-2],
+    }
+    cases.update({
+        # Identify() passes (EOI present) and the failure happens inside the scan, on the device
+        "cut_mid_interval_eoi": good[:rsts[10] + 9] + b"\xff\xd9",
+        "cut_mid_interval_eoi2": good[:rsts[10] + 30] + b"\xff\xd9",
+        "cut_last_interval_eoi": good[:len(good) - 12] + b"\xff\xd9",
+        "interval_zeroed": good[:rsts[4] + 2] + bytes(rsts[5] - rsts[4] - 2) + good[rsts[5]:],
+        "interval_ones": good[:rsts[4] + 2] + b"\xff\x00" * ((rsts[5] - rsts[4] - 2) // 2) + good[rsts[5]:],
+        "extra_rst_mid": good[:rsts[6] + 10] + b"\xff\xd3" + good[rsts[6] + 10:],
+        "non_rst_marker_as_restart": good[:rsts[8]] + b"\xff\xc8" + good[rsts[8] + 2:],
+        "trailing_rst_before_eoi": good[:-2] + b"\xff\xd5\xff\xd9",
+        "fill_bytes_before_rst": good[:rsts[9]] + b"\xff\xff\xff" + good[rsts[9]:],
+    })
+    from jpeglibrary_amd import _capi
+    for name, data in cases.items():
+        try:
+            po.decode_8bit(data)
+            ref, ref_msg = "OK", ""
+        except po.OracleError as e:
+            ref, ref_msg = e.kind, e.message
+        mine, res = _status_of_gpu(data)
+        assert mine == ref, (name, ref, ref_msg, mine, res.detail)
+        if res.detail in (1, 2, 3, 4):  # device-reported failures carry the reference's exception text
+            assert _capi.lib.jpgpu_detail_string(res.detail).decode() == ref_msg, (name, ref_msg, res.detail)
+        if ref == "OK":
+            out = jl.decode_batch([data], jl.FMT_INTERLEAVED_U8)[0][0]
+            if name != "truncated_at_restart":
+                assert np.array_equal(out, po.decode_8bit(data)[0]), name
+    # early EOI decodes exactly the intervals before it and leaves the rest of the caller's buffer untouched
+    data = cases["truncated_at_restart"]
+    d = jl.JpegDecoder()
+    d.SetInput(data)
+    d.Identify()
+    out = np.full(160 * 96 * 3, 77, np.uint8)
+    d.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(160, 96, 3, out))
+    d.Decode()
+    ref = np.full((96, 160, 3), 77, np.uint8)
+    L = po.lib()
+    import ctypes as C
+    err = C.create_string_buffer(256)
+    info = po.Info()
+    assert L.jref_decode_to_8bit(data, len(data), 3, ref.ctypes.data, ref.size, C.byref(info), err, 256) == 0
+    assert np.array_equal(out.reshape(96, 160, 3), ref)
+
+
+def test_dri_latched_at_sof_like_the_reference():
+    """without Identify(), a DRI that follows SOF is not seen by the baseline scan decoder."""
+    data = jpegsynth.encode(64, 48, "420", 75, 2, seed=8)   # jpegsynth writes DRI after SOF, like libjpeg
+    d = jl.JpegDecoder()
+    d.SetInput(data)
+    out = np.zeros(64 * 48 * 3, np.uint8)
+    d.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(64, 48, 3, out))
+    with pytest.raises(jl.JpegError):
+        d.Decode()   # restart interval still 0 at SOF time -> the first RST marker ends the bit stream
+    d2 = jl.JpegDecoder()
+    d2.SetInput(data)
+    d2.Identify()
+    d2.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(64, 48, 3, out))
+    d2.Decode()
+    ref, _ = po.decode_8bit(data)
+    assert np.array_equal(out.reshape(ref.shape), ref)
+
+
+def test_decode_scan_level2_entry():
+    """jpgpu_decode_scan with pre-parsed tables (what a C# JpegScanDecoder replacement would P/Invoke)."""
+    import ctypes as C
+
+    from jpeglibrary_amd import _capi
+
+    data = jpegsynth.encode(96, 80, "420", 75, 3, seed=21)
+    frame = _capi.Frame(96, 80, 8, 3, 0xC0, 0)
+    for i, (cid, h, v, tq) in enumerate([(1, 2, 2, 0), (2, 1, 1, 1), (3, 1, 1, 1)]):
+        frame.comp[i] = _capi.FrameComponent(cid, h, v, tq)
+    scan = _capi.Scan(3, 0, 63, 0, 0)
+    for i, (sel, td, ta) in enumerate([(1, 0, 0), (2, 1, 1), (3, 1, 1)]):
+        scan.comp[i] = _capi.ScanComponent(sel, td, ta, 0)
+    qts = _quant_tables(data)
+    qt = np.zeros((4, 64), np.uint16)
+    qt[0], qt[1] = qts[0], qts[1]
+    present = np.array([1, 1, 0, 0], np.uint8)
+    dht = ((_capi.Dht * 4) * 2)()
+    i = 2
+    while True:
+        m, ln = data[i + 1], (data[i + 2] << 8) | data[i + 3]
+        if m == 0xC4:
+            p = i + 4
+            while p < i + 2 + ln:
+                tc, th = data[p] >> 4, data[p] & 15
+                bits = data[p + 1:p + 17]
+                n = sum(bits)
+                e = dht[tc][th]
+                e.present = 1
+                e.num_values = n
+                for k in range(16):
+                    e.bits[k] = bits[k]
+                for k in range(n):
+                    e.values[k] = data[p + 17 + k]
+                p += 17 + n
+        if m == 0xDA:
+            entropy = data[i + 2 + ln:]
+            break
+        i += 2 + ln
+    ctx = jl.default_context()
+    out = np.zeros(96 * 80 * 3, np.uint8)
+    res = _capi.ImageResult()
+    consumed = C.c_size_t()
+    ebuf = np.frombuffer(entropy, np.uint8)
+    rc = _capi.lib.jpgpu_decode_scan(ctx._h, C.byref(frame), C.byref(scan), qt.ctypes.data, present.ctypes.data, C.addressof(dht), 3,
+                                     ebuf.ctypes.data, ebuf.size, jl.FMT_INTERLEAVED_U8, out.ctypes.data, out.size, C.byref(res), C.byref(consumed))
+    assert rc == 0, ctx.last_error()
+    ref, _ = po.decode_8bit(data)
+    assert np.array_equal(out.reshape(ref.shape), ref)
+    assert consumed.value == len(entropy) - 2  # reader left just before EOI
+
+
+def test_full_size_properties_4k():
+    """BASELINE config-2 geometry at full size: every image of a small 4K batch is bit-exact vs the oracle, and the
+    DRI=4 and DRI=0 encodings of the same pixels decode to identical output (restart markers carry no information)."""
+    files4 = [jpegsynth.encode(3840, 2160, "420", 75, 4, seed=1000 + i) for i in range(2)]
+    files0 = [jpegsynth.encode(3840, 2160, "420", 75, 0, seed=1000 + i) for i in range(2)]
+    outs4, res4 = jl.decode_batch(files4, jl.FMT_INTERLEAVED_U8)
+    outs0, res0 = jl.decode_batch(files0, jl.FMT_INTERLEAVED_U8)
+    for i in range(2):
+        assert res4[i].status == 0 and res0[i].status == 0
+        assert np.array_equal(outs4[i], outs0[i])
+    ref, _ = po.decode_8bit(files4[0])
+    assert np.array_equal(outs4[0], ref)

@@ -61,8 +61,8 @@ def encode_batch(n, width, height, subsampling="420", quality=75, restart_interv
     """Returns (buffer uint8[n*stride], sizes int64[n], stride). Image i uses seed0+i."""
     L = _get()
     nthreads = nthreads or os.cpu_count() or 1
-    # ~1-2.5 bpp for the recipe at Q75..Q90; 0.6 B/px + slack is ample
-    stride = stride or int(width * height * 0.6 + 65536)
+    # ~1-2.5 bpp for the recipe at Q75..Q90 (<= 0.32 B/px); 0.4 B/px + slack is ample
+    stride = stride or int(width * height * 0.4 + 65536)
     stride = (stride + 255) & ~255
     arr = (Params * n)()
     for i in range(n):
