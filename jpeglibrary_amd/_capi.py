@@ -117,7 +117,33 @@ SYMBOLS = [
 ]
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7) next to libtorch_hip.so, and two
+    HIP runtimes in one process cannot both own the GPU.  libjpgpu.so has a plain NEEDED libamdhip64.so.7, so loading
+    torch's copy first makes the dynamic linker bind libjpgpu.so to it (SONAME match): one runtime per process, and
+    device pointers / streams interoperate with torch.  Without torch installed the system ROCm runtime is used.
+    Set JPGPU_HIP_RUNTIME=system to skip the preload."""
+    if os.environ.get("JPGPU_HIP_RUNTIME", "") == "system":
+        return None
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if not spec or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    try:
+        return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+
+
 def _load():
+    _preload_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

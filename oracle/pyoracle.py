@@ -56,9 +56,9 @@ def lib():
         L.jref_set_output_writer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.jref_set_coef_tap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.jref_decode.argtypes = [C.c_void_p]
-        L.jref_decode_to_8bit.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Info),
+        L.jref_decode_to_8bit.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Info),
                                           C.c_char_p, C.c_size_t]
-        L.jref_decode_to_16bit.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Info),
+        L.jref_decode_to_16bit.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Info),
                                            C.c_char_p, C.c_size_t]
         L.jref_block_dequant_idct_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.jref_build_huffman.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
