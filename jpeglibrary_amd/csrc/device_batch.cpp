@@ -210,6 +210,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     h_scans_.assign(jobs_.size(), DevScan());
     std::vector<HuffWork> huff_work;
     std::vector<IdctWork> idct_work;
+    std::vector<IdctWork> idct_work_by_class[kNumIdctLayoutClasses];
     uint64_t out_off = 0, coef_off = 0;
     uint32_t ends_off = 0;
     compressed_bytes_ = 0;
@@ -298,13 +299,19 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             compressed_bytes_ += s.data_len;
             for (uint32_t first = 0; first < s.n_intervals; first += kHuffIntervalsPerWg) huff_work.push_back({(uint32_t)j, first});
             const uint32_t mcus_per_wg = (uint32_t)kIdctBlocksPerWg / s.blocks_per_mcu;
-            for (uint32_t first = 0; first < s.total_mcus; first += mcus_per_wg) idct_work.push_back({(uint32_t)j, first});
+            const int cls = format_ == JPGPU_FMT_INTERLEAVED_U8 ? idct_layout_class(s) : 0;
+            for (uint32_t first = 0; first < s.total_mcus; first += mcus_per_wg) idct_work_by_class[cls].push_back({(uint32_t)j, first});
         }
     }
     total_blocks_ = coef_off;
     out_bytes_ = out_off;
     total_ends_ = ends_off;
     n_huff_work_ = (int)huff_work.size();
+    idct_class_begin_[0] = 0;
+    for (int c = 0; c < kNumIdctLayoutClasses; c++) {
+        idct_work.insert(idct_work.end(), idct_work_by_class[c].begin(), idct_work_by_class[c].end());
+        idct_class_begin_[c + 1] = (int)idct_work.size();
+    }
     n_idct_work_ = (int)idct_work.size();
 
     h_status_.assign(jobs_.size(), DevScanStatus());
@@ -378,7 +385,7 @@ int DeviceBatch::run_huffman() {
 }
 int DeviceBatch::run_idct() {
     hipError_t e = launch_idct(ctx_->stream, (const int16_t *)d_coefs_.ptr, (const DevScan *)d_scans_.ptr, (const IdctWork *)d_idct_work_.ptr,
-                               n_idct_work_, (const DevScanStatus *)d_status_.ptr, (const DevQuantTable *)d_quant_pool_.ptr,
+                               idct_class_begin_, (const DevScanStatus *)d_status_.ptr, (const DevQuantTable *)d_quant_pool_.ptr,
                                (uint8_t *)d_out_.ptr, format_);
     return e == hipSuccess ? JPGPU_OK : hip_fail(e, "idct_output_kernel");
 }

@@ -8,6 +8,7 @@
 #include "../../include/jpgpu.h"
 #include "common.h"
 #include "host.h"
+#include "kernels.h"
 
 struct jpgpu_ctx {
     int device = 0;
@@ -97,6 +98,7 @@ class DeviceBatch {
     std::vector<DevQuantTable> quant_pool_;
     int n_huff_slots_ = 1;
     int n_huff_work_ = 0, n_idct_work_ = 0;
+    int idct_class_begin_[kNumIdctLayoutClasses + 1] = {};
     uint64_t total_blocks_ = 0, out_bytes_ = 0, input_bytes_ = 0, compressed_bytes_ = 0, total_pixels_ = 0;
     uint32_t total_ends_ = 0;
 

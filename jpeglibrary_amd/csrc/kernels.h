@@ -19,7 +19,12 @@ hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const De
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                           const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
                           int n_slots);
-hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *scans, const IdctWork *work, int n_work,
-                       const DevScanStatus *status, const DevQuantTable *quant_pool, uint8_t *out, int format);
+constexpr int kNumIdctLayoutClasses = 5;
+// Output layout class of a scan for INTERLEAVED_U8 (0 = generic bytewise path, else a specialised kernel).
+int idct_layout_class(const DevScan &s);
+// work is sorted by layout class; class_begin[c]..class_begin[c+1] are the workgroups of class c.
+hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *scans, const IdctWork *work,
+                       const int class_begin[kNumIdctLayoutClasses + 1], const DevScanStatus *status,
+                       const DevQuantTable *quant_pool, uint8_t *out, int format);
 
 }  // namespace jpgpu

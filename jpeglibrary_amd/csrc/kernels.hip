@@ -524,18 +524,27 @@ __device__ constexpr uint8_t kNat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24,
         y4 = a3 - mb3;                                                  \
     }
 
-// DequantizeBlockAndUnZigZag + TransformIDCT + ShiftDataLevel for one block held in registers.
-// cw: 32 dwords = 64 int16 coefficients (zig-zag), qw: 32 dwords = 64 uint16 quantisers (zig-zag).
-// out: 64 int32 samples, row-major, unclamped (the value the reference casts to short).
-__device__ __forceinline__ void block_idct(const uint32_t (&cw)[32], const uint32_t (&qw)[32], int32_t level_shift,
+// DequantizeBlockAndUnZigZag + TransformIDCT + ShiftDataLevel for one block.
+// c_lds: this lane's 64 int16 coefficients (zig-zag) in the swizzled LDS staging (8 chunks of 16 B, chunk p at
+// c_lds + ((p ^ swz) * 16)); q_lds: 64 uint16 quantisers (zig-zag) of the block's component.
+// out: 64 samples, row-major, unclamped (the value the reference casts to short), as int32.
+__device__ __forceinline__ void block_idct(const uint8_t *c_lds, uint32_t swz, const uint16_t *q_lds, int32_t level_shift,
                                            int32_t (&out)[64]) {
     float f[64];
 #pragma unroll
-    for (int k = 0; k < 64; k++) {
-        const uint32_t w = cw[k >> 1], q = qw[k >> 1];
-        const int32_t c = (k & 1) ? ((int32_t)w >> 16) : (int32_t)(int16_t)(w & 0xFFFF);
-        const int32_t qq = (k & 1) ? (int32_t)(q >> 16) : (int32_t)(q & 0xFFFF);
-        f[kNat[k]] = (float)(qq * c);  // ushort * short -> int -> float (ref: ScanDecoder/JpegScanDecoder.cs:58-61)
+    for (int piece = 0; piece < 8; piece++) {
+        const uint4 cv = *reinterpret_cast<const uint4 *>(c_lds + ((piece ^ swz) * 16));
+        const uint4 qv = reinterpret_cast<const uint4 *>(q_lds)[piece];
+        const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
+        const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = piece * 8 + j;
+            const uint32_t w = cw[j >> 1], q = qw[j >> 1];
+            const int32_t c = (j & 1) ? ((int32_t)w >> 16) : (int32_t)(int16_t)(w & 0xFFFF);
+            const int32_t qq = (j & 1) ? (int32_t)(q >> 16) : (int32_t)(q & 0xFFFF);
+            f[kNat[k]] = (float)(qq * c);  // ushort * short -> int -> float (ref: ScanDecoder/JpegScanDecoder.cs:58-61)
+        }
     }
     // pass 1: 1-D IDCT along each ROW (the reference transposes, runs the column butterfly, transposes back)
 #pragma unroll
@@ -552,17 +561,29 @@ __device__ __forceinline__ void block_idct(const uint32_t (&cw)[32], const uint3
 }
 
 __device__ __forceinline__ uint32_t clamp_u8(int32_t v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+__device__ __forceinline__ uint32_t pack4_u8(int32_t a, int32_t b, int32_t c, int32_t d) {
+    return clamp_u8(a) | (clamp_u8(b) << 8) | (clamp_u8(c) << 16) | (clamp_u8(d) << 24);
+}
+// byte gather from the 8 bytes {lo (indices 0-3), hi (indices 4-7)}: one v_perm_b32
+__device__ __forceinline__ uint32_t pick4(uint32_t lo, uint32_t hi, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+#define JPGPU_SEL(a, b, c, d) ((uint32_t)(a) | ((uint32_t)(b) << 8) | ((uint32_t)(c) << 16) | ((uint32_t)(d) << 24))
 
 constexpr int kIdctThreads = 256;
+constexpr uint32_t kPxRowStride = kIdctThreads * 8;  // bytes between sample rows in the LDS pixel tile
 
-__global__ __launch_bounds__(kIdctThreads) void idct_output_kernel(const int16_t *__restrict__ coefs,
-                                                                    const DevScan *__restrict__ scans,
-                                                                    const IdctWork *__restrict__ work,
-                                                                    const DevScanStatus *__restrict__ status,
-                                                                    const DevQuantTable *__restrict__ quant_pool,
-                                                                    uint8_t *__restrict__ out, int format) {
-    __shared__ __attribute__((aligned(16))) uint8_t sh_in[kIdctThreads * 128];   // swizzled coefficient blocks
-    __shared__ __attribute__((aligned(16))) uint8_t sh_px[kIdctThreads * 64];    // planar u8 samples, [block][64]
+// Output layout classes of the INTERLEAVED_U8 format (chosen per scan on the host, see idct_layout_class()).
+enum IdctLayout : int { kLayGeneric = 0, kLayYccH1V1 = 1, kLayYccH2V1 = 2, kLayYccH2V2 = 3, kLayGray = 4, kNumIdctLayouts = 5 };
+
+// LDS: the swizzled coefficient blocks (32 KiB) are dead once every lane holds its block in registers, so the
+// u8 sample tile ([8 rows][256 blocks][8 B], 16 KiB) aliases them after a barrier.
+template <int FMT, int LAY>
+__global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 4)) void idct_output_kernel(const int16_t *__restrict__ coefs,
+                                                                       const DevScan *__restrict__ scans,
+                                                                       const IdctWork *__restrict__ work,
+                                                                       const DevScanStatus *__restrict__ status,
+                                                                       const DevQuantTable *__restrict__ quant_pool,
+                                                                       uint8_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t sh[kIdctThreads * 128];
     __shared__ __attribute__((aligned(16))) uint16_t sh_q[kMaxScanComponents][64];
 
     const IdctWork wk = work[blockIdx.x];
@@ -582,12 +603,12 @@ __global__ __launch_bounds__(kIdctThreads) void idct_output_kernel(const int16_t
         reinterpret_cast<uint32_t *>(sh_q[c])[i] =
             reinterpret_cast<const uint32_t *>(quant_pool[s.quant_pool[s.comp[c].quant_slot]].q)[i];
     }
-    // phase A: coalesced 16-byte loads of n_blk consecutive blocks
+    // phase A: coalesced 16-byte loads of n_blk consecutive blocks into the swizzled staging
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(coefs + (s.coef_off + (uint64_t)wk.first_mcu * bpm) * 64);
         for (uint32_t c = tid; c < n_blk * 8; c += kIdctThreads) {
             const uint32_t blk = c >> 3, piece = c & 7;
-            *reinterpret_cast<uint4 *>(sh_in + blk * 128 + ((piece ^ ((blk >> 1) & 7)) * 16)) = src[c];
+            *reinterpret_cast<uint4 *>(sh + blk * 128 + ((piece ^ ((blk >> 1) & 7)) * 16)) = src[c];
         }
     }
     __syncthreads();
@@ -600,26 +621,11 @@ __global__ __launch_bounds__(kIdctThreads) void idct_output_kernel(const int16_t
     const DevScanComponent comp = s.comp[ci];
     const uint32_t mcu_x = mcu % s.mcus_per_line, mcu_y = mcu / s.mcus_per_line;
 
+    // phase B: one block per lane, entirely in registers
     int32_t px[64];
-    if (have_block) {
-        uint32_t cw[32], qw[32];
-#pragma unroll
-        for (int piece = 0; piece < 8; piece++) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(sh_in + tid * 128 + ((piece ^ ((tid >> 1) & 7)) * 16));
-            cw[piece * 4 + 0] = v.x;
-            cw[piece * 4 + 1] = v.y;
-            cw[piece * 4 + 2] = v.z;
-            cw[piece * 4 + 3] = v.w;
-            const uint4 q = reinterpret_cast<const uint4 *>(sh_q[ci])[piece];
-            qw[piece * 4 + 0] = q.x;
-            qw[piece * 4 + 1] = q.y;
-            qw[piece * 4 + 2] = q.z;
-            qw[piece * 4 + 3] = q.w;
-        }
-        block_idct(cw, qw, (int32_t)s.level_shift, px);
-    }
+    if (have_block) block_idct(sh + tid * 128, (tid >> 1) & 7, sh_q[ci], (int32_t)s.level_shift, px);
 
-    if (format == kFmtPlanarI16) {
+    if (FMT == kFmtPlanarI16) {
         // "O1": unclamped int16 at component-native resolution, planes padded to whole MCUs
         if (have_block) {
             int16_t *plane = reinterpret_cast<int16_t *>(out + s.out_off + s.plane_off[ci]);
@@ -637,105 +643,125 @@ __global__ __launch_bounds__(kIdctThreads) void idct_output_kernel(const int16_t
         }
         return;
     }
-    if (format == kFmtPlanarU8) {
+
+    // u8 formats: clamp (signed, like JpegBufferOutputWriter8Bit.ClampTo8Bit) and pack 8 samples per row
+    uint2 rows[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        rows[r].x = pack4_u8(px[r * 8 + 0], px[r * 8 + 1], px[r * 8 + 2], px[r * 8 + 3]);
+        rows[r].y = pack4_u8(px[r * 8 + 4], px[r * 8 + 5], px[r * 8 + 6], px[r * 8 + 7]);
+    }
+
+    if (FMT == kFmtPlanarU8 || (FMT == kFmtInterleavedU8 && LAY == kLayGray)) {
+        // planar u8 (planes padded to whole MCUs), or a single-component interleaved image (same addressing,
+        // pitch = W, clipped at the bottom; the host only picks kLayGray when W is a multiple of 8)
         if (have_block) {
-            uint8_t *plane = out + s.out_off + s.plane_off[ci];
-            const uint32_t pitch = s.plane_pitch[ci];
+            const bool gray = (FMT == kFmtInterleavedU8);
+            uint8_t *plane = out + s.out_off + (gray ? 0 : s.plane_off[ci]);
+            const uint32_t pitch = gray ? s.width : s.plane_pitch[ci];
             const uint32_t x0 = (mcu_x * comp.h + s.blk_x[b]) * 8, y0 = (mcu_y * comp.v + s.blk_y[b]) * 8;
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                uint2 v;
-                v.x = clamp_u8(px[r * 8 + 0]) | (clamp_u8(px[r * 8 + 1]) << 8) | (clamp_u8(px[r * 8 + 2]) << 16) | (clamp_u8(px[r * 8 + 3]) << 24);
-                v.y = clamp_u8(px[r * 8 + 4]) | (clamp_u8(px[r * 8 + 5]) << 8) | (clamp_u8(px[r * 8 + 6]) << 16) | (clamp_u8(px[r * 8 + 7]) << 24);
-                *reinterpret_cast<uint2 *>(plane + (size_t)(y0 + r) * pitch + x0) = v;
-            }
+            for (int r = 0; r < 8; r++)
+                if (!gray || y0 + r < s.height) *reinterpret_cast<uint2 *>(plane + (size_t)(y0 + r) * pitch + x0) = rows[r];
         }
         return;
     }
 
-    // ---- interleaved u8 ("O2", JpegBufferOutputWriter8Bit semantics) ----
+    // ---- interleaved u8 ("O2", JpegBufferOutputWriter8Bit semantics): stage the clamped samples in LDS,
+    //      tile[r][block] (8 B each), aliasing the coefficient staging
+    __syncthreads();  // every lane has consumed its coefficients
+    if (have_block) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(sh + r * kPxRowStride + tid * 8) = rows[r];
+    }
+    __syncthreads();
+
     const uint32_t W = s.width, H = s.height, C = s.frame_components;
-    // fast path: 3 components in frame order, luma at full sampling, chroma 1x1, row pitch 4-byte aligned
-    const bool fast = (C == 3 && s.scan_components == 3 && s.comp[0].component_index == 0 && s.comp[1].component_index == 1 &&
-                       s.comp[2].component_index == 2 && s.comp[0].hs == 1 && s.comp[0].vs == 1 && s.comp[1].h == 1 &&
-                       s.comp[1].v == 1 && s.comp[2].h == 1 && s.comp[2].v == 1 && s.max_h <= 2 && s.max_v <= 2 &&
-                       (W & 3) == 0 && (s.out_off & 3) == 0 && W % (8u * s.max_h) == 0);
-    if (!fast) {
-        // generic path: every sample stored bytewise with WriteBlockSlow's replication
-        // (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:238-268) and the sink's clipping (x<W, y<H)
+    uint8_t *img = out + s.out_off;
+
+    if (LAY == kLayGeneric) {
+        // any component count / sampling: bytewise stores with WriteBlockSlow's replication
+        // (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:238-268) and the sink's clipping (x < W, y < H)
         if (have_block) {
-            uint8_t *img = out + s.out_off;
             const uint32_t hs = comp.hs, vs = comp.vs;
             const uint32_t x0 = (mcu_x * s.max_h + s.blk_x[b]) * 8, y0 = (mcu_y * s.max_v + s.blk_y[b]) * 8;
             const uint32_t hshift = 31 - __builtin_clz(hs | 1), vshift = 31 - __builtin_clz(vs | 1);
             for (uint32_t v = 0; v < vs; v++)
-                for (uint32_t h = 0; h < hs; h++)
-                    for (uint32_t i = 0; i < 8; i++) {
-                        const uint32_t y = y0 + 8 * v + i;
-                        if (y >= H) continue;
+                for (uint32_t i = 0; i < 8; i++) {
+                    const uint32_t y = y0 + 8 * v + i;
+                    if (y >= H) continue;
+                    const uint8_t *srow = sh + ((8 * v + i) >> vshift) * kPxRowStride + tid * 8;
+                    for (uint32_t h = 0; h < hs; h++)
                         for (uint32_t j = 0; j < 8; j++) {
                             const uint32_t x = x0 + 8 * h + j;
-                            if (x >= W) continue;
-                            const uint32_t si = (((8 * v + i) >> vshift) * 8) + ((8 * h + j) >> hshift);
-                            int32_t val = 0;
-#pragma unroll
-                            for (int k = 0; k < 64; k++) val = (si == (uint32_t)k) ? px[k] : val;
-                            img[((size_t)y * W + x) * C + comp.component_index] = (uint8_t)clamp_u8(val);
+                            if (x < W) img[((size_t)y * W + x) * C + comp.component_index] = srow[(8 * h + j) >> hshift];
                         }
-                    }
+                }
         }
         return;
     }
 
-    // fast path: clamp to u8 into an LDS tile [block][8 rows][8 B], then assemble 4-pixel groups (12 B) per lane
-    if (have_block) {
-        uint32_t *dst = reinterpret_cast<uint32_t *>(sh_px + tid * 64);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            dst[r * 2 + 0] = clamp_u8(px[r * 8 + 0]) | (clamp_u8(px[r * 8 + 1]) << 8) | (clamp_u8(px[r * 8 + 2]) << 16) | (clamp_u8(px[r * 8 + 3]) << 24);
-            dst[r * 2 + 1] = clamp_u8(px[r * 8 + 4]) | (clamp_u8(px[r * 8 + 5]) << 8) | (clamp_u8(px[r * 8 + 6]) << 16) | (clamp_u8(px[r * 8 + 7]) << 24);
-        }
-    }
-    __syncthreads();
-    {
-        const uint32_t max_h = s.max_h, max_v = s.max_v;
-        const uint32_t hshift = max_h >> 1, vshift = max_v >> 1;  // max in {1,2}
-        const uint32_t groups_per_row = 2 * max_h;                 // 4-pixel groups per MCU row
-        const uint32_t rows = 8 * max_v;
-        const uint32_t b_cb = max_h * max_v, b_cr = b_cb + 1;
-        const uint32_t total_groups = rows * n_mcu * groups_per_row;
-        uint8_t *img = out + s.out_off;
-        for (uint32_t g = tid; g < total_groups; g += kIdctThreads) {
-            const uint32_t c4 = g % groups_per_row;
-            const uint32_t t2 = g / groups_per_row;
-            const uint32_t m = t2 % n_mcu;
-            const uint32_t row = t2 / n_mcu;
-            const uint32_t gm = wk.first_mcu + m;
-            const uint32_t gx = gm % s.mcus_per_line, gy = gm / s.mcus_per_line;
-            const uint32_t y = gy * rows + row;
-            if (y >= H) continue;
-            const uint32_t x = gx * 8 * max_h + c4 * 4;
-            const uint32_t xl = c4 * 4;  // x inside the MCU
-            const uint32_t by = row >> 3, bx = xl >> 3;
-            const uint32_t yw = *reinterpret_cast<const uint32_t *>(sh_px + (m * bpm + by * max_h + bx) * 64 + (row & 7) * 8 + (xl & 7));
-            const uint32_t cx = xl >> hshift, cy = row >> vshift;
-            uint32_t cb4, cr4;  // 4 chroma samples for the 4 pixels
-            if (hshift) {
-                const uint32_t cb2 = *reinterpret_cast<const uint16_t *>(sh_px + (m * bpm + b_cb) * 64 + cy * 8 + cx);
-                const uint32_t cr2 = *reinterpret_cast<const uint16_t *>(sh_px + (m * bpm + b_cr) * 64 + cy * 8 + cx);
-                cb4 = (cb2 & 0xFF) * 0x0101u | ((cb2 >> 8) * 0x01010000u);
-                cr4 = (cr2 & 0xFF) * 0x0101u | ((cr2 >> 8) * 0x01010000u);
-            } else {
-                cb4 = *reinterpret_cast<const uint32_t *>(sh_px + (m * bpm + b_cb) * 64 + cy * 8 + cx);
-                cr4 = *reinterpret_cast<const uint32_t *>(sh_px + (m * bpm + b_cr) * 64 + cy * 8 + cx);
+    // YCbCr fast paths: one task = one pixel row of one MCU (8*max_h pixels); consecutive lanes take consecutive MCUs of
+    // the same row, so a wave writes one contiguous run of the output row per store instruction group.
+    constexpr uint32_t max_h = (LAY == kLayYccH1V1) ? 1 : 2;
+    constexpr uint32_t max_v = (LAY == kLayYccH2V2) ? 2 : 1;
+    constexpr uint32_t rows_per_mcu = 8 * max_v;
+    constexpr uint32_t vshift = max_v >> 1;
+    constexpr uint32_t kbpm = max_h * max_v + 2;
+    const uint32_t n_tasks = rows_per_mcu * n_mcu;
+    for (uint32_t t = tid; t < n_tasks; t += kIdctThreads) {
+        const uint32_t row = t / n_mcu, m = t - row * n_mcu;
+        const uint32_t gm = wk.first_mcu + m;
+        const uint32_t gx = gm % s.mcus_per_line, gy = gm / s.mcus_per_line;
+        const uint32_t y = gy * rows_per_mcu + row;
+        if (y >= H) continue;
+        const uint8_t *yrow = sh + (row & 7) * kPxRowStride + (m * kbpm + (row >> 3) * max_h) * 8;
+        const uint8_t *crow = sh + (row >> vshift) * kPxRowStride + (m * kbpm + max_h * max_v) * 8;
+        if (max_h == 2) {
+            const uint4 yv = *reinterpret_cast<const uint4 *>(yrow);  // 16 luma samples (two adjacent blocks)
+            const uint4 cv = *reinterpret_cast<const uint4 *>(crow);  // 8 Cb (x,y) + 8 Cr (z,w)
+            const uint32_t cc0 = pick4(cv.x, cv.z, JPGPU_SEL(0, 4, 1, 5)), cc1 = pick4(cv.x, cv.z, JPGPU_SEL(2, 6, 3, 7));
+            const uint32_t cc2 = pick4(cv.y, cv.w, JPGPU_SEL(0, 4, 1, 5)), cc3 = pick4(cv.y, cv.w, JPGPU_SEL(2, 6, 3, 7));
+            uint4 o0, o1, o2;
+            o0.x = pick4(yv.x, cc0, JPGPU_SEL(0, 4, 5, 1));
+            o0.y = pick4(yv.x, cc0, JPGPU_SEL(4, 5, 2, 6));
+            o0.z = pick4(yv.x, cc0, JPGPU_SEL(7, 3, 6, 7));
+            o0.w = pick4(yv.y, cc1, JPGPU_SEL(0, 4, 5, 1));
+            o1.x = pick4(yv.y, cc1, JPGPU_SEL(4, 5, 2, 6));
+            o1.y = pick4(yv.y, cc1, JPGPU_SEL(7, 3, 6, 7));
+            o1.z = pick4(yv.z, cc2, JPGPU_SEL(0, 4, 5, 1));
+            o1.w = pick4(yv.z, cc2, JPGPU_SEL(4, 5, 2, 6));
+            o2.x = pick4(yv.z, cc2, JPGPU_SEL(7, 3, 6, 7));
+            o2.y = pick4(yv.w, cc3, JPGPU_SEL(0, 4, 5, 1));
+            o2.z = pick4(yv.w, cc3, JPGPU_SEL(4, 5, 2, 6));
+            o2.w = pick4(yv.w, cc3, JPGPU_SEL(7, 3, 6, 7));
+            uint4 *dst = reinterpret_cast<uint4 *>(img + ((size_t)y * W + gx * 16) * 3);
+            dst[0] = o0;
+            dst[1] = o1;
+            dst[2] = o2;
+        } else {
+            const uint2 yv = *reinterpret_cast<const uint2 *>(yrow);
+            const uint2 bv = *reinterpret_cast<const uint2 *>(crow);
+            const uint2 rv = *reinterpret_cast<const uint2 *>(crow + 8);
+            uint2 o0, o1, o2;
+            {
+                const uint32_t lo = pick4(bv.x, rv.x, JPGPU_SEL(0, 4, 1, 5)), hi = pick4(bv.x, rv.x, JPGPU_SEL(2, 6, 3, 7));
+                const uint32_t mid = pick4(lo, hi, JPGPU_SEL(2, 3, 4, 5));
+                o0.x = pick4(yv.x, lo, JPGPU_SEL(0, 4, 5, 1));
+                o0.y = pick4(yv.x, mid, JPGPU_SEL(4, 5, 2, 6));
+                o1.x = pick4(yv.x, hi, JPGPU_SEL(5, 3, 6, 7));
             }
-            const uint32_t y0_ = yw & 0xFF, y1_ = (yw >> 8) & 0xFF, y2_ = (yw >> 16) & 0xFF, y3_ = yw >> 24;
-            const uint32_t b0 = cb4 & 0xFF, b1 = (cb4 >> 8) & 0xFF, b2 = (cb4 >> 16) & 0xFF, b3 = cb4 >> 24;
-            const uint32_t r0 = cr4 & 0xFF, r1 = (cr4 >> 8) & 0xFF, r2 = (cr4 >> 16) & 0xFF, r3 = cr4 >> 24;
-            uint32_t *dst = reinterpret_cast<uint32_t *>(img + ((size_t)y * W + x) * 3);
-            dst[0] = y0_ | (b0 << 8) | (r0 << 16) | (y1_ << 24);
-            dst[1] = b1 | (r1 << 8) | (y2_ << 16) | (b2 << 24);
-            dst[2] = r2 | (y3_ << 8) | (b3 << 16) | (r3 << 24);
+            {
+                const uint32_t lo = pick4(bv.y, rv.y, JPGPU_SEL(0, 4, 1, 5)), hi = pick4(bv.y, rv.y, JPGPU_SEL(2, 6, 3, 7));
+                const uint32_t mid = pick4(lo, hi, JPGPU_SEL(2, 3, 4, 5));
+                o1.y = pick4(yv.y, lo, JPGPU_SEL(0, 4, 5, 1));
+                o2.x = pick4(yv.y, mid, JPGPU_SEL(4, 5, 2, 6));
+                o2.y = pick4(yv.y, hi, JPGPU_SEL(5, 3, 6, 7));
+            }
+            uint2 *dst = reinterpret_cast<uint2 *>(img + ((size_t)y * W + gx * 8) * 3);
+            dst[0] = o0;
+            dst[1] = o1;
+            dst[2] = o2;
         }
     }
 }
@@ -763,12 +789,55 @@ hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan
     return hipGetLastError();
 }
 
-hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *scans, const IdctWork *work, int n_work,
-                       const DevScanStatus *status, const DevQuantTable *quant_pool, uint8_t *out, int format) {
-    if (n_work <= 0) return hipSuccess;
-    hipLaunchKernelGGL(idct_output_kernel, dim3(n_work), dim3(kIdctThreads), 0, stream, coefs, scans, work, status, quant_pool,
-                       out, format);
-    return hipGetLastError();
+template <int FMT, int LAY>
+static void launch_idct_one(hipStream_t stream, const int16_t *coefs, const DevScan *scans, const IdctWork *work, int n_work,
+                            const DevScanStatus *status, const DevQuantTable *quant_pool, uint8_t *out) {
+    hipLaunchKernelGGL((idct_output_kernel<FMT, LAY>), dim3(n_work), dim3(kIdctThreads), 0, stream, coefs, scans, work, status,
+                       quant_pool, out);
+}
+
+// work is sorted by layout class; class_begin[c]..class_begin[c+1] are the workgroups of class c.
+hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *scans, const IdctWork *work,
+                       const int class_begin[kNumIdctLayoutClasses + 1], const DevScanStatus *status,
+                       const DevQuantTable *quant_pool, uint8_t *out, int format) {
+    for (int c = 0; c < kNumIdctLayoutClasses; c++) {
+        const int n = class_begin[c + 1] - class_begin[c];
+        if (n <= 0) continue;
+        const IdctWork *w = work + class_begin[c];
+        if (format == kFmtPlanarI16) {
+            launch_idct_one<kFmtPlanarI16, kLayGeneric>(stream, coefs, scans, w, n, status, quant_pool, out);
+        } else if (format == kFmtPlanarU8) {
+            launch_idct_one<kFmtPlanarU8, kLayGeneric>(stream, coefs, scans, w, n, status, quant_pool, out);
+        } else {
+            switch (c) {
+            case kLayYccH1V1: launch_idct_one<kFmtInterleavedU8, kLayYccH1V1>(stream, coefs, scans, w, n, status, quant_pool, out); break;
+            case kLayYccH2V1: launch_idct_one<kFmtInterleavedU8, kLayYccH2V1>(stream, coefs, scans, w, n, status, quant_pool, out); break;
+            case kLayYccH2V2: launch_idct_one<kFmtInterleavedU8, kLayYccH2V2>(stream, coefs, scans, w, n, status, quant_pool, out); break;
+            case kLayGray: launch_idct_one<kFmtInterleavedU8, kLayGray>(stream, coefs, scans, w, n, status, quant_pool, out); break;
+            default: launch_idct_one<kFmtInterleavedU8, kLayGeneric>(stream, coefs, scans, w, n, status, quant_pool, out); break;
+            }
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// Layout class of a scan for the INTERLEAVED_U8 format (0 = generic bytewise path).
+int idct_layout_class(const DevScan &s) {
+    const uint32_t W = s.width;
+    if (s.frame_components == 1 && s.scan_components == 1 && s.comp[0].h == 1 && s.comp[0].v == 1 && (W % 8) == 0 && (s.out_off % 8) == 0)
+        return kLayGray;
+    const bool ycc = s.frame_components == 3 && s.scan_components == 3 && s.comp[0].component_index == 0 &&
+                     s.comp[1].component_index == 1 && s.comp[2].component_index == 2 && s.comp[0].hs == 1 && s.comp[0].vs == 1 &&
+                     s.comp[1].h == 1 && s.comp[1].v == 1 && s.comp[2].h == 1 && s.comp[2].v == 1;
+    if (!ycc) return kLayGeneric;
+    if (s.max_h == 1 && s.max_v == 1 && (W % 8) == 0 && (s.out_off % 8) == 0) return kLayYccH1V1;
+    if (s.max_h == 2 && (W % 16) == 0 && (s.out_off % 16) == 0) {
+        if (s.max_v == 1) return kLayYccH2V1;
+        if (s.max_v == 2) return kLayYccH2V2;
+    }
+    return kLayGeneric;
 }
 
 }  // namespace jpgpu
