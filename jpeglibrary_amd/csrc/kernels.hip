@@ -191,37 +191,84 @@ __global__ __launch_bounds__(kScanThreads) void marker_index_kernel(const uint8_
 // Bit source of one lane == a fresh JpegBitReader positioned at the start of its restart interval
 // (ref: JpegBitReader.cs).  Byte range [pos, end) ends at the FF of the closing marker, so no marker can
 // occur inside; FF00 -> FF, FFFF -> skip one fill byte (ref: :95-138).
+//
+// Memory side: each lane streams its interval through a register window of two 16-byte aligned chunks
+// (w0 = current, w1 = prefetched next).  The load of the next chunk is issued a full chunk (~3 blocks of
+// decode work) before its first use, so HBM/L2 latency is off the critical path.  Bytes flow
+//   window dwords -> rq (64-bit little-endian raw-byte FIFO) -> buf (right-justified bit buffer, unstuffed).
 struct LaneBits {
-    const uint8_t *base;  // entropy segment base
-    uint32_t pos, end;    // raw byte offsets
-    uint32_t limit;       // bytes readable in the file (peek bound)
-    uint64_t buf;         // right-justified
+    const uint8_t *base16;  // 16-byte aligned base of the scan's entropy segment
+    uint32_t pos, end;      // raw byte offsets relative to base16 (next unread byte / closing marker)
+    uint32_t limit;         // end of the file's bytes (peek bound), relative to base16
+    uint64_t buf;           // right-justified bit buffer
     int32_t bits;
-    uint64_t win;         // 8 raw bytes at [wpos, wpos+8)
-    uint32_t wpos;
+    uint64_t rq;            // raw bytes [pos, pos + rcnt), byte at pos in bits 0..7
+    int32_t rcnt;
+    uint4 w0, w1;           // bytes [wb, wb+16) and [wb+16, wb+32)
+    uint32_t wb;            // 16-byte aligned offset of w0
+    uint32_t wi;            // next dword of w0 to move into rq (0..4)
 };
 
-__device__ __forceinline__ uint32_t lb_byte(LaneBits &r, uint32_t at) {
-    if (at - r.wpos >= 8u) {
-        r.wpos = at;
-        uint64_t w;
-        __builtin_memcpy(&w, r.base + at, 8);  // unaligned 8-byte global load (buffer is padded)
-        r.win = w;
-    }
-    return (uint32_t)(r.win >> ((at - r.wpos) * 8)) & 0xFFu;
+__device__ __forceinline__ void lb_init(LaneBits &r, const uint8_t *base16, uint32_t pos, uint32_t end, uint32_t limit) {
+    r.base16 = base16;
+    r.pos = pos;
+    r.end = end;
+    r.limit = limit;
+    r.buf = 0;
+    r.bits = 0;
+    r.wb = pos & ~15u;
+    r.w0 = *reinterpret_cast<const uint4 *>(base16 + r.wb);        // the input buffer is padded: over-reads are safe
+    r.w1 = *reinterpret_cast<const uint4 *>(base16 + r.wb + 16);
+    const uint32_t di = (pos & 15u) >> 2;
+    const uint32_t d = di == 0 ? r.w0.x : (di == 1 ? r.w0.y : (di == 2 ? r.w0.z : r.w0.w));
+    const uint32_t sh = (pos & 3u) * 8;
+    r.rq = (uint64_t)(d >> sh);
+    r.rcnt = 4 - (int32_t)(pos & 3u);
+    r.wi = di + 1;
 }
 
+// rq <- next aligned dword of the window (rcnt <= 4 on entry)
+__device__ __forceinline__ void lb_topup(LaneBits &r) {
+    if (r.wi == 4) {
+        r.w0 = r.w1;
+        r.wb += 16;
+        r.w1 = *reinterpret_cast<const uint4 *>(r.base16 + r.wb + 16);  // prefetch: first used 16 bytes from now
+        r.wi = 0;
+    }
+    const uint32_t d = r.wi == 0 ? r.w0.x : (r.wi == 1 ? r.w0.y : (r.wi == 2 ? r.w0.z : r.w0.w));
+    r.wi++;
+    r.rq |= (uint64_t)d << (r.rcnt * 8);
+    r.rcnt += 4;
+}
+
+// FillBuffer (ref: JpegBitReader.cs:95-138) with this lane's own refill policy (decoded values do not depend on it).
+// Post-condition: bits > 32, or every byte before `end` has been consumed.
 __device__ __forceinline__ void lb_refill(LaneBits &r) {
-    while (r.bits <= 56 && r.pos < r.end) {
-        uint32_t b = lb_byte(r, r.pos);
+    while (r.bits <= 32 && r.pos < r.end) {
+        if (r.rcnt <= 4) lb_topup(r);
+        const uint32_t x = (uint32_t)r.rq;
+        // fast path: four data bytes, none of them 0xFF
+        const bool has_ff = (((~x) - 0x01010101u) & x & 0x80808080u) != 0;  // some byte of ~x is zero
+        if (!has_ff && r.pos + 4 <= r.end) {
+            r.buf = (r.buf << 32) | (uint64_t)__builtin_bswap32(x);
+            r.bits += 32;
+            r.pos += 4;
+            r.rq >>= 32;
+            r.rcnt -= 4;
+            continue;
+        }
+        // slow path: one byte (rcnt >= 5 here, so the byte after an FF is available)
+        uint32_t b = x & 0xFFu;
         if (b == 0xFF) {
             if (r.pos + 1 >= r.limit) {  // the stream ended prematurely (ref: :112-116)
                 r.pos = r.end;
                 break;
             }
-            const uint32_t nb = lb_byte(r, r.pos + 1);
+            const uint32_t nb = (x >> 8) & 0xFFu;
             if (nb == 0xFF) {  // padding byte, continue reading (ref: :117-121)
                 r.pos += 1;
+                r.rq >>= 8;
+                r.rcnt -= 1;
                 continue;
             }
             if (nb != 0) {  // a marker: cannot precede `end` by construction of the index; stop feeding bits
@@ -229,8 +276,12 @@ __device__ __forceinline__ void lb_refill(LaneBits &r) {
                 break;
             }
             r.pos += 2;  // stuffed byte
+            r.rq >>= 16;
+            r.rcnt -= 2;
         } else {
             r.pos += 1;
+            r.rq >>= 8;
+            r.rcnt -= 1;
         }
         r.buf = (r.buf << 8) | b;
         r.bits += 8;
@@ -265,7 +316,7 @@ __device__ __forceinline__ LdsHuff lds_huff(const uint8_t *tabs, uint32_t slot) 
 // DecodeHuffmanCode (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:81-88, JpegHuffmanDecodingTable.cs:73-113).
 // Returns the symbol, or -1 for "Invalid Huffman code encountered.".
 __device__ __forceinline__ int32_t decode_symbol(LaneBits &r, const LdsHuff &h) {
-    if (r.bits < 16) lb_refill(r);
+    if (r.bits < 32) lb_refill(r);  // code (<= 16 bits) + magnitude (<= 16 bits) then need no second refill
     const uint32_t code16 = lb_peek16(r);
     uint32_t e = h.lut[code16 >> (16 - kHuffLutBits)];
     uint32_t size = e >> 8, sym = e & 0xFF;
@@ -347,22 +398,21 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
     const bool active = interval < n_ends;
     const uint32_t *ends_s = ends + s.ends_off;
 
+    // offsets below are relative to the 16-byte aligned base of the segment
+    const uint32_t mis = (uint32_t)(s.data_off & 15u);
+    const uint8_t *base16 = data + (s.data_off - mis);
     LaneBits r;
-    r.base = data + s.data_off;
-    r.limit = s.data_len;
-    r.buf = 0;
-    r.bits = 0;
-    r.win = 0;
-    r.wpos = 0xF0000000u;
-    r.pos = 0;
-    r.end = 0;
     uint32_t my_mcus = 0;
-    if (active) {
-        r.pos = interval == 0 ? 0u : ends_s[interval - 1] + 2u;
-        r.end = ends_s[interval];
-        my_mcus = (interval == n_intervals - 1) ? total_mcus - interval * dri_eff : dri_eff;
+    {
+        uint32_t p0 = mis, e0 = mis;
+        if (active) {
+            p0 = mis + (interval == 0 ? 0u : ends_s[interval - 1] + 2u);
+            e0 = mis + ends_s[interval];
+            my_mcus = (interval == n_intervals - 1) ? total_mcus - interval * dri_eff : dri_eff;
+        }
+        lb_init(r, base16, p0, e0, mis + s.data_len);
     }
-    const bool closed_by_marker = active && r.end < s.data_len;
+    const bool closed_by_marker = active && r.end < r.limit;
     // the wave iterates to the largest MCU count among its lanes (only the image's last interval is shorter)
     uint32_t wave_mcus = 0;
     {
