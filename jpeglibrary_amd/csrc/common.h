@@ -87,6 +87,7 @@ struct HuffWork {
 struct IdctWork {
     uint32_t scan;
     uint32_t first_mcu;
+    uint32_t n_mcus;  // consecutive MCUs handled by this workgroup (a run of tiles)
 };
 
 constexpr uint32_t kNoError = 0xFFFFFFFFu;

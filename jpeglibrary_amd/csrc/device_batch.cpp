@@ -300,7 +300,9 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             for (uint32_t first = 0; first < s.n_intervals; first += kHuffIntervalsPerWg) huff_work.push_back({(uint32_t)j, first});
             const uint32_t mcus_per_wg = (uint32_t)kIdctBlocksPerWg / s.blocks_per_mcu;
             const int cls = format_ == JPGPU_FMT_INTERLEAVED_U8 ? idct_layout_class(s) : 0;
-            for (uint32_t first = 0; first < s.total_mcus; first += mcus_per_wg) idct_work_by_class[cls].push_back({(uint32_t)j, first});
+            const uint32_t run = mcus_per_wg * (uint32_t)kIdctTilesPerWg;
+            for (uint32_t first = 0; first < s.total_mcus; first += run)
+                idct_work_by_class[cls].push_back({(uint32_t)j, first, std::min(run, s.total_mcus - first)});
         }
     }
     total_blocks_ = coef_off;
@@ -337,7 +339,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_huff_work_, huff_work.data(), huff_work.size() * sizeof(HuffWork), 0},
         {&d_idct_work_, idct_work.data(), idct_work.size() * sizeof(IdctWork), 0},
         {&d_ends_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},
-        {&d_coefs_, nullptr, 0, (size_t)total_blocks_ * 128 + 256},
+        {&d_coefs_, nullptr, 0, (size_t)total_blocks_ * 128 + (size_t)kIdctBlocksPerWg * 128 + 256},  // + one tile of slack (IDCT DMA reads whole tiles)
         {&d_out_, nullptr, 0, (size_t)out_bytes_ + 256},
         {&d_input_, nullptr, 0, (size_t)input_bytes_},
     };

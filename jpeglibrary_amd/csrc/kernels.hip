@@ -574,13 +574,10 @@ __device__ constexpr uint8_t kNat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24,
         y4 = a3 - mb3;                                                  \
     }
 
-// DequantizeBlockAndUnZigZag + TransformIDCT + ShiftDataLevel for one block.
+// DequantizeBlockAndUnZigZag for one block (ref: ScanDecoder/JpegScanDecoder.cs:50-62).
 // c_lds: this lane's 64 int16 coefficients (zig-zag) in the swizzled LDS staging (8 chunks of 16 B, chunk p at
 // c_lds + ((p ^ swz) * 16)); q_lds: 64 uint16 quantisers (zig-zag) of the block's component.
-// out: 64 samples, row-major, unclamped (the value the reference casts to short), as int32.
-__device__ __forceinline__ void block_idct(const uint8_t *c_lds, uint32_t swz, const uint16_t *q_lds, int32_t level_shift,
-                                           int32_t (&out)[64]) {
-    float f[64];
+__device__ __forceinline__ void block_dequant(const uint8_t *c_lds, uint32_t swz, const uint16_t *q_lds, float (&f)[64]) {
 #pragma unroll
     for (int piece = 0; piece < 8; piece++) {
         const uint4 cv = *reinterpret_cast<const uint4 *>(c_lds + ((piece ^ swz) * 16));
@@ -593,9 +590,14 @@ __device__ __forceinline__ void block_idct(const uint8_t *c_lds, uint32_t swz, c
             const uint32_t w = cw[j >> 1], q = qw[j >> 1];
             const int32_t c = (j & 1) ? ((int32_t)w >> 16) : (int32_t)(int16_t)(w & 0xFFFF);
             const int32_t qq = (j & 1) ? (int32_t)(q >> 16) : (int32_t)(q & 0xFFFF);
-            f[kNat[k]] = (float)(qq * c);  // ushort * short -> int -> float (ref: ScanDecoder/JpegScanDecoder.cs:58-61)
+            f[kNat[k]] = (float)(qq * c);  // ushort * short -> int -> float
         }
     }
+}
+
+// TransformIDCT + ShiftDataLevel (ref: FastFloatingPointDCT.cs:54-70, ScanDecoder/JpegScanDecoder.cs:64-73) on a
+// dequantised block held in registers.  out: 64 samples, row-major, unclamped (the value the reference casts to short).
+__device__ __forceinline__ void block_idct(float (&f)[64], int32_t level_shift, int32_t (&out)[64]) {
     // pass 1: 1-D IDCT along each ROW (the reference transposes, runs the column butterfly, transposes back)
 #pragma unroll
     for (int r = 0; r < 8; r++) JPGPU_IDCT8(f[r * 8 + 0], f[r * 8 + 1], f[r * 8 + 2], f[r * 8 + 3], f[r * 8 + 4], f[r * 8 + 5], f[r * 8 + 6], f[r * 8 + 7]);
@@ -624,28 +626,35 @@ constexpr uint32_t kPxRowStride = kIdctThreads * 8;  // bytes between sample row
 // Output layout classes of the INTERLEAVED_U8 format (chosen per scan on the host, see idct_layout_class()).
 enum IdctLayout : int { kLayGeneric = 0, kLayYccH1V1 = 1, kLayYccH2V1 = 2, kLayYccH2V2 = 3, kLayGray = 4, kNumIdctLayouts = 5 };
 
-// LDS: the swizzled coefficient blocks (32 KiB) are dead once every lane holds its block in registers, so the
-// u8 sample tile ([8 rows][256 blocks][8 B], 16 KiB) aliases them after a barrier.
+// Each workgroup walks a run of consecutive tiles (kIdctThreads / blocks_per_mcu MCUs each) of one scan.
+// Pipeline per tile:  lanes dequantise their block out of the LDS staging into registers -> barrier -> the staging is
+// refilled for tile i+1 by LDS-DMA (global_load_lds_dwordx4: no VGPRs, asynchronous; the XOR swizzle is applied to the
+// per-lane SOURCE address because the LDS side of the DMA is lane-linear) -> IDCT in registers while the DMA is in
+// flight -> clamped samples to the LDS tile -> wait for the DMA -> barrier -> output assembly + global stores.
+// All LDS lives in one array: staging 32 KiB | u8 sample tile [8 rows][256 blocks][8 B] 16 KiB | quant tables 512 B.
+typedef __attribute__((address_space(3))) void jpgpu_lds_void;
+typedef const __attribute__((address_space(1))) void jpgpu_gbl_void;
+
 template <int FMT, int LAY>
-__global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 4)) void idct_output_kernel(const int16_t *__restrict__ coefs,
-                                                                       const DevScan *__restrict__ scans,
-                                                                       const IdctWork *__restrict__ work,
-                                                                       const DevScanStatus *__restrict__ status,
-                                                                       const DevQuantTable *__restrict__ quant_pool,
-                                                                       uint8_t *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t sh[kIdctThreads * 128];
-    __shared__ __attribute__((aligned(16))) uint16_t sh_q[kMaxScanComponents][64];
+__global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 2)) void idct_output_kernel(
+    const int16_t *__restrict__ coefs, const DevScan *__restrict__ scans, const IdctWork *__restrict__ work,
+    const DevScanStatus *__restrict__ status, const DevQuantTable *__restrict__ quant_pool, uint8_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t sh_all[kIdctThreads * 128 + kIdctThreads * 64 + kMaxScanComponents * 128];
+    uint8_t *sh = sh_all;
+    uint8_t *sh_px = sh_all + kIdctThreads * 128;
+    uint16_t(*sh_q)[64] = reinterpret_cast<uint16_t(*)[64]>(sh_all + kIdctThreads * 128 + kIdctThreads * 64);
 
     const IdctWork wk = work[blockIdx.x];
     const DevScan &s = scans[wk.scan];
     const uint32_t tid = threadIdx.x;
+    const uint32_t wave = tid >> 6;
     const uint32_t bpm = s.blocks_per_mcu;
-    const uint32_t mcus_per_wg = kIdctThreads / bpm;
+    const uint32_t mcus_per_tile = kIdctThreads / bpm;
     uint32_t decoded = status ? status[wk.scan].decoded_mcus : s.total_mcus;
     if (decoded > s.total_mcus) decoded = s.total_mcus;
-    if (wk.first_mcu >= decoded) return;
-    const uint32_t n_mcu = (decoded - wk.first_mcu) < mcus_per_wg ? (decoded - wk.first_mcu) : mcus_per_wg;
-    const uint32_t n_blk = n_mcu * bpm;
+    uint32_t range_end = wk.first_mcu + wk.n_mcus;
+    if (range_end > decoded) range_end = decoded;
+    if (wk.first_mcu >= range_end) return;
 
     // quantisation tables of the scan components
     if (tid < (uint32_t)s.scan_components * 32) {
@@ -653,27 +662,51 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 4)) void 
         reinterpret_cast<uint32_t *>(sh_q[c])[i] =
             reinterpret_cast<const uint32_t *>(quant_pool[s.quant_pool[s.comp[c].quant_slot]].q)[i];
     }
-    // phase A: coalesced 16-byte loads of n_blk consecutive blocks into the swizzled staging
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(coefs + (s.coef_off + (uint64_t)wk.first_mcu * bpm) * 64);
-        for (uint32_t c = tid; c < n_blk * 8; c += kIdctThreads) {
-            const uint32_t blk = c >> 3, piece = c & 7;
-            *reinterpret_cast<uint4 *>(sh + blk * 128 + ((piece ^ ((blk >> 1) & 7)) * 16)) = src[c];
-        }
-    }
-    __syncthreads();
 
     const uint32_t mcu_local = tid / bpm;
     const uint32_t b = tid - mcu_local * bpm;
-    const uint32_t mcu = wk.first_mcu + mcu_local;
-    const bool have_block = tid < n_blk;
     const uint32_t ci = s.blk_comp[b < kMaxBlocksPerMcu ? b : 0];
     const DevScanComponent comp = s.comp[ci];
+    const uint8_t *coef_bytes = reinterpret_cast<const uint8_t *>(coefs + s.coef_off * 64);
+
+    auto tile_mcus = [&](uint32_t first) { return (range_end - first) < mcus_per_tile ? (range_end - first) : mcus_per_tile; };
+    // LDS-DMA of one tile: linear 16-byte slot c = k * 256 + tid (block c >> 3, slot c & 7) receives piece
+    // (slot ^ swizzle(block)); the swizzle term ((block >> 1) & 7) does not depend on k, so every lane's source is
+    // one fixed offset plus k * 4096.  Always a full tile: the coefficient buffer has a tile of slack behind it.
+    const uint32_t dma_lane_off = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) * 16);
+    auto dma_tile = [&](uint32_t tile_first) {
+        const uint8_t *src = coef_bytes + (uint64_t)tile_first * bpm * 128;  // wave-uniform
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            __builtin_amdgcn_global_load_lds((jpgpu_gbl_void *)(src + (uint32_t)(k * 4096) + dma_lane_off),
+                                             (jpgpu_lds_void *)(sh + ((uint32_t)k * kIdctThreads + wave * 64) * 16), 16, 0, 0);
+    };
+
+    dma_tile(wk.first_mcu);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+  for (uint32_t tile_first = wk.first_mcu; tile_first < range_end; tile_first += mcus_per_tile) {
+    const uint32_t n_mcu = tile_mcus(tile_first);
+    const uint32_t n_blk = n_mcu * bpm;
+    const uint32_t next_first = tile_first + mcus_per_tile;
+    const bool have_next = next_first < range_end;
+
+    const uint32_t mcu = tile_first + mcu_local;
+    const bool have_block = tid < n_blk;
     const uint32_t mcu_x = mcu % s.mcus_per_line, mcu_y = mcu / s.mcus_per_line;
 
-    // phase B: one block per lane, entirely in registers
+    // phase B1: dequantise this lane's block out of the staging into registers
+    float f[64];
+    if (have_block) block_dequant(sh + tid * 128, (tid >> 1) & 7, sh_q[ci], f);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every lane holds its coefficients: the staging can be refilled
+    if (have_next) dma_tile(next_first);  // in flight during the whole transform below
+
+    // phase B2: IDCT entirely in registers
     int32_t px[64];
-    if (have_block) block_idct(sh + tid * 128, (tid >> 1) & 7, sh_q[ci], (int32_t)s.level_shift, px);
+    if (have_block) block_idct(f, (int32_t)s.level_shift, px);
+    bool synced = false;
 
     if (FMT == kFmtPlanarI16) {
         // "O1": unclamped int16 at component-native resolution, planes padded to whole MCUs
@@ -691,9 +724,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 4)) void 
                 *reinterpret_cast<uint4 *>(plane + (size_t)(y0 + r) * pitch + x0) = v;
             }
         }
-        return;
-    }
-
+    } else {
     // u8 formats: clamp (signed, like JpegBufferOutputWriter8Bit.ClampTo8Bit) and pack 8 samples per row
     uint2 rows[8];
 #pragma unroll
@@ -714,17 +745,18 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 4)) void 
             for (int r = 0; r < 8; r++)
                 if (!gray || y0 + r < s.height) *reinterpret_cast<uint2 *>(plane + (size_t)(y0 + r) * pitch + x0) = rows[r];
         }
-        return;
-    }
-
-    // ---- interleaved u8 ("O2", JpegBufferOutputWriter8Bit semantics): stage the clamped samples in LDS,
-    //      tile[r][block] (8 B each), aliasing the coefficient staging
-    __syncthreads();  // every lane has consumed its coefficients
+    } else {
+    // ---- interleaved u8 ("O2", JpegBufferOutputWriter8Bit semantics): stage the clamped samples in LDS, tile[r][block]
     if (have_block) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(sh + r * kPxRowStride + tid * 8) = rows[r];
+        for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(sh_px + r * kPxRowStride + tid * 8) = rows[r];
     }
-    __syncthreads();
+    // The DMA of the next tile has had the whole transform to land.  Wait for it BEFORE this tile's global stores are
+    // issued (vmcnt retires in order: waiting later would also wait for those stores to drain), then one barrier
+    // publishes both the sample tile and the refilled staging.
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    synced = true;
 
     const uint32_t W = s.width, H = s.height, C = s.frame_components;
     uint8_t *img = out + s.out_off;
@@ -740,7 +772,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 4)) void 
                 for (uint32_t i = 0; i < 8; i++) {
                     const uint32_t y = y0 + 8 * v + i;
                     if (y >= H) continue;
-                    const uint8_t *srow = sh + ((8 * v + i) >> vshift) * kPxRowStride + tid * 8;
+                    const uint8_t *srow = sh_px + ((8 * v + i) >> vshift) * kPxRowStride + tid * 8;
                     for (uint32_t h = 0; h < hs; h++)
                         for (uint32_t j = 0; j < 8; j++) {
                             const uint32_t x = x0 + 8 * h + j;
@@ -748,9 +780,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 4)) void 
                         }
                 }
         }
-        return;
-    }
-
+    } else {
     // YCbCr fast paths: one task = one pixel row of one MCU (8*max_h pixels); consecutive lanes take consecutive MCUs of
     // the same row, so a wave writes one contiguous run of the output row per store instruction group.
     constexpr uint32_t max_h = (LAY == kLayYccH1V1) ? 1 : 2;
@@ -761,12 +791,12 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 4)) void 
     const uint32_t n_tasks = rows_per_mcu * n_mcu;
     for (uint32_t t = tid; t < n_tasks; t += kIdctThreads) {
         const uint32_t row = t / n_mcu, m = t - row * n_mcu;
-        const uint32_t gm = wk.first_mcu + m;
+        const uint32_t gm = tile_first + m;
         const uint32_t gx = gm % s.mcus_per_line, gy = gm / s.mcus_per_line;
         const uint32_t y = gy * rows_per_mcu + row;
         if (y >= H) continue;
-        const uint8_t *yrow = sh + (row & 7) * kPxRowStride + (m * kbpm + (row >> 3) * max_h) * 8;
-        const uint8_t *crow = sh + (row >> vshift) * kPxRowStride + (m * kbpm + max_h * max_v) * 8;
+        const uint8_t *yrow = sh_px + (row & 7) * kPxRowStride + (m * kbpm + (row >> 3) * max_h) * 8;
+        const uint8_t *crow = sh_px + (row >> vshift) * kPxRowStride + (m * kbpm + max_h * max_v) * 8;
         if (max_h == 2) {
             const uint4 yv = *reinterpret_cast<const uint4 *>(yrow);  // 16 luma samples (two adjacent blocks)
             const uint4 cv = *reinterpret_cast<const uint4 *>(crow);  // 8 Cb (x,y) + 8 Cr (z,w)
@@ -814,6 +844,15 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 4)) void 
             dst[2] = o2;
         }
     }
+    }  // YCbCr fast paths
+    }  // interleaved
+    }  // u8 formats
+
+    if (!synced) {  // planar / gray paths: publish the refilled staging
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+  }  // tile loop
 }
 
 // ------------------------------------------------------------------------------------------------
