@@ -121,6 +121,7 @@ def main():
         torch.cuda.set_device(local_rank)
 
     import jpeglibrary_amd as jl
+    from jpeglibrary_amd import sharding
     from tools import jpegsynth
 
     width, height, ss, quality, dri, default_images = WORKLOADS[args.workload]
@@ -131,7 +132,7 @@ def main():
     cpu = os.cpu_count() or 1
     gen_threads = args.gen_threads or max(1, cpu // max(1, min(world, 8)))
     t0 = time.perf_counter()
-    buf, sizes, stride = jpegsynth.encode_batch(n_images, width, height, ss, quality, dri, seed0=1 + rank * 1000003, nthreads=gen_threads)
+    buf, sizes, stride = jpegsynth.encode_batch(n_images, width, height, ss, quality, dri, seed0=sharding.rank_seed_base(rank), nthreads=gen_threads)
     t_gen = time.perf_counter() - t0
     files = [buf[i * stride:i * stride + int(sizes[i])] for i in range(n_images)]
     log(f"[rank {rank}] generated {n_images} x {width}x{height} {ss} Q{quality} DRI={dri}: {sizes.sum() / 1e6:.1f} MB in {t_gen:.1f} s ({gen_threads} threads)")
@@ -170,12 +171,8 @@ def main():
     stage = batch.stage_ms()  # HIP-event averages over exactly the timed steps, on the stream the kernels ran on
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    pixels_per_step = n_images * width * height * n_gpus
-    value = pixels_per_step * args.steps / elapsed / 1e6
+        elapsed = sharding.max_over_ranks(dist, elapsed, device="cuda")
+    value = sharding.aggregate_throughput(n_images * width * height, n_gpus, args.steps, elapsed)
 
     if rank == 0:
         # dominant kernel: idct_output_kernel.  Algorithmic bytes per launch: 128 B of int16 coefficients
