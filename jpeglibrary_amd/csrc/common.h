@@ -65,7 +65,7 @@ struct alignas(16) DevScan {
     uint8_t blk_y[kMaxBlocksPerMcu];
     uint16_t huff_pool[kMaxHuffSlots];   // pool indices of the tables this scan stages (0xFFFF = unused)
     uint16_t quant_pool[kMaxScanComponents];
-    uint32_t pad1[2];
+    uint64_t tok_base;   // first token slot of this scan in the token buffer (token pipeline, see K2T/K3T)
 };
 static_assert(sizeof(DevScan) % 16 == 0, "DevScan must be a multiple of 16 bytes");
 
@@ -91,6 +91,13 @@ struct IdctWork {
 };
 
 constexpr uint32_t kNoError = 0xFFFFFFFFu;
+
+// Token pipeline.  A token is one decoded coefficient: value (int16) | zig-zag index << 16 | kTokLast on the last
+// token of its block.  Every block has at least its DC token.  Interval k of a scan owns the token slots
+// [tok_base + kTokensPerByte * start_k, ...): every token consumes at least 2 bits of entropy data, so
+// kTokensPerByte = 4 slots per compressed byte can never overflow into the next interval's region.
+constexpr uint32_t kTokLast = 0x80000000u;
+constexpr uint32_t kTokensPerByte = 4;
 
 // detail codes (mirror jpgpu_detail in include/jpgpu.h)
 enum Detail : uint32_t {

@@ -8,6 +8,7 @@
 #include "device_batch.h"
 
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -39,7 +40,7 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_tokens_, &d_blk_tok_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
@@ -195,6 +196,11 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     status_valid_ = false;
     ev_used_ = 0;
+    token_buffers_ready_ = false;
+    {
+        const char *env = getenv("JPGPU_PIPELINE");
+        use_tokens_ = (env && strcmp(env, "tokens") == 0);  // default: coefficient pipeline (faster as of r1c)
+    }
 
     // ---- input layout
     uint64_t in_off = 256;
@@ -249,6 +255,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             s.data_off = img.file_offset + job_entropy_off_[j];
             s.data_len = (uint32_t)(file_len[ii] - job_entropy_off_[j]);
             s.coef_off = coef_off;
+            s.tok_base = (uint64_t)kTokensPerByte * s.data_off;  // interval slices are addressed by compressed byte offset
             s.out_off = img.out_offset;
             s.dri = g.restart_interval;
             s.mcus_per_line = (uint32_t)g.mcus_per_line;
@@ -392,6 +399,37 @@ int DeviceBatch::run_idct() {
     return e == hipSuccess ? JPGPU_OK : hip_fail(e, "idct_output_kernel");
 }
 
+// The token buffer is sized from the compressed bytes (kTokensPerByte slots of 4 B per input byte) and only allocated
+// when the token pipeline runs.
+int DeviceBatch::ensure_token_buffers() {
+    if (token_buffers_ready_) return JPGPU_OK;
+    hipError_t e = d_tokens_.reserve((size_t)input_bytes_ * kTokensPerByte * sizeof(uint32_t) + 4096);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(tokens)");
+    e = d_blk_tok_.reserve((size_t)total_blocks_ * sizeof(uint32_t) + 256);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(block token offsets)");
+    token_buffers_ready_ = true;
+    return JPGPU_OK;
+}
+
+int DeviceBatch::run_huffman_tokens() {
+    status_valid_ = false;
+    int rc = ensure_token_buffers();
+    if (rc != JPGPU_OK) return rc;
+    hipError_t e = launch_huffman_tokens(ctx_->stream, (const uint8_t *)d_input_.ptr, (const DevScan *)d_scans_.ptr,
+                                         (const HuffWork *)d_huff_work_.ptr, n_huff_work_, (const uint32_t *)d_ends_.ptr,
+                                         (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (uint32_t *)d_tokens_.ptr,
+                                         (uint32_t *)d_blk_tok_.ptr, n_huff_slots_);
+    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "huffman_tokens_kernel");
+}
+int DeviceBatch::run_idct_tokens() {
+    int rc = ensure_token_buffers();
+    if (rc != JPGPU_OK) return rc;
+    hipError_t e = launch_idct_tokens(ctx_->stream, (const uint32_t *)d_tokens_.ptr, (const uint32_t *)d_blk_tok_.ptr, (const DevScan *)d_scans_.ptr,
+                                      (const IdctWork *)d_idct_work_.ptr, idct_class_begin_, (const DevScanStatus *)d_status_.ptr,
+                                      (const DevQuantTable *)d_quant_pool_.ptr, (uint8_t *)d_out_.ptr, format_);
+    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "idct_tokens_kernel");
+}
+
 int DeviceBatch::decode() {
     hipError_t e = hipSetDevice(ctx_->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
@@ -407,9 +445,9 @@ int DeviceBatch::decode() {
     (void)hipEventRecord(ev[0], ctx_->stream);
     if ((rc = run_marker_index()) != JPGPU_OK) return rc;
     (void)hipEventRecord(ev[1], ctx_->stream);
-    if ((rc = run_huffman()) != JPGPU_OK) return rc;
+    if ((rc = use_tokens_ ? run_huffman_tokens() : run_huffman()) != JPGPU_OK) return rc;
     (void)hipEventRecord(ev[2], ctx_->stream);
-    if ((rc = run_idct()) != JPGPU_OK) return rc;
+    if ((rc = use_tokens_ ? run_idct_tokens() : run_idct()) != JPGPU_OK) return rc;
     (void)hipEventRecord(ev[3], ctx_->stream);
     ev_used_ += 4;
     return JPGPU_OK;

@@ -57,7 +57,9 @@ class DeviceBatch {
     int run_marker_index();
     int run_huffman();
     int run_idct();
-    int decode();  // all three, with stage events
+    int run_huffman_tokens();  // token pipeline (K2T)
+    int run_idct_tokens();     // token pipeline (K3T)
+    int decode();  // marker index + the selected pipeline, with stage events
     int sync();
 
     int size() const { return (int)images_.size(); }
@@ -102,6 +104,10 @@ class DeviceBatch {
     uint64_t total_blocks_ = 0, out_bytes_ = 0, input_bytes_ = 0, compressed_bytes_ = 0, total_pixels_ = 0;
     uint32_t total_ends_ = 0;
 
+    bool use_tokens_ = false;  // JPGPU_PIPELINE=tokens selects the token pipeline (K2T + K3T) in decode()
+    bool token_buffers_ready_ = false;
+    int ensure_token_buffers();
+    DevBuffer d_tokens_, d_blk_tok_;
     DevBuffer d_input_, d_scans_, d_status_, d_ends_, d_huff_pool_, d_quant_pool_, d_huff_work_, d_idct_work_, d_coefs_, d_out_;
     // stage events of every decode() since the last stage_ms() query (4 events per decode)
     std::vector<hipEvent_t> ev_pool_;

@@ -28,4 +28,12 @@ hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *
                        const int class_begin[kNumIdctLayoutClasses + 1], const DevScanStatus *status,
                        const DevQuantTable *quant_pool, uint8_t *out, int format);
 
+// token pipeline (K2T / K3T)
+hipError_t launch_huffman_tokens(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
+                                 const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, uint32_t *tokens,
+                                 uint32_t *blk_tok, int n_slots);
+hipError_t launch_idct_tokens(hipStream_t stream, const uint32_t *tokens, const uint32_t *blk_tok, const DevScan *scans,
+                              const IdctWork *work, const int class_begin[kNumIdctLayoutClasses + 1], const DevScanStatus *status,
+                              const DevQuantTable *quant_pool, uint8_t *out, int format);
+
 }  // namespace jpgpu

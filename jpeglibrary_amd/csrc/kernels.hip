@@ -177,7 +177,11 @@ __global__ __launch_bounds__(kScanThreads) void marker_index_kernel(const uint8_
         st.n_ends = found;
         st.terminator = ((uint32_t)last_pos + 1 < len) ? p[last_pos + 1] : 0;
         st.first_error = kNoError;
-        st.decoded_mcus = s.total_mcus;
+        // MCUs covered by the indexed intervals (the block-parallel stages never look past them)
+        {
+            const uint64_t covered = (uint64_t)found * (s.dri ? s.dri : s.total_mcus);
+            st.decoded_mcus = covered < s.total_mcus ? (uint32_t)covered : s.total_mcus;
+        }
         st.end_pos = (uint32_t)last_pos;
         st.pad[0] = st.pad[1] = st.pad[2] = 0;
         status[blockIdx.x] = st;
@@ -313,10 +317,19 @@ __device__ __forceinline__ LdsHuff lds_huff(const uint8_t *tabs, uint32_t slot) 
     return h;
 }
 
+__device__ __forceinline__ LdsHuff lds_huff16(const uint8_t *tabs, uint32_t off16) {
+    const uint8_t *t = tabs + off16 * 16;
+    LdsHuff h;
+    h.lut = reinterpret_cast<const uint16_t *>(t);
+    h.maxcode = reinterpret_cast<const uint16_t *>(t + offsetof(DevHuffTable, maxcode));
+    h.valoffset = t + offsetof(DevHuffTable, valoffset);
+    h.values = t + offsetof(DevHuffTable, values);
+    return h;
+}
+
 // DecodeHuffmanCode (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:81-88, JpegHuffmanDecodingTable.cs:73-113).
-// Returns the symbol, or -1 for "Invalid Huffman code encountered.".
-__device__ __forceinline__ int32_t decode_symbol(LaneBits &r, const LdsHuff &h) {
-    if (r.bits < 32) lb_refill(r);  // code (<= 16 bits) + magnitude (<= 16 bits) then need no second refill
+// Returns the symbol, or -1 for "Invalid Huffman code encountered.".  The caller has refilled the bit buffer.
+__device__ __forceinline__ int32_t decode_symbol_norefill(LaneBits &r, const LdsHuff &h) {
     const uint32_t code16 = lb_peek16(r);
     uint32_t e = h.lut[code16 >> (16 - kHuffLutBits)];
     uint32_t size = e >> 8, sym = e & 0xFF;
@@ -329,6 +342,11 @@ __device__ __forceinline__ int32_t decode_symbol(LaneBits &r, const LdsHuff &h) 
     const int32_t adv = (int32_t)size < r.bits ? (int32_t)size : r.bits;  // Math.Min(entry.CodeSize, bitsRead)
     r.bits -= adv;
     return (int32_t)sym;
+}
+
+__device__ __forceinline__ int32_t decode_symbol(LaneBits &r, const LdsHuff &h) {
+    if (r.bits < 32) lb_refill(r);  // code (<= 16 bits) + magnitude (<= 16 bits) then need no second refill
+    return decode_symbol_norefill(r, h);
 }
 
 // ReceiveAndExtend (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:100-115).  ok=false when bits are missing.
@@ -530,6 +548,186 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2T: Huffman parse to a token stream.  One lane per restart interval, lanes run FREE.
+//
+// K2 keeps the 64 lanes of a wave in lock-step per block (they share one LDS staging that is flushed per block), so
+// every block costs the wave the LONGEST of 64 symbol runs.  Here nothing is shared: each lane walks its whole interval
+// at its own pace and appends one 32-bit token per non-zero coefficient (plus the DC) to its private slice of the token
+// buffer, 16 bytes at a time, and records where every block's tokens start.  The wave finishes when its slowest lane
+// has consumed its interval (max of sums instead of sum of maxes).  Symbol decisions are the same code as K2.
+// ------------------------------------------------------------------------------------------------
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void huffman_tokens_kernel(const uint8_t *__restrict__ data,
+                                                                    const DevScan *__restrict__ scans,
+                                                                    const HuffWork *__restrict__ work,
+                                                                    const uint32_t *__restrict__ ends,
+                                                                    DevScanStatus *__restrict__ status,
+                                                                    const DevHuffTable *__restrict__ huff_pool,
+                                                                    uint32_t *__restrict__ tokens,
+                                                                    uint32_t *__restrict__ blk_tok, int n_slots) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *tabs = smem;  // n_slots * sizeof(DevHuffTable)
+    uint32_t *blk_info = reinterpret_cast<uint32_t *>(smem + (size_t)n_slots * sizeof(DevHuffTable));  // [kMaxBlocksPerMcu]
+
+    const HuffWork wk = work[blockIdx.x];
+    const DevScan &s = scans[wk.scan];
+    const uint32_t tid = threadIdx.x;
+
+    for (int slot = 0; slot < kMaxHuffSlots && slot < n_slots; slot++) {
+        const uint32_t pi = s.huff_pool[slot];
+        if (pi == 0xFFFF) continue;
+        const uint4 *src = reinterpret_cast<const uint4 *>(&huff_pool[pi]);
+        uint4 *dst = reinterpret_cast<uint4 *>(tabs + slot * sizeof(DevHuffTable));
+        for (uint32_t i = tid; i < sizeof(DevHuffTable) / 16; i += 64 * WAVES) dst[i] = src[i];
+    }
+    // per block-in-MCU: DC table offset | AC table offset << 12 | scan component << 24  (offsets in 16-byte units)
+    if (tid < kMaxBlocksPerMcu) {
+        const uint32_t ci = s.blk_comp[tid];
+        const uint32_t dc_off = s.comp[ci].dc_slot * (uint32_t)(sizeof(DevHuffTable) / 16);
+        const uint32_t ac_off = s.comp[ci].ac_slot * (uint32_t)(sizeof(DevHuffTable) / 16);
+        blk_info[tid] = dc_off | (ac_off << 12) | (ci << 24);
+    }
+    __syncthreads();
+
+    const DevScanStatus st = status[wk.scan];
+    const uint32_t n_ends = st.n_ends;
+    const uint32_t n_intervals = s.n_intervals;
+    const uint32_t total_mcus = s.total_mcus;
+    const uint32_t dri_eff = s.dri ? s.dri : total_mcus;
+    const uint32_t bpm = s.blocks_per_mcu;
+    const uint32_t interval = wk.first_interval + tid;
+    if (interval >= n_ends) return;  // nothing after the last barrier: lanes may leave
+    const uint32_t *ends_s = ends + s.ends_off;
+
+    const uint32_t mis = (uint32_t)(s.data_off & 15u);
+    const uint8_t *base16 = data + (s.data_off - mis);
+    const uint32_t start_rel = interval == 0 ? 0u : ends_s[interval - 1] + 2u;
+    LaneBits r;
+    lb_init(r, base16, mis + start_rel, mis + ends_s[interval], mis + s.data_len);
+    const bool closed_by_marker = r.end < r.limit;
+    const uint32_t my_mcus = (interval == n_intervals - 1) ? total_mcus - interval * dri_eff : dri_eff;
+    const uint32_t my_blocks = my_mcus * bpm;
+
+    uint32_t *tok = tokens + s.tok_base + (uint64_t)kTokensPerByte * start_rel;  // this lane's slice (16-byte aligned)
+    uint32_t *my_blk_tok = blk_tok + s.coef_off + (uint64_t)interval * dri_eff * bpm;
+    const uint32_t tok_rel0 = kTokensPerByte * start_rel;  // slot index relative to the scan's tok_base
+
+    int32_t pred0 = 0, pred1 = 0, pred2 = 0, pred3 = 0;  // DcPredictor per scan component
+    uint32_t err = 0;
+    uint32_t blk = 0, b_in_mcu = 0, k = 0;  // k == 0: the DC symbol of the block is pending
+    uint32_t info = blk_info[0];
+    uint32_t ntok = 0;          // tokens pushed so far
+    uint4 q = {0, 0, 0, 0};     // the last four pushed tokens, oldest in x
+    uint32_t pending = 0;       // most recent token, held back until we know whether it is the block's last
+    bool have_pending = false;
+    if (my_blocks) my_blk_tok[0] = tok_rel0;
+
+#define JPGPU_PUSH(t_)                                                        \
+    {                                                                         \
+        q.x = q.y;                                                            \
+        q.y = q.z;                                                            \
+        q.z = q.w;                                                            \
+        q.w = (t_);                                                           \
+        ntok++;                                                               \
+        if ((ntok & 3u) == 0) *reinterpret_cast<uint4 *>(tok + ntok - 4) = q; \
+    }
+
+    while (blk < my_blocks && err == 0) {
+        if (r.bits < 32) lb_refill(r);
+        const bool is_dc = (k == 0);
+        const LdsHuff h = lds_huff16(tabs, is_dc ? (info & 0xFFF) : ((info >> 12) & 0xFFF));
+        const int32_t sym = decode_symbol_norefill(r, h);
+        if (sym < 0) {
+            err = kDetailInvalidHuffmanCode;
+            break;
+        }
+        const int32_t rr = is_dc ? 0 : (sym >> 4);
+        const int32_t ss = is_dc ? sym : (sym & 15);
+        int32_t v = 0;
+        if (ss != 0) {
+            bool ok = true;
+            v = receive_extend(r, ss, ok);
+            if (!ok) {
+                err = (r.bits == 0 && closed_by_marker) ? kDetailMarkerInData : kDetailStreamEnded;
+                break;
+            }
+        }
+        if (is_dc) {
+            const uint32_t ci = info >> 24;
+            const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
+            v += pred;
+            if (ci == 0) pred0 = v;
+            else if (ci == 1) pred1 = v;
+            else if (ci == 2) pred2 = v;
+            else pred3 = v;
+        }
+        if (is_dc || ss != 0) {
+            uint32_t idx = is_dc ? 0u : (k + (uint32_t)rr);
+            idx = idx < 63u ? idx : 63u;  // Math.Min(i++, 63)
+            if (have_pending) JPGPU_PUSH(pending)
+            pending = ((uint32_t)v & 0xFFFFu) | (idx << 16);
+            have_pending = true;
+        }
+        // next position (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:199-221)
+        k = is_dc ? 1u : (ss != 0 ? k + (uint32_t)rr + 1u : (rr == 0 ? 64u : k + 16u));
+        if (k >= 64u) {
+            JPGPU_PUSH(pending | kTokLast)
+            have_pending = false;
+            blk++;
+            b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
+            k = 0;
+            if (blk < my_blocks) {
+                my_blk_tok[blk] = tok_rel0 + ntok;
+                info = blk_info[b_in_mcu];
+            }
+        }
+    }
+    // flush the partial quad
+    {
+        const uint32_t n = ntok & 3u;
+        uint32_t *dst = tok + (ntok & ~3u);
+        if (n == 1) dst[0] = q.w;
+        if (n == 2) {
+            dst[0] = q.z;
+            dst[1] = q.w;
+        }
+        if (n == 3) {
+            dst[0] = q.y;
+            dst[1] = q.z;
+            dst[2] = q.w;
+        }
+    }
+#undef JPGPU_PUSH
+
+    // restart check, identical to K2
+    uint32_t code = kNoError;
+    if (err != 0) {
+        code = (interval << 8) | err;
+    } else {
+        const bool needs_check = s.dri != 0 && (interval < n_intervals - 1 || s.restart_check_at_end);
+        if (needs_check) {
+            lb_refill(r);
+            const bool leftover = (r.bits - (r.bits & 7)) != 0 || r.pos < r.end;
+            uint32_t closing = 0xD0;
+            if (interval == n_ends - 1) closing = st.terminator;
+            if (leftover) {
+                code = (interval << 8) | kDetailExpectRestart;
+            } else if (closing == 0xD9) {
+                if (interval < n_intervals - 1) atomicMin(&status[wk.scan].decoded_mcus, (interval + 1) * dri_eff);
+            } else if ((closing & 0xF8) != 0xD0) {
+                code = (interval << 8) | kDetailExpectRestart;
+            }
+        }
+    }
+    if (code != kNoError) {
+        atomicMin(&status[wk.scan].first_error, code);
+        // blocks of a failing interval have no complete token run: keep the block-parallel stage away from them
+        if (err != 0) atomicMin(&status[wk.scan].decoded_mcus, interval * dri_eff);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3: dequantise + IDCT + level shift + block output.  One lane per block.
 // ------------------------------------------------------------------------------------------------
 
@@ -625,6 +823,101 @@ constexpr uint32_t kPxRowStride = kIdctThreads * 8;  // bytes between sample row
 
 // Output layout classes of the INTERLEAVED_U8 format (chosen per scan on the host, see idct_layout_class()).
 enum IdctLayout : int { kLayGeneric = 0, kLayYccH1V1 = 1, kLayYccH2V1 = 2, kLayYccH2V2 = 3, kLayGray = 4, kNumIdctLayouts = 5 };
+
+// Output assembly of the INTERLEAVED_U8 format from the LDS sample tile [8 rows][256 blocks][8 B] (phase C).
+// Shared by the coefficient pipeline (K3) and the token pipeline (K3T).
+template <int LAY>
+__device__ __forceinline__ void interleaved_output_from_tile(const uint8_t *sh_px, const DevScan &s, uint32_t tile_first, uint32_t n_mcu,
+                                                             uint32_t tid, bool have_block, const DevScanComponent &comp, uint32_t mcu_x,
+                                                             uint32_t mcu_y, uint32_t b, uint8_t *out) {
+    const uint32_t W = s.width, H = s.height, C = s.frame_components;
+    uint8_t *img = out + s.out_off;
+
+    if (LAY == kLayGeneric) {
+        // any component count / sampling: bytewise stores with WriteBlockSlow's replication
+        // (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:238-268) and the sink's clipping (x < W, y < H)
+        if (have_block) {
+            const uint32_t hs = comp.hs, vs = comp.vs;
+            const uint32_t x0 = (mcu_x * s.max_h + s.blk_x[b]) * 8, y0 = (mcu_y * s.max_v + s.blk_y[b]) * 8;
+            const uint32_t hshift = 31 - __builtin_clz(hs | 1), vshift = 31 - __builtin_clz(vs | 1);
+            for (uint32_t v = 0; v < vs; v++)
+                for (uint32_t i = 0; i < 8; i++) {
+                    const uint32_t y = y0 + 8 * v + i;
+                    if (y >= H) continue;
+                    const uint8_t *srow = sh_px + ((8 * v + i) >> vshift) * kPxRowStride + tid * 8;
+                    for (uint32_t h = 0; h < hs; h++)
+                        for (uint32_t j = 0; j < 8; j++) {
+                            const uint32_t x = x0 + 8 * h + j;
+                            if (x < W) img[((size_t)y * W + x) * C + comp.component_index] = srow[(8 * h + j) >> hshift];
+                        }
+                }
+        }
+    } else {
+    // YCbCr fast paths: one task = one pixel row of one MCU (8*max_h pixels); consecutive lanes take consecutive MCUs of
+    // the same row, so a wave writes one contiguous run of the output row per store instruction group.
+    constexpr uint32_t max_h = (LAY == kLayYccH1V1) ? 1 : 2;
+    constexpr uint32_t max_v = (LAY == kLayYccH2V2) ? 2 : 1;
+    constexpr uint32_t rows_per_mcu = 8 * max_v;
+    constexpr uint32_t vshift = max_v >> 1;
+    constexpr uint32_t kbpm = max_h * max_v + 2;
+    const uint32_t n_tasks = rows_per_mcu * n_mcu;
+    for (uint32_t t = tid; t < n_tasks; t += kIdctThreads) {
+        const uint32_t row = t / n_mcu, m = t - row * n_mcu;
+        const uint32_t gm = tile_first + m;
+        const uint32_t gx = gm % s.mcus_per_line, gy = gm / s.mcus_per_line;
+        const uint32_t y = gy * rows_per_mcu + row;
+        if (y >= H) continue;
+        const uint8_t *yrow = sh_px + (row & 7) * kPxRowStride + (m * kbpm + (row >> 3) * max_h) * 8;
+        const uint8_t *crow = sh_px + (row >> vshift) * kPxRowStride + (m * kbpm + max_h * max_v) * 8;
+        if (max_h == 2) {
+            const uint4 yv = *reinterpret_cast<const uint4 *>(yrow);  // 16 luma samples (two adjacent blocks)
+            const uint4 cv = *reinterpret_cast<const uint4 *>(crow);  // 8 Cb (x,y) + 8 Cr (z,w)
+            const uint32_t cc0 = pick4(cv.x, cv.z, JPGPU_SEL(0, 4, 1, 5)), cc1 = pick4(cv.x, cv.z, JPGPU_SEL(2, 6, 3, 7));
+            const uint32_t cc2 = pick4(cv.y, cv.w, JPGPU_SEL(0, 4, 1, 5)), cc3 = pick4(cv.y, cv.w, JPGPU_SEL(2, 6, 3, 7));
+            uint4 o0, o1, o2;
+            o0.x = pick4(yv.x, cc0, JPGPU_SEL(0, 4, 5, 1));
+            o0.y = pick4(yv.x, cc0, JPGPU_SEL(4, 5, 2, 6));
+            o0.z = pick4(yv.x, cc0, JPGPU_SEL(7, 3, 6, 7));
+            o0.w = pick4(yv.y, cc1, JPGPU_SEL(0, 4, 5, 1));
+            o1.x = pick4(yv.y, cc1, JPGPU_SEL(4, 5, 2, 6));
+            o1.y = pick4(yv.y, cc1, JPGPU_SEL(7, 3, 6, 7));
+            o1.z = pick4(yv.z, cc2, JPGPU_SEL(0, 4, 5, 1));
+            o1.w = pick4(yv.z, cc2, JPGPU_SEL(4, 5, 2, 6));
+            o2.x = pick4(yv.z, cc2, JPGPU_SEL(7, 3, 6, 7));
+            o2.y = pick4(yv.w, cc3, JPGPU_SEL(0, 4, 5, 1));
+            o2.z = pick4(yv.w, cc3, JPGPU_SEL(4, 5, 2, 6));
+            o2.w = pick4(yv.w, cc3, JPGPU_SEL(7, 3, 6, 7));
+            uint4 *dst = reinterpret_cast<uint4 *>(img + ((size_t)y * W + gx * 16) * 3);
+            dst[0] = o0;
+            dst[1] = o1;
+            dst[2] = o2;
+        } else {
+            const uint2 yv = *reinterpret_cast<const uint2 *>(yrow);
+            const uint2 bv = *reinterpret_cast<const uint2 *>(crow);
+            const uint2 rv = *reinterpret_cast<const uint2 *>(crow + 8);
+            uint2 o0, o1, o2;
+            {
+                const uint32_t lo = pick4(bv.x, rv.x, JPGPU_SEL(0, 4, 1, 5)), hi = pick4(bv.x, rv.x, JPGPU_SEL(2, 6, 3, 7));
+                const uint32_t mid = pick4(lo, hi, JPGPU_SEL(2, 3, 4, 5));
+                o0.x = pick4(yv.x, lo, JPGPU_SEL(0, 4, 5, 1));
+                o0.y = pick4(yv.x, mid, JPGPU_SEL(4, 5, 2, 6));
+                o1.x = pick4(yv.x, hi, JPGPU_SEL(5, 3, 6, 7));
+            }
+            {
+                const uint32_t lo = pick4(bv.y, rv.y, JPGPU_SEL(0, 4, 1, 5)), hi = pick4(bv.y, rv.y, JPGPU_SEL(2, 6, 3, 7));
+                const uint32_t mid = pick4(lo, hi, JPGPU_SEL(2, 3, 4, 5));
+                o1.y = pick4(yv.y, lo, JPGPU_SEL(0, 4, 5, 1));
+                o2.x = pick4(yv.y, mid, JPGPU_SEL(4, 5, 2, 6));
+                o2.y = pick4(yv.y, hi, JPGPU_SEL(5, 3, 6, 7));
+            }
+            uint2 *dst = reinterpret_cast<uint2 *>(img + ((size_t)y * W + gx * 8) * 3);
+            dst[0] = o0;
+            dst[1] = o1;
+            dst[2] = o2;
+        }
+    }
+    }  // YCbCr fast paths
+}
 
 // Each workgroup walks a run of consecutive tiles (kIdctThreads / blocks_per_mcu MCUs each) of one scan.
 // Pipeline per tile:  lanes dequantise their block out of the LDS staging into registers -> barrier -> the staging is
@@ -758,93 +1051,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 2)) void 
     __builtin_amdgcn_s_barrier();
     synced = true;
 
-    const uint32_t W = s.width, H = s.height, C = s.frame_components;
-    uint8_t *img = out + s.out_off;
-
-    if (LAY == kLayGeneric) {
-        // any component count / sampling: bytewise stores with WriteBlockSlow's replication
-        // (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:238-268) and the sink's clipping (x < W, y < H)
-        if (have_block) {
-            const uint32_t hs = comp.hs, vs = comp.vs;
-            const uint32_t x0 = (mcu_x * s.max_h + s.blk_x[b]) * 8, y0 = (mcu_y * s.max_v + s.blk_y[b]) * 8;
-            const uint32_t hshift = 31 - __builtin_clz(hs | 1), vshift = 31 - __builtin_clz(vs | 1);
-            for (uint32_t v = 0; v < vs; v++)
-                for (uint32_t i = 0; i < 8; i++) {
-                    const uint32_t y = y0 + 8 * v + i;
-                    if (y >= H) continue;
-                    const uint8_t *srow = sh_px + ((8 * v + i) >> vshift) * kPxRowStride + tid * 8;
-                    for (uint32_t h = 0; h < hs; h++)
-                        for (uint32_t j = 0; j < 8; j++) {
-                            const uint32_t x = x0 + 8 * h + j;
-                            if (x < W) img[((size_t)y * W + x) * C + comp.component_index] = srow[(8 * h + j) >> hshift];
-                        }
-                }
-        }
-    } else {
-    // YCbCr fast paths: one task = one pixel row of one MCU (8*max_h pixels); consecutive lanes take consecutive MCUs of
-    // the same row, so a wave writes one contiguous run of the output row per store instruction group.
-    constexpr uint32_t max_h = (LAY == kLayYccH1V1) ? 1 : 2;
-    constexpr uint32_t max_v = (LAY == kLayYccH2V2) ? 2 : 1;
-    constexpr uint32_t rows_per_mcu = 8 * max_v;
-    constexpr uint32_t vshift = max_v >> 1;
-    constexpr uint32_t kbpm = max_h * max_v + 2;
-    const uint32_t n_tasks = rows_per_mcu * n_mcu;
-    for (uint32_t t = tid; t < n_tasks; t += kIdctThreads) {
-        const uint32_t row = t / n_mcu, m = t - row * n_mcu;
-        const uint32_t gm = tile_first + m;
-        const uint32_t gx = gm % s.mcus_per_line, gy = gm / s.mcus_per_line;
-        const uint32_t y = gy * rows_per_mcu + row;
-        if (y >= H) continue;
-        const uint8_t *yrow = sh_px + (row & 7) * kPxRowStride + (m * kbpm + (row >> 3) * max_h) * 8;
-        const uint8_t *crow = sh_px + (row >> vshift) * kPxRowStride + (m * kbpm + max_h * max_v) * 8;
-        if (max_h == 2) {
-            const uint4 yv = *reinterpret_cast<const uint4 *>(yrow);  // 16 luma samples (two adjacent blocks)
-            const uint4 cv = *reinterpret_cast<const uint4 *>(crow);  // 8 Cb (x,y) + 8 Cr (z,w)
-            const uint32_t cc0 = pick4(cv.x, cv.z, JPGPU_SEL(0, 4, 1, 5)), cc1 = pick4(cv.x, cv.z, JPGPU_SEL(2, 6, 3, 7));
-            const uint32_t cc2 = pick4(cv.y, cv.w, JPGPU_SEL(0, 4, 1, 5)), cc3 = pick4(cv.y, cv.w, JPGPU_SEL(2, 6, 3, 7));
-            uint4 o0, o1, o2;
-            o0.x = pick4(yv.x, cc0, JPGPU_SEL(0, 4, 5, 1));
-            o0.y = pick4(yv.x, cc0, JPGPU_SEL(4, 5, 2, 6));
-            o0.z = pick4(yv.x, cc0, JPGPU_SEL(7, 3, 6, 7));
-            o0.w = pick4(yv.y, cc1, JPGPU_SEL(0, 4, 5, 1));
-            o1.x = pick4(yv.y, cc1, JPGPU_SEL(4, 5, 2, 6));
-            o1.y = pick4(yv.y, cc1, JPGPU_SEL(7, 3, 6, 7));
-            o1.z = pick4(yv.z, cc2, JPGPU_SEL(0, 4, 5, 1));
-            o1.w = pick4(yv.z, cc2, JPGPU_SEL(4, 5, 2, 6));
-            o2.x = pick4(yv.z, cc2, JPGPU_SEL(7, 3, 6, 7));
-            o2.y = pick4(yv.w, cc3, JPGPU_SEL(0, 4, 5, 1));
-            o2.z = pick4(yv.w, cc3, JPGPU_SEL(4, 5, 2, 6));
-            o2.w = pick4(yv.w, cc3, JPGPU_SEL(7, 3, 6, 7));
-            uint4 *dst = reinterpret_cast<uint4 *>(img + ((size_t)y * W + gx * 16) * 3);
-            dst[0] = o0;
-            dst[1] = o1;
-            dst[2] = o2;
-        } else {
-            const uint2 yv = *reinterpret_cast<const uint2 *>(yrow);
-            const uint2 bv = *reinterpret_cast<const uint2 *>(crow);
-            const uint2 rv = *reinterpret_cast<const uint2 *>(crow + 8);
-            uint2 o0, o1, o2;
-            {
-                const uint32_t lo = pick4(bv.x, rv.x, JPGPU_SEL(0, 4, 1, 5)), hi = pick4(bv.x, rv.x, JPGPU_SEL(2, 6, 3, 7));
-                const uint32_t mid = pick4(lo, hi, JPGPU_SEL(2, 3, 4, 5));
-                o0.x = pick4(yv.x, lo, JPGPU_SEL(0, 4, 5, 1));
-                o0.y = pick4(yv.x, mid, JPGPU_SEL(4, 5, 2, 6));
-                o1.x = pick4(yv.x, hi, JPGPU_SEL(5, 3, 6, 7));
-            }
-            {
-                const uint32_t lo = pick4(bv.y, rv.y, JPGPU_SEL(0, 4, 1, 5)), hi = pick4(bv.y, rv.y, JPGPU_SEL(2, 6, 3, 7));
-                const uint32_t mid = pick4(lo, hi, JPGPU_SEL(2, 3, 4, 5));
-                o1.y = pick4(yv.y, lo, JPGPU_SEL(0, 4, 5, 1));
-                o2.x = pick4(yv.y, mid, JPGPU_SEL(4, 5, 2, 6));
-                o2.y = pick4(yv.y, hi, JPGPU_SEL(5, 3, 6, 7));
-            }
-            uint2 *dst = reinterpret_cast<uint2 *>(img + ((size_t)y * W + gx * 8) * 3);
-            dst[0] = o0;
-            dst[1] = o1;
-            dst[2] = o2;
-        }
-    }
-    }  // YCbCr fast paths
+    interleaved_output_from_tile<LAY>(sh_px, s, tile_first, n_mcu, tid, have_block, comp, mcu_x, mcu_y, b, out);
     }  // interleaved
     }  // u8 formats
 
@@ -853,6 +1060,133 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 2)) void 
         __builtin_amdgcn_s_barrier();
     }
   }  // tile loop
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3T: block-parallel token expansion + dequantise + IDCT + level shift + block output.  One lane per block.
+//
+// Each lane rebuilds its block from its token run (K2T) in a private 128-byte LDS row (zeroed, then one ds_write_b16
+// per token), reads it back for DequantizeBlockAndUnZigZag and runs the same register IDCT and output assembly as K3.
+// Nothing is shared between lanes until the sample tile, so there is no staging barrier and no coefficient buffer:
+// per 4K image the stage reads ~6 MB of tokens + 0.8 MB of offsets instead of 24.9 MB of coefficients.
+// ------------------------------------------------------------------------------------------------
+
+template <int FMT, int LAY>
+__global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void idct_tokens_kernel(
+    const uint32_t *__restrict__ tokens, const uint32_t *__restrict__ blk_tok, const DevScan *__restrict__ scans,
+    const IdctWork *__restrict__ work, const DevScanStatus *__restrict__ status, const DevQuantTable *__restrict__ quant_pool,
+    uint8_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t sh_all[kIdctThreads * 128 + kIdctThreads * 64 + kMaxScanComponents * 128];
+    uint8_t *sh = sh_all;
+    uint8_t *sh_px = sh_all + kIdctThreads * 128;
+    uint16_t(*sh_q)[64] = reinterpret_cast<uint16_t(*)[64]>(sh_all + kIdctThreads * 128 + kIdctThreads * 64);
+
+    const IdctWork wk = work[blockIdx.x];
+    const DevScan &s = scans[wk.scan];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bpm = s.blocks_per_mcu;
+    const uint32_t mcus_per_tile = kIdctThreads / bpm;
+    uint32_t decoded = status ? status[wk.scan].decoded_mcus : s.total_mcus;
+    if (decoded > s.total_mcus) decoded = s.total_mcus;
+    uint32_t range_end = wk.first_mcu + wk.n_mcus;
+    if (range_end > decoded) range_end = decoded;
+    if (wk.first_mcu >= range_end) return;
+
+    if (tid < (uint32_t)s.scan_components * 32) {
+        const uint32_t c = tid >> 5, i = tid & 31;
+        reinterpret_cast<uint32_t *>(sh_q[c])[i] =
+            reinterpret_cast<const uint32_t *>(quant_pool[s.quant_pool[s.comp[c].quant_slot]].q)[i];
+    }
+    __syncthreads();
+
+    const uint32_t mcu_local = tid / bpm;
+    const uint32_t b = tid - mcu_local * bpm;
+    const uint32_t ci = s.blk_comp[b < kMaxBlocksPerMcu ? b : 0];
+    const DevScanComponent comp = s.comp[ci];
+    const uint32_t *scan_tok = tokens + s.tok_base;
+    const uint32_t *scan_blk_tok = blk_tok + s.coef_off;
+    uint8_t *row = sh + tid * 128;          // this lane's coefficient row (same swizzle as K3's staging)
+    const uint32_t swz = (tid >> 1) & 7;
+
+    for (uint32_t tile_first = wk.first_mcu; tile_first < range_end; tile_first += mcus_per_tile) {
+        const uint32_t n_mcu = (range_end - tile_first) < mcus_per_tile ? (range_end - tile_first) : mcus_per_tile;
+        const uint32_t n_blk = n_mcu * bpm;
+        const uint32_t mcu = tile_first + mcu_local;
+        const bool have_block = tid < n_blk;
+        const uint32_t mcu_x = mcu % s.mcus_per_line, mcu_y = mcu / s.mcus_per_line;
+
+        float f[64];
+        if (have_block) {
+            // token run of this block: first two quads unconditionally, the rest (rare) in a loop
+            const uint32_t off = scan_blk_tok[(uint64_t)tile_first * bpm + tid];
+            const uint32_t *tp = scan_tok + off;
+            uint4 t0, t1;
+            __builtin_memcpy(&t0, tp, 16);      // 4-byte aligned 16-byte loads
+            __builtin_memcpy(&t1, tp + 4, 16);
+            const uint4 z = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(row)[i] = z;
+            bool last = false;
+#define JPGPU_APPLY(t_)                                                                                      \
+    if (!last) {                                                                                             \
+        const uint32_t tk_ = (t_);                                                                           \
+        const uint32_t idx_ = (tk_ >> 16) & 63u;                                                             \
+        *reinterpret_cast<int16_t *>(row + (((idx_ >> 3) ^ swz) * 16) + (idx_ & 7) * 2) = (int16_t)(tk_ & 0xFFFFu); \
+        last = (tk_ & kTokLast) != 0;                                                                        \
+    }
+            JPGPU_APPLY(t0.x) JPGPU_APPLY(t0.y) JPGPU_APPLY(t0.z) JPGPU_APPLY(t0.w)
+            JPGPU_APPLY(t1.x) JPGPU_APPLY(t1.y) JPGPU_APPLY(t1.z) JPGPU_APPLY(t1.w)
+            for (uint32_t n = 8; !last && n < 64; n++) JPGPU_APPLY(tp[n])
+#undef JPGPU_APPLY
+            block_dequant(row, swz, sh_q[ci], f);
+        }
+        int32_t px[64];
+        if (have_block) block_idct(f, (int32_t)s.level_shift, px);
+
+        if (FMT == kFmtPlanarI16) {
+            if (have_block) {
+                int16_t *plane = reinterpret_cast<int16_t *>(out + s.out_off + s.plane_off[ci]);
+                const uint32_t pitch = s.plane_pitch[ci];
+                const uint32_t x0 = (mcu_x * comp.h + s.blk_x[b]) * 8, y0 = (mcu_y * comp.v + s.blk_y[b]) * 8;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    uint4 v;
+                    v.x = (uint32_t)(px[r * 8 + 0] & 0xFFFF) | ((uint32_t)px[r * 8 + 1] << 16);
+                    v.y = (uint32_t)(px[r * 8 + 2] & 0xFFFF) | ((uint32_t)px[r * 8 + 3] << 16);
+                    v.z = (uint32_t)(px[r * 8 + 4] & 0xFFFF) | ((uint32_t)px[r * 8 + 5] << 16);
+                    v.w = (uint32_t)(px[r * 8 + 6] & 0xFFFF) | ((uint32_t)px[r * 8 + 7] << 16);
+                    *reinterpret_cast<uint4 *>(plane + (size_t)(y0 + r) * pitch + x0) = v;
+                }
+            }
+            continue;
+        }
+        uint2 rows[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            rows[r].x = pack4_u8(px[r * 8 + 0], px[r * 8 + 1], px[r * 8 + 2], px[r * 8 + 3]);
+            rows[r].y = pack4_u8(px[r * 8 + 4], px[r * 8 + 5], px[r * 8 + 6], px[r * 8 + 7]);
+        }
+        if (FMT == kFmtPlanarU8 || (FMT == kFmtInterleavedU8 && LAY == kLayGray)) {
+            if (have_block) {
+                const bool gray = (FMT == kFmtInterleavedU8);
+                uint8_t *plane = out + s.out_off + (gray ? 0 : s.plane_off[ci]);
+                const uint32_t pitch = gray ? s.width : s.plane_pitch[ci];
+                const uint32_t x0 = (mcu_x * comp.h + s.blk_x[b]) * 8, y0 = (mcu_y * comp.v + s.blk_y[b]) * 8;
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+                    if (!gray || y0 + r < s.height) *reinterpret_cast<uint2 *>(plane + (size_t)(y0 + r) * pitch + x0) = rows[r];
+            }
+            continue;
+        }
+        // interleaved u8: sample tile in LDS, then the shared output assembly
+        if (have_block) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(sh_px + r * kPxRowStride + tid * 8) = rows[r];
+        }
+        __syncthreads();
+        interleaved_output_from_tile<LAY>(sh_px, s, tile_first, n_mcu, tid, have_block, comp, mcu_x, mcu_y, b, out);
+        __syncthreads();  // the tile is rewritten by the next iteration
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -904,6 +1238,50 @@ hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *
             case kLayYccH2V2: launch_idct_one<kFmtInterleavedU8, kLayYccH2V2>(stream, coefs, scans, w, n, status, quant_pool, out); break;
             case kLayGray: launch_idct_one<kFmtInterleavedU8, kLayGray>(stream, coefs, scans, w, n, status, quant_pool, out); break;
             default: launch_idct_one<kFmtInterleavedU8, kLayGeneric>(stream, coefs, scans, w, n, status, quant_pool, out); break;
+            }
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_huffman_tokens(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
+                                 const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, uint32_t *tokens,
+                                 uint32_t *blk_tok, int n_slots) {
+    if (n_work <= 0) return hipSuccess;
+    const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kMaxBlocksPerMcu * sizeof(uint32_t);
+    hipLaunchKernelGGL(huffman_tokens_kernel<kHuffWaves>, dim3(n_work), dim3(64 * kHuffWaves), lds, stream, data, scans, work, ends,
+                       status, huff_pool, tokens, blk_tok, n_slots);
+    return hipGetLastError();
+}
+
+template <int FMT, int LAY>
+static void launch_idct_tokens_one(hipStream_t stream, const uint32_t *tokens, const uint32_t *blk_tok, const DevScan *scans,
+                                   const IdctWork *work, int n_work, const DevScanStatus *status, const DevQuantTable *quant_pool,
+                                   uint8_t *out) {
+    hipLaunchKernelGGL((idct_tokens_kernel<FMT, LAY>), dim3(n_work), dim3(kIdctThreads), 0, stream, tokens, blk_tok, scans, work, status,
+                       quant_pool, out);
+}
+
+hipError_t launch_idct_tokens(hipStream_t stream, const uint32_t *tokens, const uint32_t *blk_tok, const DevScan *scans,
+                              const IdctWork *work, const int class_begin[kNumIdctLayoutClasses + 1], const DevScanStatus *status,
+                              const DevQuantTable *quant_pool, uint8_t *out, int format) {
+    for (int c = 0; c < kNumIdctLayoutClasses; c++) {
+        const int n = class_begin[c + 1] - class_begin[c];
+        if (n <= 0) continue;
+        const IdctWork *w = work + class_begin[c];
+        if (format == kFmtPlanarI16) {
+            launch_idct_tokens_one<kFmtPlanarI16, kLayGeneric>(stream, tokens, blk_tok, scans, w, n, status, quant_pool, out);
+        } else if (format == kFmtPlanarU8) {
+            launch_idct_tokens_one<kFmtPlanarU8, kLayGeneric>(stream, tokens, blk_tok, scans, w, n, status, quant_pool, out);
+        } else {
+            switch (c) {
+            case kLayYccH1V1: launch_idct_tokens_one<kFmtInterleavedU8, kLayYccH1V1>(stream, tokens, blk_tok, scans, w, n, status, quant_pool, out); break;
+            case kLayYccH2V1: launch_idct_tokens_one<kFmtInterleavedU8, kLayYccH2V1>(stream, tokens, blk_tok, scans, w, n, status, quant_pool, out); break;
+            case kLayYccH2V2: launch_idct_tokens_one<kFmtInterleavedU8, kLayYccH2V2>(stream, tokens, blk_tok, scans, w, n, status, quant_pool, out); break;
+            case kLayGray: launch_idct_tokens_one<kFmtInterleavedU8, kLayGray>(stream, tokens, blk_tok, scans, w, n, status, quant_pool, out); break;
+            default: launch_idct_tokens_one<kFmtInterleavedU8, kLayGeneric>(stream, tokens, blk_tok, scans, w, n, status, quant_pool, out); break;
             }
         }
         const hipError_t e = hipGetLastError();
