@@ -66,6 +66,9 @@ struct alignas(16) DevScan {
     uint16_t huff_pool[kMaxHuffSlots];   // pool indices of the tables this scan stages (0xFFFF = unused)
     uint16_t quant_pool[kMaxScanComponents];
     uint64_t tok_base;   // first token slot of this scan in the token buffer (token pipeline, see K2T/K3T)
+    uint32_t chunk_off;  // first entry of this scan in the chunk-summary array (K1)
+    uint32_t n_chunks;   // 4 KiB chunks covering the entropy segment (from its 16-byte aligned base)
+    uint32_t pad2[2];
 };
 static_assert(sizeof(DevScan) % 16 == 0, "DevScan must be a multiple of 16 bytes");
 
@@ -83,6 +86,16 @@ struct alignas(16) DevScanStatus {
 struct HuffWork {
     uint32_t scan;            // scan job index
     uint32_t first_interval;  // first restart interval handled by this workgroup
+};
+struct ChunkWork {
+    uint32_t scan;
+    uint32_t chunk;
+};
+struct ChunkSum {
+    uint32_t rst_cnt;     // RSTn markers whose FF lies in the chunk
+    uint32_t keep_cnt;    // bytes the chunk contributes to the unstuffed copy (markers count 2)
+    uint32_t first_term;  // raw offset of the first non-RST marker in the chunk, 0xFFFFFFFF = none
+    uint32_t pad;
 };
 struct IdctWork {
     uint32_t scan;

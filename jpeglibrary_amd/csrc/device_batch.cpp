@@ -40,7 +40,7 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_tokens_, &d_blk_tok_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_chunk_work_, &d_chunk_sums_, &d_tokens_, &d_blk_tok_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
@@ -215,6 +215,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     quant_pool_.clear();
     h_scans_.assign(jobs_.size(), DevScan());
     std::vector<HuffWork> huff_work;
+    std::vector<ChunkWork> chunk_work;
     std::vector<IdctWork> idct_work;
     std::vector<IdctWork> idct_work_by_class[kNumIdctLayoutClasses];
     uint64_t out_off = 0, coef_off = 0;
@@ -265,6 +266,10 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             if (s.total_mcus == 0) s.n_intervals = 0;
             s.ends_off = ends_off;
             ends_off += s.n_intervals;
+            s.chunk_off = (uint32_t)chunk_work.size();
+            s.n_chunks = (uint32_t)(((uint64_t)s.data_len + (s.data_off & 15u) + kMarkerChunkBytes - 1) / kMarkerChunkBytes);
+            if (s.n_chunks == 0) s.n_chunks = 1;
+            for (uint32_t c = 0; c < s.n_chunks; c++) chunk_work.push_back({(uint32_t)j, c});
             s.image_index = (uint32_t)ii;
             s.level_shift = (uint32_t)g.level_shift;
             s.width = g.frame.samples_per_line;
@@ -316,6 +321,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     out_bytes_ = out_off;
     total_ends_ = ends_off;
     n_huff_work_ = (int)huff_work.size();
+    n_chunk_work_ = (int)chunk_work.size();
     idct_class_begin_[0] = 0;
     for (int c = 0; c < kNumIdctLayoutClasses; c++) {
         idct_work.insert(idct_work.end(), idct_work_by_class[c].begin(), idct_work_by_class[c].end());
@@ -344,8 +350,12 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_huff_pool_, huff_pool_.data(), huff_pool_.size() * sizeof(DevHuffTable), 0},
         {&d_quant_pool_, quant_pool_.data(), quant_pool_.size() * sizeof(DevQuantTable), 0},
         {&d_huff_work_, huff_work.data(), huff_work.size() * sizeof(HuffWork), 0},
+        {&d_chunk_work_, chunk_work.data(), chunk_work.size() * sizeof(ChunkWork), 0},
+        {&d_chunk_sums_, nullptr, 0, chunk_work.size() * sizeof(ChunkSum) + 256},
         {&d_idct_work_, idct_work.data(), idct_work.size() * sizeof(IdctWork), 0},
         {&d_ends_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},
+        {&d_ends_u_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},
+        {&d_unstuffed_, nullptr, 0, (size_t)input_bytes_},
         {&d_coefs_, nullptr, 0, (size_t)total_blocks_ * 128 + (size_t)kIdctBlocksPerWg * 128 + 256},  // + one tile of slack (IDCT DMA reads whole tiles)
         {&d_out_, nullptr, 0, (size_t)out_bytes_ + 256},
         {&d_input_, nullptr, 0, (size_t)input_bytes_},
@@ -381,14 +391,16 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
 
 int DeviceBatch::run_marker_index() {
     status_valid_ = false;
-    hipError_t e = launch_marker_index(ctx_->stream, (const uint8_t *)d_input_.ptr, (const DevScan *)d_scans_.ptr, (int)jobs_.size(),
-                                       (uint32_t *)d_ends_.ptr, (DevScanStatus *)d_status_.ptr);
+    hipError_t e = launch_marker_index(ctx_->stream, (const uint8_t *)d_input_.ptr, (const DevScan *)d_scans_.ptr,
+                                       (const ChunkWork *)d_chunk_work_.ptr, n_chunk_work_, (ChunkSum *)d_chunk_sums_.ptr,
+                                       (uint32_t *)d_ends_.ptr, (DevScanStatus *)d_status_.ptr, (uint8_t *)d_unstuffed_.ptr,
+                                       (uint32_t *)d_ends_u_.ptr);
     return e == hipSuccess ? JPGPU_OK : hip_fail(e, "marker_index_kernel");
 }
 int DeviceBatch::run_huffman() {
     status_valid_ = false;
-    hipError_t e = launch_huffman(ctx_->stream, (const uint8_t *)d_input_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_huff_work_.ptr,
-                                  n_huff_work_, (const uint32_t *)d_ends_.ptr, (DevScanStatus *)d_status_.ptr,
+    hipError_t e = launch_huffman(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_huff_work_.ptr,
+                                  n_huff_work_, (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr,
                                   (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_);
     return e == hipSuccess ? JPGPU_OK : hip_fail(e, "huffman_decode_kernel");
 }
@@ -415,8 +427,8 @@ int DeviceBatch::run_huffman_tokens() {
     status_valid_ = false;
     int rc = ensure_token_buffers();
     if (rc != JPGPU_OK) return rc;
-    hipError_t e = launch_huffman_tokens(ctx_->stream, (const uint8_t *)d_input_.ptr, (const DevScan *)d_scans_.ptr,
-                                         (const HuffWork *)d_huff_work_.ptr, n_huff_work_, (const uint32_t *)d_ends_.ptr,
+    hipError_t e = launch_huffman_tokens(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr,
+                                         (const HuffWork *)d_huff_work_.ptr, n_huff_work_, (const uint32_t *)d_ends_u_.ptr,
                                          (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (uint32_t *)d_tokens_.ptr,
                                          (uint32_t *)d_blk_tok_.ptr, n_huff_slots_);
     return e == hipSuccess ? JPGPU_OK : hip_fail(e, "huffman_tokens_kernel");

@@ -108,6 +108,9 @@ class DeviceBatch {
     bool token_buffers_ready_ = false;
     int ensure_token_buffers();
     DevBuffer d_tokens_, d_blk_tok_;
+    DevBuffer d_chunk_work_, d_chunk_sums_;
+    int n_chunk_work_ = 0;
+    DevBuffer d_unstuffed_, d_ends_u_;  // K1 output: entropy data as the bit reader sees it + interval ends in it
     DevBuffer d_input_, d_scans_, d_status_, d_ends_, d_huff_pool_, d_quant_pool_, d_huff_work_, d_idct_work_, d_coefs_, d_out_;
     // stage events of every decode() since the last stage_ms() query (4 events per decode)
     std::vector<hipEvent_t> ev_pool_;

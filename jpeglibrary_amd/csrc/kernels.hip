@@ -52,251 +52,346 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: marker index.  One workgroup per scan job.
+// K1: marker index + unstuffing.  One workgroup per scan job.
 //
 // In entropy-coded data 0xFF is always "fresh" (the second byte of FF00 / FFxx is never FF), so
 // "data[p]==FF && data[p+1] not in {00,FF}" identifies a marker without context -- the same rule
 // JpegBitReader.FillBuffer applies byte-serially (ref: JpegBitReader.cs:95-138).
 // ends[k] = offset of the FF that closes restart interval k.  Indexing stops at the first non-RST marker
 // (or at ANY marker when DRI == 0: the reference's bit reader stops feeding bits at every marker).
+//
+// The same pass writes `udata`, the entropy segment as the reference's bit reader sees it: stuffed zeros (FF00 -> FF)
+// and fill bytes (FFFF -> skip) removed, every marker replaced by FF FF (16 one-bits: exactly the ones-padding
+// PeekBits(16) applies when an interval runs dry, JpegBitReader.cs:163-167).  ends_u[k] = position in udata of the
+// FF FF pair closing interval k.  The Huffman kernels read udata with plain word loads: no per-byte FF handling in
+// their hot loops.  udata occupies the same byte range as the raw segment (it is never longer).
 // ------------------------------------------------------------------------------------------------
 
 constexpr int kScanThreads = 256;
 constexpr uint32_t kInf = 0xFFFFFFFFu;
+constexpr uint32_t kChunkBytes = kScanThreads * 16;  // one chunk = one 4 KiB tile, 16 bytes per lane
 
-__global__ __launch_bounds__(kScanThreads) void marker_index_kernel(const uint8_t *__restrict__ data,
-                                                                      const DevScan *__restrict__ scans,
-                                                                      uint32_t *__restrict__ ends,
-                                                                      DevScanStatus *__restrict__ status) {
-    const DevScan &s = scans[blockIdx.x];
+// Per-lane classification of 16 consecutive bytes of an entropy segment (bit j = byte off + j).
+struct ByteClass {
+    uint32_t w[5];      // the 16 bytes + the byte after them
+    uint32_t rst, term; // FF of an RSTn marker / of any other marker (every marker when DRI == 0)
+    uint32_t keep;      // bytes copied to udata as they are (markers' FF included, their code byte excluded)
+};
+
+__device__ __forceinline__ ByteClass classify16(const uint8_t *p, int64_t off, uint32_t len, bool any_marker_terminates) {
+    ByteClass c;
+    c.w[0] = c.w[1] = c.w[2] = c.w[3] = c.w[4] = 0;
+    c.rst = c.term = c.keep = 0;
+    uint32_t prev = 0;
+    if (off < (int64_t)len && off + 16 > 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(p + off);  // input buffer is padded: over-read is safe
+        c.w[0] = v.x;
+        c.w[1] = v.y;
+        c.w[2] = v.z;
+        c.w[3] = v.w;
+        c.w[4] = *(p + off + 16);
+        if (off >= 1) prev = *(p + off - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t b = (c.w[j >> 2] >> ((j & 3) * 8)) & 0xFF;
+        const uint32_t nb = (c.w[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) & 0xFF;
+        const uint32_t pv = j == 0 ? prev : ((c.w[(j - 1) >> 2] >> (((j - 1) & 3) * 8)) & 0xFF);
+        const int64_t pos = off + j;
+        const bool in_seg = pos >= 0 && pos < (int64_t)len;
+        const bool has_next = pos + 1 < (int64_t)len;
+        const bool prev_ff = pos >= 1 && pv == 0xFF;
+        const bool is_marker = in_seg && has_next && b == 0xFF && nb != 0x00 && nb != 0xFF;
+        const bool is_rst = is_marker && ((nb & 0xF8) == 0xD0) && !any_marker_terminates;
+        // not copied: the stuffed 00 of FF00, the first FF of FFFF, an FF that is the very last byte, and the code byte of
+        // a marker (the lane that owns the marker's FF writes FF FF for the pair)
+        const bool dropped = (prev_ff && b != 0xFF) || (b == 0xFF && (!has_next || nb == 0xFF));
+        c.rst |= (uint32_t)is_rst << j;
+        c.term |= (uint32_t)(is_marker && !is_rst) << j;
+        c.keep |= (uint32_t)(in_seg && !dropped) << j;
+    }
+    return c;
+}
+
+// workgroup-wide exclusive prefix + total of one value per lane
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *sh_wave /*[kScanThreads/64]*/, uint32_t &total) {
+    const uint32_t incl = wave_inclusive_scan(v);
+    const uint32_t wave = threadIdx.x >> 6;
+    __syncthreads();  // sh_wave may still be read from a previous call
+    if (lane_id() == 63) sh_wave[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    total = 0;
+#pragma unroll
+    for (int i = 0; i < kScanThreads / 64; i++) {
+        const uint32_t t = sh_wave[i];
+        if ((uint32_t)i < wave) base += t;
+        total += t;
+    }
+    return base + incl - v;
+}
+
+// K1a: per-chunk summary (RST markers, bytes udata will receive, first terminating marker).
+__global__ __launch_bounds__(kScanThreads) void marker_count_kernel(const uint8_t *__restrict__ data, const DevScan *__restrict__ scans,
+                                                                     const ChunkWork *__restrict__ work, ChunkSum *__restrict__ sums) {
+    const ChunkWork wk = work[blockIdx.x];
+    const DevScan &s = scans[wk.scan];
     const uint8_t *p = data + s.data_off;
+    const int32_t misalign = (int32_t)(s.data_off & 15u);
+    const int64_t off = -(int64_t)misalign + (int64_t)wk.chunk * kChunkBytes + (int64_t)threadIdx.x * 16;
+    const ByteClass c = classify16(p, off, s.data_len, s.dri == 0);
+    __shared__ uint32_t sh_a[kScanThreads / 64], sh_b[kScanThreads / 64];
+    __shared__ uint32_t sh_term;
+    if (threadIdx.x == 0) sh_term = kInf;
+    uint32_t rst_total, keep_total;
+    block_exclusive_scan(__builtin_popcount(c.rst), sh_a, rst_total);
+    block_exclusive_scan(__builtin_popcount(c.keep) + __builtin_popcount(c.rst | c.term), sh_b, keep_total);
+    uint32_t tpos = c.term ? (uint32_t)(off + __builtin_ctz(c.term)) : kInf;
+    tpos = wave_reduce_min(tpos);
+    if (lane_id() == 0 && tpos != kInf) atomicMin(&sh_term, tpos);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ChunkSum cs;
+        cs.rst_cnt = rst_total;
+        cs.keep_cnt = keep_total;
+        cs.first_term = sh_term;
+        cs.pad = 0;
+        sums[s.chunk_off + wk.chunk] = cs;
+    }
+}
+
+// K1b: every chunk derives its position in the scan from the summaries of the chunks before it and writes its part of
+// ends[] / ends_u[] / udata; the chunk that holds the closing entry also writes the scan status.
+__global__ __launch_bounds__(kScanThreads) void marker_write_kernel(const uint8_t *__restrict__ data, const DevScan *__restrict__ scans,
+                                                                     const ChunkWork *__restrict__ work, const ChunkSum *__restrict__ sums,
+                                                                     uint32_t *__restrict__ ends, DevScanStatus *__restrict__ status,
+                                                                     uint8_t *__restrict__ udata, uint32_t *__restrict__ ends_u) {
+    const ChunkWork wk = work[blockIdx.x];
+    const DevScan &s = scans[wk.scan];
+    const uint8_t *p = data + s.data_off;
+    uint8_t *up = udata + s.data_off;
     const uint32_t len = s.data_len;
     const uint32_t cap = s.n_intervals;
-    const bool any_marker_terminates = (s.dri == 0);
     uint32_t *out = ends + s.ends_off;
-
-    __shared__ uint32_t sh_wave_total[kScanThreads / 64];
-    __shared__ uint32_t sh_term;
-    __shared__ int32_t sh_last;
-
+    uint32_t *out_u = ends_u + s.ends_off;
+    const ChunkSum *cs = sums + s.chunk_off;
     const uint32_t tid = threadIdx.x;
-    const uint32_t wave = tid >> 6;
-    const int32_t misalign = (int32_t)(reinterpret_cast<uintptr_t>(p) & 15);
-    uint32_t found = 0;      // uniform
-    int32_t last_pos = -1;   // uniform: position of the last accepted entry
-    bool done = false;
 
-    for (int64_t tile = -(int64_t)misalign; tile < (int64_t)len && !done; tile += kScanThreads * 16) {
-        if (tid == 0) {
-            sh_term = kInf;
-            sh_last = -1;
+    __shared__ uint32_t sh_a[kScanThreads / 64], sh_b[kScanThreads / 64];
+    __shared__ uint32_t sh_red[3];
+    __shared__ __attribute__((aligned(16))) uint8_t sh_tile[kChunkBytes + 2 * kScanThreads + 16];
+
+    // summaries: RSTs / udata bytes of the chunks before this one, earliest terminator of the whole scan
+    if (tid < 3) sh_red[tid] = tid == 2 ? kInf : 0u;
+    __syncthreads();
+    {
+        uint32_t r = 0, k = 0, t = kInf;
+        for (uint32_t i = tid; i < s.n_chunks; i += kScanThreads) {
+            const ChunkSum c = cs[i];
+            if (i < wk.chunk) {
+                r += c.rst_cnt;
+                k += c.keep_cnt;
+            }
+            t = c.first_term < t ? c.first_term : t;
         }
-        __syncthreads();
-        const int64_t off = tile + (int64_t)tid * 16;  // relative to p; 16-byte aligned address
-        uint32_t w[5] = {0, 0, 0, 0, 0};
-        if (off < (int64_t)len) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(p + off);  // input buffer is padded: over-read is safe
-            w[0] = v.x;
-            w[1] = v.y;
-            w[2] = v.z;
-            w[3] = v.w;
-            w[4] = *(p + off + 16);
-        }
-        uint32_t rst_mask = 0, term_mask = 0;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const uint32_t b = (w[j >> 2] >> ((j & 3) * 8)) & 0xFF;
-            const uint32_t nb = (w[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) & 0xFF;
-            const int64_t pos = off + j;
-            const bool in_range = pos >= 0 && pos + 1 < (int64_t)len;
-            const bool is_marker = in_range && b == 0xFF && nb != 0x00 && nb != 0xFF;
-            const bool is_rst = is_marker && ((nb & 0xF8) == 0xD0) && !any_marker_terminates;
-            rst_mask |= (uint32_t)is_rst << j;
-            term_mask |= (uint32_t)(is_marker && !is_rst) << j;
+        for (int o = 32; o > 0; o >>= 1) {
+            r += __shfl_xor(r, o, 64);
+            k += __shfl_xor(k, o, 64);
         }
-        // earliest terminator in the tile
-        uint32_t tpos = term_mask ? (uint32_t)(off + __builtin_ctz(term_mask)) : kInf;
-        tpos = wave_reduce_min(tpos);
-        if (lane_id() == 0 && tpos != kInf) atomicMin(&sh_term, tpos);
-        __syncthreads();
-        const uint32_t term = sh_term;
-        // drop RST markers behind the terminator
-        if (term != kInf) {
+        t = wave_reduce_min(t);
+        if (lane_id() == 0) {
+            atomicAdd(&sh_red[0], r);
+            atomicAdd(&sh_red[1], k);
+            atomicMin(&sh_red[2], t);
+        }
+    }
+    __syncthreads();
+    const uint32_t rst_base = sh_red[0], ubase = sh_red[1], term = sh_red[2];
+    const int32_t misalign = (int32_t)(s.data_off & 15u);
+    const int64_t chunk_first = -(int64_t)misalign + (int64_t)wk.chunk * kChunkBytes;
+    if (term != kInf && (int64_t)term < chunk_first) return;  // the scan's data ended in an earlier chunk
+    if (rst_base >= cap && cap > 0) return;                    // every interval was closed in an earlier chunk
+    if (cap == 0) return;
+
+    const int64_t off = chunk_first + (int64_t)tid * 16;
+    ByteClass c = classify16(p, off, len, s.dri == 0);
+    const bool term_here = term != kInf && (int64_t)term < chunk_first + (int64_t)kChunkBytes;
+    if (term_here) {  // RST markers behind the terminator do not count
 #pragma unroll
-            for (int j = 0; j < 16; j++)
-                if ((int64_t)(off + j) > (int64_t)term) rst_mask &= ~(1u << j);
-        }
-        const uint32_t cnt = __builtin_popcount(rst_mask);
-        const uint32_t incl = wave_inclusive_scan(cnt);
-        if (lane_id() == 63) sh_wave_total[wave] = incl;
-        __syncthreads();
-        uint32_t base = found;
-        uint32_t tile_total = 0;
-#pragma unroll
-        for (int i = 0; i < kScanThreads / 64; i++) {
-            const uint32_t t = sh_wave_total[i];
-            if ((uint32_t)i < wave) base += t;
-            tile_total += t;
-        }
-        uint32_t idx = base + incl - cnt;
-        int32_t my_last = -1;
-        uint32_t m = rst_mask;
+        for (int j = 0; j < 16; j++)
+            if ((int64_t)(off + j) > (int64_t)term) c.rst &= ~(1u << j);
+    }
+    uint32_t rst_total;
+    const uint32_t rst_excl = block_exclusive_scan(__builtin_popcount(c.rst), sh_a, rst_total);
+    // closing entry of the scan, if it lies in this chunk: the cap-th RST, else the terminator
+    const bool cap_here = rst_base + rst_total >= cap;
+    __shared__ uint32_t sh_last;
+    if (tid == 0) sh_last = kInf;
+    __syncthreads();
+    {
+        uint32_t idx = rst_base + rst_excl;
+        uint32_t m = c.rst;
         while (m) {
             const int j = __builtin_ctz(m);
             m &= m - 1;
-            if (idx < cap) {
-                out[idx] = (uint32_t)(off + j);
-                my_last = (int32_t)(off + j);
-            }
+            if (idx == cap - 1) sh_last = (uint32_t)(off + j);
             idx++;
         }
-        my_last = (int32_t)wave_reduce_max_i(my_last);
-        if (lane_id() == 0 && my_last >= 0) atomicMax(&sh_last, my_last);
-        __syncthreads();
-        if (sh_last >= 0) last_pos = sh_last;
-        found += tile_total;
-        if (found >= cap) {
-            found = cap;
-            done = true;
-        } else if (term != kInf) {
-            if (tid == 0) out[found] = term;
-            last_pos = (int32_t)term;
-            found += 1;
-            done = true;
+    }
+    __syncthreads();
+    uint32_t last_pos = kInf;  // raw position of the closing entry when it is in this chunk
+    if (cap_here) last_pos = sh_last;
+    else if (term_here) last_pos = term;
+    // bytes behind the closing entry are not copied; markers behind it are not entries
+    if (last_pos != kInf) {
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if ((int64_t)(off + j) > (int64_t)last_pos) {
+                c.keep &= ~(1u << j);
+                c.rst &= ~(1u << j);
+                c.term &= ~(1u << j);
+            }
+    }
+    uint32_t markers = c.rst;  // entries this lane owns: every one becomes FF FF in udata
+    if (term_here && !cap_here && (int64_t)term >= off && (int64_t)term < off + 16) markers |= 1u << (uint32_t)((int64_t)term - off);
+    uint32_t keep_total;
+    const uint32_t keep_excl = block_exclusive_scan(__builtin_popcount(c.keep) + __builtin_popcount(markers), sh_b, keep_total);
+    {
+        uint32_t dst = keep_excl;  // chunk-relative udata position
+        uint32_t idx = rst_base + rst_excl;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (c.keep & (1u << j)) {
+                const uint32_t b = (c.w[j >> 2] >> ((j & 3) * 8)) & 0xFF;
+                sh_tile[dst] = (uint8_t)b;
+                if (markers & (1u << j)) {
+                    // interval end: FF FF in udata
+                    if (c.rst & (1u << j)) {
+                        if (idx < cap) {
+                            out[idx] = (uint32_t)(off + j);
+                            out_u[idx] = ubase + dst;
+                        }
+                        idx++;
+                    } else {
+                        out[rst_base + rst_total] = (uint32_t)(off + j);  // the terminator closes interval number (RSTs before it)
+                        out_u[rst_base + rst_total] = ubase + dst;
+                    }
+                    sh_tile[dst + 1] = 0xFF;
+                    dst += 2;
+                } else {
+                    dst += 1;
+                }
+            }
         }
-        __syncthreads();
     }
-    if (!done && found < cap) {
-        // data ran out without a terminating marker: pseudo entry at the end of the data
-        if (tid == 0) out[found] = len;
-        last_pos = (int32_t)len;
-        found += 1;
+    __syncthreads();
+    {
+        const uint32_t c0 = tid * 16;
+        for (uint32_t cbeg = c0; cbeg < keep_total; cbeg += kScanThreads * 16) {
+            if (cbeg + 16 <= keep_total) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(sh_tile + cbeg);
+                __builtin_memcpy(up + ubase + cbeg, &v, 16);  // unaligned 16-byte global store
+            } else {
+                for (uint32_t i = cbeg; i < keep_total; i++) up[ubase + i] = sh_tile[i];
+            }
+        }
     }
-    if (tid == 0) {
+    // scan status: written by the chunk that holds the closing entry, or by the last chunk when the data ran out
+    const bool ran_out = (term == kInf) && !cap_here && (wk.chunk == s.n_chunks - 1);
+    if (tid == 0 && (last_pos != kInf || ran_out)) {
         DevScanStatus st;
-        st.n_ends = found;
-        st.terminator = ((uint32_t)last_pos + 1 < len) ? p[last_pos + 1] : 0;
-        st.first_error = kNoError;
-        // MCUs covered by the indexed intervals (the block-parallel stages never look past them)
-        {
-            const uint64_t covered = (uint64_t)found * (s.dri ? s.dri : s.total_mcus);
-            st.decoded_mcus = covered < s.total_mcus ? (uint32_t)covered : s.total_mcus;
+        uint32_t found;
+        uint32_t lp;
+        if (cap_here) {
+            found = cap;
+            lp = last_pos;
+        } else if (term_here) {
+            found = rst_base + rst_total + 1;
+            lp = term;
+        } else {
+            // data ran out without a terminating marker: pseudo entry at the end of the data; pad udata with ones
+            found = rst_base + rst_total + 1;
+            lp = len;
+            out[rst_base + rst_total] = len;
+            out_u[rst_base + rst_total] = ubase + keep_total;
+            up[ubase + keep_total] = 0xFF;
+            up[ubase + keep_total + 1] = 0xFF;
         }
-        st.end_pos = (uint32_t)last_pos;
-        st.pad[0] = st.pad[1] = st.pad[2] = 0;
-        status[blockIdx.x] = st;
+        st.n_ends = found;
+        st.terminator = (lp + 1 < len) ? p[lp + 1] : 0;
+        st.first_error = kNoError;
+        const uint64_t covered = (uint64_t)found * (s.dri ? s.dri : s.total_mcus);
+        st.decoded_mcus = covered < s.total_mcus ? (uint32_t)covered : s.total_mcus;
+        st.end_pos = lp;
+        st.pad[0] = ubase + keep_total;
+        st.pad[1] = st.pad[2] = 0;
+        status[wk.scan] = st;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: Huffman MCU decode.  One lane per restart interval.
+// K2 / K2T: Huffman MCU decode.  One lane per restart interval.
 // ------------------------------------------------------------------------------------------------
 
-// Bit source of one lane == a fresh JpegBitReader positioned at the start of its restart interval
-// (ref: JpegBitReader.cs).  Byte range [pos, end) ends at the FF of the closing marker, so no marker can
-// occur inside; FF00 -> FF, FFFF -> skip one fill byte (ref: :95-138).
-//
-// Memory side: each lane streams its interval through a register window of two 16-byte aligned chunks
-// (w0 = current, w1 = prefetched next).  The load of the next chunk is issued a full chunk (~3 blocks of
-// decode work) before its first use, so HBM/L2 latency is off the critical path.  Bytes flow
-//   window dwords -> rq (64-bit little-endian raw-byte FIFO) -> buf (right-justified bit buffer, unstuffed).
-struct LaneBits {
-    const uint8_t *base16;  // 16-byte aligned base of the scan's entropy segment
-    uint32_t pos, end;      // raw byte offsets relative to base16 (next unread byte / closing marker)
-    uint32_t limit;         // end of the file's bytes (peek bound), relative to base16
-    uint64_t buf;           // right-justified bit buffer
-    int32_t bits;
-    uint64_t rq;            // raw bytes [pos, pos + rcnt), byte at pos in bits 0..7
-    int32_t rcnt;
-    uint4 w0, w1;           // bytes [wb, wb+16) and [wb+16, wb+32)
-    uint32_t wb;            // 16-byte aligned offset of w0
-    uint32_t wi;            // next dword of w0 to move into rq (0..4)
+// Bit source of one lane == a fresh JpegBitReader positioned at the start of its restart interval (ref: JpegBitReader.cs),
+// reading the UNSTUFFED copy written by K1: interval bytes [ustart, uend) followed by at least 16 one-bits.
+//   hi   : the next 32 bits of the stream (bit 31 first), always fully valid after ub_consume
+//   lo   : the bits after them, left aligned, lcnt of them valid (low bits zero)
+//   rem  : real data bits left in the interval == the reference's "bits available"; reads past them see the ones
+//          padding, which is exactly PeekBits(16)'s padding (JpegBitReader.cs:163-167); once rem is 0 every peek is 0xFFFF
+// Words come from a register queue of 2 x 16 bytes (qw current, nx prefetched a whole chunk ahead: memory latency is off
+// the critical path).  All arithmetic is 32-bit.
+struct UBits {
+    const uint8_t *p;  // address of the next 16-byte chunk to prefetch
+    uint4 qw, nx;
+    uint32_t qn;
+    uint32_t hi, lo;
+    int32_t lcnt;
+    int32_t rem;
 };
 
-__device__ __forceinline__ void lb_init(LaneBits &r, const uint8_t *base16, uint32_t pos, uint32_t end, uint32_t limit) {
-    r.base16 = base16;
-    r.pos = pos;
-    r.end = end;
-    r.limit = limit;
-    r.buf = 0;
-    r.bits = 0;
-    r.wb = pos & ~15u;
-    r.w0 = *reinterpret_cast<const uint4 *>(base16 + r.wb);        // the input buffer is padded: over-reads are safe
-    r.w1 = *reinterpret_cast<const uint4 *>(base16 + r.wb + 16);
-    const uint32_t di = (pos & 15u) >> 2;
-    const uint32_t d = di == 0 ? r.w0.x : (di == 1 ? r.w0.y : (di == 2 ? r.w0.z : r.w0.w));
-    const uint32_t sh = (pos & 3u) * 8;
-    r.rq = (uint64_t)(d >> sh);
-    r.rcnt = 4 - (int32_t)(pos & 3u);
-    r.wi = di + 1;
-}
-
-// rq <- next aligned dword of the window (rcnt <= 4 on entry)
-__device__ __forceinline__ void lb_topup(LaneBits &r) {
-    if (r.wi == 4) {
-        r.w0 = r.w1;
-        r.wb += 16;
-        r.w1 = *reinterpret_cast<const uint4 *>(r.base16 + r.wb + 16);  // prefetch: first used 16 bytes from now
-        r.wi = 0;
+__device__ __forceinline__ uint32_t ub_next_word(UBits &r) {
+    const uint32_t w = r.qw.x;
+    r.qw.x = r.qw.y;
+    r.qw.y = r.qw.z;
+    r.qw.z = r.qw.w;
+    r.qn--;
+    if (r.qn == 0) {
+        r.qw = r.nx;
+        __builtin_memcpy(&r.nx, r.p, 16);  // 4-byte aligned 16-byte load; buffers are padded
+        r.p += 16;
+        r.qn = 4;
     }
-    const uint32_t d = r.wi == 0 ? r.w0.x : (r.wi == 1 ? r.w0.y : (r.wi == 2 ? r.w0.z : r.w0.w));
-    r.wi++;
-    r.rq |= (uint64_t)d << (r.rcnt * 8);
-    r.rcnt += 4;
+    return __builtin_bswap32(w);
 }
 
-// FillBuffer (ref: JpegBitReader.cs:95-138) with this lane's own refill policy (decoded values do not depend on it).
-// Post-condition: bits > 32, or every byte before `end` has been consumed.
-__device__ __forceinline__ void lb_refill(LaneBits &r) {
-    while (r.bits <= 32 && r.pos < r.end) {
-        if (r.rcnt <= 4) lb_topup(r);
-        const uint32_t x = (uint32_t)r.rq;
-        // fast path: four data bytes, none of them 0xFF
-        const bool has_ff = (((~x) - 0x01010101u) & x & 0x80808080u) != 0;  // some byte of ~x is zero
-        if (!has_ff && r.pos + 4 <= r.end) {
-            r.buf = (r.buf << 32) | (uint64_t)__builtin_bswap32(x);
-            r.bits += 32;
-            r.pos += 4;
-            r.rq >>= 32;
-            r.rcnt -= 4;
-            continue;
-        }
-        // slow path: one byte (rcnt >= 5 here, so the byte after an FF is available)
-        uint32_t b = x & 0xFFu;
-        if (b == 0xFF) {
-            if (r.pos + 1 >= r.limit) {  // the stream ended prematurely (ref: :112-116)
-                r.pos = r.end;
-                break;
-            }
-            const uint32_t nb = (x >> 8) & 0xFFu;
-            if (nb == 0xFF) {  // padding byte, continue reading (ref: :117-121)
-                r.pos += 1;
-                r.rq >>= 8;
-                r.rcnt -= 1;
-                continue;
-            }
-            if (nb != 0) {  // a marker: cannot precede `end` by construction of the index; stop feeding bits
-                r.end = r.pos;
-                break;
-            }
-            r.pos += 2;  // stuffed byte
-            r.rq >>= 16;
-            r.rcnt -= 2;
-        } else {
-            r.pos += 1;
-            r.rq >>= 8;
-            r.rcnt -= 1;
-        }
-        r.buf = (r.buf << 8) | b;
-        r.bits += 8;
+// consume n bits, 1 <= n <= 32
+__device__ __forceinline__ void ub_consume(UBits &r, uint32_t n) {
+    r.hi = __builtin_amdgcn_alignbit(r.hi, r.lo, (32u - n) & 31u);  // n == 32 -> lo
+    r.lo = n >= 32u ? 0u : (r.lo << n);
+    r.lcnt -= (int32_t)n;
+    if (r.lcnt < 0) {
+        const uint32_t d = (uint32_t)(-r.lcnt);  // 1..32 low bits of hi are missing
+        const uint32_t w = ub_next_word(r);
+        r.hi |= w >> ((32u - d) & 31u);  // d == 32 -> w
+        r.lo = d >= 32u ? 0u : (w << d);
+        r.lcnt = 32 - (int32_t)d;
     }
 }
 
-// PeekBits(16): missing low bits are filled with ones (ref: JpegBitReader.cs:157-172)
-__device__ __forceinline__ uint32_t lb_peek16(const LaneBits &r) {
-    if (r.bits >= 16) return (uint32_t)(r.buf >> (r.bits - 16)) & 0xFFFFu;
-    const int miss = 16 - r.bits;
-    return (((uint32_t)r.buf << miss) & 0xFFFFu) | ((1u << miss) - 1u);
+__device__ __forceinline__ void ub_init(UBits &r, const uint8_t *ubase, uint32_t ustart, uint32_t uend) {
+    const uint32_t a = ustart & ~3u;
+    __builtin_memcpy(&r.qw, ubase + a, 16);
+    __builtin_memcpy(&r.nx, ubase + a + 16, 16);
+    r.p = ubase + a + 32;
+    r.qn = 4;
+    r.hi = ub_next_word(r);
+    r.lo = ub_next_word(r);
+    r.lcnt = 32;
+    const uint32_t skip = (ustart & 3u) * 8;
+    if (skip) ub_consume(r, skip);
+    r.rem = (int32_t)((uend - ustart) * 8u);
 }
 
 // LDS image of a staged DevHuffTable
@@ -327,40 +422,36 @@ __device__ __forceinline__ LdsHuff lds_huff16(const uint8_t *tabs, uint32_t off1
     return h;
 }
 
-// DecodeHuffmanCode (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:81-88, JpegHuffmanDecodingTable.cs:73-113).
-// Returns the symbol, or -1 for "Invalid Huffman code encountered.".  The caller has refilled the bit buffer.
-__device__ __forceinline__ int32_t decode_symbol_norefill(LaneBits &r, const LdsHuff &h) {
-    const uint32_t code16 = lb_peek16(r);
-    uint32_t e = h.lut[code16 >> (16 - kHuffLutBits)];
+// One Huffman symbol and its magnitude bits:
+//   DecodeHuffmanCode (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:81-88, JpegHuffmanDecodingTable.cs:73-113) followed by
+//   ReceiveAndExtend (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:100-115) when the category s is non-zero
+//   (s = sym for a DC symbol, sym & 15 for an AC symbol).
+// Returns 0, or the failure detail.  value = extended magnitude (0 when s == 0).
+__device__ __forceinline__ uint32_t ub_symbol(UBits &r, const LdsHuff &h, bool is_dc, bool closed_by_marker, uint32_t &sym_out,
+                                              int32_t &value) {
+    const uint32_t code16 = r.rem > 0 ? (r.hi >> 16) : 0xFFFFu;
+    const uint32_t e = h.lut[code16 >> (16 - kHuffLutBits)];
     uint32_t size = e >> 8, sym = e & 0xFF;
     if (size == 0) {
         size = kHuffLutBits + 1;
         while (code16 > h.maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
-        if (size > 16) return -1;
+        if (size > 16) return kDetailInvalidHuffmanCode;
         sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
     }
-    const int32_t adv = (int32_t)size < r.bits ? (int32_t)size : r.bits;  // Math.Min(entry.CodeSize, bitsRead)
-    r.bits -= adv;
-    return (int32_t)sym;
-}
-
-__device__ __forceinline__ int32_t decode_symbol(LaneBits &r, const LdsHuff &h) {
-    if (r.bits < 32) lb_refill(r);  // code (<= 16 bits) + magnitude (<= 16 bits) then need no second refill
-    return decode_symbol_norefill(r, h);
-}
-
-// ReceiveAndExtend (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:100-115).  ok=false when bits are missing.
-__device__ __forceinline__ int32_t receive_extend(LaneBits &r, int32_t n, bool &ok) {
-    if (r.bits < n) {
-        lb_refill(r);
-        if (r.bits < n) {
-            ok = false;
-            return 0;
-        }
+    sym_out = sym;
+    const uint32_t s = is_dc ? sym : (sym & 15u);
+    // advance Math.Min(entry.CodeSize, bitsRead)
+    r.rem = r.rem > (int32_t)size ? r.rem - (int32_t)size : 0;
+    value = 0;
+    if (s != 0) {
+        if (s > 16u) return kDetailInvalidHuffmanCode;  // categories above 16 are outside the verified envelope
+        if ((int32_t)s > r.rem) return (r.rem == 0 && closed_by_marker) ? kDetailMarkerInData : kDetailStreamEnded;
+        const int32_t v = (int32_t)__builtin_amdgcn_ubfe(r.hi, 32u - size - s, s);
+        value = v - ((((v + v) >> s) - 1) & ((1 << s) - 1));  // Extend(v, nbits)
+        r.rem -= (int32_t)s;
     }
-    r.bits -= n;
-    const int32_t v = (int32_t)((uint32_t)(r.buf >> r.bits) & ((1u << (n & 31)) - 1u));
-    return v - ((((v + v) >> (n & 31)) - 1) & ((1 << (n & 31)) - 1));
+    ub_consume(r, size + s);
+    return 0;
 }
 
 // LDS staging of one wave: 64 blocks x 128 B, 16-byte chunks XOR-swizzled so that both the per-lane
@@ -370,11 +461,32 @@ __device__ __forceinline__ uint32_t stage_addr(uint32_t blk, uint32_t coef_index
     return blk * 128 + chunk * 16 + (coef_index & 7) * 2;
 }
 
+// Restart check after an interval (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:139-163): runs after every completed
+// interval except a final partial one.  AdvanceAlignByte + TryReadMarker: no whole byte may be left before the closing
+// marker, and the marker must be RSTn (continue) or EOI (return early).  Returns the error code word or kNoError.
+__device__ __forceinline__ uint32_t restart_check(const DevScan &s, const DevScanStatus &st, DevScanStatus *status_out, uint32_t interval,
+                                                  uint32_t n_ends, uint32_t n_intervals, uint32_t dri_eff, int32_t rem, uint32_t err) {
+    if (err != 0) return (interval << 8) | err;
+    const bool needs_check = s.dri != 0 && (interval < n_intervals - 1 || s.restart_check_at_end);
+    if (!needs_check) return kNoError;
+    uint32_t closing = 0xD0;  // entries before the last indexed one are RSTn by construction
+    if (interval == n_ends - 1) closing = st.terminator;
+    if (rem >= 8) return (interval << 8) | kDetailExpectRestart;
+    if (closing == 0xD9) {
+        if (interval < n_intervals - 1) atomicMin(&status_out->decoded_mcus, (interval + 1) * dri_eff);
+        return kNoError;
+    }
+    if ((closing & 0xF8) != 0xD0) return (interval << 8) | kDetailExpectRestart;
+    return kNoError;
+}
+
+// K2: lanes of a wave decode block b of their MCU in lock-step into a shared LDS staging that is flushed per block as
+// whole 128-byte lines of the coefficient buffer (zig-zag int16, MCU scan order).
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_t *__restrict__ data,
+__global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_t *__restrict__ udata,
                                                                     const DevScan *__restrict__ scans,
                                                                     const HuffWork *__restrict__ work,
-                                                                    const uint32_t *__restrict__ ends,
+                                                                    const uint32_t *__restrict__ ends_u,
                                                                     DevScanStatus *__restrict__ status,
                                                                     const DevHuffTable *__restrict__ huff_pool,
                                                                     int16_t *__restrict__ coefs, int n_slots) {
@@ -397,9 +509,8 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
         for (uint32_t i = tid; i < sizeof(DevHuffTable) / 16; i += 64 * WAVES) dst[i] = src[i];
     }
     uint8_t *stage = stage_all + wave * 8192;
-    // zero the staging area of this wave
     {
-        uint4 z = {0, 0, 0, 0};
+        const uint4 z = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(stage)[i * 64 + lane] = z;
     }
@@ -414,31 +525,27 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
     const uint32_t wave_first = wk.first_interval + wave * 64;
     const uint32_t interval = wave_first + lane;
     const bool active = interval < n_ends;
-    const uint32_t *ends_s = ends + s.ends_off;
+    const uint32_t *eu = ends_u + s.ends_off;
+    const uint8_t *ubase = udata + s.data_off;
 
-    // offsets below are relative to the 16-byte aligned base of the segment
-    const uint32_t mis = (uint32_t)(s.data_off & 15u);
-    const uint8_t *base16 = data + (s.data_off - mis);
-    LaneBits r;
+    UBits r;
     uint32_t my_mcus = 0;
+    bool closed_by_marker = false;
     {
-        uint32_t p0 = mis, e0 = mis;
+        uint32_t u0 = 0, u1 = 0;
         if (active) {
-            p0 = mis + (interval == 0 ? 0u : ends_s[interval - 1] + 2u);
-            e0 = mis + ends_s[interval];
+            u0 = interval == 0 ? 0u : eu[interval - 1] + 2u;
+            u1 = eu[interval];
             my_mcus = (interval == n_intervals - 1) ? total_mcus - interval * dri_eff : dri_eff;
+            closed_by_marker = !(interval == n_ends - 1 && st.terminator == 0);
         }
-        lb_init(r, base16, p0, e0, mis + s.data_len);
+        ub_init(r, ubase, u0, u1);
     }
-    const bool closed_by_marker = active && r.end < r.limit;
     // the wave iterates to the largest MCU count among its lanes (only the image's last interval is shorter)
     uint32_t wave_mcus = 0;
-    {
-        const uint32_t last_in_wave = (wave_first + 63 < n_ends ? wave_first + 63 : n_ends - 1);
-        if (wave_first < n_ends) {
-            wave_mcus = dri_eff;
-            if (wave_first == n_intervals - 1 && last_in_wave == n_intervals - 1) wave_mcus = total_mcus - wave_first * dri_eff;
-        }
+    if (wave_first < n_ends) {
+        wave_mcus = dri_eff;
+        if (wave_first == n_intervals - 1) wave_mcus = total_mcus - wave_first * dri_eff;
     }
 
     int32_t pred0 = 0, pred1 = 0, pred2 = 0, pred3 = 0;  // DcPredictor per scan component
@@ -451,44 +558,30 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
             const LdsHuff hac = lds_huff(tabs, s.comp[ci].ac_slot);
             if (active && err == 0 && mcu < my_mcus) {
                 // ReadBlockBaseline (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:179-222)
-                int32_t t = decode_symbol(r, hdc);
-                bool ok = true;
-                if (t < 0) {
-                    err = kDetailInvalidHuffmanCode;
-                } else {
-                    if (t != 0) t = receive_extend(r, t, ok);
-                    if (!ok) {
-                        err = (r.bits == 0 && closed_by_marker) ? kDetailMarkerInData : kDetailStreamEnded;
-                    } else {
-                        int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
-                        t += pred;
-                        if (ci == 0) pred0 = t;
-                        else if (ci == 1) pred1 = t;
-                        else if (ci == 2) pred2 = t;
-                        else pred3 = t;
-                        *reinterpret_cast<int16_t *>(stage + stage_addr(lane, 0)) = (int16_t)t;
-                        for (int32_t i = 1; i < 64;) {
-                            int32_t sy = decode_symbol(r, hac);
-                            if (sy < 0) {
-                                err = kDetailInvalidHuffmanCode;
-                                break;
-                            }
-                            const int32_t rr = sy >> 4;
-                            sy &= 15;
-                            if (sy != 0) {
-                                i += rr;
-                                const int32_t v = receive_extend(r, sy, ok);
-                                if (!ok) {
-                                    err = (r.bits == 0 && closed_by_marker) ? kDetailMarkerInData : kDetailStreamEnded;
-                                    break;
-                                }
-                                const int32_t idx = i < 63 ? i : 63;  // Math.Min(i++, 63)
-                                i++;
-                                *reinterpret_cast<int16_t *>(stage + stage_addr(lane, (uint32_t)idx)) = (int16_t)v;
-                            } else {
-                                if (rr == 0) break;
-                                i += 16;  // ANY r != 0, not only 15 (ref: :212-220)
-                            }
+                uint32_t sym;
+                int32_t t;
+                err = ub_symbol(r, hdc, true, closed_by_marker, sym, t);
+                if (err == 0) {
+                    const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
+                    t += pred;
+                    if (ci == 0) pred0 = t;
+                    else if (ci == 1) pred1 = t;
+                    else if (ci == 2) pred2 = t;
+                    else pred3 = t;
+                    *reinterpret_cast<int16_t *>(stage + stage_addr(lane, 0)) = (int16_t)t;
+                    for (uint32_t i = 1; i < 64;) {
+                        int32_t v;
+                        err = ub_symbol(r, hac, false, closed_by_marker, sym, v);
+                        if (err != 0) break;
+                        const uint32_t rr = sym >> 4;
+                        if ((sym & 15u) != 0) {
+                            i += rr;
+                            const uint32_t idx = i < 63 ? i : 63;  // Math.Min(i++, 63)
+                            i++;
+                            *reinterpret_cast<int16_t *>(stage + stage_addr(lane, idx)) = (int16_t)v;
+                        } else {
+                            if (rr == 0) break;
+                            i += 16;  // ANY r != 0, not only 15 (ref: :212-220)
                         }
                     }
                 }
@@ -520,29 +613,8 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
         }
     }
 
-    // Restart check (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:139-163): runs after every completed
-    // interval except a final partial one.  AdvanceAlignByte + TryReadMarker: no whole byte may be left
-    // before the closing marker, and the marker must be RSTn (continue) or EOI (return early).
     if (active) {
-        uint32_t code = kNoError;
-        if (err != 0) {
-            code = (interval << 8) | err;
-        } else {
-            const bool needs_check = s.dri != 0 && (interval < n_intervals - 1 || s.restart_check_at_end);
-            if (needs_check) {
-                lb_refill(r);
-                const bool leftover = (r.bits - (r.bits & 7)) != 0 || r.pos < r.end;
-                uint32_t closing = 0xD0;  // entries before the last indexed one are RSTn by construction
-                if (interval == n_ends - 1) closing = st.terminator;
-                if (leftover) {
-                    code = (interval << 8) | kDetailExpectRestart;
-                } else if (closing == 0xD9) {
-                    if (interval < n_intervals - 1) atomicMin(&status[wk.scan].decoded_mcus, (interval + 1) * dri_eff);
-                } else if ((closing & 0xF8) != 0xD0) {
-                    code = (interval << 8) | kDetailExpectRestart;
-                }
-            }
-        }
+        const uint32_t code = restart_check(s, st, &status[wk.scan], interval, n_ends, n_intervals, dri_eff, r.rem, err);
         if (code != kNoError) atomicMin(&status[wk.scan].first_error, code);
     }
 }
@@ -558,10 +630,10 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
 // ------------------------------------------------------------------------------------------------
 
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void huffman_tokens_kernel(const uint8_t *__restrict__ data,
+__global__ __launch_bounds__(64 * WAVES) void huffman_tokens_kernel(const uint8_t *__restrict__ udata,
                                                                     const DevScan *__restrict__ scans,
                                                                     const HuffWork *__restrict__ work,
-                                                                    const uint32_t *__restrict__ ends,
+                                                                    const uint32_t *__restrict__ ends_u,
                                                                     DevScanStatus *__restrict__ status,
                                                                     const DevHuffTable *__restrict__ huff_pool,
                                                                     uint32_t *__restrict__ tokens,
@@ -598,20 +670,19 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_tokens_kernel(const uint8_
     const uint32_t bpm = s.blocks_per_mcu;
     const uint32_t interval = wk.first_interval + tid;
     if (interval >= n_ends) return;  // nothing after the last barrier: lanes may leave
-    const uint32_t *ends_s = ends + s.ends_off;
+    const uint32_t *eu = ends_u + s.ends_off;
 
-    const uint32_t mis = (uint32_t)(s.data_off & 15u);
-    const uint8_t *base16 = data + (s.data_off - mis);
-    const uint32_t start_rel = interval == 0 ? 0u : ends_s[interval - 1] + 2u;
-    LaneBits r;
-    lb_init(r, base16, mis + start_rel, mis + ends_s[interval], mis + s.data_len);
-    const bool closed_by_marker = r.end < r.limit;
+    const uint32_t ustart = interval == 0 ? 0u : eu[interval - 1] + 2u;
+    UBits r;
+    ub_init(r, udata + s.data_off, ustart, eu[interval]);
+    const bool closed_by_marker = !(interval == n_ends - 1 && st.terminator == 0);
     const uint32_t my_mcus = (interval == n_intervals - 1) ? total_mcus - interval * dri_eff : dri_eff;
     const uint32_t my_blocks = my_mcus * bpm;
 
-    uint32_t *tok = tokens + s.tok_base + (uint64_t)kTokensPerByte * start_rel;  // this lane's slice (16-byte aligned)
+    // this lane's slice of the token buffer: kTokensPerByte slots per byte of (unstuffed) entropy data, 16-byte aligned
+    const uint32_t tok_rel0 = kTokensPerByte * ustart;  // slot index relative to the scan's tok_base
+    uint32_t *tok = tokens + s.tok_base + tok_rel0;
     uint32_t *my_blk_tok = blk_tok + s.coef_off + (uint64_t)interval * dri_eff * bpm;
-    const uint32_t tok_rel0 = kTokensPerByte * start_rel;  // slot index relative to the scan's tok_base
 
     int32_t pred0 = 0, pred1 = 0, pred2 = 0, pred3 = 0;  // DcPredictor per scan component
     uint32_t err = 0;
@@ -633,26 +704,15 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_tokens_kernel(const uint8_
         if ((ntok & 3u) == 0) *reinterpret_cast<uint4 *>(tok + ntok - 4) = q; \
     }
 
-    while (blk < my_blocks && err == 0) {
-        if (r.bits < 32) lb_refill(r);
+    while (blk < my_blocks) {
         const bool is_dc = (k == 0);
         const LdsHuff h = lds_huff16(tabs, is_dc ? (info & 0xFFF) : ((info >> 12) & 0xFFF));
-        const int32_t sym = decode_symbol_norefill(r, h);
-        if (sym < 0) {
-            err = kDetailInvalidHuffmanCode;
-            break;
-        }
-        const int32_t rr = is_dc ? 0 : (sym >> 4);
-        const int32_t ss = is_dc ? sym : (sym & 15);
-        int32_t v = 0;
-        if (ss != 0) {
-            bool ok = true;
-            v = receive_extend(r, ss, ok);
-            if (!ok) {
-                err = (r.bits == 0 && closed_by_marker) ? kDetailMarkerInData : kDetailStreamEnded;
-                break;
-            }
-        }
+        uint32_t sym;
+        int32_t v;
+        err = ub_symbol(r, h, is_dc, closed_by_marker, sym, v);
+        if (err != 0) break;
+        const uint32_t rr = is_dc ? 0u : (sym >> 4);
+        const uint32_t ss = is_dc ? sym : (sym & 15u);
         if (is_dc) {
             const uint32_t ci = info >> 24;
             const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
@@ -663,14 +723,14 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_tokens_kernel(const uint8_
             else pred3 = v;
         }
         if (is_dc || ss != 0) {
-            uint32_t idx = is_dc ? 0u : (k + (uint32_t)rr);
+            uint32_t idx = is_dc ? 0u : (k + rr);
             idx = idx < 63u ? idx : 63u;  // Math.Min(i++, 63)
             if (have_pending) JPGPU_PUSH(pending)
             pending = ((uint32_t)v & 0xFFFFu) | (idx << 16);
             have_pending = true;
         }
         // next position (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:199-221)
-        k = is_dc ? 1u : (ss != 0 ? k + (uint32_t)rr + 1u : (rr == 0 ? 64u : k + 16u));
+        k = is_dc ? 1u : (ss != 0 ? k + rr + 1u : (rr == 0 ? 64u : k + 16u));
         if (k >= 64u) {
             JPGPU_PUSH(pending | kTokLast)
             have_pending = false;
@@ -700,26 +760,7 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_tokens_kernel(const uint8_
     }
 #undef JPGPU_PUSH
 
-    // restart check, identical to K2
-    uint32_t code = kNoError;
-    if (err != 0) {
-        code = (interval << 8) | err;
-    } else {
-        const bool needs_check = s.dri != 0 && (interval < n_intervals - 1 || s.restart_check_at_end);
-        if (needs_check) {
-            lb_refill(r);
-            const bool leftover = (r.bits - (r.bits & 7)) != 0 || r.pos < r.end;
-            uint32_t closing = 0xD0;
-            if (interval == n_ends - 1) closing = st.terminator;
-            if (leftover) {
-                code = (interval << 8) | kDetailExpectRestart;
-            } else if (closing == 0xD9) {
-                if (interval < n_intervals - 1) atomicMin(&status[wk.scan].decoded_mcus, (interval + 1) * dri_eff);
-            } else if ((closing & 0xF8) != 0xD0) {
-                code = (interval << 8) | kDetailExpectRestart;
-            }
-        }
-    }
+    const uint32_t code = restart_check(s, st, &status[wk.scan], interval, n_ends, n_intervals, dri_eff, r.rem, err);
     if (code != kNoError) {
         atomicMin(&status[wk.scan].first_error, code);
         // blocks of a failing interval have no complete token run: keep the block-parallel stage away from them
@@ -1193,10 +1234,12 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
 
-hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const DevScan *scans, int n_scans, uint32_t *ends,
-                               DevScanStatus *status) {
-    if (n_scans <= 0) return hipSuccess;
-    hipLaunchKernelGGL(marker_index_kernel, dim3(n_scans), dim3(kScanThreads), 0, stream, data, scans, ends, status);
+hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const DevScan *scans, const ChunkWork *work, int n_chunks,
+                               ChunkSum *sums, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u) {
+    if (n_chunks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(marker_count_kernel, dim3(n_chunks), dim3(kScanThreads), 0, stream, data, scans, work, sums);
+    hipLaunchKernelGGL(marker_write_kernel, dim3(n_chunks), dim3(kScanThreads), 0, stream, data, scans, work, sums, ends, status, udata,
+                       ends_u);
     return hipGetLastError();
 }
 
