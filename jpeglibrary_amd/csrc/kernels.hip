@@ -92,6 +92,30 @@ __device__ __forceinline__ ByteClass classify16(const uint8_t *p, int64_t off, u
         c.w[4] = *(p + off + 16);
         if (off >= 1) prev = *(p + off - 1);
     }
+    if (off >= 1 && off + 17 <= (int64_t)len) {
+        // interior lane (all but the first and last few lanes of a segment): SWAR over the four dwords, flags in bit 7 of
+        // each byte, then packed to one bit per byte.
+        const uint32_t dw[6] = {prev << 24, c.w[0], c.w[1], c.w[2], c.w[3], c.w[4]};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t x = dw[i + 1];
+            const uint32_t nbw = __builtin_amdgcn_alignbit(dw[i + 2], x, 8);   // byte j+1 of every byte j
+            const uint32_t pvw = __builtin_amdgcn_alignbit(x, dw[i], 24);      // byte j-1
+#define JPGPU_Z80(v_) (~((((v_)&0x7F7F7F7Fu) + 0x7F7F7F7Fu) | (v_) | 0x7F7F7F7Fu))  /* 0x80 where the byte is 0 */
+            const uint32_t ff = JPGPU_Z80(~x), nff = JPGPU_Z80(~nbw), n00 = JPGPU_Z80(nbw), pff = JPGPU_Z80(~pvw);
+            const uint32_t nrst = JPGPU_Z80((nbw & 0xF8F8F8F8u) ^ 0xD0D0D0D0u);
+#undef JPGPU_Z80
+            const uint32_t marker = ff & ~n00 & ~nff;
+            const uint32_t rst = any_marker_terminates ? 0u : (marker & nrst);
+            const uint32_t dropped = (pff & ~ff) | (ff & nff);
+#define JPGPU_PACK4(m_) (((((m_) >> 7) * 0x00204081u) >> 21) & 0xFu)
+            c.rst |= JPGPU_PACK4(rst) << (4 * i);
+            c.term |= JPGPU_PACK4(marker & ~rst) << (4 * i);
+            c.keep |= JPGPU_PACK4(~dropped & 0x80808080u) << (4 * i);
+#undef JPGPU_PACK4
+        }
+        return c;
+    }
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const uint32_t b = (c.w[j >> 2] >> ((j & 3) * 8)) & 0xFF;
