@@ -180,12 +180,13 @@ def main():
         idct_bytes = totals["blocks"] * 128 + totals["output_bytes"]
         idct_s = stage["idct"] / 1e3
         achieved = idct_bytes / idct_s / 1e9
-        traffic = None
+        traffic = None  # HBM bytes per launch from the PMC counters (committed profile, scaled by the launch's image count)
         tpath = os.path.join(ROOT, "profiles", "idct_traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(f"{args.workload}:{args.format}:{n_images}")
+                tj = json.load(open(tpath)).get(f"{args.workload}:{args.format}")
+                if tj:
+                    traffic = int(tj["hbm_bytes_per_image"]) * n_images
             except Exception:
                 traffic = None
         out = {
