@@ -858,26 +858,95 @@ __device__ __forceinline__ void block_dequant(const uint8_t *c_lds, uint32_t swz
     }
 }
 
-// TransformIDCT + ShiftDataLevel (ref: FastFloatingPointDCT.cs:54-70, ScanDecoder/JpegScanDecoder.cs:64-73) on a
-// dequantised block held in registers.  out: 64 samples, row-major, unclamped (the value the reference casts to short).
-__device__ __forceinline__ void block_idct(float (&f)[64], int32_t level_shift, int32_t (&out)[64]) {
-    // pass 1: 1-D IDCT along each ROW (the reference transposes, runs the column butterfly, transposes back)
-#pragma unroll
-    for (int r = 0; r < 8; r++) JPGPU_IDCT8(f[r * 8 + 0], f[r * 8 + 1], f[r * 8 + 2], f[r * 8 + 3], f[r * 8 + 4], f[r * 8 + 5], f[r * 8 + 6], f[r * 8 + 7]);
-    // pass 2: along each COLUMN
-#pragma unroll
-    for (int c = 0; c < 8; c++) JPGPU_IDCT8(f[c], f[8 + c], f[16 + c], f[24 + c], f[32 + c], f[40 + c], f[48 + c], f[56 + c]);
-#pragma unroll
-    for (int i = 0; i < 64; i++) {
-        const float v = f[i] * 0.1250f;                      // MultiplyInplace(C_0_125)
-        const int32_t rounded = (int32_t)__builtin_rintf(v);  // MathF.Round: half to even (v_rndne_f32)
-        out[i] = (int32_t)(int16_t)(rounded + level_shift);   // (short)(Round + levelShift)
-    }
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+// The 8-point butterfly of IDCT8x4_LeftPart/RightPart (ref: FastFloatingPointDCT.cs:79-127) on T = float or a pair of
+// floats (two independent columns at once: v_pk_add_f32 / v_pk_mul_f32, each component one IEEE operation, never fused).
+// Operation order and parenthesisation are normative.
+template <typename T>
+__device__ __forceinline__ void idct8(T &y0, T &y1, T &y2, T &y3, T &y4, T &y5, T &y6, T &y7) {
+    T mz0 = y1 + y7;
+    T mz2 = y3 + y7;
+    T mz1 = y3 + y5;
+    T mz3 = y1 + y5;
+    T mz4 = (mz0 + mz1) * 1.175875602f;
+    mz2 = (mz2 * -1.961570560f) + mz4;
+    mz3 = (mz3 * -0.390180644f) + mz4;
+    mz0 = mz0 * -0.899976223f;
+    mz1 = mz1 * -2.562915447f;
+    const T mb3 = ((y7 * 0.298631336f) + mz0) + mz2;
+    const T mb2 = ((y5 * 2.053119869f) + mz1) + mz3;
+    const T mb1 = ((y3 * 3.072711026f) + mz1) + mz2;
+    const T mb0 = ((y1 * 1.501321110f) + mz0) + mz3;
+    mz4 = (y2 + y6) * 0.541196100f;
+    mz0 = y0 + y4;
+    mz1 = y0 - y4;
+    mz2 = mz4 + (y6 * -1.847759065f);
+    mz3 = mz4 + (y2 * 0.765366865f);
+    const T a0 = mz0 + mz3;
+    const T a3 = mz0 - mz3;
+    const T a1 = mz1 + mz2;
+    const T a2 = mz1 - mz2;
+    y0 = a0 + mb0;
+    y7 = a0 - mb0;
+    y1 = a1 + mb1;
+    y6 = a1 - mb1;
+    y2 = a2 + mb2;
+    y5 = a2 - mb2;
+    y3 = a3 + mb3;
+    y4 = a3 - mb3;
 }
 
-__device__ __forceinline__ uint32_t clamp_u8(int32_t v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
-__device__ __forceinline__ uint32_t pack4_u8(int32_t a, int32_t b, int32_t c, int32_t d) {
-    return clamp_u8(a) | (clamp_u8(b) << 8) | (clamp_u8(c) << 16) | (clamp_u8(d) << 24);
+// TransformIDCT + ShiftDataLevel (ref: FastFloatingPointDCT.cs:54-70, ScanDecoder/JpegScanDecoder.cs:64-73) on a
+// dequantised block held in registers, two lanes of the butterfly per instruction.
+// out[r * 4 + c2] = samples (r, 2*c2) | (r, 2*c2 + 1) << 16 as int16: (short)(Round(v) + levelShift), unclamped.
+__device__ __forceinline__ void block_idct(const float (&f)[64], int32_t level_shift, uint32_t (&out)[32]) {
+    // pass 1: 1-D IDCT along each ROW (the reference transposes, runs the column butterfly, transposes back);
+    // a[r2][c] holds rows 2*r2 and 2*r2+1 of column c
+    float2v a[4][8];
+#pragma unroll
+    for (int r2 = 0; r2 < 4; r2++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) a[r2][c] = float2v{f[(2 * r2) * 8 + c], f[(2 * r2 + 1) * 8 + c]};
+#pragma unroll
+    for (int r2 = 0; r2 < 4; r2++) idct8(a[r2][0], a[r2][1], a[r2][2], a[r2][3], a[r2][4], a[r2][5], a[r2][6], a[r2][7]);
+    // pass 2: along each COLUMN; b[r][c2] holds columns 2*c2 and 2*c2+1 of row r
+    float2v b[8][4];
+#pragma unroll
+    for (int r2 = 0; r2 < 4; r2++)
+#pragma unroll
+        for (int c2 = 0; c2 < 4; c2++) {
+            b[2 * r2][c2] = float2v{a[r2][2 * c2].x, a[r2][2 * c2 + 1].x};
+            b[2 * r2 + 1][c2] = float2v{a[r2][2 * c2].y, a[r2][2 * c2 + 1].y};
+        }
+#pragma unroll
+    for (int c2 = 0; c2 < 4; c2++) idct8(b[0][c2], b[1][c2], b[2][c2], b[3][c2], b[4][c2], b[5][c2], b[6][c2], b[7][c2]);
+    const uint32_t shift2 = ((uint32_t)level_shift & 0xFFFFu) * 0x00010001u;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int c2 = 0; c2 < 4; c2++) {
+            const float2v v = b[r][c2] * 0.1250f;                  // MultiplyInplace(C_0_125)
+            const int32_t x = (int32_t)__builtin_rintf(v.x);       // MathF.Round: half to even (v_rndne_f32)
+            const int32_t y = (int32_t)__builtin_rintf(v.y);
+            const uint32_t pk = ((uint32_t)x & 0xFFFFu) | ((uint32_t)y << 16);
+            // (short)(Round + levelShift): 16-bit wrap-around add on both halves (v_pk_add_u16)
+            const short2v sum = __builtin_bit_cast(short2v, pk) + __builtin_bit_cast(short2v, shift2);
+            out[r * 4 + c2] = __builtin_bit_cast(uint32_t, sum);
+        }
+}
+
+// signed clamp of two int16 samples to [0, 255] (JpegBufferOutputWriter8Bit.ClampTo8Bit): v_pk_max_i16 + v_pk_min_i16
+__device__ __forceinline__ uint32_t clamp2_u8(uint32_t pk) {
+    short2v v = __builtin_bit_cast(short2v, pk);
+    v = __builtin_elementwise_max(v, short2v{0, 0});
+    v = __builtin_elementwise_min(v, short2v{255, 255});
+    return __builtin_bit_cast(uint32_t, v);
+}
+// four clamped samples (two packed pairs) -> four bytes
+__device__ __forceinline__ uint32_t pack4_u8(uint32_t pk01, uint32_t pk23) {
+    return __builtin_amdgcn_perm(clamp2_u8(pk23), clamp2_u8(pk01), 0x06040200u);  // bytes 0,2 of pk01 then 0,2 of pk23
 }
 // byte gather from the 8 bytes {lo (indices 0-3), hi (indices 4-7)}: one v_perm_b32
 __device__ __forceinline__ uint32_t pick4(uint32_t lo, uint32_t hi, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
@@ -1062,7 +1131,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 2)) void 
     if (have_next) dma_tile(next_first);  // in flight during the whole transform below
 
     // phase B2: IDCT entirely in registers
-    int32_t px[64];
+    uint32_t px[32];  // int16 sample pairs
     if (have_block) block_idct(f, (int32_t)s.level_shift, px);
     bool synced = false;
 
@@ -1074,11 +1143,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 2)) void 
             const uint32_t x0 = (mcu_x * comp.h + s.blk_x[b]) * 8, y0 = (mcu_y * comp.v + s.blk_y[b]) * 8;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                uint4 v;
-                v.x = (uint32_t)(px[r * 8 + 0] & 0xFFFF) | ((uint32_t)px[r * 8 + 1] << 16);
-                v.y = (uint32_t)(px[r * 8 + 2] & 0xFFFF) | ((uint32_t)px[r * 8 + 3] << 16);
-                v.z = (uint32_t)(px[r * 8 + 4] & 0xFFFF) | ((uint32_t)px[r * 8 + 5] << 16);
-                v.w = (uint32_t)(px[r * 8 + 6] & 0xFFFF) | ((uint32_t)px[r * 8 + 7] << 16);
+                const uint4 v = {px[r * 4 + 0], px[r * 4 + 1], px[r * 4 + 2], px[r * 4 + 3]};
                 *reinterpret_cast<uint4 *>(plane + (size_t)(y0 + r) * pitch + x0) = v;
             }
         }
@@ -1087,8 +1152,8 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 2)) void 
     uint2 rows[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        rows[r].x = pack4_u8(px[r * 8 + 0], px[r * 8 + 1], px[r * 8 + 2], px[r * 8 + 3]);
-        rows[r].y = pack4_u8(px[r * 8 + 4], px[r * 8 + 5], px[r * 8 + 6], px[r * 8 + 7]);
+        rows[r].x = pack4_u8(px[r * 4 + 0], px[r * 4 + 1]);
+        rows[r].y = pack4_u8(px[r * 4 + 2], px[r * 4 + 3]);
     }
 
     if (FMT == kFmtPlanarU8 || (FMT == kFmtInterleavedU8 && LAY == kLayGray)) {
@@ -1205,7 +1270,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
 #undef JPGPU_APPLY
             block_dequant(row, swz, sh_q[ci], f);
         }
-        int32_t px[64];
+        uint32_t px[32];  // int16 sample pairs
         if (have_block) block_idct(f, (int32_t)s.level_shift, px);
 
         if (FMT == kFmtPlanarI16) {
@@ -1215,11 +1280,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
                 const uint32_t x0 = (mcu_x * comp.h + s.blk_x[b]) * 8, y0 = (mcu_y * comp.v + s.blk_y[b]) * 8;
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                    uint4 v;
-                    v.x = (uint32_t)(px[r * 8 + 0] & 0xFFFF) | ((uint32_t)px[r * 8 + 1] << 16);
-                    v.y = (uint32_t)(px[r * 8 + 2] & 0xFFFF) | ((uint32_t)px[r * 8 + 3] << 16);
-                    v.z = (uint32_t)(px[r * 8 + 4] & 0xFFFF) | ((uint32_t)px[r * 8 + 5] << 16);
-                    v.w = (uint32_t)(px[r * 8 + 6] & 0xFFFF) | ((uint32_t)px[r * 8 + 7] << 16);
+                    const uint4 v = {px[r * 4 + 0], px[r * 4 + 1], px[r * 4 + 2], px[r * 4 + 3]};
                     *reinterpret_cast<uint4 *>(plane + (size_t)(y0 + r) * pitch + x0) = v;
                 }
             }
@@ -1228,8 +1289,8 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
         uint2 rows[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            rows[r].x = pack4_u8(px[r * 8 + 0], px[r * 8 + 1], px[r * 8 + 2], px[r * 8 + 3]);
-            rows[r].y = pack4_u8(px[r * 8 + 4], px[r * 8 + 5], px[r * 8 + 6], px[r * 8 + 7]);
+            rows[r].x = pack4_u8(px[r * 4 + 0], px[r * 4 + 1]);
+            rows[r].y = pack4_u8(px[r * 4 + 2], px[r * 4 + 3]);
         }
         if (FMT == kFmtPlanarU8 || (FMT == kFmtInterleavedU8 && LAY == kLayGray)) {
             if (have_block) {
