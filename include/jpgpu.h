@@ -184,6 +184,8 @@ int jpgpu_batch_upload_coefficients(jpgpu_batch *b, int i, const int16_t *src, s
 /* hipEvent timings (ms) on the ctx stream, averaged over every jpgpu_batch_decode issued since the previous query
  * (synchronises): ms[0] marker index, ms[1] Huffman, ms[2] IDCT+output, ms[3] whole pipeline. */
 int jpgpu_batch_stage_ms(jpgpu_batch *b, float ms[4]);
+/* Synchronisation rounds the self-synchronising DRI = 0 decoder needed in the most recent decode (0 = not used). */
+int jpgpu_batch_subseq_rounds(const jpgpu_batch *b);
 /* Total entropy-segment bytes / blocks / pixels of the successfully parsed images. */
 int jpgpu_batch_totals(const jpgpu_batch *b, uint64_t *compressed_bytes, uint64_t *blocks, uint64_t *pixels,
                        uint64_t *output_bytes);

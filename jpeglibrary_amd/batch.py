@@ -78,6 +78,10 @@ class Batch:
         self._check(_lib.jpgpu_batch_stage_ms(self._h, ms))
         return {"marker_index": ms[0], "huffman": ms[1], "idct": ms[2], "total": ms[3]}
 
+    def subseq_rounds(self):
+        """Synchronisation rounds the DRI = 0 subsequence decoder needed in the last decode (0 = not used)."""
+        return _lib.jpgpu_batch_subseq_rounds(self._h)
+
     def totals(self):
         a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         _lib.jpgpu_batch_totals(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))

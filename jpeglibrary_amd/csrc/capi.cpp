@@ -171,6 +171,7 @@ int jpgpu_batch_upload_coefficients(jpgpu_batch *b, int i, const int16_t *src, s
     JPGPU_GUARD(b, b->impl.upload_coefficients(i, src, nblocks));
 }
 int jpgpu_batch_stage_ms(jpgpu_batch *b, float ms[4]) { JPGPU_GUARD(b, b->impl.stage_ms(ms)); }
+int jpgpu_batch_subseq_rounds(const jpgpu_batch *b) { return b ? b->impl.last_subseq_rounds() : 0; }
 int jpgpu_batch_totals(const jpgpu_batch *b, uint64_t *compressed_bytes, uint64_t *blocks, uint64_t *pixels, uint64_t *output_bytes) {
     if (!b) return JPGPU_ERR_ARGUMENT;
     b->impl.totals(compressed_bytes, blocks, pixels, output_bytes);

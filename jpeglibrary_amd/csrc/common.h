@@ -68,7 +68,8 @@ struct alignas(16) DevScan {
     uint64_t tok_base;   // first token slot of this scan in the token buffer (token pipeline, see K2T/K3T)
     uint32_t chunk_off;  // first entry of this scan in the chunk-summary array (K1)
     uint32_t n_chunks;   // 4 KiB chunks covering the entropy segment (from its 16-byte aligned base)
-    uint32_t pad2[2];
+    uint32_t sub_off;    // DRI = 0 scans: first slot of this scan in the subsequence state arrays (K2S)
+    uint32_t n_subs;     // DRI = 0 scans: number of 1024-bit subsequences covering the segment (0 = interval decoder)
 };
 static_assert(sizeof(DevScan) % 16 == 0, "DevScan must be a multiple of 16 bytes");
 

@@ -40,7 +40,7 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_chunk_work_, &d_chunk_sums_, &d_tokens_, &d_blk_tok_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_changed_, &d_chunk_work_, &d_chunk_sums_, &d_tokens_, &d_blk_tok_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
@@ -216,6 +216,10 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     h_scans_.assign(jobs_.size(), DevScan());
     std::vector<HuffWork> huff_work;
     std::vector<ChunkWork> chunk_work;
+    std::vector<HuffWork> sub_work;
+    sub_scan_ids_.clear();
+    total_subs_ = 0;
+    max_subs_per_scan_ = 0;
     std::vector<IdctWork> idct_work;
     std::vector<IdctWork> idct_work_by_class[kNumIdctLayoutClasses];
     uint64_t out_off = 0, coef_off = 0;
@@ -309,7 +313,18 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             coef_off += nblocks;
             img.total_blocks += nblocks;
             compressed_bytes_ += s.data_len;
-            for (uint32_t first = 0; first < s.n_intervals; first += kHuffIntervalsPerWg) huff_work.push_back({(uint32_t)j, first});
+            // scans without restart intervals are decoded by the self-synchronising subsequence decoder (K2S)
+            const bool use_subseq = s.dri == 0 && s.total_mcus > 0 && s.data_len >= 512 && getenv("JPGPU_NO_SUBSEQ") == nullptr;
+            if (use_subseq) {
+                s.n_subs = (uint32_t)(((uint64_t)s.data_len * 8 + kSubseqBits - 1) / kSubseqBits);
+                s.sub_off = total_subs_;
+                total_subs_ += s.n_subs;
+                max_subs_per_scan_ = std::max(max_subs_per_scan_, s.n_subs);
+                sub_scan_ids_.push_back((uint32_t)j);
+                for (uint32_t first = 0; first < s.n_subs; first += 256) sub_work.push_back({(uint32_t)j, first});
+            } else {
+                for (uint32_t first = 0; first < s.n_intervals; first += kHuffIntervalsPerWg) huff_work.push_back({(uint32_t)j, first});
+            }
             const uint32_t mcus_per_wg = (uint32_t)kIdctBlocksPerWg / s.blocks_per_mcu;
             const int cls = format_ == JPGPU_FMT_INTERLEAVED_U8 ? idct_layout_class(s) : 0;
             const uint32_t run = mcus_per_wg * (uint32_t)kIdctTilesPerWg;
@@ -322,6 +337,8 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     total_ends_ = ends_off;
     n_huff_work_ = (int)huff_work.size();
     n_chunk_work_ = (int)chunk_work.size();
+    n_sub_work_ = (int)sub_work.size();
+    n_sub_scans_ = (int)sub_scan_ids_.size();
     idct_class_begin_[0] = 0;
     for (int c = 0; c < kNumIdctLayoutClasses; c++) {
         idct_work.insert(idct_work.end(), idct_work_by_class[c].begin(), idct_work_by_class[c].end());
@@ -351,6 +368,13 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_quant_pool_, quant_pool_.data(), quant_pool_.size() * sizeof(DevQuantTable), 0},
         {&d_huff_work_, huff_work.data(), huff_work.size() * sizeof(HuffWork), 0},
         {&d_chunk_work_, chunk_work.data(), chunk_work.size() * sizeof(ChunkWork), 0},
+        {&d_sub_work_, sub_work.data(), sub_work.size() * sizeof(HuffWork), 0},
+        {&d_sub_scan_ids_, sub_scan_ids_.data(), sub_scan_ids_.size() * sizeof(uint32_t), 0},
+        {&d_sub_exit_a_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
+        {&d_sub_exit_b_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
+        {&d_sub_nblk_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
+        {&d_sub_first_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
+        {&d_sub_changed_, nullptr, 0, 256},
         {&d_chunk_sums_, nullptr, 0, chunk_work.size() * sizeof(ChunkSum) + 256},
         {&d_idct_work_, idct_work.data(), idct_work.size() * sizeof(IdctWork), 0},
         {&d_ends_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},
@@ -402,7 +426,23 @@ int DeviceBatch::run_huffman() {
     hipError_t e = launch_huffman(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_huff_work_.ptr,
                                   n_huff_work_, (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr,
                                   (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_);
-    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "huffman_decode_kernel");
+    if (e != hipSuccess) return hip_fail(e, "huffman_decode_kernel");
+    if (n_sub_work_ > 0) {
+        // DRI = 0 scans: the final pass scatters coefficients into a zeroed buffer
+        for (uint32_t j : sub_scan_ids_) {
+            const DevScan &s = h_scans_[j];
+            e = hipMemsetAsync((int16_t *)d_coefs_.ptr + s.coef_off * 64, 0, (size_t)s.total_mcus * s.blocks_per_mcu * 128, ctx_->stream);
+            if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(coefficients)");
+        }
+        e = launch_subseq_decode(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_sub_work_.ptr,
+                                 n_sub_work_, (const uint32_t *)d_sub_scan_ids_.ptr, n_sub_scans_, (const uint32_t *)d_ends_u_.ptr,
+                                 (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (uint32_t *)d_sub_exit_a_.ptr,
+                                 (uint32_t *)d_sub_exit_b_.ptr, (uint32_t *)d_sub_nblk_.ptr, (uint32_t *)d_sub_first_.ptr,
+                                 (uint32_t *)d_sub_changed_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (int)max_subs_per_scan_ + 2,
+                                 &last_subseq_rounds_);
+        if (e != hipSuccess) return hip_fail(e, "subsequence decode");
+    }
+    return JPGPU_OK;
 }
 int DeviceBatch::run_idct() {
     hipError_t e = launch_idct(ctx_->stream, (const int16_t *)d_coefs_.ptr, (const DevScan *)d_scans_.ptr, (const IdctWork *)d_idct_work_.ptr,
@@ -457,9 +497,10 @@ int DeviceBatch::decode() {
     (void)hipEventRecord(ev[0], ctx_->stream);
     if ((rc = run_marker_index()) != JPGPU_OK) return rc;
     (void)hipEventRecord(ev[1], ctx_->stream);
-    if ((rc = use_tokens_ ? run_huffman_tokens() : run_huffman()) != JPGPU_OK) return rc;
+    const bool tokens = use_tokens_ && n_sub_work_ == 0;  // DRI = 0 scans only have the coefficient path
+    if ((rc = tokens ? run_huffman_tokens() : run_huffman()) != JPGPU_OK) return rc;
     (void)hipEventRecord(ev[2], ctx_->stream);
-    if ((rc = use_tokens_ ? run_idct_tokens() : run_idct()) != JPGPU_OK) return rc;
+    if ((rc = tokens ? run_idct_tokens() : run_idct()) != JPGPU_OK) return rc;
     (void)hipEventRecord(ev[3], ctx_->stream);
     ev_used_ += 4;
     return JPGPU_OK;

@@ -79,6 +79,7 @@ class DeviceBatch {
     int stage_ms(float ms[4]);
     void totals(uint64_t *compressed, uint64_t *blocks, uint64_t *pixels, uint64_t *out_bytes) const;
     int format() const { return format_; }
+    int last_subseq_rounds() const { return last_subseq_rounds_; }
 
   private:
     int fail(int status, const std::string &msg);
@@ -108,6 +109,12 @@ class DeviceBatch {
     bool token_buffers_ready_ = false;
     int ensure_token_buffers();
     DevBuffer d_tokens_, d_blk_tok_;
+    // DRI = 0 scans: self-synchronising subsequence decode (K2S)
+    DevBuffer d_sub_work_, d_sub_scan_ids_, d_sub_exit_a_, d_sub_exit_b_, d_sub_nblk_, d_sub_first_, d_sub_changed_;
+    int n_sub_work_ = 0, n_sub_scans_ = 0;
+    uint32_t total_subs_ = 0, max_subs_per_scan_ = 0;
+    std::vector<uint32_t> sub_scan_ids_;
+    int last_subseq_rounds_ = 0;
     DevBuffer d_chunk_work_, d_chunk_sums_;
     int n_chunk_work_ = 0;
     DevBuffer d_unstuffed_, d_ends_u_;  // K1 output: entropy data as the bit reader sees it + interval ends in it

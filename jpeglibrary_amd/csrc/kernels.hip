@@ -793,6 +793,239 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_tokens_kernel(const uint8_
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2S: self-synchronising subsequence decode for scans WITHOUT restart intervals (DRI = 0).
+//
+// One restart interval = one lane does not scale when the whole scan is a single interval.  The unstuffed stream is cut
+// into subsequences of kSubBits bits; lane i decodes subsequence i.  Its entry state (bit position, block-in-MCU,
+// zig-zag position) is unknown a priori, so round 0 guesses (start of a block of component 0) and every later round
+// restarts lane i from the exit state lane i-1 reached in the previous round.  Huffman streams self-synchronise, so the
+// exit states stop changing after a few rounds; lane 0 is exact from the start, hence a fixed point reached from it is
+// the serial decoder's own sequence of states (Klein/Wiseman, Weissenberger/Schmidt).  After convergence the block
+// counts are prefix-summed and a final pass writes the coefficients (DC as DIFFERENCE) into the zeroed coefficient
+// buffer; a per-component prefix sum then turns the DC differences into the reference's predictor chain
+// (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:186-195).
+// ------------------------------------------------------------------------------------------------
+
+constexpr uint32_t kSubBits = 1024;
+constexpr uint32_t kSubBad = 0x80000000u;  // the lane hit an invalid code / ran out of data under its entry state
+
+// exit state word: overshoot (bits past the nominal end, 0..63) | b << 6 | k << 11 | kSubBad
+__device__ __forceinline__ uint32_t sub_pack(uint32_t overshoot, uint32_t b, uint32_t k) { return overshoot | (b << 6) | (k << 11); }
+
+// Decodes subsequence `sub` of a DRI = 0 scan from `entry` (packed like an exit of sub-1).  When `coefs` is non-null
+// the coefficients are stored (final pass), starting with block `first_block`.  Returns the exit state word; *nblk =
+// blocks COMPLETED inside the subsequence.
+template <bool FINAL>
+__device__ __forceinline__ uint32_t sub_decode(const uint8_t *ubase, uint32_t total_bits, uint32_t sub, uint32_t entry, const uint8_t *tabs,
+                                               const uint32_t *blk_info, uint32_t bpm, uint32_t &nblk, int16_t *coefs, uint32_t first_block,
+                                               uint32_t total_blocks, uint32_t &err_out, bool closed_by_marker) {
+    const uint32_t start_bit = sub * kSubBits + (entry & 63u);
+    const uint32_t end_bit = (sub + 1) * kSubBits;
+    uint32_t b_in_mcu = (entry >> 6) & 31u, k = (entry >> 11) & 127u;
+    nblk = 0;
+    err_out = 0;
+    if (start_bit >= total_bits && !FINAL) return sub_pack(0, b_in_mcu, k) | kSubBad;
+    UBits r;
+    ub_init(r, ubase, start_bit >> 3, (total_bits + 7) >> 3);
+    if (start_bit & 7u) {
+        ub_consume(r, start_bit & 7u);
+    }
+    r.rem = (int32_t)total_bits - (int32_t)start_bit;
+    uint32_t pos = start_bit;
+    uint32_t info = blk_info[b_in_mcu];
+    uint32_t blk = first_block;
+    while (pos < end_bit) {
+        if (FINAL && blk >= total_blocks) break;  // the reference stops after the last MCU
+        const bool is_dc = (k == 0);
+        const LdsHuff h = lds_huff16(tabs, is_dc ? (info & 0xFFF) : ((info >> 12) & 0xFFF));
+        uint32_t sym;
+        int32_t v;
+        const int32_t rem_before = r.rem;
+        const uint32_t e = ub_symbol(r, h, is_dc, closed_by_marker, sym, v);
+        if (e != 0) {
+            err_out = e;
+            return sub_pack(0, b_in_mcu, k) | kSubBad;
+        }
+        pos += (uint32_t)(rem_before - r.rem);
+        if (rem_before - r.rem == 0 && r.rem == 0) pos = end_bit;  // data exhausted: only padding is being read
+        const uint32_t rr = is_dc ? 0u : (sym >> 4);
+        const uint32_t ss = is_dc ? sym : (sym & 15u);
+        if (FINAL && (is_dc || ss != 0)) {
+            uint32_t idx = is_dc ? 0u : (k + rr);
+            idx = idx < 63u ? idx : 63u;
+            coefs[(uint64_t)blk * 64 + idx] = (int16_t)v;  // DC: the difference; K2S-dc adds the predictor chain
+        }
+        k = is_dc ? 1u : (ss != 0 ? k + rr + 1u : (rr == 0 ? 64u : k + 16u));
+        if (k >= 64u) {
+            nblk++;
+            blk++;
+            b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
+            k = 0;
+            info = blk_info[b_in_mcu];
+        }
+    }
+    const uint32_t over = pos > end_bit ? pos - end_bit : 0u;
+    return sub_pack(over < 63u ? over : 63u, b_in_mcu, k);
+}
+
+__device__ __forceinline__ void sub_stage_tables(const DevScan &s, const DevHuffTable *huff_pool, uint8_t *tabs, uint32_t *blk_info, int n_slots,
+                                                 uint32_t nthreads) {
+    const uint32_t tid = threadIdx.x;
+    for (int slot = 0; slot < kMaxHuffSlots && slot < n_slots; slot++) {
+        const uint32_t pi = s.huff_pool[slot];
+        if (pi == 0xFFFF) continue;
+        const uint4 *src = reinterpret_cast<const uint4 *>(&huff_pool[pi]);
+        uint4 *dst = reinterpret_cast<uint4 *>(tabs + slot * sizeof(DevHuffTable));
+        for (uint32_t i = tid; i < sizeof(DevHuffTable) / 16; i += nthreads) dst[i] = src[i];
+    }
+    if (tid < kMaxBlocksPerMcu) {
+        const uint32_t ci = s.blk_comp[tid];
+        const uint32_t dc_off = s.comp[ci].dc_slot * (uint32_t)(sizeof(DevHuffTable) / 16);
+        const uint32_t ac_off = s.comp[ci].ac_slot * (uint32_t)(sizeof(DevHuffTable) / 16);
+        blk_info[tid] = dc_off | (ac_off << 12) | (ci << 24);
+    }
+    __syncthreads();
+}
+
+// One synchronisation round.  exit_in/exit_out are double-buffered per-subsequence state words (index sub_off + sub).
+__global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+                                                            const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
+                                                            const DevScanStatus *__restrict__ status, const DevHuffTable *__restrict__ huff_pool,
+                                                            const uint32_t *__restrict__ exit_in, uint32_t *__restrict__ exit_out,
+                                                            uint32_t *__restrict__ nblk_out, uint32_t *__restrict__ changed, int round,
+                                                            int n_slots) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *tabs = smem;
+    uint32_t *blk_info = reinterpret_cast<uint32_t *>(smem + (size_t)n_slots * sizeof(DevHuffTable));
+    const HuffWork wk = work[blockIdx.x];  // first_interval holds the first subsequence of this workgroup
+    const DevScan &s = scans[wk.scan];
+    sub_stage_tables(s, huff_pool, tabs, blk_info, n_slots, 256);
+    const DevScanStatus st = status[wk.scan];
+    if (st.n_ends == 0) return;
+    const uint32_t ulen = ends_u[s.ends_off];  // DRI = 0: interval 0 starts at 0
+    const uint32_t total_bits = ulen * 8;
+    const uint32_t sub = wk.first_interval + threadIdx.x;
+    if (sub >= s.n_subs) return;
+    const uint32_t slot = s.sub_off + sub;
+    uint32_t entry = 0;  // start of a block of the first component, no overshoot
+    if (sub > 0 && round > 0) {
+        const uint32_t prev = exit_in[slot - 1];
+        if (!(prev & kSubBad)) entry = prev;
+    }
+    if (round > 0 && sub == 0) {
+        exit_out[slot] = exit_in[slot];
+        return;
+    }
+    uint32_t nblk, err;
+    const uint32_t ex = sub_decode<false>(udata + s.data_off, total_bits, sub, entry, tabs, blk_info, s.blocks_per_mcu, nblk, nullptr, 0, 0, err,
+                                          st.terminator != 0);
+    if (round == 0 || ex != exit_in[slot]) atomicOr(changed, 1u);
+    exit_out[slot] = ex;
+    nblk_out[slot] = nblk;
+}
+
+// Exclusive prefix sum of the per-subsequence block counts: first block of every subsequence.  One workgroup per scan.
+__global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__restrict__ scans, const uint32_t *__restrict__ scan_ids,
+                                                            const uint32_t *__restrict__ nblk, uint32_t *__restrict__ first_block) {
+    const DevScan &s = scans[scan_ids[blockIdx.x]];
+    __shared__ uint32_t sh[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (s.n_subs + 1023) / 1024;
+    const uint32_t lo = tid * per, hi = (lo + per) < s.n_subs ? (lo + per) : s.n_subs;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += nblk[s.sub_off + i];
+    sh[tid] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+        const uint32_t v = tid >= o ? sh[tid - o] : 0;
+        __syncthreads();
+        sh[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = sh[tid] - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+        first_block[s.sub_off + i] = run;
+        run += nblk[s.sub_off + i];
+    }
+}
+
+// Final pass: every lane decodes its subsequence from its converged entry state and stores the coefficients.
+__global__ __launch_bounds__(256) void subseq_final_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+                                                            const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
+                                                            DevScanStatus *__restrict__ status, const DevHuffTable *__restrict__ huff_pool,
+                                                            const uint32_t *__restrict__ exit_state, const uint32_t *__restrict__ first_block,
+                                                            int16_t *__restrict__ coefs, int n_slots) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *tabs = smem;
+    uint32_t *blk_info = reinterpret_cast<uint32_t *>(smem + (size_t)n_slots * sizeof(DevHuffTable));
+    const HuffWork wk = work[blockIdx.x];
+    const DevScan &s = scans[wk.scan];
+    sub_stage_tables(s, huff_pool, tabs, blk_info, n_slots, 256);
+    const DevScanStatus st = status[wk.scan];
+    if (st.n_ends == 0) return;
+    const uint32_t ulen = ends_u[s.ends_off];
+    const uint32_t total_bits = ulen * 8;
+    const uint32_t sub = wk.first_interval + threadIdx.x;
+    if (sub >= s.n_subs) return;
+    const uint32_t slot = s.sub_off + sub;
+    const uint32_t total_blocks = s.total_mcus * s.blocks_per_mcu;
+    uint32_t entry = 0;
+    if (sub > 0) {
+        const uint32_t prev = exit_state[slot - 1];
+        if (prev & kSubBad) return;  // the stream ended or failed in an earlier subsequence: reported by that lane
+        entry = prev;
+    }
+    const uint32_t fb = first_block[slot];
+    if (fb >= total_blocks) return;  // everything was decoded before this subsequence
+    uint32_t nblk, err;
+    const uint32_t ex = sub_decode<true>(udata + s.data_off, total_bits, sub, entry, tabs, blk_info, s.blocks_per_mcu, nblk,
+                                         coefs + s.coef_off * 64, fb, total_blocks, err, st.terminator != 0);
+    if ((ex & kSubBad) && err != 0) {
+        // failure on the true path: same detail codes as the interval decoder; "interval" field carries the subsequence
+        atomicMin(&status[wk.scan].first_error, (sub << 8) | err);
+    }
+}
+
+// DC differences -> DC values: per-component running sum over the scan's blocks in scan order (int32, stored as int16).
+// One workgroup per scan; every lane owns a run of consecutive MCUs.
+__global__ __launch_bounds__(1024) void subseq_dc_kernel(const DevScan *__restrict__ scans, const uint32_t *__restrict__ scan_ids,
+                                                          int16_t *__restrict__ coefs) {
+    const DevScan &s = scans[scan_ids[blockIdx.x]];
+    __shared__ int32_t sh[kMaxScanComponents][1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bpm = s.blocks_per_mcu;
+    const uint32_t per = (s.total_mcus + 1023) / 1024;
+    const uint32_t lo = tid * per, hi = (lo + per) < s.total_mcus ? (lo + per) : s.total_mcus;
+    int16_t *base = coefs + s.coef_off * 64;
+    int32_t sum[kMaxScanComponents] = {0, 0, 0, 0};
+    for (uint32_t m = lo; m < hi; m++)
+        for (uint32_t b = 0; b < bpm; b++) sum[s.blk_comp[b]] += base[((uint64_t)m * bpm + b) * 64];
+#pragma unroll
+    for (int c = 0; c < kMaxScanComponents; c++) sh[c][tid] = sum[c];
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        int32_t v[kMaxScanComponents];
+#pragma unroll
+        for (int c = 0; c < kMaxScanComponents; c++) v[c] = tid >= o ? sh[c][tid - o] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < kMaxScanComponents; c++) sh[c][tid] += v[c];
+        __syncthreads();
+    }
+    int32_t run[kMaxScanComponents];
+#pragma unroll
+    for (int c = 0; c < kMaxScanComponents; c++) run[c] = sh[c][tid] - sum[c];
+    for (uint32_t m = lo; m < hi; m++)
+        for (uint32_t b = 0; b < bpm; b++) {
+            const uint32_t c = s.blk_comp[b];
+            int16_t *p = base + ((uint64_t)m * bpm + b) * 64;
+            const int32_t t = run[c] + (int32_t)*p;  // t += DcPredictor; DcPredictor = t; coefficient = (short)t
+            run[c] = t;
+            *p = (int16_t)t;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3: dequantise + IDCT + level shift + block output.  One lane per block.
 // ------------------------------------------------------------------------------------------------
 
@@ -1063,7 +1296,7 @@ typedef __attribute__((address_space(3))) void jpgpu_lds_void;
 typedef const __attribute__((address_space(1))) void jpgpu_gbl_void;
 
 template <int FMT, int LAY>
-__global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 2)) void idct_output_kernel(
+__global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void idct_output_kernel(
     const int16_t *__restrict__ coefs, const DevScan *__restrict__ scans, const IdctWork *__restrict__ work,
     const DevScanStatus *__restrict__ status, const DevQuantTable *__restrict__ quant_pool, uint8_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint8_t sh_all[kIdctThreads * 128 + kIdctThreads * 64 + kMaxScanComponents * 128];
@@ -1372,6 +1605,42 @@ hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+// DRI = 0 scans: self-synchronising subsequence decode.  `work` lists (scan, first subsequence) per workgroup of 256 lanes;
+// `scan_ids` the scans concerned.  Runs synchronisation rounds until no exit state changes (host-checked flag).
+hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
+                                const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
+                                const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
+                                uint32_t *changed_dev, int16_t *coefs, int n_slots, int max_rounds, int *rounds_used) {
+    if (n_work <= 0 || n_scans <= 0) return hipSuccess;
+    const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kMaxBlocksPerMcu * sizeof(uint32_t);
+    uint32_t *bufs[2] = {exit_a, exit_b};
+    int round = 0;
+    for (; round < max_rounds; round++) {
+        hipError_t e = hipMemsetAsync(changed_dev, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        const uint32_t *in = bufs[(round + 1) & 1];
+        uint32_t *out = bufs[round & 1];
+        hipLaunchKernelGGL(subseq_round_kernel, dim3(n_work), dim3(256), lds, stream, udata, scans, work, ends_u, status, huff_pool, in, out,
+                           nblk, changed_dev, round, n_slots);
+        uint32_t changed = 0;
+        e = hipMemcpyAsync(&changed, changed_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        if (!changed && round > 0) {
+            round++;
+            break;
+        }
+    }
+    if (rounds_used) *rounds_used = round;
+    const uint32_t *final_state = bufs[(round + 1) & 1];  // buffer written by the last round executed
+    hipLaunchKernelGGL(subseq_scan_kernel, dim3(n_scans), dim3(1024), 0, stream, scans, scan_ids, nblk, first_block);
+    hipLaunchKernelGGL(subseq_final_kernel, dim3(n_work), dim3(256), lds, stream, udata, scans, work, ends_u, status, huff_pool, final_state,
+                       first_block, coefs, n_slots);
+    hipLaunchKernelGGL(subseq_dc_kernel, dim3(n_scans), dim3(1024), 0, stream, scans, scan_ids, coefs);
+    return hipGetLastError();
 }
 
 hipError_t launch_huffman_tokens(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,

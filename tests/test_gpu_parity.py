@@ -361,6 +361,23 @@ def test_decode_scan_level2_entry():
     assert consumed.value == len(entropy) - 2  # reader left just before EOI
 
 
+def test_dri0_uses_self_synchronising_decoder():
+    """Scans without restart intervals are decoded by parallel 1024-bit subsequences that synchronise in a few rounds;
+    the interval decoder (JPGPU_NO_SUBSEQ=1 path) and the oracle give the same coefficients."""
+    data = jpegsynth.encode(1024, 768, "420", 75, 0, seed=77)
+    b = jl.Batch().upload([data], jl.FMT_INTERLEAVED_U8).decode().sync()
+    assert b.result(0).status == 0
+    rounds = b.subseq_rounds()
+    assert 2 <= rounds <= 16, rounds
+    coefs = jl.Batch().upload([data], jl.FMT_PLANAR_I16).run_entropy().sync().coefficients(0)
+    ref, _ = po.decode_coefficients(data)
+    assert np.array_equal(coefs, ref)
+    assert np.array_equal(b.output(0), po.decode_8bit(data)[0])
+    # truncated DRI = 0 stream (EOI kept so that Identify passes): same exception class as the reference
+    cut = data[:len(data) // 2] + b"\xff\xd9"
+    assert _status_of_gpu(cut)[0] == _status_of_oracle(cut) != "OK"
+
+
 def test_full_size_properties_4k():
     """BASELINE config-2 geometry at full size: every image of a small 4K batch is bit-exact vs the oracle, and the
     DRI=4 and DRI=0 encodings of the same pixels decode to identical output (restart markers carry no information)."""
