@@ -892,8 +892,8 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
                                                             const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
                                                             const DevScanStatus *__restrict__ status, const DevHuffTable *__restrict__ huff_pool,
                                                             const uint32_t *__restrict__ exit_in, uint32_t *__restrict__ exit_out,
-                                                            uint32_t *__restrict__ nblk_out, uint32_t *__restrict__ changed, int round,
-                                                            int n_slots) {
+                                                            uint32_t *__restrict__ nblk_out, uint32_t *__restrict__ entry_used,
+                                                            uint32_t *__restrict__ changed, int round, int n_slots) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *tabs = smem;
     uint32_t *blk_info = reinterpret_cast<uint32_t *>(smem + (size_t)n_slots * sizeof(DevHuffTable));
@@ -912,10 +912,12 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
         const uint32_t prev = exit_in[slot - 1];
         if (!(prev & kSubBad)) entry = prev;
     }
-    if (round > 0 && sub == 0) {
+    // a lane whose entry state did not change since it last decoded keeps its exit state (and block count)
+    if (round > 0 && (sub == 0 || entry_used[slot] == entry)) {
         exit_out[slot] = exit_in[slot];
         return;
     }
+    entry_used[slot] = entry;
     uint32_t nblk, err;
     const uint32_t ex = sub_decode<false>(udata + s.data_off, total_bits, sub, entry, tabs, blk_info, s.blocks_per_mcu, nblk, nullptr, 0, 0, err,
                                           st.terminator != 0);
@@ -1612,7 +1614,7 @@ hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *
 hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                                 const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
-                                uint32_t *changed_dev, int16_t *coefs, int n_slots, int max_rounds, int *rounds_used) {
+                                uint32_t *entry_used, uint32_t *changed_dev, int16_t *coefs, int n_slots, int max_rounds, int *rounds_used) {
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kMaxBlocksPerMcu * sizeof(uint32_t);
     uint32_t *bufs[2] = {exit_a, exit_b};
@@ -1623,7 +1625,7 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
         const uint32_t *in = bufs[(round + 1) & 1];
         uint32_t *out = bufs[round & 1];
         hipLaunchKernelGGL(subseq_round_kernel, dim3(n_work), dim3(256), lds, stream, udata, scans, work, ends_u, status, huff_pool, in, out,
-                           nblk, changed_dev, round, n_slots);
+                           nblk, entry_used, changed_dev, round, n_slots);
         uint32_t changed = 0;
         e = hipMemcpyAsync(&changed, changed_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
         if (e != hipSuccess) return e;
