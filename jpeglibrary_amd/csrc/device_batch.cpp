@@ -40,7 +40,7 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_changed_, &d_chunk_work_, &d_chunk_sums_, &d_tokens_, &d_blk_tok_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_chunk_work_, &d_chunk_sums_, &d_tokens_, &d_blk_tok_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
@@ -375,7 +375,9 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_sub_nblk_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
         {&d_sub_first_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
         {&d_sub_entry_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
-        {&d_sub_changed_, nullptr, 0, 256},
+        {&d_sub_dcsum_, nullptr, 0, (size_t)total_subs_ * 16 + 256},
+        {&d_sub_dcentry_, nullptr, 0, (size_t)total_subs_ * 16 + 256},
+        {&d_sub_changed_, nullptr, 0, 64 * sizeof(uint32_t)},
         {&d_chunk_sums_, nullptr, 0, chunk_work.size() * sizeof(ChunkSum) + 256},
         {&d_idct_work_, idct_work.data(), idct_work.size() * sizeof(IdctWork), 0},
         {&d_ends_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},
@@ -430,16 +432,30 @@ int DeviceBatch::run_huffman() {
     if (e != hipSuccess) return hip_fail(e, "huffman_decode_kernel");
     if (n_sub_work_ > 0) {
         // DRI = 0 scans: the final pass scatters coefficients into a zeroed buffer
-        for (uint32_t j : sub_scan_ids_) {
-            const DevScan &s = h_scans_[j];
-            e = hipMemsetAsync((int16_t *)d_coefs_.ptr + s.coef_off * 64, 0, (size_t)s.total_mcus * s.blocks_per_mcu * 128, ctx_->stream);
-            if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(coefficients)");
+        uint64_t run_first = 0, run_blocks = 0;  // adjacent scans are cleared with one memset
+        for (size_t k = 0; k <= sub_scan_ids_.size(); k++) {
+            uint64_t first = 0, nblocks = 0;
+            if (k < sub_scan_ids_.size()) {
+                const DevScan &s = h_scans_[sub_scan_ids_[k]];
+                first = s.coef_off;
+                nblocks = (uint64_t)s.total_mcus * s.blocks_per_mcu;
+            }
+            if (k < sub_scan_ids_.size() && run_blocks && first == run_first + run_blocks) {
+                run_blocks += nblocks;
+                continue;
+            }
+            if (run_blocks) {
+                e = hipMemsetAsync((int16_t *)d_coefs_.ptr + run_first * 64, 0, (size_t)run_blocks * 128, ctx_->stream);
+                if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(coefficients)");
+            }
+            run_first = first;
+            run_blocks = nblocks;
         }
         e = launch_subseq_decode(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_sub_work_.ptr,
                                  n_sub_work_, (const uint32_t *)d_sub_scan_ids_.ptr, n_sub_scans_, (const uint32_t *)d_ends_u_.ptr,
                                  (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (uint32_t *)d_sub_exit_a_.ptr,
                                  (uint32_t *)d_sub_exit_b_.ptr, (uint32_t *)d_sub_nblk_.ptr, (uint32_t *)d_sub_first_.ptr,
-                                 (uint32_t *)d_sub_entry_.ptr, (uint32_t *)d_sub_changed_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (int)max_subs_per_scan_ + 2,
+                                 (uint32_t *)d_sub_entry_.ptr, d_sub_dcsum_.ptr, d_sub_dcentry_.ptr, (uint32_t *)d_sub_changed_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (int)max_subs_per_scan_ + 2,
                                  &last_subseq_rounds_);
         if (e != hipSuccess) return hip_fail(e, "subsequence decode");
     }

@@ -34,7 +34,8 @@ constexpr uint32_t kSubseqBits = 1024;
 hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                                 const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
-                                uint32_t *entry_used, uint32_t *changed_dev, int16_t *coefs, int n_slots, int max_rounds, int *rounds_used);
+                                uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
+                                int max_rounds, int *rounds_used);
 
 // token pipeline (K2T / K3T)
 hipError_t launch_huffman_tokens(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,

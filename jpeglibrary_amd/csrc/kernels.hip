@@ -815,10 +815,12 @@ __device__ __forceinline__ uint32_t sub_pack(uint32_t overshoot, uint32_t b, uin
 // Decodes subsequence `sub` of a DRI = 0 scan from `entry` (packed like an exit of sub-1).  When `coefs` is non-null
 // the coefficients are stored (final pass), starting with block `first_block`.  Returns the exit state word; *nblk =
 // blocks COMPLETED inside the subsequence.
+// dc[c]: FINAL: in = DcPredictor of component c at the entry, the chain is applied while decoding;
+//        otherwise out = sum of the DC differences of component c decoded inside the subsequence.
 template <bool FINAL>
 __device__ __forceinline__ uint32_t sub_decode(const uint8_t *ubase, uint32_t total_bits, uint32_t sub, uint32_t entry, const uint8_t *tabs,
                                                const uint32_t *blk_info, uint32_t bpm, uint32_t &nblk, int16_t *coefs, uint32_t first_block,
-                                               uint32_t total_blocks, uint32_t &err_out, bool closed_by_marker) {
+                                               uint32_t total_blocks, uint32_t &err_out, bool closed_by_marker, int32_t (&dc)[4]) {
     const uint32_t start_bit = sub * kSubBits + (entry & 63u);
     const uint32_t end_bit = (sub + 1) * kSubBits;
     uint32_t b_in_mcu = (entry >> 6) & 31u, k = (entry >> 11) & 127u;
@@ -850,10 +852,21 @@ __device__ __forceinline__ uint32_t sub_decode(const uint8_t *ubase, uint32_t to
         if (rem_before - r.rem == 0 && r.rem == 0) pos = end_bit;  // data exhausted: only padding is being read
         const uint32_t rr = is_dc ? 0u : (sym >> 4);
         const uint32_t ss = is_dc ? sym : (sym & 15u);
+        if (is_dc) {
+            // t += DcPredictor; DcPredictor = t (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:193-195); in the
+            // synchronisation rounds dc[] starts at 0 and simply accumulates the differences
+            const uint32_t ci = info >> 24;
+            const int32_t t = v + (ci == 0 ? dc[0] : (ci == 1 ? dc[1] : (ci == 2 ? dc[2] : dc[3])));
+            if (ci == 0) dc[0] = t;
+            else if (ci == 1) dc[1] = t;
+            else if (ci == 2) dc[2] = t;
+            else dc[3] = t;
+            v = t;
+        }
         if (FINAL && (is_dc || ss != 0)) {
             uint32_t idx = is_dc ? 0u : (k + rr);
             idx = idx < 63u ? idx : 63u;
-            coefs[(uint64_t)blk * 64 + idx] = (int16_t)v;  // DC: the difference; K2S-dc adds the predictor chain
+            coefs[(uint64_t)blk * 64 + idx] = (int16_t)v;
         }
         k = is_dc ? 1u : (ss != 0 ? k + rr + 1u : (rr == 0 ? 64u : k + 16u));
         if (k >= 64u) {
@@ -893,61 +906,86 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
                                                             const DevScanStatus *__restrict__ status, const DevHuffTable *__restrict__ huff_pool,
                                                             const uint32_t *__restrict__ exit_in, uint32_t *__restrict__ exit_out,
                                                             uint32_t *__restrict__ nblk_out, uint32_t *__restrict__ entry_used,
-                                                            uint32_t *__restrict__ changed, int round, int n_slots) {
+                                                            int4 *__restrict__ dcsum_out, uint32_t *__restrict__ changed, int round,
+                                                            int n_slots) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *tabs = smem;
     uint32_t *blk_info = reinterpret_cast<uint32_t *>(smem + (size_t)n_slots * sizeof(DevHuffTable));
     const HuffWork wk = work[blockIdx.x];  // first_interval holds the first subsequence of this workgroup
     const DevScan &s = scans[wk.scan];
-    sub_stage_tables(s, huff_pool, tabs, blk_info, n_slots, 256);
     const DevScanStatus st = status[wk.scan];
     if (st.n_ends == 0) return;
     const uint32_t ulen = ends_u[s.ends_off];  // DRI = 0: interval 0 starts at 0
     const uint32_t total_bits = ulen * 8;
     const uint32_t sub = wk.first_interval + threadIdx.x;
-    if (sub >= s.n_subs) return;
-    const uint32_t slot = s.sub_off + sub;
+    const bool in_range = sub < s.n_subs;
+    const uint32_t slot = s.sub_off + (in_range ? sub : 0);
     uint32_t entry = 0;  // start of a block of the first component, no overshoot
-    if (sub > 0 && round > 0) {
+    if (in_range && sub > 0 && round > 0) {
         const uint32_t prev = exit_in[slot - 1];
         if (!(prev & kSubBad)) entry = prev;
     }
-    // a lane whose entry state did not change since it last decoded keeps its exit state (and block count)
-    if (round > 0 && (sub == 0 || entry_used[slot] == entry)) {
-        exit_out[slot] = exit_in[slot];
-        return;
-    }
+    // a lane whose entry state did not change since it last decoded keeps its exit state (and block count);
+    // a workgroup with no lane left to decode leaves before staging the tables (most workgroups after round 1)
+    const bool need = in_range && !(round > 0 && (sub == 0 || entry_used[slot] == entry));
+    if (in_range && !need) exit_out[slot] = exit_in[slot];
+    if (!__syncthreads_or(need ? 1 : 0)) return;
+    sub_stage_tables(s, huff_pool, tabs, blk_info, n_slots, 256);
+    if (!need) return;
     entry_used[slot] = entry;
     uint32_t nblk, err;
+    int32_t dc[4] = {0, 0, 0, 0};
     const uint32_t ex = sub_decode<false>(udata + s.data_off, total_bits, sub, entry, tabs, blk_info, s.blocks_per_mcu, nblk, nullptr, 0, 0, err,
-                                          st.terminator != 0);
+                                          st.terminator != 0, dc);
     if (round == 0 || ex != exit_in[slot]) atomicOr(changed, 1u);
     exit_out[slot] = ex;
     nblk_out[slot] = nblk;
+    dcsum_out[slot] = make_int4(dc[0], dc[1], dc[2], dc[3]);
 }
 
-// Exclusive prefix sum of the per-subsequence block counts: first block of every subsequence.  One workgroup per scan.
+// Exclusive prefix sums over a scan's subsequences: first block and DC predictors at the entry of every subsequence.
+// One workgroup per scan.
 __global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__restrict__ scans, const uint32_t *__restrict__ scan_ids,
-                                                            const uint32_t *__restrict__ nblk, uint32_t *__restrict__ first_block) {
+                                                            const uint32_t *__restrict__ nblk, uint32_t *__restrict__ first_block,
+                                                            const int4 *__restrict__ dcsum, int4 *__restrict__ dc_entry) {
     const DevScan &s = scans[scan_ids[blockIdx.x]];
-    __shared__ uint32_t sh[1024];
+    __shared__ int32_t sh[5][1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (s.n_subs + 1023) / 1024;
     const uint32_t lo = tid * per, hi = (lo + per) < s.n_subs ? (lo + per) : s.n_subs;
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += nblk[s.sub_off + i];
-    sh[tid] = sum;
+    int32_t sum[5] = {0, 0, 0, 0, 0};
+    for (uint32_t i = lo; i < hi; i++) {
+        const int4 d = dcsum[s.sub_off + i];
+        sum[0] += (int32_t)nblk[s.sub_off + i];
+        sum[1] += d.x;
+        sum[2] += d.y;
+        sum[3] += d.z;
+        sum[4] += d.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 5; c++) sh[c][tid] = sum[c];
     __syncthreads();
     for (uint32_t o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
-        const uint32_t v = tid >= o ? sh[tid - o] : 0;
+        int32_t v[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) v[c] = tid >= o ? sh[c][tid - o] : 0;
         __syncthreads();
-        sh[tid] += v;
+#pragma unroll
+        for (int c = 0; c < 5; c++) sh[c][tid] += v[c];
         __syncthreads();
     }
-    uint32_t run = sh[tid] - sum;
+    int32_t run[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) run[c] = sh[c][tid] - sum[c];
     for (uint32_t i = lo; i < hi; i++) {
-        first_block[s.sub_off + i] = run;
-        run += nblk[s.sub_off + i];
+        first_block[s.sub_off + i] = (uint32_t)run[0];
+        dc_entry[s.sub_off + i] = make_int4(run[1], run[2], run[3], run[4]);
+        const int4 d = dcsum[s.sub_off + i];
+        run[0] += (int32_t)nblk[s.sub_off + i];
+        run[1] += d.x;
+        run[2] += d.y;
+        run[3] += d.z;
+        run[4] += d.w;
     }
 }
 
@@ -956,7 +994,7 @@ __global__ __launch_bounds__(256) void subseq_final_kernel(const uint8_t *__rest
                                                             const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
                                                             DevScanStatus *__restrict__ status, const DevHuffTable *__restrict__ huff_pool,
                                                             const uint32_t *__restrict__ exit_state, const uint32_t *__restrict__ first_block,
-                                                            int16_t *__restrict__ coefs, int n_slots) {
+                                                            const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs, int n_slots) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *tabs = smem;
     uint32_t *blk_info = reinterpret_cast<uint32_t *>(smem + (size_t)n_slots * sizeof(DevHuffTable));
@@ -980,51 +1018,14 @@ __global__ __launch_bounds__(256) void subseq_final_kernel(const uint8_t *__rest
     const uint32_t fb = first_block[slot];
     if (fb >= total_blocks) return;  // everything was decoded before this subsequence
     uint32_t nblk, err;
+    const int4 de = dc_entry[slot];
+    int32_t dc[4] = {de.x, de.y, de.z, de.w};
     const uint32_t ex = sub_decode<true>(udata + s.data_off, total_bits, sub, entry, tabs, blk_info, s.blocks_per_mcu, nblk,
-                                         coefs + s.coef_off * 64, fb, total_blocks, err, st.terminator != 0);
+                                         coefs + s.coef_off * 64, fb, total_blocks, err, st.terminator != 0, dc);
     if ((ex & kSubBad) && err != 0) {
         // failure on the true path: same detail codes as the interval decoder; "interval" field carries the subsequence
         atomicMin(&status[wk.scan].first_error, (sub << 8) | err);
     }
-}
-
-// DC differences -> DC values: per-component running sum over the scan's blocks in scan order (int32, stored as int16).
-// One workgroup per scan; every lane owns a run of consecutive MCUs.
-__global__ __launch_bounds__(1024) void subseq_dc_kernel(const DevScan *__restrict__ scans, const uint32_t *__restrict__ scan_ids,
-                                                          int16_t *__restrict__ coefs) {
-    const DevScan &s = scans[scan_ids[blockIdx.x]];
-    __shared__ int32_t sh[kMaxScanComponents][1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t bpm = s.blocks_per_mcu;
-    const uint32_t per = (s.total_mcus + 1023) / 1024;
-    const uint32_t lo = tid * per, hi = (lo + per) < s.total_mcus ? (lo + per) : s.total_mcus;
-    int16_t *base = coefs + s.coef_off * 64;
-    int32_t sum[kMaxScanComponents] = {0, 0, 0, 0};
-    for (uint32_t m = lo; m < hi; m++)
-        for (uint32_t b = 0; b < bpm; b++) sum[s.blk_comp[b]] += base[((uint64_t)m * bpm + b) * 64];
-#pragma unroll
-    for (int c = 0; c < kMaxScanComponents; c++) sh[c][tid] = sum[c];
-    __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
-        int32_t v[kMaxScanComponents];
-#pragma unroll
-        for (int c = 0; c < kMaxScanComponents; c++) v[c] = tid >= o ? sh[c][tid - o] : 0;
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < kMaxScanComponents; c++) sh[c][tid] += v[c];
-        __syncthreads();
-    }
-    int32_t run[kMaxScanComponents];
-#pragma unroll
-    for (int c = 0; c < kMaxScanComponents; c++) run[c] = sh[c][tid] - sum[c];
-    for (uint32_t m = lo; m < hi; m++)
-        for (uint32_t b = 0; b < bpm; b++) {
-            const uint32_t c = s.blk_comp[b];
-            int16_t *p = base + ((uint64_t)m * bpm + b) * 64;
-            const int32_t t = run[c] + (int32_t)*p;  // t += DcPredictor; DcPredictor = t; coefficient = (short)t
-            run[c] = t;
-            *p = (int16_t)t;
-        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1614,34 +1615,44 @@ hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *
 hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                                 const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
-                                uint32_t *entry_used, uint32_t *changed_dev, int16_t *coefs, int n_slots, int max_rounds, int *rounds_used) {
+                                uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
+                                int max_rounds, int *rounds_used) {
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kMaxBlocksPerMcu * sizeof(uint32_t);
     uint32_t *bufs[2] = {exit_a, exit_b};
+    // changed_dev[r] is set by round r; the host looks at the flags only every kCheckEvery rounds (one sync per check)
+    constexpr int kCheckEvery = 3;
+    hipError_t e = hipMemsetAsync(changed_dev, 0, 64 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
     int round = 0;
-    for (; round < max_rounds; round++) {
-        hipError_t e = hipMemsetAsync(changed_dev, 0, sizeof(uint32_t), stream);
-        if (e != hipSuccess) return e;
-        const uint32_t *in = bufs[(round + 1) & 1];
-        uint32_t *out = bufs[round & 1];
-        hipLaunchKernelGGL(subseq_round_kernel, dim3(n_work), dim3(256), lds, stream, udata, scans, work, ends_u, status, huff_pool, in, out,
-                           nblk, entry_used, changed_dev, round, n_slots);
-        uint32_t changed = 0;
-        e = hipMemcpyAsync(&changed, changed_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    bool converged = false;
+    while (!converged && round < max_rounds) {
+        const int batch_first = round;
+        for (int i = 0; i < kCheckEvery && round < max_rounds; i++, round++) {
+            const uint32_t *in = bufs[(round + 1) & 1];
+            uint32_t *out = bufs[round & 1];
+            hipLaunchKernelGGL(subseq_round_kernel, dim3(n_work), dim3(256), lds, stream, udata, scans, work, ends_u, status, huff_pool, in, out,
+                               nblk, entry_used, (int4 *)dcsum, changed_dev + (round & 63), round, n_slots);
+        }
+        uint32_t flags[64];
+        e = hipMemcpyAsync(flags, changed_dev, sizeof flags, hipMemcpyDeviceToHost, stream);
         if (e != hipSuccess) return e;
         e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return e;
-        if (!changed && round > 0) {
-            round++;
-            break;
+        // converged as soon as one round (other than round 0) changed nothing: later rounds are then no-ops
+        for (int r2 = batch_first; r2 < round; r2++)
+            if (r2 > 0 && flags[r2 & 63] == 0) converged = true;
+        if (!converged) {
+            e = hipMemsetAsync(changed_dev, 0, 64 * sizeof(uint32_t), stream);
+            if (e != hipSuccess) return e;
         }
     }
     if (rounds_used) *rounds_used = round;
     const uint32_t *final_state = bufs[(round + 1) & 1];  // buffer written by the last round executed
-    hipLaunchKernelGGL(subseq_scan_kernel, dim3(n_scans), dim3(1024), 0, stream, scans, scan_ids, nblk, first_block);
+    hipLaunchKernelGGL(subseq_scan_kernel, dim3(n_scans), dim3(1024), 0, stream, scans, scan_ids, nblk, first_block, (const int4 *)dcsum,
+                       (int4 *)dc_entry);
     hipLaunchKernelGGL(subseq_final_kernel, dim3(n_work), dim3(256), lds, stream, udata, scans, work, ends_u, status, huff_pool, final_state,
-                       first_block, coefs, n_slots);
-    hipLaunchKernelGGL(subseq_dc_kernel, dim3(n_scans), dim3(1024), 0, stream, scans, scan_ids, coefs);
+                       first_block, (const int4 *)dc_entry, coefs, n_slots);
     return hipGetLastError();
 }
 
