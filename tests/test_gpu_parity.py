@@ -390,3 +390,40 @@ def test_full_size_properties_4k():
         assert np.array_equal(outs4[i], outs0[i])
     ref, _ = po.decode_8bit(files4[0])
     assert np.array_equal(outs4[0], ref)
+
+
+def test_multi_scan_and_four_component_files():
+    """Non-interleaved baseline files (three single-component scans = three scan jobs writing one image) and a
+    4-component (CMYK) file exercise the generic bytewise output path and the multi-scan plumbing."""
+    import io
+
+    from PIL import Image
+
+    files = [
+        jpegsynth.encode(120, 88, "444", 80, 0, seed=9, noninterleaved=True),
+        jpegsynth.encode(120, 88, "444", 80, 4, seed=9, noninterleaved=True),
+        jpegsynth.encode(333, 211, "444", 60, 8, seed=10, noninterleaved=True),
+    ]
+    rng = np.random.default_rng(3)
+    buf = io.BytesIO()
+    Image.fromarray(rng.integers(0, 255, size=(70, 90, 4), dtype=np.uint8), mode="CMYK").save(buf, "JPEG", quality=80)
+    files.append(buf.getvalue())
+    outs, results = jl.decode_batch(files, jl.FMT_INTERLEAVED_U8)
+    for f, out, res in zip(files, outs, results):
+        assert res.status == 0
+        assert np.array_equal(out, po.decode_8bit(f)[0])
+    # the interleaved and non-interleaved encodings of the same pixels decode identically
+    assert np.array_equal(outs[0], jl.decode_batch([jpegsynth.encode(120, 88, "444", 80, 0, seed=9)])[0][0])
+    # reference quirk: when the MCU count is a multiple of DRI the restart check after the last MCU demands EOI/RSTn,
+    # so a scan followed by another SOS fails with "Expect restart marker." (BaselineScanDecoder.cs:139-154)
+    quirk = jpegsynth.encode(120, 88, "444", 80, 5, seed=9, noninterleaved=True)  # 165 MCUs = 33 x 5
+    assert _status_of_oracle(quirk) == "InvalidOperationException"
+    assert _status_of_gpu(quirk)[0] == "InvalidOperationException"
+    # same files through the JpegDecoder mirror (each SOS is one GPU scan decode into the caller's buffer)
+    d = jl.JpegDecoder()
+    d.SetInput(files[1])
+    d.Identify()
+    out = np.zeros(d.Width * d.Height * 3, np.uint8)
+    d.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(d.Width, d.Height, 3, out))
+    d.Decode()
+    assert np.array_equal(out.reshape(88, 120, 3), po.decode_8bit(files[1])[0])

@@ -20,6 +20,7 @@ typedef struct jsynth_params {
     int quality;          /* 1..100, libjpeg scaling */
     int restart_interval; /* MCUs, 0 = none */
     uint64_t seed;
+    int noninterleaved;   /* 4:4:4 only: three single-component scans instead of one interleaved scan */
 } jsynth_params;
 
 static const uint8_t k_zigzag_to_natural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
@@ -393,73 +394,90 @@ long jsynth_encode(const jsynth_params *prm, uint8_t *out, size_t cap) {
         seg[1] = (uint8_t)prm->restart_interval;
         p = put_marker_seg(p, 0xDD, seg, 2);
     }
-    /* SOS */
-    seg[0] = (uint8_t)ncomp;
-    seg[1] = 1;
-    seg[2] = 0x00;
-    if (ncomp == 3) {
-        seg[3] = 2;
-        seg[4] = 0x11;
-        seg[5] = 3;
-        seg[6] = 0x11;
-    }
-    seg[1 + 2 * ncomp] = 0;
-    seg[2 + 2 * ncomp] = 63;
-    seg[3 + 2 * ncomp] = 0;
-    p = put_marker_seg(p, 0xDA, seg, 4 + 2 * ncomp);
-
+    const int nscans = (prm->noninterleaved && ss == 0 && ncomp == 3) ? 3 : 1;
     synth_ctx sc;
     synth_init(&sc, w, h, prm->seed);
     size_t rowsz = (size_t)wpad;
     float *Y = (float *)malloc(sizeof(float) * rowsz * mcuh * 3);
     float *Cb = Y + rowsz * mcuh, *Cr = Cb + rowsz * mcuh;
-
     bitwriter bw = {p, out + cap - 4, 0, 0, 0};
-    int pred[3] = {0, 0, 0};
-    int mcus_before_restart = prm->restart_interval, rst_index = 0;
     float blk[64];
-    for (int my = 0; my < mcus_y && !bw.overflow; my++) {
-        for (int r = 0; r < mcuh; r++) synth_row(&sc, my * mcuh + r, wpad, Y + r * rowsz, Cb + r * rowsz, Cr + r * rowsz);
-        for (int mx = 0; mx < mcus_x; mx++) {
-            for (int by = 0; by < vmax; by++)
-                for (int bx = 0; bx < hmax; bx++) {
-                    const float *src = Y + (size_t)(by * 8) * rowsz + (size_t)mx * mcuw + bx * 8;
-                    for (int i = 0; i < 8; i++)
-                        for (int j = 0; j < 8; j++) blk[i * 8 + j] = src[i * rowsz + j] - 128.f;
-                    encode_block(&bw, blk, qdiv_l, &dcl, &acl, &pred[0]);
-                }
+    for (int scan = 0; scan < nscans && !bw.overflow; scan++) {
+        /* SOS */
+        uint8_t *hp = bw.p;
+        if (nscans == 1) {
+            seg[0] = (uint8_t)ncomp;
+            seg[1] = 1;
+            seg[2] = 0x00;
             if (ncomp == 3) {
-                for (int c = 0; c < 2; c++) {
-                    const float *pl = c == 0 ? Cb : Cr;
-                    const float *src = pl + (size_t)mx * mcuw;
-                    for (int i = 0; i < 8; i++)
-                        for (int j = 0; j < 8; j++) {
-                            float acc_ = 0.f;
-                            for (int vy = 0; vy < vmax; vy++)
-                                for (int vx = 0; vx < hmax; vx++) acc_ += src[(size_t)(i * vmax + vy) * rowsz + j * hmax + vx];
-                            float v = acc_ / (float)(hmax * vmax);
-                            blk[i * 8 + j] = floorf(v + 0.5f) - 128.f;
-                        }
-                    encode_block(&bw, blk, qdiv_c, &dcc, &acc, &pred[1 + c]);
-                }
+                seg[3] = 2;
+                seg[4] = 0x11;
+                seg[5] = 3;
+                seg[6] = 0x11;
             }
-            if (prm->restart_interval > 0 && --mcus_before_restart == 0) {
-                int last = (my == mcus_y - 1 && mx == mcus_x - 1);
-                if (!last) {
-                    bw_flush_ones(&bw);
-                    if (bw.p + 2 <= bw.end) {
-                        *bw.p++ = 0xFF;
-                        *bw.p++ = (uint8_t)(0xD0 + (rst_index & 7));
-                    } else
-                        bw.overflow = 1;
-                    rst_index++;
-                    pred[0] = pred[1] = pred[2] = 0;
+            seg[1 + 2 * ncomp] = 0;
+            seg[2 + 2 * ncomp] = 63;
+            seg[3 + 2 * ncomp] = 0;
+            hp = put_marker_seg(hp, 0xDA, seg, 4 + 2 * ncomp);
+        } else {
+            seg[0] = 1;
+            seg[1] = (uint8_t)(scan + 1);
+            seg[2] = scan == 0 ? 0x00 : 0x11;
+            seg[3] = 0;
+            seg[4] = 63;
+            seg[5] = 0;
+            hp = put_marker_seg(hp, 0xDA, seg, 6);
+        }
+        bw.p = hp;
+        bw.acc = 0;
+        bw.nbits = 0;
+        int pred[3] = {0, 0, 0};
+        int mcus_before_restart = prm->restart_interval, rst_index = 0;
+        for (int my = 0; my < mcus_y && !bw.overflow; my++) {
+            for (int r = 0; r < mcuh; r++) synth_row(&sc, my * mcuh + r, wpad, Y + r * rowsz, Cb + r * rowsz, Cr + r * rowsz);
+            for (int mx = 0; mx < mcus_x; mx++) {
+                if (nscans == 1 || scan == 0)
+                    for (int by = 0; by < vmax; by++)
+                        for (int bx = 0; bx < hmax; bx++) {
+                            const float *src = Y + (size_t)(by * 8) * rowsz + (size_t)mx * mcuw + bx * 8;
+                            for (int i = 0; i < 8; i++)
+                                for (int j = 0; j < 8; j++) blk[i * 8 + j] = src[i * rowsz + j] - 128.f;
+                            encode_block(&bw, blk, qdiv_l, &dcl, &acl, &pred[0]);
+                        }
+                if (ncomp == 3) {
+                    for (int c = 0; c < 2; c++) {
+                        if (nscans == 3 && scan != c + 1) continue;
+                        const float *pl = c == 0 ? Cb : Cr;
+                        const float *src = pl + (size_t)mx * mcuw;
+                        for (int i = 0; i < 8; i++)
+                            for (int j = 0; j < 8; j++) {
+                                float acc_ = 0.f;
+                                for (int vy = 0; vy < vmax; vy++)
+                                    for (int vx = 0; vx < hmax; vx++) acc_ += src[(size_t)(i * vmax + vy) * rowsz + j * hmax + vx];
+                                float v = acc_ / (float)(hmax * vmax);
+                                blk[i * 8 + j] = floorf(v + 0.5f) - 128.f;
+                            }
+                        encode_block(&bw, blk, qdiv_c, &dcc, &acc, &pred[1 + c]);
+                    }
                 }
-                mcus_before_restart = prm->restart_interval;
+                if (prm->restart_interval > 0 && --mcus_before_restart == 0) {
+                    int last = (my == mcus_y - 1 && mx == mcus_x - 1);
+                    if (!last) {
+                        bw_flush_ones(&bw);
+                        if (bw.p + 2 <= bw.end) {
+                            *bw.p++ = 0xFF;
+                            *bw.p++ = (uint8_t)(0xD0 + (rst_index & 7));
+                        } else
+                            bw.overflow = 1;
+                        rst_index++;
+                        pred[0] = pred[1] = pred[2] = 0;
+                    }
+                    mcus_before_restart = prm->restart_interval;
+                }
             }
         }
+        bw_flush_ones(&bw);
     }
-    bw_flush_ones(&bw);
     free(Y);
     synth_free(&sc);
     if (bw.overflow) return -2;

@@ -15,7 +15,7 @@ SUBSAMPLING = {"444": 0, "4:4:4": 0, "422": 1, "4:2:2": 1, "420": 2, "4:2:0": 2,
 
 class Params(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("subsampling", C.c_int), ("quality", C.c_int),
-                ("restart_interval", C.c_int), ("seed", C.c_uint64)]
+                ("restart_interval", C.c_int), ("seed", C.c_uint64), ("noninterleaved", C.c_int)]
 
 
 def build(force=False):
@@ -46,9 +46,10 @@ def _cap(width, height):
     return int(width * height * 3 + (1 << 16))
 
 
-def encode(width, height, subsampling="420", quality=75, restart_interval=0, seed=0) -> bytes:
+def encode(width, height, subsampling="420", quality=75, restart_interval=0, seed=0, noninterleaved=False) -> bytes:
+    """noninterleaved=True (4:4:4 only): three single-component scans instead of one interleaved scan."""
     L = _get()
-    p = Params(width, height, SUBSAMPLING[str(subsampling)], quality, restart_interval, seed)
+    p = Params(width, height, SUBSAMPLING[str(subsampling)], quality, restart_interval, seed, int(noninterleaved))
     buf = np.empty(_cap(width, height), dtype=np.uint8)
     n = L.jsynth_encode(C.byref(p), buf.ctypes.data, buf.size)
     if n < 0:
@@ -66,7 +67,7 @@ def encode_batch(n, width, height, subsampling="420", quality=75, restart_interv
     stride = (stride + 255) & ~255
     arr = (Params * n)()
     for i in range(n):
-        arr[i] = Params(width, height, SUBSAMPLING[str(subsampling)], quality, restart_interval, seed0 + i)
+        arr[i] = Params(width, height, SUBSAMPLING[str(subsampling)], quality, restart_interval, seed0 + i, 0)
     buf = np.empty(n * stride, dtype=np.uint8)
     sizes = (C.c_long * n)()
     rc = L.jsynth_encode_batch(arr, n, buf.ctypes.data, stride, sizes, nthreads)
