@@ -157,6 +157,15 @@ void jpgpu_batch_destroy(jpgpu_batch *b);
  * Returns JPGPU_OK if the batch is usable (even if some images failed). */
 int jpgpu_batch_upload(jpgpu_batch *b, const uint8_t *const *jpeg, const size_t *len, int n, int format);
 
+/* Coefficient hand-off for multi-scan (progressive, SOF2) images -- BASELINE config 5's "coefficient accumulate then single
+ * IDCT pass": the caller's progressive entropy decoder accumulates the coefficient store, the GPU runs what
+ * JpegHuffmanProgressiveScanDecoder.Dispose (ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs:421-470: dequantise, IDCT,
+ * level shift over the MCU grid) and JpegBlockAllocator.Flush (JpegBlockAllocator.cs:120-190) do.  Images are described
+ * by their frame header and quantisation tables only (qt[i][tq][64], zig-zag order); then
+ * jpgpu_batch_upload_coefficients(i, blocks in MCU scan order: MCU raster, component order, block raster in the MCU)
+ * and jpgpu_batch_run_idct. */
+int jpgpu_batch_upload_frames(jpgpu_batch *b, const jpgpu_frame *frames, const uint16_t *qt, int n, int format);
+
 /* Launches the device pipeline on the ctx stream (asynchronous):
  *   marker index -> Huffman MCU decode (ref: ...BaselineScanDecoder.cs:51-222) ->
  *   dequantise + float32 IDCT + level shift (ref: ScanDecoder/JpegScanDecoder.cs:50-73, FastFloatingPointDCT.cs:54-185) ->

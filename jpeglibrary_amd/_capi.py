@@ -71,6 +71,7 @@ SYMBOLS = [
     ("jpgpu_batch_create", C.c_int, [_P, C.POINTER(_P)]),
     ("jpgpu_batch_destroy", None, [_P]),
     ("jpgpu_batch_upload", C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int]),
+    ("jpgpu_batch_upload_frames", C.c_int, [_P, C.POINTER(Frame), C.c_void_p, C.c_int, C.c_int]),
     ("jpgpu_batch_decode", C.c_int, [_P]),
     ("jpgpu_batch_run_entropy", C.c_int, [_P]),
     ("jpgpu_batch_run_idct", C.c_int, [_P]),

@@ -44,6 +44,23 @@ class Batch:
         self.format = fmt
         return self
 
+    def upload_frames(self, frames, quant_tables, fmt=FMT_INTERLEAVED_U8):
+        """Coefficient hand-off (progressive images, BASELINE config 5): frames = list of dicts
+        {width, height, precision, components: [(id, h, v, tq), ...]}, quant_tables = uint16[n][4][64] (zig-zag order).
+        Follow with set_coefficients(i, blocks in MCU scan order) and run_idct()."""
+        n = len(frames)
+        arr = (_capi.Frame * n)()
+        for i, f in enumerate(frames):
+            arr[i].width, arr[i].height, arr[i].precision = f["width"], f["height"], f["precision"]
+            arr[i].num_components = len(f["components"])
+            arr[i].sof = f.get("sof", 0xC2)
+            for c, (cid, h, v, tq) in enumerate(f["components"]):
+                arr[i].comp[c] = _capi.FrameComponent(cid, h, v, tq)
+        qt = np.ascontiguousarray(quant_tables, dtype=np.uint16).reshape(n, 4, 64)
+        self._check(_lib.jpgpu_batch_upload_frames(self._h, arr, qt.ctypes.data, n, fmt))
+        self.format = fmt
+        return self
+
     def decode(self):
         self._check(_lib.jpgpu_batch_decode(self._h))
         return self

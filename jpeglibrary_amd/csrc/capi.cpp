@@ -125,6 +125,9 @@ void jpgpu_batch_destroy(jpgpu_batch *b) { delete b; }
 int jpgpu_batch_upload(jpgpu_batch *b, const uint8_t *const *jpeg, const size_t *len, int n, int format) {
     JPGPU_GUARD(b, b->impl.upload_files(jpeg, len, n, format));
 }
+int jpgpu_batch_upload_frames(jpgpu_batch *b, const jpgpu_frame *frames, const uint16_t *qt, int n, int format) {
+    JPGPU_GUARD(b, b->impl.upload_frames(frames, qt, n, format));
+}
 int jpgpu_batch_decode(jpgpu_batch *b) { JPGPU_GUARD(b, b->impl.decode()); }
 int jpgpu_batch_run_entropy(jpgpu_batch *b) {
     if (!b) return JPGPU_ERR_ARGUMENT;

@@ -191,6 +191,65 @@ int DeviceBatch::upload_single_job(const ScanJob &job, int format, const void *i
     return JPGPU_OK;
 }
 
+int DeviceBatch::upload_frames(const jpgpu_frame *frames, const uint16_t *qt, int n, int format) {
+    if (n < 0 || (n > 0 && (!frames || !qt))) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_frames: null argument");
+    if (format < 0 || format > 2) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_frames: unknown format");
+    format_ = format;
+    images_.assign((size_t)n, ImagePlan());
+    jobs_.clear();
+    job_image_.clear();
+    job_entropy_off_.clear();
+    std::vector<const uint8_t *> fp((size_t)n, nullptr);
+    std::vector<size_t> fl((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        ImagePlan &img = images_[i];
+        try {
+            const jpgpu_frame &f = frames[i];
+            if (f.num_components == 0 || f.num_components > 4) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "1..4 components are supported.", kDetailUnsupportedFrame);
+            HostDecoder dec;
+            FrameHeader fh;
+            fh.precision = f.precision;
+            fh.lines = f.height;
+            fh.samples_per_line = f.width;
+            fh.num_components = f.num_components;
+            ScanHeader sh;
+            sh.num_components = f.num_components;
+            sh.se = 63;
+            for (int c = 0; c < f.num_components; c++) {
+                fh.components.push_back({f.comp[c].identifier, f.comp[c].h, f.comp[c].v, f.comp[c].tq});
+                sh.components.push_back({f.comp[c].identifier, 0, 0});
+                if (f.comp[c].tq > 3) throw DecodeError(JPGPU_ERR_ARGUMENT, "quantisation table selector out of range");
+                QuantTable q;
+                q.identifier = f.comp[c].tq;
+                memcpy(q.elements, qt + ((size_t)i * 4 + f.comp[c].tq) * 64, sizeof q.elements);
+                dec.set_quantization_table(q);
+            }
+            // the IDCT stage needs no Huffman tables; a placeholder keeps the scan-job builder's checks satisfied
+            HuffTable dummy;
+            const uint8_t bits[16] = {0, 1};
+            const uint8_t vals[1] = {0};
+            HuffTable::from_bits_values(0, 0, bits, vals, 1, &dummy);
+            dec.set_huffman_table(dummy);
+            dummy.table_class = 1;
+            dec.set_huffman_table(dummy);
+            dec.set_frame_header(fh);
+            img.sof = f.sof;
+            const BaselineGeometry geo = BaselineGeometry::latch(dec, fh);
+            jobs_.push_back(make_scan_job(dec, geo, sh, nullptr, 0));
+            plan_image_geometry(img, geo);
+            img.blocks_per_mcu = (uint32_t)jobs_.back().blocks_per_mcu;
+            img.jobs.push_back((int)jobs_.size() - 1);
+            job_image_.push_back(i);
+            job_entropy_off_.push_back(0);
+        } catch (const DecodeError &e) {
+            img.status = e.status;
+            img.detail = e.detail;
+            img.error = e.what();
+        }
+    }
+    return layout_and_upload(fp, fl);
+}
+
 int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr, const std::vector<size_t> &file_len) {
     hipError_t e = hipSetDevice(ctx_->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
@@ -400,7 +459,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
     for (size_t i = 0; i < images_.size(); i++) {
         const ImagePlan &img = images_[i];
-        if (img.status != JPGPU_OK || img.jobs.empty()) continue;
+        if (img.status != JPGPU_OK || img.jobs.empty() || !file_ptr[i] || file_len[i] == 0) continue;
         e = hipMemcpyAsync((uint8_t *)d_input_.ptr + img.file_offset, file_ptr[i], file_len[i], hipMemcpyHostToDevice, ctx_->stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(input)");
         const uint64_t tail = img.file_offset + file_len[i];

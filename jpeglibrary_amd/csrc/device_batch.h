@@ -53,6 +53,8 @@ class DeviceBatch {
     int upload_files(const uint8_t *const *jpeg, const size_t *len, int n, int format);
     // One pre-built scan job whose entropy bytes are `entropy` (level-2 API and the JpegDecoder mirror).
     int upload_single_job(const ScanJob &job, int format, const void *initial_output, size_t initial_output_bytes);
+    // Coefficient hand-off (progressive / config 5): images described by frame geometry + quantisation tables only.
+    int upload_frames(const jpgpu_frame *frames, const uint16_t *qt /*[n][4][64]*/, int n, int format);
 
     int run_marker_index();
     int run_huffman();

@@ -107,6 +107,8 @@ struct jref_decoder {
     void *writer_user;
     jref_coef_tap_fn tap;
     void *tap_user;
+    jref_progressive_tap_fn ptap;
+    void *ptap_user;
 
     /* scan decoder state (baseline + progressive), ref: ScanDecoder/ *.cs */
     int scan_kind;
@@ -1277,6 +1279,17 @@ static void progressive_process_scan(jref_decoder *d, reader *r, const scan_head
 static void progressive_dispose(jref_decoder *d) {
     float block_f[64], output_f[64], temp_f[64];
     decoding_component *components = d->sd_components;
+    if (d->ptap) {
+        for (int i = 0; i < d->sd_ncomponents_alloc; i++) {
+            const decoding_component *c = &components[i];
+            if (!c->quant || c->component_index >= d->pg_nalloc) continue;
+            const component_allocation *a = &d->pg_alloc[c->component_index];
+            for (int by = 0; by < a->vblocks; by++)
+                for (int bx = 0; bx < a->hblocks; bx++)
+                    d->ptap(d->ptap_user, d->pg_blocks + (size_t)(a->offset + by * a->hblocks + bx) * 64, c->component_index, bx, by,
+                            c->quant->elements);
+        }
+    }
     for (int row_mcu = 0; row_mcu < d->sd_mcus_per_column; row_mcu++) {
         for (int col_mcu = 0; col_mcu < d->sd_mcus_per_line; col_mcu++) {
             /* iterates ALL pre-allocated components as left by the last scans */
@@ -1345,6 +1358,11 @@ void jref_set_output_writer(jref_decoder *d, jref_write_block_fn fn, void *user)
 void jref_set_coef_tap(jref_decoder *d, jref_coef_tap_fn fn, void *user) {
     d->tap = fn;
     d->tap_user = user;
+}
+
+void jref_set_progressive_tap(jref_decoder *d, jref_progressive_tap_fn fn, void *user) {
+    d->ptap = fn;
+    d->ptap_user = user;
 }
 
 int jref_get_restart_interval(const jref_decoder *d) { return d->restart_interval; }

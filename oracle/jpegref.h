@@ -52,6 +52,12 @@ typedef void (*jref_write_block_fn)(void *user, const int16_t *block, int compon
  * (64 int16 in zig-zag order).  block_index counts blocks in scan order from 0. */
 typedef void (*jref_coef_tap_fn)(void *user, const int16_t *zigzag_coefs, int component_index, long block_index);
 
+/* Optional tap (progressive only): every block of the coefficient store right before Dispose() dequantises it
+ * (ref: ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs:421-470): 64 int16 in zig-zag order, block (bx, by) of component
+ * `component_index`, and the quantisation table (zig-zag order) Dispose will use for it. */
+typedef void (*jref_progressive_tap_fn)(void *user, const int16_t *zigzag_coefs, int component_index, int bx, int by,
+                                        const uint16_t *quant_zigzag);
+
 typedef struct jref_decoder jref_decoder;
 
 jref_decoder *jref_create(void);
@@ -67,6 +73,7 @@ int jref_try_estimate_quality(jref_decoder *d, float *quality);
 /* ref: JpegDecoder.SetOutputWriter (JpegDecoder.cs:501). */
 void jref_set_output_writer(jref_decoder *d, jref_write_block_fn fn, void *user);
 void jref_set_coef_tap(jref_decoder *d, jref_coef_tap_fn fn, void *user);
+void jref_set_progressive_tap(jref_decoder *d, jref_progressive_tap_fn fn, void *user);
 /* ref: JpegDecoder.Decode (JpegDecoder.cs:509-550). */
 int jref_decode(jref_decoder *d);
 /* ref: JpegDecoder.Get/SetRestartInterval (JpegDecoder.cs:656-670), ResetTables etc. */

@@ -28,6 +28,7 @@ class Info(C.Structure):
 
 WRITE_BLOCK_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int)
 COEF_TAP_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int16), C.c_int, C.c_long)
+PROG_TAP_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16))
 
 
 def build(force=False):
@@ -55,6 +56,7 @@ def lib():
         L.jref_try_estimate_quality.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.jref_set_output_writer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.jref_set_coef_tap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.jref_set_progressive_tap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.jref_decode.argtypes = [C.c_void_p]
         L.jref_decode_to_8bit.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Info),
                                           C.c_char_p, C.c_size_t]
@@ -169,6 +171,36 @@ def decode_coefficients(data: bytes):
 
     decode_with_callbacks(data, None, tap)
     return np.stack(blocks) if blocks else np.zeros((0, 64), np.int16), np.array(comps, dtype=np.int32)
+
+
+def decode_progressive_store(data: bytes):
+    """Progressive (SOF2) files: the accumulated coefficient store right before the reference's Dispose() runs the IDCT
+    pass.  Returns (Info, blocks: {component: {(bx, by): int16[64] zig-zag}}, quant: {component: uint16[64] zig-zag})."""
+    L = lib()
+    d = L.jref_create()
+    blocks, quant = {}, {}
+    try:
+        L.jref_set_input(d, data, len(data))
+        info = Info()
+        rc = L.jref_identify(d, 0, C.byref(info))
+        if rc != 0:
+            raise OracleError(rc, L.jref_last_error(d).decode())
+
+        def _tap(_u, blk, ci, bx, by, q):
+            blocks.setdefault(ci, {})[(bx, by)] = np.ctypeslib.as_array(blk, shape=(64,)).copy()
+            if ci not in quant:
+                quant[ci] = np.ctypeslib.as_array(q, shape=(64,)).copy()
+
+        tap = PROG_TAP_FN(_tap)
+        wb = WRITE_BLOCK_FN(lambda *a: None)
+        L.jref_set_output_writer(d, C.cast(wb, C.c_void_p), None)
+        L.jref_set_progressive_tap(d, C.cast(tap, C.c_void_p), None)
+        rc = L.jref_decode(d)
+        if rc != 0:
+            raise OracleError(rc, L.jref_last_error(d).decode())
+        return info, blocks, quant
+    finally:
+        L.jref_destroy(d)
 
 
 def decode_blocks(data: bytes):

@@ -427,3 +427,45 @@ def test_multi_scan_and_four_component_files():
     d.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(d.Width, d.Height, 3, out))
     d.Decode()
     assert np.array_equal(out.reshape(88, 120, 3), po.decode_8bit(files[1])[0])
+
+
+@pytest.mark.parametrize("name", ["progress.jpg", "yellowcat_progressive_restart.jpg"])
+def test_progressive_idct_pass_on_gpu(name):
+    """BASELINE config 5 shape: multi-scan (SOF2) coefficient accumulate, then ONE dequantise + IDCT + flush pass on the
+    GPU (what JpegHuffmanProgressiveScanDecoder.Dispose + JpegBlockAllocator.Flush do).  The accumulated store comes
+    from the oracle's progressive entropy decoder; the GPU output must equal the reference's golden PNG dump."""
+    data = read_jpeg(name)
+    info, blocks, quant = po.decode_progressive_store(data)
+    comps = [(info.comp[i].identifier, info.comp[i].h, info.comp[i].v, i) for i in range(info.ncomp)]  # tq := component index
+    max_h, max_v = max(c[1] for c in comps), max(c[2] for c in comps)
+    mcus_x = -(-info.width // (8 * max_h))
+    mcus_y = -(-info.height // (8 * max_v))
+    qt = np.zeros((1, 4, 64), np.uint16)
+    for ci in range(info.ncomp):
+        qt[0, ci] = quant[ci]
+    # MCU scan order: MCU raster, component order, block raster inside the MCU; blocks outside a component's store are zero
+    coefs = []
+    for my in range(mcus_y):
+        for mx in range(mcus_x):
+            for ci, (_, h, v, _) in enumerate(comps):
+                for y in range(v):
+                    for x in range(h):
+                        coefs.append(blocks[ci].get((mx * h + x, my * v + y), np.zeros(64, np.int16)))
+    coefs = np.stack(coefs)
+    frame = {"width": info.width, "height": info.height, "precision": info.precision, "components": comps, "sof": 0xC2}
+    b = jl.Batch().upload_frames([frame], qt, jl.FMT_INTERLEAVED_U8)
+    b.set_coefficients(0, coefs)
+    b.run_idct().sync()
+    out = b.output(0)
+    assert np.array_equal(out, po.decode_8bit(data)[0])
+    # and against the reference's own golden dump (test writer semantics: (ushort) clamp -> u16 -> high byte)
+    b16 = jl.Batch().upload_frames([frame], qt, jl.FMT_PLANAR_I16)
+    b16.set_coefficients(0, coefs)
+    b16.run_idct().sync()
+    planes = b16.output(0)
+    golden = load_reference_buffer(name, info.width, info.height, info.ncomp)
+    for ci, (_, h, v, _) in enumerate(comps):
+        hs, vs = max_h // h, max_v // v
+        full = np.repeat(np.repeat(planes[ci], vs, axis=0), hs, axis=1)[:info.height, :info.width]
+        clamped = np.minimum(full.astype(np.uint16), 255).astype(np.uint16)  # (ushort) cast: negatives become max
+        assert np.array_equal(clamped * 257, golden[..., ci]), ci
