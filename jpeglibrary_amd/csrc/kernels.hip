@@ -506,7 +506,199 @@ __device__ __forceinline__ uint32_t restart_check(const DevScan &s, const DevSca
 
 // K2: lanes of a wave decode block b of their MCU in lock-step into a shared LDS staging that is flushed per block as
 // whole 128-byte lines of the coefficient buffer (zig-zag int16, MCU scan order).
-template <int WAVES>
+//
+// With 64 lanes in lock-step anything a lane does "rarely" happens in almost every iteration of the wave, so the symbol
+// loop is written without per-lane state machines:
+//  * the lane's bit source is a bit POSITION into a private 64-byte LDS ring of its unstuffed stream (17 words per lane:
+//    16 ring words stored MSB-first + a mirror of word 0, so two consecutive words are always one ds_read2; stride 17
+//    words keeps lanes on distinct banks).  Peeking 32 bits is bfe + address + ds_read2 + v_alignbit; consuming n bits is
+//    one add.  The ring is topped up once per BLOCK (16 bytes, prefetched one block ahead into registers).
+//  * one lookup of the next kK2LutBits bits returns total length (code + magnitude), code length, category and the
+//    zig-zag advance in one 32-bit word; EOB and ZRL are ordinary entries whose "coefficient" is a zero stored where
+//    nothing has been written yet, so the AC loop has no run/EOB branches.
+//  * everything else -- codes longer than the lookup, the last bits of the interval where the reference's
+//    "bits available" rules matter (JpegBitReader.cs:157-204), a ring that ran dry inside one block -- takes one
+//    exec-masked exact path (k2_slow_symbol), the same decisions as ub_symbol.
+constexpr int kK2RingStride = 68;                         // bytes per lane: 16 words + mirror of word 0
+constexpr int kK2WaveBytes = 8192 + 64 * kK2RingStride;   // coefficient staging + rings
+constexpr int kK2SmallBytes = 320;                        // maxcode[18] + valoffset[20] + values[256] + pad
+constexpr uint32_t kK2Miss = 0x80000000u;                 // lookup entry: code longer than the lookup width
+constexpr uint32_t kK2BadCategory = 0x80000001u;          // lookup entry: DC category above 16
+
+struct K2Tab {
+    const uint32_t *lut;
+    const uint16_t *maxcode;
+    const uint8_t *valoffset;
+    const uint8_t *values;
+};
+
+template <int LB>
+__device__ __forceinline__ K2Tab k2_tab(const uint8_t *tabs, uint32_t slot) {
+    constexpr uint32_t kBytes = (4u << LB) + kK2SmallBytes;
+    const uint8_t *t = tabs + slot * kBytes;
+    K2Tab h;
+    h.lut = reinterpret_cast<const uint32_t *>(t);
+    h.maxcode = reinterpret_cast<const uint16_t *>(t + (4u << LB));
+    h.valoffset = t + (4u << LB) + 36;
+    h.values = t + (4u << LB) + 56;
+    return h;
+}
+
+// zig-zag advance (in int16 BYTES, i.e. 2 x coefficients) of an AC symbol: r + 1 coefficients for a non-zero category,
+// 16 for ANY r != 0 with category 0 (ref: ...BaselineScanDecoder.cs:212-220), and "past the end" for EOB.
+__device__ __forceinline__ uint32_t k2_ac_advance(uint32_t sym) {
+    const uint32_t rr = sym >> 4;
+    return (sym & 15u) ? 2u * (rr + 1u) : (rr ? 32u : 127u);
+}
+
+// next 32 bits of the lane's stream at bit position pm1 + 1
+__device__ __forceinline__ uint32_t k2_window(const uint8_t *ring, int32_t pm1) {
+    const uint32_t t = __builtin_amdgcn_ubfe((uint32_t)pm1, 5, 4);
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(ring + t * 4);
+    return __builtin_amdgcn_alignbit(p[0], p[1], ~(uint32_t)pm1);
+}
+
+struct K2Feed {
+    const uint8_t *gp;  // global address of the chunk after nx
+    uint4 nx;           // chunk number `wr`, already loaded
+    uint32_t wr;        // 16-byte chunks written to the ring so far (the ring holds chunks wr-4 .. wr-1)
+};
+
+__device__ __forceinline__ void k2_ring_write(uint8_t *ring, uint32_t slot, const uint4 &v) {
+    uint32_t *rp = reinterpret_cast<uint32_t *>(ring + slot * 16);
+    const uint32_t w0 = __builtin_bswap32(v.x);
+    rp[0] = w0;
+    rp[1] = __builtin_bswap32(v.y);
+    rp[2] = __builtin_bswap32(v.z);
+    rp[3] = __builtin_bswap32(v.w);
+    if (slot == 0) reinterpret_cast<uint32_t *>(ring)[16] = w0;
+}
+
+// moves the prefetched chunk into the ring when the slot it replaces is no longer needed (the word before the current
+// position must stay readable: k2_window reads it) and prefetches the next one
+__device__ __forceinline__ void k2_topup(uint8_t *ring, K2Feed &f, int32_t pm1) {
+    const int32_t rdc = (pm1 < 0 ? 0 : pm1) >> 7;
+    if ((int32_t)f.wr < rdc + 4) {
+        k2_ring_write(ring, f.wr & 3u, f.nx);
+        f.wr++;
+        __builtin_memcpy(&f.nx, f.gp, 16);
+        f.gp += 16;
+    }
+}
+
+// fast-path limit: a symbol of n bits at position pos may take the fast path when pos + n <= lim, which guarantees both
+// "n real bits are available" and "the words the NEXT symbol reads (k2_symbol: up to 3 words past the one holding the bit
+// before its position) are inside the ring"
+__device__ __forceinline__ int32_t k2_limit(int32_t endpos, uint32_t wr) {
+    const int32_t loaded = (int32_t)(wr * 128u) - 128;
+    return endpos < loaded ? endpos : loaded;
+}
+
+// Exact symbol decode: DecodeHuffmanCode + ReceiveAndExtend with the reference's "bits available" rules (same decisions
+// as ub_symbol).  Returns 0 or the failure detail; n = bits consumed, value, adv = zig-zag advance (AC).
+template <int LB>
+__device__ __forceinline__ uint32_t k2_slow_symbol(uint8_t *ring, K2Feed &f, int32_t pm1, int32_t endpos, const K2Tab &h, bool is_dc,
+                                                bool closed_by_marker, uint32_t &n, int32_t &value, uint32_t &adv) {
+    const int32_t pos = pm1 + 1;
+    while ((int32_t)(f.wr * 128u) < pos + 160) k2_topup(ring, f, pm1);  // always has room here
+    const uint32_t hi = k2_window(ring, pm1);
+    int32_t rem = endpos - pos;
+    if (rem < 0) rem = 0;
+    const uint32_t code16 = rem > 0 ? (hi >> 16) : 0xFFFFu;
+    const uint32_t e = h.lut[code16 >> (16 - LB)];
+    uint32_t size, s;
+    if (e & 0x80000000u) {
+        if (e == kK2BadCategory) return kDetailInvalidHuffmanCode;
+        size = LB + 1;
+        while (code16 > h.maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
+        if (size > 16) return kDetailInvalidHuffmanCode;
+        const uint32_t sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
+        s = is_dc ? sym : (sym & 15u);
+        adv = k2_ac_advance(sym);
+        if (s > 16u) return kDetailInvalidHuffmanCode;  // categories above 16 are outside the verified envelope
+    } else {
+        size = (e >> 8) & 0xFFu;
+        s = (e >> 16) & 0xFFu;
+        adv = e >> 24;
+    }
+    rem = rem > (int32_t)size ? rem - (int32_t)size : 0;  // advance Math.Min(entry.CodeSize, bitsRead)
+    value = 0;
+    if (s != 0) {
+        if ((int32_t)s > rem) return (rem == 0 && closed_by_marker) ? kDetailMarkerInData : kDetailStreamEnded;
+        const int32_t v = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - size - s, s);
+        value = v - ((((v + v) >> s) - 1) & ((1 << s) - 1));  // Extend(v, nbits)
+    }
+    n = size + s;
+    return 0;
+}
+
+// The lane's position and the three stream words around it: w0 holds the bit BEFORE the position (word q = pm1 >> 5),
+// w1 and w2 follow.  A symbol is at most 32 bits, so q advances by at most one word per symbol; the word that would then
+// be missing (q + 3) is read from the ring at the START of the step, off the dependency chain.
+struct K2Pos {
+    int32_t pm1;  // bit position - 1, relative to the lane's 4-byte aligned origin
+    uint32_t w0, w1, w2;
+};
+
+__device__ __forceinline__ void k2_pos_init(K2Pos &p, const uint8_t *ring, int32_t pm1) {
+    const uint32_t *r = reinterpret_cast<const uint32_t *>(ring);
+    const int32_t q = pm1 >> 5;
+    p.pm1 = pm1;
+    p.w0 = r[q & 15];
+    p.w1 = r[(q + 1) & 15];
+    p.w2 = r[(q + 2) & 15];
+}
+
+// One symbol, fast path for every lane, then ONE branch the wave skips unless some lane needs the exact path for the lanes that need it (a
+// code longer than the lookup, the last bits of the interval, a ring that ran dry); advances the position.
+// On failure the lane gets adv = 255 (leaves the AC loop), n = 0, value = 0 and the detail code is returned.
+template <int LB>
+__device__ __forceinline__ uint32_t k2_symbol(uint8_t *ring, K2Feed &f, K2Pos &p, int32_t endpos, int32_t &lim, const K2Tab &h, bool is_dc,
+                                              bool closed_by_marker, int32_t &value, uint32_t &adv) {
+    const uint32_t nxt = *reinterpret_cast<const uint32_t *>(ring + __builtin_amdgcn_ubfe((uint32_t)(p.pm1 + 96), 5, 4) * 4);
+    const uint32_t hi = __builtin_amdgcn_alignbit(p.w0, p.w1, ~(uint32_t)p.pm1);
+    const uint32_t e = h.lut[hi >> (32 - LB)];
+    uint32_t n = e & 0xFFu;
+    const uint32_t cat = (e >> 16) & 0xFFu;
+    const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - n, cat);
+    value = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));  // Extend(v, nbits)
+    adv = e >> 24;
+    uint32_t err = 0;
+    // slow: the entry is flagged (sign bit) or the symbol does not fit below the limit -- one signed test
+    const bool slow = (int32_t)(e | (uint32_t)(lim - (p.pm1 + 1) - (int32_t)n)) < 0;
+    if (slow) {  // exec-masked; the wave skips it when no lane is flagged
+        err = k2_slow_symbol<LB>(ring, f, p.pm1, endpos, h, is_dc, closed_by_marker, n, value, adv);
+        lim = k2_limit(endpos, f.wr);
+        if (err != 0) {
+            n = 0;
+            value = 0;
+            adv = 255;
+        }
+    }
+    const int32_t np = p.pm1 + (int32_t)n;
+    const bool step = ((uint32_t)(np ^ p.pm1) >> 5) != 0;
+    p.pm1 = np;
+    p.w0 = step ? p.w1 : p.w0;
+    p.w1 = step ? p.w2 : p.w1;
+    p.w2 = step ? nxt : p.w2;
+    return err;
+}
+
+#ifdef JPGPU_K2_PROFILE
+__device__ unsigned long long k2_prof[8];
+#define K2_TICK() __builtin_readcyclecounter()
+#define K2_PROF_ADD(i, v) do { if (lane == 0) atomicAdd(&k2_prof[i], (unsigned long long)(v)); } while (0)
+extern "C" int jpgpu_debug_k2_profile(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(k2_prof), sizeof(k2_prof)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(k2_prof), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
+}
+#else
+#define K2_TICK() 0ull
+#define K2_PROF_ADD(i, v) do { (void)(v); } while (0)
+#endif
+
+template <int WAVES, int LB>
 __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_t *__restrict__ udata,
                                                                     const DevScan *__restrict__ scans,
                                                                     const HuffWork *__restrict__ work,
@@ -514,32 +706,69 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
                                                                     DevScanStatus *__restrict__ status,
                                                                     const DevHuffTable *__restrict__ huff_pool,
                                                                     int16_t *__restrict__ coefs, int n_slots) {
+    constexpr uint32_t kTabBytes = (4u << LB) + kK2SmallBytes;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *tabs = smem;                                                  // n_slots * sizeof(DevHuffTable)
-    uint8_t *stage_all = smem + (size_t)n_slots * sizeof(DevHuffTable);   // WAVES * 8192
+    uint8_t *tabs = smem;                                    // n_slots * kTabBytes
+    uint8_t *wave_all = smem + (size_t)n_slots * kTabBytes;  // WAVES * kK2WaveBytes
+    uint32_t *blk_info = reinterpret_cast<uint32_t *>(wave_all + WAVES * kK2WaveBytes);  // [kMaxBlocksPerMcu]
 
     const HuffWork wk = work[blockIdx.x];
     const DevScan &s = scans[wk.scan];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
     const uint32_t wave = tid >> 6;
+    const unsigned long long k2_t0 = K2_TICK();
 
-    // stage this scan's Huffman tables (ref: InitDecodeComponents resolves them per scan, JpegHuffmanScanDecoder.cs:63-64)
+    // stage this scan's Huffman tables (ref: InitDecodeComponents resolves them per scan, JpegHuffmanScanDecoder.cs:63-64):
+    // the reference's maxcode / valoffset / values verbatim, then the fused lookup derived from them
     for (int slot = 0; slot < kMaxHuffSlots && slot < n_slots; slot++) {
         const uint32_t pi = s.huff_pool[slot];
         if (pi == 0xFFFF) continue;
-        const uint4 *src = reinterpret_cast<const uint4 *>(&huff_pool[pi]);
-        uint4 *dst = reinterpret_cast<uint4 *>(tabs + slot * sizeof(DevHuffTable));
-        for (uint32_t i = tid; i < sizeof(DevHuffTable) / 16; i += 64 * WAVES) dst[i] = src[i];
+        const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&huff_pool[pi]) + offsetof(DevHuffTable, maxcode));
+        uint4 *dst = reinterpret_cast<uint4 *>(tabs + slot * kTabBytes + (4u << LB));
+        for (uint32_t i = tid; i < kK2SmallBytes / 16; i += 64 * WAVES) dst[i] = src[i];
     }
-    uint8_t *stage = stage_all + wave * 8192;
+    // per block-in-MCU: scan component | DC slot << 8 | AC slot << 16 (kept in LDS: the block loop must not touch global
+    // memory for it, a vector load there would wait for the coefficient stores of the previous block)
+    if (tid < kMaxBlocksPerMcu) {
+        const uint32_t ci = s.blk_comp[tid];
+        blk_info[tid] = ci | ((uint32_t)s.comp[ci].dc_slot << 8) | ((uint32_t)s.comp[ci].ac_slot << 16);
+    }
+    uint8_t *stage = wave_all + wave * kK2WaveBytes;
+    uint8_t *ring = stage + 8192 + lane * kK2RingStride;
     {
         const uint4 z = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(stage)[i * 64 + lane] = z;
     }
     __syncthreads();
+    for (int slot = 0; slot < kMaxHuffSlots && slot < n_slots; slot++) {
+        const uint32_t pi = s.huff_pool[slot];
+        if (pi == 0xFFFF) continue;
+        bool is_dc = false;
+        for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == slot;
+        const K2Tab h = k2_tab<LB>(tabs, slot);
+        uint32_t *lut = const_cast<uint32_t *>(h.lut);
+        for (uint32_t i = tid; i < (1u << LB); i += 64 * WAVES) {
+            const uint32_t code16 = (i << (16 - LB)) | ((1u << (16 - LB)) - 1u);
+            const uint32_t e9 = huff_pool[pi].lut[i >> (LB - kHuffLutBits)];
+            uint32_t size = e9 >> 8, sym = e9 & 0xFFu;
+            if (size == 0) {
+                size = kHuffLutBits + 1;
+                while (code16 > h.maxcode[size]) size++;
+                if (size <= (uint32_t)LB) sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
+            }
+            uint32_t e = kK2Miss;
+            if (size <= (uint32_t)LB) {
+                const uint32_t cat = is_dc ? sym : (sym & 15u);
+                e = cat > 16u ? kK2BadCategory : ((size + cat) | (size << 8) | (cat << 16) | ((is_dc ? 0u : k2_ac_advance(sym)) << 24));
+            }
+            lut[i] = e;
+        }
+    }
+    __syncthreads();
 
+    const unsigned long long k2_t1 = K2_TICK();
     const DevScanStatus st = status[wk.scan];
     const uint32_t n_ends = st.n_ends;
     const uint32_t n_intervals = s.n_intervals;
@@ -552,18 +781,35 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
     const uint32_t *eu = ends_u + s.ends_off;
     const uint8_t *ubase = udata + s.data_off;
 
-    UBits r;
+    // the lane's stream == a fresh JpegBitReader on its restart interval (ref: JpegBitReader.cs)
     uint32_t my_mcus = 0;
     bool closed_by_marker = false;
+    uint32_t u0 = 0, u1 = 0;
+    if (active) {
+        u0 = interval == 0 ? 0u : eu[interval - 1] + 2u;
+        u1 = eu[interval];
+        my_mcus = (interval == n_intervals - 1) ? total_mcus - interval * dri_eff : dri_eff;
+        closed_by_marker = !(interval == n_ends - 1 && st.terminator == 0);
+    }
+    const int32_t pm1_0 = (int32_t)((u0 & 3u) * 8u) - 1;             // bit position - 1, relative to the aligned origin
+    const int32_t endpos = pm1_0 + 1 + (int32_t)((u1 - u0) * 8u);    // first bit after the interval's data
+    K2Feed feed;
+    K2Pos pos;
     {
-        uint32_t u0 = 0, u1 = 0;
-        if (active) {
-            u0 = interval == 0 ? 0u : eu[interval - 1] + 2u;
-            u1 = eu[interval];
-            my_mcus = (interval == n_intervals - 1) ? total_mcus - interval * dri_eff : dri_eff;
-            closed_by_marker = !(interval == n_ends - 1 && st.terminator == 0);
-        }
-        ub_init(r, ubase, u0, u1);
+        const uint8_t *g = ubase + (u0 & ~3u);  // 4-byte aligned 16-byte loads; buffers are padded
+        uint4 c0, c1, c2, c3;
+        __builtin_memcpy(&c0, g, 16);
+        __builtin_memcpy(&c1, g + 16, 16);
+        __builtin_memcpy(&c2, g + 32, 16);
+        __builtin_memcpy(&c3, g + 48, 16);
+        __builtin_memcpy(&feed.nx, g + 64, 16);
+        k2_ring_write(ring, 0, c0);
+        k2_ring_write(ring, 1, c1);
+        k2_ring_write(ring, 2, c2);
+        k2_ring_write(ring, 3, c3);
+        feed.wr = 4;
+        feed.gp = g + 80;
+        k2_pos_init(pos, ring, pm1_0);
     }
     // the wave iterates to the largest MCU count among its lanes (only the image's last interval is shorter)
     uint32_t wave_mcus = 0;
@@ -574,42 +820,49 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
 
     int32_t pred0 = 0, pred1 = 0, pred2 = 0, pred3 = 0;  // DcPredictor per scan component
     uint32_t err = 0;
+    const unsigned long long k2_t2 = K2_TICK();
+    unsigned long long k2_dec = 0, k2_top = 0, k2_fl = 0;
+    uint8_t *my_stage = stage + lane * 128;
+    const uint32_t swz16 = ((lane >> 1) & 7u) << 4;  // XOR swizzle of the 16-byte chunks of the lane's staged block
+
+    // flush addressing: lane (blk, chunk) of pass `it` stores 16 bytes of the block staged by lane blk
+    const uint64_t coef_off = s.coef_off;
 
     for (uint32_t mcu = 0; mcu < wave_mcus; mcu++) {
         for (uint32_t b = 0; b < bpm; b++) {
-            const uint32_t ci = s.blk_comp[b];  // wave-uniform
-            const LdsHuff hdc = lds_huff(tabs, s.comp[ci].dc_slot);
-            const LdsHuff hac = lds_huff(tabs, s.comp[ci].ac_slot);
+            const uint32_t bi = __builtin_amdgcn_readfirstlane(blk_info[b]);  // wave-uniform
+            const uint32_t ci = bi & 0xFFu;
+            const K2Tab hdc = k2_tab<LB>(tabs, (bi >> 8) & 0xFFu);
+            const K2Tab hac = k2_tab<LB>(tabs, bi >> 16);
+            const unsigned long long k2_a = K2_TICK();
+            int32_t lim = k2_limit(endpos, feed.wr);
             if (active && err == 0 && mcu < my_mcus) {
                 // ReadBlockBaseline (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:179-222)
-                uint32_t sym;
-                int32_t t;
-                err = ub_symbol(r, hdc, true, closed_by_marker, sym, t);
-                if (err == 0) {
-                    const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
-                    t += pred;
-                    if (ci == 0) pred0 = t;
-                    else if (ci == 1) pred1 = t;
-                    else if (ci == 2) pred2 = t;
-                    else pred3 = t;
-                    *reinterpret_cast<int16_t *>(stage + stage_addr(lane, 0)) = (int16_t)t;
-                    for (uint32_t i = 1; i < 64;) {
-                        int32_t v;
-                        err = ub_symbol(r, hac, false, closed_by_marker, sym, v);
-                        if (err != 0) break;
-                        const uint32_t rr = sym >> 4;
-                        if ((sym & 15u) != 0) {
-                            i += rr;
-                            const uint32_t idx = i < 63 ? i : 63;  // Math.Min(i++, 63)
-                            i++;
-                            *reinterpret_cast<int16_t *>(stage + stage_addr(lane, idx)) = (int16_t)v;
-                        } else {
-                            if (rr == 0) break;
-                            i += 16;  // ANY r != 0, not only 15 (ref: :212-220)
-                        }
-                    }
+                int32_t v;
+                uint32_t adv = 0;
+                err = k2_symbol<LB>(ring, feed, pos, endpos, lim, hdc, true, closed_by_marker, v, adv);
+                const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
+                v += pred;
+                if (ci == 0) pred0 = v;
+                else if (ci == 1) pred1 = v;
+                else if (ci == 2) pred2 = v;
+                else pred3 = v;
+                *reinterpret_cast<int16_t *>(my_stage + swz16) = (int16_t)v;  // zig-zag index 0
+                uint32_t i2 = err == 0 ? 2u : 128u;  // 2 x zig-zag index of the next coefficient
+                while (i2 < 128u) {
+                    const uint32_t e2 = k2_symbol<LB>(ring, feed, pos, endpos, lim, hac, false, closed_by_marker, v, adv);
+                    err |= e2;
+                    i2 += adv;
+                    // Math.Min(i++, 63) for a coefficient; EOB / ZRL store a zero at a position nothing was written to yet
+                    const uint32_t at = i2 - 2u < 126u ? i2 - 2u : 126u;
+                    *reinterpret_cast<int16_t *>(my_stage + (at ^ swz16)) = (int16_t)v;
                 }
             }
+            // top up the ring HERE: the wait for the prefetched chunk then only covers memory operations issued before this
+            // block was decoded (the chunk itself and the previous block's coefficient stores), never fresh ones
+            const unsigned long long k2_b = K2_TICK();
+            k2_topup(ring, feed, pos.pm1);
+            const unsigned long long k2_c = K2_TICK();
             // flush 64 blocks of this wave to the coefficient buffer as whole 128-byte lines, re-zero the staging
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -626,7 +879,7 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
                 if (owner < n_ends) {
                     const uint32_t owner_mcus = (owner == n_intervals - 1) ? total_mcus - owner * dri_eff : dri_eff;
                     if (mcu < owner_mcus) {
-                        const uint64_t block_index = s.coef_off + ((uint64_t)owner * dri_eff + mcu) * bpm + b;
+                        const uint64_t block_index = coef_off + ((uint64_t)owner * dri_eff + mcu) * bpm + b;
                         *reinterpret_cast<uint4 *>(coefs + block_index * 64 + chunk * 8) = v;
                     }
                 }
@@ -634,11 +887,24 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned long long k2_d = K2_TICK();
+            k2_dec += k2_b - k2_a;
+            k2_top += k2_c - k2_b;
+            k2_fl += k2_d - k2_c;
         }
     }
+    K2_PROF_ADD(0, 1);
+    K2_PROF_ADD(1, k2_t1 - k2_t0);
+    K2_PROF_ADD(2, k2_t2 - k2_t1);
+    K2_PROF_ADD(3, k2_dec);
+    K2_PROF_ADD(4, k2_top);
+    K2_PROF_ADD(5, k2_fl);
+    K2_PROF_ADD(6, K2_TICK() - k2_t0);
 
     if (active) {
-        const uint32_t code = restart_check(s, st, &status[wk.scan], interval, n_ends, n_intervals, dri_eff, r.rem, err);
+        int32_t rem = endpos - (pos.pm1 + 1);
+        if (rem < 0) rem = 0;
+        const uint32_t code = restart_check(s, st, &status[wk.scan], interval, n_ends, n_intervals, dri_eff, rem, err);
         if (code != kNoError) atomicMin(&status[wk.scan].first_error, code);
     }
 }
@@ -1564,16 +1830,35 @@ hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const De
     return hipGetLastError();
 }
 
-size_t huffman_lds_bytes(int n_slots) { return (size_t)n_slots * sizeof(DevHuffTable) + (size_t)kHuffWaves * 8192; }
+// K2 lookup width: 11 bits when the scan stages at most 4 tables, 10 bits for up to 8 (LDS budget: 160 KB per CU)
+static size_t k2_lds_bytes(int n_slots, int lb) {
+    return (size_t)n_slots * ((4u << lb) + kK2SmallBytes) + (size_t)kHuffWaves * kK2WaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
+}
+size_t huffman_lds_bytes(int n_slots) { return k2_lds_bytes(n_slots, n_slots <= 4 ? 11 : 10); }
+
+template <int LB>
+static hipError_t launch_huffman_lb(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
+                                    const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
+                                    int n_slots) {
+    const size_t lds = k2_lds_bytes(n_slots, LB);
+    static bool configured = false;  // more than 64 KB of dynamic LDS has to be allowed once per kernel
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&huffman_decode_kernel<kHuffWaves, LB>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes(LB == 11 ? 4 : kMaxHuffSlots, LB));
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((huffman_decode_kernel<kHuffWaves, LB>), dim3(n_work), dim3(64 * kHuffWaves), lds, stream, data, scans, work,
+                       ends, status, huff_pool, coefs, n_slots);
+    return hipGetLastError();
+}
 
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                           const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
                           int n_slots) {
     if (n_work <= 0) return hipSuccess;
-    const size_t lds = huffman_lds_bytes(n_slots);
-    hipLaunchKernelGGL(huffman_decode_kernel<kHuffWaves>, dim3(n_work), dim3(64 * kHuffWaves), lds, stream, data, scans, work,
-                       ends, status, huff_pool, coefs, n_slots);
-    return hipGetLastError();
+    if (n_slots <= 4) return launch_huffman_lb<11>(stream, data, scans, work, n_work, ends, status, huff_pool, coefs, n_slots);
+    return launch_huffman_lb<10>(stream, data, scans, work, n_work, ends, status, huff_pool, coefs, n_slots);
 }
 
 template <int FMT, int LAY>
