@@ -49,7 +49,8 @@ typedef enum jpgpu_detail {
     JPGPU_DETAIL_MISSING_TABLE = 5,        /* Huffman / quantization table not defined. ref: ...BaselineScanDecoder.cs:72-81 */
     JPGPU_DETAIL_UNSUPPORTED_FRAME = 6,    /* SOF other than SOF0/SOF1 on this path */
     JPGPU_DETAIL_BAD_HEADER = 7,           /* marker/segment parse failure before the scan */
-    JPGPU_DETAIL_EARLY_EOI = 8             /* not an error: EOI met at a restart boundary, image partially decoded (ref: ...BaselineScanDecoder.cs:145-150) */
+    JPGPU_DETAIL_EARLY_EOI = 8,            /* not an error: EOI met at a restart boundary, image partially decoded (ref: ...BaselineScanDecoder.cs:145-150) */
+    JPGPU_DETAIL_UNEXPECTED_END = 9        /* "Unexpected end of JPEG data stream."  ref: ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs:249,295,336,350,366,404 */
 } jpgpu_detail;
 
 /* Output layouts. */

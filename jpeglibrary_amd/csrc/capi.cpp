@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <exception>
 #include <memory>
 #include <new>
 
@@ -94,6 +95,7 @@ const char *jpgpu_detail_string(int detail) {
     case JPGPU_DETAIL_UNSUPPORTED_FRAME: return "This type of JPEG stream is not supported on the GPU path.";
     case JPGPU_DETAIL_BAD_HEADER: return "Failed to decode JPEG data. Malformed marker segment.";
     case JPGPU_DETAIL_EARLY_EOI: return "EndOfImage met at a restart boundary; image partially decoded.";
+    case JPGPU_DETAIL_UNEXPECTED_END: return "Failed to decode JPEG data. Unexpected end of JPEG data stream.";
     default: return "unknown detail";
     }
 }
@@ -399,18 +401,25 @@ class GpuScanHandler final : public ScanHandler {
   public:
     explicit GpuScanHandler(jpgpu_decoder *d) : d_(d) {}
     void on_frame(HostDecoder &dec, int sof) override {
+        dispose_progressive(dec);  // a new SOF replaces the scan decoder; the old one is disposed first
         sof_ = sof;
         baseline_ = (sof == kSOF0 || sof == kSOF1);
         if (baseline_) geo_ = BaselineGeometry::latch(dec, dec.frame_header());
+        if (sof == kSOF2) prog_.begin(dec, dec.frame_header());
     }
     void on_scan(HostDecoder &dec, MarkerReader &reader, const ScanHeader &scan) override {
-        if (!baseline_)
-            throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "Only baseline / extended sequential Huffman frames (SOF0, SOF1) run on the GPU path.",
-                              kDetailUnsupportedFrame);
+        if (!baseline_ && !prog_.active())
+            throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "Only Huffman DCT frames (SOF0, SOF1, SOF2) run on the GPU path.", kDetailUnsupportedFrame);
         if (d_->writer == jpgpu_decoder::kNone) throw_invalid_operation("Output writer is not specified.");
         if (!d_->ctx) throw DecodeError(JPGPU_ERR_NO_DEVICE, "No HIP device: scans are decoded on the GPU only (no CPU fallback).");
         const uint8_t *entropy = reader.remaining_bytes();
         const size_t len = (size_t)reader.remaining_byte_count();
+        if (prog_.active()) {
+            // ref: JpegHuffmanProgressiveScanDecoder.ProcessScan: coefficients accumulate, nothing is written yet and
+            // the outer reader is not advanced; the GPU work happens in Dispose()
+            prog_.add_scan(dec, scan, entropy, len);
+            return;
+        }
         const ScanJob job = make_scan_job(dec, geo_, scan, entropy, len);
         if (!d_->batch) d_->batch.reset(new DeviceBatch(d_->ctx));
         const FrameHeader &fh = geo_.frame;
@@ -427,11 +436,68 @@ class GpuScanHandler final : public ScanHandler {
         if (oc.result.status != JPGPU_OK) throw_for_result(oc.result);
         reader.try_advance((int)oc.reader_advance);
     }
-    void on_dispose(HostDecoder &) override {}
+    void on_dispose(HostDecoder &dec) override {
+        if (std::current_exception()) {  // Decode() is failing: the reference flushes a partial store, we flush nothing
+            prog_.reset();
+            return;
+        }
+        dispose_progressive(dec);
+    }
 
   private:
+    // JpegHuffmanProgressiveScanDecoder.Dispose (:421-470): every scan of the frame on the GPU, in file order, then
+    // the dequantise + IDCT pass, then JpegBlockAllocator.Flush (JpegBlockAllocator.cs:120-149) into the writer.
+    void dispose_progressive(HostDecoder &dec) {
+        if (!prog_.active()) return;
+        ProgressiveFrame frame = std::move(prog_);
+        prog_.reset();
+        if (frame.scans().empty()) return;
+        if (!d_->batch) d_->batch.reset(new DeviceBatch(d_->ctx));
+        DeviceBatch &batch = *d_->batch;
+        const FrameHeader &fh = frame.geo().frame;
+        const bool direct = d_->writer == jpgpu_decoder::kBuffer8 && d_->sink8.width == fh.samples_per_line && d_->sink8.height == fh.lines &&
+                            d_->sink8.component_count == fh.num_components;
+        int rc = batch.upload_progressive_frame(frame, dec.input(), dec.input_len(), sof_, direct ? JPGPU_FMT_INTERLEAVED_U8 : JPGPU_FMT_PLANAR_I16);
+        if (rc == JPGPU_OK && direct) {
+            // the sink's buffer keeps whatever the caller had outside the decoded area
+        }
+        if (rc == JPGPU_OK) rc = batch.decode();
+        if (rc == JPGPU_OK) rc = batch.sync();
+        jpgpu_image_result res;
+        memset(&res, 0, sizeof res);
+        if (rc == JPGPU_OK) rc = batch.result(0, &res);
+        if (rc != JPGPU_OK) throw DecodeError(rc, "GPU progressive decode failed (see jpgpu_last_error)");
+        if (res.status != JPGPU_OK) throw_for_result(res);
+        const ImagePlan &img = *batch.image(0);
+        if (direct) {
+            if (batch.download_output(0, d_->sink8.out, (size_t)fh.samples_per_line * fh.lines * fh.num_components) != JPGPU_OK)
+                throw DecodeError(JPGPU_ERR_DEVICE, "output download failed");
+            return;
+        }
+        std::vector<uint8_t> planes(img.out_bytes);
+        if (batch.download_output(0, planes.data(), planes.size()) != JPGPU_OK) throw DecodeError(JPGPU_ERR_DEVICE, "output download failed");
+        jpgpu_write_block_fn fn = d_->writer == jpgpu_decoder::kBuffer8 ? HostSink8::write : d_->fn;
+        void *user = d_->writer == jpgpu_decoder::kBuffer8 ? (void *)&d_->sink8 : d_->user;
+        // Flush order: component, block row, block column; only the component's own block grid
+        const BaselineGeometry &g = frame.geo();
+        const int hb = (fh.samples_per_line + 7) / 8, vb = (fh.lines + 7) / 8;
+        for (int i = 0; i < fh.num_components && i < 4; i++) {
+            const int hs = g.max_h / fh.components[i].h, vs = g.max_v / fh.components[i].v;
+            const int hblocks = (hb + hs - 1) / hs, vblocks = (vb + vs - 1) / vs;
+            const jpgpu_plane_info &pl = img.plane[i];
+            const int16_t *plane = reinterpret_cast<const int16_t *>(planes.data() + pl.offset);
+            for (int row = 0; row < vblocks; row++)
+                for (int col = 0; col < hblocks; col++) {
+                    int16_t blk[64];
+                    for (int r = 0; r < 8; r++) memcpy(blk + 8 * r, plane + ((size_t)row * 8 + r) * pl.pitch + (size_t)col * 8, 16);
+                    write_block_expanded(fn, user, blk, i, col * hs * 8, row * vs * 8, hs, vs);
+                }
+        }
+    }
+
     jpgpu_decoder *d_;
     BaselineGeometry geo_;
+    ProgressiveFrame prog_;
     bool baseline_ = false;
     int sof_ = 0;
 };

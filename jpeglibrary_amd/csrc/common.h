@@ -70,7 +70,21 @@ struct alignas(16) DevScan {
     uint32_t n_chunks;   // 4 KiB chunks covering the entropy segment (from its 16-byte aligned base)
     uint32_t sub_off;    // DRI = 0 scans: first slot of this scan in the subsequence state arrays (K2S)
     uint32_t n_subs;     // DRI = 0 scans: number of 1024-bit subsequences covering the segment (0 = interval decoder)
+    // ---- progressive entropy scans (kind == kScanProgressive; ref: ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs).
+    // total_mcus counts the scan's restart UNITS: MCUs for an interleaved scan, blocks of the component otherwise
+    // (:140-194 calls HandleRestart per block); coef_off / mcus_per_line are the FRAME's: every scan of the frame
+    // accumulates into one coefficient store laid out in MCU scan order (what the IDCT pass reads).
+    uint8_t kind;              // ScanKind
+    uint8_t ss, se, ah, al;    // spectral selection / successive approximation of the scan header
+    uint8_t frame_bpm;         // blocks per MCU of the frame (all components)
+    uint8_t fblk_base[kMaxScanComponents];  // first block of the scan component inside the frame's MCU
+    uint8_t pad1[6];
+    uint16_t hblocks[kMaxScanComponents];   // the component's own block grid (ref: JpegBlockAllocator.cs:35-84);
+    uint16_t vblocks[kMaxScanComponents];   // blocks outside it go to the allocator's dummy block, i.e. nowhere
+    uint32_t units_per_line;   // non-interleaved scan: blocks per line walked by the scan (:146-147)
+    uint32_t pad2[3];
 };
+enum ScanKind : uint8_t { kScanSequential = 0, kScanFrameOnly = 1, kScanProgressive = 2 };
 static_assert(sizeof(DevScan) % 16 == 0, "DevScan must be a multiple of 16 bytes");
 
 // Device-side result of one scan job.
@@ -123,7 +137,8 @@ enum Detail : uint32_t {
     kDetailMissingTable = 5,
     kDetailUnsupportedFrame = 6,
     kDetailBadHeader = 7,
-    kDetailEarlyEoi = 8
+    kDetailEarlyEoi = 8,
+    kDetailUnexpectedEnd = 9
 };
 
 }  // namespace jpgpu

@@ -40,7 +40,7 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_chunk_work_, &d_chunk_sums_, &d_tokens_, &d_blk_tok_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_prog_work_, &d_chunk_work_, &d_chunk_sums_, &d_tokens_, &d_blk_tok_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
@@ -61,30 +61,48 @@ class PlanHandler final : public ScanHandler {
     PlanHandler(std::vector<ScanJob> *jobs) : jobs_(jobs) {}
     void on_frame(HostDecoder &dec, int sof) override {
         sof_ = sof;
+        baseline_ = false;
+        flush_progressive();  // a second SOF replaces the scan decoder: the old one is disposed first (JpegDecoder.cs:568)
         if (sof == kSOF0 || sof == kSOF1) {
             geo_ = BaselineGeometry::latch(dec, dec.frame_header());  // DRI latched at SOF time
             baseline_ = true;
-        } else {
-            baseline_ = false;
+        } else if (sof == kSOF2) {
+            prog_.begin(dec, dec.frame_header());
         }
     }
     void on_scan(HostDecoder &dec, MarkerReader &reader, const ScanHeader &scan) override {
-        if (!baseline_)
-            throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "Only baseline / extended sequential Huffman frames (SOF0, SOF1) run on this path.",
-                              kDetailUnsupportedFrame);
         const uint8_t *entropy = reader.remaining_bytes();
         const size_t len = (size_t)reader.remaining_byte_count();
+        if (prog_.active()) {
+            prog_.add_scan(dec, scan, entropy, len);  // the reference leaves the outer reader where it is
+            return;
+        }
+        if (!baseline_)
+            throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "Only Huffman DCT frames (SOF0, SOF1, SOF2) run on this path.", kDetailUnsupportedFrame);
         jobs_->push_back(make_scan_job(dec, geo_, scan, entropy, len));
         // leave the reader just before the next non-RST marker, like ProcessScan does (:167-176)
         reader.try_advance((int)find_scan_end(entropy, len));
     }
-    void on_dispose(HostDecoder &) override {}
-    const BaselineGeometry &geo() const { return geo_; }
+    void on_dispose(HostDecoder &) override { flush_progressive(); }
+    const BaselineGeometry &geo() const { return prog_geo_valid_ ? prog_geo_ : geo_; }
     int sof() const { return sof_; }
 
   private:
+    // Dispose() of the progressive scan decoder: the frame's IDCT pass, then its entropy scans in file order
+    void flush_progressive() {
+        if (!prog_.active()) return;
+        if (!prog_.scans().empty()) {
+            jobs_->push_back(prog_.make_frame_job());
+            for (ScanJob &j : prog_.scans()) jobs_->push_back(std::move(j));
+            prog_geo_ = prog_.geo();
+            prog_geo_valid_ = true;
+        }
+        prog_.reset();
+    }
     std::vector<ScanJob> *jobs_;
-    BaselineGeometry geo_;
+    BaselineGeometry geo_, prog_geo_;
+    bool prog_geo_valid_ = false;
+    ProgressiveFrame prog_;
     bool baseline_ = false;
     int sof_ = 0;
 };
@@ -151,7 +169,7 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
             for (size_t j = first_job; j < jobs_.size(); j++) {
                 img.jobs.push_back((int)j);
                 job_image_.push_back(i);
-                job_entropy_off_.push_back((uint64_t)(jobs_[j].entropy - jpeg[i]));
+                job_entropy_off_.push_back(jobs_[j].entropy ? (uint64_t)(jobs_[j].entropy - jpeg[i]) : 0u);
             }
         } catch (const DecodeError &e) {
             jobs_.resize(first_job);
@@ -189,6 +207,30 @@ int DeviceBatch::upload_single_job(const ScanJob &job, int format, const void *i
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(initial output)");
     }
     return JPGPU_OK;
+}
+
+int DeviceBatch::upload_progressive_frame(const ProgressiveFrame &frame, const uint8_t *file, size_t file_len, int sof, int format) {
+    if (format < 0 || format > 2) return fail(JPGPU_ERR_ARGUMENT, "unknown format");
+    format_ = format;
+    images_.assign(1, ImagePlan());
+    jobs_.clear();
+    job_image_.clear();
+    job_entropy_off_.clear();
+    jobs_.push_back(frame.make_frame_job());  // throws DecodeError for scan orders the reference mangles
+    for (const ScanJob &j : frame.scans()) jobs_.push_back(j);
+    ImagePlan &img = images_[0];
+    img.sof = (uint8_t)sof;
+    img.file_len = file_len;
+    plan_image_geometry(img, jobs_[0].geo);
+    img.blocks_per_mcu = (uint32_t)jobs_[0].blocks_per_mcu;
+    for (size_t j = 0; j < jobs_.size(); j++) {
+        img.jobs.push_back((int)j);
+        job_image_.push_back(0);
+        job_entropy_off_.push_back(jobs_[j].entropy ? (uint64_t)(jobs_[j].entropy - file) : 0u);
+    }
+    std::vector<const uint8_t *> fp(1, file);
+    std::vector<size_t> fl(1, file_len);
+    return layout_and_upload(fp, fl);
 }
 
 int DeviceBatch::upload_frames(const jpgpu_frame *frames, const uint16_t *qt, int n, int format) {
@@ -276,6 +318,8 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     std::vector<HuffWork> huff_work;
     std::vector<ChunkWork> chunk_work;
     std::vector<HuffWork> sub_work;
+    std::vector<std::vector<HuffWork>> prog_work_by_ordinal;
+    prog_clear_.clear();
     sub_scan_ids_.clear();
     total_subs_ = 0;
     max_subs_per_scan_ = 0;
@@ -316,22 +360,42 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             DevScan &s = h_scans_[j];
             memset(&s, 0, sizeof s);
             const BaselineGeometry &g = job.geo;
+            s.kind = (uint8_t)job.kind;
             s.data_off = img.file_offset + job_entropy_off_[j];
             s.data_len = (uint32_t)(file_len[ii] - job_entropy_off_[j]);
-            s.coef_off = coef_off;
+            if (job.kind == kScanFrameOnly) s.data_len = 0;
+            if (job.kind == kScanProgressive) {
+                // the segment ends at the next marker that is not RSTn; K1 only has to see that marker
+                const size_t end = find_scan_end(job.entropy, job.entropy_len);
+                s.data_len = (uint32_t)std::min<size_t>(end + 2, job.entropy_len);
+            }
+            // progressive entropy scans accumulate into their frame's store (the frame job precedes them)
+            s.coef_off = job.kind == kScanProgressive ? h_scans_[img.jobs[0]].coef_off : coef_off;
             s.tok_base = (uint64_t)kTokensPerByte * s.data_off;  // interval slices are addressed by compressed byte offset
             s.out_off = img.out_offset;
-            s.dri = g.restart_interval;
+            s.dri = job.kind == kScanProgressive ? job.scan_dri : g.restart_interval;
             s.mcus_per_line = (uint32_t)g.mcus_per_line;
             s.mcus_per_column = (uint32_t)g.mcus_per_column;
-            s.total_mcus = s.mcus_per_line * s.mcus_per_column;
+            s.total_mcus = job.kind == kScanProgressive ? job.total_units : s.mcus_per_line * s.mcus_per_column;
             s.n_intervals = s.dri ? (s.total_mcus + s.dri - 1) / s.dri : 1;
-            if (s.total_mcus == 0) s.n_intervals = 0;
+            if (s.total_mcus == 0 || job.kind == kScanFrameOnly) s.n_intervals = 0;
+            s.ss = job.ss;
+            s.se = job.se;
+            s.ah = job.ah;
+            s.al = job.al;
+            s.frame_bpm = job.frame_bpm;
+            s.units_per_line = job.units_per_line;
+            for (int c = 0; c < kMaxScanComponents; c++) {
+                s.fblk_base[c] = job.fblk_base[c];
+                s.hblocks[c] = job.hblocks[c];
+                s.vblocks[c] = job.vblocks[c];
+            }
             s.ends_off = ends_off;
             ends_off += s.n_intervals;
             s.chunk_off = (uint32_t)chunk_work.size();
             s.n_chunks = (uint32_t)(((uint64_t)s.data_len + (s.data_off & 15u) + kMarkerChunkBytes - 1) / kMarkerChunkBytes);
             if (s.n_chunks == 0) s.n_chunks = 1;
+            if (job.kind == kScanFrameOnly) s.n_chunks = 0;  // no entropy data: K1 / K2 skip the job
             for (uint32_t c = 0; c < s.n_chunks; c++) chunk_work.push_back({(uint32_t)j, c});
             s.image_index = (uint32_t)ii;
             s.level_shift = (uint32_t)g.level_shift;
@@ -368,13 +432,22 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             memcpy(s.blk_x, job.blk_x, sizeof s.blk_x);
             memcpy(s.blk_y, job.blk_y, sizeof s.blk_y);
 
-            const uint64_t nblocks = (uint64_t)s.total_mcus * s.blocks_per_mcu;
+            if (job.kind == kScanProgressive) {
+                if ((size_t)job.ordinal >= prog_work_by_ordinal.size()) prog_work_by_ordinal.resize((size_t)job.ordinal + 1);
+                for (uint32_t first = 0; first < s.n_intervals; first += 256) prog_work_by_ordinal[job.ordinal].push_back({(uint32_t)j, first});
+                compressed_bytes_ += s.data_len;
+                continue;  // no store of its own, no IDCT work
+            }
+            const uint64_t nblocks = (uint64_t)s.mcus_per_line * s.mcus_per_column * s.blocks_per_mcu;
+            if (job.kind == kScanFrameOnly) prog_clear_.push_back({coef_off, nblocks});
             coef_off += nblocks;
             img.total_blocks += nblocks;
             compressed_bytes_ += s.data_len;
             // scans without restart intervals are decoded by the self-synchronising subsequence decoder (K2S)
             const bool use_subseq = s.dri == 0 && s.total_mcus > 0 && s.data_len >= 512 && getenv("JPGPU_NO_SUBSEQ") == nullptr;
-            if (use_subseq) {
+            if (job.kind == kScanFrameOnly) {
+                // the Dispose() pass: IDCT work only
+            } else if (use_subseq) {
                 s.n_subs = (uint32_t)(((uint64_t)s.data_len * 8 + kSubseqBits - 1) / kSubseqBits);
                 s.sub_off = total_subs_;
                 total_subs_ += s.n_subs;
@@ -398,6 +471,12 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     n_chunk_work_ = (int)chunk_work.size();
     n_sub_work_ = (int)sub_work.size();
     n_sub_scans_ = (int)sub_scan_ids_.size();
+    std::vector<HuffWork> prog_work;
+    prog_begin_.assign(1, 0);
+    for (const std::vector<HuffWork> &w : prog_work_by_ordinal) {
+        prog_work.insert(prog_work.end(), w.begin(), w.end());
+        prog_begin_.push_back((int)prog_work.size());
+    }
     idct_class_begin_[0] = 0;
     for (int c = 0; c < kNumIdctLayoutClasses; c++) {
         idct_work.insert(idct_work.end(), idct_work_by_class[c].begin(), idct_work_by_class[c].end());
@@ -428,6 +507,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_huff_work_, huff_work.data(), huff_work.size() * sizeof(HuffWork), 0},
         {&d_chunk_work_, chunk_work.data(), chunk_work.size() * sizeof(ChunkWork), 0},
         {&d_sub_work_, sub_work.data(), sub_work.size() * sizeof(HuffWork), 0},
+        {&d_prog_work_, prog_work.data(), prog_work.size() * sizeof(HuffWork), 0},
         {&d_sub_scan_ids_, sub_scan_ids_.data(), sub_scan_ids_.size() * sizeof(uint32_t), 0},
         {&d_sub_exit_a_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
         {&d_sub_exit_b_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
@@ -517,6 +597,25 @@ int DeviceBatch::run_huffman() {
                                  (uint32_t *)d_sub_entry_.ptr, d_sub_dcsum_.ptr, d_sub_dcentry_.ptr, (uint32_t *)d_sub_changed_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (int)max_subs_per_scan_ + 2,
                                  &last_subseq_rounds_);
         if (e != hipSuccess) return hip_fail(e, "subsequence decode");
+    }
+    return run_progressive();
+}
+int DeviceBatch::run_progressive() {
+    if (prog_begin_.size() <= 1) return JPGPU_OK;
+    status_valid_ = false;
+    // every frame's store starts from zero (JpegBlockAllocator.Allocate clears it, JpegBlockAllocator.cs:81-83)
+    for (const auto &c : prog_clear_) {
+        hipError_t e = hipMemsetAsync((int16_t *)d_coefs_.ptr + c.first * 64, 0, (size_t)c.second * 128, ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(progressive store)");
+    }
+    const char *dbg_max = getenv("JPGPU_DEBUG_MAX_PROGRESSIVE_SCANS");  // debugging aid: stop after N scans per frame
+    for (size_t k = 0; k + 1 < prog_begin_.size(); k++) {
+        if (dbg_max && (int)k >= atoi(dbg_max)) break;
+        hipError_t e = launch_progressive(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr,
+                                          (const HuffWork *)d_prog_work_.ptr + prog_begin_[k], prog_begin_[k + 1] - prog_begin_[k],
+                                          (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr,
+                                          (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_);
+        if (e != hipSuccess) return hip_fail(e, "progressive_scan_kernel");
     }
     return JPGPU_OK;
 }

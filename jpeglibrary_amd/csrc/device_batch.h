@@ -51,6 +51,8 @@ class DeviceBatch {
 
     // Whole files: host parse (Identify + Decode's marker loop) -> plans/jobs -> HBM.
     int upload_files(const uint8_t *const *jpeg, const size_t *len, int n, int format);
+    // One progressive frame collected by the JpegDecoder mirror: its entropy scans + the Dispose() pass.
+    int upload_progressive_frame(const ProgressiveFrame &frame, const uint8_t *file, size_t file_len, int sof, int format);
     // One pre-built scan job whose entropy bytes are `entropy` (level-2 API and the JpegDecoder mirror).
     int upload_single_job(const ScanJob &job, int format, const void *initial_output, size_t initial_output_bytes);
     // Coefficient hand-off (progressive / config 5): images described by frame geometry + quantisation tables only.
@@ -59,6 +61,7 @@ class DeviceBatch {
     int run_marker_index();
     int run_huffman();
     int run_idct();
+    int run_progressive();     // entropy scans of progressive frames (K2P), ordinal by ordinal
     int run_huffman_tokens();  // token pipeline (K2T)
     int run_idct_tokens();     // token pipeline (K3T)
     int decode();  // marker index + the selected pipeline, with stage events
@@ -117,6 +120,10 @@ class DeviceBatch {
     uint32_t total_subs_ = 0, max_subs_per_scan_ = 0;
     std::vector<uint32_t> sub_scan_ids_;
     int last_subseq_rounds_ = 0;
+    // progressive frames: work of scan ordinal k is prog_work[prog_begin_[k] .. prog_begin_[k + 1])
+    DevBuffer d_prog_work_;
+    std::vector<int> prog_begin_;
+    std::vector<std::pair<uint64_t, uint64_t>> prog_clear_;  // (first block, blocks) of every progressive frame's store
     DevBuffer d_chunk_work_, d_chunk_sums_;
     int n_chunk_work_ = 0;
     DevBuffer d_unstuffed_, d_ends_u_;  // K1 output: entropy data as the bit reader sees it + interval ends in it

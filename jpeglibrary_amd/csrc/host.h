@@ -203,10 +203,52 @@ struct ScanJob {
     size_t entropy_len = 0;
     int blocks_per_mcu = 0;
     uint8_t blk_comp[kMaxBlocksPerMcu] = {}, blk_x[kMaxBlocksPerMcu] = {}, blk_y[kMaxBlocksPerMcu] = {};
+    // progressive frames (ScanKind): kScanFrameOnly = the Dispose() pass (dequantise + IDCT + Flush) over the frame's
+    // coefficient store, kScanProgressive = one entropy scan accumulating into that store
+    int kind = kScanSequential;
+    uint8_t ss = 0, se = 63, ah = 0, al = 0;
+    int ordinal = 0;              // position of the scan inside its frame: scans of a frame run in file order
+    uint16_t scan_dri = 0;        // DRI as read at ProcessScan time (ref: ...ProgressiveScanDecoder.cs:78), not at SOF
+    uint8_t frame_bpm = 0;
+    uint8_t fblk_base[kMaxScanComponents] = {};
+    uint16_t hblocks[kMaxScanComponents] = {}, vblocks[kMaxScanComponents] = {};
+    uint32_t units_per_line = 0, total_units = 0;
 };
 // Builds a ScanJob (validates tables like ProcessScan :69-82). Throws DecodeError with the reference's messages.
 ScanJob make_scan_job(const HostDecoder &dec, const BaselineGeometry &geo, const ScanHeader &scan, const uint8_t *entropy,
                       size_t entropy_len);
+
+// Host side of JpegHuffmanProgressiveScanDecoder (ref: ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs): collects the
+// scans of one SOF2 frame; the entropy decoding and the Dispose() pass run on the GPU.
+class ProgressiveFrame {
+  public:
+    // constructor of the scan decoder (:36-55) + JpegBlockAllocator.Allocate (JpegBlockAllocator.cs:35-84)
+    void begin(const HostDecoder &dec, const FrameHeader &fh);
+    // ProcessScan (:57-90): validates the tables the scan needs, snapshots them, records the job.
+    // The reference never advances the outer reader here; neither do we.
+    void add_scan(const HostDecoder &dec, const ScanHeader &scan, const uint8_t *entropy, size_t entropy_len);
+    // The job of the Dispose() pass (:421-470): components and quantisation tables as the LAST scans left them in
+    // the decoder's component slots.  Throws NotSupported for scan orders whose slots do not cover
+    // every frame component exactly once (the reference then transforms some component twice and another never).
+    ScanJob make_frame_job() const;
+    const BaselineGeometry &geo() const { return geo_; }
+    std::vector<ScanJob> &scans() { return scans_; }
+    const std::vector<ScanJob> &scans() const { return scans_; }
+    bool active() const { return active_; }
+    void reset() { active_ = false; scans_.clear(); }
+
+  private:
+    bool active_ = false;
+    BaselineGeometry geo_;
+    int slots_alloc_ = 0;
+    bool slot_set_[kMaxScanComponents] = {};
+    ResolvedScanComponent slot_[kMaxScanComponents];
+    QuantTable slot_quant_[kMaxScanComponents];
+    uint16_t hblocks_[kMaxScanComponents] = {}, vblocks_[kMaxScanComponents] = {};
+    uint8_t fblk_base_[kMaxScanComponents] = {};
+    uint8_t frame_bpm_ = 0;
+    std::vector<ScanJob> scans_;
+};
 
 // Scans forward over entropy-coded data to the next marker that is not RSTn, the way the reference's readers end up
 // (ref: JpegReader.cs:120-158 + ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:167-176).

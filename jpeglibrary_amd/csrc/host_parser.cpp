@@ -562,7 +562,11 @@ void HostDecoder::decode(ScanHandler &handler, bool have_output_writer) {
             to_continue = process_marker_for_decode(marker, r, handler);
         }
     } catch (...) {
-        handler.on_dispose(*this);  // finally { _scanDecoder?.Dispose(); }
+        try {
+            handler.on_dispose(*this);  // finally { _scanDecoder?.Dispose(); }
+        } catch (...) {
+            // the failure that ended the decode is the one the caller sees
+        }
         scan_decoder_created_ = false;
         throw;
     }
@@ -679,6 +683,147 @@ ScanJob make_scan_job(const HostDecoder &dec, const BaselineGeometry &geo, const
     // the job owns snapshots (huff_copy / quant_copy, addressed by slot); drop the registry pointers so nothing
     // dangles when the job is moved or the registry changes
     for (int i = 0; i < job.scan_components; i++) job.comp[i].dc = job.comp[i].ac = nullptr, job.comp[i].quant = nullptr;
+    return job;
+}
+
+// ------------------------------------------------------------------------------------------------ progressive frames
+
+void ProgressiveFrame::begin(const HostDecoder &dec, const FrameHeader &fh) {
+    reset();
+    if (fh.components.empty() && fh.num_components)
+        throw_invalid_data("Failed to decode JPEG data. Component parameters are missing in JPEG frame header.", kDetailBadHeader);
+    if (fh.num_components > kMaxScanComponents)
+        throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "More than 4 components are not supported.", kDetailUnsupportedFrame);
+    geo_ = BaselineGeometry::latch(dec, fh);
+    geo_.restart_interval = 0;  // progressive scans read DRI per scan
+    slots_alloc_ = fh.num_components;
+    for (int i = 0; i < kMaxScanComponents; i++) slot_set_[i] = false;
+    // JpegBlockAllocator.Allocate: block grid of every component (ref: JpegBlockAllocator.cs:35-84)
+    const int hb = (fh.samples_per_line + 7) / 8, vb = (fh.lines + 7) / 8;
+    int base = 0;
+    for (int i = 0; i < fh.num_components; i++) {
+        const FrameComponent &c = fh.components[i];
+        if (c.h == 0 || c.v == 0) throw_invalid_data("Failed to decode JPEG data. Attempted to divide by zero.", kDetailBadHeader);
+        const int hs = geo_.max_h / c.h, vs = geo_.max_v / c.v;
+        if (hs == 0 || vs == 0) throw_invalid_data("Failed to decode JPEG data. Attempted to divide by zero.", kDetailBadHeader);
+        hblocks_[i] = (uint16_t)((hb + hs - 1) / hs);
+        vblocks_[i] = (uint16_t)((vb + vs - 1) / vs);
+        fblk_base_[i] = (uint8_t)base;
+        base += c.h * c.v;
+    }
+    if (base > kMaxBlocksPerMcu) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "More than 16 blocks per MCU are not supported.", kDetailUnsupportedFrame);
+    frame_bpm_ = (uint8_t)base;
+    active_ = true;
+}
+
+void ProgressiveFrame::add_scan(const HostDecoder &dec, const ScanHeader &scan, const uint8_t *entropy, size_t entropy_len) {
+    const FrameHeader &fh = geo_.frame;
+    ScanJob job;
+    job.kind = kScanProgressive;
+    job.geo = geo_;
+    job.entropy = entropy;
+    job.entropy_len = entropy_len;
+    job.ss = scan.ss;
+    job.se = scan.se;
+    job.ah = scan.ah;
+    job.al = scan.al;
+    job.ordinal = (int)scans_.size();
+    job.scan_dri = dec.restart_interval();
+    job.frame_bpm = frame_bpm_;
+    job.scan_components = dec.resolve_scan(fh, scan, job.comp);  // InitDecodeComponents (:60)
+    if (scan.se > 63 || scan.ss > scan.se || scan.al > 13)
+        throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "Spectral selection / successive approximation parameters are outside the supported range.",
+                          kDetailUnsupportedFrame);
+    for (int i = 0; i < job.scan_components; i++) {  // :63-69
+        if (!job.comp[i].quant)
+            throw_invalid_data("Failed to decode JPEG data. Quantization table of component " + std::to_string(job.comp[i].component_index) + " is not defined.",
+                               kDetailMissingTable);
+    }
+    const bool interleaved = job.scan_components != 1;
+    const bool needs_dc = interleaved || scan.ss == 0;
+    for (int i = 0; i < job.scan_components; i++) {  // :97-103, :150-153, :171-174
+        if (needs_dc ? !job.comp[i].dc : !job.comp[i].ac)
+            throw_invalid_data("Failed to decode JPEG data. Huffman table of component " + std::to_string(job.comp[i].component_index) + " is not defined.",
+                               kDetailMissingTable);
+    }
+    // snapshot the tables the scan decodes with; dedupe by registry pointer
+    const HuffTable *seen[kMaxHuffSlots] = {};
+    auto slot_of = [&](const HuffTable *t) -> uint8_t {
+        for (int i = 0; i < job.n_huff; i++)
+            if (seen[i] == t) return (uint8_t)i;
+        seen[job.n_huff] = t;
+        job.huff_copy[job.n_huff] = *t;
+        return (uint8_t)job.n_huff++;
+    };
+    for (int i = 0; i < job.scan_components; i++) {
+        ResolvedScanComponent &c = job.comp[i];
+        job.dc_slot[i] = job.ac_slot[i] = 0;
+        if (needs_dc) job.dc_slot[i] = slot_of(c.dc);
+        else job.ac_slot[i] = slot_of(c.ac);
+        job.quant_copy[i] = *c.quant;
+        job.fblk_base[i] = fblk_base_[c.component_index];
+        job.hblocks[i] = hblocks_[c.component_index];
+        job.vblocks[i] = vblocks_[c.component_index];
+        // the decoder's component slots as the Dispose() pass will find them
+        slot_[i] = c;
+        slot_quant_[i] = *c.quant;
+        slot_set_[i] = true;
+    }
+    if (interleaved) {
+        job.units_per_line = (uint32_t)geo_.mcus_per_line;
+        job.total_units = (uint32_t)(geo_.mcus_per_line * geo_.mcus_per_column);
+    } else {
+        const ResolvedScanComponent &c = job.comp[0];  // :144-147
+        job.units_per_line = (uint32_t)((fh.samples_per_line + 8 * c.hs - 1) / (8 * c.hs));
+        job.total_units = job.units_per_line * (uint32_t)((fh.lines + 8 * c.vs - 1) / (8 * c.vs));
+    }
+    for (int i = 0; i < job.scan_components; i++) {
+        job.comp[i].dc = job.comp[i].ac = nullptr;
+        job.comp[i].quant = nullptr;
+    }
+    scans_.push_back(std::move(job));
+}
+
+ScanJob ProgressiveFrame::make_frame_job() const {
+    const FrameHeader &fh = geo_.frame;
+    // which slot transforms which frame component (Dispose iterates the slots, :425-447)
+    int slot_of_component[kMaxScanComponents];
+    for (int i = 0; i < kMaxScanComponents; i++) slot_of_component[i] = -1;
+    bool ok = true;
+    for (int i = 0; i < slots_alloc_; i++) {
+        if (!slot_set_[i]) ok = false;
+        else if (slot_of_component[slot_[i].component_index] >= 0) ok = false;
+        else slot_of_component[slot_[i].component_index] = i;
+    }
+    if (!ok)
+        throw DecodeError(JPGPU_ERR_NOT_SUPPORTED,
+                          "Progressive scan order leaves the decoder's component slots without one entry per frame component; "
+                          "the reference's output for such files is an artefact of its Dispose() pass and is not reproduced.",
+                          kDetailUnsupportedFrame);
+    // a sequential-style job over ALL frame components in frame order with the slots' quantisation tables
+    HostDecoder tmp;
+    FrameHeader f2 = fh;
+    ScanHeader sh;
+    sh.num_components = fh.num_components;
+    sh.se = 63;
+    for (int c = 0; c < fh.num_components; c++) {
+        f2.components[c].tq = (uint8_t)c;
+        QuantTable q = slot_quant_[slot_of_component[c]];
+        q.identifier = (uint8_t)c;
+        tmp.set_quantization_table(q);
+        sh.components.push_back({fh.components[c].identifier, 0, 0});
+    }
+    HuffTable dummy;  // the IDCT pass needs no Huffman tables; a placeholder satisfies the job builder's checks
+    const uint8_t bits[16] = {0, 1};
+    const uint8_t vals[1] = {0};
+    HuffTable::from_bits_values(0, 0, bits, vals, 1, &dummy);
+    tmp.set_huffman_table(dummy);
+    dummy.table_class = 1;
+    tmp.set_huffman_table(dummy);
+    tmp.set_frame_header(f2);
+    BaselineGeometry g = BaselineGeometry::latch(tmp, f2);
+    ScanJob job = make_scan_job(tmp, g, sh, nullptr, 0);
+    job.kind = kScanFrameOnly;
     return job;
 }
 

@@ -37,6 +37,10 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
                                 int max_rounds, int *rounds_used);
 
+// progressive frames (K2P): the scans of one ordinal (position inside their frame) of every progressive frame in the batch
+hipError_t launch_progressive(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
+                              const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs, int n_slots);
+
 // token pipeline (K2T / K3T)
 hipError_t launch_huffman_tokens(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                                  const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, uint32_t *tokens,

@@ -1059,6 +1059,293 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_tokens_kernel(const uint8_
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2P: one entropy scan of a progressive frame (ref: ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs).
+//
+// One lane per restart interval of the scan (one lane for the whole scan when DRI = 0); a workgroup belongs to one
+// scan, so the scan kind (DC / AC, first / refinement) is uniform in it.  Scans of a frame are launched in file order
+// (refinements depend on what earlier scans stored); all frames of a batch advance together, scan ordinal by ordinal.
+// Coefficients accumulate in the frame's MCU-ordered store, the layout the IDCT pass (K3) reads:
+//   * DC first / AC first write single coefficients (nothing has to be read: first passes only touch zeros),
+//   * DC refinement ORs one bit into the stored DC (fire-and-forget atomic),
+//   * AC refinement stages the block in LDS (it branches on every stored coefficient), the next block's 128 bytes are
+//     prefetched into registers meanwhile.
+// Blocks outside a component's own grid go to the reference's dummy block (JpegBlockAllocator.cs:93-114): decoded,
+// not stored.
+// ------------------------------------------------------------------------------------------------
+
+// DecodeHuffmanCode alone (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:81-88): the symbol, no magnitude bits.
+__device__ __forceinline__ uint32_t ub_huff(UBits &r, const LdsHuff &h, uint32_t &sym_out) {
+    const uint32_t code16 = r.rem > 0 ? (r.hi >> 16) : 0xFFFFu;
+    const uint32_t e = h.lut[code16 >> (16 - kHuffLutBits)];
+    uint32_t size = e >> 8, sym = e & 0xFF;
+    if (size == 0) {
+        size = kHuffLutBits + 1;
+        while (code16 > h.maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
+        if (size > 16) return kDetailInvalidHuffmanCode;
+        sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
+    }
+    sym_out = sym;
+    r.rem = r.rem > (int32_t)size ? r.rem - (int32_t)size : 0;  // advance Math.Min(entry.CodeSize, bitsRead)
+    ub_consume(r, size);
+    return 0;
+}
+
+// TryReadBits(n), 1 <= n <= 16 (ref: JpegBitReader.cs:190-204): false when fewer than n bits are left
+__device__ __forceinline__ bool ub_try_read_bits(UBits &r, uint32_t n, uint32_t &bits) {
+    if ((int32_t)n > r.rem) return false;
+    bits = r.hi >> (32u - n);
+    r.rem -= (int32_t)n;
+    ub_consume(r, n);
+    return true;
+}
+
+typedef uint32_t __attribute__((may_alias)) aliasing_u32;  // word view of a staged int16 block (type-punned on purpose)
+constexpr int kProgThreads = 256;
+constexpr int kProgBlockStride = 132;  // bytes per lane in the AC-refinement staging: 33 words keep lanes on distinct banks
+
+// block (bx, by) of scan component c in the frame's MCU-ordered coefficient store; false = the dummy block
+__device__ __forceinline__ bool prog_block_index(const DevScan &s, uint32_t c, uint32_t bx, uint32_t by, uint64_t &index) {
+    if (bx >= s.hblocks[c] || by >= s.vblocks[c]) return false;
+    const uint32_t h = s.comp[c].h, v = s.comp[c].v;
+    const uint32_t mx = bx / h, my = by / v;
+    index = s.coef_off + ((uint64_t)my * s.mcus_per_line + mx) * s.frame_bpm + s.fblk_base[c] + (by - my * v) * h + (bx - mx * h);
+    return true;
+}
+
+__global__ __launch_bounds__(kProgThreads) void progressive_scan_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+                                                                        const HuffWork *__restrict__ work,
+                                                                        const uint32_t *__restrict__ ends_u,
+                                                                        DevScanStatus *__restrict__ status,
+                                                                        const DevHuffTable *__restrict__ huff_pool, int16_t *coefs,
+                                                                        int n_slots) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *tabs = smem;                                                    // n_slots * sizeof(DevHuffTable)
+    uint8_t *stage_all = smem + (size_t)n_slots * sizeof(DevHuffTable);     // kProgThreads * kProgBlockStride
+
+    const HuffWork wk = work[blockIdx.x];
+    const DevScan &s = scans[wk.scan];
+    const uint32_t tid = threadIdx.x;
+    for (int slot = 0; slot < kMaxHuffSlots && slot < n_slots; slot++) {
+        const uint32_t pi = s.huff_pool[slot];
+        if (pi == 0xFFFF) continue;
+        const uint4 *src = reinterpret_cast<const uint4 *>(&huff_pool[pi]);
+        uint4 *dst = reinterpret_cast<uint4 *>(tabs + slot * sizeof(DevHuffTable));
+        for (uint32_t i = tid; i < sizeof(DevHuffTable) / 16; i += kProgThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const DevScanStatus st = status[wk.scan];
+    const uint32_t n_ends = st.n_ends;
+    const uint32_t n_intervals = s.n_intervals;
+    const uint32_t total_units = s.total_mcus;
+    const uint32_t dri_eff = s.dri ? s.dri : total_units;
+    const uint32_t interval = wk.first_interval + tid;
+    if (interval >= n_ends) return;  // nothing after the last barrier: lanes may leave
+    const uint32_t *eu = ends_u + s.ends_off;
+    const uint32_t ustart = interval == 0 ? 0u : eu[interval - 1] + 2u;
+    UBits r;
+    ub_init(r, udata + s.data_off, ustart, eu[interval]);
+    const bool closed_by_marker = !(interval == n_ends - 1 && st.terminator == 0);
+    const uint32_t my_units = (interval == n_intervals - 1) ? total_units - interval * dri_eff : dri_eff;
+    const uint32_t first_unit = interval * dri_eff;
+
+    const uint32_t al = s.al;
+    uint32_t err = 0;
+
+    if (s.scan_components != 1 || s.ss == 0) {
+        // ---- DC scans (:92-138 interleaved, :148-168 single component), ReadBlockProgressiveDC (:227-253)
+        int32_t pred[kMaxScanComponents] = {0, 0, 0, 0};
+        const bool interleaved = s.scan_components != 1;
+        for (uint32_t u = 0; u < my_units && err == 0; u++) {
+            const uint32_t unit = first_unit + u;
+            const uint32_t uy = unit / s.units_per_line, ux = unit - uy * s.units_per_line;
+            for (uint32_t c = 0; c < s.scan_components && err == 0; c++) {
+                const uint32_t h = interleaved ? s.comp[c].h : 1u, v = interleaved ? s.comp[c].v : 1u;
+                const LdsHuff hdc = lds_huff(tabs, s.comp[c].dc_slot);
+                for (uint32_t y = 0; y < v && err == 0; y++)
+                    for (uint32_t x = 0; x < h && err == 0; x++) {
+                        uint64_t index;
+                        const bool real = prog_block_index(s, c, ux * h + x, uy * v + y, index);
+                        if (s.ah == 0) {
+                            uint32_t sym;
+                            int32_t value;
+                            err = ub_symbol(r, hdc, true, closed_by_marker, sym, value);
+                            if (err != 0) break;
+                            const int32_t t = pred[c] + value;
+                            pred[c] = t;
+                            if (real) coefs[index * 64] = (int16_t)((uint32_t)t << al);
+                        } else {
+                            uint32_t bit;
+                            if (!ub_try_read_bits(r, 1, bit)) {
+                                err = kDetailUnexpectedEnd;
+                                break;
+                            }
+                            // blockRef |= bit << al, 16-bit (the DC is the low half of the block's first word)
+                            if (real && bit) atomicOr(reinterpret_cast<uint32_t *>(coefs + index * 64), (1u << al) & 0xFFFFu);
+                        }
+                    }
+            }
+        }
+    } else if (s.ah == 0) {
+        // ---- AC first pass (:255-311)
+        const LdsHuff hac = lds_huff(tabs, s.comp[0].ac_slot);
+        const uint32_t ss = s.ss, se = s.se;
+        uint32_t eobrun = 0;
+        for (uint32_t u = 0; u < my_units && err == 0; u++) {
+            if (eobrun != 0) {
+                eobrun--;
+                continue;
+            }
+            const uint32_t unit = first_unit + u;
+            const uint32_t by = unit / s.units_per_line, bx = unit - by * s.units_per_line;
+            uint64_t index = 0;
+            const bool real = prog_block_index(s, 0, bx, by, index);
+            int16_t *blk = coefs + index * 64;
+            for (uint32_t i = ss; i <= se; i++) {
+                uint32_t sym;
+                int32_t value;
+                err = ub_symbol(r, hac, false, closed_by_marker, sym, value);
+                if (err != 0) break;
+                const uint32_t rr = sym >> 4;
+                i += rr;
+                if ((sym & 15u) != 0) {
+                    if (real) blk[i < 63u ? i : 63u] = (int16_t)((uint32_t)value << al);
+                } else if (rr != 15u) {
+                    eobrun = 1u << rr;
+                    if (rr != 0) {
+                        uint32_t bits;
+                        if (!ub_try_read_bits(r, rr, bits)) {
+                            err = kDetailUnexpectedEnd;
+                            break;
+                        }
+                        eobrun += bits;
+                    }
+                    eobrun--;
+                    break;
+                }
+            }
+        }
+    } else {
+        // ---- AC refinement (:313-419)
+        const LdsHuff hac = lds_huff(tabs, s.comp[0].ac_slot);
+        const uint32_t ss = s.ss, se = s.se;
+        const int16_t p1 = (int16_t)(1u << al), m1 = (int16_t)(0xFFFFFFFFu << al);
+        int16_t *lb = reinterpret_cast<int16_t *>(stage_all + tid * kProgBlockStride);
+        uint32_t eobrun = 0;
+        uint4 nb[8];  // the next block, prefetched
+        bool nb_real = false;
+        uint64_t nb_index = 0;
+        auto prefetch = [&](uint32_t u) {
+            nb_real = false;
+            if (u < my_units) {
+                const uint32_t unit = first_unit + u;
+                const uint32_t by = unit / s.units_per_line, bx = unit - by * s.units_per_line;
+                nb_real = prog_block_index(s, 0, bx, by, nb_index);
+            }
+            if (nb_real) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(coefs + nb_index * 64);
+#pragma unroll
+                for (int i = 0; i < 8; i++) nb[i] = src[i];
+            } else {
+                const uint4 z = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 8; i++) nb[i] = z;
+            }
+        };
+        prefetch(0);
+        for (uint32_t u = 0; u < my_units && err == 0; u++) {
+            const bool real = nb_real;
+            const uint64_t index = nb_index;
+            {
+                aliasing_u32 *w = reinterpret_cast<aliasing_u32 *>(lb);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    w[i * 4 + 0] = nb[i].x;
+                    w[i * 4 + 1] = nb[i].y;
+                    w[i * 4 + 2] = nb[i].z;
+                    w[i * 4 + 3] = nb[i].w;
+                }
+            }
+            prefetch(u + 1);
+
+            uint32_t k = ss;
+            if (eobrun == 0) {
+                for (; k <= se; k++) {
+                    uint32_t sym;
+                    err = ub_huff(r, hac, sym);
+                    if (err != 0) break;
+                    int32_t rr = (int32_t)(sym >> 4);
+                    int16_t sval = 0;
+                    const bool nonzero = (sym & 15u) != 0;
+                    if (nonzero) {
+                        uint32_t bit;
+                        if (!ub_try_read_bits(r, 1, bit)) {
+                            err = kDetailUnexpectedEnd;
+                            break;
+                        }
+                        sval = bit ? p1 : m1;
+                    } else if (rr != 15) {
+                        eobrun = 1u << rr;
+                        if (rr != 0) {
+                            uint32_t bits;
+                            if (!ub_try_read_bits(r, (uint32_t)rr, bits)) {
+                                err = kDetailUnexpectedEnd;
+                                break;
+                            }
+                            eobrun += bits;
+                        }
+                        break;
+                    }
+                    do {
+                        int16_t c = lb[k];
+                        if (c != 0) {
+                            uint32_t bit;
+                            if (!ub_try_read_bits(r, 1, bit)) {
+                                err = kDetailUnexpectedEnd;
+                                break;
+                            }
+                            if (bit && (c & p1) == 0) lb[k] = (int16_t)(c + (c >= 0 ? p1 : m1));
+                        } else {
+                            if (--rr < 0) break;
+                        }
+                        k++;
+                    } while (k <= se);
+                    if (err != 0) break;
+                    if (nonzero && k < 64u) lb[k] = sval;
+                }
+            }
+            if (err == 0 && eobrun > 0) {
+                for (; k <= se; k++) {
+                    const int16_t c = lb[k];
+                    if (c != 0) {
+                        uint32_t bit;
+                        if (!ub_try_read_bits(r, 1, bit)) {
+                            err = kDetailUnexpectedEnd;
+                            break;
+                        }
+                        if (bit && (c & p1) == 0) lb[k] = (int16_t)(c + (c > 0 ? p1 : m1));
+                    }
+                }
+                eobrun--;
+            }
+            if (real) {
+                const aliasing_u32 *w = reinterpret_cast<const aliasing_u32 *>(lb);
+                uint4 *dst = reinterpret_cast<uint4 *>(coefs + index * 64);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint4 v = {w[i * 4 + 0], w[i * 4 + 1], w[i * 4 + 2], w[i * 4 + 3]};
+                    dst[i] = v;
+                }
+            }
+        }
+    }
+
+    // HandleRestart (:196-224) after the interval's last unit: same rules as the sequential decoder's restart check
+    const uint32_t code = restart_check(s, st, &status[wk.scan], interval, n_ends, n_intervals, dri_eff, r.rem, err);
+    if (code != kNoError) atomicMin(&status[wk.scan].first_error, code);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2S: self-synchronising subsequence decode for scans WITHOUT restart intervals (DRI = 0).
 //
 // One restart interval = one lane does not scale when the whole scan is a single interval.  The unstuffed stream is cut
@@ -1893,6 +2180,16 @@ hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+// One ordinal of progressive scans (all frames of the batch advance together).
+hipError_t launch_progressive(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
+                              const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs, int n_slots) {
+    if (n_work <= 0) return hipSuccess;
+    const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + (size_t)kProgThreads * kProgBlockStride;
+    hipLaunchKernelGGL(progressive_scan_kernel, dim3(n_work), dim3(kProgThreads), lds, stream, udata, scans, work, ends_u, status,
+                       huff_pool, coefs, n_slots);
+    return hipGetLastError();
 }
 
 // DRI = 0 scans: self-synchronising subsequence decode.  `work` lists (scan, first subsequence) per workgroup of 256 lanes;

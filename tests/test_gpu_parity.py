@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 # ------------------------------------------------------------------------------------------------ reference goldens
 
-@pytest.mark.parametrize("name", ["cramps.jpg", "lake.jpg", "testorig12.jpg"])
+@pytest.mark.parametrize("name", ["cramps.jpg", "lake.jpg", "testorig12.jpg", "progress.jpg", "yellowcat_progressive_restart.jpg"])
 def test_decode_matches_reference_golden(name):
     jpeg_bytes = read_jpeg(name)
     decoder = jl.JpegDecoder()
@@ -30,7 +30,7 @@ def test_decode_matches_reference_golden(name):
     assert np.array_equal(reference.reshape(-1), buffer)
 
 
-@pytest.mark.parametrize("name", ["cramps.jpg", "lake.jpg", "HETissueSlide.jpg"])
+@pytest.mark.parametrize("name", ["cramps.jpg", "lake.jpg", "HETissueSlide.jpg", "progress.jpg", "yellowcat_progressive_restart.jpg"])
 def test_buffer8_writer_matches_oracle(name):
     """The app writer (JpegBufferOutputWriter8Bit) fast path: interleaved u8 produced on the GPU."""
     data = read_jpeg(name)
@@ -469,3 +469,92 @@ def test_progressive_idct_pass_on_gpu(name):
         full = np.repeat(np.repeat(planes[ci], vs, axis=0), hs, axis=1)[:info.height, :info.width]
         clamped = np.minimum(full.astype(np.uint16), 255).astype(np.uint16)  # (ushort) cast: negatives become max
         assert np.array_equal(clamped * 257, golden[..., ci]), ci
+
+
+# ------------------------------------------------------------------------------------------------ progressive frames (SOF2)
+
+def _pillow_progressive(w, h, subsampling, quality, seed, restart_blocks=0, gray=False):
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 70 * np.sin(xx / 37.0 + seed) * np.cos(yy / 53.0), 128 + 60 * np.cos(xx / 91.0 + yy / 29.0),
+                    128 + 90 * np.sin((xx + yy) / 67.0)], axis=-1) + rng.normal(0, 8, (h, w, 3))
+    img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    im = Image.fromarray(img[..., 0]) if gray else Image.fromarray(img)
+    buf = io.BytesIO()
+    kw = dict(format="JPEG", quality=quality, progressive=True)
+    if not gray:
+        kw["subsampling"] = subsampling
+    if restart_blocks:
+        kw["restart_marker_blocks"] = restart_blocks
+    im.save(buf, **kw)
+    return buf.getvalue()
+
+
+PROGRESSIVE_CASES = [
+    (64, 64, "4:4:4", 75, 0, False), (333, 211, "4:2:0", 75, 0, False), (333, 211, "4:2:2", 90, 0, False),
+    (257, 129, "4:2:0", 50, 3, False), (640, 480, "4:2:0", 95, 0, False), (199, 301, "4:4:4", 30, 5, False),
+    (123, 77, None, 80, 0, True), (1024, 768, "4:2:0", 85, 16, False), (250, 130, "4:2:0", 60, 7, False),
+    (96, 80, "4:4:4", 70, 11, False),
+]
+
+
+@pytest.mark.parametrize("w,h,ss,q,rst,gray", PROGRESSIVE_CASES)
+def test_progressive_files_match_oracle(w, h, ss, q, rst, gray):
+    """Every scan kind of libjpeg's progressive script (DC first/refine, AC first with EOB runs, AC refinement), with
+    and without restart markers, decoded on the GPU through the batch API: pixels AND the accumulated coefficient store."""
+    data = _pillow_progressive(w, h, ss, q, seed=w + h, restart_blocks=rst, gray=gray)
+    assert b"\xff\xc2" in data
+    try:
+        ref, info = po.decode_8bit(data)
+    except po.OracleError as e:
+        # the reference's restart check also runs after the LAST unit of a scan when the unit count is a multiple of
+        # DRI, and then trips over the next scan's DHT/SOS ("Expect restart marker."): same failure on the GPU
+        mine, res = _status_of_gpu(data)
+        assert mine == e.kind, (e.message, mine, res.detail)
+        from jpeglibrary_amd import _capi
+        assert _capi.lib.jpgpu_detail_string(res.detail).decode() == e.message
+        return
+    outs, results = jl.decode_batch([data])
+    assert results[0].status == 0, results[0].detail
+    assert np.array_equal(outs[0], ref)
+    # the coefficient store right before the IDCT pass
+    _, blocks, _ = po.decode_progressive_store(data)
+    b = jl.Batch().upload([data]).decode().sync()
+    coefs = b.coefficients(0)
+    comps = [(info.comp[i].h, info.comp[i].v) for i in range(info.ncomp)]
+    max_h, max_v = max(c[0] for c in comps), max(c[1] for c in comps)
+    mcus_x = -(-info.width // (8 * max_h))
+    bpm = sum(c[0] * c[1] for c in comps)
+    base = 0
+    for ci, (ch, cv) in enumerate(comps):
+        for (bx, by), blk in blocks[ci].items():
+            idx = ((by // cv) * mcus_x + bx // ch) * bpm + base + (by % cv) * ch + bx % ch
+            assert np.array_equal(coefs[idx], blk), (ci, bx, by)
+        base += ch * cv
+
+
+def test_progressive_batch_mixed_with_baseline():
+    files = [read_jpeg("progress.jpg"), read_jpeg("lake.jpg"), _pillow_progressive(160, 120, "4:2:0", 70, 3),
+             bytes(jpegsynth.encode(96, 64, "420", 75, 2, seed=5)), read_jpeg("yellowcat_progressive_restart.jpg")]
+    outs, results = jl.decode_batch(files)
+    for f, o, r in zip(files, outs, results):
+        assert r.status == 0
+        assert np.array_equal(o, po.decode_8bit(bytes(f))[0])
+
+
+def test_truncated_progressive_stream_fails_like_the_reference():
+    from jpeglibrary_amd import _capi
+    data = _pillow_progressive(320, 240, "4:2:0", 85, 9)
+    for cut in (len(data) // 3, len(data) // 2, len(data) - 40):
+        bad = data[:cut] + b"\xff\xd9"
+        try:
+            po.decode_8bit(bad)
+            ref, ref_msg = "OK", ""
+        except po.OracleError as e:
+            ref, ref_msg = e.kind, e.message
+        mine, res = _status_of_gpu(bad)
+        assert mine == ref, (cut, ref, ref_msg, mine, res.detail)
+        if res.detail in (1, 2, 3, 4, 9):
+            assert _capi.lib.jpgpu_detail_string(res.detail).decode() == ref_msg, (cut, ref_msg, res.detail)
