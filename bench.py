@@ -32,12 +32,38 @@ WORKLOADS = {
     "4k_dri0": (3840, 2160, "420", 75, 0, 1024),
     "1080p_q90": (1920, 1080, "420", 90, 4, 1024),
     "512_444": (512, 512, "444", 75, 0, 1),
+    # BASELINE.json configs[4]: progressive (SOF2) 4K 4:2:0, libjpeg's default 10-scan script, DRI = 0 (made with Pillow)
+    "4k_progressive": (3840, 2160, "420p", 75, 0, 256),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def progressive_image(width, height, quality, seed):
+    """SURVEY 8d recipe (sinusoid mix + N(0, 8) noise), encoded as a progressive 4:2:0 JPEG by Pillow / libjpeg-turbo."""
+    import io
+
+    from PIL import Image
+
+    rng = np.random.default_rng(seed)
+    ph = rng.uniform(0, 2 * np.pi, 4)
+    y, x = np.mgrid[0:height, 0:width].astype(np.float32)
+    img = np.stack([128 + 70 * np.sin(x / 37 + ph[0]) * np.cos(y / 53 + ph[1]), 128 + 60 * np.cos(x / 91 + y / 29 + ph[2]),
+                    128 + 90 * np.sin((x + y) / 67 + ph[3])], axis=-1)
+    img += rng.normal(0, 8, img.shape).astype(np.float32)
+    out = io.BytesIO()
+    Image.fromarray(np.clip(np.rint(img), 0, 255).astype(np.uint8)).save(out, format="JPEG", quality=quality, progressive=True,
+                                                                          subsampling="4:2:0")
+    return out.getvalue()
+
+
+def progressive_batch(n, width, height, quality, seed0, nthreads):
+    # threads, not processes: the GPU is already initialised in this process (numpy and Pillow release the GIL)
+    with ThreadPoolExecutor(max(1, min(nthreads, 64))) as ex:
+        return list(ex.map(progressive_image, [width] * n, [height] * n, [quality] * n, [seed0 + i for i in range(n)]))
 
 
 def cpu_baseline(buf, sizes, stride, width, height, n_images, max_threads):
@@ -125,6 +151,7 @@ def main():
     from tools import jpegsynth
 
     width, height, ss, quality, dri, default_images = WORKLOADS[args.workload]
+    kind = "progressive (SOF2, 10 scans)" if ss == "420p" else "baseline"
     n_images = args.images or default_images
     fmt = jl.FMT_INTERLEAVED_U8 if args.format == "interleaved_u8" else jl.FMT_PLANAR_U8
 
@@ -132,7 +159,16 @@ def main():
     cpu = os.cpu_count() or 1
     gen_threads = args.gen_threads or max(1, cpu // max(1, min(world, 8)))
     t0 = time.perf_counter()
-    buf, sizes, stride = jpegsynth.encode_batch(n_images, width, height, ss, quality, dri, seed0=sharding.rank_seed_base(rank), nthreads=gen_threads)
+    if ss == "420p":
+        ss = "420"
+        files_b = progressive_batch(n_images, width, height, quality, sharding.rank_seed_base(rank), gen_threads)
+        sizes = np.array([len(f) for f in files_b], dtype=np.int64)
+        stride = int(sizes.max())
+        buf = np.zeros(stride * n_images + 64, np.uint8)
+        for i, f in enumerate(files_b):
+            buf[i * stride:i * stride + len(f)] = np.frombuffer(f, np.uint8)
+    else:
+        buf, sizes, stride = jpegsynth.encode_batch(n_images, width, height, ss, quality, dri, seed0=sharding.rank_seed_base(rank), nthreads=gen_threads)
     t_gen = time.perf_counter() - t0
     files = [buf[i * stride:i * stride + int(sizes[i])] for i in range(n_images)]
     log(f"[rank {rank}] generated {n_images} x {width}x{height} {ss} Q{quality} DRI={dri}: {sizes.sum() / 1e6:.1f} MB in {t_gen:.1f} s ({gen_threads} threads)")
@@ -203,7 +239,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{n_images} x {width}x{height} {ss} baseline Q{quality} DRI={dri} per GPU, output {args.format} resident in HBM",
+                "workload": f"{n_images} x {width}x{height} {ss} {kind} Q{quality} DRI={dri} per GPU, output {args.format} resident in HBM",
                 "images_per_gpu": n_images,
                 "compressed_MB_per_gpu": round(totals["compressed_bytes"] / 1e6, 1),
                 "sharding": "image-per-GPU, no collective",

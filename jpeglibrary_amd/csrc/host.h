@@ -207,7 +207,7 @@ struct ScanJob {
     // coefficient store, kScanProgressive = one entropy scan accumulating into that store
     int kind = kScanSequential;
     uint8_t ss = 0, se = 63, ah = 0, al = 0;
-    int ordinal = 0;              // position of the scan inside its frame: scans of a frame run in file order
+    int ordinal = 0;              // dependency level inside the frame: scans of one level may run together
     uint16_t scan_dri = 0;        // DRI as read at ProcessScan time (ref: ...ProgressiveScanDecoder.cs:78), not at SOF
     uint8_t frame_bpm = 0;
     uint8_t fblk_base[kMaxScanComponents] = {};

@@ -727,7 +727,11 @@ void ProgressiveFrame::add_scan(const HostDecoder &dec, const ScanHeader &scan, 
     job.se = scan.se;
     job.ah = scan.ah;
     job.al = scan.al;
-    job.ordinal = (int)scans_.size();
+    // Scans run in dependency LEVELS, not strictly one after the other: a scan waits for the earlier scans that touch
+    // the same coefficients of the same component (every kernel write is an exact 2-byte store or a 32-bit atomic OR on
+    // the DC word, so disjoint bands of the same blocks can be in flight together).  File order inside a level is
+    // irrelevant for the result; errors are still reported for the first failing scan in file order.
+    job.ordinal = 0;
     job.scan_dri = dec.restart_interval();
     job.frame_bpm = frame_bpm_;
     job.scan_components = dec.resolve_scan(fh, scan, job.comp);  // InitDecodeComponents (:60)
@@ -776,6 +780,16 @@ void ProgressiveFrame::add_scan(const HostDecoder &dec, const ScanHeader &scan, 
         const ResolvedScanComponent &c = job.comp[0];  // :144-147
         job.units_per_line = (uint32_t)((fh.samples_per_line + 8 * c.hs - 1) / (8 * c.hs));
         job.total_units = job.units_per_line * (uint32_t)((fh.lines + 8 * c.vs - 1) / (8 * c.vs));
+    }
+    for (const ScanJob &e : scans_) {
+        const bool e_interleaved = e.scan_components != 1;
+        const int e_lo = e_interleaved ? 0 : e.ss, e_hi = e_interleaved ? 0 : e.se;  // interleaved scans are DC scans
+        const int lo = interleaved ? 0 : scan.ss, hi = interleaved ? 0 : scan.se;
+        if (lo > e_hi || e_lo > hi) continue;
+        bool shares = false;
+        for (int a = 0; a < job.scan_components; a++)
+            for (int b = 0; b < e.scan_components; b++) shares |= job.comp[a].component_index == e.comp[b].component_index;
+        if (shares) job.ordinal = std::max(job.ordinal, e.ordinal + 1);
     }
     for (int i = 0; i < job.scan_components; i++) {
         job.comp[i].dc = job.comp[i].ac = nullptr;

@@ -1103,12 +1103,63 @@ typedef uint32_t __attribute__((may_alias)) aliasing_u32;  // word view of a sta
 constexpr int kProgThreads = 256;
 constexpr int kProgBlockStride = 132;  // bytes per lane in the AC-refinement staging: 33 words keep lanes on distinct banks
 
-// block (bx, by) of scan component c in the frame's MCU-ordered coefficient store; false = the dummy block
-__device__ __forceinline__ bool prog_block_index(const DevScan &s, uint32_t c, uint32_t bx, uint32_t by, uint64_t &index) {
-    if (bx >= s.hblocks[c] || by >= s.vblocks[c]) return false;
-    const uint32_t h = s.comp[c].h, v = s.comp[c].v;
-    const uint32_t mx = bx / h, my = by / v;
-    index = s.coef_off + ((uint64_t)my * s.mcus_per_line + mx) * s.frame_bpm + s.fblk_base[c] + (by - my * v) * h + (bx - mx * h);
+// Where the blocks of one scan component live in the frame's MCU-ordered coefficient store, held in registers (the
+// scan descriptor is read once: nothing in the block loops touches it again).
+struct ProgComp {
+    uint32_t h, v, hblocks, vblocks, base;
+};
+struct ProgFrame {
+    uint64_t coef_off;
+    uint32_t mcus_per_line, bpm;
+};
+__device__ __forceinline__ ProgComp prog_comp(const DevScan &s, uint32_t c) {
+    ProgComp p;
+    p.h = s.comp[c].h;
+    p.v = s.comp[c].v;
+    p.hblocks = s.hblocks[c];
+    p.vblocks = s.vblocks[c];
+    p.base = s.fblk_base[c];
+    return p;
+}
+// block (bx, by) of a component; false = the allocator's dummy block
+__device__ __forceinline__ bool prog_block_index(const ProgFrame &f, const ProgComp &p, uint32_t bx, uint32_t by, uint64_t &index) {
+    if (bx >= p.hblocks || by >= p.vblocks) return false;
+    const uint32_t mx = bx / p.h, my = by / p.v;
+    index = f.coef_off + ((uint64_t)my * f.mcus_per_line + mx) * f.bpm + p.base + (by - my * p.v) * p.h + (bx - mx * p.h);
+    return true;
+}
+
+// Raster walk over the blocks of a non-interleaved scan without divisions: (bx, by) plus their split into MCU
+// coordinates and position inside the MCU.
+struct ProgWalk {
+    uint32_t bx, by, mx, rx, my, ry;
+};
+__device__ __forceinline__ void prog_walk_init(ProgWalk &w, const ProgComp &p, uint32_t unit, uint32_t units_per_line) {
+    w.by = unit / units_per_line;
+    w.bx = unit - w.by * units_per_line;
+    w.mx = w.bx / p.h;
+    w.rx = w.bx - w.mx * p.h;
+    w.my = w.by / p.v;
+    w.ry = w.by - w.my * p.v;
+}
+__device__ __forceinline__ void prog_walk_next(ProgWalk &w, const ProgComp &p, uint32_t units_per_line) {
+    w.bx++;
+    if (++w.rx == p.h) {
+        w.rx = 0;
+        w.mx++;
+    }
+    if (w.bx == units_per_line) {
+        w.bx = w.mx = w.rx = 0;
+        w.by++;
+        if (++w.ry == p.v) {
+            w.ry = 0;
+            w.my++;
+        }
+    }
+}
+__device__ __forceinline__ bool prog_walk_index(const ProgFrame &f, const ProgComp &p, const ProgWalk &w, uint64_t &index) {
+    if (w.bx >= p.hblocks || w.by >= p.vblocks) return false;
+    index = f.coef_off + ((uint64_t)w.my * f.mcus_per_line + w.mx) * f.bpm + p.base + w.ry * p.h + w.rx;
     return true;
 }
 
@@ -1116,8 +1167,8 @@ __global__ __launch_bounds__(kProgThreads) void progressive_scan_kernel(const ui
                                                                         const HuffWork *__restrict__ work,
                                                                         const uint32_t *__restrict__ ends_u,
                                                                         DevScanStatus *__restrict__ status,
-                                                                        const DevHuffTable *__restrict__ huff_pool, int16_t *coefs,
-                                                                        int n_slots) {
+                                                                        const DevHuffTable *__restrict__ huff_pool,
+                                                                        int16_t *__restrict__ coefs, int n_slots) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *tabs = smem;                                                    // n_slots * sizeof(DevHuffTable)
     uint8_t *stage_all = smem + (size_t)n_slots * sizeof(DevHuffTable);     // kProgThreads * kProgBlockStride
@@ -1149,24 +1200,36 @@ __global__ __launch_bounds__(kProgThreads) void progressive_scan_kernel(const ui
     const uint32_t my_units = (interval == n_intervals - 1) ? total_units - interval * dri_eff : dri_eff;
     const uint32_t first_unit = interval * dri_eff;
 
-    const uint32_t al = s.al;
+    // the scan descriptor, once
+    const uint32_t al = s.al, ah = s.ah, ss = s.ss, se = s.se, ncomp = s.scan_components, units_per_line = s.units_per_line;
+    ProgFrame fr;
+    fr.coef_off = s.coef_off;
+    fr.mcus_per_line = s.mcus_per_line;
+    fr.bpm = s.frame_bpm;
     uint32_t err = 0;
 
-    if (s.scan_components != 1 || s.ss == 0) {
-        // ---- DC scans (:92-138 interleaved, :148-168 single component), ReadBlockProgressiveDC (:227-253)
+    if (ncomp != 1) {
+        // ---- interleaved scans are DC scans (:92-138), ReadBlockProgressiveDC (:227-253)
+        ProgComp pc[kMaxScanComponents];
+        uint32_t dc_slot[kMaxScanComponents];
+#pragma unroll
+        for (uint32_t c = 0; c < kMaxScanComponents; c++) {
+            pc[c] = prog_comp(s, c < ncomp ? c : 0);
+            dc_slot[c] = s.comp[c < ncomp ? c : 0].dc_slot;
+        }
         int32_t pred[kMaxScanComponents] = {0, 0, 0, 0};
-        const bool interleaved = s.scan_components != 1;
+        uint32_t uy = first_unit / units_per_line, ux = first_unit - uy * units_per_line;
         for (uint32_t u = 0; u < my_units && err == 0; u++) {
-            const uint32_t unit = first_unit + u;
-            const uint32_t uy = unit / s.units_per_line, ux = unit - uy * s.units_per_line;
-            for (uint32_t c = 0; c < s.scan_components && err == 0; c++) {
-                const uint32_t h = interleaved ? s.comp[c].h : 1u, v = interleaved ? s.comp[c].v : 1u;
-                const LdsHuff hdc = lds_huff(tabs, s.comp[c].dc_slot);
-                for (uint32_t y = 0; y < v && err == 0; y++)
-                    for (uint32_t x = 0; x < h && err == 0; x++) {
-                        uint64_t index;
-                        const bool real = prog_block_index(s, c, ux * h + x, uy * v + y, index);
-                        if (s.ah == 0) {
+#pragma unroll
+            for (uint32_t c = 0; c < kMaxScanComponents; c++) {
+                if (c >= ncomp || err != 0) continue;
+                const ProgComp p = pc[c];
+                const LdsHuff hdc = lds_huff(tabs, dc_slot[c]);
+                for (uint32_t y = 0; y < p.v && err == 0; y++)
+                    for (uint32_t x = 0; x < p.h; x++) {
+                        uint64_t index = 0;
+                        const bool real = prog_block_index(fr, p, ux * p.h + x, uy * p.v + y, index);
+                        if (ah == 0) {
                             uint32_t sym;
                             int32_t value;
                             err = ub_symbol(r, hdc, true, closed_by_marker, sym, value);
@@ -1185,158 +1248,199 @@ __global__ __launch_bounds__(kProgThreads) void progressive_scan_kernel(const ui
                         }
                     }
             }
-        }
-    } else if (s.ah == 0) {
-        // ---- AC first pass (:255-311)
-        const LdsHuff hac = lds_huff(tabs, s.comp[0].ac_slot);
-        const uint32_t ss = s.ss, se = s.se;
-        uint32_t eobrun = 0;
-        for (uint32_t u = 0; u < my_units && err == 0; u++) {
-            if (eobrun != 0) {
-                eobrun--;
-                continue;
-            }
-            const uint32_t unit = first_unit + u;
-            const uint32_t by = unit / s.units_per_line, bx = unit - by * s.units_per_line;
-            uint64_t index = 0;
-            const bool real = prog_block_index(s, 0, bx, by, index);
-            int16_t *blk = coefs + index * 64;
-            for (uint32_t i = ss; i <= se; i++) {
-                uint32_t sym;
-                int32_t value;
-                err = ub_symbol(r, hac, false, closed_by_marker, sym, value);
-                if (err != 0) break;
-                const uint32_t rr = sym >> 4;
-                i += rr;
-                if ((sym & 15u) != 0) {
-                    if (real) blk[i < 63u ? i : 63u] = (int16_t)((uint32_t)value << al);
-                } else if (rr != 15u) {
-                    eobrun = 1u << rr;
-                    if (rr != 0) {
-                        uint32_t bits;
-                        if (!ub_try_read_bits(r, rr, bits)) {
-                            err = kDetailUnexpectedEnd;
-                            break;
-                        }
-                        eobrun += bits;
-                    }
-                    eobrun--;
-                    break;
-                }
+            if (++ux == units_per_line) {
+                ux = 0;
+                uy++;
             }
         }
     } else {
-        // ---- AC refinement (:313-419)
-        const LdsHuff hac = lds_huff(tabs, s.comp[0].ac_slot);
-        const uint32_t ss = s.ss, se = s.se;
-        const int16_t p1 = (int16_t)(1u << al), m1 = (int16_t)(0xFFFFFFFFu << al);
-        int16_t *lb = reinterpret_cast<int16_t *>(stage_all + tid * kProgBlockStride);
-        uint32_t eobrun = 0;
-        uint4 nb[8];  // the next block, prefetched
-        bool nb_real = false;
-        uint64_t nb_index = 0;
-        auto prefetch = [&](uint32_t u) {
-            nb_real = false;
-            if (u < my_units) {
-                const uint32_t unit = first_unit + u;
-                const uint32_t by = unit / s.units_per_line, bx = unit - by * s.units_per_line;
-                nb_real = prog_block_index(s, 0, bx, by, nb_index);
-            }
-            if (nb_real) {
-                const uint4 *src = reinterpret_cast<const uint4 *>(coefs + nb_index * 64);
-#pragma unroll
-                for (int i = 0; i < 8; i++) nb[i] = src[i];
-            } else {
-                const uint4 z = {0, 0, 0, 0};
-#pragma unroll
-                for (int i = 0; i < 8; i++) nb[i] = z;
-            }
-        };
-        prefetch(0);
-        for (uint32_t u = 0; u < my_units && err == 0; u++) {
-            const bool real = nb_real;
-            const uint64_t index = nb_index;
-            {
-                aliasing_u32 *w = reinterpret_cast<aliasing_u32 *>(lb);
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    w[i * 4 + 0] = nb[i].x;
-                    w[i * 4 + 1] = nb[i].y;
-                    w[i * 4 + 2] = nb[i].z;
-                    w[i * 4 + 3] = nb[i].w;
+        const ProgComp p = prog_comp(s, 0);
+        ProgWalk w;
+        prog_walk_init(w, p, first_unit, units_per_line);
+        if (ss == 0) {
+            // ---- DC scan of one component (:148-168)
+            const LdsHuff hdc = lds_huff(tabs, s.comp[0].dc_slot);
+            int32_t pred = 0;
+            for (uint32_t u = 0; u < my_units; u++, prog_walk_next(w, p, units_per_line)) {
+                uint64_t index = 0;
+                const bool real = prog_walk_index(fr, p, w, index);
+                if (ah == 0) {
+                    uint32_t sym;
+                    int32_t value;
+                    err = ub_symbol(r, hdc, true, closed_by_marker, sym, value);
+                    if (err != 0) break;
+                    pred += value;
+                    if (real) coefs[index * 64] = (int16_t)((uint32_t)pred << al);
+                } else {
+                    uint32_t bit;
+                    if (!ub_try_read_bits(r, 1, bit)) {
+                        err = kDetailUnexpectedEnd;
+                        break;
+                    }
+                    if (real && bit) atomicOr(reinterpret_cast<uint32_t *>(coefs + index * 64), (1u << al) & 0xFFFFu);
                 }
             }
-            prefetch(u + 1);
-
-            uint32_t k = ss;
-            if (eobrun == 0) {
-                for (; k <= se; k++) {
+        } else if (ah == 0) {
+            // ---- AC first pass (:255-311)
+            const LdsHuff hac = lds_huff(tabs, s.comp[0].ac_slot);
+            uint32_t eobrun = 0;
+            for (uint32_t u = 0; u < my_units && err == 0; u++, prog_walk_next(w, p, units_per_line)) {
+                if (eobrun != 0) {
+                    eobrun--;
+                    continue;
+                }
+                uint64_t index = 0;
+                const bool real = prog_walk_index(fr, p, w, index);
+                int16_t *blk = coefs + index * 64;
+                for (uint32_t i = ss; i <= se; i++) {
                     uint32_t sym;
-                    err = ub_huff(r, hac, sym);
+                    int32_t value;
+                    err = ub_symbol(r, hac, false, closed_by_marker, sym, value);
                     if (err != 0) break;
-                    int32_t rr = (int32_t)(sym >> 4);
-                    int16_t sval = 0;
-                    const bool nonzero = (sym & 15u) != 0;
-                    if (nonzero) {
-                        uint32_t bit;
-                        if (!ub_try_read_bits(r, 1, bit)) {
-                            err = kDetailUnexpectedEnd;
-                            break;
-                        }
-                        sval = bit ? p1 : m1;
-                    } else if (rr != 15) {
+                    const uint32_t rr = sym >> 4;
+                    i += rr;
+                    if ((sym & 15u) != 0) {
+                        if (real) blk[i < 63u ? i : 63u] = (int16_t)((uint32_t)value << al);
+                    } else if (rr != 15u) {
                         eobrun = 1u << rr;
                         if (rr != 0) {
                             uint32_t bits;
-                            if (!ub_try_read_bits(r, (uint32_t)rr, bits)) {
+                            if (!ub_try_read_bits(r, rr, bits)) {
                                 err = kDetailUnexpectedEnd;
                                 break;
                             }
                             eobrun += bits;
                         }
+                        eobrun--;
                         break;
                     }
-                    do {
-                        int16_t c = lb[k];
-                        if (c != 0) {
+                }
+            }
+        } else {
+            // ---- AC refinement (:313-419)
+            // The reference walks the band one coefficient at a time: a correction bit for every coefficient that is
+            // already non-zero, counting down the run over the ones that are still zero.  Which coefficients are non-zero
+            // is fixed when the block is staged, so the walk is done on a 64-bit mask: the stop position is the
+            // (r + 1)-th zero bit, the correction bits of the non-zero positions passed are read as one field.
+            const LdsHuff hac = lds_huff(tabs, s.comp[0].ac_slot);
+            const int16_t p1 = (int16_t)(1u << al), m1 = (int16_t)(0xFFFFFFFFu << al);
+            int16_t *lb = reinterpret_cast<int16_t *>(stage_all + tid * kProgBlockStride);
+            aliasing_u32 *lw = reinterpret_cast<aliasing_u32 *>(lb);
+            const uint64_t band = (se >= 63u ? ~0ull : ((1ull << (se + 1u)) - 1ull)) & ~((1ull << ss) - 1ull);
+            uint32_t eobrun = 0;
+            // the next block is loaded into registers while the current one is decoded in LDS
+            uint4 n0, n1, n2, n3, n4, n5, n6, n7;
+            bool nb_real = false;
+            uint64_t nb_index = 0;
+#define JPGPU_PREFETCH_BLOCK(have_)                                                         \
+    {                                                                                       \
+        nb_real = (have_) && prog_walk_index(fr, p, w, nb_index);                           \
+        const uint4 *src_ = reinterpret_cast<const uint4 *>(coefs + (nb_real ? nb_index : fr.coef_off) * 64); \
+        n0 = src_[0]; n1 = src_[1]; n2 = src_[2]; n3 = src_[3];                             \
+        n4 = src_[4]; n5 = src_[5]; n6 = src_[6]; n7 = src_[7];                             \
+    }
+            // correction bits of the non-zero coefficients in `m_` (ascending zig-zag order == stream order)
+#define JPGPU_CORRECT(m_, strict_)                                                                      \
+    {                                                                                                   \
+        uint64_t mm_ = (m_);                                                                            \
+        uint32_t left_ = (uint32_t)__builtin_popcountll(mm_);                                           \
+        while (left_ != 0 && err == 0) {                                                                \
+            const uint32_t n_ = left_ < 16u ? left_ : 16u;                                              \
+            uint32_t field_;                                                                            \
+            if (!ub_try_read_bits(r, n_, field_)) {                                                     \
+                err = kDetailUnexpectedEnd;                                                             \
+                break;                                                                                  \
+            }                                                                                           \
+            for (uint32_t i_ = 0; i_ < n_; i_++) {                                                      \
+                const uint32_t pos_ = (uint32_t)__builtin_ctzll(mm_);                                   \
+                mm_ &= mm_ - 1;                                                                         \
+                if ((field_ >> (n_ - 1u - i_)) & 1u) {                                                  \
+                    const int16_t c_ = lb[pos_];                                                        \
+                    if ((c_ & p1) == 0) {                                                               \
+                        const int16_t nc_ = (int16_t)(c_ + ((strict_ ? c_ > 0 : c_ >= 0) ? p1 : m1));   \
+                        lb[pos_] = nc_;                                                                 \
+                        if (real) gblk[pos_] = nc_;                                                     \
+                    }                                                                                   \
+                }                                                                                       \
+            }                                                                                           \
+            left_ -= n_;                                                                                \
+        }                                                                                               \
+    }
+            JPGPU_PREFETCH_BLOCK(my_units > 0)
+            for (uint32_t u = 0; u < my_units && err == 0; u++) {
+                const bool real = nb_real;
+                const uint64_t index = nb_index;
+                uint64_t nz = 0;  // bit k: coefficient k of the block is non-zero before this scan touches it
+#define JPGPU_STAGE(i_, v_)                                                                                           \
+    lw[(i_) * 4 + 0] = (v_).x; lw[(i_) * 4 + 1] = (v_).y; lw[(i_) * 4 + 2] = (v_).z; lw[(i_) * 4 + 3] = (v_).w;       \
+    {                                                                                                                 \
+        const uint32_t q_[4] = {(v_).x, (v_).y, (v_).z, (v_).w};                                                      \
+        uint32_t b_ = 0;                                                                                              \
+        for (int j_ = 0; j_ < 4; j_++) b_ |= (((q_[j_] & 0xFFFFu) != 0 ? 1u : 0u) | ((q_[j_] >> 16) != 0 ? 2u : 0u)) << (2 * j_); \
+        nz |= (uint64_t)b_ << (8 * (i_));                                                                             \
+    }
+                JPGPU_STAGE(0, n0) JPGPU_STAGE(1, n1) JPGPU_STAGE(2, n2) JPGPU_STAGE(3, n3)
+                JPGPU_STAGE(4, n4) JPGPU_STAGE(5, n5) JPGPU_STAGE(6, n6) JPGPU_STAGE(7, n7)
+#undef JPGPU_STAGE
+                prog_walk_next(w, p, units_per_line);
+                JPGPU_PREFETCH_BLOCK(u + 1 < my_units)
+
+                // every change is written through as a 2-byte store: scans of other bands / the DC refinement of the same
+                // blocks may run concurrently (host: ProgressiveFrame::add_scan levels)
+                int16_t *gblk = coefs + index * 64;
+                uint32_t k = ss;
+                if (eobrun == 0) {
+                    for (; k <= se; k++) {
+                        uint32_t sym;
+                        err = ub_huff(r, hac, sym);
+                        if (err != 0) break;
+                        const uint32_t rr = sym >> 4;
+                        int16_t sval = 0;
+                        const bool nonzero = (sym & 15u) != 0;
+                        if (nonzero) {
                             uint32_t bit;
                             if (!ub_try_read_bits(r, 1, bit)) {
                                 err = kDetailUnexpectedEnd;
                                 break;
                             }
-                            if (bit && (c & p1) == 0) lb[k] = (int16_t)(c + (c >= 0 ? p1 : m1));
-                        } else {
-                            if (--rr < 0) break;
-                        }
-                        k++;
-                    } while (k <= se);
-                    if (err != 0) break;
-                    if (nonzero && k < 64u) lb[k] = sval;
-                }
-            }
-            if (err == 0 && eobrun > 0) {
-                for (; k <= se; k++) {
-                    const int16_t c = lb[k];
-                    if (c != 0) {
-                        uint32_t bit;
-                        if (!ub_try_read_bits(r, 1, bit)) {
-                            err = kDetailUnexpectedEnd;
+                            sval = bit ? p1 : m1;
+                        } else if (rr != 15u) {
+                            eobrun = 1u << rr;
+                            if (rr != 0) {
+                                uint32_t bits;
+                                if (!ub_try_read_bits(r, rr, bits)) {
+                                    err = kDetailUnexpectedEnd;
+                                    break;
+                                }
+                                eobrun += bits;
+                            }
                             break;
                         }
-                        if (bit && (c & p1) == 0) lb[k] = (int16_t)(c + (c > 0 ? p1 : m1));
+                        // the do/while of :340-372: stop at the (r + 1)-th still-zero coefficient at or after k
+                        const uint64_t from_k = band & ~((1ull << k) - 1ull);
+                        uint64_t z = ~nz & from_k;
+                        for (uint32_t j = 0; j < rr && z != 0; j++) z &= z - 1;
+                        const uint32_t stop = z != 0 ? (uint32_t)__builtin_ctzll(z) : se + 1u;
+                        const uint64_t passed = nz & from_k & (stop >= 64u ? ~0ull : ((1ull << stop) - 1ull));
+                        JPGPU_CORRECT(passed, false)
+                        if (err != 0) break;
+                        k = stop;
+                        if (nonzero && k < 64u) {
+                            lb[k] = sval;
+                            if (real) gblk[k] = sval;
+                        }
                     }
                 }
-                eobrun--;
-            }
-            if (real) {
-                const aliasing_u32 *w = reinterpret_cast<const aliasing_u32 *>(lb);
-                uint4 *dst = reinterpret_cast<uint4 *>(coefs + index * 64);
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const uint4 v = {w[i * 4 + 0], w[i * 4 + 1], w[i * 4 + 2], w[i * 4 + 3]};
-                    dst[i] = v;
+                if (err == 0 && eobrun > 0) {
+                    if (k <= se) {
+                        const uint64_t rest = nz & band & ~((1ull << k) - 1ull);
+                        JPGPU_CORRECT(rest, true)
+                    }
+                    eobrun--;
                 }
             }
+#undef JPGPU_PREFETCH_BLOCK
+#undef JPGPU_CORRECT
         }
     }
 
