@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--images", type=int, default=0, help="images per GPU (default: the workload's batch size)")
     ap.add_argument("--workload", default="4k_dri4", choices=sorted(WORKLOADS))
-    ap.add_argument("--format", default="interleaved_u8", choices=["interleaved_u8", "planar_u8"])
+    ap.add_argument("--format", default="interleaved_u8", choices=["interleaved_u8", "planar_u8", "rgb_u8", "rgba_u8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gen-threads", type=int, default=0)
     args = ap.parse_args()
@@ -153,7 +153,7 @@ def main():
     width, height, ss, quality, dri, default_images = WORKLOADS[args.workload]
     kind = "progressive (SOF2, 10 scans)" if ss == "420p" else "baseline"
     n_images = args.images or default_images
-    fmt = jl.FMT_INTERLEAVED_U8 if args.format == "interleaved_u8" else jl.FMT_PLANAR_U8
+    fmt = {"interleaved_u8": jl.FMT_INTERLEAVED_U8, "planar_u8": jl.FMT_PLANAR_U8, "rgb_u8": jl.FMT_RGB_U8, "rgba_u8": jl.FMT_RGBA_U8}[args.format]
 
     # ---- synthetic input: distinct seed per image and per rank
     cpu = os.cpu_count() or 1
@@ -265,7 +265,11 @@ def main():
             if os.environ.get("JPGPU_BENCH_EXPERIMENT"):  # kernel-timing experiments with deliberately broken outputs
                 raise ImportError
             for i in sorted(set([0, n_images // 2, n_images - 1])):
-                ref, _ = po.decode_8bit(bytes(files[i])) if fmt == jl.FMT_INTERLEAVED_U8 else (None, None)
+                ref = None
+                if fmt in (jl.FMT_INTERLEAVED_U8, jl.FMT_RGB_U8, jl.FMT_RGBA_U8):
+                    ref, _ = po.decode_8bit(bytes(files[i]))
+                    if fmt != jl.FMT_INTERLEAVED_U8:
+                        ref = po.ycbcr8_to_rgb(ref, rgba=(fmt == jl.FMT_RGBA_U8))
                 if ref is not None and not np.array_equal(batch.output(i), ref):
                     raise RuntimeError(f"parity failure on image {i}")
             out["parity_spot_check"] = "bit-exact vs oracle"

@@ -63,7 +63,14 @@ typedef enum jpgpu_format {
     /* "O1": planar int16 at component-native resolution, planes padded to whole MCUs, UNCLAMPED level-shifted
      * samples == the blocks JpegBlockOutputWriter.WriteBlock receives before chroma expansion
      * (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:131-134) */
-    JPGPU_FMT_PLANAR_I16 = 2
+    JPGPU_FMT_PLANAR_I16 = 2,
+    /* interleaved 8-bit R,G,B and R,G,B,A (A = 255): the step every caller of the reference runs right after the
+     * decode, fused into the writer -- JpegYCbCrToRgbConverter.ConvertYCbCr8ToRgb24 / ConvertYCbCr8ToRgba32
+     * (ref: apps/JpegDecode/JpegYCbCrToRgbConverter.cs:134-206, tables :66-118) applied to the "O2" samples; callers:
+     * apps/JpegDecode/DecodeAction.cs:71-74, tests/JpegLibrary.Benchmarks/DecoderBenchmark.cs:67.  3-component frames;
+     * 1-component frames are converted with Cb = Cr = 128 like DecodeAction.cs:57-65 does.  8-bit precision only. */
+    JPGPU_FMT_RGB_U8 = 3,
+    JPGPU_FMT_RGBA_U8 = 4
 } jpgpu_format;
 
 typedef struct jpgpu_ctx jpgpu_ctx;

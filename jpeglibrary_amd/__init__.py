@@ -4,7 +4,7 @@ Importing the package loads the in-tree HIP library (libjpgpu.so); it raises if 
 There is no CPU fallback: creating a context without a GPU raises NoDeviceError.
 """
 from . import _capi  # noqa: F401  (loads libjpgpu.so, fails loudly when absent)
-from .batch import FMT_INTERLEAVED_U8, FMT_PLANAR_I16, FMT_PLANAR_U8, Batch, decode_batch
+from .batch import FMT_INTERLEAVED_U8, FMT_PLANAR_I16, FMT_PLANAR_U8, FMT_RGB_U8, FMT_RGBA_U8, Batch, decode_batch
 from .context import Context, default_context, device_count
 from .decoder import JpegBlockOutputWriter, JpegBufferOutputWriter8Bit, JpegDecoder, JpegExtendingOutputWriter
 from .errors import (ArgumentException, DeviceError, InvalidDataException, InvalidOperationException, JpegError,
@@ -12,7 +12,7 @@ from .errors import (ArgumentException, DeviceError, InvalidDataException, Inval
 
 __all__ = [
     "Batch", "decode_batch", "Context", "default_context", "device_count", "JpegDecoder", "JpegBlockOutputWriter",
-    "JpegBufferOutputWriter8Bit", "JpegExtendingOutputWriter", "FMT_INTERLEAVED_U8", "FMT_PLANAR_U8", "FMT_PLANAR_I16",
+    "JpegBufferOutputWriter8Bit", "JpegExtendingOutputWriter", "FMT_INTERLEAVED_U8", "FMT_PLANAR_U8", "FMT_PLANAR_I16", "FMT_RGB_U8", "FMT_RGBA_U8",
     "JpegError", "InvalidDataException", "InvalidOperationException", "NotSupportedException", "ArgumentException",
     "DeviceError", "NoDeviceError",
 ]

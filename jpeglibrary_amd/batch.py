@@ -14,6 +14,7 @@ from .errors import raise_for_status
 
 _lib = _capi.lib
 FMT_INTERLEAVED_U8, FMT_PLANAR_U8, FMT_PLANAR_I16 = _capi.FMT_INTERLEAVED_U8, _capi.FMT_PLANAR_U8, _capi.FMT_PLANAR_I16
+FMT_RGB_U8, FMT_RGBA_U8 = _capi.FMT_RGB_U8, _capi.FMT_RGBA_U8
 
 
 class Batch:
@@ -110,13 +111,16 @@ class Batch:
         return p, total.value
 
     def output(self, i):
-        """Downloads image i. INTERLEAVED_U8 -> uint8[H,W,C]; PLANAR_* -> list of per-component 2-D arrays (padded)."""
+        """Downloads image i. INTERLEAVED_U8 -> uint8[H,W,C]; RGB_U8 / RGBA_U8 -> uint8[H,W,3|4];
+        PLANAR_* -> list of per-component 2-D arrays (padded)."""
         info = self.image_info(i)
         raise_for_status(info.status, _lib.jpgpu_last_error(self.ctx._h))
         raw = np.empty(info.out_bytes, dtype=np.uint8)
         self._check(_lib.jpgpu_batch_download_output(self._h, i, raw.ctypes.data, raw.size))
         if self.format == FMT_INTERLEAVED_U8:
             return raw.reshape(info.height, info.width, info.num_components)
+        if self.format in (FMT_RGB_U8, FMT_RGBA_U8):
+            return raw.reshape(info.height, info.width, 4 if self.format == FMT_RGBA_U8 else 3)
         dt = np.int16 if self.format == FMT_PLANAR_I16 else np.uint8
         planes = []
         for c in range(info.num_components):

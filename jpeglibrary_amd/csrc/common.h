@@ -39,7 +39,16 @@ struct DevScanComponent {
     uint8_t dc_slot, ac_slot; // index into DevScan::huff_pool (LDS slot)
 };
 
-enum OutputFormat : int32_t { kFmtInterleavedU8 = 0, kFmtPlanarU8 = 1, kFmtPlanarI16 = 2 };
+enum OutputFormat : int32_t { kFmtInterleavedU8 = 0, kFmtPlanarU8 = 1, kFmtPlanarI16 = 2, kFmtRgbU8 = 3, kFmtRgbaU8 = 4 };
+constexpr bool fmt_is_interleaved(int f) { return f == kFmtInterleavedU8 || f == kFmtRgbU8 || f == kFmtRgbaU8; }
+constexpr int fmt_bytes_per_pixel_rgb(int f) { return f == kFmtRgbaU8 ? 4 : 3; }
+
+// Fixed-point factors of JpegYCbCrToRgbConverter.Init (ref: apps/JpegDecode/JpegYCbCrToRgbConverter.cs:66-118):
+// R = Y + (cr_r * Cr + half >> 16), B = Y + (cb_b * Cb + half >> 16), G = Y + (cb_g * Cb + half + cr_g * Cr >> 16)
+// with Cb, Cr = sample - 128 and the results clamped to [0, 255] (the reference's clamp table).
+struct YccRgbFactors {
+    int32_t cr_r, cr_g, cb_b, cb_g;
+};
 
 // One scan job.
 struct alignas(16) DevScan {

@@ -40,7 +40,7 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_prog_work_, &d_chunk_work_, &d_chunk_sums_, &d_tokens_, &d_blk_tok_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_prog_work_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_tokens_, &d_blk_tok_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
@@ -119,6 +119,13 @@ void DeviceBatch::plan_image_geometry(ImagePlan &img, const BaselineGeometry &ge
     img.mcus_per_column = (uint32_t)geo.mcus_per_column;
     if (format_ == JPGPU_FMT_INTERLEAVED_U8) {
         img.out_bytes = (uint64_t)img.width * img.height * img.num_components;
+    } else if (format_ == JPGPU_FMT_RGB_U8 || format_ == JPGPU_FMT_RGBA_U8) {
+        if (fh.num_components != 1 && fh.num_components != 3)  // apps/JpegDecode/DecodeAction.cs:29-33
+            throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "This color space is not supported", kDetailUnsupportedFrame);
+        if (fh.precision != 8)
+            throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "RGB output is defined for 8-bit precision only (the reference converter assumes 8-bit samples).",
+                              kDetailUnsupportedFrame);
+        img.out_bytes = (uint64_t)img.width * img.height * (format_ == JPGPU_FMT_RGBA_U8 ? 4 : 3);
     } else {
         const uint64_t sample_bytes = format_ == JPGPU_FMT_PLANAR_I16 ? 2 : 1;
         uint64_t off = 0;
@@ -136,7 +143,7 @@ void DeviceBatch::plan_image_geometry(ImagePlan &img, const BaselineGeometry &ge
 
 int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int n, int format) {
     if (n < 0 || (n > 0 && (!jpeg || !len))) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: null argument");
-    if (format < 0 || format > 2) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: unknown format");
+    if (format < 0 || format > 4) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: unknown format");
     format_ = format;
     images_.assign((size_t)n, ImagePlan());
     jobs_.clear();
@@ -185,7 +192,7 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
 }
 
 int DeviceBatch::upload_single_job(const ScanJob &job, int format, const void *initial_output, size_t initial_output_bytes) {
-    if (format < 0 || format > 2) return fail(JPGPU_ERR_ARGUMENT, "unknown format");
+    if (format < 0 || format > 4) return fail(JPGPU_ERR_ARGUMENT, "unknown format");
     format_ = format;
     images_.assign(1, ImagePlan());
     jobs_.assign(1, job);
@@ -210,7 +217,7 @@ int DeviceBatch::upload_single_job(const ScanJob &job, int format, const void *i
 }
 
 int DeviceBatch::upload_progressive_frame(const ProgressiveFrame &frame, const uint8_t *file, size_t file_len, int sof, int format) {
-    if (format < 0 || format > 2) return fail(JPGPU_ERR_ARGUMENT, "unknown format");
+    if (format < 0 || format > 4) return fail(JPGPU_ERR_ARGUMENT, "unknown format");
     format_ = format;
     images_.assign(1, ImagePlan());
     jobs_.clear();
@@ -235,7 +242,7 @@ int DeviceBatch::upload_progressive_frame(const ProgressiveFrame &frame, const u
 
 int DeviceBatch::upload_frames(const jpgpu_frame *frames, const uint16_t *qt, int n, int format) {
     if (n < 0 || (n > 0 && (!frames || !qt))) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_frames: null argument");
-    if (format < 0 || format > 2) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_frames: unknown format");
+    if (format < 0 || format > 4) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_frames: unknown format");
     format_ = format;
     images_.assign((size_t)n, ImagePlan());
     jobs_.clear();
@@ -320,6 +327,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     std::vector<HuffWork> sub_work;
     std::vector<std::vector<HuffWork>> prog_work_by_ordinal;
     prog_clear_.clear();
+    rgb_convert_.clear();
     sub_scan_ids_.clear();
     total_subs_ = 0;
     max_subs_per_scan_ = 0;
@@ -458,7 +466,13 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 for (uint32_t first = 0; first < s.n_intervals; first += kHuffIntervalsPerWg) huff_work.push_back({(uint32_t)j, first});
             }
             const uint32_t mcus_per_wg = (uint32_t)kIdctBlocksPerWg / s.blocks_per_mcu;
-            const int cls = format_ == JPGPU_FMT_INTERLEAVED_U8 ? idct_layout_class(s) : 0;
+            const int cls = fmt_is_interleaved(format_) ? idct_layout_class(s) : 0;
+            if (cls == 0 && (format_ == JPGPU_FMT_RGB_U8 || format_ == JPGPU_FMT_RGBA_U8)) {
+                // no fused conversion for this layout: samples go to the scratch image, then ycc_to_rgb_kernel
+                bool listed = false;
+                for (const RgbConvert &rc : rgb_convert_) listed |= rc.image == (uint32_t)ii;
+                if (!listed) rgb_convert_.push_back({(uint32_t)ii, img.out_offset, (uint64_t)img.width * img.height, img.num_components});
+            }
             const uint32_t run = mcus_per_wg * (uint32_t)kIdctTilesPerWg;
             for (uint32_t first = 0; first < s.total_mcus; first += run)
                 idct_work_by_class[cls].push_back({(uint32_t)j, first, std::min(run, s.total_mcus - first)});
@@ -524,6 +538,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_unstuffed_, nullptr, 0, (size_t)input_bytes_},
         {&d_coefs_, nullptr, 0, (size_t)total_blocks_ * 128 + (size_t)kIdctBlocksPerWg * 128 + 256},  // + one tile of slack (IDCT DMA reads whole tiles)
         {&d_out_, nullptr, 0, (size_t)out_bytes_ + 256},
+        {&d_rgb_scratch_, nullptr, 0, rgb_convert_.empty() ? 0 : (size_t)out_bytes_ + 256},
         {&d_input_, nullptr, 0, (size_t)input_bytes_},
     };
     for (const Up &u : ups) {
@@ -620,10 +635,17 @@ int DeviceBatch::run_progressive() {
     return JPGPU_OK;
 }
 int DeviceBatch::run_idct() {
+    const YccRgbFactors kf = ycc_rgb_factors();
     hipError_t e = launch_idct(ctx_->stream, (const int16_t *)d_coefs_.ptr, (const DevScan *)d_scans_.ptr, (const IdctWork *)d_idct_work_.ptr,
                                idct_class_begin_, (const DevScanStatus *)d_status_.ptr, (const DevQuantTable *)d_quant_pool_.ptr,
-                               (uint8_t *)d_out_.ptr, format_);
-    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "idct_output_kernel");
+                               (uint8_t *)d_out_.ptr, format_, kf, (uint8_t *)d_rgb_scratch_.ptr);
+    if (e != hipSuccess) return hip_fail(e, "idct_output_kernel");
+    for (const RgbConvert &rc : rgb_convert_) {
+        e = launch_ycc_to_rgb(ctx_->stream, (const uint8_t *)d_rgb_scratch_.ptr + rc.out_offset, (uint8_t *)d_out_.ptr + rc.out_offset, rc.pixels,
+                              rc.components, format_ == JPGPU_FMT_RGBA_U8 ? 4 : 3, kf);
+        if (e != hipSuccess) return hip_fail(e, "ycc_to_rgb_kernel");
+    }
+    return JPGPU_OK;
 }
 
 // The token buffer is sized from the compressed bytes (kTokensPerByte slots of 4 B per input byte) and only allocated
@@ -672,7 +694,8 @@ int DeviceBatch::decode() {
     (void)hipEventRecord(ev[0], ctx_->stream);
     if ((rc = run_marker_index()) != JPGPU_OK) return rc;
     (void)hipEventRecord(ev[1], ctx_->stream);
-    const bool tokens = use_tokens_ && n_sub_work_ == 0;  // DRI = 0 scans only have the coefficient path
+    // DRI = 0 scans, progressive frames and the RGB formats only have the coefficient path
+    const bool tokens = use_tokens_ && n_sub_work_ == 0 && prog_begin_.size() <= 1 && format_ <= JPGPU_FMT_PLANAR_I16;
     if ((rc = tokens ? run_huffman_tokens() : run_huffman()) != JPGPU_OK) return rc;
     (void)hipEventRecord(ev[2], ctx_->stream);
     if ((rc = tokens ? run_idct_tokens() : run_idct()) != JPGPU_OK) return rc;

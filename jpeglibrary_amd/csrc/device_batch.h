@@ -124,6 +124,14 @@ class DeviceBatch {
     DevBuffer d_prog_work_;
     std::vector<int> prog_begin_;
     std::vector<std::pair<uint64_t, uint64_t>> prog_clear_;  // (first block, blocks) of every progressive frame's store
+    // RGB / RGBA output for layouts without a fused conversion: INTERLEAVED_U8 samples in a scratch image first
+    struct RgbConvert {
+        uint32_t image;
+        uint64_t out_offset, pixels;
+        int components;
+    };
+    std::vector<RgbConvert> rgb_convert_;
+    DevBuffer d_rgb_scratch_;
     DevBuffer d_chunk_work_, d_chunk_sums_;
     int n_chunk_work_ = 0;
     DevBuffer d_unstuffed_, d_ends_u_;  // K1 output: entropy data as the bit reader sees it + interval ends in it

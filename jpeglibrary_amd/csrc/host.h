@@ -250,6 +250,10 @@ class ProgressiveFrame {
     std::vector<ScanJob> scans_;
 };
 
+// Fixed-point factors of the reference's YCbCr -> RGB tables, derived the way JpegYCbCrToRgbConverter's constructor and
+// Init derive them (ref: apps/JpegDecode/JpegYCbCrToRgbConverter.cs:24-48, :87-99, Fix :121-124): float32 arithmetic.
+YccRgbFactors ycc_rgb_factors();
+
 // Scans forward over entropy-coded data to the next marker that is not RSTn, the way the reference's readers end up
 // (ref: JpegReader.cs:120-158 + ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:167-176).
 // Returns the offset of the marker's FF byte, or len when the data runs out.

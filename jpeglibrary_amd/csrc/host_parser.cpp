@@ -841,6 +841,21 @@ ScanJob ProgressiveFrame::make_frame_job() const {
     return job;
 }
 
+YccRgbFactors ycc_rgb_factors() {
+    auto fix = [](float x) { return (int32_t)((double)(x * (float)(1L << 16)) + 0.5); };  // Fix (:121-124)
+    const float luma_red = 299 / 1000.0f, luma_green = 587 / 1000.0f, luma_blue = 114 / 1000.0f;  // :34-37
+    const float f1 = 2 - 2 * luma_red;
+    const float f2 = luma_red * f1 / luma_green;
+    const float f3 = 2 - 2 * luma_blue;
+    const float f4 = luma_blue * f3 / luma_green;
+    YccRgbFactors k;
+    k.cr_r = fix(f1);    // D1
+    k.cr_g = -fix(f2);   // D2
+    k.cb_b = fix(f3);    // D3
+    k.cb_g = -fix(f4);   // D4
+    return k;
+}
+
 size_t find_scan_end(const uint8_t *data, size_t len) {
     size_t pos = 0;
     while (pos + 1 < len) {

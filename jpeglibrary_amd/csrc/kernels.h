@@ -25,9 +25,12 @@ constexpr int kNumIdctLayoutClasses = 5;
 // Output layout class of a scan for INTERLEAVED_U8 (0 = generic bytewise path, else a specialised kernel).
 int idct_layout_class(const DevScan &s);
 // work is sorted by layout class; class_begin[c]..class_begin[c+1] are the workgroups of class c.
+// RGB / RGBA formats: classes with a fused conversion write `out`; the generic class writes INTERLEAVED_U8 samples into
+// `generic_out` (same offsets), to be converted by launch_ycc_to_rgb.
 hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *scans, const IdctWork *work,
                        const int class_begin[kNumIdctLayoutClasses + 1], const DevScanStatus *status,
-                       const DevQuantTable *quant_pool, uint8_t *out, int format);
+                       const DevQuantTable *quant_pool, uint8_t *out, int format, const YccRgbFactors &kf, uint8_t *generic_out);
+hipError_t launch_ycc_to_rgb(hipStream_t stream, const uint8_t *src, uint8_t *dst, uint64_t n_pixels, int comps, int bpp, const YccRgbFactors &kf);
 
 // DRI = 0 scans (K2S): self-synchronising subsequence decode into the (zeroed) coefficient buffer; synchronises the stream.
 constexpr uint32_t kSubseqBits = 1024;

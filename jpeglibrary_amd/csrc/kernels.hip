@@ -1851,12 +1851,84 @@ constexpr uint32_t kPxRowStride = kIdctThreads * 8;  // bytes between sample row
 // Output layout classes of the INTERLEAVED_U8 format (chosen per scan on the host, see idct_layout_class()).
 enum IdctLayout : int { kLayGeneric = 0, kLayYccH1V1 = 1, kLayYccH2V1 = 2, kLayYccH2V2 = 3, kLayGray = 4, kNumIdctLayouts = 5 };
 
+// ---- YCbCr -> RGB(A) (ref: apps/JpegDecode/JpegYCbCrToRgbConverter.cs:134-206).  The reference looks the terms up in
+// tables built by Init (:66-118); with ReferenceBlackWhite = {0,255,128,255,128,255} the tables are exactly
+//   yTable[i] = i, crRTable[i] = (cr_r * (i-128) + half) >> 16, cbBTable[i] = (cb_b * (i-128) + half) >> 16,
+//   crGTable[i] = cr_g * (i-128), cbGTable[i] = cb_g * (i-128) + half,  and the clamp table is a clamp to [0, 255],
+// so the terms are computed instead of fetched (the factors come from the host, derived like Init derives them).
+struct ChromaTerms {
+    int32_t r, g, b;
+};
+__device__ __forceinline__ ChromaTerms chroma_terms(uint32_t cb_sample, uint32_t cr_sample, const YccRgbFactors &k) {
+    const int32_t cb = (int32_t)cb_sample - 128, cr = (int32_t)cr_sample - 128;
+    ChromaTerms t;
+    t.r = (k.cr_r * cr + 32768) >> 16;
+    t.b = (k.cb_b * cb + 32768) >> 16;
+    t.g = (k.cb_g * cb + 32768 + k.cr_g * cr) >> 16;
+    return t;
+}
+__device__ __forceinline__ uint32_t clamp_u8_i32(int32_t v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+// one pixel: R | G << 8 | B << 16
+__device__ __forceinline__ uint32_t rgb_pixel(uint32_t y, const ChromaTerms &t) {
+    return clamp_u8_i32((int32_t)y + t.r) | (clamp_u8_i32((int32_t)y + t.g) << 8) | (clamp_u8_i32((int32_t)y + t.b) << 16);
+}
+__device__ __forceinline__ uint32_t byte_of(uint32_t lo, uint32_t hi, int i) { return ((i < 4 ? lo : hi) >> (8 * (i & 3))) & 0xFFu; }
+// N pixels (R | G << 8 | B << 16 each) -> interleaved bytes at dst (16-byte aligned for N = 16, 8-byte aligned for N = 8)
+template <int N, int BPP>
+__device__ __forceinline__ void store_rgb_pixels(uint8_t *dst, const uint32_t (&p)[N]) {
+    if (BPP == 4) {
+#pragma unroll
+        for (int i = 0; i < N; i += 4) {
+            const uint4 v = {p[i] | 0xFF000000u, p[i + 1] | 0xFF000000u, p[i + 2] | 0xFF000000u, p[i + 3] | 0xFF000000u};
+            *reinterpret_cast<uint4 *>(dst + i * 4) = v;
+        }
+    } else {
+        uint32_t w[N * 3 / 4];
+#pragma unroll
+        for (int i = 0; i < N; i += 4) {  // four pixels -> three dwords
+            w[i * 3 / 4 + 0] = p[i] | (p[i + 1] << 24);
+            w[i * 3 / 4 + 1] = (p[i + 1] >> 8) | (p[i + 2] << 16);
+            w[i * 3 / 4 + 2] = (p[i + 2] >> 16) | (p[i + 3] << 8);
+        }
+        if (N == 16) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const uint4 v = {w[i * 4], w[i * 4 + 1], w[i * 4 + 2], w[i * 4 + 3]};
+                *reinterpret_cast<uint4 *>(dst + i * 16) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < N * 3 / 8; i++) {
+                const uint2 v = {w[i * 2], w[i * 2 + 1]};
+                *reinterpret_cast<uint2 *>(dst + i * 8) = v;
+            }
+        }
+    }
+}
+
+// Stand-alone conversion of an interleaved u8 image (C = 3: Y,Cb,Cr; C = 1: Y with Cb = Cr = 128 like
+// apps/JpegDecode/DecodeAction.cs:57-65) for the layouts the writer kernel has no fused path for.
+__global__ __launch_bounds__(256) void ycc_to_rgb_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint64_t n_pixels, int comps,
+                                                         int bpp, YccRgbFactors k) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_pixels; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t y = src[i * comps];
+        const uint32_t cb = comps == 3 ? src[i * 3 + 1] : 128u, cr = comps == 3 ? src[i * 3 + 2] : 128u;
+        const uint32_t px = rgb_pixel(y, chroma_terms(cb, cr, k));
+        uint8_t *d = dst + i * bpp;
+        d[0] = (uint8_t)px;
+        d[1] = (uint8_t)(px >> 8);
+        d[2] = (uint8_t)(px >> 16);
+        if (bpp == 4) d[3] = 255;
+    }
+}
+
 // Output assembly of the INTERLEAVED_U8 format from the LDS sample tile [8 rows][256 blocks][8 B] (phase C).
 // Shared by the coefficient pipeline (K3) and the token pipeline (K3T).
-template <int LAY>
+// CONV: 0 = the samples as they are (Y,Cb,Cr), 3 / 4 = converted to R,G,B / R,G,B,A bytes (fast layouts only).
+template <int LAY, int CONV>
 __device__ __forceinline__ void interleaved_output_from_tile(const uint8_t *sh_px, const DevScan &s, uint32_t tile_first, uint32_t n_mcu,
                                                              uint32_t tid, bool have_block, const DevScanComponent &comp, uint32_t mcu_x,
-                                                             uint32_t mcu_y, uint32_t b, uint8_t *out) {
+                                                             uint32_t mcu_y, uint32_t b, uint8_t *out, const YccRgbFactors &kf) {
     const uint32_t W = s.width, H = s.height, C = s.frame_components;
     uint8_t *img = out + s.out_off;
 
@@ -1896,7 +1968,26 @@ __device__ __forceinline__ void interleaved_output_from_tile(const uint8_t *sh_p
         if (y >= H) continue;
         const uint8_t *yrow = sh_px + (row & 7) * kPxRowStride + (m * kbpm + (row >> 3) * max_h) * 8;
         const uint8_t *crow = sh_px + (row >> vshift) * kPxRowStride + (m * kbpm + max_h * max_v) * 8;
-        if (max_h == 2) {
+        if (max_h == 2 && CONV != 0) {
+            const uint4 yv = *reinterpret_cast<const uint4 *>(yrow);  // 16 luma samples (two adjacent blocks)
+            const uint4 cv = *reinterpret_cast<const uint4 *>(crow);  // 8 Cb (x,y) + 8 Cr (z,w)
+            uint32_t px[16];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {  // one chroma sample pair covers two pixels
+                const ChromaTerms t = chroma_terms(byte_of(cv.x, cv.y, j), byte_of(cv.z, cv.w, j), kf);
+                px[2 * j] = rgb_pixel(byte_of(j < 4 ? yv.x : yv.z, j < 4 ? yv.y : yv.w, (2 * j) & 7), t);
+                px[2 * j + 1] = rgb_pixel(byte_of(j < 4 ? yv.x : yv.z, j < 4 ? yv.y : yv.w, (2 * j + 1) & 7), t);
+            }
+            store_rgb_pixels<16, (CONV == 4 ? 4 : 3)>(img + ((size_t)y * W + gx * 16) * (CONV == 4 ? 4 : 3), px);
+        } else if (CONV != 0) {
+            const uint2 yv = *reinterpret_cast<const uint2 *>(yrow);
+            const uint2 bv = *reinterpret_cast<const uint2 *>(crow);
+            const uint2 rv = *reinterpret_cast<const uint2 *>(crow + 8);
+            uint32_t px[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) px[j] = rgb_pixel(byte_of(yv.x, yv.y, j), chroma_terms(byte_of(bv.x, bv.y, j), byte_of(rv.x, rv.y, j), kf));
+            store_rgb_pixels<8, (CONV == 4 ? 4 : 3)>(img + ((size_t)y * W + gx * 8) * (CONV == 4 ? 4 : 3), px);
+        } else if (max_h == 2) {
             const uint4 yv = *reinterpret_cast<const uint4 *>(yrow);  // 16 luma samples (two adjacent blocks)
             const uint4 cv = *reinterpret_cast<const uint4 *>(crow);  // 8 Cb (x,y) + 8 Cr (z,w)
             const uint32_t cc0 = pick4(cv.x, cv.z, JPGPU_SEL(0, 4, 1, 5)), cc1 = pick4(cv.x, cv.z, JPGPU_SEL(2, 6, 3, 7));
@@ -1958,7 +2049,8 @@ typedef const __attribute__((address_space(1))) void jpgpu_gbl_void;
 template <int FMT, int LAY>
 __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void idct_output_kernel(
     const int16_t *__restrict__ coefs, const DevScan *__restrict__ scans, const IdctWork *__restrict__ work,
-    const DevScanStatus *__restrict__ status, const DevQuantTable *__restrict__ quant_pool, uint8_t *__restrict__ out) {
+    const DevScanStatus *__restrict__ status, const DevQuantTable *__restrict__ quant_pool, uint8_t *__restrict__ out, YccRgbFactors kf) {
+    constexpr int CONV = FMT == kFmtRgbU8 ? 3 : (FMT == kFmtRgbaU8 ? 4 : 0);  // fused YCbCr -> RGB(A), fast layouts and gray only
     __shared__ __attribute__((aligned(16))) uint8_t sh_all[kIdctThreads * 128 + kIdctThreads * 64 + kMaxScanComponents * 128];
     uint8_t *sh = sh_all;
     uint8_t *sh_px = sh_all + kIdctThreads * 128;
@@ -2049,7 +2141,20 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
         rows[r].y = pack4_u8(px[r * 4 + 2], px[r * 4 + 3]);
     }
 
-    if (FMT == kFmtPlanarU8 || (FMT == kFmtInterleavedU8 && LAY == kLayGray)) {
+    if (CONV != 0 && LAY == kLayGray) {
+        // a single-component image as R = G = B = Y (Cb = Cr = 128 contribute nothing, DecodeAction.cs:57-65)
+        if (have_block) {
+            const uint32_t x0 = (mcu_x * comp.h + s.blk_x[b]) * 8, y0 = (mcu_y * comp.v + s.blk_y[b]) * 8;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                if (y0 + r >= s.height) continue;
+                uint32_t px[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) px[j] = byte_of(rows[r].x, rows[r].y, j) * 0x010101u;
+                store_rgb_pixels<8, (CONV == 4 ? 4 : 3)>(out + s.out_off + ((size_t)(y0 + r) * s.width + x0) * (CONV == 4 ? 4 : 3), px);
+            }
+        }
+    } else if (FMT == kFmtPlanarU8 || (FMT == kFmtInterleavedU8 && LAY == kLayGray)) {
         // planar u8 (planes padded to whole MCUs), or a single-component interleaved image (same addressing,
         // pitch = W, clipped at the bottom; the host only picks kLayGray when W is a multiple of 8)
         if (have_block) {
@@ -2074,7 +2179,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
     __builtin_amdgcn_s_barrier();
     synced = true;
 
-    interleaved_output_from_tile<LAY>(sh_px, s, tile_first, n_mcu, tid, have_block, comp, mcu_x, mcu_y, b, out);
+    interleaved_output_from_tile<LAY, CONV>(sh_px, s, tile_first, n_mcu, tid, have_block, comp, mcu_x, mcu_y, b, out, kf);
     }  // interleaved
     }  // u8 formats
 
@@ -2203,7 +2308,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
             for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(sh_px + r * kPxRowStride + tid * 8) = rows[r];
         }
         __syncthreads();
-        interleaved_output_from_tile<LAY>(sh_px, s, tile_first, n_mcu, tid, have_block, comp, mcu_x, mcu_y, b, out);
+        interleaved_output_from_tile<LAY, 0>(sh_px, s, tile_first, n_mcu, tid, have_block, comp, mcu_x, mcu_y, b, out, YccRgbFactors{0, 0, 0, 0});
         __syncthreads();  // the tile is rewritten by the next iteration
     }
 }
@@ -2254,15 +2359,16 @@ hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan
 
 template <int FMT, int LAY>
 static void launch_idct_one(hipStream_t stream, const int16_t *coefs, const DevScan *scans, const IdctWork *work, int n_work,
-                            const DevScanStatus *status, const DevQuantTable *quant_pool, uint8_t *out) {
+                            const DevScanStatus *status, const DevQuantTable *quant_pool, uint8_t *out,
+                            YccRgbFactors kf = YccRgbFactors{0, 0, 0, 0}) {
     hipLaunchKernelGGL((idct_output_kernel<FMT, LAY>), dim3(n_work), dim3(kIdctThreads), 0, stream, coefs, scans, work, status,
-                       quant_pool, out);
+                       quant_pool, out, kf);
 }
 
 // work is sorted by layout class; class_begin[c]..class_begin[c+1] are the workgroups of class c.
 hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *scans, const IdctWork *work,
                        const int class_begin[kNumIdctLayoutClasses + 1], const DevScanStatus *status,
-                       const DevQuantTable *quant_pool, uint8_t *out, int format) {
+                       const DevQuantTable *quant_pool, uint8_t *out, int format, const YccRgbFactors &kf, uint8_t *generic_out) {
     for (int c = 0; c < kNumIdctLayoutClasses; c++) {
         const int n = class_begin[c + 1] - class_begin[c];
         if (n <= 0) continue;
@@ -2271,6 +2377,23 @@ hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *
             launch_idct_one<kFmtPlanarI16, kLayGeneric>(stream, coefs, scans, w, n, status, quant_pool, out);
         } else if (format == kFmtPlanarU8) {
             launch_idct_one<kFmtPlanarU8, kLayGeneric>(stream, coefs, scans, w, n, status, quant_pool, out);
+        } else if (format == kFmtRgbU8) {
+            switch (c) {
+            case kLayYccH1V1: launch_idct_one<kFmtRgbU8, kLayYccH1V1>(stream, coefs, scans, w, n, status, quant_pool, out, kf); break;
+            case kLayYccH2V1: launch_idct_one<kFmtRgbU8, kLayYccH2V1>(stream, coefs, scans, w, n, status, quant_pool, out, kf); break;
+            case kLayYccH2V2: launch_idct_one<kFmtRgbU8, kLayYccH2V2>(stream, coefs, scans, w, n, status, quant_pool, out, kf); break;
+            case kLayGray: launch_idct_one<kFmtRgbU8, kLayGray>(stream, coefs, scans, w, n, status, quant_pool, out, kf); break;
+            // no fused path: the samples go to `generic_out` as INTERLEAVED_U8 and are converted by launch_ycc_to_rgb
+            default: launch_idct_one<kFmtInterleavedU8, kLayGeneric>(stream, coefs, scans, w, n, status, quant_pool, generic_out); break;
+            }
+        } else if (format == kFmtRgbaU8) {
+            switch (c) {
+            case kLayYccH1V1: launch_idct_one<kFmtRgbaU8, kLayYccH1V1>(stream, coefs, scans, w, n, status, quant_pool, out, kf); break;
+            case kLayYccH2V1: launch_idct_one<kFmtRgbaU8, kLayYccH2V1>(stream, coefs, scans, w, n, status, quant_pool, out, kf); break;
+            case kLayYccH2V2: launch_idct_one<kFmtRgbaU8, kLayYccH2V2>(stream, coefs, scans, w, n, status, quant_pool, out, kf); break;
+            case kLayGray: launch_idct_one<kFmtRgbaU8, kLayGray>(stream, coefs, scans, w, n, status, quant_pool, out, kf); break;
+            default: launch_idct_one<kFmtInterleavedU8, kLayGeneric>(stream, coefs, scans, w, n, status, quant_pool, generic_out); break;
+            }
         } else {
             switch (c) {
             case kLayYccH1V1: launch_idct_one<kFmtInterleavedU8, kLayYccH1V1>(stream, coefs, scans, w, n, status, quant_pool, out); break;
@@ -2284,6 +2407,15 @@ hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+// INTERLEAVED_U8 image (comps = 1 or 3) -> RGB / RGBA, for the layouts without a fused path
+hipError_t launch_ycc_to_rgb(hipStream_t stream, const uint8_t *src, uint8_t *dst, uint64_t n_pixels, int comps, int bpp, const YccRgbFactors &kf) {
+    if (n_pixels == 0) return hipSuccess;
+    const uint64_t want = (n_pixels + 255) / 256;
+    const int grid = (int)(want < 65536 ? want : 65536);
+    hipLaunchKernelGGL(ycc_to_rgb_kernel, dim3(grid), dim3(256), 0, stream, src, dst, n_pixels, comps, bpp, kf);
+    return hipGetLastError();
 }
 
 // One ordinal of progressive scans (all frames of the batch advance together).

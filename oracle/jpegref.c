@@ -1685,3 +1685,68 @@ int jref_decode_to_16bit(const uint8_t *data, size_t len, int component_count, u
     jref_destroy(d);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * YCbCr -> RGB(A), the step the reference's callers run right after the decode
+ * (ref: apps/JpegDecode/JpegYCbCrToRgbConverter.cs; callers apps/JpegDecode/DecodeAction.cs:71-74,
+ * tests/JpegLibrary.Benchmarks/DecoderBenchmark.cs:67).  Table-driven, restated literally.
+ * ---------------------------------------------------------------------------------------------- */
+
+#define YCC_SHIFT 16
+#define YCC_ONE_HALF (1 << (YCC_SHIFT - 1))
+#define YCC_CLAMP_OFFSET 256
+
+static uint8_t ycc_clamp[4 * 256];
+static int32_t ycc_cr_r[256], ycc_cb_b[256], ycc_cr_g[256], ycc_cb_g[256], ycc_y[256];
+static int ycc_ready = 0;
+
+/* ref: :121-124 */
+static int ycc_fix(float x) { return (int)((double)(x * (float)(1L << YCC_SHIFT)) + 0.5); }
+
+/* ref: :126-129 */
+static int ycc_code2v(int c, float rb, float rw, float cr) {
+    return (int)((((float)(c - (int)rb)) * cr) / ((int)(rw - rb) != 0 ? (rw - rb) : 1.0f));
+}
+
+/* ref: :66-118 (constructor :24-48) */
+static void ycc_init(void) {
+    float luma[3] = {299 / 1000.0f, 587 / 1000.0f, 114 / 1000.0f};
+    float rbw[6] = {0.0f, 255.0f, 128.0f, 255.0f, 128.0f, 255.0f};
+    memset(ycc_clamp, 0, sizeof ycc_clamp);
+    for (int i = 0; i < 256; i++) ycc_clamp[YCC_CLAMP_OFFSET + i] = (uint8_t)i;
+    for (int i = YCC_CLAMP_OFFSET + 256; i < YCC_CLAMP_OFFSET + 256 + 2 * 256; i++) ycc_clamp[i] = 255;
+    float luma_red = luma[0], luma_green = luma[1], luma_blue = luma[2];
+    float f1 = 2 - 2 * luma_red;
+    int d1 = ycc_fix(f1);
+    float f2 = luma_red * f1 / luma_green;
+    int d2 = -ycc_fix(f2);
+    float f3 = 2 - 2 * luma_blue;
+    int d3 = ycc_fix(f3);
+    float f4 = luma_blue * f3 / luma_green;
+    int d4 = -ycc_fix(f4);
+    for (int i = 0, x = -128; i < 256; i++, x++) {
+        int cr = ycc_code2v(x, rbw[4] - 128.0f, rbw[5] - 128.0f, 127);
+        int cb = ycc_code2v(x, rbw[2] - 128.0f, rbw[3] - 128.0f, 127);
+        ycc_cr_r[i] = (d1 * cr + YCC_ONE_HALF) >> YCC_SHIFT;
+        ycc_cb_b[i] = (d3 * cb + YCC_ONE_HALF) >> YCC_SHIFT;
+        ycc_cr_g[i] = d2 * cr;
+        ycc_cb_g[i] = d4 * cb + YCC_ONE_HALF;
+        ycc_y[i] = ycc_code2v(x + 128, rbw[0], rbw[1], 255);
+    }
+    ycc_ready = 1;
+}
+
+/* ConvertYCbCr8ToRgb24 (:171-206) when bytes_per_pixel == 3, ConvertYCbCr8ToRgba32 (:134-169) when 4 */
+void jref_ycbcr8_to_rgb(const uint8_t *ycbcr, uint8_t *out, size_t count, int bytes_per_pixel) {
+    if (!ycc_ready) ycc_init();
+    for (size_t i = 0; i < count; i++) {
+        uint8_t y = ycbcr[0], cb = ycbcr[1], cr = ycbcr[2];
+        int yv = ycc_y[y];
+        out[0] = ycc_clamp[YCC_CLAMP_OFFSET + yv + ycc_cr_r[cr]];
+        out[1] = ycc_clamp[YCC_CLAMP_OFFSET + yv + ((ycc_cb_g[cb] + ycc_cr_g[cr]) >> YCC_SHIFT)];
+        out[2] = ycc_clamp[YCC_CLAMP_OFFSET + yv + ycc_cb_b[cb]];
+        if (bytes_per_pixel == 4) out[3] = 255;
+        ycbcr += 3;
+        out += bytes_per_pixel;
+    }
+}

@@ -124,4 +124,7 @@ int jref_build_huffman(const uint8_t bits[16], const uint8_t *values, int nvalue
 #ifdef __cplusplus
 }
 #endif
+/* JpegYCbCrToRgbConverter.ConvertYCbCr8ToRgb24 / ConvertYCbCr8ToRgba32 (ref: apps/JpegDecode/JpegYCbCrToRgbConverter.cs:134-206) */
+void jref_ycbcr8_to_rgb(const uint8_t *ycbcr, uint8_t *out, size_t count, int bytes_per_pixel);
+
 #endif

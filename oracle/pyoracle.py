@@ -203,6 +203,23 @@ def decode_progressive_store(data: bytes):
         L.jref_destroy(d)
 
 
+def ycbcr8_to_rgb(ycbcr: np.ndarray, rgba: bool = False, gray: bool = False) -> np.ndarray:
+    """The reference callers' colour step on an interleaved YCbCr8 image (H, W, 3) -- or (H, W, 1) with gray=True, which
+    is first widened with Cb = Cr = 128 like apps/JpegDecode/DecodeAction.cs:57-65."""
+    L = lib()
+    L.jref_ycbcr8_to_rgb.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.jref_ycbcr8_to_rgb.restype = None
+    a = np.ascontiguousarray(ycbcr, dtype=np.uint8)
+    if gray:
+        a = np.concatenate([a.reshape(a.shape[0], a.shape[1], 1), np.full((a.shape[0], a.shape[1], 2), 128, np.uint8)], axis=2)
+        a = np.ascontiguousarray(a)
+    h, w = a.shape[0], a.shape[1]
+    bpp = 4 if rgba else 3
+    out = np.empty((h, w, bpp), np.uint8)
+    L.jref_ycbcr8_to_rgb(a.ctypes.data, out.ctypes.data, h * w, bpp)
+    return out
+
+
 def decode_blocks(data: bytes):
     """All WriteBlock calls in order: list of (component_index, x, y, block[64] int16)."""
     calls = []

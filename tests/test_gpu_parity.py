@@ -558,3 +558,42 @@ def test_truncated_progressive_stream_fails_like_the_reference():
         assert mine == ref, (cut, ref, ref_msg, mine, res.detail)
         if res.detail in (1, 2, 3, 4, 9):
             assert _capi.lib.jpgpu_detail_string(res.detail).decode() == ref_msg, (cut, ref_msg, res.detail)
+
+
+# ------------------------------------------------------------------------------------------------ YCbCr -> RGB(A) in the writer
+
+RGB_CASES = [
+    (256, 128, "420", 75, 4), (256, 128, "422", 80, 0), (256, 128, "444", 90, 2),   # fused layouts
+    (333, 211, "420", 75, 8), (100, 60, "444", 60, 0),                             # widths without a fused path
+    (64, 64, "gray", 75, 0), (70, 50, "gray", 75, 0), (640, 480, "420", 95, 4),
+]
+
+
+@pytest.mark.parametrize("w,h,ss,q,dri", RGB_CASES)
+@pytest.mark.parametrize("fmt", ["rgb", "rgba"])
+def test_rgb_output_matches_reference_converter(w, h, ss, q, dri, fmt):
+    """FMT_RGB_U8 / FMT_RGBA_U8 = JpegYCbCrToRgbConverter applied to the decoded YCbCr8 buffer (what DecodeAction and the
+    reference benchmark do after Decode()), fused into the writer kernel where the layout has a fast path."""
+    data = bytes(jpegsynth.encode(w, h, ss, q, dri, seed=w * 3 + h))
+    ycc, _ = po.decode_8bit(data)
+    gray = ss == "gray"
+    ref = po.ycbcr8_to_rgb(ycc, rgba=(fmt == "rgba"), gray=gray)
+    outs, results = jl.decode_batch([data], jl.FMT_RGBA_U8 if fmt == "rgba" else jl.FMT_RGB_U8)
+    assert results[0].status == 0
+    assert np.array_equal(outs[0], ref)
+
+
+def test_rgb_output_of_reference_assets_and_progressive():
+    for name in ["lake.jpg", "cramps.jpg", "HETissueSlide.jpg", "progress.jpg"]:
+        data = read_jpeg(name)
+        ycc, info = po.decode_8bit(data)
+        ref = po.ycbcr8_to_rgb(ycc, rgba=True, gray=(info.ncomp == 1))
+        outs, results = jl.decode_batch([data], jl.FMT_RGBA_U8)
+        assert results[0].status == 0, name
+        assert np.array_equal(outs[0], ref), name
+
+
+def test_rgb_output_rejects_other_colour_spaces():
+    # 12-bit samples and 4-component frames: the reference's callers refuse them too (DecodeAction.cs:29-33)
+    _, results = jl.decode_batch([read_jpeg("testorig12.jpg")], jl.FMT_RGB_U8)
+    assert results[0].status == 3
