@@ -585,26 +585,7 @@ int DeviceBatch::run_huffman() {
                                   (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_);
     if (e != hipSuccess) return hip_fail(e, "huffman_decode_kernel");
     if (n_sub_work_ > 0) {
-        // DRI = 0 scans: the final pass scatters coefficients into a zeroed buffer
-        uint64_t run_first = 0, run_blocks = 0;  // adjacent scans are cleared with one memset
-        for (size_t k = 0; k <= sub_scan_ids_.size(); k++) {
-            uint64_t first = 0, nblocks = 0;
-            if (k < sub_scan_ids_.size()) {
-                const DevScan &s = h_scans_[sub_scan_ids_[k]];
-                first = s.coef_off;
-                nblocks = (uint64_t)s.total_mcus * s.blocks_per_mcu;
-            }
-            if (k < sub_scan_ids_.size() && run_blocks && first == run_first + run_blocks) {
-                run_blocks += nblocks;
-                continue;
-            }
-            if (run_blocks) {
-                e = hipMemsetAsync((int16_t *)d_coefs_.ptr + run_first * 64, 0, (size_t)run_blocks * 128, ctx_->stream);
-                if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(coefficients)");
-            }
-            run_first = first;
-            run_blocks = nblocks;
-        }
+        // DRI = 0 scans: the final pass writes every block of the scan as whole lines (nothing to clear)
         e = launch_subseq_decode(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_sub_work_.ptr,
                                  n_sub_work_, (const uint32_t *)d_sub_scan_ids_.ptr, n_sub_scans_, (const uint32_t *)d_ends_u_.ptr,
                                  (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (uint32_t *)d_sub_exit_a_.ptr,

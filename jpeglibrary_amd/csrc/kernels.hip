@@ -1646,40 +1646,156 @@ __global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__rest
     }
 }
 
-// Final pass: every lane decodes its subsequence from its converged entry state and stores the coefficients.
-__global__ __launch_bounds__(256) void subseq_final_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
-                                                            const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
-                                                            DevScanStatus *__restrict__ status, const DevHuffTable *__restrict__ huff_pool,
-                                                            const uint32_t *__restrict__ exit_state, const uint32_t *__restrict__ first_block,
-                                                            const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs, int n_slots) {
+// Final pass.  The converged entry states say where every subsequence's first block begins: lane i decodes the WHOLE
+// blocks that start inside subsequence i (it first skips the tail of a block the previous lane is finishing, and runs
+// past its own end to finish its last block), so every block has exactly one owner.  Lanes of a wave then work like K2:
+// block j of every lane is decoded into the wave's LDS staging in lock-step and flushed as whole 128-byte lines; the
+// coefficient buffer needs no clearing.  The DC predictor chain starts from the prefix sums of subseq_scan_kernel.
+constexpr int kSubFinalWaves = 4;
+__global__ __launch_bounds__(64 * kSubFinalWaves) void subseq_final_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+                                                                           const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
+                                                                           DevScanStatus *__restrict__ status,
+                                                                           const DevHuffTable *__restrict__ huff_pool,
+                                                                           const uint32_t *__restrict__ exit_state,
+                                                                           const uint32_t *__restrict__ first_block,
+                                                                           const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs,
+                                                                           int n_slots) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *tabs = smem;
     uint32_t *blk_info = reinterpret_cast<uint32_t *>(smem + (size_t)n_slots * sizeof(DevHuffTable));
+    uint8_t *stage_all = reinterpret_cast<uint8_t *>(blk_info + kMaxBlocksPerMcu);                    // kSubFinalWaves * 8192
+    uint32_t *meta_all = reinterpret_cast<uint32_t *>(stage_all + kSubFinalWaves * 8192);             // [waves][64][2]
     const HuffWork wk = work[blockIdx.x];
     const DevScan &s = scans[wk.scan];
-    sub_stage_tables(s, huff_pool, tabs, blk_info, n_slots, 256);
+    sub_stage_tables(s, huff_pool, tabs, blk_info, n_slots, 64 * kSubFinalWaves);
     const DevScanStatus st = status[wk.scan];
     if (st.n_ends == 0) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint8_t *stage = stage_all + wave * 8192;
+    uint32_t *meta = meta_all + wave * 128;
+    {
+        const uint4 z = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(stage)[i * 64 + lane] = z;
+    }
     const uint32_t ulen = ends_u[s.ends_off];
     const uint32_t total_bits = ulen * 8;
-    const uint32_t sub = wk.first_interval + threadIdx.x;
-    if (sub >= s.n_subs) return;
-    const uint32_t slot = s.sub_off + sub;
+    const uint32_t sub = wk.first_interval + tid;
+    const uint32_t slot = s.sub_off + (sub < s.n_subs ? sub : 0);
     const uint32_t total_blocks = s.total_mcus * s.blocks_per_mcu;
+    const uint32_t bpm = s.blocks_per_mcu;
+    const uint64_t coef_off = s.coef_off;
+    const bool closed_by_marker = st.terminator != 0;
+
+    bool live = sub < s.n_subs;
     uint32_t entry = 0;
-    if (sub > 0) {
+    if (live && sub > 0) {
         const uint32_t prev = exit_state[slot - 1];
-        if (prev & kSubBad) return;  // the stream ended or failed in an earlier subsequence: reported by that lane
-        entry = prev;
+        if (prev & kSubBad) live = false;  // the stream ended or failed in an earlier subsequence: reported by that lane
+        else entry = prev;
     }
-    const uint32_t fb = first_block[slot];
-    if (fb >= total_blocks) return;  // everything was decoded before this subsequence
-    uint32_t nblk, err;
-    const int4 de = dc_entry[slot];
-    int32_t dc[4] = {de.x, de.y, de.z, de.w};
-    const uint32_t ex = sub_decode<true>(udata + s.data_off, total_bits, sub, entry, tabs, blk_info, s.blocks_per_mcu, nblk,
-                                         coefs + s.coef_off * 64, fb, total_blocks, err, st.terminator != 0, dc);
-    if ((ex & kSubBad) && err != 0) {
+    uint32_t b_in_mcu = (entry >> 6) & 31u, k = (entry >> 11) & 127u;
+    uint32_t my_first = total_blocks, my_end = total_blocks;
+    if (live) {
+        my_first = first_block[slot] + (k != 0 ? 1u : 0u);
+        if (sub + 1 < s.n_subs) {
+            const uint32_t ex = exit_state[slot];
+            if (!(ex & kSubBad)) my_end = first_block[slot + 1] + ((((ex >> 11) & 127u) != 0) ? 1u : 0u);
+        }
+        if (my_end > total_blocks) my_end = total_blocks;  // the reference stops after the last MCU
+        if (my_first > my_end) my_first = my_end;
+    }
+    const uint32_t count = my_end - my_first;
+    meta[lane * 2] = my_first;
+    meta[lane * 2 + 1] = count;
+    const uint32_t wave_count = wave_reduce_max_i((int32_t)count);
+
+    UBits r;
+    uint32_t err = 0;
+    int32_t dc[4] = {0, 0, 0, 0};
+    uint32_t info = blk_info[b_in_mcu];
+    {
+        const uint32_t start_bit = live ? sub * kSubBits + (entry & 63u) : 0u;
+        ub_init(r, udata + s.data_off, start_bit >> 3, (total_bits + 7) >> 3);
+        if (start_bit & 7u) ub_consume(r, start_bit & 7u);
+        r.rem = (int32_t)total_bits - (int32_t)start_bit;
+        if (live && count != 0) {
+            const int4 de = dc_entry[slot];
+            dc[0] = de.x;
+            dc[1] = de.y;
+            dc[2] = de.z;
+            dc[3] = de.w;
+            // the tail of the block the previous lane owns: parsed, not stored
+            while (k != 0 && err == 0) {
+                const LdsHuff h = lds_huff16(tabs, (info >> 12) & 0xFFF);
+                uint32_t sym;
+                int32_t v;
+                err = ub_symbol(r, h, false, closed_by_marker, sym, v);
+                const uint32_t rr = sym >> 4;
+                k = (sym & 15u) != 0 ? k + rr + 1u : (rr == 0 ? 64u : k + 16u);
+                if (k >= 64u) {
+                    k = 0;
+                    b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
+                    info = blk_info[b_in_mcu];
+                }
+            }
+        }
+    }
+    uint8_t *my_stage = stage + lane * 128;
+    const uint32_t swz16 = ((lane >> 1) & 7u) << 4;
+
+    for (uint32_t j = 0; j < wave_count; j++) {
+        if (j < count && err == 0) {
+            // ReadBlockBaseline (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:179-222)
+            uint32_t sym;
+            int32_t v;
+            err = ub_symbol(r, lds_huff16(tabs, info & 0xFFF), true, closed_by_marker, sym, v);
+            if (err == 0) {
+                const uint32_t ci = info >> 24;
+                const int32_t t = v + (ci == 0 ? dc[0] : (ci == 1 ? dc[1] : (ci == 2 ? dc[2] : dc[3])));
+                if (ci == 0) dc[0] = t;
+                else if (ci == 1) dc[1] = t;
+                else if (ci == 2) dc[2] = t;
+                else dc[3] = t;
+                *reinterpret_cast<int16_t *>(my_stage + swz16) = (int16_t)t;
+                const LdsHuff hac = lds_huff16(tabs, (info >> 12) & 0xFFF);
+                for (uint32_t i = 1; i < 64;) {
+                    err = ub_symbol(r, hac, false, closed_by_marker, sym, v);
+                    if (err != 0) break;
+                    const uint32_t rr = sym >> 4;
+                    if ((sym & 15u) != 0) {
+                        i += rr;
+                        const uint32_t idx = i < 63 ? i : 63;  // Math.Min(i++, 63)
+                        i++;
+                        *reinterpret_cast<int16_t *>(my_stage + ((idx * 2) ^ swz16)) = (int16_t)v;
+                    } else {
+                        if (rr == 0) break;
+                        i += 16;  // ANY r != 0, not only 15 (ref: :212-220)
+                    }
+                }
+                b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
+                info = blk_info[b_in_mcu];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const uint32_t blk = it * 8 + (lane >> 3);
+            const uint32_t chunk = lane & 7;
+            uint4 *src = reinterpret_cast<uint4 *>(stage + blk * 128 + ((chunk ^ ((blk >> 1) & 7)) * 16));
+            const uint4 v = *src;
+            const uint4 z = {0, 0, 0, 0};
+            *src = z;
+            const uint32_t owner_first = meta[blk * 2], owner_count = meta[blk * 2 + 1];
+            if (j < owner_count) *reinterpret_cast<uint4 *>(coefs + (coef_off + owner_first + j) * 64 + chunk * 8) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (live && err != 0) {
         // failure on the true path: same detail codes as the interval decoder; "interval" field carries the subsequence
         atomicMin(&status[wk.scan].first_error, (sub << 8) | err);
     }
@@ -2469,8 +2585,9 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
     const uint32_t *final_state = bufs[(round + 1) & 1];  // buffer written by the last round executed
     hipLaunchKernelGGL(subseq_scan_kernel, dim3(n_scans), dim3(1024), 0, stream, scans, scan_ids, nblk, first_block, (const int4 *)dcsum,
                        (int4 *)dc_entry);
-    hipLaunchKernelGGL(subseq_final_kernel, dim3(n_work), dim3(256), lds, stream, udata, scans, work, ends_u, status, huff_pool, final_state,
-                       first_block, (const int4 *)dc_entry, coefs, n_slots);
+    const size_t lds_final = lds + (size_t)kSubFinalWaves * (8192 + 64 * 2 * sizeof(uint32_t));
+    hipLaunchKernelGGL(subseq_final_kernel, dim3(n_work), dim3(64 * kSubFinalWaves), lds_final, stream, udata, scans, work, ends_u, status,
+                       huff_pool, final_state, first_block, (const int4 *)dc_entry, coefs, n_slots);
     return hipGetLastError();
 }
 
