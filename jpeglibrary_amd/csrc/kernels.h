@@ -11,7 +11,7 @@ namespace jpgpu {
 constexpr int kHuffWaves = 10;                // wavefronts per Huffman workgroup
 constexpr int kHuffIntervalsPerWg = 64 * kHuffWaves;  // restart intervals per workgroup (one per lane)
 constexpr int kIdctBlocksPerWg = 256;         // 8x8 blocks per IDCT tile (one per lane)
-constexpr int kIdctTilesPerWg = 8;            // consecutive tiles walked by one IDCT workgroup (prefetch pipeline)
+constexpr int kIdctTilesPerWg = 16;           // consecutive tiles walked by one IDCT workgroup (prefetch pipeline)
 
 size_t huffman_lds_bytes(int n_slots);
 

@@ -38,6 +38,17 @@ __global__ __launch_bounds__(256) void coalesced(uint8_t *out, size_t total16) {
         if (i < total16) reinterpret_cast<uint4 *>(out)[i] = v;
 }
 
+// the traffic mix of idct_output_kernel: every byte read once, every byte written once
+__global__ __launch_bounds__(256) void copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t total16) {
+    size_t i = (size_t)blockIdx.x * 256 * 8 + threadIdx.x;
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = (i + k * 256 < total16) ? src[i + k * 256] : uint4{0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (i + k * 256 < total16) dst[i + k * 256] = v[k];
+}
+
 int main(int argc, char **argv) {
     const int delay = argc > 1 ? atoi(argv[1]) : 2000;
     const int n_images = argc > 2 ? atoi(argv[2]) : 256;
@@ -66,6 +77,21 @@ int main(int argc, char **argv) {
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         printf("coalesced: %.3f ms  %.1f GB/s\n", ms, bytes / ms / 1e6);
+    }
+    {
+        uint8_t *d2;
+        const size_t half = bytes / 2;
+        if (hipMalloc(&d2, half) != hipSuccess) return 1;
+        for (int rep = 0; rep < 3; rep++) {
+            hipEventRecord(e0);
+            const size_t total16 = half / 16;
+            hipLaunchKernelGGL(copy16, dim3((total16 + 2047) / 2048), dim3(256), 0, 0, (const uint4 *)d, (uint4 *)d2, total16);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("copy (read %zu MB + write %zu MB): %.3f ms  %.1f GB/s total\n", half >> 20, half >> 20, ms, 2.0 * half / ms / 1e6);
+        }
     }
     return 0;
 }
