@@ -752,6 +752,14 @@ int DeviceBatch::result(int i, jpgpu_image_result *res) {
         }
         if (st.decoded_mcus < h_scans_[j].total_mcus) res->detail = kDetailEarlyEoi;
     }
+    if (res->status == JPGPU_OK) {
+        for (int j : img->jobs)
+            if (!jobs_[j].refuse.empty()) {
+                res->status = JPGPU_ERR_NOT_SUPPORTED;
+                res->detail = kDetailUnsupportedFrame;
+                ctx_->last_error = jobs_[j].refuse;
+            }
+    }
     return JPGPU_OK;
 }
 

@@ -213,6 +213,7 @@ struct ScanJob {
     uint8_t fblk_base[kMaxScanComponents] = {};
     uint16_t hblocks[kMaxScanComponents] = {}, vblocks[kMaxScanComponents] = {};
     uint32_t units_per_line = 0, total_units = 0;
+    std::string refuse;  // frame job: non-empty = report NotSupported once every scan of the frame decoded cleanly
 };
 // Builds a ScanJob (validates tables like ProcessScan :69-82). Throws DecodeError with the reference's messages.
 ScanJob make_scan_job(const HostDecoder &dec, const BaselineGeometry &geo, const ScanHeader &scan, const uint8_t *entropy,
@@ -228,8 +229,8 @@ class ProgressiveFrame {
     // The reference never advances the outer reader here; neither do we.
     void add_scan(const HostDecoder &dec, const ScanHeader &scan, const uint8_t *entropy, size_t entropy_len);
     // The job of the Dispose() pass (:421-470): components and quantisation tables as the LAST scans left them in
-    // the decoder's component slots.  Throws NotSupported for scan orders whose slots do not cover
-    // every frame component exactly once (the reference then transforms some component twice and another never).
+    // the decoder's component slots.  Scan orders whose slots do not cover every frame component exactly
+    // once (the reference then transforms some component twice and another never) get ScanJob::refuse set.
     ScanJob make_frame_job() const;
     const BaselineGeometry &geo() const { return geo_; }
     std::vector<ScanJob> &scans() { return scans_; }

@@ -735,9 +735,6 @@ void ProgressiveFrame::add_scan(const HostDecoder &dec, const ScanHeader &scan, 
     job.scan_dri = dec.restart_interval();
     job.frame_bpm = frame_bpm_;
     job.scan_components = dec.resolve_scan(fh, scan, job.comp);  // InitDecodeComponents (:60)
-    if (scan.se > 63 || scan.ss > scan.se || scan.al > 13)
-        throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "Spectral selection / successive approximation parameters are outside the supported range.",
-                          kDetailUnsupportedFrame);
     for (int i = 0; i < job.scan_components; i++) {  // :63-69
         if (!job.comp[i].quant)
             throw_invalid_data("Failed to decode JPEG data. Quantization table of component " + std::to_string(job.comp[i].component_index) + " is not defined.",
@@ -750,6 +747,11 @@ void ProgressiveFrame::add_scan(const HostDecoder &dec, const ScanHeader &scan, 
             throw_invalid_data("Failed to decode JPEG data. Huffman table of component " + std::to_string(job.comp[i].component_index) + " is not defined.",
                                kDetailMissingTable);
     }
+    // the reference walks whatever band the header names; bands outside the block are outside what we reproduce
+    // (an AC refinement band that leaves the block makes it read its neighbours' coefficients; first passes clamp the index)
+    if (!interleaved && scan.ss != 0 && scan.ah != 0 && scan.se > 63)
+        throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "AC refinement scans whose spectral band leaves the block are not supported.",
+                          kDetailUnsupportedFrame);
     // snapshot the tables the scan decodes with; dedupe by registry pointer
     const HuffTable *seen[kMaxHuffSlots] = {};
     auto slot_of = [&](const HuffTable *t) -> uint8_t {
@@ -809,11 +811,9 @@ ScanJob ProgressiveFrame::make_frame_job() const {
         else if (slot_of_component[slot_[i].component_index] >= 0) ok = false;
         else slot_of_component[slot_[i].component_index] = i;
     }
-    if (!ok)
-        throw DecodeError(JPGPU_ERR_NOT_SUPPORTED,
-                          "Progressive scan order leaves the decoder's component slots without one entry per frame component; "
-                          "the reference's output for such files is an artefact of its Dispose() pass and is not reproduced.",
-                          kDetailUnsupportedFrame);
+    // Not reproduced; but a failure inside one of the scans comes first in the reference (it happens before Dispose), so
+    // the refusal is only attached to the job and reported when every scan decoded cleanly.
+    const bool refuse = !ok;
     // a sequential-style job over ALL frame components in frame order with the slots' quantisation tables
     HostDecoder tmp;
     FrameHeader f2 = fh;
@@ -822,7 +822,9 @@ ScanJob ProgressiveFrame::make_frame_job() const {
     sh.se = 63;
     for (int c = 0; c < fh.num_components; c++) {
         f2.components[c].tq = (uint8_t)c;
-        QuantTable q = slot_quant_[slot_of_component[c]];
+        QuantTable q;
+        if (slot_of_component[c] >= 0 && slot_set_[slot_of_component[c]]) q = slot_quant_[slot_of_component[c]];
+        else for (uint16_t &e : q.elements) e = 1;  // refused frame: the pass still runs, its output is not delivered
         q.identifier = (uint8_t)c;
         tmp.set_quantization_table(q);
         sh.components.push_back({fh.components[c].identifier, 0, 0});
@@ -838,6 +840,9 @@ ScanJob ProgressiveFrame::make_frame_job() const {
     BaselineGeometry g = BaselineGeometry::latch(tmp, f2);
     ScanJob job = make_scan_job(tmp, g, sh, nullptr, 0);
     job.kind = kScanFrameOnly;
+    if (refuse)
+        job.refuse = "Progressive scan order leaves the decoder's component slots without one entry per frame component; "
+                     "the reference's output for such files is an artefact of its Dispose() pass and is not reproduced.";
     return job;
 }
 

@@ -597,3 +597,71 @@ def test_rgb_output_rejects_other_colour_spaces():
     # 12-bit samples and 4-component frames: the reference's callers refuse them too (DecodeAction.cs:29-33)
     _, results = jl.decode_batch([read_jpeg("testorig12.jpg")], jl.FMT_RGB_U8)
     assert results[0].status == 3
+
+
+# ------------------------------------------------------------------------------------------------ randomised corruption
+
+def _mutate(data: bytes, rng) -> bytes:
+    """One random edit of the entropy-coded part (headers stay parseable most of the time): flip bits, drop / duplicate /
+    insert bytes, plant markers, truncate."""
+    sos = data.index(b"\xff\xda")
+    lo = sos + 4 + data[sos + 3]
+    b = bytearray(data)
+    kind = rng.integers(0, 7)
+    pos = int(rng.integers(lo, len(b) - 2))
+    if kind == 0:
+        b[pos] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 1:
+        del b[pos:pos + int(rng.integers(1, 6))]
+    elif kind == 2:
+        b[pos:pos] = bytes(rng.integers(0, 256, int(rng.integers(1, 6))).astype(np.uint8))
+    elif kind == 3:
+        b[pos:pos + 2] = bytes([0xFF, int(rng.choice([0xD0, 0xD3, 0xD7, 0xD9, 0xC4, 0xDA, 0x00, 0xFF, 0xE1]))])
+    elif kind == 4:
+        b = b[:pos] + b"\xff\xd9"
+    elif kind == 5:
+        n = int(rng.integers(1, 40))
+        b[pos:pos + n] = bytes(n)
+    else:
+        n = int(rng.integers(1, 40))
+        b[pos:pos + n] = b"\xff" * n
+    return bytes(b)
+
+
+@pytest.mark.parametrize("variant", ["dri4_420", "dri0_444", "dri1_gray", "progressive"])
+def test_random_corruptions_fail_like_the_reference(variant):
+    """200 random edits per stream kind: the GPU path must report the reference's exception class (and message, for
+    device-reported failures) or, when the reference still decodes, produce the same pixels."""
+    from jpeglibrary_amd import _capi
+    rng = np.random.default_rng({"dri4_420": 1, "dri0_444": 2, "dri1_gray": 3, "progressive": 4}[variant])
+    if variant == "dri4_420":
+        good = bytes(jpegsynth.encode(112, 80, "420", 75, 4, seed=11))
+    elif variant == "dri0_444":
+        good = bytes(jpegsynth.encode(72, 56, "444", 85, 0, seed=12))
+    elif variant == "dri1_gray":
+        good = bytes(jpegsynth.encode(96, 64, "gray", 60, 1, seed=13))
+    else:
+        good = _pillow_progressive(96, 72, "4:2:0", 80, 14, restart_blocks=0)
+    cases = [_mutate(good, rng) for _ in range(200)]
+    refs = []
+    for data in cases:
+        try:
+            refs.append(("OK", "", po.decode_8bit(data)[0]))
+        except po.OracleError as e:
+            refs.append((e.kind, e.message, None))
+    outs, results = jl.decode_batch(cases, jl.FMT_INTERLEAVED_U8)
+    names = {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException", 4: "ArgumentException"}
+    mismatches = []
+    for i, ((ref, ref_msg, ref_px), out, res) in enumerate(zip(refs, outs, results)):
+        mine = names.get(res.status, str(res.status))
+        if ref == "OK" and variant == "progressive" and mine == "NotSupportedException" and res.detail == 6:
+            # documented fence (DESIGN.md 5): a damaged scan sequence can leave the reference's Dispose() pass transforming
+            # one component twice and another never; it "succeeds" with an artefact we refuse to reproduce
+            continue
+        if mine != ref:
+            mismatches.append((i, ref, ref_msg, mine, res.detail))
+        elif ref == "OK" and res.detail != 8 and not np.array_equal(out, ref_px):  # 8 = early EOI: partial image
+            mismatches.append((i, "pixels differ", "", mine, res.detail))
+        elif ref != "OK" and res.detail in (1, 2, 3, 4, 9) and _capi.lib.jpgpu_detail_string(res.detail).decode() != ref_msg:
+            mismatches.append((i, ref, ref_msg, mine, res.detail))
+    assert not mismatches, mismatches[:10]
