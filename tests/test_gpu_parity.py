@@ -665,3 +665,42 @@ def test_random_corruptions_fail_like_the_reference(variant):
         elif ref != "OK" and res.detail in (1, 2, 3, 4, 9) and _capi.lib.jpgpu_detail_string(res.detail).decode() != ref_msg:
             mismatches.append((i, ref, ref_msg, mine, res.detail))
     assert not mismatches, mismatches[:10]
+
+
+# ------------------------------------------------------------------------------------------------ edge sizes, one batch
+
+def test_edge_sizes_and_samplings_in_one_batch():
+    """Tiny and ragged geometries (1x1 up to one-and-a-bit MCUs) for every sampling, with and without restart intervals,
+    sequential and progressive, decoded as ONE batch in every output format that has an oracle counterpart."""
+    files = []
+    for (w, h) in [(1, 1), (7, 9), (8, 8), (9, 7), (16, 16), (17, 1), (1, 33), (31, 17), (48, 40)]:
+        for ss in ("444", "422", "420", "gray"):
+            for dri in (0, 1, 3):
+                files.append(bytes(jpegsynth.encode(w, h, ss, 70, dri, seed=w * 131 + h * 7 + dri)))
+        files.append(_pillow_progressive(w, h, "4:2:0", 75, w + h))
+        files.append(_pillow_progressive(w, h, None, 75, w * h, gray=True))
+    refs = [po.decode_8bit(f) for f in files]
+    outs, results = jl.decode_batch(files, jl.FMT_INTERLEAVED_U8)
+    for i, ((ref, info), out, res) in enumerate(zip(refs, outs, results)):
+        assert res.status == 0, (i, res.status, res.detail)
+        assert np.array_equal(out, ref), i
+    outs, results = jl.decode_batch(files, jl.FMT_RGBA_U8)
+    for i, ((ref, info), out, res) in enumerate(zip(refs, outs, results)):
+        assert res.status == 0, (i, res.status, res.detail)
+        assert np.array_equal(out, po.ycbcr8_to_rgb(ref, rgba=True, gray=(info.ncomp == 1))), i
+    # unclamped samples: every WriteBlock call of the reference (sequential files: one per block, before chroma
+    # expansion only for full-resolution components) must be found in the PLANAR_I16 planes
+    b = jl.Batch().upload(files, jl.FMT_PLANAR_I16).decode().sync()
+    for i, f in enumerate(files):
+        assert b.result(i).status == 0
+        planes = b.output(i)
+        info = refs[i][1]
+        calls, _ = po.decode_blocks(f)
+        max_h = max(info.comp[c].h for c in range(info.ncomp))
+        max_v = max(info.comp[c].v for c in range(info.ncomp))
+        for (ci, x, y, blk) in calls:
+            if info.comp[ci].h != max_h or info.comp[ci].v != max_v:
+                continue  # expanded chroma blocks: covered by the interleaved comparison above
+            tile = planes[ci][y:y + 8, x:x + 8]
+            if tile.shape == (8, 8):
+                assert np.array_equal(tile.reshape(-1), np.asarray(blk)), (i, ci, x, y)
