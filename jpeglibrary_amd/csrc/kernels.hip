@@ -1557,24 +1557,57 @@ __device__ __forceinline__ void sub_stage_tables(const DevScan &s, const DevHuff
     __syncthreads();
 }
 
+// Fused lookups (the format K2 builds per workgroup: total bits | code bits << 8 | category << 16 | zig-zag advance << 24,
+// kK2Miss / kK2BadCategory) for every table of the pool, both as a DC and as an AC table: the round kernel's workgroups
+// are short-lived, so they copy the lookup instead of deriving it.  Entry (table * 2 + is_dc) * 2048 + prefix.
+constexpr int kSrLutBits = 10;
+__global__ __launch_bounds__(256) void lut_pool_kernel(const DevHuffTable *__restrict__ pool, uint32_t *__restrict__ lut_pool) {
+    const DevHuffTable &h = pool[blockIdx.x >> 1];
+    const bool is_dc = (blockIdx.x & 1) != 0;
+    for (uint32_t i = threadIdx.x; i < (1u << kSrLutBits); i += 256) {
+        const uint32_t code16 = (i << (16 - kSrLutBits)) | ((1u << (16 - kSrLutBits)) - 1u);
+        const uint32_t e9 = h.lut[i >> (kSrLutBits - kHuffLutBits)];
+        uint32_t size = e9 >> 8, sym = e9 & 0xFFu;
+        if (size == 0) {
+            size = kHuffLutBits + 1;
+            while (code16 > h.maxcode[size]) size++;
+            if (size <= (uint32_t)kSrLutBits) sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
+        }
+        uint32_t e = kK2Miss;
+        if (size <= (uint32_t)kSrLutBits) {
+            const uint32_t cat = is_dc ? sym : (sym & 15u);
+            e = cat > 16u ? kK2BadCategory : ((size + cat) | (size << 8) | (cat << 16) | ((is_dc ? 0u : k2_ac_advance(sym)) << 24));
+        }
+        lut_pool[(size_t)blockIdx.x * (1u << kSrLutBits) + i] = e;
+    }
+}
+
 // One synchronisation round.  exit_in/exit_out are double-buffered per-subsequence state words (index sub_off + sub).
+// A round only has to follow the symbol structure: code and magnitude LENGTHS, zig-zag advance, block and MCU phase, and
+// the DC differences (their per-component sums feed the predictor prefix); AC magnitudes are skipped, not extracted.
+// The stream comes through the word reader (UBits): staging it in LDS was measured and lost -- the rounds are latency
+// bound and need the occupancy more than the shorter instruction stream (13.1 vs 11.1 ms per 256 x 4K).
+
 __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
                                                             const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
                                                             const DevScanStatus *__restrict__ status, const DevHuffTable *__restrict__ huff_pool,
+                                                            const uint32_t *__restrict__ lut_pool,
                                                             const uint32_t *__restrict__ exit_in, uint32_t *__restrict__ exit_out,
                                                             uint32_t *__restrict__ nblk_out, uint32_t *__restrict__ entry_used,
                                                             int4 *__restrict__ dcsum_out, uint32_t *__restrict__ changed, int round,
                                                             int n_slots) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *tabs = smem;
-    uint32_t *blk_info = reinterpret_cast<uint32_t *>(smem + (size_t)n_slots * sizeof(DevHuffTable));
+    uint32_t *luts = reinterpret_cast<uint32_t *>(smem);                                     // n_slots << kSrLutBits
+    uint8_t *small = smem + ((size_t)n_slots << (kSrLutBits + 2));                           // n_slots * kK2SmallBytes
+    uint32_t *blk_info = reinterpret_cast<uint32_t *>(small + (size_t)n_slots * kK2SmallBytes);  // [kMaxBlocksPerMcu]
     const HuffWork wk = work[blockIdx.x];  // first_interval holds the first subsequence of this workgroup
     const DevScan &s = scans[wk.scan];
     const DevScanStatus st = status[wk.scan];
     if (st.n_ends == 0) return;
+    const uint32_t tid = threadIdx.x;
     const uint32_t ulen = ends_u[s.ends_off];  // DRI = 0: interval 0 starts at 0
     const uint32_t total_bits = ulen * 8;
-    const uint32_t sub = wk.first_interval + threadIdx.x;
+    const uint32_t sub = wk.first_interval + tid;
     const bool in_range = sub < s.n_subs;
     const uint32_t slot = s.sub_off + (in_range ? sub : 0);
     uint32_t entry = 0;  // start of a block of the first component, no overshoot
@@ -1583,23 +1616,119 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
         if (!(prev & kSubBad)) entry = prev;
     }
     // a lane whose entry state did not change since it last decoded keeps its exit state (and block count);
-    // a workgroup with no lane left to decode leaves before staging the tables (most workgroups after round 1)
+    // a workgroup with no lane left to decode leaves before staging anything (most workgroups after round 1)
     const bool need = in_range && !(round > 0 && (sub == 0 || entry_used[slot] == entry));
     if (in_range && !need) exit_out[slot] = exit_in[slot];
     if (!__syncthreads_or(need ? 1 : 0)) return;
-    sub_stage_tables(s, huff_pool, tabs, blk_info, n_slots, 256);
+
+    // ---- stage: lookups, the reference's small arrays (long codes), block info
+    for (int sl = 0; sl < kMaxHuffSlots && sl < n_slots; sl++) {
+        const uint32_t pi = s.huff_pool[sl];
+        if (pi == 0xFFFF) continue;
+        bool is_dc = false;
+        for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
+        const uint4 *src = reinterpret_cast<const uint4 *>(lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * (1u << kSrLutBits));
+        uint4 *dst = reinterpret_cast<uint4 *>(luts + ((size_t)sl << kSrLutBits));
+        for (uint32_t i = tid; i < (1u << kSrLutBits) / 4; i += 256) dst[i] = src[i];
+        const uint4 *ssrc = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&huff_pool[pi]) + offsetof(DevHuffTable, maxcode));
+        uint4 *sdst = reinterpret_cast<uint4 *>(small + sl * kK2SmallBytes);
+        if (tid < kK2SmallBytes / 16) sdst[tid] = ssrc[tid];
+    }
+    if (tid < kMaxBlocksPerMcu) {
+        const uint32_t ci = s.blk_comp[tid];
+        blk_info[tid] = ci | ((uint32_t)s.comp[ci].dc_slot << 8) | ((uint32_t)s.comp[ci].ac_slot << 16);
+    }
+    __syncthreads();
     if (!need) return;
     entry_used[slot] = entry;
-    uint32_t nblk, err;
-    int32_t dc[4] = {0, 0, 0, 0};
-    const uint32_t ex = sub_decode<false>(udata + s.data_off, total_bits, sub, entry, tabs, blk_info, s.blocks_per_mcu, nblk, nullptr, 0, 0, err,
-                                          st.terminator != 0, dc);
+
+    const uint32_t bpm = s.blocks_per_mcu;
+    const uint32_t start_bit = sub * kSubBits + (entry & 63u);
+    const uint32_t end_bit = (sub + 1) * kSubBits;
+    uint32_t b_in_mcu = (entry >> 6) & 31u, i2 = ((entry >> 11) & 127u) * 2u;
+    uint32_t nblk = 0, bad = 0;
+    int32_t dc0 = 0, dc1 = 0, dc2 = 0, dc3 = 0;
+    uint32_t ex;
+    if (start_bit >= total_bits) {
+        ex = sub_pack(0, b_in_mcu, i2 >> 1) | kSubBad;
+    } else {
+        UBits r;
+        ub_init(r, udata + s.data_off, start_bit >> 3, (total_bits + 7) >> 3);
+        if (start_bit & 7u) ub_consume(r, start_bit & 7u);
+        r.rem = (int32_t)total_bits - (int32_t)start_bit;
+        uint32_t pos = start_bit;
+        uint32_t info = blk_info[b_in_mcu];
+        while (pos < end_bit && r.rem > 0) {
+            const bool is_dc = i2 == 0;
+            const uint32_t sl = is_dc ? ((info >> 8) & 0xFFu) : (info >> 16);
+            const uint32_t hi = r.hi;
+            uint32_t e = luts[(sl << kSrLutBits) + (hi >> (32 - kSrLutBits))];
+            uint32_t n = e & 0xFFu, cat = (e >> 16) & 0xFFu, adv = e >> 24;
+            if ((int32_t)(e | (uint32_t)(r.rem - (int32_t)n)) < 0) {
+                // exact path: long code, bad category, or the last bits of the stream (same decisions as ub_symbol)
+                const uint16_t *maxcode = reinterpret_cast<const uint16_t *>(small + sl * kK2SmallBytes);
+                const uint8_t *valoffset = small + sl * kK2SmallBytes + 36, *values = small + sl * kK2SmallBytes + 56;
+                uint32_t size;
+                if (e == kK2BadCategory) {
+                    bad = 1;
+                    break;
+                }
+                const uint32_t code16 = hi >> 16;
+                if (e & 0x80000000u) {
+                    size = kSrLutBits + 1;
+                    while (code16 > maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
+                    if (size > 16) {
+                        bad = 1;
+                        break;
+                    }
+                    const uint32_t sym = values[(valoffset[size] + (code16 >> (16 - size))) & 0xFF];
+                    cat = is_dc ? sym : (sym & 15u);
+                    adv = k2_ac_advance(sym);
+                    if (cat > 16u) {
+                        bad = 1;
+                        break;
+                    }
+                } else {
+                    size = (e >> 8) & 0xFFu;
+                }
+                // the stream ends inside the symbol: nothing after it can be right
+                if ((int32_t)(size + cat) > r.rem) {
+                    bad = 1;
+                    break;
+                }
+                n = size + cat;
+            }
+            if (is_dc) {
+                const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - n, cat);
+                const int32_t v = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));  // Extend(v, nbits)
+                const uint32_t ci = info & 0xFFu;
+                if (ci == 0) dc0 += v;
+                else if (ci == 1) dc1 += v;
+                else if (ci == 2) dc2 += v;
+                else dc3 += v;
+                i2 = 2;
+            } else {
+                i2 += adv;
+            }
+            if (i2 >= 128u) {
+                nblk++;
+                b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
+                i2 = 0;
+                info = blk_info[b_in_mcu];
+            }
+            r.rem -= (int32_t)n;
+            ub_consume(r, n);
+            pos += n;
+        }
+        const uint32_t over = pos > end_bit ? pos - end_bit : 0u;
+        ex = sub_pack(over < 63u ? over : 63u, b_in_mcu, i2 >> 1);
+        if (bad) ex = sub_pack(0, b_in_mcu, i2 >> 1) | kSubBad;
+    }
     if (round == 0 || ex != exit_in[slot]) atomicOr(changed, 1u);
     exit_out[slot] = ex;
     nblk_out[slot] = nblk;
-    dcsum_out[slot] = make_int4(dc[0], dc[1], dc[2], dc[3]);
+    dcsum_out[slot] = make_int4(dc0, dc1, dc2, dc3);
 }
-
 // Exclusive prefix sums over a scan's subsequences: first block and DC predictors at the entry of every subsequence.
 // One workgroup per scan.
 __global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__restrict__ scans, const uint32_t *__restrict__ scan_ids,
@@ -2550,9 +2679,11 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
-                                int max_rounds, int *rounds_used) {
+                                int max_rounds, int *rounds_used, uint32_t *lut_pool, int n_pool_tables) {
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kMaxBlocksPerMcu * sizeof(uint32_t);
+    const size_t lds_round = ((size_t)n_slots << (kSrLutBits + 2)) + (size_t)n_slots * kK2SmallBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
+    hipLaunchKernelGGL(lut_pool_kernel, dim3(2 * n_pool_tables), dim3(256), 0, stream, huff_pool, lut_pool);
     uint32_t *bufs[2] = {exit_a, exit_b};
     // changed_dev[r] is set by round r; the host looks at the flags only every kCheckEvery rounds (one sync per check)
     constexpr int kCheckEvery = 3;
@@ -2565,8 +2696,8 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
         for (int i = 0; i < kCheckEvery && round < max_rounds; i++, round++) {
             const uint32_t *in = bufs[(round + 1) & 1];
             uint32_t *out = bufs[round & 1];
-            hipLaunchKernelGGL(subseq_round_kernel, dim3(n_work), dim3(256), lds, stream, udata, scans, work, ends_u, status, huff_pool, in, out,
-                               nblk, entry_used, (int4 *)dcsum, changed_dev + (round & 63), round, n_slots);
+            hipLaunchKernelGGL(subseq_round_kernel, dim3(n_work), dim3(256), lds_round, stream, udata, scans, work, ends_u, status, huff_pool,
+                               lut_pool, in, out, nblk, entry_used, (int4 *)dcsum, changed_dev + (round & 63), round, n_slots);
         }
         uint32_t flags[64];
         e = hipMemcpyAsync(flags, changed_dev, sizeof flags, hipMemcpyDeviceToHost, stream);
