@@ -531,7 +531,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_sub_dcsum_, nullptr, 0, (size_t)total_subs_ * 16 + 256},
         {&d_sub_dcentry_, nullptr, 0, (size_t)total_subs_ * 16 + 256},
         {&d_sub_changed_, nullptr, 0, 64 * sizeof(uint32_t)},
-        {&d_lut_pool_, nullptr, 0, total_subs_ ? huff_pool_.size() * kLutPoolBytesPerTable : 0},
+        {&d_lut_pool_, nullptr, 0, huff_pool_.size() * kLutPoolBytesPerTable},
         {&d_chunk_sums_, nullptr, 0, chunk_work.size() * sizeof(ChunkSum) + 256},
         {&d_idct_work_, idct_work.data(), idct_work.size() * sizeof(IdctWork), 0},
         {&d_ends_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},
@@ -550,6 +550,8 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(descriptors)");
         }
     }
+    e = launch_lut_pool(ctx_->stream, (const DevHuffTable *)d_huff_pool_.ptr, (int)huff_pool_.size(), (uint32_t *)d_lut_pool_.ptr);
+    if (e != hipSuccess) return hip_fail(e, "lut_pool_kernel");
     // slack before the first file and after the last one is read by the kernels' wide loads: keep it defined
     e = hipMemsetAsync(d_input_.ptr, 0, 256, ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
@@ -583,7 +585,7 @@ int DeviceBatch::run_huffman() {
     status_valid_ = false;
     hipError_t e = launch_huffman(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_huff_work_.ptr,
                                   n_huff_work_, (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr,
-                                  (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_);
+                                  (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (const uint32_t *)d_lut_pool_.ptr);
     if (e != hipSuccess) return hip_fail(e, "huffman_decode_kernel");
     if (n_sub_work_ > 0) {
         // DRI = 0 scans: the final pass writes every block of the scan as whole lines (nothing to clear)
@@ -592,7 +594,7 @@ int DeviceBatch::run_huffman() {
                                  (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (uint32_t *)d_sub_exit_a_.ptr,
                                  (uint32_t *)d_sub_exit_b_.ptr, (uint32_t *)d_sub_nblk_.ptr, (uint32_t *)d_sub_first_.ptr,
                                  (uint32_t *)d_sub_entry_.ptr, d_sub_dcsum_.ptr, d_sub_dcentry_.ptr, (uint32_t *)d_sub_changed_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (int)max_subs_per_scan_ + 2,
-                                 &last_subseq_rounds_, (uint32_t *)d_lut_pool_.ptr, (int)huff_pool_.size());
+                                 &last_subseq_rounds_, (const uint32_t *)d_lut_pool_.ptr);
         if (e != hipSuccess) return hip_fail(e, "subsequence decode");
     }
     return run_progressive();

@@ -20,7 +20,9 @@ hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const De
                                ChunkSum *sums, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u);
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                           const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
-                          int n_slots);
+                          int n_slots, const uint32_t *lut_pool);
+// lut_pool: kLutPoolBytesPerTable per pool table, filled by launch_lut_pool (K2 and the K2S round kernel copy from it)
+hipError_t launch_lut_pool(hipStream_t stream, const DevHuffTable *huff_pool, int n_tables, uint32_t *lut_pool);
 constexpr int kNumIdctLayoutClasses = 5;
 // Output layout class of a scan for INTERLEAVED_U8 (0 = generic bytewise path, else a specialised kernel).
 int idct_layout_class(const DevScan &s);
@@ -38,8 +40,8 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
-                                int max_rounds, int *rounds_used, uint32_t *lut_pool, int n_pool_tables);
-constexpr size_t kLutPoolBytesPerTable = 2 * 1024 * sizeof(uint32_t);  // fused DC + AC lookups of one pool table (lut_pool_kernel)
+                                int max_rounds, int *rounds_used, const uint32_t *lut_pool);
+constexpr size_t kLutPoolBytesPerTable = 2 * 2048 * sizeof(uint32_t);  // fused DC + AC lookups of one pool table (lut_pool_kernel)
 
 // progressive frames (K2P): the scans of one ordinal (position inside their frame) of every progressive frame in the batch
 hipError_t launch_progressive(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,

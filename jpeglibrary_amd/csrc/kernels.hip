@@ -684,6 +684,32 @@ __device__ __forceinline__ uint32_t k2_symbol(uint8_t *ring, K2Feed &f, K2Pos &p
     return err;
 }
 
+// Fused lookups (the format K2 builds per workgroup: total bits | code bits << 8 | category << 16 | zig-zag advance << 24,
+// kK2Miss / kK2BadCategory) for every table of the pool, both as a DC and as an AC table: the round kernel's workgroups
+// are short-lived, so they copy the lookup instead of deriving it.  Entry (table * 2 + is_dc) * 2048 + prefix.
+constexpr int kLutPoolBits = 11;  // K2 copies the pooled lookup as it is
+constexpr int kSrLutBits = 10;    // the round kernel keeps every other entry (a 10-bit prefix decides codes of up to 10 bits)
+__global__ __launch_bounds__(256) void lut_pool_kernel(const DevHuffTable *__restrict__ pool, uint32_t *__restrict__ lut_pool) {
+    const DevHuffTable &h = pool[blockIdx.x >> 1];
+    const bool is_dc = (blockIdx.x & 1) != 0;
+    for (uint32_t i = threadIdx.x; i < (1u << kLutPoolBits); i += 256) {
+        const uint32_t code16 = (i << (16 - kLutPoolBits)) | ((1u << (16 - kLutPoolBits)) - 1u);
+        const uint32_t e9 = h.lut[i >> (kLutPoolBits - kHuffLutBits)];
+        uint32_t size = e9 >> 8, sym = e9 & 0xFFu;
+        if (size == 0) {
+            size = kHuffLutBits + 1;
+            while (code16 > h.maxcode[size]) size++;
+            if (size <= (uint32_t)kLutPoolBits) sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
+        }
+        uint32_t e = kK2Miss;
+        if (size <= (uint32_t)kLutPoolBits) {
+            const uint32_t cat = is_dc ? sym : (sym & 15u);
+            e = cat > 16u ? kK2BadCategory : ((size + cat) | (size << 8) | (cat << 16) | ((is_dc ? 0u : k2_ac_advance(sym)) << 24));
+        }
+        lut_pool[(size_t)blockIdx.x * (1u << kLutPoolBits) + i] = e;
+    }
+}
+
 #ifdef JPGPU_K2_PROFILE
 __device__ unsigned long long k2_prof[8];
 #define K2_TICK() __builtin_readcyclecounter()
@@ -705,7 +731,8 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
                                                                     const uint32_t *__restrict__ ends_u,
                                                                     DevScanStatus *__restrict__ status,
                                                                     const DevHuffTable *__restrict__ huff_pool,
-                                                                    int16_t *__restrict__ coefs, int n_slots) {
+                                                                    int16_t *__restrict__ coefs, int n_slots,
+                                                                    const uint32_t *__restrict__ lut_pool) {
     constexpr uint32_t kTabBytes = (4u << LB) + kK2SmallBytes;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *tabs = smem;                                    // n_slots * kTabBytes
@@ -749,6 +776,11 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
         for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == slot;
         const K2Tab h = k2_tab<LB>(tabs, slot);
         uint32_t *lut = const_cast<uint32_t *>(h.lut);
+        if (LB == kLutPoolBits) {  // the lookup was derived once for the whole batch (lut_pool_kernel)
+            const uint4 *src = reinterpret_cast<const uint4 *>(lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * (1u << kLutPoolBits));
+            for (uint32_t i = tid; i < (1u << LB) / 4; i += 64 * WAVES) reinterpret_cast<uint4 *>(lut)[i] = src[i];
+            continue;
+        }
         for (uint32_t i = tid; i < (1u << LB); i += 64 * WAVES) {
             const uint32_t code16 = (i << (16 - LB)) | ((1u << (16 - LB)) - 1u);
             const uint32_t e9 = huff_pool[pi].lut[i >> (LB - kHuffLutBits)];
@@ -1557,31 +1589,6 @@ __device__ __forceinline__ void sub_stage_tables(const DevScan &s, const DevHuff
     __syncthreads();
 }
 
-// Fused lookups (the format K2 builds per workgroup: total bits | code bits << 8 | category << 16 | zig-zag advance << 24,
-// kK2Miss / kK2BadCategory) for every table of the pool, both as a DC and as an AC table: the round kernel's workgroups
-// are short-lived, so they copy the lookup instead of deriving it.  Entry (table * 2 + is_dc) * 2048 + prefix.
-constexpr int kSrLutBits = 10;
-__global__ __launch_bounds__(256) void lut_pool_kernel(const DevHuffTable *__restrict__ pool, uint32_t *__restrict__ lut_pool) {
-    const DevHuffTable &h = pool[blockIdx.x >> 1];
-    const bool is_dc = (blockIdx.x & 1) != 0;
-    for (uint32_t i = threadIdx.x; i < (1u << kSrLutBits); i += 256) {
-        const uint32_t code16 = (i << (16 - kSrLutBits)) | ((1u << (16 - kSrLutBits)) - 1u);
-        const uint32_t e9 = h.lut[i >> (kSrLutBits - kHuffLutBits)];
-        uint32_t size = e9 >> 8, sym = e9 & 0xFFu;
-        if (size == 0) {
-            size = kHuffLutBits + 1;
-            while (code16 > h.maxcode[size]) size++;
-            if (size <= (uint32_t)kSrLutBits) sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
-        }
-        uint32_t e = kK2Miss;
-        if (size <= (uint32_t)kSrLutBits) {
-            const uint32_t cat = is_dc ? sym : (sym & 15u);
-            e = cat > 16u ? kK2BadCategory : ((size + cat) | (size << 8) | (cat << 16) | ((is_dc ? 0u : k2_ac_advance(sym)) << 24));
-        }
-        lut_pool[(size_t)blockIdx.x * (1u << kSrLutBits) + i] = e;
-    }
-}
-
 // One synchronisation round.  exit_in/exit_out are double-buffered per-subsequence state words (index sub_off + sub).
 // A round only has to follow the symbol structure: code and magnitude LENGTHS, zig-zag advance, block and MCU phase, and
 // the DC differences (their per-component sums feed the predictor prefix); AC magnitudes are skipped, not extracted.
@@ -1627,9 +1634,12 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
         if (pi == 0xFFFF) continue;
         bool is_dc = false;
         for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
-        const uint4 *src = reinterpret_cast<const uint4 *>(lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * (1u << kSrLutBits));
-        uint4 *dst = reinterpret_cast<uint4 *>(luts + ((size_t)sl << kSrLutBits));
-        for (uint32_t i = tid; i < (1u << kSrLutBits) / 4; i += 256) dst[i] = src[i];
+        const uint32_t *src = lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * (1u << kLutPoolBits);
+        uint32_t *dst = luts + ((size_t)sl << kSrLutBits);
+        for (uint32_t i = tid; i < (1u << kSrLutBits); i += 256) {
+            const uint32_t e = src[2 * i];  // prefixes 2i and 2i+1 agree whenever the code has at most 10 bits
+            dst[i] = (e != kK2BadCategory && ((e & 0x80000000u) || ((e >> 8) & 0xFFu) > (uint32_t)kSrLutBits)) ? kK2Miss : e;
+        }
         const uint4 *ssrc = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&huff_pool[pi]) + offsetof(DevHuffTable, maxcode));
         uint4 *sdst = reinterpret_cast<uint4 *>(small + sl * kK2SmallBytes);
         if (tid < kK2SmallBytes / 16) sdst[tid] = ssrc[tid];
@@ -2580,7 +2590,7 @@ size_t huffman_lds_bytes(int n_slots) { return k2_lds_bytes(n_slots, n_slots <= 
 template <int LB>
 static hipError_t launch_huffman_lb(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                                     const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
-                                    int n_slots) {
+                                    int n_slots, const uint32_t *lut_pool) {
     const size_t lds = k2_lds_bytes(n_slots, LB);
     static bool configured = false;  // more than 64 KB of dynamic LDS has to be allowed once per kernel
     if (!configured) {
@@ -2590,16 +2600,23 @@ static hipError_t launch_huffman_lb(hipStream_t stream, const uint8_t *data, con
         configured = true;
     }
     hipLaunchKernelGGL((huffman_decode_kernel<kHuffWaves, LB>), dim3(n_work), dim3(64 * kHuffWaves), lds, stream, data, scans, work,
-                       ends, status, huff_pool, coefs, n_slots);
+                       ends, status, huff_pool, coefs, n_slots, lut_pool);
     return hipGetLastError();
 }
 
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                           const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
-                          int n_slots) {
+                          int n_slots, const uint32_t *lut_pool) {
     if (n_work <= 0) return hipSuccess;
-    if (n_slots <= 4) return launch_huffman_lb<11>(stream, data, scans, work, n_work, ends, status, huff_pool, coefs, n_slots);
-    return launch_huffman_lb<10>(stream, data, scans, work, n_work, ends, status, huff_pool, coefs, n_slots);
+    if (n_slots <= 4) return launch_huffman_lb<11>(stream, data, scans, work, n_work, ends, status, huff_pool, coefs, n_slots, lut_pool);
+    return launch_huffman_lb<10>(stream, data, scans, work, n_work, ends, status, huff_pool, coefs, n_slots, lut_pool);
+}
+
+// Fused lookups of every table of the pool (once per upload: the tables of a batch do not change between decodes).
+hipError_t launch_lut_pool(hipStream_t stream, const DevHuffTable *huff_pool, int n_tables, uint32_t *lut_pool) {
+    if (n_tables <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lut_pool_kernel, dim3(2 * n_tables), dim3(256), 0, stream, huff_pool, lut_pool);
+    return hipGetLastError();
 }
 
 template <int FMT, int LAY>
@@ -2679,11 +2696,11 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
-                                int max_rounds, int *rounds_used, uint32_t *lut_pool, int n_pool_tables) {
+                                int max_rounds, int *rounds_used, const uint32_t *lut_pool) {
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kMaxBlocksPerMcu * sizeof(uint32_t);
     const size_t lds_round = ((size_t)n_slots << (kSrLutBits + 2)) + (size_t)n_slots * kK2SmallBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
-    hipLaunchKernelGGL(lut_pool_kernel, dim3(2 * n_pool_tables), dim3(256), 0, stream, huff_pool, lut_pool);
+
     uint32_t *bufs[2] = {exit_a, exit_b};
     // changed_dev[r] is set by round r; the host looks at the flags only every kCheckEvery rounds (one sync per check)
     constexpr int kCheckEvery = 3;
