@@ -127,4 +127,17 @@ int jref_build_huffman(const uint8_t bits[16], const uint8_t *values, int nvalue
 /* JpegYCbCrToRgbConverter.ConvertYCbCr8ToRgb24 / ConvertYCbCr8ToRgba32 (ref: apps/JpegDecode/JpegYCbCrToRgbConverter.cs:134-206) */
 void jref_ycbcr8_to_rgb(const uint8_t *ycbcr, uint8_t *out, size_t count, int bytes_per_pixel);
 
+/* ---- encoder restatement (oracle/jpegenc.c; PARITY UNPINNED: the reference holds no encoder vectors) */
+/* JpegStandardQuantizationTable.ScaleByQuality (ref: JpegStandardQuantizationTable.cs:64-87) */
+void jref_scale_quant_table(const uint16_t *src_zigzag, int quality, uint16_t *dst_zigzag);
+/* code and length of `symbol` in a standard Huffman table: 0 DC lum, 1 AC lum, 2 DC chr, 3 AC chr */
+int jref_std_huffman_code(int table, int symbol, int *length);
+/* ShiftDataLevel + TransformFDCT + ZigZagAndQuantizeBlock (ref: JpegEncoder.cs:801-826, FastFloatingPointDCT.cs:194-362) */
+void jref_fdct_quantize_block(const int16_t *samples, const uint16_t *quant_zigzag, int16_t *out_zigzag);
+/* apps/JpegEncode/EncodeAction.cs call sequence (standard tables, optimizeCoding = false) on an interleaved 8-bit buffer */
+int jref_encode_8bit(const uint8_t *pixels, int width, int height, int components, int luma_h, int luma_v, int quality,
+                     uint8_t *out, size_t cap, size_t *out_len, int16_t *coef_tap);
+/* apps/JpegEncode/JpegRgbToYCbCrConverter.ConvertRgb24ToYCbCr8 */
+void jref_rgb_to_ycbcr8(const uint8_t *rgb, uint8_t *ycbcr, size_t count);
+
 #endif

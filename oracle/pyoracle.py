@@ -220,6 +220,55 @@ def ycbcr8_to_rgb(ycbcr: np.ndarray, rgba: bool = False, gray: bool = False) -> 
     return out
 
 
+def encode_8bit(pixels: np.ndarray, luma_h: int = 2, luma_v: int = 2, quality: int = 75, want_coefficients: bool = False):
+    """The reference encoder's EncodeAction sequence (standard tables, no optimisation) on an interleaved 8-bit image
+    (H, W, C) with C = 3 (Y, Cb, Cr) or 1.  Returns the JPEG bytes (and the quantised zig-zag blocks in encoding order)."""
+    L = lib()
+    a = np.ascontiguousarray(pixels, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a.reshape(a.shape[0], a.shape[1], 1)
+    h, w, c = a.shape
+    L.jref_encode_8bit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                   C.POINTER(C.c_size_t), C.c_void_p]
+    L.jref_encode_8bit.restype = C.c_int
+    ncomp = 1 if c == 1 else 3
+    mh, mv = luma_h, luma_v
+    mcus = (-(-w // (8 * mh))) * (-(-h // (8 * mv)))
+    nblocks = mcus * (mh * mv + (2 if ncomp == 3 else 0))
+    coefs = np.zeros((nblocks, 64), np.int16) if want_coefficients else None
+    cap = 1024 + w * h * c * 2 + nblocks * 8
+    out = np.empty(cap, np.uint8)
+    n = C.c_size_t(0)
+    rc = L.jref_encode_8bit(a.ctypes.data, w, h, c, luma_h, luma_v, quality, out.ctypes.data, cap, C.byref(n),
+                            coefs.ctypes.data if coefs is not None else None)
+    if rc != 0:
+        raise OracleError(4, "encoder output buffer too small")
+    data = out[:n.value].tobytes()
+    return (data, coefs) if want_coefficients else data
+
+
+def fdct_quantize_block(samples: np.ndarray, quant_zigzag: np.ndarray) -> np.ndarray:
+    L = lib()
+    L.jref_fdct_quantize_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.jref_fdct_quantize_block.restype = None
+    s = np.ascontiguousarray(samples, dtype=np.int16).reshape(-1, 64)
+    q = np.ascontiguousarray(quant_zigzag, dtype=np.uint16).reshape(64)
+    out = np.empty_like(s)
+    for i in range(s.shape[0]):
+        L.jref_fdct_quantize_block(s[i].ctypes.data, q.ctypes.data, out[i].ctypes.data)
+    return out
+
+
+def rgb_to_ycbcr8(rgb: np.ndarray) -> np.ndarray:
+    L = lib()
+    L.jref_rgb_to_ycbcr8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.jref_rgb_to_ycbcr8.restype = None
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    out = np.empty_like(a)
+    L.jref_rgb_to_ycbcr8(a.ctypes.data, out.ctypes.data, a.shape[0] * a.shape[1])
+    return out
+
+
 def decode_blocks(data: bytes):
     """All WriteBlock calls in order: list of (component_index, x, y, block[64] int16)."""
     calls = []
