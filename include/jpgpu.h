@@ -262,6 +262,37 @@ void jpgpu_decoder_reset_header(jpgpu_decoder *d);                              
 void jpgpu_decoder_reset_tables(jpgpu_decoder *d);                               /* ResetTables :960 */
 void jpgpu_decoder_reset_output_writer(jpgpu_decoder *d);                        /* ResetOutputWriter :975 */
 
+/* ------------------------------------------------------------------------------------------------ (4) encoder
+ * The step on the other side of the wire format: JpegEncoder.Encode() (ref: JpegEncoder.cs:255-291)
+ * for a batch of images, with the call sequence of apps/JpegEncode/EncodeAction.cs:38-63 (optimizeCoding = false):
+ *   SetQuantizationTable(ScaleByQuality(luminance, 0, quality)), SetQuantizationTable(ScaleByQuality(chrominance, 1, quality)),
+ *   SetHuffmanTable(DC/AC, 0/1, standard tables), AddComponent(1, 0, 0, 0, luma_h, luma_v) [, AddComponent(2 | 3, 1, 1, 1, 1, 1)],
+ *   SetInputReader(JpegBufferInputReader(width, height, components, pixels)), Encode().
+ * The output is the byte stream the reference writes (SOI, DQT, SOF0, DHT, SOS, entropy data, EOI).
+ * input_rgb != 0: pixels are R,G,B and JpegRgbToYCbCrConverter.ConvertRgb24ToYCbCr8 (apps/JpegEncode/
+ * JpegRgbToYCbCrConverter.cs:64-96) is applied first, like EncodeAction.cs:31-36 does. */
+typedef struct jpgpu_encode_params {
+    int32_t width, height;
+    int32_t components;      /* samples per pixel of the input buffer == encoded components: 1 or 3 */
+    int32_t luma_h, luma_v;  /* sampling factors of the first component (1, 2 or 4); the others are 1 x 1 */
+    int32_t quality;         /* 1..100, JpegStandardQuantizationTable.ScaleByQuality */
+    int32_t input_rgb;
+    int32_t reserved;
+} jpgpu_encode_params;
+typedef struct jpgpu_encoder jpgpu_encoder;
+
+int jpgpu_encoder_create(jpgpu_ctx *ctx, jpgpu_encoder **out);
+void jpgpu_encoder_destroy(jpgpu_encoder *e);
+/* SetInputReader for n images (host parse of nothing: pixels go to HBM as they are) */
+int jpgpu_encoder_upload(jpgpu_encoder *e, const uint8_t *const *pixels, const jpgpu_encode_params *params, int n);
+/* Encode(): FDCT + quantise, Huffman code lengths, bit emission, byte stuffing -- all on the device */
+int jpgpu_encoder_encode(jpgpu_encoder *e);
+int jpgpu_encoder_encoded_size(const jpgpu_encoder *e, int i, size_t *bytes);
+int jpgpu_encoder_download(jpgpu_encoder *e, int i, void *dst, size_t cap);                       /* the IBufferWriter's content */
+void *jpgpu_encoder_output_device(const jpgpu_encoder *e, int i, size_t *bytes);                  /* stream i, resident in HBM */
+/* quantised zig-zag blocks in encoding order (what ZigZagAndQuantizeBlock produced, JpegEncoder.cs:812-826) */
+int jpgpu_encoder_download_coefficients(jpgpu_encoder *e, int i, int16_t *dst, size_t cap_blocks);
+
 #ifdef __cplusplus
 }
 #endif

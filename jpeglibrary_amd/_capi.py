@@ -13,7 +13,7 @@ OK, ERR_INVALID_DATA, ERR_INVALID_OPERATION, ERR_NOT_SUPPORTED, ERR_ARGUMENT, ER
 FMT_INTERLEAVED_U8, FMT_PLANAR_U8, FMT_PLANAR_I16, FMT_RGB_U8, FMT_RGBA_U8 = 0, 1, 2, 3, 4
 
 DETAIL_NAMES = {0: "NONE", 1: "INVALID_HUFFMAN_CODE", 2: "MARKER_IN_DATA", 3: "STREAM_ENDED", 4: "EXPECT_RESTART",
-                5: "MISSING_TABLE", 6: "UNSUPPORTED_FRAME", 7: "BAD_HEADER", 8: "EARLY_EOI"}
+                5: "MISSING_TABLE", 6: "UNSUPPORTED_FRAME", 7: "BAD_HEADER", 8: "EARLY_EOI", 9: "UNEXPECTED_END"}
 
 
 class FrameComponent(C.Structure):
@@ -54,6 +54,11 @@ class ImageInfo(C.Structure):
 class ImageResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("detail", C.c_int32), ("error_interval", C.c_uint32), ("decoded_mcus", C.c_uint32),
                 ("bytes_consumed", C.c_uint32), ("terminator", C.c_uint32)]
+
+
+class EncodeParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("components", C.c_int32), ("luma_h", C.c_int32), ("luma_v", C.c_int32),
+                ("quality", C.c_int32), ("input_rgb", C.c_int32), ("reserved", C.c_int32)]
 
 
 WRITE_BLOCK_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int)
@@ -116,6 +121,14 @@ SYMBOLS = [
     ("jpgpu_decoder_reset_header", None, [_P]),
     ("jpgpu_decoder_reset_tables", None, [_P]),
     ("jpgpu_decoder_reset_output_writer", None, [_P]),
+    ("jpgpu_encoder_create", C.c_int, [_P, C.POINTER(_P)]),
+    ("jpgpu_encoder_destroy", None, [_P]),
+    ("jpgpu_encoder_upload", C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(EncodeParams), C.c_int]),
+    ("jpgpu_encoder_encode", C.c_int, [_P]),
+    ("jpgpu_encoder_encoded_size", C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
+    ("jpgpu_encoder_download", C.c_int, [_P, C.c_int, C.c_void_p, C.c_size_t]),
+    ("jpgpu_encoder_output_device", C.c_void_p, [_P, C.c_int, C.POINTER(C.c_size_t)]),
+    ("jpgpu_encoder_download_coefficients", C.c_int, [_P, C.c_int, C.c_void_p, C.c_size_t]),
 ]
 
 

@@ -9,6 +9,7 @@
 
 #include "../../include/jpgpu.h"
 #include "device_batch.h"
+#include "device_encode.h"
 #include "host.h"
 
 using namespace jpgpu;
@@ -655,6 +656,35 @@ void jpgpu_decoder_reset(jpgpu_decoder *d) {
     jpgpu_decoder_reset_header(d);
     jpgpu_decoder_reset_tables(d);
     jpgpu_decoder_reset_output_writer(d);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ (4) encoder
+
+struct jpgpu_encoder {
+    jpgpu_ctx *ctx;
+    EncodeBatch impl;
+    explicit jpgpu_encoder(jpgpu_ctx *c) : ctx(c), impl(c) {}
+};
+
+extern "C" {
+
+int jpgpu_encoder_create(jpgpu_ctx *ctx, jpgpu_encoder **out) {
+    if (!ctx || !out) return JPGPU_ERR_ARGUMENT;
+    *out = new (std::nothrow) jpgpu_encoder(ctx);
+    return *out ? JPGPU_OK : JPGPU_ERR_OUT_OF_MEMORY;
+}
+void jpgpu_encoder_destroy(jpgpu_encoder *enc) { delete enc; }
+int jpgpu_encoder_upload(jpgpu_encoder *enc, const uint8_t *const *pixels, const jpgpu_encode_params *params, int n) {
+    JPGPU_GUARD(enc, enc->impl.upload(pixels, params, n));
+}
+int jpgpu_encoder_encode(jpgpu_encoder *enc) { JPGPU_GUARD(enc, enc->impl.encode()); }
+int jpgpu_encoder_encoded_size(const jpgpu_encoder *enc, int i, size_t *bytes) { return enc ? enc->impl.encoded_size(i, bytes) : JPGPU_ERR_ARGUMENT; }
+int jpgpu_encoder_download(jpgpu_encoder *enc, int i, void *dst, size_t cap) { JPGPU_GUARD(enc, enc->impl.download(i, dst, cap)); }
+void *jpgpu_encoder_output_device(const jpgpu_encoder *enc, int i, size_t *bytes) { return enc ? enc->impl.output_device(i, bytes) : nullptr; }
+int jpgpu_encoder_download_coefficients(jpgpu_encoder *enc, int i, int16_t *dst, size_t cap_blocks) {
+    JPGPU_GUARD(enc, enc->impl.download_coefficients(i, dst, cap_blocks));
 }
 
 }  // extern "C"

@@ -1,0 +1,45 @@
+// jpeglibrary_amd/csrc/device_encode.h -- device-resident batch encode (see device_encode.cpp)
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/jpgpu.h"
+#include "device_batch.h"
+#include "encode_kernels.h"
+
+namespace jpgpu {
+
+void rgb_ycc_factors(int32_t out[8]);
+
+class EncodeBatch {
+  public:
+    explicit EncodeBatch(jpgpu_ctx *ctx) : ctx_(ctx) {}
+    ~EncodeBatch();
+    int upload(const uint8_t *const *pixels, const jpgpu_encode_params *params, int n);  // SetInputReader x n (+ H2D)
+    int encode();                                                                        // JpegEncoder.Encode() x n
+    int size() const { return (int)images_.size(); }
+    int encoded_size(int i, size_t *bytes) const;
+    int download(int i, void *dst, size_t cap);
+    int download_coefficients(int i, int16_t *dst, size_t cap_blocks);
+    uint32_t total_blocks(int i) const { return (i >= 0 && i < (int)images_.size()) ? images_[i].total_blocks : 0; }
+    void *output_device(int i, size_t *bytes) const {
+        if (i < 0 || i >= (int)images_.size() || !encoded_) return nullptr;
+        if (bytes) *bytes = (size_t)out_len_[i];
+        return (uint8_t *)d_out_.ptr + images_[i].out_off;
+    }
+
+  private:
+    int fail(int status, const std::string &msg);
+    int hip_fail(hipError_t e, const char *what);
+    jpgpu_ctx *ctx_;
+    std::vector<DevEncImage> images_;
+    std::vector<std::vector<uint8_t>> headers_;
+    std::vector<uint64_t> out_len_;
+    bool encoded_ = false;
+    uint64_t total_blocks_ = 0, out_cap_ = 0;
+    int n_work_mcu_ = 0, n_work_blk_ = 0, n_work_chunk_ = 0;
+    DevBuffer d_pixels_, d_images_, d_tables_, d_work_mcu_, d_work_blk_, d_work_chunk_, d_coefs_, d_bits_, d_bit_off_, d_raw_bits_, d_raw_,
+        d_chunk_ff_, d_out_, d_out_len_;
+};
+
+}  // namespace jpgpu

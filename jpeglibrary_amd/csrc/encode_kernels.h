@@ -1,0 +1,52 @@
+// jpeglibrary_amd/csrc/encode_kernels.h -- device structures and launch wrappers of the encoder kernels (encode_kernels.hip)
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace jpgpu {
+
+// One image to encode: the reference's JpegEncoder state after the EncodeAction call sequence
+// (ref: apps/JpegEncode/EncodeAction.cs:38-63): luma component with sampling (luma_h, luma_v) and table 0, two chroma
+// components 1x1 with table 1 (or a single component).
+struct alignas(16) DevEncImage {
+    uint64_t px_off;    // input pixels, byte offset into the batch's pixel buffer (interleaved, in_components per pixel)
+    uint64_t coef_off;  // first block in the coefficient buffer (blocks of 64 int16, zig-zag, MCU order)
+    uint64_t raw_off;   // raw (unstuffed) entropy bytes, byte offset into the raw buffer (256-byte aligned)
+    uint64_t out_off;   // finished stream, byte offset into the output buffer
+    uint32_t width, height;
+    uint32_t in_components;  // samples per input pixel
+    uint32_t components;     // 1 or 3 encoded components
+    uint32_t luma_h, luma_v;
+    uint32_t mcus_per_line, mcus_per_column, bpm, total_blocks;
+    uint32_t header_len;  // bytes of SOI..SOS already placed at out_off
+    uint32_t chunk_off;   // first entry in the per-chunk FF counters (stuffing)
+    uint32_t input_rgb;   // 1: pixels are R,G,B and are converted like JpegRgbToYCbCrConverter.ConvertRgb24ToYCbCr8
+    uint32_t pad0;
+    int32_t r2y[8];       // Fix() factors of the RGB -> YCbCr tables (host: rgb_ycc_factors)
+    uint16_t quant[2][64];  // zig-zag quantisation tables: luma, chroma
+};
+static_assert(sizeof(DevEncImage) % 16 == 0, "DevEncImage must be a multiple of 16 bytes");
+
+// JpegHuffmanEncodingTable.GetCode by symbol (ref: JpegHuffmanEncodingTable.cs:94-100); len 0 = no code
+struct EncHuffTable {
+    uint16_t code[256];
+    uint8_t len[256];
+};
+
+struct EncWork {
+    uint32_t image;
+    uint32_t first;  // first MCU / block / chunk of the workgroup (256 per workgroup)
+};
+
+hipError_t launch_fdct_quant(hipStream_t stream, const uint8_t *pixels, const DevEncImage *images, const EncWork *work, int n_work,
+                             int16_t *coefs);
+hipError_t launch_block_bits(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
+                             const int16_t *coefs, uint32_t *bits, int n_images, uint64_t *bit_off, uint64_t *raw_bits);
+hipError_t launch_emit(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
+                       const int16_t *coefs, const uint64_t *bit_off, const uint64_t *raw_bits, uint8_t *raw);
+constexpr uint32_t kEncStuffChunk = 4096;
+hipError_t launch_stuff(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const uint64_t *raw_bits,
+                        const uint8_t *raw, uint32_t *chunk_ff, uint8_t *out, uint64_t *out_len);
+
+}  // namespace jpgpu

@@ -1,0 +1,427 @@
+// jpeglibrary_amd/csrc/encode_kernels.hip -- the baseline ENCODER's hot path on gfx950.
+//
+// Reference (paths relative to /root/reference/src/JpegLibrary): JpegEncoder.WriteScanData (JpegEncoder.cs:662-741) is a
+// serial loop per block: ReadBlock (+ 2x2 box sub-sampling) -> ShiftDataLevel -> FastFloatingPointDCT.TransformFDCT ->
+// ZigZagAndQuantizeBlock -> EncodeBlock (Huffman emit through JpegWriter.WriteBits, FF byte stuffing on flush).
+// Here it becomes four device stages over a batch of images:
+//   E1 fdct_quant_kernel    one lane per MCU: gather / sub-sample the samples, float32 FDCT in the reference's operation
+//                           order (no FMA), quantise -> int16 zig-zag blocks in MCU order (the decoder's layout)
+//   E2 block_bits_kernel    one lane per block: bits its Huffman codes + magnitudes will take; prefix sums give every
+//                           block its bit offset in the scan (encoding is embarrassingly parallel once lengths are known)
+//   E3 emit_kernel          one lane per block: the codes again, ORed into the raw bit stream at the block's offset
+//   E4 stuff_*_kernel       FF -> FF 00 (JpegWriter.FlushRegister), the final one-bits padding, EOI behind the data
+// MUST be compiled with -ffp-contract=off (the reference's Vector4 arithmetic never fuses a*b+c).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "encode_kernels.h"
+
+namespace jpgpu {
+
+// ref: JpegZigZag.cs:27-38 (zig-zag index -> natural index)
+__device__ constexpr uint8_t kEncNat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                            41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                            30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// ------------------------------------------------------------------------------------------------ E1
+
+// FDCT8x4_LeftPart / RightPart for one column of eight values (ref: FastFloatingPointDCT.cs:194-311).
+// Operation order and parenthesisation are normative.
+__device__ __forceinline__ void fdct8(float &s0, float &s1, float &s2, float &s3, float &s4, float &s5, float &s6, float &s7) {
+    float c0 = s0, c1 = s7;
+    const float t0 = c0 + c1, t7 = c0 - c1;
+    c1 = s6;
+    c0 = s1;
+    const float t1 = c0 + c1, t6 = c0 - c1;
+    c1 = s5;
+    c0 = s2;
+    const float t2 = c0 + c1, t5 = c0 - c1;
+    c0 = s3;
+    c1 = s4;
+    const float t3 = c0 + c1, t4 = c0 - c1;
+    c0 = t0 + t3;
+    float c3 = t0 - t3;
+    c1 = t1 + t2;
+    float c2 = t1 - t2;
+    s0 = c0 + c1;
+    s4 = c0 - c1;
+    float w0 = 0.541196f, w1 = 1.306563f;
+    s2 = (w0 * c2) + (w1 * c3);
+    s6 = (w0 * c3) - (w1 * c2);
+    w0 = 1.175876f;
+    w1 = 0.785695f;
+    c3 = (w0 * t4) + (w1 * t7);
+    c0 = (w0 * t7) - (w1 * t4);
+    w0 = 1.387040f;
+    w1 = 0.275899f;
+    c2 = (w0 * t5) + (w1 * t6);
+    c1 = (w0 * t6) - (w1 * t5);
+    s3 = c0 - c2;
+    s5 = c3 - c1;
+    const float invsqrt2 = 0.707107f;
+    c0 = (c0 + c2) * invsqrt2;
+    c3 = (c3 + c1) * invsqrt2;
+    s1 = c0 + c3;
+    s7 = c0 - c3;
+}
+
+// TransformFDCT (ref: :343-362): the reference transposes, runs the column butterfly, transposes, runs it again; in
+// element terms pass 1 transforms every ROW of the block (over x), pass 2 every COLUMN of the result, then x 0.125.
+__device__ __forceinline__ void block_fdct(float (&f)[64]) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) fdct8(f[r * 8 + 0], f[r * 8 + 1], f[r * 8 + 2], f[r * 8 + 3], f[r * 8 + 4], f[r * 8 + 5], f[r * 8 + 6], f[r * 8 + 7]);
+#pragma unroll
+    for (int c = 0; c < 8; c++) fdct8(f[0 * 8 + c], f[1 * 8 + c], f[2 * 8 + c], f[3 * 8 + c], f[4 * 8 + c], f[5 * 8 + c], f[6 * 8 + c], f[7 * 8 + c]);
+#pragma unroll
+    for (int i = 0; i < 64; i++) f[i] = f[i] * 0.1250f;
+}
+
+// One input sample of component c at pixel (x, y); outside the image the reader leaves zeros
+// (ref: apps/JpegEncode/JpegBufferInputReader.cs:27-52).  RGB input is converted like
+// apps/JpegEncode/JpegRgbToYCbCrConverter.cs:64-96 (the tables are multiples of the Fix() factors, computed here).
+__device__ __forceinline__ int32_t enc_sample(const uint8_t *px, const DevEncImage &im, uint32_t c, uint32_t x, uint32_t y) {
+    if (x >= im.width || y >= im.height) return 0;
+    const uint8_t *p = px + ((size_t)y * im.width + x) * im.in_components;
+    if (!im.input_rgb) return p[c];
+    const int32_t r = p[0], g = p[1], b = p[2];
+    if (c == 0) return (im.r2y[0] * r + im.r2y[1] * g + im.r2y[2] * b + 32768) >> 16;
+    if (c == 1) return (-im.r2y[3] * r - im.r2y[4] * g + im.r2y[5] * b + (128 << 16) + 32767) >> 16;
+    return (im.r2y[5] * r - im.r2y[6] * g - im.r2y[7] * b + (128 << 16) + 32767) >> 16;
+}
+
+// ShiftDataLevel + TransformFDCT + ZigZagAndQuantizeBlock (ref: JpegEncoder.cs:801-826): q[i] = (short)MathF.Round(F / Q)
+__device__ __forceinline__ void fdct_quantize(const int32_t (&smp)[64], const uint16_t *quant, int32_t (&q)[64]) {
+    float f[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) f[i] = (float)(smp[i] - 128);
+    block_fdct(f);
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        const float v = f[kEncNat[i]] / (float)quant[i];
+        q[i] = (int32_t)(int16_t)(int32_t)__builtin_rintf(v);  // half to even; (short) wraps
+    }
+}
+
+// One lane per MCU.  Blocks of an MCU are produced in encoding order because the reference's sub-sampling reader
+// accumulates into the ONE block buffer WriteScanData reuses (:712, :788-799): a sub-sampled component's block starts from
+// the previous block's quantised coefficients.  `prev` carries that buffer.
+__global__ __launch_bounds__(256) void fdct_quant_kernel(const uint8_t *__restrict__ pixels, const DevEncImage *__restrict__ images,
+                                                         const EncWork *__restrict__ work, int16_t *__restrict__ coefs) {
+    const EncWork wk = work[blockIdx.x];
+    const DevEncImage &im = images[wk.image];
+    const uint32_t mcu = wk.first + threadIdx.x;
+    const uint32_t total_mcus = im.mcus_per_line * im.mcus_per_column;
+    if (mcu >= total_mcus) return;
+    const uint8_t *px = pixels + im.px_off;
+    const uint32_t mx = mcu % im.mcus_per_line, my = mcu / im.mcus_per_line;
+    const uint32_t max_h = im.luma_h, max_v = im.luma_v;
+    int16_t *out = coefs + (im.coef_off + (uint64_t)mcu * im.bpm) * 64;
+    int32_t prev[64];  // the reference's inputBuffer: the previous block's quantised zig-zag coefficients
+#pragma unroll
+    for (int i = 0; i < 64; i++) prev[i] = 0;
+    // note: the buffer also survives from one MCU to the next, but an MCU always starts with a full-resolution luma
+    // block, which overwrites it completely -- except for images with ONLY sub-sampled blocks, which cannot exist
+    uint32_t b = 0;
+    for (uint32_t c = 0; c < im.components; c++) {
+        const uint32_t h = c == 0 ? max_h : 1u, v = c == 0 ? max_v : 1u;
+        const uint32_t hs = max_h / h, vs = max_v / v;
+        const uint16_t *quant = im.quant[c == 0 ? 0 : 1];
+        for (uint32_t by = 0; by < v; by++)
+            for (uint32_t bx = 0; bx < h; bx++, b++) {
+                const uint32_t x0 = (mx * max_h + bx) * 8, y0 = (my * max_v + by) * 8;  // full-resolution origin (:709-712)
+                int32_t smp[64];
+                if (hs == 1 && vs == 1) {
+#pragma unroll
+                    for (int i = 0; i < 64; i++) smp[i] = enc_sample(px, im, c, x0 + (i & 7), y0 + (i >> 3));
+                } else {
+                    // ReadBlockWithSubsample (:756-799): box sums on top of the stale buffer, then (+delta) >> shift
+                    const uint32_t hshift = 31 - __builtin_clz(hs), vshift = 31 - __builtin_clz(vs);
+                    const uint32_t total = hshift + vshift;
+#pragma unroll
+                    for (int i = 0; i < 64; i++) {
+                        int32_t acc = prev[i];
+                        const uint32_t ox = x0 + ((i & 7) << hshift), oy = y0 + ((i >> 3) << vshift);
+                        for (uint32_t dy = 0; dy < vs; dy++)
+                            for (uint32_t dx = 0; dx < hs; dx++) acc = (int32_t)(int16_t)(acc + enc_sample(px, im, c, ox + dx, oy + dy));
+                        smp[i] = (int32_t)(int16_t)((acc + (1 << (total - 1))) >> total);
+                    }
+                }
+                fdct_quantize(smp, quant, prev);
+                uint32_t packed[32];
+#pragma unroll
+                for (int i = 0; i < 32; i++) packed[i] = ((uint32_t)prev[2 * i] & 0xFFFFu) | ((uint32_t)prev[2 * i + 1] << 16);
+                uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)b * 64);
+#pragma unroll
+                for (int i = 0; i < 8; i++) dst[i] = uint4{packed[4 * i], packed[4 * i + 1], packed[4 * i + 2], packed[4 * i + 3]};
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ E2 / E3
+
+// bits needed for |a| (ref: BitCountTable, JpegEncoder.cs:938-956)
+__device__ __forceinline__ uint32_t enc_bit_count(uint32_t a) { return a ? 32u - (uint32_t)__builtin_clz(a) : 0u; }
+
+// scan position of a block: component, and the DC value it is predicted from (EncodeBlock :835-838)
+__device__ __forceinline__ int32_t enc_dc_predictor(const DevEncImage &im, const int16_t *img_coefs, uint32_t mcu, uint32_t b, uint32_t &comp) {
+    const uint32_t ny = im.luma_h * im.luma_v;
+    comp = b < ny ? 0u : b - ny + 1u;
+    if (comp == 0 && b > 0) return img_coefs[((size_t)mcu * im.bpm + b - 1) * 64];
+    if (mcu == 0) return 0;
+    const uint32_t pb = comp == 0 ? ny - 1 : b;
+    return img_coefs[((size_t)(mcu - 1) * im.bpm + pb) * 64];
+}
+
+// Walks the symbols of one block in EncodeBlock order (:828-870) and hands (code, length) pairs to `put`.
+template <typename Put>
+__device__ __forceinline__ void enc_block_symbols(const uint4 (&cv)[8], int32_t dc_pred, const EncHuffTable &dc, const EncHuffTable &ac, Put put) {
+    uint32_t w[32] = {cv[0].x, cv[0].y, cv[0].z, cv[0].w, cv[1].x, cv[1].y, cv[1].z, cv[1].w, cv[2].x, cv[2].y, cv[2].z,
+                      cv[2].w, cv[3].x, cv[3].y, cv[3].z, cv[3].w, cv[4].x, cv[4].y, cv[4].z, cv[4].w, cv[5].x, cv[5].y,
+                      cv[5].z, cv[5].w, cv[6].x, cv[6].y, cv[6].z, cv[6].w, cv[7].x, cv[7].y, cv[7].z, cv[7].w};
+    auto coef = [&](int i) -> int32_t { return (i & 1) ? ((int32_t)w[i >> 1] >> 16) : (int32_t)(int16_t)(w[i >> 1] & 0xFFFFu); };
+    // EncodeRunLength (:893-918)
+    auto run_length = [&](const EncHuffTable &t, uint32_t run, int32_t value) {
+        int32_t a = value, bb = value;
+        if (a < 0) {
+            a = -value;
+            bb = value - 1;
+        }
+        const uint32_t bits = enc_bit_count((uint32_t)a & 0xFFFFu);
+        const uint32_t sym = ((run << 4) | bits) & 0xFFu;
+        put(t.code[sym], t.len[sym]);
+        if (bits) put((uint32_t)bb & ((1u << bits) - 1u), bits);
+    };
+    const int32_t dcv = coef(0);
+    run_length(dc, 0, dcv - dc_pred);
+    uint32_t run = 0;
+#pragma unroll 1
+    for (int i = 1; i < 64; i++) {
+        const int32_t t = coef(i);
+        if (t == 0) {
+            run++;
+        } else {
+            while (run > 15) {
+                put(ac.code[0xF0], ac.len[0xF0]);
+                run -= 16;
+            }
+            run_length(ac, run, t);
+            run = 0;
+        }
+    }
+    if (run > 0) put(ac.code[0], ac.len[0]);
+}
+
+__global__ __launch_bounds__(256) void block_bits_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
+                                                         const EncHuffTable *__restrict__ tables, const int16_t *__restrict__ coefs,
+                                                         uint32_t *__restrict__ bits) {
+    const EncWork wk = work[blockIdx.x];
+    const DevEncImage &im = images[wk.image];
+    const uint32_t blk = wk.first + threadIdx.x;
+    if (blk >= im.total_blocks) return;
+    const int16_t *img_coefs = coefs + im.coef_off * 64;
+    const uint32_t mcu = blk / im.bpm, b = blk - mcu * im.bpm;
+    uint32_t comp;
+    const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
+    const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)blk * 64);
+    const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
+    uint32_t n = 0;
+    enc_block_symbols(cv, pred, tables[comp == 0 ? 0 : 2], tables[comp == 0 ? 1 : 3], [&](uint32_t, uint32_t len) { n += len; });
+    bits[im.coef_off + blk] = n;
+}
+
+// Exclusive prefix sums of the block bit counts of one image (one workgroup per image); total -> images' raw_bits.
+__global__ __launch_bounds__(1024) void block_offsets_kernel(const DevEncImage *__restrict__ images, const uint32_t *__restrict__ bits,
+                                                             uint64_t *__restrict__ bit_off, uint64_t *__restrict__ raw_bits) {
+    const DevEncImage &im = images[blockIdx.x];
+    __shared__ uint64_t sh[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (im.total_blocks + 1023) / 1024;
+    const uint32_t lo = tid * per, hi = lo + per < im.total_blocks ? lo + per : im.total_blocks;
+    uint64_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += bits[im.coef_off + i];
+    sh[tid] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint64_t v = tid >= o ? sh[tid - o] : 0;
+        __syncthreads();
+        sh[tid] += v;
+        __syncthreads();
+    }
+    uint64_t run = sh[tid] - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+        bit_off[im.coef_off + i] = run;
+        run += bits[im.coef_off + i];
+    }
+    if (tid == 1023) raw_bits[blockIdx.x] = sh[1023];
+}
+
+// One lane per block: its codes ORed into the raw bit stream (MSB-first) at its bit offset.  The stream is kept as
+// big-endian 32-bit words, i.e. every word is stored byte-swapped; words shared with a neighbouring block are combined by
+// atomicOr (the buffer is zeroed before), which commutes with the byte swap.
+__global__ __launch_bounds__(256) void emit_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
+                                                   const EncHuffTable *__restrict__ tables, const int16_t *__restrict__ coefs,
+                                                   const uint64_t *__restrict__ bit_off, const uint64_t *__restrict__ raw_bits,
+                                                   uint8_t *__restrict__ raw) {
+    const EncWork wk = work[blockIdx.x];
+    const DevEncImage &im = images[wk.image];
+    const uint32_t blk = wk.first + threadIdx.x;
+    if (blk >= im.total_blocks) return;
+    const int16_t *img_coefs = coefs + im.coef_off * 64;
+    const uint32_t mcu = blk / im.bpm, b = blk - mcu * im.bpm;
+    uint32_t comp;
+    const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
+    const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)blk * 64);
+    const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
+    uint32_t *words = reinterpret_cast<uint32_t *>(raw + im.raw_off);
+    const uint64_t start = bit_off[im.coef_off + blk];
+    uint64_t wi = start >> 5;            // current word
+    uint32_t fill = (uint32_t)(start & 31);  // bits already taken in it (by earlier blocks)
+    uint32_t acc = 0;                    // bits of the current word, left aligned below `fill`
+    auto put = [&](uint32_t code, uint32_t len) {
+        while (len) {
+            const uint32_t room = 32u - fill;
+            const uint32_t take = len < room ? len : room;
+            const uint32_t part = (take == 32u) ? code : ((code >> (len - take)) & ((1u << take) - 1u));
+            acc |= (take == 32u) ? part : (part << (room - take));
+            fill += take;
+            len -= take;
+            if (fill == 32u) {
+                atomicOr(&words[wi], __builtin_bswap32(acc));
+                wi++;
+                fill = 0;
+                acc = 0;
+            }
+        }
+    };
+    enc_block_symbols(cv, pred, tables[comp == 0 ? 0 : 2], tables[comp == 0 ? 1 : 3], put);
+    if (blk == im.total_blocks - 1) {
+        // ExitBitMode (ref: JpegWriter.cs:123-147): pad the last byte with one-bits
+        const uint32_t rem = (uint32_t)((8u - (raw_bits[wk.image] & 7u)) & 7u);
+        if (rem) put((1u << rem) - 1u, rem);
+    }
+    if (fill) atomicOr(&words[wi], __builtin_bswap32(acc));
+}
+
+// ------------------------------------------------------------------------------------------------ E4: byte stuffing
+
+constexpr uint32_t kStuffChunk = 4096;  // raw bytes per workgroup (256 lanes x 16)
+
+__global__ __launch_bounds__(256) void stuff_count_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
+                                                          const uint64_t *__restrict__ raw_bits, const uint8_t *__restrict__ raw,
+                                                          uint32_t *__restrict__ chunk_ff) {
+    const EncWork wk = work[blockIdx.x];
+    const DevEncImage &im = images[wk.image];
+    const uint64_t raw_len = (raw_bits[wk.image] + 7) >> 3;
+    const uint64_t first = (uint64_t)wk.first * kStuffChunk + (uint64_t)threadIdx.x * 16;
+    uint32_t n = 0;
+    if (first < raw_len) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(raw + im.raw_off + first);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (first + j < raw_len && ((w[j >> 2] >> ((j & 3) * 8)) & 0xFFu) == 0xFFu) n++;
+    }
+    __shared__ uint32_t sh;
+    if (threadIdx.x == 0) sh = 0;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sh, n);
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_ff[im.chunk_off + wk.first] = sh;
+}
+
+__global__ __launch_bounds__(256) void stuff_write_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
+                                                          const uint64_t *__restrict__ raw_bits, const uint8_t *__restrict__ raw,
+                                                          const uint32_t *__restrict__ chunk_ff, uint8_t *__restrict__ out,
+                                                          uint64_t *__restrict__ out_len) {
+    const EncWork wk = work[blockIdx.x];
+    const DevEncImage &im = images[wk.image];
+    const uint64_t raw_len = (raw_bits[wk.image] + 7) >> 3;
+    const uint32_t tid = threadIdx.x;
+    // FF bytes in the chunks before this one
+    __shared__ uint32_t sh_before, sh_wave[4];
+    if (tid == 0) sh_before = 0;
+    __syncthreads();
+    {
+        uint32_t s = 0;
+        for (uint32_t i = tid; i < wk.first; i += 256) s += chunk_ff[im.chunk_off + i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if ((tid & 63) == 0 && s) atomicAdd(&sh_before, s);
+    }
+    __syncthreads();
+    const uint64_t first = (uint64_t)wk.first * kStuffChunk + (uint64_t)tid * 16;
+    uint32_t w[4] = {0, 0, 0, 0}, mine = 0, valid = 0;
+    if (first < raw_len) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(raw + im.raw_off + first);
+        w[0] = v.x;
+        w[1] = v.y;
+        w[2] = v.z;
+        w[3] = v.w;
+        valid = raw_len - first < 16 ? (uint32_t)(raw_len - first) : 16u;
+        for (uint32_t j = 0; j < valid; j++)
+            if (((w[j >> 2] >> ((j & 3) * 8)) & 0xFFu) == 0xFFu) mine++;
+    }
+    // exclusive scan of `mine` over the workgroup
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= (uint32_t)o) incl += t;
+    }
+    if ((tid & 63) == 63) sh_wave[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = sh_before;
+    for (uint32_t k = 0; k < (tid >> 6); k++) before += sh_wave[k];
+    before += incl - mine;
+    uint8_t *dst = out + im.out_off + im.header_len + first + before;
+    for (uint32_t j = 0; j < valid; j++) {
+        const uint8_t bch = (uint8_t)((w[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
+        *dst++ = bch;
+        if (bch == 0xFF) *dst++ = 0;
+    }
+    // the lane holding the last raw byte closes the stream: EOI (WriteEndOfImage :930-933) and the total length
+    if (valid && first + valid == raw_len) {
+        dst[0] = 0xFF;
+        dst[1] = 0xD9;
+        out_len[wk.image] = im.header_len + raw_len + before + mine + 2;
+    }
+    if (raw_len == 0 && wk.first == 0 && tid == 0) {
+        uint8_t *d0 = out + im.out_off + im.header_len;
+        d0[0] = 0xFF;
+        d0[1] = 0xD9;
+        out_len[wk.image] = im.header_len + 2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launch wrappers
+
+hipError_t launch_fdct_quant(hipStream_t stream, const uint8_t *pixels, const DevEncImage *images, const EncWork *work, int n_work,
+                             int16_t *coefs) {
+    if (n_work <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fdct_quant_kernel, dim3(n_work), dim3(256), 0, stream, pixels, images, work, coefs);
+    return hipGetLastError();
+}
+hipError_t launch_block_bits(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
+                             const int16_t *coefs, uint32_t *bits, int n_images, uint64_t *bit_off, uint64_t *raw_bits) {
+    if (n_work <= 0) return hipSuccess;
+    hipLaunchKernelGGL(block_bits_kernel, dim3(n_work), dim3(256), 0, stream, images, work, tables, coefs, bits);
+    hipLaunchKernelGGL(block_offsets_kernel, dim3(n_images), dim3(1024), 0, stream, images, bits, bit_off, raw_bits);
+    return hipGetLastError();
+}
+hipError_t launch_emit(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
+                       const int16_t *coefs, const uint64_t *bit_off, const uint64_t *raw_bits, uint8_t *raw) {
+    if (n_work <= 0) return hipSuccess;
+    hipLaunchKernelGGL(emit_kernel, dim3(n_work), dim3(256), 0, stream, images, work, tables, coefs, bit_off, raw_bits, raw);
+    return hipGetLastError();
+}
+hipError_t launch_stuff(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const uint64_t *raw_bits,
+                        const uint8_t *raw, uint32_t *chunk_ff, uint8_t *out, uint64_t *out_len) {
+    if (n_work <= 0) return hipSuccess;
+    hipLaunchKernelGGL(stuff_count_kernel, dim3(n_work), dim3(256), 0, stream, images, work, raw_bits, raw, chunk_ff);
+    hipLaunchKernelGGL(stuff_write_kernel, dim3(n_work), dim3(256), 0, stream, images, work, raw_bits, raw, chunk_ff, out, out_len);
+    return hipGetLastError();
+}
+
+}  // namespace jpgpu
