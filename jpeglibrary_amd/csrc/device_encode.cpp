@@ -170,7 +170,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         px_off = align_up64(px_off + (uint64_t)im.width * im.height * im.in_components, 256);
         coef_off += im.total_blocks;
         const uint32_t total_mcus = im.mcus_per_line * im.mcus_per_column;
-        for (uint32_t f = 0; f < total_mcus; f += 256) work_mcu.push_back({(uint32_t)i, f});
+        for (uint32_t f = 0; f < total_mcus; f += kEncMcusPerWg) work_mcu.push_back({(uint32_t)i, f});
         for (uint32_t f = 0; f < im.total_blocks; f += 256) work_blk.push_back({(uint32_t)i, f});
 
         // ---- marker segments, in the order Encode() writes them (JpegEncoder.cs:261-280)

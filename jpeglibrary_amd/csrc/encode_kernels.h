@@ -34,9 +34,11 @@ struct EncHuffTable {
     uint8_t len[256];
 };
 
+constexpr int kEncMcusPerWg = 128;  // MCUs (lanes) per workgroup of fdct_quant_kernel
+
 struct EncWork {
     uint32_t image;
-    uint32_t first;  // first MCU / block / chunk of the workgroup (256 per workgroup)
+    uint32_t first;  // first MCU (kEncMcusPerWg per workgroup) / block (256) / stuffing chunk index
 };
 
 hipError_t launch_fdct_quant(hipStream_t stream, const uint8_t *pixels, const DevEncImage *images, const EncWork *work, int n_work,

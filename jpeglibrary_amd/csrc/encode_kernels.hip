@@ -76,17 +76,51 @@ __device__ __forceinline__ void block_fdct(float (&f)[64]) {
     for (int i = 0; i < 64; i++) f[i] = f[i] * 0.1250f;
 }
 
+// What the sample reader needs from the image descriptor, held in registers (the descriptor is read once).
+struct EncSrc {
+    const uint8_t *px;
+    uint32_t width, height, comps;
+    bool rgb;
+    int32_t k[8];  // Fix() factors of the RGB -> YCbCr tables
+};
+
+// apps/JpegEncode/JpegRgbToYCbCrConverter.cs:64-96: the tables are i * Fix(x) (+ rounding / offset terms), so the terms
+// are computed (24-bit multiplies: factors < 2^17, samples < 2^8)
+__device__ __forceinline__ int32_t enc_convert(const EncSrc &s, uint32_t c, int32_t b0, int32_t b1, int32_t b2) {
+    if (!s.rgb) return c == 0 ? b0 : (c == 1 ? b1 : b2);
+    if (c == 0) return (__mul24(s.k[0], b0) + __mul24(s.k[1], b1) + __mul24(s.k[2], b2) + 32768) >> 16;
+    if (c == 1) return (__mul24(s.k[5], b2) - __mul24(s.k[3], b0) - __mul24(s.k[4], b1) + (128 << 16) + 32767) >> 16;
+    return (__mul24(s.k[5], b0) - __mul24(s.k[6], b1) - __mul24(s.k[7], b2) + (128 << 16) + 32767) >> 16;
+}
+
 // One input sample of component c at pixel (x, y); outside the image the reader leaves zeros
-// (ref: apps/JpegEncode/JpegBufferInputReader.cs:27-52).  RGB input is converted like
-// apps/JpegEncode/JpegRgbToYCbCrConverter.cs:64-96 (the tables are multiples of the Fix() factors, computed here).
-__device__ __forceinline__ int32_t enc_sample(const uint8_t *px, const DevEncImage &im, uint32_t c, uint32_t x, uint32_t y) {
-    if (x >= im.width || y >= im.height) return 0;
-    const uint8_t *p = px + ((size_t)y * im.width + x) * im.in_components;
-    if (!im.input_rgb) return p[c];
-    const int32_t r = p[0], g = p[1], b = p[2];
-    if (c == 0) return (im.r2y[0] * r + im.r2y[1] * g + im.r2y[2] * b + 32768) >> 16;
-    if (c == 1) return (-im.r2y[3] * r - im.r2y[4] * g + im.r2y[5] * b + (128 << 16) + 32767) >> 16;
-    return (im.r2y[5] * r - im.r2y[6] * g - im.r2y[7] * b + (128 << 16) + 32767) >> 16;
+// (ref: apps/JpegEncode/JpegBufferInputReader.cs:27-52).
+__device__ __forceinline__ int32_t enc_sample(const EncSrc &s, uint32_t c, uint32_t x, uint32_t y) {
+    if (x >= s.width || y >= s.height) return 0;
+    const uint8_t *p = s.px + ((size_t)y * s.width + x) * s.comps;
+    if (s.comps != 3) return p[0];
+    return enc_convert(s, c, p[0], p[1], p[2]);
+}
+
+// Component c of P consecutive pixels of one row, all inside the image, the row address dword aligned.
+template <int P>
+__device__ __forceinline__ void enc_row(const uint8_t *rowp, const EncSrc &s, uint32_t c, int32_t (&val)[P]) {
+    if (s.comps == 3) {
+        uint32_t w[P * 3 / 4];
+        __builtin_memcpy(w, __builtin_assume_aligned(rowp, 4), sizeof w);
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const int32_t b0 = (w[(3 * i) >> 2] >> (8 * ((3 * i) & 3))) & 0xFF;
+            const int32_t b1 = (w[(3 * i + 1) >> 2] >> (8 * ((3 * i + 1) & 3))) & 0xFF;
+            const int32_t b2 = (w[(3 * i + 2) >> 2] >> (8 * ((3 * i + 2) & 3))) & 0xFF;
+            val[i] = enc_convert(s, c, b0, b1, b2);
+        }
+    } else {
+        uint32_t w[P / 4];
+        __builtin_memcpy(w, __builtin_assume_aligned(rowp, 4), sizeof w);
+#pragma unroll
+        for (int i = 0; i < P; i++) val[i] = (w[i >> 2] >> (8 * (i & 3))) & 0xFF;
+    }
 }
 
 // ShiftDataLevel + TransformFDCT + ZigZagAndQuantizeBlock (ref: JpegEncoder.cs:801-826): q[i] = (short)MathF.Round(F / Q)
@@ -102,58 +136,126 @@ __device__ __forceinline__ void fdct_quantize(const int32_t (&smp)[64], const ui
     }
 }
 
-// One lane per MCU.  Blocks of an MCU are produced in encoding order because the reference's sub-sampling reader
-// accumulates into the ONE block buffer WriteScanData reuses (:712, :788-799): a sub-sampled component's block starts from
-// the previous block's quantised coefficients.  `prev` carries that buffer.
-__global__ __launch_bounds__(256) void fdct_quant_kernel(const uint8_t *__restrict__ pixels, const DevEncImage *__restrict__ images,
-                                                         const EncWork *__restrict__ work, int16_t *__restrict__ coefs) {
+__device__ __forceinline__ uint4 pack8_i16(const int32_t (&v)[8]) {
+    return uint4{((uint32_t)v[0] & 0xFFFFu) | ((uint32_t)v[1] << 16), ((uint32_t)v[2] & 0xFFFFu) | ((uint32_t)v[3] << 16),
+                 ((uint32_t)v[4] & 0xFFFFu) | ((uint32_t)v[5] << 16), ((uint32_t)v[6] & 0xFFFFu) | ((uint32_t)v[7] << 16)};
+}
+__device__ __forceinline__ void unpack8_i16(const uint4 &p, int32_t (&v)[8]) {
+    const uint32_t w[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (i & 1) ? ((int32_t)w[i >> 1] >> 16) : (int32_t)(int16_t)(w[i >> 1] & 0xFFFFu);
+}
+
+// One lane per MCU, kEncMcusPerWg lanes per workgroup.  Blocks of an MCU are produced in encoding order because the
+// reference's sub-sampling reader accumulates into the ONE block buffer WriteScanData reuses (:712, :788-799): a
+// sub-sampled component's block starts from the previous block's quantised coefficients.  The buffer lives in LDS
+// (sh_prev); the gathered samples go through LDS too (sh_smp), so the row loops stay rolled and the code stays small.
+// Both are laid out [row][lane] in 16-byte slots: neighbouring lanes touch neighbouring slots.
+__global__ __launch_bounds__(kEncMcusPerWg) void fdct_quant_kernel(const uint8_t *__restrict__ pixels, const DevEncImage *__restrict__ images,
+                                                                   const EncWork *__restrict__ work, int16_t *__restrict__ coefs) {
+    __shared__ uint4 sh_smp[8][kEncMcusPerWg], sh_prev[8][kEncMcusPerWg];
+    __shared__ uint16_t sh_q[2][64];
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
-    const uint32_t mcu = wk.first + threadIdx.x;
-    const uint32_t total_mcus = im.mcus_per_line * im.mcus_per_column;
-    if (mcu >= total_mcus) return;
-    const uint8_t *px = pixels + im.px_off;
-    const uint32_t mx = mcu % im.mcus_per_line, my = mcu / im.mcus_per_line;
-    const uint32_t max_h = im.luma_h, max_v = im.luma_v;
-    int16_t *out = coefs + (im.coef_off + (uint64_t)mcu * im.bpm) * 64;
-    int32_t prev[64];  // the reference's inputBuffer: the previous block's quantised zig-zag coefficients
+    const uint32_t lane = threadIdx.x;
+    if (lane < 64) {
+        sh_q[0][lane] = im.quant[0][lane];
+        sh_q[1][lane] = im.quant[1][lane];
+    }
+    __syncthreads();
+    const uint32_t mcu = wk.first + lane;
+    const uint32_t mcus_per_line = im.mcus_per_line;
+    if (mcu >= mcus_per_line * im.mcus_per_column) return;
+    EncSrc src;
+    src.px = pixels + im.px_off;
+    src.width = im.width;
+    src.height = im.height;
+    src.comps = im.in_components;
+    src.rgb = im.input_rgb != 0;
 #pragma unroll
-    for (int i = 0; i < 64; i++) prev[i] = 0;
-    // note: the buffer also survives from one MCU to the next, but an MCU always starts with a full-resolution luma
-    // block, which overwrites it completely -- except for images with ONLY sub-sampled blocks, which cannot exist
+    for (int i = 0; i < 8; i++) src.k[i] = im.r2y[i];
+    const uint32_t components = im.components, bpm = im.bpm;
+    const uint32_t max_h = im.luma_h, max_v = im.luma_v;
+    const uint32_t mx = mcu % mcus_per_line, my = mcu / mcus_per_line;
+    const bool rows_aligned = ((src.width * src.comps) & 3u) == 0;
+    int16_t *out = coefs + (im.coef_off + (uint64_t)mcu * bpm) * 64;
+    {
+        const uint4 z = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 8; r++) sh_prev[r][lane] = z;
+    }
     uint32_t b = 0;
-    for (uint32_t c = 0; c < im.components; c++) {
+#pragma unroll 1
+    for (uint32_t c = 0; c < components; c++) {
         const uint32_t h = c == 0 ? max_h : 1u, v = c == 0 ? max_v : 1u;
         const uint32_t hs = max_h / h, vs = max_v / v;
-        const uint16_t *quant = im.quant[c == 0 ? 0 : 1];
-        for (uint32_t by = 0; by < v; by++)
-            for (uint32_t bx = 0; bx < h; bx++, b++) {
-                const uint32_t x0 = (mx * max_h + bx) * 8, y0 = (my * max_v + by) * 8;  // full-resolution origin (:709-712)
-                int32_t smp[64];
-                if (hs == 1 && vs == 1) {
+        const uint32_t hshift = 31 - __builtin_clz(hs), vshift = 31 - __builtin_clz(vs);
+        const uint32_t total = hshift + vshift;
+        const uint16_t *quant = sh_q[c == 0 ? 0 : 1];
+#pragma unroll 1
+        for (uint32_t blk = 0; blk < h * v; blk++, b++) {
+            const uint32_t bx = blk % h, by = blk / h;
+            const uint32_t x0 = (mx * max_h + bx) * 8, y0 = (my * max_v + by) * 8;  // full-resolution origin (:709-712)
+            // fast path: all source pixels inside the image and the rows dword aligned -> rows are fetched as dwords
+            const bool fast = x0 + 8 * hs <= src.width && y0 + 8 * vs <= src.height && rows_aligned && hs <= 2;
+#pragma unroll 1
+            for (uint32_t r = 0; r < 8; r++) {
+                int32_t acc[8];
+                if (total == 0) {
 #pragma unroll
-                    for (int i = 0; i < 64; i++) smp[i] = enc_sample(px, im, c, x0 + (i & 7), y0 + (i >> 3));
+                    for (int i = 0; i < 8; i++) acc[i] = 0;
                 } else {
-                    // ReadBlockWithSubsample (:756-799): box sums on top of the stale buffer, then (+delta) >> shift
-                    const uint32_t hshift = 31 - __builtin_clz(hs), vshift = 31 - __builtin_clz(vs);
-                    const uint32_t total = hshift + vshift;
+                    unpack8_i16(sh_prev[r][lane], acc);  // ReadBlockWithSubsample adds to what the buffer holds (:788-799)
+                }
+#pragma unroll 1
+                for (uint32_t dy = 0; dy < vs; dy++) {
+                    const uint32_t y = y0 + (r << vshift) + dy;
+                    if (fast) {
+                        const uint8_t *rowp = src.px + ((size_t)y * src.width + x0) * src.comps;
+                        if (hs == 2) {
+                            int32_t row[16];
+                            enc_row<16>(rowp, src, c, row);
 #pragma unroll
-                    for (int i = 0; i < 64; i++) {
-                        int32_t acc = prev[i];
-                        const uint32_t ox = x0 + ((i & 7) << hshift), oy = y0 + ((i >> 3) << vshift);
-                        for (uint32_t dy = 0; dy < vs; dy++)
-                            for (uint32_t dx = 0; dx < hs; dx++) acc = (int32_t)(int16_t)(acc + enc_sample(px, im, c, ox + dx, oy + dy));
-                        smp[i] = (int32_t)(int16_t)((acc + (1 << (total - 1))) >> total);
+                            for (int i = 0; i < 8; i++) acc[i] += row[2 * i] + row[2 * i + 1];
+                        } else {
+                            int32_t row[8];
+                            enc_row<8>(rowp, src, c, row);
+#pragma unroll
+                            for (int i = 0; i < 8; i++) acc[i] += row[i];
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; i++)
+                            for (uint32_t dx = 0; dx < hs; dx++) acc[i] += enc_sample(src, c, x0 + ((uint32_t)i << hshift) + dx, y);
                     }
                 }
-                fdct_quantize(smp, quant, prev);
-                uint32_t packed[32];
+                if (total != 0) {
 #pragma unroll
-                for (int i = 0; i < 32; i++) packed[i] = ((uint32_t)prev[2 * i] & 0xFFFFu) | ((uint32_t)prev[2 * i + 1] << 16);
-                uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)b * 64);
-#pragma unroll
-                for (int i = 0; i < 8; i++) dst[i] = uint4{packed[4 * i], packed[4 * i + 1], packed[4 * i + 2], packed[4 * i + 3]};
+                    for (int i = 0; i < 8; i++) acc[i] = (int32_t)(int16_t)(((int32_t)(int16_t)acc[i] + (1 << (total - 1))) >> total);
+                }
+                sh_smp[r][lane] = pack8_i16(acc);
             }
+            // ShiftDataLevel + TransformFDCT + ZigZagAndQuantizeBlock
+            int32_t smp[64], q[64];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                int32_t row[8];
+                unpack8_i16(sh_smp[r][lane], row);
+#pragma unroll
+                for (int i = 0; i < 8; i++) smp[r * 8 + i] = row[i];
+            }
+            fdct_quantize(smp, quant, q);
+            uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)b * 64);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                int32_t row[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) row[i] = q[r * 8 + i];
+                const uint4 pk = pack8_i16(row);
+                dst[r] = pk;
+                sh_prev[r][lane] = pk;  // ZigZagAndQuantizeBlock writes into the buffer the next ReadBlock starts from
+            }
+        }
     }
 }
 
@@ -400,7 +502,7 @@ __global__ __launch_bounds__(256) void stuff_write_kernel(const DevEncImage *__r
 hipError_t launch_fdct_quant(hipStream_t stream, const uint8_t *pixels, const DevEncImage *images, const EncWork *work, int n_work,
                              int16_t *coefs) {
     if (n_work <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fdct_quant_kernel, dim3(n_work), dim3(256), 0, stream, pixels, images, work, coefs);
+    hipLaunchKernelGGL(fdct_quant_kernel, dim3(n_work), dim3(kEncMcusPerWg), 0, stream, pixels, images, work, coefs);
     return hipGetLastError();
 }
 hipError_t launch_block_bits(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
