@@ -745,3 +745,26 @@ def test_encoder_batch_gray_and_mixed_sizes():
     outs = jl.encode_batch(gray, (1, 1), 60)
     for g, o in zip(gray, outs):
         assert o == po.encode_8bit(g, 1, 1, 60)
+
+
+def test_encoder_adversarial_content():
+    """Content that stresses the entropy stage: white noise at quality 100 (long codes, many FF bytes to stuff), flat
+    images (EOB-only blocks), full-swing checkerboards (largest coefficients), saturated edges; all in one batch."""
+    rng = np.random.default_rng(5)
+    h, w = 120, 136
+    yy, xx = np.mgrid[0:h, 0:w]
+    imgs = [
+        rng.integers(0, 256, (h, w, 3)).astype(np.uint8),
+        np.full((h, w, 3), 255, np.uint8),
+        np.zeros((h, w, 3), np.uint8),
+        (((xx + yy) & 1) * 255).astype(np.uint8)[..., None].repeat(3, axis=2),
+        (((xx // 8 + yy // 8) & 1) * 255).astype(np.uint8)[..., None].repeat(3, axis=2),
+        np.where(xx[..., None] < w // 2, np.uint8(0), np.uint8(255)).repeat(3, axis=2).astype(np.uint8),
+    ]
+    for q in (1, 50, 100):
+        for luma in ((2, 2), (1, 1)):
+            outs = jl.encode_batch(imgs, luma, q)
+            for k, (im, o) in enumerate(zip(imgs, outs)):
+                ref = po.encode_8bit(im, luma[0], luma[1], q)
+                assert o == ref, (q, luma, k, len(o), len(ref))
+    assert b"\xff\x00" in jl.encode_batch([imgs[0]], (1, 1), 100)[0]
