@@ -325,7 +325,9 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     std::vector<HuffWork> huff_work;
     std::vector<ChunkWork> chunk_work;
     std::vector<HuffWork> sub_work;
-    std::vector<std::vector<HuffWork>> prog_work_by_ordinal;
+    std::vector<std::vector<HuffWork>> prog_work_by_ordinal, prog_streams_by_ordinal;
+    // a scan with fewer restart intervals than this gets one WAVE per interval (progressive_stream_kernel)
+    const uint32_t stream_max_intervals = getenv("JPGPU_PROG_STREAM_MAX_INTERVALS") ? (uint32_t)atoi(getenv("JPGPU_PROG_STREAM_MAX_INTERVALS")) : 16u;
     prog_clear_.clear();
     rgb_convert_.clear();
     sub_scan_ids_.clear();
@@ -441,8 +443,15 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             memcpy(s.blk_y, job.blk_y, sizeof s.blk_y);
 
             if (job.kind == kScanProgressive) {
-                if ((size_t)job.ordinal >= prog_work_by_ordinal.size()) prog_work_by_ordinal.resize((size_t)job.ordinal + 1);
-                for (uint32_t first = 0; first < s.n_intervals; first += 256) prog_work_by_ordinal[job.ordinal].push_back({(uint32_t)j, first});
+                if ((size_t)job.ordinal >= prog_work_by_ordinal.size()) {
+                    prog_work_by_ordinal.resize((size_t)job.ordinal + 1);
+                    prog_streams_by_ordinal.resize((size_t)job.ordinal + 1);
+                }
+                if (s.n_intervals <= stream_max_intervals) {
+                    for (uint32_t i = 0; i < s.n_intervals; i++) prog_streams_by_ordinal[job.ordinal].push_back({(uint32_t)j, i});
+                } else {
+                    for (uint32_t first = 0; first < s.n_intervals; first += 256) prog_work_by_ordinal[job.ordinal].push_back({(uint32_t)j, first});
+                }
                 compressed_bytes_ += s.data_len;
                 continue;  // no store of its own, no IDCT work
             }
@@ -490,6 +499,11 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     for (const std::vector<HuffWork> &w : prog_work_by_ordinal) {
         prog_work.insert(prog_work.end(), w.begin(), w.end());
         prog_begin_.push_back((int)prog_work.size());
+    }
+    prog_stream_begin_.assign(1, (int)prog_work.size());
+    for (const std::vector<HuffWork> &w : prog_streams_by_ordinal) {
+        prog_work.insert(prog_work.end(), w.begin(), w.end());
+        prog_stream_begin_.push_back((int)prog_work.size());
     }
     idct_class_begin_[0] = 0;
     for (int c = 0; c < kNumIdctLayoutClasses; c++) {
@@ -615,6 +629,12 @@ int DeviceBatch::run_progressive() {
                                           (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr,
                                           (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_);
         if (e != hipSuccess) return hip_fail(e, "progressive_scan_kernel");
+        e = launch_progressive_streams(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr,
+                                       (const HuffWork *)d_prog_work_.ptr + prog_stream_begin_[k],
+                                       prog_stream_begin_[k + 1] - prog_stream_begin_[k], (const uint32_t *)d_ends_u_.ptr,
+                                       (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr,
+                                       n_huff_slots_);
+        if (e != hipSuccess) return hip_fail(e, "progressive_stream_kernel");
     }
     return JPGPU_OK;
 }

@@ -124,6 +124,8 @@ class DeviceBatch {
     // progressive frames: work of scan ordinal k is prog_work[prog_begin_[k] .. prog_begin_[k + 1])
     DevBuffer d_prog_work_;
     std::vector<int> prog_begin_;
+    // ... and the scans with few, long intervals (one wave per interval): prog_work[prog_stream_begin_[k] .. [k + 1])
+    std::vector<int> prog_stream_begin_;
     std::vector<std::pair<uint64_t, uint64_t>> prog_clear_;  // (first block, blocks) of every progressive frame's store
     // RGB / RGBA output for layouts without a fused conversion: INTERLEAVED_U8 samples in a scratch image first
     struct RgbConvert {

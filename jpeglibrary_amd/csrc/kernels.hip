@@ -418,6 +418,51 @@ __device__ __forceinline__ void ub_init(UBits &r, const uint8_t *ubase, uint32_t
     r.rem = (int32_t)((uend - ustart) * 8u);
 }
 
+// The same reader over a ring of the unstuffed stream staged in LDS (K2P's wave-per-stream form): `wp` is the next ring
+// word to fetch, one word is kept prefetched in `nxt`.  The ring is topped up by the whole wave between blocks.
+constexpr uint32_t kPsRingBytes = 8192;
+constexpr uint32_t kPsRingWords = kPsRingBytes / 4;
+struct LBits {
+    const uint32_t *ring;
+    uint32_t wp, nxt;
+    uint32_t hi, lo;
+    int32_t lcnt;
+    int32_t rem;
+};
+__device__ __forceinline__ uint32_t lb_next_word(LBits &r) {
+    const uint32_t w = r.nxt;
+    r.nxt = r.ring[r.wp & (kPsRingWords - 1u)];
+    r.wp++;
+    return __builtin_bswap32(w);
+}
+__device__ __forceinline__ void ub_consume(LBits &r, uint32_t n) {
+    r.hi = __builtin_amdgcn_alignbit(r.hi, r.lo, (32u - n) & 31u);
+    r.lo = n >= 32u ? 0u : (r.lo << n);
+    r.lcnt -= (int32_t)n;
+    if (r.lcnt < 0) {
+        const uint32_t d = (uint32_t)(-r.lcnt);
+        const uint32_t w = lb_next_word(r);
+        r.hi |= w >> ((32u - d) & 31u);
+        r.lo = d >= 32u ? 0u : (w << d);
+        r.lcnt = 32 - (int32_t)d;
+    }
+}
+// ring byte 0 = the 16-byte aligned address at or below the stream's first byte; `skip` = bytes in front of it
+__device__ __forceinline__ void lb_init(LBits &r, const uint32_t *ring, uint32_t skip, uint32_t stream_bytes) {
+    r.ring = ring;
+    r.wp = 1;
+    r.nxt = ring[0];
+    r.hi = lb_next_word(r);
+    r.lo = lb_next_word(r);
+    r.lcnt = 32;
+    for (uint32_t left = skip * 8u; left != 0;) {
+        const uint32_t n = left < 32u ? left : 32u;
+        ub_consume(r, n);
+        left -= n;
+    }
+    r.rem = (int32_t)(stream_bytes * 8u);
+}
+
 // LDS image of a staged DevHuffTable
 struct LdsHuff {
     const uint16_t *lut;
@@ -451,7 +496,8 @@ __device__ __forceinline__ LdsHuff lds_huff16(const uint8_t *tabs, uint32_t off1
 //   ReceiveAndExtend (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:100-115) when the category s is non-zero
 //   (s = sym for a DC symbol, sym & 15 for an AC symbol).
 // Returns 0, or the failure detail.  value = extended magnitude (0 when s == 0).
-__device__ __forceinline__ uint32_t ub_symbol(UBits &r, const LdsHuff &h, bool is_dc, bool closed_by_marker, uint32_t &sym_out,
+template <class R>
+__device__ __forceinline__ uint32_t ub_symbol(R &r, const LdsHuff &h, bool is_dc, bool closed_by_marker, uint32_t &sym_out,
                                               int32_t &value) {
     const uint32_t code16 = r.rem > 0 ? (r.hi >> 16) : 0xFFFFu;
     const uint32_t e = h.lut[code16 >> (16 - kHuffLutBits)];
@@ -1106,7 +1152,8 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_tokens_kernel(const uint8_
 // ------------------------------------------------------------------------------------------------
 
 // DecodeHuffmanCode alone (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:81-88): the symbol, no magnitude bits.
-__device__ __forceinline__ uint32_t ub_huff(UBits &r, const LdsHuff &h, uint32_t &sym_out) {
+template <class R>
+__device__ __forceinline__ uint32_t ub_huff(R &r, const LdsHuff &h, uint32_t &sym_out) {
     const uint32_t code16 = r.rem > 0 ? (r.hi >> 16) : 0xFFFFu;
     const uint32_t e = h.lut[code16 >> (16 - kHuffLutBits)];
     uint32_t size = e >> 8, sym = e & 0xFF;
@@ -1123,7 +1170,8 @@ __device__ __forceinline__ uint32_t ub_huff(UBits &r, const LdsHuff &h, uint32_t
 }
 
 // TryReadBits(n), 1 <= n <= 16 (ref: JpegBitReader.cs:190-204): false when fewer than n bits are left
-__device__ __forceinline__ bool ub_try_read_bits(UBits &r, uint32_t n, uint32_t &bits) {
+template <class R>
+__device__ __forceinline__ bool ub_try_read_bits(R &r, uint32_t n, uint32_t &bits) {
     if ((int32_t)n > r.rem) return false;
     bits = r.hi >> (32u - n);
     r.rem -= (int32_t)n;
@@ -1479,6 +1527,358 @@ __global__ __launch_bounds__(kProgThreads) void progressive_scan_kernel(const ui
     // HandleRestart (:196-224) after the interval's last unit: same rules as the sequential decoder's restart check
     const uint32_t code = restart_check(s, st, &status[wk.scan], interval, n_ends, n_intervals, dri_eff, r.rem, err);
     if (code != kNoError) atomicMin(&status[wk.scan].first_error, code);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2P, wave-per-stream form: the same scan semantics for scans with FEW, LONG restart intervals (DRI = 0: one stream per
+// scan).  The lane-per-interval kernel above keeps every global access inside the serial symbol loop: the bit source
+// refills from HBM, refinement reads its block from HBM and every change is a global store, and on this ISA a load's
+// wait also drains the stores issued before it, so a lone lane pays a memory round trip per block (~4 us).  Here ONE
+// WAVE owns the stream and lane 0 decodes out of LDS only:
+//   * the unstuffed stream is staged in an 8 KB LDS ring, topped up 1 KB at a time by all 64 lanes between rounds;
+//   * AC scans work in rounds of kPsChunk blocks: the lanes compute the blocks' addresses, (refinement) load them into
+//     LDS and build the "non-zero before this scan" masks with one ballot per block; lane 0 decodes the round, marking
+//     what it changed in a 64-bit mask per block; the wave writes the changed coefficients back, one masked 2-byte store
+//     instruction per block (other bands / the DC bit of the same blocks may be written concurrently by other scans);
+//   * DC scans queue (block, value) pairs, up to 64 per round, flushed as one store / atomicOr instruction.
+// A round ends early when less than one block's worst case of stream is staged, so no bound on bits per block is assumed.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPsChunk = 32;              // AC blocks per round
+constexpr int kPsQueue = 64;              // DC results per round
+constexpr int32_t kPsUnitBytes = 384;     // stream bytes that must be staged before a unit is started (unless the stream ends)
+constexpr uint32_t kPsNoBlock = 0xFFFFFFFFu;
+constexpr size_t kPsLdsBytes = kPsRingBytes + (size_t)kPsChunk * 128 + kPsChunk * 4 + kPsChunk * 8 * 2 + kPsQueue * 8;
+
+__global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+                                                                const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
+                                                                DevScanStatus *__restrict__ status,
+                                                                const DevHuffTable *__restrict__ huff_pool, int16_t *__restrict__ coefs,
+                                                                int n_slots) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *tabs = smem;  // n_slots * sizeof(DevHuffTable)
+    uint8_t *base = smem + (size_t)n_slots * sizeof(DevHuffTable);
+    uint32_t *ring = reinterpret_cast<uint32_t *>(base);
+    int16_t *stage = reinterpret_cast<int16_t *>(base + kPsRingBytes);
+    uint64_t *chg = reinterpret_cast<uint64_t *>(base + kPsRingBytes + kPsChunk * 128);
+    uint64_t *nzm = chg + kPsChunk;
+    uint32_t *idx = reinterpret_cast<uint32_t *>(nzm + kPsChunk);
+    uint32_t *queue = idx + kPsChunk;  // kPsQueue x {block index, value}
+
+    const HuffWork wk = work[blockIdx.x];
+    const DevScan &s = scans[wk.scan];
+    const uint32_t lane = threadIdx.x;
+    for (int slot = 0; slot < kMaxHuffSlots && slot < n_slots; slot++) {
+        const uint32_t pi = s.huff_pool[slot];
+        if (pi == 0xFFFF) continue;
+        const uint4 *src = reinterpret_cast<const uint4 *>(&huff_pool[pi]);
+        uint4 *dst = reinterpret_cast<uint4 *>(tabs + slot * sizeof(DevHuffTable));
+        for (uint32_t i = lane; i < sizeof(DevHuffTable) / 16; i += 64) dst[i] = src[i];
+    }
+
+    const DevScanStatus st = status[wk.scan];
+    const uint32_t n_ends = st.n_ends;
+    const uint32_t n_intervals = s.n_intervals;
+    const uint32_t total_units = s.total_mcus;
+    const uint32_t dri_eff = s.dri ? s.dri : total_units;
+    const uint32_t interval = wk.first_interval;
+    if (interval >= n_ends) return;
+    const uint32_t *eu = ends_u + s.ends_off;
+    const uint32_t ustart = interval == 0 ? 0u : eu[interval - 1] + 2u;
+    const uint32_t uend = eu[interval];
+    const bool closed_by_marker = !(interval == n_ends - 1 && st.terminator == 0);
+    const uint32_t my_units = (interval == n_intervals - 1) ? total_units - interval * dri_eff : dri_eff;
+    const uint32_t first_unit = interval * dri_eff;
+
+    // ---- the stream ring
+    const uint8_t *p0 = udata + s.data_off + ustart;
+    const uint32_t skip = (uint32_t)(reinterpret_cast<uintptr_t>(p0) & 15u);
+    const uint8_t *origin = p0 - skip;
+    const uint32_t fill_end = ((skip + (uend - ustart) + 15u) & ~15u) + 16u;  // staged up to here (<= 32 bytes past the stream)
+    uint32_t fill_hi = 0;
+    uint4 *ring16 = reinterpret_cast<uint4 *>(ring);
+#define JPGPU_TOP_UP(rp_bytes_)                                                                              \
+    {                                                                                                        \
+        const uint32_t rp_ = (rp_bytes_) & ~15u;                                                             \
+        while (fill_hi < fill_end && fill_hi + 1024u <= rp_ + kPsRingBytes) {                                \
+            const uint32_t off_ = fill_hi + lane * 16u;                                                      \
+            if (off_ < fill_end) ring16[(off_ & (kPsRingBytes - 1u)) >> 4] = *reinterpret_cast<const uint4 *>(origin + off_); \
+            fill_hi += 1024u;                                                                                \
+        }                                                                                                    \
+        __syncthreads();                                                                                     \
+    }
+    JPGPU_TOP_UP(0u)
+    LBits r;
+    lb_init(r, ring, skip, uend - ustart);
+    // lane 0 only: is a unit's worst case staged (or everything there is)?
+#define JPGPU_STAGED() (fill_hi >= fill_end || (int32_t)(fill_hi - r.wp * 4u) >= kPsUnitBytes)
+
+    const uint32_t al = s.al, ah = s.ah, ss = s.ss, se = s.se, ncomp = s.scan_components, units_per_line = s.units_per_line;
+    ProgFrame fr;
+    fr.coef_off = s.coef_off;
+    fr.mcus_per_line = s.mcus_per_line;
+    fr.bpm = s.frame_bpm;
+    uint32_t err = 0;
+    uint32_t done = 0;
+
+    if (ncomp != 1 || ss == 0) {
+        // ---- DC scans (:92-168, ReadBlockProgressiveDC :227-253): interleaved, or one component
+        ProgComp pc[kMaxScanComponents];
+        uint32_t dc_slot[kMaxScanComponents];
+        uint32_t blocks_per_unit = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < kMaxScanComponents; c++) {
+            pc[c] = prog_comp(s, c < ncomp ? c : 0);
+            dc_slot[c] = s.comp[c < ncomp ? c : 0].dc_slot;
+            if (c < ncomp) blocks_per_unit += ncomp == 1 ? 1u : pc[c].h * pc[c].v;
+        }
+        int32_t pred[kMaxScanComponents] = {0, 0, 0, 0};
+        uint32_t uy = first_unit / units_per_line, ux = first_unit - uy * units_per_line;  // interleaved: MCU; else block
+        while (done < my_units && err == 0) {
+            JPGPU_TOP_UP(__builtin_amdgcn_readfirstlane(r.wp) * 4u - 12u)
+            uint32_t qn = 0, n_done = 0;
+            if (lane == 0) {
+                while (done + n_done < my_units && qn + blocks_per_unit <= (uint32_t)kPsQueue && JPGPU_STAGED()) {
+#pragma unroll
+                    for (uint32_t c = 0; c < kMaxScanComponents; c++) {
+                        if (c >= ncomp || err != 0) continue;
+                        const ProgComp p = pc[c];
+                        const LdsHuff hdc = lds_huff(tabs, dc_slot[c]);
+                        const uint32_t nh = ncomp == 1 ? 1u : p.h, nv = ncomp == 1 ? 1u : p.v;
+                        for (uint32_t y = 0; y < nv && err == 0; y++)
+                            for (uint32_t x = 0; x < nh; x++) {
+                                uint64_t index = 0;
+                                const bool real = ncomp == 1 ? prog_block_index(fr, p, ux, uy, index)
+                                                             : prog_block_index(fr, p, ux * p.h + x, uy * p.v + y, index);
+                                if (ah == 0) {
+                                    uint32_t sym;
+                                    int32_t value;
+                                    err = ub_symbol(r, hdc, true, closed_by_marker, sym, value);
+                                    if (err != 0) break;
+                                    const int32_t t = pred[c] + value;
+                                    pred[c] = t;
+                                    if (real) {
+                                        queue[2 * qn] = (uint32_t)index;
+                                        queue[2 * qn + 1] = ((uint32_t)t << al) & 0xFFFFu;
+                                        qn++;
+                                    }
+                                } else {
+                                    uint32_t bit;
+                                    if (!ub_try_read_bits(r, 1, bit)) {
+                                        err = kDetailUnexpectedEnd;
+                                        break;
+                                    }
+                                    if (real && bit) {
+                                        queue[2 * qn] = (uint32_t)index;
+                                        queue[2 * qn + 1] = (1u << al) & 0xFFFFu;
+                                        qn++;
+                                    }
+                                }
+                            }
+                    }
+                    if (err != 0) break;
+                    n_done++;
+                    if (++ux == units_per_line) {
+                        ux = 0;
+                        uy++;
+                    }
+                }
+            }
+            qn = __builtin_amdgcn_readfirstlane(qn);
+            n_done = __builtin_amdgcn_readfirstlane(n_done);
+            err = __builtin_amdgcn_readfirstlane(err);
+            __syncthreads();
+            if (lane < qn) {
+                const uint64_t at = (uint64_t)queue[2 * lane] * 64;
+                const uint32_t v = queue[2 * lane + 1];
+                if (ah == 0) coefs[at] = (int16_t)v;
+                else atomicOr(reinterpret_cast<uint32_t *>(coefs + at), v);  // blockRef |= bit << al (DC = low half of word 0)
+            }
+            __syncthreads();
+            done += n_done;
+        }
+    } else {
+        // ---- AC scans of one component: first pass (:255-311) and refinement (:313-419)
+        const ProgComp p = prog_comp(s, 0);
+        const LdsHuff hac = lds_huff(tabs, s.comp[0].ac_slot);
+        const int16_t p1 = (int16_t)(1u << al), m1 = (int16_t)(0xFFFFFFFFu << al);
+        const uint64_t band = (se >= 63u ? ~0ull : ((1ull << (se + 1u)) - 1ull)) & ~((1ull << ss) - 1ull);
+        uint32_t eobrun = 0;
+        while (done < my_units && err == 0) {
+            JPGPU_TOP_UP(__builtin_amdgcn_readfirstlane(r.wp) * 4u - 12u)
+            const uint32_t n = my_units - done < (uint32_t)kPsChunk ? my_units - done : (uint32_t)kPsChunk;
+            if (lane < n) {
+                ProgWalk w;
+                prog_walk_init(w, p, first_unit + done + lane, units_per_line);
+                uint64_t index = 0;
+                const bool real = prog_walk_index(fr, p, w, index);
+                idx[lane] = real ? (uint32_t)index : kPsNoBlock;
+                chg[lane] = 0;
+            }
+            __syncthreads();
+            if (ah != 0) {
+                for (uint32_t q = lane; q < n * 8u; q += 64u) {
+                    const uint32_t b = q >> 3, part = q & 7u, ix = idx[b];
+                    const int16_t *src = coefs + (ix != kPsNoBlock ? (uint64_t)ix : fr.coef_off) * 64 + part * 8u;
+                    reinterpret_cast<uint4 *>(stage)[q] = *reinterpret_cast<const uint4 *>(src);
+                }
+                __syncthreads();
+                uint64_t my_nz = 0;
+                for (uint32_t b = 0; b < n; b++) {
+                    const uint64_t m = __ballot(stage[b * 64u + lane] != 0);
+                    if (lane == b) my_nz = m;
+                }
+                if (lane < n) nzm[lane] = my_nz;
+                __syncthreads();
+            }
+            uint32_t n_done = 0;
+            if (lane == 0) {
+                for (; n_done < n; n_done++) {
+                    if (ah == 0 && eobrun != 0) {
+                        eobrun--;
+                        continue;
+                    }
+                    if (!JPGPU_STAGED()) break;
+                    int16_t *lb = stage + n_done * 64u;
+                    uint64_t changed = 0;
+                    if (ah == 0) {
+                        for (uint32_t i = ss; i <= se; i++) {
+                            uint32_t sym;
+                            int32_t value;
+                            err = ub_symbol(r, hac, false, closed_by_marker, sym, value);
+                            if (err != 0) break;
+                            const uint32_t rr = sym >> 4;
+                            i += rr;
+                            if ((sym & 15u) != 0) {
+                                const uint32_t pos = i < 63u ? i : 63u;
+                                lb[pos] = (int16_t)((uint32_t)value << al);
+                                changed |= 1ull << pos;
+                            } else if (rr != 15u) {
+                                eobrun = 1u << rr;
+                                if (rr != 0) {
+                                    uint32_t bits;
+                                    if (!ub_try_read_bits(r, rr, bits)) {
+                                        err = kDetailUnexpectedEnd;
+                                        break;
+                                    }
+                                    eobrun += bits;
+                                }
+                                eobrun--;
+                                break;
+                            }
+                        }
+                    } else {
+                        // the coefficient-by-coefficient walk of :340-372 on the mask of coefficients that were non-zero
+                        // when the block was staged: the stop position is the (r + 1)-th zero bit at or after k, the
+                        // correction bits of the non-zero positions passed are read as one field
+                        const uint64_t nz = nzm[n_done];
+#define JPGPU_CORRECT(m_, strict_)                                                                      \
+    {                                                                                                   \
+        uint64_t mm_ = (m_);                                                                            \
+        uint32_t left_ = (uint32_t)__builtin_popcountll(mm_);                                           \
+        while (left_ != 0 && err == 0) {                                                                \
+            const uint32_t n_ = left_ < 16u ? left_ : 16u;                                              \
+            uint32_t field_;                                                                            \
+            if (!ub_try_read_bits(r, n_, field_)) {                                                     \
+                err = kDetailUnexpectedEnd;                                                             \
+                break;                                                                                  \
+            }                                                                                           \
+            for (uint32_t i_ = 0; i_ < n_; i_++) {                                                      \
+                const uint32_t pos_ = (uint32_t)__builtin_ctzll(mm_);                                   \
+                mm_ &= mm_ - 1;                                                                         \
+                if ((field_ >> (n_ - 1u - i_)) & 1u) {                                                  \
+                    const int16_t c_ = lb[pos_];                                                        \
+                    if ((c_ & p1) == 0) {                                                               \
+                        lb[pos_] = (int16_t)(c_ + ((strict_ ? c_ > 0 : c_ >= 0) ? p1 : m1));            \
+                        changed |= 1ull << pos_;                                                        \
+                    }                                                                                   \
+                }                                                                                       \
+            }                                                                                           \
+            left_ -= n_;                                                                                \
+        }                                                                                               \
+    }
+                        uint32_t k = ss;
+                        if (eobrun == 0) {
+                            for (; k <= se; k++) {
+                                uint32_t sym;
+                                err = ub_huff(r, hac, sym);
+                                if (err != 0) break;
+                                const uint32_t rr = sym >> 4;
+                                int16_t sval = 0;
+                                const bool nonzero = (sym & 15u) != 0;
+                                if (nonzero) {
+                                    uint32_t bit;
+                                    if (!ub_try_read_bits(r, 1, bit)) {
+                                        err = kDetailUnexpectedEnd;
+                                        break;
+                                    }
+                                    sval = bit ? p1 : m1;
+                                } else if (rr != 15u) {
+                                    eobrun = 1u << rr;
+                                    if (rr != 0) {
+                                        uint32_t bits;
+                                        if (!ub_try_read_bits(r, rr, bits)) {
+                                            err = kDetailUnexpectedEnd;
+                                            break;
+                                        }
+                                        eobrun += bits;
+                                    }
+                                    break;
+                                }
+                                const uint64_t from_k = band & ~((1ull << k) - 1ull);
+                                uint64_t z = ~nz & from_k;
+                                for (uint32_t j = 0; j < rr && z != 0; j++) z &= z - 1;
+                                const uint32_t stop = z != 0 ? (uint32_t)__builtin_ctzll(z) : se + 1u;
+                                const uint64_t passed = nz & from_k & (stop >= 64u ? ~0ull : ((1ull << stop) - 1ull));
+                                JPGPU_CORRECT(passed, false)
+                                if (err != 0) break;
+                                k = stop;
+                                if (nonzero && k < 64u) {
+                                    lb[k] = sval;
+                                    changed |= 1ull << k;
+                                }
+                            }
+                        }
+                        if (err == 0 && eobrun > 0) {
+                            if (k <= se) {
+                                const uint64_t rest = nz & band & ~((1ull << k) - 1ull);
+                                JPGPU_CORRECT(rest, true)
+                            }
+                            eobrun--;
+                        }
+#undef JPGPU_CORRECT
+                    }
+                    chg[n_done] = changed;
+                    if (err != 0) break;
+                }
+            }
+            n_done = __builtin_amdgcn_readfirstlane(n_done);
+            err = __builtin_amdgcn_readfirstlane(err);
+            __syncthreads();
+            {
+                const uint32_t my_ix = lane < n ? idx[lane] : kPsNoBlock;
+                const uint64_t my_m = lane < n ? chg[lane] : 0ull;
+                uint64_t todo = __ballot(my_ix != kPsNoBlock && my_m != 0);
+                while (todo != 0) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const uint32_t ix = (uint32_t)__builtin_amdgcn_readlane((int)my_ix, b);
+                    const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_m, b);  // readlane returns int:
+                    const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_m >> 32), b);  // no sign extension
+                    const uint64_t m = (uint64_t)m_lo | ((uint64_t)m_hi << 32);
+                    if (((m >> lane) & 1ull) != 0) coefs[(uint64_t)ix * 64 + lane] = stage[b * 64u + lane];
+                }
+            }
+            __syncthreads();
+            done += n_done;
+        }
+    }
+#undef JPGPU_TOP_UP
+#undef JPGPU_STAGED
+
+    if (lane == 0) {
+        const uint32_t code = restart_check(s, st, &status[wk.scan], interval, n_ends, n_intervals, dri_eff, r.rem, err);
+        if (code != kNoError) atomicMin(&status[wk.scan].first_error, code);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2687,6 +3087,17 @@ hipError_t launch_progressive(hipStream_t stream, const uint8_t *udata, const De
     const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + (size_t)kProgThreads * kProgBlockStride;
     hipLaunchKernelGGL(progressive_scan_kernel, dim3(n_work), dim3(kProgThreads), lds, stream, udata, scans, work, ends_u, status,
                        huff_pool, coefs, n_slots);
+    return hipGetLastError();
+}
+
+// The same, one wave per (scan, restart interval): for scans with few, long intervals.
+hipError_t launch_progressive_streams(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
+                                      const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
+                                      int n_slots) {
+    if (n_work <= 0) return hipSuccess;
+    const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kPsLdsBytes;
+    hipLaunchKernelGGL(progressive_stream_kernel, dim3(n_work), dim3(64), lds, stream, udata, scans, work, ends_u, status, huff_pool,
+                       coefs, n_slots);
     return hipGetLastError();
 }
 
