@@ -418,51 +418,6 @@ __device__ __forceinline__ void ub_init(UBits &r, const uint8_t *ubase, uint32_t
     r.rem = (int32_t)((uend - ustart) * 8u);
 }
 
-// The same reader over a ring of the unstuffed stream staged in LDS (K2P's wave-per-stream form): `wp` is the next ring
-// word to fetch, one word is kept prefetched in `nxt`.  The ring is topped up by the whole wave between blocks.
-constexpr uint32_t kPsRingBytes = 8192;
-constexpr uint32_t kPsRingWords = kPsRingBytes / 4;
-struct LBits {
-    const uint32_t *ring;
-    uint32_t wp, nxt;
-    uint32_t hi, lo;
-    int32_t lcnt;
-    int32_t rem;
-};
-__device__ __forceinline__ uint32_t lb_next_word(LBits &r) {
-    const uint32_t w = r.nxt;
-    r.nxt = r.ring[r.wp & (kPsRingWords - 1u)];
-    r.wp++;
-    return __builtin_bswap32(w);
-}
-__device__ __forceinline__ void ub_consume(LBits &r, uint32_t n) {
-    r.hi = __builtin_amdgcn_alignbit(r.hi, r.lo, (32u - n) & 31u);
-    r.lo = n >= 32u ? 0u : (r.lo << n);
-    r.lcnt -= (int32_t)n;
-    if (r.lcnt < 0) {
-        const uint32_t d = (uint32_t)(-r.lcnt);
-        const uint32_t w = lb_next_word(r);
-        r.hi |= w >> ((32u - d) & 31u);
-        r.lo = d >= 32u ? 0u : (w << d);
-        r.lcnt = 32 - (int32_t)d;
-    }
-}
-// ring byte 0 = the 16-byte aligned address at or below the stream's first byte; `skip` = bytes in front of it
-__device__ __forceinline__ void lb_init(LBits &r, const uint32_t *ring, uint32_t skip, uint32_t stream_bytes) {
-    r.ring = ring;
-    r.wp = 1;
-    r.nxt = ring[0];
-    r.hi = lb_next_word(r);
-    r.lo = lb_next_word(r);
-    r.lcnt = 32;
-    for (uint32_t left = skip * 8u; left != 0;) {
-        const uint32_t n = left < 32u ? left : 32u;
-        ub_consume(r, n);
-        left -= n;
-    }
-    r.rem = (int32_t)(stream_bytes * 8u);
-}
-
 // LDS image of a staged DevHuffTable
 struct LdsHuff {
     const uint16_t *lut;
@@ -1531,23 +1486,375 @@ __global__ __launch_bounds__(kProgThreads) void progressive_scan_kernel(const ui
 
 // ------------------------------------------------------------------------------------------------
 // K2P, wave-per-stream form: the same scan semantics for scans with FEW, LONG restart intervals (DRI = 0: one stream per
-// scan).  The lane-per-interval kernel above keeps every global access inside the serial symbol loop: the bit source
-// refills from HBM, refinement reads its block from HBM and every change is a global store, and on this ISA a load's
-// wait also drains the stores issued before it, so a lone lane pays a memory round trip per block (~4 us).  Here ONE
-// WAVE owns the stream and lane 0 decodes out of LDS only:
-//   * the unstuffed stream is staged in an 8 KB LDS ring, topped up 1 KB at a time by all 64 lanes between rounds;
-//   * AC scans work in rounds of kPsChunk blocks: the lanes compute the blocks' addresses, (refinement) load them into
-//     LDS and build the "non-zero before this scan" masks with one ballot per block; lane 0 decodes the round, marking
-//     what it changed in a 64-bit mask per block; the wave writes the changed coefficients back, one masked 2-byte store
-//     instruction per block (other bands / the DC bit of the same blocks may be written concurrently by other scans);
-//   * DC scans queue (block, value) pairs, up to 64 per round, flushed as one store / atomicOr instruction.
-// A round ends early when less than one block's worst case of stream is staged, so no bound on bits per block is assumed.
+// scan).  A lone lane of the lane-per-interval kernel above pays a memory round trip per block and runs the
+// coefficient-by-coefficient walks as scalar loops on one SIMD lane.  Here ONE WAVE owns the stream and decodes it as a
+// wave-UNIFORM program: the decoder state (bit position, EOB run, zig-zag position, the 64-bit masks) lives in scalar
+// registers, the 64 lanes are the 64 coefficients of the current block:
+//   * the unstuffed stream is staged MSB-first in an 8 KB LDS ring, topped up 1 KB at a time by all lanes;
+//   * a WINDOW holds, per lane l, the 32 stream bits at offset l past the window base and the Huffman lookup of those bits
+//     (one LDS gather for 64 bit offsets at once); decoding a symbol is then two v_readlane at the current offset plus
+//     scalar arithmetic, the window is rebuilt when the offset runs past 63 (every ~7 symbols);
+//   * lane j holds coefficient j: the "non-zero before this scan" mask is one ballot, a new coefficient is a predicated
+//     move, a correction field is spread over the lanes by rank (mbcnt) instead of a loop over its bits, and the block's
+//     changes leave as ONE masked 2-byte store instruction (other bands / the DC bit of the same blocks may be written
+//     concurrently by other scans);
+//   * refinement blocks are staged in LDS in rounds of kPsChunk blocks by all lanes (addresses computed by the lanes).
 // ------------------------------------------------------------------------------------------------
-constexpr int kPsChunk = 32;              // AC blocks per round
-constexpr int kPsQueue = 64;              // DC results per round
-constexpr int32_t kPsUnitBytes = 384;     // stream bytes that must be staged before a unit is started (unless the stream ends)
+constexpr uint32_t kPsRingBytes = 8192;
+constexpr uint32_t kPsRingWords = kPsRingBytes / 4;
+constexpr int kPsChunk = 32;              // refinement blocks staged per round
+constexpr int32_t kPsUnitBytes = 384;     // stream bytes staged before a block / MCU is started (unless the stream ends)
 constexpr uint32_t kPsNoBlock = 0xFFFFFFFFu;
-constexpr size_t kPsLdsBytes = kPsRingBytes + (size_t)kPsChunk * 128 + kPsChunk * 4 + kPsChunk * 8 * 2 + kPsQueue * 8;
+constexpr uint32_t kPsBadCode = 17u << 8;  // window entry: no code of 16 bits or less matches
+constexpr size_t kPsLdsBytes = kPsRingBytes + (size_t)kPsChunk * 128 + kPsChunk * 4;
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+struct WBits {
+    const uint32_t *ring;  // MSB-first words of the stream; ring byte 0 = the 16-byte aligned address at or below its first byte
+    uint32_t pos;          // uniform: bit position of the next unread bit
+    uint32_t cur;          // uniform: pos - window base; > 63 = the window has to be rebuilt
+    int32_t rem;           // uniform: bits left before the interval's end (the reference's "bits available")
+    uint32_t peek;         // per lane: the 32 bits at window base + lane
+    uint32_t ent;          // per lane: (code size << 8) | symbol for those bits, 0 = longer than the lookup
+};
+
+// JpegHuffmanDecodingTable.Lookup for one 16-bit code, all lanes the same (ref: JpegHuffmanDecodingTable.cs:73-113)
+__device__ __forceinline__ uint32_t w_huff_scalar(const LdsHuff &h, uint32_t code16) {
+    const uint32_t e = uni(h.lut[code16 >> (16 - kHuffLutBits)]);
+    if ((e >> 8) != 0) return e;
+    uint32_t size = kHuffLutBits + 1;
+    while (code16 > uni(h.maxcode[size])) size++;  // maxcode[17] = 0xFFFF terminates
+    if (size > 16) return kPsBadCode;
+    return (size << 8) | uni(h.values[(uni(h.valoffset[size]) + (code16 >> (16 - size))) & 0xFF]);
+}
+
+template <bool LUT>
+__device__ __forceinline__ void w_refresh(WBits &d, uint32_t lane, const LdsHuff &h) {
+    const uint32_t bit = d.pos + lane;
+    const uint32_t w = bit >> 5, sh = bit & 31u;
+    const uint32_t w0 = d.ring[w & (kPsRingWords - 1u)], w1 = d.ring[(w + 1u) & (kPsRingWords - 1u)];
+    d.peek = (uint32_t)(((((uint64_t)w0) << 32) | w1) >> (32u - sh));
+    if (LUT) d.ent = h.lut[d.peek >> (32 - kHuffLutBits)];
+    d.cur = 0;
+}
+
+// DecodeHuffmanCode (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:81-88); returns the entry, the peeked bits in pk.
+// FAST = the caller has checked that the interval holds more bits than a whole block can consume: the reference's
+// "bits available" rules (JpegBitReader.cs:157-204) cannot trigger and `rem` is settled once per block instead.
+template <bool LUT, bool FAST>
+__device__ __forceinline__ uint32_t w_code(WBits &d, uint32_t lane, const LdsHuff &h, uint32_t &pk) {
+    if (d.cur > 63u) w_refresh<LUT>(d, lane, h);
+    pk = lane_get(d.peek, d.cur);
+    uint32_t e;
+    if (FAST || d.rem > 0) {
+        e = LUT ? lane_get(d.ent, d.cur) : 0u;
+        if ((e >> 8) == 0) e = w_huff_scalar(h, pk >> 16);
+    } else {
+        e = w_huff_scalar(h, 0xFFFFu);  // PeekBits with nothing left: all ones
+    }
+    return e;
+}
+template <bool LUT, bool FAST>
+__device__ __forceinline__ uint32_t w_huff(WBits &d, uint32_t lane, const LdsHuff &h, uint32_t &sym_out) {
+    uint32_t pk;
+    const uint32_t e = w_code<LUT, FAST>(d, lane, h, pk);
+    const uint32_t size = e >> 8;
+    if (size > 16u) return kDetailInvalidHuffmanCode;
+    sym_out = e & 0xFFu;
+    if (!FAST) d.rem = d.rem > (int32_t)size ? d.rem - (int32_t)size : 0;  // advance Math.Min(entry.CodeSize, bitsRead)
+    d.pos += size;
+    d.cur += size;
+    return 0;
+}
+// symbol + ReceiveAndExtend (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:100-115), as ub_symbol
+template <bool LUT, bool FAST>
+__device__ __forceinline__ uint32_t w_symbol(WBits &d, uint32_t lane, const LdsHuff &h, bool is_dc, bool closed_by_marker,
+                                             uint32_t &sym_out, int32_t &value) {
+    uint32_t pk;
+    const uint32_t e = w_code<LUT, FAST>(d, lane, h, pk);
+    const uint32_t size = e >> 8, sym = e & 0xFFu;
+    if (size > 16u) return kDetailInvalidHuffmanCode;
+    sym_out = sym;
+    const uint32_t s = is_dc ? sym : (sym & 15u);
+    if (!FAST) d.rem = d.rem > (int32_t)size ? d.rem - (int32_t)size : 0;
+    value = 0;
+    if (s != 0) {
+        if (s > 16u) return kDetailInvalidHuffmanCode;
+        if (!FAST && (int32_t)s > d.rem) return (d.rem == 0 && closed_by_marker) ? kDetailMarkerInData : kDetailStreamEnded;
+        const int32_t v = (int32_t)((pk << size) >> (32u - s));
+        value = v - ((((v + v) >> s) - 1) & ((1 << s) - 1));  // Extend(v, nbits)
+        if (!FAST) d.rem -= (int32_t)s;
+    }
+    d.pos += size + s;
+    d.cur += size + s;
+    return 0;
+}
+// TryReadBits(n), 1 <= n <= 32
+template <bool LUT, bool FAST>
+__device__ __forceinline__ bool w_read_bits(WBits &d, uint32_t lane, const LdsHuff &h, uint32_t n, uint32_t &bits) {
+    if (!FAST && (int32_t)n > d.rem) return false;
+    if (d.cur > 63u) w_refresh<LUT>(d, lane, h);
+    bits = lane_get(d.peek, d.cur) >> (32u - n);
+    if (!FAST) d.rem -= (int32_t)n;
+    d.pos += n;
+    d.cur += n;
+    return true;
+}
+
+// One AC first-pass block (:255-311): lane j = coefficient j, `changed` = positions written.
+template <bool FAST>
+__device__ __forceinline__ uint32_t w_ac_first_block(WBits &d, uint32_t lane, const LdsHuff &hac, bool closed_by_marker, uint32_t ss,
+                                                     uint32_t se, uint32_t al, uint32_t &eobrun, int32_t &c, uint64_t &changed) {
+    for (uint32_t i = ss; i <= se; i++) {
+        uint32_t sym;
+        int32_t value;
+        const uint32_t err = w_symbol<true, FAST>(d, lane, hac, false, closed_by_marker, sym, value);
+        if (err != 0) return err;
+        const uint32_t rr = sym >> 4;
+        i += rr;
+        if ((sym & 15u) != 0) {
+            const uint32_t at = i < 63u ? i : 63u;
+            if (lane == at) c = (int32_t)((uint32_t)value << al);
+            changed |= 1ull << at;
+        } else if (rr != 15u) {
+            eobrun = 1u << rr;
+            if (rr != 0) {
+                uint32_t bits;
+                if (!w_read_bits<true, FAST>(d, lane, hac, rr, bits)) return kDetailUnexpectedEnd;
+                eobrun += bits;
+            }
+            eobrun--;
+            break;
+        }
+    }
+    return 0;
+}
+
+// Correction bits of the non-zero coefficients in `mask` (ascending zig-zag order == stream order): one field, spread
+// over the lanes by rank.  (:349-361, :386-401)
+template <bool FAST>
+__device__ __forceinline__ uint32_t w_correct(WBits &d, uint32_t lane, const LdsHuff &hac, uint64_t mask, uint32_t count, bool strict,
+                                              int32_t p1, int32_t m1, int32_t &c, bool &mine) {
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const bool in_mask = ((mask >> lane) & 1ull) != 0;
+    uint32_t taken = 0;
+    while (count != 0) {
+        const uint32_t n = count < 32u ? count : 32u;
+        uint32_t field;
+        if (!w_read_bits<true, FAST>(d, lane, hac, n, field)) return kDetailUnexpectedEnd;
+        const uint32_t r = rank - taken;
+        if (in_mask && r < n && ((field >> (n - 1u - r)) & 1u) != 0 && (c & p1) == 0) {
+            c += (strict ? c > 0 : c >= 0) ? p1 : m1;
+            mine = true;
+        }
+        taken += n;
+        count -= n;
+    }
+    return 0;
+}
+
+// One AC refinement block (:313-419).  The reference walks the band one coefficient at a time: a correction bit for every
+// coefficient that is already non-zero (`nz`, fixed when the scan reaches the block), counting down the run over the
+// ones that are still zero.  On the masks: the stop position is the (r + 1)-th zero at or after k -- the lane whose
+// zero-rank matches -- and the positions passed hold exactly (stop - k - r) non-zero coefficients.
+template <bool FAST>
+__device__ __forceinline__ uint32_t w_ac_refine_block(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, int32_t p1,
+                                                      int32_t m1, uint64_t band, uint64_t nz, uint32_t &eobrun, int32_t &c, bool &mine) {
+    uint32_t k = ss;
+    const uint64_t zeros = ~nz & band;
+    // zero-rank of every lane: zeros of the band strictly below it
+    const uint32_t zrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(zeros >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)zeros, 0u));
+    const bool is_zero = ((zeros >> lane) & 1ull) != 0;
+    if (eobrun == 0) {
+        for (; k <= se; k++) {
+            uint32_t sym;
+            const uint32_t err = w_huff<true, FAST>(d, lane, hac, sym);
+            if (err != 0) return err;
+            const uint32_t rr = sym >> 4;
+            int32_t sval = 0;
+            const bool nonzero = (sym & 15u) != 0;
+            if (nonzero) {
+                uint32_t bit;
+                if (!w_read_bits<true, FAST>(d, lane, hac, 1, bit)) return kDetailUnexpectedEnd;
+                sval = bit ? p1 : m1;
+            } else if (rr != 15u) {
+                eobrun = 1u << rr;
+                if (rr != 0) {
+                    uint32_t bits;
+                    if (!w_read_bits<true, FAST>(d, lane, hac, rr, bits)) return kDetailUnexpectedEnd;
+                    eobrun += bits;
+                }
+                break;
+            }
+            // zeros of the band below k, then the lane that is the (rr + 1)-th zero from k on
+            const uint32_t below = (uint32_t)__builtin_popcountll(zeros & ((1ull << k) - 1ull));
+            const uint64_t hit = __ballot(is_zero && zrank == below + rr);
+            uint32_t stop, count;
+            if (hit != 0) {
+                stop = (uint32_t)__builtin_ctzll(hit);
+                count = stop - k - rr;
+            } else {
+                stop = se + 1u;  // the run outlasts the band
+                count = (uint32_t)__builtin_popcountll(nz & band & ~((1ull << k) - 1ull));
+            }
+            if (count != 0) {
+                const uint64_t passed = nz & band & ~((1ull << k) - 1ull) & (stop >= 64u ? ~0ull : ((1ull << stop) - 1ull));
+                const uint32_t cerr = w_correct<FAST>(d, lane, hac, passed, count, false, p1, m1, c, mine);
+                if (cerr != 0) return cerr;
+            }
+            k = stop;
+            if (nonzero && k < 64u && lane == k) {
+                c = sval;
+                mine = true;
+            }
+        }
+    }
+    if (eobrun > 0) {
+        if (k <= se) {
+            const uint64_t rest = nz & band & ~((1ull << k) - 1ull);
+            if (rest != 0) {
+                const uint32_t cerr = w_correct<FAST>(d, lane, hac, rest, (uint32_t)__builtin_popcountll(rest), true, p1, m1, c, mine);
+                if (cerr != 0) return cerr;
+            }
+        }
+        eobrun--;
+    }
+    return 0;
+}
+// ---- the same two block decoders for the bulk of the stream (more than kPsFastBits left: nothing can run dry), written
+// for the scalar unit: a taken branch costs this one wave as much as ~8 instructions, so symbol classes are resolved with
+// selects, the sign / EOB-run / correction bits are cut from the symbol's own 32-bit peek whenever they fit, and the only
+// branches per symbol are the loop itself, the window rebuild and the rare cases (long code, wide correction field).
+__device__ __forceinline__ uint32_t w_ac_first_fast(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, uint32_t al,
+                                                    uint32_t &eobrun, int32_t &c, uint64_t &changed) {
+    uint32_t i = ss;
+    for (;;) {
+        if (d.cur > 63u) w_refresh<true>(d, lane, hac);
+        const uint32_t pk = lane_get(d.peek, d.cur);
+        uint32_t e = lane_get(d.ent, d.cur);
+        if ((e >> 8) == 0) {
+            e = w_huff_scalar(hac, pk >> 16);
+            if (e >= kPsBadCode) return kDetailInvalidHuffmanCode;
+        }
+        const uint32_t size = e >> 8, rr = (e >> 4) & 15u, sz = e & 15u;
+        const uint32_t rest = pk << size;  // the bits after the code: magnitude, or the EOB run's low bits
+        if (sz == 0 && rr != 15u) {
+            eobrun = (1u << rr) - 1u + (uint32_t)(((uint64_t)rest << rr) >> 32);  // rr = 0 reads nothing
+            d.pos += size + rr;
+            d.cur += size + rr;
+            return 0;
+        }
+        i += rr;
+        const int32_t v = (int32_t)(uint32_t)(((uint64_t)rest << sz) >> 32);  // sz = 0 (ZRL): 0
+        const int32_t value = v - ((((v + v) >> sz) - 1) & ((1 << sz) - 1));   // Extend(v, nbits)
+        const uint32_t at = i < 63u ? i : 63u;
+        if (sz != 0 && lane == at) c = (int32_t)((uint32_t)value << al);
+        changed |= (uint64_t)(sz != 0 ? 1u : 0u) << at;
+        d.pos += size + sz;
+        d.cur += size + sz;
+        if (++i > se) return 0;
+    }
+}
+
+__device__ __forceinline__ uint32_t w_ac_refine_fast(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, int32_t p1,
+                                                     int32_t m1, uint64_t band, uint64_t nz, uint32_t &eobrun, int32_t &c, bool &mine) {
+    const uint64_t zeros = ~nz & band, nzb = nz & band;
+    const uint32_t zrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(zeros >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)zeros, 0u));
+    const uint32_t nrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzb, 0u));
+    const bool was_nz = ((nzb >> lane) & 1ull) != 0;
+    uint32_t k = ss;
+    uint32_t below = 0;  // zeros of the band below k
+    uint32_t nbelow = 0; // non-zero coefficients of the band below k
+    if (eobrun == 0) {
+        for (;;) {
+            if (d.cur > 63u) w_refresh<true>(d, lane, hac);
+            const uint32_t pk = lane_get(d.peek, d.cur);
+            uint32_t e = lane_get(d.ent, d.cur);
+            if ((e >> 8) == 0) {
+                e = w_huff_scalar(hac, pk >> 16);
+                if (e >= kPsBadCode) return kDetailInvalidHuffmanCode;
+            }
+            const uint32_t size = e >> 8, rr = (e >> 4) & 15u;
+            const uint32_t nonzero = (e & 15u) != 0 ? 1u : 0u;
+            if ((nonzero | (rr == 15u ? 1u : 0u)) == 0) {
+                eobrun = (1u << rr) + (uint32_t)(((uint64_t)(pk << size) << rr) >> 32);
+                d.pos += size + rr;
+                d.cur += size + rr;
+                break;
+            }
+            const uint32_t sign = (pk >> (31u - size)) & 1u;
+            uint32_t used = size + nonzero;
+            // the lane that is the (rr + 1)-th zero from k on; none = the run outlasts the band
+            const uint64_t hit = __ballot(zrank == below + rr) & zeros;
+            const bool found = hit != 0;
+            const uint32_t stop = found ? (uint32_t)__builtin_ctzll(hit) : se + 1u;
+            // non-zero coefficients in [k, stop): their correction bits follow, in order
+            const uint32_t count = found ? stop - k - rr : (uint32_t)__builtin_popcountll(nzb) - nbelow;
+            if (count != 0) {
+                const uint32_t r = nrank - nbelow;  // this lane's place in the field (when it is one of them)
+                if (used + count <= 32u) {
+                    const uint32_t field = (pk << used) >> (32u - count);
+                    used += count;
+                    if (was_nz && r < count && ((field >> (count - 1u - r)) & 1u) != 0 && (c & p1) == 0) {
+                        c += c >= 0 ? p1 : m1;
+                        mine = true;
+                    }
+                } else {
+                    d.pos += used;
+                    d.cur += used;
+                    used = 0;
+                    uint32_t taken = 0, left = count;
+                    while (left != 0) {
+                        const uint32_t n = left < 32u ? left : 32u;
+                        uint32_t field;
+                        w_read_bits<true, true>(d, lane, hac, n, field);
+                        const uint32_t rn = r - taken;
+                        if (was_nz && rn < n && ((field >> (n - 1u - rn)) & 1u) != 0 && (c & p1) == 0) {
+                            c += c >= 0 ? p1 : m1;
+                            mine = true;
+                        }
+                        taken += n;
+                        left -= n;
+                    }
+                }
+            }
+            d.pos += used;
+            d.cur += used;
+            if (nonzero != 0 && lane == stop) {  // stop = 64 (band to 63, run outlasts it): no lane
+                c = sign ? p1 : m1;
+                mine = true;
+            }
+            k = stop + 1u;
+            below += rr + 1u;
+            nbelow += count;
+            if (k > se) break;
+        }
+    }
+    if (eobrun > 0) {
+        if (k <= se) {
+            const uint32_t count = (uint32_t)__builtin_popcountll(nzb) - nbelow;
+            const uint32_t r = nrank - nbelow;
+            uint32_t taken = 0, left = count;
+            while (left != 0) {
+                const uint32_t n = left < 32u ? left : 32u;
+                uint32_t field;
+                w_read_bits<true, true>(d, lane, hac, n, field);
+                const uint32_t rn = r - taken;
+                if (was_nz && rn < n && ((field >> (n - 1u - rn)) & 1u) != 0 && (c & p1) == 0) {
+                    c += c > 0 ? p1 : m1;
+                    mine = true;
+                }
+                taken += n;
+                left -= n;
+            }
+        }
+        eobrun--;
+    }
+    return 0;
+}
+constexpr int32_t kPsFastBits = 2560;  // more than any block can consume: 63 x (16 + 16) + 14 (first), 63 x 17 + 63 + 14 (refinement)
 
 __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
                                                                 const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
@@ -1559,10 +1866,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
     uint8_t *base = smem + (size_t)n_slots * sizeof(DevHuffTable);
     uint32_t *ring = reinterpret_cast<uint32_t *>(base);
     int16_t *stage = reinterpret_cast<int16_t *>(base + kPsRingBytes);
-    uint64_t *chg = reinterpret_cast<uint64_t *>(base + kPsRingBytes + kPsChunk * 128);
-    uint64_t *nzm = chg + kPsChunk;
-    uint32_t *idx = reinterpret_cast<uint32_t *>(nzm + kPsChunk);
-    uint32_t *queue = idx + kPsChunk;  // kPsQueue x {block index, value}
+    uint32_t *idx = reinterpret_cast<uint32_t *>(base + kPsRingBytes + kPsChunk * 128);
 
     const HuffWork wk = work[blockIdx.x];
     const DevScan &s = scans[wk.scan];
@@ -1596,21 +1900,42 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
     const uint32_t fill_end = ((skip + (uend - ustart) + 15u) & ~15u) + 16u;  // staged up to here (<= 32 bytes past the stream)
     uint32_t fill_hi = 0;
     uint4 *ring16 = reinterpret_cast<uint4 *>(ring);
-#define JPGPU_TOP_UP(rp_bytes_)                                                                              \
+    WBits d;
+    d.ring = ring;
+    d.pos = skip * 8u;
+    d.cur = 64;
+    d.rem = (int32_t)((uend - ustart) * 8u);
+    d.peek = d.ent = 0;
+    // everything before the window base (16-byte granules) may be overwritten
+#define JPGPU_TOP_UP()                                                                                       \
     {                                                                                                        \
-        const uint32_t rp_ = (rp_bytes_) & ~15u;                                                             \
+        const uint32_t rp_ = ((d.pos - (d.cur > 63u ? 0u : d.cur)) >> 3) & ~15u;                             \
         while (fill_hi < fill_end && fill_hi + 1024u <= rp_ + kPsRingBytes) {                                \
             const uint32_t off_ = fill_hi + lane * 16u;                                                      \
-            if (off_ < fill_end) ring16[(off_ & (kPsRingBytes - 1u)) >> 4] = *reinterpret_cast<const uint4 *>(origin + off_); \
+            if (off_ < fill_end) {                                                                           \
+                uint4 q_ = *reinterpret_cast<const uint4 *>(origin + off_);                                  \
+                q_.x = __builtin_bswap32(q_.x); q_.y = __builtin_bswap32(q_.y);                              \
+                q_.z = __builtin_bswap32(q_.z); q_.w = __builtin_bswap32(q_.w);                              \
+                ring16[(off_ & (kPsRingBytes - 1u)) >> 4] = q_;                                              \
+            }                                                                                                \
             fill_hi += 1024u;                                                                                \
         }                                                                                                    \
         __syncthreads();                                                                                     \
     }
-    JPGPU_TOP_UP(0u)
-    LBits r;
-    lb_init(r, ring, skip, uend - ustart);
-    // lane 0 only: is a unit's worst case staged (or everything there is)?
-#define JPGPU_STAGED() (fill_hi >= fill_end || (int32_t)(fill_hi - r.wp * 4u) >= kPsUnitBytes)
+    // a unit's worst case is staged, or everything there is
+#define JPGPU_ENSURE_STAGED()                                                                                \
+    if (fill_hi < fill_end && (int32_t)(fill_hi - (d.pos >> 3)) < kPsUnitBytes) JPGPU_TOP_UP()
+    JPGPU_TOP_UP()
+    // the exact block decoders are compiled as divergent code (lane-predicated updates next to early returns); the
+    // decoder state they leave is uniform all the same: saying so keeps the bulk path on the scalar unit
+#define JPGPU_SETTLE()                      \
+    {                                       \
+        d.pos = uni(d.pos);                 \
+        d.cur = uni(d.cur);                 \
+        d.rem = (int32_t)uni((uint32_t)d.rem); \
+        eobrun = uni(eobrun);               \
+        err = uni(err);                     \
+    }
 
     const uint32_t al = s.al, ah = s.ah, ss = s.ss, se = s.se, ncomp = s.scan_components, units_per_line = s.units_per_line;
     ProgFrame fr;
@@ -1618,268 +1943,134 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
     fr.mcus_per_line = s.mcus_per_line;
     fr.bpm = s.frame_bpm;
     uint32_t err = 0;
-    uint32_t done = 0;
 
     if (ncomp != 1 || ss == 0) {
-        // ---- DC scans (:92-168, ReadBlockProgressiveDC :227-253): interleaved, or one component
+        // ---- DC scans (:92-168, ReadBlockProgressiveDC :227-253): interleaved, or one component.  A different table per
+        // component: the window holds the stream bits only, codes are looked up one at a time.
         ProgComp pc[kMaxScanComponents];
         uint32_t dc_slot[kMaxScanComponents];
-        uint32_t blocks_per_unit = 0;
 #pragma unroll
         for (uint32_t c = 0; c < kMaxScanComponents; c++) {
             pc[c] = prog_comp(s, c < ncomp ? c : 0);
             dc_slot[c] = s.comp[c < ncomp ? c : 0].dc_slot;
-            if (c < ncomp) blocks_per_unit += ncomp == 1 ? 1u : pc[c].h * pc[c].v;
         }
         int32_t pred[kMaxScanComponents] = {0, 0, 0, 0};
         uint32_t uy = first_unit / units_per_line, ux = first_unit - uy * units_per_line;  // interleaved: MCU; else block
-        while (done < my_units && err == 0) {
-            JPGPU_TOP_UP(__builtin_amdgcn_readfirstlane(r.wp) * 4u - 12u)
-            uint32_t qn = 0, n_done = 0;
-            if (lane == 0) {
-                while (done + n_done < my_units && qn + blocks_per_unit <= (uint32_t)kPsQueue && JPGPU_STAGED()) {
+        for (uint32_t u = 0; u < my_units && err == 0; u++) {
+            JPGPU_ENSURE_STAGED()
 #pragma unroll
-                    for (uint32_t c = 0; c < kMaxScanComponents; c++) {
-                        if (c >= ncomp || err != 0) continue;
-                        const ProgComp p = pc[c];
-                        const LdsHuff hdc = lds_huff(tabs, dc_slot[c]);
-                        const uint32_t nh = ncomp == 1 ? 1u : p.h, nv = ncomp == 1 ? 1u : p.v;
-                        for (uint32_t y = 0; y < nv && err == 0; y++)
-                            for (uint32_t x = 0; x < nh; x++) {
-                                uint64_t index = 0;
-                                const bool real = ncomp == 1 ? prog_block_index(fr, p, ux, uy, index)
-                                                             : prog_block_index(fr, p, ux * p.h + x, uy * p.v + y, index);
-                                if (ah == 0) {
-                                    uint32_t sym;
-                                    int32_t value;
-                                    err = ub_symbol(r, hdc, true, closed_by_marker, sym, value);
-                                    if (err != 0) break;
-                                    const int32_t t = pred[c] + value;
-                                    pred[c] = t;
-                                    if (real) {
-                                        queue[2 * qn] = (uint32_t)index;
-                                        queue[2 * qn + 1] = ((uint32_t)t << al) & 0xFFFFu;
-                                        qn++;
-                                    }
-                                } else {
-                                    uint32_t bit;
-                                    if (!ub_try_read_bits(r, 1, bit)) {
-                                        err = kDetailUnexpectedEnd;
-                                        break;
-                                    }
-                                    if (real && bit) {
-                                        queue[2 * qn] = (uint32_t)index;
-                                        queue[2 * qn + 1] = (1u << al) & 0xFFFFu;
-                                        qn++;
-                                    }
-                                }
+            for (uint32_t c = 0; c < kMaxScanComponents; c++) {
+                if (c >= ncomp || err != 0) continue;
+                const ProgComp p = pc[c];
+                const LdsHuff hdc = lds_huff(tabs, dc_slot[c]);
+                const uint32_t nh = ncomp == 1 ? 1u : p.h, nv = ncomp == 1 ? 1u : p.v;
+                for (uint32_t y = 0; y < nv && err == 0; y++)
+                    for (uint32_t x = 0; x < nh; x++) {
+                        uint64_t index = 0;
+                        const bool real = ncomp == 1 ? prog_block_index(fr, p, ux, uy, index)
+                                                     : prog_block_index(fr, p, ux * p.h + x, uy * p.v + y, index);
+                        if (ah == 0) {
+                            uint32_t sym;
+                            int32_t value;
+                            err = w_symbol<false, false>(d, lane, hdc, true, closed_by_marker, sym, value);
+                            if (err != 0) break;
+                            const int32_t t = pred[c] + value;
+                            pred[c] = t;
+                            if (real && lane == 0) coefs[index * 64] = (int16_t)((uint32_t)t << al);
+                        } else {
+                            uint32_t bit;
+                            if (!w_read_bits<false, false>(d, lane, hdc, 1, bit)) {
+                                err = kDetailUnexpectedEnd;
+                                break;
                             }
+                            // blockRef |= bit << al, 16-bit (the DC is the low half of the block's first word)
+                            if (real && bit != 0 && lane == 0) atomicOr(reinterpret_cast<uint32_t *>(coefs + index * 64), (1u << al) & 0xFFFFu);
+                        }
                     }
-                    if (err != 0) break;
-                    n_done++;
-                    if (++ux == units_per_line) {
-                        ux = 0;
-                        uy++;
-                    }
-                }
             }
-            qn = __builtin_amdgcn_readfirstlane(qn);
-            n_done = __builtin_amdgcn_readfirstlane(n_done);
-            err = __builtin_amdgcn_readfirstlane(err);
-            __syncthreads();
-            if (lane < qn) {
-                const uint64_t at = (uint64_t)queue[2 * lane] * 64;
-                const uint32_t v = queue[2 * lane + 1];
-                if (ah == 0) coefs[at] = (int16_t)v;
-                else atomicOr(reinterpret_cast<uint32_t *>(coefs + at), v);  // blockRef |= bit << al (DC = low half of word 0)
+            if (++ux == units_per_line) {
+                ux = 0;
+                uy++;
             }
-            __syncthreads();
-            done += n_done;
         }
     } else {
         // ---- AC scans of one component: first pass (:255-311) and refinement (:313-419)
         const ProgComp p = prog_comp(s, 0);
         const LdsHuff hac = lds_huff(tabs, s.comp[0].ac_slot);
-        const int16_t p1 = (int16_t)(1u << al), m1 = (int16_t)(0xFFFFFFFFu << al);
+        const int32_t p1 = (int32_t)(int16_t)(1u << al), m1 = (int32_t)(int16_t)(0xFFFFFFFFu << al);
         const uint64_t band = (se >= 63u ? ~0ull : ((1ull << (se + 1u)) - 1ull)) & ~((1ull << ss) - 1ull);
+        const uint64_t lane_bit = 1ull << lane;
         uint32_t eobrun = 0;
-        while (done < my_units && err == 0) {
-            JPGPU_TOP_UP(__builtin_amdgcn_readfirstlane(r.wp) * 4u - 12u)
-            const uint32_t n = my_units - done < (uint32_t)kPsChunk ? my_units - done : (uint32_t)kPsChunk;
-            if (lane < n) {
-                ProgWalk w;
-                prog_walk_init(w, p, first_unit + done + lane, units_per_line);
+        if (ah == 0) {
+            ProgWalk w;
+            prog_walk_init(w, p, first_unit, units_per_line);
+            for (uint32_t u = 0; u < my_units && err == 0; u++, prog_walk_next(w, p, units_per_line)) {
+                if (eobrun != 0) {
+                    eobrun--;
+                    continue;
+                }
+                JPGPU_ENSURE_STAGED()
                 uint64_t index = 0;
                 const bool real = prog_walk_index(fr, p, w, index);
-                idx[lane] = real ? (uint32_t)index : kPsNoBlock;
-                chg[lane] = 0;
+                int32_t c = 0;
+                uint64_t changed = 0;
+                if (d.rem >= kPsFastBits) {
+                    const uint32_t pos0 = d.pos;
+                    err = w_ac_first_fast(d, lane, hac, ss, se, al, eobrun, c, changed);
+                    d.rem -= (int32_t)(d.pos - pos0);
+                } else {
+                    err = w_ac_first_block<false>(d, lane, hac, closed_by_marker, ss, se, al, eobrun, c, changed);
+                    JPGPU_SETTLE()
+                }
+                if (real && (changed & lane_bit) != 0) coefs[index * 64 + lane] = (int16_t)c;
             }
-            __syncthreads();
-            if (ah != 0) {
+        } else {
+            for (uint32_t done = 0; done < my_units && err == 0;) {
+                const uint32_t n = my_units - done < (uint32_t)kPsChunk ? my_units - done : (uint32_t)kPsChunk;
+                if (lane < n) {
+                    ProgWalk w;
+                    prog_walk_init(w, p, first_unit + done + lane, units_per_line);
+                    uint64_t index = 0;
+                    const bool real = prog_walk_index(fr, p, w, index);
+                    idx[lane] = real ? (uint32_t)index : kPsNoBlock;
+                }
+                __syncthreads();
                 for (uint32_t q = lane; q < n * 8u; q += 64u) {
                     const uint32_t b = q >> 3, part = q & 7u, ix = idx[b];
                     const int16_t *src = coefs + (ix != kPsNoBlock ? (uint64_t)ix : fr.coef_off) * 64 + part * 8u;
                     reinterpret_cast<uint4 *>(stage)[q] = *reinterpret_cast<const uint4 *>(src);
                 }
                 __syncthreads();
-                uint64_t my_nz = 0;
-                for (uint32_t b = 0; b < n; b++) {
-                    const uint64_t m = __ballot(stage[b * 64u + lane] != 0);
-                    if (lane == b) my_nz = m;
-                }
-                if (lane < n) nzm[lane] = my_nz;
-                __syncthreads();
-            }
-            uint32_t n_done = 0;
-            if (lane == 0) {
-                for (; n_done < n; n_done++) {
-                    if (ah == 0 && eobrun != 0) {
-                        eobrun--;
-                        continue;
-                    }
-                    if (!JPGPU_STAGED()) break;
-                    int16_t *lb = stage + n_done * 64u;
-                    uint64_t changed = 0;
-                    if (ah == 0) {
-                        for (uint32_t i = ss; i <= se; i++) {
-                            uint32_t sym;
-                            int32_t value;
-                            err = ub_symbol(r, hac, false, closed_by_marker, sym, value);
-                            if (err != 0) break;
-                            const uint32_t rr = sym >> 4;
-                            i += rr;
-                            if ((sym & 15u) != 0) {
-                                const uint32_t pos = i < 63u ? i : 63u;
-                                lb[pos] = (int16_t)((uint32_t)value << al);
-                                changed |= 1ull << pos;
-                            } else if (rr != 15u) {
-                                eobrun = 1u << rr;
-                                if (rr != 0) {
-                                    uint32_t bits;
-                                    if (!ub_try_read_bits(r, rr, bits)) {
-                                        err = kDetailUnexpectedEnd;
-                                        break;
-                                    }
-                                    eobrun += bits;
-                                }
-                                eobrun--;
-                                break;
-                            }
-                        }
+                for (uint32_t b = 0; b < n && err == 0; b++) {
+                    JPGPU_ENSURE_STAGED()
+                    int32_t c = stage[b * 64u + lane];
+                    const uint32_t ix = uni(idx[b]);
+                    const uint64_t nz = __ballot(c != 0);
+                    bool mine = false;  // this lane's coefficient changed
+                    if (d.rem >= kPsFastBits) {
+                        const uint32_t pos0 = d.pos;
+                        err = w_ac_refine_fast(d, lane, hac, ss, se, p1, m1, band, nz, eobrun, c, mine);
+                        d.rem -= (int32_t)(d.pos - pos0);
                     } else {
-                        // the coefficient-by-coefficient walk of :340-372 on the mask of coefficients that were non-zero
-                        // when the block was staged: the stop position is the (r + 1)-th zero bit at or after k, the
-                        // correction bits of the non-zero positions passed are read as one field
-                        const uint64_t nz = nzm[n_done];
-#define JPGPU_CORRECT(m_, strict_)                                                                      \
-    {                                                                                                   \
-        uint64_t mm_ = (m_);                                                                            \
-        uint32_t left_ = (uint32_t)__builtin_popcountll(mm_);                                           \
-        while (left_ != 0 && err == 0) {                                                                \
-            const uint32_t n_ = left_ < 16u ? left_ : 16u;                                              \
-            uint32_t field_;                                                                            \
-            if (!ub_try_read_bits(r, n_, field_)) {                                                     \
-                err = kDetailUnexpectedEnd;                                                             \
-                break;                                                                                  \
-            }                                                                                           \
-            for (uint32_t i_ = 0; i_ < n_; i_++) {                                                      \
-                const uint32_t pos_ = (uint32_t)__builtin_ctzll(mm_);                                   \
-                mm_ &= mm_ - 1;                                                                         \
-                if ((field_ >> (n_ - 1u - i_)) & 1u) {                                                  \
-                    const int16_t c_ = lb[pos_];                                                        \
-                    if ((c_ & p1) == 0) {                                                               \
-                        lb[pos_] = (int16_t)(c_ + ((strict_ ? c_ > 0 : c_ >= 0) ? p1 : m1));            \
-                        changed |= 1ull << pos_;                                                        \
-                    }                                                                                   \
-                }                                                                                       \
-            }                                                                                           \
-            left_ -= n_;                                                                                \
-        }                                                                                               \
-    }
-                        uint32_t k = ss;
-                        if (eobrun == 0) {
-                            for (; k <= se; k++) {
-                                uint32_t sym;
-                                err = ub_huff(r, hac, sym);
-                                if (err != 0) break;
-                                const uint32_t rr = sym >> 4;
-                                int16_t sval = 0;
-                                const bool nonzero = (sym & 15u) != 0;
-                                if (nonzero) {
-                                    uint32_t bit;
-                                    if (!ub_try_read_bits(r, 1, bit)) {
-                                        err = kDetailUnexpectedEnd;
-                                        break;
-                                    }
-                                    sval = bit ? p1 : m1;
-                                } else if (rr != 15u) {
-                                    eobrun = 1u << rr;
-                                    if (rr != 0) {
-                                        uint32_t bits;
-                                        if (!ub_try_read_bits(r, rr, bits)) {
-                                            err = kDetailUnexpectedEnd;
-                                            break;
-                                        }
-                                        eobrun += bits;
-                                    }
-                                    break;
-                                }
-                                const uint64_t from_k = band & ~((1ull << k) - 1ull);
-                                uint64_t z = ~nz & from_k;
-                                for (uint32_t j = 0; j < rr && z != 0; j++) z &= z - 1;
-                                const uint32_t stop = z != 0 ? (uint32_t)__builtin_ctzll(z) : se + 1u;
-                                const uint64_t passed = nz & from_k & (stop >= 64u ? ~0ull : ((1ull << stop) - 1ull));
-                                JPGPU_CORRECT(passed, false)
-                                if (err != 0) break;
-                                k = stop;
-                                if (nonzero && k < 64u) {
-                                    lb[k] = sval;
-                                    changed |= 1ull << k;
-                                }
-                            }
-                        }
-                        if (err == 0 && eobrun > 0) {
-                            if (k <= se) {
-                                const uint64_t rest = nz & band & ~((1ull << k) - 1ull);
-                                JPGPU_CORRECT(rest, true)
-                            }
-                            eobrun--;
-                        }
-#undef JPGPU_CORRECT
+                        err = w_ac_refine_block<false>(d, lane, hac, ss, se, p1, m1, band, nz, eobrun, c, mine);
+                        JPGPU_SETTLE()
                     }
-                    chg[n_done] = changed;
-                    if (err != 0) break;
+                    if (ix != kPsNoBlock && mine) coefs[(uint64_t)ix * 64 + lane] = (int16_t)c;
+                    if (err == 0) done++;
                 }
             }
-            n_done = __builtin_amdgcn_readfirstlane(n_done);
-            err = __builtin_amdgcn_readfirstlane(err);
-            __syncthreads();
-            {
-                const uint32_t my_ix = lane < n ? idx[lane] : kPsNoBlock;
-                const uint64_t my_m = lane < n ? chg[lane] : 0ull;
-                uint64_t todo = __ballot(my_ix != kPsNoBlock && my_m != 0);
-                while (todo != 0) {
-                    const uint32_t b = (uint32_t)__builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const uint32_t ix = (uint32_t)__builtin_amdgcn_readlane((int)my_ix, b);
-                    const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_m, b);  // readlane returns int:
-                    const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_m >> 32), b);  // no sign extension
-                    const uint64_t m = (uint64_t)m_lo | ((uint64_t)m_hi << 32);
-                    if (((m >> lane) & 1ull) != 0) coefs[(uint64_t)ix * 64 + lane] = stage[b * 64u + lane];
-                }
-            }
-            __syncthreads();
-            done += n_done;
         }
     }
 #undef JPGPU_TOP_UP
-#undef JPGPU_STAGED
+#undef JPGPU_ENSURE_STAGED
+#undef JPGPU_SETTLE
 
     if (lane == 0) {
-        const uint32_t code = restart_check(s, st, &status[wk.scan], interval, n_ends, n_intervals, dri_eff, r.rem, err);
+        const uint32_t code = restart_check(s, st, &status[wk.scan], interval, n_ends, n_intervals, dri_eff, d.rem, err);
         if (code != kNoError) atomicMin(&status[wk.scan].first_error, code);
     }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // K2S: self-synchronising subsequence decode for scans WITHOUT restart intervals (DRI = 0).

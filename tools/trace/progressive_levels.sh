@@ -6,5 +6,5 @@ f=glob.glob("/tmp/pp/**/*kernel_trace.csv",recursive=True)[0]
 rows=[r for r in csv.DictReader(open(f)) if "progressive" in r["Kernel_Name"]]
 n=len(rows)//2
 for r in rows[-n:]:
-    print(r.get("Grid_Size_X",""), (int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6, "ms")
+    print(r["Kernel_Name"][:28], r.get("Grid_Size_X",""), (int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6, "ms")
 PY
