@@ -87,12 +87,14 @@ struct alignas(16) DevScan {
     uint8_t ss, se, ah, al;    // spectral selection / successive approximation of the scan header
     uint8_t frame_bpm;         // blocks per MCU of the frame (all components)
     uint8_t fblk_base[kMaxScanComponents];  // first block of the scan component inside the frame's MCU
-    uint8_t pad1[6];
+    uint8_t publishes;         // pipelined launch: other scans follow this one's progress (DevScanStatus::progress)
+    uint8_t pad1[5];
     uint16_t hblocks[kMaxScanComponents];   // the component's own block grid (ref: JpegBlockAllocator.cs:35-84);
     uint16_t vblocks[kMaxScanComponents];   // blocks outside it go to the allocator's dummy block, i.e. nowhere
     uint32_t units_per_line;   // non-interleaved scan: blocks per line walked by the scan (:146-147)
-    uint32_t pad2[3];
+    uint32_t dep[3];           // pipelined launch: scan jobs this scan follows (kNoDep = none), see progressive_stream_kernel
 };
+constexpr uint32_t kNoDep = 0xFFFFFFFFu;
 enum ScanKind : uint8_t { kScanSequential = 0, kScanFrameOnly = 1, kScanProgressive = 2 };
 static_assert(sizeof(DevScan) % 16 == 0, "DevScan must be a multiple of 16 bytes");
 
@@ -103,7 +105,7 @@ struct alignas(16) DevScanStatus {
     uint32_t first_error;   // (interval << 8) | detail of the lowest failing interval, 0xFFFFFFFF = none
     uint32_t decoded_mcus;  // MCUs decoded (limits the IDCT pass when EOI came early)
     uint32_t end_pos;       // byte offset (from data_off) of the terminating marker / end of data
-    uint32_t pad[3];
+    uint32_t pad[3];        // [0] unstuffed length; [1] progressive scans: restart units completed (0xFFFFFFFF = finished)
 };
 
 // Work lists: one entry per workgroup.

@@ -329,6 +329,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     // a scan with fewer restart intervals than this gets one WAVE per interval (progressive_stream_kernel)
     const uint32_t stream_max_intervals = getenv("JPGPU_PROG_STREAM_MAX_INTERVALS") ? (uint32_t)atoi(getenv("JPGPU_PROG_STREAM_MAX_INTERVALS")) : 16u;
     prog_clear_.clear();
+    prog_pipelined_ = getenv("JPGPU_PROG_NO_PIPELINE") == nullptr;
     rgb_convert_.clear();
     sub_scan_ids_.clear();
     total_subs_ = 0;
@@ -447,6 +448,10 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                     prog_work_by_ordinal.resize((size_t)job.ordinal + 1);
                     prog_streams_by_ordinal.resize((size_t)job.ordinal + 1);
                 }
+                // the frame job precedes its scans in the job list: scan k of the frame is job img.jobs[0] + 1 + k
+                for (int d = 0; d < 3; d++) s.dep[d] = d < job.n_deps && job.deps[d] >= 0 ? (uint32_t)(img.jobs[0] + 1 + job.deps[d]) : kNoDep;
+                s.publishes = job.has_consumers ? 1 : 0;
+                if (job.n_deps > 3 || s.n_intervals != 1 || s.n_intervals > stream_max_intervals) prog_pipelined_ = false;
                 if (s.n_intervals <= stream_max_intervals) {
                     for (uint32_t i = 0; i < s.n_intervals; i++) prog_streams_by_ordinal[job.ordinal].push_back({(uint32_t)j, i});
                 } else {
@@ -622,6 +627,17 @@ int DeviceBatch::run_progressive() {
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(progressive store)");
     }
     const char *dbg_max = getenv("JPGPU_DEBUG_MAX_PROGRESSIVE_SCANS");  // debugging aid: stop after N scans per frame
+    if (prog_pipelined_ && !dbg_max) {
+        // every scan is one stream: one launch, the work list ordered by level (workgroups start in list order, so a
+        // scan's producers are always running or done when it starts); dependent scans follow their producers' progress
+        const int n = prog_stream_begin_.back() - prog_stream_begin_.front();
+        hipError_t e = launch_progressive_streams(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr,
+                                                  (const HuffWork *)d_prog_work_.ptr + prog_stream_begin_.front(), n,
+                                                  (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr,
+                                                  (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, 1);
+        if (e != hipSuccess) return hip_fail(e, "progressive_stream_kernel");
+        return JPGPU_OK;
+    }
     for (size_t k = 0; k + 1 < prog_begin_.size(); k++) {
         if (dbg_max && (int)k >= atoi(dbg_max)) break;
         hipError_t e = launch_progressive(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr,
@@ -633,7 +649,7 @@ int DeviceBatch::run_progressive() {
                                        (const HuffWork *)d_prog_work_.ptr + prog_stream_begin_[k],
                                        prog_stream_begin_[k + 1] - prog_stream_begin_[k], (const uint32_t *)d_ends_u_.ptr,
                                        (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr,
-                                       n_huff_slots_);
+                                       n_huff_slots_, 0);
         if (e != hipSuccess) return hip_fail(e, "progressive_stream_kernel");
     }
     return JPGPU_OK;

@@ -126,6 +126,7 @@ class DeviceBatch {
     std::vector<int> prog_begin_;
     // ... and the scans with few, long intervals (one wave per interval): prog_work[prog_stream_begin_[k] .. [k + 1])
     std::vector<int> prog_stream_begin_;
+    bool prog_pipelined_ = false;  // all progressive scans are single streams with <= 3 direct dependencies: one launch
     std::vector<std::pair<uint64_t, uint64_t>> prog_clear_;  // (first block, blocks) of every progressive frame's store
     // RGB / RGBA output for layouts without a fused conversion: INTERLEAVED_U8 samples in a scratch image first
     struct RgbConvert {

@@ -208,6 +208,12 @@ struct ScanJob {
     int kind = kScanSequential;
     uint8_t ss = 0, se = 63, ah = 0, al = 0;
     int ordinal = 0;              // dependency level inside the frame: scans of one level may run together
+    // direct dependencies (indices into the frame's scan list; transitive ones dropped): with them the scans of a frame
+    // can run as ONE launch, a dependent scan following its producers MCU row by MCU row (device_batch.cpp)
+    int deps[3] = {-1, -1, -1};
+    int n_deps = 0;           // > 3: the frame's scans run level by level
+    uint64_t dep_closure = 0; // every scan this one transitively depends on (bit = index in the frame's scan list)
+    bool has_consumers = false;
     uint16_t scan_dri = 0;        // DRI as read at ProcessScan time (ref: ...ProgressiveScanDecoder.cs:78), not at SOF
     uint8_t frame_bpm = 0;
     uint8_t fblk_base[kMaxScanComponents] = {};

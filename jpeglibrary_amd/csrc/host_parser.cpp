@@ -783,7 +783,9 @@ void ProgressiveFrame::add_scan(const HostDecoder &dec, const ScanHeader &scan, 
         job.units_per_line = (uint32_t)((fh.samples_per_line + 8 * c.hs - 1) / (8 * c.hs));
         job.total_units = job.units_per_line * (uint32_t)((fh.lines + 8 * c.vs - 1) / (8 * c.vs));
     }
-    for (const ScanJob &e : scans_) {
+    std::vector<int> sharing;
+    for (size_t ei = 0; ei < scans_.size(); ei++) {
+        const ScanJob &e = scans_[ei];
         const bool e_interleaved = e.scan_components != 1;
         const int e_lo = e_interleaved ? 0 : e.ss, e_hi = e_interleaved ? 0 : e.se;  // interleaved scans are DC scans
         const int lo = interleaved ? 0 : scan.ss, hi = interleaved ? 0 : scan.se;
@@ -791,7 +793,20 @@ void ProgressiveFrame::add_scan(const HostDecoder &dec, const ScanHeader &scan, 
         bool shares = false;
         for (int a = 0; a < job.scan_components; a++)
             for (int b = 0; b < e.scan_components; b++) shares |= job.comp[a].component_index == e.comp[b].component_index;
-        if (shares) job.ordinal = std::max(job.ordinal, e.ordinal + 1);
+        if (!shares) continue;
+        job.ordinal = std::max(job.ordinal, e.ordinal + 1);
+        sharing.push_back((int)ei);
+        if (ei < 64) job.dep_closure |= e.dep_closure | (1ull << ei);
+    }
+    // direct dependencies: sharing scans that no other sharing scan already waits for
+    if (scans_.size() >= 64) job.n_deps = 4;  // outside the bookkeeping: level by level
+    for (int ei : sharing) {
+        bool implied = false;
+        for (int fi : sharing) implied |= fi != ei && fi < 64 && ei < 64 && ((scans_[fi].dep_closure >> ei) & 1ull) != 0;
+        if (implied) continue;
+        if (job.n_deps < 3) job.deps[job.n_deps] = ei;
+        job.n_deps++;
+        scans_[ei].has_consumers = true;
     }
     for (int i = 0; i < job.scan_components; i++) {
         job.comp[i].dc = job.comp[i].ac = nullptr;

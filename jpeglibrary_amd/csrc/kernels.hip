@@ -1860,7 +1860,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                                                                 const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
                                                                 DevScanStatus *__restrict__ status,
                                                                 const DevHuffTable *__restrict__ huff_pool, int16_t *__restrict__ coefs,
-                                                                int n_slots) {
+                                                                int n_slots, int pipelined) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *tabs = smem;  // n_slots * sizeof(DevHuffTable)
     uint8_t *base = smem + (size_t)n_slots * sizeof(DevHuffTable);
@@ -1885,7 +1885,11 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
     const uint32_t total_units = s.total_mcus;
     const uint32_t dri_eff = s.dri ? s.dri : total_units;
     const uint32_t interval = wk.first_interval;
-    if (interval >= n_ends) return;
+    if (interval >= n_ends) {  // no data for this interval; followers must not wait for it
+        if (pipelined != 0 && s.publishes != 0 && lane == 0)
+            __hip_atomic_store(&status[wk.scan].pad[1], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     const uint32_t *eu = ends_u + s.ends_off;
     const uint32_t ustart = interval == 0 ? 0u : eu[interval - 1] + 2u;
     const uint32_t uend = eu[interval];
@@ -1944,6 +1948,57 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
     fr.bpm = s.frame_bpm;
     uint32_t err = 0;
 
+    // ---- one launch for all scans of all frames (pipelined != 0): a scan that refines what earlier scans stored follows
+    // them MCU row by MCU row.  Every scan that has followers publishes the number of restart units it has completed
+    // (after a device-scope release fence) every kPsPublishEvery units; a follower converts that to whole MCU rows of
+    // the frame -- the one currency scans of different interleaving share -- and waits (acquire) before it touches a row.
+    // Workgroups start in work-list order and the list is sorted by dependency level, so whatever a scan waits for
+    // is running or finished.
+    const bool publishes = pipelined != 0 && s.publishes != 0;
+    uint32_t *my_progress = &status[wk.scan].pad[1];
+    const uint32_t my_units_per_row = units_per_line * (ncomp == 1 ? (uint32_t)s.comp[0].v : 1u);
+    uint32_t dep_scan[3], dep_units_per_row[3];
+    uint32_t rows_ready = pipelined != 0 ? 0u : 0xFFFFFFFFu;  // MCU rows every producer has completed
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        dep_scan[k] = pipelined != 0 ? s.dep[k] : kNoDep;
+        dep_units_per_row[k] = 1;
+        if (dep_scan[k] != kNoDep) {
+            const DevScan &ds = scans[dep_scan[k]];
+            dep_units_per_row[k] = ds.units_per_line * (ds.scan_components == 1 ? (uint32_t)ds.comp[0].v : 1u);
+        }
+    }
+    if (dep_scan[0] == kNoDep) rows_ready = 0xFFFFFFFFu;
+    // wait until the producers have finished MCU row `row_`
+#define JPGPU_FOLLOW(row_)                                                                                      \
+    if ((row_) >= rows_ready) {                                                                                 \
+        for (;;) {                                                                                              \
+            uint32_t r_ = 0xFFFFFFFFu;                                                                          \
+            _Pragma("unroll") for (int k_ = 0; k_ < 3; k_++) {                                                  \
+                if (dep_scan[k_] == kNoDep) continue;                                                           \
+                const uint32_t p_ = __hip_atomic_load(&status[dep_scan[k_]].pad[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                const uint32_t q_ = p_ == 0xFFFFFFFFu ? p_ : p_ / dep_units_per_row[k_];                       \
+                r_ = q_ < r_ ? q_ : r_;                                                                         \
+            }                                                                                                   \
+            rows_ready = uni(r_);                                                                               \
+            if ((row_) < rows_ready) break;                                                                     \
+            __builtin_amdgcn_s_sleep(32);                                                                       \
+        }                                                                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                                      \
+    }
+#define JPGPU_PUBLISH(units_)                                                                                   \
+    if (publishes) {                                                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                                                      \
+        if (lane == 0) __hip_atomic_store(my_progress, (units_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   \
+    }
+    constexpr uint32_t kPsPublishEvery = 64;
+    // the scans at the end of the dependency chains are the long poles (the last refinement carries most of the bits):
+    // they win the issue arbitration against the scans sharing their SIMD
+    if (pipelined != 0) {
+        if (dep_scan[0] != kNoDep && !publishes) __builtin_amdgcn_s_setprio(3);
+        else if (dep_scan[0] != kNoDep) __builtin_amdgcn_s_setprio(2);
+    }
+
     if (ncomp != 1 || ss == 0) {
         // ---- DC scans (:92-168, ReadBlockProgressiveDC :227-253): interleaved, or one component.  A different table per
         // component: the window holds the stream bits only, codes are looked up one at a time.
@@ -1958,6 +2013,8 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
         uint32_t uy = first_unit / units_per_line, ux = first_unit - uy * units_per_line;  // interleaved: MCU; else block
         for (uint32_t u = 0; u < my_units && err == 0; u++) {
             JPGPU_ENSURE_STAGED()
+            if (rows_ready != 0xFFFFFFFFu) JPGPU_FOLLOW((first_unit + u) / my_units_per_row)
+            if ((u & (kPsPublishEvery - 1u)) == 0 && u != 0) JPGPU_PUBLISH(u)
 #pragma unroll
             for (uint32_t c = 0; c < kMaxScanComponents; c++) {
                 if (c >= ncomp || err != 0) continue;
@@ -2005,11 +2062,13 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
             ProgWalk w;
             prog_walk_init(w, p, first_unit, units_per_line);
             for (uint32_t u = 0; u < my_units && err == 0; u++, prog_walk_next(w, p, units_per_line)) {
+                if ((u & (kPsPublishEvery - 1u)) == 0 && u != 0) JPGPU_PUBLISH(u)
                 if (eobrun != 0) {
                     eobrun--;
                     continue;
                 }
                 JPGPU_ENSURE_STAGED()
+                JPGPU_FOLLOW(w.my)
                 uint64_t index = 0;
                 const bool real = prog_walk_index(fr, p, w, index);
                 int32_t c = 0;
@@ -2027,6 +2086,8 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
         } else {
             for (uint32_t done = 0; done < my_units && err == 0;) {
                 const uint32_t n = my_units - done < (uint32_t)kPsChunk ? my_units - done : (uint32_t)kPsChunk;
+                if (done != 0) JPGPU_PUBLISH(done)
+                JPGPU_FOLLOW((first_unit + done + n - 1u) / my_units_per_row)
                 if (lane < n) {
                     ProgWalk w;
                     prog_walk_init(w, p, first_unit + done + lane, units_per_line);
@@ -2061,9 +2122,12 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
             }
         }
     }
+    JPGPU_PUBLISH(0xFFFFFFFFu)  // finished (or failed: followers must not wait for units that will never come)
 #undef JPGPU_TOP_UP
 #undef JPGPU_ENSURE_STAGED
 #undef JPGPU_SETTLE
+#undef JPGPU_FOLLOW
+#undef JPGPU_PUBLISH
 
     if (lane == 0) {
         const uint32_t code = restart_check(s, st, &status[wk.scan], interval, n_ends, n_intervals, dri_eff, d.rem, err);
@@ -3284,11 +3348,11 @@ hipError_t launch_progressive(hipStream_t stream, const uint8_t *udata, const De
 // The same, one wave per (scan, restart interval): for scans with few, long intervals.
 hipError_t launch_progressive_streams(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                                       const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
-                                      int n_slots) {
+                                      int n_slots, int pipelined) {
     if (n_work <= 0) return hipSuccess;
     const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kPsLdsBytes;
     hipLaunchKernelGGL(progressive_stream_kernel, dim3(n_work), dim3(64), lds, stream, udata, scans, work, ends_u, status, huff_pool,
-                       coefs, n_slots);
+                       coefs, n_slots, pipelined);
     return hipGetLastError();
 }
 
