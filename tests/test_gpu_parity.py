@@ -768,3 +768,21 @@ def test_encoder_adversarial_content():
                 ref = po.encode_8bit(im, luma[0], luma[1], q)
                 assert o == ref, (q, luma, k, len(o), len(ref))
     assert b"\xff\x00" in jl.encode_batch([imgs[0]], (1, 1), 100)[0]
+
+
+@pytest.mark.parametrize("env", [
+    {"JPGPU_PROG_NO_PIPELINE": "1"},                    # wave-per-stream kernel, one launch per dependency level
+    {"JPGPU_PROG_STREAM_MAX_INTERVALS": "0"},           # lane-per-interval kernel for every scan
+    {"JPGPU_PROG_STREAM_MAX_INTERVALS": "1000000"},     # wave-per-stream kernel even for scans with many restart intervals
+])
+@pytest.mark.parametrize("name", ["progress.jpg", "yellowcat_progressive_restart.jpg"])
+def test_progressive_kernel_variants_agree_with_the_oracle(name, env, monkeypatch):
+    """The progressive path picks its kernel per scan (lanes per restart interval / one wave per stream) and runs the
+    stream kernel either as one pipelined launch or level by level: every combination must give the reference's samples."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    data = read_jpeg(name)
+    ref, _ = po.decode_8bit(data)
+    outs, results = jl.decode_batch([data, data])
+    for out in outs:
+        assert np.array_equal(np.asarray(out).reshape(ref.shape), ref)
