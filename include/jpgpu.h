@@ -293,6 +293,30 @@ void *jpgpu_encoder_output_device(const jpgpu_encoder *e, int i, size_t *bytes);
 /* quantised zig-zag blocks in encoding order (what ZigZagAndQuantizeBlock produced, JpegEncoder.cs:812-826) */
 int jpgpu_encoder_download_coefficients(jpgpu_encoder *e, int i, int16_t *dst, size_t cap_blocks);
 
+/* ------------------------------------------------------------------------------------------------
+ * (5) Optimizer -- replaces JpegOptimizer (ref: JpegOptimizer.cs) for single-scan baseline files:
+ *     SetInput (:57-63) + Scan() (:66-153) + SetOutput (:523-526) + Optimize(strip) (:540-648).  The marker walks run on
+ *     the host, the two symbol passes (ProcessScanBaseline :360-463, CopyScanBaseline :719-829) on the device, the new
+ *     Huffman tables are JpegHuffmanEncodingTableBuilder.Build(false) (JpegHuffmanEncodingTableBuilder.cs:68-175).
+ *     Not supported (JPGPU_ERR_NOT_SUPPORTED): more than one scan, progressive frames, MostOptimalCoding.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct jpgpu_optimizer jpgpu_optimizer;
+int jpgpu_optimizer_create(jpgpu_ctx *ctx, jpgpu_optimizer **out);
+void jpgpu_optimizer_destroy(jpgpu_optimizer *o);
+/* SetInput for n files (host marker walks + H2D); strip = Optimize(strip)'s argument */
+int jpgpu_optimizer_upload(jpgpu_optimizer *o, const uint8_t *const *jpeg, const size_t *len, int n, int strip);
+/* Scan() + Optimize(strip) for every file */
+int jpgpu_optimizer_run(jpgpu_optimizer *o);
+/* status of file i with the reference's exception classes; out_len = bytes Optimize() wrote */
+int jpgpu_optimizer_result(jpgpu_optimizer *o, int i, jpgpu_image_result *res, size_t *out_len);
+int jpgpu_optimizer_download(jpgpu_optimizer *o, int i, void *dst, size_t cap);  /* the IBufferWriter's content */
+/* what Scan() counted for table `table` of file i, in the order the reference creates its table builders (:381-413) */
+int jpgpu_optimizer_statistics(const jpgpu_optimizer *o, int i, int table, uint8_t *table_class, uint8_t *identifier, uint32_t *counts);
+int jpgpu_optimizer_last_ms(const jpgpu_optimizer *o, float *ms);  /* device time of the last run (HIP events) */
+/* JpegHuffmanEncodingTableBuilder.Build(false) for one table: DHT counts and values, and GetCode() for all 256 symbols */
+int jpgpu_build_optimal_huffman_table(const uint32_t *counts, uint8_t *bits, uint8_t *values, int *num_values, uint16_t *code,
+                                      uint8_t *length);
+
 #ifdef __cplusplus
 }
 #endif

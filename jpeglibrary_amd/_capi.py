@@ -129,6 +129,15 @@ SYMBOLS = [
     ("jpgpu_encoder_download", C.c_int, [_P, C.c_int, C.c_void_p, C.c_size_t]),
     ("jpgpu_encoder_output_device", C.c_void_p, [_P, C.c_int, C.POINTER(C.c_size_t)]),
     ("jpgpu_encoder_download_coefficients", C.c_int, [_P, C.c_int, C.c_void_p, C.c_size_t]),
+    ("jpgpu_optimizer_create", C.c_int, [_P, C.POINTER(_P)]),
+    ("jpgpu_optimizer_destroy", None, [_P]),
+    ("jpgpu_optimizer_upload", C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int]),
+    ("jpgpu_optimizer_run", C.c_int, [_P]),
+    ("jpgpu_optimizer_result", C.c_int, [_P, C.c_int, C.POINTER(ImageResult), C.POINTER(C.c_size_t)]),
+    ("jpgpu_optimizer_download", C.c_int, [_P, C.c_int, C.c_void_p, C.c_size_t]),
+    ("jpgpu_optimizer_statistics", C.c_int, [_P, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("jpgpu_optimizer_last_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("jpgpu_build_optimal_huffman_table", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]),
 ]
 
 

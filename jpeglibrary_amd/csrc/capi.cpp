@@ -10,6 +10,7 @@
 #include "../../include/jpgpu.h"
 #include "device_batch.h"
 #include "device_encode.h"
+#include "device_optimize.h"
 #include "host.h"
 
 using namespace jpgpu;
@@ -685,6 +686,64 @@ int jpgpu_encoder_download(jpgpu_encoder *enc, int i, void *dst, size_t cap) { J
 void *jpgpu_encoder_output_device(const jpgpu_encoder *enc, int i, size_t *bytes) { return enc ? enc->impl.output_device(i, bytes) : nullptr; }
 int jpgpu_encoder_download_coefficients(jpgpu_encoder *enc, int i, int16_t *dst, size_t cap_blocks) {
     JPGPU_GUARD(enc, enc->impl.download_coefficients(i, dst, cap_blocks));
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ (5) optimizer
+
+struct jpgpu_optimizer {
+    jpgpu_ctx *ctx;
+    OptimizeBatch impl;
+    explicit jpgpu_optimizer(jpgpu_ctx *c) : ctx(c), impl(c) {}
+};
+
+extern "C" {
+
+int jpgpu_optimizer_create(jpgpu_ctx *ctx, jpgpu_optimizer **out) {
+    if (!ctx || !out) return JPGPU_ERR_ARGUMENT;
+    *out = new (std::nothrow) jpgpu_optimizer(ctx);
+    return *out ? JPGPU_OK : JPGPU_ERR_OUT_OF_MEMORY;
+}
+void jpgpu_optimizer_destroy(jpgpu_optimizer *opt) { delete opt; }
+int jpgpu_optimizer_upload(jpgpu_optimizer *opt, const uint8_t *const *jpeg, const size_t *len, int n, int strip) {
+    JPGPU_GUARD(opt, opt->impl.upload(jpeg, len, n, strip));
+}
+int jpgpu_optimizer_run(jpgpu_optimizer *opt) { JPGPU_GUARD(opt, opt->impl.run()); }
+int jpgpu_optimizer_result(jpgpu_optimizer *opt, int i, jpgpu_image_result *res, size_t *out_len) {
+    JPGPU_GUARD(opt, opt->impl.result(i, res, out_len));
+}
+int jpgpu_optimizer_download(jpgpu_optimizer *opt, int i, void *dst, size_t cap) { JPGPU_GUARD(opt, opt->impl.download(i, dst, cap)); }
+int jpgpu_optimizer_statistics(const jpgpu_optimizer *opt, int i, int table, uint8_t *table_class, uint8_t *identifier, uint32_t *counts) {
+    if (!opt || !table_class || !identifier || !counts) return JPGPU_ERR_ARGUMENT;
+    return opt->impl.statistics(i, table, table_class, identifier, counts) ? JPGPU_OK : JPGPU_ERR_ARGUMENT;
+}
+int jpgpu_optimizer_last_ms(const jpgpu_optimizer *opt, float *ms) {
+    if (!opt || !ms) return JPGPU_ERR_ARGUMENT;
+    *ms = opt->impl.last_ms();
+    return JPGPU_OK;
+}
+int jpgpu_build_optimal_huffman_table(const uint32_t *counts, uint8_t *bits, uint8_t *values, int *num_values, uint16_t *code, uint8_t *length) {
+    if (!counts || !bits || !values || !num_values) return JPGPU_ERR_ARGUMENT;
+    std::vector<OptimalCode> codes;
+    if (!build_optimal_table(counts, &codes)) return JPGPU_ERR_INVALID_OPERATION;
+    memset(bits, 0, 16);
+    for (size_t i = 0; i < codes.size(); i++) {
+        if (codes[i].length >= 1 && codes[i].length <= 16) bits[codes[i].length - 1]++;
+        values[i] = codes[i].symbol;
+    }
+    *num_values = (int)codes.size();
+    if (code && length) {
+        for (int s = 0; s < 256; s++) {
+            code[s] = codes[0].code;
+            length[s] = codes[0].length;
+        }
+        for (const OptimalCode &c : codes) {
+            code[c.symbol] = c.code;
+            length[c.symbol] = c.length;
+        }
+    }
+    return JPGPU_OK;
 }
 
 }  // extern "C"

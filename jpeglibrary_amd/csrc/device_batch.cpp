@@ -556,8 +556,8 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_ends_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},
         {&d_ends_u_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},
         {&d_unstuffed_, nullptr, 0, (size_t)input_bytes_},
-        {&d_coefs_, nullptr, 0, (size_t)total_blocks_ * 128 + (size_t)kIdctBlocksPerWg * 128 + 256},  // + one tile of slack (IDCT DMA reads whole tiles)
-        {&d_out_, nullptr, 0, (size_t)out_bytes_ + 256},
+        {&d_coefs_, nullptr, 0, entropy_only_ ? 256 : (size_t)total_blocks_ * 128 + (size_t)kIdctBlocksPerWg * 128 + 256},  // + one tile of slack (IDCT DMA reads whole tiles)
+        {&d_out_, nullptr, 0, entropy_only_ ? 256 : (size_t)out_bytes_ + 256},
         {&d_rgb_scratch_, nullptr, 0, rgb_convert_.empty() ? 0 : (size_t)out_bytes_ + 256},
         {&d_input_, nullptr, 0, (size_t)input_bytes_},
     };

@@ -85,8 +85,12 @@ class DeviceBatch {
     void totals(uint64_t *compressed, uint64_t *blocks, uint64_t *pixels, uint64_t *out_bytes) const;
     int format() const { return format_; }
     int last_subseq_rounds() const { return last_subseq_rounds_; }
+    // the optimizer path only needs the files, the scan descriptors and the marker index: no coefficient / sample buffers
+    void set_entropy_only(bool on) { entropy_only_ = on; }
 
   private:
+    friend class OptimizeBatch;
+    bool entropy_only_ = false;
     int fail(int status, const std::string &msg);
     int hip_fail(hipError_t e, const char *what);
     int layout_and_upload(const std::vector<const uint8_t *> &file_ptr, const std::vector<size_t> &file_len);

@@ -1,0 +1,675 @@
+// jpeglibrary_amd/csrc/device_optimize.cpp -- JpegOptimizer (ref: JpegOptimizer.cs) for a batch of baseline files.
+//
+// The reference runs two passes over one file: Scan() decodes every symbol of the scan and counts it per Huffman table
+// (:360-463), builds new tables from the counts (JpegHuffmanEncodingTableBuilder.Build), and Optimize() walks the file
+// again, copying the segments it keeps, writing the new DHT in place of the first one and re-writing the scan symbol by
+// symbol with the new codes (:540-880).  Here the marker walks run on the host (they touch a few hundred bytes), the
+// symbol passes on the GPU: K1 (marker index + unstuffing, shared with the decoder) then KT count -> host table build ->
+// KT measure -> exclusive scan -> KT emit (kernels.hip).  The output is assembled from the host pieces and the
+// device-resident scan data at download time.
+//
+// Fences (reported as JPGPU_ERR_NOT_SUPPORTED): files with more than one scan (the reference builds its tables from the
+// LAST scan only, :462, and then fails or writes garbage for the others), progressive frames (:580-582), a DRI whose value
+// at the scan differs from the last DRI of the file (the decoder-side parser shared here latches the last one),
+// MostOptimalCoding (package merge).  Parity of the bytes: see oracle/jpegopt.inc's header (unpinned; .NET's unstable
+// sort decides the order of equal-length symbols in the DHT).
+#include "device_optimize.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace jpgpu {
+
+// ------------------------------------------------------------------------------------------------ table builder
+namespace {
+struct Sym {
+    int64_t frequency;
+    int16_t value;
+    uint16_t code_size;
+    int16_t others;
+};
+inline int cmp_size(const Sym &x, const Sym &y) { return x.code_size < y.code_size ? -1 : (x.code_size > y.code_size ? 1 : 0); }
+
+// Array.Sort(T[], Comparison<T>) of .NET Core 3.0+ / .NET 5+ (ArraySortHelper<T>.IntrospectiveSort): the reference sorts
+// its symbols by code size with it, and the sort is not stable.
+struct NetSort {
+    static void swap_if_greater(Sym *k, int i, int j) {
+        if (i != j && cmp_size(k[i], k[j]) > 0) std::swap(k[i], k[j]);
+    }
+    static void insertion(Sym *k, int n) {
+        for (int i = 0; i < n - 1; i++) {
+            const Sym t = k[i + 1];
+            int j = i;
+            while (j >= 0 && cmp_size(t, k[j]) < 0) {
+                k[j + 1] = k[j];
+                j--;
+            }
+            k[j + 1] = t;
+        }
+    }
+    static void down_heap(Sym *k, int i, int n) {
+        const Sym d = k[i - 1];
+        while (i <= n >> 1) {
+            int child = 2 * i;
+            if (child < n && cmp_size(k[child - 1], k[child]) < 0) child++;
+            if (!(cmp_size(d, k[child - 1]) < 0)) break;
+            k[i - 1] = k[child - 1];
+            i = child;
+        }
+        k[i - 1] = d;
+    }
+    static void heap(Sym *k, int n) {
+        for (int i = n >> 1; i >= 1; i--) down_heap(k, i, n);
+        for (int i = n; i > 1; i--) {
+            std::swap(k[0], k[i - 1]);
+            down_heap(k, 1, i - 1);
+        }
+    }
+    static int partition(Sym *k, int n) {
+        const int hi = n - 1, middle = hi >> 1;
+        swap_if_greater(k, 0, middle);
+        swap_if_greater(k, 0, hi);
+        swap_if_greater(k, middle, hi);
+        const Sym pivot = k[middle];
+        std::swap(k[middle], k[hi - 1]);
+        int left = 0, right = hi - 1;
+        while (left < right) {
+            while (cmp_size(k[++left], pivot) < 0) {
+            }
+            while (cmp_size(pivot, k[--right]) < 0) {
+            }
+            if (left >= right) break;
+            std::swap(k[left], k[right]);
+        }
+        if (left != hi - 1) std::swap(k[left], k[hi - 1]);
+        return left;
+    }
+    static void intro(Sym *k, int n, int depth) {
+        while (n > 1) {
+            if (n <= 16) {
+                if (n == 2) {
+                    swap_if_greater(k, 0, 1);
+                } else if (n == 3) {
+                    swap_if_greater(k, 0, 1);
+                    swap_if_greater(k, 0, 2);
+                    swap_if_greater(k, 1, 2);
+                } else {
+                    insertion(k, n);
+                }
+                return;
+            }
+            if (depth == 0) {
+                heap(k, n);
+                return;
+            }
+            depth--;
+            const int p = partition(k, n);
+            intro(k + p + 1, n - (p + 1), depth);
+            n = p;
+        }
+    }
+    static void sort(Sym *k, int n) {
+        if (n < 2) return;
+        int log2 = 0;
+        for (unsigned v = (unsigned)n; v > 1; v >>= 1) log2++;
+        intro(k, n, 2 * (log2 + 1));
+    }
+};
+}  // namespace
+
+bool build_optimal_table(const uint32_t freq[256], std::vector<OptimalCode> *codes) {
+    int code_count = 0;
+    for (int i = 0; i < 256; i++) code_count += freq[i] != 0;
+    if (code_count == 0) return false;
+    Sym s[257];
+    int n = 0;
+    for (int i = 0; i < 256; i++)
+        if (freq[i] != 0) s[n++] = {(int64_t)freq[i], (int16_t)i, 0, -1};
+    s[n++] = {1, -1, 0, -1};  // the reserved symbol that keeps the all-ones code unused
+    // Figure K.1 as the reference runs it (:178-235): least frequency, FIRST index among equals
+    for (;;) {
+        int v1 = -1, v2 = -1;
+        int64_t f1 = -1, f2 = -1;
+        for (int i = 0; i < n; i++)
+            if (s[i].frequency >= 0 && (v1 == -1 || s[i].frequency < f1)) {
+                v1 = i;
+                f1 = s[i].frequency;
+            }
+        for (int i = 0; i < n; i++)
+            if (s[i].frequency >= 0 && i != v1 && (v2 == -1 || s[i].frequency < f2)) {
+                v2 = i;
+                f2 = s[i].frequency;
+            }
+        if (v2 == -1) break;
+        s[v1].frequency += s[v2].frequency;
+        s[v2].frequency = -1;
+        s[v1].code_size++;
+        while (s[v1].others != -1) {
+            v1 = s[v1].others;
+            s[v1].code_size++;
+        }
+        s[v1].others = (int16_t)v2;
+        s[v2].code_size++;
+        while (s[v2].others != -1) {
+            v2 = s[v2].others;
+            s[v2].code_size++;
+        }
+    }
+    // Figures K.2 / K.3 on the reference's 0-based 60-entry byte array (:117-158)
+    uint8_t bits[60] = {};
+    int index = 32;
+    for (int i = 0; i < n; i++) {
+        const int cs = s[i].code_size;
+        if (cs > 0) {
+            index = std::max(index, cs);
+            if (index >= 60) return false;
+            bits[cs - 1]++;
+        }
+    }
+    for (;;) {
+        while (bits[index] > 0) {
+            int j = index - 1;
+            do {
+                j -= 1;
+            } while (bits[j] == 0);
+            bits[index] = (uint8_t)(bits[index] - 2);
+            bits[index - 1] = (uint8_t)(bits[index - 1] + 1);
+            bits[j + 1] = (uint8_t)(bits[j + 1] + 2);
+            bits[j] = (uint8_t)(bits[j] - 1);
+        }
+        index -= 1;
+        if (index != 15) continue;
+        while (bits[index] == 0) index--;
+        bits[index]--;
+        break;
+    }
+    for (int i = 0; i < n; i++)
+        if (s[i].value == -1) s[i].code_size = 0xFFFF;
+    NetSort::sort(s, n);
+    // BuildCanonicalCode (:237-283)
+    codes->assign((size_t)code_count, OptimalCode{0, 0, 0});
+    int length = 1, at = 0;
+    uint8_t left = bits[0];
+    for (int i = 0; i < code_count; i++) {
+        while (left == 0) {
+            left = bits[++at];
+            length++;
+        }
+        left--;
+        (*codes)[i].symbol = (uint8_t)s[i].value;
+        (*codes)[i].length = (uint8_t)length;
+    }
+    uint16_t code = 0;
+    int count = (*codes)[0].length;
+    for (int i = 1; i < code_count; i++) {
+        OptimalCode &c = (*codes)[i];
+        if (c.length > count) {
+            code++;
+            code = (uint16_t)(code << (c.length - count));
+            c.code = code;
+            count = c.length;
+        } else {
+            c.code = ++code;
+        }
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ batch
+OptimizeBatch::~OptimizeBatch() {
+    for (DevBuffer *b : {&d_work_, &d_scan_ids_, &d_hist_, &d_enc_, &d_sizes_, &d_offsets_, &d_base_, &d_totals_, &d_out_}) b->release();
+    if (ev0_) (void)hipEventDestroy(ev0_);
+    if (ev1_) (void)hipEventDestroy(ev1_);
+}
+int OptimizeBatch::fail(int status, const std::string &msg) {
+    ctx_->last_error = msg;
+    return status;
+}
+int OptimizeBatch::hip_fail(hipError_t e, const char *what) {
+    return fail(JPGPU_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+namespace {
+void put_marker(std::string &o, int m) {
+    o.push_back((char)0xFF);
+    o.push_back((char)m);
+}
+void put_length(std::string &o, uint16_t length) {  // JpegWriter.WriteLength: length + 2, big endian (:309-321)
+    const uint16_t v = (uint16_t)(length + 2);
+    o.push_back((char)(v >> 8));
+    o.push_back((char)v);
+}
+struct Refuse {
+    int status, detail;
+    std::string msg;
+};
+[[noreturn]] void refuse(int status, const std::string &msg, int detail = 0) { throw Refuse{status, detail, msg}; }
+std::string at_offset(int off, const char *msg) { return "Failed to decode JPEG data at offset " + std::to_string(off) + ". " + msg; }
+}  // namespace
+
+// Scan()'s and Optimize()'s marker walks (JpegOptimizer.cs:66-153, :540-648) on the host.  Leaves the pieces of the
+// output in p.pieces; the scan itself is located for the device passes.
+void OptimizeBatch::plan_file(Plan &p, const uint8_t *data, size_t len, bool strip) {
+    // ---- Scan(): tables, frame, restart interval as of the scan; exactly one scan
+    std::vector<QuantTable> quant;  // _quantizationTables: replace by identifier, else append (:319-338)
+    bool have_frame = false;
+    int n_scans = 0;
+    uint16_t dri = 0, dri_at_scan = 0;
+    {
+        if (len == 0) refuse(JPGPU_ERR_INVALID_OPERATION, "Input buffer is not specified.");
+        MarkerReader r(data, len);
+        bool eoi = false;
+        while (!eoi && !r.is_empty()) {
+            int marker;
+            if (!r.try_read_marker(&marker)) refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "No marker found."));
+            uint16_t length;
+            const uint8_t *buf;
+            auto segment = [&]() {
+                if (!r.try_read_length(&length))
+                    refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "Unexpected end of input data when reading segment length."));
+                if (!r.try_read_bytes(length, &buf))
+                    refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "Unexpected end of input data when reading segment content."));
+            };
+            switch (marker) {
+            case 0xD8: break;
+            case 0xC0:
+            case 0xC1: {
+                segment();
+                FrameHeader fh;
+                int consumed = 0;
+                if (!FrameHeader::try_parse(buf, length, false, &fh, &consumed))
+                    refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count() - length + consumed, "Failed to parse frame header."));
+                if (have_frame) refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "Multiple frame is not supported."));
+                have_frame = true;
+                break;
+            }
+            case 0xC2: refuse(JPGPU_ERR_NOT_SUPPORTED, "Progressive JPEG is not supported currently.", kDetailUnsupportedFrame);
+            case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
+                refuse(JPGPU_ERR_INVALID_DATA,
+                       at_offset(r.consumed_byte_count(), ("This type of JPEG stream is not supported (StartOfFrame" + std::to_string(marker - 0xC0) + ").").c_str()),
+                       kDetailUnsupportedFrame);
+            case 0xC4: segment(); break;  // the decoding tables are the decoder-side parser's business (batch_)
+            case 0xDB: {
+                segment();
+                const int base = r.consumed_byte_count() - length;
+                int off = 0;
+                while (off < (int)length) {
+                    QuantTable t;
+                    int consumed = 0;
+                    if (!QuantTable::try_parse(buf + off, (size_t)length - off, &t, &consumed))
+                        refuse(JPGPU_ERR_INVALID_DATA, at_offset(base + off, "Failed to parse quantization table."));
+                    off += consumed;
+                    bool replaced = false;
+                    for (QuantTable &q : quant)
+                        if (q.identifier == t.identifier) {
+                            q = t;
+                            replaced = true;
+                        }
+                    if (!replaced) quant.push_back(t);
+                }
+                break;
+            }
+            case 0xDD:
+                segment();
+                if (length < 2)
+                    refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "Unexpected end of input data when reading segment content."));
+                dri = (uint16_t)(buf[0] << 8 | buf[1]);
+                break;
+            case 0xDA: {
+                segment();
+                if (!have_frame) refuse(JPGPU_ERR_INVALID_OPERATION, "Object reference not set to an instance of an object.");
+                if (++n_scans > 1)
+                    refuse(JPGPU_ERR_NOT_SUPPORTED, "Files with more than one scan are not supported by the optimizer path.", kDetailUnsupportedFrame);
+                dri_at_scan = dri;
+                const size_t end = find_scan_end(r.remaining_bytes(), (size_t)r.remaining_byte_count());
+                r.try_advance((int)end);
+                break;
+            }
+            case 0xD0: case 0xD1: case 0xD2: case 0xD3: case 0xD4: case 0xD5: case 0xD6: case 0xD7: break;
+            case 0xD9: eoi = true; break;
+            default:
+                if (!r.try_read_length(&length))
+                    refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "Unexpected end of input data when reading segment length."));
+                if (!r.try_advance(length))
+                    refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "Unexpected end of input data reached."));
+                break;
+            }
+        }
+        if (n_scans == 0) refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "No image data is read."));
+        if (dri_at_scan != dri)
+            refuse(JPGPU_ERR_NOT_SUPPORTED, "A restart interval that changes after the scan is not supported by the optimizer path.", kDetailUnsupportedFrame);
+    }
+    // ---- Optimize(strip)
+    MarkerReader r(data, len);
+    std::string cur;
+    auto flush = [&]() {
+        if (!cur.empty()) p.pieces.push_back({Piece::kBytes, cur});
+        cur.clear();
+    };
+    auto copy_segment = [&](const uint8_t **bytes, uint16_t *n) {  // CopyMarkerData (:661-675)
+        uint16_t length;
+        const uint8_t *buf;
+        if (!r.try_read_length(&length))
+            refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "Unexpected end of input data when reading segment length."));
+        if (!r.try_read_bytes(length, &buf))
+            refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "Unexpected end of input data when reading segment content."));
+        put_length(cur, length);
+        cur.append((const char *)buf, length);
+        if (bytes) *bytes = buf;
+        if (n) *n = length;
+    };
+    bool eoi = false, dht_written = false, dqt_written = false;
+    while (!eoi && !r.is_empty()) {
+        int marker;
+        if (!r.try_read_marker(&marker)) refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "No marker found."));
+        switch (marker) {
+        case 0xD8: put_marker(cur, marker); break;
+        case 0xE0:
+        case 0xC0:
+        case 0xC1:
+            put_marker(cur, marker);
+            copy_segment(nullptr, nullptr);
+            break;
+        case 0xC4:  // the segment's own bytes are not skipped: the marker search runs through them (:596-602)
+            if (!dht_written) {
+                flush();
+                p.pieces.push_back({Piece::kHuffmanTables, std::string()});
+                dht_written = true;
+            }
+            break;
+        case 0xDB:
+            if (!dqt_written) {
+                put_marker(cur, 0xDB);
+                uint16_t total = 0;
+                for (const QuantTable &q : quant) total = (uint16_t)(total + (uint8_t)(q.precision == 0 ? 65 : 129));
+                put_length(cur, total);
+                for (const QuantTable &q : quant) {
+                    cur.push_back((char)(q.precision << 4 | (q.identifier & 0xF)));
+                    for (int k = 0; k < 64; k++) {
+                        if (q.precision != 0) cur.push_back((char)(q.elements[k] >> 8));
+                        cur.push_back((char)q.elements[k]);
+                    }
+                }
+                dqt_written = true;
+            }
+            break;
+        case 0xDA: {
+            put_marker(cur, marker);
+            copy_segment(nullptr, nullptr);
+            flush();
+            p.pieces.push_back({Piece::kEntropy, std::string()});
+            const size_t end = find_scan_end(r.remaining_bytes(), (size_t)r.remaining_byte_count());
+            r.try_advance((int)end);
+            break;
+        }
+        case 0xD0: case 0xD1: case 0xD2: case 0xD3: case 0xD4: case 0xD5: case 0xD6: case 0xD7: put_marker(cur, marker); break;
+        case 0xD9:
+            put_marker(cur, 0xD9);
+            eoi = true;
+            break;
+        default:
+            if (strip) {
+                uint16_t length;
+                if (!r.try_read_length(&length))
+                    refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "Unexpected end of input data when reading segment length."));
+                if (!r.try_advance(length))
+                    refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "Unexpected end of input data when reading segment content."));
+            } else {
+                put_marker(cur, marker);
+                copy_segment(nullptr, nullptr);
+            }
+            break;
+        }
+    }
+    flush();
+}
+
+int OptimizeBatch::upload(const uint8_t *const *jpeg, const size_t *len, int n, int strip) {
+    if (n < 0 || (n > 0 && (!jpeg || !len))) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_optimizer_upload: bad arguments");
+    plans_.assign((size_t)n, Plan());
+    ran_ = false;
+    for (int i = 0; i < n; i++) {
+        try {
+            plan_file(plans_[i], jpeg[i], len[i], strip != 0);
+        } catch (const Refuse &e) {
+            plans_[i].status = e.status;
+            plans_[i].detail = e.detail;
+            plans_[i].error = e.msg;
+            plans_[i].pieces.clear();
+        }
+    }
+    // the decoder-side parser resolves the scan (tables, geometry, restart interval) and lays the files out in HBM
+    batch_.set_entropy_only(true);
+    int rc = batch_.upload_files(jpeg, len, n, JPGPU_FMT_PLANAR_U8);
+    if (rc != JPGPU_OK) return rc;
+    scan_ids_.clear();
+    work_.clear();
+    for (int i = 0; i < n; i++) {
+        Plan &p = plans_[i];
+        if (p.status != JPGPU_OK) continue;
+        const ImagePlan *img = batch_.image(i);
+        if (img->status != JPGPU_OK) {
+            p.status = img->status;
+            p.detail = img->detail;
+            p.error = img->error;
+            continue;
+        }
+        if (img->jobs.size() != 1 || batch_.jobs_[img->jobs[0]].kind != kScanSequential) {
+            p.status = JPGPU_ERR_NOT_SUPPORTED;
+            p.detail = kDetailUnsupportedFrame;
+            p.error = "Only single-scan baseline files are supported by the optimizer path.";
+            continue;
+        }
+        p.job = img->jobs[0];
+        const DevScan &s = batch_.h_scans_[p.job];
+        scan_ids_.push_back((uint32_t)p.job);
+        for (uint32_t first = 0; first < s.n_intervals; first += 256) work_.push_back({(uint32_t)p.job, first});
+    }
+    struct Up {
+        DevBuffer *buf;
+        const void *src;
+        size_t bytes, reserve;
+    };
+    const size_t n_jobs = batch_.h_scans_.size();
+    const Up ups[] = {
+        {&d_work_, work_.data(), work_.size() * sizeof(HuffWork), 0},
+        {&d_scan_ids_, scan_ids_.data(), scan_ids_.size() * sizeof(uint32_t), 0},
+        {&d_hist_, nullptr, 0, n_jobs * kMaxHuffSlots * 256 * sizeof(uint32_t) + 256},
+        {&d_enc_, nullptr, 0, n_jobs * kMaxHuffSlots * sizeof(EncHuffTable) + 256},
+        {&d_sizes_, nullptr, 0, (size_t)batch_.total_ends_ * sizeof(uint32_t) + 256},
+        {&d_offsets_, nullptr, 0, (size_t)batch_.total_ends_ * sizeof(uint64_t) + 256},
+        {&d_base_, nullptr, 0, scan_ids_.size() * sizeof(uint64_t) + 256},
+        {&d_totals_, nullptr, 0, scan_ids_.size() * sizeof(uint64_t) + 256},
+    };
+    for (const Up &u : ups) {
+        hipError_t e = u.buf->reserve(std::max(u.bytes, u.reserve));
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+        if (u.bytes) {
+            e = hipMemcpyAsync(u.buf->ptr, u.src, u.bytes, hipMemcpyHostToDevice, ctx_->stream);
+            if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(optimizer work)");
+        }
+    }
+    return JPGPU_OK;
+}
+
+int OptimizeBatch::run() {
+    ran_ = false;
+    if (!ev0_) {
+        if (hipEventCreate(&ev0_) != hipSuccess || hipEventCreate(&ev1_) != hipSuccess) return fail(JPGPU_ERR_DEVICE, "hipEventCreate");
+    }
+    (void)hipEventRecord(ev0_, ctx_->stream);
+    int rc = batch_.run_marker_index();
+    if (rc != JPGPU_OK) return rc;
+    const size_t n_jobs = batch_.h_scans_.size();
+    const int n_work = (int)work_.size(), n_scans = (int)scan_ids_.size();
+    const uint8_t *udata = (const uint8_t *)batch_.d_unstuffed_.ptr, *input = (const uint8_t *)batch_.d_input_.ptr;
+    const DevScan *scans = (const DevScan *)batch_.d_scans_.ptr;
+    DevScanStatus *status = (DevScanStatus *)batch_.d_status_.ptr;
+    const DevHuffTable *pool = (const DevHuffTable *)batch_.d_huff_pool_.ptr;
+    const uint32_t *ends_u = (const uint32_t *)batch_.d_ends_u_.ptr, *ends_raw = (const uint32_t *)batch_.d_ends_.ptr;
+    const int n_slots = batch_.n_huff_slots_;
+    // ---- Scan(): IncrementCodeCount for every symbol
+    hipError_t e = hipMemsetAsync(d_hist_.ptr, 0, n_jobs * kMaxHuffSlots * 256 * sizeof(uint32_t), ctx_->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(histograms)");
+    e = launch_transcode(ctx_->stream, 0, udata, input, scans, (const HuffWork *)d_work_.ptr, n_work, ends_u, ends_raw, status, pool,
+                         (uint32_t *)d_hist_.ptr, nullptr, nullptr, nullptr, nullptr, n_slots);
+    if (e != hipSuccess) return hip_fail(e, "transcode_kernel<count>");
+    h_hist_.assign(n_jobs * kMaxHuffSlots * 256, 0);
+    e = hipMemcpyAsync(h_hist_.data(), d_hist_.ptr, h_hist_.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx_->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(histograms)");
+    e = hipStreamSynchronize(ctx_->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    // ---- BuildTables (:462): one table per (class, identifier) in builder-creation order == the job's slot order
+    std::vector<EncHuffTable> enc(n_jobs * kMaxHuffSlots);
+    memset(enc.data(), 0, enc.size() * sizeof(EncHuffTable));
+    for (Plan &p : plans_) {
+        if (p.status != JPGPU_OK || p.job < 0) continue;
+        const ScanJob &job = batch_.jobs_[p.job];
+        std::string body;
+        for (int t = 0; t < job.n_huff; t++) {
+            std::vector<OptimalCode> codes;
+            const uint32_t *freq = &h_hist_[((size_t)p.job * kMaxHuffSlots + t) * 256];
+            if (!build_optimal_table(freq, &codes)) continue;  // a failing scan: reported from the device status below
+            EncHuffTable &et = enc[(size_t)p.job * kMaxHuffSlots + t];
+            // GetCode(symbol) = codes[_symbolMap[symbol]], and _symbolMap is 0 for symbols without a code (JpegHuffmanEncodingTable.cs:18-33, 90-96)
+            for (int sym = 0; sym < 256; sym++) {
+                et.code[sym] = codes[0].code;
+                et.len[sym] = codes[0].length;
+            }
+            for (const OptimalCode &c : codes) {
+                et.code[c.symbol] = c.code;
+                et.len[c.symbol] = c.length;
+            }
+            // JpegHuffmanEncodingTableCollection.Write (:172-190) + JpegHuffmanEncodingTable.TryWrite (:37-79)
+            body.push_back((char)(job.huff_copy[t].table_class << 4 | (job.huff_copy[t].identifier & 0xF)));
+            for (int l = 1; l <= 16; l++) {
+                int count = 0;
+                for (const OptimalCode &c : codes) count += c.length == l;
+                body.push_back((char)count);
+            }
+            for (const OptimalCode &c : codes) body.push_back((char)c.symbol);
+        }
+        p.dht.clear();
+        put_marker(p.dht, 0xC4);
+        put_length(p.dht, (uint16_t)body.size());
+        p.dht += body;
+    }
+    e = hipMemcpyAsync(d_enc_.ptr, enc.data(), enc.size() * sizeof(EncHuffTable), hipMemcpyHostToDevice, ctx_->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(encoding tables)");
+    // ---- Optimize(): size of every interval, offsets, bytes
+    e = launch_transcode(ctx_->stream, 1, udata, input, scans, (const HuffWork *)d_work_.ptr, n_work, ends_u, ends_raw, status, pool, nullptr,
+                         (const EncHuffTable *)d_enc_.ptr, (uint32_t *)d_sizes_.ptr, nullptr, nullptr, n_slots);
+    if (e != hipSuccess) return hip_fail(e, "transcode_kernel<measure>");
+    e = launch_transcode_offsets(ctx_->stream, scans, (const uint32_t *)d_scan_ids_.ptr, n_scans, (const uint32_t *)d_sizes_.ptr, nullptr,
+                                 nullptr, (uint64_t *)d_totals_.ptr);
+    if (e != hipSuccess) return hip_fail(e, "transcode_offsets_kernel");
+    std::vector<uint64_t> totals((size_t)n_scans), base((size_t)n_scans);
+    if (n_scans) {
+        e = hipMemcpyAsync(totals.data(), d_totals_.ptr, totals.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(totals)");
+    }
+    e = hipStreamSynchronize(ctx_->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    uint64_t out_bytes = 0;
+    for (int k = 0; k < n_scans; k++) {
+        base[k] = out_bytes;
+        out_bytes = (out_bytes + totals[k] + 255) & ~(uint64_t)255;
+    }
+    e = d_out_.reserve((size_t)out_bytes + 256);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(optimizer output)");
+    if (n_scans) {
+        e = hipMemcpyAsync(d_base_.ptr, base.data(), base.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(bases)");
+    }
+    e = launch_transcode_offsets(ctx_->stream, scans, (const uint32_t *)d_scan_ids_.ptr, n_scans, (const uint32_t *)d_sizes_.ptr,
+                                 (const uint64_t *)d_base_.ptr, (uint64_t *)d_offsets_.ptr, nullptr);
+    if (e != hipSuccess) return hip_fail(e, "transcode_offsets_kernel");
+    e = launch_transcode(ctx_->stream, 2, udata, input, scans, (const HuffWork *)d_work_.ptr, n_work, ends_u, ends_raw, status, pool, nullptr,
+                         (const EncHuffTable *)d_enc_.ptr, nullptr, (const uint64_t *)d_offsets_.ptr, (uint8_t *)d_out_.ptr, n_slots);
+    if (e != hipSuccess) return hip_fail(e, "transcode_kernel<emit>");
+    (void)hipEventRecord(ev1_, ctx_->stream);
+    e = hipStreamSynchronize(ctx_->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    (void)hipEventElapsedTime(&last_ms_, ev0_, ev1_);
+    int k = 0;
+    for (Plan &p : plans_) {
+        if (p.status != JPGPU_OK || p.job < 0) continue;
+        p.entropy_off = base[k];
+        p.entropy_len = totals[k];
+        k++;
+        p.out_len = 0;
+        for (const Piece &pc : p.pieces)
+            p.out_len += pc.kind == Piece::kBytes ? pc.bytes.size() : (pc.kind == Piece::kHuffmanTables ? p.dht.size() : p.entropy_len);
+    }
+    ran_ = true;
+    return JPGPU_OK;
+}
+
+int OptimizeBatch::result(int i, jpgpu_image_result *res, size_t *out_len) {
+    if (i < 0 || i >= (int)plans_.size() || !res) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_optimizer_result: bad index");
+    memset(res, 0, sizeof *res);
+    if (out_len) *out_len = 0;
+    const Plan &p = plans_[i];
+    if (p.status != JPGPU_OK) {
+        res->status = p.status;
+        res->detail = p.detail;
+        ctx_->last_error = p.error;
+        return JPGPU_OK;
+    }
+    if (!ran_) return fail(JPGPU_ERR_INVALID_OPERATION, "jpgpu_optimizer_result: run() has not completed");
+    int rc = batch_.result(i, res);  // device-side scan errors, with the reference's exception classes
+    if (rc != JPGPU_OK) return rc;
+    if (res->status == JPGPU_OK) {
+        // a restart check that meets EOI (early EOI, or an MCU count that is a multiple of DRI) makes Scan() return before
+        // it builds its tables (:437-442); Optimize() then throws InvalidOperationException (:542-545)
+        const DevScan &s = batch_.h_scans_[p.job];
+        const DevScanStatus &st = batch_.h_status_[p.job];
+        const bool check_saw_eoi = s.dri != 0 && st.terminator == 0xD9 &&
+                                   (st.n_ends < s.n_intervals || (st.n_ends == s.n_intervals && s.restart_check_at_end != 0));
+        if (check_saw_eoi) {
+            res->status = JPGPU_ERR_INVALID_OPERATION;
+            ctx_->last_error = "Operation is not valid due to the current state of the object.";
+        }
+    }
+    if (res->status == JPGPU_OK && out_len) *out_len = (size_t)p.out_len;
+    return JPGPU_OK;
+}
+
+int OptimizeBatch::download(int i, void *dst, size_t cap) {
+    jpgpu_image_result res;
+    size_t n = 0;
+    int rc = result(i, &res, &n);
+    if (rc != JPGPU_OK) return rc;
+    if (res.status != JPGPU_OK) return fail(res.status, ctx_->last_error);
+    if (!dst || cap < n) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_optimizer_download: buffer too small");
+    const Plan &p = plans_[i];
+    uint8_t *o = (uint8_t *)dst;
+    for (const Piece &pc : p.pieces) {
+        if (pc.kind == Piece::kBytes) {
+            memcpy(o, pc.bytes.data(), pc.bytes.size());
+            o += pc.bytes.size();
+        } else if (pc.kind == Piece::kHuffmanTables) {
+            memcpy(o, p.dht.data(), p.dht.size());
+            o += p.dht.size();
+        } else if (p.entropy_len) {
+            hipError_t e = hipMemcpy(o, (const uint8_t *)d_out_.ptr + p.entropy_off, (size_t)p.entropy_len, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return hip_fail(e, "hipMemcpy(optimizer output)");
+            o += p.entropy_len;
+        }
+    }
+    return JPGPU_OK;
+}
+
+bool OptimizeBatch::statistics(int i, int t, uint8_t *table_class, uint8_t *identifier, uint32_t counts[256]) const {
+    if (i < 0 || i >= (int)plans_.size() || !ran_) return false;
+    const Plan &p = plans_[i];
+    if (p.status != JPGPU_OK || p.job < 0) return false;
+    const ScanJob &job = batch_.jobs_[p.job];
+    if (t < 0 || t >= job.n_huff) return false;
+    *table_class = job.huff_copy[t].table_class;
+    *identifier = job.huff_copy[t].identifier;
+    memcpy(counts, &h_hist_[((size_t)p.job * kMaxHuffSlots + t) * 256], 256 * sizeof(uint32_t));
+    return true;
+}
+
+}  // namespace jpgpu

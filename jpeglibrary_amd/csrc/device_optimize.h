@@ -1,0 +1,67 @@
+// jpeglibrary_amd/csrc/device_optimize.h -- device-resident batch of JpegOptimizer runs (see device_optimize.cpp)
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/jpgpu.h"
+#include "device_batch.h"
+#include "encode_kernels.h"
+
+namespace jpgpu {
+
+// JpegHuffmanEncodingTableBuilder.Build(false) (ref: JpegHuffmanEncodingTableBuilder.cs:68-175, 237-283): canonical
+// codes in DHT order from the 256 symbol counts.  false = "No symbol is recorded." / a code size beyond the
+// reference's 60-entry array.
+struct OptimalCode {
+    uint16_t code;
+    uint8_t symbol, length;
+};
+bool build_optimal_table(const uint32_t freq[256], std::vector<OptimalCode> *codes);
+
+class OptimizeBatch {
+  public:
+    explicit OptimizeBatch(jpgpu_ctx *ctx) : ctx_(ctx), batch_(ctx) {}
+    ~OptimizeBatch();
+    // SetInput x n: host marker walks (Scan()'s and Optimize()'s) + H2D of the files
+    int upload(const uint8_t *const *jpeg, const size_t *len, int n, int strip);
+    // Scan() + Optimize(strip) x n: statistics, tables, transcode
+    int run();
+    int size() const { return (int)plans_.size(); }
+    int result(int i, jpgpu_image_result *res, size_t *out_len);
+    int download(int i, void *dst, size_t cap);
+    // the statistics Scan() collected for table `t` of image i (builder-creation order); false past the last table
+    bool statistics(int i, int t, uint8_t *table_class, uint8_t *identifier, uint32_t counts[256]) const;
+    float last_ms() const { return last_ms_; }
+
+  private:
+    // Optimize()'s output is a fixed sequence of pieces: bytes known on the host, the new DHT segment, the scan's data
+    struct Piece {
+        enum Kind { kBytes, kHuffmanTables, kEntropy } kind;
+        std::string bytes;
+    };
+    struct Plan {
+        int status = JPGPU_OK, detail = 0;
+        std::string error;
+        std::vector<Piece> pieces;
+        int job = -1;  // scan job inside batch_
+        std::string dht;  // the rewritten DHT segment (marker, length, tables)
+        uint64_t entropy_off = 0, entropy_len = 0;
+        uint64_t out_len = 0;
+    };
+    int fail(int status, const std::string &msg);
+    int hip_fail(hipError_t e, const char *what);
+    void plan_file(Plan &p, const uint8_t *data, size_t len, bool strip);
+
+    jpgpu_ctx *ctx_;
+    DeviceBatch batch_;
+    std::vector<Plan> plans_;
+    std::vector<uint32_t> scan_ids_;   // jobs that are transcoded
+    std::vector<HuffWork> work_;
+    std::vector<uint32_t> h_hist_;     // [jobs][8][256]
+    bool ran_ = false;
+    float last_ms_ = 0;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    DevBuffer d_work_, d_scan_ids_, d_hist_, d_enc_, d_sizes_, d_offsets_, d_base_, d_totals_, d_out_;
+};
+
+}  // namespace jpgpu

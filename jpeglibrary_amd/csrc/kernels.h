@@ -58,4 +58,13 @@ hipError_t launch_idct_tokens(hipStream_t stream, const uint32_t *tokens, const 
                               const IdctWork *work, const int class_begin[kNumIdctLayoutClasses + 1], const DevScanStatus *status,
                               const DevQuantTable *quant_pool, uint8_t *out, int format);
 
+
+// KT: symbol-level Huffman transcode of baseline scans (JpegOptimizer): mode 0 count, 1 measure, 2 emit (kernels.hip)
+struct EncHuffTable;
+hipError_t launch_transcode(hipStream_t stream, int mode, const uint8_t *udata, const uint8_t *input, const DevScan *scans,
+                            const HuffWork *work, int n_work, const uint32_t *ends_u, const uint32_t *ends_raw, DevScanStatus *status,
+                            const DevHuffTable *huff_pool, uint32_t *hist, const EncHuffTable *enc, uint32_t *sizes,
+                            const uint64_t *offsets, uint8_t *out, int n_slots);
+hipError_t launch_transcode_offsets(hipStream_t stream, const DevScan *scans, const uint32_t *scan_ids, int n_scans, const uint32_t *sizes,
+                                    const uint64_t *base, uint64_t *offsets, uint64_t *totals);
 }  // namespace jpgpu

@@ -1750,3 +1750,9 @@ void jref_ycbcr8_to_rgb(const uint8_t *ycbcr, uint8_t *out, size_t count, int by
         out += bytes_per_pixel;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * JpegOptimizer (ref: JpegOptimizer.cs, JpegHuffmanEncodingTableBuilder.cs): shares the reader, bit reader and decoding
+ * tables above.
+ * ---------------------------------------------------------------------------------------------- */
+#include "jpegopt.inc"

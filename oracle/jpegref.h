@@ -121,6 +121,18 @@ int jref_build_huffman(const uint8_t bits[16], const uint8_t *values, int nvalue
                        uint8_t lookahead_symbol[256], uint16_t maxcode[18], uint8_t valoffset[19],
                        uint8_t values_out[256]);
 
+/* ---- JpegOptimizer restatement (oracle/jpegopt.inc; ref: JpegOptimizer.cs).  PARITY UNPINNED, see the file header. */
+/* SetInput + Scan + SetOutput + Optimize(strip) on a fresh optimizer; *out is malloc'ed (jref_free). */
+int jref_optimize(const uint8_t *in, size_t len, int strip, uint8_t **out, size_t *out_len, char *err, size_t err_cap);
+/* Scan() alone: per table (builder-creation order) class, identifier and the 256 symbol counts; freq is [8][256]. */
+int jref_optimizer_statistics(const uint8_t *in, size_t len, uint8_t table_class[8], uint8_t identifier[8], uint32_t *freq,
+                              int *ntables, char *err, size_t err_cap);
+/* JpegHuffmanEncodingTableBuilder.Build(false) for one table: DHT counts / values and GetCode() for all 256 symbols.
+ * Returns 0, -1 ("No symbol is recorded."), -2 (a code size beyond the reference's 60-entry array). */
+int jref_build_optimal_table(const uint32_t freq[256], uint8_t bits_out[16], uint8_t values_out[256], int *nvalues,
+                             uint16_t code_out[256], uint8_t length_out[256]);
+void jref_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

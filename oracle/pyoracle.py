@@ -301,3 +301,58 @@ def build_huffman(bits, values):
     if not ok:
         raise ValueError("huffman table rejected")
     return las, lasym, maxcode, valoff, vout
+
+
+# ---------------------------------------------------------------------------------------------- JpegOptimizer restatement
+def optimize(data: bytes, strip: bool = True) -> bytes:
+    """new JpegOptimizer(): SetInput(data); Scan(); SetOutput(buffer); Optimize(strip) -> the written bytes.
+    Raises OracleError(code, message) where the reference throws."""
+    L = lib()
+    L.jref_optimize.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+    L.jref_optimize.restype = C.c_int
+    L.jref_free.argtypes = [C.c_void_p]
+    L.jref_free.restype = None
+    out = C.c_void_p()
+    n = C.c_size_t(0)
+    err = C.create_string_buffer(256)
+    rc = L.jref_optimize(data, len(data), 1 if strip else 0, C.byref(out), C.byref(n), err, 256)
+    if rc != 0:
+        raise OracleError(rc, err.value.decode("utf-8", "replace"))
+    try:
+        return C.string_at(out.value, n.value)
+    finally:
+        L.jref_free(out)
+
+
+def optimizer_statistics(data: bytes):
+    """Scan() alone: [(table_class, identifier, counts[256])] in the order the reference creates its table builders."""
+    L = lib()
+    L.jref_optimizer_statistics.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_char_p,
+                                            C.c_size_t]
+    L.jref_optimizer_statistics.restype = C.c_int
+    cls = np.zeros(8, np.uint8)
+    ident = np.zeros(8, np.uint8)
+    freq = np.zeros((8, 256), np.uint32)
+    n = C.c_int(0)
+    err = C.create_string_buffer(256)
+    rc = L.jref_optimizer_statistics(data, len(data), cls.ctypes.data, ident.ctypes.data, freq.ctypes.data, C.byref(n), err, 256)
+    if rc != 0:
+        raise OracleError(rc, err.value.decode("utf-8", "replace"))
+    return [(int(cls[i]), int(ident[i]), freq[i].copy()) for i in range(n.value)]
+
+
+def build_optimal_table(freq: np.ndarray):
+    """JpegHuffmanEncodingTableBuilder.Build(false): (bits[16], values[n], code[256], length[256])."""
+    L = lib()
+    L.jref_build_optimal_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+    L.jref_build_optimal_table.restype = C.c_int
+    f = np.ascontiguousarray(freq, dtype=np.uint32).reshape(256)
+    bits = np.zeros(16, np.uint8)
+    values = np.zeros(256, np.uint8)
+    code = np.zeros(256, np.uint16)
+    length = np.zeros(256, np.uint8)
+    n = C.c_int(0)
+    rc = L.jref_build_optimal_table(f.ctypes.data, bits.ctypes.data, values.ctypes.data, C.byref(n), code.ctypes.data, length.ctypes.data)
+    if rc != 0:
+        raise OracleError(4, "No symbol is recorded." if rc == -1 else "code size outside the reference's array")
+    return bits, values[:n.value].copy(), code, length

@@ -786,3 +786,77 @@ def test_progressive_kernel_variants_agree_with_the_oracle(name, env, monkeypatc
     outs, results = jl.decode_batch([data, data])
     for out in outs:
         assert np.array_equal(np.asarray(out).reshape(ref.shape), ref)
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+
+def _synth_jpeg(w, h, quality=75, subsampling=2, restart=0, seed=0, gray=False):
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 70 * np.sin(xx / 37 + 1) * np.cos(yy / 53), 128 + 60 * np.cos(xx / 91 + yy / 29), 128 + 90 * np.sin((xx + yy) / 67)], -1)
+    img = np.clip(np.rint(img + rng.normal(0, 8, img.shape)), 0, 255).astype(np.uint8)
+    out = io.BytesIO()
+    kw = dict(format="JPEG", quality=quality)
+    if not gray:
+        kw["subsampling"] = subsampling
+    if restart:
+        kw["restart_marker_blocks"] = restart
+    Image.fromarray(img[..., 0] if gray else img).save(out, **kw)
+    return out.getvalue()
+
+
+def _optimizer_files():
+    return [read_jpeg("lake.jpg"), read_jpeg("cramps.jpg"), read_jpeg("HETissueSlide.jpg"), _synth_jpeg(200, 136, restart=4),
+            _synth_jpeg(333, 77, subsampling=0, restart=11, seed=2), _synth_jpeg(64, 64, gray=True, seed=3),
+            _synth_jpeg(640, 360, quality=95, subsampling=1, restart=7, seed=4), _synth_jpeg(1920, 1088, restart=7, seed=5)]
+
+
+@pytest.mark.parametrize("strip", [True, False])
+def test_optimizer_matches_the_reference_restatement_byte_for_byte(strip):
+    """JpegOptimizer.Scan() + Optimize(strip) for a mixed batch (DRI and no DRI, gray, 4:4:4 / 4:2:2 / 4:2:0): the statistics,
+    the rebuilt DHT, the re-written scan and every copied segment must equal the restatement's output."""
+    files = _optimizer_files()
+    b = jl.OptimizeBatch().upload(files, strip).run()
+    for i, f in enumerate(files):
+        ref = po.optimize(f, strip)
+        got = b.output(i)
+        assert got == ref, (i, len(got), len(ref))
+        stats = b.statistics(i)
+        ref_stats = po.optimizer_statistics(f)
+        assert [(c, t) for c, t, _ in stats] == [(c, t) for c, t, _ in ref_stats]
+        for (_, _, a), (_, _, r) in zip(stats, ref_stats):
+            assert np.array_equal(a, r)
+    b.close()
+
+
+def test_reference_optimizer_test_on_the_gpu():
+    """tests/JpegLibrary.Tests/Optimizer/OptimizerTests.cs:26-47 with the GPU optimizer: smaller, same pixels."""
+    data = read_jpeg("lake.jpg")
+    for strip in (True, False):
+        out = jl.optimize_batch([data], strip)[0]
+        assert len(out) < len(data)
+        a, _ = po.decode_8bit(data)
+        b2, _ = po.decode_8bit(out)
+        assert np.array_equal(a, b2)
+
+
+def test_optimizer_failures_follow_the_reference():
+    good = read_jpeg("lake.jpg")
+    files = [good, _synth_jpeg(200, 120, restart=4), read_jpeg("progress.jpg"), good[:100000], b"\xff\xd8\xff\xd9", good]
+    b = jl.OptimizeBatch().upload(files, True).run()
+    assert b.output(0) == po.optimize(good, True) and b.output(5) == b.output(0)
+    # MCU count a multiple of DRI: Scan() gives up at the EOI it meets in the restart check, Optimize() throws
+    with pytest.raises(jl.InvalidOperationException):
+        b.output(1)
+    with pytest.raises(po.OracleError):
+        po.optimize(files[1], True)
+    with pytest.raises(jl.NotSupportedException):
+        b.output(2)
+    for i in (3, 4):
+        with pytest.raises(jl.JpegError):
+            b.output(i)
+        with pytest.raises(po.OracleError):
+            po.optimize(files[i], True)
+    b.close()
