@@ -11,8 +11,8 @@
 // Fences (reported as JPGPU_ERR_NOT_SUPPORTED): files with more than one scan (the reference builds its tables from the
 // LAST scan only, :462, and then fails or writes garbage for the others), progressive frames (:580-582), a DRI whose value
 // at the scan differs from the last DRI of the file (the decoder-side parser shared here latches the last one),
-// MostOptimalCoding (package merge).  Parity of the bytes: see oracle/jpegopt.inc's header (unpinned; .NET's unstable
-// sort decides the order of equal-length symbols in the DHT).
+// MostOptimalCoding (package merge).  Parity of the bytes is unpinned (the reference holds no golden bytes, and
+// .NET's unstable sort decides the order of equal-length symbols in the DHT).
 #include "device_optimize.h"
 
 #include <algorithm>

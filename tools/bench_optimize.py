@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""tools/bench_optimize.py -- Mpixels/s of the GPU optimizer (JpegOptimizer.Scan + Optimize) on the
+benchmark's synthetic 4K 4:2:0 Q75 files, next to the restatement on the host cores.  Not the headline benchmark
+(that is bench.py); prints one JSON line.
+
+    python tools/bench_optimize.py [--images 256] [--steps 5] [--dri 7]
+
+DRI = 7 rather than the headline's 4: with 32 400 MCUs per image a restart interval that divides the MCU count makes the
+reference's Scan() give up at the EOI it meets in its last restart check (JpegOptimizer.cs:437-442).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--quality", type=int, default=75)
+    ap.add_argument("--dri", type=int, default=7)
+    ap.add_argument("--cpu-images", type=int, default=0, help="files timed on the host (default: min(images, cores))")
+    args = ap.parse_args()
+    import jpeglibrary_amd as jl
+    from oracle import pyoracle as po
+    from tools import jpegsynth
+
+    threads = os.cpu_count() or 8
+    t0 = time.perf_counter()
+    buf, sizes, stride = jpegsynth.encode_batch(args.images, args.width, args.height, "420", args.quality, args.dri, seed0=1, nthreads=threads)
+    files = [bytes(buf[i * stride:i * stride + int(sizes[i])]) for i in range(args.images)]
+    gen_s = time.perf_counter() - t0
+    b = jl.OptimizeBatch().upload(files, True)
+    b.run()
+    t0 = time.perf_counter()
+    dev_ms = []
+    for _ in range(args.steps):
+        b.run()
+        dev_ms.append(b.last_ms())
+    dt = (time.perf_counter() - t0) / args.steps
+    px = args.images * args.width * args.height
+    outs = [b.result(i)[1] for i in range(args.images)]
+    ref0 = po.optimize(files[0], True)
+    exact = b.output(0) == ref0
+    n_cpu = args.cpu_images or min(args.images, threads)
+    t1 = time.perf_counter()
+    with ThreadPoolExecutor(min(threads, n_cpu)) as ex:
+        list(ex.map(lambda f: po.optimize(f, True), files[:n_cpu]))
+    cpu_dt = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    po.optimize(files[0], True)
+    cpu1 = args.width * args.height / (time.perf_counter() - t2) / 1e6
+    print(json.dumps({
+        "metric": "Mpixels/s optimized (JpegOptimizer Scan + Optimize, baseline 4:2:0)", "value": round(px / dt / 1e6, 1), "unit": "Mpixels/s",
+        "ms_per_step": round(dt * 1e3, 2), "device_ms": round(sum(dev_ms) / len(dev_ms), 2), "images": args.images, "dri": args.dri,
+        "input_MB": round(sum(len(f) for f in files) / 1e6, 1), "output_MB": round(sum(outs) / 1e6, 1),
+        "size_ratio": round(sum(outs) / sum(len(f) for f in files), 4), "byte_exact_vs_restatement": bool(exact),
+        "cpu_baseline": {"value": round(n_cpu * args.width * args.height / cpu_dt / 1e6, 1), "unit": "Mpixels/s", "cores": min(threads, n_cpu),
+                         "kind": "port", "sample": f"{n_cpu} of the files, one optimizer per core ({cpu_dt:.1f} s wall); single core: {cpu1:.1f} Mpixels/s"},
+        "host": {"gen_s": round(gen_s, 1)}}))
+    b.close()
+
+
+if __name__ == "__main__":
+    main()
