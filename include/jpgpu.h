@@ -277,7 +277,8 @@ typedef struct jpgpu_encode_params {
     int32_t luma_h, luma_v;  /* sampling factors of the first component (1, 2 or 4); the others are 1 x 1 */
     int32_t quality;         /* 1..100, JpegStandardQuantizationTable.ScaleByQuality */
     int32_t input_rgb;
-    int32_t reserved;
+    int32_t optimize_coding; /* EncodeAction's optimizeCoding (EncodeAction.cs:40-46): Huffman tables built from the image's own
+                                statistics (TransformBlocks / BuildHuffmanTables / WritePreparedScanData, JpegEncoder.cs:264-274) */
 } jpgpu_encode_params;
 typedef struct jpgpu_encoder jpgpu_encoder;
 

@@ -3,6 +3,7 @@
 // The host writes the marker segments (SOI, DQT, SOF0, DHT, SOS -- the reference's JpegWriter calls, byte for byte);
 // the per-block arithmetic and the entropy coding run in encode_kernels.hip.
 #include "device_encode.h"
+#include "device_optimize.h"
 
 #include <string.h>
 
@@ -118,7 +119,7 @@ void rgb_ycc_factors(int32_t out[8]) {
 
 EncodeBatch::~EncodeBatch() {
     for (DevBuffer *b : {&d_pixels_, &d_images_, &d_tables_, &d_work_mcu_, &d_work_blk_, &d_work_chunk_, &d_coefs_, &d_bits_, &d_bit_off_,
-                         &d_raw_bits_, &d_raw_, &d_chunk_ff_, &d_out_, &d_out_len_})
+                         &d_raw_bits_, &d_raw_, &d_chunk_ff_, &d_out_, &d_out_len_, &d_hist_})
         b->release();
 }
 
@@ -137,6 +138,10 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     images_.assign((size_t)n, DevEncImage());
     headers_.assign((size_t)n, std::vector<uint8_t>());
+    headers_pre_.assign((size_t)n, std::vector<uint8_t>());
+    headers_post_.assign((size_t)n, std::vector<uint8_t>());
+    optimized_.clear();
+    status_.assign((size_t)n, JPGPU_OK);
     encoded_ = false;
     std::vector<EncWork> work_mcu, work_blk;
     uint64_t px_off = 0, coef_off = 0;
@@ -164,6 +169,10 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         im.bpm = im.luma_h * im.luma_v + (im.components == 3 ? 2 : 0);
         im.total_blocks = im.mcus_per_line * im.mcus_per_column * im.bpm;
         im.input_rgb = p.input_rgb ? 1 : 0;
+        if (p.optimize_coding) {
+            optimized_.push_back(i);
+            im.table_base = 4u * (uint32_t)optimized_.size();  // tables 0..3 are the standard ones
+        }
         rgb_ycc_factors(im.r2y);
         scale_by_quality(kStdLum, p.quality, im.quant[0]);
         scale_by_quality(kStdChr, p.quality, im.quant[1]);
@@ -196,6 +205,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
             h.push_back(c == 0 ? (uint8_t)((im.luma_h << 4) | im.luma_v) : (uint8_t)0x11);
             h.push_back(c == 0 ? 0 : 1);
         }
+        headers_pre_[i] = h;
         put_marker(h, 0xC4);  // WriteHuffmanTables (:336-352): ONE segment, tables in SetHuffmanTable order
         int total = 0;
         for (int t = 0; t < 4; t++) total += 1 + 16 + kStd[t].count;
@@ -205,6 +215,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
             for (int l = 0; l < 16; l++) h.push_back(kStd[t].lengths[l]);
             for (int k = 0; k < kStd[t].count; k++) h.push_back(kStd[t].values[k]);
         }
+        const size_t sos_at = h.size();
         put_marker(h, 0xDA);  // WriteStartOfScan (:387-413)
         put_length(h, (uint16_t)(1 + 2 * ncomp + 3));
         h.push_back((uint8_t)ncomp);
@@ -215,13 +226,17 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         h.push_back(0);
         h.push_back(63);
         h.push_back(0);
+        headers_post_[i].assign(h.begin() + (long)sos_at, h.end());
         im.header_len = (uint32_t)h.size();
+        // optimizeCoding: the DHT is written once the statistics are in; reserve the largest it can be (4 x 256 symbols)
+        if (im.table_base != 0) im.header_len = (uint32_t)(headers_pre_[i].size() + 4 + 4 * (1 + 16 + 256) + headers_post_[i].size());
     }
     total_blocks_ = coef_off;
     n_work_mcu_ = (int)work_mcu.size();
     n_work_blk_ = (int)work_blk.size();
 
-    EncHuffTable tables[4];
+    std::vector<EncHuffTable> tables(4 + 4 * optimized_.size());
+    memset(tables.data(), 0, tables.size() * sizeof(EncHuffTable));
     for (int t = 0; t < 4; t++) build_enc_table(kStd[t], &tables[t]);
 
     struct Up {
@@ -230,7 +245,8 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         size_t bytes, reserve;
     };
     const Up ups[] = {
-        {&d_tables_, tables, sizeof tables, 0},
+        {&d_tables_, tables.data(), tables.size() * sizeof(EncHuffTable), 0},
+        {&d_hist_, nullptr, 0, (size_t)n * 4 * 256 * sizeof(uint32_t) + 256},
         {&d_work_mcu_, work_mcu.data(), work_mcu.size() * sizeof(EncWork), 0},
         {&d_work_blk_, work_blk.data(), work_blk.size() * sizeof(EncWork), 0},
         {&d_pixels_, nullptr, 0, (size_t)px_off + 256},
@@ -270,6 +286,57 @@ int EncodeBatch::encode() {
     e = launch_fdct_quant(ctx_->stream, (const uint8_t *)d_pixels_.ptr, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_mcu_.ptr, n_work_mcu_,
                           (int16_t *)d_coefs_.ptr);
     if (e != hipSuccess) return hip_fail(e, "fdct_quant_kernel");
+    if (!optimized_.empty()) {
+        // optimizeCoding: BuildHuffmanTables (:491-550) -- statistics on the device, JpegHuffmanEncodingTableBuilder.Build on the host
+        e = hipMemsetAsync(d_hist_.ptr, 0, (size_t)n * 4 * 256 * sizeof(uint32_t), ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(statistics)");
+        e = launch_block_stats(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_blk_.ptr, n_work_blk_,
+                               (const int16_t *)d_coefs_.ptr, (uint32_t *)d_hist_.ptr);
+        if (e != hipSuccess) return hip_fail(e, "block_stats_kernel");
+        std::vector<uint32_t> hist((size_t)n * 4 * 256);
+        e = hipMemcpyAsync(hist.data(), d_hist_.ptr, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx_->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpy(statistics)");
+        std::vector<EncHuffTable> built(4 * optimized_.size());
+        memset(built.data(), 0, built.size() * sizeof(EncHuffTable));
+        for (size_t k = 0; k < optimized_.size(); k++) {
+            const int i = optimized_[k];
+            std::vector<uint8_t> &h = headers_[i];
+            h = headers_pre_[i];
+            std::vector<uint8_t> body;
+            status_[i] = JPGPU_OK;
+            for (int t = 0; t < 4; t++) {  // every builder of the collection, in SetHuffmanTable order: DC0, AC0, DC1, AC1
+                std::vector<OptimalCode> codes;
+                if (!build_optimal_table(&hist[((size_t)i * 4 + t) * 256], &codes)) {
+                    status_[i] = JPGPU_ERR_INVALID_OPERATION;  // "No symbol is recorded." (a single-component image: empty chrominance builders)
+                    break;
+                }
+                EncHuffTable &et = built[4 * k + t];
+                for (int sym = 0; sym < 256; sym++) {  // GetCode of a symbol without a code: the table's first code
+                    et.code[sym] = codes[0].code;
+                    et.len[sym] = codes[0].length;
+                }
+                for (const OptimalCode &c : codes) {
+                    et.code[c.symbol] = c.code;
+                    et.len[c.symbol] = c.length;
+                }
+                body.push_back((uint8_t)(((t & 1) << 4) | (t >> 1)));
+                for (int l = 1; l <= 16; l++) {
+                    int count = 0;
+                    for (const OptimalCode &c : codes) count += c.length == l;
+                    body.push_back((uint8_t)count);
+                }
+                for (const OptimalCode &c : codes) body.push_back(c.symbol);
+            }
+            put_marker(h, 0xC4);
+            put_length(h, (uint16_t)body.size());
+            h.insert(h.end(), body.begin(), body.end());
+            h.insert(h.end(), headers_post_[i].begin(), headers_post_[i].end());
+            images_[i].header_len = (uint32_t)h.size();
+        }
+        e = hipMemcpyAsync((EncHuffTable *)d_tables_.ptr + 4, built.data(), built.size() * sizeof(EncHuffTable), hipMemcpyHostToDevice, ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(built tables)");
+    }
     e = launch_block_bits(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_blk_.ptr, n_work_blk_,
                           (const EncHuffTable *)d_tables_.ptr, (const int16_t *)d_coefs_.ptr, (uint32_t *)d_bits_.ptr, n, (uint64_t *)d_bit_off_.ptr,
                           (uint64_t *)d_raw_bits_.ptr);
@@ -328,6 +395,10 @@ int EncodeBatch::encode() {
 
 int EncodeBatch::encoded_size(int i, size_t *bytes) const {
     if (i < 0 || i >= (int)images_.size() || !bytes || !encoded_) return JPGPU_ERR_ARGUMENT;
+    if (status_[i] != JPGPU_OK) {
+        ctx_->last_error = "No symbol is recorded.";
+        return status_[i];
+    }
     *bytes = (size_t)out_len_[i];
     return JPGPU_OK;
 }
@@ -335,6 +406,7 @@ int EncodeBatch::encoded_size(int i, size_t *bytes) const {
 int EncodeBatch::download(int i, void *dst, size_t cap) {
     if (i < 0 || i >= (int)images_.size() || !dst) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_encode_download: bad argument");
     if (!encoded_) return fail(JPGPU_ERR_INVALID_OPERATION, "Nothing has been encoded yet.");
+    if (status_[i] != JPGPU_OK) return fail(status_[i], "No symbol is recorded.");
     if (cap < out_len_[i]) return fail(JPGPU_ERR_ARGUMENT, "Destination buffer is too small.");
     hipError_t e = hipMemcpy(dst, (const uint8_t *)d_out_.ptr + images_[i].out_off, (size_t)out_len_[i], hipMemcpyDeviceToHost);
     return e == hipSuccess ? JPGPU_OK : hip_fail(e, "hipMemcpy(encoded stream)");
@@ -344,8 +416,22 @@ int EncodeBatch::download_coefficients(int i, int16_t *dst, size_t cap_blocks) {
     if (i < 0 || i >= (int)images_.size() || !dst) return fail(JPGPU_ERR_ARGUMENT, "bad argument");
     if (!encoded_) return fail(JPGPU_ERR_INVALID_OPERATION, "Nothing has been encoded yet.");
     if (cap_blocks < images_[i].total_blocks) return fail(JPGPU_ERR_ARGUMENT, "Destination buffer is too small.");
-    hipError_t e = hipMemcpy(dst, (const int16_t *)d_coefs_.ptr + images_[i].coef_off * 64, (size_t)images_[i].total_blocks * 128, hipMemcpyDeviceToHost);
-    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "hipMemcpy(coefficients)");
+    const DevEncImage &im = images_[i];
+    hipError_t e = hipMemcpy(dst, (const int16_t *)d_coefs_.ptr + im.coef_off * 64, (size_t)im.total_blocks * 128, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(coefficients)");
+    if (im.table_base != 0) {
+        // optimizeCoding: the blocks as BuildHuffmanTables / WritePreparedScanData see them -- luma blocks outside the
+        // component's own grid alias the allocator's dummy block (enc_source_block in encode_kernels.hip)
+        const uint32_t ny = im.luma_h * im.luma_v, last = (im.mcus_per_line * im.mcus_per_column - 1) * im.bpm + ny - 1;
+        for (uint32_t blk = 0; blk < im.total_blocks; blk++) {
+            const uint32_t mcu = blk / im.bpm, b = blk - mcu * im.bpm;
+            if (b >= ny) continue;
+            const uint32_t bx = (mcu % im.mcus_per_line) * im.luma_h + b % im.luma_h, by = (mcu / im.mcus_per_line) * im.luma_v + b / im.luma_h;
+            if (bx < (im.width + 7) / 8 && by < (im.height + 7) / 8) continue;
+            if (blk != last) memcpy(dst + (size_t)blk * 64, dst + (size_t)last * 64, 128);
+        }
+    }
+    return JPGPU_OK;
 }
 
 }  // namespace jpgpu

@@ -19,6 +19,7 @@ class EncodeBatch {
     int encode();                                                                        // JpegEncoder.Encode() x n
     int size() const { return (int)images_.size(); }
     int encoded_size(int i, size_t *bytes) const;
+    int image_status(int i) const { return (i >= 0 && i < (int)status_.size()) ? status_[i] : JPGPU_ERR_ARGUMENT; }
     int download(int i, void *dst, size_t cap);
     int download_coefficients(int i, int16_t *dst, size_t cap_blocks);
     uint32_t total_blocks(int i) const { return (i >= 0 && i < (int)images_.size()) ? images_[i].total_blocks : 0; }
@@ -33,7 +34,12 @@ class EncodeBatch {
     int hip_fail(hipError_t e, const char *what);
     jpgpu_ctx *ctx_;
     std::vector<DevEncImage> images_;
-    std::vector<std::vector<uint8_t>> headers_;
+    std::vector<std::vector<uint8_t>> headers_;        // SOI .. SOS as Encode() writes them (optimizeCoding: rebuilt per encode())
+    std::vector<std::vector<uint8_t>> headers_pre_;    // optimizeCoding: SOI, DQT, SOF0 ...
+    std::vector<std::vector<uint8_t>> headers_post_;   // ... and SOS; the DHT between them depends on the statistics
+    std::vector<int> optimized_;                       // images with optimizeCoding
+    std::vector<int> status_;                          // per image: JPGPU_OK or the reference's failure ("No symbol is recorded.")
+    DevBuffer d_hist_;
     std::vector<uint64_t> out_len_;
     bool encoded_ = false;
     uint64_t total_blocks_ = 0, out_cap_ = 0;

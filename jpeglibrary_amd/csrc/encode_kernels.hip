@@ -179,6 +179,7 @@ __global__ __launch_bounds__(kEncMcusPerWg) void fdct_quant_kernel(const uint8_t
     const uint32_t mx = mcu % mcus_per_line, my = mcu / mcus_per_line;
     const bool rows_aligned = ((src.width * src.comps) & 3u) == 0;
     int16_t *out = coefs + (im.coef_off + (uint64_t)mcu * bpm) * 64;
+    const bool own_blocks = im.table_base != 0;  // optimizeCoding: TransformBlocks (:414-485)
     {
         const uint4 z = {0, 0, 0, 0};
 #pragma unroll
@@ -205,7 +206,9 @@ __global__ __launch_bounds__(kEncMcusPerWg) void fdct_quant_kernel(const uint8_t
 #pragma unroll
                     for (int i = 0; i < 8; i++) acc[i] = 0;
                 } else {
-                    unpack8_i16(sh_prev[r][lane], acc);  // ReadBlockWithSubsample adds to what the buffer holds (:788-799)
+                    // ReadBlockWithSubsample adds to what the buffer holds (:788-799): WriteScanData's one reused buffer
+                    // (the previous block's coefficients), or the block's own zeroed allocator slot in TransformBlocks
+                    unpack8_i16(sh_prev[r][lane], acc);
                 }
 #pragma unroll 1
                 for (uint32_t dy = 0; dy < vs; dy++) {
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(kEncMcusPerWg) void fdct_quant_kernel(const uint8_t
                 for (int i = 0; i < 8; i++) row[i] = q[r * 8 + i];
                 const uint4 pk = pack8_i16(row);
                 dst[r] = pk;
-                sh_prev[r][lane] = pk;  // ZigZagAndQuantizeBlock writes into the buffer the next ReadBlock starts from
+                if (!own_blocks) sh_prev[r][lane] = pk;  // ZigZagAndQuantizeBlock writes into the buffer the next ReadBlock starts from
             }
         }
     }
@@ -264,14 +267,30 @@ __global__ __launch_bounds__(kEncMcusPerWg) void fdct_quant_kernel(const uint8_t
 // bits needed for |a| (ref: BitCountTable, JpegEncoder.cs:938-956)
 __device__ __forceinline__ uint32_t enc_bit_count(uint32_t a) { return a ? 32u - (uint32_t)__builtin_clz(a) : 0u; }
 
+// optimizeCoding keeps the blocks in a JpegBlockAllocator: blocks of the MCU grid outside the component's own grid of
+// ceil(ceil(W / 8) / hs) x ceil(ceil(H / 8) / vs) blocks all alias its ONE dummy block (JpegBlockAllocator.cs:93-114), so
+// the statistics and the scan see, for each of them, what the LAST such block of TransformBlocks left there.  Only the
+// luma component can leave its grid (the others are 1 x 1 per MCU), and whenever some block does, the last luma block of
+// the last MCU does: that block's coefficients stand in for all of them.
+__device__ __forceinline__ uint32_t enc_source_block(const DevEncImage &im, uint32_t blk) {
+    if (im.table_base == 0) return blk;
+    const uint32_t ny = im.luma_h * im.luma_v;
+    const uint32_t mcu = blk / im.bpm, b = blk - mcu * im.bpm;
+    if (b >= ny) return blk;
+    const uint32_t mx = mcu % im.mcus_per_line, my = mcu / im.mcus_per_line;
+    const uint32_t bx = mx * im.luma_h + b % im.luma_h, by = my * im.luma_v + b / im.luma_h;
+    if (bx < (im.width + 7) / 8 && by < (im.height + 7) / 8) return blk;
+    return (im.mcus_per_line * im.mcus_per_column - 1) * im.bpm + ny - 1;
+}
+
 // scan position of a block: component, and the DC value it is predicted from (EncodeBlock :835-838)
 __device__ __forceinline__ int32_t enc_dc_predictor(const DevEncImage &im, const int16_t *img_coefs, uint32_t mcu, uint32_t b, uint32_t &comp) {
     const uint32_t ny = im.luma_h * im.luma_v;
     comp = b < ny ? 0u : b - ny + 1u;
-    if (comp == 0 && b > 0) return img_coefs[((size_t)mcu * im.bpm + b - 1) * 64];
+    if (comp == 0 && b > 0) return img_coefs[(size_t)enc_source_block(im, mcu * im.bpm + b - 1) * 64];
     if (mcu == 0) return 0;
     const uint32_t pb = comp == 0 ? ny - 1 : b;
-    return img_coefs[((size_t)(mcu - 1) * im.bpm + pb) * 64];
+    return img_coefs[(size_t)enc_source_block(im, (mcu - 1) * im.bpm + pb) * 64];
 }
 
 // Walks the symbols of one block in EncodeBlock order (:828-870) and hands (code, length) pairs to `put`.
@@ -324,11 +343,55 @@ __global__ __launch_bounds__(256) void block_bits_kernel(const DevEncImage *__re
     const uint32_t mcu = blk / im.bpm, b = blk - mcu * im.bpm;
     uint32_t comp;
     const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
-    const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)blk * 64);
+    const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)enc_source_block(im, blk) * 64);
     const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
     uint32_t n = 0;
-    enc_block_symbols(cv, pred, tables[comp == 0 ? 0 : 2], tables[comp == 0 ? 1 : 3], [&](uint32_t, uint32_t len) { n += len; });
+    enc_block_symbols(cv, pred, tables[im.table_base + (comp == 0 ? 0 : 2)], tables[im.table_base + (comp == 0 ? 1 : 3)], [&](uint32_t, uint32_t len) { n += len; });
     bits[im.coef_off + blk] = n;
+}
+
+// optimizeCoding: GatherBlockStatistics (:552-597) for the 256 blocks of a workgroup: LDS histograms of the four tables
+// (DC0, AC0, DC1, AC1), merged into the image's counters.
+__global__ __launch_bounds__(256) void block_stats_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
+                                                          const int16_t *__restrict__ coefs, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t lh[4 * 256];
+    const EncWork wk = work[blockIdx.x];
+    const DevEncImage &im = images[wk.image];
+    for (uint32_t i = threadIdx.x; i < 4u * 256u; i += 256u) lh[i] = 0;
+    __syncthreads();
+    const uint32_t blk = wk.first + threadIdx.x;
+    if (im.table_base != 0 && blk < im.total_blocks) {
+        const int16_t *img_coefs = coefs + im.coef_off * 64;
+        const uint32_t mcu = blk / im.bpm, b = blk - mcu * im.bpm;
+        uint32_t comp;
+        const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
+        const int16_t *c = img_coefs + (size_t)enc_source_block(im, blk) * 64;
+        uint32_t *hdc = lh + (comp == 0 ? 0 : 2) * 256, *hac = lh + (comp == 0 ? 1 : 3) * 256;
+        auto symbol = [](uint32_t run, int32_t value) -> uint32_t {  // GatherRunLengthCodeStatistics (:872-891)
+            const uint32_t a = (uint32_t)(value < 0 ? -value : value);
+            return ((run << 4) | enc_bit_count(a & 0xFFFFu)) & 0xFFu;
+        };
+        atomicAdd(&hdc[symbol(0, (int32_t)c[0] - pred)], 1u);
+        uint32_t run = 0;
+        for (int i = 1; i < 64; i++) {
+            const int32_t t = c[i];
+            if (t == 0) {
+                run++;
+            } else {
+                while (run > 15) {
+                    atomicAdd(&hac[0xF0], 1u);
+                    run -= 16;
+                }
+                atomicAdd(&hac[symbol(run, t)], 1u);
+                run = 0;
+            }
+        }
+        if (run > 0) atomicAdd(&hac[0], 1u);
+    }
+    __syncthreads();
+    uint32_t *gh = hist + (size_t)wk.image * 4 * 256;
+    for (uint32_t i = threadIdx.x; i < 4u * 256u; i += 256u)
+        if (lh[i] != 0) atomicAdd(&gh[i], lh[i]);
 }
 
 // Exclusive prefix sums of the block bit counts of one image (one workgroup per image); total -> images' raw_bits.
@@ -372,7 +435,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const DevEncImage *__restrict
     const uint32_t mcu = blk / im.bpm, b = blk - mcu * im.bpm;
     uint32_t comp;
     const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
-    const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)blk * 64);
+    const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)enc_source_block(im, blk) * 64);
     const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
     uint32_t *words = reinterpret_cast<uint32_t *>(raw + im.raw_off);
     const uint64_t start = bit_off[im.coef_off + blk];
@@ -395,7 +458,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const DevEncImage *__restrict
             }
         }
     };
-    enc_block_symbols(cv, pred, tables[comp == 0 ? 0 : 2], tables[comp == 0 ? 1 : 3], put);
+    enc_block_symbols(cv, pred, tables[im.table_base + (comp == 0 ? 0 : 2)], tables[im.table_base + (comp == 0 ? 1 : 3)], put);
     if (blk == im.total_blocks - 1) {
         // ExitBitMode (ref: JpegWriter.cs:123-147): pad the last byte with one-bits
         const uint32_t rem = (uint32_t)((8u - (raw_bits[wk.image] & 7u)) & 7u);
@@ -510,6 +573,12 @@ hipError_t launch_block_bits(hipStream_t stream, const DevEncImage *images, cons
     if (n_work <= 0) return hipSuccess;
     hipLaunchKernelGGL(block_bits_kernel, dim3(n_work), dim3(256), 0, stream, images, work, tables, coefs, bits);
     hipLaunchKernelGGL(block_offsets_kernel, dim3(n_images), dim3(1024), 0, stream, images, bits, bit_off, raw_bits);
+    return hipGetLastError();
+}
+hipError_t launch_block_stats(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const int16_t *coefs,
+                              uint32_t *hist) {
+    if (n_work <= 0) return hipSuccess;
+    hipLaunchKernelGGL(block_stats_kernel, dim3(n_work), dim3(256), 0, stream, images, work, coefs, hist);
     return hipGetLastError();
 }
 hipError_t launch_emit(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,

@@ -375,8 +375,54 @@ static void encode_block(writer *w, enc_component *c, const int16_t *block) {
  * `pixels` = interleaved 8-bit samples (JpegBufferInputReader(width, height, components, buffer)).
  * coef_tap (optional): receives every block's quantised zig-zag coefficients in encoding order.
  * Returns 0 and the byte count in *out_len; 1 when `cap` is too small (out_len still holds the size needed). */
+/* GatherRunLengthCodeStatistics :872-891 */
+static void gather_run_length(uint32_t *freq, int run, int value) {
+    int a = value < 0 ? -value : value;
+    int bits = a < 0x100 ? bit_count(a) : 8 + bit_count(a >> 8);
+    freq[((run << 4) | bits) & 255]++;
+}
+/* GatherBlockStatistics :552-597 */
+static void gather_block(enc_component *c, const int16_t *block, uint32_t *dc_freq, uint32_t *ac_freq) {
+    int value = block[0];
+    int t = value - c->dc_predictor;
+    c->dc_predictor = value;
+    gather_run_length(dc_freq, 0, t);
+    int run = 0;
+    for (int i = 1; i < 64; i++) {
+        t = block[i];
+        if (t == 0) {
+            run++;
+        } else {
+            while (run > 15) {
+                ac_freq[0xF0]++;
+                run -= 16;
+            }
+            gather_run_length(ac_freq, run, t);
+            run = 0;
+        }
+    }
+    if (run > 0) ac_freq[0]++;
+}
+
+int jref_build_optimal_table(const uint32_t freq[256], uint8_t bits_out[16], uint8_t values_out[256], int *nvalues, uint16_t code_out[256],
+                             uint8_t length_out[256]);
+
 int jref_encode_8bit(const uint8_t *pixels, int width, int height, int components, int luma_h, int luma_v, int quality,
                      uint8_t *out, size_t cap, size_t *out_len, int16_t *coef_tap) {
+    return jref_encode_8bit_ex(pixels, width, height, components, luma_h, luma_v, quality, 0, out, cap, out_len, coef_tap);
+}
+
+/* optimize_coding != 0: EncodeAction's other branch (apps/JpegEncode/EncodeAction.cs:40-46): SetHuffmanTable(isDc, id) with no
+ * table for DC0, AC0, DC1, AC1, which makes Encode() (JpegEncoder.cs:255-291) run TransformBlocks (:414-485) into a
+ * JpegBlockAllocator, BuildHuffmanTables (:491-550; JpegHuffmanEncodingTableBuilder.Build(false), restated in jpegopt.inc),
+ * WriteHuffmanTables with the built tables and WritePreparedScanData (:604-655).  Two things differ from the other branch
+ * and are restated as they are: every block is transformed in its OWN (zeroed) allocator block, so the sub-sampling reader
+ * no longer accumulates onto the previous block's coefficients; and blocks of the MCU grid that lie outside a component's
+ * own block grid all alias the allocator's ONE dummy block (JpegBlockAllocator.cs:93-114), so they are encoded with whatever
+ * the last of them left there.  Returns 2 when a table has no symbol ("No symbol is recorded.": a single-component image,
+ * whose chrominance builders stay empty). */
+int jref_encode_8bit_ex(const uint8_t *pixels, int width, int height, int components, int luma_h, int luma_v, int quality,
+                        int optimize_coding, uint8_t *out, size_t cap, size_t *out_len, int16_t *coef_tap) {
     uint16_t q_lum[64], q_chr[64];
     jref_scale_quant_table(k_std_lum, quality, q_lum);
     jref_scale_quant_table(k_std_chr, quality, q_chr);
@@ -425,8 +471,92 @@ int jref_encode_8bit(const uint8_t *pixels, int width, int height, int component
             w_byte(&w, (uint8_t)comps[i].quant_id);
         }
     }
+    /* ---- optimizeCoding: TransformBlocks + BuildHuffmanTables, then the built tables replace the standard ones */
+    int16_t *store = NULL; /* JpegBlockAllocator: block 0 = the dummy, then the components' own grids */
+    int grid_w[3] = {0, 0, 0}, grid_h[3] = {0, 0, 0}, grid_off[3] = {0, 0, 0};
+    enc_table o_tab[4];
+    uint8_t o_bits[4][16], o_vals[4][256];
+    int o_n[4] = {0, 0, 0, 0};
+    if (optimize_coding) {
+        int max_h = 1, max_v = 1;
+        for (int i = 0; i < ncomp; i++) {
+            comps[i].dc_predictor = 0;
+            if (comps[i].h > max_h) max_h = comps[i].h;
+            if (comps[i].v > max_v) max_v = comps[i].v;
+        }
+        int hb = (width + 7) / 8, vb = (height + 7) / 8, index = 1;
+        for (int i = 0; i < ncomp; i++) {
+            comps[i].hs = max_h / comps[i].h;
+            comps[i].vs = max_v / comps[i].v;
+            grid_w[i] = (hb + comps[i].hs - 1) / comps[i].hs;
+            grid_h[i] = (vb + comps[i].vs - 1) / comps[i].vs;
+            grid_off[i] = index;
+            index += grid_w[i] * grid_h[i];
+        }
+        store = (int16_t *)calloc((size_t)index * 64, sizeof(int16_t));
+#define BLOCK_REF(ci, bx, by) (store + 64 * (size_t)(((bx) >= grid_w[ci] || (by) >= grid_h[ci]) ? 0 : grid_off[ci] + (by)*grid_w[ci] + (bx)))
+        int mcus_per_line = (width + 8 * max_h - 1) / (8 * max_h);
+        int mcus_per_column = (height + 8 * max_v - 1) / (8 * max_v);
+        buffer_reader rd = {pixels, width, height, components};
+        for (int row_mcu = 0; row_mcu < mcus_per_column; row_mcu++)
+            for (int col_mcu = 0; col_mcu < mcus_per_line; col_mcu++)
+                for (int ci = 0; ci < ncomp; ci++) {
+                    enc_component *c = &comps[ci];
+                    int offset_x = col_mcu * c->h, offset_y = row_mcu * c->v;
+                    for (int y = 0; y < c->v; y++)
+                        for (int x = 0; x < c->h; x++) {
+                            int16_t *block = BLOCK_REF(ci, offset_x + x, offset_y + y);
+                            enc_read_block(&rd, block, c->component_index, (offset_x + x) * 8 * c->hs, (offset_y + y) * 8 * c->vs, c->hs, c->vs);
+                            int16_t q[64];
+                            jref_fdct_quantize_block(block, c->quant, q);
+                            memcpy(block, q, sizeof q);
+                        }
+                }
+        /* BuildHuffmanTables */
+        uint32_t freq[4][256];
+        memset(freq, 0, sizeof freq);
+        for (int i = 0; i < ncomp; i++) comps[i].dc_predictor = 0;
+        for (int row_mcu = 0; row_mcu < mcus_per_column; row_mcu++)
+            for (int col_mcu = 0; col_mcu < mcus_per_line; col_mcu++)
+                for (int ci = 0; ci < ncomp; ci++) {
+                    enc_component *c = &comps[ci];
+                    for (int y = 0; y < c->v; y++)
+                        for (int x = 0; x < c->h; x++)
+                            gather_block(c, BLOCK_REF(ci, col_mcu * c->h + x, row_mcu * c->v + y), freq[2 * c->dc_id], freq[2 * c->ac_id + 1]);
+                }
+        for (int t = 0; t < 4; t++) { /* _huffmanTables.BuildTables: every builder of the collection, in SetHuffmanTable order */
+            uint16_t code[256];
+            uint8_t len[256];
+            if (jref_build_optimal_table(freq[t], o_bits[t], o_vals[t], &o_n[t], code, len) != 0) {
+                free(store);
+                *out_len = 0;
+                return 2;
+            }
+            memset(&o_tab[t], 0, sizeof o_tab[t]);
+            for (int sym = 0; sym < 256; sym++) {
+                o_tab[t].code[sym] = code[sym];
+                o_tab[t].code_len[sym] = len[sym];
+            }
+        }
+        comps[0].dc = &o_tab[0];
+        comps[0].ac = &o_tab[1];
+        for (int i = 1; i < ncomp; i++) {
+            comps[i].dc = &o_tab[2];
+            comps[i].ac = &o_tab[3];
+        }
+        const int cls[4] = {0, 1, 0, 1}, ids[4] = {0, 0, 1, 1};
+        int total = 0;
+        for (int t = 0; t < 4; t++) total += 1 + 16 + o_n[t];
+        w_marker(&w, 0xC4);
+        w_length(&w, (uint16_t)total);
+        for (int t = 0; t < 4; t++) {
+            w_byte(&w, (uint8_t)((cls[t] << 4) | ids[t]));
+            for (int l = 0; l < 16; l++) w_byte(&w, o_bits[t][l]);
+            for (int i = 0; i < o_n[t]; i++) w_byte(&w, o_vals[t][i]);
+        }
+    }
     /* WriteHuffmanTables :336-352: one DHT segment, tables in SetHuffmanTable order (DC0, AC0, DC1, AC1) */
-    {
+    if (!optimize_coding) {
         const enc_table *tabs[4] = {&t_dc_lum, &t_ac_lum, &t_dc_chr, &t_ac_chr};
         const int cls[4] = {0, 1, 0, 1}, ids[4] = {0, 0, 1, 1};
         int total = 0;
@@ -452,6 +582,32 @@ int jref_encode_8bit(const uint8_t *pixels, int width, int height, int component
         w_byte(&w, 63);
         w_byte(&w, 0);
     }
+    if (optimize_coding) { /* WritePreparedScanData :604-655 */
+        int max_h = 1, max_v = 1;
+        for (int i = 0; i < ncomp; i++) {
+            comps[i].dc_predictor = 0;
+            if (comps[i].h > max_h) max_h = comps[i].h;
+            if (comps[i].v > max_v) max_v = comps[i].v;
+        }
+        int mcus_per_line = (width + 8 * max_h - 1) / (8 * max_h);
+        int mcus_per_column = (height + 8 * max_v - 1) / (8 * max_v);
+        size_t nblock = 0;
+        for (int row_mcu = 0; row_mcu < mcus_per_column; row_mcu++)
+            for (int col_mcu = 0; col_mcu < mcus_per_line; col_mcu++)
+                for (int ci = 0; ci < ncomp; ci++) {
+                    enc_component *c = &comps[ci];
+                    for (int y = 0; y < c->v; y++)
+                        for (int x = 0; x < c->h; x++) {
+                            const int16_t *block = BLOCK_REF(ci, col_mcu * c->h + x, row_mcu * c->v + y);
+                            if (coef_tap) memcpy(coef_tap + nblock * 64, block, 64 * sizeof(int16_t));
+                            nblock++;
+                            encode_block(&w, c, block);
+                        }
+                }
+        w_exit_bit_mode(&w);
+        free(store);
+#undef BLOCK_REF
+    } else
     /* WriteScanData :662-741 */
     {
         int max_h = 1, max_v = 1;

@@ -220,7 +220,8 @@ def ycbcr8_to_rgb(ycbcr: np.ndarray, rgba: bool = False, gray: bool = False) -> 
     return out
 
 
-def encode_8bit(pixels: np.ndarray, luma_h: int = 2, luma_v: int = 2, quality: int = 75, want_coefficients: bool = False):
+def encode_8bit(pixels: np.ndarray, luma_h: int = 2, luma_v: int = 2, quality: int = 75, want_coefficients: bool = False,
+                optimize_coding: bool = False):
     """The reference encoder's EncodeAction sequence (standard tables, no optimisation) on an interleaved 8-bit image
     (H, W, C) with C = 3 (Y, Cb, Cr) or 1.  Returns the JPEG bytes (and the quantised zig-zag blocks in encoding order)."""
     L = lib()
@@ -228,9 +229,9 @@ def encode_8bit(pixels: np.ndarray, luma_h: int = 2, luma_v: int = 2, quality: i
     if a.ndim == 2:
         a = a.reshape(a.shape[0], a.shape[1], 1)
     h, w, c = a.shape
-    L.jref_encode_8bit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
-                                   C.POINTER(C.c_size_t), C.c_void_p]
-    L.jref_encode_8bit.restype = C.c_int
+    L.jref_encode_8bit_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                      C.POINTER(C.c_size_t), C.c_void_p]
+    L.jref_encode_8bit_ex.restype = C.c_int
     ncomp = 1 if c == 1 else 3
     mh, mv = luma_h, luma_v
     mcus = (-(-w // (8 * mh))) * (-(-h // (8 * mv)))
@@ -239,8 +240,10 @@ def encode_8bit(pixels: np.ndarray, luma_h: int = 2, luma_v: int = 2, quality: i
     cap = 1024 + w * h * c * 2 + nblocks * 8
     out = np.empty(cap, np.uint8)
     n = C.c_size_t(0)
-    rc = L.jref_encode_8bit(a.ctypes.data, w, h, c, luma_h, luma_v, quality, out.ctypes.data, cap, C.byref(n),
-                            coefs.ctypes.data if coefs is not None else None)
+    rc = L.jref_encode_8bit_ex(a.ctypes.data, w, h, c, luma_h, luma_v, quality, 1 if optimize_coding else 0, out.ctypes.data, cap, C.byref(n),
+                               coefs.ctypes.data if coefs is not None else None)
+    if rc == 2:
+        raise OracleError(2, "No symbol is recorded.")
     if rc != 0:
         raise OracleError(4, "encoder output buffer too small")
     data = out[:n.value].tobytes()

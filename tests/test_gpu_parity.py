@@ -860,3 +860,38 @@ def test_optimizer_failures_follow_the_reference():
         with pytest.raises(po.OracleError):
             po.optimize(files[i], True)
     b.close()
+
+
+@pytest.mark.parametrize("luma,w,h", [((2, 2), 64, 48), ((2, 2), 100, 70), ((2, 2), 37, 29), ((1, 1), 61, 35), ((2, 1), 90, 41), ((4, 1), 130, 33),
+                                      ((2, 2), 640, 360)])
+def test_encoder_optimize_coding_matches_the_restatement(luma, w, h):
+    """EncodeAction's optimizeCoding: TransformBlocks into the block allocator (own block per position, dummy block for
+    positions outside a component's grid), BuildHuffmanTables, WritePreparedScanData -- coefficients, DHT and scan bytes."""
+    rng = np.random.default_rng(w * 1000 + h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    smooth = np.stack([128 + 90 * np.sin(xx / 17) * np.cos(yy / 23), 128 + 70 * np.cos(xx / 31 + yy / 11), 128 + 80 * np.sin((xx + yy) / 19)], -1)
+    imgs = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8), np.clip(np.rint(smooth + rng.normal(0, 6, smooth.shape)), 0, 255).astype(np.uint8)]
+    for q in (30, 75, 95):
+        b = jl.EncodeBatch().upload(imgs, luma, q, optimize_coding=True).encode()
+        for k, im in enumerate(imgs):
+            ref, ref_coefs = po.encode_8bit(im, luma[0], luma[1], q, want_coefficients=True, optimize_coding=True)
+            assert np.array_equal(b.coefficients(k), ref_coefs), (q, k)
+            got = b.output(k)
+            assert got == ref, (q, k, len(got), len(ref))
+            assert len(got) <= len(po.encode_8bit(im, luma[0], luma[1], q)) + 64
+        b.close()
+
+
+def test_encoder_optimize_coding_mixed_batch_and_gray_failure():
+    rng = np.random.default_rng(9)
+    rgb = rng.integers(0, 256, (50, 70, 3)).astype(np.uint8)
+    gray = rng.integers(0, 256, (40, 40)).astype(np.uint8)
+    out = jl.encode_batch([rgb], (2, 2), 80, rgb=True, optimize_coding=True)[0]
+    assert out == po.encode_8bit(po.rgb_to_ycbcr8(rgb), 2, 2, 80, optimize_coding=True)
+    b = jl.EncodeBatch().upload([gray, rgb], (1, 1), 80, optimize_coding=True).encode()
+    with pytest.raises(jl.InvalidOperationException):  # "No symbol is recorded.": the chrominance builders of a gray image stay empty
+        b.output(0)
+    with pytest.raises(po.OracleError):
+        po.encode_8bit(gray, 1, 1, 80, optimize_coding=True)
+    assert b.output(1) == po.encode_8bit(rgb, 1, 1, 80, optimize_coding=True)
+    b.close()

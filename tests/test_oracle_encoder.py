@@ -94,3 +94,20 @@ def test_subsampled_blocks_accumulate_on_the_previous_blocks_coefficients():
     assert np.array_equal(po.fdct_quantize_block(samples.reshape(64), chr_q)[0], coefs[4])
     clean = ((box + 2) >> 2).astype(np.int16)
     assert not np.array_equal(po.fdct_quantize_block(clean.reshape(64), chr_q)[0], coefs[4]) or not stale.any()
+
+
+def test_optimize_coding_round_trips_and_shrinks():
+    """EncodeAction's optimizeCoding branch of the restatement: the stream decodes back to the tapped coefficients (with
+    the restated decoder and with Pillow's), and is not larger than the standard-table stream."""
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    for (w, h), luma in (((64, 48), (2, 2)), ((37, 29), (2, 2)), ((90, 41), (2, 1)), ((61, 35), (1, 1))):
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        std = po.encode_8bit(img, luma[0], luma[1], 75)
+        opt, coefs = po.encode_8bit(img, luma[0], luma[1], 75, want_coefficients=True, optimize_coding=True)
+        assert len(opt) < len(std)
+        assert np.array_equal(po.decode_coefficients(opt)[0], coefs)
+        assert Image.open(io.BytesIO(opt)).size == (w, h)
+    with pytest.raises(po.OracleError):
+        po.encode_8bit(img[..., 0], 1, 1, 75, optimize_coding=True)
