@@ -58,7 +58,7 @@ int DeviceBatch::hip_fail(hipError_t e, const char *what) {
 namespace {
 class PlanHandler final : public ScanHandler {
   public:
-    PlanHandler(std::vector<ScanJob> *jobs) : jobs_(jobs) {}
+    explicit PlanHandler(std::vector<ScanJob> *jobs, bool first_scan_only = false) : jobs_(jobs), first_scan_only_(first_scan_only) {}
     void on_frame(HostDecoder &dec, int sof) override {
         sof_ = sof;
         baseline_ = false;
@@ -80,8 +80,9 @@ class PlanHandler final : public ScanHandler {
         if (!baseline_)
             throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "Only Huffman DCT frames (SOF0, SOF1, SOF2) run on this path.", kDetailUnsupportedFrame);
         jobs_->push_back(make_scan_job(dec, geo_, scan, entropy, len));
-        // leave the reader just before the next non-RST marker, like ProcessScan does (:167-176)
-        reader.try_advance((int)find_scan_end(entropy, len));
+        // leave the reader just before the next non-RST marker, like ProcessScan does (:167-176); the optimizer path only
+        // wants the scan resolved (what follows it is its own marker walk's business): nothing is left to read
+        reader.try_advance(first_scan_only_ ? (int)len : (int)find_scan_end(entropy, len));
     }
     void on_dispose(HostDecoder &) override { flush_progressive(); }
     const BaselineGeometry &geo() const { return prog_geo_valid_ ? prog_geo_ : geo_; }
@@ -100,6 +101,7 @@ class PlanHandler final : public ScanHandler {
         prog_.reset();
     }
     std::vector<ScanJob> *jobs_;
+    bool first_scan_only_ = false;
     BaselineGeometry geo_, prog_geo_;
     bool prog_geo_valid_ = false;
     ProgressiveFrame prog_;
@@ -162,10 +164,17 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
             if (len[i] > 0x7FFFFFF0u) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "JPEG streams of 2 GiB or more are not supported.");
             HostDecoder dec;
             dec.set_input(jpeg[i], len[i]);
-            dec.identify(false);  // every reference caller runs Identify before Decode; it latches the LAST DRI (F4)
+            if (entropy_only_) {
+                // optimizer path: JpegOptimizer.Scan() runs no Identify(); the restart interval is the one in force at the
+                // scan (OptimizeBatch::plan_file found it) unless a DRI segment in front of the frame header says otherwise
+                if ((size_t)i < preset_dri_.size()) dec.set_restart_interval(preset_dri_[i]);
+            } else {
+                dec.identify(false);  // every reference caller runs Identify before Decode; it latches the LAST DRI (F4)
+            }
             img.sof = (uint8_t)dec.start_of_frame();
-            PlanHandler handler(&jobs_);
+            PlanHandler handler(&jobs_, entropy_only_);
             dec.decode(handler, true);
+            if (entropy_only_) img.sof = (uint8_t)dec.start_of_frame();
             if (jobs_.size() == first_job) {
                 // no scan: Decode() succeeds without writing anything; keep the frame geometry for the caller
                 if (img.sof == kSOF0 || img.sof == kSOF1) plan_image_geometry(img, BaselineGeometry::latch(dec, dec.frame_header()));

@@ -87,10 +87,12 @@ class DeviceBatch {
     int last_subseq_rounds() const { return last_subseq_rounds_; }
     // the optimizer path only needs the files, the scan descriptors and the marker index: no coefficient / sample buffers
     void set_entropy_only(bool on) { entropy_only_ = on; }
+    void set_preset_restart_intervals(std::vector<int> v) { preset_dri_ = std::move(v); }
 
   private:
     friend class OptimizeBatch;
     bool entropy_only_ = false;
+    std::vector<int> preset_dri_;  // entropy-only mode: restart interval in force at each file's scan
     int fail(int status, const std::string &msg);
     int hip_fail(hipError_t e, const char *what);
     int layout_and_upload(const std::vector<const uint8_t *> &file_ptr, const std::vector<size_t> &file_len);

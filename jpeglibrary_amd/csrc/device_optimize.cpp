@@ -252,6 +252,8 @@ std::string at_offset(int off, const char *msg) { return "Failed to decode JPEG 
 void OptimizeBatch::plan_file(Plan &p, const uint8_t *data, size_t len, bool strip) {
     // ---- Scan(): tables, frame, restart interval as of the scan; exactly one scan
     std::vector<QuantTable> quant;  // _quantizationTables: replace by identifier, else append (:319-338)
+    bool after_scan = false;  // from here on a failure of the walks is only met once the scan itself went through
+    try {
     bool have_frame = false;
     int n_scans = 0;
     uint16_t dri = 0, dri_at_scan = 0;
@@ -321,6 +323,8 @@ void OptimizeBatch::plan_file(Plan &p, const uint8_t *data, size_t len, bool str
                 if (++n_scans > 1)
                     refuse(JPGPU_ERR_NOT_SUPPORTED, "Files with more than one scan are not supported by the optimizer path.", kDetailUnsupportedFrame);
                 dri_at_scan = dri;
+                p.dri_at_scan = dri;
+                after_scan = true;
                 const size_t end = find_scan_end(r.remaining_bytes(), (size_t)r.remaining_byte_count());
                 r.try_advance((int)end);
                 break;
@@ -422,6 +426,13 @@ void OptimizeBatch::plan_file(Plan &p, const uint8_t *data, size_t len, bool str
         }
     }
     flush();
+    } catch (const Refuse &e) {
+        if (!after_scan || e.status == JPGPU_ERR_NOT_SUPPORTED) throw;
+        p.late_status = e.status;
+        p.late_detail = e.detail;
+        p.late_error = e.msg;
+        p.pieces.clear();
+    }
 }
 
 int OptimizeBatch::upload(const uint8_t *const *jpeg, const size_t *len, int n, int strip) {
@@ -440,6 +451,11 @@ int OptimizeBatch::upload(const uint8_t *const *jpeg, const size_t *len, int n, 
     }
     // the decoder-side parser resolves the scan (tables, geometry, restart interval) and lays the files out in HBM
     batch_.set_entropy_only(true);
+    {
+        std::vector<int> dri((size_t)n, 0);
+        for (int i = 0; i < n; i++) dri[i] = plans_[i].dri_at_scan;
+        batch_.set_preset_restart_intervals(std::move(dri));
+    }
     int rc = batch_.upload_files(jpeg, len, n, JPGPU_FMT_PLANAR_U8);
     if (rc != JPGPU_OK) return rc;
     scan_ids_.clear();
@@ -462,6 +478,13 @@ int OptimizeBatch::upload(const uint8_t *const *jpeg, const size_t *len, int n, 
         }
         p.job = img->jobs[0];
         const DevScan &s = batch_.h_scans_[p.job];
+        if ((int)s.dri != p.dri_at_scan) {  // a DRI segment in front of the frame header that a later one overrides
+            p.status = JPGPU_ERR_NOT_SUPPORTED;
+            p.detail = kDetailUnsupportedFrame;
+            p.error = "A restart interval that changes between the frame header and the scan is not supported by the optimizer path.";
+            p.job = -1;
+            continue;
+        }
         scan_ids_.push_back((uint32_t)p.job);
         for (uint32_t first = 0; first < s.n_intervals; first += 256) work_.push_back({(uint32_t)p.job, first});
     }
@@ -585,7 +608,7 @@ int OptimizeBatch::run() {
                                  (const uint64_t *)d_base_.ptr, (uint64_t *)d_offsets_.ptr, nullptr);
     if (e != hipSuccess) return hip_fail(e, "transcode_offsets_kernel");
     e = launch_transcode(ctx_->stream, 2, udata, input, scans, (const HuffWork *)d_work_.ptr, n_work, ends_u, ends_raw, status, pool, nullptr,
-                         (const EncHuffTable *)d_enc_.ptr, nullptr, (const uint64_t *)d_offsets_.ptr, (uint8_t *)d_out_.ptr, n_slots);
+                         (const EncHuffTable *)d_enc_.ptr, (uint32_t *)d_sizes_.ptr, (const uint64_t *)d_offsets_.ptr, (uint8_t *)d_out_.ptr, n_slots);
     if (e != hipSuccess) return hip_fail(e, "transcode_kernel<emit>");
     (void)hipEventRecord(ev1_, ctx_->stream);
     e = hipStreamSynchronize(ctx_->stream);
@@ -629,6 +652,10 @@ int OptimizeBatch::result(int i, jpgpu_image_result *res, size_t *out_len) {
         if (check_saw_eoi) {
             res->status = JPGPU_ERR_INVALID_OPERATION;
             ctx_->last_error = "Operation is not valid due to the current state of the object.";
+        } else if (p.late_status != JPGPU_OK) {
+            res->status = p.late_status;
+            res->detail = p.late_detail;
+            ctx_->last_error = p.late_error;
         }
     }
     if (res->status == JPGPU_OK && out_len) *out_len = (size_t)p.out_len;

@@ -42,6 +42,11 @@ class OptimizeBatch {
     struct Plan {
         int status = JPGPU_OK, detail = 0;
         std::string error;
+        // failures of the marker walks BEHIND the scan: the reference meets them only once the scan itself went through
+        // (Scan() throws from ProcessScanBaseline first), so they are reported after the device-side status
+        int late_status = JPGPU_OK, late_detail = 0;
+        std::string late_error;
+        int dri_at_scan = 0;
         std::vector<Piece> pieces;
         int job = -1;  // scan job inside batch_
         std::string dht;  // the rewritten DHT segment (marker, length, tables)

@@ -3557,7 +3557,9 @@ __global__ __launch_bounds__(kTcThreads) void transcode_kernel(const uint8_t *__
     const uint32_t total_mcus = s.total_mcus;
     const uint32_t dri_eff = s.dri ? s.dri : total_mcus;
     const uint32_t interval = wk.first_interval + tid;
-    const bool active = interval < n_ends && interval < n_intervals;
+    bool active = interval < n_ends && interval < n_intervals;
+    // emit: an interval that failed in the measure pass owns no bytes of the output (its size is 0): it must not write
+    if (MODE == 2 && active && sizes[s.ends_off + interval] == 0) active = false;
     uint32_t err = 0;
     if (active) {
         const uint32_t *eu = ends_u + s.ends_off;

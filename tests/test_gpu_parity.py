@@ -895,3 +895,38 @@ def test_encoder_optimize_coding_mixed_batch_and_gray_failure():
         po.encode_8bit(gray, 1, 1, 80, optimize_coding=True)
     assert b.output(1) == po.encode_8bit(rgb, 1, 1, 80, optimize_coding=True)
     b.close()
+
+
+@pytest.mark.parametrize("variant", ["dri7_420", "dri0_444", "dri3_gray"])
+def test_optimizer_random_corruptions_follow_the_reference(variant):
+    """150 random edits per stream kind through the optimizer: where the reference's JpegOptimizer still produces a
+    stream the GPU path must produce the same bytes; where it throws, the same exception class.  (Files the device path
+    refuses by design -- several scans, progressive, a DRI that changes after the scan -- are skipped.)"""
+    rng = np.random.default_rng({"dri7_420": 21, "dri0_444": 22, "dri3_gray": 23}[variant])
+    if variant == "dri7_420":
+        good = bytes(jpegsynth.encode(112, 80, "420", 75, 7, seed=31))   # 35 MCUs
+    elif variant == "dri0_444":
+        good = bytes(jpegsynth.encode(72, 56, "444", 85, 0, seed=32))
+    else:
+        good = bytes(jpegsynth.encode(88, 64, "gray", 60, 3, seed=33))   # 88 MCUs
+    cases = [good] + [_mutate(good, rng) for _ in range(150)]
+    names = {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException", 4: "ArgumentException"}
+    b = jl.OptimizeBatch().upload(cases, True).run()
+    mismatches, compared = [], 0
+    for i, data in enumerate(cases):
+        try:
+            ref, ref_kind = po.optimize(data, True), "OK"
+        except po.OracleError as e:
+            ref, ref_kind = None, e.kind
+        res, size = b.result(i)
+        mine = names.get(res.status, str(res.status))
+        if mine == "NotSupportedException":
+            continue
+        compared += 1
+        if mine != ref_kind:
+            mismatches.append((i, ref_kind, mine, res.detail))
+        elif ref is not None and b.output(i) != ref:
+            mismatches.append((i, "bytes differ", len(ref), size))
+    b.close()
+    assert compared > 100
+    assert not mismatches, mismatches[:10]
