@@ -277,8 +277,9 @@ typedef struct jpgpu_encode_params {
     int32_t luma_h, luma_v;  /* sampling factors of the first component (1, 2 or 4); the others are 1 x 1 */
     int32_t quality;         /* 1..100, JpegStandardQuantizationTable.ScaleByQuality */
     int32_t input_rgb;
-    int32_t optimize_coding; /* EncodeAction's optimizeCoding (EncodeAction.cs:40-46): Huffman tables built from the image's own
-                                statistics (TransformBlocks / BuildHuffmanTables / WritePreparedScanData, JpegEncoder.cs:264-274) */
+    int32_t optimize_coding; /* 1 = EncodeAction's optimizeCoding (EncodeAction.cs:40-46): Huffman tables built from the image's own
+                                statistics (TransformBlocks / BuildHuffmanTables / WritePreparedScanData, JpegEncoder.cs:264-274);
+                                2 = the same with JpegEncoder.MostOptimalCoding (:43) */
 } jpgpu_encode_params;
 typedef struct jpgpu_encoder jpgpu_encoder;
 
@@ -299,13 +300,15 @@ int jpgpu_encoder_download_coefficients(jpgpu_encoder *e, int i, int16_t *dst, s
  *     SetInput (:57-63) + Scan() (:66-153) + SetOutput (:523-526) + Optimize(strip) (:540-648).  The marker walks run on
  *     the host, the two symbol passes (ProcessScanBaseline :360-463, CopyScanBaseline :719-829) on the device, the new
  *     Huffman tables are JpegHuffmanEncodingTableBuilder.Build(false) (JpegHuffmanEncodingTableBuilder.cs:68-175).
- *     Not supported (JPGPU_ERR_NOT_SUPPORTED): more than one scan, progressive frames, MostOptimalCoding.
+ *     Not supported (JPGPU_ERR_NOT_SUPPORTED): more than one scan, progressive frames.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct jpgpu_optimizer jpgpu_optimizer;
 int jpgpu_optimizer_create(jpgpu_ctx *ctx, jpgpu_optimizer **out);
 void jpgpu_optimizer_destroy(jpgpu_optimizer *o);
 /* SetInput for n files (host marker walks + H2D); strip = Optimize(strip)'s argument */
 int jpgpu_optimizer_upload(jpgpu_optimizer *o, const uint8_t *const *jpeg, const size_t *len, int n, int strip);
+/* JpegOptimizer.MostOptimalCoding (:38): Build(optimal = true), the package-merge builder */
+int jpgpu_optimizer_set_most_optimal_coding(jpgpu_optimizer *o, int on);
 /* Scan() + Optimize(strip) for every file */
 int jpgpu_optimizer_run(jpgpu_optimizer *o);
 /* status of file i with the reference's exception classes; out_len = bytes Optimize() wrote */
@@ -315,8 +318,8 @@ int jpgpu_optimizer_download(jpgpu_optimizer *o, int i, void *dst, size_t cap); 
 int jpgpu_optimizer_statistics(const jpgpu_optimizer *o, int i, int table, uint8_t *table_class, uint8_t *identifier, uint32_t *counts);
 int jpgpu_optimizer_last_ms(const jpgpu_optimizer *o, float *ms);  /* device time of the last run (HIP events) */
 /* JpegHuffmanEncodingTableBuilder.Build(false) for one table: DHT counts and values, and GetCode() for all 256 symbols */
-int jpgpu_build_optimal_huffman_table(const uint32_t *counts, uint8_t *bits, uint8_t *values, int *num_values, uint16_t *code,
-                                      uint8_t *length);
+int jpgpu_build_optimal_huffman_table(const uint32_t *counts, int most_optimal, uint8_t *bits, uint8_t *values, int *num_values,
+                                      uint16_t *code, uint8_t *length);
 
 #ifdef __cplusplus
 }

@@ -137,7 +137,8 @@ SYMBOLS = [
     ("jpgpu_optimizer_download", C.c_int, [_P, C.c_int, C.c_void_p, C.c_size_t]),
     ("jpgpu_optimizer_statistics", C.c_int, [_P, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("jpgpu_optimizer_last_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
-    ("jpgpu_build_optimal_huffman_table", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]),
+    ("jpgpu_build_optimal_huffman_table", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]),
+    ("jpgpu_optimizer_set_most_optimal_coding", C.c_int, [_P, C.c_int]),
 ]
 
 

@@ -709,6 +709,11 @@ void jpgpu_optimizer_destroy(jpgpu_optimizer *opt) { delete opt; }
 int jpgpu_optimizer_upload(jpgpu_optimizer *opt, const uint8_t *const *jpeg, const size_t *len, int n, int strip) {
     JPGPU_GUARD(opt, opt->impl.upload(jpeg, len, n, strip));
 }
+int jpgpu_optimizer_set_most_optimal_coding(jpgpu_optimizer *opt, int on) {
+    if (!opt) return JPGPU_ERR_ARGUMENT;
+    opt->impl.set_most_optimal_coding(on != 0);
+    return JPGPU_OK;
+}
 int jpgpu_optimizer_run(jpgpu_optimizer *opt) { JPGPU_GUARD(opt, opt->impl.run()); }
 int jpgpu_optimizer_result(jpgpu_optimizer *opt, int i, jpgpu_image_result *res, size_t *out_len) {
     JPGPU_GUARD(opt, opt->impl.result(i, res, out_len));
@@ -723,10 +728,11 @@ int jpgpu_optimizer_last_ms(const jpgpu_optimizer *opt, float *ms) {
     *ms = opt->impl.last_ms();
     return JPGPU_OK;
 }
-int jpgpu_build_optimal_huffman_table(const uint32_t *counts, uint8_t *bits, uint8_t *values, int *num_values, uint16_t *code, uint8_t *length) {
+int jpgpu_build_optimal_huffman_table(const uint32_t *counts, int most_optimal, uint8_t *bits, uint8_t *values, int *num_values, uint16_t *code,
+                                      uint8_t *length) {
     if (!counts || !bits || !values || !num_values) return JPGPU_ERR_ARGUMENT;
     std::vector<OptimalCode> codes;
-    if (!build_optimal_table(counts, &codes)) return JPGPU_ERR_INVALID_OPERATION;
+    if (!build_optimal_table(counts, &codes, most_optimal != 0)) return JPGPU_ERR_INVALID_OPERATION;
     memset(bits, 0, 16);
     for (size_t i = 0; i < codes.size(); i++) {
         if (codes[i].length >= 1 && codes[i].length <= 16) bits[codes[i].length - 1]++;

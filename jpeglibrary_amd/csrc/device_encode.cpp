@@ -141,6 +141,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
     headers_pre_.assign((size_t)n, std::vector<uint8_t>());
     headers_post_.assign((size_t)n, std::vector<uint8_t>());
     optimized_.clear();
+    most_optimal_.assign((size_t)n, 0);
     status_.assign((size_t)n, JPGPU_OK);
     encoded_ = false;
     std::vector<EncWork> work_mcu, work_blk;
@@ -170,6 +171,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         im.total_blocks = im.mcus_per_line * im.mcus_per_column * im.bpm;
         im.input_rgb = p.input_rgb ? 1 : 0;
         if (p.optimize_coding) {
+            most_optimal_[i] = p.optimize_coding == 2;  // JpegEncoder.MostOptimalCoding
             optimized_.push_back(i);
             im.table_base = 4u * (uint32_t)optimized_.size();  // tables 0..3 are the standard ones
         }
@@ -307,7 +309,7 @@ int EncodeBatch::encode() {
             status_[i] = JPGPU_OK;
             for (int t = 0; t < 4; t++) {  // every builder of the collection, in SetHuffmanTable order: DC0, AC0, DC1, AC1
                 std::vector<OptimalCode> codes;
-                if (!build_optimal_table(&hist[((size_t)i * 4 + t) * 256], &codes)) {
+                if (!build_optimal_table(&hist[((size_t)i * 4 + t) * 256], &codes, most_optimal_[i] != 0)) {
                     status_[i] = JPGPU_ERR_INVALID_OPERATION;  // "No symbol is recorded." (a single-component image: empty chrominance builders)
                     break;
                 }

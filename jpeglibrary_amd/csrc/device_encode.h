@@ -38,6 +38,7 @@ class EncodeBatch {
     std::vector<std::vector<uint8_t>> headers_pre_;    // optimizeCoding: SOI, DQT, SOF0 ...
     std::vector<std::vector<uint8_t>> headers_post_;   // ... and SOS; the DHT between them depends on the statistics
     std::vector<int> optimized_;                       // images with optimizeCoding
+    std::vector<uint8_t> most_optimal_;                // ... and MostOptimalCoding (package merge)
     std::vector<int> status_;                          // per image: JPGPU_OK or the reference's failure ("No symbol is recorded.")
     DevBuffer d_hist_;
     std::vector<uint64_t> out_len_;

@@ -28,96 +28,203 @@ struct Sym {
     uint16_t code_size;
     int16_t others;
 };
-inline int cmp_size(const Sym &x, const Sym &y) { return x.code_size < y.code_size ? -1 : (x.code_size > y.code_size ? 1 : 0); }
 
-// Array.Sort(T[], Comparison<T>) of .NET Core 3.0+ / .NET 5+ (ArraySortHelper<T>.IntrospectiveSort): the reference sorts
-// its symbols by code size with it, and the sort is not stable.
+// Array.Sort(T[], Comparison<T>) / List<T>.Sort(Comparison<T>) of .NET Core 3.0+ / .NET 5+ (ArraySortHelper<T>.IntrospectiveSort:
+// insertion sort up to 16 elements, median-of-three pivot parked at hi - 1, heapsort below depth 2 * (log2(n) + 1)).  The
+// reference orders its symbols and its package-merge nodes with it, and the sort is not stable: what it leaves depends on
+// the algorithm, so the algorithm is restated.  It only moves whole elements and looks at them through the comparison,
+// which makes an array of pointers to the elements take exactly the same path.
+template <typename T, typename Cmp>
 struct NetSort {
-    static void swap_if_greater(Sym *k, int i, int j) {
-        if (i != j && cmp_size(k[i], k[j]) > 0) std::swap(k[i], k[j]);
+    const T **k;
+    Cmp cmp;
+    void swap_if_greater(int i, int j) {
+        if (i != j && cmp(*k[i], *k[j]) > 0) std::swap(k[i], k[j]);
     }
-    static void insertion(Sym *k, int n) {
+    void insertion(int lo, int n) {
         for (int i = 0; i < n - 1; i++) {
-            const Sym t = k[i + 1];
+            const T *t = k[lo + i + 1];
             int j = i;
-            while (j >= 0 && cmp_size(t, k[j]) < 0) {
-                k[j + 1] = k[j];
+            while (j >= 0 && cmp(*t, *k[lo + j]) < 0) {
+                k[lo + j + 1] = k[lo + j];
                 j--;
             }
-            k[j + 1] = t;
+            k[lo + j + 1] = t;
         }
     }
-    static void down_heap(Sym *k, int i, int n) {
-        const Sym d = k[i - 1];
+    void down_heap(int lo, int i, int n) {
+        const T *d = k[lo + i - 1];
         while (i <= n >> 1) {
             int child = 2 * i;
-            if (child < n && cmp_size(k[child - 1], k[child]) < 0) child++;
-            if (!(cmp_size(d, k[child - 1]) < 0)) break;
-            k[i - 1] = k[child - 1];
+            if (child < n && cmp(*k[lo + child - 1], *k[lo + child]) < 0) child++;
+            if (!(cmp(*d, *k[lo + child - 1]) < 0)) break;
+            k[lo + i - 1] = k[lo + child - 1];
             i = child;
         }
-        k[i - 1] = d;
+        k[lo + i - 1] = d;
     }
-    static void heap(Sym *k, int n) {
-        for (int i = n >> 1; i >= 1; i--) down_heap(k, i, n);
+    void heap(int lo, int n) {
+        for (int i = n >> 1; i >= 1; i--) down_heap(lo, i, n);
         for (int i = n; i > 1; i--) {
-            std::swap(k[0], k[i - 1]);
-            down_heap(k, 1, i - 1);
+            std::swap(k[lo], k[lo + i - 1]);
+            down_heap(lo, 1, i - 1);
         }
     }
-    static int partition(Sym *k, int n) {
+    int partition(int lo, int n) {
         const int hi = n - 1, middle = hi >> 1;
-        swap_if_greater(k, 0, middle);
-        swap_if_greater(k, 0, hi);
-        swap_if_greater(k, middle, hi);
-        const Sym pivot = k[middle];
-        std::swap(k[middle], k[hi - 1]);
+        swap_if_greater(lo, lo + middle);
+        swap_if_greater(lo, lo + hi);
+        swap_if_greater(lo + middle, lo + hi);
+        const T *pivot = k[lo + middle];
+        std::swap(k[lo + middle], k[lo + hi - 1]);
         int left = 0, right = hi - 1;
         while (left < right) {
-            while (cmp_size(k[++left], pivot) < 0) {
+            while (cmp(*k[lo + ++left], *pivot) < 0) {
             }
-            while (cmp_size(pivot, k[--right]) < 0) {
+            while (cmp(*pivot, *k[lo + --right]) < 0) {
             }
             if (left >= right) break;
-            std::swap(k[left], k[right]);
+            std::swap(k[lo + left], k[lo + right]);
         }
-        if (left != hi - 1) std::swap(k[left], k[hi - 1]);
+        if (left != hi - 1) std::swap(k[lo + left], k[lo + hi - 1]);
         return left;
     }
-    static void intro(Sym *k, int n, int depth) {
+    void intro(int lo, int n, int depth) {
         while (n > 1) {
             if (n <= 16) {
                 if (n == 2) {
-                    swap_if_greater(k, 0, 1);
+                    swap_if_greater(lo, lo + 1);
                 } else if (n == 3) {
-                    swap_if_greater(k, 0, 1);
-                    swap_if_greater(k, 0, 2);
-                    swap_if_greater(k, 1, 2);
+                    swap_if_greater(lo, lo + 1);
+                    swap_if_greater(lo, lo + 2);
+                    swap_if_greater(lo + 1, lo + 2);
                 } else {
-                    insertion(k, n);
+                    insertion(lo, n);
                 }
                 return;
             }
             if (depth == 0) {
-                heap(k, n);
+                heap(lo, n);
                 return;
             }
             depth--;
-            const int p = partition(k, n);
-            intro(k + p + 1, n - (p + 1), depth);
+            const int p = partition(lo, n);
+            intro(lo + p + 1, n - (p + 1), depth);
             n = p;
         }
     }
-    static void sort(Sym *k, int n) {
-        if (n < 2) return;
-        int log2 = 0;
-        for (unsigned v = (unsigned)n; v > 1; v >>= 1) log2++;
-        intro(k, n, 2 * (log2 + 1));
-    }
 };
+template <typename T, typename Cmp>
+void net_sort(std::vector<const T *> &ptrs, Cmp cmp) {
+    const int n = (int)ptrs.size();
+    if (n < 2) return;
+    int log2 = 0;
+    for (unsigned v = (unsigned)n; v > 1; v >>= 1) log2++;
+    NetSort<T, Cmp> s{ptrs.data(), cmp};
+    s.intro(0, n, 2 * (log2 + 1));
+}
+template <typename Cmp>
+void net_sort_symbols(Sym *s, int n, Cmp cmp) {
+    std::vector<Sym> copy(s, s + n);
+    std::vector<const Sym *> ptrs((size_t)n);
+    for (int i = 0; i < n; i++) ptrs[i] = &copy[i];
+    net_sort<Sym>(ptrs, cmp);
+    for (int i = 0; i < n; i++) s[i] = *ptrs[i];
+}
+
+// BuildCanonicalCode: code words for lengths already in DHT order (:237-283, :470-497)
+void assign_canonical_codes(std::vector<OptimalCode> &codes) {
+    uint16_t code = 0;
+    int count = codes[0].length;
+    codes[0].code = 0;
+    for (size_t i = 1; i < codes.size(); i++) {
+        OptimalCode &c = codes[i];
+        if (c.length > count) {
+            code++;
+            code = (uint16_t)(code << (c.length - count));
+            c.code = code;
+            count = c.length;
+        } else {
+            c.code = ++code;
+        }
+    }
+}
+
+// MostOptimalCoding: BuildUsingPackageMerge + RunPackageMerge (JpegHuffmanEncodingTableBuilder.cs:289-428)
+struct PmNode {
+    int64_t frequency = 0;
+    int16_t index = 0;
+    const PmNode *left = nullptr, *right = nullptr;
+};
+void pm_traverse(const PmNode *node, Sym *symbols) {
+    if (!node) return;
+    if (!node->left) {
+        symbols[node->index].code_size++;
+    } else {
+        pm_traverse(node->left, symbols);
+        pm_traverse(node->right, symbols);
+    }
+}
+bool build_package_merge(const uint32_t freq[256], std::vector<OptimalCode> *codes) {
+    int code_count = 0;
+    for (int i = 0; i < 256; i++) code_count += freq[i] != 0;
+    if (code_count == 0) return false;
+    Sym s[257];
+    int n = 0;
+    for (int i = 0; i < 256; i++)
+        if (freq[i] != 0) s[n++] = {(int64_t)freq[i], (int16_t)i, 0, 0};
+    s[n++] = {0, -1, 0, 0};
+    net_sort_symbols(s, n, [](const Sym &x, const Sym &y) { return y.frequency < x.frequency ? -1 : (y.frequency > x.frequency ? 1 : 0); });
+    std::vector<PmNode> pool;
+    pool.reserve((size_t)n * 40);
+    std::vector<const PmNode *> levels[16];
+    for (int l = 15; l >= 0; l--)
+        for (int i = 0; i < n; i++) {
+            pool.push_back(PmNode{s[i].frequency, (int16_t)i, nullptr, nullptr});
+            levels[l].push_back(&pool.back());
+        }
+    auto desc = [](const PmNode &x, const PmNode &y) { return y.frequency < x.frequency ? -1 : (y.frequency > x.frequency ? 1 : 0); };
+    auto asc = [](const PmNode &x, const PmNode &y) { return x.frequency < y.frequency ? -1 : (x.frequency > y.frequency ? 1 : 0); };
+    for (int l = 15; l > 0; l--) {
+        std::vector<const PmNode *> &nodes = levels[l];
+        net_sort<PmNode>(nodes, desc);
+        while (nodes.size() >= 2) {
+            const PmNode *n1 = nodes[nodes.size() - 1], *n2 = nodes[nodes.size() - 2];
+            nodes.resize(nodes.size() - 2);
+            pool.push_back(PmNode{n1->frequency + n2->frequency, 0, n1, n2});
+            levels[l - 1].push_back(&pool.back());
+        }
+    }
+    net_sort<PmNode>(levels[0], asc);
+    const int select = std::max(1, 2 * (n - 1));
+    for (int i = 0; i < select; i++) pm_traverse(levels[0][(size_t)i], s);
+    net_sort_symbols(s, n, [](const Sym &x, const Sym &y) {  // SymbolComparer (:430-453)
+        if (x.code_size > y.code_size) return 1;
+        if (x.code_size < y.code_size) return -1;
+        if (x.frequency > y.frequency) return -1;
+        if (x.frequency < y.frequency) return 1;
+        return 0;
+    });
+    int index = 0;
+    for (int i = n - 1; i >= 0; i--)
+        if (s[i].value == -1) {
+            index = i;
+            break;
+        }
+    for (int i = index; i < n - 1; i++) s[i] = s[i + 1];
+    codes->assign((size_t)code_count, OptimalCode{0, 0, 0});
+    for (int i = 0; i < code_count; i++) {
+        if (s[i].code_size > 16) return false;
+        (*codes)[i].symbol = (uint8_t)s[i].value;
+        (*codes)[i].length = (uint8_t)s[i].code_size;
+    }
+    assign_canonical_codes(*codes);
+    return true;
+}
 }  // namespace
 
-bool build_optimal_table(const uint32_t freq[256], std::vector<OptimalCode> *codes) {
+bool build_optimal_table(const uint32_t freq[256], std::vector<OptimalCode> *codes, bool most_optimal) {
+    if (most_optimal) return build_package_merge(freq, codes);
     int code_count = 0;
     for (int i = 0; i < 256; i++) code_count += freq[i] != 0;
     if (code_count == 0) return false;
@@ -185,7 +292,7 @@ bool build_optimal_table(const uint32_t freq[256], std::vector<OptimalCode> *cod
     }
     for (int i = 0; i < n; i++)
         if (s[i].value == -1) s[i].code_size = 0xFFFF;
-    NetSort::sort(s, n);
+    net_sort_symbols(s, n, [](const Sym &x, const Sym &y) { return x.code_size < y.code_size ? -1 : (x.code_size > y.code_size ? 1 : 0); });
     // BuildCanonicalCode (:237-283)
     codes->assign((size_t)code_count, OptimalCode{0, 0, 0});
     int length = 1, at = 0;
@@ -199,19 +306,7 @@ bool build_optimal_table(const uint32_t freq[256], std::vector<OptimalCode> *cod
         (*codes)[i].symbol = (uint8_t)s[i].value;
         (*codes)[i].length = (uint8_t)length;
     }
-    uint16_t code = 0;
-    int count = (*codes)[0].length;
-    for (int i = 1; i < code_count; i++) {
-        OptimalCode &c = (*codes)[i];
-        if (c.length > count) {
-            code++;
-            code = (uint16_t)(code << (c.length - count));
-            c.code = code;
-            count = c.length;
-        } else {
-            c.code = ++code;
-        }
-    }
+    assign_canonical_codes(*codes);
     return true;
 }
 
@@ -552,7 +647,7 @@ int OptimizeBatch::run() {
         for (int t = 0; t < job.n_huff; t++) {
             std::vector<OptimalCode> codes;
             const uint32_t *freq = &h_hist_[((size_t)p.job * kMaxHuffSlots + t) * 256];
-            if (!build_optimal_table(freq, &codes)) continue;  // a failing scan: reported from the device status below
+            if (!build_optimal_table(freq, &codes, most_optimal_)) continue;  // a failing scan: reported from the device status below
             EncHuffTable &et = enc[(size_t)p.job * kMaxHuffSlots + t];
             // GetCode(symbol) = codes[_symbolMap[symbol]], and _symbolMap is 0 for symbols without a code (JpegHuffmanEncodingTable.cs:18-33, 90-96)
             for (int sym = 0; sym < 256; sym++) {

@@ -16,7 +16,7 @@ struct OptimalCode {
     uint16_t code;
     uint8_t symbol, length;
 };
-bool build_optimal_table(const uint32_t freq[256], std::vector<OptimalCode> *codes);
+bool build_optimal_table(const uint32_t freq[256], std::vector<OptimalCode> *codes, bool most_optimal = false);  // Build(optimal)
 
 class OptimizeBatch {
   public:
@@ -32,6 +32,7 @@ class OptimizeBatch {
     // the statistics Scan() collected for table `t` of image i (builder-creation order); false past the last table
     bool statistics(int i, int t, uint8_t *table_class, uint8_t *identifier, uint32_t counts[256]) const;
     float last_ms() const { return last_ms_; }
+    void set_most_optimal_coding(bool on) { most_optimal_ = on; }  // JpegOptimizer.MostOptimalCoding
 
   private:
     // Optimize()'s output is a fixed sequence of pieces: bytes known on the host, the new DHT segment, the scan's data
@@ -64,6 +65,7 @@ class OptimizeBatch {
     std::vector<HuffWork> work_;
     std::vector<uint32_t> h_hist_;     // [jobs][8][256]
     bool ran_ = false;
+    bool most_optimal_ = false;
     float last_ms_ = 0;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     DevBuffer d_work_, d_scan_ids_, d_hist_, d_enc_, d_sizes_, d_offsets_, d_base_, d_totals_, d_out_;

@@ -42,7 +42,7 @@ class EncodeBatch:
             keep.append(a)
             ptrs[i] = a.ctypes.data
             h, w, c = a.shape
-            params[i] = _capi.EncodeParams(w, h, c, luma[0], luma[1], quality, 1 if rgb else 0, 1 if optimize_coding else 0)
+            params[i] = _capi.EncodeParams(w, h, c, luma[0], luma[1], quality, 1 if rgb else 0, int(optimize_coding))
             mcus = (-(-w // (8 * luma[0]))) * (-(-h // (8 * luma[1])))
             self._blocks.append(mcus * (luma[0] * luma[1] + (2 if c == 3 else 0)))
         self._check(_lib.jpgpu_encoder_upload(self._h, ptrs, params, n))

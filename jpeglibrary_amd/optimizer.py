@@ -27,6 +27,11 @@ class OptimizeBatch:
     def _check(self, rc):
         raise_for_status(rc, _lib.jpgpu_last_error(self.ctx._h))
 
+    def set_most_optimal_coding(self, on=True):
+        """JpegOptimizer.MostOptimalCoding"""
+        self._check(_lib.jpgpu_optimizer_set_most_optimal_coding(self._h, 1 if on else 0))
+        return self
+
     def upload(self, files, strip=True):
         n = len(files)
         ptrs = (C.c_void_p * n)()
@@ -92,24 +97,24 @@ class OptimizeBatch:
             pass
 
 
-def optimize_batch(files, strip=True, ctx=None):
+def optimize_batch(files, strip=True, ctx=None, most_optimal=False):
     """One-call helper: the optimized bytes of every file (raises on the first failing file)."""
-    b = OptimizeBatch(ctx).upload(files, strip).run()
+    b = OptimizeBatch(ctx).set_most_optimal_coding(most_optimal).upload(files, strip).run()
     try:
         return [b.output(i) for i in range(len(b))]
     finally:
         b.close()
 
 
-def build_optimal_huffman_table(counts):
-    """JpegHuffmanEncodingTableBuilder.Build(false) (host code of the optimizer path): (bits[16], values[n], code[256], length[256])."""
+def build_optimal_huffman_table(counts, most_optimal=False):
+    """JpegHuffmanEncodingTableBuilder.Build(most_optimal) (host code of the optimizer path): (bits[16], values[n], code[256], length[256])."""
     f = np.ascontiguousarray(counts, dtype=np.uint32).reshape(256)
     bits = np.zeros(16, np.uint8)
     values = np.zeros(256, np.uint8)
     code = np.zeros(256, np.uint16)
     length = np.zeros(256, np.uint8)
     n = C.c_int()
-    rc = _lib.jpgpu_build_optimal_huffman_table(f.ctypes.data, bits.ctypes.data, values.ctypes.data, C.byref(n), code.ctypes.data,
-                                                length.ctypes.data)
+    rc = _lib.jpgpu_build_optimal_huffman_table(f.ctypes.data, 1 if most_optimal else 0, bits.ctypes.data, values.ctypes.data, C.byref(n),
+                                                code.ctypes.data, length.ctypes.data)
     raise_for_status(rc, b"No symbol is recorded.")
     return bits, values[:n.value].copy(), code, length

@@ -404,8 +404,6 @@ static void gather_block(enc_component *c, const int16_t *block, uint32_t *dc_fr
     if (run > 0) ac_freq[0]++;
 }
 
-int jref_build_optimal_table(const uint32_t freq[256], uint8_t bits_out[16], uint8_t values_out[256], int *nvalues, uint16_t code_out[256],
-                             uint8_t length_out[256]);
 
 int jref_encode_8bit(const uint8_t *pixels, int width, int height, int components, int luma_h, int luma_v, int quality,
                      uint8_t *out, size_t cap, size_t *out_len, int16_t *coef_tap) {
@@ -527,7 +525,7 @@ int jref_encode_8bit_ex(const uint8_t *pixels, int width, int height, int compon
         for (int t = 0; t < 4; t++) { /* _huffmanTables.BuildTables: every builder of the collection, in SetHuffmanTable order */
             uint16_t code[256];
             uint8_t len[256];
-            if (jref_build_optimal_table(freq[t], o_bits[t], o_vals[t], &o_n[t], code, len) != 0) {
+            if (jref_build_optimal_table_ex(freq[t], optimize_coding == 2 /* MostOptimalCoding */, o_bits[t], o_vals[t], &o_n[t], code, len) != 0) {
                 free(store);
                 *out_len = 0;
                 return 2;

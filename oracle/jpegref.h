@@ -132,6 +132,10 @@ int jref_optimizer_statistics(const uint8_t *in, size_t len, uint8_t table_class
 int jref_build_optimal_table(const uint32_t freq[256], uint8_t bits_out[16], uint8_t values_out[256], int *nvalues,
                              uint16_t code_out[256], uint8_t length_out[256]);
 void jref_free(void *p);
+/* the same with JpegOptimizer.MostOptimalCoding / Build(optimal) = the package-merge builder (:289-497) */
+int jref_optimize_ex(const uint8_t *in, size_t len, int strip, int most_optimal, uint8_t **out, size_t *out_len, char *err, size_t err_cap);
+int jref_build_optimal_table_ex(const uint32_t freq[256], int most_optimal, uint8_t bits_out[16], uint8_t values_out[256], int *nvalues,
+                                uint16_t code_out[256], uint8_t length_out[256]);
 
 #ifdef __cplusplus
 }

@@ -240,7 +240,7 @@ def encode_8bit(pixels: np.ndarray, luma_h: int = 2, luma_v: int = 2, quality: i
     cap = 1024 + w * h * c * 2 + nblocks * 8
     out = np.empty(cap, np.uint8)
     n = C.c_size_t(0)
-    rc = L.jref_encode_8bit_ex(a.ctypes.data, w, h, c, luma_h, luma_v, quality, 1 if optimize_coding else 0, out.ctypes.data, cap, C.byref(n),
+    rc = L.jref_encode_8bit_ex(a.ctypes.data, w, h, c, luma_h, luma_v, quality, int(optimize_coding), out.ctypes.data, cap, C.byref(n),
                                coefs.ctypes.data if coefs is not None else None)
     if rc == 2:
         raise OracleError(2, "No symbol is recorded.")
@@ -307,18 +307,18 @@ def build_huffman(bits, values):
 
 
 # ---------------------------------------------------------------------------------------------- JpegOptimizer restatement
-def optimize(data: bytes, strip: bool = True) -> bytes:
+def optimize(data: bytes, strip: bool = True, most_optimal: bool = False) -> bytes:
     """new JpegOptimizer(): SetInput(data); Scan(); SetOutput(buffer); Optimize(strip) -> the written bytes.
     Raises OracleError(code, message) where the reference throws."""
     L = lib()
-    L.jref_optimize.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
-    L.jref_optimize.restype = C.c_int
+    L.jref_optimize_ex.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+    L.jref_optimize_ex.restype = C.c_int
     L.jref_free.argtypes = [C.c_void_p]
     L.jref_free.restype = None
     out = C.c_void_p()
     n = C.c_size_t(0)
     err = C.create_string_buffer(256)
-    rc = L.jref_optimize(data, len(data), 1 if strip else 0, C.byref(out), C.byref(n), err, 256)
+    rc = L.jref_optimize_ex(data, len(data), 1 if strip else 0, 1 if most_optimal else 0, C.byref(out), C.byref(n), err, 256)
     if rc != 0:
         raise OracleError(rc, err.value.decode("utf-8", "replace"))
     try:
@@ -344,18 +344,19 @@ def optimizer_statistics(data: bytes):
     return [(int(cls[i]), int(ident[i]), freq[i].copy()) for i in range(n.value)]
 
 
-def build_optimal_table(freq: np.ndarray):
-    """JpegHuffmanEncodingTableBuilder.Build(false): (bits[16], values[n], code[256], length[256])."""
+def build_optimal_table(freq: np.ndarray, most_optimal: bool = False):
+    """JpegHuffmanEncodingTableBuilder.Build(most_optimal): (bits[16], values[n], code[256], length[256])."""
     L = lib()
-    L.jref_build_optimal_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
-    L.jref_build_optimal_table.restype = C.c_int
+    L.jref_build_optimal_table_ex.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+    L.jref_build_optimal_table_ex.restype = C.c_int
     f = np.ascontiguousarray(freq, dtype=np.uint32).reshape(256)
     bits = np.zeros(16, np.uint8)
     values = np.zeros(256, np.uint8)
     code = np.zeros(256, np.uint16)
     length = np.zeros(256, np.uint8)
     n = C.c_int(0)
-    rc = L.jref_build_optimal_table(f.ctypes.data, bits.ctypes.data, values.ctypes.data, C.byref(n), code.ctypes.data, length.ctypes.data)
+    rc = L.jref_build_optimal_table_ex(f.ctypes.data, 1 if most_optimal else 0, bits.ctypes.data, values.ctypes.data, C.byref(n), code.ctypes.data,
+                                       length.ctypes.data)
     if rc != 0:
         raise OracleError(4, "No symbol is recorded." if rc == -1 else "code size outside the reference's array")
     return bits, values[:n.value].copy(), code, length

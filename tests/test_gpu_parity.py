@@ -930,3 +930,19 @@ def test_optimizer_random_corruptions_follow_the_reference(variant):
     b.close()
     assert compared > 100
     assert not mismatches, mismatches[:10]
+
+
+def test_most_optimal_coding_optimizer_and_encoder():
+    """MostOptimalCoding (the package-merge table builder) through both callers: JpegOptimizer and JpegEncoder."""
+    files = _optimizer_files()[:5]
+    b = jl.OptimizeBatch().set_most_optimal_coding(True).upload(files, False).run()
+    for i, f in enumerate(files):
+        assert b.output(i) == po.optimize(f, False, most_optimal=True), i
+    b.close()
+    rng = np.random.default_rng(12)
+    imgs = [rng.integers(0, 256, (70, 100, 3)).astype(np.uint8), (rng.integers(0, 64, (45, 61, 3)) * 3).astype(np.uint8)]
+    for luma in ((2, 2), (1, 1)):
+        e = jl.EncodeBatch().upload(imgs, luma, 80, optimize_coding=2).encode()
+        for k, im in enumerate(imgs):
+            assert e.output(k) == po.encode_8bit(im, luma[0], luma[1], 80, optimize_coding=2), (luma, k)
+        e.close()

@@ -99,6 +99,13 @@ def test_table_builder_of_the_product_matches_the_restatement(seed):
     bits, values, code, length = po.build_optimal_table(freq)
     b2, v2, c2, l2 = jl.build_optimal_huffman_table(freq)
     assert np.array_equal(bits, b2) and np.array_equal(values, v2) and np.array_equal(code, c2) and np.array_equal(length, l2)
+    # MostOptimalCoding (package merge): product == restatement, never costlier than a 16-bit-limited code has to be
+    pb, pv, pc, pl = po.build_optimal_table(freq, most_optimal=True)
+    qb, qv, qc, ql = jl.build_optimal_huffman_table(freq, most_optimal=True)
+    assert np.array_equal(pb, qb) and np.array_equal(pv, qv) and np.array_equal(pc, qc) and np.array_equal(pl, ql)
+    assert pl[symbols].max() <= 16 and sum(int(pb[l - 1]) * 2.0 ** -l for l in range(1, 17)) < 1.0
+    if n > 1:
+        assert int((freq[symbols].astype(np.int64) * pl[symbols]).sum()) <= int((freq[symbols].astype(np.int64) * length[symbols]).sum())
     # a prefix code of at most 16 bits that never uses the all-ones code word
     assert bits.sum() == n and set(values.tolist()) == set(symbols.tolist())
     kraft = sum(int(bits[l - 1]) * 2.0 ** -l for l in range(1, 17))
@@ -117,6 +124,14 @@ def test_length_limiting_kicks_in_for_fibonacci_counts():
     assert length[:40].max() == 16 and bits.sum() == 40
     b2, v2, c2, l2 = jl.build_optimal_huffman_table(freq)
     assert np.array_equal(bits, b2) and np.array_equal(values, v2) and np.array_equal(length, l2)
+
+
+def test_most_optimal_coding_on_the_reference_asset():
+    data = read("lake.jpg")
+    std = po.optimize(data, True)
+    best = po.optimize(data, True, most_optimal=True)
+    assert len(best) <= len(std) < len(data)
+    assert np.array_equal(pillow_pixels(data), pillow_pixels(best))
 
 
 def test_errors_of_the_restatement():
