@@ -9,9 +9,8 @@
 // device-resident scan data at download time.
 //
 // Fences (reported as JPGPU_ERR_NOT_SUPPORTED): files with more than one scan (the reference builds its tables from the
-// LAST scan only, :462, and then fails or writes garbage for the others), progressive frames (:580-582), a DRI whose value
-// at the scan differs from the last DRI of the file (the decoder-side parser shared here latches the last one),
-// MostOptimalCoding (package merge).  Parity of the bytes is unpinned (the reference holds no golden bytes, and
+// LAST scan only, :462, and then fails or writes garbage for the others), progressive frames (:580-582), a restart interval
+// that changes between the frame header and the scan or after the scan.  Parity of the bytes is unpinned (the reference holds no golden bytes, and
 // .NET's unstable sort decides the order of equal-length symbols in the DHT).
 #include "device_optimize.h"
 
