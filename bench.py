@@ -258,6 +258,20 @@ def main():
             },
             "host": {"gen_s": round(t_gen, 1), "parse_upload_s": round(t_upload, 2), "cpu_count": cpu},
         }
+        # D2H of the pixels: reported, never part of `value`; a bounded sample of the images, pageable host memory
+        try:
+            n_d2h = min(n_images, 16)
+            t_d = time.perf_counter()
+            nbytes = 0
+            for i in range(n_d2h):
+                o = batch.output(i)
+                nbytes += sum(p.nbytes for p in o) if isinstance(o, list) else o.nbytes
+            t_d = time.perf_counter() - t_d
+            out["host"]["d2h_GBps"] = round(nbytes / t_d / 1e9, 2)
+            out["host"]["d2h_sample"] = f"{n_d2h} images, {nbytes / 1e6:.0f} MB"
+        except Exception as e:  # pragma: no cover
+            out["host"]["d2h_GBps"] = None
+            out["host"]["d2h_error"] = str(e)[:80]
         # spot check after timing: a few images bit-exact against the oracle (checker only)
         try:
             from oracle import pyoracle as po
