@@ -627,6 +627,22 @@ int DeviceBatch::run_huffman() {
     }
     return run_progressive();
 }
+// The synchronisation of the DRI = 0 scans alone (optimizer path): converged exit states + first block of every subsequence.
+int DeviceBatch::run_subseq_sync(const uint32_t **final_state, const uint32_t **first_block) {
+    *final_state = (const uint32_t *)d_sub_exit_a_.ptr;
+    *first_block = (const uint32_t *)d_sub_first_.ptr;
+    if (n_sub_work_ <= 0) return JPGPU_OK;
+    status_valid_ = false;
+    hipError_t e = launch_subseq_sync(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_sub_work_.ptr,
+                                      n_sub_work_, (const uint32_t *)d_sub_scan_ids_.ptr, n_sub_scans_, (const uint32_t *)d_ends_u_.ptr,
+                                      (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (uint32_t *)d_sub_exit_a_.ptr,
+                                      (uint32_t *)d_sub_exit_b_.ptr, (uint32_t *)d_sub_nblk_.ptr, (uint32_t *)d_sub_first_.ptr,
+                                      (uint32_t *)d_sub_entry_.ptr, d_sub_dcsum_.ptr, d_sub_dcentry_.ptr, (uint32_t *)d_sub_changed_.ptr,
+                                      n_huff_slots_, (int)max_subs_per_scan_ + 2, &last_subseq_rounds_, (const uint32_t *)d_lut_pool_.ptr,
+                                      final_state);
+    if (e != hipSuccess) return hip_fail(e, "subsequence synchronisation");
+    return JPGPU_OK;
+}
 int DeviceBatch::run_progressive() {
     if (prog_begin_.size() <= 1) return JPGPU_OK;
     status_valid_ = false;

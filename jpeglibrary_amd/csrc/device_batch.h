@@ -60,6 +60,7 @@ class DeviceBatch {
 
     int run_marker_index();
     int run_huffman();
+    int run_subseq_sync(const uint32_t **final_state, const uint32_t **first_block);  // K2S rounds + prefix sums only
     int run_idct();
     int run_progressive();     // entropy scans of progressive frames (K2P), ordinal by ordinal
     int run_huffman_tokens();  // token pipeline (K2T)

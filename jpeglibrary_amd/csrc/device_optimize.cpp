@@ -311,7 +311,10 @@ bool build_optimal_table(const uint32_t freq[256], std::vector<OptimalCode> *cod
 
 // ------------------------------------------------------------------------------------------------ batch
 OptimizeBatch::~OptimizeBatch() {
-    for (DevBuffer *b : {&d_work_, &d_scan_ids_, &d_hist_, &d_enc_, &d_sizes_, &d_offsets_, &d_base_, &d_totals_, &d_out_}) b->release();
+    for (DevBuffer *b : {&d_work_, &d_scan_ids_, &d_hist_, &d_enc_, &d_sizes_, &d_offsets_, &d_base_, &d_totals_, &d_out_, &d_sub_work_,
+                         &d_sub_scan_ids_, &d_sub_bits_, &d_sub_bitoff_, &d_sub_totals_, &d_scan_raw_off_, &d_raw_, &d_simages_, &d_swork_chunk_,
+                         &d_chunk_ff_, &d_sout_, &d_sout_len_})
+        b->release();
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
 }
@@ -554,6 +557,8 @@ int OptimizeBatch::upload(const uint8_t *const *jpeg, const size_t *len, int n, 
     if (rc != JPGPU_OK) return rc;
     scan_ids_.clear();
     work_.clear();
+    sub_scan_ids_.clear();
+    sub_work_.clear();
     for (int i = 0; i < n; i++) {
         Plan &p = plans_[i];
         if (p.status != JPGPU_OK) continue;
@@ -579,8 +584,14 @@ int OptimizeBatch::upload(const uint8_t *const *jpeg, const size_t *len, int n, 
             p.job = -1;
             continue;
         }
-        scan_ids_.push_back((uint32_t)p.job);
-        for (uint32_t first = 0; first < s.n_intervals; first += 256) work_.push_back({(uint32_t)p.job, first});
+        p.by_subsequence = s.n_subs != 0;  // the batch marks DRI = 0 scans for the self-synchronising subsequence machinery
+        if (p.by_subsequence) {
+            sub_scan_ids_.push_back((uint32_t)p.job);
+            for (uint32_t first = 0; first < s.n_subs; first += 256) sub_work_.push_back({(uint32_t)p.job, first});
+        } else {
+            scan_ids_.push_back((uint32_t)p.job);
+            for (uint32_t first = 0; first < s.n_intervals; first += 256) work_.push_back({(uint32_t)p.job, first});
+        }
     }
     struct Up {
         DevBuffer *buf;
@@ -597,6 +608,14 @@ int OptimizeBatch::upload(const uint8_t *const *jpeg, const size_t *len, int n, 
         {&d_offsets_, nullptr, 0, (size_t)batch_.total_ends_ * sizeof(uint64_t) + 256},
         {&d_base_, nullptr, 0, scan_ids_.size() * sizeof(uint64_t) + 256},
         {&d_totals_, nullptr, 0, scan_ids_.size() * sizeof(uint64_t) + 256},
+        {&d_sub_work_, sub_work_.data(), sub_work_.size() * sizeof(HuffWork), 0},
+        {&d_sub_scan_ids_, sub_scan_ids_.data(), sub_scan_ids_.size() * sizeof(uint32_t), 0},
+        {&d_sub_bits_, nullptr, 0, (size_t)batch_.total_subs_ * sizeof(uint32_t) + 256},
+        {&d_sub_bitoff_, nullptr, 0, (size_t)batch_.total_subs_ * sizeof(uint64_t) + 256},
+        {&d_sub_totals_, nullptr, 0, sub_scan_ids_.size() * sizeof(uint64_t) + 256},
+        {&d_scan_raw_off_, nullptr, 0, n_jobs * sizeof(uint64_t) + 256},
+        {&d_simages_, nullptr, 0, sub_scan_ids_.size() * sizeof(DevEncImage) + 256},
+        {&d_sout_len_, nullptr, 0, sub_scan_ids_.size() * sizeof(uint64_t) + 256},
     };
     for (const Up &u : ups) {
         hipError_t e = u.buf->reserve(std::max(u.bytes, u.reserve));
@@ -631,6 +650,16 @@ int OptimizeBatch::run() {
     e = launch_transcode(ctx_->stream, 0, udata, input, scans, (const HuffWork *)d_work_.ptr, n_work, ends_u, ends_raw, status, pool,
                          (uint32_t *)d_hist_.ptr, nullptr, nullptr, nullptr, nullptr, n_slots);
     if (e != hipSuccess) return hip_fail(e, "transcode_kernel<count>");
+    // scans without restart intervals: the decoder's self-synchronising subsequences, then the same three passes per subsequence
+    const int n_sub_work = (int)sub_work_.size(), n_sub_scans = (int)sub_scan_ids_.size();
+    const uint32_t *exit_state = nullptr, *first_block = nullptr;
+    if (n_sub_scans) {
+        rc = batch_.run_subseq_sync(&exit_state, &first_block);
+        if (rc != JPGPU_OK) return rc;
+        e = launch_subseq_transcode(ctx_->stream, 0, udata, scans, (const HuffWork *)d_sub_work_.ptr, n_sub_work, ends_u, status, pool, exit_state,
+                                    first_block, (uint32_t *)d_hist_.ptr, nullptr, nullptr, nullptr, nullptr, nullptr, n_slots);
+        if (e != hipSuccess) return hip_fail(e, "subseq_transcode_kernel<count>");
+    }
     h_hist_.assign(n_jobs * kMaxHuffSlots * 256, 0);
     e = hipMemcpyAsync(h_hist_.data(), d_hist_.ptr, h_hist_.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(histograms)");
@@ -685,6 +714,18 @@ int OptimizeBatch::run() {
         e = hipMemcpyAsync(totals.data(), d_totals_.ptr, totals.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx_->stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(totals)");
     }
+    std::vector<uint64_t> sub_total_bits((size_t)n_sub_scans);
+    if (n_sub_scans) {
+        e = launch_subseq_transcode(ctx_->stream, 1, udata, scans, (const HuffWork *)d_sub_work_.ptr, n_sub_work, ends_u, status, pool, exit_state,
+                                    first_block, nullptr, (const EncHuffTable *)d_enc_.ptr, (uint32_t *)d_sub_bits_.ptr, nullptr, nullptr, nullptr,
+                                    n_slots);
+        if (e != hipSuccess) return hip_fail(e, "subseq_transcode_kernel<measure>");
+        e = launch_subseq_bit_offsets(ctx_->stream, scans, (const uint32_t *)d_sub_scan_ids_.ptr, n_sub_scans, (const uint32_t *)d_sub_bits_.ptr,
+                                      (uint64_t *)d_sub_bitoff_.ptr, (uint64_t *)d_sub_totals_.ptr);
+        if (e != hipSuccess) return hip_fail(e, "subseq_bit_offsets_kernel");
+        e = hipMemcpyAsync(sub_total_bits.data(), d_sub_totals_.ptr, sub_total_bits.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(bit totals)");
+    }
     e = hipStreamSynchronize(ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
     uint64_t out_bytes = 0;
@@ -704,16 +745,70 @@ int OptimizeBatch::run() {
     e = launch_transcode(ctx_->stream, 2, udata, input, scans, (const HuffWork *)d_work_.ptr, n_work, ends_u, ends_raw, status, pool, nullptr,
                          (const EncHuffTable *)d_enc_.ptr, (uint32_t *)d_sizes_.ptr, (const uint64_t *)d_offsets_.ptr, (uint8_t *)d_out_.ptr, n_slots);
     if (e != hipSuccess) return hip_fail(e, "transcode_kernel<emit>");
+    std::vector<DevEncImage> simages((size_t)n_sub_scans);
+    std::vector<uint64_t> sout_len((size_t)n_sub_scans);
+    if (n_sub_scans) {
+        // raw (unstuffed) bit buffers + the encoder's stuffing stage (E4): descriptors in the encoder's image form
+        std::vector<uint64_t> scan_raw_off(n_jobs, 0);
+        std::vector<EncWork> work_chunk;
+        uint64_t raw_off = 0, out_off = 0;
+        uint32_t chunk_off = 0;
+        memset(simages.data(), 0, simages.size() * sizeof(DevEncImage));
+        for (int k2 = 0; k2 < n_sub_scans; k2++) {
+            const uint64_t raw_len = (sub_total_bits[k2] + 7) / 8;
+            DevEncImage &im = simages[k2];
+            im.raw_off = raw_off;
+            im.out_off = out_off;
+            im.chunk_off = chunk_off;
+            im.header_len = 0;
+            scan_raw_off[sub_scan_ids_[k2]] = raw_off;
+            const uint32_t chunks = std::max<uint32_t>(1u, (uint32_t)((raw_len + kEncStuffChunk - 1) / kEncStuffChunk));
+            for (uint32_t c = 0; c < chunks; c++) work_chunk.push_back({(uint32_t)k2, c});
+            chunk_off += chunks;
+            raw_off = (raw_off + raw_len + 64 + 255) & ~(uint64_t)255;
+            out_off = (out_off + 2 * raw_len + 2 + 64 + 255) & ~(uint64_t)255;  // every byte may need stuffing
+        }
+        const struct {
+            DevBuffer *buf;
+            size_t bytes;
+        } grow[] = {{&d_raw_, (size_t)raw_off + 256}, {&d_sout_, (size_t)out_off + 256}, {&d_chunk_ff_, (size_t)chunk_off * sizeof(uint32_t) + 256},
+                    {&d_swork_chunk_, work_chunk.size() * sizeof(EncWork) + 16}};
+        for (const auto &g : grow) {
+            e = g.buf->reserve(g.bytes);
+            if (e != hipSuccess) return hip_fail(e, "hipMalloc(optimizer raw buffers)");
+        }
+        e = hipMemsetAsync(d_raw_.ptr, 0, (size_t)raw_off + 256, ctx_->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_scan_raw_off_.ptr, scan_raw_off.data(), scan_raw_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx_->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_simages_.ptr, simages.data(), simages.size() * sizeof(DevEncImage), hipMemcpyHostToDevice, ctx_->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_swork_chunk_.ptr, work_chunk.data(), work_chunk.size() * sizeof(EncWork), hipMemcpyHostToDevice, ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(optimizer raw descriptors)");
+        e = launch_subseq_transcode(ctx_->stream, 2, udata, scans, (const HuffWork *)d_sub_work_.ptr, n_sub_work, ends_u, status, pool, exit_state,
+                                    first_block, nullptr, (const EncHuffTable *)d_enc_.ptr, (uint32_t *)d_sub_bits_.ptr,
+                                    (const uint64_t *)d_sub_bitoff_.ptr, (const uint64_t *)d_scan_raw_off_.ptr, (uint8_t *)d_raw_.ptr, n_slots);
+        if (e != hipSuccess) return hip_fail(e, "subseq_transcode_kernel<emit>");
+        e = launch_stuff(ctx_->stream, (const DevEncImage *)d_simages_.ptr, (const EncWork *)d_swork_chunk_.ptr, (int)work_chunk.size(),
+                         (const uint64_t *)d_sub_totals_.ptr, (const uint8_t *)d_raw_.ptr, (uint32_t *)d_chunk_ff_.ptr, (uint8_t *)d_sout_.ptr,
+                         (uint64_t *)d_sout_len_.ptr);
+        if (e != hipSuccess) return hip_fail(e, "stuff kernels");
+        e = hipMemcpyAsync(sout_len.data(), d_sout_len_.ptr, sout_len.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(stuffed lengths)");
+    }
     (void)hipEventRecord(ev1_, ctx_->stream);
     e = hipStreamSynchronize(ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
     (void)hipEventElapsedTime(&last_ms_, ev0_, ev1_);
-    int k = 0;
+    int k = 0, ks = 0;
     for (Plan &p : plans_) {
         if (p.status != JPGPU_OK || p.job < 0) continue;
-        p.entropy_off = base[k];
-        p.entropy_len = totals[k];
-        k++;
+        if (p.by_subsequence) {
+            p.entropy_off = simages[ks].out_off;
+            p.entropy_len = sout_len[ks] >= 2 ? sout_len[ks] - 2 : 0;  // the stuffing stage closes with EOI: that belongs to the host pieces here
+            ks++;
+        } else {
+            p.entropy_off = base[k];
+            p.entropy_len = totals[k];
+            k++;
+        }
         p.out_len = 0;
         for (const Piece &pc : p.pieces)
             p.out_len += pc.kind == Piece::kBytes ? pc.bytes.size() : (pc.kind == Piece::kHuffmanTables ? p.dht.size() : p.entropy_len);
@@ -773,7 +868,8 @@ int OptimizeBatch::download(int i, void *dst, size_t cap) {
             memcpy(o, p.dht.data(), p.dht.size());
             o += p.dht.size();
         } else if (p.entropy_len) {
-            hipError_t e = hipMemcpy(o, (const uint8_t *)d_out_.ptr + p.entropy_off, (size_t)p.entropy_len, hipMemcpyDeviceToHost);
+            const uint8_t *src = (const uint8_t *)(p.by_subsequence ? d_sout_.ptr : d_out_.ptr) + p.entropy_off;
+            hipError_t e = hipMemcpy(o, src, (size_t)p.entropy_len, hipMemcpyDeviceToHost);
             if (e != hipSuccess) return hip_fail(e, "hipMemcpy(optimizer output)");
             o += p.entropy_len;
         }

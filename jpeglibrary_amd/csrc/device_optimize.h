@@ -52,6 +52,7 @@ class OptimizeBatch {
         int job = -1;  // scan job inside batch_
         std::string dht;  // the rewritten DHT segment (marker, length, tables)
         uint64_t entropy_off = 0, entropy_len = 0;
+        bool by_subsequence = false;  // DRI = 0 scan: transcoded by subsequence (KTS), bytes in d_sout_
         uint64_t out_len = 0;
     };
     int fail(int status, const std::string &msg);
@@ -61,14 +62,19 @@ class OptimizeBatch {
     jpgpu_ctx *ctx_;
     DeviceBatch batch_;
     std::vector<Plan> plans_;
-    std::vector<uint32_t> scan_ids_;   // jobs that are transcoded
+    std::vector<uint32_t> scan_ids_;   // jobs that are transcoded, one lane per restart interval ...
     std::vector<HuffWork> work_;
+    std::vector<uint32_t> sub_scan_ids_;  // ... and the DRI = 0 jobs transcoded by subsequence
+    std::vector<HuffWork> sub_work_;
     std::vector<uint32_t> h_hist_;     // [jobs][8][256]
     bool ran_ = false;
     bool most_optimal_ = false;
     float last_ms_ = 0;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     DevBuffer d_work_, d_scan_ids_, d_hist_, d_enc_, d_sizes_, d_offsets_, d_base_, d_totals_, d_out_;
+    // subsequence path: bit counts / offsets per subsequence, raw (unstuffed) bits, the encoder's stuffing stage
+    DevBuffer d_sub_work_, d_sub_scan_ids_, d_sub_bits_, d_sub_bitoff_, d_sub_totals_, d_scan_raw_off_, d_raw_, d_simages_, d_swork_chunk_,
+        d_chunk_ff_, d_sout_, d_sout_len_;
 };
 
 }  // namespace jpgpu

@@ -67,4 +67,16 @@ hipError_t launch_transcode(hipStream_t stream, int mode, const uint8_t *udata, 
                             const uint64_t *offsets, uint8_t *out, int n_slots);
 hipError_t launch_transcode_offsets(hipStream_t stream, const DevScan *scans, const uint32_t *scan_ids, int n_scans, const uint32_t *sizes,
                                     const uint64_t *base, uint64_t *offsets, uint64_t *totals);
+// K2S synchronisation alone + KTS: transcode of DRI = 0 scans by subsequence (kernels.hip)
+hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
+                              const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
+                              const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
+                              uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int n_slots, int max_rounds,
+                              int *rounds_used, const uint32_t *lut_pool, const uint32_t **final_state_out);
+hipError_t launch_subseq_transcode(hipStream_t stream, int mode, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
+                                   const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, const uint32_t *exit_state,
+                                   const uint32_t *first_block, uint32_t *hist, const EncHuffTable *enc, uint32_t *sub_bits,
+                                   const uint64_t *sub_bitoff, const uint64_t *scan_raw_off, uint8_t *raw, int n_slots);
+hipError_t launch_subseq_bit_offsets(hipStream_t stream, const DevScan *scans, const uint32_t *scan_ids, int n_scans, const uint32_t *sub_bits,
+                                     uint64_t *bitoff, uint64_t *totals);
 }  // namespace jpgpu

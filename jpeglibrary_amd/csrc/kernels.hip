@@ -3359,13 +3359,15 @@ hipError_t launch_progressive_streams(hipStream_t stream, const uint8_t *udata, 
 
 // DRI = 0 scans: self-synchronising subsequence decode.  `work` lists (scan, first subsequence) per workgroup of 256 lanes;
 // `scan_ids` the scans concerned.  Runs synchronisation rounds until no exit state changes (host-checked flag).
-hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
-                                const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
-                                const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
-                                uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
-                                int max_rounds, int *rounds_used, const uint32_t *lut_pool) {
+// The synchronisation part alone (rounds until the exit states stop changing, then the block / DC prefix sums); leaves the
+// converged exit states in *final_state.  Shared by the decoder (subseq_final_kernel) and the optimizer (subseq_transcode_kernel).
+hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
+                              const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
+                              const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
+                              uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int n_slots, int max_rounds,
+                              int *rounds_used, const uint32_t *lut_pool, const uint32_t **final_state_out) {
+    *final_state_out = exit_a;
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
-    const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kMaxBlocksPerMcu * sizeof(uint32_t);
     const size_t lds_round = ((size_t)n_slots << (kSrLutBits + 2)) + (size_t)n_slots * kK2SmallBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
 
     uint32_t *bufs[2] = {exit_a, exit_b};
@@ -3397,9 +3399,24 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
         }
     }
     if (rounds_used) *rounds_used = round;
-    const uint32_t *final_state = bufs[(round + 1) & 1];  // buffer written by the last round executed
+    *final_state_out = bufs[(round + 1) & 1];  // buffer written by the last round executed
     hipLaunchKernelGGL(subseq_scan_kernel, dim3(n_scans), dim3(1024), 0, stream, scans, scan_ids, nblk, first_block, (const int4 *)dcsum,
                        (int4 *)dc_entry);
+    return hipGetLastError();
+}
+
+hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
+                                const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
+                                const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
+                                uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
+                                int max_rounds, int *rounds_used, const uint32_t *lut_pool) {
+    if (n_work <= 0 || n_scans <= 0) return hipSuccess;
+    const uint32_t *final_state = nullptr;
+    hipError_t e = launch_subseq_sync(stream, udata, scans, work, n_work, scan_ids, n_scans, ends_u, status, huff_pool, exit_a, exit_b, nblk,
+                                      first_block, entry_used, dcsum, dc_entry, changed_dev, n_slots, max_rounds, rounds_used, lut_pool,
+                                      &final_state);
+    if (e != hipSuccess) return e;
+    const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kMaxBlocksPerMcu * sizeof(uint32_t);
     const size_t lds_final = lds + (size_t)kSubFinalWaves * (8192 + 64 * 2 * sizeof(uint32_t));
     hipLaunchKernelGGL(subseq_final_kernel, dim3(n_work), dim3(64 * kSubFinalWaves), lds_final, stream, udata, scans, work, ends_u, status,
                        huff_pool, final_state, first_block, (const int4 *)dc_entry, coefs, n_slots);
@@ -3713,6 +3730,243 @@ hipError_t launch_transcode_offsets(hipStream_t stream, const DevScan *scans, co
                                     const uint64_t *base, uint64_t *offsets, uint64_t *totals) {
     if (n_scans <= 0) return hipSuccess;
     hipLaunchKernelGGL(transcode_offsets_kernel, dim3(n_scans), dim3(1024), 0, stream, scans, scan_ids, sizes, base, offsets, totals);
+    return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// KTS: the transcode of scans WITHOUT restart intervals.  One lane per restart interval leaves a DRI = 0 scan to a single
+// lane; instead the scan is cut into the decoder's self-synchronising subsequences (K2S: launch_subseq_sync), and lane i
+// transcodes the WHOLE blocks that start inside subsequence i (block-aligned ownership, as subseq_final_kernel).  The
+// output of a lane is no longer byte aligned: MODE 1 measures bits, an exclusive scan gives bit offsets, MODE 2 ORs the
+// code words into a zeroed raw buffer (as the encoder's emit_kernel) and the encoder's stuffing kernels turn that into
+// the final bytes.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void subseq_transcode_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+                                                                const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
+                                                                DevScanStatus *__restrict__ status,
+                                                                const DevHuffTable *__restrict__ huff_pool,
+                                                                const uint32_t *__restrict__ exit_state,
+                                                                const uint32_t *__restrict__ first_block, uint32_t *__restrict__ hist,
+                                                                const EncHuffTable *__restrict__ enc, uint32_t *__restrict__ sub_bits,
+                                                                const uint64_t *__restrict__ sub_bitoff,
+                                                                const uint64_t *__restrict__ scan_raw_off, uint8_t *__restrict__ raw,
+                                                                int n_slots) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *tabs = smem;
+    uint32_t *blk_info = reinterpret_cast<uint32_t *>(smem + (size_t)n_slots * sizeof(DevHuffTable));
+    uint8_t *extra = reinterpret_cast<uint8_t *>(blk_info + kMaxBlocksPerMcu);  // MODE 0: hist[8][256] u32; else EncHuffTable[8]
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(extra);
+    const EncHuffTable *lenc = reinterpret_cast<const EncHuffTable *>(extra);
+    const HuffWork wk = work[blockIdx.x];
+    const DevScan &s = scans[wk.scan];
+    const uint32_t tid = threadIdx.x;
+    if (MODE == 0) {
+        for (uint32_t i = tid; i < kMaxHuffSlots * 256u; i += 256u) lhist[i] = 0;
+    } else {
+        const uint4 *src = reinterpret_cast<const uint4 *>(enc + (size_t)wk.scan * kMaxHuffSlots);
+        uint4 *dst = reinterpret_cast<uint4 *>(extra);
+        for (uint32_t i = tid; i < kMaxHuffSlots * sizeof(EncHuffTable) / 16; i += 256u) dst[i] = src[i];
+    }
+    sub_stage_tables(s, huff_pool, tabs, blk_info, n_slots, 256);  // ends with a barrier
+    const DevScanStatus st = status[wk.scan];
+    const uint32_t ulen = ends_u[s.ends_off];
+    const uint32_t total_bits = ulen * 8;
+    const uint32_t sub = wk.first_interval + tid;
+    const uint32_t slot = s.sub_off + (sub < s.n_subs ? sub : 0);
+    const uint32_t total_blocks = s.total_mcus * s.blocks_per_mcu;
+    const uint32_t bpm = s.blocks_per_mcu;
+    const bool closed_by_marker = st.terminator != 0;
+    constexpr uint32_t kSlot16 = (uint32_t)(sizeof(DevHuffTable) / 16);
+
+    bool live = sub < s.n_subs && st.n_ends != 0;
+    uint32_t entry = 0;
+    if (live && sub > 0) {
+        const uint32_t prev = exit_state[slot - 1];
+        if (prev & kSubBad) live = false;  // the stream ended or failed in an earlier subsequence: reported by that lane
+        else entry = prev;
+    }
+    uint32_t b_in_mcu = (entry >> 6) & 31u, k = (entry >> 11) & 127u;
+    uint32_t my_first = total_blocks, my_end = total_blocks;
+    if (live) {
+        my_first = first_block[slot] + (k != 0 ? 1u : 0u);
+        if (sub + 1 < s.n_subs) {
+            const uint32_t ex = exit_state[slot];
+            if (!(ex & kSubBad)) my_end = first_block[slot + 1] + ((((ex >> 11) & 127u) != 0) ? 1u : 0u);
+        }
+        if (my_end > total_blocks) my_end = total_blocks;  // the reference stops after the last MCU
+        if (my_first > my_end) my_first = my_end;
+    }
+    uint32_t count = my_end - my_first;
+    // emit: a lane that failed in the measure pass owns no bits of the output (its size is 0): it must not write
+    if (MODE == 2 && live && sub_bits[slot] == 0) count = 0;
+    uint32_t err = 0;
+    uint32_t nbits = 0;  // bits this lane produces
+    if (live && count != 0) {
+        UBits r;
+        const uint32_t start_bit = sub * kSubBits + (entry & 63u);
+        ub_init(r, udata + s.data_off, start_bit >> 3, (total_bits + 7) >> 3);
+        if (start_bit & 7u) ub_consume(r, start_bit & 7u);
+        r.rem = (int32_t)total_bits - (int32_t)start_bit;
+        uint32_t info = blk_info[b_in_mcu];
+        // the tail of the block the previous lane owns: parsed, not transcoded
+        while (k != 0 && err == 0) {
+            const LdsHuff h = lds_huff16(tabs, (info >> 12) & 0xFFF);
+            uint32_t sym;
+            int32_t v;
+            err = ub_symbol(r, h, false, closed_by_marker, sym, v);
+            const uint32_t rr = sym >> 4;
+            k = (sym & 15u) != 0 ? k + rr + 1u : (rr == 0 ? 64u : k + 16u);
+            if (k >= 64u) {
+                k = 0;
+                b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
+                info = blk_info[b_in_mcu];
+            }
+        }
+        // MODE 2: the bit writer (emit_kernel's): words of the scan's raw buffer, MSB first, byte-swapped into stream order
+        uint32_t *words = nullptr;
+        uint64_t wi = 0;
+        uint32_t fill = 0, acc = 0;
+        if (MODE == 2) {
+            words = reinterpret_cast<uint32_t *>(raw + scan_raw_off[wk.scan]);
+            const uint64_t start = sub_bitoff[slot];
+            wi = start >> 5;
+            fill = (uint32_t)(start & 31);
+        }
+        auto put = [&](uint32_t code, uint32_t len) {
+            nbits += len;
+            if (MODE != 2) return;
+            while (len) {
+                const uint32_t room = 32u - fill;
+                const uint32_t take = len < room ? len : room;
+                const uint32_t part = (take == 32u) ? code : ((code >> (len - take)) & ((1u << take) - 1u));
+                acc |= (take == 32u) ? part : (part << (room - take));
+                fill += take;
+                len -= take;
+                if (fill == 32u) {
+                    atomicOr(&words[wi], __builtin_bswap32(acc));
+                    wi++;
+                    fill = 0;
+                    acc = 0;
+                }
+            }
+        };
+        for (uint32_t j = 0; j < count && err == 0; j++) {
+            const uint32_t dc_slot = (info & 0xFFFu) / kSlot16, ac_slot = ((info >> 12) & 0xFFFu) / kSlot16;
+            const LdsHuff hdc = lds_huff16(tabs, info & 0xFFF), hac = lds_huff16(tabs, (info >> 12) & 0xFFF);
+            uint32_t sym;
+            err = ub_huff(r, hdc, sym);
+            if (err != 0) break;
+            if (MODE == 0) atomicAdd(&lhist[dc_slot * 256u + sym], 1u);
+            else put(lenc[dc_slot].code[sym], lenc[dc_slot].len[sym]);
+            if (sym != 0) {
+                uint32_t bits;
+                if (sym > 16u) {
+                    err = kDetailInvalidHuffmanCode;
+                    break;
+                }
+                if (!ub_try_read_bits(r, sym, bits)) {
+                    err = (r.rem == 0 && closed_by_marker) ? kDetailMarkerInData : kDetailStreamEnded;
+                    break;
+                }
+                if (MODE != 0) put(bits, sym);
+            }
+            for (uint32_t i = 1; i < 64u;) {
+                err = ub_huff(r, hac, sym);
+                if (err != 0) break;
+                if (MODE == 0) atomicAdd(&lhist[ac_slot * 256u + sym], 1u);
+                else put(lenc[ac_slot].code[sym], lenc[ac_slot].len[sym]);
+                const uint32_t rr = sym >> 4, sz = sym & 15u;
+                if (sz != 0) {
+                    i += rr + 1u;
+                    uint32_t bits;
+                    if (!ub_try_read_bits(r, sz, bits)) {
+                        err = (r.rem == 0 && closed_by_marker) ? kDetailMarkerInData : kDetailStreamEnded;
+                        break;
+                    }
+                    if (MODE != 0) put(bits, sz);
+                } else {
+                    if (rr == 0) break;
+                    i += 16u;
+                }
+            }
+            b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
+            info = blk_info[b_in_mcu];
+        }
+        if (MODE == 2 && err == 0) {
+            if (my_end == total_blocks) {
+                // ExitBitMode (JpegWriter.cs:141-166): the lane that writes the scan's last block pads the last byte with ones
+                const uint64_t total = sub_bitoff[slot] + nbits;
+                const uint32_t pad = (uint32_t)((8u - (total & 7u)) & 7u);
+                if (pad) put((1u << pad) - 1u, pad);
+            }
+            if (fill) atomicOr(&words[wi], __builtin_bswap32(acc));
+        }
+    }
+    if (MODE == 1 && sub < s.n_subs) sub_bits[slot] = err == 0 ? nbits : 0u;
+    if (live && err != 0) atomicMin(&status[wk.scan].first_error, (sub << 8) | err);
+    if (MODE == 0) {
+        __syncthreads();
+        uint32_t *gh = hist + (size_t)wk.scan * kMaxHuffSlots * 256u;
+        for (uint32_t i = tid; i < kMaxHuffSlots * 256u; i += 256u) {
+            const uint32_t v = lhist[i];
+            if (v != 0) atomicAdd(&gh[i], v);
+        }
+    }
+}
+
+// Exclusive scan of the subsequence bit counts of every scan: bitoff[i] = bits before subsequence i; totals[scan] = all bits.
+__global__ __launch_bounds__(1024) void subseq_bit_offsets_kernel(const DevScan *__restrict__ scans, const uint32_t *__restrict__ scan_ids,
+                                                                  const uint32_t *__restrict__ sub_bits, uint64_t *__restrict__ bitoff,
+                                                                  uint64_t *__restrict__ totals) {
+    __shared__ uint64_t part[1024];
+    const DevScan &s = scans[scan_ids[blockIdx.x]];
+    const uint32_t n = s.n_subs, tid = threadIdx.x;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
+    const uint32_t *sz = sub_bits + s.sub_off;
+    uint64_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += sz[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint64_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    if (tid == 1023) totals[blockIdx.x] = part[1023];
+    uint64_t at = part[tid] - sum;
+    uint64_t *of = bitoff + s.sub_off;
+    for (uint32_t i = lo; i < hi; i++) {
+        of[i] = at;
+        at += sz[i];
+    }
+}
+
+hipError_t launch_subseq_transcode(hipStream_t stream, int mode, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
+                                   const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, const uint32_t *exit_state,
+                                   const uint32_t *first_block, uint32_t *hist, const EncHuffTable *enc, uint32_t *sub_bits,
+                                   const uint64_t *sub_bitoff, const uint64_t *scan_raw_off, uint8_t *raw, int n_slots) {
+    if (n_work <= 0) return hipSuccess;
+    const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kMaxBlocksPerMcu * 4 + (size_t)kMaxHuffSlots * 1024;
+    if (mode == 0)
+        hipLaunchKernelGGL(subseq_transcode_kernel<0>, dim3(n_work), dim3(256), lds, stream, udata, scans, work, ends_u, status, huff_pool,
+                           exit_state, first_block, hist, enc, sub_bits, sub_bitoff, scan_raw_off, raw, n_slots);
+    else if (mode == 1)
+        hipLaunchKernelGGL(subseq_transcode_kernel<1>, dim3(n_work), dim3(256), lds, stream, udata, scans, work, ends_u, status, huff_pool,
+                           exit_state, first_block, hist, enc, sub_bits, sub_bitoff, scan_raw_off, raw, n_slots);
+    else
+        hipLaunchKernelGGL(subseq_transcode_kernel<2>, dim3(n_work), dim3(256), lds, stream, udata, scans, work, ends_u, status, huff_pool,
+                           exit_state, first_block, hist, enc, sub_bits, sub_bitoff, scan_raw_off, raw, n_slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_subseq_bit_offsets(hipStream_t stream, const DevScan *scans, const uint32_t *scan_ids, int n_scans, const uint32_t *sub_bits,
+                                     uint64_t *bitoff, uint64_t *totals) {
+    if (n_scans <= 0) return hipSuccess;
+    hipLaunchKernelGGL(subseq_bit_offsets_kernel, dim3(n_scans), dim3(1024), 0, stream, scans, scan_ids, sub_bits, bitoff, totals);
     return hipGetLastError();
 }
 
