@@ -7,13 +7,13 @@ from . import _capi  # noqa: F401  (loads libjpgpu.so, fails loudly when absent)
 from .batch import FMT_INTERLEAVED_U8, FMT_PLANAR_I16, FMT_PLANAR_U8, FMT_RGB_U8, FMT_RGBA_U8, Batch, decode_batch
 from .context import Context, default_context, device_count
 from .encoder import EncodeBatch, encode_batch
-from .optimizer import OptimizeBatch, build_optimal_huffman_table, optimize_batch
+from .optimizer import JpegOptimizer, OptimizeBatch, build_optimal_huffman_table, optimize_batch
 from .decoder import JpegBlockOutputWriter, JpegBufferOutputWriter8Bit, JpegDecoder, JpegExtendingOutputWriter
 from .errors import (ArgumentException, DeviceError, InvalidDataException, InvalidOperationException, JpegError,
                      NoDeviceError, NotSupportedException)
 
 __all__ = [
-    "Batch", "decode_batch", "EncodeBatch", "encode_batch", "OptimizeBatch", "optimize_batch", "build_optimal_huffman_table", "Context", "default_context", "device_count", "JpegDecoder", "JpegBlockOutputWriter",
+    "Batch", "decode_batch", "EncodeBatch", "encode_batch", "JpegOptimizer", "OptimizeBatch", "optimize_batch", "build_optimal_huffman_table", "Context", "default_context", "device_count", "JpegDecoder", "JpegBlockOutputWriter",
     "JpegBufferOutputWriter8Bit", "JpegExtendingOutputWriter", "FMT_INTERLEAVED_U8", "FMT_PLANAR_U8", "FMT_PLANAR_I16", "FMT_RGB_U8", "FMT_RGBA_U8",
     "JpegError", "InvalidDataException", "InvalidOperationException", "NotSupportedException", "ArgumentException",
     "DeviceError", "NoDeviceError",

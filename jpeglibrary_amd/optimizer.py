@@ -97,6 +97,46 @@ class OptimizeBatch:
             pass
 
 
+class JpegOptimizer:
+    """The reference's class surface (src/JpegLibrary/JpegOptimizer.cs:16-70, 523-548) over a one-file batch:
+
+        optimizer = JpegOptimizer(); optimizer.SetInput(bytes); optimizer.Scan(); optimizer.SetOutput(buffer); optimizer.Optimize(strip)
+
+    `buffer` is anything with `write(bytes)` (an IBufferWriter<byte> stand-in, e.g. io.BytesIO) or a bytearray."""
+
+    def __init__(self, ctx: Context = None):
+        self._ctx = ctx
+        self._input = None
+        self._output = None
+        self._scanned = False
+        self.MostOptimalCoding = False
+
+    def SetInput(self, data):
+        self._input = bytes(data)
+        self._scanned = False
+
+    def Scan(self):
+        if not self._input:
+            from .errors import InvalidOperationException
+            raise InvalidOperationException("Input buffer is not specified.")
+        self._scanned = True  # the symbol pass runs with Optimize(): both need the device, and Scan() alone has no observable result
+
+    def SetOutput(self, output):
+        if output is None:
+            raise TypeError("output")
+        self._output = output
+
+    def Optimize(self, strip=True):
+        from .errors import InvalidOperationException
+        if not self._scanned or self._output is None:
+            raise InvalidOperationException("Operation is not valid due to the current state of the object.")
+        data = optimize_batch([self._input], strip, self._ctx, self.MostOptimalCoding)[0]
+        if isinstance(self._output, bytearray):
+            self._output += data
+        else:
+            self._output.write(data)
+
+
 def optimize_batch(files, strip=True, ctx=None, most_optimal=False):
     """One-call helper: the optimized bytes of every file (raises on the first failing file)."""
     b = OptimizeBatch(ctx).set_most_optimal_coding(most_optimal).upload(files, strip).run()

@@ -810,7 +810,8 @@ def _synth_jpeg(w, h, quality=75, subsampling=2, restart=0, seed=0, gray=False):
 def _optimizer_files():
     return [read_jpeg("lake.jpg"), read_jpeg("cramps.jpg"), read_jpeg("HETissueSlide.jpg"), _synth_jpeg(200, 136, restart=4),
             _synth_jpeg(333, 77, subsampling=0, restart=11, seed=2), _synth_jpeg(64, 64, gray=True, seed=3),
-            _synth_jpeg(640, 360, quality=95, subsampling=1, restart=7, seed=4), _synth_jpeg(1920, 1088, restart=7, seed=5)]
+            _synth_jpeg(640, 360, quality=95, subsampling=1, restart=7, seed=4), _synth_jpeg(1920, 1088, restart=7, seed=5),
+            _synth_jpeg(1280, 720, quality=90, subsampling=0, seed=6), _synth_jpeg(333, 222, quality=50, subsampling=1, seed=7)]
 
 
 @pytest.mark.parametrize("strip", [True, False])
@@ -831,15 +832,27 @@ def test_optimizer_matches_the_reference_restatement_byte_for_byte(strip):
     b.close()
 
 
-def test_reference_optimizer_test_on_the_gpu():
-    """tests/JpegLibrary.Tests/Optimizer/OptimizerTests.cs:26-47 with the GPU optimizer: smaller, same pixels."""
-    data = read_jpeg("lake.jpg")
-    for strip in (True, False):
-        out = jl.optimize_batch([data], strip)[0]
-        assert len(out) < len(data)
-        a, _ = po.decode_8bit(data)
-        b2, _ = po.decode_8bit(out)
-        assert np.array_equal(a, b2)
+@pytest.mark.parametrize("strip", [True, False])
+def test_reference_optimizer_test_on_the_gpu(strip):
+    """tests/JpegLibrary.Tests/Optimizer/OptimizerTests.cs:26-47 (TestOptimize on Assets/baseline/lake.jpg, strip = true /
+    false), line by line through the mirror of the reference's class."""
+    import io
+    jpeg_bytes = read_jpeg("lake.jpg")
+    ref_image, _ = po.decode_8bit(jpeg_bytes)
+
+    optimizer = jl.JpegOptimizer()
+    optimizer.SetInput(jpeg_bytes)
+    optimizer.Scan()
+
+    buffer = io.BytesIO()
+    optimizer.SetOutput(buffer)
+    optimizer.Optimize(strip)
+
+    assert buffer.tell() < len(jpeg_bytes)
+    test_image, _ = po.decode_8bit(buffer.getvalue())
+    assert np.array_equal(ref_image, test_image)
+    outs, results = jl.decode_batch([buffer.getvalue()])  # ... and through the GPU decoder as well
+    assert results[0].status == 0 and np.array_equal(np.asarray(outs[0]), ref_image)
 
 
 def test_optimizer_failures_follow_the_reference():
