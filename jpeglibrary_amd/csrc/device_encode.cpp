@@ -182,6 +182,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         coef_off += im.total_blocks;
         const uint32_t total_mcus = im.mcus_per_line * im.mcus_per_column;
         for (uint32_t f = 0; f < total_mcus; f += kEncMcusPerWg) work_mcu.push_back({(uint32_t)i, f});
+        im.work_first = (uint32_t)work_blk.size();
         for (uint32_t f = 0; f < im.total_blocks; f += 256) work_blk.push_back({(uint32_t)i, f});
 
         // ---- marker segments, in the order Encode() writes them (JpegEncoder.cs:261-280)
@@ -254,7 +255,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         {&d_pixels_, nullptr, 0, (size_t)px_off + 256},
         {&d_coefs_, nullptr, 0, (size_t)total_blocks_ * 128 + 256},
         {&d_bits_, nullptr, 0, (size_t)total_blocks_ * sizeof(uint32_t) + 256},
-        {&d_bit_off_, nullptr, 0, (size_t)total_blocks_ * sizeof(uint64_t) + 256},
+        {&d_bit_off_, nullptr, 0, work_blk.size() * (sizeof(uint64_t) + sizeof(uint32_t)) + 512},  // per workgroup: base (u64) | bits (u32)
         {&d_raw_bits_, nullptr, 0, (size_t)n * sizeof(uint64_t) + 256},
         {&d_out_len_, nullptr, 0, (size_t)n * sizeof(uint64_t) + 256},
         {&d_images_, nullptr, 0, (size_t)n * sizeof(DevEncImage) + 256},
@@ -339,8 +340,9 @@ int EncodeBatch::encode() {
         e = hipMemcpyAsync((EncHuffTable *)d_tables_.ptr + 4, built.data(), built.size() * sizeof(EncHuffTable), hipMemcpyHostToDevice, ctx_->stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(built tables)");
     }
+    uint32_t *wg_bits = reinterpret_cast<uint32_t *>((uint8_t *)d_bit_off_.ptr + (((size_t)n_work_blk_ * sizeof(uint64_t) + 255) & ~(size_t)255));
     e = launch_block_bits(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_blk_.ptr, n_work_blk_,
-                          (const EncHuffTable *)d_tables_.ptr, (const int16_t *)d_coefs_.ptr, (uint32_t *)d_bits_.ptr, n, (uint64_t *)d_bit_off_.ptr,
+                          (const EncHuffTable *)d_tables_.ptr, (const int16_t *)d_coefs_.ptr, (uint32_t *)d_bits_.ptr, n, wg_bits, (uint64_t *)d_bit_off_.ptr,
                           (uint64_t *)d_raw_bits_.ptr);
     if (e != hipSuccess) return hip_fail(e, "block_bits_kernel");
     // the sizes of the raw and finished streams depend on the data: one host round trip
@@ -382,7 +384,8 @@ int EncodeBatch::encode() {
         e = hipMemcpyAsync((uint8_t *)d_out_.ptr + images_[i].out_off, headers_[i].data(), headers_[i].size(), hipMemcpyHostToDevice, ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(headers)");
     e = launch_emit(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_blk_.ptr, n_work_blk_, (const EncHuffTable *)d_tables_.ptr,
-                    (const int16_t *)d_coefs_.ptr, (const uint64_t *)d_bit_off_.ptr, (const uint64_t *)d_raw_bits_.ptr, (uint8_t *)d_raw_.ptr);
+                    (const int16_t *)d_coefs_.ptr, (const uint32_t *)d_bits_.ptr, (const uint64_t *)d_bit_off_.ptr, (const uint64_t *)d_raw_bits_.ptr,
+                    (uint8_t *)d_raw_.ptr);
     if (e != hipSuccess) return hip_fail(e, "emit_kernel");
     e = launch_stuff(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_chunk_.ptr, n_work_chunk_, (const uint64_t *)d_raw_bits_.ptr,
                      (const uint8_t *)d_raw_.ptr, (uint32_t *)d_chunk_ff_.ptr, (uint8_t *)d_out_.ptr, (uint64_t *)d_out_len_.ptr);

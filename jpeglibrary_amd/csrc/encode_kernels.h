@@ -24,6 +24,8 @@ struct alignas(16) DevEncImage {
     uint32_t input_rgb;   // 1: pixels are R,G,B and are converted like JpegRgbToYCbCrConverter.ConvertRgb24ToYCbCr8
     uint32_t table_base;  // first of the image's 4 tables (DC0, AC0, DC1, AC1) in the table array; 0 = the standard tables.
                           // != 0 = optimizeCoding (tables built from the image): the TransformBlocks / allocator semantics apply
+    uint32_t work_first;  // first workgroup of this image in the per-256-blocks work list (block_bits / emit)
+    uint32_t pad1[3];
     int32_t r2y[8];       // Fix() factors of the RGB -> YCbCr tables (host: rgb_ycc_factors)
     uint16_t quant[2][64];  // zig-zag quantisation tables: luma, chroma
 };
@@ -45,12 +47,12 @@ struct EncWork {
 hipError_t launch_fdct_quant(hipStream_t stream, const uint8_t *pixels, const DevEncImage *images, const EncWork *work, int n_work,
                              int16_t *coefs);
 hipError_t launch_block_bits(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
-                             const int16_t *coefs, uint32_t *bits, int n_images, uint64_t *bit_off, uint64_t *raw_bits);
+                             const int16_t *coefs, uint32_t *bits, int n_images, uint32_t *wg_bits, uint64_t *wg_base, uint64_t *raw_bits);
 // optimizeCoding: GatherBlockStatistics for every block (ref: JpegEncoder.cs:552-597) -> hist[image][4][256]
 hipError_t launch_block_stats(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const int16_t *coefs,
                               uint32_t *hist);
 hipError_t launch_emit(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
-                       const int16_t *coefs, const uint64_t *bit_off, const uint64_t *raw_bits, uint8_t *raw);
+                       const int16_t *coefs, const uint32_t *bits, const uint64_t *wg_base, const uint64_t *raw_bits, uint8_t *raw);
 constexpr uint32_t kEncStuffChunk = 4096;
 hipError_t launch_stuff(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const uint64_t *raw_bits,
                         const uint8_t *raw, uint32_t *chunk_ff, uint8_t *out, uint64_t *out_len);

@@ -332,22 +332,43 @@ __device__ __forceinline__ void enc_block_symbols(const uint4 (&cv)[8], int32_t 
     if (run > 0) put(ac.code[0], ac.len[0]);
 }
 
+// E2: bits of every block (EncodeBlock with a counting writer).  bits[] receives the block's offset inside its workgroup
+// of 256 blocks, wg_bits[] the workgroup's total: the image-wide scan (block_offsets_kernel) then runs over one entry per
+// workgroup instead of one per block.
 __global__ __launch_bounds__(256) void block_bits_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
                                                          const EncHuffTable *__restrict__ tables, const int16_t *__restrict__ coefs,
-                                                         uint32_t *__restrict__ bits) {
+                                                         uint32_t *__restrict__ bits, uint32_t *__restrict__ wg_bits) {
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
     const uint32_t blk = wk.first + threadIdx.x;
-    if (blk >= im.total_blocks) return;
+    uint32_t n = 0;
+    if (blk < im.total_blocks) {
     const int16_t *img_coefs = coefs + im.coef_off * 64;
     const uint32_t mcu = blk / im.bpm, b = blk - mcu * im.bpm;
     uint32_t comp;
     const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
     const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)enc_source_block(im, blk) * 64);
     const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
-    uint32_t n = 0;
     enc_block_symbols(cv, pred, tables[im.table_base + (comp == 0 ? 0 : 2)], tables[im.table_base + (comp == 0 ? 1 : 3)], [&](uint32_t, uint32_t len) { n += len; });
-    bits[im.coef_off + blk] = n;
+    }
+    // exclusive scan of n over the workgroup
+    __shared__ uint32_t sh_wave[4];
+    uint32_t incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if ((threadIdx.x & 63) >= (uint32_t)o) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) sh_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (k < (threadIdx.x >> 6)) before += sh_wave[k];
+        total += sh_wave[k];
+    }
+    if (blk < im.total_blocks) bits[im.coef_off + blk] = before + incl - n;
+    if (threadIdx.x == 0) wg_bits[blockIdx.x] = total;
 }
 
 // optimizeCoding: GatherBlockStatistics (:552-597) for the 256 blocks of a workgroup: LDS histograms of the four tables
@@ -394,16 +415,18 @@ __global__ __launch_bounds__(256) void block_stats_kernel(const DevEncImage *__r
         if (lh[i] != 0) atomicAdd(&gh[i], lh[i]);
 }
 
-// Exclusive prefix sums of the block bit counts of one image (one workgroup per image); total -> images' raw_bits.
-__global__ __launch_bounds__(1024) void block_offsets_kernel(const DevEncImage *__restrict__ images, const uint32_t *__restrict__ bits,
-                                                             uint64_t *__restrict__ bit_off, uint64_t *__restrict__ raw_bits) {
+// Exclusive prefix sums of the workgroup bit totals of one image (one workgroup per image); total -> images' raw_bits.
+__global__ __launch_bounds__(1024) void block_offsets_kernel(const DevEncImage *__restrict__ images, const uint32_t *__restrict__ wg_bits,
+                                                             uint64_t *__restrict__ wg_base, uint64_t *__restrict__ raw_bits) {
     const DevEncImage &im = images[blockIdx.x];
     __shared__ uint64_t sh[1024];
     const uint32_t tid = threadIdx.x;
-    const uint32_t per = (im.total_blocks + 1023) / 1024;
-    const uint32_t lo = tid * per, hi = lo + per < im.total_blocks ? lo + per : im.total_blocks;
+    const uint32_t n = (im.total_blocks + 255) / 256;  // workgroups of block_bits_kernel / emit_kernel for this image
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
+    const uint32_t *src = wg_bits + im.work_first;
     uint64_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += bits[im.coef_off + i];
+    for (uint32_t i = lo; i < hi; i++) sum += src[i];
     sh[tid] = sum;
     __syncthreads();
     for (uint32_t o = 1; o < 1024; o <<= 1) {
@@ -414,8 +437,8 @@ __global__ __launch_bounds__(1024) void block_offsets_kernel(const DevEncImage *
     }
     uint64_t run = sh[tid] - sum;
     for (uint32_t i = lo; i < hi; i++) {
-        bit_off[im.coef_off + i] = run;
-        run += bits[im.coef_off + i];
+        wg_base[im.work_first + i] = run;
+        run += src[i];
     }
     if (tid == 1023) raw_bits[blockIdx.x] = sh[1023];
 }
@@ -425,8 +448,8 @@ __global__ __launch_bounds__(1024) void block_offsets_kernel(const DevEncImage *
 // atomicOr (the buffer is zeroed before), which commutes with the byte swap.
 __global__ __launch_bounds__(256) void emit_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
                                                    const EncHuffTable *__restrict__ tables, const int16_t *__restrict__ coefs,
-                                                   const uint64_t *__restrict__ bit_off, const uint64_t *__restrict__ raw_bits,
-                                                   uint8_t *__restrict__ raw) {
+                                                   const uint32_t *__restrict__ bits, const uint64_t *__restrict__ wg_base,
+                                                   const uint64_t *__restrict__ raw_bits, uint8_t *__restrict__ raw) {
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
     const uint32_t blk = wk.first + threadIdx.x;
@@ -438,7 +461,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const DevEncImage *__restrict
     const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)enc_source_block(im, blk) * 64);
     const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
     uint32_t *words = reinterpret_cast<uint32_t *>(raw + im.raw_off);
-    const uint64_t start = bit_off[im.coef_off + blk];
+    const uint64_t start = wg_base[blockIdx.x] + bits[im.coef_off + blk];
     uint64_t wi = start >> 5;            // current word
     uint32_t fill = (uint32_t)(start & 31);  // bits already taken in it (by earlier blocks)
     uint32_t acc = 0;                    // bits of the current word, left aligned below `fill`
@@ -569,10 +592,10 @@ hipError_t launch_fdct_quant(hipStream_t stream, const uint8_t *pixels, const De
     return hipGetLastError();
 }
 hipError_t launch_block_bits(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
-                             const int16_t *coefs, uint32_t *bits, int n_images, uint64_t *bit_off, uint64_t *raw_bits) {
+                             const int16_t *coefs, uint32_t *bits, int n_images, uint32_t *wg_bits, uint64_t *wg_base, uint64_t *raw_bits) {
     if (n_work <= 0) return hipSuccess;
-    hipLaunchKernelGGL(block_bits_kernel, dim3(n_work), dim3(256), 0, stream, images, work, tables, coefs, bits);
-    hipLaunchKernelGGL(block_offsets_kernel, dim3(n_images), dim3(1024), 0, stream, images, bits, bit_off, raw_bits);
+    hipLaunchKernelGGL(block_bits_kernel, dim3(n_work), dim3(256), 0, stream, images, work, tables, coefs, bits, wg_bits);
+    hipLaunchKernelGGL(block_offsets_kernel, dim3(n_images), dim3(1024), 0, stream, images, wg_bits, wg_base, raw_bits);
     return hipGetLastError();
 }
 hipError_t launch_block_stats(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const int16_t *coefs,
@@ -582,9 +605,9 @@ hipError_t launch_block_stats(hipStream_t stream, const DevEncImage *images, con
     return hipGetLastError();
 }
 hipError_t launch_emit(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
-                       const int16_t *coefs, const uint64_t *bit_off, const uint64_t *raw_bits, uint8_t *raw) {
+                       const int16_t *coefs, const uint32_t *bits, const uint64_t *wg_base, const uint64_t *raw_bits, uint8_t *raw) {
     if (n_work <= 0) return hipSuccess;
-    hipLaunchKernelGGL(emit_kernel, dim3(n_work), dim3(256), 0, stream, images, work, tables, coefs, bit_off, raw_bits, raw);
+    hipLaunchKernelGGL(emit_kernel, dim3(n_work), dim3(256), 0, stream, images, work, tables, coefs, bits, wg_base, raw_bits, raw);
     return hipGetLastError();
 }
 hipError_t launch_stuff(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const uint64_t *raw_bits,
