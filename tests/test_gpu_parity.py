@@ -959,3 +959,29 @@ def test_most_optimal_coding_optimizer_and_encoder():
         for k, im in enumerate(imgs):
             assert e.output(k) == po.encode_8bit(im, luma[0], luma[1], 80, optimize_coding=2), (luma, k)
         e.close()
+
+
+def test_optimizer_edge_sizes_and_samplings_in_one_batch():
+    """Tiny and ragged geometries for every sampling, with and without restart intervals, through the optimizer as ONE batch:
+    the bytes of the restatement, or its failure class (an MCU count that is a multiple of DRI makes the reference give up)."""
+    files = []
+    for (w, h) in [(1, 1), (7, 9), (8, 8), (16, 16), (17, 1), (1, 33), (31, 17), (48, 40), (129, 65)]:
+        for ss in ("444", "422", "420", "gray"):
+            for dri in (0, 1, 3):
+                files.append(bytes(jpegsynth.encode(w, h, ss, 70, dri, seed=w * 131 + h * 7 + dri)))
+    names = {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException", 4: "ArgumentException"}
+    for strip in (True, False):
+        b = jl.OptimizeBatch().upload(files, strip).run()
+        n_ok = 0
+        for i, f in enumerate(files):
+            try:
+                ref, kind = po.optimize(f, strip), "OK"
+            except po.OracleError as e:
+                ref, kind = None, e.kind
+            res, size = b.result(i)
+            assert names.get(res.status) == kind, (i, strip, kind, res.status, res.detail)
+            if ref is not None:
+                assert b.output(i) == ref, (i, strip)
+                n_ok += 1
+        assert n_ok > len(files) // 2
+        b.close()
