@@ -1501,7 +1501,7 @@ __global__ __launch_bounds__(kProgThreads) void progressive_scan_kernel(const ui
 //     concurrently by other scans);
 //   * refinement blocks are staged in LDS in rounds of kPsChunk blocks by all lanes (addresses computed by the lanes).
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kPsRingBytes = 8192;
+constexpr uint32_t kPsRingBytes = 4096;
 constexpr uint32_t kPsRingWords = kPsRingBytes / 4;
 constexpr int kPsChunk = 32;              // refinement blocks staged per round
 constexpr int32_t kPsUnitBytes = 384;     // stream bytes staged before a block / MCU is started (unless the stream ends)
