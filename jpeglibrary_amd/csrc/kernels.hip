@@ -1491,7 +1491,8 @@ __global__ __launch_bounds__(kProgThreads) void progressive_scan_kernel(const ui
 // coefficient-by-coefficient walks as scalar loops on one SIMD lane.  Here ONE WAVE owns the stream and decodes it as a
 // wave-UNIFORM program: the decoder state (bit position, EOB run, zig-zag position, the 64-bit masks) lives in scalar
 // registers, the 64 lanes are the 64 coefficients of the current block:
-//   * the unstuffed stream is staged MSB-first in an 8 KB LDS ring, topped up 1 KB at a time by all lanes;
+//   * the unstuffed stream is staged MSB-first in a 4 KB LDS ring, topped up 1 KB at a time by all lanes (small enough that
+//     all ten scans of 256 frames are resident at once);
 //   * a WINDOW holds, per lane l, the 32 stream bits at offset l past the window base and the Huffman lookup of those bits
 //     (one LDS gather for 64 bit offsets at once); decoding a symbol is then two v_readlane at the current offset plus
 //     scalar arithmetic, the window is rebuilt when the offset runs past 63 (every ~7 symbols);
