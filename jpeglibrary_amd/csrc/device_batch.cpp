@@ -334,6 +334,16 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     std::vector<HuffWork> huff_work;
     std::vector<ChunkWork> chunk_work;
     std::vector<HuffWork> sub_work;
+    // DRI = 0 scans are cut into subsequences of 1024 bits; when that gives more lanes than the machine can use anyway the
+    // subsequences grow (2048, 4096 bits): a longer one re-synchronises inside itself more often, so fewer rounds
+    uint32_t subseq_shift = 10;
+    {
+        uint64_t dri0_bits = 0;
+        for (size_t j = 0; j < jobs_.size(); j++)
+            if (jobs_[j].kind == kScanSequential && jobs_[j].geo.restart_interval == 0) dri0_bits += (uint64_t)jobs_[j].entropy_len * 8;
+        while (subseq_shift < 12 && (dri0_bits >> subseq_shift) >= 500000u) subseq_shift++;
+        if (const char *ev = getenv("JPGPU_SUBSEQ_SHIFT")) subseq_shift = (uint32_t)std::min(12, std::max(10, atoi(ev)));
+    }
     std::vector<std::vector<HuffWork>> prog_work_by_ordinal, prog_streams_by_ordinal;
     // a scan with fewer restart intervals than this gets one WAVE per interval (progressive_stream_kernel)
     const uint32_t stream_max_intervals = getenv("JPGPU_PROG_STREAM_MAX_INTERVALS") ? (uint32_t)atoi(getenv("JPGPU_PROG_STREAM_MAX_INTERVALS")) : 16u;
@@ -479,7 +489,8 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             if (job.kind == kScanFrameOnly) {
                 // the Dispose() pass: IDCT work only
             } else if (use_subseq) {
-                s.n_subs = (uint32_t)(((uint64_t)s.data_len * 8 + kSubseqBits - 1) / kSubseqBits);
+                s.sub_shift = (uint8_t)subseq_shift;
+                s.n_subs = (uint32_t)((((uint64_t)s.data_len * 8) + ((1u << subseq_shift) - 1)) >> subseq_shift);
                 s.sub_off = total_subs_;
                 total_subs_ += s.n_subs;
                 max_subs_per_scan_ = std::max(max_subs_per_scan_, s.n_subs);

@@ -35,7 +35,7 @@ hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *
 hipError_t launch_ycc_to_rgb(hipStream_t stream, const uint8_t *src, uint8_t *dst, uint64_t n_pixels, int comps, int bpp, const YccRgbFactors &kf);
 
 // DRI = 0 scans (K2S): self-synchronising subsequence decode into the (zeroed) coefficient buffer; synchronises the stream.
-constexpr uint32_t kSubseqBits = 1024;
+constexpr uint32_t kSubseqBits = 1024;  // smallest subsequence (DevScan::sub_shift = 10); large batches use 2048 / 4096 bits
 hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                                 const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,

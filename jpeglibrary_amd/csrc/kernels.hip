@@ -2142,7 +2142,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
 // K2S: self-synchronising subsequence decode for scans WITHOUT restart intervals (DRI = 0).
 //
 // One restart interval = one lane does not scale when the whole scan is a single interval.  The unstuffed stream is cut
-// into subsequences of kSubBits bits; lane i decodes subsequence i.  Its entry state (bit position, block-in-MCU,
+// into subsequences of 1 << sub_shift bits; lane i decodes subsequence i.  Its entry state (bit position, block-in-MCU,
 // zig-zag position) is unknown a priori, so round 0 guesses (start of a block of component 0) and every later round
 // restarts lane i from the exit state lane i-1 reached in the previous round.  Huffman streams self-synchronise, so the
 // exit states stop changing after a few rounds; lane 0 is exact from the start, hence a fixed point reached from it is
@@ -2152,7 +2152,8 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
 // (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:186-195).
 // ------------------------------------------------------------------------------------------------
 
-constexpr uint32_t kSubBits = 1024;
+// subsequence length: (1 << DevScan::sub_shift) bits -- 1024 for small batches (more lanes), up to 4096 for large ones (a
+// longer subsequence re-synchronises more often inside itself: fewer rounds until the exit states stop changing)
 constexpr uint32_t kSubBad = 0x80000000u;  // the lane hit an invalid code / ran out of data under its entry state
 
 // exit state word: overshoot (bits past the nominal end, 0..63) | b << 6 | k << 11 | kSubBad
@@ -2164,11 +2165,11 @@ __device__ __forceinline__ uint32_t sub_pack(uint32_t overshoot, uint32_t b, uin
 // dc[c]: FINAL: in = DcPredictor of component c at the entry, the chain is applied while decoding;
 //        otherwise out = sum of the DC differences of component c decoded inside the subsequence.
 template <bool FINAL>
-__device__ __forceinline__ uint32_t sub_decode(const uint8_t *ubase, uint32_t total_bits, uint32_t sub, uint32_t entry, const uint8_t *tabs,
+__device__ __forceinline__ uint32_t sub_decode(const uint8_t *ubase, uint32_t total_bits, uint32_t sub_shift, uint32_t sub, uint32_t entry, const uint8_t *tabs,
                                                const uint32_t *blk_info, uint32_t bpm, uint32_t &nblk, int16_t *coefs, uint32_t first_block,
                                                uint32_t total_blocks, uint32_t &err_out, bool closed_by_marker, int32_t (&dc)[4]) {
-    const uint32_t start_bit = sub * kSubBits + (entry & 63u);
-    const uint32_t end_bit = (sub + 1) * kSubBits;
+    const uint32_t start_bit = (sub << sub_shift) + (entry & 63u);
+    const uint32_t end_bit = (sub + 1) << sub_shift;
     uint32_t b_in_mcu = (entry >> 6) & 31u, k = (entry >> 11) & 127u;
     nblk = 0;
     err_out = 0;
@@ -2310,8 +2311,8 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
     entry_used[slot] = entry;
 
     const uint32_t bpm = s.blocks_per_mcu;
-    const uint32_t start_bit = sub * kSubBits + (entry & 63u);
-    const uint32_t end_bit = (sub + 1) * kSubBits;
+    const uint32_t start_bit = (sub << s.sub_shift) + (entry & 63u);
+    const uint32_t end_bit = (sub + 1) << s.sub_shift;
     uint32_t b_in_mcu = (entry >> 6) & 31u, i2 = ((entry >> 11) & 127u) * 2u;
     uint32_t nblk = 0, bad = 0;
     int32_t dc0 = 0, dc1 = 0, dc2 = 0, dc3 = 0;
@@ -2511,7 +2512,7 @@ __global__ __launch_bounds__(64 * kSubFinalWaves) void subseq_final_kernel(const
     int32_t dc[4] = {0, 0, 0, 0};
     uint32_t info = blk_info[b_in_mcu];
     {
-        const uint32_t start_bit = live ? sub * kSubBits + (entry & 63u) : 0u;
+        const uint32_t start_bit = live ? (sub << s.sub_shift) + (entry & 63u) : 0u;
         ub_init(r, udata + s.data_off, start_bit >> 3, (total_bits + 7) >> 3);
         if (start_bit & 7u) ub_consume(r, start_bit & 7u);
         r.rem = (int32_t)total_bits - (int32_t)start_bit;
@@ -3806,7 +3807,7 @@ __global__ __launch_bounds__(256) void subseq_transcode_kernel(const uint8_t *__
     uint32_t nbits = 0;  // bits this lane produces
     if (live && count != 0) {
         UBits r;
-        const uint32_t start_bit = sub * kSubBits + (entry & 63u);
+        const uint32_t start_bit = (sub << s.sub_shift) + (entry & 63u);
         ub_init(r, udata + s.data_off, start_bit >> 3, (total_bits + 7) >> 3);
         if (start_bit & 7u) ub_consume(r, start_bit & 7u);
         r.rem = (int32_t)total_bits - (int32_t)start_bit;
