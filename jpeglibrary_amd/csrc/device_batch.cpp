@@ -342,7 +342,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         for (size_t j = 0; j < jobs_.size(); j++)
             if (jobs_[j].kind == kScanSequential && jobs_[j].geo.restart_interval == 0) dri0_bits += (uint64_t)jobs_[j].entropy_len * 8;
         while (subseq_shift < 12 && (dri0_bits >> subseq_shift) >= 500000u) subseq_shift++;
-        if (const char *ev = getenv("JPGPU_SUBSEQ_SHIFT")) subseq_shift = (uint32_t)std::min(12, std::max(10, atoi(ev)));
+        if (const char *ev = getenv("JPGPU_SUBSEQ_SHIFT")) subseq_shift = (uint32_t)std::min(14, std::max(10, atoi(ev)));
     }
     std::vector<std::vector<HuffWork>> prog_work_by_ordinal, prog_streams_by_ordinal;
     // a scan with fewer restart intervals than this gets one WAVE per interval (progressive_stream_kernel)
