@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""tools/stress_parity.py [n] [seed] -- random corpus through the GPU paths vs the CPU restatements (checker only).
+
+Pillow / libjpeg-turbo files of random size, quality, sampling, restart interval, progressive / optimize flags:
+decode (YCbCr8 + RGBA) and, for the single-scan baseline ones, the optimizer (both strip settings).  Prints a summary;
+exit code 1 on any mismatch.  Not part of the test suite (it takes minutes with large n)."""
+import io
+import os
+import sys
+
+import numpy as np
+from PIL import Image, ImageFile
+
+ImageFile.MAXBLOCK = 1 << 24  # Pillow sizes its encoder buffer from this for optimize / progressive
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import jpeglibrary_amd as jl
+from oracle import pyoracle as po
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+files, kinds = [], []
+for i in range(n):
+    w, h = int(rng.integers(1, 301)), int(rng.integers(1, 301))
+    if rng.random() < 0.1:
+        w, h = int(rng.integers(300, 1200)), int(rng.integers(300, 900))
+    gray = rng.random() < 0.2
+    base = rng.integers(0, 256, (h, w, 1 if gray else 3))
+    smooth = rng.random() < 0.6
+    if smooth:
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = (128 + 100 * np.sin(xx / rng.uniform(3, 60) + yy / rng.uniform(3, 60)))[..., None] + rng.normal(0, rng.uniform(0, 20), base.shape)
+    img = np.clip(np.rint(base), 0, 255).astype(np.uint8)
+    kw = dict(format="JPEG", quality=int(rng.integers(3, 101)))
+    if not gray:
+        kw["subsampling"] = int(rng.integers(0, 3))
+    prog = rng.random() < 0.25
+    if prog:
+        kw["progressive"] = True
+    if rng.random() < 0.5:
+        kw["restart_marker_blocks"] = int(rng.integers(1, 12))
+    if rng.random() < 0.3:
+        kw["optimize"] = True
+    out = io.BytesIO()
+    Image.fromarray(img[..., 0] if gray else img).save(out, **kw)
+    files.append(out.getvalue())
+    kinds.append((w, h, gray, prog, kw))
+
+bad = 0
+names = {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException", 4: "ArgumentException"}
+# ---- decode
+refs = []
+for f in files:
+    try:
+        refs.append(("OK", po.decode_8bit(f)))
+    except po.OracleError as e:
+        refs.append((e.kind, None))
+outs, results = jl.decode_batch(files, jl.FMT_INTERLEAVED_U8)
+outs4, results4 = jl.decode_batch(files, jl.FMT_RGBA_U8)
+for i, ((kind, ref), out, res, out4, res4) in enumerate(zip(refs, outs, results, outs4, results4)):
+    mine = names.get(res.status, str(res.status))
+    if mine != kind:
+        bad += 1
+        print("decode status", i, kinds[i], kind, mine, res.detail)
+    elif kind == "OK":
+        px, info = ref
+        if not np.array_equal(np.asarray(out), px):
+            bad += 1
+            print("decode pixels", i, kinds[i])
+        if res4.status != 0 or not np.array_equal(np.asarray(out4), po.ycbcr8_to_rgb(px, rgba=True, gray=(info.ncomp == 1))):
+            bad += 1
+            print("decode rgba", i, kinds[i])
+# ---- optimizer
+n_opt = 0
+for strip in (True, False):
+    b = jl.OptimizeBatch().upload(files, strip).run()
+    for i, f in enumerate(files):
+        res, size = b.result(i)
+        mine = names.get(res.status, str(res.status))
+        if mine == "NotSupportedException":
+            continue
+        try:
+            ref, kind = po.optimize(f, strip), "OK"
+        except po.OracleError as e:
+            ref, kind = None, e.kind
+        if mine != kind:
+            bad += 1
+            print("optimize status", i, strip, kinds[i], kind, mine, res.detail)
+        elif ref is not None:
+            n_opt += 1
+            if b.output(i) != ref:
+                bad += 1
+                print("optimize bytes", i, strip, kinds[i])
+    b.close()
+print(f"stress: {n} files, {sum(k[3] for k in kinds)} progressive, {n_opt} optimizer outputs compared, mismatches: {bad}")
+sys.exit(1 if bad else 0)
