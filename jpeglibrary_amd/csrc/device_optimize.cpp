@@ -471,6 +471,23 @@ void OptimizeBatch::plan_file(Plan &p, const uint8_t *data, size_t len, bool str
             put_marker(cur, marker);
             copy_segment(nullptr, nullptr);
             break;
+        case 0xC2: {  // ProcessFrameHeader, then "not supported" (:580-582).  Reached on baseline files too: the walk does not
+                      // skip the DQT / DHT payloads, and a quantisation table may hold the bytes FF C2 (low qualities)
+            uint16_t length;
+            const uint8_t *buf;
+            if (!r.try_read_length(&length))
+                refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "Unexpected end of input data when reading segment length."));
+            if (!r.try_read_bytes(length, &buf))
+                refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "Unexpected end of input data when reading segment content."));
+            FrameHeader fh;
+            int consumed = 0;
+            if (!FrameHeader::try_parse(buf, length, false, &fh, &consumed))
+                refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count() - length + consumed, "Failed to parse frame header."));
+            refuse(JPGPU_ERR_INVALID_DATA, "Progressive JPEG is not supported currently.");
+        }
+        case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
+            refuse(JPGPU_ERR_INVALID_DATA,
+                   at_offset(r.consumed_byte_count(), ("This type of JPEG stream is not supported (StartOfFrame" + std::to_string(marker - 0xC0) + ").").c_str()));
         case 0xC4:  // the segment's own bytes are not skipped: the marker search runs through them (:596-602)
             if (!dht_written) {
                 flush();

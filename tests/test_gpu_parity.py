@@ -985,3 +985,30 @@ def test_optimizer_edge_sizes_and_samplings_in_one_batch():
                 n_ok += 1
         assert n_ok > len(files) // 2
         b.close()
+
+
+def test_optimizer_low_quality_tables_with_ff_bytes():
+    """Optimize() does not skip the DQT / DHT payloads (JpegOptimizer.cs:596-609): its marker search runs through them, and a
+    low-quality quantisation table holds FF bytes -- followed by C2 the reference throws "Progressive JPEG is not supported
+    currently." on a baseline file, followed by other values it skips or copies phantom segments.  Whatever it does, the GPU
+    path must do the same."""
+    files = []
+    for q in range(3, 31):
+        files.append(_synth_jpeg(200, 152, quality=q, seed=q, gray=(q % 2 == 0)))
+        files.append(_synth_jpeg(918, 866, quality=q, seed=100 + q, gray=True))
+    names = {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException", 4: "ArgumentException"}
+    kinds = set()
+    for strip in (True, False):
+        b = jl.OptimizeBatch().upload(files, strip).run()
+        for i, f in enumerate(files):
+            try:
+                ref, kind = po.optimize(f, strip), "OK"
+            except po.OracleError as e:
+                ref, kind = None, e.kind
+            kinds.add(kind)
+            res, size = b.result(i)
+            assert names.get(res.status) == kind, (i, strip, kind, res.status, res.detail)
+            if ref is not None:
+                assert b.output(i) == ref, (i, strip)
+        b.close()
+    assert "OK" in kinds
