@@ -92,5 +92,36 @@ for strip in (True, False):
                 bad += 1
                 print("optimize bytes", i, strip, kinds[i])
     b.close()
-print(f"stress: {n} files, {sum(k[3] for k in kinds)} progressive, {n_opt} optimizer outputs compared, mismatches: {bad}")
+# ---- encoder: random images / samplings / qualities / table modes, grouped by the parameters one batch shares
+n_enc = 0
+groups = {}
+for i in range(max(60, n // 4)):
+    w, h = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+    gray = rng.random() < 0.15
+    luma = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (4, 2)][int(rng.integers(0, 6))] if not gray else (1, 1)
+    q = int(rng.integers(1, 101))
+    mode = int(rng.integers(0, 3))
+    rgb = (not gray) and rng.random() < 0.5
+    img = rng.integers(0, 256, (h, w) if gray else (h, w, 3)).astype(np.uint8)
+    if rng.random() < 0.5:
+        img = (img.astype(np.int32) // int(rng.integers(1, 40)) * int(rng.integers(1, 8))).clip(0, 255).astype(np.uint8)
+    groups.setdefault((luma, q, mode, rgb), []).append(img)
+for (luma, q, mode, rgb), imgs in groups.items():
+    e = jl.EncodeBatch().upload(imgs, luma, q, rgb=rgb, optimize_coding=mode).encode()
+    for k, im in enumerate(imgs):
+        src = po.rgb_to_ycbcr8(im) if rgb else im
+        try:
+            ref = po.encode_8bit(src, luma[0], luma[1], q, optimize_coding=mode)
+        except po.OracleError:
+            ref = None
+        try:
+            got = e.output(k)
+        except jl.JpegError:
+            got = None
+        n_enc += 1
+        if got != ref:
+            bad += 1
+            print("encode", luma, q, mode, rgb, im.shape, None if got is None else len(got), None if ref is None else len(ref))
+    e.close()
+print(f"stress: {n} files, {sum(k[3] for k in kinds)} progressive, {n_opt} optimizer outputs compared, {n_enc} encoder outputs compared, mismatches: {bad}")
 sys.exit(1 if bad else 0)
