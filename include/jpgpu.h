@@ -50,7 +50,8 @@ typedef enum jpgpu_detail {
     JPGPU_DETAIL_UNSUPPORTED_FRAME = 6,    /* SOF other than SOF0/SOF1 on this path */
     JPGPU_DETAIL_BAD_HEADER = 7,           /* marker/segment parse failure before the scan */
     JPGPU_DETAIL_EARLY_EOI = 8,            /* not an error: EOI met at a restart boundary, image partially decoded (ref: ...BaselineScanDecoder.cs:145-150) */
-    JPGPU_DETAIL_UNEXPECTED_END = 9        /* "Unexpected end of JPEG data stream."  ref: ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs:249,295,336,350,366,404 */
+    JPGPU_DETAIL_UNEXPECTED_END = 9,       /* "Unexpected end of JPEG data stream."  ref: ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs:249,295,336,350,366,404 */
+    JPGPU_DETAIL_NULL_TABLE = 10           /* optimizer: a block needs a Huffman table that was never defined (the reference dereferences null, JpegOptimizer.cs:468-480) */
 } jpgpu_detail;
 
 /* Output layouts. */

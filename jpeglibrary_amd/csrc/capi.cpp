@@ -98,6 +98,7 @@ const char *jpgpu_detail_string(int detail) {
     case JPGPU_DETAIL_BAD_HEADER: return "Failed to decode JPEG data. Malformed marker segment.";
     case JPGPU_DETAIL_EARLY_EOI: return "EndOfImage met at a restart boundary; image partially decoded.";
     case JPGPU_DETAIL_UNEXPECTED_END: return "Failed to decode JPEG data. Unexpected end of JPEG data stream.";
+    case JPGPU_DETAIL_NULL_TABLE: return "Object reference not set to an instance of an object.";
     default: return "unknown detail";
     }
 }

@@ -106,7 +106,8 @@ struct alignas(16) DevScanStatus {
     uint32_t first_error;   // (interval << 8) | detail of the lowest failing interval, 0xFFFFFFFF = none
     uint32_t decoded_mcus;  // MCUs decoded (limits the IDCT pass when EOI came early)
     uint32_t end_pos;       // byte offset (from data_off) of the terminating marker / end of data
-    uint32_t pad[3];        // [0] unstuffed length; [1] progressive scans: restart units completed (0xFFFFFFFF = finished)
+    uint32_t pad[3];        // [0] unstuffed length; [1] progressive scans: restart units completed (0xFFFFFFFF = finished);
+                            // [2] optimizer walk: bits of the stream left unread behind the scan's last block
 };
 
 // Work lists: one entry per workgroup.
@@ -150,7 +151,8 @@ enum Detail : uint32_t {
     kDetailUnsupportedFrame = 6,
     kDetailBadHeader = 7,
     kDetailEarlyEoi = 8,
-    kDetailUnexpectedEnd = 9
+    kDetailUnexpectedEnd = 9,
+    kDetailNullTable = 10  // optimizer walk: a block needs a Huffman table that was never defined (the reference's null reference)
 };
 
 }  // namespace jpgpu

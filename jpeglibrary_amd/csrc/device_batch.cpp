@@ -79,7 +79,7 @@ class PlanHandler final : public ScanHandler {
         }
         if (!baseline_)
             throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "Only Huffman DCT frames (SOF0, SOF1, SOF2) run on this path.", kDetailUnsupportedFrame);
-        jobs_->push_back(make_scan_job(dec, geo_, scan, entropy, len));
+        jobs_->push_back(make_scan_job(dec, geo_, scan, entropy, len, first_scan_only_));
         // leave the reader just before the next non-RST marker, like ProcessScan does (:167-176); the optimizer path only
         // wants the scan resolved (what follows it is its own marker walk's business): nothing is left to read
         reader.try_advance(first_scan_only_ ? (int)len : (int)find_scan_end(entropy, len));
@@ -160,6 +160,7 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
         file_len[i] = len[i];
         img.file_len = len[i];
         const size_t first_job = jobs_.size();
+        bool decoding = false;  // Identify() is over, Decode()'s marker loop is running
         try {
             if (len[i] > 0x7FFFFFF0u) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "JPEG streams of 2 GiB or more are not supported.");
             HostDecoder dec;
@@ -173,7 +174,9 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
             }
             img.sof = (uint8_t)dec.start_of_frame();
             PlanHandler handler(&jobs_, entropy_only_);
+            decoding = true;
             dec.decode(handler, true);
+            decoding = false;
             if (entropy_only_) img.sof = (uint8_t)dec.start_of_frame();
             if (jobs_.size() == first_job) {
                 // no scan: Decode() succeeds without writing anything; keep the frame geometry for the caller
@@ -188,13 +191,30 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
                 job_entropy_off_.push_back(jobs_[j].entropy ? (uint64_t)(jobs_[j].entropy - jpeg[i]) : 0u);
             }
         } catch (const DecodeError &e) {
-            jobs_.resize(first_job);
-            job_image_.resize(first_job);
-            job_entropy_off_.resize(first_job);
-            img.jobs.clear();
-            img.status = e.status;
-            img.detail = e.detail;
-            img.error = e.what();
+            // progressive frames are only complete at Dispose(): nothing of a frame that failed half-way is kept
+            bool keep = decoding && jobs_.size() > first_job;
+            for (size_t j = first_job; keep && j < jobs_.size(); j++) keep = jobs_[j].kind == kScanSequential;
+            if (keep) {
+                // scans handed to the scan decoder before the walk failed: they run, the failure is reported behind them
+                img.late_status = e.status;
+                img.late_detail = e.detail;
+                img.late_error = e.what();
+                plan_image_geometry(img, jobs_[first_job].geo);
+                img.blocks_per_mcu = (uint32_t)jobs_[first_job].blocks_per_mcu;
+                for (size_t j = first_job; j < jobs_.size(); j++) {
+                    img.jobs.push_back((int)j);
+                    job_image_.push_back(i);
+                    job_entropy_off_.push_back(jobs_[j].entropy ? (uint64_t)(jobs_[j].entropy - jpeg[i]) : 0u);
+                }
+            } else {
+                jobs_.resize(first_job);
+                job_image_.resize(first_job);
+                job_entropy_off_.resize(first_job);
+                img.jobs.clear();
+                img.status = e.status;
+                img.detail = e.detail;
+                img.error = e.what();
+            }
         }
     }
     return layout_and_upload(file_ptr, file_len);
@@ -485,7 +505,9 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             img.total_blocks += nblocks;
             compressed_bytes_ += s.data_len;
             // scans without restart intervals are decoded by the self-synchronising subsequence decoder (K2S)
-            const bool use_subseq = s.dri == 0 && s.total_mcus > 0 && s.data_len >= 512 && getenv("JPGPU_NO_SUBSEQ") == nullptr;
+            bool null_table = false;
+            for (int c = 0; c < job.scan_components; c++) null_table |= job.dc_slot[c] == kNullHuffSlot || job.ac_slot[c] == kNullHuffSlot;
+            const bool use_subseq = s.dri == 0 && s.total_mcus > 0 && s.data_len >= 512 && !null_table && getenv("JPGPU_NO_SUBSEQ") == nullptr;
             if (job.kind == kScanFrameOnly) {
                 // the Dispose() pass: IDCT work only
             } else if (use_subseq) {
@@ -822,10 +844,16 @@ int DeviceBatch::result(int i, jpgpu_image_result *res) {
             res->detail = (int32_t)detail;
             res->error_interval = st.first_error >> 8;
             // exception class thrown by the reference for each failure
-            res->status = detail == kDetailExpectRestart ? JPGPU_ERR_INVALID_OPERATION : JPGPU_ERR_INVALID_DATA;
+            res->status = (detail == kDetailExpectRestart || detail == kDetailNullTable) ? JPGPU_ERR_INVALID_OPERATION : JPGPU_ERR_INVALID_DATA;
             break;
         }
         if (st.decoded_mcus < h_scans_[j].total_mcus) res->detail = kDetailEarlyEoi;
+    }
+    if (res->status == JPGPU_OK && img->late_status != JPGPU_OK) {
+        res->status = img->late_status;
+        res->detail = img->late_detail;
+        ctx_->last_error = img->late_error;
+        return JPGPU_OK;
     }
     if (res->status == JPGPU_OK) {
         for (int j : img->jobs)

@@ -31,6 +31,11 @@ struct ImagePlan {
     int status = JPGPU_OK;
     int detail = 0;
     std::string error;
+    // a failure of the marker walk BEHIND a scan that was already handed to the scan decoder: the reference only meets it
+    // if that scan itself decodes (Decode() runs ProcessScan before it reads the next marker), so it is reported after the
+    // device-side status of the scans recorded before it
+    int late_status = JPGPU_OK, late_detail = 0;
+    std::string late_error;
     uint16_t width = 0, height = 0;
     uint8_t precision = 0, num_components = 0, sof = 0;
     uint32_t restart_interval = 0;

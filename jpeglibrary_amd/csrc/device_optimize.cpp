@@ -382,7 +382,8 @@ void OptimizeBatch::plan_file(Plan &p, const uint8_t *data, size_t len, bool str
                 have_frame = true;
                 break;
             }
-            case 0xC2: refuse(JPGPU_ERR_NOT_SUPPORTED, "Progressive JPEG is not supported currently.", kDetailUnsupportedFrame);
+            // StartOfFrame2 is not among Scan()'s cases (:95-146): a progressive frame header is skipped like an APPn segment and
+            // the first SOS then finds no frame header (the null reference below)
             case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
                 refuse(JPGPU_ERR_INVALID_DATA,
                        at_offset(r.consumed_byte_count(), ("This type of JPEG stream is not supported (StartOfFrame" + std::to_string(marker - 0xC0) + ").").c_str()),
@@ -858,6 +859,11 @@ int OptimizeBatch::result(int i, jpgpu_image_result *res, size_t *out_len) {
         if (check_saw_eoi) {
             res->status = JPGPU_ERR_INVALID_OPERATION;
             ctx_->last_error = "Operation is not valid due to the current state of the object.";
+        } else if (st.terminator == 0 && st.pad[2] >= 8) {
+            // the data ran out behind the scan with whole bytes left and no marker among them: Scan()'s marker loop fails (:82-86)
+            res->status = JPGPU_ERR_INVALID_DATA;
+            res->detail = kDetailBadHeader;
+            ctx_->last_error = "Failed to decode JPEG data at offset " + std::to_string(batch_.image(i)->file_len) + ". No marker found.";
         } else if (p.late_status != JPGPU_OK) {
             res->status = p.late_status;
             res->detail = p.late_detail;

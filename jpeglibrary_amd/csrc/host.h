@@ -222,8 +222,12 @@ struct ScanJob {
     std::string refuse;  // frame job: non-empty = report NotSupported once every scan of the frame decoded cleanly
 };
 // Builds a ScanJob (validates tables like ProcessScan :69-82). Throws DecodeError with the reference's messages.
+// optimizer_rules: JpegOptimizer's view of the same scan (JpegOptimizer.cs:381-413): quantisation tables play no part, and a
+// Huffman table that is not defined is only met (as a null reference) when a block that needs it is reached -- the slot
+// is kNullHuffSlot and the device walk reports kDetailNullTable there.
 ScanJob make_scan_job(const HostDecoder &dec, const BaselineGeometry &geo, const ScanHeader &scan, const uint8_t *entropy,
-                      size_t entropy_len);
+                      size_t entropy_len, bool optimizer_rules = false);
+constexpr uint8_t kNullHuffSlot = 0xFF;
 
 // Host side of JpegHuffmanProgressiveScanDecoder (ref: ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs): collects the
 // scans of one SOF2 frame; the entropy decoding and the Dispose() pass run on the GPU.

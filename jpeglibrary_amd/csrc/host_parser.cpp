@@ -638,7 +638,7 @@ BaselineGeometry BaselineGeometry::latch(const HostDecoder &dec, const FrameHead
 }
 
 ScanJob make_scan_job(const HostDecoder &dec, const BaselineGeometry &geo, const ScanHeader &scan, const uint8_t *entropy,
-                      size_t entropy_len) {
+                      size_t entropy_len, bool optimizer_rules) {
     ScanJob job;
     job.geo = geo;
     job.entropy = entropy;
@@ -648,6 +648,7 @@ ScanJob make_scan_job(const HostDecoder &dec, const BaselineGeometry &geo, const
     job.scan_components = dec.resolve_scan(geo.frame, scan, job.comp);
     for (int i = 0; i < job.scan_components; i++) {
         ResolvedScanComponent &c = job.comp[i];
+        if (optimizer_rules) continue;
         if (!c.dc || !c.ac)
             throw_invalid_data("Failed to decode JPEG data. Huffman table of component " + std::to_string(c.component_index) + " is not defined.", kDetailMissingTable);
         if (!c.quant)
@@ -665,9 +666,9 @@ ScanJob make_scan_job(const HostDecoder &dec, const BaselineGeometry &geo, const
     int nblk = 0;
     for (int i = 0; i < job.scan_components; i++) {
         ResolvedScanComponent &c = job.comp[i];
-        job.dc_slot[i] = slot_of(c.dc);
-        job.ac_slot[i] = slot_of(c.ac);
-        job.quant_copy[i] = *c.quant;
+        job.dc_slot[i] = c.dc ? slot_of(c.dc) : kNullHuffSlot;
+        job.ac_slot[i] = c.ac ? slot_of(c.ac) : kNullHuffSlot;
+        if (c.quant) job.quant_copy[i] = *c.quant;
         // block order inside an MCU: scan-component order, then y < v, then x < h (ref: ...BaselineScanDecoder.cs:107-118)
         for (int y = 0; y < c.v; y++)
             for (int x = 0; x < c.h; x++) {

@@ -3599,6 +3599,10 @@ __global__ __launch_bounds__(kTcThreads) void transcode_kernel(const uint8_t *__
             const uint32_t info = blk_info[b_in_mcu];
             b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
             const uint32_t dc_slot = info & 0xFFu, ac_slot = info >> 8;
+            if (dc_slot == 0xFFu) {  // the reference dereferences a table that was never defined
+                err = kDetailNullTable;
+                break;
+            }
             const LdsHuff hdc = lds_huff(tabs, dc_slot), hac = lds_huff(tabs, ac_slot);
             // DC (:470-476 / :839-847)
             uint32_t sym;
@@ -3619,6 +3623,10 @@ __global__ __launch_bounds__(kTcThreads) void transcode_kernel(const uint8_t *__
                 if (MODE != 0) tc_put<MODE>(w, bits, sym, dst);
             }
             // AC (:478-493 / :849-876)
+            if (ac_slot == 0xFFu) {
+                err = kDetailNullTable;
+                break;
+            }
             for (uint32_t i = 1; i < 64u;) {
                 err = ub_huff(r, hac, sym);
                 if (err != 0) break;
@@ -3664,6 +3672,8 @@ __global__ __launch_bounds__(kTcThreads) void transcode_kernel(const uint8_t *__
             atomicMin(&status[wk.scan].first_error, code);
             if (MODE == 1) sizes[s.ends_off + interval] = 0;
         }
+        // whole bytes the scan leaves unread: if no marker follows them the reference's outer loop fails ("No marker found.")
+        if (MODE == 0 && err == 0 && interval == n_intervals - 1) status[wk.scan].pad[2] = (uint32_t)(r.rem > 0 ? r.rem : 0);
     } else if (MODE == 1 && interval < n_intervals) {
         sizes[s.ends_off + interval] = 0;  // intervals the marker index never found (EOI came early / data ran out)
     }
@@ -3805,6 +3815,7 @@ __global__ __launch_bounds__(256) void subseq_transcode_kernel(const uint8_t *__
     if (MODE == 2 && live && sub_bits[slot] == 0) count = 0;
     uint32_t err = 0;
     uint32_t nbits = 0;  // bits this lane produces
+    uint32_t leftover_bits = 0;  // bits of the stream behind this lane's last block
     if (live && count != 0) {
         UBits r;
         const uint32_t start_bit = (sub << s.sub_shift) + (entry & 63u);
@@ -3896,6 +3907,7 @@ __global__ __launch_bounds__(256) void subseq_transcode_kernel(const uint8_t *__
             b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
             info = blk_info[b_in_mcu];
         }
+        leftover_bits = (uint32_t)(r.rem > 0 ? r.rem : 0);
         if (MODE == 2 && err == 0) {
             if (my_end == total_blocks) {
                 // ExitBitMode (JpegWriter.cs:141-166): the lane that writes the scan's last block pads the last byte with ones
@@ -3908,6 +3920,7 @@ __global__ __launch_bounds__(256) void subseq_transcode_kernel(const uint8_t *__
     }
     if (MODE == 1 && sub < s.n_subs) sub_bits[slot] = err == 0 ? nbits : 0u;
     if (live && err != 0) atomicMin(&status[wk.scan].first_error, (sub << 8) | err);
+    if (MODE == 0 && live && err == 0 && count != 0 && my_end == total_blocks) status[wk.scan].pad[2] = leftover_bits;
     if (MODE == 0) {
         __syncthreads();
         uint32_t *gh = hist + (size_t)wk.scan * kMaxHuffSlots * 256u;

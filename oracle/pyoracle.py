@@ -237,7 +237,7 @@ def encode_8bit(pixels: np.ndarray, luma_h: int = 2, luma_v: int = 2, quality: i
     mcus = (-(-w // (8 * mh))) * (-(-h // (8 * mv)))
     nblocks = mcus * (mh * mv + (2 if ncomp == 3 else 0))
     coefs = np.zeros((nblocks, 64), np.int16) if want_coefficients else None
-    cap = 1024 + w * h * c * 2 + nblocks * 8
+    cap = 2048 + nblocks * 512  # 64 symbols x (16 + 11) bits per block, every byte stuffed, with room to spare
     out = np.empty(cap, np.uint8)
     n = C.c_size_t(0)
     rc = L.jref_encode_8bit_ex(a.ctypes.data, w, h, c, luma_h, luma_v, quality, int(optimize_coding), out.ctypes.data, cap, C.byref(n),

@@ -92,6 +92,101 @@ for strip in (True, False):
                 bad += 1
                 print("optimize bytes", i, strip, kinds[i])
     b.close()
+# ---- corrupted streams: random edits of the entropy-coded part (and sometimes of a header byte) of baseline files
+def mutate(data, rng):
+    sos = data.index(b"\xff\xda")
+    lo = sos + 4 + data[sos + 3]
+    b = bytearray(data)
+    kind = int(rng.integers(0, 8))
+    if len(b) - 2 <= lo:
+        return bytes(b)
+    pos = int(rng.integers(lo, len(b) - 2))
+    if kind == 0:
+        b[pos] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 1:
+        del b[pos:pos + int(rng.integers(1, 6))]
+    elif kind == 2:
+        b[pos:pos] = bytes(rng.integers(0, 256, int(rng.integers(1, 6))).astype(np.uint8))
+    elif kind == 3:
+        b[pos:pos + 2] = bytes([0xFF, int(rng.choice([0xD0, 0xD3, 0xD7, 0xD9, 0xC4, 0xDA, 0x00, 0xFF, 0xE1, 0xC2]))])
+    elif kind == 4:
+        b = b[:pos] + b"\xff\xd9"
+    elif kind == 5:
+        k = int(rng.integers(1, 40))
+        b[pos:pos + k] = bytes(k)
+    elif kind == 6:
+        k = int(rng.integers(1, 40))
+        b[pos:pos + k] = b"\xff" * k
+    else:
+        hp = int(rng.integers(2, lo))  # a header byte
+        b[hp] ^= 1 << int(rng.integers(0, 8))
+    return bytes(b)
+
+
+def dc_category_above_16(data):
+    """A DHT that gives a DC table a symbol above 16: outside the verified envelope."""
+    i = 2
+    while i + 4 <= len(data):
+        if data[i] != 0xFF:
+            i += 1
+            continue
+        m = data[i + 1]
+        if m in (0x00, 0xFF) or 0xD0 <= m <= 0xD9:
+            i += 2
+            continue
+        ln = (data[i + 2] << 8) | data[i + 3]
+        if m == 0xC4:
+            seg, j = data[i + 4:i + 2 + ln], 0
+            while j + 17 <= len(seg):
+                cnt = sum(seg[j + 1:j + 17])
+                if (seg[j] >> 4) == 0 and any(v > 16 for v in seg[j + 17:j + 17 + cnt]):
+                    return True
+                j += 17 + cnt
+        if m == 0xDA:
+            return False
+        i += 2 + ln
+    return False
+
+
+n_mut = 0
+mut = [mutate(f, rng) for f, k in zip(files, kinds) if not k[3]][: max(100, n // 3)]
+mut = [f for f in mut if not dc_category_above_16(f)]
+refs = []
+for f in mut:
+    try:
+        refs.append(("OK", po.decode_8bit(f)[0]))
+    except po.OracleError as e:
+        refs.append((e.kind, None))
+outs, results = jl.decode_batch(mut, jl.FMT_INTERLEAVED_U8)
+for i, ((kind, px), out, res) in enumerate(zip(refs, outs, results)):
+    mine = names.get(res.status, str(res.status))
+    n_mut += 1
+    if mine == "NotSupportedException" and kind != mine and res.detail == 6:
+        continue  # documented fence (DESIGN.md 5): frame types / scan sequences outside the path
+    if mine != kind:
+        bad += 1
+        print("mutated decode status", i, kind, mine, res.detail)
+    elif kind == "OK" and res.detail != 8 and not np.array_equal(np.asarray(out), px):
+        bad += 1
+        print("mutated decode pixels", i)
+b = jl.OptimizeBatch().upload(mut, True).run()
+for i, f in enumerate(mut):
+    res, size = b.result(i)
+    mine = names.get(res.status, str(res.status))
+    if mine == "NotSupportedException":
+        continue
+    try:
+        ref, kind = po.optimize(f, True), "OK"
+    except po.OracleError as e:
+        ref, kind = None, e.kind
+    if mine != kind:
+        bad += 1
+        print("mutated optimize status", i, kind, mine, res.detail)
+    elif ref is not None and b.output(i) != ref:
+        bad += 1
+        print("mutated optimize bytes", i)
+b.close()
+
 # ---- encoder: random images / samplings / qualities / table modes, grouped by the parameters one batch shares
 n_enc = 0
 groups = {}
@@ -123,5 +218,5 @@ for (luma, q, mode, rgb), imgs in groups.items():
             bad += 1
             print("encode", luma, q, mode, rgb, im.shape, None if got is None else len(got), None if ref is None else len(ref))
     e.close()
-print(f"stress: {n} files, {sum(k[3] for k in kinds)} progressive, {n_opt} optimizer outputs compared, {n_enc} encoder outputs compared, mismatches: {bad}")
+print(f"stress: {n} files, {sum(k[3] for k in kinds)} progressive, {n_opt} optimizer outputs compared, {n_enc} encoder outputs compared, {n_mut} corrupted files, mismatches: {bad}")
 sys.exit(1 if bad else 0)
