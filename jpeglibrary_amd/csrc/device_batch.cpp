@@ -59,6 +59,13 @@ namespace {
 class PlanHandler final : public ScanHandler {
   public:
     explicit PlanHandler(std::vector<ScanJob> *jobs, bool first_scan_only = false) : jobs_(jobs), first_scan_only_(first_scan_only) {}
+    // Second walk of a file whose sequential scans are already planned (`ends` = where each one's data stops): nothing is
+    // recorded, and scan number `swallow` leaves the reader ONE byte into its terminating marker.  That is where the
+    // reference's reader stands when exactly one whole byte was left in the bit reader behind the last block: the marker
+    // has been pulled into the bit reader, TryPeekMarker() only shows it once the buffer is empty, so the two bytes are
+    // not given back (ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:167-176, JpegBitReader.cs:152-155).
+    PlanHandler(const std::vector<size_t> *ends, int swallow) : jobs_(nullptr), replay_ends_(ends), swallow_(swallow) {}
+    const std::vector<size_t> &sequential_ends() const { return ends_; }
     void on_frame(HostDecoder &dec, int sof) override {
         sof_ = sof;
         baseline_ = false;
@@ -79,7 +86,19 @@ class PlanHandler final : public ScanHandler {
         }
         if (!baseline_)
             throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "Only Huffman DCT frames (SOF0, SOF1, SOF2) run on this path.", kDetailUnsupportedFrame);
+        if (replay_ends_) {
+            const int k = replayed_++;
+            if (k > swallow_ || k >= (int)replay_ends_->size())
+                throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "A scan behind a scan that left one byte unread is not supported.", kDetailUnsupportedFrame);
+            reader.try_advance((int)(*replay_ends_)[k] + (k == swallow_ ? 1 : 0));
+            return;
+        }
         jobs_->push_back(make_scan_job(dec, geo_, scan, entropy, len, first_scan_only_));
+        if (!first_scan_only_) {
+            ends_.push_back(find_scan_end(entropy, len));
+            reader.try_advance((int)ends_.back());
+            return;
+        }
         // leave the reader just before the next non-RST marker, like ProcessScan does (:167-176); the optimizer path only
         // wants the scan resolved (what follows it is its own marker walk's business): nothing is left to read
         reader.try_advance(first_scan_only_ ? (int)len : (int)find_scan_end(entropy, len));
@@ -92,7 +111,7 @@ class PlanHandler final : public ScanHandler {
     // Dispose() of the progressive scan decoder: the frame's IDCT pass, then its entropy scans in file order
     void flush_progressive() {
         if (!prog_.active()) return;
-        if (!prog_.scans().empty()) {
+        if (!prog_.scans().empty() && jobs_) {
             jobs_->push_back(prog_.make_frame_job());
             for (ScanJob &j : prog_.scans()) jobs_->push_back(std::move(j));
             prog_geo_ = prog_.geo();
@@ -101,6 +120,9 @@ class PlanHandler final : public ScanHandler {
         prog_.reset();
     }
     std::vector<ScanJob> *jobs_;
+    std::vector<size_t> ends_;
+    const std::vector<size_t> *replay_ends_ = nullptr;
+    int swallow_ = -1, replayed_ = 0;
     bool first_scan_only_ = false;
     BaselineGeometry geo_, prog_geo_;
     bool prog_geo_valid_ = false;
@@ -161,6 +183,7 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
         img.file_len = len[i];
         const size_t first_job = jobs_.size();
         bool decoding = false;  // Identify() is over, Decode()'s marker loop is running
+        std::vector<size_t> seq_ends;
         try {
             if (len[i] > 0x7FFFFFF0u) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "JPEG streams of 2 GiB or more are not supported.");
             HostDecoder dec;
@@ -175,7 +198,12 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
             img.sof = (uint8_t)dec.start_of_frame();
             PlanHandler handler(&jobs_, entropy_only_);
             decoding = true;
-            dec.decode(handler, true);
+            try {
+                dec.decode(handler, true);
+            } catch (...) {
+                seq_ends = handler.sequential_ends();
+                throw;
+            }
             decoding = false;
             if (entropy_only_) img.sof = (uint8_t)dec.start_of_frame();
             if (jobs_.size() == first_job) {
@@ -190,6 +218,7 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
                 job_image_.push_back(i);
                 job_entropy_off_.push_back(jobs_[j].entropy ? (uint64_t)(jobs_[j].entropy - jpeg[i]) : 0u);
             }
+            seq_ends = handler.sequential_ends();
         } catch (const DecodeError &e) {
             // progressive frames are only complete at Dispose(): nothing of a frame that failed half-way is kept
             bool keep = decoding && jobs_.size() > first_job;
@@ -216,8 +245,37 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
                 img.error = e.what();
             }
         }
+        if (!entropy_only_ && img.status == JPGPU_OK) plan_swallowed_terminator(img, jpeg[i], len[i], seq_ends);
     }
     return layout_and_upload(file_ptr, file_len);
+}
+
+// What Decode() ends in when the LAST sequential scan of the file leaves its reader one byte into the terminating marker.
+void DeviceBatch::plan_swallowed_terminator(ImagePlan &img, const uint8_t *file, size_t len, const std::vector<size_t> &ends) {
+    img.swallow_status = JPGPU_OK;
+    img.swallow_detail = 0;
+    img.swallow_error.clear();
+    img.swallow_job = -1;
+    if (ends.empty() || img.jobs.empty()) return;
+    int last = -1, n_seq = 0;
+    for (int j : img.jobs)
+        if (jobs_[j].kind == kScanSequential) {
+            last = j;
+            n_seq++;
+        }
+    if (last < 0 || n_seq != (int)ends.size() || ends.back() >= jobs_[last].entropy_len) return;  // no marker behind it
+    img.swallow_job = last;
+    try {
+        HostDecoder dec;
+        dec.set_input(file, len);
+        dec.identify(false);
+        PlanHandler replay(&ends, n_seq - 1);
+        dec.decode(replay, true);
+    } catch (const DecodeError &e) {
+        img.swallow_status = e.status;
+        img.swallow_detail = e.detail;
+        img.swallow_error = e.what();
+    }
 }
 
 int DeviceBatch::upload_single_job(const ScanJob &job, int format, const void *initial_output, size_t initial_output_bytes) {
@@ -834,6 +892,7 @@ int DeviceBatch::result(int i, jpgpu_image_result *res) {
     int rc = fetch_status();
     if (rc != JPGPU_OK) return rc;
     res->status = JPGPU_OK;
+    bool swallowed = false;
     for (int j : img->jobs) {
         const DevScanStatus &st = h_status_[j];
         res->decoded_mcus = st.decoded_mcus;
@@ -848,6 +907,22 @@ int DeviceBatch::result(int i, jpgpu_image_result *res) {
             break;
         }
         if (st.decoded_mcus < h_scans_[j].total_mcus) res->detail = kDetailEarlyEoi;
+        if (!entropy_only_ && jobs_[j].kind == kScanSequential && st.terminator != 0 && (st.pad[2] >> 3) == 1 && st.decoded_mcus >= h_scans_[j].total_mcus) {
+            // one whole byte left behind the last block: the reference resumes its walk inside the terminating marker
+            if (j != img->swallow_job) {
+                res->status = JPGPU_ERR_NOT_SUPPORTED;
+                res->detail = kDetailUnsupportedFrame;
+                ctx_->last_error = "A scan that leaves one byte unread in front of its terminating marker is only supported as the last scan.";
+                return JPGPU_OK;
+            }
+            swallowed = true;
+        }
+    }
+    if (res->status == JPGPU_OK && swallowed) {
+        res->status = img->swallow_status;
+        if (res->status != JPGPU_OK) res->detail = img->swallow_detail;
+        ctx_->last_error = img->swallow_error;
+        return JPGPU_OK;
     }
     if (res->status == JPGPU_OK && img->late_status != JPGPU_OK) {
         res->status = img->late_status;

@@ -36,6 +36,10 @@ struct ImagePlan {
     // device-side status of the scans recorded before it
     int late_status = JPGPU_OK, late_detail = 0;
     std::string late_error;
+    // what the walk ends in instead when scan job `swallow_job` (the file's last sequential scan) leaves exactly one whole
+    // byte unread: the reference's reader then resumes one byte INTO the terminating marker (plan_swallowed_terminator)
+    int swallow_job = -1, swallow_status = JPGPU_OK, swallow_detail = 0;
+    std::string swallow_error;
     uint16_t width = 0, height = 0;
     uint8_t precision = 0, num_components = 0, sof = 0;
     uint32_t restart_interval = 0;
@@ -103,6 +107,7 @@ class DeviceBatch {
     int hip_fail(hipError_t e, const char *what);
     int layout_and_upload(const std::vector<const uint8_t *> &file_ptr, const std::vector<size_t> &file_len);
     void plan_image_geometry(ImagePlan &img, const BaselineGeometry &geo);
+    void plan_swallowed_terminator(ImagePlan &img, const uint8_t *file, size_t len, const std::vector<size_t> &ends);
     int fetch_status();
 
     jpgpu_ctx *ctx_;

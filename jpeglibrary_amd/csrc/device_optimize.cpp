@@ -344,9 +344,19 @@ struct Refuse {
 std::string at_offset(int off, const char *msg) { return "Failed to decode JPEG data at offset " + std::to_string(off) + ". " + msg; }
 }  // namespace
 
+// find_scan_end of the scan the walks of one file keep coming back to (four walks, one search)
+size_t OptimizeBatch::scan_end(const uint8_t *entropy, size_t len) {
+    if (entropy != end_key_ || len != end_len_) {
+        end_key_ = entropy;
+        end_len_ = len;
+        end_val_ = find_scan_end(entropy, len);
+    }
+    return end_val_;
+}
+
 // Scan()'s and Optimize()'s marker walks (JpegOptimizer.cs:66-153, :540-648) on the host.  Leaves the pieces of the
 // output in p.pieces; the scan itself is located for the device passes.
-void OptimizeBatch::plan_file(Plan &p, const uint8_t *data, size_t len, bool strip) {
+void OptimizeBatch::plan_file(Plan &p, const uint8_t *data, size_t len, bool strip, bool swallow_terminator) {
     // ---- Scan(): tables, frame, restart interval as of the scan; exactly one scan
     std::vector<QuantTable> quant;  // _quantizationTables: replace by identifier, else append (:319-338)
     bool after_scan = false;  // from here on a failure of the walks is only met once the scan itself went through
@@ -423,8 +433,8 @@ void OptimizeBatch::plan_file(Plan &p, const uint8_t *data, size_t len, bool str
                 dri_at_scan = dri;
                 p.dri_at_scan = dri;
                 after_scan = true;
-                const size_t end = find_scan_end(r.remaining_bytes(), (size_t)r.remaining_byte_count());
-                r.try_advance((int)end);
+                const size_t end = scan_end(r.remaining_bytes(), (size_t)r.remaining_byte_count());
+                r.try_advance((int)end + (swallow_terminator && end < (size_t)r.remaining_byte_count() ? 1 : 0));
                 break;
             }
             case 0xD0: case 0xD1: case 0xD2: case 0xD3: case 0xD4: case 0xD5: case 0xD6: case 0xD7: break;
@@ -517,8 +527,8 @@ void OptimizeBatch::plan_file(Plan &p, const uint8_t *data, size_t len, bool str
             copy_segment(nullptr, nullptr);
             flush();
             p.pieces.push_back({Piece::kEntropy, std::string()});
-            const size_t end = find_scan_end(r.remaining_bytes(), (size_t)r.remaining_byte_count());
-            r.try_advance((int)end);
+            const size_t end = scan_end(r.remaining_bytes(), (size_t)r.remaining_byte_count());
+            r.try_advance((int)end + (swallow_terminator && end < (size_t)r.remaining_byte_count() ? 1 : 0));
             break;
         }
         case 0xD0: case 0xD1: case 0xD2: case 0xD3: case 0xD4: case 0xD5: case 0xD6: case 0xD7: put_marker(cur, marker); break;
@@ -562,6 +572,29 @@ int OptimizeBatch::upload(const uint8_t *const *jpeg, const size_t *len, int n, 
             plans_[i].detail = e.detail;
             plans_[i].error = e.msg;
             plans_[i].pieces.clear();
+        }
+        if (plans_[i].status == JPGPU_OK) {
+            // the same walks with the reader resuming inside the scan's terminating marker: only the verdict is kept (a
+            // walk that still goes through would write a different file: refused)
+            Plan &p = plans_[i];
+            Plan alt;
+            p.swallow_status = JPGPU_ERR_NOT_SUPPORTED;
+            p.swallow_detail = kDetailUnsupportedFrame;
+            p.swallow_error = "A scan that leaves one byte unread in front of its terminating marker is not supported by the optimizer path.";
+            try {
+                plan_file(alt, jpeg[i], len[i], strip != 0, true);
+                if (alt.late_status != JPGPU_OK) {
+                    p.swallow_status = alt.late_status;
+                    p.swallow_detail = alt.late_detail;
+                    p.swallow_error = alt.late_error;
+                }
+            } catch (const Refuse &e) {
+                if (e.status != JPGPU_ERR_NOT_SUPPORTED) {
+                    p.swallow_status = e.status;
+                    p.swallow_detail = e.detail;
+                    p.swallow_error = e.msg;
+                }
+            }
         }
     }
     // the decoder-side parser resolves the scan (tables, geometry, restart interval) and lays the files out in HBM
@@ -864,6 +897,10 @@ int OptimizeBatch::result(int i, jpgpu_image_result *res, size_t *out_len) {
             res->status = JPGPU_ERR_INVALID_DATA;
             res->detail = kDetailBadHeader;
             ctx_->last_error = "Failed to decode JPEG data at offset " + std::to_string(batch_.image(i)->file_len) + ". No marker found.";
+        } else if (st.terminator != 0 && (st.pad[2] >> 3) == 1) {
+            res->status = p.swallow_status;
+            res->detail = p.swallow_detail;
+            ctx_->last_error = p.swallow_error;
         } else if (p.late_status != JPGPU_OK) {
             res->status = p.late_status;
             res->detail = p.late_detail;

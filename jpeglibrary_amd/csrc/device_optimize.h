@@ -47,6 +47,10 @@ class OptimizeBatch {
         // (Scan() throws from ProcessScanBaseline first), so they are reported after the device-side status
         int late_status = JPGPU_OK, late_detail = 0;
         std::string late_error;
+        // ... and what the walks end in instead when the scan leaves exactly one whole byte unread: the reference's reader
+        // then resumes one byte INTO the terminating marker (DeviceBatch::plan_swallowed_terminator has the mechanism)
+        int swallow_status = JPGPU_OK, swallow_detail = 0;
+        std::string swallow_error;
         int dri_at_scan = 0;
         std::vector<Piece> pieces;
         int job = -1;  // scan job inside batch_
@@ -57,7 +61,10 @@ class OptimizeBatch {
     };
     int fail(int status, const std::string &msg);
     int hip_fail(hipError_t e, const char *what);
-    void plan_file(Plan &p, const uint8_t *data, size_t len, bool strip);
+    void plan_file(Plan &p, const uint8_t *data, size_t len, bool strip, bool swallow_terminator = false);
+    size_t scan_end(const uint8_t *entropy, size_t len);
+    const uint8_t *end_key_ = nullptr;
+    size_t end_len_ = 0, end_val_ = 0;
 
     jpgpu_ctx *ctx_;
     DeviceBatch batch_;

@@ -158,7 +158,7 @@ class HostDecoder {
     size_t input_len() const { return input_len_; }
 
     // ref: InitDecodeComponents (ScanDecoder/JpegHuffmanScanDecoder.cs:17-72)
-    int resolve_scan(const FrameHeader &fh, const ScanHeader &sh, ResolvedScanComponent out[kMaxScanComponents]) const;
+    int resolve_scan(const FrameHeader &fh, const ScanHeader &sh, ResolvedScanComponent out[kMaxScanComponents], bool optimizer_rules = false) const;
 
   private:
     bool process_marker_for_identification(int marker, MarkerReader &r, bool load_qt);  // :114-162

@@ -589,13 +589,15 @@ void HostDecoder::load_tables(const uint8_t *data, size_t len) {
     }
 }
 
-int HostDecoder::resolve_scan(const FrameHeader &fh, const ScanHeader &sh, ResolvedScanComponent out[kMaxScanComponents]) const {
+int HostDecoder::resolve_scan(const FrameHeader &fh, const ScanHeader &sh, ResolvedScanComponent out[kMaxScanComponents], bool optimizer_rules) const {
     int max_h = 1, max_v = 1;
     for (const FrameComponent &c : fh.components) {
         max_h = std::max(max_h, (int)c.h);
         max_v = std::max(max_v, (int)c.v);
     }
-    if ((int)fh.num_components < (int)sh.num_components) throw_invalid_operation("Operation is not valid due to the current state of the object.");
+    // JpegOptimizer's own resolution (JpegOptimizer.cs:375-393) has no such check: it only fails on a selector no frame component carries
+    if (!optimizer_rules && (int)fh.num_components < (int)sh.num_components)
+        throw_invalid_operation("Operation is not valid due to the current state of the object.");
     if (sh.num_components > kMaxScanComponents) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "More than 4 components in a scan are not supported.", kDetailUnsupportedFrame);
     for (int i = 0; i < sh.num_components; i++) {
         const ScanComponent &sc = sh.components[i];
@@ -606,7 +608,7 @@ int HostDecoder::resolve_scan(const FrameHeader &fh, const ScanHeader &sh, Resol
                 component_index = j;
                 fc = &fh.components[j];
             }
-        if (!fc) throw_invalid_data("Failed to decode JPEG data. The specified component is missing.", kDetailBadHeader);
+        if (!fc) throw_invalid_data(optimizer_rules ? "Found invalid data while decoding." : "Failed to decode JPEG data. The specified component is missing.", kDetailBadHeader);
         if (fc->h == 0 || fc->v == 0) throw_invalid_data("Failed to decode JPEG data. Attempted to divide by zero.", kDetailBadHeader);
         ResolvedScanComponent &c = out[i];
         c.component_index = component_index;
@@ -645,7 +647,7 @@ ScanJob make_scan_job(const HostDecoder &dec, const BaselineGeometry &geo, const
     job.entropy_len = entropy_len;
     if (geo.frame.components.empty() && geo.frame.num_components)
         throw_invalid_data("Failed to decode JPEG data. Component parameters are missing in JPEG frame header.", kDetailBadHeader);
-    job.scan_components = dec.resolve_scan(geo.frame, scan, job.comp);
+    job.scan_components = dec.resolve_scan(geo.frame, scan, job.comp, optimizer_rules);
     for (int i = 0; i < job.scan_components; i++) {
         ResolvedScanComponent &c = job.comp[i];
         if (optimizer_rules) continue;

@@ -493,6 +493,9 @@ __device__ __forceinline__ uint32_t stage_addr(uint32_t blk, uint32_t coef_index
 __device__ __forceinline__ uint32_t restart_check(const DevScan &s, const DevScanStatus &st, DevScanStatus *status_out, uint32_t interval,
                                                   uint32_t n_ends, uint32_t n_intervals, uint32_t dri_eff, int32_t rem, uint32_t err) {
     if (err != 0) return (interval << 8) | err;
+    // bits left behind the scan's last block when the scan's terminating marker closes that interval: the host needs the
+    // whole bytes among them for the reader position the reference resumes its marker walk from (:167-176)
+    if (interval == n_intervals - 1) status_out->pad[2] = (interval == n_ends - 1 && rem > 0) ? (uint32_t)rem : 0u;
     const bool needs_check = s.dri != 0 && (interval < n_intervals - 1 || s.restart_check_at_end);
     if (!needs_check) return kNoError;
     uint32_t closing = 0xD0;  // entries before the last indexed one are RSTn by construction
@@ -2596,6 +2599,8 @@ __global__ __launch_bounds__(64 * kSubFinalWaves) void subseq_final_kernel(const
         // failure on the true path: same detail codes as the interval decoder; "interval" field carries the subsequence
         atomicMin(&status[wk.scan].first_error, (sub << 8) | err);
     }
+    // bits left behind the scan's last block (see restart_check)
+    if (live && err == 0 && count != 0 && my_end == total_blocks) status[wk.scan].pad[2] = r.rem > 0 ? (uint32_t)r.rem : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3672,8 +3677,6 @@ __global__ __launch_bounds__(kTcThreads) void transcode_kernel(const uint8_t *__
             atomicMin(&status[wk.scan].first_error, code);
             if (MODE == 1) sizes[s.ends_off + interval] = 0;
         }
-        // whole bytes the scan leaves unread: if no marker follows them the reference's outer loop fails ("No marker found.")
-        if (MODE == 0 && err == 0 && interval == n_intervals - 1) status[wk.scan].pad[2] = (uint32_t)(r.rem > 0 ? r.rem : 0);
     } else if (MODE == 1 && interval < n_intervals) {
         sizes[s.ends_off + interval] = 0;  // intervals the marker index never found (EOI came early / data ran out)
     }

@@ -148,6 +148,14 @@ def dc_category_above_16(data):
     return False
 
 
+def keep(tag, i, data):
+    """Mismatching inputs go to gpurun_out/stress/ (merged back from the GPU box) for a CPU-side look."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "stress")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, f"seed{sys.argv[2] if len(sys.argv) > 2 else 1}_{tag}_{i}.jpg"), "wb") as fh:
+        fh.write(data)
+
+
 n_mut = 0
 mut = [mutate(f, rng) for f, k in zip(files, kinds) if not k[3]][: max(100, n // 3)]
 mut = [f for f in mut if not dc_category_above_16(f)]
@@ -166,9 +174,11 @@ for i, ((kind, px), out, res) in enumerate(zip(refs, outs, results)):
     if mine != kind:
         bad += 1
         print("mutated decode status", i, kind, mine, res.detail)
+        keep("dec", i, mut[i])
     elif kind == "OK" and res.detail != 8 and not np.array_equal(np.asarray(out), px):
         bad += 1
         print("mutated decode pixels", i)
+        keep("decpx", i, mut[i])
 b = jl.OptimizeBatch().upload(mut, True).run()
 for i, f in enumerate(mut):
     res, size = b.result(i)
@@ -182,9 +192,11 @@ for i, f in enumerate(mut):
     if mine != kind:
         bad += 1
         print("mutated optimize status", i, kind, mine, res.detail)
+        keep("opt", i, f)
     elif ref is not None and b.output(i) != ref:
         bad += 1
         print("mutated optimize bytes", i)
+        keep("optb", i, f)
 b.close()
 
 # ---- encoder: random images / samplings / qualities / table modes, grouped by the parameters one batch shares
