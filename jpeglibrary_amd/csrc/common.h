@@ -67,7 +67,7 @@ struct alignas(16) DevScan {
     uint16_t width, height;  // frame SamplesPerLine / NumberOfLines
     uint8_t precision, frame_components, scan_components, max_h, max_v, blocks_per_mcu;
     uint8_t restart_check_at_end;  // dri > 0 && total_mcus % dri == 0: the reference runs the restart check after the last MCU
-    uint8_t pad0;
+    uint8_t shadow_mask;  // bit c: a later scan component resolves to the same frame component; c's blocks never reach the output
     DevScanComponent comp[kMaxScanComponents];
     uint8_t blk_comp[kMaxBlocksPerMcu];  // block-in-MCU -> scan component slot
     uint8_t blk_x[kMaxBlocksPerMcu];     // block-in-MCU -> x, y inside the component's MCU footprint

@@ -184,9 +184,10 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
         const size_t first_job = jobs_.size();
         bool decoding = false;  // Identify() is over, Decode()'s marker loop is running
         std::vector<size_t> seq_ends;
+        HostDecoder dec;
+        PlanHandler handler(&jobs_, entropy_only_);
         try {
             if (len[i] > 0x7FFFFFF0u) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "JPEG streams of 2 GiB or more are not supported.");
-            HostDecoder dec;
             dec.set_input(jpeg[i], len[i]);
             if (entropy_only_) {
                 // optimizer path: JpegOptimizer.Scan() runs no Identify(); the restart interval is the one in force at the
@@ -196,7 +197,6 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
                 dec.identify(false);  // every reference caller runs Identify before Decode; it latches the LAST DRI (F4)
             }
             img.sof = (uint8_t)dec.start_of_frame();
-            PlanHandler handler(&jobs_, entropy_only_);
             decoding = true;
             try {
                 dec.decode(handler, true);
@@ -220,9 +220,15 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
             }
             seq_ends = handler.sequential_ends();
         } catch (const DecodeError &e) {
-            // progressive frames are only complete at Dispose(): nothing of a frame that failed half-way is kept
-            bool keep = decoding && jobs_.size() > first_job;
-            for (size_t j = first_job; keep && j < jobs_.size(); j++) keep = jobs_[j].kind == kScanSequential;
+            // the scans of a progressive frame recorded before the walk failed ran in the reference too (each ProcessScan
+            // decodes its scan on the spot): they are kept so that their own failures come first
+            if (decoding && e.status != JPGPU_ERR_NOT_SUPPORTED) {
+                try {
+                    handler.on_dispose(dec);
+                } catch (const DecodeError &) {
+                }
+            }
+            bool keep = decoding && jobs_.size() > first_job && e.status != JPGPU_ERR_NOT_SUPPORTED;
             if (keep) {
                 // scans handed to the scan decoder before the walk failed: they run, the failure is reported behind them
                 img.late_status = e.status;
@@ -296,6 +302,7 @@ int DeviceBatch::upload_single_job(const ScanJob &job, int format, const void *i
     int rc = layout_and_upload(fp, fl);
     if (rc != JPGPU_OK) return rc;
     if (initial_output && initial_output_bytes) {
+        out_clear_.clear();  // the caller's buffer is the canvas: what this scan does not write keeps the caller's samples
         const size_t nbytes = std::min<size_t>(initial_output_bytes, img.out_bytes);
         hipError_t e = hipMemcpyAsync((uint8_t *)d_out_.ptr + img.out_offset, initial_output, nbytes, hipMemcpyHostToDevice, ctx_->stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(initial output)");
@@ -536,6 +543,10 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                     s.plane_pitch[c] = img.plane[fc].pitch;
                 }
             }
+            s.shadow_mask = 0;
+            for (int c = 0; c < job.scan_components; c++)
+                for (int d = c + 1; d < job.scan_components; d++)
+                    if (job.comp[c].component_index == job.comp[d].component_index) s.shadow_mask |= (uint8_t)(1u << c);
             memcpy(s.blk_comp, job.blk_comp, sizeof s.blk_comp);
             memcpy(s.blk_x, job.blk_x, sizeof s.blk_x);
             memcpy(s.blk_y, job.blk_y, sizeof s.blk_y);
@@ -565,7 +576,8 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             // scans without restart intervals are decoded by the self-synchronising subsequence decoder (K2S)
             bool null_table = false;
             for (int c = 0; c < job.scan_components; c++) null_table |= job.dc_slot[c] == kNullHuffSlot || job.ac_slot[c] == kNullHuffSlot;
-            const bool use_subseq = s.dri == 0 && s.total_mcus > 0 && s.data_len >= 512 && !null_table && getenv("JPGPU_NO_SUBSEQ") == nullptr;
+            const bool use_subseq = s.dri == 0 && s.total_mcus > 0 && s.data_len >= 512 && !null_table && getenv("JPGPU_NO_SUBSEQ") == nullptr &&
+                                    !(entropy_only_ && (size_t)ii < preset_no_subseq_.size() && preset_no_subseq_[ii]);
             if (job.kind == kScanFrameOnly) {
                 // the Dispose() pass: IDCT work only
             } else if (use_subseq) {
@@ -609,6 +621,20 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     for (const std::vector<HuffWork> &w : prog_streams_by_ordinal) {
         prog_work.insert(prog_work.end(), w.begin(), w.end());
         prog_stream_begin_.push_back((int)prog_work.size());
+    }
+    // Images whose scans do not cover every frame component (a scan header that names one component twice and another never;
+    // no scan at all): the reference leaves those samples of the caller's buffer alone.  The batch owns the output buffer,
+    // so "alone" is defined as zero, what a freshly allocated managed array holds.
+    out_clear_.clear();
+    for (const ImagePlan &img : images_) {
+        if (img.status != JPGPU_OK || img.out_bytes == 0) continue;
+        uint32_t covered = 0;
+        for (int j : img.jobs) {
+            const DevScan &s = h_scans_[j];
+            if (jobs_[j].kind == kScanProgressive) continue;
+            for (int c = 0; c < s.scan_components; c++) covered |= 1u << s.comp[c].component_index;
+        }
+        if (covered != (1u << img.num_components) - 1u) out_clear_.push_back({img.out_offset, img.out_bytes});
     }
     idct_class_begin_[0] = 0;
     for (int c = 0; c < kNumIdctLayoutClasses; c++) {
@@ -770,8 +796,20 @@ int DeviceBatch::run_progressive() {
     }
     return JPGPU_OK;
 }
+int DeviceBatch::clear_partial_outputs() {
+    for (const auto &c : out_clear_) {
+        hipError_t e = hipMemsetAsync((uint8_t *)d_out_.ptr + c.first, 0, c.second, ctx_->stream);
+        if (e == hipSuccess && d_rgb_scratch_.ptr && c.first + c.second <= d_rgb_scratch_.cap)
+            e = hipMemsetAsync((uint8_t *)d_rgb_scratch_.ptr + c.first, 0, c.second, ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(output)");
+    }
+    return JPGPU_OK;
+}
+
 int DeviceBatch::run_idct() {
     const YccRgbFactors kf = ycc_rgb_factors();
+    int rc0 = clear_partial_outputs();
+    if (rc0 != JPGPU_OK) return rc0;
     hipError_t e = launch_idct(ctx_->stream, (const int16_t *)d_coefs_.ptr, (const DevScan *)d_scans_.ptr, (const IdctWork *)d_idct_work_.ptr,
                                idct_class_begin_, (const DevScanStatus *)d_status_.ptr, (const DevQuantTable *)d_quant_pool_.ptr,
                                (uint8_t *)d_out_.ptr, format_, kf, (uint8_t *)d_rgb_scratch_.ptr);
@@ -809,6 +847,7 @@ int DeviceBatch::run_huffman_tokens() {
 int DeviceBatch::run_idct_tokens() {
     int rc = ensure_token_buffers();
     if (rc != JPGPU_OK) return rc;
+    if ((rc = clear_partial_outputs()) != JPGPU_OK) return rc;
     hipError_t e = launch_idct_tokens(ctx_->stream, (const uint32_t *)d_tokens_.ptr, (const uint32_t *)d_blk_tok_.ptr, (const DevScan *)d_scans_.ptr,
                                       (const IdctWork *)d_idct_work_.ptr, idct_class_begin_, (const DevScanStatus *)d_status_.ptr,
                                       (const DevQuantTable *)d_quant_pool_.ptr, (uint8_t *)d_out_.ptr, format_);
@@ -907,7 +946,7 @@ int DeviceBatch::result(int i, jpgpu_image_result *res) {
             break;
         }
         if (st.decoded_mcus < h_scans_[j].total_mcus) res->detail = kDetailEarlyEoi;
-        if (!entropy_only_ && jobs_[j].kind == kScanSequential && st.terminator != 0 && (st.pad[2] >> 3) == 1 && st.decoded_mcus >= h_scans_[j].total_mcus) {
+        if (!entropy_only_ && jobs_[j].kind == kScanSequential && st.terminator != 0 && (st.terminator & 0xF8u) != 0xD0u && (st.pad[2] >> 3) == 1 && st.decoded_mcus >= h_scans_[j].total_mcus) {
             // one whole byte left behind the last block: the reference resumes its walk inside the terminating marker
             if (j != img->swallow_job) {
                 res->status = JPGPU_ERR_NOT_SUPPORTED;

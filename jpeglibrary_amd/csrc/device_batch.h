@@ -98,17 +98,21 @@ class DeviceBatch {
     // the optimizer path only needs the files, the scan descriptors and the marker index: no coefficient / sample buffers
     void set_entropy_only(bool on) { entropy_only_ = on; }
     void set_preset_restart_intervals(std::vector<int> v) { preset_dri_ = std::move(v); }
+    void set_preset_no_subseq(std::vector<uint8_t> v) { preset_no_subseq_ = std::move(v); }
 
   private:
     friend class OptimizeBatch;
     bool entropy_only_ = false;
     std::vector<int> preset_dri_;  // entropy-only mode: restart interval in force at each file's scan
+    std::vector<uint8_t> preset_no_subseq_;  // entropy-only mode: files whose DRI = 0 scan stays on the interval kernel
     int fail(int status, const std::string &msg);
     int hip_fail(hipError_t e, const char *what);
     int layout_and_upload(const std::vector<const uint8_t *> &file_ptr, const std::vector<size_t> &file_len);
     void plan_image_geometry(ImagePlan &img, const BaselineGeometry &geo);
     void plan_swallowed_terminator(ImagePlan &img, const uint8_t *file, size_t len, const std::vector<size_t> &ends);
     int fetch_status();
+    int clear_partial_outputs();
+    std::vector<std::pair<uint64_t, uint64_t>> out_clear_;  // (offset, bytes) of images whose scans leave frame components unwritten
 
     jpgpu_ctx *ctx_;
     int format_ = JPGPU_FMT_INTERLEAVED_U8;

@@ -349,7 +349,8 @@ size_t OptimizeBatch::scan_end(const uint8_t *entropy, size_t len) {
     if (entropy != end_key_ || len != end_len_) {
         end_key_ = entropy;
         end_len_ = len;
-        end_val_ = find_scan_end(entropy, len);
+        end_rsts_.clear();
+        end_val_ = find_scan_end(entropy, len, &end_rsts_);
     }
     return end_val_;
 }
@@ -362,6 +363,7 @@ void OptimizeBatch::plan_file(Plan &p, const uint8_t *data, size_t len, bool str
     bool after_scan = false;  // from here on a failure of the walks is only met once the scan itself went through
     try {
     bool have_frame = false;
+    FrameHeader frame;
     int n_scans = 0;
     uint16_t dri = 0, dri_at_scan = 0;
     {
@@ -390,6 +392,7 @@ void OptimizeBatch::plan_file(Plan &p, const uint8_t *data, size_t len, bool str
                     refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count() - length + consumed, "Failed to parse frame header."));
                 if (have_frame) refuse(JPGPU_ERR_INVALID_DATA, at_offset(r.consumed_byte_count(), "Multiple frame is not supported."));
                 have_frame = true;
+                frame = fh;
                 break;
             }
             // StartOfFrame2 is not among Scan()'s cases (:95-146): a progressive frame header is skipped like an APPn segment and
@@ -528,6 +531,20 @@ void OptimizeBatch::plan_file(Plan &p, const uint8_t *data, size_t len, bool str
             flush();
             p.pieces.push_back({Piece::kEntropy, std::string()});
             const size_t end = scan_end(r.remaining_bytes(), (size_t)r.remaining_byte_count());
+            {
+                // More RSTn markers than the frame's intervals need: the scan stops behind its last MCU and the walk meets
+                // the others as markers of their own, copied one by one (:603-612).  The first of them depends on where
+                // the bit reader stood (transcode_kernel decides it), the rest are certain.
+                int max_h = 1, max_v = 1;
+                for (const FrameComponent &c : frame.components) {
+                    max_h = std::max(max_h, (int)c.h);
+                    max_v = std::max(max_v, (int)c.v);
+                }
+                const uint64_t mcus = (uint64_t)((frame.samples_per_line + 8 * max_h - 1) / (8 * max_h)) * ((frame.lines + 8 * max_v - 1) / (8 * max_v));
+                const uint64_t intervals = dri_at_scan ? (mcus + dri_at_scan - 1) / dri_at_scan : 1;
+                p.rsts_in_scan = end_rsts_.size();
+                for (size_t k = (size_t)intervals; k < end_rsts_.size(); k++) put_marker(cur, (uint8_t)end_rsts_[k]);
+            }
             r.try_advance((int)end + (swallow_terminator && end < (size_t)r.remaining_byte_count() ? 1 : 0));
             break;
         }
@@ -601,8 +618,13 @@ int OptimizeBatch::upload(const uint8_t *const *jpeg, const size_t *len, int n, 
     batch_.set_entropy_only(true);
     {
         std::vector<int> dri((size_t)n, 0);
-        for (int i = 0; i < n; i++) dri[i] = plans_[i].dri_at_scan;
+        std::vector<uint8_t> no_subseq((size_t)n, 0);
+        for (int i = 0; i < n; i++) {
+            dri[i] = plans_[i].dri_at_scan;
+            no_subseq[i] = plans_[i].rsts_in_scan != 0;  // RSTn behind the last block: the interval kernel knows what to do
+        }
         batch_.set_preset_restart_intervals(std::move(dri));
+        batch_.set_preset_no_subseq(std::move(no_subseq));
     }
     int rc = batch_.upload_files(jpeg, len, n, JPGPU_FMT_PLANAR_U8);
     if (rc != JPGPU_OK) return rc;
@@ -636,6 +658,7 @@ int OptimizeBatch::upload(const uint8_t *const *jpeg, const size_t *len, int n, 
             continue;
         }
         p.by_subsequence = s.n_subs != 0;  // the batch marks DRI = 0 scans for the self-synchronising subsequence machinery
+                                           // (not those with RSTn markers in the data: upload() asks for the interval path)
         if (p.by_subsequence) {
             sub_scan_ids_.push_back((uint32_t)p.job);
             for (uint32_t first = 0; first < s.n_subs; first += 256) sub_work_.push_back({(uint32_t)p.job, first});
@@ -897,7 +920,7 @@ int OptimizeBatch::result(int i, jpgpu_image_result *res, size_t *out_len) {
             res->status = JPGPU_ERR_INVALID_DATA;
             res->detail = kDetailBadHeader;
             ctx_->last_error = "Failed to decode JPEG data at offset " + std::to_string(batch_.image(i)->file_len) + ". No marker found.";
-        } else if (st.terminator != 0 && (st.pad[2] >> 3) == 1) {
+        } else if (st.terminator != 0 && (st.terminator & 0xF8u) != 0xD0u && (st.pad[2] >> 3) == 1) {
             res->status = p.swallow_status;
             res->detail = p.swallow_detail;
             ctx_->last_error = p.swallow_error;

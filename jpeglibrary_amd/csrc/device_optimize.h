@@ -52,6 +52,7 @@ class OptimizeBatch {
         int swallow_status = JPGPU_OK, swallow_detail = 0;
         std::string swallow_error;
         int dri_at_scan = 0;
+        size_t rsts_in_scan = 0;  // RSTn markers between the scan header and the scan's terminating marker
         std::vector<Piece> pieces;
         int job = -1;  // scan job inside batch_
         std::string dht;  // the rewritten DHT segment (marker, length, tables)
@@ -65,6 +66,7 @@ class OptimizeBatch {
     size_t scan_end(const uint8_t *entropy, size_t len);
     const uint8_t *end_key_ = nullptr;
     size_t end_len_ = 0, end_val_ = 0;
+    std::string end_rsts_;
 
     jpgpu_ctx *ctx_;
     DeviceBatch batch_;

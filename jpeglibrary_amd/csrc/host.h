@@ -268,6 +268,6 @@ YccRgbFactors ycc_rgb_factors();
 // Scans forward over entropy-coded data to the next marker that is not RSTn, the way the reference's readers end up
 // (ref: JpegReader.cs:120-158 + ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:167-176).
 // Returns the offset of the marker's FF byte, or len when the data runs out.
-size_t find_scan_end(const uint8_t *data, size_t len);
+size_t find_scan_end(const uint8_t *data, size_t len, std::string *restart_markers = nullptr);  // optionally: the RSTn bytes in front of it
 
 }  // namespace jpgpu

@@ -879,7 +879,7 @@ YccRgbFactors ycc_rgb_factors() {
     return k;
 }
 
-size_t find_scan_end(const uint8_t *data, size_t len) {
+size_t find_scan_end(const uint8_t *data, size_t len, std::string *restart_markers) {
     size_t pos = 0;
     while (pos + 1 < len) {
         const uint8_t *q = static_cast<const uint8_t *>(memchr(data + pos, 0xFF, len - 1 - pos));
@@ -891,6 +891,7 @@ size_t find_scan_end(const uint8_t *data, size_t len) {
         } else if (nb == 0xFF) {
             pos += 1;
         } else if (is_restart_marker(nb)) {
+            if (restart_markers) restart_markers->push_back((char)nb);
             pos += 2;
         } else {
             return pos;

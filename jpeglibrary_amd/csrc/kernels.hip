@@ -495,7 +495,7 @@ __device__ __forceinline__ uint32_t restart_check(const DevScan &s, const DevSca
     if (err != 0) return (interval << 8) | err;
     // bits left behind the scan's last block when the scan's terminating marker closes that interval: the host needs the
     // whole bytes among them for the reader position the reference resumes its marker walk from (:167-176)
-    if (interval == n_intervals - 1) status_out->pad[2] = (interval == n_ends - 1 && rem > 0) ? (uint32_t)rem : 0u;
+    if (interval == n_intervals - 1) status_out->pad[2] = rem > 0 ? (uint32_t)rem : 0u;
     const bool needs_check = s.dri != 0 && (interval < n_intervals - 1 || s.restart_check_at_end);
     if (!needs_check) return kNoError;
     uint32_t closing = 0xD0;  // entries before the last indexed one are RSTn by construction
@@ -3024,6 +3024,9 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
 
     const uint32_t mcu = tile_first + mcu_local;
     const bool have_block = tid < n_blk;
+    // a scan component whose frame component a LATER scan component also resolves to: the reference writes its blocks first
+    // and the later component's over them (WriteBlock by ComponentIndex, :118-134), so only the later ones reach the output
+    const bool writes = have_block && ((s.shadow_mask >> ci) & 1u) == 0;
     const uint32_t mcu_x = mcu % s.mcus_per_line, mcu_y = mcu / s.mcus_per_line;
 
     // phase B1: dequantise this lane's block out of the staging into registers
@@ -3040,7 +3043,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
 
     if (FMT == kFmtPlanarI16) {
         // "O1": unclamped int16 at component-native resolution, planes padded to whole MCUs
-        if (have_block) {
+        if (writes) {
             int16_t *plane = reinterpret_cast<int16_t *>(out + s.out_off + s.plane_off[ci]);
             const uint32_t pitch = s.plane_pitch[ci];
             const uint32_t x0 = (mcu_x * comp.h + s.blk_x[b]) * 8, y0 = (mcu_y * comp.v + s.blk_y[b]) * 8;
@@ -3061,7 +3064,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
 
     if (CONV != 0 && LAY == kLayGray) {
         // a single-component image as R = G = B = Y (Cb = Cr = 128 contribute nothing, DecodeAction.cs:57-65)
-        if (have_block) {
+        if (writes) {
             const uint32_t x0 = (mcu_x * comp.h + s.blk_x[b]) * 8, y0 = (mcu_y * comp.v + s.blk_y[b]) * 8;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
@@ -3075,7 +3078,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
     } else if (FMT == kFmtPlanarU8 || (FMT == kFmtInterleavedU8 && LAY == kLayGray)) {
         // planar u8 (planes padded to whole MCUs), or a single-component interleaved image (same addressing,
         // pitch = W, clipped at the bottom; the host only picks kLayGray when W is a multiple of 8)
-        if (have_block) {
+        if (writes) {
             const bool gray = (FMT == kFmtInterleavedU8);
             uint8_t *plane = out + s.out_off + (gray ? 0 : s.plane_off[ci]);
             const uint32_t pitch = gray ? s.width : s.plane_pitch[ci];
@@ -3097,7 +3100,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
     __builtin_amdgcn_s_barrier();
     synced = true;
 
-    interleaved_output_from_tile<LAY, CONV>(sh_px, s, tile_first, n_mcu, tid, have_block, comp, mcu_x, mcu_y, b, out, kf);
+    interleaved_output_from_tile<LAY, CONV>(sh_px, s, tile_first, n_mcu, tid, writes, comp, mcu_x, mcu_y, b, out, kf);
     }  // interleaved
     }  // u8 formats
 
@@ -3159,6 +3162,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
         const uint32_t n_blk = n_mcu * bpm;
         const uint32_t mcu = tile_first + mcu_local;
         const bool have_block = tid < n_blk;
+        const bool writes = have_block && ((s.shadow_mask >> ci) & 1u) == 0;  // see idct_kernel
         const uint32_t mcu_x = mcu % s.mcus_per_line, mcu_y = mcu / s.mcus_per_line;
 
         float f[64];
@@ -3190,7 +3194,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
         if (have_block) block_idct(f, (int32_t)s.level_shift, px);
 
         if (FMT == kFmtPlanarI16) {
-            if (have_block) {
+            if (writes) {
                 int16_t *plane = reinterpret_cast<int16_t *>(out + s.out_off + s.plane_off[ci]);
                 const uint32_t pitch = s.plane_pitch[ci];
                 const uint32_t x0 = (mcu_x * comp.h + s.blk_x[b]) * 8, y0 = (mcu_y * comp.v + s.blk_y[b]) * 8;
@@ -3209,7 +3213,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
             rows[r].y = pack4_u8(px[r * 4 + 2], px[r * 4 + 3]);
         }
         if (FMT == kFmtPlanarU8 || (FMT == kFmtInterleavedU8 && LAY == kLayGray)) {
-            if (have_block) {
+            if (writes) {
                 const bool gray = (FMT == kFmtInterleavedU8);
                 uint8_t *plane = out + s.out_off + (gray ? 0 : s.plane_off[ci]);
                 const uint32_t pitch = gray ? s.width : s.plane_pitch[ci];
@@ -3226,7 +3230,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
             for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(sh_px + r * kPxRowStride + tid * 8) = rows[r];
         }
         __syncthreads();
-        interleaved_output_from_tile<LAY, 0>(sh_px, s, tile_first, n_mcu, tid, have_block, comp, mcu_x, mcu_y, b, out, YccRgbFactors{0, 0, 0, 0});
+        interleaved_output_from_tile<LAY, 0>(sh_px, s, tile_first, n_mcu, tid, writes, comp, mcu_x, mcu_y, b, out, YccRgbFactors{0, 0, 0, 0});
         __syncthreads();  // the tile is rewritten by the next iteration
     }
 }
@@ -3662,7 +3666,15 @@ __global__ __launch_bounds__(kTcThreads) void transcode_kernel(const uint8_t *__
                 tc_flush_bytes<MODE>(w, 1, dst);
             }
             // the RSTn the reference copies from the input after every interval it continues from (:805-807)
-            const bool marker_follows = interval + 1 < n_ends && interval + 1 < n_intervals;
+            // ... and an RSTn behind the LAST one (more restart markers than the frame needs): the restart check behind a
+            // complete interval copies it like the others (:796-811); behind a partial one the bit reader has pulled it in
+            // while refilling unless four or more bytes are still unread, and hands the reader back
+            // RemainingBits / 8 bytes in front of the marker's END (:818-831): with two or more unread bytes the outer
+            // walk finds the marker again and copies it (:603-612), with none or one it is lost.  RSTn markers further
+            // behind are the host walk's (OptimizeBatch::plan_file).
+            const bool rst_closes_last = interval == n_intervals - 1 && interval == n_ends - 1 && (st.terminator & 0xF8u) == 0xD0u;
+            const bool rst_behind_last = rst_closes_last && (s.restart_check_at_end ? r.rem < 8 : r.rem >= 16);
+            const bool marker_follows = (interval + 1 < n_ends && interval + 1 < n_intervals) || rst_behind_last;
             if (marker_follows) {
                 if (MODE == 2) {
                     dst[w.bytes] = 0xFF;

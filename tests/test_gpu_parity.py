@@ -975,9 +975,15 @@ def _structural_edits(good):
     edits["no_dqt"] = good[:a] + good[b:]
     a, b = seg(0xDA)
     edits["scan_selector_not_in_frame"] = good[:a + 5] + b"\x77" + good[a + 6:]
+    if good[a + 4] == 3:  # two scan components resolve to frame component 3, none to component 1: written twice / never
+        edits["first_selector_is_the_third"] = good[:a + 5] + good[a + 9:a + 10] + good[a + 6:]
     f0, _ = seg(0xC0)
     gray_frame = good[:f0 + 9] + b"\x01" + good[f0 + 10:]  # a frame header that only admits to its first component
     edits["more_scan_components_than_frame"] = gray_frame[:f0 + 2] + (good[f0 + 2:f0 + 4]) + gray_frame[f0 + 4:]
+    # a frame header that asks for fewer MCU rows than the scan carries: 28 MCUs, with DRI = 4 the restart check behind the
+    # last MCU finds one more RSTn (the optimizer copies it), the rest of the scan is skipped as fill
+    edits["frame_height_64"] = good[:f0 + 5] + b"\x00\x40" + good[f0 + 7:]
+    edits["frame_height_33"] = good[:f0 + 5] + b"\x00\x21" + good[f0 + 7:]
     edits["sof2_in_scan_tail"] = body + b"\xff\xc2" + bytes(12)
     edits["second_sos_behind_scan"] = body + good[a:b] + bytes(30) + b"\xff\xd9"
     edits["truncated_in_scan"] = good[:b + (len(good) - b) // 2]
@@ -1023,6 +1029,39 @@ def test_marker_walk_around_the_scan_follows_the_reference(restart):
     ob.close()
     db.close()
     assert not problems, problems
+
+
+def test_progressive_scan_failures_come_before_later_walk_failures():
+    """Every ProcessScan of a progressive frame decodes its scan on the spot, so a failure inside an early scan wins over
+    a broken segment further down the file (found by tools/stress_parity.py on corrupted progressive files)."""
+    good = read_jpeg("yellowcat_progressive_restart.jpg")
+    sos = [i for i in range(len(good) - 1) if good[i] == 0xFF and good[i + 1] == 0xDA]
+    assert len(sos) >= 3
+    rst = good.index(b"\xff\xd0", sos[0])
+    broken_scan = good[:rst] + b"\x12\x34" + good[rst + 2:]
+    cases = {
+        "broken_first_scan": broken_scan,
+        "broken_first_scan_cut_in_third_header": broken_scan[:sos[2] + 5],
+        "cut_in_third_header": good[:sos[2] + 5],
+        "broken_first_scan_no_tables_for_second": broken_scan[:sos[0]] + broken_scan[sos[0]:sos[1]].replace(b"\xff\xc4", b"\xff\xe9") + broken_scan[sos[1]:],
+        "no_tables_for_second": good[:sos[0]] + good[sos[0]:sos[1]].replace(b"\xff\xc4", b"\xff\xe9") + good[sos[1]:],
+        "cut_in_second_scan": good[:(sos[1] + sos[2]) // 2],
+    }
+    names = {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException", 4: "ArgumentException"}
+    keys = list(cases)
+    outs, results = jl.decode_batch([cases[k] for k in keys], jl.FMT_INTERLEAVED_U8)
+    kinds = {}
+    for k, out, res in zip(keys, outs, results):
+        try:
+            ref, kind = po.decode_8bit(cases[k])[0], "OK"
+        except po.OracleError as e:
+            ref, kind = None, e.kind
+        kinds[k] = kind
+        assert names.get(res.status) == kind, (k, kind, res.status, res.detail)
+        if ref is not None:
+            assert np.array_equal(np.asarray(out), ref), k
+    # the order is what is tested (a cut header is no such case: Identify() already walks into it before Decode() starts)
+    assert kinds["broken_first_scan_no_tables_for_second"] != kinds["no_tables_for_second"], kinds
 
 
 def test_encoder_one_pixel_wide_noise_at_quality_100():

@@ -199,6 +199,30 @@ for i, f in enumerate(mut):
         keep("optb", i, f)
 b.close()
 
+# ---- corrupted progressive streams: the same edits anywhere behind the first SOS (entropy data, later DHT / SOS headers)
+pmut = [mutate(f, rng) for f, k in zip(files, kinds) if k[3]][: max(60, n // 6)]
+pmut = [f for f in pmut if not dc_category_above_16(f)]
+prefs = []
+for f in pmut:
+    try:
+        prefs.append(("OK", po.decode_8bit(f)[0]))
+    except po.OracleError as e:
+        prefs.append((e.kind, None))
+outs, results = jl.decode_batch(pmut, jl.FMT_INTERLEAVED_U8)
+for i, ((kind, px), out, res) in enumerate(zip(prefs, outs, results)):
+    mine = names.get(res.status, str(res.status))
+    n_mut += 1
+    if mine == "NotSupportedException" and kind != mine and res.detail == 6:
+        continue
+    if mine != kind:
+        bad += 1
+        print("mutated progressive status", i, kind, mine, res.detail)
+        keep("pdec", i, pmut[i])
+    elif kind == "OK" and res.detail != 8 and not np.array_equal(np.asarray(out), px):
+        bad += 1
+        print("mutated progressive pixels", i)
+        keep("pdecpx", i, pmut[i])
+
 # ---- encoder: random images / samplings / qualities / table modes, grouped by the parameters one batch shares
 n_enc = 0
 groups = {}
