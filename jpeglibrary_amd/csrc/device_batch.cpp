@@ -208,7 +208,7 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
             if (entropy_only_) img.sof = (uint8_t)dec.start_of_frame();
             if (jobs_.size() == first_job) {
                 // no scan: Decode() succeeds without writing anything; keep the frame geometry for the caller
-                if (img.sof == kSOF0 || img.sof == kSOF1) plan_image_geometry(img, BaselineGeometry::latch(dec, dec.frame_header()));
+                if (img.sof == kSOF0 || img.sof == kSOF1 || img.sof == kSOF2) plan_image_geometry(img, BaselineGeometry::latch(dec, dec.frame_header()));
             } else {
                 plan_image_geometry(img, jobs_[first_job].geo);
                 img.blocks_per_mcu = (uint32_t)jobs_[first_job].blocks_per_mcu;

@@ -1046,6 +1046,8 @@ def test_progressive_scan_failures_come_before_later_walk_failures():
         "broken_first_scan_no_tables_for_second": broken_scan[:sos[0]] + broken_scan[sos[0]:sos[1]].replace(b"\xff\xc4", b"\xff\xe9") + broken_scan[sos[1]:],
         "no_tables_for_second": good[:sos[0]] + good[sos[0]:sos[1]].replace(b"\xff\xc4", b"\xff\xe9") + good[sos[1]:],
         "cut_in_second_scan": good[:(sos[1] + sos[2]) // 2],
+        # a frame header whose length field swallows every scan: Decode() succeeds without writing a sample
+        "frame_header_covers_the_scans": good[:good.index(b"\xff\xc2") + 2] + (len(good) - good.index(b"\xff\xc2") - 6).to_bytes(2, "big") + good[good.index(b"\xff\xc2") + 4:],
     }
     names = {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException", 4: "ArgumentException"}
     keys = list(cases)
