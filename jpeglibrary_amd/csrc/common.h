@@ -67,7 +67,8 @@ struct alignas(16) DevScan {
     uint16_t width, height;  // frame SamplesPerLine / NumberOfLines
     uint8_t precision, frame_components, scan_components, max_h, max_v, blocks_per_mcu;
     uint8_t restart_check_at_end;  // dri > 0 && total_mcus % dri == 0: the reference runs the restart check after the last MCU
-    uint8_t shadow_mask;  // bit c: a later scan component resolves to the same frame component; c's blocks never reach the output
+    uint8_t shadow_mask;  // bit c (c < 4): a later scan component resolves to the same frame component; c's blocks never reach
+                          // the output.  kKeepUnreachedMcus: MCUs behind an early EOI are left alone instead of zeroed
     DevScanComponent comp[kMaxScanComponents];
     uint8_t blk_comp[kMaxBlocksPerMcu];  // block-in-MCU -> scan component slot
     uint8_t blk_x[kMaxBlocksPerMcu];     // block-in-MCU -> x, y inside the component's MCU footprint
@@ -96,6 +97,7 @@ struct alignas(16) DevScan {
     uint32_t dep[3];           // pipelined launch: scan jobs this scan follows (kNoDep = none), see progressive_stream_kernel
 };
 constexpr uint32_t kNoDep = 0xFFFFFFFFu;
+constexpr uint8_t kKeepUnreachedMcus = 0x80;
 enum ScanKind : uint8_t { kScanSequential = 0, kScanFrameOnly = 1, kScanProgressive = 2 };
 static_assert(sizeof(DevScan) % 16 == 0, "DevScan must be a multiple of 16 bytes");
 

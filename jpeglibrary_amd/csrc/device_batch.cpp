@@ -299,7 +299,9 @@ int DeviceBatch::upload_single_job(const ScanJob &job, int format, const void *i
     img.jobs.push_back(0);
     std::vector<const uint8_t *> fp(1, job.entropy);
     std::vector<size_t> fl(1, job.entropy_len);
+    keep_canvas_ = initial_output && initial_output_bytes;
     int rc = layout_and_upload(fp, fl);
+    keep_canvas_ = false;
     if (rc != JPGPU_OK) return rc;
     if (initial_output && initial_output_bytes) {
         out_clear_.clear();  // the caller's buffer is the canvas: what this scan does not write keeps the caller's samples
@@ -543,7 +545,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                     s.plane_pitch[c] = img.plane[fc].pitch;
                 }
             }
-            s.shadow_mask = 0;
+            s.shadow_mask = keep_canvas_ ? kKeepUnreachedMcus : 0;
             for (int c = 0; c < job.scan_components; c++)
                 for (int d = c + 1; d < job.scan_components; d++)
                     if (job.comp[c].component_index == job.comp[d].component_index) s.shadow_mask |= (uint8_t)(1u << c);

@@ -112,6 +112,7 @@ class DeviceBatch {
     void plan_swallowed_terminator(ImagePlan &img, const uint8_t *file, size_t len, const std::vector<size_t> &ends);
     int fetch_status();
     int clear_partial_outputs();
+    bool keep_canvas_ = false;  // layout of a single scan job over the caller's samples: nothing the scan does not write is touched
     std::vector<std::pair<uint64_t, uint64_t>> out_clear_;  // (offset, bytes) of images whose scans leave frame components unwritten
 
     jpgpu_ctx *ctx_;

@@ -2980,11 +2980,15 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
     const uint32_t wave = tid >> 6;
     const uint32_t bpm = s.blocks_per_mcu;
     const uint32_t mcus_per_tile = kIdctThreads / bpm;
+    // MCUs the scan never reached (EOI met in a restart check, :144-150): the reference leaves their samples as the caller's
+    // buffer held them -- zero in the buffer the batch owns -- so they go through the same output code with zero samples
     uint32_t decoded = status ? status[wk.scan].decoded_mcus : s.total_mcus;
     if (decoded > s.total_mcus) decoded = s.total_mcus;
     uint32_t range_end = wk.first_mcu + wk.n_mcus;
-    if (range_end > decoded) range_end = decoded;
-    if (wk.first_mcu >= range_end) return;
+    if ((s.shadow_mask & kKeepUnreachedMcus) != 0) {  // the caller's canvas (jpgpu_decode_scan): unreached MCUs are not touched
+        if (range_end > decoded) range_end = decoded;
+        if (wk.first_mcu >= range_end) return;
+    }
 
     // quantisation tables of the scan components
     if (tid < (uint32_t)s.scan_components * 32) {
@@ -3039,6 +3043,10 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
     // phase B2: IDCT entirely in registers
     uint32_t px[32];  // int16 sample pairs
     if (have_block) block_idct(f, (int32_t)s.level_shift, px);
+    if (mcu >= decoded) {
+#pragma unroll
+        for (int i = 0; i < 32; i++) px[i] = 0;
+    }
     bool synced = false;
 
     if (FMT == kFmtPlanarI16) {
@@ -3135,11 +3143,15 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
     const uint32_t tid = threadIdx.x;
     const uint32_t bpm = s.blocks_per_mcu;
     const uint32_t mcus_per_tile = kIdctThreads / bpm;
+    // MCUs the scan never reached (EOI met in a restart check, :144-150): the reference leaves their samples as the caller's
+    // buffer held them -- zero in the buffer the batch owns -- so they go through the same output code with zero samples
     uint32_t decoded = status ? status[wk.scan].decoded_mcus : s.total_mcus;
     if (decoded > s.total_mcus) decoded = s.total_mcus;
     uint32_t range_end = wk.first_mcu + wk.n_mcus;
-    if (range_end > decoded) range_end = decoded;
-    if (wk.first_mcu >= range_end) return;
+    if ((s.shadow_mask & kKeepUnreachedMcus) != 0) {  // the caller's canvas (jpgpu_decode_scan): unreached MCUs are not touched
+        if (range_end > decoded) range_end = decoded;
+        if (wk.first_mcu >= range_end) return;
+    }
 
     if (tid < (uint32_t)s.scan_components * 32) {
         const uint32_t c = tid >> 5, i = tid & 31;
@@ -3166,7 +3178,12 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
         const uint32_t mcu_x = mcu % s.mcus_per_line, mcu_y = mcu / s.mcus_per_line;
 
         float f[64];
-        if (have_block) {
+        const bool reached = mcu < decoded;
+        if (!reached) {
+#pragma unroll
+            for (int i = 0; i < 64; i++) f[i] = 0.0f;
+        }
+        if (have_block && reached) {
             // token run of this block: first two quads unconditionally, the rest (rare) in a loop
             const uint32_t off = scan_blk_tok[(uint64_t)tile_first * bpm + tid];
             const uint32_t *tp = scan_tok + off;
@@ -3192,6 +3209,10 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
         }
         uint32_t px[32];  // int16 sample pairs
         if (have_block) block_idct(f, (int32_t)s.level_shift, px);
+        if (!reached) {
+#pragma unroll
+            for (int i = 0; i < 32; i++) px[i] = 0;
+        }
 
         if (FMT == kFmtPlanarI16) {
             if (writes) {
