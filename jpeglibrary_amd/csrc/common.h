@@ -131,6 +131,7 @@ struct IdctWork {
     uint32_t scan;
     uint32_t first_mcu;
     uint32_t n_mcus;  // consecutive MCUs handled by this workgroup (a run of tiles)
+    uint32_t mcus_per_tile;  // MCUs one pass of the workgroup transforms (<= 256 / blocks_per_mcu, see idct_mcus_per_tile)
 };
 
 constexpr uint32_t kNoError = 0xFFFFFFFFu;

@@ -56,6 +56,22 @@ int DeviceBatch::hip_fail(hipError_t e, const char *what) {
 
 // Planner: what JpegScanDecoder.Create / ProcessScan become while the batch is being laid out.
 namespace {
+// Workgroup i of a launch runs on XCD i % 8 (round-robin dispatch), each XCD behind its own L2.  Work lists are built in
+// memory order; interleaving them gives every XCD one contiguous run, so that neighbouring work items -- which share the
+// cache lines at their common boundary -- meet in one L2 instead of writing two halves of a line from two.
+template <typename T>
+void xcd_interleave(std::vector<T> &w, int xcds) {
+    if (xcds <= 1 || w.size() < (size_t)xcds * 8) return;
+    const size_t n = w.size(), per = (n + xcds - 1) / xcds;
+    std::vector<T> m;
+    m.reserve(n);
+    for (size_t i = 0; m.size() < n; i++) {
+        const size_t src = (i % xcds) * per + i / xcds;
+        if (src < n) m.push_back(w[src]);
+    }
+    w.swap(m);
+}
+
 class PlanHandler final : public ScanHandler {
   public:
     explicit PlanHandler(std::vector<ScanJob> *jobs, bool first_scan_only = false) : jobs_(jobs), first_scan_only_(first_scan_only) {}
@@ -442,6 +458,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     max_subs_per_scan_ = 0;
     std::vector<IdctWork> idct_work;
     std::vector<IdctWork> idct_work_by_class[kNumIdctLayoutClasses];
+    const bool tile_align = !(getenv("JPGPU_TILE_ALIGN") && atoi(getenv("JPGPU_TILE_ALIGN")) == 0);  // A/B switch, default on
     uint64_t out_off = 0, coef_off = 0;
     uint32_t ends_off = 0;
     compressed_bytes_ = 0;
@@ -593,7 +610,21 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             } else {
                 for (uint32_t first = 0; first < s.n_intervals; first += kHuffIntervalsPerWg) huff_work.push_back({(uint32_t)j, first});
             }
-            const uint32_t mcus_per_wg = (uint32_t)kIdctBlocksPerWg / s.blocks_per_mcu;
+            uint32_t mcus_per_wg = (uint32_t)kIdctBlocksPerWg / s.blocks_per_mcu;
+            if (tile_align) {
+                // a tile whose pixel rows are whole 128-byte lines: neighbouring tiles (other workgroups, other XCDs, other
+                // L2s) never write two halves of one line
+                uint32_t row_bytes = 8u * s.max_h;
+                if (format_ == JPGPU_FMT_INTERLEAVED_U8) row_bytes *= s.frame_components;
+                else if (format_ == JPGPU_FMT_RGB_U8) row_bytes *= 3;
+                else if (format_ == JPGPU_FMT_RGBA_U8) row_bytes *= 4;
+                else if (format_ == JPGPU_FMT_PLANAR_I16) row_bytes *= 2;
+                for (uint32_t t = mcus_per_wg; t * 4 >= mcus_per_wg * 3 && t > 0; t--)
+                    if ((t * row_bytes) % 128 == 0) {
+                        mcus_per_wg = t;
+                        break;
+                    }
+            }
             const int cls = fmt_is_interleaved(format_) ? idct_layout_class(s) : 0;
             if (cls == 0 && (format_ == JPGPU_FMT_RGB_U8 || format_ == JPGPU_FMT_RGBA_U8)) {
                 // no fused conversion for this layout: samples go to the scratch image, then ycc_to_rgb_kernel
@@ -603,7 +634,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             }
             const uint32_t run = mcus_per_wg * (uint32_t)kIdctTilesPerWg;
             for (uint32_t first = 0; first < s.total_mcus; first += run)
-                idct_work_by_class[cls].push_back({(uint32_t)j, first, std::min(run, s.total_mcus - first)});
+                idct_work_by_class[cls].push_back({(uint32_t)j, first, std::min(run, s.total_mcus - first), mcus_per_wg});
         }
     }
     total_blocks_ = coef_off;
@@ -639,8 +670,11 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         if (covered != (1u << img.num_components) - 1u) out_clear_.push_back({img.out_offset, img.out_bytes});
     }
     idct_class_begin_[0] = 0;
+    const int xcds = getenv("JPGPU_XCD_MAP") ? atoi(getenv("JPGPU_XCD_MAP")) : 8;  // MI355X: 8 XCDs; 0 / 1 = memory order (A/B switch)
     for (int c = 0; c < kNumIdctLayoutClasses; c++) {
-        idct_work.insert(idct_work.end(), idct_work_by_class[c].begin(), idct_work_by_class[c].end());
+        std::vector<IdctWork> &w = idct_work_by_class[c];
+        xcd_interleave(w, xcds);
+        idct_work.insert(idct_work.end(), w.begin(), w.end());
         idct_class_begin_[c + 1] = (int)idct_work.size();
     }
     n_idct_work_ = (int)idct_work.size();

@@ -2979,7 +2979,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6;
     const uint32_t bpm = s.blocks_per_mcu;
-    const uint32_t mcus_per_tile = kIdctThreads / bpm;
+    const uint32_t mcus_per_tile = wk.mcus_per_tile;
     // MCUs the scan never reached (EOI met in a restart check, :144-150): the reference leaves their samples as the caller's
     // buffer held them -- zero in the buffer the batch owns -- so they go through the same output code with zero samples
     uint32_t decoded = status ? status[wk.scan].decoded_mcus : s.total_mcus;
@@ -3008,12 +3008,14 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
     // (slot ^ swizzle(block)); the swizzle term ((block >> 1) & 7) does not depend on k, so every lane's source is
     // one fixed offset plus k * 4096.  Always a full tile: the coefficient buffer has a tile of slack behind it.
     const uint32_t dma_lane_off = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) * 16);
+    const uint32_t tile_blocks = mcus_per_tile * bpm;
     auto dma_tile = [&](uint32_t tile_first) {
         const uint8_t *src = coef_bytes + (uint64_t)tile_first * bpm * 128;  // wave-uniform
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            __builtin_amdgcn_global_load_lds((jpgpu_gbl_void *)(src + (uint32_t)(k * 4096) + dma_lane_off),
-                                             (jpgpu_lds_void *)(sh + ((uint32_t)k * kIdctThreads + wave * 64) * 16), 16, 0, 0);
+            if (k < 6 || (uint32_t)k * 32 + (tid >> 3) < tile_blocks)  // blocks behind the tile's last MCU are not fetched
+                __builtin_amdgcn_global_load_lds((jpgpu_gbl_void *)(src + (uint32_t)(k * 4096) + dma_lane_off),
+                                                 (jpgpu_lds_void *)(sh + ((uint32_t)k * kIdctThreads + wave * 64) * 16), 16, 0, 0);
     };
 
     dma_tile(wk.first_mcu);
@@ -3142,7 +3144,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
     const DevScan &s = scans[wk.scan];
     const uint32_t tid = threadIdx.x;
     const uint32_t bpm = s.blocks_per_mcu;
-    const uint32_t mcus_per_tile = kIdctThreads / bpm;
+    const uint32_t mcus_per_tile = wk.mcus_per_tile;
     // MCUs the scan never reached (EOI met in a restart check, :144-150): the reference leaves their samples as the caller's
     // buffer held them -- zero in the buffer the batch owns -- so they go through the same output code with zero samples
     uint32_t decoded = status ? status[wk.scan].decoded_mcus : s.total_mcus;
