@@ -16,8 +16,8 @@ constexpr int kIdctTilesPerWg = 16;           // consecutive tiles walked by one
 size_t huffman_lds_bytes(int n_slots);
 
 constexpr uint32_t kMarkerChunkBytes = 4096;  // K1 chunk size (256 lanes x 16 bytes)
-hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const DevScan *scans, const ChunkWork *work, int n_chunks,
-                               ChunkSum *sums, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u);
+hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const DevScan *scans, int n_scans, const ChunkWork *work,
+                               int n_chunks, ChunkSum *sums, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u);
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                           const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
                           int n_slots, const uint32_t *lut_pool);

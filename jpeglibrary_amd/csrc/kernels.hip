@@ -185,8 +185,41 @@ __global__ __launch_bounds__(kScanThreads) void marker_count_kernel(const uint8_
     }
 }
 
-// K1b: every chunk derives its position in the scan from the summaries of the chunks before it and writes its part of
-// ends[] / ends_u[] / udata; the chunk that holds the closing entry also writes the scan status.
+// K1p: the summaries of one scan turned into what each of its chunks needs: RSTs / udata bytes of the chunks BEFORE it (in
+// place of its own counts) and the earliest terminator of the whole scan (pad).  One workgroup per scan job.
+__global__ __launch_bounds__(kScanThreads) void marker_prefix_kernel(const DevScan *__restrict__ scans, ChunkSum *__restrict__ sums) {
+    const DevScan &s = scans[blockIdx.x];
+    const uint32_t n = s.n_chunks, tid = threadIdx.x;
+    if (n == 0) return;
+    ChunkSum *cs = sums + s.chunk_off;
+    __shared__ uint32_t sh_a[kScanThreads / 64], sh_b[kScanThreads / 64];
+    __shared__ uint32_t sh_term;
+    if (tid == 0) sh_term = kInf;
+    __syncthreads();
+    uint32_t rst_run = 0, keep_run = 0;
+    for (uint32_t base = 0; base < n; base += kScanThreads) {
+        const uint32_t i = base + tid;
+        ChunkSum c = {0, 0, kInf, 0};
+        if (i < n) c = cs[i];
+        uint32_t rst_total, keep_total;
+        const uint32_t r = block_exclusive_scan(c.rst_cnt, sh_a, rst_total);
+        const uint32_t k = block_exclusive_scan(c.keep_cnt, sh_b, keep_total);
+        const uint32_t t = wave_reduce_min(c.first_term);
+        if (lane_id() == 0 && t != kInf) atomicMin(&sh_term, t);
+        if (i < n) {
+            cs[i].rst_cnt = rst_run + r;
+            cs[i].keep_cnt = keep_run + k;
+        }
+        rst_run += rst_total;
+        keep_run += keep_total;
+        __syncthreads();  // sh_a / sh_b are reused by the next round
+    }
+    const uint32_t term = sh_term;
+    for (uint32_t i = tid; i < n; i += kScanThreads) cs[i].pad = term;
+}
+
+// K1b: every chunk takes its position in the scan from K1p and writes its part of ends[] / ends_u[] / udata; the chunk
+// that holds the closing entry also writes the scan status.
 __global__ __launch_bounds__(kScanThreads) void marker_write_kernel(const uint8_t *__restrict__ data, const DevScan *__restrict__ scans,
                                                                      const ChunkWork *__restrict__ work, const ChunkSum *__restrict__ sums,
                                                                      uint32_t *__restrict__ ends, DevScanStatus *__restrict__ status,
@@ -203,36 +236,11 @@ __global__ __launch_bounds__(kScanThreads) void marker_write_kernel(const uint8_
     const uint32_t tid = threadIdx.x;
 
     __shared__ uint32_t sh_a[kScanThreads / 64], sh_b[kScanThreads / 64];
-    __shared__ uint32_t sh_red[3];
     __shared__ __attribute__((aligned(16))) uint8_t sh_tile[kChunkBytes + 2 * kScanThreads + 16];
 
-    // summaries: RSTs / udata bytes of the chunks before this one, earliest terminator of the whole scan
-    if (tid < 3) sh_red[tid] = tid == 2 ? kInf : 0u;
-    __syncthreads();
-    {
-        uint32_t r = 0, k = 0, t = kInf;
-        for (uint32_t i = tid; i < s.n_chunks; i += kScanThreads) {
-            const ChunkSum c = cs[i];
-            if (i < wk.chunk) {
-                r += c.rst_cnt;
-                k += c.keep_cnt;
-            }
-            t = c.first_term < t ? c.first_term : t;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            r += __shfl_xor(r, o, 64);
-            k += __shfl_xor(k, o, 64);
-        }
-        t = wave_reduce_min(t);
-        if (lane_id() == 0) {
-            atomicAdd(&sh_red[0], r);
-            atomicAdd(&sh_red[1], k);
-            atomicMin(&sh_red[2], t);
-        }
-    }
-    __syncthreads();
-    const uint32_t rst_base = sh_red[0], ubase = sh_red[1], term = sh_red[2];
+    // RSTs / udata bytes of the chunks before this one, earliest terminator of the whole scan (marker_prefix_kernel)
+    const ChunkSum mine = cs[wk.chunk];
+    const uint32_t rst_base = mine.rst_cnt, ubase = mine.keep_cnt, term = mine.pad;
     const int32_t misalign = (int32_t)(s.data_off & 15u);
     const int64_t chunk_first = -(int64_t)misalign + (int64_t)wk.chunk * kChunkBytes;
     if (term != kInf && (int64_t)term < chunk_first) return;  // the scan's data ended in an earlier chunk
@@ -3262,10 +3270,11 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
 
-hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const DevScan *scans, const ChunkWork *work, int n_chunks,
-                               ChunkSum *sums, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u) {
+hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const DevScan *scans, int n_scans, const ChunkWork *work,
+                               int n_chunks, ChunkSum *sums, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u) {
     if (n_chunks <= 0) return hipSuccess;
     hipLaunchKernelGGL(marker_count_kernel, dim3(n_chunks), dim3(kScanThreads), 0, stream, data, scans, work, sums);
+    hipLaunchKernelGGL(marker_prefix_kernel, dim3(n_scans), dim3(kScanThreads), 0, stream, scans, sums);
     hipLaunchKernelGGL(marker_write_kernel, dim3(n_chunks), dim3(kScanThreads), 0, stream, data, scans, work, sums, ends, status, udata,
                        ends_u);
     return hipGetLastError();
