@@ -102,6 +102,21 @@ class PlanHandler final : public ScanHandler {
         }
         if (!baseline_)
             throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "Only Huffman DCT frames (SOF0, SOF1, SOF2) run on this path.", kDetailUnsupportedFrame);
+        if (scan.num_components == 0) {
+            // A scan header that names no component: ProcessScan walks the MCUs without reading a bit (:99-136).  With a
+            // restart interval the first restart check finds the bit buffer full and no marker (:139-154); without one
+            // the reader is left where it is and the outer walk skips the entropy data as fill.
+            const uint64_t mcus = (uint64_t)geo_.mcus_per_line * (uint64_t)geo_.mcus_per_column;
+            if (geo_.restart_interval != 0 && mcus >= geo_.restart_interval && len != 0 &&
+                !(len >= 2 && entropy[0] == 0xFF && entropy[1] != 0x00 && entropy[1] != 0xFF))
+                throw DecodeError(JPGPU_ERR_INVALID_OPERATION, "Expect restart marker.", kDetailExpectRestart);
+            if (first_scan_only_)
+                throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "A scan without components is not supported by the optimizer path.", kDetailUnsupportedFrame);
+            if (geo_.restart_interval != 0 && mcus >= geo_.restart_interval)
+                throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "A scan without components in front of restart markers is not supported.", kDetailUnsupportedFrame);
+            reader.try_advance((int)find_scan_end(entropy, len));
+            return;
+        }
         if (replay_ends_) {
             const int k = replayed_++;
             if (k > swallow_ || k >= (int)replay_ends_->size())
@@ -610,6 +625,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             } else {
                 for (uint32_t first = 0; first < s.n_intervals; first += kHuffIntervalsPerWg) huff_work.push_back({(uint32_t)j, first});
             }
+            if (s.blocks_per_mcu == 0) continue;  // cannot happen for a resolved scan (sampling factors are checked); no blocks, no work
             uint32_t mcus_per_wg = (uint32_t)kIdctBlocksPerWg / s.blocks_per_mcu;
             if (tile_align) {
                 // a tile whose pixel rows are whole 128-byte lines: neighbouring tiles (other workgroups, other XCDs, other

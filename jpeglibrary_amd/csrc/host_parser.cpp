@@ -737,6 +737,8 @@ void ProgressiveFrame::add_scan(const HostDecoder &dec, const ScanHeader &scan, 
     job.ordinal = 0;
     job.scan_dri = dec.restart_interval();
     job.frame_bpm = frame_bpm_;
+    if (scan.num_components == 0)
+        throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "A progressive scan without components is not supported.", kDetailUnsupportedFrame);
     job.scan_components = dec.resolve_scan(fh, scan, job.comp);  // InitDecodeComponents (:60)
     for (int i = 0; i < job.scan_components; i++) {  // :63-69
         if (!job.comp[i].quant)

@@ -1,0 +1,41 @@
+#!/bin/bash
+# tools/profile_pmc.sh TAG [bench args...] -- rocprofv3 kernel-trace + PMC passes of bench.py on the GPU box.
+# Counters go in their own runs (never combined with sys/hip tracing; see the gpurun rules). Writes gpurun_out/pmc_TAG/.
+set -u
+TAG=${1:-x}; shift
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+ARGS="${@:---images 64}"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/tools/bench_encode.py $ARGS > $OUT/trace.log 2>&1
+i=0
+for PMC in \
+  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+  "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+  "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_LEVEL_WAVES" \
+  "FETCH_SIZE TCC_HIT_sum" \
+  "WRITE_SIZE TCC_MISS_sum TCC_EA0_RDREQ_sum" \
+  "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum TCC_READ_sum" \
+  "GRBM_GUI_ACTIVE GRBM_COUNT" ; do
+  i=$((i+1))
+  rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -- python3 $R/tools/bench_encode.py $ARGS > $OUT/pmc$i.log 2>&1
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections, os
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0][-60:]
+        agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+with open(out + "/summary.txt", "w") as fo:
+    for k, d in sorted(agg.items()):
+        if "jpgpu" not in k: continue
+        fo.write(k + "\n")
+        for c, v in sorted(d.items()):
+            fo.write(f"  {c:28s} n={len(v):3d} mean={sum(v)/len(v):.4g}\n")
+    for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
+        fo.write(open(f).read())
+print(open(out + "/summary.txt").read())
+PY
