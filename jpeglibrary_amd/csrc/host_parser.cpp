@@ -619,6 +619,10 @@ int HostDecoder::resolve_scan(const FrameHeader &fh, const ScanHeader &sh, Resol
         c.quant = quantization_table(fc->tq);
         c.hs = max_h / fc->h;
         c.vs = max_v / fc->v;
+        // WriteBlockSlow replicates with SHIFTS (log2 of the ratio, ...BaselineScanDecoder.cs:238-268): for a ratio that is not a
+        // power of two it indexes past the 8 samples of a row.  Not reproduced.
+        if (!optimizer_rules && ((c.hs & (c.hs - 1)) != 0 || (c.vs & (c.vs - 1)) != 0 || max_h % fc->h != 0 || max_v % fc->v != 0))
+            throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "Sampling factor ratios that are not powers of two are not supported.", kDetailUnsupportedFrame);
     }
     return sh.num_components;
 }
@@ -792,8 +796,13 @@ void ProgressiveFrame::add_scan(const HostDecoder &dec, const ScanHeader &scan, 
     for (size_t ei = 0; ei < scans_.size(); ei++) {
         const ScanJob &e = scans_[ei];
         const bool e_interleaved = e.scan_components != 1;
-        const int e_lo = e_interleaved ? 0 : e.ss, e_hi = e_interleaved ? 0 : e.se;  // interleaved scans are DC scans
-        const int lo = interleaved ? 0 : scan.ss, hi = interleaved ? 0 : scan.se;
+        // The band a scan may WRITE is wider than its header says: the reference stores a first-pass coefficient at
+        // min(k, 63) after k += run without looking at Se (:262-275), and a refinement pass its new coefficient at the index
+        // the zero-history walk stopped at, which may be Se + 1 (:330-345).  Well-formed streams never do that, corrupted
+        // ones do, and then file order decides what a coefficient ends up as: such scans must not share a level.
+        auto written_hi = [](bool il, int ss_, int se_, int ah_) { return il || ss_ == 0 ? se_ : std::min(63, se_ + (ah_ == 0 ? 15 : 1)); };
+        const int e_lo = e_interleaved ? 0 : e.ss, e_hi = e_interleaved ? 0 : written_hi(false, e.ss, e.se, e.ah);  // interleaved scans are DC scans
+        const int lo = interleaved ? 0 : scan.ss, hi = interleaved ? 0 : written_hi(false, scan.ss, scan.se, scan.ah);
         if (lo > e_hi || e_lo > hi) continue;
         bool shares = false;
         for (int a = 0; a < job.scan_components; a++)

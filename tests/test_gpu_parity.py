@@ -3,6 +3,8 @@
 Bit-exact everywhere: coefficients (Huffman stage), samples (IDCT stage), and every output layout.
 Mirrors the reference's own decode tests (tests/JpegLibrary.Tests/Decoder/HuffmanSequentialDecodeTests.cs:23-43).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1065,6 +1067,18 @@ def test_progressive_scan_failures_come_before_later_walk_failures():
             assert np.array_equal(np.asarray(out), ref), k
     # the order is what is tested (a cut header is no such case: Identify() already walks into it before Decode() starts)
     assert kinds["broken_first_scan_no_tables_for_second"] != kinds["no_tables_for_second"], kinds
+
+
+def test_progressive_band_overrun_is_ordered_like_the_file():
+    """A corrupted first-pass AC scan (band 1-5) stores a coefficient behind its band, where the 6-63 scan of the same
+    component also stores: file order decides.  The two scans used to share a dependency level, and which store won
+    depended on where the image sat in the batch (found by tools/stress_parity.py, 24 x 1500 files)."""
+    data = read_jpeg(os.path.join("stress", "progressive_band_overrun.jpg"))
+    ref = po.decode_8bit(data)[0]
+    outs, results = jl.decode_batch([data] * 12, jl.FMT_INTERLEAVED_U8)
+    for k, (o, r) in enumerate(zip(outs, results)):
+        assert r.status == 0
+        assert np.array_equal(np.asarray(o), ref), k
 
 
 def test_encoder_one_pixel_wide_noise_at_quality_100():
