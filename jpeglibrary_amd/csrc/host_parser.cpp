@@ -609,7 +609,8 @@ int HostDecoder::resolve_scan(const FrameHeader &fh, const ScanHeader &sh, Resol
                 fc = &fh.components[j];
             }
         if (!fc) throw_invalid_data(optimizer_rules ? "Found invalid data while decoding." : "Failed to decode JPEG data. The specified component is missing.", kDetailBadHeader);
-        if (fc->h == 0 || fc->v == 0) throw_invalid_data("Failed to decode JPEG data. Attempted to divide by zero.", kDetailBadHeader);
+        // JpegOptimizer never divides by the sampling factors (:395-413): a zero factor just gives the component no blocks
+        if (!optimizer_rules && (fc->h == 0 || fc->v == 0)) throw_invalid_data("Failed to decode JPEG data. Attempted to divide by zero.", kDetailBadHeader);
         ResolvedScanComponent &c = out[i];
         c.component_index = component_index;
         c.h = fc->h;
@@ -617,8 +618,8 @@ int HostDecoder::resolve_scan(const FrameHeader &fh, const ScanHeader &sh, Resol
         c.dc = huffman_table(true, sc.td);
         c.ac = huffman_table(false, sc.ta);
         c.quant = quantization_table(fc->tq);
-        c.hs = max_h / fc->h;
-        c.vs = max_v / fc->v;
+        c.hs = fc->h ? max_h / fc->h : 1;
+        c.vs = fc->v ? max_v / fc->v : 1;
         // WriteBlockSlow replicates with SHIFTS (log2 of the ratio, ...BaselineScanDecoder.cs:238-268): for a ratio that is not a
         // power of two it indexes past the 8 samples of a row.  Not reproduced.
         if (!optimizer_rules && ((c.hs & (c.hs - 1)) != 0 || (c.vs & (c.vs - 1)) != 0 || max_h % fc->h != 0 || max_v % fc->v != 0))
@@ -686,6 +687,7 @@ ScanJob make_scan_job(const HostDecoder &dec, const BaselineGeometry &geo, const
                 nblk++;
             }
     }
+    if (nblk == 0) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "A scan without blocks is not supported.", kDetailUnsupportedFrame);
     job.blocks_per_mcu = nblk;
     // the job owns snapshots (huff_copy / quant_copy, addressed by slot); drop the registry pointers so nothing
     // dangles when the job is moved or the registry changes
@@ -743,6 +745,8 @@ void ProgressiveFrame::add_scan(const HostDecoder &dec, const ScanHeader &scan, 
     job.frame_bpm = frame_bpm_;
     if (scan.num_components == 0)
         throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "A progressive scan without components is not supported.", kDetailUnsupportedFrame);
+    if (scan.se > 63 || scan.ss > 63)  // the reference's block readers then walk into the next blocks of its store
+        throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "A spectral selection beyond coefficient 63 is not supported.", kDetailUnsupportedFrame);
     job.scan_components = dec.resolve_scan(fh, scan, job.comp);  // InitDecodeComponents (:60)
     for (int i = 0; i < job.scan_components; i++) {  // :63-69
         if (!job.comp[i].quant)

@@ -902,6 +902,10 @@ static int init_decode_components(jref_decoder *d, const frame_header *fh, const
         if (c->h == 0 || c->v == 0) THROW_SCAN_INVALID(d, "Attempted to divide by zero."); /* DivideByZeroException */
         c->hs = max_h / c->h;
         c->vs = max_v / c->v;
+        /* not restated: for a ratio that is not a power of two WriteBlockSlow's shifted indices leave the block's 64 samples
+         * (unsafe reads in the reference, :247-266); the checker refuses instead of guessing what lies behind them */
+        if ((c->hs & (c->hs - 1)) != 0 || (c->vs & (c->vs - 1)) != 0)
+            throw_err(d, JREF_NOT_SUPPORTED, "Sampling factor ratios that are not powers of two are outside the restated envelope.");
         c->dc_predictor = 0;
     }
     return sh->ncomp;
@@ -950,6 +954,8 @@ static void scan_decoder_create(jref_decoder *d, int marker) {
         if (fh->comp[i].h == 0 || fh->comp[i].v == 0) THROW_SCAN_INVALID(d, "Attempted to divide by zero.");
         a->hs = max_h / fh->comp[i].h;
         a->vs = max_v / fh->comp[i].v;
+        if ((a->hs & (a->hs - 1)) != 0 || (a->vs & (a->vs - 1)) != 0) /* see init_decode_components */
+            throw_err(d, JREF_NOT_SUPPORTED, "Sampling factor ratios that are not powers of two are outside the restated envelope.");
         a->hblocks = (hblocks + a->hs - 1) / a->hs;
         a->vblocks = (vblocks + a->vs - 1) / a->vs;
         a->offset = index;
@@ -1205,6 +1211,10 @@ static void pg_read_block_ac(jref_decoder *d, bit_reader *b, const huff_table *a
 /* ref: JpegHuffmanProgressiveScanDecoder.cs:57-194 */
 static void progressive_process_scan(jref_decoder *d, reader *r, const scan_header *sh) {
     if (!d->writer) throw_err(d, JREF_INVALID_OPERATION, "Operation is not valid.");
+    /* not restated: a spectral selection that ends behind coefficient 63 makes the reference's block readers walk into the
+     * NEXT blocks of its store (Unsafe.Add without a bound, :322-413); the checker refuses instead of following it there */
+    if (sh->se > 63 || sh->ss > 63)
+        throw_err(d, JREF_NOT_SUPPORTED, "A spectral selection beyond coefficient 63 is outside the restated envelope.");
     const frame_header *fh = &d->sd_frame;
     int ncomp = init_decode_components(d, fh, sh, d->sd_components, d->sd_ncomponents_alloc);
     decoding_component *components = d->sd_components;
