@@ -190,7 +190,11 @@ int jpgpu_batch_image_info(const jpgpu_batch *b, int i, jpgpu_image_info *info);
 /* Valid after jpgpu_batch_sync. */
 int jpgpu_batch_result(jpgpu_batch *b, int i, jpgpu_image_result *res);
 
-/* Device pointers (HBM) of the whole-batch buffers; outputs stay resident for downstream GPU consumers. */
+/* Device pointers (HBM) of the whole-batch buffers; outputs stay resident for downstream GPU consumers.
+ * Samples the reference would leave as the caller's buffer held them -- MCUs behind an early EOI
+ * (JpegHuffmanBaselineScanDecoder.cs:144-150), components no scan writes, images without any scan -- read as zero here:
+ * the batch owns the buffer, and zero is what a freshly allocated managed array holds.  (jpgpu_decode_scan, which
+ * decodes over the caller's own samples, leaves them alone.) */
 void *jpgpu_batch_output_device(const jpgpu_batch *b, uint64_t *total_bytes);
 void *jpgpu_batch_coefficients_device(const jpgpu_batch *b, uint64_t *total_blocks);
 /* Copies one image's output / coefficient blocks (int16[blocks][64], zig-zag order, MCU scan order) to the host. */
@@ -216,7 +220,9 @@ int jpgpu_batch_totals(const jpgpu_batch *b, uint64_t *compressed_bytes, uint64_
  * JpegQuantizationTable.Elements (JpegQuantizationTable.cs:47); qt_present[i] = !IsEmpty.
  * dht[0][id] are DC tables, dht[1][id] AC tables.  `entropy` points just after the SOS segment
  * (reader.RemainingBytes); *bytes_consumed is what the reference advances the reader by.
- * Output is written to host memory `out` (cap bytes) in `format`.
+ * Output is written to host memory `out` (cap bytes) in `format`; what `out` holds on entry is the canvas: samples the
+ * scan does not write (other components of a non-interleaved scan, MCUs behind an early EOI) keep their values, as
+ * with the reference's writers (JpegBufferOutputWriter8Bit.cs:28-60).
  */
 int jpgpu_decode_scan(jpgpu_ctx *ctx, const jpgpu_frame *frame, const jpgpu_scan *scan, const uint16_t qt[4][64],
                       const uint8_t qt_present[4], const jpgpu_dht dht[2][4], uint16_t restart_interval,
