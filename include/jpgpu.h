@@ -88,6 +88,13 @@ int jpgpu_create(int device, jpgpu_ctx **out);
 void jpgpu_destroy(jpgpu_ctx *ctx);
 /* Last error text of this context (thread-compatible, not thread-safe). ctx may be NULL for create failures. */
 const char *jpgpu_last_error(const jpgpu_ctx *ctx);
+/* Host threads jpgpu_batch_upload may use for this context (header parsing of the files, copies into the pinned staging
+ * ring, full marker walks of the files that need one).  0 = default: min(hardware threads, 32), or JPGPU_HOST_THREADS.
+ * The reference is single-threaded per decoder ("one decoder per thread"); a batch is where the host fans out. */
+int jpgpu_set_host_threads(jpgpu_ctx *ctx, int threads);
+/* Image-per-GPU sharding: of n_items, rank `rank` of `world` takes items first, first + stride, ... (count of
+ * them): image i -> GPU i mod G.  Independent contexts, no exchange between them; any out pointer may be NULL. */
+void jpgpu_shard(int n_items, int rank, int world, int *first, int *stride, int *count);
 const char *jpgpu_status_string(int status);
 const char *jpgpu_detail_string(int detail);
 
@@ -165,6 +172,23 @@ void jpgpu_batch_destroy(jpgpu_batch *b);
  * `format` is a jpgpu_format.  Images whose headers fail to parse get a per-image status and are skipped.
  * Returns JPGPU_OK if the batch is usable (even if some images failed). */
 int jpgpu_batch_upload(jpgpu_batch *b, const uint8_t *const *jpeg, const size_t *len, int n, int format);
+/* What the last jpgpu_batch_upload did.  The host reads headers only: both marker loops stop behind the first SOS header and
+ * the file is planned as one sequential scan closed by EOI; the bytes behind the header are looked at by the device, which
+ * reports the first marker that is not RSTn (what Identify's walk, JpegDecoder.cs:75-162 / JpegReader.cs:120-158, would
+ * meet next).  n_header_only = files whose plan was confirmed that way; n_full_walk = files that took the full host walks
+ * of Identify and Decode (several scans, progressive, segments or garbage behind the scan, truncated data).  The bytes
+ * travel through a pinned staging ring on the context's upload stream, beside whatever runs on its decode stream. */
+typedef struct jpgpu_ingest_stats {
+    int32_t threads;        /* host threads used */
+    int32_t n_header_only;
+    int32_t n_full_walk;
+    float parse_ms;         /* header-only plans */
+    float copy_ms;          /* staging copies + H2D + device verdict */
+    float full_walk_ms;     /* full marker walks (+ the reader-position verdicts of the confirmed plans) */
+    float layout_ms;        /* descriptors, work lists, device allocations */
+    float total_ms;
+} jpgpu_ingest_stats;
+int jpgpu_batch_ingest_stats(const jpgpu_batch *b, jpgpu_ingest_stats *stats);
 
 /* Coefficient hand-off for multi-scan (progressive, SOF2) images -- BASELINE config 5's "coefficient accumulate then single
  * IDCT pass": the caller's progressive entropy decoder accumulates the coefficient store, the GPU runs what
@@ -208,6 +232,10 @@ int jpgpu_batch_upload_coefficients(jpgpu_batch *b, int i, const int16_t *src, s
 int jpgpu_batch_stage_ms(jpgpu_batch *b, float ms[4]);
 /* Synchronisation rounds the self-synchronising DRI = 0 decoder needed in the most recent decode (0 = not used). */
 int jpgpu_batch_subseq_rounds(const jpgpu_batch *b);
+/* Times the single-launch progressive path gave up waiting inside the kernel (its scans follow each other's progress, which
+ * relies on workgroups being dispatched in list order) and the step was re-issued scan level by scan level.  Valid after
+ * jpgpu_batch_result. */
+int jpgpu_batch_progressive_fallbacks(const jpgpu_batch *b);
 /* Total entropy-segment bytes / blocks / pixels of the successfully parsed images. */
 int jpgpu_batch_totals(const jpgpu_batch *b, uint64_t *compressed_bytes, uint64_t *blocks, uint64_t *pixels,
                        uint64_t *output_bytes);

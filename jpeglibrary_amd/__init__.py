@@ -4,6 +4,7 @@ Importing the package loads the in-tree HIP library (libjpgpu.so); it raises if 
 There is no CPU fallback: creating a context without a GPU raises NoDeviceError.
 """
 from . import _capi  # noqa: F401  (loads libjpgpu.so, fails loudly when absent)
+from . import sharding  # noqa: F401
 from .batch import FMT_INTERLEAVED_U8, FMT_PLANAR_I16, FMT_PLANAR_U8, FMT_RGB_U8, FMT_RGBA_U8, Batch, decode_batch
 from .context import Context, default_context, device_count
 from .encoder import EncodeBatch, encode_batch

@@ -61,6 +61,11 @@ class EncodeParams(C.Structure):
                 ("quality", C.c_int32), ("input_rgb", C.c_int32), ("optimize_coding", C.c_int32)]
 
 
+class IngestStats(C.Structure):
+    _fields_ = [("threads", C.c_int32), ("n_header_only", C.c_int32), ("n_full_walk", C.c_int32), ("parse_ms", C.c_float),
+                ("copy_ms", C.c_float), ("full_walk_ms", C.c_float), ("layout_ms", C.c_float), ("total_ms", C.c_float)]
+
+
 WRITE_BLOCK_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int)
 
 # every symbol include/jpgpu.h declares: (name, restype, argtypes)
@@ -71,6 +76,10 @@ SYMBOLS = [
     ("jpgpu_create", C.c_int, [C.c_int, C.POINTER(_P)]),
     ("jpgpu_destroy", None, [_P]),
     ("jpgpu_last_error", C.c_char_p, [_P]),
+    ("jpgpu_set_host_threads", C.c_int, [_P, C.c_int]),
+    ("jpgpu_shard", None, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("jpgpu_batch_ingest_stats", C.c_int, [_P, C.POINTER(IngestStats)]),
+    ("jpgpu_batch_progressive_fallbacks", C.c_int, [_P]),
     ("jpgpu_status_string", C.c_char_p, [C.c_int]),
     ("jpgpu_detail_string", C.c_char_p, [C.c_int]),
     ("jpgpu_batch_create", C.c_int, [_P, C.POINTER(_P)]),

@@ -96,6 +96,16 @@ class Batch:
         self._check(_lib.jpgpu_batch_stage_ms(self._h, ms))
         return {"marker_index": ms[0], "huffman": ms[1], "idct": ms[2], "total": ms[3]}
 
+    def ingest_stats(self):
+        """What the last upload() did: files planned from their headers alone vs full host walks, and where the time went."""
+        st = _capi.IngestStats()
+        self._check(_lib.jpgpu_batch_ingest_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in _capi.IngestStats._fields_}
+
+    def progressive_fallbacks(self):
+        """Times the single-launch progressive path timed out and the step was re-issued level by level."""
+        return _lib.jpgpu_batch_progressive_fallbacks(self._h)
+
     def subseq_rounds(self):
         """Synchronisation rounds the DRI = 0 subsequence decoder needed in the last decode (0 = not used)."""
         return _lib.jpgpu_batch_subseq_rounds(self._h)

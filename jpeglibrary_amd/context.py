@@ -18,6 +18,10 @@ class Context:
         raise_for_status(rc, _lib.jpgpu_last_error(None))
         self.device = device
 
+    def set_host_threads(self, threads: int):
+        """Host threads upload() may use (0 = default: min(hardware threads, 32) or JPGPU_HOST_THREADS)."""
+        raise_for_status(_lib.jpgpu_set_host_threads(self._h, threads), b"jpgpu_set_host_threads failed")
+
     def last_error(self) -> str:
         return _lib.jpgpu_last_error(self._h).decode("utf-8", "replace")
 

@@ -57,6 +57,11 @@ int jpgpu_create(int device, jpgpu_ctx **out) {
         g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
         return JPGPU_ERR_DEVICE;
     }
+    if ((e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        (void)hipStreamDestroy(ctx->stream);
+        return JPGPU_ERR_DEVICE;
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
     *out = ctx.release();
@@ -67,7 +72,28 @@ void jpgpu_destroy(jpgpu_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
+    for (int i = 0; i < StagingRing::kSlots; i++) {
+        if (ctx->staging.slot[i]) (void)hipHostFree(ctx->staging.slot[i]);
+        if (ctx->staging.drained[i]) (void)hipEventDestroy(ctx->staging.drained[i]);
+    }
+    if (ctx->staging.verdict) (void)hipHostFree(ctx->staging.verdict);
     delete ctx;
+}
+
+int jpgpu_set_host_threads(jpgpu_ctx *ctx, int threads) {
+    if (!ctx || threads < 0) return JPGPU_ERR_ARGUMENT;
+    ctx->host_threads = threads;
+    return JPGPU_OK;
+}
+
+void jpgpu_shard(int n_items, int rank, int world, int *first, int *stride, int *count) {
+    // image i -> GPU i mod G: rank r takes items r, r + world, r + 2 world, ...
+    if (world < 1) world = 1;
+    if (rank < 0) rank = 0;
+    if (first) *first = rank;
+    if (stride) *stride = world;
+    if (count) *count = n_items > rank ? (n_items - rank + world - 1) / world : 0;
 }
 
 const char *jpgpu_last_error(const jpgpu_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
@@ -134,11 +160,11 @@ int jpgpu_batch_upload_frames(jpgpu_batch *b, const jpgpu_frame *frames, const u
     JPGPU_GUARD(b, b->impl.upload_frames(frames, qt, n, format));
 }
 int jpgpu_batch_decode(jpgpu_batch *b) { JPGPU_GUARD(b, b->impl.decode()); }
-int jpgpu_batch_run_entropy(jpgpu_batch *b) {
-    if (!b) return JPGPU_ERR_ARGUMENT;
-    int rc = b->impl.run_marker_index();
-    return rc != JPGPU_OK ? rc : b->impl.run_huffman();
+static int run_entropy_stages(DeviceBatch &impl) {
+    const int rc = impl.run_marker_index();
+    return rc != JPGPU_OK ? rc : impl.run_huffman();
 }
+int jpgpu_batch_run_entropy(jpgpu_batch *b) { JPGPU_GUARD(b, run_entropy_stages(b->impl)); }
 int jpgpu_batch_run_idct(jpgpu_batch *b) { JPGPU_GUARD(b, b->impl.run_idct()); }
 int jpgpu_batch_sync(jpgpu_batch *b) { JPGPU_GUARD(b, b->impl.sync()); }
 int jpgpu_batch_size(const jpgpu_batch *b) { return b ? b->impl.size() : 0; }
@@ -180,6 +206,20 @@ int jpgpu_batch_upload_coefficients(jpgpu_batch *b, int i, const int16_t *src, s
 }
 int jpgpu_batch_stage_ms(jpgpu_batch *b, float ms[4]) { JPGPU_GUARD(b, b->impl.stage_ms(ms)); }
 int jpgpu_batch_subseq_rounds(const jpgpu_batch *b) { return b ? b->impl.last_subseq_rounds() : 0; }
+int jpgpu_batch_progressive_fallbacks(const jpgpu_batch *b) { return b ? b->impl.progressive_fallbacks() : 0; }
+int jpgpu_batch_ingest_stats(const jpgpu_batch *b, jpgpu_ingest_stats *stats) {
+    if (!b || !stats) return JPGPU_ERR_ARGUMENT;
+    const IngestStats &s = b->impl.ingest_stats();
+    stats->threads = s.threads;
+    stats->n_header_only = s.n_header_only;
+    stats->n_full_walk = s.n_full_walk;
+    stats->parse_ms = s.parse_ms;
+    stats->copy_ms = s.copy_ms;
+    stats->full_walk_ms = s.full_walk_ms;
+    stats->layout_ms = s.layout_ms;
+    stats->total_ms = s.total_ms;
+    return JPGPU_OK;
+}
 int jpgpu_batch_totals(const jpgpu_batch *b, uint64_t *compressed_bytes, uint64_t *blocks, uint64_t *pixels, uint64_t *output_bytes) {
     if (!b) return JPGPU_ERR_ARGUMENT;
     b->impl.totals(compressed_bytes, blocks, pixels, output_bytes);

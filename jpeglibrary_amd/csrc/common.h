@@ -75,7 +75,7 @@ struct alignas(16) DevScan {
     uint8_t blk_y[kMaxBlocksPerMcu];
     uint16_t huff_pool[kMaxHuffSlots];   // pool indices of the tables this scan stages (0xFFFF = unused)
     uint16_t quant_pool[kMaxScanComponents];
-    uint64_t tok_base;   // first token slot of this scan in the token buffer (token pipeline, see K2T/K3T)
+    uint64_t reserved0;  // (was: token pipeline slot base; the pipeline was removed in round 2)
     uint32_t chunk_off;  // first entry of this scan in the chunk-summary array (K1)
     uint32_t n_chunks;   // 4 KiB chunks covering the entropy segment (from its 16-byte aligned base)
     uint32_t sub_off;    // DRI = 0 scans: first slot of this scan in the subsequence state arrays (K2S)
@@ -136,13 +136,6 @@ struct IdctWork {
 
 constexpr uint32_t kNoError = 0xFFFFFFFFu;
 
-// Token pipeline.  A token is one decoded coefficient: value (int16) | zig-zag index << 16 | kTokLast on the last
-// token of its block.  Every block has at least its DC token.  Interval k of a scan owns the token slots
-// [tok_base + kTokensPerByte * start_k, ...): every token consumes at least 2 bits of entropy data, so
-// kTokensPerByte = 4 slots per compressed byte can never overflow into the next interval's region.
-constexpr uint32_t kTokLast = 0x80000000u;
-constexpr uint32_t kTokensPerByte = 4;
-
 // detail codes (mirror jpgpu_detail in include/jpgpu.h)
 enum Detail : uint32_t {
     kDetailNone = 0,
@@ -155,7 +148,8 @@ enum Detail : uint32_t {
     kDetailBadHeader = 7,
     kDetailEarlyEoi = 8,
     kDetailUnexpectedEnd = 9,
-    kDetailNullTable = 10  // optimizer walk: a block needs a Huffman table that was never defined (the reference's null reference)
+    kDetailNullTable = 10,  // optimizer walk: a block needs a Huffman table that was never defined (the reference's null reference)
+    kDetailSpinTimeout = 11  // internal, never reported: a progressive scan of the pipelined launch gave up waiting for its producers
 };
 
 }  // namespace jpgpu

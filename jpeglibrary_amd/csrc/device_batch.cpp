@@ -12,7 +12,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 
+#include "host_pool.h"
 #include "kernels.h"
 
 namespace jpgpu {
@@ -40,7 +44,7 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_lut_pool_, &d_prog_work_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_tokens_, &d_blk_tok_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
@@ -163,7 +167,7 @@ class PlanHandler final : public ScanHandler {
 };
 }  // namespace
 
-void DeviceBatch::plan_image_geometry(ImagePlan &img, const BaselineGeometry &geo) {
+void DeviceBatch::plan_image_geometry(ImagePlan &img, const BaselineGeometry &geo) const {
     const FrameHeader &fh = geo.frame;
     img.width = fh.samples_per_line;
     img.height = fh.lines;
@@ -182,6 +186,8 @@ void DeviceBatch::plan_image_geometry(ImagePlan &img, const BaselineGeometry &ge
                               kDetailUnsupportedFrame);
         img.out_bytes = (uint64_t)img.width * img.height * (format_ == JPGPU_FMT_RGBA_U8 ? 4 : 3);
     } else {
+        if (fh.num_components > 4)  // jpgpu_plane_info describes four planes; a fifth component would land on plane 0
+            throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "The planar output formats describe at most 4 components.", kDetailUnsupportedFrame);
         const uint64_t sample_bytes = format_ == JPGPU_FMT_PLANAR_I16 ? 2 : 1;
         uint64_t off = 0;
         for (int c = 0; c < fh.num_components && c < 4; c++) {
@@ -196,116 +202,203 @@ void DeviceBatch::plan_image_geometry(ImagePlan &img, const BaselineGeometry &ge
     }
 }
 
-int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int n, int format) {
-    if (n < 0 || (n > 0 && (!jpeg || !len))) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: null argument");
-    if (format < 0 || format > 4) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: unknown format");
-    format_ = format;
-    images_.assign((size_t)n, ImagePlan());
-    jobs_.clear();
-    job_image_.clear();
-    job_entropy_off_.clear();
-    std::vector<const uint8_t *> file_ptr((size_t)n);
-    std::vector<size_t> file_len((size_t)n);
+// ---------------------------------------------------------------------------------------------------------------- ingest
+//
+// jpgpu_batch_upload = SetInput + Identify + Decode's marker loop for n files (ref: JpegDecoder.cs:75-162, 509-617), without
+// the host ever walking entropy-coded bytes in the common case:
+//   1. header-only plan, one file per crew thread: Identify's walk up to the first SOS header, then Decode's walk up to the
+//      same point; the file is planned as "this one sequential scan, its data closed by EOI" (FastPlanHandler);
+//   2. the files go to HBM through the context's pinned staging ring: the crew copies the caller's bytes into 32 MiB slots,
+//      every full slot leaves as one DMA on the upload stream while the next ones are being filled;
+//   3. the device reads the bytes behind each SOS header once (first_marker_kernel) and reports the first marker that is
+//      not RSTn: where that is EOI, Identify and Decode would have seen nothing else either (neither looks behind EOI) and
+//      the plan stands -- including Identify's "last DRI in the file" (every DRI lay in front of the SOS);
+//   4. every other file (several scans, progressive, tables or garbage behind the scan, truncated data, a Decode-walk
+//      failure that a later Identify failure would pre-empt) takes the full walk of both loops, also on the crew.
 
-    for (int i = 0; i < n; i++) {
-        ImagePlan &img = images_[i];
-        file_ptr[i] = jpeg[i];
-        file_len[i] = len[i];
-        img.file_len = len[i];
-        const size_t first_job = jobs_.size();
-        bool decoding = false;  // Identify() is over, Decode()'s marker loop is running
-        std::vector<size_t> seq_ends;
-        HostDecoder dec;
-        PlanHandler handler(&jobs_, entropy_only_);
+namespace {
+struct NeedFullWalk {};  // the header-only planner met something that is not "headers, one sequential scan"
+
+class FastPlanHandler final : public ScanHandler {
+  public:
+    explicit FastPlanHandler(std::vector<ScanJob> *jobs) : jobs_(jobs) {}
+    void on_frame(HostDecoder &dec, int sof) override {
+        if (sof != kSOF0 && sof != kSOF1) throw NeedFullWalk{};
+        geo_ = BaselineGeometry::latch(dec, dec.frame_header());  // DRI latched at SOF time
+    }
+    void on_scan(HostDecoder &dec, MarkerReader &reader, const ScanHeader &scan) override {
+        if (scan.num_components == 0) throw NeedFullWalk{};
+        const uint8_t *entropy = reader.remaining_bytes();
+        const size_t len = (size_t)reader.remaining_byte_count();
+        jobs_->push_back(make_scan_job(dec, geo_, scan, entropy, len, false));
+        reader.try_advance((int)len);  // the plan: nothing but this scan's data and an EOI follow (checked on the device)
+    }
+    void on_dispose(HostDecoder &) override {}
+
+  private:
+    std::vector<ScanJob> *jobs_;
+    BaselineGeometry geo_;
+};
+}  // namespace
+
+struct DeviceBatch::FilePlan {
+    ImagePlan img;
+    std::vector<ScanJob> jobs;
+    std::vector<size_t> seq_ends;  // where each sequential scan's data stops (offset from the scan's first entropy byte)
+    bool speculative = false;      // header-only plan, waiting for the device's verdict
+    bool need_full = false;
+    size_t scan_data_pos = 0;      // offset of the first entropy byte in the file (speculative plans)
+};
+
+// Identify + Decode's marker loop over the whole file (both walk the entropy bytes): the general path.
+void DeviceBatch::plan_file_full(const uint8_t *file, size_t len, int index, FilePlan &fp) const {
+    fp.jobs.clear();
+    fp.seq_ends.clear();
+    fp.speculative = false;
+    fp.img = ImagePlan();
+    ImagePlan &img = fp.img;
+    img.file_len = len;
+    bool decoding = false;  // Identify() is over, Decode()'s marker loop is running
+    HostDecoder dec;
+    PlanHandler handler(&fp.jobs, entropy_only_);
+    try {
+        if (len > 0x7FFFFFF0u) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "JPEG streams of 2 GiB or more are not supported.");
+        dec.set_input(file, len);
+        if (entropy_only_) {
+            // optimizer path: JpegOptimizer.Scan() runs no Identify(); the restart interval is the one in force at the
+            // scan (OptimizeBatch::plan_file found it) unless a DRI segment in front of the frame header says otherwise
+            if ((size_t)index < preset_dri_.size()) dec.set_restart_interval(preset_dri_[index]);
+        } else {
+            dec.identify(false);  // every reference caller runs Identify before Decode; it latches the LAST DRI (F4)
+        }
+        img.sof = (uint8_t)dec.start_of_frame();
+        decoding = true;
         try {
-            if (len[i] > 0x7FFFFFF0u) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "JPEG streams of 2 GiB or more are not supported.");
-            dec.set_input(jpeg[i], len[i]);
-            if (entropy_only_) {
-                // optimizer path: JpegOptimizer.Scan() runs no Identify(); the restart interval is the one in force at the
-                // scan (OptimizeBatch::plan_file found it) unless a DRI segment in front of the frame header says otherwise
-                if ((size_t)i < preset_dri_.size()) dec.set_restart_interval(preset_dri_[i]);
-            } else {
-                dec.identify(false);  // every reference caller runs Identify before Decode; it latches the LAST DRI (F4)
-            }
-            img.sof = (uint8_t)dec.start_of_frame();
-            decoding = true;
+            dec.decode(handler, true);
+        } catch (...) {
+            fp.seq_ends = handler.sequential_ends();
+            throw;
+        }
+        decoding = false;
+        if (entropy_only_) img.sof = (uint8_t)dec.start_of_frame();
+        if (fp.jobs.empty()) {
+            // no scan: Decode() succeeds without writing anything; keep the frame geometry for the caller
+            if (img.sof == kSOF0 || img.sof == kSOF1 || img.sof == kSOF2) plan_image_geometry(img, BaselineGeometry::latch(dec, dec.frame_header()));
+        } else {
+            plan_image_geometry(img, fp.jobs[0].geo);
+            img.blocks_per_mcu = (uint32_t)fp.jobs[0].blocks_per_mcu;
+        }
+        fp.seq_ends = handler.sequential_ends();
+    } catch (const DecodeError &e) {
+        // the scans of a progressive frame recorded before the walk failed ran in the reference too (each ProcessScan
+        // decodes its scan on the spot): they are kept so that their own failures come first
+        if (decoding && e.status != JPGPU_ERR_NOT_SUPPORTED) {
             try {
-                dec.decode(handler, true);
-            } catch (...) {
-                seq_ends = handler.sequential_ends();
-                throw;
-            }
-            decoding = false;
-            if (entropy_only_) img.sof = (uint8_t)dec.start_of_frame();
-            if (jobs_.size() == first_job) {
-                // no scan: Decode() succeeds without writing anything; keep the frame geometry for the caller
-                if (img.sof == kSOF0 || img.sof == kSOF1 || img.sof == kSOF2) plan_image_geometry(img, BaselineGeometry::latch(dec, dec.frame_header()));
-            } else {
-                plan_image_geometry(img, jobs_[first_job].geo);
-                img.blocks_per_mcu = (uint32_t)jobs_[first_job].blocks_per_mcu;
-            }
-            for (size_t j = first_job; j < jobs_.size(); j++) {
-                img.jobs.push_back((int)j);
-                job_image_.push_back(i);
-                job_entropy_off_.push_back(jobs_[j].entropy ? (uint64_t)(jobs_[j].entropy - jpeg[i]) : 0u);
-            }
-            seq_ends = handler.sequential_ends();
-        } catch (const DecodeError &e) {
-            // the scans of a progressive frame recorded before the walk failed ran in the reference too (each ProcessScan
-            // decodes its scan on the spot): they are kept so that their own failures come first
-            if (decoding && e.status != JPGPU_ERR_NOT_SUPPORTED) {
-                try {
-                    handler.on_dispose(dec);
-                } catch (const DecodeError &) {
-                }
-            }
-            bool keep = decoding && jobs_.size() > first_job && e.status != JPGPU_ERR_NOT_SUPPORTED;
-            if (keep) {
-                // scans handed to the scan decoder before the walk failed: they run, the failure is reported behind them
-                img.late_status = e.status;
-                img.late_detail = e.detail;
-                img.late_error = e.what();
-                plan_image_geometry(img, jobs_[first_job].geo);
-                img.blocks_per_mcu = (uint32_t)jobs_[first_job].blocks_per_mcu;
-                for (size_t j = first_job; j < jobs_.size(); j++) {
-                    img.jobs.push_back((int)j);
-                    job_image_.push_back(i);
-                    job_entropy_off_.push_back(jobs_[j].entropy ? (uint64_t)(jobs_[j].entropy - jpeg[i]) : 0u);
-                }
-            } else {
-                jobs_.resize(first_job);
-                job_image_.resize(first_job);
-                job_entropy_off_.resize(first_job);
-                img.jobs.clear();
-                img.status = e.status;
-                img.detail = e.detail;
-                img.error = e.what();
+                handler.on_dispose(dec);
+            } catch (const DecodeError &) {
             }
         }
-        if (!entropy_only_ && img.status == JPGPU_OK) plan_swallowed_terminator(img, jpeg[i], len[i], seq_ends);
+        const bool keep = decoding && !fp.jobs.empty() && e.status != JPGPU_ERR_NOT_SUPPORTED;
+        if (keep) {
+            // scans handed to the scan decoder before the walk failed: they run, the failure is reported behind them
+            img.late_status = e.status;
+            img.late_detail = e.detail;
+            img.late_error = e.what();
+            try {
+                plan_image_geometry(img, fp.jobs[0].geo);
+                img.blocks_per_mcu = (uint32_t)fp.jobs[0].blocks_per_mcu;
+            } catch (const DecodeError &e2) {
+                fp.jobs.clear();
+                img.status = e2.status;
+                img.detail = e2.detail;
+                img.error = e2.what();
+            }
+        } else {
+            fp.jobs.clear();
+            img.status = e.status;
+            img.detail = e.detail;
+            img.error = e.what();
+        }
     }
-    return layout_and_upload(file_ptr, file_len);
+    if (!entropy_only_ && img.status == JPGPU_OK) plan_swallowed_terminator(fp, file, len, false);
+}
+
+// Headers only: both marker loops up to the first SOS header, the scan planned as the file's only one.
+void DeviceBatch::plan_file_headers(const uint8_t *file, size_t len, FilePlan &fp) const {
+    fp.jobs.clear();
+    fp.seq_ends.clear();
+    fp.speculative = fp.need_full = false;
+    fp.img = ImagePlan();
+    ImagePlan &img = fp.img;
+    img.file_len = len;
+    if (entropy_only_ || len > 0x7FFFFFF0u) {
+        fp.need_full = true;  // optimizer walks have rules of their own; oversize files are refused by the full path
+        return;
+    }
+    HostDecoder dec;
+    try {
+        dec.set_input(file, len);
+        if (!dec.identify_until_scan(false, &fp.scan_data_pos)) {
+            fp.need_full = true;  // no scan in the file: the walk just done WAS the whole Identify; let the general path plan it
+            return;
+        }
+        if (!dec.has_frame_header()) {
+            fp.need_full = true;  // SOS in front of any SOF: Identify's verdict depends on what follows the scan
+            return;
+        }
+    } catch (const DecodeError &e) {
+        // Identify fails in front of the first scan: that is what the caller sees, whatever follows
+        img.status = e.status;
+        img.detail = e.detail;
+        img.error = e.what();
+        return;
+    }
+    img.sof = (uint8_t)dec.start_of_frame();
+    try {
+        FastPlanHandler handler(&fp.jobs);
+        dec.decode(handler, true);
+        if (fp.jobs.size() != 1) throw NeedFullWalk{};
+        plan_image_geometry(img, fp.jobs[0].geo);
+        img.blocks_per_mcu = (uint32_t)fp.jobs[0].blocks_per_mcu;
+        fp.speculative = true;
+    } catch (const NeedFullWalk &) {
+        fp.need_full = true;
+    } catch (const DecodeError &) {
+        // Decode's loop fails before the scan is planned -- but Identify walks the WHOLE file first, and a failure of
+        // its own behind the scan would be the one the caller sees: only the full walk can tell
+        fp.need_full = true;
+    }
+    if (fp.need_full) fp.jobs.clear();
 }
 
 // What Decode() ends in when the LAST sequential scan of the file leaves its reader one byte into the terminating marker.
-void DeviceBatch::plan_swallowed_terminator(ImagePlan &img, const uint8_t *file, size_t len, const std::vector<size_t> &ends) {
+// identify_is_clean: the header-only path already knows that Identify() succeeds (and what it latched lies in front of
+// the first SOS): its walk over the entropy data is not repeated.
+void DeviceBatch::plan_swallowed_terminator(FilePlan &fp, const uint8_t *file, size_t len, bool identify_is_clean) const {
+    ImagePlan &img = fp.img;
     img.swallow_status = JPGPU_OK;
     img.swallow_detail = 0;
     img.swallow_error.clear();
     img.swallow_job = -1;
-    if (ends.empty() || img.jobs.empty()) return;
+    const std::vector<size_t> &ends = fp.seq_ends;
+    if (ends.empty() || fp.jobs.empty()) return;
     int last = -1, n_seq = 0;
-    for (int j : img.jobs)
-        if (jobs_[j].kind == kScanSequential) {
-            last = j;
+    for (size_t j = 0; j < fp.jobs.size(); j++)
+        if (fp.jobs[j].kind == kScanSequential) {
+            last = (int)j;
             n_seq++;
         }
-    if (last < 0 || n_seq != (int)ends.size() || ends.back() >= jobs_[last].entropy_len) return;  // no marker behind it
-    img.swallow_job = last;
+    if (last < 0 || n_seq != (int)ends.size() || ends.back() >= fp.jobs[last].entropy_len) return;  // no marker behind it
+    img.swallow_job = last;  // index into fp.jobs; upload_files turns it into a batch job index
     try {
         HostDecoder dec;
         dec.set_input(file, len);
-        dec.identify(false);
+        if (identify_is_clean) {
+            size_t pos;
+            (void)dec.identify_until_scan(false, &pos);
+        } else {
+            dec.identify(false);
+        }
         PlanHandler replay(&ends, n_seq - 1);
         dec.decode(replay, true);
     } catch (const DecodeError &e) {
@@ -313,6 +406,261 @@ void DeviceBatch::plan_swallowed_terminator(ImagePlan &img, const uint8_t *file,
         img.swallow_detail = e.detail;
         img.swallow_error = e.what();
     }
+}
+
+static int default_host_threads() {
+    if (const char *ev = getenv("JPGPU_HOST_THREADS")) return std::max(1, atoi(ev));
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::min(32u, std::max(1u, hc));
+}
+
+int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int n, int format) {
+    if (n < 0 || (n > 0 && (!jpeg || !len))) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: null argument");
+    if (format < 0 || format > 4) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: unknown format");
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return (float)std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    const clk::time_point t_begin = clk::now();
+    ingest_ = IngestStats();
+    hipError_t e = hipSetDevice(ctx_->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    format_ = format;
+    images_.assign((size_t)n, ImagePlan());
+    jobs_.clear();
+    job_image_.clear();
+    job_entropy_off_.clear();
+    std::vector<const uint8_t *> file_ptr(jpeg, jpeg + n);
+    std::vector<size_t> file_len(len, len + n);
+    std::vector<FilePlan> plans((size_t)n);
+
+    uint64_t total_bytes = 0;
+    for (int i = 0; i < n; i++) total_bytes += len[i];
+    const int want = ctx_->host_threads > 0 ? ctx_->host_threads : default_host_threads();
+    // no more threads than there is work for: one per 8 files or per 2 MiB, whichever asks for more
+    const int useful = (int)std::max<uint64_t>((uint64_t)(n + 7) / 8, total_bytes >> 21);
+    WorkCrew crew(std::max(1, std::min(want, useful)));
+    ingest_.threads = crew.threads();
+
+    // ---- 1. header-only plans
+    clk::time_point t0 = clk::now();
+    crew.run((size_t)n, [&](size_t i, int) { plan_file_headers(jpeg[i], len[i], plans[i]); });
+    ingest_.parse_ms = ms_since(t0);
+
+    // ---- 2. the files -> HBM (every file gets its slot, whatever became of its plan: the layout does not wait for plans)
+    t0 = clk::now();
+    uint64_t in_off = 256;
+    for (int i = 0; i < n; i++) {
+        plans[i].img.file_offset = in_off;
+        if (len[i] <= 0x7FFFFFF0u) in_off = align_up(in_off + len[i], 256);
+    }
+    input_bytes_ = in_off + 256;
+    int rc = stage_files(crew, file_ptr, file_len, plans);
+    if (rc != JPGPU_OK) return rc;
+
+    // ---- 3. the device's verdict on the header-only plans
+    std::vector<int> spec;
+    for (int i = 0; i < n; i++)
+        if (plans[i].speculative) spec.push_back(i);
+    if (!spec.empty()) {
+        std::vector<uint32_t> first;
+        rc = verify_plans(plans, spec, first);
+        if (rc != JPGPU_OK) return rc;
+        for (size_t k = 0; k < spec.size(); k++) {
+            FilePlan &fp = plans[spec[k]];
+            const uint8_t *data = jpeg[spec[k]] + fp.scan_data_pos;
+            const size_t dlen = len[spec[k]] - fp.scan_data_pos;
+            const uint32_t pos = first[k];
+            // classify16 only calls FF xx a marker when xx exists: pos + 1 < dlen
+            if (pos != 0xFFFFFFFFu && (size_t)pos + 1 < dlen && data[pos] == 0xFF && data[pos + 1] == kEOI) {
+                fp.seq_ends.assign(1, (size_t)pos);
+            } else {
+                fp.speculative = false;
+                fp.need_full = true;
+                fp.jobs.clear();
+            }
+        }
+    } else {
+        e = hipStreamSynchronize(ctx_->upload_stream);  // the caller's buffers may be released after upload returns
+        if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(upload)");
+    }
+    ingest_.copy_ms = ms_since(t0);
+
+    // ---- 4. the rest: "one byte into the terminator" verdicts of the confirmed plans, full walks of everything else
+    t0 = clk::now();
+    crew.run((size_t)n, [&](size_t i, int) {
+        FilePlan &fp = plans[i];
+        const uint64_t off = fp.img.file_offset;
+        if (fp.speculative) plan_swallowed_terminator(fp, jpeg[i], len[i], true);
+        else if (fp.need_full) plan_file_full(jpeg[i], len[i], (int)i, fp);
+        fp.img.file_offset = off;
+    });
+    ingest_.full_walk_ms = ms_since(t0);
+
+    // ---- 5. merge into the batch's job list (file order)
+    t0 = clk::now();
+    for (int i = 0; i < n; i++) {
+        FilePlan &fp = plans[i];
+        const size_t first_job = jobs_.size();
+        if (fp.speculative) ingest_.n_header_only++;
+        else if (fp.need_full) ingest_.n_full_walk++;
+        images_[i] = std::move(fp.img);
+        ImagePlan &img = images_[i];
+        img.file_len = len[i];
+        img.jobs.clear();
+        if (img.status != JPGPU_OK) continue;
+        for (size_t j = 0; j < fp.jobs.size(); j++) {
+            img.jobs.push_back((int)(first_job + j));
+            job_image_.push_back(i);
+            job_entropy_off_.push_back(fp.jobs[j].entropy ? (uint64_t)(fp.jobs[j].entropy - jpeg[i]) : 0u);
+            jobs_.push_back(std::move(fp.jobs[j]));
+        }
+        if (img.swallow_job >= 0) img.swallow_job += (int)first_job;
+    }
+    plans.clear();
+    files_resident_ = true;
+    rc = layout_and_upload(file_ptr, file_len);
+    files_resident_ = false;
+    ingest_.layout_ms = ms_since(t0);
+    ingest_.total_ms = ms_since(t_begin);
+    return rc;
+}
+
+// Step 2 of the ingest: caller memory -> pinned staging ring -> HBM.  The input buffer is cut into pieces that never cross
+// a 32 MiB slot; the crew copies pieces in buffer order, whoever completes a slot sends it off (one DMA per slot) and
+// records the event that frees the slot for the chunk four slots later.
+int DeviceBatch::stage_files(WorkCrew &crew, const std::vector<const uint8_t *> &file_ptr, const std::vector<size_t> &file_len,
+                             const std::vector<FilePlan> &plans) {
+    hipError_t e = d_input_.reserve((size_t)input_bytes_);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(input)");
+    struct Piece {
+        const uint8_t *src;  // nullptr: zero fill (slack in front of the first file, behind the last, between files)
+        uint64_t dst;
+        uint32_t n;
+    };
+    constexpr uint64_t kSlot = StagingRing::kSlotBytes;
+    constexpr uint32_t kPieceMax = 2u << 20;
+    std::vector<Piece> pieces;
+    auto add = [&](const uint8_t *src, uint64_t dst, uint64_t n) {
+        while (n) {
+            const uint64_t room = kSlot - dst % kSlot;
+            const uint32_t m = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(n, room), kPieceMax);
+            pieces.push_back({src, dst, m});
+            if (src) src += m;
+            dst += m;
+            n -= m;
+        }
+    };
+    uint64_t pos = 0;
+    for (size_t i = 0; i < plans.size(); i++) {
+        const uint64_t off = plans[i].img.file_offset;
+        if (file_len[i] > 0x7FFFFFF0u || file_len[i] == 0 || !file_ptr[i]) continue;
+        if (off > pos) add(nullptr, pos, off - pos);
+        add(file_ptr[i], off, file_len[i]);
+        pos = off + file_len[i];
+    }
+    if (input_bytes_ > pos) add(nullptr, pos, input_bytes_ - pos);
+
+    const size_t n_chunks = (size_t)((input_bytes_ + kSlot - 1) / kSlot);
+    std::vector<std::atomic<int>> remaining(n_chunks);
+    std::vector<std::atomic<int>> state(n_chunks);  // 0 = being filled, 1 = DMA issued (event recorded), 2 = slot known drained
+    for (size_t c = 0; c < n_chunks; c++) {
+        remaining[c].store(0, std::memory_order_relaxed);
+        state[c].store(0, std::memory_order_relaxed);
+    }
+    for (const Piece &p : pieces) remaining[p.dst / kSlot].fetch_add(1, std::memory_order_relaxed);
+    StagingRing &ring = ctx_->staging;
+    for (size_t c = 0; c < std::min<size_t>(n_chunks, StagingRing::kSlots); c++) {
+        if (!ring.slot[c]) {
+            e = hipHostMalloc((void **)&ring.slot[c], kSlot, hipHostMallocDefault);
+            if (e != hipSuccess) return hip_fail(e, "hipHostMalloc(staging)");
+        }
+        if (!ring.drained[c]) {
+            e = hipEventCreateWithFlags(&ring.drained[c], hipEventDisableTiming);
+            if (e != hipSuccess) return hip_fail(e, "hipEventCreate(staging)");
+        }
+    }
+    std::atomic<int> hip_error{(int)hipSuccess};
+    const int device = ctx_->device;
+    hipStream_t up = ctx_->upload_stream;
+    uint8_t *d_in = (uint8_t *)d_input_.ptr;
+    const uint64_t total = input_bytes_;
+    crew.run(pieces.size(), [&](size_t k, int) {
+        const Piece &p = pieces[k];
+        const size_t c = (size_t)(p.dst / kSlot);
+        const int slot = (int)(c % StagingRing::kSlots);
+        if (hip_error.load(std::memory_order_relaxed) != (int)hipSuccess) return;
+        (void)hipSetDevice(device);
+        if (c >= (size_t)StagingRing::kSlots) {
+            // the slot still holds chunk c - kSlots until that chunk's DMA has read it
+            std::atomic<int> &prev = state[c - StagingRing::kSlots];
+            while (prev.load(std::memory_order_acquire) == 0) {
+                if (hip_error.load(std::memory_order_relaxed) != (int)hipSuccess) return;
+                std::this_thread::yield();
+            }
+            if (prev.load(std::memory_order_acquire) == 1) {
+                const hipError_t es = hipEventSynchronize(ring.drained[slot]);
+                if (es != hipSuccess) {
+                    hip_error.store((int)es);
+                    return;
+                }
+                prev.store(2, std::memory_order_release);
+            }
+        }
+        uint8_t *dst = ring.slot[slot] + (p.dst - (uint64_t)c * kSlot);
+        if (p.src) memcpy(dst, p.src, p.n);
+        else memset(dst, 0, p.n);
+        if (remaining[c].fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            const uint64_t base = (uint64_t)c * kSlot;
+            const size_t bytes = (size_t)std::min<uint64_t>(kSlot, total - base);
+            hipError_t ec = hipMemcpyAsync(d_in + base, ring.slot[slot], bytes, hipMemcpyHostToDevice, up);
+            if (ec == hipSuccess) ec = hipEventRecord(ring.drained[slot], up);
+            if (ec != hipSuccess) hip_error.store((int)ec);
+            state[c].store(1, std::memory_order_release);
+        }
+    });
+    if (hip_error.load() != (int)hipSuccess) {
+        (void)hipStreamSynchronize(up);
+        return hip_fail((hipError_t)hip_error.load(), "staged H2D");
+    }
+    return JPGPU_OK;
+}
+
+// Step 3 of the ingest: first marker that is not RSTn behind every planned SOS header (first_marker_kernel); synchronises
+// the upload stream, so the caller's buffers are free once this returns.
+int DeviceBatch::verify_plans(const std::vector<FilePlan> &plans, const std::vector<int> &spec, std::vector<uint32_t> &first) {
+    const size_t n = spec.size();
+    std::vector<uint32_t> host(3 * n);  // {offset lo, length} pairs, then offset hi
+    uint32_t max_len = 0;
+    for (size_t k = 0; k < n; k++) {
+        const FilePlan &fp = plans[spec[k]];
+        const uint64_t off = fp.img.file_offset + fp.scan_data_pos;
+        const uint32_t dlen = (uint32_t)(fp.img.file_len - fp.scan_data_pos);
+        host[2 * k] = (uint32_t)off;
+        host[2 * k + 1] = dlen;
+        host[2 * n + k] = (uint32_t)(off >> 32);
+        max_len = std::max(max_len, dlen);
+    }
+    hipError_t e = d_verify_.reserve(4 * n * sizeof(uint32_t) + 256);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(verify)");
+    StagingRing &ring = ctx_->staging;
+    if (ring.verdict_cap < n) {
+        if (ring.verdict) (void)hipHostFree(ring.verdict);
+        ring.verdict = nullptr;
+        ring.verdict_cap = 0;
+        const size_t cap = std::max<size_t>(n, 4096);
+        e = hipHostMalloc((void **)&ring.verdict, cap * sizeof(uint32_t), hipHostMallocDefault);
+        if (e != hipSuccess) return hip_fail(e, "hipHostMalloc(verdict)");
+        ring.verdict_cap = cap;
+    }
+    hipStream_t up = ctx_->upload_stream;
+    uint32_t *d = (uint32_t *)d_verify_.ptr;
+    e = hipMemcpyAsync(d, host.data(), 3 * n * sizeof(uint32_t), hipMemcpyHostToDevice, up);
+    if (e == hipSuccess) e = hipMemsetAsync(d + 3 * n, 0xFF, n * sizeof(uint32_t), up);
+    if (e == hipSuccess) e = launch_first_marker(up, (const uint8_t *)d_input_.ptr, d, d + 2 * n, (int)n, max_len, d + 3 * n);
+    if (e == hipSuccess) e = hipMemcpyAsync(ring.verdict, d + 3 * n, n * sizeof(uint32_t), hipMemcpyDeviceToHost, up);
+    if (e == hipSuccess) e = hipStreamSynchronize(up);
+    if (e != hipSuccess) return hip_fail(e, "ingest verification");
+    first.assign(ring.verdict, ring.verdict + n);
+    return JPGPU_OK;
 }
 
 int DeviceBatch::upload_single_job(const ScanJob &job, int format, const void *initial_output, size_t initial_output_bytes) {
@@ -337,7 +685,8 @@ int DeviceBatch::upload_single_job(const ScanJob &job, int format, const void *i
     if (initial_output && initial_output_bytes) {
         out_clear_.clear();  // the caller's buffer is the canvas: what this scan does not write keeps the caller's samples
         const size_t nbytes = std::min<size_t>(initial_output_bytes, img.out_bytes);
-        hipError_t e = hipMemcpyAsync((uint8_t *)d_out_.ptr + img.out_offset, initial_output, nbytes, hipMemcpyHostToDevice, ctx_->stream);
+        hipError_t e = hipMemcpyAsync((uint8_t *)d_out_.ptr + img.out_offset, initial_output, nbytes, hipMemcpyHostToDevice, ctx_->upload_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx_->upload_stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(initial output)");
     }
     return JPGPU_OK;
@@ -431,19 +780,17 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     status_valid_ = false;
     ev_used_ = 0;
-    token_buffers_ready_ = false;
-    {
-        const char *env = getenv("JPGPU_PIPELINE");
-        use_tokens_ = (env && strcmp(env, "tokens") == 0);  // default: coefficient pipeline (faster as of r1c)
-    }
 
-    // ---- input layout
-    uint64_t in_off = 256;
-    for (size_t i = 0; i < images_.size(); i++) {
-        images_[i].file_offset = in_off;
-        if (images_[i].status == JPGPU_OK && !images_[i].jobs.empty()) in_off = align_up(in_off + file_len[i], 256);
+    // ---- input layout (jpgpu_batch_upload has laid the files out and sent them already: files_resident_)
+    if (!files_resident_) {
+        uint64_t in_off = 256;
+        for (size_t i = 0; i < images_.size(); i++) {
+            images_[i].file_offset = in_off;
+            if (images_[i].status == JPGPU_OK && !images_[i].jobs.empty()) in_off = align_up(in_off + file_len[i], 256);
+        }
+        input_bytes_ = in_off + 256;
     }
-    input_bytes_ = in_off + 256;
+    hipStream_t up = ctx_->upload_stream;  // everything an upload does stays off the decode stream
 
     // ---- per-image output / coefficient layout, scan descriptors, pools, work lists
     huff_pool_.clear();
@@ -467,6 +814,9 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     const uint32_t stream_max_intervals = getenv("JPGPU_PROG_STREAM_MAX_INTERVALS") ? (uint32_t)atoi(getenv("JPGPU_PROG_STREAM_MAX_INTERVALS")) : 16u;
     prog_clear_.clear();
     prog_pipelined_ = getenv("JPGPU_PROG_NO_PIPELINE") == nullptr;
+    // polls (~2-3 us each) a follower scan of the pipelined launch may spend before it gives up: ~10 s by default
+    prog_spin_budget_ = getenv("JPGPU_PROG_SPIN_BUDGET") ? (uint32_t)strtoul(getenv("JPGPU_PROG_SPIN_BUDGET"), nullptr, 10) : (1u << 22);
+    prog_fallbacks_ = 0;
     rgb_convert_.clear();
     sub_scan_ids_.clear();
     total_subs_ = 0;
@@ -479,11 +829,26 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     compressed_bytes_ = 0;
     total_pixels_ = 0;
     n_huff_slots_ = 1;
+    // the device image of a table depends on BITS / HUFFVAL alone: look those up before building it (a batch of
+    // camera files carries the same four tables a thousand times)
+    struct HuffKey {
+        uint8_t bits[16];
+        uint16_t num_values;
+        uint8_t values[256];
+    };
+    std::vector<HuffKey> huff_keys;
     auto huff_index = [&](const HuffTable &t) -> uint16_t {
+        for (size_t i = 0; i < huff_keys.size(); i++)
+            if (huff_keys[i].num_values == t.num_values && memcmp(huff_keys[i].bits, t.bits, 16) == 0 &&
+                memcmp(huff_keys[i].values, t.values, t.num_values) == 0)
+                return (uint16_t)i;
         DevHuffTable d;
         t.to_device(&d);
-        for (size_t i = 0; i < huff_pool_.size(); i++)
-            if (memcmp(&huff_pool_[i], &d, sizeof d) == 0) return (uint16_t)i;
+        HuffKey k;
+        memcpy(k.bits, t.bits, 16);
+        k.num_values = t.num_values;
+        memcpy(k.values, t.values, sizeof k.values);
+        huff_keys.push_back(k);
         huff_pool_.push_back(d);
         return (uint16_t)(huff_pool_.size() - 1);
     };
@@ -520,7 +885,6 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             }
             // progressive entropy scans accumulate into their frame's store (the frame job precedes them)
             s.coef_off = job.kind == kScanProgressive ? h_scans_[img.jobs[0]].coef_off : coef_off;
-            s.tok_base = (uint64_t)kTokensPerByte * s.data_off;  // interval slices are addressed by compressed byte offset
             s.out_off = img.out_offset;
             s.dri = job.kind == kScanProgressive ? job.scan_dri : g.restart_interval;
             s.mcus_per_line = (uint32_t)g.mcus_per_line;
@@ -677,13 +1041,16 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     out_clear_.clear();
     for (const ImagePlan &img : images_) {
         if (img.status != JPGPU_OK || img.out_bytes == 0) continue;
-        uint32_t covered = 0;
+        // frame components are 0..254 (a baseline frame may carry up to 255; scans are capped at 4): a 256-bit set
+        uint64_t covered[4] = {0, 0, 0, 0};
         for (int j : img.jobs) {
             const DevScan &s = h_scans_[j];
             if (jobs_[j].kind == kScanProgressive) continue;
-            for (int c = 0; c < s.scan_components; c++) covered |= 1u << s.comp[c].component_index;
+            for (int c = 0; c < s.scan_components; c++) covered[s.comp[c].component_index >> 6] |= 1ull << (s.comp[c].component_index & 63);
         }
-        if (covered != (1u << img.num_components) - 1u) out_clear_.push_back({img.out_offset, img.out_bytes});
+        bool all = true;
+        for (int c = 0; c < img.num_components; c++) all &= ((covered[c >> 6] >> (c & 63)) & 1ull) != 0;
+        if (!all) out_clear_.push_back({img.out_offset, img.out_bytes});
     }
     idct_class_begin_[0] = 0;
     const int xcds = getenv("JPGPU_XCD_MAP") ? atoi(getenv("JPGPU_XCD_MAP")) : 8;  // MI355X: 8 XCDs; 0 / 1 = memory order (A/B switch)
@@ -743,29 +1110,32 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         e = u.buf->reserve(std::max(u.bytes, u.reserve));
         if (e != hipSuccess) return hip_fail(e, "hipMalloc");
         if (u.bytes) {
-            e = hipMemcpyAsync(u.buf->ptr, u.src, u.bytes, hipMemcpyHostToDevice, ctx_->stream);
+            e = hipMemcpyAsync(u.buf->ptr, u.src, u.bytes, hipMemcpyHostToDevice, up);
             if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(descriptors)");
         }
     }
-    e = launch_lut_pool(ctx_->stream, (const DevHuffTable *)d_huff_pool_.ptr, (int)huff_pool_.size(), (uint32_t *)d_lut_pool_.ptr);
+    e = launch_lut_pool(up, (const DevHuffTable *)d_huff_pool_.ptr, (int)huff_pool_.size(), (uint32_t *)d_lut_pool_.ptr);
     if (e != hipSuccess) return hip_fail(e, "lut_pool_kernel");
-    // slack before the first file and after the last one is read by the kernels' wide loads: keep it defined
-    e = hipMemsetAsync(d_input_.ptr, 0, 256, ctx_->stream);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
-    for (size_t i = 0; i < images_.size(); i++) {
-        const ImagePlan &img = images_[i];
-        if (img.status != JPGPU_OK || img.jobs.empty() || !file_ptr[i] || file_len[i] == 0) continue;
-        e = hipMemcpyAsync((uint8_t *)d_input_.ptr + img.file_offset, file_ptr[i], file_len[i], hipMemcpyHostToDevice, ctx_->stream);
-        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(input)");
-        const uint64_t tail = img.file_offset + file_len[i];
-        if (align_up(tail, 256) > tail) {
-            e = hipMemsetAsync((uint8_t *)d_input_.ptr + tail, 0, (size_t)(align_up(tail, 256) - tail), ctx_->stream);
-            if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(tail)");
+    if (!files_resident_) {
+        // single scan jobs / frames handed over by the decoder mirror: small, copied as they are
+        // slack before the first file and after the last one is read by the kernels' wide loads: keep it defined
+        e = hipMemsetAsync(d_input_.ptr, 0, 256, up);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+        for (size_t i = 0; i < images_.size(); i++) {
+            const ImagePlan &img = images_[i];
+            if (img.status != JPGPU_OK || img.jobs.empty() || !file_ptr[i] || file_len[i] == 0) continue;
+            e = hipMemcpyAsync((uint8_t *)d_input_.ptr + img.file_offset, file_ptr[i], file_len[i], hipMemcpyHostToDevice, up);
+            if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(input)");
+            const uint64_t tail = img.file_offset + file_len[i];
+            if (align_up(tail, 256) > tail) {
+                e = hipMemsetAsync((uint8_t *)d_input_.ptr + tail, 0, (size_t)(align_up(tail, 256) - tail), up);
+                if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(tail)");
+            }
         }
+        e = hipMemsetAsync((uint8_t *)d_input_.ptr + input_bytes_ - 256, 0, 256, up);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(slack)");
     }
-    e = hipMemsetAsync((uint8_t *)d_input_.ptr + input_bytes_ - 256, 0, 256, ctx_->stream);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(slack)");
-    e = hipStreamSynchronize(ctx_->stream);  // the caller's buffers may be released after upload returns
+    e = hipStreamSynchronize(up);  // the caller's buffers may be released after upload returns
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(upload)");
     return JPGPU_OK;
 }
@@ -828,7 +1198,7 @@ int DeviceBatch::run_progressive() {
         hipError_t e = launch_progressive_streams(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr,
                                                   (const HuffWork *)d_prog_work_.ptr + prog_stream_begin_.front(), n,
                                                   (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr,
-                                                  (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, 1);
+                                                  (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, 1, prog_spin_budget_);
         if (e != hipSuccess) return hip_fail(e, "progressive_stream_kernel");
         return JPGPU_OK;
     }
@@ -843,7 +1213,7 @@ int DeviceBatch::run_progressive() {
                                        (const HuffWork *)d_prog_work_.ptr + prog_stream_begin_[k],
                                        prog_stream_begin_[k + 1] - prog_stream_begin_[k], (const uint32_t *)d_ends_u_.ptr,
                                        (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr,
-                                       n_huff_slots_, 0);
+                                       n_huff_slots_, 0, 0);
         if (e != hipSuccess) return hip_fail(e, "progressive_stream_kernel");
     }
     return JPGPU_OK;
@@ -874,38 +1244,6 @@ int DeviceBatch::run_idct() {
     return JPGPU_OK;
 }
 
-// The token buffer is sized from the compressed bytes (kTokensPerByte slots of 4 B per input byte) and only allocated
-// when the token pipeline runs.
-int DeviceBatch::ensure_token_buffers() {
-    if (token_buffers_ready_) return JPGPU_OK;
-    hipError_t e = d_tokens_.reserve((size_t)input_bytes_ * kTokensPerByte * sizeof(uint32_t) + 4096);
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc(tokens)");
-    e = d_blk_tok_.reserve((size_t)total_blocks_ * sizeof(uint32_t) + 256);
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc(block token offsets)");
-    token_buffers_ready_ = true;
-    return JPGPU_OK;
-}
-
-int DeviceBatch::run_huffman_tokens() {
-    status_valid_ = false;
-    int rc = ensure_token_buffers();
-    if (rc != JPGPU_OK) return rc;
-    hipError_t e = launch_huffman_tokens(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr,
-                                         (const HuffWork *)d_huff_work_.ptr, n_huff_work_, (const uint32_t *)d_ends_u_.ptr,
-                                         (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (uint32_t *)d_tokens_.ptr,
-                                         (uint32_t *)d_blk_tok_.ptr, n_huff_slots_);
-    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "huffman_tokens_kernel");
-}
-int DeviceBatch::run_idct_tokens() {
-    int rc = ensure_token_buffers();
-    if (rc != JPGPU_OK) return rc;
-    if ((rc = clear_partial_outputs()) != JPGPU_OK) return rc;
-    hipError_t e = launch_idct_tokens(ctx_->stream, (const uint32_t *)d_tokens_.ptr, (const uint32_t *)d_blk_tok_.ptr, (const DevScan *)d_scans_.ptr,
-                                      (const IdctWork *)d_idct_work_.ptr, idct_class_begin_, (const DevScanStatus *)d_status_.ptr,
-                                      (const DevQuantTable *)d_quant_pool_.ptr, (uint8_t *)d_out_.ptr, format_);
-    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "idct_tokens_kernel");
-}
-
 int DeviceBatch::decode() {
     hipError_t e = hipSetDevice(ctx_->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
@@ -921,11 +1259,9 @@ int DeviceBatch::decode() {
     (void)hipEventRecord(ev[0], ctx_->stream);
     if ((rc = run_marker_index()) != JPGPU_OK) return rc;
     (void)hipEventRecord(ev[1], ctx_->stream);
-    // DRI = 0 scans, progressive frames and the RGB formats only have the coefficient path
-    const bool tokens = use_tokens_ && n_sub_work_ == 0 && prog_begin_.size() <= 1 && format_ <= JPGPU_FMT_PLANAR_I16;
-    if ((rc = tokens ? run_huffman_tokens() : run_huffman()) != JPGPU_OK) return rc;
+    if ((rc = run_huffman()) != JPGPU_OK) return rc;
     (void)hipEventRecord(ev[2], ctx_->stream);
-    if ((rc = tokens ? run_idct_tokens() : run_idct()) != JPGPU_OK) return rc;
+    if ((rc = run_idct()) != JPGPU_OK) return rc;
     (void)hipEventRecord(ev[3], ctx_->stream);
     ev_used_ += 4;
     return JPGPU_OK;
@@ -965,6 +1301,20 @@ int DeviceBatch::fetch_status() {
     if (!h_status_.empty()) {
         hipError_t e = hipMemcpy(h_status_.data(), d_status_.ptr, h_status_.size() * sizeof(DevScanStatus), hipMemcpyDeviceToHost);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpy(status)");
+    }
+    if (prog_pipelined_) {
+        // A scan of the pipelined progressive launch ran out of polls waiting for its producers: the launch relies on
+        // workgroups starting in list order, which the dispatcher does but HIP does not promise.  The whole step is issued
+        // again with the frames' scans level by level (fresh launches, no waiting inside a kernel); the batch stays that way.
+        bool timed_out = false;
+        for (const DevScanStatus &st : h_status_) timed_out |= st.first_error != kNoError && (st.first_error & 0xFFu) == kDetailSpinTimeout;
+        if (timed_out) {
+            prog_pipelined_ = false;
+            prog_fallbacks_++;
+            rc = decode();
+            if (rc != JPGPU_OK) return rc;
+            return fetch_status();
+        }
     }
     status_valid_ = true;
     return JPGPU_OK;

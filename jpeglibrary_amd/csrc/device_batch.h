@@ -10,9 +10,24 @@
 #include "host.h"
 #include "kernels.h"
 
+// Pinned staging ring of a context: the caller's (pageable) file bytes are copied into it by the host crew and leave it
+// as few large DMAs on the context's upload stream (ref input contract: caller-owned, possibly multi-segment
+// ReadOnlySequence<byte>, apps/JpegDecode/MemoryPoolBufferWriter.cs:166-174 -- "the shim linearises into pinned memory").
+struct StagingRing {
+    static constexpr int kSlots = 4;
+    static constexpr size_t kSlotBytes = 32u << 20;
+    uint8_t *slot[kSlots] = {};
+    hipEvent_t drained[kSlots] = {};  // recorded behind the DMA that reads the slot
+    uint32_t *verdict = nullptr;      // pinned: per-file results of the ingest verification kernel
+    size_t verdict_cap = 0;
+};
+
 struct jpgpu_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;         // kernels of jpgpu_batch_decode and friends
+    hipStream_t upload_stream = nullptr;  // H2D of jpgpu_batch_upload: runs beside another batch's decode on `stream`
+    StagingRing staging;
+    int host_threads = 0;                 // crew size of jpgpu_batch_upload; 0 = min(hardware threads, 32)
     std::string last_error;
     int num_cus = 0;
 };
@@ -25,6 +40,14 @@ struct DevBuffer {
     size_t cap = 0;
     hipError_t reserve(size_t bytes);
     void release();
+};
+
+// What the last jpgpu_batch_upload did (jpgpu_batch_ingest_stats).
+struct IngestStats {
+    int threads = 0;
+    int n_header_only = 0;  // files whose plan came from their headers alone, confirmed by the device
+    int n_full_walk = 0;    // files that took the full Identify + Decode marker walks on the host
+    float parse_ms = 0, copy_ms = 0, full_walk_ms = 0, layout_ms = 0, total_ms = 0;
 };
 
 struct ImagePlan {
@@ -53,8 +76,11 @@ struct ImagePlan {
     size_t file_len = 0;
 };
 
+class WorkCrew;
+
 class DeviceBatch {
   public:
+    const IngestStats &ingest_stats() const { return ingest_; }
     explicit DeviceBatch(jpgpu_ctx *ctx) : ctx_(ctx) {}
     ~DeviceBatch();
 
@@ -72,8 +98,6 @@ class DeviceBatch {
     int run_subseq_sync(const uint32_t **final_state, const uint32_t **first_block);  // K2S rounds + prefix sums only
     int run_idct();
     int run_progressive();     // entropy scans of progressive frames (K2P), ordinal by ordinal
-    int run_huffman_tokens();  // token pipeline (K2T)
-    int run_idct_tokens();     // token pipeline (K3T)
     int decode();  // marker index + the selected pipeline, with stage events
     int sync();
 
@@ -95,6 +119,7 @@ class DeviceBatch {
     void totals(uint64_t *compressed, uint64_t *blocks, uint64_t *pixels, uint64_t *out_bytes) const;
     int format() const { return format_; }
     int last_subseq_rounds() const { return last_subseq_rounds_; }
+    int progressive_fallbacks() const { return prog_fallbacks_; }
     // the optimizer path only needs the files, the scan descriptors and the marker index: no coefficient / sample buffers
     void set_entropy_only(bool on) { entropy_only_ = on; }
     void set_preset_restart_intervals(std::vector<int> v) { preset_dri_ = std::move(v); }
@@ -108,8 +133,18 @@ class DeviceBatch {
     int fail(int status, const std::string &msg);
     int hip_fail(hipError_t e, const char *what);
     int layout_and_upload(const std::vector<const uint8_t *> &file_ptr, const std::vector<size_t> &file_len);
-    void plan_image_geometry(ImagePlan &img, const BaselineGeometry &geo);
-    void plan_swallowed_terminator(ImagePlan &img, const uint8_t *file, size_t len, const std::vector<size_t> &ends);
+    void plan_image_geometry(ImagePlan &img, const BaselineGeometry &geo) const;
+    // ingest (jpgpu_batch_upload), see device_batch.cpp
+    struct FilePlan;
+    void plan_file_headers(const uint8_t *file, size_t len, FilePlan &fp) const;
+    void plan_file_full(const uint8_t *file, size_t len, int index, FilePlan &fp) const;
+    void plan_swallowed_terminator(FilePlan &fp, const uint8_t *file, size_t len, bool identify_is_clean) const;
+    int stage_files(WorkCrew &crew, const std::vector<const uint8_t *> &file_ptr, const std::vector<size_t> &file_len,
+                    const std::vector<FilePlan> &plans);
+    int verify_plans(const std::vector<FilePlan> &plans, const std::vector<int> &spec, std::vector<uint32_t> &first);
+    bool files_resident_ = false;  // layout_and_upload: the files are in d_input_ already (staged by upload_files)
+    IngestStats ingest_;
+    DevBuffer d_verify_;
     int fetch_status();
     int clear_partial_outputs();
     bool keep_canvas_ = false;  // layout of a single scan job over the caller's samples: nothing the scan does not write is touched
@@ -132,10 +167,6 @@ class DeviceBatch {
     uint64_t total_blocks_ = 0, out_bytes_ = 0, input_bytes_ = 0, compressed_bytes_ = 0, total_pixels_ = 0;
     uint32_t total_ends_ = 0;
 
-    bool use_tokens_ = false;  // JPGPU_PIPELINE=tokens selects the token pipeline (K2T + K3T) in decode()
-    bool token_buffers_ready_ = false;
-    int ensure_token_buffers();
-    DevBuffer d_tokens_, d_blk_tok_;
     // DRI = 0 scans: self-synchronising subsequence decode (K2S)
     DevBuffer d_lut_pool_;  // fused lookups of every pool table (K2S round kernel)
     DevBuffer d_sub_work_, d_sub_scan_ids_, d_sub_exit_a_, d_sub_exit_b_, d_sub_nblk_, d_sub_first_, d_sub_entry_, d_sub_dcsum_, d_sub_dcentry_, d_sub_changed_;
@@ -149,6 +180,8 @@ class DeviceBatch {
     // ... and the scans with few, long intervals (one wave per interval): prog_work[prog_stream_begin_[k] .. [k + 1])
     std::vector<int> prog_stream_begin_;
     bool prog_pipelined_ = false;  // all progressive scans are single streams with <= 3 direct dependencies: one launch
+    uint32_t prog_spin_budget_ = 1u << 22;  // polls a follower scan may spend in the pipelined launch (JPGPU_PROG_SPIN_BUDGET)
+    int prog_fallbacks_ = 0;                // times the pipelined launch timed out and the step was re-issued level by level
     std::vector<std::pair<uint64_t, uint64_t>> prog_clear_;  // (first block, blocks) of every progressive frame's store
     // RGB / RGBA output for layouts without a fused conversion: INTERLEAVED_U8 samples in a scratch image first
     struct RgbConvert {

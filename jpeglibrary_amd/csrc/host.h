@@ -132,6 +132,11 @@ class HostDecoder {
   public:
     void set_input(const uint8_t *data, size_t len);  // :56-62
     int identify(bool load_quantization_tables);      // :75-105, returns consumed byte count
+    // The same walk, stopped behind the header of the first SOS (the batch ingest's header-only parse: what lies behind
+    // that header is looked at by the device, DeviceBatch::upload_files).  Returns true when it stopped there
+    // (*scan_data_pos = offset of the first entropy byte), false when the walk reached EOI / the end of the data first --
+    // then it WAS the whole Identify(), "Frame header was not found." included.
+    bool identify_until_scan(bool load_quantization_tables, size_t *scan_data_pos);
     bool try_estimate_quality(float *quality) const;  // :169-196
     void decode(ScanHandler &handler, bool have_output_writer);  // :509-550
     void load_tables(const uint8_t *data, size_t len);           // :319-363

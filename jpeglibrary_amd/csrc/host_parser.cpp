@@ -477,6 +477,24 @@ int HostDecoder::identify(bool load_quantization_tables) {
     return r.consumed_byte_count();
 }
 
+bool HostDecoder::identify_until_scan(bool load_quantization_tables, size_t *scan_data_pos) {
+    if (!input_ || input_len_ == 0) throw_invalid_operation("Input buffer is not specified.");
+    MarkerReader r(input_, input_len_);
+    frame_.reset();
+    bool to_continue = true;
+    while (to_continue && !r.is_empty()) {
+        int marker;
+        if (!r.try_read_marker(&marker)) throw_invalid_data_at(r.consumed_byte_count(), "No marker found.", kDetailBadHeader);
+        to_continue = process_marker_for_identification(marker, r, load_quantization_tables);
+        if (marker == kSOS) {
+            *scan_data_pos = (size_t)r.consumed_byte_count();
+            return true;
+        }
+    }
+    if (!frame_) throw_invalid_operation("Frame header was not found.");
+    return false;
+}
+
 // ref: JpegStandardQuantizationTable.cs:12-34 (zig-zag order as stored by the reference)
 static const uint16_t kStdLum[64] = {16, 11, 12, 14, 12, 10, 16, 14, 13, 14, 18, 17, 16, 19, 24, 40, 26, 24, 22, 22, 24, 49,
                                      35, 37, 29, 40, 58, 51, 61, 60, 57, 51, 56, 55, 64, 72, 92, 78, 64, 68, 87, 69, 55, 56,

@@ -48,16 +48,11 @@ hipError_t launch_progressive(hipStream_t stream, const uint8_t *udata, const De
                               const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs, int n_slots);
 hipError_t launch_progressive_streams(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                                       const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
-                                      int n_slots, int pipelined);
+                                      int n_slots, int pipelined, uint32_t spin_budget);
 
-// token pipeline (K2T / K3T)
-hipError_t launch_huffman_tokens(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
-                                 const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, uint32_t *tokens,
-                                 uint32_t *blk_tok, int n_slots);
-hipError_t launch_idct_tokens(hipStream_t stream, const uint32_t *tokens, const uint32_t *blk_tok, const DevScan *scans,
-                              const IdctWork *work, const int class_begin[kNumIdctLayoutClasses + 1], const DevScanStatus *status,
-                              const DevQuantTable *quant_pool, uint8_t *out, int format);
-
+// K0 (ingest verification): offset of the first non-RST marker in each segment {offset lo, length} (+ offset hi), 0xFFFFFFFF = none
+hipError_t launch_first_marker(hipStream_t stream, const uint8_t *data, const void *segs, const uint32_t *seg_hi, int n_segs,
+                               uint32_t max_len, uint32_t *first);
 
 // KT: symbol-level Huffman transcode of baseline scans (JpegOptimizer): mode 0 count, 1 measure, 2 emit (kernels.hip)
 struct EncHuffTable;

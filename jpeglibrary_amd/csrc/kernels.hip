@@ -185,6 +185,26 @@ __global__ __launch_bounds__(kScanThreads) void marker_count_kernel(const uint8_
     }
 }
 
+// K0 (ingest): where does the entropy data that follows a file's first SOS end?  The host parses headers only and plans
+// every file as "one scan whose data runs up to an EOI"; this kernel looks at the bytes the host never touches and reports,
+// per file, the offset of the first marker in them that is not RSTn -- what JpegDecoder.Identify's walk over the same bytes
+// would stop at next (ref: JpegDecoder.cs:75-162, JpegReader.cs:120-158: FF00 and FFFF are skipped, RSTn is a no-op).  The
+// host keeps its plan only where that marker is EOI; every other file takes the full host walk.  One workgroup per 4 KiB,
+// grid (chunks of the longest segment, segments); segs[i] = {byte offset in `data`, length}.
+__global__ __launch_bounds__(kScanThreads) void first_marker_kernel(const uint8_t *__restrict__ data, const uint2 *__restrict__ segs,
+                                                                     const uint32_t *__restrict__ seg_hi, uint32_t *__restrict__ first) {
+    const uint32_t seg = blockIdx.y;
+    const uint64_t seg_off = (uint64_t)segs[seg].x | ((uint64_t)seg_hi[seg] << 32);
+    const uint32_t len = segs[seg].y;
+    const int32_t misalign = (int32_t)(seg_off & 15u);
+    const int64_t off = -(int64_t)misalign + (int64_t)blockIdx.x * kChunkBytes + (int64_t)threadIdx.x * 16;
+    if ((int64_t)blockIdx.x * kChunkBytes - misalign >= (int64_t)len) return;
+    const ByteClass c = classify16(data + seg_off, off, len, false);
+    uint32_t tpos = c.term ? (uint32_t)(off + __builtin_ctz(c.term)) : kInf;
+    tpos = wave_reduce_min(tpos);
+    if (lane_id() == 0 && tpos != kInf) atomicMin(&first[seg], tpos);
+}
+
 // K1p: the summaries of one scan turned into what each of its chunks needs: RSTs / udata bytes of the chunks BEFORE it (in
 // place of its own counts) and the earliest terminator of the whole scan (pad).  One workgroup per scan job.
 __global__ __launch_bounds__(kScanThreads) void marker_prefix_kernel(const DevScan *__restrict__ scans, ChunkSum *__restrict__ sums) {
@@ -364,7 +384,7 @@ __global__ __launch_bounds__(kScanThreads) void marker_write_kernel(const uint8_
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2 / K2T: Huffman MCU decode.  One lane per restart interval.
+// K2: Huffman MCU decode.  One lane per restart interval.
 // ------------------------------------------------------------------------------------------------
 
 // Bit source of one lane == a fresh JpegBitReader positioned at the start of its restart interval (ref: JpegBitReader.cs),
@@ -951,155 +971,6 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
         if (rem < 0) rem = 0;
         const uint32_t code = restart_check(s, st, &status[wk.scan], interval, n_ends, n_intervals, dri_eff, rem, err);
         if (code != kNoError) atomicMin(&status[wk.scan].first_error, code);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2T: Huffman parse to a token stream.  One lane per restart interval, lanes run FREE.
-//
-// K2 keeps the 64 lanes of a wave in lock-step per block (they share one LDS staging that is flushed per block), so
-// every block costs the wave the LONGEST of 64 symbol runs.  Here nothing is shared: each lane walks its whole interval
-// at its own pace and appends one 32-bit token per non-zero coefficient (plus the DC) to its private slice of the token
-// buffer, 16 bytes at a time, and records where every block's tokens start.  The wave finishes when its slowest lane
-// has consumed its interval (max of sums instead of sum of maxes).  Symbol decisions are the same code as K2.
-// ------------------------------------------------------------------------------------------------
-
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void huffman_tokens_kernel(const uint8_t *__restrict__ udata,
-                                                                    const DevScan *__restrict__ scans,
-                                                                    const HuffWork *__restrict__ work,
-                                                                    const uint32_t *__restrict__ ends_u,
-                                                                    DevScanStatus *__restrict__ status,
-                                                                    const DevHuffTable *__restrict__ huff_pool,
-                                                                    uint32_t *__restrict__ tokens,
-                                                                    uint32_t *__restrict__ blk_tok, int n_slots) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *tabs = smem;  // n_slots * sizeof(DevHuffTable)
-    uint32_t *blk_info = reinterpret_cast<uint32_t *>(smem + (size_t)n_slots * sizeof(DevHuffTable));  // [kMaxBlocksPerMcu]
-
-    const HuffWork wk = work[blockIdx.x];
-    const DevScan &s = scans[wk.scan];
-    const uint32_t tid = threadIdx.x;
-
-    for (int slot = 0; slot < kMaxHuffSlots && slot < n_slots; slot++) {
-        const uint32_t pi = s.huff_pool[slot];
-        if (pi == 0xFFFF) continue;
-        const uint4 *src = reinterpret_cast<const uint4 *>(&huff_pool[pi]);
-        uint4 *dst = reinterpret_cast<uint4 *>(tabs + slot * sizeof(DevHuffTable));
-        for (uint32_t i = tid; i < sizeof(DevHuffTable) / 16; i += 64 * WAVES) dst[i] = src[i];
-    }
-    // per block-in-MCU: DC table offset | AC table offset << 12 | scan component << 24  (offsets in 16-byte units)
-    if (tid < kMaxBlocksPerMcu) {
-        const uint32_t ci = s.blk_comp[tid];
-        const uint32_t dc_off = s.comp[ci].dc_slot * (uint32_t)(sizeof(DevHuffTable) / 16);
-        const uint32_t ac_off = s.comp[ci].ac_slot * (uint32_t)(sizeof(DevHuffTable) / 16);
-        blk_info[tid] = dc_off | (ac_off << 12) | (ci << 24);
-    }
-    __syncthreads();
-
-    const DevScanStatus st = status[wk.scan];
-    const uint32_t n_ends = st.n_ends;
-    const uint32_t n_intervals = s.n_intervals;
-    const uint32_t total_mcus = s.total_mcus;
-    const uint32_t dri_eff = s.dri ? s.dri : total_mcus;
-    const uint32_t bpm = s.blocks_per_mcu;
-    const uint32_t interval = wk.first_interval + tid;
-    if (interval >= n_ends) return;  // nothing after the last barrier: lanes may leave
-    const uint32_t *eu = ends_u + s.ends_off;
-
-    const uint32_t ustart = interval == 0 ? 0u : eu[interval - 1] + 2u;
-    UBits r;
-    ub_init(r, udata + s.data_off, ustart, eu[interval]);
-    const bool closed_by_marker = !(interval == n_ends - 1 && st.terminator == 0);
-    const uint32_t my_mcus = (interval == n_intervals - 1) ? total_mcus - interval * dri_eff : dri_eff;
-    const uint32_t my_blocks = my_mcus * bpm;
-
-    // this lane's slice of the token buffer: kTokensPerByte slots per byte of (unstuffed) entropy data, 16-byte aligned
-    const uint32_t tok_rel0 = kTokensPerByte * ustart;  // slot index relative to the scan's tok_base
-    uint32_t *tok = tokens + s.tok_base + tok_rel0;
-    uint32_t *my_blk_tok = blk_tok + s.coef_off + (uint64_t)interval * dri_eff * bpm;
-
-    int32_t pred0 = 0, pred1 = 0, pred2 = 0, pred3 = 0;  // DcPredictor per scan component
-    uint32_t err = 0;
-    uint32_t blk = 0, b_in_mcu = 0, k = 0;  // k == 0: the DC symbol of the block is pending
-    uint32_t info = blk_info[0];
-    uint32_t ntok = 0;          // tokens pushed so far
-    uint4 q = {0, 0, 0, 0};     // the last four pushed tokens, oldest in x
-    uint32_t pending = 0;       // most recent token, held back until we know whether it is the block's last
-    bool have_pending = false;
-    if (my_blocks) my_blk_tok[0] = tok_rel0;
-
-#define JPGPU_PUSH(t_)                                                        \
-    {                                                                         \
-        q.x = q.y;                                                            \
-        q.y = q.z;                                                            \
-        q.z = q.w;                                                            \
-        q.w = (t_);                                                           \
-        ntok++;                                                               \
-        if ((ntok & 3u) == 0) *reinterpret_cast<uint4 *>(tok + ntok - 4) = q; \
-    }
-
-    while (blk < my_blocks) {
-        const bool is_dc = (k == 0);
-        const LdsHuff h = lds_huff16(tabs, is_dc ? (info & 0xFFF) : ((info >> 12) & 0xFFF));
-        uint32_t sym;
-        int32_t v;
-        err = ub_symbol(r, h, is_dc, closed_by_marker, sym, v);
-        if (err != 0) break;
-        const uint32_t rr = is_dc ? 0u : (sym >> 4);
-        const uint32_t ss = is_dc ? sym : (sym & 15u);
-        if (is_dc) {
-            const uint32_t ci = info >> 24;
-            const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
-            v += pred;
-            if (ci == 0) pred0 = v;
-            else if (ci == 1) pred1 = v;
-            else if (ci == 2) pred2 = v;
-            else pred3 = v;
-        }
-        if (is_dc || ss != 0) {
-            uint32_t idx = is_dc ? 0u : (k + rr);
-            idx = idx < 63u ? idx : 63u;  // Math.Min(i++, 63)
-            if (have_pending) JPGPU_PUSH(pending)
-            pending = ((uint32_t)v & 0xFFFFu) | (idx << 16);
-            have_pending = true;
-        }
-        // next position (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:199-221)
-        k = is_dc ? 1u : (ss != 0 ? k + rr + 1u : (rr == 0 ? 64u : k + 16u));
-        if (k >= 64u) {
-            JPGPU_PUSH(pending | kTokLast)
-            have_pending = false;
-            blk++;
-            b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
-            k = 0;
-            if (blk < my_blocks) {
-                my_blk_tok[blk] = tok_rel0 + ntok;
-                info = blk_info[b_in_mcu];
-            }
-        }
-    }
-    // flush the partial quad
-    {
-        const uint32_t n = ntok & 3u;
-        uint32_t *dst = tok + (ntok & ~3u);
-        if (n == 1) dst[0] = q.w;
-        if (n == 2) {
-            dst[0] = q.z;
-            dst[1] = q.w;
-        }
-        if (n == 3) {
-            dst[0] = q.y;
-            dst[1] = q.z;
-            dst[2] = q.w;
-        }
-    }
-#undef JPGPU_PUSH
-
-    const uint32_t code = restart_check(s, st, &status[wk.scan], interval, n_ends, n_intervals, dri_eff, r.rem, err);
-    if (code != kNoError) {
-        atomicMin(&status[wk.scan].first_error, code);
-        // blocks of a failing interval have no complete token run: keep the block-parallel stage away from them
-        if (err != 0) atomicMin(&status[wk.scan].decoded_mcus, interval * dri_eff);
     }
 }
 
@@ -1873,7 +1744,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                                                                 const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
                                                                 DevScanStatus *__restrict__ status,
                                                                 const DevHuffTable *__restrict__ huff_pool, int16_t *__restrict__ coefs,
-                                                                int n_slots, int pipelined) {
+                                                                int n_slots, int pipelined, uint32_t spin_budget) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *tabs = smem;  // n_slots * sizeof(DevHuffTable)
     uint8_t *base = smem + (size_t)n_slots * sizeof(DevHuffTable);
@@ -1966,7 +1837,10 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
     // (after a device-scope release fence) every kPsPublishEvery units; a follower converts that to whole MCU rows of
     // the frame -- the one currency scans of different interleaving share -- and waits (acquire) before it touches a row.
     // Workgroups start in work-list order and the list is sorted by dependency level, so whatever a scan waits for
-    // is running or finished.
+    // is running or finished.  That order is what the dispatcher is OBSERVED to do, not a contract (HIP promises no dispatch
+    // order): every poll draws on `spin_budget`; a scan that exhausts it gives up with kDetailSpinTimeout, publishes
+    // "finished" so that its own followers drain too, and the host re-issues the frame's scans level by level in fresh
+    // launches (DeviceBatch::fetch_status).
     const bool publishes = pipelined != 0 && s.publishes != 0;
     uint32_t *my_progress = &status[wk.scan].pad[1];
     const uint32_t my_units_per_row = units_per_line * (ncomp == 1 ? (uint32_t)s.comp[0].v : 1u);
@@ -1995,6 +1869,11 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
             }                                                                                                   \
             rows_ready = uni(r_);                                                                               \
             if ((row_) < rows_ready) break;                                                                     \
+            if (spin_budget == 0) {                                                                             \
+                err = kDetailSpinTimeout;                                                                       \
+                break;                                                                                          \
+            }                                                                                                   \
+            spin_budget--;                                                                                      \
             __builtin_amdgcn_s_sleep(32);                                                                       \
         }                                                                                                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                                      \
@@ -2082,6 +1961,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                 }
                 JPGPU_ENSURE_STAGED()
                 JPGPU_FOLLOW(w.my)
+                if (err != 0) break;  // gave up waiting (kDetailSpinTimeout)
                 uint64_t index = 0;
                 const bool real = prog_walk_index(fr, p, w, index);
                 int32_t c = 0;
@@ -2101,6 +1981,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                 const uint32_t n = my_units - done < (uint32_t)kPsChunk ? my_units - done : (uint32_t)kPsChunk;
                 if (done != 0) JPGPU_PUBLISH(done)
                 JPGPU_FOLLOW((first_unit + done + n - 1u) / my_units_per_row)
+                if (err != 0) break;  // gave up waiting (kDetailSpinTimeout)
                 if (lane < n) {
                     ProgWalk w;
                     prog_walk_init(w, p, first_unit + done + lane, units_per_line);
@@ -2849,7 +2730,6 @@ __global__ __launch_bounds__(256) void ycc_to_rgb_kernel(const uint8_t *__restri
 }
 
 // Output assembly of the INTERLEAVED_U8 format from the LDS sample tile [8 rows][256 blocks][8 B] (phase C).
-// Shared by the coefficient pipeline (K3) and the token pipeline (K3T).
 // CONV: 0 = the samples as they are (Y,Cb,Cr), 3 / 4 = converted to R,G,B / R,G,B,A bytes (fast layouts only).
 template <int LAY, int CONV>
 __device__ __forceinline__ void interleaved_output_from_tile(const uint8_t *sh_px, const DevScan &s, uint32_t tile_first, uint32_t n_mcu,
@@ -3130,145 +3010,20 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3T: block-parallel token expansion + dequantise + IDCT + level shift + block output.  One lane per block.
-//
-// Each lane rebuilds its block from its token run (K2T) in a private 128-byte LDS row (zeroed, then one ds_write_b16
-// per token), reads it back for DequantizeBlockAndUnZigZag and runs the same register IDCT and output assembly as K3.
-// Nothing is shared between lanes until the sample tile, so there is no staging barrier and no coefficient buffer:
-// per 4K image the stage reads ~6 MB of tokens + 0.8 MB of offsets instead of 24.9 MB of coefficients.
-// ------------------------------------------------------------------------------------------------
-
-template <int FMT, int LAY>
-__global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void idct_tokens_kernel(
-    const uint32_t *__restrict__ tokens, const uint32_t *__restrict__ blk_tok, const DevScan *__restrict__ scans,
-    const IdctWork *__restrict__ work, const DevScanStatus *__restrict__ status, const DevQuantTable *__restrict__ quant_pool,
-    uint8_t *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t sh_all[kIdctThreads * 128 + kIdctThreads * 64 + kMaxScanComponents * 128];
-    uint8_t *sh = sh_all;
-    uint8_t *sh_px = sh_all + kIdctThreads * 128;
-    uint16_t(*sh_q)[64] = reinterpret_cast<uint16_t(*)[64]>(sh_all + kIdctThreads * 128 + kIdctThreads * 64);
-
-    const IdctWork wk = work[blockIdx.x];
-    const DevScan &s = scans[wk.scan];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t bpm = s.blocks_per_mcu;
-    const uint32_t mcus_per_tile = wk.mcus_per_tile;
-    // MCUs the scan never reached (EOI met in a restart check, :144-150): the reference leaves their samples as the caller's
-    // buffer held them -- zero in the buffer the batch owns -- so they go through the same output code with zero samples
-    uint32_t decoded = status ? status[wk.scan].decoded_mcus : s.total_mcus;
-    if (decoded > s.total_mcus) decoded = s.total_mcus;
-    uint32_t range_end = wk.first_mcu + wk.n_mcus;
-    if ((s.shadow_mask & kKeepUnreachedMcus) != 0) {  // the caller's canvas (jpgpu_decode_scan): unreached MCUs are not touched
-        if (range_end > decoded) range_end = decoded;
-        if (wk.first_mcu >= range_end) return;
-    }
-
-    if (tid < (uint32_t)s.scan_components * 32) {
-        const uint32_t c = tid >> 5, i = tid & 31;
-        reinterpret_cast<uint32_t *>(sh_q[c])[i] =
-            reinterpret_cast<const uint32_t *>(quant_pool[s.quant_pool[s.comp[c].quant_slot]].q)[i];
-    }
-    __syncthreads();
-
-    const uint32_t mcu_local = tid / bpm;
-    const uint32_t b = tid - mcu_local * bpm;
-    const uint32_t ci = s.blk_comp[b < kMaxBlocksPerMcu ? b : 0];
-    const DevScanComponent comp = s.comp[ci];
-    const uint32_t *scan_tok = tokens + s.tok_base;
-    const uint32_t *scan_blk_tok = blk_tok + s.coef_off;
-    uint8_t *row = sh + tid * 128;          // this lane's coefficient row (same swizzle as K3's staging)
-    const uint32_t swz = (tid >> 1) & 7;
-
-    for (uint32_t tile_first = wk.first_mcu; tile_first < range_end; tile_first += mcus_per_tile) {
-        const uint32_t n_mcu = (range_end - tile_first) < mcus_per_tile ? (range_end - tile_first) : mcus_per_tile;
-        const uint32_t n_blk = n_mcu * bpm;
-        const uint32_t mcu = tile_first + mcu_local;
-        const bool have_block = tid < n_blk;
-        const bool writes = have_block && ((s.shadow_mask >> ci) & 1u) == 0;  // see idct_kernel
-        const uint32_t mcu_x = mcu % s.mcus_per_line, mcu_y = mcu / s.mcus_per_line;
-
-        float f[64];
-        const bool reached = mcu < decoded;
-        if (!reached) {
-#pragma unroll
-            for (int i = 0; i < 64; i++) f[i] = 0.0f;
-        }
-        if (have_block && reached) {
-            // token run of this block: first two quads unconditionally, the rest (rare) in a loop
-            const uint32_t off = scan_blk_tok[(uint64_t)tile_first * bpm + tid];
-            const uint32_t *tp = scan_tok + off;
-            uint4 t0, t1;
-            __builtin_memcpy(&t0, tp, 16);      // 4-byte aligned 16-byte loads
-            __builtin_memcpy(&t1, tp + 4, 16);
-            const uint4 z = {0, 0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(row)[i] = z;
-            bool last = false;
-#define JPGPU_APPLY(t_)                                                                                      \
-    if (!last) {                                                                                             \
-        const uint32_t tk_ = (t_);                                                                           \
-        const uint32_t idx_ = (tk_ >> 16) & 63u;                                                             \
-        *reinterpret_cast<int16_t *>(row + (((idx_ >> 3) ^ swz) * 16) + (idx_ & 7) * 2) = (int16_t)(tk_ & 0xFFFFu); \
-        last = (tk_ & kTokLast) != 0;                                                                        \
-    }
-            JPGPU_APPLY(t0.x) JPGPU_APPLY(t0.y) JPGPU_APPLY(t0.z) JPGPU_APPLY(t0.w)
-            JPGPU_APPLY(t1.x) JPGPU_APPLY(t1.y) JPGPU_APPLY(t1.z) JPGPU_APPLY(t1.w)
-            for (uint32_t n = 8; !last && n < 64; n++) JPGPU_APPLY(tp[n])
-#undef JPGPU_APPLY
-            block_dequant(row, swz, sh_q[ci], f);
-        }
-        uint32_t px[32];  // int16 sample pairs
-        if (have_block) block_idct(f, (int32_t)s.level_shift, px);
-        if (!reached) {
-#pragma unroll
-            for (int i = 0; i < 32; i++) px[i] = 0;
-        }
-
-        if (FMT == kFmtPlanarI16) {
-            if (writes) {
-                int16_t *plane = reinterpret_cast<int16_t *>(out + s.out_off + s.plane_off[ci]);
-                const uint32_t pitch = s.plane_pitch[ci];
-                const uint32_t x0 = (mcu_x * comp.h + s.blk_x[b]) * 8, y0 = (mcu_y * comp.v + s.blk_y[b]) * 8;
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const uint4 v = {px[r * 4 + 0], px[r * 4 + 1], px[r * 4 + 2], px[r * 4 + 3]};
-                    *reinterpret_cast<uint4 *>(plane + (size_t)(y0 + r) * pitch + x0) = v;
-                }
-            }
-            continue;
-        }
-        uint2 rows[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            rows[r].x = pack4_u8(px[r * 4 + 0], px[r * 4 + 1]);
-            rows[r].y = pack4_u8(px[r * 4 + 2], px[r * 4 + 3]);
-        }
-        if (FMT == kFmtPlanarU8 || (FMT == kFmtInterleavedU8 && LAY == kLayGray)) {
-            if (writes) {
-                const bool gray = (FMT == kFmtInterleavedU8);
-                uint8_t *plane = out + s.out_off + (gray ? 0 : s.plane_off[ci]);
-                const uint32_t pitch = gray ? s.width : s.plane_pitch[ci];
-                const uint32_t x0 = (mcu_x * comp.h + s.blk_x[b]) * 8, y0 = (mcu_y * comp.v + s.blk_y[b]) * 8;
-#pragma unroll
-                for (int r = 0; r < 8; r++)
-                    if (!gray || y0 + r < s.height) *reinterpret_cast<uint2 *>(plane + (size_t)(y0 + r) * pitch + x0) = rows[r];
-            }
-            continue;
-        }
-        // interleaved u8: sample tile in LDS, then the shared output assembly
-        if (have_block) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) *reinterpret_cast<uint2 *>(sh_px + r * kPxRowStride + tid * 8) = rows[r];
-        }
-        __syncthreads();
-        interleaved_output_from_tile<LAY, 0>(sh_px, s, tile_first, n_mcu, tid, writes, comp, mcu_x, mcu_y, b, out, YccRgbFactors{0, 0, 0, 0});
-        __syncthreads();  // the tile is rewritten by the next iteration
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
+
+hipError_t launch_first_marker(hipStream_t stream, const uint8_t *data, const void *segs, const uint32_t *seg_hi, int n_segs,
+                               uint32_t max_len, uint32_t *first) {
+    if (n_segs <= 0) return hipSuccess;
+    const uint32_t chunks = (max_len + 15u + kChunkBytes - 1) / kChunkBytes + 1;
+    for (int base = 0; base < n_segs; base += 65535) {  // grid.y limit
+        const int n = n_segs - base < 65535 ? n_segs - base : 65535;
+        hipLaunchKernelGGL(first_marker_kernel, dim3(chunks, n), dim3(kScanThreads), 0, stream, data, (const uint2 *)segs + base, seg_hi + base,
+                           first + base);
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const DevScan *scans, int n_scans, const ChunkWork *work,
                                int n_chunks, ChunkSum *sums, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u) {
@@ -3392,11 +3147,11 @@ hipError_t launch_progressive(hipStream_t stream, const uint8_t *udata, const De
 // The same, one wave per (scan, restart interval): for scans with few, long intervals.
 hipError_t launch_progressive_streams(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                                       const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
-                                      int n_slots, int pipelined) {
+                                      int n_slots, int pipelined, uint32_t spin_budget) {
     if (n_work <= 0) return hipSuccess;
     const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kPsLdsBytes;
     hipLaunchKernelGGL(progressive_stream_kernel, dim3(n_work), dim3(64), lds, stream, udata, scans, work, ends_u, status, huff_pool,
-                       coefs, n_slots, pipelined);
+                       coefs, n_slots, pipelined, spin_budget);
     return hipGetLastError();
 }
 
@@ -3466,50 +3221,6 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
     return hipGetLastError();
 }
 
-hipError_t launch_huffman_tokens(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
-                                 const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, uint32_t *tokens,
-                                 uint32_t *blk_tok, int n_slots) {
-    if (n_work <= 0) return hipSuccess;
-    const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kMaxBlocksPerMcu * sizeof(uint32_t);
-    hipLaunchKernelGGL(huffman_tokens_kernel<kHuffWaves>, dim3(n_work), dim3(64 * kHuffWaves), lds, stream, data, scans, work, ends,
-                       status, huff_pool, tokens, blk_tok, n_slots);
-    return hipGetLastError();
-}
-
-template <int FMT, int LAY>
-static void launch_idct_tokens_one(hipStream_t stream, const uint32_t *tokens, const uint32_t *blk_tok, const DevScan *scans,
-                                   const IdctWork *work, int n_work, const DevScanStatus *status, const DevQuantTable *quant_pool,
-                                   uint8_t *out) {
-    hipLaunchKernelGGL((idct_tokens_kernel<FMT, LAY>), dim3(n_work), dim3(kIdctThreads), 0, stream, tokens, blk_tok, scans, work, status,
-                       quant_pool, out);
-}
-
-hipError_t launch_idct_tokens(hipStream_t stream, const uint32_t *tokens, const uint32_t *blk_tok, const DevScan *scans,
-                              const IdctWork *work, const int class_begin[kNumIdctLayoutClasses + 1], const DevScanStatus *status,
-                              const DevQuantTable *quant_pool, uint8_t *out, int format) {
-    for (int c = 0; c < kNumIdctLayoutClasses; c++) {
-        const int n = class_begin[c + 1] - class_begin[c];
-        if (n <= 0) continue;
-        const IdctWork *w = work + class_begin[c];
-        if (format == kFmtPlanarI16) {
-            launch_idct_tokens_one<kFmtPlanarI16, kLayGeneric>(stream, tokens, blk_tok, scans, w, n, status, quant_pool, out);
-        } else if (format == kFmtPlanarU8) {
-            launch_idct_tokens_one<kFmtPlanarU8, kLayGeneric>(stream, tokens, blk_tok, scans, w, n, status, quant_pool, out);
-        } else {
-            switch (c) {
-            case kLayYccH1V1: launch_idct_tokens_one<kFmtInterleavedU8, kLayYccH1V1>(stream, tokens, blk_tok, scans, w, n, status, quant_pool, out); break;
-            case kLayYccH2V1: launch_idct_tokens_one<kFmtInterleavedU8, kLayYccH2V1>(stream, tokens, blk_tok, scans, w, n, status, quant_pool, out); break;
-            case kLayYccH2V2: launch_idct_tokens_one<kFmtInterleavedU8, kLayYccH2V2>(stream, tokens, blk_tok, scans, w, n, status, quant_pool, out); break;
-            case kLayGray: launch_idct_tokens_one<kFmtInterleavedU8, kLayGray>(stream, tokens, blk_tok, scans, w, n, status, quant_pool, out); break;
-            default: launch_idct_tokens_one<kFmtInterleavedU8, kLayGeneric>(stream, tokens, blk_tok, scans, w, n, status, quant_pool, out); break;
-            }
-        }
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
-}
-
 // Layout class of a scan for the INTERLEAVED_U8 format (0 = generic bytewise path).
 int idct_layout_class(const DevScan &s) {
     const uint32_t W = s.width;
@@ -3534,7 +3245,7 @@ int idct_layout_class(const DevScan &s) {
 //
 // The optimizer never reconstructs coefficients: it re-reads the scan symbol by symbol and re-writes every symbol with a
 // table built from the scan's own statistics, copying the magnitude bits.  One lane per restart interval, lanes run
-// free (as K2T); the same walk runs three times:
+// free; the same walk runs three times:
 //   MODE 0  count    -- IncrementCodeCount per (table, symbol): LDS histograms per workgroup, merged into the scan's
 //                       8 x 256 counters in HBM (the host then runs JpegHuffmanEncodingTableBuilder.Build per table);
 //   MODE 1  measure  -- the exact number of bytes the interval will occupy in the output: the writer is simulated in

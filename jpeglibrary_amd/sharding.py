@@ -8,8 +8,15 @@ def rank_seed_base(rank: int) -> int:
 
 
 def shard_indices(n_items: int, rank: int, world: int):
-    """Round-robin shard of a global list: item i goes to rank i % world (image i -> GPU i mod G)."""
-    return list(range(rank, n_items, world))
+    """Round-robin shard of a global list: item i goes to rank i % world (image i -> GPU i mod G).
+    The same rule as the C ABI's jpgpu_shard (include/jpgpu.h), which it calls."""
+    import ctypes as C
+
+    from . import _capi
+
+    first, stride, count = C.c_int(), C.c_int(), C.c_int()
+    _capi.lib.jpgpu_shard(n_items, rank, world, C.byref(first), C.byref(stride), C.byref(count))
+    return [first.value + k * stride.value for k in range(count.value)]
 
 
 def max_over_ranks(dist, value: float, device=None) -> float:

@@ -1674,6 +1674,134 @@ int jref_decode_to_8bit(const uint8_t *data, size_t len, int component_count, ui
     return rc;
 }
 
+/* ---- bench.py's CPU baseline: one independent decoder per host thread (see jpegref.h) ---- */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct jref_mt_shared {
+    const uint8_t *const *files;
+    const size_t *lens;
+    int n, component_count, threads, warm;
+    pthread_mutex_t lock;
+    pthread_cond_t cv;
+    int ready, go, abort_run;
+    int first_error; /* status of the first failing image, 0 = none */
+    char err[256];
+} jref_mt_shared;
+typedef struct jref_mt_thread {
+    jref_mt_shared *sh;
+    int tid;
+    uint64_t pixels;
+    struct timespec t_done;
+} jref_mt_thread;
+
+static void *jref_mt_main(void *arg) {
+    jref_mt_thread *me = (jref_mt_thread *)arg;
+    jref_mt_shared *sh = me->sh;
+    uint8_t *out = NULL;
+    size_t cap = 0;
+    char err[256];
+    jref_info info;
+    /* size and touch this thread's output buffer before the clock starts (Identify of its images only) */
+    for (int i = me->tid; i < sh->n; i += sh->threads) {
+        jref_decoder *d = jref_create();
+        jref_set_input(d, sh->files[i], sh->lens[i]);
+        if (jref_identify(d, 0, &info) == JREF_OK) {
+            const size_t need = (size_t)info.width * info.height * sh->component_count;
+            if (need > cap) cap = need;
+        }
+        jref_destroy(d);
+    }
+    if (cap) {
+        out = (uint8_t *)malloc(cap);
+        if (out) memset(out, 0, cap);
+    }
+    if (sh->warm && out && me->tid < sh->n)
+        (void)jref_decode_to_8bit(sh->files[me->tid], sh->lens[me->tid], sh->component_count, out, cap, &info, err, sizeof err);
+    pthread_mutex_lock(&sh->lock);
+    sh->ready++;
+    pthread_cond_broadcast(&sh->cv);
+    while (!sh->go) pthread_cond_wait(&sh->cv, &sh->lock);
+    const int aborted = sh->abort_run;
+    pthread_mutex_unlock(&sh->lock);
+    for (int i = me->tid; i < sh->n && out && !aborted; i += sh->threads) {
+        const int rc = jref_decode_to_8bit(sh->files[i], sh->lens[i], sh->component_count, out, cap, &info, err, sizeof err);
+        if (rc != JREF_OK) {
+            pthread_mutex_lock(&sh->lock);
+            if (!sh->first_error) {
+                sh->first_error = rc;
+                snprintf(sh->err, sizeof sh->err, "image %d: %.200s", i, err);
+            }
+            pthread_mutex_unlock(&sh->lock);
+            break;
+        }
+        me->pixels += (uint64_t)info.width * (uint64_t)info.height;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &me->t_done);
+    free(out);
+    return NULL;
+}
+
+int jref_decode_batch_mt(const uint8_t *const *files, const size_t *lens, int n, int component_count, int threads, int warm,
+                         double *seconds, uint64_t *pixels, char *err, size_t errcap) {
+    if (seconds) *seconds = 0;
+    if (pixels) *pixels = 0;
+    if (n <= 0 || threads <= 0 || !files || !lens) return JREF_ARGUMENT;
+    if (threads > n) threads = n;
+    jref_mt_shared sh;
+    memset(&sh, 0, sizeof sh);
+    sh.files = files;
+    sh.lens = lens;
+    sh.n = n;
+    sh.component_count = component_count;
+    sh.threads = threads;
+    sh.warm = warm;
+    pthread_mutex_init(&sh.lock, NULL);
+    pthread_cond_init(&sh.cv, NULL);
+    jref_mt_thread *th = (jref_mt_thread *)calloc((size_t)threads, sizeof *th);
+    pthread_t *ids = (pthread_t *)calloc((size_t)threads, sizeof *ids);
+    if (!th || !ids) {
+        free(th);
+        free(ids);
+        return JREF_INVALID_OPERATION;
+    }
+    int started = 0;
+    for (int t = 0; t < threads; t++) {
+        th[t].sh = &sh;
+        th[t].tid = t;
+        if (pthread_create(&ids[t], NULL, jref_mt_main, &th[t]) != 0) break;
+        started++;
+    }
+    /* the clock starts when every thread has its buffer and is parked */
+    struct timespec t_start;
+    pthread_mutex_lock(&sh.lock);
+    while (sh.ready < started) pthread_cond_wait(&sh.cv, &sh.lock);
+    if (started != threads) {
+        sh.abort_run = 1;
+        sh.first_error = JREF_INVALID_OPERATION;
+        snprintf(sh.err, sizeof sh.err, "pthread_create failed after %d of %d threads", started, threads);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t_start);
+    sh.go = 1;
+    pthread_cond_broadcast(&sh.cv);
+    pthread_mutex_unlock(&sh.lock);
+    uint64_t px = 0;
+    struct timespec t_end = t_start;
+    for (int t = 0; t < started; t++) {
+        pthread_join(ids[t], NULL);
+        px += th[t].pixels;
+        if (th[t].t_done.tv_sec > t_end.tv_sec || (th[t].t_done.tv_sec == t_end.tv_sec && th[t].t_done.tv_nsec > t_end.tv_nsec)) t_end = th[t].t_done;
+    }
+    if (seconds) *seconds = (double)(t_end.tv_sec - t_start.tv_sec) + (double)(t_end.tv_nsec - t_start.tv_nsec) * 1e-9;
+    if (pixels) *pixels = px;
+    if (err && errcap) snprintf(err, errcap, "%s", sh.err);
+    pthread_cond_destroy(&sh.cv);
+    pthread_mutex_destroy(&sh.lock);
+    free(th);
+    free(ids);
+    return sh.first_error;
+}
+
 int jref_decode_to_16bit(const uint8_t *data, size_t len, int component_count, uint16_t *out, size_t out_cap,
                          jref_info *info, char *err, size_t errcap) {
     jref_decoder *d = jref_create();

@@ -110,6 +110,16 @@ int jref_decode_to_8bit(const uint8_t *data, size_t len, int component_count, ui
 int jref_decode_to_16bit(const uint8_t *data, size_t len, int component_count, uint16_t *out, size_t out_cap,
                          jref_info *info, char *err, size_t errcap);
 
+/* ---- CPU baseline of bench.py: mirrors tests/JpegLibrary.Benchmarks/DecoderBenchmark.cs:51-73 (TestJpegLibrary: new
+ * JpegDecoder, SetInput, Identify, SetOutputWriter(JpegBufferOutputWriter over a YCbCr8 buffer), Decode) with one
+ * independent decoder per host thread, the way a caller of the single-threaded reference fills a many-core box.
+ * `threads` native threads (pthreads); thread t decodes images t, t + threads, ...; each owns one output buffer of
+ * width * height * component_count bytes, allocated and touched before the clock starts; with `warm` != 0 every thread
+ * decodes its first image once before the clock starts.  *seconds = wall time from the common start until the last thread
+ * is done; *pixels = pixels decoded inside that time.  Returns 0, or the status of the first failing image. */
+int jref_decode_batch_mt(const uint8_t *const *files, const size_t *lens, int n, int component_count, int threads, int warm,
+                         double *seconds, uint64_t *pixels, char *err, size_t errcap);
+
 /* ---- primitives exported for unit parity tests ---- */
 /* ref: ScanDecoder/JpegScanDecoder.cs:50-73 + FastFloatingPointDCT.cs:54-70: one block, zig-zag int16 in,
  * spatial int16 out (row-major), unclamped. quant in zig-zag order. */

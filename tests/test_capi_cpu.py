@@ -37,6 +37,21 @@ def test_version_and_strings():
     assert _capi.lib.jpgpu_detail_string(4) == b"Expect restart marker."
 
 
+def test_shard_rule_is_image_i_to_gpu_i_mod_g():
+    """jpgpu_shard (include/jpgpu.h) and its Python mirror: disjoint, complete, round-robin."""
+    from jpeglibrary_amd import _capi, sharding
+
+    for n, world in [(0, 1), (1, 8), (7, 8), (8, 8), (8192, 8), (1000, 3)]:
+        seen = []
+        for rank in range(world):
+            first, stride, count = C.c_int(), C.c_int(), C.c_int()
+            _capi.lib.jpgpu_shard(n, rank, world, C.byref(first), C.byref(stride), C.byref(count))
+            mine = [first.value + k * stride.value for k in range(count.value)]
+            assert mine == list(range(rank, n, world)) == sharding.shard_indices(n, rank, world)
+            seen += mine
+        assert sorted(seen) == list(range(n))
+
+
 def test_no_cpu_fallback_without_gpu():
     import jpeglibrary_amd as jl
 

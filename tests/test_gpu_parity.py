@@ -1168,3 +1168,51 @@ def test_optimizer_low_quality_tables_with_ff_bytes():
                 assert b.output(i) == ref, (i, strip)
         b.close()
     assert "OK" in kinds
+
+
+# ------------------------------------------------------------------------------------------------ stress reproducers
+
+def _stress_files():
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stress")
+    return sorted(f for f in os.listdir(d) if f.endswith(".jpg"))
+
+
+@pytest.mark.parametrize("name", _stress_files())
+def test_stress_reproducers_match_the_oracle(name):
+    """Inputs on which tools/stress_parity.py once found the GPU path and the restatement apart (batch-position dependent
+    progressive levels, frame heights smaller than the scan, optimizer pieces, refused envelopes): each one alone and
+    inside a batch of copies and neighbours, through the decoder (YCbCr8 and RGBA) and the optimizer."""
+    data = read_jpeg(os.path.join("stress", name))
+    names = {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException", 4: "ArgumentException"}
+    try:
+        ref, ref_kind = po.decode_8bit(data)[0], "OK"
+    except po.OracleError as e:
+        ref, ref_kind = None, e.kind
+    neighbours = [jpegsynth.encode(64, 48, "420", 75, 2, seed=3), read_jpeg("progress.jpg")]
+    files = [data, neighbours[0], data, neighbours[1], data]
+    for fmt in (jl.FMT_INTERLEAVED_U8, jl.FMT_RGBA_U8):
+        b = jl.Batch().upload(files, fmt).decode().sync()
+        for i in (0, 2, 4):
+            res = b.result(i)
+            if ref_kind == "OK" and fmt == jl.FMT_RGBA_U8 and ref.shape[2] not in (1, 3):
+                continue
+            assert names.get(res.status) == ref_kind, (name, i, fmt, ref_kind, res.status, res.detail)
+            if ref is not None:
+                want = ref if fmt == jl.FMT_INTERLEAVED_U8 else po.ycbcr8_to_rgb(ref, rgba=True)
+                assert np.array_equal(b.output(i), want), (name, i, fmt)
+        b.close()
+    for strip in (False, True):
+        try:
+            oref, okind = po.optimize(data, strip), "OK"
+        except po.OracleError as e:
+            oref, okind = None, e.kind
+        ob = jl.OptimizeBatch().upload([data, neighbours[0], data], strip).run()
+        for i in (0, 2):
+            res, _ = ob.result(i)
+            mine = names.get(res.status)
+            if mine == "NotSupportedException" and okind != mine:
+                continue  # optimizer fences (several scans, progressive): refused by design, DESIGN.md
+            assert mine == okind, (name, strip, okind, mine, res.detail)
+            if oref is not None:
+                assert ob.output(i) == oref, (name, strip)
+        ob.close()

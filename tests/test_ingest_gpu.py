@@ -1,0 +1,198 @@
+"""jpgpu_batch_upload: the host reads headers only, the device confirms what lies behind the first SOS header.
+
+SURVEY 8f N1 (ref: JpegDecoder.Identify's full-stream walk, JpegDecoder.cs:75-162 + JpegReader.cs:120-158).  Every case
+is checked against the oracle's Identify + Decode, whichever way the file was planned; the ingest statistics say which way.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import jpeglibrary_amd as jl
+from golden_util import read_jpeg
+from oracle import pyoracle as po
+from tools import jpegsynth
+
+pytestmark = pytest.mark.gpu
+
+NAMES = {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException", 4: "ArgumentException"}
+
+
+def _oracle(data):
+    try:
+        return "OK", po.decode_8bit(data)[0]
+    except po.OracleError as e:
+        return e.kind, None
+
+
+def _check_batch(files, expect_header_only=None, ctx=None):
+    b = jl.Batch(ctx).upload(files, jl.FMT_INTERLEAVED_U8).decode().sync()
+    st = b.ingest_stats()
+    problems = []
+    for i, f in enumerate(files):
+        kind, ref = _oracle(bytes(f))
+        res = b.result(i)
+        mine = NAMES.get(res.status, str(res.status))
+        if mine != kind:
+            problems.append((i, kind, mine, res.detail))
+        elif ref is not None and not np.array_equal(b.output(i), ref):
+            problems.append((i, "samples differ"))
+    b.close()
+    assert not problems, problems
+    if expect_header_only is not None:
+        assert st["n_header_only"] == expect_header_only, st
+        assert st["n_header_only"] + st["n_full_walk"] <= len(files)
+    return st
+
+
+def test_clean_files_are_planned_from_their_headers():
+    files = [jpegsynth.encode(w, h, ss, q, dri, seed=w + h) for (w, h, ss, q, dri) in
+             [(512, 512, "444", 75, 0), (640, 368, "420", 75, 4), (331, 177, "422", 80, 3), (100, 75, "gray", 60, 1), (17, 9, "420", 75, 1)]]
+    files += [read_jpeg("cramps.jpg"), read_jpeg("lake.jpg")]
+    st = _check_batch(files, expect_header_only=len(files))
+    assert st["n_full_walk"] == 0
+
+
+def test_files_that_need_the_full_walk_get_it():
+    good = bytes(jpegsynth.encode(160, 96, "420", 75, 2, seed=42))
+    body = good[:-2]
+    sos = good.index(b"\xff\xda")
+    dri = good.index(b"\xff\xdd")
+    dri_seg = good[dri:dri + 6]
+    no_dri = good[:dri] + good[dri + 6:]
+    cases = {
+        # header-only plans that the device confirms
+        "clean": (good, True),
+        "bytes_behind_eoi": (good + bytes(range(1, 200)), True),
+        "second_eoi": (good + b"\xff\xd9", True),
+        "early_eoi_at_restart": (None, True),  # filled in below
+        # the first marker behind the scan is not EOI: Identify / Decode go on walking
+        "com_behind_scan": (body + b"\xff\xfe\x00\x04ab\xff\xd9", False),
+        "bad_segment_behind_scan": (body + b"\xff\xfe\x00\x09ab\xff\xd9", False),
+        # Identify latches the LAST DRI of the file, also one behind the scan: decoded with the wrong interval
+        "dri_behind_scan": (body + b"\xff\xdd\x00\x04\x00\x07\xff\xd9", False),
+        "dri_only_behind_scan": (no_dri[:-2] + dri_seg + b"\xff\xd9", False),
+        "second_sof_behind_scan": (body + good[good.index(b"\xff\xc0"):sos] + b"\xff\xd9", False),
+        "no_eoi": (body, False),
+        "truncated_in_scan": (good[:sos + 14 + 200], False),
+        "zeros_for_eoi": (body + bytes(2), False),
+        "multi_scan": (bytes(jpegsynth.encode(96, 64, "444", 75, 0, seed=5, noninterleaved=True)), False),
+        "progressive": (read_jpeg("progress.jpg"), False),
+        "progressive_restart": (read_jpeg("yellowcat_progressive_restart.jpg"), False),
+        "no_scan_at_all": (good[:sos] + b"\xff\xd9", False),
+        "sos_before_sof": (good[:2] + good[sos:sos + 14] + good[2:], False),
+        "not_a_jpeg": (bytes(range(256)) * 4, None),
+        "empty_ish": (b"\xff\xd8", None),
+    }
+    rsts = [i for i in range(sos + 14, len(good) - 1) if good[i] == 0xFF and 0xD0 <= good[i + 1] <= 0xD7]
+    cases["early_eoi_at_restart"] = (good[:rsts[10]] + b"\xff\xd9", True)
+    keys = list(cases)
+    for k in keys:  # one by one: the statistics say how each file was planned
+        data, header_only = cases[k]
+        st = _check_batch([data])
+        if header_only is not None:
+            assert (st["n_header_only"], st["n_full_walk"]) == ((1, 0) if header_only else (0, 1)), (k, st)
+    # and all of them in one batch (files of both kinds next to each other in the staging ring)
+    st = _check_batch([cases[k][0] for k in keys])
+    assert st["n_header_only"] == sum(1 for k in keys if cases[k][1] is True), st
+
+
+def test_one_unread_byte_in_front_of_the_terminator_on_the_header_only_path():
+    """The reference resumes its marker walk one byte INTO the terminating marker when exactly one whole byte was left in
+    the bit reader: the header-only path replays that walk from the headers and the bytes behind EOI."""
+    good = bytes(jpegsynth.encode(104, 72, "420", 80, 4, seed=91))
+    body = good[:-2]
+    files = []
+    for k in (1, 2, 3):
+        files.append(body + bytes([0x5A] * k) + b"\xff\xd9")
+        files.append(body + bytes([0x5A] * k) + b"\xff\xd9\xff\xd9")
+        files.append(body + bytes([0x5A] * k) + b"\xff\xd9\xff\xfe\x00\x04ab")
+        files.append(body + bytes([0x5A] * k) + b"\xff\xd9\xff\xfe\x00\x09ab")
+    st = _check_batch(files)
+    assert st["n_header_only"] == len(files), st
+
+
+def test_staging_ring_wraps_and_thread_counts_agree():
+    """More input than the four 32 MiB staging slots hold (the ring wraps), pieces that straddle slots, and the same batch
+    through 1, 3 and the default number of host threads."""
+    n = 160
+    buf, sizes, stride = jpegsynth.encode_batch(n, 3840, 2160, "420", 75, 4, seed0=7000, nthreads=8)
+    files = [buf[i * stride:i * stride + int(sizes[i])] for i in range(n)]
+    assert sum(len(f) for f in files) > 5 * (32 << 20)
+    ctx = jl.Context(0)
+    outs = {}
+    for threads in (0, 1, 3):
+        ctx.set_host_threads(threads)
+        b = jl.Batch(ctx).upload(files, jl.FMT_INTERLEAVED_U8).decode().sync()
+        st = b.ingest_stats()
+        assert st["n_header_only"] == n and st["n_full_walk"] == 0, st
+        if threads:
+            assert st["threads"] == threads
+        assert all(b.result(i).status == 0 for i in range(n))
+        outs[threads] = [b.output(i) for i in (0, 31, 32, 33, 97, n - 1)]
+        b.close()
+    for k, i in enumerate((0, 31, 32, 33, 97, n - 1)):
+        ref, _ = po.decode_8bit(bytes(files[i]))
+        for threads in outs:
+            assert np.array_equal(outs[threads][k], ref), (threads, i)
+    ctx.close()
+
+
+def test_upload_of_one_batch_runs_beside_the_decode_of_another():
+    """Two batches of one context: B is uploaded (upload stream, host crew) while A decodes (decode stream)."""
+    ctx = jl.Context(0)
+    buf, sizes, stride = jpegsynth.encode_batch(24, 1920, 1080, "420", 90, 4, seed0=300, nthreads=8)
+    files = [buf[i * stride:i * stride + int(sizes[i])] for i in range(24)]
+    a, b = jl.Batch(ctx), jl.Batch(ctx)
+    a.upload(files[:12], jl.FMT_INTERLEAVED_U8)
+    for _ in range(3):
+        a.decode()                                   # asynchronous: returns once the kernels are queued
+        b.upload(files[12:], jl.FMT_INTERLEAVED_U8)  # meanwhile
+        a.sync()
+        b.decode()
+        a.upload(files[:12], jl.FMT_INTERLEAVED_U8)
+        b.sync()
+    a.decode().sync()
+    for batch, part in ((a, files[:12]), (b, files[12:])):
+        for i in (0, 5, 11):
+            assert batch.result(i).status == 0
+            assert np.array_equal(batch.output(i), po.decode_8bit(bytes(part[i]))[0])
+    a.close()
+    b.close()
+    ctx.close()
+
+
+def test_two_contexts_from_two_threads_shard_one_file_list():
+    """image i -> GPU i mod G, one context per GPU / thread, no exchange.  With one GPU in the box both
+    contexts sit on device 0; what is exercised is that contexts are independent and callable concurrently."""
+    n = 24
+    files = [jpegsynth.encode(320 + 16 * (i % 5), 200 + 8 * (i % 3), "420" if i % 2 else "444", 75, (i % 4) * 2, seed=900 + i) for i in range(n)]
+    world = 2
+    got = [None] * n
+    errors = []
+
+    def rank_main(rank):
+        try:
+            ctx = jl.Context(0)
+            mine = jl.sharding.shard_indices(n, rank, world)
+            b = jl.Batch(ctx).upload([files[i] for i in mine], jl.FMT_INTERLEAVED_U8)
+            for _ in range(4):
+                b.decode()
+            b.sync()
+            for k, i in enumerate(mine):
+                assert b.result(k).status == 0
+                got[i] = b.output(k)
+            b.close()
+            ctx.close()
+        except Exception as e:  # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert sorted(jl.sharding.shard_indices(n, 0, world) + jl.sharding.shard_indices(n, 1, world)) == list(range(n))
+    for i in range(n):
+        assert np.array_equal(got[i], po.decode_8bit(bytes(files[i]))[0]), i

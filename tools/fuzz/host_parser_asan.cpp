@@ -63,6 +63,17 @@ int main(int argc, char **argv) {
         size_t n;
         while ((n = fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
         fclose(f);
+        // the batch ingest's header-only walk: Identify up to the first SOS header, then Decode's loop with a handler that
+        // plans the scan and skips to the end of the data (DeviceBatch::plan_file_headers)
+        try {
+            HostDecoder dec;
+            dec.set_input(d.data(), d.size());
+            size_t pos = 0;
+            if (dec.identify_until_scan(false, &pos) && pos > d.size()) return 1;
+            ok++;
+        } catch (const DecodeError &) {
+            failed++;
+        }
         for (int optimizer_rules = 0; optimizer_rules < 2; optimizer_rules++) {
             try {
                 HostDecoder dec;
