@@ -66,38 +66,77 @@ def progressive_batch(n, width, height, quality, seed0, nthreads):
         return list(ex.map(progressive_image, [width] * n, [height] * n, [quality] * n, [seed0 + i for i in range(n)]))
 
 
+def host_cpu_budget():
+    """Hardware threads this process may actually use: the scheduler affinity mask and the cgroup CPU quota both bound it
+    (os.cpu_count() reports the machine's threads even inside a container that is granted a few of them)."""
+    info = {"cpu_count": os.cpu_count() or 1}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    quota = None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        pass
+    if quota is None:
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        info["cgroup_quota_cpus"] = round(quota, 2)
+    return info
+
+
 def cpu_baseline(files, width, height, max_threads):
     """Reference-equivalent CPU path (oracle/jpegref.c, jref_decode_batch_mt): Identify + Decode into a
     JpegBufferOutputWriter8Bit-style YCbCr8 buffer, mirroring tests/JpegLibrary.Benchmarks/DecoderBenchmark.cs:51-73, one
     independent decoder per native host thread (pthreads; per-thread output buffer allocated and touched before the clock
-    starts, one untimed warm decode per thread, >= 8 images per thread), on a bounded sample of the same images."""
+    starts, one untimed warm decode per thread, 8 images per thread), on a bounded sample of the same images.
+    The thread count is swept (8, 16, ... up to the machine's hardware threads) and the BEST rate is the baseline: a
+    container is often granted fewer CPUs than os.cpu_count() reports, and oversubscribing those must not be what is timed."""
     from oracle import pyoracle as po
 
-    cores = max(1, min(max_threads, os.cpu_count() or 1))
+    budget = host_cpu_budget()
+    hw = max(1, min(max_threads, budget["cpu_count"]))
     n = len(files)
     # single thread: ~3-6 s of work
     n1 = max(1, min(n, int(4.0 * 100e6 / (width * height)) or 1))
     s1, px1 = po.decode_batch_mt(files[:n1], 3, 1, warm=True)
     single = px1 / 1e6 / s1
-    # all threads: >= 8 images per thread (the batch's images, repeated if there are fewer), capped at ~25 s of wall time
-    per_thread = 8
-    est = per_thread * width * height / 1e6 / max(single * 0.5, 1e-3)  # SMT siblings run at roughly half speed
-    while per_thread > 1 and est > 25.0:
-        per_thread //= 2
-        est /= 2
-    sample = [files[i % n] for i in range(cores * per_thread)]
-    sall, pxall = po.decode_batch_mt(sample, 3, cores, warm=True)
-    value = pxall / 1e6 / sall
+    counts = sorted({min(hw, c) for c in (8, 16, 32, 64, 128, 256, hw)})
+    sweep, spent = [], 0.0
+    best = None
+    for threads in counts:
+        per_thread = 8
+        sample = [files[i % n] for i in range(threads * per_thread)]
+        sec, px = po.decode_batch_mt(sample, 3, threads, warm=True)
+        rate = px / 1e6 / sec
+        sweep.append({"threads": threads, "Mpixels/s": round(rate, 1), "wall_s": round(sec, 2), "decodes": len(sample)})
+        spent += sec
+        if best is None or rate > best[0]:
+            best = (rate, threads, len(sample), sec)
+        if spent > 40.0:  # bounded: the sweep stops early on a slow host
+            break
+    value, cores, decodes, sall = best
     return {
         "value": round(value, 2),
         "unit": "Mpixels/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{len(sample)} decodes ({per_thread} per thread) over {min(n, len(sample))} of the benchmark's images, Identify+Decode into an "
-                  f"interleaved YCbCr8 buffer, one decoder per native thread, buffers pre-touched, one warm decode per thread "
-                  f"({sall:.2f} s wall); single thread: {single:.1f} Mpixels/s over {n1} images",
+        "sample": f"{decodes} decodes (8 per thread) of the benchmark's images, Identify+Decode into an interleaved YCbCr8 buffer, one "
+                  f"decoder per native thread, buffers pre-touched, one warm decode per thread ({sall:.2f} s wall); best of the thread "
+                  f"sweep; single thread: {single:.1f} Mpixels/s over {n1} images",
         "single_core_value": round(single, 2),
         "scaling_efficiency": round(value / (single * cores), 3),
+        "thread_sweep": sweep,
+        "host_cpu_budget": budget,
     }
 
 

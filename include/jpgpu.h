@@ -89,7 +89,7 @@ void jpgpu_destroy(jpgpu_ctx *ctx);
 /* Last error text of this context (thread-compatible, not thread-safe). ctx may be NULL for create failures. */
 const char *jpgpu_last_error(const jpgpu_ctx *ctx);
 /* Host threads jpgpu_batch_upload may use for this context (header parsing of the files, copies into the pinned staging
- * ring, full marker walks of the files that need one).  0 = default: min(hardware threads, 32), or JPGPU_HOST_THREADS.
+ * ring, full marker walks of the files that need one).  0 = default: min(CPUs granted to the process, 16), or JPGPU_HOST_THREADS.
  * The reference is single-threaded per decoder ("one decoder per thread"); a batch is where the host fans out. */
 int jpgpu_set_host_threads(jpgpu_ctx *ctx, int threads);
 /* Image-per-GPU sharding: of n_items, rank `rank` of `world` takes items first, first + stride, ... (count of

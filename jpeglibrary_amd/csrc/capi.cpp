@@ -64,6 +64,8 @@ int jpgpu_create(int device, jpgpu_ctx **out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    if (const char *ev = getenv("JPGPU_STAGING_SLOTS")) ctx->staging.n_slots = std::min((int)StagingRing::kMaxSlots, std::max(2, atoi(ev)));
+    if (const char *ev = getenv("JPGPU_STAGING_SLOT_MB")) ctx->staging.slot_bytes = (size_t)std::min(256, std::max(1, atoi(ev))) << 20;
     *out = ctx.release();
     return JPGPU_OK;
 }
@@ -73,7 +75,7 @@ void jpgpu_destroy(jpgpu_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
-    for (int i = 0; i < StagingRing::kSlots; i++) {
+    for (int i = 0; i < StagingRing::kMaxSlots; i++) {
         if (ctx->staging.slot[i]) (void)hipHostFree(ctx->staging.slot[i]);
         if (ctx->staging.drained[i]) (void)hipEventDestroy(ctx->staging.drained[i]);
     }

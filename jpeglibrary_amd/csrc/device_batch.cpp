@@ -8,6 +8,8 @@
 #include "device_batch.h"
 
 #include <hip/hip_runtime.h>
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -390,6 +392,15 @@ void DeviceBatch::plan_swallowed_terminator(FilePlan &fp, const uint8_t *file, s
         }
     if (last < 0 || n_seq != (int)ends.size() || ends.back() >= fp.jobs[last].entropy_len) return;  // no marker behind it
     img.swallow_job = last;  // index into fp.jobs; upload_files turns it into a batch job index
+    if (identify_is_clean && n_seq == 1 && (size_t)(fp.jobs[last].entropy - file) + ends.back() + 2 == len) {
+        // The EOI closes the file (every clean file): the replayed walk would step over the scan to one byte into the
+        // marker, find a single byte left and fail in TryReadMarker (JpegDecoder.cs:533-537).  Written down directly: a
+        // thousand exceptions thrown from a crew of threads serialise on the unwinder's lock.
+        img.swallow_status = JPGPU_ERR_INVALID_DATA;
+        img.swallow_detail = kDetailBadHeader;
+        img.swallow_error = "Failed to decode JPEG data at offset " + std::to_string(len - 1) + ". No marker found.";
+        return;
+    }
     try {
         HostDecoder dec;
         dec.set_input(file, len);
@@ -408,10 +419,24 @@ void DeviceBatch::plan_swallowed_terminator(FilePlan &fp, const uint8_t *file, s
     }
 }
 
+// Crew size when the caller did not choose one: the CPUs this process may really use -- the affinity mask and the cgroup
+// CPU quota both bound it (a container often reports the machine's 256 threads and is granted 16) -- capped at 16.
 static int default_host_threads() {
     if (const char *ev = getenv("JPGPU_HOST_THREADS")) return std::max(1, atoi(ev));
-    const unsigned hc = std::thread::hardware_concurrency();
-    return (int)std::min(32u, std::max(1u, hc));
+    unsigned cpus = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) cpus = std::min(cpus, (unsigned)CPU_COUNT(&set));
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[32] = {0};
+        long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long quota = atol(q);
+            if (quota > 0) cpus = std::min(cpus, (unsigned)std::max(1L, (quota + period - 1) / period));
+        }
+        fclose(f);
+    }
+    return (int)std::min(16u, cpus);  // a handful of threads already keep the host link busy (profiles/r02_ingest_sweep.jsonl)
 }
 
 int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int n, int format) {
@@ -536,7 +561,9 @@ int DeviceBatch::stage_files(WorkCrew &crew, const std::vector<const uint8_t *> 
         uint64_t dst;
         uint32_t n;
     };
-    constexpr uint64_t kSlot = StagingRing::kSlotBytes;
+    StagingRing &ring = ctx_->staging;
+    const uint64_t kSlot = ring.slot_bytes;
+    const size_t n_slots = (size_t)ring.n_slots;
     constexpr uint32_t kPieceMax = 2u << 20;
     std::vector<Piece> pieces;
     auto add = [&](const uint8_t *src, uint64_t dst, uint64_t n) {
@@ -567,14 +594,13 @@ int DeviceBatch::stage_files(WorkCrew &crew, const std::vector<const uint8_t *> 
         state[c].store(0, std::memory_order_relaxed);
     }
     for (const Piece &p : pieces) remaining[p.dst / kSlot].fetch_add(1, std::memory_order_relaxed);
-    StagingRing &ring = ctx_->staging;
-    for (size_t c = 0; c < std::min<size_t>(n_chunks, StagingRing::kSlots); c++) {
+    for (size_t c = 0; c < std::min<size_t>(n_chunks, n_slots); c++) {
         if (!ring.slot[c]) {
             e = hipHostMalloc((void **)&ring.slot[c], kSlot, hipHostMallocDefault);
             if (e != hipSuccess) return hip_fail(e, "hipHostMalloc(staging)");
         }
         if (!ring.drained[c]) {
-            e = hipEventCreateWithFlags(&ring.drained[c], hipEventDisableTiming);
+            e = hipEventCreateWithFlags(&ring.drained[c], hipEventDisableTiming | hipEventBlockingSync);
             if (e != hipSuccess) return hip_fail(e, "hipEventCreate(staging)");
         }
     }
@@ -586,12 +612,12 @@ int DeviceBatch::stage_files(WorkCrew &crew, const std::vector<const uint8_t *> 
     crew.run(pieces.size(), [&](size_t k, int) {
         const Piece &p = pieces[k];
         const size_t c = (size_t)(p.dst / kSlot);
-        const int slot = (int)(c % StagingRing::kSlots);
+        const int slot = (int)(c % n_slots);
         if (hip_error.load(std::memory_order_relaxed) != (int)hipSuccess) return;
         (void)hipSetDevice(device);
-        if (c >= (size_t)StagingRing::kSlots) {
-            // the slot still holds chunk c - kSlots until that chunk's DMA has read it
-            std::atomic<int> &prev = state[c - StagingRing::kSlots];
+        if (c >= n_slots) {
+            // the slot still holds chunk c - n_slots until that chunk's DMA has read it
+            std::atomic<int> &prev = state[c - n_slots];
             while (prev.load(std::memory_order_acquire) == 0) {
                 if (hip_error.load(std::memory_order_relaxed) != (int)hipSuccess) return;
                 std::this_thread::yield();
@@ -1051,6 +1077,10 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         bool all = true;
         for (int c = 0; c < img.num_components; c++) all &= ((covered[c >> 6] >> (c & 63)) & 1ull) != 0;
         if (!all) out_clear_.push_back({img.out_offset, img.out_bytes});
+        // RGB / RGBA = the callers' converter applied to the YCbCr8 buffer (DecodeAction.cs:71-74): an image without any scan
+        // leaves that buffer as it was (zero here), and the converter still runs over it
+        if (img.jobs.empty() && (format_ == JPGPU_FMT_RGB_U8 || format_ == JPGPU_FMT_RGBA_U8))
+            rgb_convert_.push_back({(uint32_t)(&img - images_.data()), img.out_offset, (uint64_t)img.width * img.height, img.num_components});
     }
     idct_class_begin_[0] = 0;
     const int xcds = getenv("JPGPU_XCD_MAP") ? atoi(getenv("JPGPU_XCD_MAP")) : 8;  // MI355X: 8 XCDs; 0 / 1 = memory order (A/B switch)

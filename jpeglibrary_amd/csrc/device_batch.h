@@ -14,10 +14,11 @@
 // as few large DMAs on the context's upload stream (ref input contract: caller-owned, possibly multi-segment
 // ReadOnlySequence<byte>, apps/JpegDecode/MemoryPoolBufferWriter.cs:166-174 -- "the shim linearises into pinned memory").
 struct StagingRing {
-    static constexpr int kSlots = 4;
-    static constexpr size_t kSlotBytes = 32u << 20;
-    uint8_t *slot[kSlots] = {};
-    hipEvent_t drained[kSlots] = {};  // recorded behind the DMA that reads the slot
+    static constexpr int kMaxSlots = 16;
+    int n_slots = 8;                  // JPGPU_STAGING_SLOTS (8 x 32 MiB: profiles/r02_ingest_sweep.jsonl)
+    size_t slot_bytes = 32u << 20;    // JPGPU_STAGING_SLOT_MB; fixed once the first slot exists
+    uint8_t *slot[kMaxSlots] = {};
+    hipEvent_t drained[kMaxSlots] = {};  // recorded behind the DMA that reads the slot
     uint32_t *verdict = nullptr;      // pinned: per-file results of the ingest verification kernel
     size_t verdict_cap = 0;
 };
@@ -27,7 +28,7 @@ struct jpgpu_ctx {
     hipStream_t stream = nullptr;         // kernels of jpgpu_batch_decode and friends
     hipStream_t upload_stream = nullptr;  // H2D of jpgpu_batch_upload: runs beside another batch's decode on `stream`
     StagingRing staging;
-    int host_threads = 0;                 // crew size of jpgpu_batch_upload; 0 = min(hardware threads, 32)
+    int host_threads = 0;                 // crew size of jpgpu_batch_upload; 0 = min(CPUs granted to the process, 16)
     std::string last_error;
     int num_cus = 0;
 };

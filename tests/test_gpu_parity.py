@@ -1198,7 +1198,7 @@ def test_stress_reproducers_match_the_oracle(name):
                 continue
             assert names.get(res.status) == ref_kind, (name, i, fmt, ref_kind, res.status, res.detail)
             if ref is not None:
-                want = ref if fmt == jl.FMT_INTERLEAVED_U8 else po.ycbcr8_to_rgb(ref, rgba=True)
+                want = ref if fmt == jl.FMT_INTERLEAVED_U8 else po.ycbcr8_to_rgb(ref, rgba=True, gray=(ref.shape[2] == 1))
                 assert np.array_equal(b.output(i), want), (name, i, fmt)
         b.close()
     for strip in (False, True):

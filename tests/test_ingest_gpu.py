@@ -112,16 +112,18 @@ def test_one_unread_byte_in_front_of_the_terminator_on_the_header_only_path():
     assert st["n_header_only"] == len(files), st
 
 
-def test_staging_ring_wraps_and_thread_counts_agree():
-    """More input than the four 32 MiB staging slots hold (the ring wraps), pieces that straddle slots, and the same batch
-    through 1, 3 and the default number of host threads."""
-    n = 160
+def test_staging_ring_wraps_and_thread_counts_agree(monkeypatch):
+    """More input than the staging ring holds (here 3 slots of 4 MiB: the ring wraps a dozen times), files that straddle
+    slots, and the same batch through 1, 3, 7 and the default number of host threads."""
+    n = 48
     buf, sizes, stride = jpegsynth.encode_batch(n, 3840, 2160, "420", 75, 4, seed0=7000, nthreads=8)
     files = [buf[i * stride:i * stride + int(sizes[i])] for i in range(n)]
-    assert sum(len(f) for f in files) > 5 * (32 << 20)
+    assert sum(len(f) for f in files) > 12 * (4 << 20)
+    monkeypatch.setenv("JPGPU_STAGING_SLOTS", "3")
+    monkeypatch.setenv("JPGPU_STAGING_SLOT_MB", "4")
     ctx = jl.Context(0)
     outs = {}
-    for threads in (0, 1, 3):
+    for threads in (0, 1, 3, 7):
         ctx.set_host_threads(threads)
         b = jl.Batch(ctx).upload(files, jl.FMT_INTERLEAVED_U8).decode().sync()
         st = b.ingest_stats()
@@ -129,9 +131,9 @@ def test_staging_ring_wraps_and_thread_counts_agree():
         if threads:
             assert st["threads"] == threads
         assert all(b.result(i).status == 0 for i in range(n))
-        outs[threads] = [b.output(i) for i in (0, 31, 32, 33, 97, n - 1)]
+        outs[threads] = [b.output(i) for i in (0, 3, 4, 11, 12, 31, n - 1)]
         b.close()
-    for k, i in enumerate((0, 31, 32, 33, 97, n - 1)):
+    for k, i in enumerate((0, 3, 4, 11, 12, 31, n - 1)):
         ref, _ = po.decode_8bit(bytes(files[i]))
         for threads in outs:
             assert np.array_equal(outs[threads][k], ref), (threads, i)
