@@ -202,7 +202,11 @@ int jpgpu_batch_upload_frames(jpgpu_batch *b, const jpgpu_frame *frames, const u
 /* Launches the device pipeline on the ctx stream (asynchronous):
  *   marker index -> Huffman MCU decode (ref: ...BaselineScanDecoder.cs:51-222) ->
  *   dequantise + float32 IDCT + level shift (ref: ScanDecoder/JpegScanDecoder.cs:50-73, FastFloatingPointDCT.cs:54-185) ->
- *   block output in the batch's format (ref: ...BaselineScanDecoder.cs:225-268 + the sink). */
+ *   block output in the batch's format (ref: ...BaselineScanDecoder.cs:225-268 + the sink).
+ * Large batches (>= 4 Mi blocks of restart-interval scans) are issued as two halves of images on two streams, the Huffman
+ * stage of the second half beside the output stage of the first (latency-bound beside HBM-bound); the first call after an
+ * upload or a jpgpu_batch_stage_ms query and every 8th after it run serially so that stage times exist.  JPGPU_OVERLAP=0
+ * keeps every call serial.  Results do not depend on the issue order. */
 int jpgpu_batch_decode(jpgpu_batch *b);
 /* Individual stages, for stage-level parity tests and profiling. */
 int jpgpu_batch_run_entropy(jpgpu_batch *b); /* marker index + Huffman -> coefficient buffer */
@@ -227,8 +231,9 @@ int jpgpu_batch_download_coefficients(jpgpu_batch *b, int i, int16_t *dst, size_
 /* Overwrites one image's coefficient blocks from the host (IDCT-stage parity tests; config-5 style accumulate-then-IDCT). */
 int jpgpu_batch_upload_coefficients(jpgpu_batch *b, int i, const int16_t *src, size_t nblocks);
 
-/* hipEvent timings (ms) on the ctx stream, averaged over every jpgpu_batch_decode issued since the previous query
- * (synchronises): ms[0] marker index, ms[1] Huffman, ms[2] IDCT+output, ms[3] whole pipeline. */
+/* hipEvent timings (ms) on the ctx stream over the jpgpu_batch_decode calls issued since the previous query (synchronises):
+ * ms[0] marker index, ms[1] Huffman, ms[2] IDCT+output, averaged over the calls that ran serially (see jpgpu_batch_decode);
+ * ms[3] whole pipeline, averaged over all calls. */
 int jpgpu_batch_stage_ms(jpgpu_batch *b, float ms[4]);
 /* Synchronisation rounds the self-synchronising DRI = 0 decoder needed in the most recent decode (0 = not used). */
 int jpgpu_batch_subseq_rounds(const jpgpu_batch *b);

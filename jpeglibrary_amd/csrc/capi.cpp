@@ -57,9 +57,11 @@ int jpgpu_create(int device, jpgpu_ctx **out) {
         g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
         return JPGPU_ERR_DEVICE;
     }
-    if ((e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking)) != hipSuccess) {
+    if ((e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess) {
         g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
         (void)hipStreamDestroy(ctx->stream);
+        if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
         return JPGPU_ERR_DEVICE;
     }
     hipDeviceProp_t prop;
@@ -75,6 +77,7 @@ void jpgpu_destroy(jpgpu_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     for (int i = 0; i < StagingRing::kMaxSlots; i++) {
         if (ctx->staging.slot[i]) (void)hipHostFree(ctx->staging.slot[i]);
         if (ctx->staging.drained[i]) (void)hipEventDestroy(ctx->staging.drained[i]);

@@ -46,7 +46,7 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
@@ -1092,6 +1092,43 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     }
     n_idct_work_ = (int)idct_work.size();
 
+    // ---- two halves for decode()'s overlapped issue order (see decode()): images [0, split) and [split, n), balanced by
+    // blocks; the Huffman work list is in image order already (one index splits it), the IDCT work gets a second list with
+    // the classes of each half interleaved over the XCDs on their own
+    overlap_ok_ = false;
+    std::vector<IdctWork> idct_work_split;
+    {
+        const char *ev = getenv("JPGPU_OVERLAP");
+        const bool wanted = !(ev && atoi(ev) == 0);
+        uint32_t split_image = 0;
+        uint64_t acc = 0;
+        for (size_t ii = 0; ii < images_.size() && acc * 2 < total_blocks_; ii++) {
+            acc += images_[ii].total_blocks;
+            split_image = (uint32_t)ii + 1;
+        }
+        huff_split_ = 0;
+        while (huff_split_ < n_huff_work_ && h_scans_[huff_work[huff_split_].scan].image_index < split_image) huff_split_++;
+        // worth it for batches that keep the machine busy for milliseconds: the split costs four launches and two events
+        if (wanted && !entropy_only_ && sub_work.empty() && prog_work.empty() && total_blocks_ >= (4u << 20) && huff_split_ > 0 &&
+            huff_split_ < n_huff_work_ && rgb_convert_.empty()) {
+            for (int half = 0; half < 2; half++) {
+                idct_split_begin_[half][0] = (int)idct_work_split.size();
+                for (int c = 0; c < kNumIdctLayoutClasses; c++) {
+                    std::vector<IdctWork> w;
+                    // idct_work_by_class[c] was interleaved above: take the entries back in memory order
+                    for (const IdctWork &x : idct_work_by_class[c])
+                        if ((h_scans_[x.scan].image_index < split_image) == (half == 0)) w.push_back(x);
+                    std::sort(w.begin(), w.end(), [](const IdctWork &a, const IdctWork &b) { return a.scan != b.scan ? a.scan < b.scan : a.first_mcu < b.first_mcu; });
+                    xcd_interleave(w, xcds);
+                    idct_work_split.insert(idct_work_split.end(), w.begin(), w.end());
+                    idct_split_begin_[half][c + 1] = (int)idct_work_split.size();
+                }
+            }
+            overlap_ok_ = true;
+        }
+    }
+    decodes_since_query_ = 0;
+
     h_status_.assign(jobs_.size(), DevScanStatus());
     for (size_t j = 0; j < jobs_.size(); j++) {
         DevScanStatus &st = h_status_[j];
@@ -1128,6 +1165,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_lut_pool_, nullptr, 0, huff_pool_.size() * kLutPoolBytesPerTable},
         {&d_chunk_sums_, nullptr, 0, chunk_work.size() * sizeof(ChunkSum) + 256},
         {&d_idct_work_, idct_work.data(), idct_work.size() * sizeof(IdctWork), 0},
+        {&d_idct_work_split_, idct_work_split.data(), idct_work_split.size() * sizeof(IdctWork), 0},
         {&d_ends_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},
         {&d_ends_u_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},
         {&d_unstuffed_, nullptr, 0, (size_t)input_bytes_},
@@ -1274,10 +1312,26 @@ int DeviceBatch::run_idct() {
     return JPGPU_OK;
 }
 
+// One pass of the device pipeline over the batch.
+//
+// Issue order.  K2 (Huffman) is bound by the latency of its serial symbol chains and leaves most of the HBM bandwidth idle;
+// K3 (IDCT + output) is bound by HBM and leaves most of the issue slots idle.  For batches large enough to matter the batch
+// is cut in two halves of images and issued on the context's two streams so that the second half's K2 runs beside the first
+// half's K3:
+//     stream : K1(all)  K2(A) ------ K3(A) ----------------- [join] 
+//     stream2:                 wait  K2(B) ------ K3(B) ------/
+// (16.1 vs 17.2 ms per 1024 x 4K measured with two contexts in round 1; more parts or streams gave nothing more.)
+// Kernels that share the machine have no duration of their own, and bench.py's per-kernel roofline is computed from
+// exactly that: the first decode() after an upload or a jpgpu_batch_stage_ms query, and every 8th after it, is issued
+// serially on one stream with an event between the stages.  jpgpu_batch_stage_ms reports the stage times from those serial
+// passes and the whole-pipeline time over all passes.  JPGPU_OVERLAP=0 keeps every pass serial.
 int DeviceBatch::decode() {
     hipError_t e = hipSetDevice(ctx_->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-    if (ev_used_ + 4 > 4 * 256) ev_used_ = 0;  // bound the pool: keep the most recent decodes only
+    if (ev_used_ + 4 > 4 * 256) {  // bound the pool: keep the most recent decodes only
+        ev_used_ = 0;
+        ev_serial_.clear();
+    }
     while (ev_pool_.size() < ev_used_ + 4) {
         hipEvent_t ev = nullptr;
         e = hipEventCreate(&ev);
@@ -1285,14 +1339,44 @@ int DeviceBatch::decode() {
         ev_pool_.push_back(ev);
     }
     hipEvent_t *ev = &ev_pool_[ev_used_];
+    const bool serial = !overlap_ok_ || (decodes_since_query_ % kSerialEvery) == 0;
+    decodes_since_query_++;
     int rc;
-    (void)hipEventRecord(ev[0], ctx_->stream);
-    if ((rc = run_marker_index()) != JPGPU_OK) return rc;
-    (void)hipEventRecord(ev[1], ctx_->stream);
-    if ((rc = run_huffman()) != JPGPU_OK) return rc;
-    (void)hipEventRecord(ev[2], ctx_->stream);
-    if ((rc = run_idct()) != JPGPU_OK) return rc;
-    (void)hipEventRecord(ev[3], ctx_->stream);
+    hipStream_t s1 = ctx_->stream, s2 = ctx_->stream2;
+    (void)hipEventRecord(ev[0], s1);
+    if (serial) {
+        if ((rc = run_marker_index()) != JPGPU_OK) return rc;
+        (void)hipEventRecord(ev[1], s1);
+        if ((rc = run_huffman()) != JPGPU_OK) return rc;
+        (void)hipEventRecord(ev[2], s1);
+        if ((rc = run_idct()) != JPGPU_OK) return rc;
+        (void)hipEventRecord(ev[3], s1);
+    } else {
+        status_valid_ = false;
+        const YccRgbFactors kf = ycc_rgb_factors();
+        if ((rc = run_marker_index()) != JPGPU_OK) return rc;
+        if ((rc = clear_partial_outputs()) != JPGPU_OK) return rc;
+        auto k2 = [&](hipStream_t st, int first, int n) {
+            return launch_huffman(st, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_huff_work_.ptr + first, n,
+                                  (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr,
+                                  (int16_t *)d_coefs_.ptr, n_huff_slots_, (const uint32_t *)d_lut_pool_.ptr);
+        };
+        auto k3 = [&](hipStream_t st, int half) {
+            return launch_idct(st, (const int16_t *)d_coefs_.ptr, (const DevScan *)d_scans_.ptr, (const IdctWork *)d_idct_work_split_.ptr,
+                               idct_split_begin_[half], (const DevScanStatus *)d_status_.ptr, (const DevQuantTable *)d_quant_pool_.ptr,
+                               (uint8_t *)d_out_.ptr, format_, kf, (uint8_t *)d_rgb_scratch_.ptr);
+        };
+        if ((e = k2(s1, 0, huff_split_)) != hipSuccess) return hip_fail(e, "huffman_decode_kernel");
+        (void)hipEventRecord(ev[1], s1);  // K1 and K2(A) are done: the second half may start
+        if ((e = hipStreamWaitEvent(s2, ev[1], 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
+        if ((e = k2(s2, huff_split_, n_huff_work_ - huff_split_)) != hipSuccess) return hip_fail(e, "huffman_decode_kernel");
+        if ((e = k3(s1, 0)) != hipSuccess) return hip_fail(e, "idct_output_kernel");
+        if ((e = k3(s2, 1)) != hipSuccess) return hip_fail(e, "idct_output_kernel");
+        (void)hipEventRecord(ev[2], s2);
+        if ((e = hipStreamWaitEvent(s1, ev[2], 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");  // join
+        (void)hipEventRecord(ev[3], s1);
+    }
+    ev_serial_.push_back(serial);
     ev_used_ += 4;
     return JPGPU_OK;
 }
@@ -1302,25 +1386,33 @@ int DeviceBatch::sync() {
     return e == hipSuccess ? JPGPU_OK : hip_fail(e, "hipStreamSynchronize");
 }
 
-// Average per-stage device time over every decode() issued since the previous query (HIP events on the ctx stream).
+// Average device time (HIP events on the decode stream) over the decode() calls issued since the previous query: the three
+// stages from the passes that were issued serially (see decode()), the whole pipeline over all passes.
 int DeviceBatch::stage_ms(float ms[4]) {
     if (ev_used_ == 0) return fail(JPGPU_ERR_INVALID_OPERATION, "jpgpu_batch_stage_ms: no decode has run since the last query");
     int rc = sync();
     if (rc != JPGPU_OK) return rc;
     double acc[4] = {0, 0, 0, 0};
     const size_t n = ev_used_ / 4;
+    size_t n_serial = 0;
     for (size_t k = 0; k < n; k++) {
         hipEvent_t *ev = &ev_pool_[k * 4];
         float t;
-        for (int i = 0; i < 3; i++) {
-            if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) != hipSuccess) return fail(JPGPU_ERR_DEVICE, "hipEventElapsedTime failed");
-            acc[i] += t;
+        if (k < ev_serial_.size() && ev_serial_[k]) {
+            for (int i = 0; i < 3; i++) {
+                if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) != hipSuccess) return fail(JPGPU_ERR_DEVICE, "hipEventElapsedTime failed");
+                acc[i] += t;
+            }
+            n_serial++;
         }
         if (hipEventElapsedTime(&t, ev[0], ev[3]) != hipSuccess) return fail(JPGPU_ERR_DEVICE, "hipEventElapsedTime failed");
         acc[3] += t;
     }
-    for (int i = 0; i < 4; i++) ms[i] = (float)(acc[i] / (double)n);
+    for (int i = 0; i < 3; i++) ms[i] = n_serial ? (float)(acc[i] / (double)n_serial) : 0.0f;
+    ms[3] = (float)(acc[3] / (double)n);
     ev_used_ = 0;
+    ev_serial_.clear();
+    decodes_since_query_ = 0;
     return JPGPU_OK;
 }
 

@@ -26,6 +26,7 @@ struct StagingRing {
 struct jpgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;         // kernels of jpgpu_batch_decode and friends
+    hipStream_t stream2 = nullptr;        // second half of a large batch in jpgpu_batch_decode (DeviceBatch::decode)
     hipStream_t upload_stream = nullptr;  // H2D of jpgpu_batch_upload: runs beside another batch's decode on `stream`
     StagingRing staging;
     int host_threads = 0;                 // crew size of jpgpu_batch_upload; 0 = min(CPUs granted to the process, 16)
@@ -199,6 +200,14 @@ class DeviceBatch {
     // stage events of every decode() since the last stage_ms() query (4 events per decode)
     std::vector<hipEvent_t> ev_pool_;
     size_t ev_used_ = 0;
+    std::vector<bool> ev_serial_;  // per decode(): issued serially with stage events (true) or as two overlapped halves
+    // decode() in two halves (K2 of the second beside K3 of the first)
+    static constexpr int kSerialEvery = 8;
+    bool overlap_ok_ = false;
+    int decodes_since_query_ = 0;
+    int huff_split_ = 0;
+    int idct_split_begin_[2][kNumIdctLayoutClasses + 1] = {};
+    DevBuffer d_idct_work_split_;
 };
 
 }  // namespace jpgpu

@@ -113,12 +113,12 @@ def test_one_unread_byte_in_front_of_the_terminator_on_the_header_only_path():
 
 
 def test_staging_ring_wraps_and_thread_counts_agree(monkeypatch):
-    """More input than the staging ring holds (here 3 slots of 4 MiB: the ring wraps a dozen times), files that straddle
+    """More input than the staging ring holds (here 3 slots of 4 MiB: the ring wraps several times), files that straddle
     slots, and the same batch through 1, 3, 7 and the default number of host threads."""
     n = 48
     buf, sizes, stride = jpegsynth.encode_batch(n, 3840, 2160, "420", 75, 4, seed0=7000, nthreads=8)
     files = [buf[i * stride:i * stride + int(sizes[i])] for i in range(n)]
-    assert sum(len(f) for f in files) > 12 * (4 << 20)
+    assert sum(len(f) for f in files) > 10 * (4 << 20)
     monkeypatch.setenv("JPGPU_STAGING_SLOTS", "3")
     monkeypatch.setenv("JPGPU_STAGING_SLOT_MB", "4")
     ctx = jl.Context(0)
@@ -198,3 +198,44 @@ def test_two_contexts_from_two_threads_shard_one_file_list():
     assert sorted(jl.sharding.shard_indices(n, 0, world) + jl.sharding.shard_indices(n, 1, world)) == list(range(n))
     for i in range(n):
         assert np.array_equal(got[i], po.decode_8bit(bytes(files[i]))[0]), i
+
+
+def test_overlapped_issue_order_gives_the_serial_result(monkeypatch):
+    """jpgpu_batch_decode cuts large batches in two halves and runs the second half's Huffman stage beside the first
+    half's output stage (two streams); every 8th call is serial.  Same bytes either way, and against the oracle."""
+    n = 26  # 26 x 194 400 blocks: above the 4 Mi block threshold
+    buf, sizes, stride = jpegsynth.encode_batch(n, 3840, 2160, "420", 75, 4, seed0=4100, nthreads=8)
+    files = [buf[i * stride:i * stride + int(sizes[i])] for i in range(n)]
+    b = jl.Batch().upload(files, jl.FMT_INTERLEAVED_U8)
+    b.decode().sync()                       # first call: serial, with stage events
+    serial = [b.output(i).copy() for i in range(n)]
+    first = b.stage_ms()
+    assert first["huffman"] > 0 and first["idct"] > 0
+    p, total = b.output_device_ptr()
+    b.decode()                              # serial again (first call after the query) ...
+    for _ in range(5):
+        b.decode()                          # ... then five overlapped ones
+    b.sync()
+    st = b.stage_ms()
+    assert st["total"] > 0 and st["idct"] > 0
+    for i in range(n):
+        assert b.result(i).status == 0
+        assert np.array_equal(b.output(i), serial[i]), i
+    for i in (0, n // 2 - 1, n // 2, n - 1):
+        assert np.array_equal(serial[i], po.decode_8bit(bytes(files[i]))[0]), i
+    b.close()
+    # a corrupted file in each half: error reporting does not depend on the issue order either
+    bad = [bytes(f) for f in files]
+    for i in (3, n - 2):
+        d = bytearray(bad[i])
+        d[len(d) // 2: len(d) // 2 + 3] = b"\xff\xc4\x00"
+        bad[i] = bytes(d)
+    res = []
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("JPGPU_OVERLAP", overlap)
+        bb = jl.Batch().upload(bad, jl.FMT_INTERLEAVED_U8)
+        bb.decode().decode().sync()
+        res.append([(bb.result(i).status, bb.result(i).detail, bb.result(i).error_interval) for i in range(n)])
+        bb.close()
+    assert res[0] == res[1]
+    assert res[0][3][0] != 0 and res[0][n - 2][0] != 0 and res[0][0][0] == 0
