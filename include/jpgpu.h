@@ -203,10 +203,10 @@ int jpgpu_batch_upload_frames(jpgpu_batch *b, const jpgpu_frame *frames, const u
  *   marker index -> Huffman MCU decode (ref: ...BaselineScanDecoder.cs:51-222) ->
  *   dequantise + float32 IDCT + level shift (ref: ScanDecoder/JpegScanDecoder.cs:50-73, FastFloatingPointDCT.cs:54-185) ->
  *   block output in the batch's format (ref: ...BaselineScanDecoder.cs:225-268 + the sink).
- * Large batches (>= 4 Mi blocks of restart-interval scans) are issued as two halves of images on two streams, the Huffman
- * stage of the second half beside the output stage of the first (latency-bound beside HBM-bound); the first call after an
- * upload or a jpgpu_batch_stage_ms query and every 8th after it run serially so that stage times exist.  JPGPU_OVERLAP=0
- * keeps every call serial.  Results do not depend on the issue order. */
+ * With JPGPU_OVERLAP=1 large batches (>= 4 Mi blocks of restart-interval scans) are issued as two halves of images on two
+ * streams, the Huffman stage of the second half beside the output stage of the first; the first call after an upload or a
+ * jpgpu_batch_stage_ms query and every 8th after it still run serially so that stage times exist.  Off by default: it
+ * stopped paying once both stages became HBM-heavy.  Results do not depend on the issue order. */
 int jpgpu_batch_decode(jpgpu_batch *b);
 /* Individual stages, for stage-level parity tests and profiling. */
 int jpgpu_batch_run_entropy(jpgpu_batch *b); /* marker index + Huffman -> coefficient buffer */

@@ -1098,8 +1098,11 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     overlap_ok_ = false;
     std::vector<IdctWork> idct_work_split;
     {
+        // OFF by default: with the round-2 kernels both stages are HBM-heavy (K2 writes the coefficient buffer at 4.7 TB/s)
+        // and cannot share a CU (K2 takes 159 KB of its 160 KB LDS), so the halves time-slice instead of overlapping:
+        // 16.39-16.52 ms overlapped vs 16.16-16.37 ms serial per 1024 x 4K (gpurun r02e, both issue orders below)
         const char *ev = getenv("JPGPU_OVERLAP");
-        const bool wanted = !(ev && atoi(ev) == 0);
+        const bool wanted = ev && atoi(ev) != 0;
         uint32_t split_image = 0;
         uint64_t acc = 0;
         for (size_t ii = 0; ii < images_.size() && acc * 2 < total_blocks_; ii++) {
@@ -1320,11 +1323,12 @@ int DeviceBatch::run_idct() {
 // half's K3:
 //     stream : K1(all)  K2(A) ------ K3(A) ----------------- [join] 
 //     stream2:                 wait  K2(B) ------ K3(B) ------/
-// (16.1 vs 17.2 ms per 1024 x 4K measured with two contexts in round 1; more parts or streams gave nothing more.)
+// (16.1 vs 17.2 ms per 1024 x 4K measured with two contexts in round 1, with K3 at 10.5 ms; with round 2's kernels it no
+// longer pays -- see the numbers at `wanted` in layout_and_upload -- so the mode is opt-in: JPGPU_OVERLAP=1.)
 // Kernels that share the machine have no duration of their own, and bench.py's per-kernel roofline is computed from
 // exactly that: the first decode() after an upload or a jpgpu_batch_stage_ms query, and every 8th after it, is issued
 // serially on one stream with an event between the stages.  jpgpu_batch_stage_ms reports the stage times from those serial
-// passes and the whole-pipeline time over all passes.  JPGPU_OVERLAP=0 keeps every pass serial.
+// passes and the whole-pipeline time over all passes.
 int DeviceBatch::decode() {
     hipError_t e = hipSetDevice(ctx_->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
@@ -1366,8 +1370,10 @@ int DeviceBatch::decode() {
                                idct_split_begin_[half], (const DevScanStatus *)d_status_.ptr, (const DevQuantTable *)d_quant_pool_.ptr,
                                (uint8_t *)d_out_.ptr, format_, kf, (uint8_t *)d_rgb_scratch_.ptr);
         };
+        static const int mode = getenv("JPGPU_OVERLAP_MODE") ? atoi(getenv("JPGPU_OVERLAP_MODE")) : 1;
+        if (mode == 2) (void)hipEventRecord(ev[1], s1);  // experiment: the second half starts right behind K1
         if ((e = k2(s1, 0, huff_split_)) != hipSuccess) return hip_fail(e, "huffman_decode_kernel");
-        (void)hipEventRecord(ev[1], s1);  // K1 and K2(A) are done: the second half may start
+        if (mode != 2) (void)hipEventRecord(ev[1], s1);  // K1 and K2(A) are done: the second half may start
         if ((e = hipStreamWaitEvent(s2, ev[1], 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
         if ((e = k2(s2, huff_split_, n_huff_work_ - huff_split_)) != hipSuccess) return hip_fail(e, "huffman_decode_kernel");
         if ((e = k3(s1, 0)) != hipSuccess) return hip_fail(e, "idct_output_kernel");

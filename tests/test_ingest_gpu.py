@@ -201,9 +201,10 @@ def test_two_contexts_from_two_threads_shard_one_file_list():
 
 
 def test_overlapped_issue_order_gives_the_serial_result(monkeypatch):
-    """jpgpu_batch_decode cuts large batches in two halves and runs the second half's Huffman stage beside the first
-    half's output stage (two streams); every 8th call is serial.  Same bytes either way, and against the oracle."""
+    """With JPGPU_OVERLAP=1 jpgpu_batch_decode cuts large batches in two halves and runs the second half's Huffman stage
+    beside the first half's output stage (two streams); every 8th call is serial.  Same bytes either way, and against the oracle."""
     n = 26  # 26 x 194 400 blocks: above the 4 Mi block threshold
+    monkeypatch.setenv("JPGPU_OVERLAP", "1")
     buf, sizes, stride = jpegsynth.encode_batch(n, 3840, 2160, "420", 75, 4, seed0=4100, nthreads=8)
     files = [buf[i * stride:i * stride + int(sizes[i])] for i in range(n)]
     b = jl.Batch().upload(files, jl.FMT_INTERLEAVED_U8)
