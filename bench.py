@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ingest", action="store_true", help="skip the ingest-inclusive (upload beside decode) measurement")
     ap.add_argument("--gen-threads", type=int, default=0)
+    ap.add_argument("--distinct", type=int, default=0, help="experiments only: synthesise this many distinct images and repeat them "
+                                                            "to fill the batch (default: every image of the batch is distinct)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -220,7 +222,8 @@ def main():
     t0 = time.perf_counter()
     if ss == "420p":
         ss = "420"
-        files_b = progressive_batch(n_images, width, height, quality, sharding.rank_seed_base(rank), gen_threads)
+        files_b = progressive_batch(min(n_images, args.distinct or n_images), width, height, quality, sharding.rank_seed_base(rank), gen_threads)
+        files_b = [files_b[i % len(files_b)] for i in range(n_images)]
         sizes = np.array([len(f) for f in files_b], dtype=np.int64)
         stride = int(sizes.max())
         buf = np.zeros(stride * n_images + 64, np.uint8)
@@ -315,6 +318,7 @@ def main():
             "config": {
                 "workload": f"{n_images} x {width}x{height} {ss} {kind} Q{quality} DRI={dri} per GPU, output {args.format} resident in HBM",
                 "images_per_gpu": n_images,
+                **({"distinct_images": args.distinct} if args.distinct and args.distinct < n_images else {}),
                 "compressed_MB_per_gpu": round(totals["compressed_bytes"] / 1e6, 1),
                 "sharding": "image-per-GPU, no collective",
             },

@@ -46,7 +46,7 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_prog_sync_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
@@ -1156,6 +1156,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_chunk_work_, chunk_work.data(), chunk_work.size() * sizeof(ChunkWork), 0},
         {&d_sub_work_, sub_work.data(), sub_work.size() * sizeof(HuffWork), 0},
         {&d_prog_work_, prog_work.data(), prog_work.size() * sizeof(HuffWork), 0},
+        {&d_prog_sync_, nullptr, 0, (size_t)(prog_work.empty() ? 0 : 256)},
         {&d_sub_scan_ids_, sub_scan_ids_.data(), sub_scan_ids_.size() * sizeof(uint32_t), 0},
         {&d_sub_exit_a_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
         {&d_sub_exit_b_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
@@ -1262,14 +1263,21 @@ int DeviceBatch::run_progressive() {
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(progressive store)");
     }
     const char *dbg_max = getenv("JPGPU_DEBUG_MAX_PROGRESSIVE_SCANS");  // debugging aid: stop after N scans per frame
-    if (prog_pipelined_ && !dbg_max) {
-        // every scan is one stream: one launch, the work list ordered by level (workgroups start in list order, so a
-        // scan's producers are always running or done when it starts); dependent scans follow their producers' progress
-        const int n = prog_stream_begin_.back() - prog_stream_begin_.front();
+    // The single pipelined launch needs every workgroup resident (see the residency rule in progressive_stream_kernel): one
+    // wave per workgroup, LDS is what bounds them per CU; three quarters of that bound are used, the kernel itself checks.
+    const int n_streams = prog_stream_begin_.back() - prog_stream_begin_.front();
+    const size_t lds_per_wg = (progressive_stream_lds_bytes(n_huff_slots_) + 1023) / 1024 * 1024;
+    const int per_cu = (int)std::min<size_t>(32, (160u << 10) / lds_per_wg) * 3 / 4;
+    const bool fits = n_streams <= per_cu * (ctx_->num_cus > 0 ? ctx_->num_cus : 256);
+    if (prog_pipelined_ && fits && !dbg_max) {
+        // every scan is one stream: one launch, the work list ordered by level; dependent scans follow their producers' progress
+        hipError_t e0 = hipMemsetAsync(d_prog_sync_.ptr, 0, 256, ctx_->stream);
+        if (e0 != hipSuccess) return hip_fail(e0, "hipMemsetAsync(progressive sync)");
+        const int n = n_streams;
         hipError_t e = launch_progressive_streams(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr,
                                                   (const HuffWork *)d_prog_work_.ptr + prog_stream_begin_.front(), n,
                                                   (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr,
-                                                  (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, 1, prog_spin_budget_);
+                                                  (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, 1, prog_spin_budget_, (uint32_t *)d_prog_sync_.ptr);
         if (e != hipSuccess) return hip_fail(e, "progressive_stream_kernel");
         return JPGPU_OK;
     }
@@ -1284,7 +1292,7 @@ int DeviceBatch::run_progressive() {
                                        (const HuffWork *)d_prog_work_.ptr + prog_stream_begin_[k],
                                        prog_stream_begin_[k + 1] - prog_stream_begin_[k], (const uint32_t *)d_ends_u_.ptr,
                                        (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr,
-                                       n_huff_slots_, 0, 0);
+                                       n_huff_slots_, 0, 0, nullptr);
         if (e != hipSuccess) return hip_fail(e, "progressive_stream_kernel");
     }
     return JPGPU_OK;
@@ -1467,6 +1475,10 @@ int DeviceBatch::result(int i, jpgpu_image_result *res) {
         res->decoded_mcus = st.decoded_mcus;
         res->terminator = st.terminator;
         res->bytes_consumed = st.end_pos;
+        if (st.first_error != kNoError && getenv("JPGPU_DEBUG_STATUS"))
+            fprintf(stderr, "[jpgpu] image %d job %d kind %d Ss %d Se %d Ah %d Al %d comps %d: first_error %08x decoded %u of %u end_pos %u\n", i, j,
+                    (int)jobs_[j].kind, jobs_[j].ss, jobs_[j].se, jobs_[j].ah, jobs_[j].al, jobs_[j].scan_components, st.first_error, st.decoded_mcus,
+                    h_scans_[j].total_mcus, st.end_pos);
         if (st.first_error != kNoError) {
             const uint32_t detail = st.first_error & 0xFF;
             res->detail = (int32_t)detail;

@@ -177,7 +177,7 @@ class DeviceBatch {
     std::vector<uint32_t> sub_scan_ids_;
     int last_subseq_rounds_ = 0;
     // progressive frames: work of scan ordinal k is prog_work[prog_begin_[k] .. prog_begin_[k + 1])
-    DevBuffer d_prog_work_;
+    DevBuffer d_prog_work_, d_prog_sync_;  // d_prog_sync_: workgroups of the pipelined launch that have started
     std::vector<int> prog_begin_;
     // ... and the scans with few, long intervals (one wave per interval): prog_work[prog_stream_begin_[k] .. [k + 1])
     std::vector<int> prog_stream_begin_;

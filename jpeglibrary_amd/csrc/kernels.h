@@ -48,7 +48,8 @@ hipError_t launch_progressive(hipStream_t stream, const uint8_t *udata, const De
                               const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs, int n_slots);
 hipError_t launch_progressive_streams(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                                       const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
-                                      int n_slots, int pipelined, uint32_t spin_budget);
+                                      int n_slots, int pipelined, uint32_t spin_budget, uint32_t *started);
+size_t progressive_stream_lds_bytes(int n_slots);  // LDS of one stream workgroup (residency estimate of the pipelined launch)
 
 // K0 (ingest verification): offset of the first non-RST marker in each segment {offset lo, length} (+ offset hi), 0xFFFFFFFF = none
 hipError_t launch_first_marker(hipStream_t stream, const uint8_t *data, const void *segs, const uint32_t *seg_hi, int n_segs,

@@ -1384,19 +1384,20 @@ __global__ __launch_bounds__(kProgThreads) void progressive_scan_kernel(const ui
 //     concurrently by other scans);
 //   * refinement blocks are staged in LDS in rounds of kPsChunk blocks by all lanes (addresses computed by the lanes).
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kPsRingBytes = 4096;
-constexpr uint32_t kPsRingWords = kPsRingBytes / 4;
-constexpr int kPsChunk = 32;              // refinement blocks staged per round
+// LDS per stream (one wave): the stream ring (a power of two >= 2 KB: top-ups come in 1 KB pieces) and the staging of the
+// refinement blocks.  Both are launch parameters: the smaller they are, the more streams a CU holds (the kernel is bound
+// by instruction issue latency, co-resident waves are what hides it) -- 2 KB + 16 blocks = 23 streams per CU with two
+// Huffman tables, 4 KB + 32 blocks = 14 (JPGPU_PS_RING / JPGPU_PS_CHUNK, A/B in profiles/r02_progressive_lds.txt).
 constexpr int32_t kPsUnitBytes = 384;     // stream bytes staged before a block / MCU is started (unless the stream ends)
 constexpr uint32_t kPsNoBlock = 0xFFFFFFFFu;
 constexpr uint32_t kPsBadCode = 17u << 8;  // window entry: no code of 16 bits or less matches
-constexpr size_t kPsLdsBytes = kPsRingBytes + (size_t)kPsChunk * 128 + kPsChunk * 4;
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
 struct WBits {
     const uint32_t *ring;  // MSB-first words of the stream; ring byte 0 = the 16-byte aligned address at or below its first byte
+    uint32_t wmask;        // uniform: ring size in words - 1
     uint32_t pos;          // uniform: bit position of the next unread bit
     uint32_t cur;          // uniform: pos - window base; > 63 = the window has to be rebuilt
     int32_t rem;           // uniform: bits left before the interval's end (the reference's "bits available")
@@ -1418,7 +1419,7 @@ template <bool LUT>
 __device__ __forceinline__ void w_refresh(WBits &d, uint32_t lane, const LdsHuff &h) {
     const uint32_t bit = d.pos + lane;
     const uint32_t w = bit >> 5, sh = bit & 31u;
-    const uint32_t w0 = d.ring[w & (kPsRingWords - 1u)], w1 = d.ring[(w + 1u) & (kPsRingWords - 1u)];
+    const uint32_t w0 = d.ring[w & d.wmask], w1 = d.ring[(w + 1u) & d.wmask];
     d.peek = (uint32_t)(((((uint64_t)w0) << 32) | w1) >> (32u - sh));
     if (LUT) d.ent = h.lut[d.peek >> (32 - kHuffLutBits)];
     d.cur = 0;
@@ -1740,15 +1741,25 @@ __device__ __forceinline__ uint32_t w_ac_refine_fast(WBits &d, uint32_t lane, co
 }
 constexpr int32_t kPsFastBits = 2560;  // more than any block can consume: 63 x (16 + 16) + 14 (first), 63 x 17 + 63 + 14 (refinement)
 
+// A coefficient store of the stream kernel.  wt: write-through at agent scope (global_store_short sc1), which does not leave
+// the line in this XCD's L2 (kept for experiments: it thinned out, but did not remove, the wrong parses seen when a
+// pipelined launch was not fully resident -- see the residency rule in progressive_stream_kernel).
+__device__ __forceinline__ void ps_store(int16_t *p, int16_t v, bool wt) {
+    if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
                                                                 const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
                                                                 DevScanStatus *__restrict__ status,
                                                                 const DevHuffTable *__restrict__ huff_pool, int16_t *__restrict__ coefs,
-                                                                int n_slots, int pipelined, uint32_t spin_budget) {
+                                                                int n_slots, int pipelined, uint32_t spin_budget, uint32_t ring_bytes,
+                                                                uint32_t chunk_blocks, uint32_t *__restrict__ started) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *tabs = smem;  // n_slots * sizeof(DevHuffTable)
     uint8_t *base = smem + (size_t)n_slots * sizeof(DevHuffTable);
     uint32_t *ring = reinterpret_cast<uint32_t *>(base);
+    const uint32_t kPsRingBytes = ring_bytes, kPsChunk = chunk_blocks;  // uniform launch parameters (see kPsRingMax)
     int16_t *stage = reinterpret_cast<int16_t *>(base + kPsRingBytes);
     uint32_t *idx = reinterpret_cast<uint32_t *>(base + kPsRingBytes + kPsChunk * 128);
 
@@ -1790,6 +1801,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
     uint4 *ring16 = reinterpret_cast<uint4 *>(ring);
     WBits d;
     d.ring = ring;
+    d.wmask = kPsRingBytes / 4u - 1u;
     d.pos = skip * 8u;
     d.cur = 64;
     d.rem = (int32_t)((uend - ustart) * 8u);
@@ -1842,6 +1854,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
     // "finished" so that its own followers drain too, and the host re-issues the frame's scans level by level in fresh
     // launches (DeviceBatch::fetch_status).
     const bool publishes = pipelined != 0 && s.publishes != 0;
+    const bool wt = false;
     uint32_t *my_progress = &status[wk.scan].pad[1];
     const uint32_t my_units_per_row = units_per_line * (ncomp == 1 ? (uint32_t)s.comp[0].v : 1u);
     uint32_t dep_scan[3], dep_units_per_row[3];
@@ -1856,6 +1869,33 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
         }
     }
     if (dep_scan[0] == kNoDep) rows_ready = 0xFFFFFFFFu;
+    // RESIDENCY RULE.  The follow-your-producers protocol below is only ever run with every workgroup of the launch
+    // co-resident: HIP promises no dispatch order, so a follower that holds a slot while its producer still waits for one
+    // can starve the machine -- and, observed on MI355X with launches several times larger than what the CUs hold, a
+    // small share of followers then parsed blocks with coefficients missing although their producers had published far
+    // beyond them (1024 x 4K progressive, ~1 % of the last frames, root cause not isolated; agent-scope fences as the
+    // guide prescribes, an acquire per chunk and write-through stores did not remove it; launches in which every
+    // workgroup is resident, and level-by-level launches of any size, never showed it).  So: every workgroup counts itself
+    // in at its start; a follower goes on only once all have (a fully resident grid starts within a microsecond), and
+    // gives up with kDetailSpinTimeout otherwise -- the host then re-issues the scans level by level.  The host only
+    // chooses the pipelined launch for grids that fit (DeviceBatch::run_progressive), so this is the safety net for
+    // co-tenants on the device and for an occupancy estimate that was too generous.
+    if (pipelined != 0) {
+        if (lane == 0) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (dep_scan[0] != kNoDep) {
+            uint32_t polls = spin_budget < 4096u ? spin_budget : 4096u;
+            for (;;) {
+                const uint32_t n_ = uni(__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (n_ >= gridDim.x) break;
+                if (polls == 0) {
+                    err = kDetailSpinTimeout;
+                    break;
+                }
+                polls--;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+    }
     // wait until the producers have finished MCU row `row_`
 #define JPGPU_FOLLOW(row_)                                                                                      \
     if ((row_) >= rows_ready) {                                                                                 \
@@ -1877,10 +1917,18 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
             __builtin_amdgcn_s_sleep(32);                                                                       \
         }                                                                                                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                                      \
+        /* the invalidate completes asynchronously: nothing may be loaded before it has (MI355X guide, G16) */  \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
     }
+    // Release: the wave's own stores drained, the XCD's L2 written back, and -- spelled out in asm because hipcc (ROCm 7.2)
+    // drops the wait behind buffer_wbl2 when it believes the counter is empty, letting the flag overtake the write-back: a
+    // follower then parses a block with stale coefficients (seen as sporadic "invalid Huffman code" failures once a batch
+    // held more streams than the machine keeps resident) -- only then the progress word.
 #define JPGPU_PUBLISH(units_)                                                                                   \
     if (publishes) {                                                                                            \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                                                      \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
         if (lane == 0) __hip_atomic_store(my_progress, (units_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   \
     }
     constexpr uint32_t kPsPublishEvery = 64;
@@ -1925,7 +1973,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                             if (err != 0) break;
                             const int32_t t = pred[c] + value;
                             pred[c] = t;
-                            if (real && lane == 0) coefs[index * 64] = (int16_t)((uint32_t)t << al);
+                            if (real && lane == 0) ps_store(coefs + index * 64, (int16_t)((uint32_t)t << al), wt);
                         } else {
                             uint32_t bit;
                             if (!w_read_bits<false, false>(d, lane, hdc, 1, bit)) {
@@ -1974,12 +2022,12 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                     err = w_ac_first_block<false>(d, lane, hac, closed_by_marker, ss, se, al, eobrun, c, changed);
                     JPGPU_SETTLE()
                 }
-                if (real && (changed & lane_bit) != 0) coefs[index * 64 + lane] = (int16_t)c;
+                if (real && (changed & lane_bit) != 0) ps_store(coefs + index * 64 + lane, (int16_t)c, wt);
             }
         } else {
             for (uint32_t done = 0; done < my_units && err == 0;) {
                 const uint32_t n = my_units - done < (uint32_t)kPsChunk ? my_units - done : (uint32_t)kPsChunk;
-                if (done != 0) JPGPU_PUBLISH(done)
+                if (done != 0 && (done & 31u) == 0) JPGPU_PUBLISH(done)  // a release fence costs microseconds: every 32 blocks
                 JPGPU_FOLLOW((first_unit + done + n - 1u) / my_units_per_row)
                 if (err != 0) break;  // gave up waiting (kDetailSpinTimeout)
                 if (lane < n) {
@@ -2010,7 +2058,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                         err = w_ac_refine_block<false>(d, lane, hac, ss, se, p1, m1, band, nz, eobrun, c, mine);
                         JPGPU_SETTLE()
                     }
-                    if (ix != kPsNoBlock && mine) coefs[(uint64_t)ix * 64 + lane] = (int16_t)c;
+                    if (ix != kPsNoBlock && mine) ps_store(coefs + (uint64_t)ix * 64 + lane, (int16_t)c, wt);
                     if (err == 0) done++;
                 }
             }
@@ -3144,14 +3192,37 @@ hipError_t launch_progressive(hipStream_t stream, const uint8_t *udata, const De
     return hipGetLastError();
 }
 
+// LDS one stream workgroup (one wave) takes: the host sizes pipelined launches by it (every workgroup must be resident).
+static void ps_lds_shape(uint32_t &ring, uint32_t &chunk) {
+    static const uint32_t ring_ = [] {
+        const char *ev = getenv("JPGPU_PS_RING");
+        const uint32_t v = ev ? (uint32_t)atoi(ev) : 2048u;
+        return v >= 4096u ? 4096u : 2048u;
+    }();
+    static const uint32_t chunk_ = [] {
+        const char *ev = getenv("JPGPU_PS_CHUNK");
+        const uint32_t v = ev ? (uint32_t)atoi(ev) : 16u;
+        return v >= 32u ? 32u : (v >= 16u ? 16u : 8u);
+    }();
+    ring = ring_;
+    chunk = chunk_;
+}
+size_t progressive_stream_lds_bytes(int n_slots) {
+    uint32_t ring, chunk;
+    ps_lds_shape(ring, chunk);
+    return (size_t)n_slots * sizeof(DevHuffTable) + ring + (size_t)chunk * 128 + chunk * 4;
+}
+
 // The same, one wave per (scan, restart interval): for scans with few, long intervals.
 hipError_t launch_progressive_streams(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                                       const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
-                                      int n_slots, int pipelined, uint32_t spin_budget) {
+                                      int n_slots, int pipelined, uint32_t spin_budget, uint32_t *started) {
     if (n_work <= 0) return hipSuccess;
-    const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kPsLdsBytes;
+    uint32_t ring, chunk;
+    ps_lds_shape(ring, chunk);
+    const size_t lds = progressive_stream_lds_bytes(n_slots);
     hipLaunchKernelGGL(progressive_stream_kernel, dim3(n_work), dim3(64), lds, stream, udata, scans, work, ends_u, status, huff_pool,
-                       coefs, n_slots, pipelined, spin_budget);
+                       coefs, n_slots, pipelined, spin_budget, ring, chunk, started);
     return hipGetLastError();
 }
 

@@ -536,6 +536,57 @@ def test_progressive_files_match_oracle(w, h, ss, q, rst, gray):
         base += ch * cv
 
 
+def test_progressive_4k_images_match_the_oracle():
+    """BASELINE config 5 at full size: 3840x2160 4:2:0 progressive (libjpeg's 10-scan script, DRI = 0), three images in one
+    batch, all scans of all frames in the single pipelined launch; samples against the oracle."""
+    files = [_pillow_progressive(3840, 2160, "4:2:0", 75, seed) for seed in (11, 12, 13)]
+    b = jl.Batch().upload(files).decode().sync()
+    for i, f in enumerate(files):
+        assert b.result(i).status == 0, (i, b.result(i).detail)
+        ref, info = po.decode_8bit(f)
+        assert info.sof == 0xC2 and ref.shape == (2160, 3840, 3)
+        assert np.array_equal(b.output(i), ref), i
+    assert b.progressive_fallbacks() == 0
+    b.close()
+
+
+def _many_small_progressive(n):
+    distinct = [_pillow_progressive(64 + 8 * (k % 5), 48 + 8 * (k % 3), ["4:2:0", "4:4:4", "4:2:2"][k % 3], 60 + k, 500 + k) for k in range(24)]
+    refs = [po.decode_8bit(d)[0] for d in distinct]
+    return [distinct[i % 24] for i in range(n)], [refs[i % 24] for i in range(n)]
+
+
+def test_more_progressive_streams_than_the_machine_keeps_resident():
+    """The single pipelined launch gives every scan one workgroup that follows its producers' progress from inside the
+    kernel: 2400 frames x 10 scans = 24 000 workgroups, several times what 256 CUs hold at once, so followers are
+    dispatched long before some producers exist.  Every frame exact, no fallback needed."""
+    files, refs = _many_small_progressive(2400)
+    b = jl.Batch().upload(files)
+    for _ in range(3):
+        b.decode()
+    b.sync()
+    bad = [i for i in range(len(files)) if b.result(i).status != 0 or not np.array_equal(b.output(i), refs[i])]
+    assert not bad, bad[:10]
+    assert b.progressive_fallbacks() == 0
+    b.close()
+
+
+def test_progressive_spin_budget_exhausted_falls_back_level_by_level(monkeypatch):
+    """With no polls to spend (JPGPU_PROG_SPIN_BUDGET=0) every follower that is not already satisfied gives up; the host
+    sees the internal time-out status and re-issues the step scan level by scan level in fresh launches: same samples."""
+    monkeypatch.setenv("JPGPU_PROG_SPIN_BUDGET", "0")
+    files, refs = _many_small_progressive(300)
+    files += [_pillow_progressive(1024, 768, "4:2:0", 85, 77)]
+    refs += [po.decode_8bit(files[-1])[0]]
+    b = jl.Batch().upload(files).decode().sync()
+    bad = [i for i in range(len(files)) if b.result(i).status != 0 or not np.array_equal(b.output(i), refs[i])]
+    assert not bad, bad[:10]
+    assert b.progressive_fallbacks() == 1
+    b.decode().sync()  # stays level by level
+    assert all(b.result(i).status == 0 for i in range(len(files))) and b.progressive_fallbacks() == 1
+    b.close()
+
+
 def test_progressive_batch_mixed_with_baseline():
     files = [read_jpeg("progress.jpg"), read_jpeg("lake.jpg"), _pillow_progressive(160, 120, "4:2:0", 70, 3),
              bytes(jpegsynth.encode(96, 64, "420", 75, 2, seed=5)), read_jpeg("yellowcat_progressive_restart.jpg")]
