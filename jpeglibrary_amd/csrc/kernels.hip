@@ -2099,75 +2099,6 @@ constexpr uint32_t kSubBad = 0x80000000u;  // the lane hit an invalid code / ran
 // exit state word: overshoot (bits past the nominal end, 0..63) | b << 6 | k << 11 | kSubBad
 __device__ __forceinline__ uint32_t sub_pack(uint32_t overshoot, uint32_t b, uint32_t k) { return overshoot | (b << 6) | (k << 11); }
 
-// Decodes subsequence `sub` of a DRI = 0 scan from `entry` (packed like an exit of sub-1).  When `coefs` is non-null
-// the coefficients are stored (final pass), starting with block `first_block`.  Returns the exit state word; *nblk =
-// blocks COMPLETED inside the subsequence.
-// dc[c]: FINAL: in = DcPredictor of component c at the entry, the chain is applied while decoding;
-//        otherwise out = sum of the DC differences of component c decoded inside the subsequence.
-template <bool FINAL>
-__device__ __forceinline__ uint32_t sub_decode(const uint8_t *ubase, uint32_t total_bits, uint32_t sub_shift, uint32_t sub, uint32_t entry, const uint8_t *tabs,
-                                               const uint32_t *blk_info, uint32_t bpm, uint32_t &nblk, int16_t *coefs, uint32_t first_block,
-                                               uint32_t total_blocks, uint32_t &err_out, bool closed_by_marker, int32_t (&dc)[4]) {
-    const uint32_t start_bit = (sub << sub_shift) + (entry & 63u);
-    const uint32_t end_bit = (sub + 1) << sub_shift;
-    uint32_t b_in_mcu = (entry >> 6) & 31u, k = (entry >> 11) & 127u;
-    nblk = 0;
-    err_out = 0;
-    if (start_bit >= total_bits && !FINAL) return sub_pack(0, b_in_mcu, k) | kSubBad;
-    UBits r;
-    ub_init(r, ubase, start_bit >> 3, (total_bits + 7) >> 3);
-    if (start_bit & 7u) {
-        ub_consume(r, start_bit & 7u);
-    }
-    r.rem = (int32_t)total_bits - (int32_t)start_bit;
-    uint32_t pos = start_bit;
-    uint32_t info = blk_info[b_in_mcu];
-    uint32_t blk = first_block;
-    while (pos < end_bit) {
-        if (FINAL && blk >= total_blocks) break;  // the reference stops after the last MCU
-        const bool is_dc = (k == 0);
-        const LdsHuff h = lds_huff16(tabs, is_dc ? (info & 0xFFF) : ((info >> 12) & 0xFFF));
-        uint32_t sym;
-        int32_t v;
-        const int32_t rem_before = r.rem;
-        const uint32_t e = ub_symbol(r, h, is_dc, closed_by_marker, sym, v);
-        if (e != 0) {
-            err_out = e;
-            return sub_pack(0, b_in_mcu, k) | kSubBad;
-        }
-        pos += (uint32_t)(rem_before - r.rem);
-        if (rem_before - r.rem == 0 && r.rem == 0) pos = end_bit;  // data exhausted: only padding is being read
-        const uint32_t rr = is_dc ? 0u : (sym >> 4);
-        const uint32_t ss = is_dc ? sym : (sym & 15u);
-        if (is_dc) {
-            // t += DcPredictor; DcPredictor = t (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:193-195); in the
-            // synchronisation rounds dc[] starts at 0 and simply accumulates the differences
-            const uint32_t ci = info >> 24;
-            const int32_t t = v + (ci == 0 ? dc[0] : (ci == 1 ? dc[1] : (ci == 2 ? dc[2] : dc[3])));
-            if (ci == 0) dc[0] = t;
-            else if (ci == 1) dc[1] = t;
-            else if (ci == 2) dc[2] = t;
-            else dc[3] = t;
-            v = t;
-        }
-        if (FINAL && (is_dc || ss != 0)) {
-            uint32_t idx = is_dc ? 0u : (k + rr);
-            idx = idx < 63u ? idx : 63u;
-            coefs[(uint64_t)blk * 64 + idx] = (int16_t)v;
-        }
-        k = is_dc ? 1u : (ss != 0 ? k + rr + 1u : (rr == 0 ? 64u : k + 16u));
-        if (k >= 64u) {
-            nblk++;
-            blk++;
-            b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
-            k = 0;
-            info = blk_info[b_in_mcu];
-        }
-    }
-    const uint32_t over = pos > end_bit ? pos - end_bit : 0u;
-    return sub_pack(over < 63u ? over : 63u, b_in_mcu, k);
-}
-
 __device__ __forceinline__ void sub_stage_tables(const DevScan &s, const DevHuffTable *huff_pool, uint8_t *tabs, uint32_t *blk_info, int n_slots,
                                                  uint32_t nthreads) {
     const uint32_t tid = threadIdx.x;
@@ -2185,6 +2116,63 @@ __device__ __forceinline__ void sub_stage_tables(const DevScan &s, const DevHuff
         blk_info[tid] = dc_off | (ac_off << 12) | (ci << 24);
     }
     __syncthreads();
+}
+
+// Tables of a scan staged the way K2 lays them out (fused lookup of 1 << LB entries, then the reference's small arrays),
+// for the subsequence kernels.  The lookups come from the pool built once per upload (lut_pool_kernel, 11-bit prefixes);
+// LB = 10 keeps every other entry (prefixes 2i and 2i + 1 agree whenever the code has at most 10 bits).
+template <int LB>
+__device__ __forceinline__ void k2_stage_scan_tables(const DevScan &s, const DevHuffTable *huff_pool, const uint32_t *lut_pool, uint8_t *tabs,
+                                                     uint32_t *blk_info, int n_slots, uint32_t nthreads) {
+    constexpr uint32_t kTabBytes = (4u << LB) + kK2SmallBytes;
+    const uint32_t tid = threadIdx.x;
+    for (int sl = 0; sl < kMaxHuffSlots && sl < n_slots; sl++) {
+        const uint32_t pi = s.huff_pool[sl];
+        if (pi == 0xFFFF) continue;
+        bool is_dc = false;
+        for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
+        const uint32_t *src = lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * (1u << kLutPoolBits);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(tabs + sl * kTabBytes);
+        if (LB == kLutPoolBits) {
+            for (uint32_t i = tid; i < (1u << LB) / 4; i += nthreads) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+        } else {
+            for (uint32_t i = tid; i < (1u << LB); i += nthreads) {
+                const uint32_t e = src[i << (kLutPoolBits - LB)];
+                dst[i] = (e != kK2BadCategory && ((e & 0x80000000u) || ((e >> 8) & 0xFFu) > (uint32_t)LB)) ? kK2Miss : e;
+            }
+        }
+        const uint4 *ssrc = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&huff_pool[pi]) + offsetof(DevHuffTable, maxcode));
+        uint4 *sdst = reinterpret_cast<uint4 *>(tabs + sl * kTabBytes + (4u << LB));
+        if (tid < kK2SmallBytes / 16) sdst[tid] = ssrc[tid];
+    }
+    if (tid < kMaxBlocksPerMcu) {
+        const uint32_t ci = s.blk_comp[tid];
+        blk_info[tid] = ci | ((uint32_t)s.comp[ci].dc_slot << 8) | ((uint32_t)s.comp[ci].ac_slot << 16);
+    }
+}
+
+// A lane's stream positioned at bit `start_bit` of the scan's unstuffed data: K2's ring + feed + position (64 bytes staged,
+// the next 16 prefetched).  Returns pm1 of the start; *endpos = position of the first bit behind the data.
+__device__ __forceinline__ int32_t k2_open_at_bit(const uint8_t *ubase, uint32_t start_bit, uint32_t total_bits, uint8_t *ring, K2Feed &feed,
+                                                  K2Pos &pos, int32_t *endpos) {
+    const uint32_t u0 = start_bit >> 3;
+    const int32_t pm1_0 = (int32_t)((u0 & 3u) * 8u + (start_bit & 7u)) - 1;
+    *endpos = pm1_0 + 1 + (int32_t)(total_bits - start_bit);
+    const uint8_t *g = ubase + (u0 & ~3u);  // 4-byte aligned 16-byte loads; buffers are padded
+    uint4 c0, c1, c2, c3;
+    __builtin_memcpy(&c0, g, 16);
+    __builtin_memcpy(&c1, g + 16, 16);
+    __builtin_memcpy(&c2, g + 32, 16);
+    __builtin_memcpy(&c3, g + 48, 16);
+    __builtin_memcpy(&feed.nx, g + 64, 16);
+    k2_ring_write(ring, 0, c0);
+    k2_ring_write(ring, 1, c1);
+    k2_ring_write(ring, 2, c2);
+    k2_ring_write(ring, 3, c3);
+    feed.wr = 4;
+    feed.gp = g + 80;
+    k2_pos_init(pos, ring, pm1_0);
+    return pm1_0;
 }
 
 // One synchronisation round.  exit_in/exit_out are double-buffered per-subsequence state words (index sub_off + sub).
@@ -2337,6 +2325,9 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
     nblk_out[slot] = nblk;
     dcsum_out[slot] = make_int4(dc0, dc1, dc2, dc3);
 }
+// (A version on K2's per-lane LDS ring -- the bit source of the final pass below -- was built and measured in round 2: 2.45 ms
+// per round against 1.92 ms for this one at 1024 x 4K; the ring's 17 KB per workgroup halve the occupancy, and the rounds
+// need the occupancy more.)
 // Exclusive prefix sums over a scan's subsequences: first block and DC predictors at the entry of every subsequence.
 // One workgroup per scan.
 __global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__restrict__ scans, const uint32_t *__restrict__ scan_ids,
@@ -2385,36 +2376,43 @@ __global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__rest
 
 // Final pass.  The converged entry states say where every subsequence's first block begins: lane i decodes the WHOLE
 // blocks that start inside subsequence i (it first skips the tail of a block the previous lane is finishing, and runs
-// past its own end to finish its last block), so every block has exactly one owner.  Lanes of a wave then work like K2:
-// block j of every lane is decoded into the wave's LDS staging in lock-step and flushed as whole 128-byte lines; the
-// coefficient buffer needs no clearing.  The DC predictor chain starts from the prefix sums of subseq_scan_kernel.
+// past its own end to finish its last block), so every block has exactly one owner.  Lanes of a wave then work like K2
+// -- the same ring, lookups and symbol step, with the tables picked per lane because the lanes stand at different blocks of
+// their MCUs: block j of every lane is decoded into the wave's LDS staging in lock-step and flushed as whole 128-byte
+// lines; the coefficient buffer needs no clearing.  The DC predictor chain starts from the prefix sums of
+// subseq_scan_kernel.  (First version: the generic word reader and symbol decoder, 11.0 ms per 1024 x 4K against K2's 5.7.)
 constexpr int kSubFinalWaves = 4;
+constexpr int kSfLB = 10;
+constexpr uint32_t kSfTabBytes = (4u << kSfLB) + kK2SmallBytes;
+constexpr int kSfWaveBytes = kK2WaveBytes + 64 * 2 * (int)sizeof(uint32_t);  // K2's staging + rings, then (first block, count) per lane
 __global__ __launch_bounds__(64 * kSubFinalWaves) void subseq_final_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
                                                                            const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
                                                                            DevScanStatus *__restrict__ status,
                                                                            const DevHuffTable *__restrict__ huff_pool,
+                                                                           const uint32_t *__restrict__ lut_pool,
                                                                            const uint32_t *__restrict__ exit_state,
                                                                            const uint32_t *__restrict__ first_block,
                                                                            const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs,
                                                                            int n_slots) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *tabs = smem;
-    uint32_t *blk_info = reinterpret_cast<uint32_t *>(smem + (size_t)n_slots * sizeof(DevHuffTable));
-    uint8_t *stage_all = reinterpret_cast<uint8_t *>(blk_info + kMaxBlocksPerMcu);                    // kSubFinalWaves * 8192
-    uint32_t *meta_all = reinterpret_cast<uint32_t *>(stage_all + kSubFinalWaves * 8192);             // [waves][64][2]
+    uint8_t *tabs = smem;                                                    // n_slots * kSfTabBytes
+    uint8_t *wave_all = smem + (size_t)n_slots * kSfTabBytes;                // kSubFinalWaves * kSfWaveBytes
+    uint32_t *blk_info = reinterpret_cast<uint32_t *>(wave_all + kSubFinalWaves * kSfWaveBytes);  // [kMaxBlocksPerMcu]
     const HuffWork wk = work[blockIdx.x];
     const DevScan &s = scans[wk.scan];
-    sub_stage_tables(s, huff_pool, tabs, blk_info, n_slots, 64 * kSubFinalWaves);
     const DevScanStatus st = status[wk.scan];
     if (st.n_ends == 0) return;
+    k2_stage_scan_tables<kSfLB>(s, huff_pool, lut_pool, tabs, blk_info, n_slots, 64 * kSubFinalWaves);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint8_t *stage = stage_all + wave * 8192;
-    uint32_t *meta = meta_all + wave * 128;
+    uint8_t *stage = wave_all + wave * kSfWaveBytes;
+    uint8_t *ring = stage + 8192 + lane * kK2RingStride;
+    uint32_t *meta = reinterpret_cast<uint32_t *>(stage + kK2WaveBytes);
     {
         const uint4 z = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(stage)[i * 64 + lane] = z;
     }
+    __syncthreads();
     const uint32_t ulen = ends_u[s.ends_off];
     const uint32_t total_bits = ulen * 8;
     const uint32_t sub = wk.first_interval + tid;
@@ -2431,10 +2429,11 @@ __global__ __launch_bounds__(64 * kSubFinalWaves) void subseq_final_kernel(const
         if (prev & kSubBad) live = false;  // the stream ended or failed in an earlier subsequence: reported by that lane
         else entry = prev;
     }
-    uint32_t b_in_mcu = (entry >> 6) & 31u, k = (entry >> 11) & 127u;
+    uint32_t b_in_mcu = (entry >> 6) & 31u;
+    uint32_t i2 = ((entry >> 11) & 127u) * 2u;  // 2 x zig-zag position inside the block in progress at the entry
     uint32_t my_first = total_blocks, my_end = total_blocks;
     if (live) {
-        my_first = first_block[slot] + (k != 0 ? 1u : 0u);
+        my_first = first_block[slot] + (i2 != 0 ? 1u : 0u);
         if (sub + 1 < s.n_subs) {
             const uint32_t ex = exit_state[slot];
             if (!(ex & kSubBad)) my_end = first_block[slot + 1] + ((((ex >> 11) & 127u) != 0) ? 1u : 0u);
@@ -2447,73 +2446,80 @@ __global__ __launch_bounds__(64 * kSubFinalWaves) void subseq_final_kernel(const
     meta[lane * 2 + 1] = count;
     const uint32_t wave_count = wave_reduce_max_i((int32_t)count);
 
-    UBits r;
+    const bool decodes = live && count != 0;
+    const uint32_t start_bit = decodes ? (sub << s.sub_shift) + (entry & 63u) : 0u;
+    K2Feed feed;
+    K2Pos pos;
+    int32_t endpos = 0;
+    (void)k2_open_at_bit(udata + s.data_off, start_bit < total_bits ? start_bit : 0u, total_bits, ring, feed, pos, &endpos);
+    int32_t lim = k2_limit(endpos, feed.wr);
     uint32_t err = 0;
-    int32_t dc[4] = {0, 0, 0, 0};
+    int32_t pred0 = 0, pred1 = 0, pred2 = 0, pred3 = 0;
     uint32_t info = blk_info[b_in_mcu];
+    if (decodes) {
+        const int4 de = dc_entry[slot];
+        pred0 = de.x;
+        pred1 = de.y;
+        pred2 = de.z;
+        pred3 = de.w;
+    }
+    // the tail of the block the previous lane owns: parsed, not stored
     {
-        const uint32_t start_bit = live ? (sub << s.sub_shift) + (entry & 63u) : 0u;
-        ub_init(r, udata + s.data_off, start_bit >> 3, (total_bits + 7) >> 3);
-        if (start_bit & 7u) ub_consume(r, start_bit & 7u);
-        r.rem = (int32_t)total_bits - (int32_t)start_bit;
-        if (live && count != 0) {
-            const int4 de = dc_entry[slot];
-            dc[0] = de.x;
-            dc[1] = de.y;
-            dc[2] = de.z;
-            dc[3] = de.w;
-            // the tail of the block the previous lane owns: parsed, not stored
-            while (k != 0 && err == 0) {
-                const LdsHuff h = lds_huff16(tabs, (info >> 12) & 0xFFF);
-                uint32_t sym;
+        bool tail = decodes && i2 != 0;
+        uint32_t it = 0;
+        while (__ballot(tail) != 0) {
+            if (tail) {
                 int32_t v;
-                err = ub_symbol(r, h, false, closed_by_marker, sym, v);
-                const uint32_t rr = sym >> 4;
-                k = (sym & 15u) != 0 ? k + rr + 1u : (rr == 0 ? 64u : k + 16u);
-                if (k >= 64u) {
-                    k = 0;
+                uint32_t adv;
+                err = k2_symbol<kSfLB>(ring, feed, pos, endpos, lim, k2_tab<kSfLB>(tabs, info >> 16), false, closed_by_marker, v, adv);
+                i2 += adv;
+                if (err != 0 || i2 >= 128u) {
+                    tail = false;
+                    i2 = 0;
                     b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
                     info = blk_info[b_in_mcu];
                 }
             }
+            if ((++it & 3u) == 0) {
+                k2_topup(ring, feed, pos.pm1);
+                lim = k2_limit(endpos, feed.wr);
+            }
         }
     }
+    k2_topup(ring, feed, pos.pm1);
     uint8_t *my_stage = stage + lane * 128;
     const uint32_t swz16 = ((lane >> 1) & 7u) << 4;
 
     for (uint32_t j = 0; j < wave_count; j++) {
+        lim = k2_limit(endpos, feed.wr);
         if (j < count && err == 0) {
             // ReadBlockBaseline (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:179-222)
-            uint32_t sym;
+            const uint32_t ci = info & 0xFFu;
+            const K2Tab hdc = k2_tab<kSfLB>(tabs, (info >> 8) & 0xFFu);
+            const K2Tab hac = k2_tab<kSfLB>(tabs, info >> 16);
             int32_t v;
-            err = ub_symbol(r, lds_huff16(tabs, info & 0xFFF), true, closed_by_marker, sym, v);
-            if (err == 0) {
-                const uint32_t ci = info >> 24;
-                const int32_t t = v + (ci == 0 ? dc[0] : (ci == 1 ? dc[1] : (ci == 2 ? dc[2] : dc[3])));
-                if (ci == 0) dc[0] = t;
-                else if (ci == 1) dc[1] = t;
-                else if (ci == 2) dc[2] = t;
-                else dc[3] = t;
-                *reinterpret_cast<int16_t *>(my_stage + swz16) = (int16_t)t;
-                const LdsHuff hac = lds_huff16(tabs, (info >> 12) & 0xFFF);
-                for (uint32_t i = 1; i < 64;) {
-                    err = ub_symbol(r, hac, false, closed_by_marker, sym, v);
-                    if (err != 0) break;
-                    const uint32_t rr = sym >> 4;
-                    if ((sym & 15u) != 0) {
-                        i += rr;
-                        const uint32_t idx = i < 63 ? i : 63;  // Math.Min(i++, 63)
-                        i++;
-                        *reinterpret_cast<int16_t *>(my_stage + ((idx * 2) ^ swz16)) = (int16_t)v;
-                    } else {
-                        if (rr == 0) break;
-                        i += 16;  // ANY r != 0, not only 15 (ref: :212-220)
-                    }
-                }
-                b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
-                info = blk_info[b_in_mcu];
+            uint32_t adv = 0;
+            err = k2_symbol<kSfLB>(ring, feed, pos, endpos, lim, hdc, true, closed_by_marker, v, adv);
+            const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
+            v += pred;
+            if (ci == 0) pred0 = v;
+            else if (ci == 1) pred1 = v;
+            else if (ci == 2) pred2 = v;
+            else pred3 = v;
+            *reinterpret_cast<int16_t *>(my_stage + swz16) = (int16_t)v;  // zig-zag index 0
+            uint32_t k2i = err == 0 ? 2u : 128u;
+            while (k2i < 128u) {
+                const uint32_t e2 = k2_symbol<kSfLB>(ring, feed, pos, endpos, lim, hac, false, closed_by_marker, v, adv);
+                err |= e2;
+                k2i += adv;
+                // Math.Min(i++, 63) for a coefficient; EOB / ZRL store a zero at a position nothing was written to yet
+                const uint32_t at = k2i - 2u < 126u ? k2i - 2u : 126u;
+                *reinterpret_cast<int16_t *>(my_stage + (at ^ swz16)) = (int16_t)v;
             }
+            b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
+            info = blk_info[b_in_mcu];
         }
+        k2_topup(ring, feed, pos.pm1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2537,7 +2543,10 @@ __global__ __launch_bounds__(64 * kSubFinalWaves) void subseq_final_kernel(const
         atomicMin(&status[wk.scan].first_error, (sub << 8) | err);
     }
     // bits left behind the scan's last block (see restart_check)
-    if (live && err == 0 && count != 0 && my_end == total_blocks) status[wk.scan].pad[2] = r.rem > 0 ? (uint32_t)r.rem : 0u;
+    if (live && err == 0 && count != 0 && my_end == total_blocks) {
+        const int32_t rem = endpos - (pos.pm1 + 1);
+        status[wk.scan].pad[2] = rem > 0 ? (uint32_t)rem : 0u;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3285,10 +3294,16 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                       first_block, entry_used, dcsum, dc_entry, changed_dev, n_slots, max_rounds, rounds_used, lut_pool,
                                       &final_state);
     if (e != hipSuccess) return e;
-    const size_t lds = (size_t)n_slots * sizeof(DevHuffTable) + kMaxBlocksPerMcu * sizeof(uint32_t);
-    const size_t lds_final = lds + (size_t)kSubFinalWaves * (8192 + 64 * 2 * sizeof(uint32_t));
+    const size_t lds_final = (size_t)n_slots * kSfTabBytes + (size_t)kSubFinalWaves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
+    static bool configured = false;  // more than 64 KB of dynamic LDS has to be allowed once per kernel
+    if (!configured) {
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&subseq_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)((size_t)kMaxHuffSlots * kSfTabBytes + (size_t)kSubFinalWaves * kSfWaveBytes + 64));
+        if (ea != hipSuccess) return ea;
+        configured = true;
+    }
     hipLaunchKernelGGL(subseq_final_kernel, dim3(n_work), dim3(64 * kSubFinalWaves), lds_final, stream, udata, scans, work, ends_u, status,
-                       huff_pool, final_state, first_block, (const int4 *)dc_entry, coefs, n_slots);
+                       huff_pool, lut_pool, final_state, first_block, (const int4 *)dc_entry, coefs, n_slots);
     return hipGetLastError();
 }
 

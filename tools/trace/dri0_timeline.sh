@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -- python3 $GRAFT_REPO_ROOT/bench.py --workload 4k_dri0 --images 256 --steps 1 --warmup 1 --no-cpu-baseline > /tmp/pp.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -- python3 $GRAFT_REPO_ROOT/bench.py --workload 4k_dri0 --images ${IMAGES:-1024} --steps 1 --warmup 1 --no-ingest --no-cpu-baseline > /tmp/pp.log 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob("/tmp/pp/**/*kernel_trace.csv",recursive=True)[0]
