@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ingest", action="store_true", help="skip the ingest-inclusive (upload beside decode) measurement")
     ap.add_argument("--gen-threads", type=int, default=0)
+    ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (RCCL) even for a single rank: runs the barrier / "
+                                                         "MAX-reduce path of the multi-GPU launch on a one-GPU box")
     ap.add_argument("--distinct", type=int, default=0, help="experiments only: synthesise this many distinct images and repeat them "
                                                             "to fill the batch (default: every image of the batch is distinct)")
     args = ap.parse_args()
@@ -197,11 +199,14 @@ def main():
     import torch
 
     dist = None
-    if world > 1:
+    if world > 1 or args.dist:
         import torch.distributed as dist_
 
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:

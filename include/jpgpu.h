@@ -71,7 +71,13 @@ typedef enum jpgpu_format {
      * apps/JpegDecode/DecodeAction.cs:71-74, tests/JpegLibrary.Benchmarks/DecoderBenchmark.cs:67.  3-component frames;
      * 1-component frames are converted with Cb = Cr = 128 like DecodeAction.cs:57-65 does.  8-bit precision only. */
     JPGPU_FMT_RGB_U8 = 3,
-    JPGPU_FMT_RGBA_U8 = 4
+    JPGPU_FMT_RGBA_U8 = 4,
+    /* "O3": the sink of the reference's own decode tests, tests/JpegLibrary.Tests/Utils/JpegExtendingOutputWriter.cs:30-112
+     * constructed with componentCount = 4 as HuffmanSequentialDecodeTests.cs:23-43 does: uint16 out[(y*W+x)*4 + c],
+     * (ushort)sample clamped to 2^P - 1 (a negative sample becomes the maximum), the P bits spread over 16
+     * (FastExpandBits / ExpandBits :86-111), sub-sampled components replicated like WriteBlockSlow, clipped to W x H;
+     * channels >= the frame's component count stay zero.  What the golden PNG pairs of the reference hold. */
+    JPGPU_FMT_EXTENDED_U16 = 5
 } jpgpu_format;
 
 typedef struct jpgpu_ctx jpgpu_ctx;

@@ -5,7 +5,7 @@ There is no CPU fallback: creating a context without a GPU raises NoDeviceError.
 """
 from . import _capi  # noqa: F401  (loads libjpgpu.so, fails loudly when absent)
 from . import sharding  # noqa: F401
-from .batch import FMT_INTERLEAVED_U8, FMT_PLANAR_I16, FMT_PLANAR_U8, FMT_RGB_U8, FMT_RGBA_U8, Batch, decode_batch
+from .batch import FMT_EXTENDED_U16, FMT_INTERLEAVED_U8, FMT_PLANAR_I16, FMT_PLANAR_U8, FMT_RGB_U8, FMT_RGBA_U8, Batch, decode_batch
 from .context import Context, default_context, device_count
 from .encoder import EncodeBatch, encode_batch
 from .optimizer import JpegOptimizer, OptimizeBatch, build_optimal_huffman_table, optimize_batch
@@ -15,7 +15,7 @@ from .errors import (ArgumentException, DeviceError, InvalidDataException, Inval
 
 __all__ = [
     "Batch", "decode_batch", "EncodeBatch", "encode_batch", "JpegOptimizer", "OptimizeBatch", "optimize_batch", "build_optimal_huffman_table", "Context", "default_context", "device_count", "JpegDecoder", "JpegBlockOutputWriter",
-    "JpegBufferOutputWriter8Bit", "JpegExtendingOutputWriter", "FMT_INTERLEAVED_U8", "FMT_PLANAR_U8", "FMT_PLANAR_I16", "FMT_RGB_U8", "FMT_RGBA_U8",
+    "JpegBufferOutputWriter8Bit", "JpegExtendingOutputWriter", "FMT_INTERLEAVED_U8", "FMT_PLANAR_U8", "FMT_PLANAR_I16", "FMT_RGB_U8", "FMT_RGBA_U8", "FMT_EXTENDED_U16",
     "JpegError", "InvalidDataException", "InvalidOperationException", "NotSupportedException", "ArgumentException",
     "DeviceError", "NoDeviceError",
 ]

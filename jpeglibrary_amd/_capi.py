@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libjpgpu.so")
 
 OK, ERR_INVALID_DATA, ERR_INVALID_OPERATION, ERR_NOT_SUPPORTED, ERR_ARGUMENT, ERR_DEVICE, ERR_NO_DEVICE, ERR_OOM = range(8)
-FMT_INTERLEAVED_U8, FMT_PLANAR_U8, FMT_PLANAR_I16, FMT_RGB_U8, FMT_RGBA_U8 = 0, 1, 2, 3, 4
+FMT_INTERLEAVED_U8, FMT_PLANAR_U8, FMT_PLANAR_I16, FMT_RGB_U8, FMT_RGBA_U8, FMT_EXTENDED_U16 = 0, 1, 2, 3, 4, 5
 
 DETAIL_NAMES = {0: "NONE", 1: "INVALID_HUFFMAN_CODE", 2: "MARKER_IN_DATA", 3: "STREAM_ENDED", 4: "EXPECT_RESTART",
                 5: "MISSING_TABLE", 6: "UNSUPPORTED_FRAME", 7: "BAD_HEADER", 8: "EARLY_EOI", 9: "UNEXPECTED_END"}

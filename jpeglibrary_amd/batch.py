@@ -14,7 +14,7 @@ from .errors import raise_for_status
 
 _lib = _capi.lib
 FMT_INTERLEAVED_U8, FMT_PLANAR_U8, FMT_PLANAR_I16 = _capi.FMT_INTERLEAVED_U8, _capi.FMT_PLANAR_U8, _capi.FMT_PLANAR_I16
-FMT_RGB_U8, FMT_RGBA_U8 = _capi.FMT_RGB_U8, _capi.FMT_RGBA_U8
+FMT_RGB_U8, FMT_RGBA_U8, FMT_EXTENDED_U16 = _capi.FMT_RGB_U8, _capi.FMT_RGBA_U8, _capi.FMT_EXTENDED_U16
 
 
 class Batch:
@@ -121,7 +121,7 @@ class Batch:
         return p, total.value
 
     def output(self, i):
-        """Downloads image i. INTERLEAVED_U8 -> uint8[H,W,C]; RGB_U8 / RGBA_U8 -> uint8[H,W,3|4];
+        """Downloads image i. INTERLEAVED_U8 -> uint8[H,W,C]; RGB_U8 / RGBA_U8 -> uint8[H,W,3|4]; EXTENDED_U16 -> uint16[H,W,4];
         PLANAR_* -> list of per-component 2-D arrays (padded)."""
         info = self.image_info(i)
         raise_for_status(info.status, _lib.jpgpu_last_error(self.ctx._h))
@@ -131,6 +131,8 @@ class Batch:
             return raw.reshape(info.height, info.width, info.num_components)
         if self.format in (FMT_RGB_U8, FMT_RGBA_U8):
             return raw.reshape(info.height, info.width, 4 if self.format == FMT_RGBA_U8 else 3)
+        if self.format == FMT_EXTENDED_U16:  # the reference tests' JpegExtendingOutputWriter buffer: ushort x 4 per pixel
+            return raw.view(np.uint16).reshape(info.height, info.width, 4)
         dt = np.int16 if self.format == FMT_PLANAR_I16 else np.uint8
         planes = []
         for c in range(info.num_components):

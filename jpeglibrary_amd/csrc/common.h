@@ -39,7 +39,8 @@ struct DevScanComponent {
     uint8_t dc_slot, ac_slot; // index into DevScan::huff_pool (LDS slot)
 };
 
-enum OutputFormat : int32_t { kFmtInterleavedU8 = 0, kFmtPlanarU8 = 1, kFmtPlanarI16 = 2, kFmtRgbU8 = 3, kFmtRgbaU8 = 4 };
+enum OutputFormat : int32_t { kFmtInterleavedU8 = 0, kFmtPlanarU8 = 1, kFmtPlanarI16 = 2, kFmtRgbU8 = 3, kFmtRgbaU8 = 4, kFmtExtendedU16 = 5 };
+constexpr int kNumOutputFormats = 6;
 constexpr bool fmt_is_interleaved(int f) { return f == kFmtInterleavedU8 || f == kFmtRgbU8 || f == kFmtRgbaU8; }
 constexpr int fmt_bytes_per_pixel_rgb(int f) { return f == kFmtRgbaU8 ? 4 : 3; }
 

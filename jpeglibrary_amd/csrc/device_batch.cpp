@@ -46,7 +46,7 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_prog_sync_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_prog_sync_, &d_planes_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
@@ -190,7 +190,8 @@ void DeviceBatch::plan_image_geometry(ImagePlan &img, const BaselineGeometry &ge
     } else {
         if (fh.num_components > 4)  // jpgpu_plane_info describes four planes; a fifth component would land on plane 0
             throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "The planar output formats describe at most 4 components.", kDetailUnsupportedFrame);
-        const uint64_t sample_bytes = format_ == JPGPU_FMT_PLANAR_I16 ? 2 : 1;
+        // EXTENDED_U16 is produced from int16 planes (K3's PLANAR_I16 output in a scratch buffer, see run_idct)
+        const uint64_t sample_bytes = (format_ == JPGPU_FMT_PLANAR_I16 || format_ == JPGPU_FMT_EXTENDED_U16) ? 2 : 1;
         uint64_t off = 0;
         for (int c = 0; c < fh.num_components && c < 4; c++) {
             jpgpu_plane_info &p = img.plane[c];
@@ -201,6 +202,10 @@ void DeviceBatch::plan_image_geometry(ImagePlan &img, const BaselineGeometry &ge
             off = align_up(off + (uint64_t)p.pitch * p.height * sample_bytes, 256);
         }
         img.out_bytes = off;
+        if (format_ == JPGPU_FMT_EXTENDED_U16) {
+            img.planes_bytes = off;
+            img.out_bytes = (uint64_t)img.width * img.height * 4 * sizeof(uint16_t);
+        }
     }
 }
 
@@ -441,7 +446,7 @@ static int default_host_threads() {
 
 int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int n, int format) {
     if (n < 0 || (n > 0 && (!jpeg || !len))) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: null argument");
-    if (format < 0 || format > 4) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: unknown format");
+    if (format < 0 || format >= kNumOutputFormats) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: unknown format");
     using clk = std::chrono::steady_clock;
     auto ms_since = [](clk::time_point t0) { return (float)std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     const clk::time_point t_begin = clk::now();
@@ -690,7 +695,7 @@ int DeviceBatch::verify_plans(const std::vector<FilePlan> &plans, const std::vec
 }
 
 int DeviceBatch::upload_single_job(const ScanJob &job, int format, const void *initial_output, size_t initial_output_bytes) {
-    if (format < 0 || format > 4) return fail(JPGPU_ERR_ARGUMENT, "unknown format");
+    if (format < 0 || format >= kNumOutputFormats) return fail(JPGPU_ERR_ARGUMENT, "unknown format");
     format_ = format;
     images_.assign(1, ImagePlan());
     jobs_.assign(1, job);
@@ -719,7 +724,7 @@ int DeviceBatch::upload_single_job(const ScanJob &job, int format, const void *i
 }
 
 int DeviceBatch::upload_progressive_frame(const ProgressiveFrame &frame, const uint8_t *file, size_t file_len, int sof, int format) {
-    if (format < 0 || format > 4) return fail(JPGPU_ERR_ARGUMENT, "unknown format");
+    if (format < 0 || format >= kNumOutputFormats) return fail(JPGPU_ERR_ARGUMENT, "unknown format");
     format_ = format;
     images_.assign(1, ImagePlan());
     jobs_.clear();
@@ -744,7 +749,7 @@ int DeviceBatch::upload_progressive_frame(const ProgressiveFrame &frame, const u
 
 int DeviceBatch::upload_frames(const jpgpu_frame *frames, const uint16_t *qt, int n, int format) {
     if (n < 0 || (n > 0 && (!frames || !qt))) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_frames: null argument");
-    if (format < 0 || format > 4) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_frames: unknown format");
+    if (format < 0 || format >= kNumOutputFormats) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_frames: unknown format");
     format_ = format;
     images_.assign((size_t)n, ImagePlan());
     jobs_.clear();
@@ -850,7 +855,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     std::vector<IdctWork> idct_work;
     std::vector<IdctWork> idct_work_by_class[kNumIdctLayoutClasses];
     const bool tile_align = !(getenv("JPGPU_TILE_ALIGN") && atoi(getenv("JPGPU_TILE_ALIGN")) == 0);  // A/B switch, default on
-    uint64_t out_off = 0, coef_off = 0;
+    uint64_t out_off = 0, coef_off = 0, planes_off = 0;
     uint32_t ends_off = 0;
     compressed_bytes_ = 0;
     total_pixels_ = 0;
@@ -890,10 +895,12 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     for (size_t ii = 0; ii < images_.size(); ii++) {
         ImagePlan &img = images_[ii];
         img.out_offset = out_off;
+        img.planes_offset = planes_off;
         img.coef_offset = coef_off;
         img.total_blocks = 0;
         if (img.status != JPGPU_OK) continue;
         out_off = align_up(out_off + img.out_bytes, 256);
+        planes_off = align_up(planes_off + img.planes_bytes, 256);
         if (!img.jobs.empty()) total_pixels_ += (uint64_t)img.width * img.height;
         for (int j : img.jobs) {
             const ScanJob &job = jobs_[j];
@@ -911,7 +918,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             }
             // progressive entropy scans accumulate into their frame's store (the frame job precedes them)
             s.coef_off = job.kind == kScanProgressive ? h_scans_[img.jobs[0]].coef_off : coef_off;
-            s.out_off = img.out_offset;
+            s.out_off = format_ == JPGPU_FMT_EXTENDED_U16 ? img.planes_offset : img.out_offset;
             s.dri = job.kind == kScanProgressive ? job.scan_dri : g.restart_interval;
             s.mcus_per_line = (uint32_t)g.mcus_per_line;
             s.mcus_per_column = (uint32_t)g.mcus_per_column;
@@ -1024,7 +1031,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 if (format_ == JPGPU_FMT_INTERLEAVED_U8) row_bytes *= s.frame_components;
                 else if (format_ == JPGPU_FMT_RGB_U8) row_bytes *= 3;
                 else if (format_ == JPGPU_FMT_RGBA_U8) row_bytes *= 4;
-                else if (format_ == JPGPU_FMT_PLANAR_I16) row_bytes *= 2;
+                else if (format_ == JPGPU_FMT_PLANAR_I16 || format_ == JPGPU_FMT_EXTENDED_U16) row_bytes *= 2;
                 for (uint32_t t = mcus_per_wg; t * 4 >= mcus_per_wg * 3 && t > 0; t--)
                     if ((t * row_bytes) % 128 == 0) {
                         mcus_per_wg = t;
@@ -1045,6 +1052,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     }
     total_blocks_ = coef_off;
     out_bytes_ = out_off;
+    planes_bytes_ = planes_off;
     total_ends_ = ends_off;
     n_huff_work_ = (int)huff_work.size();
     n_chunk_work_ = (int)chunk_work.size();
@@ -1076,7 +1084,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         }
         bool all = true;
         for (int c = 0; c < img.num_components; c++) all &= ((covered[c >> 6] >> (c & 63)) & 1ull) != 0;
-        if (!all) out_clear_.push_back({img.out_offset, img.out_bytes});
+        if (!all) out_clear_.push_back({img.out_offset, img.out_bytes, img.planes_offset, img.planes_bytes});
         // RGB / RGBA = the callers' converter applied to the YCbCr8 buffer (DecodeAction.cs:71-74): an image without any scan
         // leaves that buffer as it was (zero here), and the converter still runs over it
         if (img.jobs.empty() && (format_ == JPGPU_FMT_RGB_U8 || format_ == JPGPU_FMT_RGBA_U8))
@@ -1113,7 +1121,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         while (huff_split_ < n_huff_work_ && h_scans_[huff_work[huff_split_].scan].image_index < split_image) huff_split_++;
         // worth it for batches that keep the machine busy for milliseconds: the split costs four launches and two events
         if (wanted && !entropy_only_ && sub_work.empty() && prog_work.empty() && total_blocks_ >= (4u << 20) && huff_split_ > 0 &&
-            huff_split_ < n_huff_work_ && rgb_convert_.empty()) {
+            huff_split_ < n_huff_work_ && rgb_convert_.empty() && format_ != JPGPU_FMT_EXTENDED_U16) {
             for (int half = 0; half < 2; half++) {
                 idct_split_begin_[half][0] = (int)idct_work_split.size();
                 for (int c = 0; c < kNumIdctLayoutClasses; c++) {
@@ -1176,6 +1184,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_coefs_, nullptr, 0, entropy_only_ ? 256 : (size_t)total_blocks_ * 128 + (size_t)kIdctBlocksPerWg * 128 + 256},  // + one tile of slack (IDCT DMA reads whole tiles)
         {&d_out_, nullptr, 0, entropy_only_ ? 256 : (size_t)out_bytes_ + 256},
         {&d_rgb_scratch_, nullptr, 0, rgb_convert_.empty() ? 0 : (size_t)out_bytes_ + 256},
+        {&d_planes_, nullptr, 0, format_ == JPGPU_FMT_EXTENDED_U16 && !entropy_only_ ? (size_t)planes_bytes_ + 256 : 0},
         {&d_input_, nullptr, 0, (size_t)input_bytes_},
     };
     for (const Up &u : ups) {
@@ -1300,6 +1309,8 @@ int DeviceBatch::run_progressive() {
 int DeviceBatch::clear_partial_outputs() {
     for (const auto &c : out_clear_) {
         hipError_t e = hipMemsetAsync((uint8_t *)d_out_.ptr + c.first, 0, c.second, ctx_->stream);
+        if (e == hipSuccess && format_ == JPGPU_FMT_EXTENDED_U16 && c.planes_bytes)
+            e = hipMemsetAsync((uint8_t *)d_planes_.ptr + c.planes_first, 0, c.planes_bytes, ctx_->stream);
         if (e == hipSuccess && d_rgb_scratch_.ptr && c.first + c.second <= d_rgb_scratch_.cap)
             e = hipMemsetAsync((uint8_t *)d_rgb_scratch_.ptr + c.first, 0, c.second, ctx_->stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(output)");
@@ -1311,10 +1322,31 @@ int DeviceBatch::run_idct() {
     const YccRgbFactors kf = ycc_rgb_factors();
     int rc0 = clear_partial_outputs();
     if (rc0 != JPGPU_OK) return rc0;
+    const bool extended = format_ == JPGPU_FMT_EXTENDED_U16;
     hipError_t e = launch_idct(ctx_->stream, (const int16_t *)d_coefs_.ptr, (const DevScan *)d_scans_.ptr, (const IdctWork *)d_idct_work_.ptr,
                                idct_class_begin_, (const DevScanStatus *)d_status_.ptr, (const DevQuantTable *)d_quant_pool_.ptr,
-                               (uint8_t *)d_out_.ptr, format_, kf, (uint8_t *)d_rgb_scratch_.ptr);
+                               extended ? (uint8_t *)d_planes_.ptr : (uint8_t *)d_out_.ptr, extended ? (int)JPGPU_FMT_PLANAR_I16 : format_, kf,
+                               (uint8_t *)d_rgb_scratch_.ptr);
     if (e != hipSuccess) return hip_fail(e, "idct_output_kernel");
+    if (extended) {
+        // "O3": the int16 planes (WriteBlock's arguments) through the test writer's clamp + bit expansion, one pass per image
+        for (const ImagePlan &img : images_) {
+            if (img.status != JPGPU_OK || img.jobs.empty() || img.out_bytes == 0) continue;
+            uint64_t off[4] = {0, 0, 0, 0};
+            uint32_t pitch[4] = {1, 1, 1, 1}, hsh[4] = {0, 0, 0, 0}, vsh[4] = {0, 0, 0, 0};
+            const BaselineGeometry &g = jobs_[img.jobs[0]].geo;
+            for (int c = 0; c < img.num_components && c < 4; c++) {
+                off[c] = img.planes_offset + img.plane[c].offset;
+                pitch[c] = img.plane[c].pitch;
+                const int hs = g.max_h / std::max<int>(1, g.frame.components[c].h), vs = g.max_v / std::max<int>(1, g.frame.components[c].v);
+                while ((1 << (hsh[c] + 1)) <= hs) hsh[c]++;
+                while ((1 << (vsh[c] + 1)) <= vs) vsh[c]++;
+            }
+            e = launch_extend_u16(ctx_->stream, (const uint8_t *)d_planes_.ptr, (uint16_t *)((uint8_t *)d_out_.ptr + img.out_offset), off, pitch, hsh, vsh,
+                                  img.width, img.height, img.num_components, img.precision);
+            if (e != hipSuccess) return hip_fail(e, "extend_u16_kernel");
+        }
+    }
     for (const RgbConvert &rc : rgb_convert_) {
         e = launch_ycc_to_rgb(ctx_->stream, (const uint8_t *)d_rgb_scratch_.ptr + rc.out_offset, (uint8_t *)d_out_.ptr + rc.out_offset, rc.pixels,
                               rc.components, format_ == JPGPU_FMT_RGBA_U8 ? 4 : 3, kf);

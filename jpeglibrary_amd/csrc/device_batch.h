@@ -71,6 +71,7 @@ struct ImagePlan {
     uint32_t mcus_per_line = 0, mcus_per_column = 0, blocks_per_mcu = 0;
     uint64_t total_blocks = 0;
     uint64_t out_offset = 0, out_bytes = 0;
+    uint64_t planes_offset = 0, planes_bytes = 0;  // EXTENDED_U16: the int16 planes K3 writes, in DeviceBatch::d_planes_
     uint64_t coef_offset = 0;
     jpgpu_plane_info plane[4] = {};
     std::vector<int> jobs;     // indices into DeviceBatch::jobs_
@@ -150,7 +151,11 @@ class DeviceBatch {
     int fetch_status();
     int clear_partial_outputs();
     bool keep_canvas_ = false;  // layout of a single scan job over the caller's samples: nothing the scan does not write is touched
-    std::vector<std::pair<uint64_t, uint64_t>> out_clear_;  // (offset, bytes) of images whose scans leave frame components unwritten
+    struct OutClear {
+        uint64_t first, second;              // (offset, bytes) in the output buffer
+        uint64_t planes_first, planes_bytes; // EXTENDED_U16: the image's int16 planes
+    };
+    std::vector<OutClear> out_clear_;  // images whose scans leave frame components unwritten
 
     jpgpu_ctx *ctx_;
     int format_ = JPGPU_FMT_INTERLEAVED_U8;
@@ -166,7 +171,8 @@ class DeviceBatch {
     int n_huff_slots_ = 1;
     int n_huff_work_ = 0, n_idct_work_ = 0;
     int idct_class_begin_[kNumIdctLayoutClasses + 1] = {};
-    uint64_t total_blocks_ = 0, out_bytes_ = 0, input_bytes_ = 0, compressed_bytes_ = 0, total_pixels_ = 0;
+    uint64_t total_blocks_ = 0, out_bytes_ = 0, planes_bytes_ = 0, input_bytes_ = 0, compressed_bytes_ = 0, total_pixels_ = 0;
+    DevBuffer d_planes_;  // EXTENDED_U16: K3's PLANAR_I16 output, converted by extend_u16_kernel
     uint32_t total_ends_ = 0;
 
     // DRI = 0 scans: self-synchronising subsequence decode (K2S)

@@ -2786,6 +2786,49 @@ __global__ __launch_bounds__(256) void ycc_to_rgb_kernel(const uint8_t *__restri
     }
 }
 
+// "O3", the xunit tests' sink (ref: tests/JpegLibrary.Tests/Utils/JpegExtendingOutputWriter.cs:30-112) as a device format:
+// out[(y * W + x) * 4 + c] (componentCount = 4, the way every test constructs it), uint16.  Input: the PLANAR_I16 planes K3
+// wrote = WriteBlock's arguments before chroma expansion.  WriteBlockSlow replicates with shifts (:238-268), so pixel (x, y)
+// of component c is plane_c[y >> vshift][x >> hshift]; the writer then takes (ushort)sample -- a negative sample becomes a
+// large value -- clamps to 2^P - 1 and spreads the P bits over 16 (FastExpandBits for P >= 8, ExpandBits below).
+struct ExtendPlanes {
+    uint64_t plane_off[4];  // byte offsets of the int16 planes in `planes`
+    uint32_t pitch[4];      // samples
+    uint32_t hshift[4], vshift[4];
+    uint32_t width, height, ncomp, precision;
+};
+__global__ __launch_bounds__(256) void extend_u16_kernel(const uint8_t *__restrict__ planes, uint16_t *__restrict__ out, ExtendPlanes g) {
+    const uint64_t px = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (px >= (uint64_t)g.width * g.height) return;
+    const uint32_t y = (uint32_t)(px / g.width), x = (uint32_t)(px - (uint64_t)y * g.width);
+    const uint32_t p = g.precision, mx = (1u << p) - 1u;
+    uint16_t v4[4] = {0, 0, 0, 0};
+    for (uint32_t c = 0; c < g.ncomp && c < 4u; c++) {
+        const int16_t *pl = reinterpret_cast<const int16_t *>(planes + g.plane_off[c]);
+        const uint32_t s = (uint32_t)(uint16_t)pl[(uint64_t)(y >> g.vshift[c]) * g.pitch[c] + (x >> g.hshift[c])];
+        uint32_t bits = s < mx ? s : mx;  // Clamp((ushort)sample, max)
+        if (p >= 8u) {
+            const uint32_t rem = 16u - p;
+            bits = (bits << rem) | (bits & ((1u << rem) - 1u));  // FastExpandBits, as written
+        } else {
+            uint32_t cur = p;
+            while (cur < 16u) {
+                bits = (bits << p) | bits;
+                cur += p;
+            }
+            if (cur > 16u) {
+                bits >>= p;
+                cur -= p;
+                const uint32_t rem = 16u - cur;
+                bits = (bits << rem) | (bits & ((1u << rem) - 1u));
+            }
+        }
+        v4[c] = (uint16_t)bits;
+    }
+    // channels the frame does not have keep what the caller's (fresh, zeroed) buffer held: the batch owns the buffer, so zero
+    *reinterpret_cast<uint2 *>(out + px * 4) = uint2{(uint32_t)v4[0] | ((uint32_t)v4[1] << 16), (uint32_t)v4[2] | ((uint32_t)v4[3] << 16)};
+}
+
 // Output assembly of the INTERLEAVED_U8 format from the LDS sample tile [8 rows][256 blocks][8 B] (phase C).
 // CONV: 0 = the samples as they are (Y,Cb,Cr), 3 / 4 = converted to R,G,B / R,G,B,A bytes (fast layouts only).
 template <int LAY, int CONV>
@@ -3069,6 +3112,25 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
+
+hipError_t launch_extend_u16(hipStream_t stream, const uint8_t *planes, uint16_t *out, const uint64_t plane_off[4], const uint32_t pitch[4],
+                             const uint32_t hshift[4], const uint32_t vshift[4], uint32_t width, uint32_t height, uint32_t ncomp, uint32_t precision) {
+    ExtendPlanes g;
+    for (int c = 0; c < 4; c++) {
+        g.plane_off[c] = plane_off[c];
+        g.pitch[c] = pitch[c];
+        g.hshift[c] = hshift[c];
+        g.vshift[c] = vshift[c];
+    }
+    g.width = width;
+    g.height = height;
+    g.ncomp = ncomp;
+    g.precision = precision;
+    const uint64_t n = (uint64_t)width * height;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(extend_u16_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, planes, out, g);
+    return hipGetLastError();
+}
 
 hipError_t launch_first_marker(hipStream_t stream, const uint8_t *data, const void *segs, const uint32_t *seg_hi, int n_segs,
                                uint32_t max_len, uint32_t *first) {

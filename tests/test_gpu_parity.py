@@ -32,6 +32,29 @@ def test_decode_matches_reference_golden(name):
     assert np.array_equal(reference.reshape(-1), buffer)
 
 
+def test_extended_u16_device_format_matches_the_reference_goldens():
+    """JPGPU_FMT_EXTENDED_U16 = the buffer of the reference tests' JpegExtendingOutputWriter (componentCount 4), produced on
+    the device: all five golden assets in ONE batch, one download each, compared with the reference's own PNG dumps --
+    and with the WriteBlock-callback path of the decoder mirror on a 4:2:2 and a clipped 12-bit-like case."""
+    names = ["cramps.jpg", "lake.jpg", "testorig12.jpg", "progress.jpg", "yellowcat_progressive_restart.jpg"]
+    files = [read_jpeg(n) for n in names]
+    b = jl.Batch().upload(files, jl.FMT_EXTENDED_U16).decode().sync()
+    for i, n in enumerate(names):
+        assert b.result(i).status == 0, n
+        info = b.image_info(i)
+        reference = load_reference_buffer(n, info.width, info.height, info.num_components)
+        assert np.array_equal(b.output(i), reference), n
+    b.close()
+    # synthetic cases against the oracle's own 16-bit sink (samples outside [0, 2^P - 1] included: Q30 overshoots)
+    extra = [jpegsynth.encode(331, 177, "422", 30, 3, seed=7), jpegsynth.encode(100, 75, "gray", 60, 1, seed=8),
+             jpegsynth.encode(96, 64, "444", 75, 0, seed=5, noninterleaved=True), jpegsynth.encode(17, 9, "420", 20, 1, seed=9)]
+    b = jl.Batch().upload(extra, jl.FMT_EXTENDED_U16).decode().sync()
+    for i, f in enumerate(extra):
+        assert b.result(i).status == 0
+        assert np.array_equal(b.output(i), po.decode_16bit(bytes(f), component_count=4)[0]), i
+    b.close()
+
+
 @pytest.mark.parametrize("name", ["cramps.jpg", "lake.jpg", "HETissueSlide.jpg", "progress.jpg", "yellowcat_progressive_restart.jpg"])
 def test_buffer8_writer_matches_oracle(name):
     """The app writer (JpegBufferOutputWriter8Bit) fast path: interleaved u8 produced on the GPU."""

@@ -240,3 +240,23 @@ def test_overlapped_issue_order_gives_the_serial_result(monkeypatch):
         bb.close()
     assert res[0] == res[1]
     assert res[0][3][0] != 0 and res[0][n - 2][0] != 0 and res[0][0][0] == 0
+
+
+def test_bench_runs_its_rccl_path_under_torchrun_with_one_rank():
+    """The driver launches bench.py under torch.distributed.run with one rank per GPU; with one GPU in the box the same
+    launcher, one rank, and --dist make bench.py create the RCCL process group and go through its barrier and its
+    MAX-reduce of the elapsed time (device tensor), the code the N > 1 runs depend on."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "bench.py"), "--gpus", "1", "--dist", "--workload", "1080p_q90", "--images", "8", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-ingest"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["parity_spot_check"] == "bit-exact vs oracle"
