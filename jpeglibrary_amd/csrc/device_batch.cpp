@@ -856,7 +856,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     std::vector<IdctWork> idct_work_by_class[kNumIdctLayoutClasses];
     const bool tile_align = !(getenv("JPGPU_TILE_ALIGN") && atoi(getenv("JPGPU_TILE_ALIGN")) == 0);  // A/B switch, default on
     uint64_t out_off = 0, coef_off = 0, planes_off = 0;
-    uint32_t ends_off = 0;
+    uint32_t ends_off = 0, total_chunks = 0;
     compressed_bytes_ = 0;
     total_pixels_ = 0;
     n_huff_slots_ = 1;
@@ -938,11 +938,12 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             }
             s.ends_off = ends_off;
             ends_off += s.n_intervals;
-            s.chunk_off = (uint32_t)chunk_work.size();
+            s.chunk_off = total_chunks;
             s.n_chunks = (uint32_t)(((uint64_t)s.data_len + (s.data_off & 15u) + kMarkerChunkBytes - 1) / kMarkerChunkBytes);
             if (s.n_chunks == 0) s.n_chunks = 1;
             if (job.kind == kScanFrameOnly) s.n_chunks = 0;  // no entropy data: K1 / K2 skip the job
-            for (uint32_t c = 0; c < s.n_chunks; c++) chunk_work.push_back({(uint32_t)j, c});
+            for (uint32_t c = 0; c < s.n_chunks; c += kMarkerChunksPerWg) chunk_work.push_back({(uint32_t)j, c});
+            total_chunks += s.n_chunks;
             s.image_index = (uint32_t)ii;
             s.level_shift = (uint32_t)g.level_shift;
             s.width = g.frame.samples_per_line;
@@ -1175,7 +1176,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_sub_dcentry_, nullptr, 0, (size_t)total_subs_ * 16 + 256},
         {&d_sub_changed_, nullptr, 0, 64 * sizeof(uint32_t)},
         {&d_lut_pool_, nullptr, 0, huff_pool_.size() * kLutPoolBytesPerTable},
-        {&d_chunk_sums_, nullptr, 0, chunk_work.size() * sizeof(ChunkSum) + 256},
+        {&d_chunk_sums_, nullptr, 0, (size_t)total_chunks * sizeof(ChunkSum) + 256},
         {&d_idct_work_, idct_work.data(), idct_work.size() * sizeof(IdctWork), 0},
         {&d_idct_work_split_, idct_work_split.data(), idct_work_split.size() * sizeof(IdctWork), 0},
         {&d_ends_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},

@@ -159,29 +159,33 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 // K1a: per-chunk summary (RST markers, bytes udata will receive, first terminating marker).
 __global__ __launch_bounds__(kScanThreads) void marker_count_kernel(const uint8_t *__restrict__ data, const DevScan *__restrict__ scans,
                                                                      const ChunkWork *__restrict__ work, ChunkSum *__restrict__ sums) {
-    const ChunkWork wk = work[blockIdx.x];
-    const DevScan &s = scans[wk.scan];
+    const ChunkWork wk0 = work[blockIdx.x];
+    const DevScan &s = scans[wk0.scan];
     const uint8_t *p = data + s.data_off;
     const int32_t misalign = (int32_t)(s.data_off & 15u);
-    const int64_t off = -(int64_t)misalign + (int64_t)wk.chunk * kChunkBytes + (int64_t)threadIdx.x * 16;
-    const ByteClass c = classify16(p, off, s.data_len, s.dri == 0);
     __shared__ uint32_t sh_a[kScanThreads / 64], sh_b[kScanThreads / 64];
     __shared__ uint32_t sh_term;
-    if (threadIdx.x == 0) sh_term = kInf;
-    uint32_t rst_total, keep_total;
-    block_exclusive_scan(__builtin_popcount(c.rst), sh_a, rst_total);
-    block_exclusive_scan(__builtin_popcount(c.keep) + __builtin_popcount(c.rst | c.term), sh_b, keep_total);
-    uint32_t tpos = c.term ? (uint32_t)(off + __builtin_ctz(c.term)) : kInf;
-    tpos = wave_reduce_min(tpos);
-    if (lane_id() == 0 && tpos != kInf) atomicMin(&sh_term, tpos);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        ChunkSum cs;
-        cs.rst_cnt = rst_total;
-        cs.keep_cnt = keep_total;
-        cs.first_term = sh_term;
-        cs.pad = 0;
-        sums[s.chunk_off + wk.chunk] = cs;
+    // kMarkerChunksPerWg consecutive chunks per workgroup (1: see kernels.h)
+    for (uint32_t chunk = wk0.chunk; chunk < wk0.chunk + kMarkerChunksPerWg && chunk < s.n_chunks; chunk++) {
+        const int64_t off = -(int64_t)misalign + (int64_t)chunk * kChunkBytes + (int64_t)threadIdx.x * 16;
+        const ByteClass c = classify16(p, off, s.data_len, s.dri == 0);
+        __syncthreads();  // sh_term of the previous chunk has been read
+        if (threadIdx.x == 0) sh_term = kInf;
+        uint32_t rst_total, keep_total;
+        block_exclusive_scan(__builtin_popcount(c.rst), sh_a, rst_total);
+        block_exclusive_scan(__builtin_popcount(c.keep) + __builtin_popcount(c.rst | c.term), sh_b, keep_total);
+        uint32_t tpos = c.term ? (uint32_t)(off + __builtin_ctz(c.term)) : kInf;
+        tpos = wave_reduce_min(tpos);
+        if (lane_id() == 0 && tpos != kInf) atomicMin(&sh_term, tpos);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ChunkSum cs;
+            cs.rst_cnt = rst_total;
+            cs.keep_cnt = keep_total;
+            cs.first_term = sh_term;
+            cs.pad = 0;
+            sums[s.chunk_off + chunk] = cs;
+        }
     }
 }
 
@@ -240,12 +244,13 @@ __global__ __launch_bounds__(kScanThreads) void marker_prefix_kernel(const DevSc
 
 // K1b: every chunk takes its position in the scan from K1p and writes its part of ends[] / ends_u[] / udata; the chunk
 // that holds the closing entry also writes the scan status.
-__global__ __launch_bounds__(kScanThreads) void marker_write_kernel(const uint8_t *__restrict__ data, const DevScan *__restrict__ scans,
-                                                                     const ChunkWork *__restrict__ work, const ChunkSum *__restrict__ sums,
-                                                                     uint32_t *__restrict__ ends, DevScanStatus *__restrict__ status,
-                                                                     uint8_t *__restrict__ udata, uint32_t *__restrict__ ends_u) {
-    const ChunkWork wk = work[blockIdx.x];
-    const DevScan &s = scans[wk.scan];
+struct ChunkRef {
+    uint32_t scan, chunk;
+};
+__device__ __forceinline__ void marker_write_chunk(const uint8_t *__restrict__ data, const DevScan &s, const ChunkRef wk,
+                                                   const ChunkSum *__restrict__ sums, uint32_t *__restrict__ ends,
+                                                   DevScanStatus *__restrict__ status, uint8_t *__restrict__ udata,
+                                                   uint32_t *__restrict__ ends_u) {
     const uint8_t *p = data + s.data_off;
     uint8_t *up = udata + s.data_off;
     const uint32_t len = s.data_len;
@@ -380,6 +385,19 @@ __global__ __launch_bounds__(kScanThreads) void marker_write_kernel(const uint8_
         st.pad[0] = ubase + keep_total;
         st.pad[1] = st.pad[2] = 0;
         status[wk.scan] = st;
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void marker_write_kernel(const uint8_t *__restrict__ data, const DevScan *__restrict__ scans,
+                                                                     const ChunkWork *__restrict__ work, const ChunkSum *__restrict__ sums,
+                                                                     uint32_t *__restrict__ ends, DevScanStatus *__restrict__ status,
+                                                                     uint8_t *__restrict__ udata, uint32_t *__restrict__ ends_u) {
+    const ChunkWork wk0 = work[blockIdx.x];
+    const DevScan &s = scans[wk0.scan];
+    // kMarkerChunksPerWg consecutive chunks per workgroup (see marker_count_kernel)
+    for (uint32_t chunk = wk0.chunk; chunk < wk0.chunk + kMarkerChunksPerWg && chunk < s.n_chunks; chunk++) {
+        __syncthreads();  // the shared tile / scan scratch of the previous chunk is free
+        marker_write_chunk(data, s, ChunkRef{wk0.scan, chunk}, sums, ends, status, udata, ends_u);
     }
 }
 
