@@ -47,7 +47,7 @@ for k, d in agg.items():
     if "idct_output_kernel" in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d and images:
         fetch_kb = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
         write_kb = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
-        entry = {"kernel": k.split("jpgpu::")[-1], "hbm_bytes_per_image": int((2 * fetch_kb + write_kb) * 1000 / images),
+        entry = {"kernel": k.split("jpgpu::")[-1], "hbm_bytes_per_image": int((2 * fetch_kb + write_kb) * 1024 / images),
                  "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb, "images_in_profiled_launch": images,
                  "library_sha256": sha,
                  "correction": "gfx950: FETCH_SIZE counts wide coalesced reads (incl. global_load_lds_dwordx4) at 1/2 -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact for 16-B/lane stores",
