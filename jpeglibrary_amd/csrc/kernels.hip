@@ -2469,7 +2469,12 @@ __global__ __launch_bounds__(64 * kSubFinalWaves) void subseq_final_kernel(const
     K2Feed feed;
     K2Pos pos;
     int32_t endpos = 0;
-    (void)k2_open_at_bit(udata + s.data_off, start_bit < total_bits ? start_bit : 0u, total_bits, ring, feed, pos, &endpos);
+    // A lane that owns blocks but starts behind the data (the stream ran out at a symbol boundary in an earlier subsequence)
+    // decodes them the way the reference does: from the all-ones padding, i.e. with no data bits at all (its loads still
+    // have to stay inside the buffer: it opens the stream at bit 0 and sees it as empty).
+    const bool behind_data = start_bit >= total_bits;
+    const int32_t pm1_0 = k2_open_at_bit(udata + s.data_off, behind_data ? 0u : start_bit, total_bits, ring, feed, pos, &endpos);
+    if (behind_data) endpos = pm1_0 + 1;
     int32_t lim = k2_limit(endpos, feed.wr);
     uint32_t err = 0;
     int32_t pred0 = 0, pred1 = 0, pred2 = 0, pred3 = 0;
