@@ -46,7 +46,7 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_sub_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_prog_sync_, &d_planes_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_sub_work_, &d_sub_final_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_prog_sync_, &d_planes_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
@@ -1058,6 +1058,10 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     n_huff_work_ = (int)huff_work.size();
     n_chunk_work_ = (int)chunk_work.size();
     n_sub_work_ = (int)sub_work.size();
+    std::vector<HuffWork> sub_final_work;  // the final pass takes larger workgroups than the rounds (kernels.h: subseq_final_waves)
+    for (uint32_t j : sub_scan_ids_)
+        for (uint32_t first = 0; first < h_scans_[j].n_subs; first += 64u * (uint32_t)subseq_final_waves(n_huff_slots_)) sub_final_work.push_back({j, first});
+    n_sub_final_work_ = (int)sub_final_work.size();
     n_sub_scans_ = (int)sub_scan_ids_.size();
     std::vector<HuffWork> prog_work;
     prog_begin_.assign(1, 0);
@@ -1164,6 +1168,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_huff_work_, huff_work.data(), huff_work.size() * sizeof(HuffWork), 0},
         {&d_chunk_work_, chunk_work.data(), chunk_work.size() * sizeof(ChunkWork), 0},
         {&d_sub_work_, sub_work.data(), sub_work.size() * sizeof(HuffWork), 0},
+        {&d_sub_final_work_, sub_final_work.data(), sub_final_work.size() * sizeof(HuffWork), 0},
         {&d_prog_work_, prog_work.data(), prog_work.size() * sizeof(HuffWork), 0},
         {&d_prog_sync_, nullptr, 0, (size_t)(prog_work.empty() ? 0 : 256)},
         {&d_sub_scan_ids_, sub_scan_ids_.data(), sub_scan_ids_.size() * sizeof(uint32_t), 0},
@@ -1243,7 +1248,7 @@ int DeviceBatch::run_huffman() {
                                  (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (uint32_t *)d_sub_exit_a_.ptr,
                                  (uint32_t *)d_sub_exit_b_.ptr, (uint32_t *)d_sub_nblk_.ptr, (uint32_t *)d_sub_first_.ptr,
                                  (uint32_t *)d_sub_entry_.ptr, d_sub_dcsum_.ptr, d_sub_dcentry_.ptr, (uint32_t *)d_sub_changed_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (int)max_subs_per_scan_ + 2,
-                                 &last_subseq_rounds_, (const uint32_t *)d_lut_pool_.ptr);
+                                 &last_subseq_rounds_, (const uint32_t *)d_lut_pool_.ptr, (const HuffWork *)d_sub_final_work_.ptr, n_sub_final_work_);
         if (e != hipSuccess) return hip_fail(e, "subsequence decode");
     }
     return run_progressive();

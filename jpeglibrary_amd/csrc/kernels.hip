@@ -2399,11 +2399,11 @@ __global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__rest
 // their MCUs: block j of every lane is decoded into the wave's LDS staging in lock-step and flushed as whole 128-byte
 // lines; the coefficient buffer needs no clearing.  The DC predictor chain starts from the prefix sums of
 // subseq_scan_kernel.  (First version: the generic word reader and symbol decoder, 11.0 ms per 1024 x 4K against K2's 5.7.)
-constexpr int kSubFinalWaves = 4;
+constexpr int kSubFinalMaxWaves = 4;  // the launch picks subseq_final_waves(n_slots)
 constexpr int kSfLB = 10;
 constexpr uint32_t kSfTabBytes = (4u << kSfLB) + kK2SmallBytes;
 constexpr int kSfWaveBytes = kK2WaveBytes + 64 * 2 * (int)sizeof(uint32_t);  // K2's staging + rings, then (first block, count) per lane
-__global__ __launch_bounds__(64 * kSubFinalWaves) void subseq_final_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+__global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
                                                                            const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
                                                                            DevScanStatus *__restrict__ status,
                                                                            const DevHuffTable *__restrict__ huff_pool,
@@ -2413,14 +2413,15 @@ __global__ __launch_bounds__(64 * kSubFinalWaves) void subseq_final_kernel(const
                                                                            const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs,
                                                                            int n_slots) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t n_waves = blockDim.x >> 6;
     uint8_t *tabs = smem;                                                    // n_slots * kSfTabBytes
-    uint8_t *wave_all = smem + (size_t)n_slots * kSfTabBytes;                // kSubFinalWaves * kSfWaveBytes
-    uint32_t *blk_info = reinterpret_cast<uint32_t *>(wave_all + kSubFinalWaves * kSfWaveBytes);  // [kMaxBlocksPerMcu]
+    uint8_t *wave_all = smem + (size_t)n_slots * kSfTabBytes;                // n_waves * kSfWaveBytes
+    uint32_t *blk_info = reinterpret_cast<uint32_t *>(wave_all + n_waves * kSfWaveBytes);  // [kMaxBlocksPerMcu]
     const HuffWork wk = work[blockIdx.x];
     const DevScan &s = scans[wk.scan];
     const DevScanStatus st = status[wk.scan];
     if (st.n_ends == 0) return;
-    k2_stage_scan_tables<kSfLB>(s, huff_pool, lut_pool, tabs, blk_info, n_slots, 64 * kSubFinalWaves);
+    k2_stage_scan_tables<kSfLB>(s, huff_pool, lut_pool, tabs, blk_info, n_slots, blockDim.x);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t *stage = wave_all + wave * kSfWaveBytes;
     uint8_t *ring = stage + 8192 + lane * kK2RingStride;
@@ -3372,22 +3373,24 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
-                                int max_rounds, int *rounds_used, const uint32_t *lut_pool) {
+                                int max_rounds, int *rounds_used, const uint32_t *lut_pool, const HuffWork *final_work, int n_final_work) {
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const uint32_t *final_state = nullptr;
     hipError_t e = launch_subseq_sync(stream, udata, scans, work, n_work, scan_ids, n_scans, ends_u, status, huff_pool, exit_a, exit_b, nblk,
                                       first_block, entry_used, dcsum, dc_entry, changed_dev, n_slots, max_rounds, rounds_used, lut_pool,
                                       &final_state);
     if (e != hipSuccess) return e;
-    const size_t lds_final = (size_t)n_slots * kSfTabBytes + (size_t)kSubFinalWaves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
+    const int waves = subseq_final_waves(n_slots);
+    const size_t lds_final = (size_t)n_slots * kSfTabBytes + (size_t)waves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
     static bool configured = false;  // more than 64 KB of dynamic LDS has to be allowed once per kernel
     if (!configured) {
         const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&subseq_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)((size_t)kMaxHuffSlots * kSfTabBytes + (size_t)kSubFinalWaves * kSfWaveBytes + 64));
+                                                  160 * 1024);
         if (ea != hipSuccess) return ea;
         configured = true;
     }
-    hipLaunchKernelGGL(subseq_final_kernel, dim3(n_work), dim3(64 * kSubFinalWaves), lds_final, stream, udata, scans, work, ends_u, status,
+    // final_work: (scan, first subsequence) per workgroup of waves * 64 lanes (the rounds' work list is per 256)
+    hipLaunchKernelGGL(subseq_final_kernel, dim3(n_final_work), dim3(64 * waves), lds_final, stream, udata, scans, final_work, ends_u, status,
                        huff_pool, lut_pool, final_state, first_block, (const int4 *)dc_entry, coefs, n_slots);
     return hipGetLastError();
 }
