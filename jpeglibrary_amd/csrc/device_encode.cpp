@@ -118,7 +118,7 @@ void rgb_ycc_factors(int32_t out[8]) {
 }
 
 EncodeBatch::~EncodeBatch() {
-    for (DevBuffer *b : {&d_pixels_, &d_images_, &d_tables_, &d_work_mcu_, &d_work_blk_, &d_work_chunk_, &d_coefs_, &d_bits_, &d_bit_off_,
+    for (DevBuffer *b : {&d_samples_, &d_pixels_, &d_images_, &d_tables_, &d_work_mcu_, &d_work_blk_, &d_work_chunk_, &d_coefs_, &d_bits_, &d_bit_off_,
                          &d_raw_bits_, &d_raw_, &d_chunk_ff_, &d_out_, &d_out_len_, &d_hist_})
         b->release();
 }
@@ -145,7 +145,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
     status_.assign((size_t)n, JPGPU_OK);
     encoded_ = false;
     std::vector<EncWork> work_mcu, work_blk;
-    uint64_t px_off = 0, coef_off = 0;
+    uint64_t px_off = 0, coef_off = 0, smp_off = 0;
     for (int i = 0; i < n; i++) {
         const jpgpu_encode_params &p = params[i];
         // argument checks of the reference's setters (JpegEncoder.cs:175-184, EncodeAction.cs:19-22)
@@ -181,6 +181,9 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         px_off = align_up64(px_off + (uint64_t)im.width * im.height * im.in_components, 256);
         coef_off += im.total_blocks;
         const uint32_t total_mcus = im.mcus_per_line * im.mcus_per_column;
+        if ((smp_off >> 8) > 0xFFFFFFFFull) return fail(JPGPU_ERR_OUT_OF_MEMORY, "sample buffer beyond 1 TiB");
+        im.smp_off_256 = (uint32_t)(smp_off >> 8);
+        smp_off = align_up64(smp_off + (uint64_t)total_mcus * enc_sample_bytes_per_mcu(im.luma_h, im.luma_v, im.components), 256);
         for (uint32_t f = 0; f < total_mcus; f += kEncMcusPerWg) work_mcu.push_back({(uint32_t)i, f});
         im.work_first = (uint32_t)work_blk.size();
         for (uint32_t f = 0; f < im.total_blocks; f += 256) work_blk.push_back({(uint32_t)i, f});
@@ -254,6 +257,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         {&d_work_blk_, work_blk.data(), work_blk.size() * sizeof(EncWork), 0},
         {&d_pixels_, nullptr, 0, (size_t)px_off + 256},
         {&d_coefs_, nullptr, 0, (size_t)total_blocks_ * 128 + 256},
+        {&d_samples_, nullptr, 0, (size_t)smp_off + 256},
         {&d_bits_, nullptr, 0, (size_t)total_blocks_ * sizeof(uint32_t) + 256},
         {&d_bit_off_, nullptr, 0, work_blk.size() * (sizeof(uint64_t) + sizeof(uint32_t)) + 512},  // per workgroup: base (u64) | bits (u32)
         {&d_raw_bits_, nullptr, 0, (size_t)n * sizeof(uint64_t) + 256},
@@ -287,7 +291,7 @@ int EncodeBatch::encode() {
     e = hipMemcpyAsync(d_images_.ptr, images_.data(), (size_t)n * sizeof(DevEncImage), hipMemcpyHostToDevice, ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(images)");
     e = launch_fdct_quant(ctx_->stream, (const uint8_t *)d_pixels_.ptr, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_mcu_.ptr, n_work_mcu_,
-                          (int16_t *)d_coefs_.ptr);
+                          (uint8_t *)d_samples_.ptr, (int16_t *)d_coefs_.ptr);
     if (e != hipSuccess) return hip_fail(e, "fdct_quant_kernel");
     if (!optimized_.empty()) {
         // optimizeCoding: BuildHuffmanTables (:491-550) -- statistics on the device, JpegHuffmanEncodingTableBuilder.Build on the host

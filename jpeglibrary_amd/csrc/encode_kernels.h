@@ -25,7 +25,8 @@ struct alignas(16) DevEncImage {
     uint32_t table_base;  // first of the image's 4 tables (DC0, AC0, DC1, AC1) in the table array; 0 = the standard tables.
                           // != 0 = optimizeCoding (tables built from the image): the TransformBlocks / allocator semantics apply
     uint32_t work_first;  // first workgroup of this image in the per-256-blocks work list (block_bits / emit)
-    uint32_t pad1[3];
+    uint32_t smp_off_256; // gathered samples of the image (E1a -> E1b), offset into the sample buffer in units of 256 bytes
+    uint32_t pad1[2];
     int32_t r2y[8];       // Fix() factors of the RGB -> YCbCr tables (host: rgb_ycc_factors)
     uint16_t quant[2][64];  // zig-zag quantisation tables: luma, chroma
 };
@@ -44,8 +45,10 @@ struct EncWork {
     uint32_t first;  // first MCU (kEncMcusPerWg per workgroup) / block (256) / stuffing chunk index
 };
 
+// E1a (pixel pass into `samples`, enc_sample_stride bytes per MCU) + E1b (FDCT + quantisation)
 hipError_t launch_fdct_quant(hipStream_t stream, const uint8_t *pixels, const DevEncImage *images, const EncWork *work, int n_work,
-                             int16_t *coefs);
+                             uint8_t *samples, int16_t *coefs);
+size_t enc_sample_bytes_per_mcu(uint32_t luma_h, uint32_t luma_v, uint32_t components);
 hipError_t launch_block_bits(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
                              const int16_t *coefs, uint32_t *bits, int n_images, uint32_t *wg_bits, uint64_t *wg_base, uint64_t *raw_bits);
 // optimizeCoding: GatherBlockStatistics for every block (ref: JpegEncoder.cs:552-597) -> hist[image][4][256]

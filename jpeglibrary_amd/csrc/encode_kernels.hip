@@ -146,24 +146,78 @@ __device__ __forceinline__ void unpack8_i16(const uint4 &p, int32_t (&v)[8]) {
     for (int i = 0; i < 8; i++) v[i] = (i & 1) ? ((int32_t)w[i >> 1] >> 16) : (int32_t)(int16_t)(w[i >> 1] & 0xFFFFu);
 }
 
-// One lane per MCU, kEncMcusPerWg lanes per workgroup.  Blocks of an MCU are produced in encoding order because the
-// reference's sub-sampling reader accumulates into the ONE block buffer WriteScanData reuses (:712, :788-799): a
-// sub-sampled component's block starts from the previous block's quantised coefficients.  The buffer lives in LDS
-// (sh_prev); the gathered samples go through LDS too (sh_smp), so the row loops stay rolled and the code stays small.
-// Both are laid out [row][lane] in 16-byte slots: neighbouring lanes touch neighbouring slots.
-__global__ __launch_bounds__(kEncMcusPerWg) void fdct_quant_kernel(const uint8_t *__restrict__ pixels, const DevEncImage *__restrict__ images,
-                                                                   const EncWork *__restrict__ work, int16_t *__restrict__ coefs) {
-    __shared__ uint4 sh_smp[8][kEncMcusPerWg], sh_prev[8][kEncMcusPerWg];
-    __shared__ uint16_t sh_q[2][64];
+// All three components of P consecutive pixels of one row, all inside the image, the row address dword aligned.
+template <int P>
+__device__ __forceinline__ void enc_row3(const uint8_t *rowp, const EncSrc &s, int32_t (&c0)[P], int32_t (&c1)[P], int32_t (&c2)[P]) {
+    uint32_t w[P * 3 / 4];
+    __builtin_memcpy(w, __builtin_assume_aligned(rowp, 4), sizeof w);
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const int32_t b0 = (w[(3 * i) >> 2] >> (8 * ((3 * i) & 3))) & 0xFF;
+        const int32_t b1 = (w[(3 * i + 1) >> 2] >> (8 * ((3 * i + 1) & 3))) & 0xFF;
+        const int32_t b2 = (w[(3 * i + 2) >> 2] >> (8 * ((3 * i + 2) & 3))) & 0xFF;
+        c0[i] = enc_convert(s, 0, b0, b1, b2);
+        c1[i] = enc_convert(s, 1, b0, b1, b2);
+        c2[i] = enc_convert(s, 2, b0, b1, b2);
+    }
+}
+
+// Samples of one MCU as E1b reads them (enc_sample_stride bytes): luma_h x luma_v luma blocks of 64 bytes (the block's 64
+// samples, row-major), then for a 3-component image two blocks of 64 int16: per chroma sample the SUM of the converted
+// values of the luma_h x luma_v pixels it covers (what ReadBlockWithSubsample adds up, JpegEncoder.cs:788-799; the rounding
+// shift -- and, without optimizeCoding, the previous block's coefficients it is added to -- come in E1b).
+__host__ __device__ constexpr uint32_t enc_sample_stride(uint32_t luma_h, uint32_t luma_v, uint32_t components) {
+    return luma_h * luma_v * 64u + (components > 1 ? (components - 1) * 128u : 0u);
+}
+
+// The luma_v pixel rows behind chroma row k of one MCU, HS = luma_h blocks of 8 pixels each: luma samples to their blocks,
+// chroma values summed per chroma sample (8 / HS of them per block of 8 pixels: with HS fixed the sums stay in registers).
+template <int HS>
+__device__ __forceinline__ void enc_gather_rows(const EncSrc &src, uint32_t x0, uint32_t ymcu, uint32_t k, uint32_t V, uint32_t components,
+                                                bool rows_aligned, uint8_t *out, int32_t (&sum1)[8], int32_t (&sum2)[8]) {
+    for (uint32_t dy = 0; dy < V; dy++) {
+        const uint32_t ry = k * V + dy;  // pixel row inside the MCU
+        const uint32_t y = ymcu + ry;
+        const uint32_t by = ry >> 3, r = ry & 7u;
+#pragma unroll
+        for (int bx = 0; bx < HS; bx++) {
+            const uint32_t x = x0 + (uint32_t)bx * 8;
+            int32_t c0[8], c1[8], c2[8];
+            if (x + 8 <= src.width && y < src.height && rows_aligned && src.comps == 3) {
+                enc_row3<8>(src.px + ((size_t)y * src.width + x) * 3, src, c0, c1, c2);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    c0[i] = enc_sample(src, 0, x + i, y);
+                    c1[i] = components > 1 ? enc_sample(src, 1, x + i, y) : 0;
+                    c2[i] = components > 1 ? enc_sample(src, 2, x + i, y) : 0;
+                }
+            }
+            uint2 pk;
+            pk.x = (uint32_t)c0[0] | ((uint32_t)c0[1] << 8) | ((uint32_t)c0[2] << 16) | ((uint32_t)c0[3] << 24);
+            pk.y = (uint32_t)c0[4] | ((uint32_t)c0[5] << 8) | ((uint32_t)c0[6] << 16) | ((uint32_t)c0[7] << 24);
+            *reinterpret_cast<uint2 *>(out + (by * HS + (uint32_t)bx) * 64 + r * 8) = pk;
+            if (components > 1) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    constexpr int kShift = HS == 1 ? 0 : (HS == 2 ? 1 : 2);
+                    sum1[(bx * 8 + i) >> kShift] += c1[i];  // compile-time index
+                    sum2[(bx * 8 + i) >> kShift] += c2[i];
+                }
+            }
+        }
+    }
+}
+
+// E1a: the pixel pass.  One lane per (MCU, chroma row k of the MCU): the luma_v pixel rows behind that chroma row, 8 x luma_h
+// pixels each -- converted once (RGB -> YCbCr when asked to), luma samples to their blocks, chroma values summed.  Lanes of
+// a wave are consecutive MCUs of one k, so a wave reads whole contiguous stretches of a pixel row.
+__global__ __launch_bounds__(8 * kEncMcusPerWg) void enc_gather_kernel(const uint8_t *__restrict__ pixels, const DevEncImage *__restrict__ images,
+                                                                       const EncWork *__restrict__ work, uint8_t *__restrict__ samples) {
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
-    const uint32_t lane = threadIdx.x;
-    if (lane < 64) {
-        sh_q[0][lane] = im.quant[0][lane];
-        sh_q[1][lane] = im.quant[1][lane];
-    }
-    __syncthreads();
-    const uint32_t mcu = wk.first + lane;
+    const uint32_t m = threadIdx.x % kEncMcusPerWg, k = threadIdx.x / kEncMcusPerWg;
+    const uint32_t mcu = wk.first + m;
     const uint32_t mcus_per_line = im.mcus_per_line;
     if (mcu >= mcus_per_line * im.mcus_per_column) return;
     EncSrc src;
@@ -174,90 +228,97 @@ __global__ __launch_bounds__(kEncMcusPerWg) void fdct_quant_kernel(const uint8_t
     src.rgb = im.input_rgb != 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) src.k[i] = im.r2y[i];
-    const uint32_t components = im.components, bpm = im.bpm;
-    const uint32_t max_h = im.luma_h, max_v = im.luma_v;
+    const uint32_t H = im.luma_h, V = im.luma_v, components = im.components;
     const uint32_t mx = mcu % mcus_per_line, my = mcu / mcus_per_line;
+    const uint32_t x0 = mx * 8 * H;
     const bool rows_aligned = ((src.width * src.comps) & 3u) == 0;
-    int16_t *out = coefs + (im.coef_off + (uint64_t)mcu * bpm) * 64;
-    const bool own_blocks = im.table_base != 0;  // optimizeCoding: TransformBlocks (:414-485)
-    {
-        const uint4 z = {0, 0, 0, 0};
-#pragma unroll
-        for (int r = 0; r < 8; r++) sh_prev[r][lane] = z;
+    uint8_t *out = samples + (uint64_t)im.smp_off_256 * 256u + (uint64_t)mcu * enc_sample_stride(H, V, components);
+    int32_t sum1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sum2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (H == 1) enc_gather_rows<1>(src, x0, my * 8 * V, k, V, components, rows_aligned, out, sum1, sum2);
+    else if (H == 2) enc_gather_rows<2>(src, x0, my * 8 * V, k, V, components, rows_aligned, out, sum1, sum2);
+    else enc_gather_rows<4>(src, x0, my * 8 * V, k, V, components, rows_aligned, out, sum1, sum2);
+    if (components > 1) {
+        uint8_t *cb = out + H * V * 64 + k * 16;
+        *reinterpret_cast<uint4 *>(cb) = pack8_i16(sum1);
+        *reinterpret_cast<uint4 *>(cb + 128) = pack8_i16(sum2);
     }
-    uint32_t b = 0;
+}
+
+// E1b: one lane per MCU, kEncMcusPerWg lanes per workgroup: the gathered samples through ShiftDataLevel + TransformFDCT +
+// ZigZagAndQuantizeBlock.  Blocks of an MCU are produced in encoding order because the reference's sub-sampling reader
+// accumulates into the ONE block buffer WriteScanData reuses (:712, :788-799): a sub-sampled component's block starts from
+// the previous block's quantised coefficients (kept here in registers, packed).  With optimizeCoding every block has its
+// own zeroed allocator slot (TransformBlocks :414-485) and nothing carries over.
+// (First version: one kernel, the gather inside the block loop row by row through LDS -- 211 VGPRs and 33 KB of LDS kept
+// it at 2 waves per SIMD with a load-use wait per pixel row: 2.4 ms per 64 x 4K, 47 % of the wave cycles waiting.)
+__global__ __launch_bounds__(kEncMcusPerWg) void fdct_quant_kernel(const uint8_t *__restrict__ samples, const DevEncImage *__restrict__ images,
+                                                                   const EncWork *__restrict__ work, int16_t *__restrict__ coefs) {
+    __shared__ uint16_t sh_q[2][64];
+    const EncWork wk = work[blockIdx.x];
+    const DevEncImage &im = images[wk.image];
+    const uint32_t lane = threadIdx.x;
+    if (lane < 64) {
+        sh_q[0][lane] = im.quant[0][lane];
+        sh_q[1][lane] = im.quant[1][lane];
+    }
+    __syncthreads();
+    const uint32_t mcu = wk.first + lane;
+    if (mcu >= im.mcus_per_line * im.mcus_per_column) return;
+    const uint32_t components = im.components, bpm = im.bpm;
+    const uint32_t H = im.luma_h, V = im.luma_v, ny = H * V;
+    const uint32_t total = (31 - __builtin_clz(H)) + (31 - __builtin_clz(V));  // rounding shift of a chroma sample
+    const bool own_blocks = im.table_base != 0;
+    const uint8_t *in = samples + (uint64_t)im.smp_off_256 * 256u + (uint64_t)mcu * enc_sample_stride(H, V, components);
+    int16_t *out = coefs + (im.coef_off + (uint64_t)mcu * bpm) * 64;
+    uint4 prev[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) prev[r] = uint4{0, 0, 0, 0};
+    // the samples of block b + 1 are fetched while block b is transformed (8 x 16 bytes; a luma block uses the first four)
+    uint4 raw[8];
+    auto fetch = [&](uint32_t bb, uint4 (&dst)[8]) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(bb < ny ? in + bb * 64 : in + ny * 64 + (bb - ny) * 128);
+#pragma unroll
+        for (int v4 = 0; v4 < 4; v4++) dst[v4] = p[v4];
+        if (bb >= ny) {
+#pragma unroll
+            for (int v4 = 4; v4 < 8; v4++) dst[v4] = p[v4];
+        }
+    };
+    fetch(0, raw);
 #pragma unroll 1
-    for (uint32_t c = 0; c < components; c++) {
-        const uint32_t h = c == 0 ? max_h : 1u, v = c == 0 ? max_v : 1u;
-        const uint32_t hs = max_h / h, vs = max_v / v;
-        const uint32_t hshift = 31 - __builtin_clz(hs), vshift = 31 - __builtin_clz(vs);
-        const uint32_t total = hshift + vshift;
-        const uint16_t *quant = sh_q[c == 0 ? 0 : 1];
-#pragma unroll 1
-        for (uint32_t blk = 0; blk < h * v; blk++, b++) {
-            const uint32_t bx = blk % h, by = blk / h;
-            const uint32_t x0 = (mx * max_h + bx) * 8, y0 = (my * max_v + by) * 8;  // full-resolution origin (:709-712)
-            // fast path: all source pixels inside the image and the rows dword aligned -> rows are fetched as dwords
-            const bool fast = x0 + 8 * hs <= src.width && y0 + 8 * vs <= src.height && rows_aligned && hs <= 2;
-#pragma unroll 1
-            for (uint32_t r = 0; r < 8; r++) {
-                int32_t acc[8];
-                if (total == 0) {
+    for (uint32_t b = 0; b < bpm; b++) {
+        int32_t smp[64], q[64];
+        if (b < ny) {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) acc[i] = 0;
-                } else {
-                    // ReadBlockWithSubsample adds to what the buffer holds (:788-799): WriteScanData's one reused buffer
-                    // (the previous block's coefficients), or the block's own zeroed allocator slot in TransformBlocks
-                    unpack8_i16(sh_prev[r][lane], acc);
-                }
-#pragma unroll 1
-                for (uint32_t dy = 0; dy < vs; dy++) {
-                    const uint32_t y = y0 + (r << vshift) + dy;
-                    if (fast) {
-                        const uint8_t *rowp = src.px + ((size_t)y * src.width + x0) * src.comps;
-                        if (hs == 2) {
-                            int32_t row[16];
-                            enc_row<16>(rowp, src, c, row);
+            for (int v4 = 0; v4 < 4; v4++) {
+                const uint32_t ww[4] = {raw[v4].x, raw[v4].y, raw[v4].z, raw[v4].w};
 #pragma unroll
-                            for (int i = 0; i < 8; i++) acc[i] += row[2 * i] + row[2 * i + 1];
-                        } else {
-                            int32_t row[8];
-                            enc_row<8>(rowp, src, c, row);
-#pragma unroll
-                            for (int i = 0; i < 8; i++) acc[i] += row[i];
-                        }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 8; i++)
-                            for (uint32_t dx = 0; dx < hs; dx++) acc[i] += enc_sample(src, c, x0 + ((uint32_t)i << hshift) + dx, y);
-                    }
-                }
-                if (total != 0) {
-#pragma unroll
-                    for (int i = 0; i < 8; i++) acc[i] = (int32_t)(int16_t)(((int32_t)(int16_t)acc[i] + (1 << (total - 1))) >> total);
-                }
-                sh_smp[r][lane] = pack8_i16(acc);
+                for (int i = 0; i < 16; i++) smp[v4 * 16 + i] = (int32_t)((ww[i >> 2] >> (8 * (i & 3))) & 0xFFu);
             }
-            // ShiftDataLevel + TransformFDCT + ZigZagAndQuantizeBlock
-            int32_t smp[64], q[64];
+        } else {
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                int32_t row[8];
-                unpack8_i16(sh_smp[r][lane], row);
+                int32_t sum[8], base[8];
+                unpack8_i16(raw[r], sum);
+                unpack8_i16(prev[r], base);
 #pragma unroll
-                for (int i = 0; i < 8; i++) smp[r * 8 + i] = row[i];
+                for (int i = 0; i < 8; i++) {
+                    if (total == 0) smp[r * 8 + i] = sum[i];
+                    else smp[r * 8 + i] = (int32_t)(int16_t)(((int32_t)(int16_t)(base[i] + sum[i]) + (1 << (total - 1))) >> total);
+                }
             }
-            fdct_quantize(smp, quant, q);
-            uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)b * 64);
+        }
+        if (b + 1 < bpm) fetch(b + 1, raw);
+        fdct_quantize(smp, sh_q[b < ny ? 0 : 1], q);
+        uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)b * 64);
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                int32_t row[8];
+        for (int r = 0; r < 8; r++) {
+            int32_t row[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) row[i] = q[r * 8 + i];
-                const uint4 pk = pack8_i16(row);
-                dst[r] = pk;
-                if (!own_blocks) sh_prev[r][lane] = pk;  // ZigZagAndQuantizeBlock writes into the buffer the next ReadBlock starts from
-            }
+            for (int i = 0; i < 8; i++) row[i] = q[r * 8 + i];
+            const uint4 pk = pack8_i16(row);
+            dst[r] = pk;
+            if (!own_blocks) prev[r] = pk;  // ZigZagAndQuantizeBlock writes into the buffer the next ReadBlock starts from
         }
     }
 }
@@ -585,10 +646,13 @@ __global__ __launch_bounds__(256) void stuff_write_kernel(const DevEncImage *__r
 
 // ------------------------------------------------------------------------------------------------ launch wrappers
 
+size_t enc_sample_bytes_per_mcu(uint32_t luma_h, uint32_t luma_v, uint32_t components) { return enc_sample_stride(luma_h, luma_v, components); }
+
 hipError_t launch_fdct_quant(hipStream_t stream, const uint8_t *pixels, const DevEncImage *images, const EncWork *work, int n_work,
-                             int16_t *coefs) {
+                             uint8_t *samples, int16_t *coefs) {
     if (n_work <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fdct_quant_kernel, dim3(n_work), dim3(kEncMcusPerWg), 0, stream, pixels, images, work, coefs);
+    hipLaunchKernelGGL(enc_gather_kernel, dim3(n_work), dim3(8 * kEncMcusPerWg), 0, stream, pixels, images, work, samples);
+    hipLaunchKernelGGL(fdct_quant_kernel, dim3(n_work), dim3(kEncMcusPerWg), 0, stream, samples, images, work, coefs);
     return hipGetLastError();
 }
 hipError_t launch_block_bits(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
