@@ -1058,6 +1058,16 @@ __device__ __forceinline__ ProgComp prog_comp(const DevScan &s, uint32_t c) {
     return p;
 }
 // block (bx, by) of a component; false = the allocator's dummy block
+// DC refinement, blockRef |= bit << al (JpegHuffmanProgressiveScanDecoder.cs ReadBlockProgressiveDC, the Ah != 0 arm), on the
+// 16-bit DC ALONE.  Round 1 spelled this as a 32-bit atomic OR on the block's first word; that read-modify-write also writes
+// coefficient 1 back, and coefficient 1 belongs to the AC scans of the same frame, which store it with plain 16-bit writes at
+// the same time (same launch level; any time in the pipelined launch): whenever the atomic's read and write straddled such a
+// store, coefficient 1 reverted to its old value and the next refinement of that band lost its place in the bit stream
+// ("invalid Huffman code" in a handful of frames per thousand, only under tight following -- the long hunt is in DESIGN.md).
+// The DC has one writer at a time (DC scans of a component follow each other), so no atomic is needed.
+__device__ __forceinline__ void dc_refine_or(int16_t *dc, uint32_t al) {
+    *dc = (int16_t)((uint16_t)*dc | (uint16_t)(1u << al));
+}
 __device__ __forceinline__ bool prog_block_index(const ProgFrame &f, const ProgComp &p, uint32_t bx, uint32_t by, uint64_t &index) {
     if (bx >= p.hblocks || by >= p.vblocks) return false;
     const uint32_t mx = bx / p.h, my = by / p.v;
@@ -1179,8 +1189,7 @@ __global__ __launch_bounds__(kProgThreads) void progressive_scan_kernel(const ui
                                 err = kDetailUnexpectedEnd;
                                 break;
                             }
-                            // blockRef |= bit << al, 16-bit (the DC is the low half of the block's first word)
-                            if (real && bit) atomicOr(reinterpret_cast<uint32_t *>(coefs + index * 64), (1u << al) & 0xFFFFu);
+                            if (real && bit) dc_refine_or(coefs + index * 64, al);
                         }
                     }
             }
@@ -1213,7 +1222,7 @@ __global__ __launch_bounds__(kProgThreads) void progressive_scan_kernel(const ui
                         err = kDetailUnexpectedEnd;
                         break;
                     }
-                    if (real && bit) atomicOr(reinterpret_cast<uint32_t *>(coefs + index * 64), (1u << al) & 0xFFFFu);
+                    if (real && bit) dc_refine_or(coefs + index * 64, al);
                 }
             }
         } else if (ah == 0) {
@@ -1413,6 +1422,33 @@ constexpr uint32_t kPsBadCode = 17u << 8;  // window entry: no code of 16 bits o
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
+// Scope of the release / acquire pair of the pipelined progressive launch: "agent" (buffer_wbl2 sc1 / buffer_inv sc1), what the
+// memory model asks for between workgroups of one device.  A build switch because the system-scope forms were tried during the
+// hunt for the wrong parses that turned out to be dc_refine_or's story (they only moved the timing); no measurable cost either way.
+#ifndef JPGPU_PS_SCOPE
+#define JPGPU_PS_SCOPE "agent"
+#endif
+#ifdef JPGPU_PS_PROFILE
+// cycle accounting of the refinement path of progressive_stream_kernel (diagnostic build only: -DJPGPU_PS_PROFILE)
+__device__ unsigned long long ps_prof[8];
+#define PS_TICK() __builtin_readcyclecounter()
+#define PS_ADD(i, v) do { if (lane == 0) atomicAdd(&ps_prof[i], (unsigned long long)(v)); } while (0)
+#if JPGPU_PS_PROFILE > 1
+#define PS_COUNT(i) PS_ADD(i, 1)  /* event counts (perturbs the timing: use for counts only) */
+#else
+#define PS_COUNT(i) do { } while (0)
+#endif
+extern "C" int jpgpu_debug_ps_profile(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ps_prof), sizeof(ps_prof)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(ps_prof), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
+}
+#else
+#define PS_TICK() 0ull
+#define PS_ADD(i, v) do { (void)(v); } while (0)
+#define PS_COUNT(i) do { } while (0)
+#endif
+
 struct WBits {
     const uint32_t *ring;  // MSB-first words of the stream; ring byte 0 = the 16-byte aligned address at or below its first byte
     uint32_t wmask;        // uniform: ring size in words - 1
@@ -1441,6 +1477,7 @@ __device__ __forceinline__ void w_refresh(WBits &d, uint32_t lane, const LdsHuff
     d.peek = (uint32_t)(((((uint64_t)w0) << 32) | w1) >> (32u - sh));
     if (LUT) d.ent = h.lut[d.peek >> (32 - kHuffLutBits)];
     d.cur = 0;
+    PS_COUNT(7);
 }
 
 // DecodeHuffmanCode (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:81-88); returns the entry, the peeked bits in pk.
@@ -1672,6 +1709,7 @@ __device__ __forceinline__ uint32_t w_ac_refine_fast(WBits &d, uint32_t lane, co
     uint32_t nbelow = 0; // non-zero coefficients of the band below k
     if (eobrun == 0) {
         for (;;) {
+            PS_COUNT(6);
             if (d.cur > 63u) w_refresh<true>(d, lane, hac);
             const uint32_t pk = lane_get(d.peek, d.cur);
             uint32_t e = lane_get(d.ent, d.cur);
@@ -1759,13 +1797,6 @@ __device__ __forceinline__ uint32_t w_ac_refine_fast(WBits &d, uint32_t lane, co
 }
 constexpr int32_t kPsFastBits = 2560;  // more than any block can consume: 63 x (16 + 16) + 14 (first), 63 x 17 + 63 + 14 (refinement)
 
-// A coefficient store of the stream kernel.  wt: write-through at agent scope (global_store_short sc1), which does not leave
-// the line in this XCD's L2 (kept for experiments: it thinned out, but did not remove, the wrong parses seen when a
-// pipelined launch was not fully resident -- see the residency rule in progressive_stream_kernel).
-__device__ __forceinline__ void ps_store(int16_t *p, int16_t v, bool wt) {
-    if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
 
 __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
                                                                 const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
@@ -1872,7 +1903,6 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
     // "finished" so that its own followers drain too, and the host re-issues the frame's scans level by level in fresh
     // launches (DeviceBatch::fetch_status).
     const bool publishes = pipelined != 0 && s.publishes != 0;
-    const bool wt = false;
     uint32_t *my_progress = &status[wk.scan].pad[1];
     const uint32_t my_units_per_row = units_per_line * (ncomp == 1 ? (uint32_t)s.comp[0].v : 1u);
     uint32_t dep_scan[3], dep_units_per_row[3];
@@ -1887,20 +1917,17 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
         }
     }
     if (dep_scan[0] == kNoDep) rows_ready = 0xFFFFFFFFu;
-    // RESIDENCY RULE.  The follow-your-producers protocol below is only ever run with every workgroup of the launch
-    // co-resident: HIP promises no dispatch order, so a follower that holds a slot while its producer still waits for one
-    // can starve the machine -- and, observed on MI355X with launches several times larger than what the CUs hold, a
-    // small share of followers then parsed blocks with coefficients missing although their producers had published far
-    // beyond them (1024 x 4K progressive, ~1 % of the last frames, root cause not isolated; agent-scope fences as the
-    // guide prescribes, an acquire per chunk and write-through stores did not remove it; launches in which every
-    // workgroup is resident, and level-by-level launches of any size, never showed it).  So: every workgroup counts itself
-    // in at its start; a follower goes on only once all have (a fully resident grid starts within a microsecond), and
-    // gives up with kDetailSpinTimeout otherwise -- the host then re-issues the scans level by level.  The host only
-    // chooses the pipelined launch for grids that fit (DeviceBatch::run_progressive), so this is the safety net for
-    // co-tenants on the device and for an occupancy estimate that was too generous.
+    // RESIDENCY RULE.  The follow-your-producers protocol below is run with every workgroup of the launch co-resident: HIP
+    // promises no dispatch order, so a follower that holds a slot while its producer still waits for one can starve the
+    // machine.  Every workgroup counts itself in at its start; a follower goes on only once all have (a fully resident
+    // grid starts within a microsecond), and gives up with kDetailSpinTimeout otherwise -- the host then re-issues the
+    // scans level by level.  The host only chooses the pipelined launch for grids that fit (DeviceBatch::run_progressive),
+    // so this is the safety net for co-tenants on the device and for an occupancy estimate that was too generous.
+    // (Larger grids do work on MI355X as dispatched today -- workgroups start in work-list order, producers first -- and
+    // JPGPU_PROG_FORCE_PIPELINE=1 runs them that way, skipping the count-in; measured no faster than level by level.)
     if (pipelined != 0) {
         if (lane == 0) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (dep_scan[0] != kNoDep) {
+        if (dep_scan[0] != kNoDep && pipelined != 2) {  // pipelined == 2: a grid that is not resident (JPGPU_PROG_FORCE_PIPELINE)
             uint32_t polls = spin_budget < 4096u ? spin_budget : 4096u;
             for (;;) {
                 const uint32_t n_ = uni(__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -1934,18 +1961,17 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
             spin_budget--;                                                                                      \
             __builtin_amdgcn_s_sleep(32);                                                                       \
         }                                                                                                       \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, JPGPU_PS_SCOPE);                                               \
         /* the invalidate completes asynchronously: nothing may be loaded before it has (MI355X guide, G16) */  \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
     }
     // Release: the wave's own stores drained, the XCD's L2 written back, and -- spelled out in asm because hipcc (ROCm 7.2)
-    // drops the wait behind buffer_wbl2 when it believes the counter is empty, letting the flag overtake the write-back: a
-    // follower then parses a block with stale coefficients (seen as sporadic "invalid Huffman code" failures once a batch
-    // held more streams than the machine keeps resident) -- only then the progress word.
+    // drops the wait behind buffer_wbl2 when it believes the counter is empty, which would let the flag overtake the
+    // write-back -- only then the progress word.
 #define JPGPU_PUBLISH(units_)                                                                                   \
     if (publishes) {                                                                                            \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, JPGPU_PS_SCOPE);                                               \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
         if (lane == 0) __hip_atomic_store(my_progress, (units_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   \
     }
@@ -1991,15 +2017,14 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                             if (err != 0) break;
                             const int32_t t = pred[c] + value;
                             pred[c] = t;
-                            if (real && lane == 0) ps_store(coefs + index * 64, (int16_t)((uint32_t)t << al), wt);
+                            if (real && lane == 0) coefs[index * 64] = (int16_t)((uint32_t)t << al);
                         } else {
                             uint32_t bit;
                             if (!w_read_bits<false, false>(d, lane, hdc, 1, bit)) {
                                 err = kDetailUnexpectedEnd;
                                 break;
                             }
-                            // blockRef |= bit << al, 16-bit (the DC is the low half of the block's first word)
-                            if (real && bit != 0 && lane == 0) atomicOr(reinterpret_cast<uint32_t *>(coefs + index * 64), (1u << al) & 0xFFFFu);
+                            if (real && bit != 0 && lane == 0) dc_refine_or(coefs + index * 64, al);
                         }
                     }
             }
@@ -2040,14 +2065,18 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                     err = w_ac_first_block<false>(d, lane, hac, closed_by_marker, ss, se, al, eobrun, c, changed);
                     JPGPU_SETTLE()
                 }
-                if (real && (changed & lane_bit) != 0) ps_store(coefs + index * 64 + lane, (int16_t)c, wt);
+                if (real && (changed & lane_bit) != 0) coefs[index * 64 + lane] = (int16_t)c;
             }
         } else {
+            unsigned long long ps_stage = 0, ps_wait = 0, ps_blocks = 0, ps_t0 = PS_TICK();
             for (uint32_t done = 0; done < my_units && err == 0;) {
                 const uint32_t n = my_units - done < (uint32_t)kPsChunk ? my_units - done : (uint32_t)kPsChunk;
+                const unsigned long long ps_a = PS_TICK();
                 if (done != 0 && (done & 31u) == 0) JPGPU_PUBLISH(done)  // a release fence costs microseconds: every 32 blocks
                 JPGPU_FOLLOW((first_unit + done + n - 1u) / my_units_per_row)
                 if (err != 0) break;  // gave up waiting (kDetailSpinTimeout)
+                const unsigned long long ps_b = PS_TICK();
+                ps_wait += ps_b - ps_a;
                 if (lane < n) {
                     ProgWalk w;
                     prog_walk_init(w, p, first_unit + done + lane, units_per_line);
@@ -2062,6 +2091,8 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                     reinterpret_cast<uint4 *>(stage)[q] = *reinterpret_cast<const uint4 *>(src);
                 }
                 __syncthreads();
+                const unsigned long long ps_c = PS_TICK();
+                ps_stage += ps_c - ps_b;
                 for (uint32_t b = 0; b < n && err == 0; b++) {
                     JPGPU_ENSURE_STAGED()
                     int32_t c = stage[b * 64u + lane];
@@ -2076,9 +2107,18 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                         err = w_ac_refine_block<false>(d, lane, hac, ss, se, p1, m1, band, nz, eobrun, c, mine);
                         JPGPU_SETTLE()
                     }
-                    if (ix != kPsNoBlock && mine) ps_store(coefs + (uint64_t)ix * 64 + lane, (int16_t)c, wt);
+                    if (ix != kPsNoBlock && mine) coefs[(uint64_t)ix * 64 + lane] = (int16_t)c;
                     if (err == 0) done++;
                 }
+                ps_blocks += PS_TICK() - ps_c;
+            }
+            if (ah == 1 && al == 0) {  // the last luma / chroma refinements
+                PS_ADD(0, 1);
+                PS_ADD(1, my_units);
+                PS_ADD(2, ps_wait);
+                PS_ADD(3, ps_stage);
+                PS_ADD(4, ps_blocks);
+                PS_ADD(5, PS_TICK() - ps_t0);
             }
         }
     }

@@ -579,11 +579,14 @@ def _many_small_progressive(n):
     return [distinct[i % 24] for i in range(n)], [refs[i % 24] for i in range(n)]
 
 
-def test_more_progressive_streams_than_the_machine_keeps_resident():
-    """The single pipelined launch gives every scan one workgroup that follows its producers' progress from inside the
-    kernel: 2400 frames x 10 scans = 24 000 workgroups, several times what 256 CUs hold at once, so followers are
-    dispatched long before some producers exist.  Every frame exact, no fallback needed."""
-    files, refs = _many_small_progressive(2400)
+@pytest.mark.parametrize("frames,force", [(800, False), (2400, False), (2400, True)])
+def test_more_progressive_streams_than_the_machine_keeps_resident(frames, force, monkeypatch):
+    """Ten scans per frame, one workgroup each.  800 frames = 8 000 workgroups: more than 256 CUs hold at once, still one
+    pipelined launch (followers are dispatched behind their producers, without the count-in gate); 2 400 frames = 24 000:
+    level by level, or -- forced -- pipelined all the same.  Every frame exact, no fallback needed."""
+    if force:
+        monkeypatch.setenv("JPGPU_PROG_FORCE_PIPELINE", "1")
+    files, refs = _many_small_progressive(frames)
     b = jl.Batch().upload(files)
     for _ in range(3):
         b.decode()
@@ -592,6 +595,22 @@ def test_more_progressive_streams_than_the_machine_keeps_resident():
     assert not bad, bad[:10]
     assert b.progressive_fallbacks() == 0
     b.close()
+
+
+def test_dc_refinement_beside_ac_scans_of_the_same_frame():
+    """1024 x 4K progressive frames in one pipelined launch at 14 workgroups per CU: the regime in which the DC refinement
+    scan and the AC scans of one frame run neck and neck on the same blocks.  The DC refinement used to be a 32-bit atomic
+    OR on the block's first word and now and then put an old coefficient 1 back over the AC scan's store: 7-16 frames per
+    pass failed with "invalid Huffman code" in the next refinement of that band.  (Own process: the LDS shape is read once.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JPGPU_PS_RING="4096", JPGPU_PS_CHUNK="32", JPGPU_PROG_FORCE_PIPELINE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "trace", "progressive_oversubscribed.py"), "1024"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("n=1024")]
+    assert r.returncode == 0 and len(lines) == 3, r.stdout[-2000:] + r.stderr[-2000:]
+    assert all("failed 0 [] differing []" in ln for ln in lines), lines
 
 
 def test_progressive_spin_budget_exhausted_falls_back_level_by_level(monkeypatch):
