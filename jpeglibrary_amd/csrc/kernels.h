@@ -19,7 +19,7 @@ constexpr uint32_t kMarkerChunkBytes = 4096;  // K1 chunk size (256 lanes x 16 b
 // consecutive chunks of one scan handled by one K1 workgroup (one work-list entry).  4 was measured in round 2: K1 1.53 ms
 // instead of 1.27-1.35 per 1024 x 4K -- the quarter of a million small workgroups are not what K1 waits for, and chunks taken
 // one after the other inside a workgroup hide less latency than the same chunks in separate workgroups
-constexpr uint32_t kMarkerChunksPerWg = 1;
+constexpr uint32_t kMarkerChunksPerWg = 1;  // marker_count_kernel takes several work entries per workgroup and relies on 1 here
 hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const DevScan *scans, int n_scans, const ChunkWork *work,
                                int n_chunks, ChunkSum *sums, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u);
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,

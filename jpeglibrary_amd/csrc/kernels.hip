@@ -42,14 +42,25 @@ __device__ __forceinline__ uint32_t wave_reduce_max_i(int32_t v) {
     }
     return (uint32_t)v;
 }
+// DPP forms of the wave-wide sums (all 64 lanes must be active): data-parallel-primitive operands move values between lanes
+// inside the VALU, no LDS crossbar round trip per step as with ds_bpermute (__shfl_*).  Control codes: row_shr:n = 0x110 + n,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143, wave_shl:1 = 0x130, wave_shr:1 = 0x138; lanes without a source receive 0.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-    uint32_t l = lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(v, o, 64);
-        if (l >= (uint32_t)o) v += t;
-    }
+    v += dpp0<0x111>(v);       // inside each row of 16 lanes
+    v += dpp0<0x112>(v);
+    v += dpp0<0x114>(v);
+    v += dpp0<0x118>(v);
+    v += dpp0<0x142, 0xA>(v);  // rows 1 and 3 take the total of the row before them
+    v += dpp0<0x143, 0xC>(v);  // rows 2 and 3 take the total of rows 0-1
     return v;
+}
+// sum over the wave, the same value in every lane (as a scalar)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -71,6 +82,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
 constexpr int kScanThreads = 256;
 constexpr uint32_t kInf = 0xFFFFFFFFu;
 constexpr uint32_t kChunkBytes = kScanThreads * 16;  // one chunk = one 4 KiB tile, 16 bytes per lane
+constexpr int kCountChunksPerWg = 4;                  // marker_count_kernel: tiles in flight per workgroup
 
 // Per-lane classification of 16 consecutive bytes of an entropy segment (bit j = byte off + j).
 struct ByteClass {
@@ -79,19 +91,42 @@ struct ByteClass {
     uint32_t keep;      // bytes copied to udata as they are (markers' FF included, their code byte excluded)
 };
 
-__device__ __forceinline__ ByteClass classify16(const uint8_t *p, int64_t off, uint32_t len, bool any_marker_terminates) {
+// The lane's 16 bytes and, for the two lanes at the ends of a wave, the byte before / after them.  Nothing here waits for the
+// data, so a caller can issue several of these before it classifies the first (lanes out of range read the segment's first bytes
+// and drop them: no branch around the 16-byte load).
+struct Raw16 {
+    uint4 v;
+    uint32_t edge;
+};
+__device__ __forceinline__ Raw16 load16(const uint8_t *p, int64_t off, uint32_t len) {
+    const bool in_range = off < (int64_t)len && off + 16 > 0;
+    const uint32_t l = lane_id();
+    Raw16 r;
+    r.v = *reinterpret_cast<const uint4 *>(p + (in_range ? off : 0));
+    r.edge = 0;
+    if (in_range && (l == 63 || (l == 0 && off >= 1))) r.edge = *(p + (l == 0 ? off - 1 : off + 16));  // one two-lane load
+    if (!in_range) r.v = uint4{0, 0, 0, 0};
+    return r;
+}
+
+__device__ __forceinline__ ByteClass classify16(const Raw16 &raw, int64_t off, uint32_t len, bool any_marker_terminates) {
     ByteClass c;
-    c.w[0] = c.w[1] = c.w[2] = c.w[3] = c.w[4] = 0;
+    c.w[0] = raw.v.x;
+    c.w[1] = raw.v.y;
+    c.w[2] = raw.v.z;
+    c.w[3] = raw.v.w;
     c.rst = c.term = c.keep = 0;
     uint32_t prev = 0;
-    if (off < (int64_t)len && off + 16 > 0) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(p + off);  // input buffer is padded: over-read is safe
-        c.w[0] = v.x;
-        c.w[1] = v.y;
-        c.w[2] = v.z;
-        c.w[3] = v.w;
-        c.w[4] = *(p + off + 16);
-        if (off >= 1) prev = *(p + off - 1);
+    const bool in_range = off < (int64_t)len && off + 16 > 0;
+    // the byte after / before the lane's 16: the neighbouring lane holds it (consecutive lanes take consecutive 16 bytes; a lane
+    // out of range holds zeros, and its byte is only ever asked for by positions whose own range checks fail); the two lanes
+    // at the ends of the wave use the byte they loaded.  All 64 lanes get here (DPP reads the neighbours' registers).
+    {
+        const uint32_t l = lane_id();
+        const uint32_t nxt = dpp0<0x130>(c.w[0]) & 0xFFu, prv = dpp0<0x138>(c.w[3]) >> 24;
+        c.w[4] = l == 63 ? raw.edge : nxt;
+        if (off >= 1) prev = l == 0 ? raw.edge : prv;
+        if (!in_range) c.w[4] = 0, prev = 0;
     }
     if (off >= 1 && off + 17 <= (int64_t)len) {
         // interior lane (all but the first and last few lanes of a segment): SWAR over the four dwords, flags in bit 7 of
@@ -139,6 +174,10 @@ __device__ __forceinline__ ByteClass classify16(const uint8_t *p, int64_t off, u
 }
 
 // workgroup-wide exclusive prefix + total of one value per lane
+__device__ __forceinline__ ByteClass classify16(const uint8_t *p, int64_t off, uint32_t len, bool any_marker_terminates) {
+    return classify16(load16(p, off, len), off, len, any_marker_terminates);
+}
+
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *sh_wave /*[kScanThreads/64]*/, uint32_t &total) {
     const uint32_t incl = wave_inclusive_scan(v);
     const uint32_t wave = threadIdx.x >> 6;
@@ -158,34 +197,67 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 
 // K1a: per-chunk summary (RST markers, bytes udata will receive, first terminating marker).
 __global__ __launch_bounds__(kScanThreads) void marker_count_kernel(const uint8_t *__restrict__ data, const DevScan *__restrict__ scans,
-                                                                     const ChunkWork *__restrict__ work, ChunkSum *__restrict__ sums) {
-    const ChunkWork wk0 = work[blockIdx.x];
-    const DevScan &s = scans[wk0.scan];
-    const uint8_t *p = data + s.data_off;
-    const int32_t misalign = (int32_t)(s.data_off & 15u);
-    __shared__ uint32_t sh_a[kScanThreads / 64], sh_b[kScanThreads / 64];
-    __shared__ uint32_t sh_term;
-    // kMarkerChunksPerWg consecutive chunks per workgroup (1: see kernels.h)
-    for (uint32_t chunk = wk0.chunk; chunk < wk0.chunk + kMarkerChunksPerWg && chunk < s.n_chunks; chunk++) {
-        const int64_t off = -(int64_t)misalign + (int64_t)chunk * kChunkBytes + (int64_t)threadIdx.x * 16;
-        const ByteClass c = classify16(p, off, s.data_len, s.dri == 0);
-        __syncthreads();  // sh_term of the previous chunk has been read
-        if (threadIdx.x == 0) sh_term = kInf;
-        uint32_t rst_total, keep_total;
-        block_exclusive_scan(__builtin_popcount(c.rst), sh_a, rst_total);
-        block_exclusive_scan(__builtin_popcount(c.keep) + __builtin_popcount(c.rst | c.term), sh_b, keep_total);
-        uint32_t tpos = c.term ? (uint32_t)(off + __builtin_ctz(c.term)) : kInf;
-        tpos = wave_reduce_min(tpos);
-        if (lane_id() == 0 && tpos != kInf) atomicMin(&sh_term, tpos);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            ChunkSum cs;
-            cs.rst_cnt = rst_total;
-            cs.keep_cnt = keep_total;
-            cs.first_term = sh_term;
-            cs.pad = 0;
-            sums[s.chunk_off + chunk] = cs;
+                                                                     const ChunkWork *__restrict__ work, uint32_t n_work,
+                                                                     ChunkSum *__restrict__ sums) {
+    // kCountChunksPerWg entries of the work list per workgroup (they may belong to different scans), all their loads issued
+    // before the first is classified: a workgroup that waits for one 4 KiB tile at a time spends its life in load latency
+    // (work entry -> scan descriptor -> data: 2.1 TB/s with 262 144 such workgroups per 1024 x 4K).
+    __shared__ uint32_t sh_cnt[kCountChunksPerWg][kScanThreads / 64], sh_term[kCountChunksPerWg][kScanThreads / 64];
+    const uint32_t first = blockIdx.x * kCountChunksPerWg;
+    Raw16 raw[kCountChunksPerWg];
+    int64_t off[kCountChunksPerWg];
+    uint32_t len[kCountChunksPerWg], sum_at[kCountChunksPerWg];
+    bool any_marker[kCountChunksPerWg];
+    // three separate loops: the work entries, then the descriptors, then the data -- each level's loads in flight together
+    ChunkWork wk[kCountChunksPerWg];
+#pragma unroll
+    for (int i = 0; i < kCountChunksPerWg; i++) wk[i] = work[first + i < n_work ? first + i : n_work - 1];  // a tail entry repeats the last one (nothing is written for it)
+    uint64_t data_off[kCountChunksPerWg];
+#pragma unroll
+    for (int i = 0; i < kCountChunksPerWg; i++) {
+        const DevScan &s = scans[wk[i].scan];
+        data_off[i] = s.data_off;
+        len[i] = s.data_len;
+        sum_at[i] = s.chunk_off + wk[i].chunk;
+        any_marker[i] = s.dri == 0;
+    }
+#pragma unroll
+    for (int i = 0; i < kCountChunksPerWg; i++) {
+        off[i] = -(int64_t)(data_off[i] & 15u) + (int64_t)wk[i].chunk * kChunkBytes + (int64_t)threadIdx.x * 16;
+        raw[i] = load16(data + data_off[i], off[i], len[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < kCountChunksPerWg; i++) {
+        const ByteClass c = classify16(raw[i], off[i], len[i], any_marker[i]);
+        // totals only: both counts in one word (a wave holds at most 512 markers and writes at most 1536 bytes), one sum per wave
+        const uint32_t cnt = wave_sum((uint32_t)__builtin_popcount(c.rst) |
+                                      ((uint32_t)(__builtin_popcount(c.keep) + __builtin_popcount(c.rst | c.term)) << 16));
+        // first terminating marker of the wave: offsets grow with the lane, so it is in the lowest lane that has one
+        const uint64_t has_term = __ballot(c.term != 0);
+        uint32_t tpos = kInf;
+        if (has_term != 0) tpos = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off[i] + __builtin_ctz(c.term | 0x10000u)), (int)__builtin_ctzll(has_term));
+        if (lane_id() == 0) {
+            sh_cnt[i][threadIdx.x >> 6] = cnt;
+            sh_term[i][threadIdx.x >> 6] = tpos;
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < kCountChunksPerWg && first + threadIdx.x < n_work) {
+        uint32_t total = 0, term = kInf;
+#pragma unroll
+        for (int w = 0; w < kScanThreads / 64; w++) {
+            total += sh_cnt[threadIdx.x][w];
+            term = sh_term[threadIdx.x][w] < term ? sh_term[threadIdx.x][w] : term;
+        }
+        ChunkSum cs;
+        cs.rst_cnt = total & 0xFFFFu;
+        cs.keep_cnt = total >> 16;
+        cs.first_term = term;
+        cs.pad = 0;
+        uint32_t at = sum_at[0];
+#pragma unroll
+        for (int i = 1; i < kCountChunksPerWg; i++) at = threadIdx.x == (uint32_t)i ? sum_at[i] : at;
+        sums[at] = cs;
     }
 }
 
@@ -204,9 +276,10 @@ __global__ __launch_bounds__(kScanThreads) void first_marker_kernel(const uint8_
     const int64_t off = -(int64_t)misalign + (int64_t)blockIdx.x * kChunkBytes + (int64_t)threadIdx.x * 16;
     if ((int64_t)blockIdx.x * kChunkBytes - misalign >= (int64_t)len) return;
     const ByteClass c = classify16(data + seg_off, off, len, false);
-    uint32_t tpos = c.term ? (uint32_t)(off + __builtin_ctz(c.term)) : kInf;
-    tpos = wave_reduce_min(tpos);
-    if (lane_id() == 0 && tpos != kInf) atomicMin(&first[seg], tpos);
+    const uint64_t has_term = __ballot(c.term != 0);  // offsets grow with the lane: the lowest lane with a marker has the first
+    if (has_term == 0) return;
+    const uint32_t tpos = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off + __builtin_ctz(c.term | 0x10000u)), (int)__builtin_ctzll(has_term));
+    if (lane_id() == 0) atomicMin(&first[seg], tpos);
 }
 
 // K1p: the summaries of one scan turned into what each of its chunks needs: RSTs / udata bytes of the chunks BEFORE it (in
@@ -3211,7 +3284,8 @@ hipError_t launch_first_marker(hipStream_t stream, const uint8_t *data, const vo
 hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const DevScan *scans, int n_scans, const ChunkWork *work,
                                int n_chunks, ChunkSum *sums, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u) {
     if (n_chunks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(marker_count_kernel, dim3(n_chunks), dim3(kScanThreads), 0, stream, data, scans, work, sums);
+    hipLaunchKernelGGL(marker_count_kernel, dim3((n_chunks + kCountChunksPerWg - 1) / kCountChunksPerWg), dim3(kScanThreads), 0, stream, data,
+                       scans, work, (uint32_t)n_chunks, sums);
     hipLaunchKernelGGL(marker_prefix_kernel, dim3(n_scans), dim3(kScanThreads), 0, stream, scans, sums);
     hipLaunchKernelGGL(marker_write_kernel, dim3(n_chunks), dim3(kScanThreads), 0, stream, data, scans, work, sums, ends, status, udata,
                        ends_u);
