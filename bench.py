@@ -124,11 +124,18 @@ def cpu_baseline(files, width, height, max_threads):
             best = (rate, threads, len(sample), sec)
         if spent > 40.0:  # bounded: the sweep stops early on a slow host
             break
-    value, cores, decodes, sall = best
+    value, threads_best, decodes, sall = best
+    # cores = the CPUs those threads could actually occupy: never more than the affinity mask / cgroup quota grants
+    # (the sweep's best point is often an oversubscribed one by a percent of noise; efficiency is per CPU, not per thread)
+    granted = min(budget.get("affinity", budget["cpu_count"]), budget["cpu_count"])
+    if "cgroup_quota_cpus" in budget:
+        granted = min(granted, max(1, int(round(budget["cgroup_quota_cpus"]))))
+    cores = max(1, min(threads_best, granted))
     return {
         "value": round(value, 2),
         "unit": "Mpixels/s",
         "cores": cores,
+        "threads": threads_best,
         "kind": "port",
         "sample": f"{decodes} decodes (8 per thread) of the benchmark's images, Identify+Decode into an interleaved YCbCr8 buffer, one "
                   f"decoder per native thread, buffers pre-touched, one warm decode per thread ({sall:.2f} s wall); best of the thread "
