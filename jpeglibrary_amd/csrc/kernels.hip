@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "common.h"
 #include "kernels.h"
 #include "encode_kernels.h"
@@ -3305,18 +3307,29 @@ static size_t k2_lds_bytes(int n_slots, int lb) {
 }
 size_t huffman_lds_bytes(int n_slots) { return k2_lds_bytes(n_slots, n_slots <= 4 ? 11 : 10); }
 
+// More than 64 KB of dynamic LDS has to be allowed per kernel -- and per DEVICE: a process that drives several devices (one
+// jpgpu_ctx each) must do it on each of them.  done: one bit per device ordinal.
+static hipError_t allow_dynamic_lds(const void *kernel, int bytes, std::atomic<uint64_t> &done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
+
 template <int LB>
 static hipError_t launch_huffman_lb(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                                     const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
                                     int n_slots, const uint32_t *lut_pool) {
     const size_t lds = k2_lds_bytes(n_slots, LB);
-    static bool configured = false;  // more than 64 KB of dynamic LDS has to be allowed once per kernel
-    if (!configured) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&huffman_decode_kernel<kHuffWaves, LB>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes(LB == 11 ? 4 : kMaxHuffSlots, LB));
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};
+    const hipError_t ea = allow_dynamic_lds(reinterpret_cast<const void *>(&huffman_decode_kernel<kHuffWaves, LB>),
+                                            (int)k2_lds_bytes(LB == 11 ? 4 : kMaxHuffSlots, LB), configured);
+    if (ea != hipSuccess) return ea;
     hipLaunchKernelGGL((huffman_decode_kernel<kHuffWaves, LB>), dim3(n_work), dim3(64 * kHuffWaves), lds, stream, data, scans, work,
                        ends, status, huff_pool, coefs, n_slots, lut_pool);
     return hipGetLastError();
@@ -3507,13 +3520,9 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
     if (e != hipSuccess) return e;
     const int waves = subseq_final_waves(n_slots);
     const size_t lds_final = (size_t)n_slots * kSfTabBytes + (size_t)waves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
-    static bool configured = false;  // more than 64 KB of dynamic LDS has to be allowed once per kernel
-    if (!configured) {
-        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&subseq_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  160 * 1024);
-        if (ea != hipSuccess) return ea;
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};
+    const hipError_t ea = allow_dynamic_lds(reinterpret_cast<const void *>(&subseq_final_kernel), 160 * 1024, configured);
+    if (ea != hipSuccess) return ea;
     // final_work: (scan, first subsequence) per workgroup of waves * 64 lanes (the rounds' work list is per 256)
     hipLaunchKernelGGL(subseq_final_kernel, dim3(n_final_work), dim3(64 * waves), lds_final, stream, udata, scans, final_work, ends_u, status,
                        huff_pool, lut_pool, final_state, first_block, (const int4 *)dc_entry, coefs, n_slots);
