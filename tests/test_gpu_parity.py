@@ -617,6 +617,7 @@ def test_progressive_spin_budget_exhausted_falls_back_level_by_level(monkeypatch
     """With no polls to spend (JPGPU_PROG_SPIN_BUDGET=0) every follower that is not already satisfied gives up; the host
     sees the internal time-out status and re-issues the step scan level by scan level in fresh launches: same samples."""
     monkeypatch.setenv("JPGPU_PROG_SPIN_BUDGET", "0")
+    monkeypatch.delenv("JPGPU_PROG_NO_PIPELINE", raising=False)  # (the suite is also run under the A/B switches)
     files, refs = _many_small_progressive(300)
     files += [_pillow_progressive(1024, 768, "4:2:0", 85, 77)]
     refs += [po.decode_8bit(files[-1])[0]]
