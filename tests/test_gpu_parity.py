@@ -1310,3 +1310,19 @@ def test_stress_reproducers_match_the_oracle(name):
             if oref is not None:
                 assert ob.output(i) == oref, (name, strip)
         ob.close()
+
+
+def test_offsets_inside_one_image_pass_4_gib():
+    """38 000 x 38 000 4:2:0 (1.44 Gpixel, 8.5 M MCUs): the image's samples (4.33 GB) and its coefficient blocks (4.33 GB) both
+    reach past 2^32 bytes, its entropy segment is ~180 MB -- every in-image offset of K1 / K2 / K3 has to be 64-bit.  With
+    restart intervals (K2) here; the DRI = 0 form and the format's maximum, 65 535 x 65 535, go through
+    tools/trace/huge_image.py (both exact)."""
+    w = h = 38000
+    data = bytes(jpegsynth.encode(w, h, "420", 75, 8, seed=9))
+    outs, results = jl.decode_batch([data])
+    assert results[0].status == 0
+    ref = po.decode_8bit(data)[0]
+    assert outs[0].shape == ref.shape == (h, w, 3)
+    for y0 in range(0, h, 4096):  # in slabs: no 4 GB comparison mask
+        assert np.array_equal(outs[0][y0:y0 + 4096], ref[y0:y0 + 4096]), y0
+
