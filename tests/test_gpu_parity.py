@@ -1326,3 +1326,50 @@ def test_offsets_inside_one_image_pass_4_gib():
     for y0 in range(0, h, 4096):  # in slabs: no 4 GB comparison mask
         assert np.array_equal(outs[0][y0:y0 + 4096], ref[y0:y0 + 4096]), y0
 
+
+def test_empty_and_header_only_inputs_fail_like_the_reference():
+    """No files at all, files of zero / one / two bytes, SOI alone, SOI + EOI, headers without a scan, a frame of zero lines:
+    the same exception class and message as the checker, per file, beside a good neighbour in the same batch."""
+    outs, results = jl.decode_batch([])
+    assert outs == [] and results == []
+    good = bytes(jpegsynth.encode(64, 48, "420", 75, 2, seed=3))
+    sos = good.index(b"\xff\xda")
+    sof = good.index(b"\xff\xc0")
+    cases = {
+        "zero_bytes": b"",
+        "one_byte": b"\xff",
+        "soi_only": b"\xff\xd8",
+        "soi_eoi": b"\xff\xd8\xff\xd9",
+        "not_a_jpeg": b"GIF89a" + bytes(32),
+        "headers_then_eoi": good[:sos] + b"\xff\xd9",
+        "headers_cut": good[:sos],
+        "zero_lines": good[:sof + 5] + b"\x00\x00" + good[sof + 7:],
+        "zero_width": good[:sof + 7] + b"\x00\x00" + good[sof + 9:],
+    }
+    names = list(cases)
+    files = [good] + [cases[n] for n in names] + [good]
+    outs, results = jl.decode_batch(files)
+    ref_good = po.decode_8bit(good)[0]
+    assert results[0].status == 0 and results[-1].status == 0
+    assert np.array_equal(outs[0], ref_good) and np.array_equal(outs[-1], ref_good)
+    kinds = {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException"}
+    for n, res, out in zip(names, results[1:-1], outs[1:-1]):
+        try:
+            ref = po.decode_8bit(cases[n])[0]
+            kind, msg = "OK", ""
+        except po.OracleError as e:
+            ref, kind, msg = None, e.kind, e.message
+        assert kinds[res.status] == kind, (n, kind, msg, res.status, res.detail)
+        if kind == "OK":
+            assert np.array_equal(out, ref), n
+            continue
+        # the message: through the JpegDecoder mirror (SetInput / Identify / Decode raise the reference's exceptions)
+        with pytest.raises(jl.JpegError) as ei:
+            d = jl.JpegDecoder()
+            d.SetInput(cases[n])
+            d.Identify()
+            buf = np.zeros(max(1, d.Width * d.Height * 3), np.uint8)
+            d.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(d.Width, d.Height, 3, buf))
+            d.Decode()
+        assert type(ei.value).__name__ == kind and str(ei.value) == msg, (n, kind, msg, type(ei.value).__name__, str(ei.value))
+
