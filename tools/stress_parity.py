@@ -3,7 +3,8 @@
 
 Pillow / libjpeg-turbo files of random size, quality, sampling, restart interval, progressive / optimize flags:
 decode (YCbCr8 + RGBA) and, for the single-scan baseline ones, the optimizer (both strip settings).  Prints a summary;
-exit code 1 on any mismatch.  Not part of the test suite (it takes minutes with large n)."""
+exit code 1 on any mismatch.  Not part of the test suite (it takes minutes with large n).  STRESS_SCALE=k multiplies the image
+dimensions (1..300 -> k..300k pixels a side)."""
 import io
 import os
 import sys
@@ -11,7 +12,7 @@ import sys
 import numpy as np
 from PIL import Image, ImageFile
 
-ImageFile.MAXBLOCK = 1 << 24  # Pillow sizes its encoder buffer from this for optimize / progressive
+ImageFile.MAXBLOCK = 1 << 27  # Pillow sizes its encoder buffer from this for optimize / progressive (large with STRESS_SCALE)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import jpeglibrary_amd as jl
@@ -19,11 +20,14 @@ from oracle import pyoracle as po
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+scale = int(os.environ.get("STRESS_SCALE", "1"))
 files, kinds = [], []
 for i in range(n):
     w, h = int(rng.integers(1, 301)), int(rng.integers(1, 301))
     if rng.random() < 0.1:
         w, h = int(rng.integers(300, 1200)), int(rng.integers(300, 900))
+    if scale > 1:  # STRESS_SCALE=n: large images (scans of many workgroups / subsequences / streams); use a small n
+        w, h = w * scale, h * scale
     gray = rng.random() < 0.2
     base = rng.integers(0, 256, (h, w, 1 if gray else 3))
     smooth = rng.random() < 0.6
