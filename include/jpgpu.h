@@ -326,6 +326,11 @@ typedef struct jpgpu_encode_params {
     int32_t optimize_coding; /* 1 = EncodeAction's optimizeCoding (EncodeAction.cs:40-46): Huffman tables built from the image's own
                                 statistics (TransformBlocks / BuildHuffmanTables / WritePreparedScanData, JpegEncoder.cs:264-274);
                                 2 = the same with JpegEncoder.MostOptimalCoding (:43) */
+    int32_t restart_interval; /* 0 = none = everything the reference's encoder can write.  n > 0 is an EXTENSION (SURVEY.md 8f N3,
+                                "+ DRI emission"; JpegEncoder has no restart support): a DRI segment in front of SOF0 and, in front
+                                of every MCU whose index is a non-zero multiple of n, one-bit padding to a byte boundary, RSTm
+                                (m modulo 8) and the DC predictors back at zero (T.81 B.2.4.4 / E.1.4: what libjpeg writes, and what
+                                JpegDecoder reads back: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:139-163).  1..65535 */
 } jpgpu_encode_params;
 typedef struct jpgpu_encoder jpgpu_encoder;
 

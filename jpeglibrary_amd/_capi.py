@@ -58,7 +58,7 @@ class ImageResult(C.Structure):
 
 class EncodeParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("components", C.c_int32), ("luma_h", C.c_int32), ("luma_v", C.c_int32),
-                ("quality", C.c_int32), ("input_rgb", C.c_int32), ("optimize_coding", C.c_int32)]
+                ("quality", C.c_int32), ("input_rgb", C.c_int32), ("optimize_coding", C.c_int32), ("restart_interval", C.c_int32)]
 
 
 class IngestStats(C.Structure):

@@ -118,8 +118,8 @@ void rgb_ycc_factors(int32_t out[8]) {
 }
 
 EncodeBatch::~EncodeBatch() {
-    for (DevBuffer *b : {&d_samples_, &d_pixels_, &d_images_, &d_tables_, &d_work_mcu_, &d_work_blk_, &d_work_chunk_, &d_coefs_, &d_bits_, &d_bit_off_,
-                         &d_raw_bits_, &d_raw_, &d_chunk_ff_, &d_out_, &d_out_len_, &d_hist_})
+    for (DevBuffer *b : {&d_samples_, &d_pixels_, &d_images_, &d_tables_, &d_work_mcu_, &d_work_blk_, &d_work_stat_, &d_work_chunk_, &d_coefs_, &d_bits_, &d_bit_off_,
+                         &d_raw_bits_, &d_raw_, &d_marks_, &d_chunk_ff_, &d_out_, &d_out_len_, &d_hist_})
         b->release();
 }
 
@@ -144,7 +144,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
     most_optimal_.assign((size_t)n, 0);
     status_.assign((size_t)n, JPGPU_OK);
     encoded_ = false;
-    std::vector<EncWork> work_mcu, work_blk;
+    std::vector<EncWork> work_mcu, work_blk, work_stat;  // per 128 MCUs | per 256 units (blocks or restart intervals) | per 256 blocks
     uint64_t px_off = 0, coef_off = 0, smp_off = 0;
     for (int i = 0; i < n; i++) {
         const jpgpu_encode_params &p = params[i];
@@ -155,6 +155,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         if (p.width <= 0 || p.height <= 0 || p.width > 65535 || p.height > 65535) return fail(JPGPU_ERR_ARGUMENT, "image dimensions out of range");
         if (p.components != 1 && p.components != 3) return fail(JPGPU_ERR_NOT_SUPPORTED, "1 or 3 components are supported.");
         if (p.input_rgb && p.components != 3) return fail(JPGPU_ERR_ARGUMENT, "RGB input needs 3 components.");
+        if (p.restart_interval < 0 || p.restart_interval > 65535) return fail(JPGPU_ERR_ARGUMENT, "restart interval out of range (0..65535)");
         DevEncImage &im = images_[i];
         memset(&im, 0, sizeof im);
         im.px_off = px_off;
@@ -170,6 +171,9 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         im.bpm = im.luma_h * im.luma_v + (im.components == 3 ? 2 : 0);
         im.total_blocks = im.mcus_per_line * im.mcus_per_column * im.bpm;
         im.input_rgb = p.input_rgb ? 1 : 0;
+        // restart intervals (an extension, see jpgpu_encode_params): block_bits / emit then take one lane per INTERVAL
+        im.restart_interval = (uint32_t)p.restart_interval;
+        im.n_units = im.restart_interval ? (im.mcus_per_line * im.mcus_per_column + im.restart_interval - 1) / im.restart_interval : im.total_blocks;
         if (p.optimize_coding) {
             most_optimal_[i] = p.optimize_coding == 2;  // JpegEncoder.MostOptimalCoding
             optimized_.push_back(i);
@@ -186,7 +190,9 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         smp_off = align_up64(smp_off + (uint64_t)total_mcus * enc_sample_bytes_per_mcu(im.luma_h, im.luma_v, im.components), 256);
         for (uint32_t f = 0; f < total_mcus; f += kEncMcusPerWg) work_mcu.push_back({(uint32_t)i, f});
         im.work_first = (uint32_t)work_blk.size();
-        for (uint32_t f = 0; f < im.total_blocks; f += 256) work_blk.push_back({(uint32_t)i, f});
+        for (uint32_t f = 0; f < im.n_units; f += 256) work_blk.push_back({(uint32_t)i, f});
+        if (p.optimize_coding)
+            for (uint32_t f = 0; f < im.total_blocks; f += 256) work_stat.push_back({(uint32_t)i, f});
 
         // ---- marker segments, in the order Encode() writes them (JpegEncoder.cs:261-280)
         std::vector<uint8_t> &h = headers_[i];
@@ -197,6 +203,12 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         for (int t = 0; t < 2; t++) {
             h.push_back((uint8_t)t);  // precision 0 << 4 | identifier
             for (int k = 0; k < 64; k++) h.push_back((uint8_t)im.quant[t][k]);
+        }
+        if (im.restart_interval) {  // DRI in front of SOF0: the reference's decoder latches it there even without Identify()
+            put_marker(h, 0xDD);
+            put_length(h, 2);
+            h.push_back((uint8_t)(im.restart_interval >> 8));
+            h.push_back((uint8_t)im.restart_interval);
         }
         put_marker(h, 0xC0);  // WriteStartOfFrame (:353-386)
         put_length(h, (uint16_t)(6 + 3 * ncomp));
@@ -240,6 +252,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
     total_blocks_ = coef_off;
     n_work_mcu_ = (int)work_mcu.size();
     n_work_blk_ = (int)work_blk.size();
+    n_work_stat_ = (int)work_stat.size();
 
     std::vector<EncHuffTable> tables(4 + 4 * optimized_.size());
     memset(tables.data(), 0, tables.size() * sizeof(EncHuffTable));
@@ -255,6 +268,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         {&d_hist_, nullptr, 0, (size_t)n * 4 * 256 * sizeof(uint32_t) + 256},
         {&d_work_mcu_, work_mcu.data(), work_mcu.size() * sizeof(EncWork), 0},
         {&d_work_blk_, work_blk.data(), work_blk.size() * sizeof(EncWork), 0},
+        {&d_work_stat_, work_stat.data(), work_stat.size() * sizeof(EncWork), 16},
         {&d_pixels_, nullptr, 0, (size_t)px_off + 256},
         {&d_coefs_, nullptr, 0, (size_t)total_blocks_ * 128 + 256},
         {&d_samples_, nullptr, 0, (size_t)smp_off + 256},
@@ -297,7 +311,7 @@ int EncodeBatch::encode() {
         // optimizeCoding: BuildHuffmanTables (:491-550) -- statistics on the device, JpegHuffmanEncodingTableBuilder.Build on the host
         e = hipMemsetAsync(d_hist_.ptr, 0, (size_t)n * 4 * 256 * sizeof(uint32_t), ctx_->stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(statistics)");
-        e = launch_block_stats(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_blk_.ptr, n_work_blk_,
+        e = launch_block_stats(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_stat_.ptr, n_work_stat_,
                                (const int16_t *)d_coefs_.ptr, (uint32_t *)d_hist_.ptr);
         if (e != hipSuccess) return hip_fail(e, "block_stats_kernel");
         std::vector<uint32_t> hist((size_t)n * 4 * 256);
@@ -367,20 +381,22 @@ int EncodeBatch::encode() {
         for (uint32_t c = 0; c < std::max(chunks, 1u); c++) work_chunk.push_back({(uint32_t)i, c});
         chunk_off += std::max(chunks, 1u);
         raw_off = align_up64(raw_off + raw_len + 64, 256);
-        out_off = align_up64(out_off + im.header_len + 2 * raw_len + 2 + 64, 256);  // every byte may need stuffing
+        // every byte may need stuffing; two marker bytes per restart interval
+        out_off = align_up64(out_off + im.header_len + 2 * raw_len + 2 + 64 + (im.restart_interval ? 2 * (uint64_t)im.n_units : 0), 256);
     }
     n_work_chunk_ = (int)work_chunk.size();
     out_cap_ = out_off;
     const struct {
         DevBuffer *buf;
         size_t bytes;
-    } grow[] = {{&d_raw_, (size_t)raw_off + 256}, {&d_out_, (size_t)out_off + 256}, {&d_chunk_ff_, (size_t)chunk_off * sizeof(uint32_t) + 256},
+    } grow[] = {{&d_raw_, (size_t)raw_off + 256}, {&d_marks_, (size_t)raw_off / 8 + 256}, {&d_out_, (size_t)out_off + 256}, {&d_chunk_ff_, (size_t)chunk_off * sizeof(uint32_t) + 256},
                 {&d_work_chunk_, work_chunk.size() * sizeof(EncWork) + 16}};
     for (const auto &g : grow) {
         e = g.buf->reserve(g.bytes);
         if (e != hipSuccess) return hip_fail(e, "hipMalloc");
     }
     e = hipMemsetAsync(d_raw_.ptr, 0, (size_t)raw_off + 256, ctx_->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_marks_.ptr, 0, (size_t)raw_off / 8 + 256, ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(raw)");
     e = hipMemcpyAsync(d_work_chunk_.ptr, work_chunk.data(), work_chunk.size() * sizeof(EncWork), hipMemcpyHostToDevice, ctx_->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_images_.ptr, images_.data(), (size_t)n * sizeof(DevEncImage), hipMemcpyHostToDevice, ctx_->stream);
@@ -389,10 +405,11 @@ int EncodeBatch::encode() {
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(headers)");
     e = launch_emit(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_blk_.ptr, n_work_blk_, (const EncHuffTable *)d_tables_.ptr,
                     (const int16_t *)d_coefs_.ptr, (const uint32_t *)d_bits_.ptr, (const uint64_t *)d_bit_off_.ptr, (const uint64_t *)d_raw_bits_.ptr,
-                    (uint8_t *)d_raw_.ptr);
+                    (uint8_t *)d_raw_.ptr, (uint32_t *)d_marks_.ptr);
     if (e != hipSuccess) return hip_fail(e, "emit_kernel");
     e = launch_stuff(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_chunk_.ptr, n_work_chunk_, (const uint64_t *)d_raw_bits_.ptr,
-                     (const uint8_t *)d_raw_.ptr, (uint32_t *)d_chunk_ff_.ptr, (uint8_t *)d_out_.ptr, (uint64_t *)d_out_len_.ptr);
+                     (const uint8_t *)d_raw_.ptr, (const uint32_t *)d_marks_.ptr, (uint32_t *)d_chunk_ff_.ptr, (uint8_t *)d_out_.ptr,
+                     (uint64_t *)d_out_len_.ptr);
     if (e != hipSuccess) return hip_fail(e, "stuff kernels");
     out_len_.assign((size_t)n, 0);
     e = hipMemcpyAsync(out_len_.data(), d_out_len_.ptr, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx_->stream);

@@ -44,9 +44,9 @@ class EncodeBatch {
     std::vector<uint64_t> out_len_;
     bool encoded_ = false;
     uint64_t total_blocks_ = 0, out_cap_ = 0;
-    int n_work_mcu_ = 0, n_work_blk_ = 0, n_work_chunk_ = 0;
+    int n_work_mcu_ = 0, n_work_blk_ = 0, n_work_stat_ = 0, n_work_chunk_ = 0;
     DevBuffer d_samples_;  // E1a -> E1b: gathered samples, enc_sample_bytes_per_mcu per MCU
-    DevBuffer d_pixels_, d_images_, d_tables_, d_work_mcu_, d_work_blk_, d_work_chunk_, d_coefs_, d_bits_, d_bit_off_, d_raw_bits_, d_raw_,
+    DevBuffer d_pixels_, d_images_, d_tables_, d_work_mcu_, d_work_blk_, d_work_stat_, d_work_chunk_, d_coefs_, d_bits_, d_bit_off_, d_raw_bits_, d_raw_, d_marks_,
         d_chunk_ff_, d_out_, d_out_len_;
 };
 

@@ -861,7 +861,8 @@ int OptimizeBatch::run() {
                                     (const uint64_t *)d_sub_bitoff_.ptr, (const uint64_t *)d_scan_raw_off_.ptr, (uint8_t *)d_raw_.ptr, n_slots);
         if (e != hipSuccess) return hip_fail(e, "subseq_transcode_kernel<emit>");
         e = launch_stuff(ctx_->stream, (const DevEncImage *)d_simages_.ptr, (const EncWork *)d_swork_chunk_.ptr, (int)work_chunk.size(),
-                         (const uint64_t *)d_sub_totals_.ptr, (const uint8_t *)d_raw_.ptr, (uint32_t *)d_chunk_ff_.ptr, (uint8_t *)d_sout_.ptr,
+                         (const uint64_t *)d_sub_totals_.ptr, (const uint8_t *)d_raw_.ptr, nullptr /* no restart marks: restart_interval is 0 */,
+                         (uint32_t *)d_chunk_ff_.ptr, (uint8_t *)d_sout_.ptr,
                          (uint64_t *)d_sout_len_.ptr);
         if (e != hipSuccess) return hip_fail(e, "stuff kernels");
         e = hipMemcpyAsync(sout_len.data(), d_sout_len_.ptr, sout_len.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx_->stream);

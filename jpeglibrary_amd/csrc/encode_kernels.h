@@ -26,7 +26,8 @@ struct alignas(16) DevEncImage {
                           // != 0 = optimizeCoding (tables built from the image): the TransformBlocks / allocator semantics apply
     uint32_t work_first;  // first workgroup of this image in the per-256-blocks work list (block_bits / emit)
     uint32_t smp_off_256; // gathered samples of the image (E1a -> E1b), offset into the sample buffer in units of 256 bytes
-    uint32_t pad1[2];
+    uint32_t restart_interval;  // MCUs per restart interval, 0 = none (see jpgpu_encode_params)
+    uint32_t n_units;     // lanes of block_bits / emit for this image: its blocks, or its restart intervals
     int32_t r2y[8];       // Fix() factors of the RGB -> YCbCr tables (host: rgb_ycc_factors)
     uint16_t quant[2][64];  // zig-zag quantisation tables: luma, chroma
 };
@@ -55,9 +56,11 @@ hipError_t launch_block_bits(hipStream_t stream, const DevEncImage *images, cons
 hipError_t launch_block_stats(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const int16_t *coefs,
                               uint32_t *hist);
 hipError_t launch_emit(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
-                       const int16_t *coefs, const uint32_t *bits, const uint64_t *wg_base, const uint64_t *raw_bits, uint8_t *raw);
+                       const int16_t *coefs, const uint32_t *bits, const uint64_t *wg_base, const uint64_t *raw_bits, uint8_t *raw,
+                       uint32_t *marks);
 constexpr uint32_t kEncStuffChunk = 4096;
+// marks: one bit per raw byte (word (raw_off >> 5) + (j >> 5), bit j & 31 for byte j of the image): a restart marker follows it
 hipError_t launch_stuff(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const uint64_t *raw_bits,
-                        const uint8_t *raw, uint32_t *chunk_ff, uint8_t *out, uint64_t *out_len);
+                        const uint8_t *raw, const uint32_t *marks, uint32_t *chunk_ff, uint8_t *out, uint64_t *out_len);
 
 }  // namespace jpgpu

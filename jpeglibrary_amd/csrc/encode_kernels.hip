@@ -350,6 +350,7 @@ __device__ __forceinline__ int32_t enc_dc_predictor(const DevEncImage &im, const
     comp = b < ny ? 0u : b - ny + 1u;
     if (comp == 0 && b > 0) return img_coefs[(size_t)enc_source_block(im, mcu * im.bpm + b - 1) * 64];
     if (mcu == 0) return 0;
+    if (im.restart_interval != 0 && mcu % im.restart_interval == 0) return 0;  // first MCU of a restart interval (extension)
     const uint32_t pb = comp == 0 ? ny - 1 : b;
     return img_coefs[(size_t)enc_source_block(im, (mcu - 1) * im.bpm + pb) * 64];
 }
@@ -401,10 +402,27 @@ __global__ __launch_bounds__(256) void block_bits_kernel(const DevEncImage *__re
                                                          uint32_t *__restrict__ bits, uint32_t *__restrict__ wg_bits) {
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
-    const uint32_t blk = wk.first + threadIdx.x;
+    const uint32_t blk = wk.first + threadIdx.x;  // block, or restart interval
     uint32_t n = 0;
-    if (blk < im.total_blocks) {
     const int16_t *img_coefs = coefs + im.coef_off * 64;
+    if (im.restart_interval != 0) {
+        // one lane per restart interval: the bits of all its blocks, rounded up to whole bytes (the interval ends with one-bit
+        // padding and the next one starts on a byte boundary: its marker is not part of the bit stream)
+        if (blk < im.n_units) {
+            const uint32_t first_mcu = blk * im.restart_interval, total_mcus = im.mcus_per_line * im.mcus_per_column;
+            const uint32_t end_mcu = first_mcu + im.restart_interval < total_mcus ? first_mcu + im.restart_interval : total_mcus;
+            for (uint32_t mcu = first_mcu; mcu < end_mcu; mcu++)
+                for (uint32_t b = 0; b < im.bpm; b++) {
+                    uint32_t comp;
+                    const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
+                    const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)enc_source_block(im, mcu * im.bpm + b) * 64);
+                    const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
+                    enc_block_symbols(cv, pred, tables[im.table_base + (comp == 0 ? 0 : 2)], tables[im.table_base + (comp == 0 ? 1 : 3)],
+                                      [&](uint32_t, uint32_t len) { n += len; });
+                }
+            n = (n + 7u) & ~7u;
+        }
+    } else if (blk < im.total_blocks) {
     const uint32_t mcu = blk / im.bpm, b = blk - mcu * im.bpm;
     uint32_t comp;
     const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
@@ -428,7 +446,7 @@ __global__ __launch_bounds__(256) void block_bits_kernel(const DevEncImage *__re
         if (k < (threadIdx.x >> 6)) before += sh_wave[k];
         total += sh_wave[k];
     }
-    if (blk < im.total_blocks) bits[im.coef_off + blk] = before + incl - n;
+    if (blk < im.n_units) bits[im.coef_off + blk] = before + incl - n;
     if (threadIdx.x == 0) wg_bits[blockIdx.x] = total;
 }
 
@@ -482,7 +500,7 @@ __global__ __launch_bounds__(1024) void block_offsets_kernel(const DevEncImage *
     const DevEncImage &im = images[blockIdx.x];
     __shared__ uint64_t sh[1024];
     const uint32_t tid = threadIdx.x;
-    const uint32_t n = (im.total_blocks + 255) / 256;  // workgroups of block_bits_kernel / emit_kernel for this image
+    const uint32_t n = (im.n_units + 255) / 256;  // workgroups of block_bits_kernel / emit_kernel for this image
     const uint32_t per = (n + 1023) / 1024;
     const uint32_t lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
     const uint32_t *src = wg_bits + im.work_first;
@@ -510,17 +528,13 @@ __global__ __launch_bounds__(1024) void block_offsets_kernel(const DevEncImage *
 __global__ __launch_bounds__(256) void emit_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
                                                    const EncHuffTable *__restrict__ tables, const int16_t *__restrict__ coefs,
                                                    const uint32_t *__restrict__ bits, const uint64_t *__restrict__ wg_base,
-                                                   const uint64_t *__restrict__ raw_bits, uint8_t *__restrict__ raw) {
+                                                   const uint64_t *__restrict__ raw_bits, uint8_t *__restrict__ raw,
+                                                   uint32_t *__restrict__ marks) {
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
-    const uint32_t blk = wk.first + threadIdx.x;
-    if (blk >= im.total_blocks) return;
+    const uint32_t blk = wk.first + threadIdx.x;  // block, or restart interval
+    if (blk >= im.n_units) return;
     const int16_t *img_coefs = coefs + im.coef_off * 64;
-    const uint32_t mcu = blk / im.bpm, b = blk - mcu * im.bpm;
-    uint32_t comp;
-    const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
-    const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)enc_source_block(im, blk) * 64);
-    const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
     uint32_t *words = reinterpret_cast<uint32_t *>(raw + im.raw_off);
     const uint64_t start = wg_base[blockIdx.x] + bits[im.coef_off + blk];
     uint64_t wi = start >> 5;            // current word
@@ -542,6 +556,38 @@ __global__ __launch_bounds__(256) void emit_kernel(const DevEncImage *__restrict
             }
         }
     };
+    if (im.restart_interval != 0) {
+        // one lane per restart interval: its blocks, one-bit padding to the byte boundary (ExitBitMode), and a mark on its
+        // last byte when a restart marker follows (the stuffing pass writes RSTm there)
+        const uint32_t first_mcu = blk * im.restart_interval, total_mcus = im.mcus_per_line * im.mcus_per_column;
+        const uint32_t end_mcu = first_mcu + im.restart_interval < total_mcus ? first_mcu + im.restart_interval : total_mcus;
+        uint32_t nbits = 0;
+        auto put_counted = [&](uint32_t code, uint32_t len) {
+            nbits += len;
+            put(code, len);
+        };
+        for (uint32_t mcu = first_mcu; mcu < end_mcu; mcu++)
+            for (uint32_t b = 0; b < im.bpm; b++) {
+                uint32_t comp;
+                const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
+                const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)enc_source_block(im, mcu * im.bpm + b) * 64);
+                const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
+                enc_block_symbols(cv, pred, tables[im.table_base + (comp == 0 ? 0 : 2)], tables[im.table_base + (comp == 0 ? 1 : 3)], put_counted);
+            }
+        const uint32_t rem = (8u - (nbits & 7u)) & 7u;
+        if (rem) put((1u << rem) - 1u, rem);
+        if (fill) atomicOr(&words[wi], __builtin_bswap32(acc));
+        if (blk + 1 < im.n_units) {
+            const uint64_t last_byte = (start >> 3) + ((nbits + 7u) >> 3) - 1u;
+            atomicOr(&marks[(im.raw_off >> 5) + (last_byte >> 5)], 1u << (uint32_t)(last_byte & 31u));
+        }
+        return;
+    }
+    const uint32_t mcu = blk / im.bpm, b = blk - mcu * im.bpm;
+    uint32_t comp;
+    const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
+    const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)enc_source_block(im, blk) * 64);
+    const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
     enc_block_symbols(cv, pred, tables[im.table_base + (comp == 0 ? 0 : 2)], tables[im.table_base + (comp == 0 ? 1 : 3)], put);
     if (blk == im.total_blocks - 1) {
         // ExitBitMode (ref: JpegWriter.cs:123-147): pad the last byte with one-bits
@@ -555,9 +601,17 @@ __global__ __launch_bounds__(256) void emit_kernel(const DevEncImage *__restrict
 
 constexpr uint32_t kStuffChunk = 4096;  // raw bytes per workgroup (256 lanes x 16)
 
+// The 16 mark bits of the raw bytes [first, first + 16) of an image (first is a multiple of 16): a restart marker follows
+// the marked byte.
+__device__ __forceinline__ uint32_t enc_marks16(const DevEncImage &im, const uint32_t *__restrict__ marks, uint64_t first) {
+    if (im.restart_interval == 0) return 0;
+    return (marks[(im.raw_off >> 5) + (first >> 5)] >> (uint32_t)(first & 31u)) & 0xFFFFu;
+}
+
+// chunk_ff: FF bytes of the chunk (the bytes stuffing adds) in the low half, marked bytes (two marker bytes each) in the high half
 __global__ __launch_bounds__(256) void stuff_count_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
                                                           const uint64_t *__restrict__ raw_bits, const uint8_t *__restrict__ raw,
-                                                          uint32_t *__restrict__ chunk_ff) {
+                                                          const uint32_t *__restrict__ marks, uint32_t *__restrict__ chunk_ff) {
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
     const uint64_t raw_len = (raw_bits[wk.image] + 7) >> 3;
@@ -569,6 +623,7 @@ __global__ __launch_bounds__(256) void stuff_count_kernel(const DevEncImage *__r
 #pragma unroll
         for (int j = 0; j < 16; j++)
             if (first + j < raw_len && ((w[j >> 2] >> ((j & 3) * 8)) & 0xFFu) == 0xFFu) n++;
+        n += (uint32_t)__builtin_popcount(enc_marks16(im, marks, first)) << 16;
     }
     __shared__ uint32_t sh;
     if (threadIdx.x == 0) sh = 0;
@@ -582,26 +637,34 @@ __global__ __launch_bounds__(256) void stuff_count_kernel(const DevEncImage *__r
 
 __global__ __launch_bounds__(256) void stuff_write_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
                                                           const uint64_t *__restrict__ raw_bits, const uint8_t *__restrict__ raw,
-                                                          const uint32_t *__restrict__ chunk_ff, uint8_t *__restrict__ out,
-                                                          uint64_t *__restrict__ out_len) {
+                                                          const uint32_t *__restrict__ marks, const uint32_t *__restrict__ chunk_ff,
+                                                          uint8_t *__restrict__ out, uint64_t *__restrict__ out_len) {
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
     const uint64_t raw_len = (raw_bits[wk.image] + 7) >> 3;
     const uint32_t tid = threadIdx.x;
-    // FF bytes in the chunks before this one
-    __shared__ uint32_t sh_before, sh_wave[4];
-    if (tid == 0) sh_before = 0;
+    // FF bytes and marked bytes in the chunks before this one (an image's chunks: a few hundred at most per workgroup)
+    __shared__ uint32_t sh_ff, sh_mk, sh_wave[4];
+    if (tid == 0) sh_ff = 0, sh_mk = 0;
     __syncthreads();
     {
-        uint32_t s = 0;
-        for (uint32_t i = tid; i < wk.first; i += 256) s += chunk_ff[im.chunk_off + i];
+        uint32_t sf = 0, sm = 0;
+        for (uint32_t i = tid; i < wk.first; i += 256) {
+            const uint32_t c = chunk_ff[im.chunk_off + i];
+            sf += c & 0xFFFFu;
+            sm += c >> 16;
+        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if ((tid & 63) == 0 && s) atomicAdd(&sh_before, s);
+        for (int o = 32; o > 0; o >>= 1) {
+            sf += __shfl_xor(sf, o, 64);
+            sm += __shfl_xor(sm, o, 64);
+        }
+        if ((tid & 63) == 0 && sf) atomicAdd(&sh_ff, sf);
+        if ((tid & 63) == 0 && sm) atomicAdd(&sh_mk, sm);
     }
     __syncthreads();
     const uint64_t first = (uint64_t)wk.first * kStuffChunk + (uint64_t)tid * 16;
-    uint32_t w[4] = {0, 0, 0, 0}, mine = 0, valid = 0;
+    uint32_t w[4] = {0, 0, 0, 0}, mine = 0, valid = 0, mk = 0;
     if (first < raw_len) {
         const uint4 v = *reinterpret_cast<const uint4 *>(raw + im.raw_off + first);
         w[0] = v.x;
@@ -611,8 +674,10 @@ __global__ __launch_bounds__(256) void stuff_write_kernel(const DevEncImage *__r
         valid = raw_len - first < 16 ? (uint32_t)(raw_len - first) : 16u;
         for (uint32_t j = 0; j < valid; j++)
             if (((w[j >> 2] >> ((j & 3) * 8)) & 0xFFu) == 0xFFu) mine++;
+        mk = enc_marks16(im, marks, first);
+        mine |= (uint32_t)__builtin_popcount(mk) << 16;
     }
-    // exclusive scan of `mine` over the workgroup
+    // exclusive scan of `mine` (both halves at once: a chunk holds at most 4096 of either) over the workgroup
     uint32_t incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -621,20 +686,26 @@ __global__ __launch_bounds__(256) void stuff_write_kernel(const DevEncImage *__r
     }
     if ((tid & 63) == 63) sh_wave[tid >> 6] = incl;
     __syncthreads();
-    uint32_t before = sh_before;
-    for (uint32_t k = 0; k < (tid >> 6); k++) before += sh_wave[k];
-    before += incl - mine;
-    uint8_t *dst = out + im.out_off + im.header_len + first + before;
+    uint32_t in_chunk = incl - mine;
+    for (uint32_t k = 0; k < (tid >> 6); k++) in_chunk += sh_wave[k];
+    const uint32_t before = sh_ff + (in_chunk & 0xFFFFu);  // bytes stuffing added in front of this lane
+    uint32_t markers = sh_mk + (in_chunk >> 16);            // restart markers written in front of this lane
+    uint8_t *dst = out + im.out_off + im.header_len + first + before + 2ull * markers;
     for (uint32_t j = 0; j < valid; j++) {
         const uint8_t bch = (uint8_t)((w[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
         *dst++ = bch;
         if (bch == 0xFF) *dst++ = 0;
+        if ((mk >> j) & 1u) {  // the interval ends here: RSTm, m counting modulo 8 (never stuffed)
+            *dst++ = 0xFF;
+            *dst++ = (uint8_t)(0xD0u + (markers & 7u));
+            markers++;
+        }
     }
     // the lane holding the last raw byte closes the stream: EOI (WriteEndOfImage :930-933) and the total length
     if (valid && first + valid == raw_len) {
         dst[0] = 0xFF;
         dst[1] = 0xD9;
-        out_len[wk.image] = im.header_len + raw_len + before + mine + 2;
+        out_len[wk.image] = im.header_len + raw_len + before + (mine & 0xFFFFu) + 2ull * markers + 2;
     }
     if (raw_len == 0 && wk.first == 0 && tid == 0) {
         uint8_t *d0 = out + im.out_off + im.header_len;
@@ -669,16 +740,17 @@ hipError_t launch_block_stats(hipStream_t stream, const DevEncImage *images, con
     return hipGetLastError();
 }
 hipError_t launch_emit(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
-                       const int16_t *coefs, const uint32_t *bits, const uint64_t *wg_base, const uint64_t *raw_bits, uint8_t *raw) {
+                       const int16_t *coefs, const uint32_t *bits, const uint64_t *wg_base, const uint64_t *raw_bits, uint8_t *raw,
+                       uint32_t *marks) {
     if (n_work <= 0) return hipSuccess;
-    hipLaunchKernelGGL(emit_kernel, dim3(n_work), dim3(256), 0, stream, images, work, tables, coefs, bits, wg_base, raw_bits, raw);
+    hipLaunchKernelGGL(emit_kernel, dim3(n_work), dim3(256), 0, stream, images, work, tables, coefs, bits, wg_base, raw_bits, raw, marks);
     return hipGetLastError();
 }
 hipError_t launch_stuff(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const uint64_t *raw_bits,
-                        const uint8_t *raw, uint32_t *chunk_ff, uint8_t *out, uint64_t *out_len) {
+                        const uint8_t *raw, const uint32_t *marks, uint32_t *chunk_ff, uint8_t *out, uint64_t *out_len) {
     if (n_work <= 0) return hipSuccess;
-    hipLaunchKernelGGL(stuff_count_kernel, dim3(n_work), dim3(256), 0, stream, images, work, raw_bits, raw, chunk_ff);
-    hipLaunchKernelGGL(stuff_write_kernel, dim3(n_work), dim3(256), 0, stream, images, work, raw_bits, raw, chunk_ff, out, out_len);
+    hipLaunchKernelGGL(stuff_count_kernel, dim3(n_work), dim3(256), 0, stream, images, work, raw_bits, raw, marks, chunk_ff);
+    hipLaunchKernelGGL(stuff_write_kernel, dim3(n_work), dim3(256), 0, stream, images, work, raw_bits, raw, marks, chunk_ff, out, out_len);
     return hipGetLastError();
 }
 

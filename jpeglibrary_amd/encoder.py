@@ -27,9 +27,10 @@ class EncodeBatch:
     def _check(self, rc):
         raise_for_status(rc, _lib.jpgpu_last_error(self.ctx._h))
 
-    def upload(self, images, luma=(2, 2), quality=75, rgb=False, optimize_coding=False):
+    def upload(self, images, luma=(2, 2), quality=75, rgb=False, optimize_coding=False, restart_interval=0):
         """images: list of uint8 arrays (H, W, 3) or (H, W) / (H, W, 1).  luma = sampling factors of the first component.
-        optimize_coding = EncodeAction's switch: Huffman tables built from each image's own statistics."""
+        optimize_coding = EncodeAction's switch: Huffman tables built from each image's own statistics.
+        restart_interval = MCUs between restart markers (0 = none, as the reference's encoder; an extension, see jpgpu.h)."""
         n = len(images)
         ptrs = (C.c_void_p * n)()
         params = (_capi.EncodeParams * n)()
@@ -42,7 +43,7 @@ class EncodeBatch:
             keep.append(a)
             ptrs[i] = a.ctypes.data
             h, w, c = a.shape
-            params[i] = _capi.EncodeParams(w, h, c, luma[0], luma[1], quality, 1 if rgb else 0, int(optimize_coding))
+            params[i] = _capi.EncodeParams(w, h, c, luma[0], luma[1], quality, 1 if rgb else 0, int(optimize_coding), int(restart_interval))
             mcus = (-(-w // (8 * luma[0]))) * (-(-h // (8 * luma[1])))
             self._blocks.append(mcus * (luma[0] * luma[1] + (2 if c == 3 else 0)))
         self._check(_lib.jpgpu_encoder_upload(self._h, ptrs, params, n))
@@ -80,9 +81,9 @@ class EncodeBatch:
             pass
 
 
-def encode_batch(images, luma=(2, 2), quality=75, rgb=False, ctx=None, optimize_coding=False):
+def encode_batch(images, luma=(2, 2), quality=75, rgb=False, ctx=None, optimize_coding=False, restart_interval=0):
     """One-call helper: list of JPEG byte strings."""
-    b = EncodeBatch(ctx).upload(images, luma, quality, rgb, optimize_coding).encode()
+    b = EncodeBatch(ctx).upload(images, luma, quality, rgb, optimize_coding, restart_interval).encode()
     outs = [b.output(i) for i in range(len(b))]
     b.close()
     return outs

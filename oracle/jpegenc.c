@@ -421,6 +421,18 @@ int jref_encode_8bit(const uint8_t *pixels, int width, int height, int component
  * whose chrominance builders stay empty). */
 int jref_encode_8bit_ex(const uint8_t *pixels, int width, int height, int components, int luma_h, int luma_v, int quality,
                         int optimize_coding, uint8_t *out, size_t cap, size_t *out_len, int16_t *coef_tap) {
+    return jref_encode_8bit_dri(pixels, width, height, components, luma_h, luma_v, quality, optimize_coding, 0, out, cap, out_len, coef_tap);
+}
+
+/* restart_interval != 0 is an EXTENSION (SURVEY 8f N3 "+ DRI emission"): the reference's encoder writes no restart markers
+ * at all, so there is no reference behaviour to restate.  The definition is T.81's (B.2.4.4, E.1.4; what libjpeg writes): a DRI
+ * segment -- placed in front of SOF0, where the reference's decoder sees it even without Identify() -- and, in
+ * front of every MCU whose index is a non-zero multiple of the interval, the bit buffer padded with one-bits (ExitBitMode),
+ * RSTm with m counting modulo 8, and every DC predictor back at zero.  The statistics pass of optimizeCoding resets its
+ * predictors at the same MCUs.  What pins it: the golden-pinned decoder restatement decodes such a stream to the coefficients
+ * that went in, and so does libjpeg-turbo. */
+int jref_encode_8bit_dri(const uint8_t *pixels, int width, int height, int components, int luma_h, int luma_v, int quality,
+                         int optimize_coding, int restart_interval, uint8_t *out, size_t cap, size_t *out_len, int16_t *coef_tap) {
     uint16_t q_lum[64], q_chr[64];
     jref_scale_quant_table(k_std_lum, quality, q_lum);
     jref_scale_quant_table(k_std_chr, quality, q_chr);
@@ -452,6 +464,12 @@ int jref_encode_8bit_ex(const uint8_t *pixels, int width, int height, int compon
             w_byte(&w, (uint8_t)((0 << 4) | t));
             for (int i = 0; i < 64; i++) w_byte(&w, (uint8_t)tabs[t][i]);
         }
+    }
+    if (restart_interval > 0) { /* extension: DRI, Lr = 4 */
+        w_marker(&w, 0xDD);
+        w_length(&w, 2);
+        w_byte(&w, (uint8_t)(restart_interval >> 8));
+        w_byte(&w, (uint8_t)restart_interval);
     }
     /* WriteStartOfFrame :353-386 */
     {
@@ -515,13 +533,17 @@ int jref_encode_8bit_ex(const uint8_t *pixels, int width, int height, int compon
         memset(freq, 0, sizeof freq);
         for (int i = 0; i < ncomp; i++) comps[i].dc_predictor = 0;
         for (int row_mcu = 0; row_mcu < mcus_per_column; row_mcu++)
-            for (int col_mcu = 0; col_mcu < mcus_per_line; col_mcu++)
+            for (int col_mcu = 0; col_mcu < mcus_per_line; col_mcu++) {
+                const int mcu_index = row_mcu * mcus_per_line + col_mcu;
+                if (restart_interval > 0 && mcu_index > 0 && mcu_index % restart_interval == 0)
+                    for (int i = 0; i < ncomp; i++) comps[i].dc_predictor = 0;
                 for (int ci = 0; ci < ncomp; ci++) {
                     enc_component *c = &comps[ci];
                     for (int y = 0; y < c->v; y++)
                         for (int x = 0; x < c->h; x++)
                             gather_block(c, BLOCK_REF(ci, col_mcu * c->h + x, row_mcu * c->v + y), freq[2 * c->dc_id], freq[2 * c->ac_id + 1]);
                 }
+            }
         for (int t = 0; t < 4; t++) { /* _huffmanTables.BuildTables: every builder of the collection, in SetHuffmanTable order */
             uint16_t code[256];
             uint8_t len[256];
@@ -590,8 +612,15 @@ int jref_encode_8bit_ex(const uint8_t *pixels, int width, int height, int compon
         int mcus_per_line = (width + 8 * max_h - 1) / (8 * max_h);
         int mcus_per_column = (height + 8 * max_v - 1) / (8 * max_v);
         size_t nblock = 0;
+        int rst = 0;
         for (int row_mcu = 0; row_mcu < mcus_per_column; row_mcu++)
-            for (int col_mcu = 0; col_mcu < mcus_per_line; col_mcu++)
+            for (int col_mcu = 0; col_mcu < mcus_per_line; col_mcu++) {
+                const int mcu_index = row_mcu * mcus_per_line + col_mcu;
+                if (restart_interval > 0 && mcu_index > 0 && mcu_index % restart_interval == 0) {
+                    w_exit_bit_mode(&w);
+                    w_marker(&w, (uint8_t)(0xD0 + (rst++ & 7)));
+                    for (int i = 0; i < ncomp; i++) comps[i].dc_predictor = 0;
+                }
                 for (int ci = 0; ci < ncomp; ci++) {
                     enc_component *c = &comps[ci];
                     for (int y = 0; y < c->v; y++)
@@ -602,6 +631,7 @@ int jref_encode_8bit_ex(const uint8_t *pixels, int width, int height, int compon
                             encode_block(&w, c, block);
                         }
                 }
+            }
         w_exit_bit_mode(&w);
         free(store);
 #undef BLOCK_REF
@@ -624,10 +654,17 @@ int jref_encode_8bit_ex(const uint8_t *pixels, int width, int height, int compon
         int16_t input_buffer[64]; /* ONE buffer for every block (see the header comment) */
         memset(input_buffer, 0, sizeof input_buffer);
         size_t nblock = 0;
+        int rst = 0;
         for (int row_mcu = 0; row_mcu < mcus_per_column; row_mcu++) {
             int offset_y = row_mcu * max_v;
             for (int col_mcu = 0; col_mcu < mcus_per_line; col_mcu++) {
                 int offset_x = col_mcu * max_h;
+                const int mcu_index = row_mcu * mcus_per_line + col_mcu;
+                if (restart_interval > 0 && mcu_index > 0 && mcu_index % restart_interval == 0) {
+                    w_exit_bit_mode(&w);
+                    w_marker(&w, (uint8_t)(0xD0 + (rst++ & 7)));
+                    for (int i = 0; i < ncomp; i++) comps[i].dc_predictor = 0;
+                }
                 for (int ci = 0; ci < ncomp; ci++) {
                     enc_component *c = &comps[ci];
                     for (int y = 0; y < c->v; y++) {

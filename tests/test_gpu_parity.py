@@ -1373,3 +1373,73 @@ def test_empty_and_header_only_inputs_fail_like_the_reference():
             d.Decode()
         assert type(ei.value).__name__ == kind and str(ei.value) == msg, (n, kind, msg, type(ei.value).__name__, str(ei.value))
 
+
+@pytest.mark.parametrize("ri", [1, 2, 5, 8, 64, 5000])
+@pytest.mark.parametrize("w,h,luma,q,opt", [(90, 70, (2, 2), 75, 0), (257, 131, (2, 1), 92, 0), (64, 64, (1, 1), 40, 1), (301, 203, (2, 2), 100, 2),
+                                            (33, 17, (1, 2), 60, 0)])
+def test_encoder_restart_intervals(w, h, luma, q, opt, ri):
+    """The encoder's restart-interval mode (an extension: JpegEncoder has none; SURVEY 8f N3 "+ DRI emission"): DRI in front of
+    SOF0, one-bit padding + RSTm + predictor reset every ri MCUs.  Byte-exact against the checker's definition (T.81 / libjpeg),
+    with standard and optimised tables; the stream decodes -- checker and GPU -- to the pixels of the checker's own stream, its
+    coefficients are the ones that went in, and libjpeg-turbo reads it."""
+    import io
+
+    from PIL import Image
+    rgb = _enc_image(w, h, w * 3 + h + ri)
+    ycc = po.rgb_to_ycbcr8(rgb)
+    ref, ref_coefs = po.encode_8bit(ycc, luma[0], luma[1], q, want_coefficients=True, optimize_coding=opt, restart_interval=ri)
+    b = jl.EncodeBatch().upload([ycc], luma, q, optimize_coding=opt, restart_interval=ri).encode()
+    assert np.array_equal(b.coefficients(0), ref_coefs)
+    out = b.output(0)
+    assert out == ref
+    mcus = -(-w // (8 * luma[0])) * -(-h // (8 * luma[1]))
+    assert out.count(b"\xff\xdd\x00\x04" + bytes([ri >> 8, ri & 255])) == 1
+    outs, results = jl.decode_batch([out])
+    assert results[0].status == 0 and results[0].terminator == 0xD9 and np.array_equal(outs[0], po.decode_8bit(ref)[0])
+    if opt == 0:
+        dec_coefs = po.decode_coefficients(out)[0]
+        assert np.array_equal(np.asarray(dec_coefs).reshape(-1, 64), ref_coefs)
+    im = Image.open(io.BytesIO(out))
+    im.load()
+    assert im.size == (w, h)
+    assert (mcus - 1) // ri == sum(1 for _ in _rst_markers(out))
+
+
+def _rst_markers(data):
+    """Offsets of the RSTm markers of a baseline stream's entropy segment (FF Dn behind SOS; FF 00 is stuffing)."""
+    i = data.index(b"\xff\xda")
+    i += 2 + ((data[i + 2] << 8) | data[i + 3])
+    while i + 1 < len(data):
+        if data[i] == 0xFF and 0xD0 <= data[i + 1] <= 0xD7:
+            yield i
+            i += 2
+        else:
+            i += 1
+
+
+def test_encoder_restart_intervals_in_a_mixed_batch():
+    """Images with and without restart intervals, gray and colour, in one batch (lane per block and lane per interval side by
+    side in the same launches)."""
+    imgs = [po.rgb_to_ycbcr8(_enc_image(96, 64, 1)), po.rgb_to_ycbcr8(_enc_image(50, 70, 2)), po.rgb_to_ycbcr8(_enc_image(256, 256, 3))[..., 0],
+            po.rgb_to_ycbcr8(_enc_image(400, 300, 4))]
+    ris = [0, 3, 4, 7]
+    b = jl.EncodeBatch()
+    n = len(imgs)
+    import ctypes as C
+    from jpeglibrary_amd import _capi
+    ptrs = (C.c_void_p * n)()
+    params = (_capi.EncodeParams * n)()
+    keep = []
+    for i, (im, ri) in enumerate(zip(imgs, ris)):
+        a = np.ascontiguousarray(im if im.ndim == 3 else im[..., None])
+        keep.append(a)
+        ptrs[i] = a.ctypes.data
+        params[i] = _capi.EncodeParams(a.shape[1], a.shape[0], a.shape[2], 2 if a.shape[2] == 3 else 1, 2 if a.shape[2] == 3 else 1, 80, 0, 0, ri)
+    b._check(_capi.lib.jpgpu_encoder_upload(b._h, ptrs, params, n))
+    b._n = n
+    b.encode()
+    for i, (im, ri) in enumerate(zip(imgs, ris)):
+        lum = 2 if im.ndim == 3 else 1
+        assert b.output(i) == po.encode_8bit(im, lum, lum, 80, restart_interval=ri), i
+    b.close()
+

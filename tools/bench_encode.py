@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--quality", type=int, default=75)
+    ap.add_argument("--dri", type=int, default=0, help="restart interval in MCUs (0 = none, the reference encoder's only mode)")
     args = ap.parse_args()
     import jpeglibrary_amd as jl
     from oracle import pyoracle as po
@@ -42,7 +43,7 @@ def main():
     with ThreadPoolExecutor(16) as ex:
         base = list(ex.map(lambda s: image(args.width, args.height, s), range(distinct)))
     imgs = [base[i % distinct] for i in range(args.images)]
-    b = jl.EncodeBatch().upload(imgs, (2, 2), args.quality, rgb=True)
+    b = jl.EncodeBatch().upload(imgs, (2, 2), args.quality, rgb=True, restart_interval=args.dri)
     b.encode()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -50,14 +51,14 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     px = args.images * args.width * args.height
     out0 = b.output(0)
-    ref = po.encode_8bit(po.rgb_to_ycbcr8(imgs[0]), 2, 2, args.quality)
+    ref = po.encode_8bit(po.rgb_to_ycbcr8(imgs[0]), 2, 2, args.quality, restart_interval=args.dri)
     t1 = time.perf_counter()
     n_cpu = min(distinct, 4)
     for i in range(n_cpu):
         po.encode_8bit(po.rgb_to_ycbcr8(imgs[i]), 2, 2, args.quality)
     cpu = n_cpu * args.width * args.height / (time.perf_counter() - t1) / 1e6
     print(json.dumps({"metric": "Mpixels/s encoded (RGB 4:2:0 baseline, standard tables)", "value": round(px / dt / 1e6, 1),
-                      "ms_per_step": round(dt * 1e3, 2), "images": args.images, "bytes_per_image": len(out0),
+                      "ms_per_step": round(dt * 1e3, 2), "images": args.images, "restart_interval": args.dri, "bytes_per_image": len(out0),
                       "byte_exact_vs_oracle": out0 == ref, "cpu_oracle_single_core_Mpx_s": round(cpu, 1)}))
 
 

@@ -237,16 +237,17 @@ for i in range(max(60, n // 4)):
     q = int(rng.integers(1, 101))
     mode = int(rng.integers(0, 3))
     rgb = (not gray) and rng.random() < 0.5
+    ri = int(rng.integers(1, 40)) if rng.random() < 0.4 else 0  # restart interval (the encoder's extension)
     img = rng.integers(0, 256, (h, w) if gray else (h, w, 3)).astype(np.uint8)
     if rng.random() < 0.5:
         img = (img.astype(np.int32) // int(rng.integers(1, 40)) * int(rng.integers(1, 8))).clip(0, 255).astype(np.uint8)
-    groups.setdefault((luma, q, mode, rgb), []).append(img)
-for (luma, q, mode, rgb), imgs in groups.items():
-    e = jl.EncodeBatch().upload(imgs, luma, q, rgb=rgb, optimize_coding=mode).encode()
+    groups.setdefault((luma, q, mode, rgb, ri), []).append(img)
+for (luma, q, mode, rgb, ri), imgs in groups.items():
+    e = jl.EncodeBatch().upload(imgs, luma, q, rgb=rgb, optimize_coding=mode, restart_interval=ri).encode()
     for k, im in enumerate(imgs):
         src = po.rgb_to_ycbcr8(im) if rgb else im
         try:
-            ref = po.encode_8bit(src, luma[0], luma[1], q, optimize_coding=mode)
+            ref = po.encode_8bit(src, luma[0], luma[1], q, optimize_coding=mode, restart_interval=ri)
         except po.OracleError:
             ref = None
         try:
@@ -256,7 +257,7 @@ for (luma, q, mode, rgb), imgs in groups.items():
         n_enc += 1
         if got != ref:
             bad += 1
-            print("encode", luma, q, mode, rgb, im.shape, None if got is None else len(got), None if ref is None else len(ref))
+            print("encode", luma, q, mode, rgb, ri, im.shape, None if got is None else len(got), None if ref is None else len(ref))
     e.close()
 print(f"stress: {n} files, {sum(k[3] for k in kinds)} progressive, {n_opt} optimizer outputs compared, {n_enc} encoder outputs compared, {n_mut} corrupted files, mismatches: {bad}")
 sys.exit(1 if bad else 0)
