@@ -111,3 +111,35 @@ def test_optimize_coding_round_trips_and_shrinks():
         assert Image.open(io.BytesIO(opt)).size == (w, h)
     with pytest.raises(po.OracleError):
         po.encode_8bit(img[..., 0], 1, 1, 75, optimize_coding=True)
+
+
+@pytest.mark.parametrize("ri", [1, 3, 8, 1000])
+@pytest.mark.parametrize("opt", [0, 1])
+def test_restart_interval_extension_round_trips(ri, opt):
+    """The checker's definition of the encoder's restart-interval mode (an extension: the reference's JpegEncoder has none): one DRI
+    segment in front of SOF0, RSTm with m counting modulo 8 in front of every MCU that is a non-zero multiple of the interval,
+    and a stream that the golden-pinned decoder restatement and libjpeg-turbo both read back -- the restatement to exactly the
+    coefficients that went in, and, decoded, to the pixels of the same image encoded without restart markers."""
+    from PIL import Image
+    for (w, h), luma in (((90, 70), (2, 2)), ((37, 29), (2, 1)), ((64, 40), (1, 1))):
+        img = _image(w, h, w + h)
+        data, coefs = po.encode_8bit(img, luma[0], luma[1], 80, want_coefficients=True, optimize_coding=opt, restart_interval=ri)
+        plain = po.encode_8bit(img, luma[0], luma[1], 80, optimize_coding=opt)
+        sof = data.index(b"\xff\xc0")
+        assert data.count(b"\xff\xdd\x00\x04" + bytes([ri >> 8, ri & 255])) == 1 and data.index(b"\xff\xdd") < sof
+        mcus = -(-w // (8 * luma[0])) * -(-h // (8 * luma[1]))
+        i = data.index(b"\xff\xda")
+        i += 2 + ((data[i + 2] << 8) | data[i + 3])
+        seen = []
+        while i + 1 < len(data):
+            if data[i] == 0xFF and 0xD0 <= data[i + 1] <= 0xD7:
+                seen.append(data[i + 1] - 0xD0)
+                i += 2
+            else:
+                i += 1
+        assert seen == [k & 7 for k in range((mcus - 1) // ri)]
+        if not opt:
+            assert np.array_equal(po.decode_coefficients(data)[0], coefs)
+        assert np.array_equal(po.decode_8bit(data)[0], po.decode_8bit(plain)[0])
+        assert Image.open(io.BytesIO(data)).size == (w, h)
+
