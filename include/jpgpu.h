@@ -251,6 +251,27 @@ int jpgpu_batch_progressive_fallbacks(const jpgpu_batch *b);
 int jpgpu_batch_totals(const jpgpu_batch *b, uint64_t *compressed_bytes, uint64_t *blocks, uint64_t *pixels,
                        uint64_t *output_bytes);
 
+/* ------------------------------------------------------------------------------------------------ (1b) several devices
+ * The multi-GPU driver of SURVEY.md 7 step 6 / 8e inside the library: one context, one batch and one host thread per listed
+ * device, image i of a call on device slot i mod G (jpgpu_shard's rule), no exchange between the devices.  Replaces the
+ * caller-side loop "one JpegDecoder per thread" (Threading) for a whole file list.  A device may be listed more than
+ * once (two independent contexts on it).  jpgpu_multi_decode uploads and decodes every shard concurrently and returns when
+ * all of them are done; results and outputs are then read through the shard's batch (jpgpu_batch_result,
+ * jpgpu_batch_output_device / _download_output, ...) at the local index jpgpu_multi_locate gives. */
+typedef struct jpgpu_multi jpgpu_multi;
+int jpgpu_multi_create(const int *devices, int n_devices, jpgpu_multi **out);
+void jpgpu_multi_destroy(jpgpu_multi *m);
+int jpgpu_multi_devices(const jpgpu_multi *m);
+const char *jpgpu_multi_last_error(const jpgpu_multi *m);
+/* Decodes n files in `format`; returns the first non-OK call status of any shard (per-image failures are per-image results, as
+ * with jpgpu_batch_*).  upload_ms / decode_ms (may be NULL): the slowest shard's time in each phase. */
+int jpgpu_multi_decode(jpgpu_multi *m, const uint8_t *const *jpeg, const size_t *len, int n, int format, double *upload_ms,
+                       double *decode_ms);
+/* Where image i of the last jpgpu_multi_decode went: the device slot (index into `devices`) and its index in that slot's batch. */
+int jpgpu_multi_locate(const jpgpu_multi *m, int i, int *slot, int *local_index);
+jpgpu_batch *jpgpu_multi_batch(jpgpu_multi *m, int slot);
+jpgpu_ctx *jpgpu_multi_context(jpgpu_multi *m, int slot);
+
 /* ------------------------------------------------------------------------------------------------ (2) per scan
  * Replaces JpegScanDecoder.ProcessScan(ref JpegReader, JpegScanHeader) for SOF0/SOF1
  * (ref: ScanDecoder/JpegScanDecoder.cs:12-36, ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:51-177).

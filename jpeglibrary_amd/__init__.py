@@ -10,11 +10,12 @@ from .context import Context, default_context, device_count
 from .encoder import EncodeBatch, encode_batch
 from .optimizer import JpegOptimizer, OptimizeBatch, build_optimal_huffman_table, optimize_batch
 from .decoder import JpegBlockOutputWriter, JpegBufferOutputWriter8Bit, JpegDecoder, JpegExtendingOutputWriter
+from .multi import MultiDecoder
 from .errors import (ArgumentException, DeviceError, InvalidDataException, InvalidOperationException, JpegError,
                      NoDeviceError, NotSupportedException)
 
 __all__ = [
-    "Batch", "decode_batch", "EncodeBatch", "encode_batch", "JpegOptimizer", "OptimizeBatch", "optimize_batch", "build_optimal_huffman_table", "Context", "default_context", "device_count", "JpegDecoder", "JpegBlockOutputWriter",
+    "Batch", "decode_batch", "MultiDecoder", "EncodeBatch", "encode_batch", "JpegOptimizer", "OptimizeBatch", "optimize_batch", "build_optimal_huffman_table", "Context", "default_context", "device_count", "JpegDecoder", "JpegBlockOutputWriter",
     "JpegBufferOutputWriter8Bit", "JpegExtendingOutputWriter", "FMT_INTERLEAVED_U8", "FMT_PLANAR_U8", "FMT_PLANAR_I16", "FMT_RGB_U8", "FMT_RGBA_U8", "FMT_EXTENDED_U16",
     "JpegError", "InvalidDataException", "InvalidOperationException", "NotSupportedException", "ArgumentException",
     "DeviceError", "NoDeviceError",

@@ -78,6 +78,15 @@ SYMBOLS = [
     ("jpgpu_last_error", C.c_char_p, [_P]),
     ("jpgpu_set_host_threads", C.c_int, [_P, C.c_int]),
     ("jpgpu_shard", None, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("jpgpu_multi_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
+    ("jpgpu_multi_destroy", None, [_P]),
+    ("jpgpu_multi_devices", C.c_int, [_P]),
+    ("jpgpu_multi_last_error", C.c_char_p, [_P]),
+    ("jpgpu_multi_decode", C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double)]),
+    ("jpgpu_multi_locate", C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("jpgpu_multi_batch", _P, [_P, C.c_int]),
+    ("jpgpu_multi_context", _P, [_P, C.c_int]),
     ("jpgpu_batch_ingest_stats", C.c_int, [_P, C.POINTER(IngestStats)]),
     ("jpgpu_batch_progressive_fallbacks", C.c_int, [_P]),
     ("jpgpu_status_string", C.c_char_p, [C.c_int]),

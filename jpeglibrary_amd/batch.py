@@ -17,6 +17,11 @@ FMT_INTERLEAVED_U8, FMT_PLANAR_U8, FMT_PLANAR_I16 = _capi.FMT_INTERLEAVED_U8, _c
 FMT_RGB_U8, FMT_RGBA_U8, FMT_EXTENDED_U16 = _capi.FMT_RGB_U8, _capi.FMT_RGBA_U8, _capi.FMT_EXTENDED_U16
 
 
+class _BorrowedContext:
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+
+
 class Batch:
     def __init__(self, ctx: Context = None):
         self.ctx = ctx or default_context()
@@ -153,10 +158,21 @@ class Batch:
         coefs = np.ascontiguousarray(coefs, dtype=np.int16).reshape(-1, 64)
         self._check(_lib.jpgpu_batch_upload_coefficients(self._h, i, coefs.ctypes.data, coefs.shape[0]))
 
+    @classmethod
+    def _borrowed(cls, handle, ctx_handle, fmt):
+        """A view on a batch some other object owns (MultiDecoder's shards): same accessors, close() leaves it alone."""
+        self = cls.__new__(cls)
+        self.ctx = _BorrowedContext(ctx_handle)
+        self._h = C.c_void_p(handle)
+        self.format = fmt
+        self._keep = None
+        self._owned = False
+        return self
+
     def close(self):
-        if self._h:
+        if self._h and getattr(self, "_owned", True):
             _lib.jpgpu_batch_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:

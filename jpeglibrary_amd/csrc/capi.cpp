@@ -3,9 +3,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <exception>
 #include <memory>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "../../include/jpgpu.h"
 #include "device_batch.h"
@@ -102,6 +105,124 @@ void jpgpu_shard(int n_items, int rank, int world, int *first, int *stride, int 
 }
 
 const char *jpgpu_last_error(const jpgpu_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
+
+// ---------------------------------------------------------------------------------------------- several devices
+// one context + batch + host thread per device slot, image i on slot i mod G, nothing shared.
+struct jpgpu_multi {
+    struct Slot {
+        jpgpu_ctx *ctx = nullptr;
+        jpgpu_batch *batch = nullptr;
+        std::vector<const uint8_t *> files;
+        std::vector<size_t> lens;
+        int status = JPGPU_OK;
+        double upload_ms = 0, decode_ms = 0;
+    };
+    std::vector<Slot> slots;
+    int n_items = 0;
+    std::string last_error;
+};
+
+int jpgpu_multi_create(const int *devices, int n_devices, jpgpu_multi **out) {
+    if (!out) return JPGPU_ERR_ARGUMENT;
+    *out = nullptr;
+    if (!devices || n_devices <= 0) {
+        g_create_error = "jpgpu_multi_create: no devices";
+        return JPGPU_ERR_ARGUMENT;
+    }
+    std::unique_ptr<jpgpu_multi> m(new (std::nothrow) jpgpu_multi);
+    if (!m) return JPGPU_ERR_OUT_OF_MEMORY;
+    m->slots.resize((size_t)n_devices);
+    int rc = JPGPU_OK;
+    for (int s = 0; s < n_devices && rc == JPGPU_OK; s++) {
+        rc = jpgpu_create(devices[s], &m->slots[(size_t)s].ctx);
+        if (rc == JPGPU_OK) rc = jpgpu_batch_create(m->slots[(size_t)s].ctx, &m->slots[(size_t)s].batch);
+    }
+    if (rc != JPGPU_OK) {
+        jpgpu_multi_destroy(m.release());
+        return rc;
+    }
+    *out = m.release();
+    return JPGPU_OK;
+}
+
+void jpgpu_multi_destroy(jpgpu_multi *m) {
+    if (!m) return;
+    for (jpgpu_multi::Slot &s : m->slots) {
+        if (s.batch) jpgpu_batch_destroy(s.batch);
+        if (s.ctx) jpgpu_destroy(s.ctx);
+    }
+    delete m;
+}
+
+int jpgpu_multi_devices(const jpgpu_multi *m) { return m ? (int)m->slots.size() : 0; }
+const char *jpgpu_multi_last_error(const jpgpu_multi *m) { return m ? m->last_error.c_str() : g_create_error.c_str(); }
+
+int jpgpu_multi_decode(jpgpu_multi *m, const uint8_t *const *jpeg, const size_t *len, int n, int format, double *upload_ms,
+                       double *decode_ms) {
+    if (!m || n < 0 || (n > 0 && (!jpeg || !len))) return JPGPU_ERR_ARGUMENT;
+    const int world = (int)m->slots.size();
+    m->n_items = n;
+    m->last_error.clear();
+    for (int s = 0; s < world; s++) {
+        jpgpu_multi::Slot &sl = m->slots[(size_t)s];
+        int first, stride, count;
+        jpgpu_shard(n, s, world, &first, &stride, &count);
+        sl.files.clear();
+        sl.lens.clear();
+        for (int k = 0, i = first; k < count; k++, i += stride) {
+            sl.files.push_back(jpeg[i]);
+            sl.lens.push_back(len[i]);
+        }
+        sl.status = JPGPU_OK;
+        sl.upload_ms = sl.decode_ms = 0;
+    }
+    // one host thread per device slot: upload (header parse, staging, H2D), decode, wait -- the shards never meet
+    auto run = [format](jpgpu_multi::Slot *sl) {
+        using clk = std::chrono::steady_clock;
+        const auto t0 = clk::now();
+        int rc = jpgpu_batch_upload(sl->batch, sl->files.data(), sl->lens.data(), (int)sl->files.size(), format);
+        const auto t1 = clk::now();
+        if (rc == JPGPU_OK) rc = jpgpu_batch_decode(sl->batch);
+        if (rc == JPGPU_OK) rc = jpgpu_batch_sync(sl->batch);
+        const auto t2 = clk::now();
+        sl->status = rc;
+        sl->upload_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        sl->decode_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    };
+    try {
+        std::vector<std::thread> threads;
+        for (int s = 1; s < world; s++) threads.emplace_back(run, &m->slots[(size_t)s]);
+        run(&m->slots[0]);
+        for (std::thread &t : threads) t.join();
+    } catch (const std::exception &e) {
+        m->last_error = e.what();
+        return JPGPU_ERR_DEVICE;
+    }
+    int rc = JPGPU_OK;
+    double up = 0, dec = 0;
+    for (int s = 0; s < world; s++) {
+        const jpgpu_multi::Slot &sl = m->slots[(size_t)s];
+        if (sl.status != JPGPU_OK && rc == JPGPU_OK) {
+            rc = sl.status;
+            m->last_error = std::string("device slot ") + std::to_string(s) + ": " + jpgpu_last_error(sl.ctx);
+        }
+        up = std::max(up, sl.upload_ms);
+        dec = std::max(dec, sl.decode_ms);
+    }
+    if (upload_ms) *upload_ms = up;
+    if (decode_ms) *decode_ms = dec;
+    return rc;
+}
+
+int jpgpu_multi_locate(const jpgpu_multi *m, int i, int *slot, int *local_index) {
+    if (!m || i < 0 || i >= m->n_items) return JPGPU_ERR_ARGUMENT;
+    const int world = (int)m->slots.size();
+    if (slot) *slot = i % world;
+    if (local_index) *local_index = i / world;
+    return JPGPU_OK;
+}
+jpgpu_batch *jpgpu_multi_batch(jpgpu_multi *m, int slot) { return m && slot >= 0 && slot < (int)m->slots.size() ? m->slots[(size_t)slot].batch : nullptr; }
+jpgpu_ctx *jpgpu_multi_context(jpgpu_multi *m, int slot) { return m && slot >= 0 && slot < (int)m->slots.size() ? m->slots[(size_t)slot].ctx : nullptr; }
 
 const char *jpgpu_status_string(int status) {
     switch (status) {

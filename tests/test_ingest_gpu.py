@@ -260,3 +260,43 @@ def test_bench_runs_its_rccl_path_under_torchrun_with_one_rank():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["parity_spot_check"] == "bit-exact vs oracle"
+
+
+def test_multi_device_driver_shards_round_robin_and_matches_the_oracle():
+    """jpgpu_multi_*: the in-library driver of SURVEY 8e.  One MI355X here, so the device is listed three times (three
+    independent contexts, three host threads uploading and decoding at once): image i lands on slot i mod 3 at local index
+    i // 3, every image equals the checker -- baseline, DRI = 0, progressive and a corrupted file among them -- and the same
+    list through one plain batch gives the same bytes."""
+    import io
+
+    from PIL import Image
+    files = []
+    for i in range(23):
+        files.append(bytes(jpegsynth.encode(64 + 16 * (i % 7), 48 + 8 * (i % 5), ["420", "444", "422"][i % 3], 60 + i, [0, 2, 5][i % 3], seed=100 + i)))
+    rng = np.random.default_rng(4)
+    for k in range(4):
+        buf = io.BytesIO()
+        Image.fromarray(rng.integers(0, 256, (40 + 9 * k, 56 + 7 * k, 3), dtype=np.uint8)).save(buf, format="JPEG", quality=70 + k, progressive=True)
+        files.append(buf.getvalue())
+    files.append(files[3][: len(files[3]) // 2])  # truncated: a per-image failure, not a failure of the call
+    m = jl.MultiDecoder([0, 0, 0])
+    m.decode(files)
+    assert len(m) == len(files)
+    plain_outs, plain_results = jl.decode_batch(files)
+    for i, f in enumerate(files):
+        assert m.locate(i) == (i % 3, i // 3)
+        res = m.result(i)
+        assert res.status == plain_results[i].status and res.detail == plain_results[i].detail
+        if res.status == 0:
+            assert np.array_equal(m.output(i), po.decode_8bit(f)[0]), i
+            assert np.array_equal(m.output(i), plain_outs[i]), i
+    assert plain_results[-1].status != 0
+    assert m.upload_ms > 0 and m.decode_ms > 0
+    # a second call on the same driver, another format, fewer files than slots
+    m.decode(files[:2], jl.FMT_RGBA_U8)
+    for i in range(2):
+        assert np.array_equal(m.output(i), jl.decode_batch([files[i]], jl.FMT_RGBA_U8)[0][0])
+    m.close()
+    with pytest.raises(jl.JpegError):
+        jl.MultiDecoder([])
+
