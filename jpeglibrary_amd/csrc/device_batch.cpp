@@ -1281,18 +1281,19 @@ int DeviceBatch::run_progressive() {
     // One pipelined launch, or one launch per level?  One wave per workgroup, LDS bounds them per CU.
     //  - up to three quarters of what the CUs hold: pipelined with the count-in gate (every workgroup resident, see the
     //    residency rule in progressive_stream_kernel; the kernel itself checks);
-    //  - up to twice what the CUs hold: still pipelined, no gate -- the work list is ordered by level and MI355X starts
+    //  - up to one and a half times what the CUs hold: still pipelined, no gate -- the work list is ordered by level and MI355X starts
     //    workgroups in list order, so a follower never holds a slot its producer still needs; should that ever not hold, the
     //    bounded spin gives up and fetch_status() falls back to level by level.  Measured (4K 4:2:0 progressive, ms per batch,
-    //    level by level vs pipelined): 448 frames 651 / 402, 640: 716 / 588, 896: 791 / 727, 1024: 832 / 791;
-    //  - beyond: level by level (2048 frames: 1295 vs 1426 pipelined -- by then every level fills the machine on its own).
+    //    level by level vs pipelined): 448 frames 651 / 402, 640: 716 / 588, 896: 791 / 727;
+    //  - beyond: level by level (1024 frames: 832 vs 790-885 pipelined, run to run; 2048 frames: 1295 vs 1426 -- by then
+    //    every level fills the machine on its own).
     const int n_streams = prog_stream_begin_.back() - prog_stream_begin_.front();
     const size_t lds_per_wg = (progressive_stream_lds_bytes(n_huff_slots_) + 1023) / 1024 * 1024;
     const int cus = ctx_->num_cus > 0 ? ctx_->num_cus : 256;
     const int per_cu = (int)std::min<size_t>(32, (160u << 10) / lds_per_wg);
     const bool force = getenv("JPGPU_PROG_FORCE_PIPELINE") != nullptr;  // experiments: pipelined without the gate, any size
     const bool resident = n_streams <= per_cu * 3 / 4 * cus;
-    const bool fits = resident || n_streams <= 2 * per_cu * cus || force;
+    const bool fits = resident || n_streams <= 3 * per_cu * cus / 2 || force;
     const int launch_mode = resident && !force ? 1 : 2;
     if (prog_pipelined_ && fits && !dbg_max) {
         // every scan is one stream: one launch, the work list ordered by level; dependent scans follow their producers' progress
