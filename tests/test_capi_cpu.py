@@ -61,6 +61,10 @@ def test_no_cpu_fallback_without_gpu():
         jl.Context(0)
     with pytest.raises(jl.NoDeviceError):
         jl.JpegDecoder()
+    with pytest.raises(jl.NoDeviceError):
+        jl.MultiDecoder([0, 1])  # the multi-device driver creates its contexts up front: no device, no driver
+    with pytest.raises(jl.NoDeviceError):
+        jl.EncodeBatch()
     # host-only decoder: parsing works, Decode() refuses (scans run on the GPU only)
     import numpy as np
     from golden_util import read_jpeg
