@@ -359,6 +359,11 @@ int jpgpu_encoder_create(jpgpu_ctx *ctx, jpgpu_encoder **out);
 void jpgpu_encoder_destroy(jpgpu_encoder *e);
 /* SetInputReader for n images (host parse of nothing: pixels go to HBM as they are) */
 int jpgpu_encoder_upload(jpgpu_encoder *e, const uint8_t *const *pixels, const jpgpu_encode_params *params, int n);
+/* SetQuantizationTable(new JpegQuantizationTable(0, identifier, elements)) for image i (JpegEncoder.cs:102-126): the caller's own
+ * table instead of the standard one scaled by `quality`.  identifier 0 = the first component's table, 1 = the other components';
+ * 64 elements in zig-zag order, element precision 0, so 1..255 each (the segment stores bytes; 0 would divide by zero in
+ * ZigZagAndQuantizeBlock).  Between jpgpu_encoder_upload and jpgpu_encoder_encode. */
+int jpgpu_encoder_set_quantization_table(jpgpu_encoder *e, int i, int identifier, const uint16_t *zigzag64);
 /* Encode(): FDCT + quantise, Huffman code lengths, bit emission, byte stuffing -- all on the device */
 int jpgpu_encoder_encode(jpgpu_encoder *e);
 int jpgpu_encoder_encoded_size(const jpgpu_encoder *e, int i, size_t *bytes);

@@ -10,12 +10,15 @@ from .context import Context, default_context, device_count
 from .encoder import EncodeBatch, encode_batch
 from .optimizer import JpegOptimizer, OptimizeBatch, build_optimal_huffman_table, optimize_batch
 from .decoder import JpegBlockOutputWriter, JpegBufferOutputWriter8Bit, JpegDecoder, JpegExtendingOutputWriter
+from .jpeg_encoder import (JpegBufferInputReader, JpegEncoder, JpegHuffmanEncodingTable, JpegQuantizationTable, JpegStandardHuffmanEncodingTable,
+                           JpegStandardQuantizationTable)
 from .multi import MultiDecoder
 from .errors import (ArgumentException, DeviceError, InvalidDataException, InvalidOperationException, JpegError,
                      NoDeviceError, NotSupportedException)
 
 __all__ = [
-    "Batch", "decode_batch", "MultiDecoder", "EncodeBatch", "encode_batch", "JpegOptimizer", "OptimizeBatch", "optimize_batch", "build_optimal_huffman_table", "Context", "default_context", "device_count", "JpegDecoder", "JpegBlockOutputWriter",
+    "Batch", "decode_batch", "MultiDecoder", "JpegEncoder", "JpegQuantizationTable", "JpegStandardQuantizationTable", "JpegHuffmanEncodingTable",
+    "JpegStandardHuffmanEncodingTable", "JpegBufferInputReader", "EncodeBatch", "encode_batch", "JpegOptimizer", "OptimizeBatch", "optimize_batch", "build_optimal_huffman_table", "Context", "default_context", "device_count", "JpegDecoder", "JpegBlockOutputWriter",
     "JpegBufferOutputWriter8Bit", "JpegExtendingOutputWriter", "FMT_INTERLEAVED_U8", "FMT_PLANAR_U8", "FMT_PLANAR_I16", "FMT_RGB_U8", "FMT_RGBA_U8", "FMT_EXTENDED_U16",
     "JpegError", "InvalidDataException", "InvalidOperationException", "NotSupportedException", "ArgumentException",
     "DeviceError", "NoDeviceError",

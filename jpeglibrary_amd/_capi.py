@@ -142,6 +142,7 @@ SYMBOLS = [
     ("jpgpu_encoder_create", C.c_int, [_P, C.POINTER(_P)]),
     ("jpgpu_encoder_destroy", None, [_P]),
     ("jpgpu_encoder_upload", C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(EncodeParams), C.c_int]),
+    ("jpgpu_encoder_set_quantization_table", C.c_int, [_P, C.c_int, C.c_int, C.c_void_p]),
     ("jpgpu_encoder_encode", C.c_int, [_P]),
     ("jpgpu_encoder_encoded_size", C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
     ("jpgpu_encoder_download", C.c_int, [_P, C.c_int, C.c_void_p, C.c_size_t]),

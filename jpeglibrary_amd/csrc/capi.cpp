@@ -847,6 +847,9 @@ void jpgpu_encoder_destroy(jpgpu_encoder *enc) { delete enc; }
 int jpgpu_encoder_upload(jpgpu_encoder *enc, const uint8_t *const *pixels, const jpgpu_encode_params *params, int n) {
     JPGPU_GUARD(enc, enc->impl.upload(pixels, params, n));
 }
+int jpgpu_encoder_set_quantization_table(jpgpu_encoder *enc, int i, int identifier, const uint16_t *zigzag64) {
+    JPGPU_GUARD(enc, enc->impl.set_quantization_table(i, identifier, zigzag64));
+}
 int jpgpu_encoder_encode(jpgpu_encoder *enc) { JPGPU_GUARD(enc, enc->impl.encode()); }
 int jpgpu_encoder_encoded_size(const jpgpu_encoder *enc, int i, size_t *bytes) { return enc ? enc->impl.encoded_size(i, bytes) : JPGPU_ERR_ARGUMENT; }
 int jpgpu_encoder_download(jpgpu_encoder *enc, int i, void *dst, size_t cap) { JPGPU_GUARD(enc, enc->impl.download(i, dst, cap)); }

@@ -296,6 +296,23 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
     return e == hipSuccess ? JPGPU_OK : hip_fail(e, "hipStreamSynchronize(upload)");
 }
 
+int EncodeBatch::set_quantization_table(int i, int identifier, const uint16_t *zigzag64) {
+    if (i < 0 || i >= (int)images_.size() || !zigzag64) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_encoder_set_quantization_table: bad argument");
+    if (identifier != 0 && identifier != 1) return fail(JPGPU_ERR_NOT_SUPPORTED, "Quantization table identifiers 0 and 1 are supported.");
+    for (int k = 0; k < 64; k++)
+        if (zigzag64[k] == 0 || zigzag64[k] > 255) return fail(JPGPU_ERR_ARGUMENT, "Quantization table elements must be in 1..255 (element precision 0).");
+    DevEncImage &im = images_[(size_t)i];
+    // the DQT segment upload() wrote: SOI, FF DB, length, then per table one identifier byte + 64 elements
+    const size_t at = 2 + 2 + 2 + (size_t)identifier * 65 + 1;
+    for (int k = 0; k < 64; k++) {
+        im.quant[identifier][k] = zigzag64[k];
+        headers_[(size_t)i][at + (size_t)k] = (uint8_t)zigzag64[k];
+        headers_pre_[(size_t)i][at + (size_t)k] = (uint8_t)zigzag64[k];
+    }
+    encoded_ = false;
+    return JPGPU_OK;
+}
+
 int EncodeBatch::encode() {
     hipError_t e = hipSetDevice(ctx_->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");

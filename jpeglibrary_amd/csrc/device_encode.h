@@ -16,6 +16,7 @@ class EncodeBatch {
     explicit EncodeBatch(jpgpu_ctx *ctx) : ctx_(ctx) {}
     ~EncodeBatch();
     int upload(const uint8_t *const *pixels, const jpgpu_encode_params *params, int n);  // SetInputReader x n (+ H2D)
+    int set_quantization_table(int i, int identifier, const uint16_t *zigzag64);           // SetQuantizationTable of image i
     int encode();                                                                        // JpegEncoder.Encode() x n
     int size() const { return (int)images_.size(); }
     int encoded_size(int i, size_t *bytes) const;

@@ -50,6 +50,12 @@ class EncodeBatch:
         self._n = n
         return self
 
+    def set_quantization_table(self, i, identifier, zigzag64):
+        """SetQuantizationTable for image i: the caller's own table (zig-zag order, 1..255) instead of the scaled standard one."""
+        q = np.ascontiguousarray(zigzag64, dtype=np.uint16).reshape(64)
+        self._check(_lib.jpgpu_encoder_set_quantization_table(self._h, i, identifier, q.ctypes.data))
+        return self
+
     def encode(self):
         self._check(_lib.jpgpu_encoder_encode(self._h))
         return self

@@ -433,9 +433,20 @@ int jref_encode_8bit_ex(const uint8_t *pixels, int width, int height, int compon
  * that went in, and so does libjpeg-turbo. */
 int jref_encode_8bit_dri(const uint8_t *pixels, int width, int height, int components, int luma_h, int luma_v, int quality,
                          int optimize_coding, int restart_interval, uint8_t *out, size_t cap, size_t *out_len, int16_t *coef_tap) {
+    return jref_encode_8bit_tables(pixels, width, height, components, luma_h, luma_v, quality, NULL, NULL, optimize_coding, restart_interval, out,
+                                   cap, out_len, coef_tap);
+}
+
+/* quant_lum / quant_chr != NULL: the tables the caller handed to SetQuantizationTable (identifiers 0 and 1, zig-zag order, element
+ * precision 0: JpegEncoder.cs:102-126) instead of the standard ones scaled by `quality`. */
+int jref_encode_8bit_tables(const uint8_t *pixels, int width, int height, int components, int luma_h, int luma_v, int quality,
+                            const uint16_t *quant_lum, const uint16_t *quant_chr, int optimize_coding, int restart_interval, uint8_t *out,
+                            size_t cap, size_t *out_len, int16_t *coef_tap) {
     uint16_t q_lum[64], q_chr[64];
-    jref_scale_quant_table(k_std_lum, quality, q_lum);
-    jref_scale_quant_table(k_std_chr, quality, q_chr);
+    jref_scale_quant_table(k_std_lum, quality > 0 ? quality : 50, q_lum);
+    jref_scale_quant_table(k_std_chr, quality > 0 ? quality : 50, q_chr);
+    if (quant_lum) memcpy(q_lum, quant_lum, sizeof q_lum);
+    if (quant_chr) memcpy(q_chr, quant_chr, sizeof q_chr);
     enc_table t_dc_lum, t_ac_lum, t_dc_chr, t_ac_chr;
     enc_table_build(&t_dc_lum, k_dc_lum_len, k_dc_val, 12);
     enc_table_build(&t_ac_lum, k_ac_lum_len, k_ac_lum_val, 162);

@@ -164,6 +164,9 @@ void jref_fdct_quantize_block(const int16_t *samples, const uint16_t *quant_zigz
 int jref_encode_8bit(const uint8_t *pixels, int width, int height, int components, int luma_h, int luma_v, int quality,
                      uint8_t *out, size_t cap, size_t *out_len, int16_t *coef_tap);
 /* the same with EncodeAction's optimizeCoding switch (tables built from the image's own statistics); 2 = "No symbol is recorded." */
+int jref_encode_8bit_tables(const uint8_t *pixels, int width, int height, int components, int luma_h, int luma_v, int quality,
+                            const uint16_t *quant_lum, const uint16_t *quant_chr, int optimize_coding, int restart_interval, uint8_t *out,
+                            size_t cap, size_t *out_len, int16_t *coef_tap);
 int jref_encode_8bit_dri(const uint8_t *pixels, int width, int height, int components, int luma_h, int luma_v, int quality,
                          int optimize_coding, int restart_interval, uint8_t *out, size_t cap, size_t *out_len, int16_t *coef_tap);
 int jref_encode_8bit_ex(const uint8_t *pixels, int width, int height, int components, int luma_h, int luma_v, int quality,

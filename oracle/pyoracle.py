@@ -221,18 +221,23 @@ def ycbcr8_to_rgb(ycbcr: np.ndarray, rgba: bool = False, gray: bool = False) -> 
 
 
 def encode_8bit(pixels: np.ndarray, luma_h: int = 2, luma_v: int = 2, quality: int = 75, want_coefficients: bool = False,
-                optimize_coding: bool = False, restart_interval: int = 0):
+                optimize_coding: bool = False, restart_interval: int = 0, quant_tables=None):
     """The reference encoder's EncodeAction sequence (standard tables, no optimisation) on an interleaved 8-bit image
     (H, W, C) with C = 3 (Y, Cb, Cr) or 1.  Returns the JPEG bytes (and the quantised zig-zag blocks in encoding order).
-    restart_interval != 0: the extension of jref_encode_8bit_dri (the reference encoder has no restart markers)."""
+    restart_interval != 0: the extension of jref_encode_8bit_dri (the reference encoder has no restart markers).
+    quant_tables = (luminance, chrominance) uint16[64] in zig-zag order: SetQuantizationTable with the caller's own tables."""
     L = lib()
     a = np.ascontiguousarray(pixels, dtype=np.uint8)
     if a.ndim == 2:
         a = a.reshape(a.shape[0], a.shape[1], 1)
     h, w, c = a.shape
-    L.jref_encode_8bit_dri.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                       C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
-    L.jref_encode_8bit_dri.restype = C.c_int
+    L.jref_encode_8bit_tables.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+    L.jref_encode_8bit_tables.restype = C.c_int
+    ql = qc = None
+    if quant_tables is not None:
+        ql = np.ascontiguousarray(quant_tables[0], dtype=np.uint16).reshape(64)
+        qc = np.ascontiguousarray(quant_tables[1], dtype=np.uint16).reshape(64)
     ncomp = 1 if c == 1 else 3
     mh, mv = luma_h, luma_v
     mcus = (-(-w // (8 * mh))) * (-(-h // (8 * mv)))
@@ -241,8 +246,9 @@ def encode_8bit(pixels: np.ndarray, luma_h: int = 2, luma_v: int = 2, quality: i
     cap = 2048 + nblocks * 512 + mcus * 3  # 64 symbols x (16 + 11) bits per block, every byte stuffed, with room to spare
     out = np.empty(cap, np.uint8)
     n = C.c_size_t(0)
-    rc = L.jref_encode_8bit_dri(a.ctypes.data, w, h, c, luma_h, luma_v, quality, int(optimize_coding), int(restart_interval), out.ctypes.data,
-                                cap, C.byref(n), coefs.ctypes.data if coefs is not None else None)
+    rc = L.jref_encode_8bit_tables(a.ctypes.data, w, h, c, luma_h, luma_v, quality, ql.ctypes.data if ql is not None else None,
+                                   qc.ctypes.data if qc is not None else None, int(optimize_coding), int(restart_interval), out.ctypes.data, cap,
+                                   C.byref(n), coefs.ctypes.data if coefs is not None else None)
     if rc == 2:
         raise OracleError(2, "No symbol is recorded.")
     if rc != 0:

@@ -1443,3 +1443,65 @@ def test_encoder_restart_intervals_in_a_mixed_batch():
         assert b.output(i) == po.encode_8bit(im, lum, lum, 80, restart_interval=ri), i
     b.close()
 
+
+
+
+def _encode_action(ycbcr, quality, optimize_coding, luma=(2, 2), most_optimal=False, tables=None):
+    """apps/JpegEncode/EncodeAction.cs:38-63, line by line, on the JpegEncoder mirror."""
+    h, w, _ = ycbcr.shape
+    encoder = jl.JpegEncoder()
+    if tables is None:
+        encoder.SetQuantizationTable(jl.JpegStandardQuantizationTable.ScaleByQuality(jl.JpegStandardQuantizationTable.GetLuminanceTable(0, 0), quality))
+        encoder.SetQuantizationTable(jl.JpegStandardQuantizationTable.ScaleByQuality(jl.JpegStandardQuantizationTable.GetChrominanceTable(0, 1), quality))
+    else:
+        encoder.SetQuantizationTable(jl.JpegQuantizationTable(0, 0, tables[0]))
+        encoder.SetQuantizationTable(jl.JpegQuantizationTable(0, 1, tables[1]))
+    if optimize_coding:
+        encoder.SetHuffmanTable(True, 0)
+        encoder.SetHuffmanTable(False, 0)
+        encoder.SetHuffmanTable(True, 1)
+        encoder.SetHuffmanTable(False, 1)
+    else:
+        encoder.SetHuffmanTable(True, 0, jl.JpegStandardHuffmanEncodingTable.GetLuminanceDCTable())
+        encoder.SetHuffmanTable(False, 0, jl.JpegStandardHuffmanEncodingTable.GetLuminanceACTable())
+        encoder.SetHuffmanTable(True, 1, jl.JpegStandardHuffmanEncodingTable.GetChrominanceDCTable())
+        encoder.SetHuffmanTable(False, 1, jl.JpegStandardHuffmanEncodingTable.GetChrominanceACTable())
+    encoder.MostOptimalCoding = most_optimal
+    encoder.AddComponent(1, 0, 0, 0, luma[0], luma[1])  # Y component
+    encoder.AddComponent(2, 1, 1, 1, 1, 1)  # Cb component
+    encoder.AddComponent(3, 1, 1, 1, 1, 1)  # Cr component
+    encoder.SetInputReader(jl.JpegBufferInputReader(w, h, 3, ycbcr))
+    writer = bytearray()
+    encoder.SetOutput(writer)
+    encoder.Encode()
+    return bytes(writer)
+
+
+@pytest.mark.parametrize("quality,optimize_coding,most_optimal", [(75, False, False), (30, True, False), (92, True, True)])
+def test_jpeg_encoder_mirror_runs_the_encode_action_sequence(quality, optimize_coding, most_optimal):
+    """The reference's own caller (EncodeAction) transcribed onto the JpegEncoder mirror: the bytes of the checker."""
+    ycc = po.rgb_to_ycbcr8(_enc_image(150, 98, quality))
+    out = _encode_action(ycc, quality, optimize_coding, most_optimal=most_optimal)
+    assert out == po.encode_8bit(ycc, 2, 2, quality, optimize_coding=(2 if most_optimal else 1) if optimize_coding else 0)
+
+
+def test_jpeg_encoder_mirror_takes_the_callers_quantization_tables():
+    """SetQuantizationTable with tables that are no scaled standard table: flat, steep, and libjpeg's quality-100 all-ones."""
+    ycc = po.rgb_to_ycbcr8(_enc_image(97, 61, 3))
+    rng = np.random.default_rng(8)
+    for lum, chr_ in [(np.full(64, 7), np.full(64, 19)), (np.arange(1, 65), np.arange(64, 0, -1) * 3), (np.ones(64), np.ones(64)),
+                      (rng.integers(1, 256, 64), rng.integers(1, 256, 64))]:
+        for opt in (False, True):
+            ref = po.encode_8bit(ycc, 2, 1, 50, optimize_coding=opt, quant_tables=(lum, chr_))
+            assert _encode_action(ycc, 50, opt, luma=(2, 1), tables=(lum.tolist(), chr_.tolist())) == ref
+            outs, results = jl.decode_batch([ref])
+            assert results[0].status == 0 and np.array_equal(outs[0], po.decode_8bit(ref)[0])
+    b = jl.EncodeBatch().upload([ycc], (2, 2), 75)
+    with pytest.raises(jl.ArgumentException):
+        b.set_quantization_table(0, 0, np.zeros(64))
+    with pytest.raises(jl.ArgumentException):
+        b.set_quantization_table(0, 1, np.full(64, 256))
+    with pytest.raises(jl.NotSupportedException):
+        b.set_quantization_table(0, 2, np.ones(64))
+    b.close()
+
