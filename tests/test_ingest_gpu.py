@@ -242,6 +242,13 @@ def test_overlapped_issue_order_gives_the_serial_result(monkeypatch):
     assert res[0][3][0] != 0 and res[0][n - 2][0] != 0 and res[0][0][0] == 0
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_bench_runs_its_rccl_path_under_torchrun_with_one_rank():
     """The driver launches bench.py under torch.distributed.run with one rank per GPU; with one GPU in the box the same
     launcher, one rank, and --dist make bench.py create the RCCL process group and go through its barrier and its
@@ -252,7 +259,7 @@ def test_bench_runs_its_rccl_path_under_torchrun_with_one_rank():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(root, "bench.py"), "--gpus", "1", "--dist", "--workload", "1080p_q90", "--images", "8", "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline", "--no-ingest"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
