@@ -338,46 +338,54 @@ __device__ __forceinline__ void marker_write_chunk(const uint8_t *__restrict__ d
     __shared__ uint32_t sh_a[kScanThreads / 64], sh_b[kScanThreads / 64];
     __shared__ __attribute__((aligned(16))) uint8_t sh_tile[kChunkBytes + 2 * kScanThreads + 16];
 
+    // the tile's bytes are asked for BEFORE the chunk's summary is waited for: two load latencies side by side instead of in a row
+    const int32_t misalign = (int32_t)(s.data_off & 15u);
+    const int64_t chunk_first = -(int64_t)misalign + (int64_t)wk.chunk * kChunkBytes;
+    const int64_t off = chunk_first + (int64_t)tid * 16;
+    const Raw16 raw = load16(p, off, len);
     // RSTs / udata bytes of the chunks before this one, earliest terminator of the whole scan (marker_prefix_kernel)
     const ChunkSum mine = cs[wk.chunk];
     const uint32_t rst_base = mine.rst_cnt, ubase = mine.keep_cnt, term = mine.pad;
-    const int32_t misalign = (int32_t)(s.data_off & 15u);
-    const int64_t chunk_first = -(int64_t)misalign + (int64_t)wk.chunk * kChunkBytes;
     if (term != kInf && (int64_t)term < chunk_first) return;  // the scan's data ended in an earlier chunk
     if (rst_base >= cap && cap > 0) return;                    // every interval was closed in an earlier chunk
     if (cap == 0) return;
 
-    const int64_t off = chunk_first + (int64_t)tid * 16;
-    ByteClass c = classify16(p, off, len, s.dri == 0);
+    ByteClass c = classify16(raw, off, len, s.dri == 0);
     const bool term_here = term != kInf && (int64_t)term < chunk_first + (int64_t)kChunkBytes;
     if (term_here) {  // RST markers behind the terminator do not count
 #pragma unroll
         for (int j = 0; j < 16; j++)
             if ((int64_t)(off + j) > (int64_t)term) c.rst &= ~(1u << j);
     }
-    uint32_t rst_total;
-    const uint32_t rst_excl = block_exclusive_scan(__builtin_popcount(c.rst), sh_a, rst_total);
+    // One packed scan serves both prefixes in every chunk but the one that closes the scan: RSTs in the low half, udata
+    // bytes (kept bytes + one more per entry) in the high half -- a chunk holds at most 2048 of the first and 6144 of the second.
+    uint32_t packed_total;
+    const uint32_t packed_excl = block_exclusive_scan((uint32_t)__builtin_popcount(c.rst) |
+                                                      ((uint32_t)(__builtin_popcount(c.keep) + __builtin_popcount(c.rst)) << 16), sh_a, packed_total);
+    const uint32_t rst_excl = packed_excl & 0xFFFFu, rst_total = packed_total & 0xFFFFu;
     // closing entry of the scan, if it lies in this chunk: the cap-th RST, else the terminator
     const bool cap_here = rst_base + rst_total >= cap;
-    __shared__ uint32_t sh_last;
-    if (tid == 0) sh_last = kInf;
-    __syncthreads();
-    {
-        uint32_t idx = rst_base + rst_excl;
-        uint32_t m = c.rst;
-        while (m) {
-            const int j = __builtin_ctz(m);
-            m &= m - 1;
-            if (idx == cap - 1) sh_last = (uint32_t)(off + j);
-            idx++;
-        }
-    }
-    __syncthreads();
     uint32_t last_pos = kInf;  // raw position of the closing entry when it is in this chunk
-    if (cap_here) last_pos = sh_last;
-    else if (term_here) last_pos = term;
-    // bytes behind the closing entry are not copied; markers behind it are not entries
-    if (last_pos != kInf) {
+    uint32_t markers = c.rst;  // entries this lane owns: every one becomes FF FF in udata
+    uint32_t keep_excl = packed_excl >> 16, keep_total = packed_total >> 16;
+    if (cap_here || term_here) {  // workgroup-uniform: one chunk per scan
+        __shared__ uint32_t sh_last;
+        if (tid == 0) sh_last = kInf;
+        __syncthreads();
+        {
+            uint32_t idx = rst_base + rst_excl;
+            uint32_t m = c.rst;
+            while (m) {
+                const int j = __builtin_ctz(m);
+                m &= m - 1;
+                if (idx == cap - 1) sh_last = (uint32_t)(off + j);
+                idx++;
+            }
+        }
+        __syncthreads();
+        if (cap_here) last_pos = sh_last;
+        else last_pos = term;
+        // bytes behind the closing entry are not copied; markers behind it are not entries
 #pragma unroll
         for (int j = 0; j < 16; j++)
             if ((int64_t)(off + j) > (int64_t)last_pos) {
@@ -385,11 +393,10 @@ __device__ __forceinline__ void marker_write_chunk(const uint8_t *__restrict__ d
                 c.rst &= ~(1u << j);
                 c.term &= ~(1u << j);
             }
+        markers = c.rst;
+        if (term_here && !cap_here && (int64_t)term >= off && (int64_t)term < off + 16) markers |= 1u << (uint32_t)((int64_t)term - off);
+        keep_excl = block_exclusive_scan(__builtin_popcount(c.keep) + __builtin_popcount(markers), sh_b, keep_total);
     }
-    uint32_t markers = c.rst;  // entries this lane owns: every one becomes FF FF in udata
-    if (term_here && !cap_here && (int64_t)term >= off && (int64_t)term < off + 16) markers |= 1u << (uint32_t)((int64_t)term - off);
-    uint32_t keep_total;
-    const uint32_t keep_excl = block_exclusive_scan(__builtin_popcount(c.keep) + __builtin_popcount(markers), sh_b, keep_total);
     {
         uint32_t dst = keep_excl;  // chunk-relative udata position
         uint32_t idx = rst_base + rst_excl;
