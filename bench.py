@@ -127,9 +127,7 @@ def cpu_baseline(files, width, height, max_threads):
     value, threads_best, decodes, sall = best
     # cores = the CPUs those threads could actually occupy: never more than the affinity mask / cgroup quota grants
     # (the sweep's best point is often an oversubscribed one by a percent of noise; efficiency is per CPU, not per thread)
-    granted = min(budget.get("affinity", budget["cpu_count"]), budget["cpu_count"])
-    if "cgroup_quota_cpus" in budget:
-        granted = min(granted, max(1, int(round(budget["cgroup_quota_cpus"]))))
+    granted = granted_cpus(budget)
     cores = max(1, min(threads_best, granted))
     return {
         "value": round(value, 2),
@@ -147,17 +145,23 @@ def cpu_baseline(files, width, height, max_threads):
     }
 
 
-def ingest_inclusive(jl, ctx, batch, files, fmt, rounds):
-    """Mpixels/s with the host in the loop: while batch A decodes (decode stream), batch B is parsed (headers only),
-    staged through pinned memory and sent to HBM (upload stream), then the roles swap.  One round = one batch ingested AND
-    one batch decoded; the compressed bytes start in pageable host memory."""
+def ingest_inclusive(jl, ctx, batch, files, fmt, rounds, pinned=False, sync_ranks=None):
+    """Seconds per batch with the host in the loop: while batch A decodes (decode stream), batch B is parsed (headers only)
+    and sent to HBM (upload stream), then the roles swap.  One round = one batch ingested AND one batch decoded.
+    pinned=False: the compressed bytes start in pageable host memory and travel through the pinned staging ring (the host
+    crew copies them); pinned=True: they lie in page-locked memory and are DMA'd from there (jpgpu_batch_upload_segments
+    with JPGPU_UPLOAD_PINNED_ARENA: one read buffer, a few large DMAs, no host thread touches an entropy-coded byte)."""
     other = jl.Batch(ctx)
-    other.upload(files, fmt)  # allocates the second set of device buffers (not timed)
+    up = (lambda b: b.upload_segments(files, fmt, pinned=True, arena=True)) if pinned else (lambda b: b.upload(files, fmt))
+    up(other)  # allocates the second set of device buffers (not timed)
+    up(batch)
     cur, nxt = batch, other
+    if sync_ranks:
+        sync_ranks()
     t0 = time.perf_counter()
     for _ in range(rounds):
         cur.decode()
-        nxt.upload(files, fmt)
+        up(nxt)
         cur.sync()
         cur, nxt = nxt, cur
     elapsed = time.perf_counter() - t0
@@ -167,6 +171,13 @@ def ingest_inclusive(jl, ctx, batch, files, fmt, rounds):
             raise RuntimeError("ingest-inclusive loop: an image failed")
     other.close()
     return elapsed / rounds, stats
+
+
+def granted_cpus(budget):
+    g = min(budget.get("affinity", budget["cpu_count"]), budget["cpu_count"])
+    if "cgroup_quota_cpus" in budget:
+        g = min(g, max(1, int(round(budget["cgroup_quota_cpus"]))))
+    return max(1, g)
 
 
 def library_sha256():
@@ -189,6 +200,7 @@ def main():
     ap.add_argument("--format", default="interleaved_u8", choices=["interleaved_u8", "planar_u8", "rgb_u8", "rgba_u8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ingest", action="store_true", help="skip the ingest-inclusive (upload beside decode) measurement")
+    ap.add_argument("--no-planar-pass", action="store_true", help="skip the short PLANAR_U8 pass behind roofline.read_frac_planar")
     ap.add_argument("--gen-threads", type=int, default=0)
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (RCCL) even for a single rank: runs the barrier / "
                                                          "MAX-reduce path of the multi-GPU launch on a one-GPU box")
@@ -206,6 +218,7 @@ def main():
     import torch
 
     dist = None
+    host_group = None
     if world > 1 or args.dist:
         import torch.distributed as dist_
 
@@ -216,6 +229,9 @@ def main():
         os.environ.setdefault("WORLD_SIZE", str(world))
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # host-side rendezvous (gloo): ranks that wait here block in a socket read and leave their CPUs to the rank that is
+        # measuring something on the host (the CPU baseline) -- an RCCL barrier would keep a core per waiting rank spinning
+        host_group = dist.new_group(backend="gloo")
     else:
         torch.cuda.set_device(local_rank)
 
@@ -228,9 +244,12 @@ def main():
     n_images = args.images or default_images
     fmt = {"interleaved_u8": jl.FMT_INTERLEAVED_U8, "planar_u8": jl.FMT_PLANAR_U8, "rgb_u8": jl.FMT_RGB_U8, "rgba_u8": jl.FMT_RGBA_U8}[args.format]
 
-    # ---- synthetic input: distinct seed per image and per rank
+    # ---- synthetic input: distinct seed per image and per rank.  All ranks generate at once and share the CPUs the job is
+    # granted (affinity mask / cgroup quota, not os.cpu_count()): granted // world threads each
     cpu = os.cpu_count() or 1
-    gen_threads = args.gen_threads or max(1, cpu // max(1, min(world, 8)))
+    budget = host_cpu_budget()
+    granted = granted_cpus(budget)
+    gen_threads = args.gen_threads or max(1, granted // max(1, world))
     t0 = time.perf_counter()
     if ss == "420p":
         ss = "420"
@@ -247,7 +266,14 @@ def main():
     files = [buf[i * stride:i * stride + int(sizes[i])] for i in range(n_images)]
     log(f"[rank {rank}] generated {n_images} x {width}x{height} {ss} Q{quality} DRI={dri}: {sizes.sum() / 1e6:.1f} MB in {t_gen:.1f} s ({gen_threads} threads)")
 
+    gen_s_ranks = [round(t_gen, 1)]
+    if dist is not None:
+        gen_s_ranks = [None] * world
+        dist.all_gather_object(gen_s_ranks, round(t_gen, 1), group=host_group)
+
     ctx = jl.Context(local_rank)
+    if world > 1:
+        ctx.set_host_threads(max(1, min(16, granted // world)))  # the ranks' ingest crews share the granted CPUs
     batch = jl.Batch(ctx)
     batch.upload(files, fmt)  # first call: device buffers and the pinned staging ring are allocated here
     t0 = time.perf_counter()
@@ -285,6 +311,40 @@ def main():
     if dist is not None:
         elapsed = sharding.max_over_ranks(dist, elapsed, device="cuda")
     value = sharding.aggregate_throughput(n_images * width * height, n_gpus, args.steps, elapsed)
+
+    # ---- the same workload with the host in the loop (never `value`): upload of batch k+1 beside the decode of batch k, on
+    # every rank at once (the ranks' crews share the host), the slowest rank's time per batch; from pageable memory through
+    # the staging ring, and from page-locked memory by DMA (zero-copy)
+    ingest_res = {}
+    if not args.no_ingest:
+        rounds = max(4, min(args.steps, 8))
+        for key in ("pageable", "pinned"):
+            per_batch_s, st, err = float("inf"), None, None
+            met = [False]
+
+            def meet():
+                met[0] = True
+                barrier()
+            try:
+                src = files
+                arena = None
+                if key == "pinned":
+                    arena = ctx.host_alloc(int(buf.size))
+                    arena[:] = buf
+                    src = [arena[i * stride:i * stride + int(sizes[i])] for i in range(n_images)]
+                per_batch_s, st = ingest_inclusive(jl, ctx, batch, src, fmt, rounds, pinned=(key == "pinned"), sync_ranks=meet)
+                if arena is not None:
+                    ctx.host_free(arena)
+            except Exception as e:  # pragma: no cover
+                err = str(e)[:160]
+                per_batch_s = float("inf")
+                if not met[0]:
+                    barrier()  # the other ranks are waiting at the start line
+            if dist is not None:
+                per_batch_s = sharding.max_over_ranks(dist, per_batch_s, device="cuda")
+            ingest_res[key] = (per_batch_s, st, err)
+        batch.upload(files, fmt)  # leave the batch as the timed region had it (the spot check below reads it)
+        batch.decode().sync()
 
     if rank == 0:
         # dominant kernel: idct_output_kernel.  Algorithmic bytes per launch: 128 B of int16 coefficients
@@ -347,20 +407,46 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_source,
             },
-            "host": {"gen_s": round(t_gen, 1), "parse_upload_s": round(t_upload, 4), "cpu_count": cpu,
+            "host": {"gen_s": round(t_gen, 1), "gen_s_per_rank": gen_s_ranks, "gen_threads_per_rank": gen_threads, "parse_upload_s": round(t_upload, 4),
+                     "cpu_count": cpu, "granted_cpus": granted,
                      "ingest": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in ingest.items()}},
         }
-        # the same workload with the host in the loop: upload of batch k+1 beside the decode of batch k (never `value`)
-        if not args.no_ingest and world == 1:
+        for key, name in (("pageable", "value_ingest_inclusive"), ("pinned", "value_ingest_inclusive_pinned")):
+            if key not in ingest_res:
+                continue
+            per_batch_s, st, err = ingest_res[key]
+            if err is None and per_batch_s != float("inf"):
+                out[name] = round(n_images * n_gpus * width * height / 1e6 / per_batch_s, 1)
+                out["host"][f"ingest_inclusive_{key}_ms_per_batch"] = round(per_batch_s * 1e3, 2)
+                out["host"][f"ingest_{key}"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items()}
+            else:
+                out[name] = None
+                out["host"][f"ingest_inclusive_{key}_error"] = err
+        if ingest_res:
+            out["host"]["ingest_inclusive_note"] = ("whole job, slowest rank per batch; header-only host parse + H2D of batch k+1 beside the decode of "
+                                                    "batch k (two batches per context); pageable: the host crew copies the files into the pinned "
+                                                    "staging ring; pinned: the files lie in page-locked memory and are DMA'd from there")
+        # north_star's literal bar -- the IDCT stage's share of the HBM READ bandwidth -- is defined on the planar sink
+        # (192 B per block): a short pass of the same batch with PLANAR_U8 output, K3 timed by HIP events
+        if args.format == "interleaved_u8" and not args.no_planar_pass:
             try:
-                per_batch_s, st = ingest_inclusive(jl, ctx, batch, files, fmt, rounds=max(4, min(args.steps, 8)))
-                out["value_ingest_inclusive"] = round(n_images * width * height / 1e6 / per_batch_s, 1)
-                out["host"]["ingest_inclusive_ms_per_batch"] = round(per_batch_s * 1e3, 2)
-                out["host"]["ingest_inclusive_note"] = ("compressed bytes start in pageable host memory; header-only host parse + pinned "
-                                                        "staging + H2D of batch k+1 overlap the decode of batch k (two batches, one context)")
+                pb = jl.Batch(ctx).upload(files, jl.FMT_PLANAR_U8)
+                for _ in range(2):
+                    pb.decode()
+                pb.sync()
+                pb.stage_ms()
+                for _ in range(5):
+                    pb.decode()
+                pst = pb.stage_ms()
+                ptot = pb.totals()
+                pb.close()
+                out["roofline"]["read_frac_planar"] = round(ptot["blocks"] * 128 / (pst["idct"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4)
+                out["roofline"]["planar_pass"] = {"kernel": "idct_output_kernel<1,0>", "steps": 5, "idct_ms": round(pst["idct"], 4),
+                                                  "algorithmic_bytes": ptot["blocks"] * 128 + ptot["output_bytes"],
+                                                  "achieved": round((ptot["blocks"] * 128 + ptot["output_bytes"]) / (pst["idct"] / 1e3) / 1e9, 1)}
             except Exception as e:  # pragma: no cover
-                out["value_ingest_inclusive"] = None
-                out["host"]["ingest_inclusive_error"] = str(e)[:120]
+                out["roofline"]["read_frac_planar"] = None
+                out["roofline"]["planar_pass_error"] = str(e)[:120]
         # D2H of the pixels: reported, never part of `value`; a bounded sample of the images, pageable host memory
         try:
             n_d2h = min(n_images, 16)
@@ -392,13 +478,14 @@ def main():
             out["parity_spot_check"] = "bit-exact vs oracle"
         except ImportError:
             out["parity_spot_check"] = "oracle unavailable"
-        if world == 1 and not args.no_cpu_baseline:
+        # rank 0 alone, the other ranks parked in the host-side barrier below (blocked in a socket read, not spinning)
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(files, width, height, cpu)
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
 
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=host_group)
         dist.destroy_process_group()
 
 

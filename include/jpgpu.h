@@ -98,6 +98,15 @@ const char *jpgpu_last_error(const jpgpu_ctx *ctx);
  * ring, full marker walks of the files that need one).  0 = default: min(CPUs granted to the process, 16), or JPGPU_HOST_THREADS.
  * The reference is single-threaded per decoder ("one decoder per thread"); a batch is where the host fans out. */
 int jpgpu_set_host_threads(jpgpu_ctx *ctx, int threads);
+/* Page-locked host memory for the zero-copy ingest (jpgpu_batch_upload_segments with JPGPU_UPLOAD_PINNED).  The reference's
+ * callers own their input (SetInput takes a ReadOnlyMemory / ReadOnlySequence<byte>, JpegDecoder.cs:49-62, filled e.g. by
+ * apps/JpegDecode/MemoryPoolBufferWriter.cs); a C# shim either reads its files into jpgpu_host_alloc'd memory or pins its
+ * own array (GCHandle) and registers it, so that the DMA engine reads the bytes where they lie.  Registration costs a few
+ * microseconds per page: do it once per buffer, not per decode. */
+int jpgpu_host_alloc(jpgpu_ctx *ctx, size_t bytes, void **out);
+int jpgpu_host_free(jpgpu_ctx *ctx, void *p);
+int jpgpu_host_register(jpgpu_ctx *ctx, void *p, size_t bytes);
+int jpgpu_host_unregister(jpgpu_ctx *ctx, void *p);
 /* Image-per-GPU sharding: of n_items, rank `rank` of `world` takes items first, first + stride, ... (count of
  * them): image i -> GPU i mod G.  Independent contexts, no exchange between them; any out pointer may be NULL. */
 void jpgpu_shard(int n_items, int rank, int world, int *first, int *stride, int *count);
@@ -178,6 +187,29 @@ void jpgpu_batch_destroy(jpgpu_batch *b);
  * `format` is a jpgpu_format.  Images whose headers fail to parse get a per-image status and are skipped.
  * Returns JPGPU_OK if the batch is usable (even if some images failed). */
 int jpgpu_batch_upload(jpgpu_batch *b, const uint8_t *const *jpeg, const size_t *len, int n, int format);
+/* The same for input that is not one contiguous span per file: file i consists of the next segments_per_file[i] entries of
+ * `segments`, in order -- the ReadOnlySequence<byte> of JpegDecoder.SetInput (JpegDecoder.cs:56-62), which the reference reads
+ * in place segment by segment (apps/JpegDecode/MemoryPoolBufferWriter.cs:166-174 builds such a sequence,
+ * apps/JpegDecode/DecodeAction.cs:81-98 hands it over).  The host looks at the headers only (the first 64 KiB of a
+ * multi-segment file are gathered for that; a file whose first scan starts later, or that needs the full marker walks, is
+ * linearised on the host as a whole); the entropy-coded bytes travel segment by segment.
+ * flags: JPGPU_UPLOAD_PINNED = every segment lies in page-locked memory (jpgpu_host_alloc / jpgpu_host_register): the
+ * segments are DMA'd to HBM from where they lie -- no staging copy, no host thread touches the entropy bytes.  Without the
+ * flag the segments go through the pinned staging ring like jpgpu_batch_upload's files.
+ * Ordering: an upload is ordered behind device work this batch has issued and not yet synchronised (it will not overwrite
+ * inputs a running decode of the SAME batch still reads); results of that earlier work are lost with the upload. */
+typedef struct jpgpu_segment {
+    const uint8_t *data;
+    size_t len;
+} jpgpu_segment;
+#define JPGPU_UPLOAD_PINNED 1u
+/* All segments lie inside ONE page-locked allocation (a read buffer the caller fills file after file), every file contiguous,
+ * and the bytes BETWEEN the files belong to that allocation too (they are read, never interpreted): the device copy mirrors
+ * the arena's layout and the whole span travels as a few large DMAs instead of one per file.  Falls back to one DMA per segment
+ * when the files are not contiguous or the span is mostly gaps (more than twice the payload). */
+#define JPGPU_UPLOAD_PINNED_ARENA 2u
+int jpgpu_batch_upload_segments(jpgpu_batch *b, const jpgpu_segment *segments, const int *segments_per_file, int n, int format,
+                                unsigned flags);
 /* What the last jpgpu_batch_upload did.  The host reads headers only: both marker loops stop behind the first SOS header and
  * the file is planned as one sequential scan closed by EOI; the bytes behind the header are looked at by the device, which
  * reports the first marker that is not RSTn (what Identify's walk, JpegDecoder.cs:75-162 / JpegReader.cs:120-158, would
@@ -193,6 +225,8 @@ typedef struct jpgpu_ingest_stats {
     float full_walk_ms;     /* full marker walks (+ the reader-position verdicts of the confirmed plans) */
     float layout_ms;        /* descriptors, work lists, device allocations */
     float total_ms;
+    int32_t n_pinned_dma;   /* segments sent by DMA straight from the caller's page-locked memory (JPGPU_UPLOAD_PINNED) */
+    int32_t n_linearised;   /* multi-segment files the host had to gather as a whole (full marker walks) */
 } jpgpu_ingest_stats;
 int jpgpu_batch_ingest_stats(const jpgpu_batch *b, jpgpu_ingest_stats *stats);
 
@@ -267,9 +301,19 @@ const char *jpgpu_multi_last_error(const jpgpu_multi *m);
  * with jpgpu_batch_*).  upload_ms / decode_ms (may be NULL): the slowest shard's time in each phase. */
 int jpgpu_multi_decode(jpgpu_multi *m, const uint8_t *const *jpeg, const size_t *len, int n, int format, double *upload_ms,
                        double *decode_ms);
+/* The same in two halves, for callers that feed the devices continuously.  Every slot owns TWO batches: jpgpu_multi_submit
+ * uploads call k's shards into the idle one of each slot, launches their decode and returns while the devices work;
+ * jpgpu_multi_wait(ticket) blocks until that call's decodes are done.  Submitting call k+1 before waiting for call k puts its
+ * host parse + H2D beside call k's decode (upload stream / decode stream of each context); at most two calls may be in
+ * flight, and a ticket's outputs stay valid until the second submit after it.  flags: JPGPU_UPLOAD_PINNED as in
+ * jpgpu_batch_upload_segments (every file one page-locked segment).  The host crew of slot s is (CPUs granted to the
+ * process) / G threads -- G slots share the machine -- unless jpgpu_set_host_threads / JPGPU_HOST_THREADS says otherwise. */
+int jpgpu_multi_submit(jpgpu_multi *m, const uint8_t *const *jpeg, const size_t *len, int n, int format, unsigned flags, int *ticket);
+int jpgpu_multi_wait(jpgpu_multi *m, int ticket, double *upload_ms, double *decode_ms);
+jpgpu_batch *jpgpu_multi_batch_of(jpgpu_multi *m, int ticket, int slot);
 /* Where image i of the last jpgpu_multi_decode went: the device slot (index into `devices`) and its index in that slot's batch. */
 int jpgpu_multi_locate(const jpgpu_multi *m, int i, int *slot, int *local_index);
-jpgpu_batch *jpgpu_multi_batch(jpgpu_multi *m, int slot);
+jpgpu_batch *jpgpu_multi_batch(jpgpu_multi *m, int slot); /* of the most recent jpgpu_multi_decode / _submit */
 jpgpu_ctx *jpgpu_multi_context(jpgpu_multi *m, int slot);
 
 /* ------------------------------------------------------------------------------------------------ (2) per scan
@@ -289,6 +333,39 @@ int jpgpu_decode_scan(jpgpu_ctx *ctx, const jpgpu_frame *frame, const jpgpu_scan
                       const uint8_t *entropy, size_t len, int format, void *out, size_t cap,
                       jpgpu_image_result *result, size_t *bytes_consumed);
 
+/* ------------------------------------------------------------------------------------------------ (2b) per scan, SOF2
+ * Replaces JpegHuffmanProgressiveScanDecoder behind JpegScanDecoder.Create(SOF2, ...) (ScanDecoder/JpegScanDecoder.cs:18-36):
+ * what JpegDecoder.ProcessFrameHeader / ProcessScanHeader / Decode's finally call on it (JpegDecoder.cs:562-570, 592-599,
+ * 545-549), so that a C# JpegDecoder keeps its own marker loop for progressive files too.
+ *   jpgpu_progressive_begin    the constructor (ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs:23-55): MCU geometry, and
+ *                              JpegBlockAllocator.Allocate (JpegBlockAllocator.cs:35-84) -- the zeroed coefficient store, in HBM,
+ *                              where it stays between the calls.
+ *   jpgpu_progressive_scan     ProcessScan (:57-90): resolves the scan's components against the tables passed (the decoder's
+ *                              registry at this SOS: GetHuffmanTable / GetQuantizationTable, JpegDecoder.cs:869, 910) and the
+ *                              restart interval in force NOW (GetRestartInterval read per scan, :78 -- it may change between
+ *                              scans), then decodes the scan into the store on the GPU before it returns: the status is this
+ *                              scan's (reference exception classes and messages, as jpgpu_decode_scan).  `entropy` = the bytes
+ *                              behind the SOS header; the segment ends at the first marker that is not RSTn.  *bytes_consumed is
+ *                              always 0: the reference's progressive ProcessScan never advances the outer reader, Decode's
+ *                              TryReadMarker finds the next marker by itself (JpegReader.cs:120-158).
+ *   jpgpu_progressive_dispose  Dispose (:421-470): dequantise + IDCT + level shift over the MCU grid with the quantisation tables
+ *                              the LAST scans left in the decoder's component slots, then
+ *                              JpegBlockAllocator.Flush (JpegBlockAllocator.cs:120-190) into `out` in `format`
+ *                              (jpgpu_progressive_output_size says how large), or, _to_writer, as WriteBlock calls in Flush's order.
+ *                              Scan orders whose slots do not cover every component once return JPGPU_ERR_NOT_SUPPORTED.
+ *                              After a failing scan the store holds what the kernels wrote before they stopped (the reference
+ *                              flushes its partial store from Decode's finally; the blocks in front of the failing restart
+ *                              interval are the same, the rest is not reproduced).
+ */
+typedef struct jpgpu_progressive jpgpu_progressive;
+int jpgpu_progressive_begin(jpgpu_ctx *ctx, const jpgpu_frame *frame, jpgpu_progressive **out);
+int jpgpu_progressive_scan(jpgpu_progressive *p, const jpgpu_scan *scan, const uint16_t qt[4][64], const uint8_t qt_present[4],
+                           const jpgpu_dht dht[2][4], uint16_t restart_interval, const uint8_t *entropy, size_t len,
+                           jpgpu_image_result *result, size_t *bytes_consumed);
+int jpgpu_progressive_output_size(jpgpu_progressive *p, int format, size_t *bytes);
+int jpgpu_progressive_dispose(jpgpu_progressive *p, int format, void *out, size_t cap);
+void jpgpu_progressive_destroy(jpgpu_progressive *p);
+
 /* ------------------------------------------------------------------------------------------------ (3) decoder
  * Handle-based mirror of the public JpegDecoder surface (ref: JpegDecoder.cs).  Names follow the reference.
  */
@@ -296,6 +373,10 @@ int jpgpu_decode_scan(jpgpu_ctx *ctx, const jpgpu_frame *frame, const jpgpu_scan
  * full-resolution pixel coordinates; same call order as the reference (MCU raster, scan-component order,
  * block raster in MCU, sub-block raster for expanded chroma). */
 typedef void (*jpgpu_write_block_fn)(void *user, const int16_t *block, int component_index, int x, int y);
+
+/* jpgpu_progressive_dispose for an arbitrary JpegBlockOutputWriter: the IDCT pass on the GPU, then the WriteBlock calls of
+ * JpegBlockAllocator.Flush (component, block row, block column; sub-sampled components expanded) replayed on the host. */
+int jpgpu_progressive_dispose_to_writer(jpgpu_progressive *p, jpgpu_write_block_fn fn, void *user);
 
 /* ctx may be NULL for host-only use (Identify / metadata / tables); Decode then returns JPGPU_ERR_NO_DEVICE. */
 int jpgpu_decoder_create(jpgpu_ctx *ctx, jpgpu_decoder **out);          /* new JpegDecoder()                */
@@ -323,6 +404,21 @@ int jpgpu_decoder_set_output_writer(jpgpu_decoder *d, jpgpu_write_block_fn fn, v
 int jpgpu_decoder_set_output_buffer8(jpgpu_decoder *d, int width, int height, int component_count, uint8_t *out,
                                      size_t cap);
 int jpgpu_decoder_decode(jpgpu_decoder *d);                                      /* Decode :509-550 */
+/* The TIFF-style surface (JPEG-in-TIFF keeps tables, frame header and strips apart; SURVEY 5 "checkpoint / resume" row): the
+ * caller sets the pieces itself instead of letting Decode()'s marker loop find them, then hands over one scan's entropy data. */
+int jpgpu_decoder_set_start_of_frame(jpgpu_decoder *d, int marker);              /* StartOfFrame { set; } :43 (0xC0 / 0xC1 / 0xC2) */
+int jpgpu_decoder_set_frame_header(jpgpu_decoder *d, const jpgpu_frame *frame);  /* SetFrameHeader :404-407 (frame->sof is NOT applied) */
+/* SetHuffmanTable(JpegHuffmanDecodingTable) :793-815: replaces the entry with the same class (0 = DC, 1 = AC) and identifier */
+int jpgpu_decoder_set_huffman_table(jpgpu_decoder *d, int table_class, int identifier, const uint8_t bits[16], const uint8_t *values,
+                                    int num_values);
+/* SetQuantizationTable(JpegQuantizationTable) :840-861: 64 elements in zig-zag order (JpegQuantizationTable.cs:47) */
+int jpgpu_decoder_set_quantization_table(jpgpu_decoder *d, int element_precision, int identifier, const uint16_t *zigzag64);
+int jpgpu_decoder_clear_huffman_table(jpgpu_decoder *d);                         /* ClearHuffmanTable :768-771 */
+int jpgpu_decoder_clear_quantization_table(jpgpu_decoder *d);                    /* ClearQuantizationTable :784-787 */
+/* ProcessScan(ref JpegReader, JpegScanHeader) :624-632: JpegScanDecoder.Create(StartOfFrame, this, GetFrameHeader()) -- the restart
+ * interval is latched at this moment -- one ProcessScan over `entropy` (reader.RemainingBytes), Dispose.  The output
+ * goes to the writer set with jpgpu_decoder_set_output_writer / _set_output_buffer8; *bytes_consumed = the reader's advance. */
+int jpgpu_decoder_process_scan(jpgpu_decoder *d, const jpgpu_scan *scan, const uint8_t *entropy, size_t len, size_t *bytes_consumed);
 void jpgpu_decoder_reset(jpgpu_decoder *d);                                      /* Reset :930 */
 void jpgpu_decoder_reset_input(jpgpu_decoder *d);                                /* ResetInput :941 */
 void jpgpu_decoder_reset_header(jpgpu_decoder *d);                               /* ResetHeader :949 */
@@ -395,6 +491,12 @@ int jpgpu_optimizer_download(jpgpu_optimizer *o, int i, void *dst, size_t cap); 
 int jpgpu_optimizer_statistics(const jpgpu_optimizer *o, int i, int table, uint8_t *table_class, uint8_t *identifier, uint32_t *counts);
 int jpgpu_optimizer_last_ms(const jpgpu_optimizer *o, float *ms);  /* device time of the last run (HIP events) */
 /* JpegHuffmanEncodingTableBuilder.Build(false) for one table: DHT counts and values, and GetCode() for all 256 symbols */
+/* The order .NET's Array.Sort(T[], Comparison<T>) / List<T>.Sort(Comparison<T>) leaves n elements in when the comparison looks at
+ * an int32 key alone (ascending): perm[i] = original index of the element that ends up at position i.  That sort is not stable,
+ * and the reference orders equal-length symbols (JpegHuffmanEncodingTableBuilder.cs:171) and its package-merge nodes (:352,
+ * :374, :395) with it, so the DHT bytes the optimizer and the encoder write depend on the runtime's algorithm (restated from
+ * ArraySortHelper<T>.IntrospectiveSort).  Exposed so that the restatement can be held against independent ones. */
+int jpgpu_net_sort_permutation(const int32_t *keys, int n, int32_t *perm);
 int jpgpu_build_optimal_huffman_table(const uint32_t *counts, int most_optimal, uint8_t *bits, uint8_t *values, int *num_values,
                                       uint16_t *code, uint8_t *length);
 

@@ -9,7 +9,8 @@ from .batch import FMT_EXTENDED_U16, FMT_INTERLEAVED_U8, FMT_PLANAR_I16, FMT_PLA
 from .context import Context, default_context, device_count
 from .encoder import EncodeBatch, encode_batch
 from .optimizer import JpegOptimizer, OptimizeBatch, build_optimal_huffman_table, optimize_batch
-from .decoder import JpegBlockOutputWriter, JpegBufferOutputWriter8Bit, JpegDecoder, JpegExtendingOutputWriter
+from .decoder import (JpegBlockOutputWriter, JpegBufferOutputWriter8Bit, JpegDecoder, JpegExtendingOutputWriter, JpegFrameComponentSpecificationParameters,
+                      JpegFrameHeader, JpegGpuProgressiveScanDecoder, JpegHuffmanDecodingTable, JpegScanComponentSpecificationParameters, JpegScanHeader)
 from .jpeg_encoder import (JpegBufferInputReader, JpegEncoder, JpegHuffmanEncodingTable, JpegQuantizationTable, JpegStandardHuffmanEncodingTable,
                            JpegStandardQuantizationTable)
 from .multi import MultiDecoder
@@ -19,7 +20,8 @@ from .errors import (ArgumentException, DeviceError, InvalidDataException, Inval
 __all__ = [
     "Batch", "decode_batch", "MultiDecoder", "JpegEncoder", "JpegQuantizationTable", "JpegStandardQuantizationTable", "JpegHuffmanEncodingTable",
     "JpegStandardHuffmanEncodingTable", "JpegBufferInputReader", "EncodeBatch", "encode_batch", "JpegOptimizer", "OptimizeBatch", "optimize_batch", "build_optimal_huffman_table", "Context", "default_context", "device_count", "JpegDecoder", "JpegBlockOutputWriter",
-    "JpegBufferOutputWriter8Bit", "JpegExtendingOutputWriter", "FMT_INTERLEAVED_U8", "FMT_PLANAR_U8", "FMT_PLANAR_I16", "FMT_RGB_U8", "FMT_RGBA_U8", "FMT_EXTENDED_U16",
+    "JpegBufferOutputWriter8Bit", "JpegExtendingOutputWriter", "JpegFrameHeader", "JpegFrameComponentSpecificationParameters", "JpegScanHeader",
+    "JpegScanComponentSpecificationParameters", "JpegHuffmanDecodingTable", "JpegGpuProgressiveScanDecoder", "FMT_INTERLEAVED_U8", "FMT_PLANAR_U8", "FMT_PLANAR_I16", "FMT_RGB_U8", "FMT_RGBA_U8", "FMT_EXTENDED_U16",
     "JpegError", "InvalidDataException", "InvalidOperationException", "NotSupportedException", "ArgumentException",
     "DeviceError", "NoDeviceError",
 ]

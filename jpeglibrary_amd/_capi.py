@@ -63,7 +63,16 @@ class EncodeParams(C.Structure):
 
 class IngestStats(C.Structure):
     _fields_ = [("threads", C.c_int32), ("n_header_only", C.c_int32), ("n_full_walk", C.c_int32), ("parse_ms", C.c_float),
-                ("copy_ms", C.c_float), ("full_walk_ms", C.c_float), ("layout_ms", C.c_float), ("total_ms", C.c_float)]
+                ("copy_ms", C.c_float), ("full_walk_ms", C.c_float), ("layout_ms", C.c_float), ("total_ms", C.c_float),
+                ("n_pinned_dma", C.c_int32), ("n_linearised", C.c_int32)]
+
+
+class Segment(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_size_t)]
+
+
+UPLOAD_PINNED = 1
+UPLOAD_PINNED_ARENA = 2
 
 
 WRITE_BLOCK_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int)
@@ -77,6 +86,10 @@ SYMBOLS = [
     ("jpgpu_destroy", None, [_P]),
     ("jpgpu_last_error", C.c_char_p, [_P]),
     ("jpgpu_set_host_threads", C.c_int, [_P, C.c_int]),
+    ("jpgpu_host_alloc", C.c_int, [_P, C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("jpgpu_host_free", C.c_int, [_P, C.c_void_p]),
+    ("jpgpu_host_register", C.c_int, [_P, C.c_void_p, C.c_size_t]),
+    ("jpgpu_host_unregister", C.c_int, [_P, C.c_void_p]),
     ("jpgpu_shard", None, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("jpgpu_multi_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
     ("jpgpu_multi_destroy", None, [_P]),
@@ -84,6 +97,9 @@ SYMBOLS = [
     ("jpgpu_multi_last_error", C.c_char_p, [_P]),
     ("jpgpu_multi_decode", C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]),
+    ("jpgpu_multi_submit", C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_int)]),
+    ("jpgpu_multi_wait", C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("jpgpu_multi_batch_of", _P, [_P, C.c_int, C.c_int]),
     ("jpgpu_multi_locate", C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("jpgpu_multi_batch", _P, [_P, C.c_int]),
     ("jpgpu_multi_context", _P, [_P, C.c_int]),
@@ -94,6 +110,7 @@ SYMBOLS = [
     ("jpgpu_batch_create", C.c_int, [_P, C.POINTER(_P)]),
     ("jpgpu_batch_destroy", None, [_P]),
     ("jpgpu_batch_upload", C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int]),
+    ("jpgpu_batch_upload_segments", C.c_int, [_P, C.POINTER(Segment), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_uint]),
     ("jpgpu_batch_upload_frames", C.c_int, [_P, C.POINTER(Frame), C.c_void_p, C.c_int, C.c_int]),
     ("jpgpu_batch_decode", C.c_int, [_P]),
     ("jpgpu_batch_run_entropy", C.c_int, [_P]),
@@ -113,6 +130,20 @@ SYMBOLS = [
     ("jpgpu_decode_scan", C.c_int, [_P, C.POINTER(Frame), C.POINTER(Scan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint16,
                                     C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(ImageResult),
                                     C.POINTER(C.c_size_t)]),
+    ("jpgpu_progressive_begin", C.c_int, [_P, C.POINTER(Frame), C.POINTER(_P)]),
+    ("jpgpu_progressive_scan", C.c_int, [_P, C.POINTER(Scan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint16, C.c_void_p, C.c_size_t,
+                                         C.POINTER(ImageResult), C.POINTER(C.c_size_t)]),
+    ("jpgpu_progressive_output_size", C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
+    ("jpgpu_progressive_dispose", C.c_int, [_P, C.c_int, C.c_void_p, C.c_size_t]),
+    ("jpgpu_progressive_dispose_to_writer", C.c_int, [_P, C.c_void_p, C.c_void_p]),
+    ("jpgpu_progressive_destroy", None, [_P]),
+    ("jpgpu_decoder_set_start_of_frame", C.c_int, [_P, C.c_int]),
+    ("jpgpu_decoder_set_frame_header", C.c_int, [_P, C.POINTER(Frame)]),
+    ("jpgpu_decoder_set_huffman_table", C.c_int, [_P, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    ("jpgpu_decoder_set_quantization_table", C.c_int, [_P, C.c_int, C.c_int, C.c_void_p]),
+    ("jpgpu_decoder_clear_huffman_table", C.c_int, [_P]),
+    ("jpgpu_decoder_clear_quantization_table", C.c_int, [_P]),
+    ("jpgpu_decoder_process_scan", C.c_int, [_P, C.POINTER(Scan), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("jpgpu_decoder_create", C.c_int, [_P, C.POINTER(_P)]),
     ("jpgpu_decoder_destroy", None, [_P]),
     ("jpgpu_decoder_last_error", C.c_char_p, [_P]),
@@ -156,6 +187,7 @@ SYMBOLS = [
     ("jpgpu_optimizer_download", C.c_int, [_P, C.c_int, C.c_void_p, C.c_size_t]),
     ("jpgpu_optimizer_statistics", C.c_int, [_P, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("jpgpu_optimizer_last_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("jpgpu_net_sort_permutation", C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     ("jpgpu_build_optimal_huffman_table", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]),
     ("jpgpu_optimizer_set_most_optimal_coding", C.c_int, [_P, C.c_int]),
 ]

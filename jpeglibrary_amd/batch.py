@@ -50,6 +50,29 @@ class Batch:
         self.format = fmt
         return self
 
+    def upload_segments(self, files, fmt=FMT_INTERLEAVED_U8, pinned=False, arena=False):
+        """files: list of files, each a LIST of bytes-like / uint8-array segments (the ReadOnlySequence<byte> a reference
+        caller hands to SetInput, read in place).  pinned=True: every segment lies in page-locked memory
+        (Context.host_alloc / host_register) and is DMA'd to HBM from where it lies.  arena=True (JPGPU_UPLOAD_PINNED_ARENA): all
+        of them are views into ONE page-locked array, every file contiguous -- the span travels as a few large DMAs."""
+        keep, segs, per = [], [], []
+        for f in files:
+            parts = f if isinstance(f, (list, tuple)) else [f]
+            per.append(len(parts))
+            for part in parts:
+                a = np.frombuffer(part, dtype=np.uint8) if not isinstance(part, np.ndarray) else part
+                if not a.flags["C_CONTIGUOUS"]:
+                    if pinned or arena:
+                        raise ValueError("a pinned segment must be contiguous (a copy would leave the page-locked memory)")
+                    a = np.ascontiguousarray(a)
+                keep.append(a)
+                segs.append((a.ctypes.data if a.size else None, a.size))
+        arr = (_capi.Segment * max(1, len(segs)))(*[_capi.Segment(d, n) for d, n in segs])
+        cnt = (C.c_int * max(1, len(per)))(*per)
+        self._check(_lib.jpgpu_batch_upload_segments(self._h, arr, cnt, len(per), fmt, (_capi.UPLOAD_PINNED_ARENA if arena else 0) | (_capi.UPLOAD_PINNED if pinned else 0)))
+        self.format = fmt
+        return self
+
     def upload_frames(self, frames, quant_tables, fmt=FMT_INTERLEAVED_U8):
         """Coefficient hand-off (progressive images, BASELINE config 5): frames = list of dicts
         {width, height, precision, components: [(id, h, v, tq), ...]}, quant_tables = uint16[n][4][64] (zig-zag order).

@@ -106,19 +106,53 @@ void jpgpu_shard(int n_items, int rank, int world, int *first, int *stride, int 
 
 const char *jpgpu_last_error(const jpgpu_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
 
+// ---------------------------------------------------------------------------------------------- page-locked host memory
+static int host_mem_call(jpgpu_ctx *ctx, hipError_t e, const char *what) {
+    if (e == hipSuccess) return JPGPU_OK;
+    if (ctx) ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? JPGPU_ERR_OUT_OF_MEMORY : JPGPU_ERR_DEVICE;
+}
+int jpgpu_host_alloc(jpgpu_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) return JPGPU_ERR_ARGUMENT;
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    return host_mem_call(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable), "hipHostMalloc");
+}
+int jpgpu_host_free(jpgpu_ctx *ctx, void *p) {
+    if (!ctx) return JPGPU_ERR_ARGUMENT;
+    if (!p) return JPGPU_OK;
+    return host_mem_call(ctx, hipHostFree(p), "hipHostFree");
+}
+int jpgpu_host_register(jpgpu_ctx *ctx, void *p, size_t bytes) {
+    if (!ctx || !p || !bytes) return JPGPU_ERR_ARGUMENT;
+    (void)hipSetDevice(ctx->device);
+    return host_mem_call(ctx, hipHostRegister(p, bytes, hipHostRegisterPortable), "hipHostRegister");
+}
+int jpgpu_host_unregister(jpgpu_ctx *ctx, void *p) {
+    if (!ctx || !p) return JPGPU_ERR_ARGUMENT;
+    return host_mem_call(ctx, hipHostUnregister(p), "hipHostUnregister");
+}
+
 // ---------------------------------------------------------------------------------------------- several devices
-// one context + batch + host thread per device slot, image i on slot i mod G, nothing shared.
+// one context + two batches + one host thread per device slot, image i on slot i mod G, nothing shared.
+// Two batches per slot: call k + 1 is parsed and sent to HBM (upload stream) while call k decodes (decode stream).
 struct jpgpu_multi {
     struct Slot {
         jpgpu_ctx *ctx = nullptr;
-        jpgpu_batch *batch = nullptr;
-        std::vector<const uint8_t *> files;
-        std::vector<size_t> lens;
-        int status = JPGPU_OK;
-        double upload_ms = 0, decode_ms = 0;
+        jpgpu_batch *batch[2] = {nullptr, nullptr};
+        std::vector<jpgpu_segment> segs;
+        std::vector<int> per_file;
+        int status[2] = {JPGPU_OK, JPGPU_OK};
+        double upload_ms[2] = {0, 0}, decode_ms[2] = {0, 0};
+        std::chrono::steady_clock::time_point launched[2];
     };
     std::vector<Slot> slots;
-    int n_items = 0;
+    int n_items[2] = {0, 0};
+    int next_ticket = 0;      // tickets count up; ticket t lives in batch t & 1
+    int last_ticket = -1;
+    bool pending[2] = {false, false};
+    int ticket_in[2] = {-1, -1};  // the ticket whose call lives in batch k
     std::string last_error;
 };
 
@@ -132,10 +166,14 @@ int jpgpu_multi_create(const int *devices, int n_devices, jpgpu_multi **out) {
     std::unique_ptr<jpgpu_multi> m(new (std::nothrow) jpgpu_multi);
     if (!m) return JPGPU_ERR_OUT_OF_MEMORY;
     m->slots.resize((size_t)n_devices);
+    // G slots share the CPUs the process is granted: each slot's crew gets its share (an explicit JPGPU_HOST_THREADS is per slot)
+    const int crew = getenv("JPGPU_HOST_THREADS") ? 0 : std::max(1, std::min(16, jpgpu::granted_host_cpus() / n_devices));
     int rc = JPGPU_OK;
     for (int s = 0; s < n_devices && rc == JPGPU_OK; s++) {
-        rc = jpgpu_create(devices[s], &m->slots[(size_t)s].ctx);
-        if (rc == JPGPU_OK) rc = jpgpu_batch_create(m->slots[(size_t)s].ctx, &m->slots[(size_t)s].batch);
+        jpgpu_multi::Slot &sl = m->slots[(size_t)s];
+        rc = jpgpu_create(devices[s], &sl.ctx);
+        if (rc == JPGPU_OK) sl.ctx->host_threads = crew;
+        for (int k = 0; k < 2 && rc == JPGPU_OK; k++) rc = jpgpu_batch_create(sl.ctx, &sl.batch[k]);
     }
     if (rc != JPGPU_OK) {
         jpgpu_multi_destroy(m.release());
@@ -148,7 +186,8 @@ int jpgpu_multi_create(const int *devices, int n_devices, jpgpu_multi **out) {
 void jpgpu_multi_destroy(jpgpu_multi *m) {
     if (!m) return;
     for (jpgpu_multi::Slot &s : m->slots) {
-        if (s.batch) jpgpu_batch_destroy(s.batch);
+        for (jpgpu_batch *b : s.batch)
+            if (b) jpgpu_batch_destroy(b);
         if (s.ctx) jpgpu_destroy(s.ctx);
     }
     delete m;
@@ -157,71 +196,121 @@ void jpgpu_multi_destroy(jpgpu_multi *m) {
 int jpgpu_multi_devices(const jpgpu_multi *m) { return m ? (int)m->slots.size() : 0; }
 const char *jpgpu_multi_last_error(const jpgpu_multi *m) { return m ? m->last_error.c_str() : g_create_error.c_str(); }
 
-int jpgpu_multi_decode(jpgpu_multi *m, const uint8_t *const *jpeg, const size_t *len, int n, int format, double *upload_ms,
-                       double *decode_ms) {
+int jpgpu_multi_submit(jpgpu_multi *m, const uint8_t *const *jpeg, const size_t *len, int n, int format, unsigned flags, int *ticket) {
     if (!m || n < 0 || (n > 0 && (!jpeg || !len))) return JPGPU_ERR_ARGUMENT;
     const int world = (int)m->slots.size();
-    m->n_items = n;
+    const int t = m->next_ticket, k = t & 1;
     m->last_error.clear();
+    if (m->pending[k]) {
+        m->last_error = "jpgpu_multi_submit: two calls are in flight already (wait for the older one first)";
+        return JPGPU_ERR_INVALID_OPERATION;
+    }
     for (int s = 0; s < world; s++) {
         jpgpu_multi::Slot &sl = m->slots[(size_t)s];
         int first, stride, count;
         jpgpu_shard(n, s, world, &first, &stride, &count);
-        sl.files.clear();
-        sl.lens.clear();
-        for (int k = 0, i = first; k < count; k++, i += stride) {
-            sl.files.push_back(jpeg[i]);
-            sl.lens.push_back(len[i]);
-        }
-        sl.status = JPGPU_OK;
-        sl.upload_ms = sl.decode_ms = 0;
+        sl.segs.clear();
+        for (int j = 0, i = first; j < count; j++, i += stride) sl.segs.push_back({jpeg[i], len[i]});
+        sl.per_file.assign((size_t)count, 1);
+        sl.status[k] = JPGPU_OK;
+        sl.upload_ms[k] = sl.decode_ms[k] = 0;
     }
-    // one host thread per device slot: upload (header parse, staging, H2D), decode, wait -- the shards never meet
-    auto run = [format](jpgpu_multi::Slot *sl) {
+    // one host thread per device slot: upload (header parse, staging or pinned DMA, H2D) and the decode's launches; the shards
+    // never meet.  The threads are joined before this returns: what stays in flight is device work only.
+    auto run = [format, flags, k](jpgpu_multi::Slot *sl) {
         using clk = std::chrono::steady_clock;
         const auto t0 = clk::now();
-        int rc = jpgpu_batch_upload(sl->batch, sl->files.data(), sl->lens.data(), (int)sl->files.size(), format);
+        int rc = jpgpu_batch_upload_segments(sl->batch[k], sl->segs.data(), sl->per_file.data(), (int)sl->per_file.size(), format, flags);
         const auto t1 = clk::now();
-        if (rc == JPGPU_OK) rc = jpgpu_batch_decode(sl->batch);
-        if (rc == JPGPU_OK) rc = jpgpu_batch_sync(sl->batch);
-        const auto t2 = clk::now();
-        sl->status = rc;
-        sl->upload_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-        sl->decode_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        if (rc == JPGPU_OK) rc = jpgpu_batch_decode(sl->batch[k]);
+        sl->status[k] = rc;
+        sl->upload_ms[k] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        sl->launched[k] = t1;
     };
-    try {
+    {
         std::vector<std::thread> threads;
-        for (int s = 1; s < world; s++) threads.emplace_back(run, &m->slots[(size_t)s]);
+        struct Joiner {  // a thread that failed to start (EAGAIN) must not leave started ones joinable behind it
+            std::vector<std::thread> &t;
+            ~Joiner() {
+                for (std::thread &x : t)
+                    if (x.joinable()) x.join();
+            }
+        } joiner{threads};
+        threads.reserve((size_t)world);
+        int started = 1;
+        try {
+            for (int s = 1; s < world; s++, started++) threads.emplace_back(run, &m->slots[(size_t)s]);
+        } catch (const std::exception &) {
+            // the slots without a thread of their own run on this one, after slot 0
+        }
         run(&m->slots[0]);
-        for (std::thread &t : threads) t.join();
-    } catch (const std::exception &e) {
-        m->last_error = e.what();
-        return JPGPU_ERR_DEVICE;
+        for (int s = started; s < world; s++) run(&m->slots[(size_t)s]);
     }
+    m->n_items[k] = n;
+    m->pending[k] = true;
+    m->ticket_in[k] = t;
+    m->last_ticket = t;
+    m->next_ticket++;
+    if (ticket) *ticket = t;
+    int rc = JPGPU_OK;
+    for (int s = 0; s < world && rc == JPGPU_OK; s++)
+        if (m->slots[(size_t)s].status[k] != JPGPU_OK) {
+            rc = m->slots[(size_t)s].status[k];
+            m->last_error = std::string("device slot ") + std::to_string(s) + ": " + jpgpu_last_error(m->slots[(size_t)s].ctx);
+        }
+    return rc;
+}
+
+int jpgpu_multi_wait(jpgpu_multi *m, int ticket, double *upload_ms, double *decode_ms) {
+    if (!m || ticket < 0 || ticket >= m->next_ticket || ticket + 2 < m->next_ticket) return JPGPU_ERR_ARGUMENT;
+    const int k = ticket & 1;
+    const int world = (int)m->slots.size();
     int rc = JPGPU_OK;
     double up = 0, dec = 0;
     for (int s = 0; s < world; s++) {
-        const jpgpu_multi::Slot &sl = m->slots[(size_t)s];
-        if (sl.status != JPGPU_OK && rc == JPGPU_OK) {
-            rc = sl.status;
+        jpgpu_multi::Slot &sl = m->slots[(size_t)s];
+        if (m->pending[k] && sl.status[k] == JPGPU_OK) {
+            sl.status[k] = jpgpu_batch_sync(sl.batch[k]);
+            sl.decode_ms[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sl.launched[k]).count();
+        }
+        if (sl.status[k] != JPGPU_OK && rc == JPGPU_OK) {
+            rc = sl.status[k];
             m->last_error = std::string("device slot ") + std::to_string(s) + ": " + jpgpu_last_error(sl.ctx);
         }
-        up = std::max(up, sl.upload_ms);
-        dec = std::max(dec, sl.decode_ms);
+        up = std::max(up, sl.upload_ms[k]);
+        dec = std::max(dec, sl.decode_ms[k]);
     }
+    m->pending[k] = false;
     if (upload_ms) *upload_ms = up;
     if (decode_ms) *decode_ms = dec;
     return rc;
 }
 
+int jpgpu_multi_decode(jpgpu_multi *m, const uint8_t *const *jpeg, const size_t *len, int n, int format, double *upload_ms,
+                       double *decode_ms) {
+    if (!m) return JPGPU_ERR_ARGUMENT;
+    // the synchronous form: nothing else may be in flight behind it
+    for (int k = 0; k < 2; k++)
+        if (m->pending[k]) (void)jpgpu_multi_wait(m, m->ticket_in[k], nullptr, nullptr);
+    int ticket = -1;
+    const int rc = jpgpu_multi_submit(m, jpeg, len, n, format, 0, &ticket);
+    if (ticket < 0) return rc;
+    const int rc2 = jpgpu_multi_wait(m, ticket, upload_ms, decode_ms);
+    return rc != JPGPU_OK ? rc : rc2;
+}
+
 int jpgpu_multi_locate(const jpgpu_multi *m, int i, int *slot, int *local_index) {
-    if (!m || i < 0 || i >= m->n_items) return JPGPU_ERR_ARGUMENT;
+    if (!m || m->last_ticket < 0 || i < 0 || i >= m->n_items[m->last_ticket & 1]) return JPGPU_ERR_ARGUMENT;
     const int world = (int)m->slots.size();
     if (slot) *slot = i % world;
     if (local_index) *local_index = i / world;
     return JPGPU_OK;
 }
-jpgpu_batch *jpgpu_multi_batch(jpgpu_multi *m, int slot) { return m && slot >= 0 && slot < (int)m->slots.size() ? m->slots[(size_t)slot].batch : nullptr; }
+jpgpu_batch *jpgpu_multi_batch_of(jpgpu_multi *m, int ticket, int slot) {
+    if (!m || slot < 0 || slot >= (int)m->slots.size() || ticket < 0 || ticket >= m->next_ticket || ticket + 2 < m->next_ticket) return nullptr;
+    return m->slots[(size_t)slot].batch[ticket & 1];
+}
+jpgpu_batch *jpgpu_multi_batch(jpgpu_multi *m, int slot) { return m ? jpgpu_multi_batch_of(m, m->last_ticket, slot) : nullptr; }
 jpgpu_ctx *jpgpu_multi_context(jpgpu_multi *m, int slot) { return m && slot >= 0 && slot < (int)m->slots.size() ? m->slots[(size_t)slot].ctx : nullptr; }
 
 const char *jpgpu_status_string(int status) {
@@ -281,6 +370,9 @@ void jpgpu_batch_destroy(jpgpu_batch *b) { delete b; }
 
 int jpgpu_batch_upload(jpgpu_batch *b, const uint8_t *const *jpeg, const size_t *len, int n, int format) {
     JPGPU_GUARD(b, b->impl.upload_files(jpeg, len, n, format));
+}
+int jpgpu_batch_upload_segments(jpgpu_batch *b, const jpgpu_segment *segments, const int *segments_per_file, int n, int format, unsigned flags) {
+    JPGPU_GUARD(b, b->impl.upload_segments(segments, segments_per_file, n, format, flags));
 }
 int jpgpu_batch_upload_frames(jpgpu_batch *b, const jpgpu_frame *frames, const uint16_t *qt, int n, int format) {
     JPGPU_GUARD(b, b->impl.upload_frames(frames, qt, n, format));
@@ -344,6 +436,8 @@ int jpgpu_batch_ingest_stats(const jpgpu_batch *b, jpgpu_ingest_stats *stats) {
     stats->full_walk_ms = s.full_walk_ms;
     stats->layout_ms = s.layout_ms;
     stats->total_ms = s.total_ms;
+    stats->n_pinned_dma = s.n_pinned_dma;
+    stats->n_linearised = s.n_linearised;
     return JPGPU_OK;
 }
 int jpgpu_batch_totals(const jpgpu_batch *b, uint64_t *compressed_bytes, uint64_t *blocks, uint64_t *pixels, uint64_t *output_bytes) {
@@ -425,6 +519,25 @@ struct HostSink8 {
         }
     }
 };
+
+// JpegBlockAllocator.Flush (JpegBlockAllocator.cs:120-190) from PLANAR_I16 planes: component, block row, block column, only the
+// component's own block grid, sub-sampled components expanded like WriteBlockSlow.
+void flush_planes_to_writer(const BaselineGeometry &g, const ImagePlan &img, const uint8_t *planes, jpgpu_write_block_fn fn, void *user) {
+    const FrameHeader &fh = g.frame;
+    const int hb = (fh.samples_per_line + 7) / 8, vb = (fh.lines + 7) / 8;
+    for (int i = 0; i < fh.num_components && i < 4; i++) {
+        const int hs = g.max_h / fh.components[i].h, vs = g.max_v / fh.components[i].v;
+        const int hblocks = (hb + hs - 1) / hs, vblocks = (vb + vs - 1) / vs;
+        const jpgpu_plane_info &pl = img.plane[i];
+        const int16_t *plane = reinterpret_cast<const int16_t *>(planes + pl.offset);
+        for (int row = 0; row < vblocks; row++)
+            for (int col = 0; col < hblocks; col++) {
+                int16_t blk[64];
+                for (int r = 0; r < 8; r++) memcpy(blk + 8 * r, plane + ((size_t)row * 8 + r) * pl.pitch + (size_t)col * 8, 16);
+                write_block_expanded(fn, user, blk, i, col * hs * 8, row * vs * 8, hs, vs);
+            }
+    }
+}
 
 struct ScanOutcome {
     jpgpu_image_result result;
@@ -647,21 +760,7 @@ class GpuScanHandler final : public ScanHandler {
         if (batch.download_output(0, planes.data(), planes.size()) != JPGPU_OK) throw DecodeError(JPGPU_ERR_DEVICE, "output download failed");
         jpgpu_write_block_fn fn = d_->writer == jpgpu_decoder::kBuffer8 ? HostSink8::write : d_->fn;
         void *user = d_->writer == jpgpu_decoder::kBuffer8 ? (void *)&d_->sink8 : d_->user;
-        // Flush order: component, block row, block column; only the component's own block grid
-        const BaselineGeometry &g = frame.geo();
-        const int hb = (fh.samples_per_line + 7) / 8, vb = (fh.lines + 7) / 8;
-        for (int i = 0; i < fh.num_components && i < 4; i++) {
-            const int hs = g.max_h / fh.components[i].h, vs = g.max_v / fh.components[i].v;
-            const int hblocks = (hb + hs - 1) / hs, vblocks = (vb + vs - 1) / vs;
-            const jpgpu_plane_info &pl = img.plane[i];
-            const int16_t *plane = reinterpret_cast<const int16_t *>(planes.data() + pl.offset);
-            for (int row = 0; row < vblocks; row++)
-                for (int col = 0; col < hblocks; col++) {
-                    int16_t blk[64];
-                    for (int r = 0; r < 8; r++) memcpy(blk + 8 * r, plane + ((size_t)row * 8 + r) * pl.pitch + (size_t)col * 8, 16);
-                    write_block_expanded(fn, user, blk, i, col * hs * 8, row * vs * 8, hs, vs);
-                }
-        }
+        flush_planes_to_writer(frame.geo(), img, planes.data(), fn, user);
     }
 
     jpgpu_decoder *d_;
@@ -828,6 +927,278 @@ void jpgpu_decoder_reset(jpgpu_decoder *d) {
 
 }  // extern "C"
 
+// ------------------------------------------------------------------------------------------------ (2b) progressive, per scan
+
+struct jpgpu_progressive {
+    jpgpu_ctx *ctx;
+    HostDecoder dec;         // the frame header, and the tables / restart interval in force at the scan being processed
+    ProgressiveFrame frame;  // the scan decoder's host state: component slots, block grids (ref: ...ProgressiveScanDecoder.cs:23-55)
+    DeviceBatch batch;       // owns the coefficient store in HBM between the calls
+    int n_scans = 0;
+    explicit jpgpu_progressive(jpgpu_ctx *c) : ctx(c), batch(c) {}
+};
+
+namespace {
+void load_tables_from_arguments(HostDecoder &dec, const uint16_t qt[4][64], const uint8_t qt_present[4], const jpgpu_dht dht[2][4]) {
+    dec.reset_tables();
+    for (int id = 0; id < 4; id++) {
+        if (qt && qt_present && qt_present[id]) {
+            QuantTable q;
+            q.identifier = (uint8_t)id;
+            memcpy(q.elements, qt[id], sizeof q.elements);
+            dec.set_quantization_table(q);
+        }
+        for (int cls = 0; cls < 2 && dht; cls++) {
+            const jpgpu_dht &d = dht[cls][id];
+            if (!d.present) continue;
+            HuffTable t;
+            if (!HuffTable::from_bits_values((uint8_t)cls, (uint8_t)id, d.bits, d.values, d.num_values, &t))
+                throw_invalid_data("Failed to parse Huffman table.", kDetailBadHeader);
+            dec.set_huffman_table(t);
+        }
+    }
+}
+FrameHeader frame_from_argument(const jpgpu_frame *frame) {
+    FrameHeader fh;
+    fh.precision = frame->precision;
+    fh.lines = frame->height;
+    fh.samples_per_line = frame->width;
+    fh.num_components = frame->num_components;
+    for (int i = 0; i < frame->num_components && i < 4; i++) fh.components.push_back({frame->comp[i].identifier, frame->comp[i].h, frame->comp[i].v, frame->comp[i].tq});
+    return fh;
+}
+ScanHeader scan_from_argument(const jpgpu_scan *scan) {
+    ScanHeader sh;
+    sh.num_components = scan->num_components;
+    sh.ss = scan->ss;
+    sh.se = scan->se;
+    sh.ah = scan->ah;
+    sh.al = scan->al;
+    for (int i = 0; i < scan->num_components && i < 4; i++) sh.components.push_back({scan->comp[i].selector, scan->comp[i].td, scan->comp[i].ta});
+    return sh;
+}
+template <typename F>
+int guarded_ctx(jpgpu_ctx *ctx, jpgpu_image_result *result, F &&f) {
+    try {
+        return f();
+    } catch (const DecodeError &e) {
+        ctx->last_error = e.what();
+        if (result) {
+            memset(result, 0, sizeof *result);
+            result->status = e.status;
+            result->detail = e.detail;
+        }
+        return e.status;
+    } catch (const std::bad_alloc &) {
+        ctx->last_error = "host allocation failed";
+        return JPGPU_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception &e) {
+        ctx->last_error = e.what();
+        return JPGPU_ERR_DEVICE;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int jpgpu_progressive_begin(jpgpu_ctx *ctx, const jpgpu_frame *frame, jpgpu_progressive **out) {
+    if (!ctx || !out) return JPGPU_ERR_ARGUMENT;
+    *out = nullptr;
+    if (!frame) {
+        ctx->last_error = "jpgpu_progressive_begin: null frame header";
+        return JPGPU_ERR_ARGUMENT;
+    }
+    return guarded_ctx(ctx, nullptr, [&] {
+        if (frame->sof != kSOF2) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "This image type is not supported.", kDetailUnsupportedFrame);
+        if (frame->num_components > 4) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "More than 4 components are not supported.", kDetailUnsupportedFrame);
+        std::unique_ptr<jpgpu_progressive> p(new jpgpu_progressive(ctx));
+        const FrameHeader fh = frame_from_argument(frame);
+        p->dec.set_frame_header(fh);
+        p->dec.set_start_of_frame(kSOF2);
+        p->frame.begin(p->dec, fh);  // the scan decoder's constructor + JpegBlockAllocator.Allocate
+        *out = p.release();
+        return (int)JPGPU_OK;
+    });
+}
+
+int jpgpu_progressive_scan(jpgpu_progressive *p, const jpgpu_scan *scan, const uint16_t qt[4][64], const uint8_t qt_present[4],
+                           const jpgpu_dht dht[2][4], uint16_t restart_interval, const uint8_t *entropy, size_t len,
+                           jpgpu_image_result *result, size_t *bytes_consumed) {
+    if (!p) return JPGPU_ERR_ARGUMENT;
+    if (!scan || !qt || !qt_present || !dht || (!entropy && len)) {
+        p->ctx->last_error = "jpgpu_progressive_scan: null argument";
+        return JPGPU_ERR_ARGUMENT;
+    }
+    if (bytes_consumed) *bytes_consumed = 0;  // ProcessScan leaves the outer reader where it is
+    return guarded_ctx(p->ctx, result, [&] {
+        if (scan->num_components > 4) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "More than 4 components are not supported.", kDetailUnsupportedFrame);
+        load_tables_from_arguments(p->dec, qt, qt_present, dht);
+        p->dec.set_restart_interval(restart_interval);
+        const size_t before = p->frame.scans().size();
+        p->frame.add_scan(p->dec, scan_from_argument(scan), entropy, len);  // ProcessScan's checks (:57-69) and the component slots
+        int rc = p->batch.upload_progressive_scan(p->frame, (int)before, p->n_scans == 0);
+        // the caller's entropy bytes are in HBM now; the recorded job must not keep pointing at them
+        p->frame.scans()[before].entropy = nullptr;
+        p->frame.scans()[before].entropy_len = 0;
+        if (rc != JPGPU_OK) return rc;
+        p->n_scans++;
+        if ((rc = p->batch.run_marker_index()) != JPGPU_OK) return rc;
+        if ((rc = p->batch.run_huffman()) != JPGPU_OK) return rc;
+        if ((rc = p->batch.sync()) != JPGPU_OK) return rc;
+        jpgpu_image_result res;
+        if ((rc = p->batch.result(0, &res)) != JPGPU_OK) return rc;
+        if (result) *result = res;
+        if (res.status != JPGPU_OK) p->ctx->last_error = jpgpu_detail_string(res.detail);
+        return (int)res.status;
+    });
+}
+
+namespace {
+int progressive_idct_pass(jpgpu_progressive *p, int format) {
+    int rc = p->batch.upload_progressive_dispose(p->frame, format);
+    if (rc == JPGPU_OK) rc = p->batch.run_idct();
+    if (rc == JPGPU_OK) rc = p->batch.sync();
+    if (rc != JPGPU_OK) return rc;
+    jpgpu_image_result res;
+    if ((rc = p->batch.result(0, &res)) != JPGPU_OK) return rc;
+    if (res.status != JPGPU_OK) return res.status;  // a scan order whose Dispose() pass the reference mangles
+    return JPGPU_OK;
+}
+}  // namespace
+
+int jpgpu_progressive_dispose(jpgpu_progressive *p, int format, void *out, size_t cap) {
+    if (!p) return JPGPU_ERR_ARGUMENT;
+    if (!out) {
+        p->ctx->last_error = "jpgpu_progressive_dispose: null output";
+        return JPGPU_ERR_ARGUMENT;
+    }
+    return guarded_ctx(p->ctx, nullptr, [&] {
+        if (p->n_scans == 0) return (int)JPGPU_OK;  // Dispose() of an untouched store writes zero-coefficient blocks; nothing decoded, nothing delivered
+        int rc = progressive_idct_pass(p, format);
+        if (rc != JPGPU_OK) return rc;
+        return p->batch.download_output(0, out, cap);
+    });
+}
+
+int jpgpu_progressive_dispose_to_writer(jpgpu_progressive *p, jpgpu_write_block_fn fn, void *user) {
+    if (!p) return JPGPU_ERR_ARGUMENT;
+    if (!fn) {
+        p->ctx->last_error = "Value cannot be null. (Parameter 'outputWriter')";
+        return JPGPU_ERR_ARGUMENT;
+    }
+    return guarded_ctx(p->ctx, nullptr, [&] {
+        if (p->n_scans == 0) return (int)JPGPU_OK;
+        int rc = progressive_idct_pass(p, JPGPU_FMT_PLANAR_I16);
+        if (rc != JPGPU_OK) return rc;
+        const ImagePlan &img = *p->batch.image(0);
+        std::vector<uint8_t> planes(img.out_bytes);
+        if ((rc = p->batch.download_output(0, planes.data(), planes.size())) != JPGPU_OK) return rc;
+        flush_planes_to_writer(p->frame.geo(), img, planes.data(), fn, user);
+        return (int)JPGPU_OK;
+    });
+}
+
+int jpgpu_progressive_output_size(jpgpu_progressive *p, int format, size_t *bytes) {
+    if (!p || !bytes) return JPGPU_ERR_ARGUMENT;
+    return guarded_ctx(p->ctx, nullptr, [&] {
+        const FrameHeader &fh = p->frame.geo().frame;
+        const BaselineGeometry &g = p->frame.geo();
+        size_t n = 0;
+        if (format == JPGPU_FMT_INTERLEAVED_U8) n = (size_t)fh.samples_per_line * fh.lines * fh.num_components;
+        else if (format == JPGPU_FMT_RGB_U8) n = (size_t)fh.samples_per_line * fh.lines * 3;
+        else if (format == JPGPU_FMT_RGBA_U8) n = (size_t)fh.samples_per_line * fh.lines * 4;
+        else if (format == JPGPU_FMT_EXTENDED_U16) n = (size_t)fh.samples_per_line * fh.lines * 8;
+        else if (format == JPGPU_FMT_PLANAR_U8 || format == JPGPU_FMT_PLANAR_I16) {
+            const size_t sb = format == JPGPU_FMT_PLANAR_I16 ? 2 : 1;
+            for (int c = 0; c < fh.num_components && c < 4; c++) {
+                const size_t plane = (size_t)g.mcus_per_line * fh.components[c].h * 8 * (size_t)g.mcus_per_column * fh.components[c].v * 8 * sb;
+                n = (n + plane + 255) / 256 * 256;
+            }
+        } else {
+            throw DecodeError(JPGPU_ERR_ARGUMENT, "unknown format");
+        }
+        *bytes = n;
+        return (int)JPGPU_OK;
+    });
+}
+
+void jpgpu_progressive_destroy(jpgpu_progressive *p) { delete p; }
+
+// ------------------------------------------------------------------------------------------------ (3b) TIFF-style decoder surface
+
+int jpgpu_decoder_set_start_of_frame(jpgpu_decoder *d, int marker) {
+    return guarded(d, [&] {
+        d->host.set_start_of_frame(marker & 0xFF);
+        return JPGPU_OK;
+    });
+}
+int jpgpu_decoder_set_frame_header(jpgpu_decoder *d, const jpgpu_frame *frame) {
+    return guarded(d, [&] {
+        if (!frame) throw DecodeError(JPGPU_ERR_ARGUMENT, "Value cannot be null. (Parameter 'frameHeader')");
+        if (frame->num_components > 4) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "More than 4 components are not supported.", kDetailUnsupportedFrame);
+        d->host.set_frame_header(frame_from_argument(frame));
+        return JPGPU_OK;
+    });
+}
+int jpgpu_decoder_set_huffman_table(jpgpu_decoder *d, int table_class, int identifier, const uint8_t bits[16], const uint8_t *values, int num_values) {
+    return guarded(d, [&] {
+        if (!bits || (!values && num_values)) throw DecodeError(JPGPU_ERR_ARGUMENT, "Value cannot be null. (Parameter 'table')");
+        HuffTable t;
+        if (table_class < 0 || table_class > 1 || identifier < 0 || identifier > 3 || num_values < 0 || num_values > 256 ||
+            !HuffTable::from_bits_values((uint8_t)table_class, (uint8_t)identifier, bits, values, num_values, &t))
+            throw_invalid_data("Failed to parse Huffman table.", kDetailBadHeader);
+        d->host.set_huffman_table(t);
+        return JPGPU_OK;
+    });
+}
+int jpgpu_decoder_set_quantization_table(jpgpu_decoder *d, int element_precision, int identifier, const uint16_t *zigzag64) {
+    return guarded(d, [&] {
+        if (!zigzag64) throw DecodeError(JPGPU_ERR_ARGUMENT, "No actual quantization table is provided. (Parameter 'table')");  // :842-845
+        if (identifier < 0 || identifier > 3 || element_precision < 0 || element_precision > 1)
+            throw DecodeError(JPGPU_ERR_ARGUMENT, "Specified argument was out of the range of valid values. (Parameter 'identifier')");
+        QuantTable q;
+        q.precision = (uint8_t)element_precision;
+        q.identifier = (uint8_t)identifier;
+        memcpy(q.elements, zigzag64, sizeof q.elements);
+        d->host.set_quantization_table(q);
+        return JPGPU_OK;
+    });
+}
+int jpgpu_decoder_clear_huffman_table(jpgpu_decoder *d) {
+    return guarded(d, [&] {
+        d->host.clear_huffman_tables();
+        return JPGPU_OK;
+    });
+}
+int jpgpu_decoder_clear_quantization_table(jpgpu_decoder *d) {
+    return guarded(d, [&] {
+        d->host.clear_quantization_tables();
+        return JPGPU_OK;
+    });
+}
+// JpegDecoder.ProcessScan(ref JpegReader, JpegScanHeader) (:624-632): a scan decoder for StartOfFrame over the frame header
+// set before, ONE scan, Dispose (for a progressive frame that is the IDCT pass + Flush over this one scan's coefficients).
+int jpgpu_decoder_process_scan(jpgpu_decoder *d, const jpgpu_scan *scan, const uint8_t *entropy, size_t len, size_t *bytes_consumed) {
+    if (bytes_consumed) *bytes_consumed = 0;
+    return guarded(d, [&] {
+        if (!scan || (!entropy && len)) throw DecodeError(JPGPU_ERR_ARGUMENT, "Value cannot be null. (Parameter 'scanHeader')");
+        const int sof = d->host.start_of_frame();
+        (void)d->host.frame_header();  // "Call Identify() before this operation." when SetFrameHeader was not called (:378)
+        if (sof != kSOF0 && sof != kSOF1 && sof != kSOF2)
+            throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "This image type is not supported.", kDetailUnsupportedFrame);  // :629 (scan decoders outside this path)
+        if (scan->num_components > 4) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "More than 4 components are not supported.", kDetailUnsupportedFrame);
+        GpuScanHandler handler(d);
+        handler.on_frame(d->host, sof);  // JpegScanDecoder.Create: the restart interval is latched here
+        MarkerReader reader(entropy, len);
+        handler.on_scan(d->host, reader, scan_from_argument(scan));
+        handler.on_dispose(d->host);
+        if (bytes_consumed) *bytes_consumed = (size_t)reader.consumed_byte_count();
+        return JPGPU_OK;
+    });
+}
+
+}  // extern "C"
+
 // ------------------------------------------------------------------------------------------------ (4) encoder
 
 struct jpgpu_encoder {
@@ -896,6 +1267,11 @@ int jpgpu_optimizer_statistics(const jpgpu_optimizer *opt, int i, int table, uin
 int jpgpu_optimizer_last_ms(const jpgpu_optimizer *opt, float *ms) {
     if (!opt || !ms) return JPGPU_ERR_ARGUMENT;
     *ms = opt->impl.last_ms();
+    return JPGPU_OK;
+}
+int jpgpu_net_sort_permutation(const int32_t *keys, int n, int32_t *perm) {
+    if (n < 0 || (n > 0 && (!keys || !perm))) return JPGPU_ERR_ARGUMENT;
+    net_sort_permutation(keys, n, perm);
     return JPGPU_OK;
 }
 int jpgpu_build_optimal_huffman_table(const uint32_t *counts, int most_optimal, uint8_t *bits, uint8_t *values, int *num_values, uint16_t *code,

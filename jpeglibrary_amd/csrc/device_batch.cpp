@@ -50,6 +50,7 @@ DeviceBatch::~DeviceBatch() {
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
+    if (done_ev_) (void)hipEventDestroy(done_ev_);
 }
 
 int DeviceBatch::fail(int status, const std::string &msg) {
@@ -425,65 +426,225 @@ void DeviceBatch::plan_swallowed_terminator(FilePlan &fp, const uint8_t *file, s
 }
 
 // Crew size when the caller did not choose one: the CPUs this process may really use -- the affinity mask and the cgroup
-// CPU quota both bound it (a container often reports the machine's 256 threads and is granted 16) -- capped at 16.
-static int default_host_threads() {
-    if (const char *ev = getenv("JPGPU_HOST_THREADS")) return std::max(1, atoi(ev));
+// CPU quota (v2 cpu.max, v1 cpu.cfs_quota_us) both bound it (a container often reports the machine's 256 threads and is
+// granted 16) -- capped at 16.
+int granted_host_cpus() {
     unsigned cpus = std::max(1u, std::thread::hardware_concurrency());
     cpu_set_t set;
     CPU_ZERO(&set);
     if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) cpus = std::min(cpus, (unsigned)CPU_COUNT(&set));
+    bool have_quota = false;
     if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
         char q[32] = {0};
         long period = 0;
-        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
-            const long quota = atol(q);
-            if (quota > 0) cpus = std::min(cpus, (unsigned)std::max(1L, (quota + period - 1) / period));
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && period > 0) {
+            have_quota = true;
+            if (strcmp(q, "max") != 0) {
+                const long quota = atol(q);
+                if (quota > 0) cpus = std::min(cpus, (unsigned)std::max(1L, (quota + period - 1) / period));
+            }
         }
         fclose(f);
     }
-    return (int)std::min(16u, cpus);  // a handful of threads already keep the host link busy (profiles/r02_ingest_sweep.jsonl)
+    if (!have_quota) {  // cgroup v1: cpu.cfs_quota_us (-1 = unlimited) / cpu.cfs_period_us
+        long quota = -1, period = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(f, "%ld", &quota) != 1) quota = -1;
+            fclose(f);
+        }
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(f, "%ld", &period) != 1) period = 0;
+            fclose(f);
+        }
+        if (quota > 0 && period > 0) cpus = std::min(cpus, (unsigned)std::max(1L, (quota + period - 1) / period));
+    }
+    return (int)cpus;
+}
+int default_host_threads() {
+    if (const char *ev = getenv("JPGPU_HOST_THREADS")) return std::max(1, atoi(ev));
+    return std::min(16, granted_host_cpus());  // a handful of threads already keep the host link busy (profiles/r02_ingest_sweep.jsonl)
+}
+
+// One input file as the caller handed it over: a list of segments (one for jpgpu_batch_upload), and the contiguous bytes the
+// host parser reads -- the file itself, or what was gathered of a multi-segment file (its head for the header-only plan, all
+// of it for the full marker walks).
+struct DeviceBatch::FileSegs {
+    const jpgpu_segment *seg = nullptr;
+    int n = 0;
+    size_t len = 0;
+    const uint8_t *base = nullptr;
+    size_t base_len = 0;
+    std::vector<uint8_t> gathered;
+    static constexpr size_t kHeadBytes = 64u << 10;
+    bool whole() const { return base_len == len; }
+    void gather(size_t want) {
+        want = std::min(want, len);
+        gathered.resize(want);
+        size_t pos = 0;
+        for (int k = 0; k < n && pos < want; k++) {
+            const size_t m = std::min(seg[k].len, want - pos);
+            if (m) memcpy(gathered.data() + pos, seg[k].data, m);
+            pos += m;
+        }
+        base = gathered.data();
+        base_len = want;
+    }
+    uint8_t at(size_t off) const {
+        for (int k = 0; k < n; k++) {
+            if (off < seg[k].len) return seg[k].data[off];
+            off -= seg[k].len;
+        }
+        return 0;
+    }
+};
+
+int DeviceBatch::mark_work() {
+    if (!done_ev_) {
+        hipError_t e = hipEventCreateWithFlags(&done_ev_, hipEventDisableTiming);
+        if (e != hipSuccess) return hip_fail(e, "hipEventCreate(done)");
+    }
+    hipError_t e = hipEventRecord(done_ev_, ctx_->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipEventRecord(done)");
+    work_in_flight_ = true;
+    return JPGPU_OK;
+}
+
+// An upload rewrites the batch's inputs, descriptors and work lists on the upload stream; kernels this batch launched on the
+// decode stream and nobody waited for may still be reading them.  The upload stream waits for them on the device (the host
+// does not block, another batch's decode is not waited for).
+int DeviceBatch::order_upload_behind_work() {
+    if (!work_in_flight_ || !done_ev_) return JPGPU_OK;
+    hipError_t e = hipStreamWaitEvent(ctx_->upload_stream, done_ev_, 0);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent(upload behind decode)");
+    return JPGPU_OK;
 }
 
 int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int n, int format) {
     if (n < 0 || (n > 0 && (!jpeg || !len))) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: null argument");
+    std::vector<jpgpu_segment> segs((size_t)n);
+    std::vector<int> per((size_t)n, 1);
+    for (int i = 0; i < n; i++) segs[(size_t)i] = {jpeg[i], len[i]};
+    return upload_segments(segs.data(), per.data(), n, format, 0);
+}
+
+int DeviceBatch::upload_segments(const jpgpu_segment *segments, const int *segments_per_file, int n, int format, unsigned flags) {
+    if (n < 0 || (n > 0 && (!segments || !segments_per_file))) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: null argument");
     if (format < 0 || format >= kNumOutputFormats) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: unknown format");
+    if (flags & ~(JPGPU_UPLOAD_PINNED | JPGPU_UPLOAD_PINNED_ARENA)) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_segments: unknown flag");
+    const bool pinned = (flags & (JPGPU_UPLOAD_PINNED | JPGPU_UPLOAD_PINNED_ARENA)) != 0;
     using clk = std::chrono::steady_clock;
     auto ms_since = [](clk::time_point t0) { return (float)std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     const clk::time_point t_begin = clk::now();
     ingest_ = IngestStats();
     hipError_t e = hipSetDevice(ctx_->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    int rc = order_upload_behind_work();
+    if (rc != JPGPU_OK) return rc;
     format_ = format;
     images_.assign((size_t)n, ImagePlan());
     jobs_.clear();
     job_image_.clear();
     job_entropy_off_.clear();
-    std::vector<const uint8_t *> file_ptr(jpeg, jpeg + n);
-    std::vector<size_t> file_len(len, len + n);
+    constexpr size_t kMaxFile = 0x7FFFFFF0u;
+    std::vector<FileSegs> files((size_t)n);
+    uint64_t total_bytes = 0;
+    {
+        const jpgpu_segment *sp = segments;
+        for (int i = 0; i < n; i++) {
+            FileSegs &f = files[(size_t)i];
+            if (segments_per_file[i] < 0) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_segments: negative segment count");
+            f.seg = sp;
+            f.n = segments_per_file[i];
+            sp += f.n;
+            for (int k = 0; k < f.n; k++) {
+                if (f.seg[k].len && !f.seg[k].data) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload: null segment");
+                f.len += f.seg[k].len;
+            }
+            if (f.n == 1) {
+                f.base = f.seg[0].data;
+                f.base_len = f.len;
+            }
+            total_bytes += f.len;
+        }
+    }
     std::vector<FilePlan> plans((size_t)n);
 
-    uint64_t total_bytes = 0;
-    for (int i = 0; i < n; i++) total_bytes += len[i];
     const int want = ctx_->host_threads > 0 ? ctx_->host_threads : default_host_threads();
     // no more threads than there is work for: one per 8 files or per 2 MiB, whichever asks for more
     const int useful = (int)std::max<uint64_t>((uint64_t)(n + 7) / 8, total_bytes >> 21);
     WorkCrew crew(std::max(1, std::min(want, useful)));
     ingest_.threads = crew.threads();
 
-    // ---- 1. header-only plans
+    // ---- 1. header-only plans (a multi-segment file: over its first 64 KiB, gathered; should its first scan start behind
+    //         them, or the plan not be "headers + one sequential scan", the whole file is gathered for the full walks)
     clk::time_point t0 = clk::now();
-    crew.run((size_t)n, [&](size_t i, int) { plan_file_headers(jpeg[i], len[i], plans[i]); });
+    std::atomic<int> n_linearised{0};
+    crew.run((size_t)n, [&](size_t i, int) {
+        FileSegs &f = files[i];
+        FilePlan &fp = plans[i];
+        if (f.len > kMaxFile) {
+            fp.img.file_len = f.len;
+            fp.need_full = true;  // refused by the full path before it reads a byte
+            return;
+        }
+        if (f.n > 1) f.gather(FileSegs::kHeadBytes);
+        plan_file_headers(f.base, f.base_len, fp);
+        if (!f.whole()) {
+            if (fp.speculative) {
+                fp.jobs[0].entropy_len = f.len - fp.scan_data_pos;
+            } else {
+                f.gather(f.len);
+                n_linearised.fetch_add(1, std::memory_order_relaxed);
+                plan_file_headers(f.base, f.base_len, fp);
+            }
+        }
+        fp.img.file_len = f.len;
+    });
     ingest_.parse_ms = ms_since(t0);
 
     // ---- 2. the files -> HBM (every file gets its slot, whatever became of its plan: the layout does not wait for plans)
     t0 = clk::now();
+    // One page-locked arena (JPGPU_UPLOAD_PINNED_ARENA): the device copy keeps the arena's own layout -- file i lies where it
+    // lies in the arena, relative to the lowest address -- so the whole span travels as a few large DMAs instead of one per
+    // file (1 MiB copies reach ~36 GB/s on this link, 32 MiB ones 56).  Needs every file contiguous in memory and a span
+    // that is mostly payload; otherwise the files go one DMA per segment.
+    arena_span_ = {nullptr, 0};
+    if ((flags & JPGPU_UPLOAD_PINNED_ARENA) && n > 0) {
+        const uint8_t *lo = nullptr, *hi = nullptr;
+        bool contiguous = true;
+        for (int i = 0; i < n && contiguous; i++) {
+            const FileSegs &f = files[(size_t)i];
+            if (f.len == 0) continue;
+            if (f.len > kMaxFile) contiguous = false;
+            const uint8_t *expect = nullptr;
+            for (int k = 0; k < f.n; k++) {
+                if (!f.seg[k].len) continue;
+                if (expect && f.seg[k].data != expect) contiguous = false;
+                if (!lo || f.seg[k].data < lo) lo = f.seg[k].data;
+                if (!hi || f.seg[k].data + f.seg[k].len > hi) hi = f.seg[k].data + f.seg[k].len;
+                expect = f.seg[k].data + f.seg[k].len;
+            }
+        }
+        if (contiguous && lo && (uint64_t)(hi - lo) <= 2 * total_bytes + (1u << 20)) arena_span_ = {lo, (size_t)(hi - lo)};
+    }
     uint64_t in_off = 256;
-    for (int i = 0; i < n; i++) {
-        plans[i].img.file_offset = in_off;
-        if (len[i] <= 0x7FFFFFF0u) in_off = align_up(in_off + len[i], 256);
+    if (arena_span_.first) {
+        for (int i = 0; i < n; i++) {
+            const FileSegs &f = files[(size_t)i];
+            const uint8_t *first = nullptr;
+            for (int k = 0; k < f.n && !first; k++)
+                if (f.seg[k].len) first = f.seg[k].data;
+            plans[i].img.file_offset = 256 + (first ? (uint64_t)(first - arena_span_.first) : 0u);
+        }
+        in_off = align_up(256 + arena_span_.second, 256);
+    } else {
+        for (int i = 0; i < n; i++) {
+            plans[i].img.file_offset = in_off;
+            if (files[(size_t)i].len <= kMaxFile) in_off = align_up(in_off + files[(size_t)i].len, 256);
+        }
     }
     input_bytes_ = in_off + 256;
-    int rc = stage_files(crew, file_ptr, file_len, plans);
+    rc = stage_files(crew, files, plans, pinned);
     if (rc != JPGPU_OK) return rc;
 
     // ---- 3. the device's verdict on the header-only plans
@@ -496,11 +657,11 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
         if (rc != JPGPU_OK) return rc;
         for (size_t k = 0; k < spec.size(); k++) {
             FilePlan &fp = plans[spec[k]];
-            const uint8_t *data = jpeg[spec[k]] + fp.scan_data_pos;
-            const size_t dlen = len[spec[k]] - fp.scan_data_pos;
+            const FileSegs &f = files[(size_t)spec[k]];
+            const size_t dlen = f.len - fp.scan_data_pos;
             const uint32_t pos = first[k];
             // classify16 only calls FF xx a marker when xx exists: pos + 1 < dlen
-            if (pos != 0xFFFFFFFFu && (size_t)pos + 1 < dlen && data[pos] == 0xFF && data[pos + 1] == kEOI) {
+            if (pos != 0xFFFFFFFFu && (size_t)pos + 1 < dlen && f.at(fp.scan_data_pos + pos) == 0xFF && f.at(fp.scan_data_pos + pos + 1) == kEOI) {
                 fp.seq_ends.assign(1, (size_t)pos);
             } else {
                 fp.speculative = false;
@@ -512,35 +673,56 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
         e = hipStreamSynchronize(ctx_->upload_stream);  // the caller's buffers may be released after upload returns
         if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(upload)");
     }
+    work_in_flight_ = false;  // the upload stream waited for this batch's earlier device work, and has been drained
     ingest_.copy_ms = ms_since(t0);
 
     // ---- 4. the rest: "one byte into the terminator" verdicts of the confirmed plans, full walks of everything else
     t0 = clk::now();
     crew.run((size_t)n, [&](size_t i, int) {
         FilePlan &fp = plans[i];
+        FileSegs &f = files[i];
         const uint64_t off = fp.img.file_offset;
-        if (fp.speculative) plan_swallowed_terminator(fp, jpeg[i], len[i], true);
-        else if (fp.need_full) plan_file_full(jpeg[i], len[i], (int)i, fp);
+        // a multi-segment file planned from its head: the direct verdict needs nothing but offsets when the EOI closes the
+        // file; anything else replays the walk over the whole file, i.e. takes the general path
+        if (fp.speculative && !f.whole() && fp.scan_data_pos + fp.seq_ends[0] + 2 != f.len) {
+            fp.speculative = false;
+            fp.need_full = true;
+        }
+        if (fp.speculative) {
+            plan_swallowed_terminator(fp, f.base, f.len, true);
+        } else if (fp.need_full) {
+            if (!f.whole() && f.len <= kMaxFile) {
+                f.gather(f.len);
+                n_linearised.fetch_add(1, std::memory_order_relaxed);
+            }
+            plan_file_full(f.base, f.len, (int)i, fp);
+        }
         fp.img.file_offset = off;
     });
     ingest_.full_walk_ms = ms_since(t0);
+    ingest_.n_linearised = n_linearised.load();
 
     // ---- 5. merge into the batch's job list (file order)
     t0 = clk::now();
+    std::vector<const uint8_t *> file_ptr((size_t)n);
+    std::vector<size_t> file_len((size_t)n);
     for (int i = 0; i < n; i++) {
         FilePlan &fp = plans[i];
+        const FileSegs &f = files[(size_t)i];
+        file_ptr[(size_t)i] = f.base;
+        file_len[(size_t)i] = f.len;
         const size_t first_job = jobs_.size();
         if (fp.speculative) ingest_.n_header_only++;
         else if (fp.need_full) ingest_.n_full_walk++;
         images_[i] = std::move(fp.img);
         ImagePlan &img = images_[i];
-        img.file_len = len[i];
+        img.file_len = f.len;
         img.jobs.clear();
         if (img.status != JPGPU_OK) continue;
         for (size_t j = 0; j < fp.jobs.size(); j++) {
             img.jobs.push_back((int)(first_job + j));
             job_image_.push_back(i);
-            job_entropy_off_.push_back(fp.jobs[j].entropy ? (uint64_t)(fp.jobs[j].entropy - jpeg[i]) : 0u);
+            job_entropy_off_.push_back(fp.jobs[j].entropy ? (uint64_t)(fp.jobs[j].entropy - f.base) : 0u);
             jobs_.push_back(std::move(fp.jobs[j]));
         }
         if (img.swallow_job >= 0) img.swallow_job += (int)first_job;
@@ -554,13 +736,51 @@ int DeviceBatch::upload_files(const uint8_t *const *jpeg, const size_t *len, int
     return rc;
 }
 
-// Step 2 of the ingest: caller memory -> pinned staging ring -> HBM.  The input buffer is cut into pieces that never cross
-// a 32 MiB slot; the crew copies pieces in buffer order, whoever completes a slot sends it off (one DMA per slot) and
-// records the event that frees the slot for the chunk four slots later.
-int DeviceBatch::stage_files(WorkCrew &crew, const std::vector<const uint8_t *> &file_ptr, const std::vector<size_t> &file_len,
-                             const std::vector<FilePlan> &plans) {
+// Step 2 of the ingest: caller memory -> HBM.
+//  - pageable input: through the pinned staging ring.  The input buffer is cut into pieces that never cross a 32 MiB slot;
+//    the crew copies pieces in buffer order, whoever completes a slot sends it off (one DMA per slot) and records the event
+//    that frees the slot for the chunk n_slots later;
+//  - page-locked input (JPGPU_UPLOAD_PINNED): one DMA per segment from where the caller's bytes lie; the slack between the
+//    files is zeroed by one fill of the whole input buffer in front of the copies (~0.3 ms per GB, on the device).
+int DeviceBatch::stage_files(WorkCrew &crew, const std::vector<FileSegs> &files, const std::vector<FilePlan> &plans, bool pinned) {
     hipError_t e = d_input_.reserve((size_t)input_bytes_);
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(input)");
+    constexpr size_t kMaxFile = 0x7FFFFFF0u;
+    hipStream_t up = ctx_->upload_stream;
+    uint8_t *d_in = (uint8_t *)d_input_.ptr;
+    if (pinned && arena_span_.first) {
+        // the slack in front of the span and behind it is read by the kernels' wide loads: defined (zero); what lies between
+        // the files inside the span are the arena's own bytes (nothing a result depends on: every read is bounded by a length)
+        e = hipMemsetAsync(d_in, 0, 256, up);
+        const uint64_t tail = 256 + arena_span_.second;
+        if (e == hipSuccess) e = hipMemsetAsync(d_in + tail, 0, (size_t)(input_bytes_ - tail), up);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(input slack)");
+        constexpr size_t kChunk = 32u << 20;
+        for (size_t off = 0; off < arena_span_.second; off += kChunk) {
+            const size_t m = std::min(kChunk, arena_span_.second - off);
+            e = hipMemcpyAsync(d_in + 256 + off, arena_span_.first + off, m, hipMemcpyHostToDevice, up);
+            if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(pinned arena)");
+            ingest_.n_pinned_dma++;
+        }
+        return JPGPU_OK;
+    }
+    if (pinned) {
+        e = hipMemsetAsync(d_in, 0, (size_t)input_bytes_, up);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(input)");
+        for (size_t i = 0; i < plans.size(); i++) {
+            const FileSegs &f = files[i];
+            if (f.len > kMaxFile || f.len == 0) continue;
+            uint64_t off = plans[i].img.file_offset;
+            for (int k = 0; k < f.n; k++) {
+                if (!f.seg[k].len) continue;
+                e = hipMemcpyAsync(d_in + off, f.seg[k].data, f.seg[k].len, hipMemcpyHostToDevice, up);
+                if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(pinned segment)");
+                off += f.seg[k].len;
+                ingest_.n_pinned_dma++;
+            }
+        }
+        return JPGPU_OK;
+    }
     struct Piece {
         const uint8_t *src;  // nullptr: zero fill (slack in front of the first file, behind the last, between files)
         uint64_t dst;
@@ -583,11 +803,16 @@ int DeviceBatch::stage_files(WorkCrew &crew, const std::vector<const uint8_t *> 
     };
     uint64_t pos = 0;
     for (size_t i = 0; i < plans.size(); i++) {
-        const uint64_t off = plans[i].img.file_offset;
-        if (file_len[i] > 0x7FFFFFF0u || file_len[i] == 0 || !file_ptr[i]) continue;
+        const FileSegs &f = files[i];
+        uint64_t off = plans[i].img.file_offset;
+        if (f.len > kMaxFile || f.len == 0) continue;
         if (off > pos) add(nullptr, pos, off - pos);
-        add(file_ptr[i], off, file_len[i]);
-        pos = off + file_len[i];
+        for (int k = 0; k < f.n; k++) {
+            if (!f.seg[k].len) continue;
+            add(f.seg[k].data, off, f.seg[k].len);
+            off += f.seg[k].len;
+        }
+        pos = off;
     }
     if (input_bytes_ > pos) add(nullptr, pos, input_bytes_ - pos);
 
@@ -611,8 +836,6 @@ int DeviceBatch::stage_files(WorkCrew &crew, const std::vector<const uint8_t *> 
     }
     std::atomic<int> hip_error{(int)hipSuccess};
     const int device = ctx_->device;
-    hipStream_t up = ctx_->upload_stream;
-    uint8_t *d_in = (uint8_t *)d_input_.ptr;
     const uint64_t total = input_bytes_;
     crew.run(pieces.size(), [&](size_t k, int) {
         const Piece &p = pieces[k];
@@ -747,6 +970,62 @@ int DeviceBatch::upload_progressive_frame(const ProgressiveFrame &frame, const u
     return layout_and_upload(fp, fl);
 }
 
+int DeviceBatch::upload_progressive_scan(const ProgressiveFrame &frame, int scan_index, bool first_scan) {
+    if (scan_index < 0 || scan_index >= (int)frame.scans().size()) return fail(JPGPU_ERR_ARGUMENT, "progressive scan index out of range");
+    format_ = JPGPU_FMT_INTERLEAVED_U8;  // no samples are produced by a scan; the smallest output layout
+    images_.assign(1, ImagePlan());
+    jobs_.clear();
+    job_image_.clear();
+    job_entropy_off_.clear();
+    jobs_.push_back(frame.make_frame_job());  // the store's geometry (and position: block 0 of the coefficient buffer)
+    jobs_.push_back(frame.scans()[(size_t)scan_index]);
+    ScanJob &scan = jobs_.back();
+    // the scans this one depends on ran in earlier calls: nothing to wait for inside the launch
+    scan.n_deps = 0;
+    scan.deps[0] = scan.deps[1] = scan.deps[2] = -1;
+    scan.ordinal = 0;
+    scan.has_consumers = false;
+    ImagePlan &img = images_[0];
+    img.sof = kSOF2;
+    img.file_len = scan.entropy_len;
+    plan_image_geometry(img, jobs_[0].geo);
+    img.blocks_per_mcu = (uint32_t)jobs_[0].blocks_per_mcu;
+    for (size_t j = 0; j < jobs_.size(); j++) {
+        img.jobs.push_back((int)j);
+        job_image_.push_back(0);
+        job_entropy_off_.push_back(0);
+    }
+    std::vector<const uint8_t *> fp(1, scan.entropy);
+    std::vector<size_t> fl(1, scan.entropy_len);
+    const int rc = layout_and_upload(fp, fl);
+    keep_progressive_store_ = !first_scan;
+    defer_refusal_ = true;
+    return rc;
+}
+
+int DeviceBatch::upload_progressive_dispose(const ProgressiveFrame &frame, int format) {
+    if (format < 0 || format >= kNumOutputFormats) return fail(JPGPU_ERR_ARGUMENT, "unknown format");
+    format_ = format;
+    images_.assign(1, ImagePlan());
+    jobs_.clear();
+    job_image_.clear();
+    job_entropy_off_.clear();
+    jobs_.push_back(frame.make_frame_job());
+    ImagePlan &img = images_[0];
+    img.sof = kSOF2;
+    plan_image_geometry(img, jobs_[0].geo);
+    img.blocks_per_mcu = (uint32_t)jobs_[0].blocks_per_mcu;
+    img.jobs.push_back(0);
+    job_image_.push_back(0);
+    job_entropy_off_.push_back(0);
+    std::vector<const uint8_t *> fp(1, nullptr);
+    std::vector<size_t> fl(1, 0);
+    const int rc = layout_and_upload(fp, fl);
+    keep_progressive_store_ = true;
+    defer_refusal_ = false;
+    return rc;
+}
+
 int DeviceBatch::upload_frames(const jpgpu_frame *frames, const uint16_t *qt, int n, int format) {
     if (n < 0 || (n > 0 && (!frames || !qt))) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_frames: null argument");
     if (format < 0 || format >= kNumOutputFormats) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_frames: unknown format");
@@ -809,8 +1088,14 @@ int DeviceBatch::upload_frames(const jpgpu_frame *frames, const uint16_t *qt, in
 int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr, const std::vector<size_t> &file_len) {
     hipError_t e = hipSetDevice(ctx_->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    {
+        const int rc0 = order_upload_behind_work();
+        if (rc0 != JPGPU_OK) return rc0;
+    }
     status_valid_ = false;
     ev_used_ = 0;
+    keep_progressive_store_ = false;
+    defer_refusal_ = false;
 
     // ---- input layout (jpgpu_batch_upload has laid the files out and sent them already: files_resident_)
     if (!files_resident_) {
@@ -1224,6 +1509,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     }
     e = hipStreamSynchronize(up);  // the caller's buffers may be released after upload returns
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(upload)");
+    work_in_flight_ = false;  // the upload stream waited for this batch's earlier device work
     return JPGPU_OK;
 }
 
@@ -1233,7 +1519,7 @@ int DeviceBatch::run_marker_index() {
                                        (const ChunkWork *)d_chunk_work_.ptr, n_chunk_work_, (ChunkSum *)d_chunk_sums_.ptr,
                                        (uint32_t *)d_ends_.ptr, (DevScanStatus *)d_status_.ptr, (uint8_t *)d_unstuffed_.ptr,
                                        (uint32_t *)d_ends_u_.ptr);
-    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "marker_index_kernel");
+    return e == hipSuccess ? mark_work() : hip_fail(e, "marker_index_kernel");
 }
 int DeviceBatch::run_huffman() {
     status_valid_ = false;
@@ -1251,7 +1537,8 @@ int DeviceBatch::run_huffman() {
                                  &last_subseq_rounds_, (const uint32_t *)d_lut_pool_.ptr, (const HuffWork *)d_sub_final_work_.ptr, n_sub_final_work_);
         if (e != hipSuccess) return hip_fail(e, "subsequence decode");
     }
-    return run_progressive();
+    const int rc = run_progressive();
+    return rc != JPGPU_OK ? rc : mark_work();
 }
 // The synchronisation of the DRI = 0 scans alone (optimizer path): converged exit states + first block of every subsequence.
 int DeviceBatch::run_subseq_sync(const uint32_t **final_state, const uint32_t **first_block) {
@@ -1267,13 +1554,14 @@ int DeviceBatch::run_subseq_sync(const uint32_t **final_state, const uint32_t **
                                       n_huff_slots_, (int)max_subs_per_scan_ + 2, &last_subseq_rounds_, (const uint32_t *)d_lut_pool_.ptr,
                                       final_state);
     if (e != hipSuccess) return hip_fail(e, "subsequence synchronisation");
-    return JPGPU_OK;
+    return mark_work();
 }
 int DeviceBatch::run_progressive() {
     if (prog_begin_.size() <= 1) return JPGPU_OK;
     status_valid_ = false;
     // every frame's store starts from zero (JpegBlockAllocator.Allocate clears it, JpegBlockAllocator.cs:81-83)
     for (const auto &c : prog_clear_) {
+        if (keep_progressive_store_) break;  // per-scan boundary: the store holds the scans of earlier calls
         hipError_t e = hipMemsetAsync((int16_t *)d_coefs_.ptr + c.first * 64, 0, (size_t)c.second * 128, ctx_->stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(progressive store)");
     }
@@ -1369,7 +1657,7 @@ int DeviceBatch::run_idct() {
                               rc.components, format_ == JPGPU_FMT_RGBA_U8 ? 4 : 3, kf);
         if (e != hipSuccess) return hip_fail(e, "ycc_to_rgb_kernel");
     }
-    return JPGPU_OK;
+    return mark_work();
 }
 
 // One pass of the device pipeline over the batch.
@@ -1441,12 +1729,16 @@ int DeviceBatch::decode() {
     }
     ev_serial_.push_back(serial);
     ev_used_ += 4;
-    return JPGPU_OK;
+    return mark_work();
 }
 
+// Waits for the device work THIS batch has issued (the event behind its last launch): another batch of the context may be
+// decoding on the same stream -- jpgpu_multi_wait waits for call k while call k + 1 runs -- and is not waited for.
 int DeviceBatch::sync() {
-    hipError_t e = hipStreamSynchronize(ctx_->stream);
-    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "hipStreamSynchronize");
+    hipError_t e = work_in_flight_ && done_ev_ ? hipEventSynchronize(done_ev_) : hipStreamSynchronize(ctx_->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    work_in_flight_ = false;
+    return JPGPU_OK;
 }
 
 // Average device time (HIP events on the decode stream) over the decode() calls issued since the previous query: the three
@@ -1560,7 +1852,7 @@ int DeviceBatch::result(int i, jpgpu_image_result *res) {
         ctx_->last_error = img->late_error;
         return JPGPU_OK;
     }
-    if (res->status == JPGPU_OK) {
+    if (res->status == JPGPU_OK && !defer_refusal_) {
         for (int j : img->jobs)
             if (!jobs_[j].refuse.empty()) {
                 res->status = JPGPU_ERR_NOT_SUPPORTED;

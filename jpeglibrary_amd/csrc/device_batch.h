@@ -10,6 +10,13 @@
 #include "host.h"
 #include "kernels.h"
 
+namespace jpgpu {
+// Crew size when the caller did not choose one: the CPUs this process may really use (affinity mask, cgroup v2 / v1 quota),
+// capped at 16; JPGPU_HOST_THREADS overrides.  granted_host_cpus() is the same figure without the cap and the override.
+int default_host_threads();
+int granted_host_cpus();
+}  // namespace jpgpu
+
 // Pinned staging ring of a context: the caller's (pageable) file bytes are copied into it by the host crew and leave it
 // as few large DMAs on the context's upload stream (ref input contract: caller-owned, possibly multi-segment
 // ReadOnlySequence<byte>, apps/JpegDecode/MemoryPoolBufferWriter.cs:166-174 -- "the shim linearises into pinned memory").
@@ -50,6 +57,8 @@ struct IngestStats {
     int n_header_only = 0;  // files whose plan came from their headers alone, confirmed by the device
     int n_full_walk = 0;    // files that took the full Identify + Decode marker walks on the host
     float parse_ms = 0, copy_ms = 0, full_walk_ms = 0, layout_ms = 0, total_ms = 0;
+    int n_pinned_dma = 0;   // segments DMA'd straight from the caller's page-locked memory
+    int n_linearised = 0;   // multi-segment files gathered as a whole on the host
 };
 
 struct ImagePlan {
@@ -89,8 +98,19 @@ class DeviceBatch {
 
     // Whole files: host parse (Identify + Decode's marker loop) -> plans/jobs -> HBM.
     int upload_files(const uint8_t *const *jpeg, const size_t *len, int n, int format);
+    // The same for files handed over as lists of segments (the ReadOnlySequence<byte> a reference caller passes to SetInput,
+    // JpegDecoder.cs:56-62; multi-segment: apps/JpegDecode/MemoryPoolBufferWriter.cs:166-174): file i is the next
+    // segments_per_file[i] entries of `segments`.  flags & JPGPU_UPLOAD_PINNED: every segment lies in page-locked memory
+    // (jpgpu_host_alloc / jpgpu_host_register) and is DMA'd to HBM from where it lies -- no staging copy, no crew time.
+    int upload_segments(const jpgpu_segment *segments, const int *segments_per_file, int n, int format, unsigned flags);
     // One progressive frame collected by the JpegDecoder mirror: its entropy scans + the Dispose() pass.
     int upload_progressive_frame(const ProgressiveFrame &frame, const uint8_t *file, size_t file_len, int sof, int format);
+    // The per-scan boundary (jpgpu_progressive_*): ONE entropy scan of the frame (index into frame.scans()) accumulating into
+    // the frame's coefficient store, which lives in d_coefs_ and persists from call to call (same frame, same layout, the
+    // buffers only grow); first_scan clears it like JpegBlockAllocator.Allocate does.  Then run_marker_index + run_huffman.
+    int upload_progressive_scan(const ProgressiveFrame &frame, int scan_index, bool first_scan);
+    // ... and the Dispose() pass alone over that store: the frame job without entropy scans; then run_idct.
+    int upload_progressive_dispose(const ProgressiveFrame &frame, int format);
     // One pre-built scan job whose entropy bytes are `entropy` (level-2 API and the JpegDecoder mirror).
     int upload_single_job(const ScanJob &job, int format, const void *initial_output, size_t initial_output_bytes);
     // Coefficient hand-off (progressive / config 5): images described by frame geometry + quantisation tables only.
@@ -102,7 +122,7 @@ class DeviceBatch {
     int run_idct();
     int run_progressive();     // entropy scans of progressive frames (K2P), ordinal by ordinal
     int decode();  // marker index + the selected pipeline, with stage events
-    int sync();
+    int sync();    // waits for THIS batch's device work (an event behind its last launch), not for the whole stream
 
     int size() const { return (int)images_.size(); }
     const ImagePlan *image(int i) const { return (i >= 0 && i < (int)images_.size()) ? &images_[i] : nullptr; }
@@ -142,14 +162,23 @@ class DeviceBatch {
     void plan_file_headers(const uint8_t *file, size_t len, FilePlan &fp) const;
     void plan_file_full(const uint8_t *file, size_t len, int index, FilePlan &fp) const;
     void plan_swallowed_terminator(FilePlan &fp, const uint8_t *file, size_t len, bool identify_is_clean) const;
-    int stage_files(WorkCrew &crew, const std::vector<const uint8_t *> &file_ptr, const std::vector<size_t> &file_len,
-                    const std::vector<FilePlan> &plans);
+    struct FileSegs;
+    int stage_files(WorkCrew &crew, const std::vector<FileSegs> &files, const std::vector<FilePlan> &plans, bool pinned);
+    // device work of this batch issued since its last sync(): uploads are ordered behind it (an upload right
+    // after an un-synced decode must not overwrite what that decode's kernels still read)
+    int mark_work();
+    int order_upload_behind_work();
+    std::pair<const uint8_t *, size_t> arena_span_ = {nullptr, 0};  // JPGPU_UPLOAD_PINNED_ARENA: the span the device copy mirrors
+    hipEvent_t done_ev_ = nullptr;
+    bool work_in_flight_ = false;
     int verify_plans(const std::vector<FilePlan> &plans, const std::vector<int> &spec, std::vector<uint32_t> &first);
     bool files_resident_ = false;  // layout_and_upload: the files are in d_input_ already (staged by upload_files)
     IngestStats ingest_;
     DevBuffer d_verify_;
     int fetch_status();
     int clear_partial_outputs();
+    bool keep_progressive_store_ = false;  // run_progressive: the store holds earlier scans' coefficients (per-scan boundary)
+    bool defer_refusal_ = false;           // result(): a frame job's `refuse` is the Dispose() pass's business, not a scan's
     bool keep_canvas_ = false;  // layout of a single scan job over the caller's samples: nothing the scan does not write is touched
     struct OutClear {
         uint64_t first, second;              // (offset, bytes) in the output buffer

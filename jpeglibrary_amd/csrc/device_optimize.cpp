@@ -222,6 +222,13 @@ bool build_package_merge(const uint32_t freq[256], std::vector<OptimalCode> *cod
 }
 }  // namespace
 
+void net_sort_permutation(const int32_t *keys, int n, int32_t *perm) {
+    std::vector<const int32_t *> ptrs((size_t)std::max(0, n));
+    for (int i = 0; i < n; i++) ptrs[(size_t)i] = keys + i;
+    net_sort<int32_t>(ptrs, [](const int32_t &x, const int32_t &y) { return x < y ? -1 : (x > y ? 1 : 0); });
+    for (int i = 0; i < n; i++) perm[i] = (int32_t)(ptrs[(size_t)i] - keys);
+}
+
 bool build_optimal_table(const uint32_t freq[256], std::vector<OptimalCode> *codes, bool most_optimal) {
     if (most_optimal) return build_package_merge(freq, codes);
     int code_count = 0;
@@ -272,11 +279,15 @@ bool build_optimal_table(const uint32_t freq[256], std::vector<OptimalCode> *cod
             bits[cs - 1]++;
         }
     }
+    // The counters are BYTES in the reference (Span<byte> bits, :118): 256 codes of one length -- 255 symbols of nearly equal
+    // frequency plus the reserved one, a perfect tree of depth 8 -- wrap to zero, and the searches below then walk off the
+    // front of the span: the reference throws IndexOutOfRangeException.  Same here: failure, not a walk through the stack.
     for (;;) {
         while (bits[index] > 0) {
             int j = index - 1;
             do {
                 j -= 1;
+                if (j < 0) return false;
             } while (bits[j] == 0);
             bits[index] = (uint8_t)(bits[index] - 2);
             bits[index - 1] = (uint8_t)(bits[index - 1] + 1);
@@ -285,7 +296,10 @@ bool build_optimal_table(const uint32_t freq[256], std::vector<OptimalCode> *cod
         }
         index -= 1;
         if (index != 15) continue;
-        while (bits[index] == 0) index--;
+        while (bits[index] == 0) {
+            index--;
+            if (index < 0) return false;
+        }
         bits[index]--;
         break;
     }
@@ -749,7 +763,17 @@ int OptimizeBatch::run() {
         for (int t = 0; t < job.n_huff; t++) {
             std::vector<OptimalCode> codes;
             const uint32_t *freq = &h_hist_[((size_t)p.job * kMaxHuffSlots + t) * 256];
-            if (!build_optimal_table(freq, &codes, most_optimal_)) continue;  // a failing scan: reported from the device status below
+            if (!build_optimal_table(freq, &codes, most_optimal_)) {
+                // no symbol counted: a failing scan, reported from the device status below.  Symbols counted and no table: the
+                // reference's byte counters overflowed (build_optimal_table) -- its Build() dies with IndexOutOfRangeException
+                bool any = false;
+                for (int sym = 0; sym < 256; sym++) any |= freq[sym] != 0;
+                if (any && p.late_status == JPGPU_OK) {  // behind the scan's own failures: BuildTables runs after ProcessScanBaseline (:462)
+                    p.late_status = JPGPU_ERR_INVALID_OPERATION;
+                    p.late_error = "Index was outside the bounds of the array.";
+                }
+                continue;
+            }
             EncHuffTable &et = enc[(size_t)p.job * kMaxHuffSlots + t];
             // GetCode(symbol) = codes[_symbolMap[symbol]], and _symbolMap is 0 for symbols without a code (JpegHuffmanEncodingTable.cs:18-33, 90-96)
             for (int sym = 0; sym < 256; sym++) {

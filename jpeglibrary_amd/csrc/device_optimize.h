@@ -16,6 +16,8 @@ struct OptimalCode {
     uint16_t code;
     uint8_t symbol, length;
 };
+// perm[i] = original index of the key the restated Array.Sort(T[], Comparison<T>) leaves at position i (ascending by key)
+void net_sort_permutation(const int32_t *keys, int n, int32_t *perm);
 bool build_optimal_table(const uint32_t freq[256], std::vector<OptimalCode> *codes, bool most_optimal = false);  // Build(optimal)
 
 class OptimizeBatch {

@@ -159,6 +159,8 @@ class HostDecoder {
     void reset_input() { input_ = nullptr; input_len_ = 0; }                            // :941
     void reset_header() { frame_.reset(); restart_interval_ = 0; }                      // :949
     void reset_tables() { huff_.clear(); quant_.clear(); }                              // :960
+    void clear_huffman_tables() { huff_.clear(); }                                      // ClearHuffmanTable :768-771
+    void clear_quantization_tables() { quant_.clear(); }                                // ClearQuantizationTable :784-787
     const uint8_t *input() const { return input_; }
     size_t input_len() const { return input_len_; }
 

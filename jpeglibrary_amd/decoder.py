@@ -104,6 +104,143 @@ class JpegExtendingOutputWriter(JpegBlockOutputWriter):
         out[y:y + wh, x:x + ww, componentIndex] = (self._expand(v) & 0xFFFF).astype(np.uint16)
 
 
+class JpegFrameComponentSpecificationParameters:
+    """ref: JpegFrameHeader.cs:243-249"""
+
+    def __init__(self, identifier, horizontalSamplingFactor, verticalSamplingFactor, quantizationTableSelector):  # noqa: N803
+        self.Identifier, self.HorizontalSamplingFactor = int(identifier), int(horizontalSamplingFactor)
+        self.VerticalSamplingFactor, self.QuantizationTableSelector = int(verticalSamplingFactor), int(quantizationTableSelector)
+
+
+class JpegFrameHeader:
+    """ref: JpegFrameHeader.cs:22-29 (the SOF payload)."""
+
+    def __init__(self, samplePrecision, numberOfLines, samplesPerLine, numberOfComponents, components):  # noqa: N803
+        self.SamplePrecision, self.NumberOfLines, self.SamplesPerLine = int(samplePrecision), int(numberOfLines), int(samplesPerLine)
+        self.NumberOfComponents, self.Components = int(numberOfComponents), list(components or [])
+
+    def _c(self, sof=0):
+        f = _capi.Frame()
+        f.width, f.height, f.precision, f.num_components, f.sof = self.SamplesPerLine, self.NumberOfLines, self.SamplePrecision, self.NumberOfComponents, sof
+        for i, c in enumerate(self.Components[:4]):
+            f.comp[i] = _capi.FrameComponent(c.Identifier, c.HorizontalSamplingFactor, c.VerticalSamplingFactor, c.QuantizationTableSelector)
+        return f
+
+
+class JpegScanComponentSpecificationParameters:
+    """ref: JpegScanHeader.cs:265-270"""
+
+    def __init__(self, scanComponentSelector, dcEntropyCodingTableSelector, acEntropyCodingTableSelector):  # noqa: N803
+        self.ScanComponentSelector = int(scanComponentSelector)
+        self.DcEntropyCodingTableSelector, self.AcEntropyCodingTableSelector = int(dcEntropyCodingTableSelector), int(acEntropyCodingTableSelector)
+
+
+class JpegScanHeader:
+    """ref: JpegScanHeader.cs:23-31 (the SOS payload)."""
+
+    def __init__(self, numberOfComponents, components, startOfSpectralSelection, endOfSpectralSelection,  # noqa: N803
+                 successiveApproximationBitPositionHigh, successiveApproximationBitPositionLow):  # noqa: N803
+        self.NumberOfComponents, self.Components = int(numberOfComponents), list(components or [])
+        self.StartOfSpectralSelection, self.EndOfSpectralSelection = int(startOfSpectralSelection), int(endOfSpectralSelection)
+        self.SuccessiveApproximationBitPositionHigh = int(successiveApproximationBitPositionHigh)
+        self.SuccessiveApproximationBitPositionLow = int(successiveApproximationBitPositionLow)
+
+    def _c(self):
+        s = _capi.Scan()
+        s.num_components, s.ss, s.se = self.NumberOfComponents, self.StartOfSpectralSelection, self.EndOfSpectralSelection
+        s.ah, s.al = self.SuccessiveApproximationBitPositionHigh, self.SuccessiveApproximationBitPositionLow
+        for i, c in enumerate(self.Components[:4]):
+            s.comp[i] = _capi.ScanComponent(c.ScanComponentSelector, c.DcEntropyCodingTableSelector, c.AcEntropyCodingTableSelector, 0)
+        return s
+
+
+class JpegHuffmanDecodingTable:
+    """ref: JpegHuffmanDecodingTable.cs -- the DHT payload behind the Tc/Th byte: BITS[16] + HUFFVAL (TryParse :249-291).
+    The canonical codes and lookup tables are derived on the host side of the library, as Configure (:339-376) does."""
+
+    def __init__(self, tableClass, identifier, bits, values):  # noqa: N803
+        self.TableClass, self.Identifier = int(tableClass), int(identifier)
+        self.bits, self.values = bytes(bits), bytes(values)
+        if len(self.bits) != 16:
+            raise ArgumentException("BITS must hold 16 counts.")
+
+
+def _tables_c(quantizationTables, huffmanTables):  # noqa: N803
+    """(qt[4][64], qt_present[4], dht[2][4]) for the per-scan entry points, from the decoder-registry-style lists."""
+    qt = np.zeros((4, 64), np.uint16)
+    present = np.zeros(4, np.uint8)
+    for q in quantizationTables or []:
+        if q is None or q.IsEmpty:
+            continue
+        qt[q.Identifier & 3] = np.asarray(q.Elements, np.uint16)
+        present[q.Identifier & 3] = 1
+    dht = ((_capi.Dht * 4) * 2)()
+    for t in huffmanTables or []:
+        d = dht[t.TableClass & 1][t.Identifier & 3]
+        d.present = 1
+        for i in range(16):
+            d.bits[i] = t.bits[i]
+        d.num_values = len(t.values)
+        for i, v in enumerate(t.values[:256]):
+            d.values[i] = v
+    return qt, present, dht
+
+
+class JpegGpuProgressiveScanDecoder:
+    """The per-scan boundary for SOF2 frames (include/jpgpu.h 2b: jpgpu_progressive_*): what JpegDecoder does with the scan
+    decoder JpegScanDecoder.Create(SOF2, ...) returns -- constructor at SOF, ProcessScan at every SOS with the tables and the
+    restart interval in force there, Dispose at the end (ref: ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs:23-90, 421-470;
+    JpegDecoder.cs:562-570, 592-599, 545-549).  The coefficient store lives in HBM between the calls."""
+
+    def __init__(self, frameHeader, ctx: Context = None):  # noqa: N803
+        self._ctx = ctx or default_context()
+        self._h = C.c_void_p()
+        f = frameHeader._c(0xC2)
+        raise_for_status(_lib.jpgpu_progressive_begin(self._ctx._h, C.byref(f), C.byref(self._h)), _lib.jpgpu_last_error(self._ctx._h))
+
+    def ProcessScan(self, entropy, scanHeader, quantizationTables, huffmanTables, restartInterval=0):  # noqa: N802,N803
+        """Decodes one scan into the store; raises the reference's exception for this scan.  Returns the reader advance (0)."""
+        a = np.frombuffer(entropy, dtype=np.uint8) if not isinstance(entropy, np.ndarray) else np.ascontiguousarray(entropy, dtype=np.uint8)
+        qt, present, dht = _tables_c(quantizationTables, huffmanTables)
+        sc = scanHeader._c()
+        res = _capi.ImageResult()
+        consumed = C.c_size_t()
+        rc = _lib.jpgpu_progressive_scan(self._h, C.byref(sc), qt.ctypes.data, present.ctypes.data, C.cast(dht, C.c_void_p), int(restartInterval),
+                                         a.ctypes.data if a.size else None, a.size, C.byref(res), C.byref(consumed))
+        raise_for_status(rc, _lib.jpgpu_last_error(self._ctx._h))
+        return consumed.value
+
+    def output_size(self, fmt):
+        n = C.c_size_t()
+        raise_for_status(_lib.jpgpu_progressive_output_size(self._h, fmt, C.byref(n)), _lib.jpgpu_last_error(self._ctx._h))
+        return n.value
+
+    def Dispose(self, outputWriter=None, fmt=None):  # noqa: N802,N803
+        """The IDCT pass + Flush.  outputWriter: a JpegBlockOutputWriter (WriteBlock calls in Flush's order); or fmt: one of the
+        FMT_* device layouts, returned as a flat uint8 array."""
+        if outputWriter is not None:
+            def _cb(_user, blk, ci, x, y):
+                outputWriter.WriteBlock(np.ctypeslib.as_array(blk, shape=(64,)), ci, x, y)
+
+            cb = _capi.WRITE_BLOCK_FN(_cb)
+            raise_for_status(_lib.jpgpu_progressive_dispose_to_writer(self._h, C.cast(cb, C.c_void_p), None), _lib.jpgpu_last_error(self._ctx._h))
+            return None
+        out = np.zeros(self.output_size(fmt), np.uint8)
+        raise_for_status(_lib.jpgpu_progressive_dispose(self._h, fmt, out.ctypes.data, out.size), _lib.jpgpu_last_error(self._ctx._h))
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.jpgpu_progressive_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class JpegDecoder:
     """ref: src/JpegLibrary/JpegDecoder.cs (public surface).  Scans are decoded on the MI355X."""
 
@@ -146,7 +283,40 @@ class JpegDecoder:
     Height = property(lambda self: self._need_header(_lib.jpgpu_decoder_height(self._h)))
     Precision = property(lambda self: self._need_header(_lib.jpgpu_decoder_precision(self._h)))
     NumberOfComponents = property(lambda self: self._need_header(_lib.jpgpu_decoder_number_of_components(self._h)))
-    StartOfFrame = property(lambda self: _lib.jpgpu_decoder_start_of_frame(self._h))
+    StartOfFrame = property(lambda self: _lib.jpgpu_decoder_start_of_frame(self._h),
+                            lambda self, marker: self._check(_lib.jpgpu_decoder_set_start_of_frame(self._h, int(marker))))  # { get; set; } :43
+
+    # -- the TIFF-style surface: the caller supplies frame header and tables, then hands over one scan's data
+    def SetFrameHeader(self, frameHeader):  # noqa: N802,N803  (:404-407)
+        f = frameHeader._c()
+        self._check(_lib.jpgpu_decoder_set_frame_header(self._h, C.byref(f)))
+
+    def SetHuffmanTable(self, table):  # noqa: N802  (:793-815)
+        if table is None:
+            raise ArgumentException("Value cannot be null. (Parameter 'table')")
+        bits = (C.c_uint8 * 16)(*table.bits)
+        vals = (C.c_uint8 * max(1, len(table.values)))(*table.values)
+        self._check(_lib.jpgpu_decoder_set_huffman_table(self._h, table.TableClass, table.Identifier, bits, vals, len(table.values)))
+
+    def SetQuantizationTable(self, table):  # noqa: N802  (:840-861)
+        if table is None or table.IsEmpty:
+            raise ArgumentException("No actual quantization table is provided. (Parameter 'table')")
+        el = np.asarray(table.Elements, np.uint16)
+        self._check(_lib.jpgpu_decoder_set_quantization_table(self._h, table.ElementPrecision, table.Identifier, el.ctypes.data))
+
+    def ClearHuffmanTable(self):  # noqa: N802  (:768-771)
+        self._check(_lib.jpgpu_decoder_clear_huffman_table(self._h))
+
+    def ClearQuantizationTable(self):  # noqa: N802  (:784-787)
+        self._check(_lib.jpgpu_decoder_clear_quantization_table(self._h))
+
+    def ProcessScan(self, reader, scanHeader):  # noqa: N802,N803  (:624-632)
+        """reader: the bytes behind the SOS header (JpegReader.RemainingBytes).  Returns how far the reference advances the reader."""
+        a = np.frombuffer(reader, dtype=np.uint8) if not isinstance(reader, np.ndarray) else np.ascontiguousarray(reader, dtype=np.uint8)
+        sc = scanHeader._c()
+        n = C.c_size_t()
+        self._check(_lib.jpgpu_decoder_process_scan(self._h, C.byref(sc), a.ctypes.data if a.size else None, a.size, C.byref(n)))
+        return n.value
 
     def GetMaximumHorizontalSampling(self):  # noqa: N802
         v = _lib.jpgpu_decoder_get_maximum_horizontal_sampling(self._h)

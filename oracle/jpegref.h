@@ -139,6 +139,8 @@ int jref_optimizer_statistics(const uint8_t *in, size_t len, uint8_t table_class
                               int *ntables, char *err, size_t err_cap);
 /* JpegHuffmanEncodingTableBuilder.Build(false) for one table: DHT counts / values and GetCode() for all 256 symbols.
  * Returns 0, -1 ("No symbol is recorded."), -2 (a code size beyond the reference's 60-entry array). */
+/* Test hook: the order the restated Array.Sort leaves n int32 keys in (perm[i] = original index of the element at position i). */
+void jref_net_sort_permutation(const int32_t *keys, int n, int32_t *perm);
 int jref_build_optimal_table(const uint32_t freq[256], uint8_t bits_out[16], uint8_t values_out[256], int *nvalues,
                              uint16_t code_out[256], uint8_t length_out[256]);
 void jref_free(void *p);

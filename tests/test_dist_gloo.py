@@ -38,6 +38,13 @@ def _worker(rank, world, port, q):
         d.Identify()
         pixels += d.Width * d.Height
     dist.barrier()
+    # bench.py's host-side group: per-rank generation times gathered as objects, and the parking barrier the ranks wait in
+    # while rank 0 measures the CPU baseline
+    host_group = dist.new_group(backend="gloo")
+    gen = [None] * world
+    dist.all_gather_object(gen, round(0.1 * (rank + 1), 1), group=host_group)
+    assert gen == [round(0.1 * (r + 1), 1) for r in range(world)]
+    dist.barrier(group=host_group)
     elapsed = 0.5 + rank  # pretend rank 1 is slower
     emax = sharding.max_over_ranks(dist, elapsed)
     value = sharding.aggregate_throughput(pixels, world, steps=2, elapsed_max=emax)

@@ -412,8 +412,9 @@ def test_full_size_properties_4k():
     for i in range(2):
         assert res4[i].status == 0 and res0[i].status == 0
         assert np.array_equal(outs4[i], outs0[i])
-    ref, _ = po.decode_8bit(files4[0])
-    assert np.array_equal(outs4[0], ref)
+        # each encoding against the checker's decode of ITS OWN bytes (not only transitively through the other one)
+        assert np.array_equal(outs4[i], po.decode_8bit(files4[i])[0]), i
+        assert np.array_equal(outs0[i], po.decode_8bit(files0[i])[0]), i
 
 
 def test_multi_scan_and_four_component_files():
@@ -601,16 +602,27 @@ def test_dc_refinement_beside_ac_scans_of_the_same_frame():
     """1024 x 4K progressive frames in one pipelined launch at 14 workgroups per CU: the regime in which the DC refinement
     scan and the AC scans of one frame run neck and neck on the same blocks.  The DC refinement used to be a 32-bit atomic
     OR on the block's first word and now and then put an old coefficient 1 back over the AC scan's store: 7-16 frames per
-    pass failed with "invalid Huffman code" in the next refinement of that band.  (Own process: the LDS shape is read once.)"""
+    pass failed with "invalid Huffman code" in the next refinement of that band.  The 16 source frames are compared with the
+    checker's samples, the 1008 copies with their sources.  (Own process: the LDS shape is read once.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, JPGPU_PS_RING="4096", JPGPU_PS_CHUNK="32", JPGPU_PROG_FORCE_PIPELINE="1")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "trace", "progressive_oversubscribed.py"), "1024"], env=env,
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("n=1024")]
     assert r.returncode == 0 and len(lines) == 3, r.stdout[-2000:] + r.stderr[-2000:]
     assert all("failed 0 [] differing []" in ln for ln in lines), lines
+    # the 16 sources against the CHECKER (the tool itself only compares copies with their source): same generator, same seeds
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    from bench import progressive_batch
+    src = progressive_batch(16, 3840, 2160, 75, 1, 16)
+    with ThreadPoolExecutor(8) as ex:
+        want = list(ex.map(lambda f: hashlib.sha256(po.decode_8bit(f)[0].tobytes()).hexdigest(), src))
+    got = {int(ln.split()[1]): ln.split()[2] for ln in r.stdout.splitlines() if ln.startswith("sha256 ")}
+    assert [got.get(i) for i in range(16)] == want
 
 
 def test_progressive_spin_budget_exhausted_falls_back_level_by_level(monkeypatch):

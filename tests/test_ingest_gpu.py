@@ -260,13 +260,17 @@ def test_bench_runs_its_rccl_path_under_torchrun_with_one_rank():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(root, "bench.py"), "--gpus", "1", "--dist", "--workload", "1080p_q90", "--images", "8", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--no-ingest"]
+           os.path.join(root, "bench.py"), "--gpus", "1", "--dist", "--workload", "1080p_q90", "--images", "8", "--steps", "2", "--warmup", "1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["parity_spot_check"] == "bit-exact vs oracle"
+    # what a SCALE run's lines must carry too: the CPU baseline (rank 0, the other ranks parked in a host-side
+    # barrier), the ingest-inclusive rates (all ranks at once, pageable and page-locked input) and the planar-sink read fraction
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"
+    assert out["value_ingest_inclusive"] > 0 and out["value_ingest_inclusive_pinned"] > 0
+    assert out["host"]["ingest_pinned"]["n_pinned_dma"] >= 1 and out["host"]["gen_s_per_rank"] and out["roofline"]["read_frac_planar"] > 0
 
 
 def test_multi_device_driver_shards_round_robin_and_matches_the_oracle():
@@ -307,3 +311,195 @@ def test_multi_device_driver_shards_round_robin_and_matches_the_oracle():
     with pytest.raises(jl.JpegError):
         jl.MultiDecoder([])
 
+
+
+# ------------------------------------------------------------------------------------------------ round 3: segments, pinned, overlap
+
+def _split(data, cuts):
+    """bytes -> list of segments cut at the given offsets (the multi-segment ReadOnlySequence a reference caller may hand over)."""
+    cuts = sorted({c for c in cuts if 0 < c < len(data)})
+    parts, prev = [], 0
+    for c in cuts + [len(data)]:
+        parts.append(bytes(data[prev:c]))
+        prev = c
+    return parts
+
+
+def _variety():
+    """Files of every ingest kind: header-only plans, full walks (progressive, several scans, garbage behind the scan,
+    bytes behind EOI that do not close the file), failures, and one whose first scan starts behind the 64 KiB head."""
+    good = bytes(jpegsynth.encode(160, 96, "420", 75, 2, seed=42))
+    sos = good.index(b"\xff\xda")
+    app = b"\xff\xe1" + (65000).to_bytes(2, "big") + bytes(64998)       # pushes the SOS header behind the gathered head
+    big_head = good[:2] + app + app + good[2:]
+    files = [
+        good,
+        bytes(jpegsynth.encode(512, 512, "444", 75, 0, seed=3)),
+        bytes(jpegsynth.encode(331, 177, "422", 80, 3, seed=9)),
+        good + bytes(range(1, 200)),                                     # bytes behind EOI
+        good[:-2] + b"\x5a\xff\xd9\xff\xfe\x00\x04ab",                  # one unread byte in front of the terminator + a segment behind EOI
+        good[:-2] + b"\xff\xfe\x00\x04ab\xff\xd9",                      # COM behind the scan: full walk
+        good[:sos + 14 + 200],                                           # truncated in the scan
+        read_jpeg("progress.jpg"),
+        read_jpeg("yellowcat_progressive_restart.jpg"),
+        read_jpeg("lake.jpg"),
+        bytes(jpegsynth.encode(96, 64, "444", 75, 0, seed=5, noninterleaved=True)),
+        big_head,
+        b"\xff\xd8",
+        b"",
+    ]
+    return files
+
+
+def test_files_handed_over_as_segment_lists_decode_like_contiguous_ones():
+    """jpgpu_batch_upload_segments (ref: JpegDecoder.SetInput(ReadOnlySequence<byte>), JpegDecoder.cs:56-62; a multi-segment
+    sequence: apps/JpegDecode/MemoryPoolBufferWriter.cs:166-174 with DecodeAction.cs:81-98's 16 KiB reads): every file cut
+    at 16 KiB like the reference app reads it, at awkward places (inside markers, one-byte segments, empty segments), and
+    whole -- same per-image status and the same samples as the contiguous upload, which equals the checker."""
+    files = _variety()
+    plain = jl.Batch().upload(files, jl.FMT_INTERLEAVED_U8).decode().sync()
+    for cutter in (lambda d: list(range(16384, len(d), 16384)),
+                   lambda d: [1, 2, 3, 4, 20, 21, len(d) // 3, len(d) // 3 + 1, len(d) - 2, len(d) - 1],
+                   lambda d: []):
+        segs = [_split(f, cutter(f)) for f in files]
+        segs[1] = segs[1][:1] + [b""] + segs[1][1:]  # an empty segment in the middle of a file
+        b = jl.Batch().upload_segments(segs, jl.FMT_INTERLEAVED_U8).decode().sync()
+        st = b.ingest_stats()
+        for i, f in enumerate(files):
+            r0, r1 = plain.result(i), b.result(i)
+            assert (r0.status, r0.detail) == (r1.status, r1.detail), (i, r0.status, r1.status)
+            kind, ref = _oracle(f)
+            assert NAMES.get(r1.status, str(r1.status)) == kind, (i, kind, r1.status)
+            if ref is not None:
+                assert np.array_equal(b.output(i), ref), i
+        assert st["n_pinned_dma"] == 0
+        b.close()
+    plain.close()
+
+
+def test_page_locked_input_goes_to_hbm_without_a_staging_copy():
+    """JPGPU_UPLOAD_PINNED: files read into jpgpu_host_alloc'd memory (and a caller-owned array registered with
+    jpgpu_host_register) are DMA'd from where they lie -- n_pinned_dma counts the copies -- and decode to the checker's samples;
+    multi-segment pinned files too."""
+    ctx = jl.Context(0)
+    files = _variety()
+    total = sum(len(f) for f in files)
+    arena = ctx.host_alloc(total + 64 * len(files))
+    views, pos = [], 0
+    for f in files:
+        arena[pos:pos + len(f)] = np.frombuffer(f, np.uint8)
+        views.append(arena[pos:pos + len(f)])
+        pos += (len(f) + 63) // 64 * 64
+    b = jl.Batch(ctx).upload_segments(views, jl.FMT_INTERLEAVED_U8, pinned=True).decode().sync()
+    st = b.ingest_stats()
+    assert st["n_pinned_dma"] == sum(1 for f in files if len(f)), st
+    for i, f in enumerate(files):
+        kind, ref = _oracle(f)
+        r = b.result(i)
+        assert NAMES.get(r.status, str(r.status)) == kind, (i, kind, r.status)
+        if ref is not None:
+            assert np.array_equal(b.output(i), ref), i
+    # JPGPU_UPLOAD_PINNED_ARENA: the device copy mirrors the arena (one DMA for this span) -- with marker look-alikes in the
+    # gaps between the files, which nothing may interpret
+    junk = np.frombuffer(b"\xff\xd9\xff\xda\xff\x00\xff\xd0\xff\xff\x00" * ((arena.size // 11) + 1), np.uint8)[:arena.size]
+    arena[:] = junk
+    pos = 0
+    for f in files:
+        arena[pos:pos + len(f)] = np.frombuffer(f, np.uint8)
+        pos += (len(f) + 63) // 64 * 64
+    b.upload_segments(views, jl.FMT_INTERLEAVED_U8, arena=True).decode().sync()
+    st = b.ingest_stats()
+    assert 1 <= st["n_pinned_dma"] <= 2, st
+    for i, f in enumerate(files):
+        kind, ref = _oracle(f)
+        assert NAMES.get(b.result(i).status) == kind, i
+        if ref is not None:
+            assert np.array_equal(b.output(i), ref), i
+    # the same file listed many times (a benchmark repeating a few images): the copies share their bytes in HBM
+    rep = [views[1], views[9], views[1], views[1], views[9]]
+    b.upload_segments(rep, jl.FMT_INTERLEAVED_U8, arena=True).decode().sync()
+    for i, v in enumerate(rep):
+        assert np.array_equal(b.output(i), po.decode_8bit(bytes(v))[0]), i
+    # the same arena as two segments per file
+    segs = [[v[:len(v) // 2], v[len(v) // 2:]] if len(v) > 4 else [v] for v in views]
+    b.upload_segments(segs, jl.FMT_INTERLEAVED_U8, pinned=True).decode().sync()
+    for i, f in enumerate(files):
+        kind, ref = _oracle(f)
+        assert NAMES.get(b.result(i).status) == kind, i
+        if ref is not None:
+            assert np.array_equal(b.output(i), ref), i
+    b.close()
+    # the caller's own array, page-locked in place
+    mine = np.frombuffer(bytearray(files[1]), np.uint8)
+    ctx.host_register(mine)
+    b2 = jl.Batch(ctx).upload_segments([mine], jl.FMT_RGBA_U8, pinned=True).decode().sync()
+    assert np.array_equal(b2.output(0), po.ycbcr8_to_rgb(po.decode_8bit(files[1])[0], rgba=True))
+    b2.close()
+    ctx.host_unregister(mine)
+    ctx.host_free(arena)
+    ctx.close()
+
+
+def test_an_upload_right_after_an_unsynchronised_decode_waits_for_it():
+    """uploads run on the upload stream and used to overwrite the inputs of a decode of the SAME batch that nobody
+    had waited for.  Now the upload is ordered behind the batch's own device work: decode, re-upload other files at once,
+    decode -- many times -- and the samples are the second file set's."""
+    buf, sizes, stride = jpegsynth.encode_batch(12, 1920, 1080, "420", 90, 4, seed0=820, nthreads=8)
+    files = [buf[i * stride:i * stride + int(sizes[i])] for i in range(12)]
+    a, b = files[:6], files[6:]
+    batch = jl.Batch().upload(a, jl.FMT_INTERLEAVED_U8)
+    for _ in range(6):
+        batch.decode()          # not waited for
+        batch.upload(b, jl.FMT_INTERLEAVED_U8)
+        batch.decode()          # not waited for either
+        batch.upload(a, jl.FMT_INTERLEAVED_U8)
+    batch.decode()
+    batch.upload(b, jl.FMT_INTERLEAVED_U8)
+    batch.decode().sync()
+    for i in range(6):
+        assert batch.result(i).status == 0
+        assert np.array_equal(batch.output(i), po.decode_8bit(bytes(b[i]))[0]), i
+    batch.close()
+
+
+def test_multi_device_driver_config4_workload_pinned_and_overlapped():
+    """BASELINE config 4's workload (1920x1080 4:2:0 Q90, DRI = 4) through jpgpu_multi_* over three slots (one MI355X here,
+    listed three times): 66 images per call from page-locked memory (no staging copy), two calls in flight -- call 1 is
+    uploaded while call 0 decodes -- every image of both calls against the checker; then the synchronous form from pageable
+    memory gives the same bytes."""
+    n = 66
+    buf, sizes, stride = jpegsynth.encode_batch(2 * n, 1920, 1080, "420", 90, 4, seed0=5000, nthreads=8)
+    m = jl.MultiDecoder([0, 0, 0])
+    ctx0 = jl.Batch._borrowed(0, jl._capi.lib.jpgpu_multi_context(m._h, 0), 0).ctx
+    arena = C_host_alloc(ctx0, int(stride) * 2 * n)
+    arena[:] = buf[:arena.size]
+    files = [arena[i * stride:i * stride + int(sizes[i])] for i in range(2 * n)]
+    t0 = m.submit(files[:n], jl.FMT_INTERLEAVED_U8, pinned=True)
+    t1 = m.submit(files[n:], jl.FMT_INTERLEAVED_U8, pinned=True)
+    with pytest.raises(jl.JpegError):
+        m.submit(files[:3])          # a third call in flight is refused
+    m.wait(t0)
+    for i in range(n):
+        assert m.result_of(t0, i).status == 0
+    st = m.shard_of(t0, 1).ingest_stats()
+    assert st["n_pinned_dma"] == len(range(1, n, 3)) and st["n_header_only"] == st["n_pinned_dma"], st
+    m.wait(t1)
+    for i in range(0, n, 5):
+        assert np.array_equal(m.output_of(t0, i), po.decode_8bit(bytes(files[i]))[0]), i
+        assert np.array_equal(m.output_of(t1, i), po.decode_8bit(bytes(files[n + i]))[0]), i
+    first = [m.output_of(t1, i) for i in (0, 1, 2, n - 1)]
+    m.decode([bytes(f) for f in files[n:]])       # synchronous, pageable
+    for k, i in enumerate((0, 1, 2, n - 1)):
+        assert m.result(i).status == 0
+        assert np.array_equal(m.output(i), first[k]), i
+    import ctypes as C
+    jl._capi.lib.jpgpu_host_free(ctx0._h, C.c_void_p(arena.ctypes.data))
+    m.close()
+
+
+def C_host_alloc(borrowed_ctx, nbytes):
+    import ctypes as C
+
+    p = C.c_void_p()
+    assert jl._capi.lib.jpgpu_host_alloc(borrowed_ctx._h, nbytes, C.byref(p)) == 0
+    return np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype=np.uint8)

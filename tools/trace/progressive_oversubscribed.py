@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Decode n copies of a few 4K progressive images under different stream-kernel LDS shapes / launch modes and list the
-images that fail or differ from the first copy of their source (debugging aid for the pipelined progressive launch)."""
+images that fail or differ from the first copy of their source; the sha256 of every first copy's samples is printed
+("sha256 <source> <hex>", last pass) so that the test that runs this tool can hold them against the checker's samples.
+Debugging aid for the pipelined progressive launch."""
 import os
 import sys
 
@@ -14,6 +16,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 distinct = 16
 src = progressive_batch(distinct, 3840, 2160, 75, 1, 16)
 files = [src[i % distinct] for i in range(n)]
+import hashlib  # noqa: E402
 b = jl.Batch().upload(files, jl.FMT_INTERLEAVED_U8)
 for rep in range(3):
     b.decode().sync()
@@ -21,6 +24,9 @@ for rep in range(3):
     diff = []
     if not bad:
         first = [b.output(i) for i in range(distinct)]
+        if rep == 2:
+            for i in range(distinct):
+                print(f"sha256 {i} {hashlib.sha256(first[i].tobytes()).hexdigest()}", flush=True)
         for i in range(distinct, n, 37):
             if not np.array_equal(b.output(i), first[i % distinct]):
                 diff.append(i)
