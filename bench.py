@@ -329,9 +329,13 @@ def main():
                 src = files
                 arena = None
                 if key == "pinned":
-                    arena = ctx.host_alloc(int(buf.size))
-                    arena[:] = buf
-                    src = [arena[i * stride:i * stride + int(sizes[i])] for i in range(n_images)]
+                    # one page-locked read buffer, the files back to back (64-byte aligned) as an application that reads
+                    # its files straight into it would have them
+                    offs = np.concatenate([[0], np.cumsum((sizes.astype(np.int64) + 63) // 64 * 64)])
+                    arena = ctx.host_alloc(int(offs[-1]) + 64)
+                    for i in range(n_images):
+                        arena[offs[i]:offs[i] + int(sizes[i])] = files[i]
+                    src = [arena[offs[i]:offs[i] + int(sizes[i])] for i in range(n_images)]
                 per_batch_s, st = ingest_inclusive(jl, ctx, batch, src, fmt, rounds, pinned=(key == "pinned"), sync_ranks=meet)
                 if arena is not None:
                     ctx.host_free(arena)

@@ -1269,18 +1269,23 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             memcpy(s.blk_y, job.blk_y, sizeof s.blk_y);
 
             if (job.kind == kScanProgressive) {
-                if ((size_t)job.ordinal >= prog_work_by_ordinal.size()) {
-                    prog_work_by_ordinal.resize((size_t)job.ordinal + 1);
-                    prog_streams_by_ordinal.resize((size_t)job.ordinal + 1);
+                // launch groups: dependency levels; JPGPU_PROG_BY_SCAN=1 (profiling aid): scan k of every frame in a launch of its
+                // own, in file order -- one kernel duration per scan kind of the script (tools/trace/progressive_by_scan.sh)
+                static const bool by_scan = getenv("JPGPU_PROG_BY_SCAN") != nullptr;
+                const int ordinal = by_scan ? j - img.jobs[0] - 1 : job.ordinal;
+                if (by_scan) prog_pipelined_ = false;
+                if ((size_t)ordinal >= prog_work_by_ordinal.size()) {
+                    prog_work_by_ordinal.resize((size_t)ordinal + 1);
+                    prog_streams_by_ordinal.resize((size_t)ordinal + 1);
                 }
                 // the frame job precedes its scans in the job list: scan k of the frame is job img.jobs[0] + 1 + k
                 for (int d = 0; d < 3; d++) s.dep[d] = d < job.n_deps && job.deps[d] >= 0 ? (uint32_t)(img.jobs[0] + 1 + job.deps[d]) : kNoDep;
                 s.publishes = job.has_consumers ? 1 : 0;
                 if (job.n_deps > 3 || s.n_intervals != 1 || s.n_intervals > stream_max_intervals) prog_pipelined_ = false;
                 if (s.n_intervals <= stream_max_intervals) {
-                    for (uint32_t i = 0; i < s.n_intervals; i++) prog_streams_by_ordinal[job.ordinal].push_back({(uint32_t)j, i});
+                    for (uint32_t i = 0; i < s.n_intervals; i++) prog_streams_by_ordinal[ordinal].push_back({(uint32_t)j, i});
                 } else {
-                    for (uint32_t first = 0; first < s.n_intervals; first += 256) prog_work_by_ordinal[job.ordinal].push_back({(uint32_t)j, first});
+                    for (uint32_t first = 0; first < s.n_intervals; first += 256) prog_work_by_ordinal[ordinal].push_back({(uint32_t)j, first});
                 }
                 compressed_bytes_ += s.data_len;
                 continue;  // no store of its own, no IDCT work

@@ -849,7 +849,7 @@ __device__ unsigned long long k2_prof[8];
 #define K2_PROF_ADD(i, v) do { if (lane == 0) atomicAdd(&k2_prof[i], (unsigned long long)(v)); } while (0)
 extern "C" int jpgpu_debug_k2_profile(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(k2_prof), sizeof(k2_prof)) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(k2_prof), z, sizeof z) != hipSuccess) return 1; }
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(k2_prof), z, sizeof z) != hipSuccess) return 1; }
     return 0;
 }
 #else
@@ -1503,6 +1503,14 @@ constexpr uint32_t kPsBadCode = 17u << 8;  // window entry: no code of 16 bits o
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ uint32_t lane_put(uint32_t old, uint32_t v, uint32_t l) {
+    // (no clang builtin for it in ROCm 7.2; gfx9 allows one SGPR on the constant bus: the lane select travels in M0)
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(v), "s"(l) : "m0");
+    return old;
+}
 
 // Scope of the release / acquire pair of the pipelined progressive launch: "agent" (buffer_wbl2 sc1 / buffer_inv sc1), what the
 // memory model asks for between workgroups of one device.  A build switch because the system-scope forms were tried during the
@@ -1512,7 +1520,7 @@ __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l) { return (u
 #endif
 #ifdef JPGPU_PS_PROFILE
 // cycle accounting of the refinement path of progressive_stream_kernel (diagnostic build only: -DJPGPU_PS_PROFILE)
-__device__ unsigned long long ps_prof[8];
+__device__ unsigned long long ps_prof[16];
 #define PS_TICK() __builtin_readcyclecounter()
 #define PS_ADD(i, v) do { if (lane == 0) atomicAdd(&ps_prof[i], (unsigned long long)(v)); } while (0)
 #if JPGPU_PS_PROFILE > 1
@@ -1522,7 +1530,7 @@ __device__ unsigned long long ps_prof[8];
 #endif
 extern "C" int jpgpu_debug_ps_profile(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ps_prof), sizeof(ps_prof)) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(ps_prof), z, sizeof z) != hipSuccess) return 1; }
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(ps_prof), z, sizeof z) != hipSuccess) return 1; }
     return 0;
 }
 #else
@@ -1539,6 +1547,10 @@ struct WBits {
     int32_t rem;           // uniform: bits left before the interval's end (the reference's "bits available")
     uint32_t peek;         // per lane: the 32 bits at window base + lane
     uint32_t ent;          // per lane: (code size << 8) | symbol for those bits, 0 = longer than the lookup
+    uint32_t ent2;         // per lane, refinement scans only: `ent` pre-digested for the scalar symbol loop (r2_digest)
+#ifdef JPGPU_PS_PROFILE
+    unsigned long long t_pro = 0, t_loop = 0, t_epi = 0, t_refresh = 0, n_exits = 0;  // cycles inside w_ac_refine_parse
+#endif
 };
 
 // JpegHuffmanDecodingTable.Lookup for one 16-bit code, all lanes the same (ref: JpegHuffmanDecodingTable.cs:73-113)
@@ -1877,6 +1889,557 @@ __device__ __forceinline__ uint32_t w_ac_refine_fast(WBits &d, uint32_t lane, co
     }
     return 0;
 }
+
+// ---- AC first pass, bulk path, parse-only form (same idea as w_ac_refine_parse): the serial loop reads the pre-digested window
+// entry, advances the zig-zag index and the position, and writes down in lane n where symbol n's coefficient goes, how many
+// magnitude bits it has and where the symbol ends; afterwards every symbol lane cuts its own magnitude out of the LDS ring, extends
+// it (ReceiveAndExtend, :100-115) and stores it.  (ReadBlockProgressiveAC, :255-311.)
+constexpr uint32_t kF2Special = 1u << 20;
+__device__ __forceinline__ uint32_t f2_digest(uint32_t e /* (code size << 8) | symbol; code size 0 = not in the lookup */) {
+    const uint32_t size = e >> 8, rr = (e >> 4) & 15u, sz = e & 15u;
+    const uint32_t special = (size == 0 || (sz == 0 && rr != 15u)) ? kF2Special : 0u;
+    return special | (rr << 12) | (sz << 6) | (size + sz);  // bits 0-5: code + magnitude bits, 6-10: magnitude bits, 12-15: run
+}
+__device__ __forceinline__ uint32_t w_ac_first_parse(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, uint32_t al,
+                                                     uint32_t &eobrun, int16_t *blk /* nullptr = the dummy block */) {
+    se = uni(se);
+    const uint32_t ringbits = uni((d.wmask + 1u) * 32u - 1u);
+    uint32_t rec = 0;  // lane n: position (<= 63) | magnitude bits << 6 | ring bit position behind the symbol << 11
+    uint32_t nsym = 0, i = uni(ss);
+    uint32_t cur = uni(d.cur);
+    uint32_t winpos = uni(d.pos) - cur;
+    for (;;) {
+        uint32_t reason, e, t, at;
+        cur = uni(cur);
+        i = uni(i);
+        nsym = uni(nsym);
+        asm volatile(
+            "1:\n\t"
+            "s_cmp_gt_u32 %[cur], 63\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "v_readlane_b32 %[e], %[ent2], %[cur]\n\t"
+            "s_cmp_ge_u32 %[e], 0x100000\n\t"
+            "s_cbranch_scc1 3f\n\t"
+            "s_bfe_u32 %[t], %[e], 0x4000c\n\t"
+            "s_add_u32 %[i], %[i], %[t]\n\t"
+            "s_min_u32 %[at], %[i], 63\n\t"
+            "s_and_b32 %[t], %[e], 63\n\t"
+            "s_add_u32 %[cur], %[cur], %[t]\n\t"
+            "s_add_u32 %[t], %[winpos], %[cur]\n\t"
+            "s_and_b32 %[t], %[t], %[ringbits]\n\t"
+            "s_lshl_b32 %[t], %[t], 11\n\t"
+            "s_and_b32 %[e], %[e], 0x7c0\n\t"
+            "s_or_b32 %[t], %[t], %[e]\n\t"
+            "s_or_b32 %[t], %[t], %[at]\n\t"
+            "s_mov_b32 m0, %[nsym]\n\t"
+            "v_writelane_b32 %[rec], %[t], m0\n\t"
+            "s_add_u32 %[nsym], %[nsym], 1\n\t"
+            "s_add_u32 %[i], %[i], 1\n\t"
+            "s_cmp_le_u32 %[i], %[se]\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "s_mov_b32 %[reason], 0\n\t"
+            "s_branch 5f\n"
+            "2:\n\t"
+            "s_mov_b32 %[reason], 1\n\t"
+            "s_branch 5f\n"
+            "3:\n\t"
+            "s_mov_b32 %[reason], 2\n"
+            "5:\n\t"
+            : [cur] "+s"(cur), [i] "+s"(i), [nsym] "+s"(nsym), [rec] "+v"(rec), [reason] "=&s"(reason), [e] "=&s"(e), [t] "=&s"(t), [at] "=&s"(at)
+            : [winpos] "s"(winpos), [ringbits] "s"(ringbits), [se] "s"(se), [ent2] "v"(d.ent2)
+            : "scc", "m0", "memory");
+        cur = uni(cur);
+        i = uni(i);
+        nsym = uni(nsym);
+        reason = uni(reason);
+        if (reason == 0) break;
+        if (reason == 1) {
+            d.pos = winpos + cur;
+            w_refresh<true>(d, lane, hac);
+            d.ent2 = f2_digest(d.ent);
+            winpos = uni(d.pos);
+            cur = 0;
+            continue;
+        }
+        // long code or end-of-band symbol
+        const uint32_t pk = lane_get(d.peek, cur);
+        uint32_t raw = lane_get(d.ent, cur);
+        if ((raw >> 8) == 0) {
+            raw = w_huff_scalar(hac, pk >> 16);
+            if (raw >= kPsBadCode) return kDetailInvalidHuffmanCode;
+        }
+        const uint32_t size = raw >> 8, rr = (raw >> 4) & 15u, sz = raw & 15u;
+        if (sz == 0 && rr != 15u) {
+            eobrun = (1u << rr) - 1u + (uint32_t)(((uint64_t)(pk << size) << rr) >> 32);  // rr = 0 reads nothing
+            cur += size + rr;
+            break;
+        }
+        i += rr;
+        cur += size + sz;
+        rec = lane_put(rec, (((winpos + cur) & ringbits) << 11) | (sz << 6) | (i < 63u ? i : 63u), nsym);
+        nsym++;
+        if (++i > se) break;
+    }
+    d.cur = cur;
+    d.pos = winpos + cur;
+    nsym = uni(nsym);
+    const uint32_t sz = (rec >> 6) & 31u, at = rec & 63u;
+    bool store = lane < nsym && sz != 0 && blk != nullptr;
+    // a corrupted stream may run the index past 63: the reference then overwrites coefficient 63 again and again (:283), the last wins
+    const uint64_t at63 = __ballot(store && at == 63u);
+    if (at63 != 0 && lane != 63u - (uint32_t)__builtin_clzll(at63) && at == 63u) store = false;
+    if (store) {
+        const uint32_t mp = ((rec >> 11) - sz) & ringbits;  // the first magnitude bit
+        const uint32_t w0 = d.ring[(mp >> 5) & d.wmask], w1 = d.ring[((mp >> 5) + 1u) & d.wmask];
+        const uint32_t top = (uint32_t)(((((uint64_t)w0) << 32) | w1) >> (32u - (mp & 31u)));
+        const int32_t v = (int32_t)(top >> (32u - sz));
+        const int32_t value = v - ((((v + v) >> sz) - 1) & ((1 << sz) - 1));  // Extend(v, nbits)
+        blk[at] = (int16_t)((uint32_t)value << al);
+    }
+    return 0;
+}
+
+// ---- AC refinement, bulk path, third form (round 3).  What bounds this kernel is the scalar instruction stream of ONE wave
+// (~5 cycles per instruction, ~30 per taken branch), and the form above spends 75-100 instructions and 8-10 branches per
+// symbol because every symbol also APPLIES its effects: correction fields cut and spread over the lanes, the new coefficient
+// placed, wide fields looped over.  Here the serial loop only PARSES -- per symbol: the pre-digested window entry, the stop
+// position (the (r + 1)-th zero from k on: one compare against the lanes' zero-ranks), three additions for the position --
+// and writes down, in lane i of two record registers, where symbol i stopped and how many code / sign bits the block had
+// consumed by then.  Everything else is done once per block by all lanes at the same time:
+//   * every coefficient that was non-zero before the scan takes exactly ONE correction bit in its block (while a run passes
+//     it, :349-361, or in the tail behind an end-of-band, :396-413): its position is
+//         block start + (code and sign bits of the symbols up to the one whose run passes it) + (its rank among the non-zero
+//         coefficients of the band),
+//     the symbol being the number of recorded stops below the lane (mbcnt of the stop mask), its bits fetched from the record
+//     register of that symbol lane (ds_bpermute), the bit itself from the LDS ring;
+//   * the new coefficient of symbol i (sign bit right behind its code) is stored by lane i straight to the block.
+// Same stream positions, same stores as the coefficient-by-coefficient walk of the reference.
+constexpr uint32_t kR2Special = 1u << 16;  // window entry: code longer than the lookup, or an end-of-band symbol
+__device__ __forceinline__ uint32_t r2_digest(uint32_t e /* (code size << 8) | symbol; code size 0 = not in the lookup */) {
+    const uint32_t size = e >> 8, rr = (e >> 4) & 15u, nonzero = (e & 15u) != 0 ? 1u : 0u;
+    const uint32_t special = (size == 0 || (nonzero == 0 && rr != 15u)) ? kR2Special : 0u;
+    return special | (rr << 8) | (nonzero << 7) | (size + nonzero);  // bits 0-5: code + sign bits, 7: sign follows, 8-11: run
+}
+
+__device__ __forceinline__ uint32_t w_ac_refine_parse(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, int32_t p1,
+                                                      int32_t m1, uint64_t band, uint64_t nz, uint32_t &eobrun, int32_t &c, bool &mine,
+                                                      int16_t *blk /* the block in the store; nullptr = the dummy block */) {
+#ifdef JPGPU_PS_PROFILE
+    const unsigned long long t_a = PS_TICK();
+    unsigned long long t_r = 0;
+#endif
+    // (uniform values all of them, but the compiler cannot always tell after the divergent exact path: the asm below takes SGPRs)
+    auto uni64 = [](uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); };
+    ss = uni(ss);
+    se = uni(se);
+    eobrun = uni(eobrun);
+    const uint64_t zeros = uni64(~nz & band), nzb = uni64(nz & band);
+    const uint32_t zrank = mbcnt64(zeros), nrank = mbcnt64(nzb);
+    const uint32_t blockpos = uni(d.pos);
+    const uint32_t ringbits = uni((d.wmask + 1u) * 32u - 1u);
+    uint32_t rec_bits = 0;  // lane i: code + sign bits of the block's symbols 0 .. i
+    uint32_t rec_stop = 0;  // lane i: stop position | sign follows << 7 | ring bit position of the sign << 8
+    uint32_t nsym = 0, symbits = 0;
+    uint32_t k = ss, zc = 0;  // next position, zeros of the band below it
+    uint64_t stopmask = 0;
+#ifdef JPGPU_PS_PROFILE
+    const unsigned long long t_b = PS_TICK();
+#endif
+    if (eobrun == 0) {
+        uint32_t cur = uni(d.cur);
+        uint32_t winpos = uni(d.pos) - cur;
+        for (;;) {
+            // The straight path -- window entry in the lookup, a plain (run, +-1) or ZRL symbol, its stop inside the band -- is
+            // hand-written: hipcc turns any C++ phrasing of this loop into a state machine of 50-100 scalar instructions and
+            // 5-10 branches per symbol, and one wave issues an instruction every ~5 cycles.  ~33 instructions,
+            // one taken branch per symbol.  It leaves for everything else with a reason code:
+            //   0 the band is done (k > Se)   1 the window has to be rebuilt   2 long code or end-of-band symbol
+            //   3 the run outlasts the band -- for 2 and 3 nothing of the symbol has been applied yet.
+            uint32_t reason, e, rr, adv, tgt, stop, t;
+            uint64_t hit;
+            cur = uni(cur);
+            k = uni(k);
+            zc = uni(zc);
+            symbits = uni(symbits);
+            nsym = uni(nsym);
+            stopmask = uni64(stopmask);
+            asm volatile(
+                "1:\n\t"
+                "s_cmp_gt_u32 %[cur], 63\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "v_readlane_b32 %[e], %[ent2], %[cur]\n\t"
+                "s_cmp_ge_u32 %[e], 0x10000\n\t"
+                "s_cbranch_scc1 3f\n\t"
+                "s_bfe_u32 %[rr], %[e], 0x40008\n\t"
+                "s_and_b32 %[adv], %[e], 63\n\t"
+                "s_add_u32 %[tgt], %[zc], %[rr]\n\t"
+                "v_cmp_eq_u32_e32 vcc, %[tgt], %[zrank]\n\t"
+                "s_and_b64 %[hit], vcc, %[zeros]\n\t"
+                "s_cbranch_scc0 4f\n\t"
+                "s_ff1_i32_b64 %[stop], %[hit]\n\t"
+                "s_add_u32 %[symbits], %[symbits], %[adv]\n\t"
+                "s_mov_b32 m0, %[nsym]\n\t"
+                "v_writelane_b32 %[recb], %[symbits], m0\n\t"
+                "s_add_u32 %[t], %[winpos], %[cur]\n\t"
+                "s_add_u32 %[t], %[t], %[adv]\n\t"
+                "s_add_u32 %[t], %[t], -1\n\t"
+                "s_and_b32 %[t], %[t], %[ringbits]\n\t"
+                "s_lshl_b32 %[t], %[t], 8\n\t"
+                "s_and_b32 %[e], %[e], 0x80\n\t"
+                "s_or_b32 %[t], %[t], %[e]\n\t"
+                "s_or_b32 %[t], %[t], %[stop]\n\t"
+                "v_writelane_b32 %[recs], %[t], m0\n\t"
+                "s_add_u32 %[nsym], %[nsym], 1\n\t"
+                "s_bitset1_b64 %[stopmask], %[stop]\n\t"
+                "s_add_u32 %[cur], %[cur], %[adv]\n\t"
+                "s_add_u32 %[cur], %[cur], %[stop]\n\t"
+                "s_sub_u32 %[cur], %[cur], %[k]\n\t"
+                "s_sub_u32 %[cur], %[cur], %[rr]\n\t"
+                "s_add_u32 %[k], %[stop], 1\n\t"
+                "s_add_u32 %[zc], %[tgt], 1\n\t"
+                "s_cmp_le_u32 %[k], %[se]\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "s_mov_b32 %[reason], 0\n\t"
+                "s_branch 5f\n"
+                "2:\n\t"
+                "s_mov_b32 %[reason], 1\n\t"
+                "s_branch 5f\n"
+                "3:\n\t"
+                "s_mov_b32 %[reason], 2\n\t"
+                "s_branch 5f\n"
+                "4:\n\t"
+                "s_mov_b32 %[reason], 3\n"
+                "5:\n\t"
+                : [cur] "+s"(cur), [k] "+s"(k), [zc] "+s"(zc), [symbits] "+s"(symbits), [nsym] "+s"(nsym), [stopmask] "+s"(stopmask),
+                  [recb] "+v"(rec_bits), [recs] "+v"(rec_stop), [reason] "=&s"(reason), [e] "=&s"(e), [rr] "=&s"(rr), [adv] "=&s"(adv),
+                  [tgt] "=&s"(tgt), [stop] "=&s"(stop), [t] "=&s"(t), [hit] "=&s"(hit)
+                : [winpos] "s"(winpos), [ringbits] "s"(ringbits), [se] "s"(se), [zeros] "s"(zeros), [ent2] "v"(d.ent2), [zrank] "v"(zrank)
+                : "vcc", "scc", "m0", "memory");
+            // (SGPR results: said again, the divergence analysis gives up on an asm statement with this many outputs)
+            cur = uni(cur);
+            k = uni(k);
+            zc = uni(zc);
+            symbits = uni(symbits);
+            nsym = uni(nsym);
+            stopmask = uni64(stopmask);
+            reason = uni(reason);
+#ifdef JPGPU_PS_PROFILE
+            d.n_exits++;
+#endif
+            if (reason == 0) break;
+            if (reason == 1) {
+#ifdef JPGPU_PS_PROFILE
+                const unsigned long long t_x = PS_TICK();
+#endif
+                d.pos = winpos + cur;
+                w_refresh<true>(d, lane, hac);
+                d.ent2 = r2_digest(d.ent);
+                winpos = uni(d.pos);
+                cur = 0;
+#ifdef JPGPU_PS_PROFILE
+                t_r += PS_TICK() - t_x;
+#endif
+                continue;
+            }
+            // one symbol outside the straight path
+            PS_COUNT(6);
+            const uint32_t pk = lane_get(d.peek, cur);
+            uint32_t raw = lane_get(d.ent, cur);
+            if ((raw >> 8) == 0) {
+                raw = w_huff_scalar(hac, pk >> 16);
+                if (raw >= kPsBadCode) return kDetailInvalidHuffmanCode;
+            }
+            const uint32_t e2 = r2_digest(raw);
+            if (e2 >= kR2Special) {  // EOBn (:337-350): the run's low bits follow the code
+                const uint32_t size = raw >> 8, r2 = (raw >> 4) & 15u;
+                eobrun = (1u << r2) + (uint32_t)(((uint64_t)(pk << size) << r2) >> 32);
+                symbits += size + r2;
+                cur += size + r2;
+                break;
+            }
+            const uint32_t rr2 = (e2 >> 8) & 15u, adv2 = e2 & 63u;
+            const uint32_t tgt2 = zc + rr2;
+            const uint64_t hit2 = __ballot(zrank == tgt2) & zeros;  // the lane that is the (rr + 1)-th zero from k on
+            symbits += adv2;
+            rec_bits = lane_put(rec_bits, symbits, nsym);
+            const uint32_t signpos = (winpos + cur + adv2 - 1u) & ringbits;
+            if (hit2 == 0) {  // the run outlasts the band: every non-zero coefficient left is passed, the new one lands behind Se
+                rec_stop = lane_put(rec_stop, (signpos << 8) | (e2 & 0x80u) | (se + 1u), nsym);
+                nsym++;
+                cur += adv2 + (uint32_t)__builtin_popcountll(nzb) - (k - ss - zc);
+                k = se + 1u;
+                zc = (uint32_t)__builtin_popcountll(zeros);
+                break;
+            }
+            const uint32_t stop2 = (uint32_t)__builtin_ctzll(hit2);
+            rec_stop = lane_put(rec_stop, (signpos << 8) | (e2 & 0x80u) | stop2, nsym);
+            nsym++;
+            stopmask |= 1ull << stop2;
+            cur += adv2 + (stop2 - k - rr2);  // the non-zero coefficients in [k, stop): their correction bits follow
+            k = stop2 + 1u;
+            zc = tgt2 + 1u;
+            if (k > se) break;
+        }
+        d.cur = cur;
+        d.pos = winpos + cur;
+    }
+    if (eobrun > 0) {
+        // the tail (:396-413): every non-zero coefficient from k on takes one correction bit
+        const uint32_t tail = (uint32_t)__builtin_popcountll(nzb) - (k - ss - zc);
+        d.pos += tail;
+        d.cur += tail;
+        eobrun--;
+    }
+#ifdef JPGPU_PS_PROFILE
+    const unsigned long long t_c = PS_TICK();
+#endif
+    symbits = uni(symbits);
+    nsym = uni(nsym);
+    stopmask = uni64(stopmask);
+    rec_bits = lane_put(rec_bits, symbits, nsym);  // the tail's lanes look at "symbol" nsym: all of the block's code bits
+    if (nzb != 0) {
+        // the correction bits, all at once
+        const uint32_t sym_of_lane = mbcnt64(stopmask);  // recorded stops below this lane = the symbol whose run passes it
+        const uint32_t bits_before = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sym_of_lane << 2), (int)rec_bits);
+        const uint32_t bp = blockpos + bits_before + nrank;
+        const uint32_t w = d.ring[(bp >> 5) & d.wmask];
+        if (((nzb >> lane) & 1ull) != 0 && ((w >> (31u - (bp & 31u))) & 1u) != 0 && (c & p1) == 0) {
+            c += c >= 0 ? p1 : m1;  // (the tail's test is c > 0: the same thing for a coefficient that is not zero)
+            mine = true;
+        }
+    }
+    if (lane < nsym && (rec_stop & 0x80u) != 0 && (rec_stop & 0x7Fu) < 64u && blk != nullptr) {
+        // the new coefficients (:363-367): symbol lanes store them where their runs stopped
+        const uint32_t sp = rec_stop >> 8;
+        const uint32_t w = d.ring[(sp >> 5) & d.wmask];
+        blk[rec_stop & 0x7Fu] = (int16_t)(((w >> (31u - (sp & 31u))) & 1u) != 0 ? p1 : m1);
+    }
+#ifdef JPGPU_PS_PROFILE
+    d.t_pro += t_b - t_a;
+    d.t_loop += t_c - t_b - t_r;
+    d.t_refresh += t_r;
+    d.t_epi += PS_TICK() - t_c;
+#endif
+    return 0;
+}
+
+// ---- AC refinement, bulk path, fourth form: the symbol loop in the VECTOR unit's instruction stream.
+// tools/microbench/issue_latency.hip (one wave, cycles per instruction): any simple instruction ~4.2; a SALU instruction that
+// reads an SGPR the VALU has just written (v_readlane -> s_cmp, v_cmp -> s_and) stalls ~20 more; a conditional branch costs ~15
+// even when it is NOT taken, ~16-20 when it is; a dependent LDS read 53, ds_bpermute 61.  The third form above (scalar loop,
+// 33 instructions, two such crossings and four branches per symbol) therefore ran at ~465 cycles per symbol.  Here every value
+// of the chain lives in a VGPR (the same in all lanes), the only SGPRs are the lane selects of the two v_readlane (written by
+// v_readfirstlane, read by the VALU: no stall), nothing is decided by a branch but the loop itself (commits are selects on one
+// "this symbol is a plain one inside the window and its run ends inside the band" condition), and the stop position is not
+// searched for but looked up:
+//   * per block, lane r of `ntab` holds Ss + (the number of non-zero coefficients of the band below its r-th zero), scattered
+//     there by one ds_permute; the stop of a symbol that consumes zeros up to rank t is then t + ntab[t], and the correction
+//     bits its run passes are ntab[t] - Ss minus those passed before: position = block's first offset + code bits + ntab[t];
+//   * the new coefficient (sign bit pre-digested into the window entry) goes into lane `stop` of the block's register, the
+//     lanes from the symbol's first position on note the code bits consumed so far (their correction bit comes after them);
+//   * afterwards every lane that was non-zero fetches ITS correction bit: block start + noted code bits + its rank.
+constexpr uint32_t kR4Special = 0x80000000u;
+__device__ __forceinline__ uint32_t r4_digest(uint32_t e /* (code size << 8) | symbol; code size 0 = not in the lookup */, uint32_t peek) {
+    const uint32_t size = e >> 8, rr = (e >> 4) & 15u, nonzero = (e & 15u) != 0 ? 1u : 0u;
+    const uint32_t special = (size == 0 || (nonzero == 0 && rr != 15u)) ? kR4Special : 0u;
+    const uint32_t sign = (peek << (size & 31u)) >> 31;  // the bit behind the code
+    return special | (sign << 11) | ((nonzero ^ 1u) << 10) | (rr << 6) | (size + nonzero);
+}
+
+__device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, int32_t p1,
+                                                   int32_t m1, uint64_t band, uint64_t nz, uint32_t &eobrun, int32_t &c, bool &mine) {
+#ifdef JPGPU_PS_PROFILE
+    const unsigned long long t_a = PS_TICK();
+    unsigned long long t_r = 0;
+#endif
+    auto uni64 = [](uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); };
+    ss = uni(ss);
+    se = uni(se);
+    eobrun = uni(eobrun);
+    const uint64_t zeros = uni64(~nz & band), nzb = uni64(nz & band);
+    const uint32_t zrank = mbcnt64(zeros), nrank = mbcnt64(nzb);
+    const uint32_t blockpos = uni(d.pos);
+    const uint32_t nnz = (uint32_t)__builtin_popcountll(nzb);
+    uint32_t bits = 0;     // per lane: code / sign / run bits of the block consumed before this lane's correction bit
+    uint32_t symbits = 0;  // ... by the symbols so far
+    uint32_t cv = (uint32_t)c, minev = 0;
+    uint32_t winpos = blockpos - uni(d.cur);  // stream position of the window's first bit
+    if (eobrun == 0) {
+        const uint32_t nzeros = (uint32_t)__builtin_popcountll(zeros);
+        const bool is_zero = ((zeros >> lane) & 1ull) != 0;
+        // lane r <- the r-th zero of the band (the other lanes fill the remaining slots: a permutation, nothing collides)
+        const uint32_t slot = is_zero ? zrank : nzeros + (lane - zrank);
+        uint32_t ntab = (uint32_t)__builtin_amdgcn_ds_permute((int)(slot << 2), (int)(ss + nrank));
+        ntab = lane < nzeros ? ntab : 0x10000u;  // no such zero: the run outlasts the band
+        uint32_t cur = uni(d.cur);
+        uint32_t base = cur - ss;   // a symbol's offset in the window = base + code bits before it + ntab[zeros consumed before it]
+        uint32_t zc = 0;            // zeros of the band consumed so far
+        uint32_t kprev = ss - 1u;   // position in front of the next symbol's first one
+        const uint32_t dpm = (uint32_t)(p1 - m1), m1v = (uint32_t)m1;
+        for (;;) {
+            uint32_t stop, scur, se_, st, sn, ve, rr, t, tm, adv, symn, u, curn, pl, sg;
+            uint64_t sp;
+#ifdef JPGPU_R4_CXX
+            // the loop below, spelled in C++ (debugging aid: same operations, the compiler's schedule)
+            for (;;) {
+                ve = lane_get(d.ent2, cur);
+                rr = (ve >> 6) & 15u;
+                t = zc + rr;
+                tm = t < 63u ? t : 63u;
+                adv = ve & 63u;
+                symn = symbits + adv;
+                sn = lane_get(ntab, tm);
+                stop = sn + t;
+                curn = base + symn + sn;
+                u = (ve & 0x80000000u) | cur | sn;
+                const bool ok = u < 64u;
+                if (ok) symbits = symn;
+                if (lane > kprev) bits = symbits;
+                if (ok) kprev = stop;
+                if (!ok) stop = 0xFFFFu;
+                if (ok) cur = curn;
+                if (ok) zc = t + 1u;
+                pl = (ve & 0x400u) | stop;
+                sg = ((ve >> 11) & 1u) * dpm + m1v;
+                if (lane == pl) {
+                    cv = sg;
+                    minev = 1;
+                }
+                if (!(se > stop)) break;
+            }
+            (void)scur; (void)se_; (void)st; (void)sp; (void)curn; (void)pl; (void)sg; (void)u;
+#else
+            asm volatile(
+                // gfx940-family hazards the assembler does not fix in inline asm (LLVM's GCNHazardRecognizer does, for compiled code):
+                // a VALU instruction may read an SGPR / VCC another VALU instruction wrote only 2 wait states later, a lane select 4,
+                // v_readlane / v_readfirstlane a VGPR written by the VALU 1 later.  The gaps are filled with independent work
+                // where there is any.
+                "1:\n\t"
+                "v_readfirstlane_b32 %[scur], %[cur]\n\t"
+                "s_nop 3\n\t"
+                "v_readlane_b32 %[se_], %[ent2], %[scur]\n\t"
+                "s_nop 1\n\t"
+                "v_mov_b32_e32 %[ve], %[se_]\n\t"
+                "v_bfe_u32 %[rr], %[ve], 6, 4\n\t"
+                "v_add_u32_e32 %[t], %[zc], %[rr]\n\t"
+                "v_min_u32_e32 %[tm], 63, %[t]\n\t"
+                "v_and_b32_e32 %[adv], 63, %[ve]\n\t"
+                "v_readfirstlane_b32 %[st], %[tm]\n\t"
+                "v_add_u32_e32 %[symn], %[symbits], %[adv]\n\t"
+                "v_and_b32_e32 %[u], 0x80000000, %[ve]\n\t"
+                "v_add_u32_e32 %[rr], 1, %[t]\n\t"
+                "v_and_b32_e32 %[pl], 0x400, %[ve]\n\t"
+                "v_readlane_b32 %[sn], %[ntab], %[st]\n\t"
+                "v_bfe_u32 %[sg], %[ve], 11, 1\n\t"
+                "v_mad_u32_u24 %[sg], %[sg], %[dpm], %[m1v]\n\t"
+                "v_add_u32_e32 %[stop], %[sn], %[t]\n\t"
+                "v_add3_u32 %[curn], %[base], %[symn], %[sn]\n\t"
+                "v_or3_b32 %[u], %[u], %[cur], %[sn]\n\t"
+                "v_cmp_gt_u32_e32 vcc, 64, %[u]\n\t"
+                "v_cmp_gt_u32_e64 %[sp], %[lane], %[kprev]\n\t"
+                "s_nop 0\n\t"
+                "v_cndmask_b32_e32 %[symbits], %[symbits], %[symn], vcc\n\t"
+                "v_cndmask_b32_e32 %[kprev], %[kprev], %[stop], vcc\n\t"
+                "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[sp]\n\t"
+                "v_cndmask_b32_e32 %[stop], %[none], %[stop], vcc\n\t"
+                "v_cndmask_b32_e32 %[cur], %[cur], %[curn], vcc\n\t"
+                "v_cndmask_b32_e32 %[zc], %[zc], %[rr], vcc\n\t"
+                "v_or_b32_e32 %[pl], %[pl], %[stop]\n\t"
+                "v_cmp_eq_u32_e64 %[sp], %[lane], %[pl]\n\t"
+                "v_cmp_gt_u32_e32 vcc, %[se], %[stop]\n\t"
+                "s_nop 0\n\t"
+                "v_cndmask_b32_e64 %[cv], %[cv], %[sg], %[sp]\n\t"
+                "v_cndmask_b32_e64 %[minev], %[minev], 1, %[sp]\n\t"
+                "s_cbranch_vccnz 1b\n\t"
+                : [cur] "+v"(cur), [zc] "+v"(zc), [symbits] "+v"(symbits), [kprev] "+v"(kprev), [bits] "+v"(bits), [cv] "+v"(cv),
+                  [minev] "+v"(minev), [stop] "=&v"(stop), [scur] "=&s"(scur), [se_] "=&s"(se_), [st] "=&s"(st), [sn] "=&s"(sn),
+                  [sp] "=&s"(sp), [ve] "=&v"(ve), [rr] "=&v"(rr), [t] "=&v"(t), [tm] "=&v"(tm), [adv] "=&v"(adv), [symn] "=&v"(symn),
+                  [u] "=&v"(u), [curn] "=&v"(curn), [pl] "=&v"(pl), [sg] "=&v"(sg)
+                : [ent2] "v"(d.ent2), [ntab] "v"(ntab), [lane] "v"(lane), [base] "v"(base), [dpm] "v"(dpm), [m1v] "v"(m1v), [none] "v"(0xFFFFu), [se] "s"(se)
+                : "vcc", "memory");
+#endif
+            cur = uni(cur);
+            zc = uni(zc);
+            symbits = uni(symbits);
+            kprev = uni(kprev);
+            stop = uni(stop);
+#ifdef JPGPU_PS_PROFILE
+            d.n_exits++;
+#endif
+            if (stop != 0xFFFFu) break;  // the last symbol was applied and its run ended at Se: the band is done
+            if (cur > 63u) {
+#ifdef JPGPU_PS_PROFILE
+                const unsigned long long t_x = PS_TICK();
+#endif
+                d.pos = winpos + cur;
+                w_refresh<true>(d, lane, hac);
+                d.ent2 = r4_digest(d.ent, d.peek);
+                winpos = uni(d.pos);
+                base -= cur;
+                cur = 0;
+#ifdef JPGPU_PS_PROFILE
+                t_r += PS_TICK() - t_x;
+#endif
+                continue;
+            }
+            // one symbol by hand: a code longer than the lookup, an end-of-band symbol, or a run that outlasts the band
+            PS_COUNT(6);
+            const uint32_t pk = lane_get(d.peek, cur);
+            uint32_t raw = lane_get(d.ent, cur);
+            if ((raw >> 8) == 0) {
+                raw = w_huff_scalar(hac, pk >> 16);
+                if (raw >= kPsBadCode) return kDetailInvalidHuffmanCode;
+            }
+            const uint32_t e2 = r4_digest(raw, pk);
+            const uint32_t size = raw >> 8, r2 = (raw >> 4) & 15u;
+            if (e2 >= kR4Special) {  // EOBn (:337-350): the run's low bits follow the code; the tail's lanes come behind all of it
+                eobrun = (1u << r2) + (uint32_t)(((uint64_t)(pk << size) << r2) >> 32);
+                symbits += size + r2;
+                if (lane > kprev) bits = symbits;
+                break;
+            }
+            const uint32_t adv2 = e2 & 63u, tgt2 = zc + r2;
+            const uint32_t n2 = lane_get(ntab, tgt2 < 63u ? tgt2 : 63u);
+            symbits += adv2;
+            if (lane > kprev) bits = symbits;
+            const uint32_t stop2 = n2 >= 0x10000u ? se + 1u : tgt2 + n2;  // no such zero: the new coefficient lands behind Se (:363-367)
+            if ((e2 & 0x400u) == 0 && lane == stop2) {
+                cv = (uint32_t)((e2 & 0x800u) != 0 ? p1 : m1);
+                minev = 1;
+            }
+            if (n2 >= 0x10000u || stop2 >= se) break;  // every non-zero coefficient left has been passed
+            cur = base + symbits + n2;
+            zc = tgt2 + 1u;
+            kprev = stop2;
+        }
+    }
+#ifdef JPGPU_PS_PROFILE
+    const unsigned long long t_c = PS_TICK();
+#endif
+    symbits = uni(symbits);
+    if (eobrun > 0) eobrun--;
+    // every coefficient that was non-zero takes exactly one correction bit: behind the code bits noted for its lane, in rank order
+    if (nzb != 0) {
+        const uint32_t bp = blockpos + bits + nrank;
+        const uint32_t w = d.ring[(bp >> 5) & d.wmask];
+        if (((nzb >> lane) & 1ull) != 0 && ((w >> (31u - (bp & 31u))) & 1u) != 0 && (cv & (uint32_t)p1) == 0) {
+            cv += (int32_t)cv >= 0 ? (uint32_t)p1 : (uint32_t)m1;  // (the tail's test is c > 0: the same thing for a coefficient that is not zero)
+            minev = 1;
+        }
+    }
+    const uint32_t consumed = symbits + nnz;
+    d.pos = blockpos + consumed;
+    d.cur = d.pos - winpos;
+    c = (int32_t)(int16_t)cv;
+    mine = minev != 0;
+#ifdef JPGPU_PS_PROFILE
+    d.t_pro += 0;
+    d.t_loop += t_c - t_a - t_r;
+    d.t_refresh += t_r;
+    d.t_epi += PS_TICK() - t_c;
+#endif
+    return 0;
+}
 constexpr int32_t kPsFastBits = 2560;  // more than any block can consume: 63 x (16 + 16) + 14 (first), 63 x 17 + 63 + 14 (refinement)
 
 
@@ -2076,8 +2639,54 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
             dc_slot[c] = s.comp[c < ncomp ? c : 0].dc_slot;
         }
         int32_t pred[kMaxScanComponents] = {0, 0, 0, 0};
-        uint32_t uy = first_unit / units_per_line, ux = first_unit - uy * units_per_line;  // interleaved: MCU; else block
-        for (uint32_t u = 0; u < my_units && err == 0; u++) {
+        uint32_t u0 = 0;
+        if (ah != 0) {
+            // DC refinement (ReadBlockProgressiveDC, the Ah != 0 arm, :240-252): ONE bit per block and nothing else in the
+            // stream, so block n of the interval owns stream bit n -- no serial parse at all.  64 blocks per pass, one per lane:
+            // the lane's bit is the top bit of its window word.  Whole units per pass (the serial loop below finishes the
+            // interval's tail, where the "bits available" rules may matter).
+            uint32_t bpu = 0, cbase[kMaxScanComponents + 1];
+#pragma unroll
+            for (uint32_t c = 0; c < kMaxScanComponents; c++) {
+                cbase[c] = bpu;
+                if (c < ncomp) bpu += ncomp == 1 ? 1u : pc[c].h * pc[c].v;
+            }
+            cbase[kMaxScanComponents] = bpu;
+            const uint32_t group = bpu != 0 && bpu <= 64u ? 64u / bpu : 0u;
+            uint32_t passes = 0;
+            while (group != 0 && u0 + group <= my_units && err == 0 && d.rem >= 128) {
+                JPGPU_ENSURE_STAGED()
+                if (rows_ready != 0xFFFFFFFFu) JPGPU_FOLLOW((first_unit + u0 + group - 1u) / my_units_per_row)
+                if (err != 0) break;
+                if ((passes++ & 7u) == 7u) JPGPU_PUBLISH(u0)
+                d.cur = 64;
+                w_refresh<false>(d, lane, lds_huff(tabs, dc_slot[0]));
+                const uint32_t nb = group * bpu;
+                if (lane < nb && (d.peek >> 31) != 0) {
+                    const uint32_t unit = first_unit + u0 + lane / bpu, within = lane - (lane / bpu) * bpu;
+                    uint32_t c = 0;
+#pragma unroll
+                    for (uint32_t q = 1; q < kMaxScanComponents; q++)
+                        if (q < ncomp && within >= cbase[q]) c = q;
+                    ProgComp p = pc[0];
+#pragma unroll
+                    for (uint32_t q = 1; q < kMaxScanComponents; q++)
+                        if (c == q) p = pc[q];
+                    const uint32_t r = within - (c == 0 ? 0u : (c == 1 ? cbase[1] : (c == 2 ? cbase[2] : cbase[3])));
+                    const uint32_t vy = unit / units_per_line, vx = unit - vy * units_per_line;
+                    uint64_t index = 0;
+                    const bool real = ncomp == 1 ? prog_block_index(fr, p, vx, vy, index)
+                                                 : prog_block_index(fr, p, vx * p.h + r % p.h, vy * p.v + r / p.h, index);
+                    if (real) dc_refine_or(coefs + index * 64, al);
+                }
+                d.pos += nb;
+                d.cur = 64;
+                d.rem -= (int32_t)nb;
+                u0 += group;
+            }
+        }
+        uint32_t uy = (first_unit + u0) / units_per_line, ux = (first_unit + u0) - uy * units_per_line;  // interleaved: MCU; else block
+        for (uint32_t u = u0; u < my_units && err == 0; u++) {
             JPGPU_ENSURE_STAGED()
             if (rows_ready != 0xFFFFFFFFu) JPGPU_FOLLOW((first_unit + u) / my_units_per_row)
             if ((u & (kPsPublishEvery - 1u)) == 0 && u != 0) JPGPU_PUBLISH(u)
@@ -2141,7 +2750,11 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                 uint64_t changed = 0;
                 if (d.rem >= kPsFastBits) {
                     const uint32_t pos0 = d.pos;
+#ifdef JPGPU_PS_OLD_REFINE
                     err = w_ac_first_fast(d, lane, hac, ss, se, al, eobrun, c, changed);
+#else
+                    err = w_ac_first_parse(d, lane, hac, ss, se, al, eobrun, real ? coefs + index * 64 : nullptr);
+#endif
                     d.rem -= (int32_t)(d.pos - pos0);
                 } else {
                     err = w_ac_first_block<false>(d, lane, hac, closed_by_marker, ss, se, al, eobrun, c, changed);
@@ -2183,7 +2796,35 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                     bool mine = false;  // this lane's coefficient changed
                     if (d.rem >= kPsFastBits) {
                         const uint32_t pos0 = d.pos;
+#ifdef JPGPU_PS_OLD_REFINE
                         err = w_ac_refine_fast(d, lane, hac, ss, se, p1, m1, band, nz, eobrun, c, mine);
+#elif defined(JPGPU_PS_REFINE3)
+                        err = w_ac_refine_parse(d, lane, hac, ss, se, p1, m1, band, nz, eobrun, c, mine,
+                                                ix != kPsNoBlock ? coefs + (uint64_t)ix * 64 : nullptr);
+#else
+#ifdef JPGPU_PS_CHECK
+                        {
+                            WBits d3 = d;
+                            d3.ent2 = r2_digest(d3.ent);  // (the window entries as the third form wants them)
+                            uint32_t eob3 = eobrun;
+                            int32_t c3 = c;
+                            bool mine3 = false;
+                            const uint32_t e3 = w_ac_refine_parse(d3, lane, hac, ss, se, p1, m1, band, nz, eob3, c3, mine3, nullptr);
+                            WBits d4 = d;
+                            uint32_t eob4 = eobrun;
+                            int32_t c4 = c;
+                            bool mine4 = false;
+                            const uint32_t e4 = w_ac_refine_v4(d4, lane, hac, ss, se, p1, m1, band, nz, eob4, c4, mine4);
+                            const bool bad = e3 != e4 || d3.pos != d4.pos || eob3 != eob4;
+                            const uint64_t cbad = __ballot(((nz >> lane) & 1ull) != 0 && c3 != c4);
+                            if ((bad || cbad != 0) && lane == 0)
+                                printf("refine mismatch: block %u pos0 %u cur0 %u eobrun0 %u nz %llx band %llx | v3 err %u pos %u eob %u | v4 err %u pos %u eob %u | corr lanes %llx\n",
+                                       done, d.pos, d.cur, eobrun, (unsigned long long)nz, (unsigned long long)band, e3, d3.pos, eob3, e4, d4.pos, eob4,
+                                       (unsigned long long)cbad);
+                        }
+#endif
+                        err = w_ac_refine_v4(d, lane, hac, ss, se, p1, m1, band, nz, eobrun, c, mine);
+#endif
                         d.rem -= (int32_t)(d.pos - pos0);
                     } else {
                         err = w_ac_refine_block<false>(d, lane, hac, ss, se, p1, m1, band, nz, eobrun, c, mine);
@@ -2201,6 +2842,13 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                 PS_ADD(3, ps_stage);
                 PS_ADD(4, ps_blocks);
                 PS_ADD(5, PS_TICK() - ps_t0);
+#ifdef JPGPU_PS_PROFILE
+                PS_ADD(8, d.t_pro);
+                PS_ADD(9, d.t_loop);
+                PS_ADD(10, d.t_epi);
+                PS_ADD(11, d.t_refresh);
+                PS_ADD(12, d.n_exits);
+#endif
             }
         }
     }

@@ -17,12 +17,13 @@ b = jl.Batch().upload(files).decode().sync()
 for rep in range(int(__import__("os").environ.get("REPS", "1"))):
     print("failing:", [(i, b.result(i).status, b.result(i).detail) for i in range(64) if b.result(i).status != 0][:5], "fallbacks", b.progressive_fallbacks(), flush=True)
     b.decode().sync()
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 lib = C.CDLL(_capi.LIB_PATH)
 lib.jpgpu_debug_ps_profile(out, 1)
 b.decode().sync()
 lib.jpgpu_debug_ps_profile(out, 0)
 n, units, wait, stage, blocks, total = [out[i] for i in range(6)]
 print("symbols (refinement fast path, all scans)", out[6], "window refreshes (all stream scans)", out[7])
+print(f"inside the parse-only block decoder, cycles per block: prologue {out[8]/units:.0f}, symbol loop {out[9]/units:.0f}, window rebuilds {out[11]/units:.0f}, epilogue {out[10]/units:.0f}; loop exits per block {out[12]/units:.2f}")
 print(f"last refinement scans: {n} streams, {units} blocks; cycles per block: follow/wait {wait/units:.0f}, staging {stage/units:.0f}, block loop {blocks/units:.0f}, all {total/units:.0f}")
 PY
