@@ -81,6 +81,10 @@ void jpgpu_destroy(jpgpu_ctx *ctx) {
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    for (hipStream_t st : ctx->prog_stream)
+        if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : ctx->prog_ev)
+        if (ev) (void)hipEventDestroy(ev);
     for (int i = 0; i < StagingRing::kMaxSlots; i++) {
         if (ctx->staging.slot[i]) (void)hipHostFree(ctx->staging.slot[i]);
         if (ctx->staging.drained[i]) (void)hipEventDestroy(ctx->staging.drained[i]);

@@ -1126,6 +1126,8 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         if (const char *ev = getenv("JPGPU_SUBSEQ_SHIFT")) subseq_shift = (uint32_t)std::min(14, std::max(10, atoi(ev)));
     }
     std::vector<std::vector<HuffWork>> prog_work_by_ordinal, prog_streams_by_ordinal;
+    std::vector<std::vector<HuffWork>> prog_chain_work[jpgpu_ctx::kProgChains];  // [chain][ordinal in the frame's chain]
+    prog_chains_ok_ = true;
     // a scan with fewer restart intervals than this gets one WAVE per interval (progressive_stream_kernel)
     const uint32_t stream_max_intervals = getenv("JPGPU_PROG_STREAM_MAX_INTERVALS") ? (uint32_t)atoi(getenv("JPGPU_PROG_STREAM_MAX_INTERVALS")) : 16u;
     prog_clear_.clear();
@@ -1284,7 +1286,18 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 if (job.n_deps > 3 || s.n_intervals != 1 || s.n_intervals > stream_max_intervals) prog_pipelined_ = false;
                 if (s.n_intervals <= stream_max_intervals) {
                     for (uint32_t i = 0; i < s.n_intervals; i++) prog_streams_by_ordinal[ordinal].push_back({(uint32_t)j, i});
+                    // chain of the scan: DC scans (interleaved, or Ss = 0) touch coefficient 0 only, an AC scan the band of ONE
+                    // component (what it may write beyond its header stays inside that component's AC coefficients)
+                    const int chain = (job.scan_components != 1 || job.ss == 0) ? 0 : 1 + std::min(3, job.comp[0].component_index);
+                    int in_chain = 0;
+                    for (int jj = img.jobs[0] + 1; jj < j; jj++) {
+                        const ScanJob &o = jobs_[jj];
+                        in_chain += ((o.scan_components != 1 || o.ss == 0) ? 0 : 1 + std::min(3, o.comp[0].component_index)) == chain;
+                    }
+                    if (prog_chain_work[chain].size() <= (size_t)in_chain) prog_chain_work[chain].resize((size_t)in_chain + 1);
+                    for (uint32_t i = 0; i < s.n_intervals; i++) prog_chain_work[chain][(size_t)in_chain].push_back({(uint32_t)j, i});
                 } else {
+                    prog_chains_ok_ = false;  // a scan of many restart intervals (lane kernel): level by level
                     for (uint32_t first = 0; first < s.n_intervals; first += 256) prog_work_by_ordinal[ordinal].push_back({(uint32_t)j, first});
                 }
                 compressed_bytes_ += s.data_len;
@@ -1363,6 +1376,13 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     for (const std::vector<HuffWork> &w : prog_streams_by_ordinal) {
         prog_work.insert(prog_work.end(), w.begin(), w.end());
         prog_stream_begin_.push_back((int)prog_work.size());
+    }
+    for (int x = 0; x < jpgpu_ctx::kProgChains; x++) {
+        prog_chain_begin_[x].assign(1, (int)prog_work.size());
+        for (const std::vector<HuffWork> &w : prog_chain_work[x]) {
+            prog_work.insert(prog_work.end(), w.begin(), w.end());
+            prog_chain_begin_[x].push_back((int)prog_work.size());
+        }
     }
     // Images whose scans do not cover every frame component (a scan header that names one component twice and another never;
     // no scan at all): the reference leaves those samples of the caller's buffer alone.  The batch owns the output buffer,
@@ -1586,8 +1606,50 @@ int DeviceBatch::run_progressive() {
     const int per_cu = (int)std::min<size_t>(32, (160u << 10) / lds_per_wg);
     const bool force = getenv("JPGPU_PROG_FORCE_PIPELINE") != nullptr;  // experiments: pipelined without the gate, any size
     const bool resident = n_streams <= per_cu * 3 / 4 * cus;
-    const bool fits = resident || n_streams <= 3 * per_cu * cus / 2 || force;
+    // (round 3, ADVICE r2: the ungated pipelined launch of grids up to 1.5 x what the CUs hold relied on workgroups starting in
+    // list order; it is opt-in now -- JPGPU_PROG_FORCE_PIPELINE -- and larger batches take the chain launches below)
+    const bool fits = resident || force;
     const int launch_mode = resident && !force ? 1 : 2;
+    const bool no_chains = getenv("JPGPU_PROG_NO_CHAINS") != nullptr;  // A/B switch: level-by-level launches instead
+    if (!(prog_pipelined_ && fits) && prog_chains_ok_ && !no_chains && !dbg_max && getenv("JPGPU_PROG_BY_SCAN") == nullptr && n_streams > 0) {
+        // Batches that do not fit one resident launch.  Scans of different chains -- the DC scans; the AC scans of component 0,
+        // 1, 2, 3 -- never touch the same coefficients, scans of one chain follow each other in file order: every chain gets a
+        // stream of its own and one launch per ordinal (the j-th scan of the chain in every frame).  No waiting inside a
+        // kernel, nothing assumed about dispatch order; the chains fill each other's idle SIMDs (a launch of n one-wave
+        // workgroups keeps n / 1024 waves per SIMD busy, and a lone wave issues an instruction every ~5 cycles at best), and
+        // the step takes as long as its longest chain instead of the sum over dependency levels.
+        jpgpu_ctx *cx = ctx_;
+        for (int x = 0; x < jpgpu_ctx::kProgChains; x++) {
+            if (!cx->prog_stream[x]) {
+                hipError_t e = hipStreamCreateWithFlags(&cx->prog_stream[x], hipStreamNonBlocking);
+                if (e != hipSuccess) return hip_fail(e, "hipStreamCreate(progressive chain)");
+            }
+        }
+        for (int x = 0; x <= jpgpu_ctx::kProgChains; x++) {
+            if (!cx->prog_ev[x]) {
+                hipError_t e = hipEventCreateWithFlags(&cx->prog_ev[x], hipEventDisableTiming);
+                if (e != hipSuccess) return hip_fail(e, "hipEventCreate(progressive chain)");
+            }
+        }
+        hipError_t e = hipEventRecord(cx->prog_ev[jpgpu_ctx::kProgChains], cx->stream);  // K1 and the cleared stores are behind this
+        if (e != hipSuccess) return hip_fail(e, "hipEventRecord");
+        for (int x = 0; x < jpgpu_ctx::kProgChains; x++) {
+            if (prog_chain_begin_[x].size() <= 1) continue;
+            hipStream_t st = cx->prog_stream[x];
+            if ((e = hipStreamWaitEvent(st, cx->prog_ev[jpgpu_ctx::kProgChains], 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
+            for (size_t jx = 0; jx + 1 < prog_chain_begin_[x].size(); jx++) {
+                e = launch_progressive_streams(st, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr,
+                                               (const HuffWork *)d_prog_work_.ptr + prog_chain_begin_[x][jx],
+                                               prog_chain_begin_[x][jx + 1] - prog_chain_begin_[x][jx], (const uint32_t *)d_ends_u_.ptr,
+                                               (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr,
+                                               n_huff_slots_, 0, 0, nullptr);
+                if (e != hipSuccess) return hip_fail(e, "progressive_stream_kernel");
+            }
+            if ((e = hipEventRecord(cx->prog_ev[x], st)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+            if ((e = hipStreamWaitEvent(cx->stream, cx->prog_ev[x], 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
+        }
+        return JPGPU_OK;
+    }
     if (prog_pipelined_ && fits && !dbg_max) {
         // every scan is one stream: one launch, the work list ordered by level; dependent scans follow their producers' progress
         hipError_t e0 = hipMemsetAsync(d_prog_sync_.ptr, 0, 256, ctx_->stream);

@@ -35,6 +35,11 @@ struct jpgpu_ctx {
     hipStream_t stream = nullptr;         // kernels of jpgpu_batch_decode and friends
     hipStream_t stream2 = nullptr;        // second half of a large batch in jpgpu_batch_decode (DeviceBatch::decode)
     hipStream_t upload_stream = nullptr;  // H2D of jpgpu_batch_upload: runs beside another batch's decode on `stream`
+    // progressive batches too large for one resident launch: the DC scans and every component's AC scans form chains that never
+    // touch the same coefficients; each chain's launches go to a stream of its own (DeviceBatch::run_progressive)
+    static constexpr int kProgChains = 5;
+    hipStream_t prog_stream[kProgChains] = {};
+    hipEvent_t prog_ev[kProgChains + 1] = {};
     StagingRing staging;
     int host_threads = 0;                 // crew size of jpgpu_batch_upload; 0 = min(CPUs granted to the process, 16)
     std::string last_error;
@@ -217,6 +222,10 @@ class DeviceBatch {
     std::vector<int> prog_begin_;
     // ... and the scans with few, long intervals (one wave per interval): prog_work[prog_stream_begin_[k] .. [k + 1])
     std::vector<int> prog_stream_begin_;
+    // ... and the same stream work once more, grouped by chain (0 = DC scans, 1 + c = the AC scans of frame component c) and by
+    // the scan's ordinal inside its frame's chain: prog_work[prog_chain_begin_[x][j] .. [x][j + 1])
+    std::vector<int> prog_chain_begin_[jpgpu_ctx::kProgChains];
+    bool prog_chains_ok_ = false;
     bool prog_pipelined_ = false;  // all progressive scans are single streams with <= 3 direct dependencies: one launch
     uint32_t prog_spin_budget_ = 1u << 22;  // polls a follower scan may spend in the pipelined launch (JPGPU_PROG_SPIN_BUDGET)
     int prog_fallbacks_ = 0;                // times the pipelined launch timed out and the step was re-issued level by level

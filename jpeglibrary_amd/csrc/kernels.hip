@@ -2276,6 +2276,9 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
         uint32_t zc = 0;            // zeros of the band consumed so far
         uint32_t kprev = ss - 1u;   // position in front of the next symbol's first one
         const uint32_t dpm = (uint32_t)(p1 - m1), m1v = (uint32_t)m1;
+#ifdef JPGPU_PS_PROFILE
+        d.t_pro += PS_TICK() - t_a;
+#endif
         for (;;) {
             uint32_t stop, scur, se_, st, sn, ve, rr, t, tm, adv, symn, u, curn, pl, sg;
             uint64_t sp;
@@ -2433,8 +2436,7 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
     c = (int32_t)(int16_t)cv;
     mine = minev != 0;
 #ifdef JPGPU_PS_PROFILE
-    d.t_pro += 0;
-    d.t_loop += t_c - t_a - t_r;
+    d.t_loop += t_c - t_a - t_r;  // (includes the prologue, reported separately in t_pro)
     d.t_refresh += t_r;
     d.t_epi += PS_TICK() - t_c;
 #endif
@@ -2682,6 +2684,168 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                 d.pos += nb;
                 d.cur = 64;
                 d.rem -= (int32_t)nb;
+                u0 += group;
+            }
+        }
+        if (ah == 0) {
+            // DC first pass (ReadBlockProgressiveDC, :232-243): ONE symbol per block -- the category, then that many magnitude
+            // bits -- so the only serial thing is the position.  64 blocks (whole MCUs) per pass: a hand-written loop walks the
+            // window entries (~25 instructions per block: pre-digested entry of the block's DC table, advance, note in lane n
+            // where block n's magnitude ends), then all lanes at once cut their magnitudes out of the ring, extend them, run
+            // one prefix sum per component for the predictors and store.  Up to two distinct DC tables per scan; the tail of
+            // the interval (and anything unusual: a code longer than the lookup, a window rebuild) goes block by block below.
+            uint32_t bpu = 0, cbase[kMaxScanComponents + 1];
+#pragma unroll
+            for (uint32_t c = 0; c < kMaxScanComponents; c++) {
+                cbase[c] = bpu;
+                if (c < ncomp) bpu += ncomp == 1 ? 1u : pc[c].h * pc[c].v;
+            }
+            cbase[kMaxScanComponents] = bpu;
+            const uint32_t slot_a = dc_slot[0];
+            uint32_t slot_b = slot_a;
+            bool two_tables = true;
+#pragma unroll
+            for (uint32_t c = 1; c < kMaxScanComponents; c++)
+                if (c < ncomp && dc_slot[c] != slot_a) {
+                    if (slot_b == slot_a) slot_b = dc_slot[c];
+                    else if (dc_slot[c] != slot_b) two_tables = false;
+                }
+            const uint32_t group = two_tables && bpu != 0 && bpu <= 64u ? 64u / bpu : 0u;
+            const uint32_t nb = group * bpu;
+            // component of the block this lane stands for in a pass, and its place inside the MCU
+            const uint32_t within = bpu != 0 ? lane - (lane / bpu) * bpu : 0u;
+            uint32_t my_c = 0;
+#pragma unroll
+            for (uint32_t q = 1; q < kMaxScanComponents; q++)
+                if (q < ncomp && within >= cbase[q]) my_c = q;
+            ProgComp my_p = pc[0];
+            uint32_t my_slot = dc_slot[0];
+#pragma unroll
+            for (uint32_t q = 1; q < kMaxScanComponents; q++)
+                if (my_c == q) {
+                    my_p = pc[q];
+                    my_slot = dc_slot[q];
+                }
+            const uint32_t my_r = within - (my_c == 0 ? 0u : (my_c == 1 ? cbase[1] : (my_c == 2 ? cbase[2] : cbase[3])));
+            const uint64_t tabmask = __ballot(lane < nb && my_slot != slot_a);  // blocks of a pass that decode with the second table
+            const LdsHuff ha = lds_huff(tabs, slot_a), hb = lds_huff(tabs, slot_b);
+            const uint32_t ringbits = uni((d.wmask + 1u) * 32u - 1u);
+            uint32_t ent_a = 0, ent_b = 0;  // the window entries, pre-digested: special << 31 | category << 6 | code + magnitude bits
+            auto digest = [](uint32_t e) {
+                const uint32_t size = e >> 8, cat = e & 0xFFu;
+                return ((size == 0 || cat > 16u) ? 0x80000000u : 0u) | ((cat & 31u) << 6) | ((size + cat) & 63u);
+            };
+            uint32_t passes = 0;
+            while (group != 0 && u0 + group <= my_units && err == 0 && d.rem >= kPsFastBits) {
+                JPGPU_ENSURE_STAGED()
+                if (rows_ready != 0xFFFFFFFFu) JPGPU_FOLLOW((first_unit + u0 + group - 1u) / my_units_per_row)
+                if (err != 0) break;
+                if ((passes++ & 7u) == 7u) JPGPU_PUBLISH(u0)
+                const uint32_t pos0 = uni(d.pos);
+                uint32_t cur = uni(d.cur), winpos = pos0 - cur;
+                uint32_t rec = 0;   // lane n: (category << 6 | code + magnitude bits) << 16 | ring position behind block n's magnitude
+                uint32_t nblk = 0;  // blocks of the pass parsed so far
+                for (;;) {
+                    uint32_t sblk = uni(nblk), stop_, scur, sa, sb, ve, vb, adv, curn, u, pp, val, nbn;
+                    uint64_t sel, sp;
+                    cur = uni(cur);
+                    asm volatile(
+                        "1:\n\t"
+                        "v_readfirstlane_b32 %[scur], %[cur]\n\t"
+                        "s_bitcmp1_b64 %[tabmask], %[sblk]\n\t"
+                        "s_cselect_b64 %[sel], -1, 0\n\t"
+                        "s_add_u32 %[sblk], %[sblk], 1\n\t"
+                        "s_nop 0\n\t"
+                        "v_readlane_b32 %[sa], %[enta], %[scur]\n\t"
+                        "v_readlane_b32 %[sb], %[entb], %[scur]\n\t"
+                        "v_add_u32_e32 %[nbn], 1, %[nblk]\n\t"
+                        "v_mov_b32_e32 %[ve], %[sa]\n\t"
+                        "v_cmp_eq_u32_e64 %[sp], %[lane], %[nblk]\n\t"
+                        "v_mov_b32_e32 %[vb], %[sb]\n\t"
+                        "v_cndmask_b32_e64 %[ve], %[ve], %[vb], %[sel]\n\t"
+                        "v_and_b32_e32 %[adv], 63, %[ve]\n\t"
+                        "v_add_u32_e32 %[curn], %[cur], %[adv]\n\t"
+                        "v_and_b32_e32 %[u], 0x80000000, %[ve]\n\t"
+                        "v_or_b32_e32 %[u], %[u], %[cur]\n\t"
+                        "v_cmp_gt_u32_e32 vcc, 64, %[u]\n\t"
+                        "v_add_u32_e32 %[pp], %[winposv], %[curn]\n\t"
+                        "v_and_b32_e32 %[pp], %[ringv], %[pp]\n\t"
+                        "v_lshl_or_b32 %[val], %[ve], 16, %[pp]\n\t"
+                        "v_cndmask_b32_e32 %[cur], %[cur], %[curn], vcc\n\t"
+                        "v_cndmask_b32_e64 %[rec], %[rec], %[val], %[sp]\n\t"
+                        "v_cndmask_b32_e32 %[nblk], %[nblk], %[nbn], vcc\n\t"
+                        "v_cndmask_b32_e32 %[stop], %[none], %[nbn], vcc\n\t"
+                        "s_nop 0\n\t"
+                        "v_cmp_gt_u32_e32 vcc, %[nb], %[stop]\n\t"
+                        "s_nop 1\n\t"
+                        "s_cbranch_vccnz 1b\n\t"
+                        : [cur] "+v"(cur), [nblk] "+v"(nblk), [rec] "+v"(rec), [sblk] "+s"(sblk), [stop] "=&v"(stop_), [scur] "=&s"(scur),
+                          [sa] "=&s"(sa), [sb] "=&s"(sb), [sel] "=&s"(sel), [sp] "=&s"(sp), [ve] "=&v"(ve), [vb] "=&v"(vb), [adv] "=&v"(adv),
+                          [curn] "=&v"(curn), [u] "=&v"(u), [pp] "=&v"(pp), [val] "=&v"(val), [nbn] "=&v"(nbn)
+                        : [enta] "v"(ent_a), [entb] "v"(ent_b), [lane] "v"(lane), [winposv] "v"(winpos), [ringv] "v"(ringbits),
+                          [none] "v"(0xFFFFu), [tabmask] "s"(tabmask), [nb] "s"(nb)
+                        : "vcc", "scc", "memory");
+                    cur = uni(cur);
+                    nblk = uni(nblk);
+                    if (uni(stop_) != 0xFFFFu) break;  // the pass is complete
+                    if (cur > 63u) {
+                        d.pos = winpos + cur;
+                        d.cur = 64;
+                        w_refresh<false>(d, lane, ha);
+                        ent_a = digest(ha.lut[d.peek >> (32 - kHuffLutBits)]);
+                        ent_b = digest(hb.lut[d.peek >> (32 - kHuffLutBits)]);
+                        winpos = uni(d.pos);
+                        cur = 0;
+                        continue;
+                    }
+                    // one block by hand: a code longer than the lookup (or no code at all)
+                    const bool use_b = ((tabmask >> nblk) & 1ull) != 0;
+                    const uint32_t pk = lane_get(d.peek, cur);
+                    const uint32_t raw = w_huff_scalar(use_b ? hb : ha, pk >> 16);
+                    const uint32_t size = raw >> 8, cat = raw & 0xFFu;
+                    if (size > 16u || cat > 16u) {
+                        err = kDetailInvalidHuffmanCode;
+                        break;
+                    }
+                    cur += size + cat;
+                    if (lane == nblk) rec = ((((cat & 31u) << 6) | ((size + cat) & 63u)) << 16) | ((winpos + cur) & ringbits);
+                    nblk++;
+                    if (nblk >= nb) break;
+                }
+                if (err != 0) {
+                    // the failing block is somewhere in this pass: let the block-by-block loop find it from the pass's first unit
+                    d.pos = pos0;
+                    d.cur = 64;
+                    err = 0;
+                    break;
+                }
+                // all lanes: magnitude, ReceiveAndExtend (:100-115), predictor prefix per component, store
+                const uint32_t cat = (rec >> 22) & 31u;
+                const uint32_t mp = ((rec & 0xFFFFu) - cat) & ringbits;
+                const uint32_t w0 = d.ring[(mp >> 5) & d.wmask], w1 = d.ring[((mp >> 5) + 1u) & d.wmask];
+                const uint32_t top = (uint32_t)(((((uint64_t)w0) << 32) | w1) >> (32u - (mp & 31u)));
+                const int32_t v = cat != 0 ? (int32_t)(top >> (32u - cat)) : 0;
+                const int32_t diff = lane < nb && cat != 0 ? v - ((((v + v) >> cat) - 1) & ((1 << cat) - 1)) : 0;
+                int32_t value = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < kMaxScanComponents; q++) {
+                    if (q >= ncomp) continue;
+                    const bool in_q = lane < nb && my_c == q;
+                    const uint32_t incl = wave_inclusive_scan(in_q ? (uint32_t)diff : 0u);
+                    if (in_q) value = pred[q] + (int32_t)incl;
+                    pred[q] += (int32_t)lane_get(incl, 63);
+                }
+                if (lane < nb) {
+                    const uint32_t unit = first_unit + u0 + lane / bpu;
+                    const uint32_t vy = unit / units_per_line, vx = unit - vy * units_per_line;
+                    uint64_t index = 0;
+                    const bool real = ncomp == 1 ? prog_block_index(fr, my_p, vx, vy, index)
+                                                 : prog_block_index(fr, my_p, vx * my_p.h + my_r % my_p.h, vy * my_p.v + my_r / my_p.h, index);
+                    if (real) coefs[index * 64] = (int16_t)((uint32_t)value << al);
+                }
+                d.pos = winpos + cur;
+                d.cur = cur;  // the window and its pre-digested entries stay valid for the next pass
+                d.rem -= (int32_t)(d.pos - pos0);
                 u0 += group;
             }
         }

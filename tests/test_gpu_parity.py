@@ -582,9 +582,10 @@ def _many_small_progressive(n):
 
 @pytest.mark.parametrize("frames,force", [(800, False), (2400, False), (2400, True)])
 def test_more_progressive_streams_than_the_machine_keeps_resident(frames, force, monkeypatch):
-    """Ten scans per frame, one workgroup each.  800 frames = 8 000 workgroups: more than 256 CUs hold at once, still one
-    pipelined launch (followers are dispatched behind their producers, without the count-in gate); 2 400 frames = 24 000:
-    level by level, or -- forced -- pipelined all the same.  Every frame exact, no fallback needed."""
+    """Ten scans per frame, one workgroup each.  800 frames = 8 000 workgroups, 2 400 frames = 24 000: more than 256 CUs hold at
+    once, so the scans run as chain launches on streams of their own (the DC scans; each component's AC scans: no waiting inside
+    a kernel) -- or, forced, as one pipelined launch without the count-in gate (JPGPU_PROG_FORCE_PIPELINE: followers are
+    dispatched behind their producers).  Every frame exact, no fallback needed."""
     if force:
         monkeypatch.setenv("JPGPU_PROG_FORCE_PIPELINE", "1")
     files, refs = _many_small_progressive(frames)
@@ -878,7 +879,8 @@ def test_encoder_adversarial_content():
 
 
 @pytest.mark.parametrize("env", [
-    {"JPGPU_PROG_NO_PIPELINE": "1"},                    # wave-per-stream kernel, one launch per dependency level
+    {"JPGPU_PROG_NO_PIPELINE": "1"},                    # wave-per-stream kernel, chain launches (a stream per chain of scans)
+    {"JPGPU_PROG_NO_PIPELINE": "1", "JPGPU_PROG_NO_CHAINS": "1"},  # ... one launch per dependency level
     {"JPGPU_PROG_STREAM_MAX_INTERVALS": "0"},           # lane-per-interval kernel for every scan
     {"JPGPU_PROG_STREAM_MAX_INTERVALS": "1000000"},     # wave-per-stream kernel even for scans with many restart intervals
 ])
