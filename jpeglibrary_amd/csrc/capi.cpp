@@ -383,6 +383,7 @@ int jpgpu_batch_upload_frames(jpgpu_batch *b, const jpgpu_frame *frames, const u
 }
 int jpgpu_batch_decode(jpgpu_batch *b) { JPGPU_GUARD(b, b->impl.decode()); }
 static int run_entropy_stages(DeviceBatch &impl) {
+    impl.note_entropy_only_request();
     const int rc = impl.run_marker_index();
     return rc != JPGPU_OK ? rc : impl.run_huffman();
 }

@@ -135,6 +135,15 @@ struct IdctWork {
     uint32_t mcus_per_tile;  // MCUs one pass of the workgroup transforms (<= 256 / blocks_per_mcu, see idct_mcus_per_tile)
 };
 
+// EXTENDED_U16 ("O3"): one image of the batch for extend_u16_kernel
+struct ExtendPlanes {
+    uint64_t plane_off[4];  // byte offsets of the int16 planes in the planes buffer
+    uint64_t out_off;       // byte offset of the image's uint16 x 4 output
+    uint32_t pitch[4];      // samples
+    uint32_t hshift[4], vshift[4];
+    uint32_t width, height, ncomp, precision;
+};
+
 constexpr uint32_t kNoError = 0xFFFFFFFFu;
 
 // detail codes (mirror jpgpu_detail in include/jpgpu.h)

@@ -46,7 +46,7 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_sub_work_, &d_sub_final_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_prog_sync_, &d_planes_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_sub_work_, &d_sub_final_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_prog_sync_, &d_planes_, &d_extend_desc_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
@@ -1132,8 +1132,9 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     const uint32_t stream_max_intervals = getenv("JPGPU_PROG_STREAM_MAX_INTERVALS") ? (uint32_t)atoi(getenv("JPGPU_PROG_STREAM_MAX_INTERVALS")) : 16u;
     prog_clear_.clear();
     prog_pipelined_ = getenv("JPGPU_PROG_NO_PIPELINE") == nullptr;
-    // polls (~2-3 us each) a follower scan of the pipelined launch may spend before it gives up: ~10 s by default
-    prog_spin_budget_ = getenv("JPGPU_PROG_SPIN_BUDGET") ? (uint32_t)strtoul(getenv("JPGPU_PROG_SPIN_BUDGET"), nullptr, 10) : (1u << 22);
+    // polls (~2-3 us each) a follower scan of the pipelined launch may spend before it gives up: ~0.3 s by default (a fully
+    // resident grid -- the only kind that takes the pipelined launch by default -- makes progress within microseconds)
+    prog_spin_budget_ = getenv("JPGPU_PROG_SPIN_BUDGET") ? (uint32_t)strtoul(getenv("JPGPU_PROG_SPIN_BUDGET"), nullptr, 10) : (1u << 17);
     prog_fallbacks_ = 0;
     rgb_convert_.clear();
     sub_scan_ids_.clear();
@@ -1701,21 +1702,39 @@ int DeviceBatch::run_idct() {
                                (uint8_t *)d_rgb_scratch_.ptr);
     if (e != hipSuccess) return hip_fail(e, "idct_output_kernel");
     if (extended) {
-        // "O3": the int16 planes (WriteBlock's arguments) through the test writer's clamp + bit expansion, one pass per image
+        // "O3": the int16 planes (WriteBlock's arguments) through the test writer's clamp + bit expansion: ONE launch for the
+        // batch, a descriptor per image (it was a launch per image)
+        std::vector<ExtendPlanes> desc;
+        uint32_t max_pixels = 0;
         for (const ImagePlan &img : images_) {
             if (img.status != JPGPU_OK || img.jobs.empty() || img.out_bytes == 0) continue;
-            uint64_t off[4] = {0, 0, 0, 0};
-            uint32_t pitch[4] = {1, 1, 1, 1}, hsh[4] = {0, 0, 0, 0}, vsh[4] = {0, 0, 0, 0};
-            const BaselineGeometry &g = jobs_[img.jobs[0]].geo;
+            ExtendPlanes g;
+            memset(&g, 0, sizeof g);
+            const BaselineGeometry &geo = jobs_[img.jobs[0]].geo;
+            for (int c = 0; c < 4; c++) g.pitch[c] = 1;
             for (int c = 0; c < img.num_components && c < 4; c++) {
-                off[c] = img.planes_offset + img.plane[c].offset;
-                pitch[c] = img.plane[c].pitch;
-                const int hs = g.max_h / std::max<int>(1, g.frame.components[c].h), vs = g.max_v / std::max<int>(1, g.frame.components[c].v);
-                while ((1 << (hsh[c] + 1)) <= hs) hsh[c]++;
-                while ((1 << (vsh[c] + 1)) <= vs) vsh[c]++;
+                g.plane_off[c] = img.planes_offset + img.plane[c].offset;
+                g.pitch[c] = img.plane[c].pitch;
+                const int hs = geo.max_h / std::max<int>(1, geo.frame.components[c].h), vs = geo.max_v / std::max<int>(1, geo.frame.components[c].v);
+                while ((1 << (g.hshift[c] + 1)) <= hs) g.hshift[c]++;
+                while ((1 << (g.vshift[c] + 1)) <= vs) g.vshift[c]++;
             }
-            e = launch_extend_u16(ctx_->stream, (const uint8_t *)d_planes_.ptr, (uint16_t *)((uint8_t *)d_out_.ptr + img.out_offset), off, pitch, hsh, vsh,
-                                  img.width, img.height, img.num_components, img.precision);
+            g.out_off = img.out_offset;
+            g.width = img.width;
+            g.height = img.height;
+            g.ncomp = img.num_components;
+            g.precision = img.precision;
+            max_pixels = std::max<uint64_t>(max_pixels, std::min<uint64_t>((uint64_t)img.width * img.height, 0xFFFFFFFFu));
+            desc.push_back(g);
+        }
+        if (!desc.empty()) {
+            e = d_extend_desc_.reserve(desc.size() * sizeof(ExtendPlanes));
+            if (e != hipSuccess) return hip_fail(e, "hipMalloc(extend descriptors)");
+            e = hipMemcpyAsync(d_extend_desc_.ptr, desc.data(), desc.size() * sizeof(ExtendPlanes), hipMemcpyHostToDevice, ctx_->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx_->stream);  // `desc` is a local (pageable) vector; a few KB
+            if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(extend descriptors)");
+            e = launch_extend_u16(ctx_->stream, (const uint8_t *)d_planes_.ptr, (uint8_t *)d_out_.ptr, (const ExtendPlanes *)d_extend_desc_.ptr,
+                                  (int)desc.size(), max_pixels);
             if (e != hipSuccess) return hip_fail(e, "extend_u16_kernel");
         }
     }
@@ -1755,6 +1774,7 @@ int DeviceBatch::decode() {
         ev_pool_.push_back(ev);
     }
     hipEvent_t *ev = &ev_pool_[ev_used_];
+    in_decode_request_ = true;
     const bool serial = !overlap_ok_ || (decodes_since_query_ % kSerialEvery) == 0;
     decodes_since_query_++;
     int rc;
@@ -1853,9 +1873,16 @@ int DeviceBatch::fetch_status() {
         bool timed_out = false;
         for (const DevScanStatus &st : h_status_) timed_out |= st.first_error != kNoError && (st.first_error & 0xFFu) == kDetailSpinTimeout;
         if (timed_out) {
+            // re-issue what the caller had asked for -- the entropy stage alone (jpgpu_batch_run_entropy; coefficients a caller
+            // uploaded for the IDCT stage are then left alone by the output stage that is NOT run) or the whole pipeline
             prog_pipelined_ = false;
             prog_fallbacks_++;
-            rc = decode();
+            if (in_decode_request_) {
+                rc = decode();
+            } else {
+                rc = run_marker_index();
+                if (rc == JPGPU_OK) rc = run_huffman();
+            }
             if (rc != JPGPU_OK) return rc;
             return fetch_status();
         }

@@ -146,6 +146,7 @@ class DeviceBatch {
     int stage_ms(float ms[4]);
     void totals(uint64_t *compressed, uint64_t *blocks, uint64_t *pixels, uint64_t *out_bytes) const;
     int format() const { return format_; }
+    void note_entropy_only_request() { in_decode_request_ = false; }
     int last_subseq_rounds() const { return last_subseq_rounds_; }
     int progressive_fallbacks() const { return prog_fallbacks_; }
     // the optimizer path only needs the files, the scan descriptors and the marker index: no coefficient / sample buffers
@@ -207,6 +208,8 @@ class DeviceBatch {
     int idct_class_begin_[kNumIdctLayoutClasses + 1] = {};
     uint64_t total_blocks_ = 0, out_bytes_ = 0, planes_bytes_ = 0, input_bytes_ = 0, compressed_bytes_ = 0, total_pixels_ = 0;
     DevBuffer d_planes_;  // EXTENDED_U16: K3's PLANAR_I16 output, converted by extend_u16_kernel
+    DevBuffer d_extend_desc_;
+    bool in_decode_request_ = false;  // the last entropy stage was issued by decode() (fetch_status's fallback re-issues the same thing)
     uint32_t total_ends_ = 0;
 
     // DRI = 0 scans: self-synchronising subsequence decode (K2S)

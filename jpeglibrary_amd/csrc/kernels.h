@@ -59,8 +59,8 @@ hipError_t launch_progressive_streams(hipStream_t stream, const uint8_t *udata, 
 size_t progressive_stream_lds_bytes(int n_slots);  // LDS of one stream workgroup (residency estimate of the pipelined launch)
 
 // "O3": PLANAR_I16 planes -> the test writer's uint16 x 4 form (extend_u16_kernel)
-hipError_t launch_extend_u16(hipStream_t stream, const uint8_t *planes, uint16_t *out, const uint64_t plane_off[4], const uint32_t pitch[4],
-                             const uint32_t hshift[4], const uint32_t vshift[4], uint32_t width, uint32_t height, uint32_t ncomp, uint32_t precision);
+hipError_t launch_extend_u16(hipStream_t stream, const uint8_t *planes, uint8_t *out_base, const ExtendPlanes *images, int n_images,
+                             uint32_t max_pixels);
 
 // K0 (ingest verification): offset of the first non-RST marker in each segment {offset lo, length} (+ offset hi), 0xFFFFFFFF = none
 hipError_t launch_first_marker(hipStream_t stream, const uint8_t *data, const void *segs, const uint32_t *seg_hi, int n_segs,

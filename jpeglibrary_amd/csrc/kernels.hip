@@ -3756,15 +3756,12 @@ __global__ __launch_bounds__(256) void ycc_to_rgb_kernel(const uint8_t *__restri
 // wrote = WriteBlock's arguments before chroma expansion.  WriteBlockSlow replicates with shifts (:238-268), so pixel (x, y)
 // of component c is plane_c[y >> vshift][x >> hshift]; the writer then takes (ushort)sample -- a negative sample becomes a
 // large value -- clamps to 2^P - 1 and spreads the P bits over 16 (FastExpandBits for P >= 8, ExpandBits below).
-struct ExtendPlanes {
-    uint64_t plane_off[4];  // byte offsets of the int16 planes in `planes`
-    uint32_t pitch[4];      // samples
-    uint32_t hshift[4], vshift[4];
-    uint32_t width, height, ncomp, precision;
-};
-__global__ __launch_bounds__(256) void extend_u16_kernel(const uint8_t *__restrict__ planes, uint16_t *__restrict__ out, ExtendPlanes g) {
-    const uint64_t px = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (px >= (uint64_t)g.width * g.height) return;
+// One launch for the whole batch: blockIdx.y = image (its descriptor in HBM), blockIdx.x strides over the image's pixels.
+__global__ __launch_bounds__(256) void extend_u16_kernel(const uint8_t *__restrict__ planes, uint8_t *__restrict__ out_base,
+                                                         const ExtendPlanes *__restrict__ images) {
+    const ExtendPlanes g = images[blockIdx.y];
+    uint16_t *out = reinterpret_cast<uint16_t *>(out_base + g.out_off);
+    for (uint64_t px = (uint64_t)blockIdx.x * 256 + threadIdx.x; px < (uint64_t)g.width * g.height; px += (uint64_t)gridDim.x * 256) {
     const uint32_t y = (uint32_t)(px / g.width), x = (uint32_t)(px - (uint64_t)y * g.width);
     const uint32_t p = g.precision, mx = (1u << p) - 1u;
     uint16_t v4[4] = {0, 0, 0, 0};
@@ -3792,6 +3789,7 @@ __global__ __launch_bounds__(256) void extend_u16_kernel(const uint8_t *__restri
     }
     // channels the frame does not have keep what the caller's (fresh, zeroed) buffer held: the batch owns the buffer, so zero
     *reinterpret_cast<uint2 *>(out + px * 4) = uint2{(uint32_t)v4[0] | ((uint32_t)v4[1] << 16), (uint32_t)v4[2] | ((uint32_t)v4[3] << 16)};
+    }
 }
 
 // Output assembly of the INTERLEAVED_U8 format from the LDS sample tile [8 rows][256 blocks][8 B] (phase C).
@@ -3952,17 +3950,19 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
 
     const uint32_t mcu_local = tid / bpm;
     const uint32_t b = tid - mcu_local * bpm;
-    const uint32_t ci = s.blk_comp[b < kMaxBlocksPerMcu ? b : 0];
-    const DevScanComponent comp = s.comp[ci];
+    const uint32_t ci_early = s.blk_comp[b < kMaxBlocksPerMcu ? b : 0];
     const uint8_t *coef_bytes = reinterpret_cast<const uint8_t *>(coefs + s.coef_off * 64);
 
     auto tile_mcus = [&](uint32_t first) { return (range_end - first) < mcus_per_tile ? (range_end - first) : mcus_per_tile; };
     // LDS-DMA of one tile: linear 16-byte slot c = k * 256 + tid (block c >> 3, slot c & 7) receives piece
     // (slot ^ swizzle(block)); the swizzle term ((block >> 1) & 7) does not depend on k, so every lane's source is
     // one fixed offset plus k * 4096.  Always a full tile: the coefficient buffer has a tile of slack behind it.
-    const uint32_t dma_lane_off = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) * 16);
     const uint32_t tile_blocks = mcus_per_tile * bpm;
     auto dma_tile = [&](uint32_t tile_first) {
+        // (recomputed per tile, three instructions, rather than kept in a register across the transform)
+        uint32_t t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const uint32_t dma_lane_off = (t_ >> 3) * 128 + (((t_ & 7) ^ ((t_ >> 4) & 7)) * 16);
         const uint8_t *src = coef_bytes + (uint64_t)tile_first * bpm * 128;  // wave-uniform
 #pragma unroll
         for (int k = 0; k < 8; k++)
@@ -3985,12 +3985,11 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
     const bool have_block = tid < n_blk;
     // a scan component whose frame component a LATER scan component also resolves to: the reference writes its blocks first
     // and the later component's over them (WriteBlock by ComponentIndex, :118-134), so only the later ones reach the output
-    const bool writes = have_block && ((s.shadow_mask >> ci) & 1u) == 0;
-    const uint32_t mcu_x = mcu % s.mcus_per_line, mcu_y = mcu / s.mcus_per_line;
+    const bool writes = have_block && ((s.shadow_mask >> ci_early) & 1u) == 0;
 
     // phase B1: dequantise this lane's block out of the staging into registers
     float f[64];
-    if (have_block) block_dequant(sh + tid * 128, (tid >> 1) & 7, sh_q[ci], f);
+    if (have_block) block_dequant(sh + tid * 128, (tid >> 1) & 7, sh_q[ci_early], f);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every lane holds its coefficients: the staging can be refilled
     if (have_next) dma_tile(next_first);  // in flight during the whole transform below
@@ -4003,6 +4002,14 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
         for (int i = 0; i < 32; i++) px[i] = 0;
     }
     bool synced = false;
+    // the MCU's place in the image is only needed from here on: computed behind the transform (an empty asm the compiler may not
+    // move across keeps it from being hoisted in front of it), two registers fewer are alive while the 64 + 32 of the
+    // transform are -- what four of the sixteen variants spilled (profiles/r03_kernel_resources.txt)
+    uint32_t mcu_late = mcu, b_late = b;
+    asm volatile("" : "+v"(mcu_late), "+v"(b_late));
+    const uint32_t mcu_y = mcu_late / s.mcus_per_line, mcu_x = mcu_late - mcu_y * s.mcus_per_line;
+    const uint32_t ci = s.blk_comp[b_late < kMaxBlocksPerMcu ? b_late : 0];  // (again: one byte from the L1-resident descriptor)
+    const DevScanComponent comp = s.comp[ci];
 
     if (FMT == kFmtPlanarI16) {
         // "O1": unclamped int16 at component-native resolution, planes padded to whole MCUs
@@ -4078,22 +4085,14 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
 
-hipError_t launch_extend_u16(hipStream_t stream, const uint8_t *planes, uint16_t *out, const uint64_t plane_off[4], const uint32_t pitch[4],
-                             const uint32_t hshift[4], const uint32_t vshift[4], uint32_t width, uint32_t height, uint32_t ncomp, uint32_t precision) {
-    ExtendPlanes g;
-    for (int c = 0; c < 4; c++) {
-        g.plane_off[c] = plane_off[c];
-        g.pitch[c] = pitch[c];
-        g.hshift[c] = hshift[c];
-        g.vshift[c] = vshift[c];
+hipError_t launch_extend_u16(hipStream_t stream, const uint8_t *planes, uint8_t *out_base, const ExtendPlanes *images, int n_images,
+                             uint32_t max_pixels) {
+    if (n_images <= 0 || max_pixels == 0) return hipSuccess;
+    const uint32_t bx = (uint32_t)std::min<uint64_t>(((uint64_t)max_pixels + 255) / 256, 4096);
+    for (int base = 0; base < n_images; base += 65535) {  // grid.y limit
+        const int n = n_images - base < 65535 ? n_images - base : 65535;
+        hipLaunchKernelGGL(extend_u16_kernel, dim3(bx, (uint32_t)n), dim3(256), 0, stream, planes, out_base, images + base);
     }
-    g.width = width;
-    g.height = height;
-    g.ncomp = ncomp;
-    g.precision = precision;
-    const uint64_t n = (uint64_t)width * height;
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(extend_u16_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, planes, out, g);
     return hipGetLastError();
 }
 
