@@ -462,6 +462,10 @@ int jpgpu_encoder_upload(jpgpu_encoder *e, const uint8_t *const *pixels, const j
 int jpgpu_encoder_set_quantization_table(jpgpu_encoder *e, int i, int identifier, const uint16_t *zigzag64);
 /* Encode(): FDCT + quantise, Huffman code lengths, bit emission, byte stuffing -- all on the device */
 int jpgpu_encoder_encode(jpgpu_encoder *e);
+/* Device time (ms, HIP events) of the last jpgpu_encoder_encode by stage: ms[0] pixels -> quantised zig-zag blocks (ReadBlock, FDCT,
+ * ZigZagAndQuantizeBlock: JpegEncoder.cs:662-741, 812-826; with optimize_coding also GatherBlockStatistics :552-597), ms[1] code lengths
+ * and bit offsets, ms[2] bit emission (EncodeBlock :828-925), ms[3] byte stuffing (JpegWriter.cs:133-232), ms[4] their sum. */
+int jpgpu_encoder_stage_ms(jpgpu_encoder *e, float ms[5]);
 int jpgpu_encoder_encoded_size(const jpgpu_encoder *e, int i, size_t *bytes);
 int jpgpu_encoder_download(jpgpu_encoder *e, int i, void *dst, size_t cap);                       /* the IBufferWriter's content */
 void *jpgpu_encoder_output_device(const jpgpu_encoder *e, int i, size_t *bytes);                  /* stream i, resident in HBM */

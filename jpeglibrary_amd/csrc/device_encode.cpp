@@ -118,6 +118,8 @@ void rgb_ycc_factors(int32_t out[8]) {
 }
 
 EncodeBatch::~EncodeBatch() {
+    for (hipEvent_t ev : ev_)
+        if (ev) (void)hipEventDestroy(ev);
     for (DevBuffer *b : {&d_samples_, &d_pixels_, &d_images_, &d_tables_, &d_work_mcu_, &d_work_blk_, &d_work_stat_, &d_work_chunk_, &d_coefs_, &d_bits_, &d_bit_off_,
                          &d_raw_bits_, &d_raw_, &d_marks_, &d_chunk_ff_, &d_out_, &d_out_len_, &d_hist_})
         b->release();
@@ -318,9 +320,12 @@ int EncodeBatch::encode() {
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     const int n = (int)images_.size();
     if (n == 0) return JPGPU_OK;
+    for (hipEvent_t &ev : ev_)
+        if (!ev && (e = hipEventCreate(&ev)) != hipSuccess) return hip_fail(e, "hipEventCreate");
     // image descriptors (raw / output offsets are filled in once the bit counts are known)
     e = hipMemcpyAsync(d_images_.ptr, images_.data(), (size_t)n * sizeof(DevEncImage), hipMemcpyHostToDevice, ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(images)");
+    (void)hipEventRecord(ev_[0], ctx_->stream);
     e = launch_fdct_quant(ctx_->stream, (const uint8_t *)d_pixels_.ptr, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_mcu_.ptr, n_work_mcu_,
                           (uint8_t *)d_samples_.ptr, (int16_t *)d_coefs_.ptr);
     if (e != hipSuccess) return hip_fail(e, "fdct_quant_kernel");
@@ -375,11 +380,13 @@ int EncodeBatch::encode() {
         e = hipMemcpyAsync((EncHuffTable *)d_tables_.ptr + 4, built.data(), built.size() * sizeof(EncHuffTable), hipMemcpyHostToDevice, ctx_->stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(built tables)");
     }
+    (void)hipEventRecord(ev_[1], ctx_->stream);
     uint32_t *wg_bits = reinterpret_cast<uint32_t *>((uint8_t *)d_bit_off_.ptr + (((size_t)n_work_blk_ * sizeof(uint64_t) + 255) & ~(size_t)255));
     e = launch_block_bits(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_blk_.ptr, n_work_blk_,
                           (const EncHuffTable *)d_tables_.ptr, (const int16_t *)d_coefs_.ptr, (uint32_t *)d_bits_.ptr, n, wg_bits, (uint64_t *)d_bit_off_.ptr,
                           (uint64_t *)d_raw_bits_.ptr);
     if (e != hipSuccess) return hip_fail(e, "block_bits_kernel");
+    (void)hipEventRecord(ev_[2], ctx_->stream);
     // the sizes of the raw and finished streams depend on the data: one host round trip
     std::vector<uint64_t> raw_bits((size_t)n);
     e = hipMemcpyAsync(raw_bits.data(), d_raw_bits_.ptr, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx_->stream);
@@ -420,19 +427,33 @@ int EncodeBatch::encode() {
     for (int i = 0; i < n && e == hipSuccess; i++)
         e = hipMemcpyAsync((uint8_t *)d_out_.ptr + images_[i].out_off, headers_[i].data(), headers_[i].size(), hipMemcpyHostToDevice, ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(headers)");
+    (void)hipEventRecord(ev_[3], ctx_->stream);
     e = launch_emit(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_blk_.ptr, n_work_blk_, (const EncHuffTable *)d_tables_.ptr,
                     (const int16_t *)d_coefs_.ptr, (const uint32_t *)d_bits_.ptr, (const uint64_t *)d_bit_off_.ptr, (const uint64_t *)d_raw_bits_.ptr,
                     (uint8_t *)d_raw_.ptr, (uint32_t *)d_marks_.ptr);
     if (e != hipSuccess) return hip_fail(e, "emit_kernel");
+    (void)hipEventRecord(ev_[4], ctx_->stream);
     e = launch_stuff(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_chunk_.ptr, n_work_chunk_, (const uint64_t *)d_raw_bits_.ptr,
                      (const uint8_t *)d_raw_.ptr, (const uint32_t *)d_marks_.ptr, (uint32_t *)d_chunk_ff_.ptr, (uint8_t *)d_out_.ptr,
                      (uint64_t *)d_out_len_.ptr);
     if (e != hipSuccess) return hip_fail(e, "stuff kernels");
+    (void)hipEventRecord(ev_[5], ctx_->stream);
     out_len_.assign((size_t)n, 0);
     e = hipMemcpyAsync(out_len_.data(), d_out_len_.ptr, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx_->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpy(stream lengths)");
     encoded_ = true;
+    return JPGPU_OK;
+}
+
+int EncodeBatch::stage_ms(float ms[5]) {
+    if (!encoded_ || !ev_[5]) return fail(JPGPU_ERR_INVALID_OPERATION, "jpgpu_encoder_stage_ms: no encode has run");
+    const int pairs[4][2] = {{0, 1}, {1, 2}, {3, 4}, {4, 5}};  // (the statistics pass of optimizeCoding counts as E1)
+    ms[4] = 0;
+    for (int k = 0; k < 4; k++) {
+        if (hipEventElapsedTime(&ms[k], ev_[pairs[k][0]], ev_[pairs[k][1]]) != hipSuccess) return fail(JPGPU_ERR_DEVICE, "hipEventElapsedTime failed");
+        ms[4] += ms[k];
+    }
     return JPGPU_OK;
 }
 

@@ -18,6 +18,9 @@ class EncodeBatch {
     int upload(const uint8_t *const *pixels, const jpgpu_encode_params *params, int n);  // SetInputReader x n (+ H2D)
     int set_quantization_table(int i, int identifier, const uint16_t *zigzag64);           // SetQuantizationTable of image i
     int encode();                                                                        // JpegEncoder.Encode() x n
+    // device time of the last encode() by stage (HIP events on the context's stream): E1 pixels -> quantised blocks, E2 bit counts
+    // and offsets, E3 bit emission, E4 byte stuffing; ms[4] = the four together (the host round trips between them excluded)
+    int stage_ms(float ms[5]);
     int size() const { return (int)images_.size(); }
     int encoded_size(int i, size_t *bytes) const;
     int image_status(int i) const { return (i >= 0 && i < (int)status_.size()) ? status_[i] : JPGPU_ERR_ARGUMENT; }
@@ -44,6 +47,7 @@ class EncodeBatch {
     DevBuffer d_hist_;
     std::vector<uint64_t> out_len_;
     bool encoded_ = false;
+    hipEvent_t ev_[6] = {};
     uint64_t total_blocks_ = 0, out_cap_ = 0;
     int n_work_mcu_ = 0, n_work_blk_ = 0, n_work_stat_ = 0, n_work_chunk_ = 0;
     DevBuffer d_samples_;  // E1a -> E1b: gathered samples, enc_sample_bytes_per_mcu per MCU

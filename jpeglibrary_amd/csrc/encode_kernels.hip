@@ -371,8 +371,8 @@ __device__ __forceinline__ void enc_block_symbols(const uint4 (&cv)[8], int32_t 
         }
         const uint32_t bits = enc_bit_count((uint32_t)a & 0xFFFFu);
         const uint32_t sym = ((run << 4) | bits) & 0xFFu;
-        put(t.code[sym], t.len[sym]);
-        if (bits) put((uint32_t)bb & ((1u << bits) - 1u), bits);
+        // the code and the magnitude bits behind it as ONE field (16 + 15 bits at most): one call of the bit writer per symbol
+        put((t.code[sym] << bits) | ((uint32_t)bb & ((1u << bits) - 1u)), t.len[sym] + bits);
     };
     const int32_t dcv = coef(0);
     run_length(dc, 0, dcv - dc_pred);
@@ -394,14 +394,25 @@ __device__ __forceinline__ void enc_block_symbols(const uint4 (&cv)[8], int32_t 
     if (run > 0) put(ac.code[0], ac.len[0]);
 }
 
+// The four Huffman encoding tables of an image (DC0, AC0, DC1, AC1: 3 KB) staged in LDS: every symbol of every lane looks two of
+// their entries up.
+__device__ __forceinline__ void enc_stage_tables(const EncHuffTable *__restrict__ tables, uint32_t table_base, EncHuffTable *sh_tab) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(tables + table_base);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(sh_tab);
+    for (uint32_t i = threadIdx.x; i < 4u * (uint32_t)sizeof(EncHuffTable) / 4u; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
 // E2: bits of every block (EncodeBlock with a counting writer).  bits[] receives the block's offset inside its workgroup
 // of 256 blocks, wg_bits[] the workgroup's total: the image-wide scan (block_offsets_kernel) then runs over one entry per
 // workgroup instead of one per block.
 __global__ __launch_bounds__(256) void block_bits_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
                                                          const EncHuffTable *__restrict__ tables, const int16_t *__restrict__ coefs,
                                                          uint32_t *__restrict__ bits, uint32_t *__restrict__ wg_bits) {
+    __shared__ EncHuffTable sh_tab[4];
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
+    enc_stage_tables(tables, im.table_base, sh_tab);
     const uint32_t blk = wk.first + threadIdx.x;  // block, or restart interval
     uint32_t n = 0;
     const int16_t *img_coefs = coefs + im.coef_off * 64;
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(256) void block_bits_kernel(const DevEncImage *__re
                     const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
                     const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)enc_source_block(im, mcu * im.bpm + b) * 64);
                     const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
-                    enc_block_symbols(cv, pred, tables[im.table_base + (comp == 0 ? 0 : 2)], tables[im.table_base + (comp == 0 ? 1 : 3)],
+                    enc_block_symbols(cv, pred, sh_tab[comp == 0 ? 0 : 2], sh_tab[comp == 0 ? 1 : 3],
                                       [&](uint32_t, uint32_t len) { n += len; });
                 }
             n = (n + 7u) & ~7u;
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(256) void block_bits_kernel(const DevEncImage *__re
     const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
     const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)enc_source_block(im, blk) * 64);
     const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
-    enc_block_symbols(cv, pred, tables[im.table_base + (comp == 0 ? 0 : 2)], tables[im.table_base + (comp == 0 ? 1 : 3)], [&](uint32_t, uint32_t len) { n += len; });
+    enc_block_symbols(cv, pred, sh_tab[comp == 0 ? 0 : 2], sh_tab[comp == 0 ? 1 : 3], [&](uint32_t, uint32_t len) { n += len; });
     }
     // exclusive scan of n over the workgroup
     __shared__ uint32_t sh_wave[4];
@@ -523,40 +534,60 @@ __global__ __launch_bounds__(1024) void block_offsets_kernel(const DevEncImage *
 }
 
 // One lane per block: its codes ORed into the raw bit stream (MSB-first) at its bit offset.  The stream is kept as
-// big-endian 32-bit words, i.e. every word is stored byte-swapped; words shared with a neighbouring block are combined by
-// atomicOr (the buffer is zeroed before), which commutes with the byte swap.
+// big-endian 32-bit words, i.e. every word is stored byte-swapped.
+// Round 3: the 256 blocks (or restart intervals) of a workgroup own ONE contiguous stretch of the stream -- from the
+// workgroup's base to the next one's -- so the lanes assemble it in LDS (ds_or on words the workgroup zeroed; ~3 per block)
+// and the workgroup writes it out with plain coalesced stores; only its first and last word can be shared with a
+// neighbouring workgroup and go out as atomicOr on the zeroed buffer.  Before, every completed word of every lane was an
+// atomicOr in HBM (150 M of them per 256 x 4K: emit_kernel 5.05 ms against 2.2 ms for the same walk in block_bits_kernel).
+// A stretch longer than the LDS buffer (32 KB = 1 024 bits per block on average: restart intervals of many MCUs at high
+// quality) falls back to the global atomics.
+constexpr uint32_t kEmitLdsWords = 8192;
 __global__ __launch_bounds__(256) void emit_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
                                                    const EncHuffTable *__restrict__ tables, const int16_t *__restrict__ coefs,
                                                    const uint32_t *__restrict__ bits, const uint64_t *__restrict__ wg_base,
                                                    const uint64_t *__restrict__ raw_bits, uint8_t *__restrict__ raw,
                                                    uint32_t *__restrict__ marks) {
+    __shared__ uint32_t sh_words[kEmitLdsWords];
+    __shared__ EncHuffTable sh_tab[4];
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
+    enc_stage_tables(tables, im.table_base, sh_tab);
     const uint32_t blk = wk.first + threadIdx.x;  // block, or restart interval
-    if (blk >= im.n_units) return;
+    const bool active = blk < im.n_units;
     const int16_t *img_coefs = coefs + im.coef_off * 64;
     uint32_t *words = reinterpret_cast<uint32_t *>(raw + im.raw_off);
-    const uint64_t start = wg_base[blockIdx.x] + bits[im.coef_off + blk];
+    // the workgroup's stretch of the stream, in whole words
+    const uint64_t wg_start = wg_base[blockIdx.x];
+    const bool last_wg = wk.first + 256u >= im.n_units;
+    const uint64_t wg_end = last_wg ? ((raw_bits[wk.image] + 7ull) & ~7ull) : wg_base[blockIdx.x + 1];
+    const uint64_t first_word = wg_start >> 5;
+    const uint64_t span_bits = wg_end - (first_word << 5);
+    const bool use_lds = span_bits <= (uint64_t)kEmitLdsWords * 32u;  // the same for every lane
+    const uint32_t n_words = use_lds ? (uint32_t)((span_bits + 31u) >> 5) : 0u;
+    for (uint32_t w = threadIdx.x; w < n_words; w += 256u) sh_words[w] = 0;
+    __syncthreads();
+    const uint64_t start = wg_start + (active ? bits[im.coef_off + blk] : 0u);
     uint64_t wi = start >> 5;            // current word
-    uint32_t fill = (uint32_t)(start & 31);  // bits already taken in it (by earlier blocks)
-    uint32_t acc = 0;                    // bits of the current word, left aligned below `fill`
-    auto put = [&](uint32_t code, uint32_t len) {
-        while (len) {
-            const uint32_t room = 32u - fill;
-            const uint32_t take = len < room ? len : room;
-            const uint32_t part = (take == 32u) ? code : ((code >> (len - take)) & ((1u << take) - 1u));
-            acc |= (take == 32u) ? part : (part << (room - take));
-            fill += take;
-            len -= take;
-            if (fill == 32u) {
-                atomicOr(&words[wi], __builtin_bswap32(acc));
-                wi++;
-                fill = 0;
-                acc = 0;
-            }
+    uint32_t fill = (uint32_t)(start & 31);  // bits already taken in it (by earlier blocks): always < 32 between calls
+    uint64_t acc = 0;                    // the current word in the high half, what spills over in the low half
+    auto flush_word = [&](uint32_t w) {
+        if (use_lds) atomicOr(&sh_words[(uint32_t)(wi - first_word)], w);
+        else atomicOr(&words[wi], __builtin_bswap32(w));
+    };
+    auto flush = [&]() { flush_word((uint32_t)(acc >> 32)); };
+    auto put = [&](uint32_t code, uint32_t len) {  // len <= 32 (31 from enc_block_symbols), code < 2^len
+        if (len == 0) return;  // a symbol the table has no code for (and the reference writes nothing for)
+        acc |= (uint64_t)code << (64u - fill - len);
+        fill += len;
+        if (fill >= 32u) {
+            flush();
+            wi++;
+            acc <<= 32;
+            fill -= 32u;
         }
     };
-    if (im.restart_interval != 0) {
+    if (active && im.restart_interval != 0) {
         // one lane per restart interval: its blocks, one-bit padding to the byte boundary (ExitBitMode), and a mark on its
         // last byte when a restart marker follows (the stuffing pass writes RSTm there)
         const uint32_t first_mcu = blk * im.restart_interval, total_mcus = im.mcus_per_line * im.mcus_per_column;
@@ -572,29 +603,40 @@ __global__ __launch_bounds__(256) void emit_kernel(const DevEncImage *__restrict
                 const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
                 const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)enc_source_block(im, mcu * im.bpm + b) * 64);
                 const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
-                enc_block_symbols(cv, pred, tables[im.table_base + (comp == 0 ? 0 : 2)], tables[im.table_base + (comp == 0 ? 1 : 3)], put_counted);
+                enc_block_symbols(cv, pred, sh_tab[comp == 0 ? 0 : 2], sh_tab[comp == 0 ? 1 : 3], put_counted);
             }
         const uint32_t rem = (8u - (nbits & 7u)) & 7u;
         if (rem) put((1u << rem) - 1u, rem);
-        if (fill) atomicOr(&words[wi], __builtin_bswap32(acc));
+        if (fill) flush();
         if (blk + 1 < im.n_units) {
             const uint64_t last_byte = (start >> 3) + ((nbits + 7u) >> 3) - 1u;
             atomicOr(&marks[(im.raw_off >> 5) + (last_byte >> 5)], 1u << (uint32_t)(last_byte & 31u));
         }
-        return;
+    } else if (active) {
+        const uint32_t mcu = blk / im.bpm, b = blk - mcu * im.bpm;
+        uint32_t comp;
+        const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
+        const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)enc_source_block(im, blk) * 64);
+        const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
+        enc_block_symbols(cv, pred, sh_tab[comp == 0 ? 0 : 2], sh_tab[comp == 0 ? 1 : 3], put);
+        if (blk == im.total_blocks - 1) {
+            // ExitBitMode (ref: JpegWriter.cs:123-147): pad the last byte with one-bits
+            const uint32_t rem = (uint32_t)((8u - (raw_bits[wk.image] & 7u)) & 7u);
+            if (rem) put((1u << rem) - 1u, rem);
+        }
+        if (fill) flush();
     }
-    const uint32_t mcu = blk / im.bpm, b = blk - mcu * im.bpm;
-    uint32_t comp;
-    const int32_t pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
-    const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)enc_source_block(im, blk) * 64);
-    const uint4 cv[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
-    enc_block_symbols(cv, pred, tables[im.table_base + (comp == 0 ? 0 : 2)], tables[im.table_base + (comp == 0 ? 1 : 3)], put);
-    if (blk == im.total_blocks - 1) {
-        // ExitBitMode (ref: JpegWriter.cs:123-147): pad the last byte with one-bits
-        const uint32_t rem = (uint32_t)((8u - (raw_bits[wk.image] & 7u)) & 7u);
-        if (rem) put((1u << rem) - 1u, rem);
+    if (n_words != 0) {
+        __syncthreads();
+        for (uint32_t w = threadIdx.x; w < n_words; w += 256u) {
+            const uint32_t v = __builtin_bswap32(sh_words[w]);
+            if (w == 0 || w + 1 == n_words) {
+                if (v) atomicOr(&words[first_word + w], v);  // may be shared with the neighbouring workgroup's stretch
+            } else {
+                words[first_word + w] = v;
+            }
+        }
     }
-    if (fill) atomicOr(&words[wi], __builtin_bswap32(acc));
 }
 
 // ------------------------------------------------------------------------------------------------ E4: byte stuffing

@@ -63,6 +63,12 @@ class EncodeBatch:
     def __len__(self):
         return self._n
 
+    def stage_ms(self):
+        """Device time of the last encode() by stage (HIP events)."""
+        ms = (C.c_float * 5)()
+        self._check(_lib.jpgpu_encoder_stage_ms(self._h, ms))
+        return {"fdct_quant": ms[0], "block_bits": ms[1], "emit": ms[2], "stuff": ms[3], "total": ms[4]}
+
     def output(self, i) -> bytes:
         size = C.c_size_t()
         self._check(_lib.jpgpu_encoder_encoded_size(self._h, i, C.byref(size)))
