@@ -121,7 +121,7 @@ int jpgpu_host_alloc(jpgpu_ctx *ctx, size_t bytes, void **out) {
     if (!ctx || !out) return JPGPU_ERR_ARGUMENT;
     *out = nullptr;
     (void)hipSetDevice(ctx->device);
-    return host_mem_call(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable), "hipHostMalloc");
+    return host_mem_call(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped), "hipHostMalloc");
 }
 int jpgpu_host_free(jpgpu_ctx *ctx, void *p) {
     if (!ctx) return JPGPU_ERR_ARGUMENT;
@@ -131,7 +131,7 @@ int jpgpu_host_free(jpgpu_ctx *ctx, void *p) {
 int jpgpu_host_register(jpgpu_ctx *ctx, void *p, size_t bytes) {
     if (!ctx || !p || !bytes) return JPGPU_ERR_ARGUMENT;
     (void)hipSetDevice(ctx->device);
-    return host_mem_call(ctx, hipHostRegister(p, bytes, hipHostRegisterPortable), "hipHostRegister");
+    return host_mem_call(ctx, hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped), "hipHostRegister");
 }
 int jpgpu_host_unregister(jpgpu_ctx *ctx, void *p) {
     if (!ctx || !p) return JPGPU_ERR_ARGUMENT;

@@ -122,6 +122,13 @@ struct ChunkWork {
     uint32_t scan;
     uint32_t chunk;
 };
+// one piece of a page-locked input segment for gather_pinned_kernel: `len` bytes at host address `src` -> input buffer + dst_off
+struct GatherPiece {
+    uint64_t src;
+    uint64_t dst_off;
+    uint32_t len;
+    uint32_t pad;
+};
 struct ChunkSum {
     uint32_t rst_cnt;     // RSTn markers whose FF lies in the chunk
     uint32_t keep_cnt;    // bytes the chunk contributes to the unstuffed copy (markers count 2)

@@ -46,7 +46,7 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_sub_work_, &d_sub_final_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_prog_sync_, &d_planes_, &d_extend_desc_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_sub_work_, &d_sub_final_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_prog_sync_, &d_planes_, &d_extend_desc_, &d_gather_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
@@ -765,19 +765,37 @@ int DeviceBatch::stage_files(WorkCrew &crew, const std::vector<FileSegs> &files,
         return JPGPU_OK;
     }
     if (pinned) {
+        // segments scattered in page-locked memory: the device pulls them itself (gather_pinned_kernel, 32 KiB pieces) -- one
+        // launch instead of one hipMemcpyAsync per segment (JPGPU_PINNED_MEMCPY=1: the copy engine, per segment, as before)
         e = hipMemsetAsync(d_in, 0, (size_t)input_bytes_, up);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(input)");
+        const bool by_memcpy = getenv("JPGPU_PINNED_MEMCPY") != nullptr;
+        constexpr uint32_t kPiece = 32u << 10;
+        std::vector<GatherPiece> gp;
         for (size_t i = 0; i < plans.size(); i++) {
             const FileSegs &f = files[i];
             if (f.len > kMaxFile || f.len == 0) continue;
             uint64_t off = plans[i].img.file_offset;
             for (int k = 0; k < f.n; k++) {
                 if (!f.seg[k].len) continue;
-                e = hipMemcpyAsync(d_in + off, f.seg[k].data, f.seg[k].len, hipMemcpyHostToDevice, up);
-                if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(pinned segment)");
+                if (by_memcpy) {
+                    e = hipMemcpyAsync(d_in + off, f.seg[k].data, f.seg[k].len, hipMemcpyHostToDevice, up);
+                    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(pinned segment)");
+                } else {
+                    for (size_t at = 0; at < f.seg[k].len; at += kPiece)
+                        gp.push_back({(uint64_t)(uintptr_t)(f.seg[k].data + at), off + at, (uint32_t)std::min<size_t>(kPiece, f.seg[k].len - at), 0u});
+                }
                 off += f.seg[k].len;
                 ingest_.n_pinned_dma++;
             }
+        }
+        if (!gp.empty()) {
+            e = d_gather_.reserve(gp.size() * sizeof(GatherPiece));
+            if (e != hipSuccess) return hip_fail(e, "hipMalloc(gather list)");
+            e = hipMemcpyAsync(d_gather_.ptr, gp.data(), gp.size() * sizeof(GatherPiece), hipMemcpyHostToDevice, up);
+            if (e == hipSuccess) e = hipStreamSynchronize(up);  // `gp` is a local (pageable) vector
+            if (e == hipSuccess) e = launch_gather_pinned(up, (const GatherPiece *)d_gather_.ptr, (int)gp.size(), d_in);
+            if (e != hipSuccess) return hip_fail(e, "gather_pinned_kernel");
         }
         return JPGPU_OK;
     }

@@ -209,6 +209,7 @@ class DeviceBatch {
     uint64_t total_blocks_ = 0, out_bytes_ = 0, planes_bytes_ = 0, input_bytes_ = 0, compressed_bytes_ = 0, total_pixels_ = 0;
     DevBuffer d_planes_;  // EXTENDED_U16: K3's PLANAR_I16 output, converted by extend_u16_kernel
     DevBuffer d_extend_desc_;
+    DevBuffer d_gather_;  // JPGPU_UPLOAD_PINNED: the piece list of gather_pinned_kernel
     bool in_decode_request_ = false;  // the last entropy stage was issued by decode() (fetch_status's fallback re-issues the same thing)
     uint32_t total_ends_ = 0;
 

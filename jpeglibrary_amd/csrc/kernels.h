@@ -63,6 +63,8 @@ hipError_t launch_extend_u16(hipStream_t stream, const uint8_t *planes, uint8_t 
                              uint32_t max_pixels);
 
 // K0 (ingest verification): offset of the first non-RST marker in each segment {offset lo, length} (+ offset hi), 0xFFFFFFFF = none
+// JPGPU_UPLOAD_PINNED, segments scattered in page-locked host memory: the device reads them over the host link itself
+hipError_t launch_gather_pinned(hipStream_t stream, const GatherPiece *pieces, int n_pieces, uint8_t *dst);
 hipError_t launch_first_marker(hipStream_t stream, const uint8_t *data, const void *segs, const uint32_t *seg_hi, int n_segs,
                                uint32_t max_len, uint32_t *first);
 

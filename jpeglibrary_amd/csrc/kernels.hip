@@ -269,6 +269,24 @@ __global__ __launch_bounds__(kScanThreads) void marker_count_kernel(const uint8_
 // would stop at next (ref: JpegDecoder.cs:75-162, JpegReader.cs:120-158: FF00 and FFFF are skipped, RSTn is a no-op).  The
 // host keeps its plan only where that marker is EOI; every other file takes the full host walk.  One workgroup per 4 KiB,
 // grid (chunks of the longest segment, segments); segs[i] = {byte offset in `data`, length}.
+// Zero-copy ingest of segments that lie scattered in page-locked host memory (JPGPU_UPLOAD_PINNED without the arena layout):
+// the device pulls them over the host link itself -- one workgroup per 32 KiB piece, 16 bytes per lane and step -- instead of one
+// hipMemcpyAsync per segment (~33 us of host time each: 1 MiB files arrive at 30 GB/s from one thread and at 13 GB/s when
+// two or three contexts issue them side by side; profiles/r03a_multi_slots.jsonl).  Page-locked memory is mapped into the
+// device's address space under the host's own addresses (hipHostMalloc; hipHostRegister with the Mapped flag).
+__global__ __launch_bounds__(256) void gather_pinned_kernel(const GatherPiece *__restrict__ pieces, uint8_t *__restrict__ dst) {
+    const GatherPiece pc = pieces[blockIdx.x];
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(pc.src);
+    uint8_t *d = dst + pc.dst_off;
+    const uint32_t n16 = pc.len & ~15u;
+    for (uint32_t i = threadIdx.x * 16u; i < n16; i += 256u * 16u) {
+        uint4 v;
+        __builtin_memcpy(&v, src + i, 16);  // (the source may sit at any byte address: unaligned global loads are fine on gfx9+)
+        __builtin_memcpy(d + i, &v, 16);
+    }
+    if (threadIdx.x < (pc.len & 15u)) d[n16 + threadIdx.x] = src[n16 + threadIdx.x];
+}
+
 __global__ __launch_bounds__(kScanThreads) void first_marker_kernel(const uint8_t *__restrict__ data, const uint2 *__restrict__ segs,
                                                                      const uint32_t *__restrict__ seg_hi, uint32_t *__restrict__ first) {
     const uint32_t seg = blockIdx.y;
@@ -4093,6 +4111,12 @@ hipError_t launch_extend_u16(hipStream_t stream, const uint8_t *planes, uint8_t 
         const int n = n_images - base < 65535 ? n_images - base : 65535;
         hipLaunchKernelGGL(extend_u16_kernel, dim3(bx, (uint32_t)n), dim3(256), 0, stream, planes, out_base, images + base);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_pinned(hipStream_t stream, const GatherPiece *pieces, int n_pieces, uint8_t *dst) {
+    if (n_pieces <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_pinned_kernel, dim3((uint32_t)n_pieces), dim3(256), 0, stream, pieces, dst);
     return hipGetLastError();
 }
 

@@ -43,8 +43,10 @@ print(open(out + "/summary.txt").read())
 # roofline.traffic of bench.py: HBM bytes per image of the IDCT kernel, tied to the binary that was profiled
 sha = hashlib.sha256(open(os.path.join(root, "jpeglibrary_amd", "libjpgpu.so"), "rb").read()).hexdigest()
 images = int(opt("--images", "0") or 0)
+kfmt = {"interleaved_u8": 0, "planar_u8": 1, "rgb_u8": 3, "rgba_u8": 4}[opt("--format", "interleaved_u8")]
 for k, d in agg.items():
-    if "idct_output_kernel" in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d and images:
+    # the variant of the format that was asked for (bench.py's short planar pass runs idct_output_kernel<1, 0> besides)
+    if f"idct_output_kernel<{kfmt}," in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d and images:
         fetch_kb = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
         write_kb = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
         entry = {"kernel": k.split("jpgpu::")[-1], "hbm_bytes_per_image": int((2 * fetch_kb + write_kb) * 1024 / images),

@@ -5,20 +5,26 @@
 #   gpurun -- 'bash tools/trace/final_evidence.sh headline'   the headline's kernel statistics and bench line back to back on a
 #                                                             RESTED box (K3 drifts from 9.25 to 9.8-10 ms on a box that has
 #                                                             been under load for minutes), after idct_traffic.json is in place
-# Outputs under gpurun_out/ (pmc_r02d/, all_r02d/, r02i/); copy into profiles/ as r02d_*.
+# Outputs under gpurun_out/ (pmc_$TAG/, all_$TAG/, ${TAG}_headline/); copy into profiles/ as ${TAG}_* (TAG from the environment).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${TAG:-r03a}
 cd $R
 if [ "${1:-}" = "headline" ]; then
-  mkdir -p gpurun_out/r02i
-  ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ingest > /tmp/ks.log 2>&1; cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r02i/kernel_stats_1024img.csv )
-  python3 bench.py --steps 20 --warmup 5 > gpurun_out/r02i/bench.json 2>/dev/null
-  cut -c1-200 gpurun_out/r02i/bench.json
+  mkdir -p gpurun_out/${TAG}_headline
+  ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ingest > /tmp/ks.log 2>&1; cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_headline/kernel_stats_1024img.csv )
+  python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_headline/bench.json 2>/dev/null
+  cut -c1-200 gpurun_out/${TAG}_headline/bench.json
   exit 0
 fi
-bash tools/profile_pmc.sh r02d --images 128 --steps 2 --warmup 1 --no-cpu-baseline --no-ingest > gpurun_out/pmc_r02d.log 2>&1
-cp gpurun_out/pmc_r02d/idct_traffic_entry.json profiles/idct_traffic.json
-bash tools/trace/evidence_all.sh r02d 2>&1 | tail -1
-python3 tools/bench_encode.py --images 256 > gpurun_out/all_r02d/bench_encode_256.json 2>/dev/null
-python3 tools/bench_encode.py --images 256 --dri 4 > gpurun_out/all_r02d/bench_encode_256_dri4.json 2>/dev/null
+bash tools/profile_pmc.sh $TAG --images 128 --steps 2 --warmup 1 --no-cpu-baseline --no-ingest --no-planar-pass > gpurun_out/pmc_$TAG.log 2>&1
+cp gpurun_out/pmc_$TAG/idct_traffic_entry.json profiles/idct_traffic.json
+bash tools/trace/evidence_all.sh $TAG 2>&1 | tail -1
+python3 tools/bench_encode.py --images 256 > gpurun_out/all_$TAG/bench_encode_256.json 2>/dev/null
+python3 tools/bench_encode.py --images 256 --dri 4 > gpurun_out/all_$TAG/bench_encode_256_dri4.json 2>/dev/null
+python3 tools/bench_optimize.py --images 256 > gpurun_out/all_$TAG/bench_optimize_256.json 2>/dev/null
+bash tools/trace/progressive_by_scan.sh 256 $R/gpurun_out/all_$TAG/progressive_by_scan_256.txt > /dev/null 2>&1
+bash tools/trace/progressive_by_scan.sh 2048 $R/gpurun_out/all_$TAG/progressive_by_scan_2048.txt > /dev/null 2>&1
+python3 tools/trace/multi_slots.py 256 3 $R/gpurun_out/all_$TAG/multi_slots.jsonl > gpurun_out/all_$TAG/multi_slots.txt 2>&1
+( cd tools/microbench && ./issue_latency > $R/gpurun_out/all_$TAG/issue_latency.txt 2>&1 )
 sha256sum jpeglibrary_amd/libjpgpu.so
