@@ -1568,6 +1568,7 @@ struct WBits {
     uint32_t ent2;         // per lane, refinement scans only: `ent` pre-digested for the scalar symbol loop (r2_digest)
 #ifdef JPGPU_PS_PROFILE
     unsigned long long t_pro = 0, t_loop = 0, t_epi = 0, t_refresh = 0, n_exits = 0;  // cycles inside w_ac_refine_parse
+    uint32_t n_trips = 0;  // trips of the symbol loop (JPGPU_PS_PROFILE > 1)
 #endif
 };
 
@@ -2256,12 +2257,19 @@ __device__ __forceinline__ uint32_t w_ac_refine_parse(WBits &d, uint32_t lane, c
 //   * the new coefficient (sign bit pre-digested into the window entry) goes into lane `stop` of the block's register, the
 //     lanes from the symbol's first position on note the code bits consumed so far (their correction bit comes after them);
 //   * afterwards every lane that was non-zero fetches ITS correction bit: block start + noted code bits + its rank.
-constexpr uint32_t kR4Special = 0x80000000u;
-__device__ __forceinline__ uint32_t r4_digest(uint32_t e /* (code size << 8) | symbol; code size 0 = not in the lookup */, uint32_t peek) {
+constexpr uint32_t kR4Special = 0x80000000u, kR4Eob = 0x40000000u, kR4Zrl = 0x2000u;
+// window entry as the loop wants it: code bits (+ 1 sign bit) in bits 0-5, run + 1 in bits 6-12 (64 + for a symbol the loop
+// cannot apply: its target then lies behind every zero), ZRL in bit 13, the new coefficient itself in bits 14-29; bit 31: not
+// for the loop, bit 30: ... because it is EOBn, n = run
+__device__ __forceinline__ uint32_t r4_digest(uint32_t e /* (code size << 8) | symbol; code size 0 = not in the lookup */, uint32_t peek,
+                                              int32_t p1, int32_t m1) {
     const uint32_t size = e >> 8, rr = (e >> 4) & 15u, nonzero = (e & 15u) != 0 ? 1u : 0u;
-    const uint32_t special = (size == 0 || (nonzero == 0 && rr != 15u)) ? kR4Special : 0u;
+    const bool special = size == 0 || (nonzero == 0 && rr != 15u);
     const uint32_t sign = (peek << (size & 31u)) >> 31;  // the bit behind the code
-    return special | (sign << 11) | ((nonzero ^ 1u) << 10) | (rr << 6) | (size + nonzero);
+    const uint32_t value = (uint32_t)(sign != 0 ? p1 : m1) & 0xFFFFu;
+    // (an end-of-band symbol found in the lookup says so: what ends almost every block is then applied without a second lookup)
+    return (special ? kR4Special | (size != 0 ? kR4Eob : 0u) | (64u << 6) : (value << 14)) | (nonzero != 0 ? 0u : kR4Zrl) | ((rr + 1u) << 6) |
+           (size + nonzero);
 }
 
 __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, int32_t p1,
@@ -2280,7 +2288,7 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
     const uint32_t nnz = (uint32_t)__builtin_popcountll(nzb);
     uint32_t bits = 0;     // per lane: code / sign / run bits of the block consumed before this lane's correction bit
     uint32_t symbits = 0;  // ... by the symbols so far
-    uint32_t cv = (uint32_t)c, minev = 0;
+    uint32_t cv = (uint32_t)c;
     uint32_t winpos = blockpos - uni(d.cur);  // stream position of the window's first bit
     if (eobrun == 0) {
         const uint32_t nzeros = (uint32_t)__builtin_popcountll(zeros);
@@ -2291,96 +2299,96 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
         ntab = lane < nzeros ? ntab : 0x10000u;  // no such zero: the run outlasts the band
         uint32_t cur = uni(d.cur);
         uint32_t base = cur - ss;   // a symbol's offset in the window = base + code bits before it + ntab[zeros consumed before it]
-        uint32_t zc = 0;            // zeros of the band consumed so far
+        uint32_t zq = 0xFFFFFFFFu;  // zeros of the band consumed so far, minus one
         uint32_t kprev = ss - 1u;   // position in front of the next symbol's first one
-        const uint32_t dpm = (uint32_t)(p1 - m1), m1v = (uint32_t)m1;
 #ifdef JPGPU_PS_PROFILE
         d.t_pro += PS_TICK() - t_a;
 #endif
         for (;;) {
-            uint32_t stop, scur, se_, st, sn, ve, rr, t, tm, adv, symn, u, curn, pl, sg;
-            uint64_t sp;
+            uint32_t stop = 0xFFFFu;
 #ifdef JPGPU_R4_CXX
             // the loop below, spelled in C++ (debugging aid: same operations, the compiler's schedule)
+            uint32_t se_ = 0;
             for (;;) {
-                ve = lane_get(d.ent2, cur);
-                rr = (ve >> 6) & 15u;
-                t = zc + rr;
-                tm = t < 63u ? t : 63u;
-                adv = ve & 63u;
-                symn = symbits + adv;
-                sn = lane_get(ntab, tm);
-                stop = sn + t;
-                curn = base + symn + sn;
-                u = (ve & 0x80000000u) | cur | sn;
-                const bool ok = u < 64u;
+                const uint32_t ve = se_ = lane_get(d.ent2, cur);
+                const uint32_t t = zq + ((ve >> 6) & 127u);
+                const uint32_t symn = symbits + (ve & 63u);
+                const uint32_t sn = lane_get(ntab, t < 63u ? t : 63u);
+                const bool ok = (t | cur | sn) < 64u;
                 if (ok) symbits = symn;
                 if (lane > kprev) bits = symbits;
-                if (ok) kprev = stop;
-                if (!ok) stop = 0xFFFFu;
-                if (ok) cur = curn;
-                if (ok) zc = t + 1u;
-                pl = (ve & 0x400u) | stop;
-                sg = ((ve >> 11) & 1u) * dpm + m1v;
-                if (lane == pl) {
-                    cv = sg;
-                    minev = 1;
+                stop = ok ? sn + t : 0xFFFFu;
+                if (ok) {
+                    kprev = stop;
+                    cur = base + symn + sn;
+                    zq = t;
                 }
+                if (lane == ((ve & kR4Zrl) | stop)) cv = (ve >> 14) & 0xFFFFu;
                 if (!(se > stop)) break;
             }
-            (void)scur; (void)se_; (void)st; (void)sp; (void)curn; (void)pl; (void)sg; (void)u;
 #else
+            uint32_t scur, st, sn, se_ = 0, rr, t = 0, tm, adv, symn = 0, u, curn, pl, sg = 0, stopr = 0;
+            uint64_t sok = 0, spb = 0, spp;
             asm volatile(
-                // gfx940-family hazards the assembler does not fix in inline asm (LLVM's GCNHazardRecognizer does, for compiled code):
-                // a VALU instruction may read an SGPR / VCC another VALU instruction wrote only 2 wait states later, a lane select 4,
-                // v_readlane / v_readfirstlane a VGPR written by the VALU 1 later.  The gaps are filled with independent work
-                // where there is any.
+                // One symbol per trip, 27 instructions and three fillers.  gfx940-family hazards the assembler does not fix in
+                // inline asm (LLVM's GCNHazardRecognizer does, for compiled code): a VALU instruction may read an SGPR / VCC
+                // another VALU instruction wrote only 2 wait states later, a lane select 4, v_readlane / v_readfirstlane a VGPR
+                // written by the VALU 1 later.  The gaps are filled with the PREVIOUS symbol's commits, none of which the
+                // chain cur -> entry -> zero rank -> ntab -> cur needs: they run at the top of the next trip (all of them no-ops in
+                // the first: sok = spb = 0, pl = none) and once more behind the loop.
+                "v_mov_b32_e32 %[stop], %[none]\n\t"  // (not a tied input: the compiler would share ONE register holding 0xFFFF)
                 "1:\n\t"
+#if defined(JPGPU_PS_PROFILE) && JPGPU_PS_PROFILE > 1
+                "v_add_u32_e32 %[trips], 1, %[trips]\n\t"
+#endif
                 "v_readfirstlane_b32 %[scur], %[cur]\n\t"
-                "s_nop 3\n\t"
+                "v_and_or_b32 %[pl], %[se_], %[zrl], %[stop]\n\t"                // previous symbol: where its coefficient goes (nowhere for ZRL)
+                "v_cndmask_b32_e64 %[symbits], %[symbits], %[symn], %[sok]\n\t"  // ... its code bits
+                "v_cmp_eq_u32_e64 %[spp], %[lane], %[pl]\n\t"
+                "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t"     // ... noted by the lanes from its first position on
                 "v_readlane_b32 %[se_], %[ent2], %[scur]\n\t"
-                "s_nop 1\n\t"
-                "v_mov_b32_e32 %[ve], %[se_]\n\t"
-                "v_bfe_u32 %[rr], %[ve], 6, 4\n\t"
-                "v_add_u32_e32 %[t], %[zc], %[rr]\n\t"
+                "v_cndmask_b32_e64 %[kprev], %[kprev], %[stopr], %[sok]\n\t"
+                "v_cndmask_b32_e64 %[zq], %[zq], %[t], %[sok]\n\t"
+                "v_bfe_u32 %[rr], %[se_], 6, 7\n\t"
+                "v_cndmask_b32_e64 %[cv], %[cv], %[sg], %[spp]\n\t"
+                "v_add_u32_e32 %[t], %[zq], %[rr]\n\t"
                 "v_min_u32_e32 %[tm], 63, %[t]\n\t"
-                "v_and_b32_e32 %[adv], 63, %[ve]\n\t"
+                "v_and_b32_e64 %[adv], 63, %[se_]\n\t"
                 "v_readfirstlane_b32 %[st], %[tm]\n\t"
                 "v_add_u32_e32 %[symn], %[symbits], %[adv]\n\t"
-                "v_and_b32_e32 %[u], 0x80000000, %[ve]\n\t"
-                "v_add_u32_e32 %[rr], 1, %[t]\n\t"
-                "v_and_b32_e32 %[pl], 0x400, %[ve]\n\t"
+                "v_bfe_u32 %[sg], %[se_], 14, 16\n\t"
+                "v_cmp_gt_u32_e64 %[spb], %[lane], %[kprev]\n\t"
+                "s_nop 0\n\t"
                 "v_readlane_b32 %[sn], %[ntab], %[st]\n\t"
-                "v_bfe_u32 %[sg], %[ve], 11, 1\n\t"
-                "v_mad_u32_u24 %[sg], %[sg], %[dpm], %[m1v]\n\t"
-                "v_add_u32_e32 %[stop], %[sn], %[t]\n\t"
+                "s_nop 1\n\t"
                 "v_add3_u32 %[curn], %[base], %[symn], %[sn]\n\t"
-                "v_or3_b32 %[u], %[u], %[cur], %[sn]\n\t"
-                "v_cmp_gt_u32_e32 vcc, 64, %[u]\n\t"
-                "v_cmp_gt_u32_e64 %[sp], %[lane], %[kprev]\n\t"
+                "v_or3_b32 %[u], %[t], %[cur], %[sn]\n\t"
+                "v_cmp_gt_u32_e64 %[sok], 64, %[u]\n\t"
+                "v_add_u32_e32 %[stopr], %[sn], %[t]\n\t"
                 "s_nop 0\n\t"
-                "v_cndmask_b32_e32 %[symbits], %[symbits], %[symn], vcc\n\t"
-                "v_cndmask_b32_e32 %[kprev], %[kprev], %[stop], vcc\n\t"
-                "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[sp]\n\t"
-                "v_cndmask_b32_e32 %[stop], %[none], %[stop], vcc\n\t"
-                "v_cndmask_b32_e32 %[cur], %[cur], %[curn], vcc\n\t"
-                "v_cndmask_b32_e32 %[zc], %[zc], %[rr], vcc\n\t"
-                "v_or_b32_e32 %[pl], %[pl], %[stop]\n\t"
-                "v_cmp_eq_u32_e64 %[sp], %[lane], %[pl]\n\t"
+                "v_cndmask_b32_e64 %[cur], %[cur], %[curn], %[sok]\n\t"
+                "v_cndmask_b32_e64 %[stop], %[none], %[stopr], %[sok]\n\t"
                 "v_cmp_gt_u32_e32 vcc, %[se], %[stop]\n\t"
-                "s_nop 0\n\t"
-                "v_cndmask_b32_e64 %[cv], %[cv], %[sg], %[sp]\n\t"
-                "v_cndmask_b32_e64 %[minev], %[minev], 1, %[sp]\n\t"
                 "s_cbranch_vccnz 1b\n\t"
-                : [cur] "+v"(cur), [zc] "+v"(zc), [symbits] "+v"(symbits), [kprev] "+v"(kprev), [bits] "+v"(bits), [cv] "+v"(cv),
-                  [minev] "+v"(minev), [stop] "=&v"(stop), [scur] "=&s"(scur), [se_] "=&s"(se_), [st] "=&s"(st), [sn] "=&s"(sn),
-                  [sp] "=&s"(sp), [ve] "=&v"(ve), [rr] "=&v"(rr), [t] "=&v"(t), [tm] "=&v"(tm), [adv] "=&v"(adv), [symn] "=&v"(symn),
-                  [u] "=&v"(u), [curn] "=&v"(curn), [pl] "=&v"(pl), [sg] "=&v"(sg)
-                : [ent2] "v"(d.ent2), [ntab] "v"(ntab), [lane] "v"(lane), [base] "v"(base), [dpm] "v"(dpm), [m1v] "v"(m1v), [none] "v"(0xFFFFu), [se] "s"(se)
+                "v_and_or_b32 %[pl], %[se_], %[zrl], %[stop]\n\t"
+                "v_cndmask_b32_e64 %[symbits], %[symbits], %[symn], %[sok]\n\t"
+                "v_cmp_eq_u32_e64 %[spp], %[lane], %[pl]\n\t"
+                "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t"
+                "v_cndmask_b32_e64 %[kprev], %[kprev], %[stopr], %[sok]\n\t"
+                "v_cndmask_b32_e64 %[zq], %[zq], %[t], %[sok]\n\t"
+                "v_cndmask_b32_e64 %[cv], %[cv], %[sg], %[spp]\n\t"
+                : [cur] "+v"(cur), [zq] "+v"(zq), [symbits] "+v"(symbits), [kprev] "+v"(kprev), [bits] "+v"(bits), [cv] "+v"(cv),
+                  [stop] "=&v"(stop), [se_] "+s"(se_), [sok] "+s"(sok), [spb] "+s"(spb), [t] "+v"(t), [symn] "+v"(symn), [sg] "+v"(sg),
+                  [stopr] "+v"(stopr), [scur] "=&s"(scur), [st] "=&s"(st), [sn] "=&s"(sn), [spp] "=&s"(spp), [rr] "=&v"(rr), [tm] "=&v"(tm),
+                  [adv] "=&v"(adv), [u] "=&v"(u), [curn] "=&v"(curn), [pl] "=&v"(pl)
+#if defined(JPGPU_PS_PROFILE) && JPGPU_PS_PROFILE > 1
+                  , [trips] "+v"(d.n_trips)
+#endif
+                : [ent2] "v"(d.ent2), [ntab] "v"(ntab), [lane] "v"(lane), [base] "v"(base), [none] "v"(0xFFFFu), [zrl] "v"(kR4Zrl), [se] "s"(se)
                 : "vcc", "memory");
 #endif
             cur = uni(cur);
-            zc = uni(zc);
+            zq = uni(zq);
             symbits = uni(symbits);
             kprev = uni(kprev);
             stop = uni(stop);
@@ -2394,7 +2402,7 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
 #endif
                 d.pos = winpos + cur;
                 w_refresh<true>(d, lane, hac);
-                d.ent2 = r4_digest(d.ent, d.peek);
+                d.ent2 = r4_digest(d.ent, d.peek, p1, m1);
                 winpos = uni(d.pos);
                 base -= cur;
                 cur = 0;
@@ -2403,7 +2411,14 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
 #endif
                 continue;
             }
-            // one symbol by hand: a code longer than the lookup, an end-of-band symbol, or a run that outlasts the band
+            if ((se_ & kR4Eob) != 0) {  // EOBn (:337-350), the loop's last entry: the run's low bits follow the code
+                const uint32_t size = se_ & 63u, r2 = ((se_ >> 6) & 31u) - 1u;
+                eobrun = (1u << r2) + (uint32_t)(((uint64_t)(lane_get(d.peek, cur) << size) << r2) >> 32);
+                symbits += size + r2;
+                if (lane > kprev) bits = symbits;  // the tail's lanes come behind all of it
+                break;
+            }
+            // one symbol by hand: a code longer than the lookup (EOBn among them), or a run that outlasts the band
             PS_COUNT(6);
             const uint32_t pk = lane_get(d.peek, cur);
             uint32_t raw = lane_get(d.ent, cur);
@@ -2411,7 +2426,7 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
                 raw = w_huff_scalar(hac, pk >> 16);
                 if (raw >= kPsBadCode) return kDetailInvalidHuffmanCode;
             }
-            const uint32_t e2 = r4_digest(raw, pk);
+            const uint32_t e2 = r4_digest(raw, pk, p1, m1);
             const uint32_t size = raw >> 8, r2 = (raw >> 4) & 15u;
             if (e2 >= kR4Special) {  // EOBn (:337-350): the run's low bits follow the code; the tail's lanes come behind all of it
                 eobrun = (1u << r2) + (uint32_t)(((uint64_t)(pk << size) << r2) >> 32);
@@ -2419,18 +2434,15 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
                 if (lane > kprev) bits = symbits;
                 break;
             }
-            const uint32_t adv2 = e2 & 63u, tgt2 = zc + r2;
+            const uint32_t adv2 = e2 & 63u, tgt2 = zq + 1u + r2;
             const uint32_t n2 = lane_get(ntab, tgt2 < 63u ? tgt2 : 63u);
             symbits += adv2;
             if (lane > kprev) bits = symbits;
             const uint32_t stop2 = n2 >= 0x10000u ? se + 1u : tgt2 + n2;  // no such zero: the new coefficient lands behind Se (:363-367)
-            if ((e2 & 0x400u) == 0 && lane == stop2) {
-                cv = (uint32_t)((e2 & 0x800u) != 0 ? p1 : m1);
-                minev = 1;
-            }
+            if ((e2 & kR4Zrl) == 0 && lane == stop2) cv = (e2 >> 14) & 0xFFFFu;
             if (n2 >= 0x10000u || stop2 >= se) break;  // every non-zero coefficient left has been passed
             cur = base + symbits + n2;
-            zc = tgt2 + 1u;
+            zq = tgt2;
             kprev = stop2;
         }
     }
@@ -2440,19 +2452,18 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
     symbits = uni(symbits);
     if (eobrun > 0) eobrun--;
     // every coefficient that was non-zero takes exactly one correction bit: behind the code bits noted for its lane, in rank order
+    int32_t cn = (int32_t)(int16_t)cv;
     if (nzb != 0) {
         const uint32_t bp = blockpos + bits + nrank;
         const uint32_t w = d.ring[(bp >> 5) & d.wmask];
-        if (((nzb >> lane) & 1ull) != 0 && ((w >> (31u - (bp & 31u))) & 1u) != 0 && (cv & (uint32_t)p1) == 0) {
-            cv += (int32_t)cv >= 0 ? (uint32_t)p1 : (uint32_t)m1;  // (the tail's test is c > 0: the same thing for a coefficient that is not zero)
-            minev = 1;
-        }
+        if (((nzb >> lane) & 1ull) != 0 && ((w >> (31u - (bp & 31u))) & 1u) != 0 && (cn & p1) == 0)
+            cn += cn >= 0 ? p1 : m1;  // (the tail's test is c > 0: the same thing for a coefficient that is not zero)
     }
     const uint32_t consumed = symbits + nnz;
     d.pos = blockpos + consumed;
     d.cur = d.pos - winpos;
-    c = (int32_t)(int16_t)cv;
-    mine = minev != 0;
+    mine = cn != c;  // a new coefficient is never 0, a correction never leaves the value alone
+    c = cn;
 #ifdef JPGPU_PS_PROFILE
     d.t_loop += t_c - t_a - t_r;  // (includes the prologue, reported separately in t_pro)
     d.t_refresh += t_r;
@@ -2970,10 +2981,17 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                 __syncthreads();
                 const unsigned long long ps_c = PS_TICK();
                 ps_stage += ps_c - ps_b;
+                int32_t c_next = stage[lane];
+                uint32_t ix_next = idx[0];
                 for (uint32_t b = 0; b < n && err == 0; b++) {
                     JPGPU_ENSURE_STAGED()
-                    int32_t c = stage[b * 64u + lane];
-                    const uint32_t ix = uni(idx[b]);
+                    int32_t c = c_next;
+                    const uint32_t ix = uni(ix_next);
+                    {  // the next block's coefficients are on their way while this one is parsed
+                        const uint32_t bn = b + 1u < n ? b + 1u : b;
+                        c_next = stage[bn * 64u + lane];
+                        ix_next = idx[bn];
+                    }
                     const uint64_t nz = __ballot(c != 0);
                     bool mine = false;  // this lane's coefficient changed
                     if (d.rem >= kPsFastBits) {
@@ -3030,6 +3048,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                 PS_ADD(10, d.t_epi);
                 PS_ADD(11, d.t_refresh);
                 PS_ADD(12, d.n_exits);
+                PS_ADD(13, d.n_trips);
 #endif
             }
         }

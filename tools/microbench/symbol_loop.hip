@@ -1,0 +1,184 @@
+// tools/microbench/symbol_loop.hip -- cycles per trip of the AC-refinement symbol loop of progressive_stream_kernel
+// (w_ac_refine_v4 in jpeglibrary_amd/csrc/kernels.hip), alone on one wave with synthetic window entries: every entry a plain
+// symbol with run 0, so a loop entry makes 63 - zq0 trips before the zero rank runs off the table.  Timed with s_memtime at two
+// trip counts; printed: the difference per trip.  Variants:
+//   full     the loop as shipped (rotated commits fill the hazard gaps)
+//   chain    only what the next trip needs (cur -> entry -> zero rank -> ntab -> cur) and the exit test: the floor
+//   nofill   the chain with the four hazard gaps as s_nop
+//   hipcc --offload-arch=gfx950 -O3 -o symbol_loop symbol_loop.hip && ./symbol_loop
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+__device__ __forceinline__ uint64_t tick() {
+    uint64_t t;
+    asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+template <int kVariant>
+__device__ __forceinline__ uint32_t run(uint32_t lane, uint32_t ent2, uint32_t ntab, uint32_t zq0, uint32_t se, uint32_t &trips) {
+    // (every value goes through an empty asm: hipcc lets a tied "+v" operand and an input operand that hold the same known value
+    // share ONE register, which the loop then overwrites under the input's feet)
+    auto hide = [](uint32_t x) {
+        asm volatile("" : "+v"(x));
+        return x;
+    };
+    uint32_t cur = hide(0), zq = zq0, symbits = hide(0), kprev = hide(0), bits = hide(0), cv = hide(0), stop;
+    uint32_t scur, st, sn, se_ = 0, rr, t = hide(0), tm, adv, symn = hide(0), u, curn, pl, sg = hide(0), stopr = hide(0);
+    uint64_t sok = 0, spb = 0, spp;
+    const uint32_t base = hide(0);
+    trips = hide(trips);
+    if (kVariant == 0) {
+        asm volatile(
+            "v_mov_b32_e32 %[stop], %[none]\n\t"
+            "1:\n\t"
+            "v_add_u32_e32 %[trips], 1, %[trips]\n\t"
+            "v_readfirstlane_b32 %[scur], %[cur]\n\t"
+            "v_and_or_b32 %[pl], %[se_], %[zrl], %[stop]\n\t"
+            "v_cndmask_b32_e64 %[symbits], %[symbits], %[symn], %[sok]\n\t"
+            "v_cmp_eq_u32_e64 %[spp], %[lane], %[pl]\n\t"
+            "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t"
+            "v_readlane_b32 %[se_], %[ent2], %[scur]\n\t"
+            "v_cndmask_b32_e64 %[kprev], %[kprev], %[stopr], %[sok]\n\t"
+            "v_cndmask_b32_e64 %[zq], %[zq], %[t], %[sok]\n\t"
+            "v_bfe_u32 %[rr], %[se_], 6, 7\n\t"
+            "v_cndmask_b32_e64 %[cv], %[cv], %[sg], %[spp]\n\t"
+            "v_add_u32_e32 %[t], %[zq], %[rr]\n\t"
+            "v_min_u32_e32 %[tm], 63, %[t]\n\t"
+            "v_and_b32_e64 %[adv], 63, %[se_]\n\t"
+            "v_readfirstlane_b32 %[st], %[tm]\n\t"
+            "v_add_u32_e32 %[symn], %[symbits], %[adv]\n\t"
+            "v_bfe_u32 %[sg], %[se_], 14, 16\n\t"
+            "v_cmp_gt_u32_e64 %[spb], %[lane], %[kprev]\n\t"
+            "s_nop 0\n\t"
+            "v_readlane_b32 %[sn], %[ntab], %[st]\n\t"
+            "s_nop 1\n\t"
+            "v_add3_u32 %[curn], %[base], %[symn], %[sn]\n\t"
+            "v_or3_b32 %[u], %[t], %[cur], %[sn]\n\t"
+            "v_cmp_gt_u32_e64 %[sok], 64, %[u]\n\t"
+            "v_add_u32_e32 %[stopr], %[sn], %[t]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32_e64 %[cur], %[cur], %[curn], %[sok]\n\t"
+            "v_cndmask_b32_e64 %[stop], %[none], %[stopr], %[sok]\n\t"
+            "v_cmp_gt_u32_e32 vcc, %[se], %[stop]\n\t"
+            "s_cbranch_vccnz 1b\n\t"
+            : [cur] "+v"(cur), [zq] "+v"(zq), [symbits] "+v"(symbits), [kprev] "+v"(kprev), [bits] "+v"(bits), [cv] "+v"(cv),
+              [stop] "=&v"(stop), [se_] "+s"(se_), [sok] "+s"(sok), [spb] "+s"(spb), [t] "+v"(t), [symn] "+v"(symn), [sg] "+v"(sg),
+              [stopr] "+v"(stopr), [scur] "=&s"(scur), [st] "=&s"(st), [sn] "=&s"(sn), [spp] "=&s"(spp), [rr] "=&v"(rr), [tm] "=&v"(tm),
+              [adv] "=&v"(adv), [u] "=&v"(u), [curn] "=&v"(curn), [pl] "=&v"(pl)
+            , [trips] "+v"(trips)
+            : [ent2] "v"(ent2), [ntab] "v"(ntab), [lane] "v"(lane), [base] "v"(base), [none] "v"(0xFFFFu), [zrl] "v"(0x2000u), [se] "s"(se)
+            : "vcc", "memory");
+    } else if (kVariant == 1) {
+        // the chain and nothing else; gaps left to the hardware's own interlocks where there are none required by the ISA
+        // manual they are kept as s_nop (lane select 4, SGPR read 2)
+        asm volatile(
+            "v_mov_b32_e32 %[stop], %[none]\n\t"
+            "1:\n\t"
+            "v_add_u32_e32 %[trips], 1, %[trips]\n\t"
+            "v_readfirstlane_b32 %[scur], %[cur]\n\t"
+            "s_nop 3\n\t"
+            "v_readlane_b32 %[se_], %[ent2], %[scur]\n\t"
+            "s_nop 1\n\t"
+            "v_bfe_u32 %[rr], %[se_], 6, 7\n\t"
+            "v_add_u32_e32 %[t], %[zq], %[rr]\n\t"
+            "v_min_u32_e32 %[tm], 63, %[t]\n\t"
+            "s_nop 0\n\t"
+            "v_readfirstlane_b32 %[st], %[tm]\n\t"
+            "s_nop 3\n\t"
+            "v_readlane_b32 %[sn], %[ntab], %[st]\n\t"
+            "s_nop 1\n\t"
+            "v_add3_u32 %[curn], %[base], %[symbits], %[sn]\n\t"
+            "v_or3_b32 %[u], %[t], %[cur], %[sn]\n\t"
+            "v_cmp_gt_u32_e64 %[sok], 64, %[u]\n\t"
+            "v_add_u32_e32 %[stopr], %[sn], %[t]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32_e64 %[cur], %[cur], %[curn], %[sok]\n\t"
+            "v_cndmask_b32_e64 %[zq], %[zq], %[t], %[sok]\n\t"
+            "v_cndmask_b32_e64 %[stop], %[none], %[stopr], %[sok]\n\t"
+            "v_cmp_gt_u32_e32 vcc, %[se], %[stop]\n\t"
+            "s_cbranch_vccnz 1b\n\t"
+            : [cur] "+v"(cur), [zq] "+v"(zq), [symbits] "+v"(symbits), [stop] "=&v"(stop), [se_] "+s"(se_), [sok] "+s"(sok), [t] "+v"(t),
+              [stopr] "+v"(stopr), [scur] "=&s"(scur), [st] "=&s"(st), [sn] "=&s"(sn), [rr] "=&v"(rr), [tm] "=&v"(tm), [u] "=&v"(u),
+              [curn] "=&v"(curn)
+            , [trips] "+v"(trips)
+            : [ent2] "v"(ent2), [ntab] "v"(ntab), [base] "v"(base), [none] "v"(0xFFFFu), [se] "s"(se)
+            : "vcc", "memory");
+    } else {
+        // the same chain through LDS instead of v_readlane: entry and zero table read with ds_bpermute (address in a VGPR,
+        // no SGPR round trip)
+        uint32_t a, b;
+        asm volatile(
+            "v_mov_b32_e32 %[stop], %[none]\n\t"
+            "1:\n\t"
+            "v_add_u32_e32 %[trips], 1, %[trips]\n\t"
+            "v_lshlrev_b32_e32 %[a], 2, %[cur]\n\t"
+            "ds_bpermute_b32 %[rr], %[a], %[ent2]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_bfe_u32 %[rr], %[rr], 6, 7\n\t"
+            "v_add_u32_e32 %[t], %[zq], %[rr]\n\t"
+            "v_min_u32_e32 %[tm], 63, %[t]\n\t"
+            "v_lshlrev_b32_e32 %[b], 2, %[tm]\n\t"
+            "ds_bpermute_b32 %[u], %[b], %[ntab]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_add3_u32 %[curn], %[base], %[symbits], %[u]\n\t"
+            "v_add_u32_e32 %[stopr], %[u], %[t]\n\t"
+            "v_or3_b32 %[u], %[t], %[cur], %[u]\n\t"
+            "v_cmp_gt_u32_e64 %[sok], 64, %[u]\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32_e64 %[cur], %[cur], %[curn], %[sok]\n\t"
+            "v_cndmask_b32_e64 %[zq], %[zq], %[t], %[sok]\n\t"
+            "v_cndmask_b32_e64 %[stop], %[none], %[stopr], %[sok]\n\t"
+            "v_cmp_gt_u32_e32 vcc, %[se], %[stop]\n\t"
+            "s_cbranch_vccnz 1b\n\t"
+            : [cur] "+v"(cur), [zq] "+v"(zq), [symbits] "+v"(symbits), [stop] "=&v"(stop), [sok] "+s"(sok), [t] "+v"(t), [stopr] "+v"(stopr),
+              [rr] "=&v"(rr), [tm] "=&v"(tm), [u] "=&v"(u), [curn] "=&v"(curn), [a] "=&v"(a), [b] "=&v"(b)
+            , [trips] "+v"(trips)
+            : [ent2] "v"(ent2), [ntab] "v"(ntab), [base] "v"(base), [none] "v"(0xFFFFu), [se] "s"(se)
+            : "vcc", "memory");
+    }
+    return cur + zq + symbits + bits + cv + stop + kprev;
+}
+
+template <int kVariant>
+__global__ void k(uint64_t *out, uint32_t seed) {
+    const uint32_t lane = threadIdx.x;
+    // every window entry: 0 code bits (so the window offset stays put), run 0, not ZRL; the zero table: rank r -> 0 (offset stays 0)
+    const uint32_t ent2 = (1u << 6) | (seed & 0u), ntab = 0;
+    uint32_t sink = 0;
+    uint64_t dt[2];
+    uint32_t trips[2] = {0, 0};
+    for (int warm = 0; warm < 2; warm++)
+        for (int which = 0; which < 2; which++) {
+            const uint32_t zq0 = which == 0 ? 31u : 0xFFFFFFFFu;  // 32 trips or 64
+            const uint64_t t0 = tick();
+            for (int rep = 0; rep < 64; rep++) sink += run<kVariant>(lane, ent2, ntab, zq0 + (sink & 0u), 200u, trips[which]);
+            dt[which] = tick() - t0;
+        }
+    if (lane == 0) {
+        out[0] = dt[0];
+        out[1] = dt[1];
+        out[2] = sink;
+        out[3] = trips[0];
+        out[4] = trips[1];
+    }
+}
+
+int main() {
+    uint64_t *d, h[5];
+    hipMalloc(&d, sizeof h);
+    const char *names[3] = {"full loop (as shipped)", "chain only, gaps as s_nop", "chain through ds_bpermute"};
+    for (int v = 0; v < 3; v++) {
+        if (v == 0) k<0><<<1, 64>>>(d, 5);
+        if (v == 1) k<1><<<1, 64>>>(d, 5);
+        if (v == 2) k<2><<<1, 64>>>(d, 5);
+        hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+        // 64 entries of (fixed cost + n trips); the trip counts differ by 32 (+ the one that fails: the same in both)
+        // two timed passes of 64 loop entries each (the counters run over both)
+        printf("%-32s %7.2f ticks per trip (short entries: %llu ticks, %llu trips; long entries: %llu ticks, %llu trips)\n", names[v],
+               (double)(h[1] - h[0]) / ((double)(h[4] - h[3]) / 2.0), (unsigned long long)h[0], (unsigned long long)h[3] / 2,
+               (unsigned long long)h[1], (unsigned long long)h[4] / 2);
+    }
+    return 0;
+}

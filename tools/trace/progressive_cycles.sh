@@ -24,6 +24,6 @@ b.decode().sync()
 lib.jpgpu_debug_ps_profile(out, 0)
 n, units, wait, stage, blocks, total = [out[i] for i in range(6)]
 print("symbols (refinement fast path, all scans)", out[6], "window refreshes (all stream scans)", out[7])
-print(f"inside the parse-only block decoder, cycles per block: prologue {out[8]/units:.0f}, prologue + symbol loop {out[9]/units:.0f}, window rebuilds {out[11]/units:.0f}, epilogue {out[10]/units:.0f}; loop exits per block {out[12]/units:.2f}")
+print(f"inside the parse-only block decoder, cycles per block: prologue {out[8]/units:.0f}, prologue + symbol loop {out[9]/units:.0f}, window rebuilds {out[11]/units:.0f}, epilogue {out[10]/units:.0f}; loop exits per block {out[12]/units:.2f}, loop trips per block (PSP=2 only) {out[13]/units:.2f}")
 print(f"last refinement scans: {n} streams, {units} blocks; cycles per block: follow/wait {wait/units:.0f}, staging {stage/units:.0f}, block loop {blocks/units:.0f}, all {total/units:.0f}")
 PY
