@@ -2272,6 +2272,19 @@ __device__ __forceinline__ uint32_t r4_digest(uint32_t e /* (code size << 8) | s
            (size + nonzero);
 }
 
+// the block's zero table: lane r holds Ss + (the number of non-zero coefficients of the band below its r-th zero)
+constexpr uint32_t kR4NoZero = 0xFFu;  // zero-table entry: no such zero, the run outlasts the band
+__device__ __forceinline__ uint32_t r4_zero_table(uint32_t lane, uint32_t ss, uint64_t band, uint64_t nz) {
+    const uint64_t zeros = ~nz & band, nzb = nz & band;
+    const uint32_t zrank = mbcnt64(zeros), nrank = mbcnt64(nzb);
+    const uint32_t nzeros = (uint32_t)__builtin_popcountll(zeros);
+    const bool is_zero = ((zeros >> lane) & 1ull) != 0;
+    // lane r <- the r-th zero of the band (the other lanes fill the remaining slots: a permutation, nothing collides)
+    const uint32_t slot = is_zero ? zrank : nzeros + (lane - zrank);
+    const uint32_t t = (uint32_t)__builtin_amdgcn_ds_permute((int)(slot << 2), (int)(ss + nrank));
+    return lane < nzeros ? t : kR4NoZero;
+}
+
 __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, int32_t p1,
                                                    int32_t m1, uint64_t band, uint64_t nz, uint32_t &eobrun, int32_t &c, bool &mine) {
 #ifdef JPGPU_PS_PROFILE
@@ -2282,21 +2295,19 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
     ss = uni(ss);
     se = uni(se);
     eobrun = uni(eobrun);
-    const uint64_t zeros = uni64(~nz & band), nzb = uni64(nz & band);
-    const uint32_t zrank = mbcnt64(zeros), nrank = mbcnt64(nzb);
+    const uint64_t nzb = uni64(nz & band);
+    const uint32_t nrank = mbcnt64(nzb);
     const uint32_t blockpos = uni(d.pos);
     const uint32_t nnz = (uint32_t)__builtin_popcountll(nzb);
     uint32_t bits = 0;     // per lane: code / sign / run bits of the block consumed before this lane's correction bit
     uint32_t symbits = 0;  // ... by the symbols so far
     uint32_t cv = (uint32_t)c;
     uint32_t winpos = blockpos - uni(d.cur);  // stream position of the window's first bit
+#ifdef JPGPU_PS_ABLATE_LOOP  // timing experiment (tools/trace/progressive_ablation.sh): no block is parsed, the rest runs
+    eobrun = 0x40000000u;
+#endif
     if (eobrun == 0) {
-        const uint32_t nzeros = (uint32_t)__builtin_popcountll(zeros);
-        const bool is_zero = ((zeros >> lane) & 1ull) != 0;
-        // lane r <- the r-th zero of the band (the other lanes fill the remaining slots: a permutation, nothing collides)
-        const uint32_t slot = is_zero ? zrank : nzeros + (lane - zrank);
-        uint32_t ntab = (uint32_t)__builtin_amdgcn_ds_permute((int)(slot << 2), (int)(ss + nrank));
-        ntab = lane < nzeros ? ntab : 0x10000u;  // no such zero: the run outlasts the band
+        const uint32_t ntab = r4_zero_table(lane, ss, band, nz);
         uint32_t cur = uni(d.cur);
         uint32_t base = cur - ss;   // a symbol's offset in the window = base + code bits before it + ntab[zeros consumed before it]
         uint32_t zq = 0xFFFFFFFFu;  // zeros of the band consumed so far, minus one
@@ -2304,8 +2315,10 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
 #ifdef JPGPU_PS_PROFILE
         d.t_pro += PS_TICK() - t_a;
 #endif
-        for (;;) {
-            uint32_t stop = 0xFFFFu;
+        bool again;
+        do {
+            again = false;
+            uint32_t stop, slow, eobv;
 #ifdef JPGPU_R4_CXX
             // the loop below, spelled in C++ (debugging aid: same operations, the compiler's schedule)
             uint32_t se_ = 0;
@@ -2326,9 +2339,20 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
                 if (lane == ((ve & kR4Zrl) | stop)) cv = (ve >> 14) & 0xFFFFu;
                 if (!(se > stop)) break;
             }
+            slow = eobv = 0;
+            if (stop == 0xFFFFu) {
+                if (cur <= 63u && (se_ & kR4Eob) != 0) {
+                    const uint32_t size = se_ & 63u, r2 = ((se_ >> 6) & 31u) - 1u;
+                    eobv = (1u << r2) + (uint32_t)(((uint64_t)(lane_get(d.peek, cur) << size) << r2) >> 32);
+                    symbits += size + r2;
+                } else {
+                    slow = 1;
+                }
+            }
+            if (lane > kprev) bits = symbits;
 #else
-            uint32_t scur, st, sn, se_ = 0, rr, t = 0, tm, adv, symn = 0, u, curn, pl, sg = 0, stopr = 0;
-            uint64_t sok = 0, spb = 0, spp;
+            uint32_t scur, st, sn, se_, rr, t, tm, adv, symn, u, curn, pl, sg, stopr;
+            uint64_t sok, spb, spp;
             asm volatile(
                 // One symbol per trip, 27 instructions and three fillers.  gfx940-family hazards the assembler does not fix in
                 // inline asm (LLVM's GCNHazardRecognizer does, for compiled code): a VALU instruction may read an SGPR / VCC
@@ -2336,7 +2360,12 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
                 // written by the VALU 1 later.  The gaps are filled with the PREVIOUS symbol's commits, none of which the
                 // chain cur -> entry -> zero rank -> ntab -> cur needs: they run at the top of the next trip (all of them no-ops in
                 // the first: sok = spb = 0, pl = none) and once more behind the loop.
-                "v_mov_b32_e32 %[stop], %[none]\n\t"  // (not a tied input: the compiler would share ONE register holding 0xFFFF)
+                // (Nothing comes in through a tied operand that could come in as a constant: hipcc lets a tied operand and
+                // an input that hold the same known value share ONE register, which the loop then overwrites under the input.)
+                "v_mov_b32_e32 %[stop], %[none]\n\t"
+                "s_mov_b32 %[se_], 0\n\t"
+                "s_mov_b64 %[sok], 0\n\t"
+                "s_mov_b64 %[spb], 0\n\t"
                 "1:\n\t"
 #if defined(JPGPU_PS_PROFILE) && JPGPU_PS_PROFILE > 1
                 "v_add_u32_e32 %[trips], 1, %[trips]\n\t"
@@ -2370,6 +2399,7 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
                 "v_cndmask_b32_e64 %[stop], %[none], %[stopr], %[sok]\n\t"
                 "v_cmp_gt_u32_e32 vcc, %[se], %[stop]\n\t"
                 "s_cbranch_vccnz 1b\n\t"
+                // the last symbol's commits
                 "v_and_or_b32 %[pl], %[se_], %[zrl], %[stop]\n\t"
                 "v_cndmask_b32_e64 %[symbits], %[symbits], %[symn], %[sok]\n\t"
                 "v_cmp_eq_u32_e64 %[spp], %[lane], %[pl]\n\t"
@@ -2377,74 +2407,100 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
                 "v_cndmask_b32_e64 %[kprev], %[kprev], %[stopr], %[sok]\n\t"
                 "v_cndmask_b32_e64 %[zq], %[zq], %[t], %[sok]\n\t"
                 "v_cndmask_b32_e64 %[cv], %[cv], %[sg], %[spp]\n\t"
+                // What stopped the loop?  Nearly always EOBn (:337-350), found in the lookup: se_ is that entry, scur its offset
+                // in the window.  Applied here, without a branch: the run's low bits follow the code, the tail's lanes come
+                // behind all of it.  slow != 0: something else (window used up, code longer than the lookup, run past the band).
+                "v_readlane_b32 %[sn], %[peek], %[scur]\n\t"
+                "v_bfe_u32 %[rr], %[se_], 6, 5\n\t"              // run + 1
+                "v_and_b32_e64 %[adv], 63, %[se_]\n\t"           // code size
+                "v_add_u32_e32 %[rr], -1, %[rr]\n\t"
+                "v_lshlrev_b32_e64 %[u], %[adv], %[sn]\n\t"      // the bits behind the code
+                "v_sub_u32_e32 %[tm], 32, %[rr]\n\t"
+                "v_bfe_u32 %[u], %[u], %[tm], %[rr]\n\t"         // ... the first `run` of them (none: 0)
+                "v_lshlrev_b32_e64 %[curn], %[rr], 1\n\t"
+                "v_add_u32_e32 %[eobv], %[curn], %[u]\n\t"       // the end-of-band run
+                "v_add3_u32 %[symn], %[symbits], %[adv], %[rr]\n\t"
+                "v_lshrrev_b32_e32 %[pl], 6, %[cur]\n\t"         // window used up?
+                "v_bfe_u32 %[u], %[se_], 30, 1\n\t"              // an EOBn entry?
+                "v_xor_b32_e32 %[u], 1, %[u]\n\t"
+                "v_or_b32_e32 %[pl], %[pl], %[u]\n\t"
+                "v_cmp_eq_u32_e64 %[spp], %[stop], %[none]\n\t"  // the loop stopped on an entry it could not apply
+                "v_cmp_gt_u32_e64 %[spb], %[lane], %[kprev]\n\t"
+                "s_nop 0\n\t"
+                "v_cndmask_b32_e64 %[slow], 0, %[pl], %[spp]\n\t"
+                "v_cndmask_b32_e64 %[pl], 1, %[pl], %[spp]\n\t"
+                "v_cmp_eq_u32_e64 %[sok], 0, %[pl]\n\t"          // ... and it is an EOBn
+                "s_nop 1\n\t"
+                "v_cndmask_b32_e64 %[symbits], %[symbits], %[symn], %[sok]\n\t"
+                "v_cndmask_b32_e64 %[eobv], 0, %[eobv], %[sok]\n\t"
+                "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t"
                 : [cur] "+v"(cur), [zq] "+v"(zq), [symbits] "+v"(symbits), [kprev] "+v"(kprev), [bits] "+v"(bits), [cv] "+v"(cv),
-                  [stop] "=&v"(stop), [se_] "+s"(se_), [sok] "+s"(sok), [spb] "+s"(spb), [t] "+v"(t), [symn] "+v"(symn), [sg] "+v"(sg),
-                  [stopr] "+v"(stopr), [scur] "=&s"(scur), [st] "=&s"(st), [sn] "=&s"(sn), [spp] "=&s"(spp), [rr] "=&v"(rr), [tm] "=&v"(tm),
-                  [adv] "=&v"(adv), [u] "=&v"(u), [curn] "=&v"(curn), [pl] "=&v"(pl)
+                  [stop] "=&v"(stop), [slow] "=&v"(slow), [eobv] "=&v"(eobv), [se_] "=&s"(se_), [sok] "=&s"(sok), [spb] "=&s"(spb),
+                  [t] "=&v"(t), [symn] "=&v"(symn), [sg] "=&v"(sg), [stopr] "=&v"(stopr), [scur] "=&s"(scur), [st] "=&s"(st),
+                  [sn] "=&s"(sn), [spp] "=&s"(spp), [rr] "=&v"(rr), [tm] "=&v"(tm), [adv] "=&v"(adv), [u] "=&v"(u), [curn] "=&v"(curn),
+                  [pl] "=&v"(pl)
 #if defined(JPGPU_PS_PROFILE) && JPGPU_PS_PROFILE > 1
                   , [trips] "+v"(d.n_trips)
 #endif
-                : [ent2] "v"(d.ent2), [ntab] "v"(ntab), [lane] "v"(lane), [base] "v"(base), [none] "v"(0xFFFFu), [zrl] "v"(kR4Zrl), [se] "s"(se)
+                : [ent2] "v"(d.ent2), [ntab] "v"(ntab), [peek] "v"(d.peek), [lane] "v"(lane), [base] "v"(base), [none] "v"(0xFFFFu),
+                  [zrl] "v"(kR4Zrl), [se] "s"(se)
                 : "vcc", "memory");
 #endif
-            cur = uni(cur);
-            zq = uni(zq);
-            symbits = uni(symbits);
-            kprev = uni(kprev);
-            stop = uni(stop);
 #ifdef JPGPU_PS_PROFILE
             d.n_exits++;
 #endif
-            if (stop != 0xFFFFu) break;  // the last symbol was applied and its run ended at Se: the band is done
-            if (cur > 63u) {
+            eobrun = uni(eobv);  // (0 unless the loop ended on an EOBn entry)
+            if (uni(slow) != 0) {
+                cur = uni(cur);
+                zq = uni(zq);
+                symbits = uni(symbits);
+                kprev = uni(kprev);
+                if (cur > 63u) {
 #ifdef JPGPU_PS_PROFILE
-                const unsigned long long t_x = PS_TICK();
+                    const unsigned long long t_x = PS_TICK();
 #endif
-                d.pos = winpos + cur;
-                w_refresh<true>(d, lane, hac);
-                d.ent2 = r4_digest(d.ent, d.peek, p1, m1);
-                winpos = uni(d.pos);
-                base -= cur;
-                cur = 0;
+                    d.pos = winpos + cur;
+                    w_refresh<true>(d, lane, hac);
+                    d.ent2 = r4_digest(d.ent, d.peek, p1, m1);
+                    winpos = uni(d.pos);
+                    base -= cur;
+                    cur = 0;
+                    again = true;
 #ifdef JPGPU_PS_PROFILE
-                t_r += PS_TICK() - t_x;
+                    t_r += PS_TICK() - t_x;
 #endif
-                continue;
+                } else {
+                    // one symbol by hand: a code longer than the lookup (EOBn among them), or a run that outlasts the band
+                    PS_COUNT(6);
+                    const uint32_t pk = lane_get(d.peek, cur);
+                    uint32_t raw = lane_get(d.ent, cur);
+                    if ((raw >> 8) == 0) {
+                        raw = w_huff_scalar(hac, pk >> 16);
+                        if (raw >= kPsBadCode) return kDetailInvalidHuffmanCode;
+                    }
+                    const uint32_t e2 = r4_digest(raw, pk, p1, m1);
+                    const uint32_t size = raw >> 8, r2 = (raw >> 4) & 15u;
+                    if (e2 >= kR4Special) {  // EOBn (:337-350): the run's low bits follow the code; the tail's lanes come behind all of it
+                        eobrun = (1u << r2) + (uint32_t)(((uint64_t)(pk << size) << r2) >> 32);
+                        symbits += size + r2;
+                        if (lane > kprev) bits = symbits;
+                    } else {
+                        const uint32_t adv2 = e2 & 63u, tgt2 = zq + 1u + r2;
+                        const uint32_t n2 = lane_get(ntab, tgt2 < 63u ? tgt2 : 63u);
+                        symbits += adv2;
+                        if (lane > kprev) bits = symbits;
+                        const uint32_t stop2 = n2 >= 64u ? se + 1u : tgt2 + n2;  // no such zero: the new coefficient lands behind Se (:363-367)
+                        if ((e2 & kR4Zrl) == 0 && lane == stop2) cv = (e2 >> 14) & 0xFFFFu;
+                        if (n2 < 64u && stop2 < se) {  // (else every non-zero coefficient left has been passed)
+                            cur = base + symbits + n2;
+                            zq = tgt2;
+                            kprev = stop2;
+                            again = true;
+                        }
+                    }
+                }
             }
-            if ((se_ & kR4Eob) != 0) {  // EOBn (:337-350), the loop's last entry: the run's low bits follow the code
-                const uint32_t size = se_ & 63u, r2 = ((se_ >> 6) & 31u) - 1u;
-                eobrun = (1u << r2) + (uint32_t)(((uint64_t)(lane_get(d.peek, cur) << size) << r2) >> 32);
-                symbits += size + r2;
-                if (lane > kprev) bits = symbits;  // the tail's lanes come behind all of it
-                break;
-            }
-            // one symbol by hand: a code longer than the lookup (EOBn among them), or a run that outlasts the band
-            PS_COUNT(6);
-            const uint32_t pk = lane_get(d.peek, cur);
-            uint32_t raw = lane_get(d.ent, cur);
-            if ((raw >> 8) == 0) {
-                raw = w_huff_scalar(hac, pk >> 16);
-                if (raw >= kPsBadCode) return kDetailInvalidHuffmanCode;
-            }
-            const uint32_t e2 = r4_digest(raw, pk, p1, m1);
-            const uint32_t size = raw >> 8, r2 = (raw >> 4) & 15u;
-            if (e2 >= kR4Special) {  // EOBn (:337-350): the run's low bits follow the code; the tail's lanes come behind all of it
-                eobrun = (1u << r2) + (uint32_t)(((uint64_t)(pk << size) << r2) >> 32);
-                symbits += size + r2;
-                if (lane > kprev) bits = symbits;
-                break;
-            }
-            const uint32_t adv2 = e2 & 63u, tgt2 = zq + 1u + r2;
-            const uint32_t n2 = lane_get(ntab, tgt2 < 63u ? tgt2 : 63u);
-            symbits += adv2;
-            if (lane > kprev) bits = symbits;
-            const uint32_t stop2 = n2 >= 0x10000u ? se + 1u : tgt2 + n2;  // no such zero: the new coefficient lands behind Se (:363-367)
-            if ((e2 & kR4Zrl) == 0 && lane == stop2) cv = (e2 >> 14) & 0xFFFFu;
-            if (n2 >= 0x10000u || stop2 >= se) break;  // every non-zero coefficient left has been passed
-            cur = base + symbits + n2;
-            zq = tgt2;
-            kprev = stop2;
-        }
+        } while (again);
     }
 #ifdef JPGPU_PS_PROFILE
     const unsigned long long t_c = PS_TICK();
@@ -2453,7 +2509,11 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
     if (eobrun > 0) eobrun--;
     // every coefficient that was non-zero takes exactly one correction bit: behind the code bits noted for its lane, in rank order
     int32_t cn = (int32_t)(int16_t)cv;
+#ifdef JPGPU_PS_ABLATE_EPILOGUE  // timing experiment: no correction bits
+    if (false) {
+#else
     if (nzb != 0) {
+#endif
         const uint32_t bp = blockpos + bits + nrank;
         const uint32_t w = d.ring[(bp >> 5) & d.wmask];
         if (((nzb >> lane) & 1ull) != 0 && ((w >> (31u - (bp & 31u))) & 1u) != 0 && (cn & p1) == 0)
@@ -2469,6 +2529,238 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
     d.t_refresh += t_r;
     d.t_epi += PS_TICK() - t_c;
 #endif
+    return 0;
+}
+// ---- AC refinement, bulk path, fifth form: the WHOLE block in one instruction sequence.
+// rocprofv3's counters on the fourth form (tools/trace/progressive_pmc.sh, per block of the last luma refinement): 480 wave
+// instructions of which the symbol loop is ~200, 30 branches, and as many wave cycles waiting as issuing -- one wave issues one
+// instruction every four cycles whatever it is (tools/microbench/fetch_rate.hip), a branch costs ~16 more, a scalar instruction
+// that reads what a vector instruction has just written ~20.  The compiler's code around the loop (masks and ranks of the
+// band, the zero table, the hand-over of uniform values between the scalar and the vector unit, the correction bits, a
+// state machine of a dozen branches for the loop's exits) is therefore written out here as well, straight-line and in the
+// vector unit's instruction stream: prologue (~40 instructions), the loop and its end-of-band tail as in the fourth form, the
+// correction bits (~25).  What it does not do -- rebuild the window, decode a code longer than the lookup, a run that
+// outlasts the band -- it hands back (status 1) with all of its state in registers, and is re-entered at the loop (`resume`
+// 1) or at the correction bits (2) once the C++ below has dealt with it.
+__device__ __forceinline__ uint32_t w_ac_refine_v5(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, int32_t p1,
+                                                   int32_t m1, uint32_t inband /* all ones in the lanes Ss..Se */, uint32_t &eobrun,
+                                                   int32_t &c, bool &mine) {
+    ss = uni(ss);
+    se = uni(se);
+    const uint32_t blockpos = uni(d.pos), cur0 = uni(d.cur), wmask = uni(d.wmask);
+    const uint32_t ring_lds = uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t *)d.ring);
+    uint32_t winpos = blockpos - cur0;  // stream position of the window's first bit
+    auto undefined = [] {
+        uint32_t x;
+        asm volatile("" : "=v"(x));  // (a register, no instruction: the sequence below sets it)
+        return x;
+    };
+    uint32_t cv = undefined(), eobv = eobrun, cur = undefined(), zq = undefined(), symbits = undefined(), kprev = undefined(),
+             bits = undefined(), ntab = undefined(), nrank = undefined(), nnz = undefined(), base = undefined();
+    uint32_t status, consumed, cn;
+    // (one way round the loop and one way out of it: with a `return` or a `break` in the middle hipcc turns the exits into a
+    // state variable and a dozen scalar branches that every block would walk through)
+    uint32_t resume = 0, fail = 0;
+    do {
+        uint32_t stop, slow, scur, st, sn, se_, x0, x1, x2, x3, x4, x5, x6, x7, x8, x9;
+        uint64_t sok, spb, spp;
+        asm volatile(
+            "s_cmp_eq_u32 %[resume], 1\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "s_cmp_eq_u32 %[resume], 2\n\t"
+            "s_cbranch_scc1 5f\n\t"
+            // ---- prologue: the band's non-zero coefficients (ranks, count) and its zeros (ranks, count); the zero table --
+            // lane r: Ss + the number of non-zero coefficients below the r-th zero -- by one ds_permute
+            "v_and_b32_e32 %[x0], %[c], %[inb]\n\t"
+            "v_not_b32_e32 %[x1], %[inb]\n\t"
+            "v_or_b32_e32 %[x1], %[x1], %[c]\n\t"
+            "v_cmp_ne_u32_e32 vcc, 0, %[x0]\n\t"
+            "v_mov_b32_e32 %[cv], %[c]\n\t"
+            "v_mov_b32_e32 %[symbits], 0\n\t"
+            "v_mbcnt_lo_u32_b32 %[nrank], vcc_lo, 0\n\t"
+            "v_mbcnt_hi_u32_b32 %[nrank], vcc_hi, %[nrank]\n\t"
+            "v_bcnt_u32_b32 %[nnz], vcc_lo, 0\n\t"
+            "v_bcnt_u32_b32 %[nnz], vcc_hi, %[nnz]\n\t"
+            "v_cmp_eq_u32_e32 vcc, 0, %[x1]\n\t"
+            "v_mov_b32_e32 %[bits], 0\n\t"
+            "v_add_u32_e32 %[x3], %[ss], %[nrank]\n\t"
+            "v_mbcnt_lo_u32_b32 %[x0], vcc_lo, 0\n\t"
+            "v_mbcnt_hi_u32_b32 %[x0], vcc_hi, %[x0]\n\t"        // rank among the zeros
+            "v_bcnt_u32_b32 %[x1], vcc_lo, 0\n\t"
+            "v_bcnt_u32_b32 %[x1], vcc_hi, %[x1]\n\t"            // zeros in the band
+            "v_sub_u32_e32 %[x2], %[lane], %[x0]\n\t"
+            "v_add_u32_e32 %[x2], %[x2], %[x1]\n\t"
+            "v_cndmask_b32_e32 %[x2], %[x2], %[x0], vcc\n\t"      // r-th zero -> lane r, the others behind (a permutation)
+            "v_lshlrev_b32_e32 %[x2], 2, %[x2]\n\t"
+            "ds_permute_b32 %[ntab], %[x2], %[x3]\n\t"
+            "v_mov_b32_e32 %[cur], %[cur0]\n\t"
+            "v_subrev_u32_e32 %[base], %[ss], %[cur]\n\t"         // a symbol's window offset = base + code bits before it + ntab[zeros before it]
+            "v_mov_b32_e32 %[zq], -1\n\t"
+            "v_add_u32_e64 %[kprev], %[ss], -1\n\t"
+            "v_cmp_gt_u32_e32 vcc, %[x1], %[lane]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cndmask_b32_e32 %[ntab], %[noz], %[ntab], vcc\n\t"  // no such zero: the run outlasts the band
+            "v_cmp_ne_u32_e32 vcc, 0, %[eobv]\n\t"                 // inside an end-of-band run: correction bits only
+            "s_cbranch_vccnz 5f\n\t"
+            // ---- the symbol loop (fourth form): one symbol per trip; the previous symbol's commits fill the hazard gaps
+            "2:\n\t"
+            "v_mov_b32_e32 %[stop], %[none]\n\t"
+            "s_mov_b32 %[se_], 0\n\t"
+            "s_mov_b64 %[sok], 0\n\t"
+            "s_mov_b64 %[spb], 0\n\t"
+            "1:\n\t"
+            "v_readfirstlane_b32 %[scur], %[cur]\n\t"
+            "v_and_or_b32 %[x5], %[se_], %[zrl], %[stop]\n\t"
+            "v_cndmask_b32_e64 %[symbits], %[symbits], %[x3], %[sok]\n\t"
+            "v_cmp_eq_u32_e64 %[spp], %[lane], %[x5]\n\t"
+            "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t"
+            "v_readlane_b32 %[se_], %[ent2], %[scur]\n\t"
+            "v_cndmask_b32_e64 %[kprev], %[kprev], %[x9], %[sok]\n\t"
+            "v_cndmask_b32_e64 %[zq], %[zq], %[x2], %[sok]\n\t"
+            "v_bfe_u32 %[x0], %[se_], 6, 7\n\t"
+            "v_cndmask_b32_e64 %[cv], %[cv], %[x8], %[spp]\n\t"
+            "v_add_u32_e32 %[x2], %[zq], %[x0]\n\t"               // x2 = t: rank of the zero the symbol's run ends on
+            "v_min_u32_e32 %[x1], 63, %[x2]\n\t"
+            "v_and_b32_e64 %[x4], 63, %[se_]\n\t"
+            "v_readfirstlane_b32 %[st], %[x1]\n\t"
+            "v_add_u32_e32 %[x3], %[symbits], %[x4]\n\t"          // x3 = symn
+            "v_bfe_u32 %[x8], %[se_], 14, 16\n\t"                 // x8 = the new coefficient
+            "v_cmp_gt_u32_e64 %[spb], %[lane], %[kprev]\n\t"
+            "s_nop 0\n\t"
+            "v_readlane_b32 %[sn], %[ntab], %[st]\n\t"
+            "s_nop 1\n\t"
+            "v_add3_u32 %[x6], %[base], %[x3], %[sn]\n\t"         // x6 = curn
+            "v_or3_b32 %[x7], %[x2], %[cur], %[sn]\n\t"
+            "v_cmp_gt_u32_e64 %[sok], 64, %[x7]\n\t"
+            "v_add_u32_e32 %[x9], %[sn], %[x2]\n\t"               // x9 = stopr
+            "s_nop 0\n\t"
+            "v_cndmask_b32_e64 %[cur], %[cur], %[x6], %[sok]\n\t"
+            "v_cndmask_b32_e64 %[stop], %[none], %[x9], %[sok]\n\t"
+            "v_cmp_gt_u32_e32 vcc, %[se], %[stop]\n\t"
+            "s_cbranch_vccnz 1b\n\t"
+            "v_and_or_b32 %[x5], %[se_], %[zrl], %[stop]\n\t"
+            "v_cndmask_b32_e64 %[symbits], %[symbits], %[x3], %[sok]\n\t"
+            "v_cmp_eq_u32_e64 %[spp], %[lane], %[x5]\n\t"
+            "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t"
+            "v_cndmask_b32_e64 %[kprev], %[kprev], %[x9], %[sok]\n\t"
+            "v_cndmask_b32_e64 %[zq], %[zq], %[x2], %[sok]\n\t"
+            "v_cndmask_b32_e64 %[cv], %[cv], %[x8], %[spp]\n\t"
+            // what stopped the loop?  EOBn found in the lookup is applied here (fourth form's tail)
+            "v_readlane_b32 %[sn], %[peek], %[scur]\n\t"
+            "v_bfe_u32 %[x0], %[se_], 6, 5\n\t"
+            "v_and_b32_e64 %[x4], 63, %[se_]\n\t"
+            "v_add_u32_e32 %[x0], -1, %[x0]\n\t"
+            "v_lshlrev_b32_e64 %[x7], %[x4], %[sn]\n\t"
+            "v_sub_u32_e32 %[x1], 32, %[x0]\n\t"
+            "v_bfe_u32 %[x7], %[x7], %[x1], %[x0]\n\t"
+            "v_lshlrev_b32_e64 %[x6], %[x0], 1\n\t"
+            "v_add_u32_e32 %[x6], %[x6], %[x7]\n\t"               // the end-of-band run
+            "v_add3_u32 %[x3], %[symbits], %[x4], %[x0]\n\t"
+            "v_lshrrev_b32_e32 %[x5], 6, %[cur]\n\t"
+            "v_bfe_u32 %[x7], %[se_], 30, 1\n\t"
+            "v_xor_b32_e32 %[x7], 1, %[x7]\n\t"
+            "v_or_b32_e32 %[x5], %[x5], %[x7]\n\t"
+            "v_cmp_eq_u32_e64 %[spp], %[stop], %[none]\n\t"
+            "v_cmp_gt_u32_e64 %[spb], %[lane], %[kprev]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32_e64 %[slow], 0, %[x5], %[spp]\n\t"
+            "v_cndmask_b32_e64 %[x5], 1, %[x5], %[spp]\n\t"
+            "v_cmp_eq_u32_e64 %[sok], 0, %[x5]\n\t"
+            "v_cmp_ne_u32_e32 vcc, 0, %[slow]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32_e64 %[symbits], %[symbits], %[x3], %[sok]\n\t"
+            "v_cndmask_b32_e64 %[eobv], 0, %[x6], %[sok]\n\t"
+            "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t"
+            "v_mov_b32_e32 %[status], 1\n\t"
+            "s_cbranch_vccnz 9f\n\t"                               // something for the C++ below
+            // ---- the block's end: this block counts against the run; every coefficient of the band that was non-zero takes
+            // exactly one correction bit, behind the code bits noted for its lane, in rank order
+            "5:\n\t"
+            "v_sub_u32_e64 %[eobv], %[eobv], 1 clamp\n\t"
+            "v_add3_u32 %[x0], %[pos0], %[bits], %[nrank]\n\t"
+            "v_lshrrev_b32_e32 %[x1], 5, %[x0]\n\t"
+            "v_and_b32_e32 %[x1], %[wmask], %[x1]\n\t"
+            "v_lshl_add_u32 %[x1], %[x1], 2, %[ring]\n\t"
+            "ds_read_b32 %[x1], %[x1]\n\t"
+            "v_not_b32_e32 %[x0], %[x0]\n\t"
+            "v_and_b32_e32 %[x2], %[c], %[inb]\n\t"
+            "v_and_b32_e32 %[x3], %[p1v], %[c]\n\t"
+            "v_cmp_ne_u32_e64 %[spp], 0, %[x2]\n\t"               // was non-zero, in the band
+            "v_cmp_eq_u32_e64 %[sok], 0, %[x3]\n\t"               // this bit not set yet
+            "v_cmp_gt_i32_e64 %[spb], 0, %[c]\n\t"
+            "v_add_u32_e32 %[consumed], %[symbits], %[nnz]\n\t"
+            "v_mov_b32_e32 %[status], 0\n\t"
+            "v_cndmask_b32_e64 %[x2], %[p1v], %[m1v], %[spb]\n\t"
+            "v_cndmask_b32_e64 %[x2], 0, %[x2], %[sok]\n\t"
+            "v_cndmask_b32_e64 %[x2], 0, %[x2], %[spp]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_lshrrev_b32_e32 %[x1], %[x0], %[x1]\n\t"
+            "v_bfe_i32 %[x1], %[x1], 0, 1\n\t"
+            "v_and_b32_e32 %[x2], %[x2], %[x1]\n\t"
+            "v_add_u32_e32 %[cn], %[cv], %[x2]\n\t"
+            "v_bfe_i32 %[cn], %[cn], 0, 16\n\t"
+            "9:\n\t"
+            : [cv] "+v"(cv), [eobv] "+v"(eobv), [cur] "+v"(cur), [zq] "+v"(zq), [symbits] "+v"(symbits), [kprev] "+v"(kprev),
+              [bits] "+v"(bits), [ntab] "+v"(ntab), [nrank] "+v"(nrank), [nnz] "+v"(nnz), [base] "+v"(base), [stop] "=&v"(stop),
+              [slow] "=&v"(slow), [status] "=&v"(status), [consumed] "=&v"(consumed), [cn] "=&v"(cn), [scur] "=&s"(scur), [st] "=&s"(st),
+              [sn] "=&s"(sn), [se_] "=&s"(se_), [sok] "=&s"(sok), [spb] "=&s"(spb), [spp] "=&s"(spp), [x0] "=&v"(x0), [x1] "=&v"(x1),
+              [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [x5] "=&v"(x5), [x6] "=&v"(x6), [x7] "=&v"(x7), [x8] "=&v"(x8), [x9] "=&v"(x9)
+            : [c] "v"(c), [inb] "v"(inband), [ent2] "v"(d.ent2), [peek] "v"(d.peek), [lane] "v"(lane), [p1v] "v"(p1), [m1v] "v"(m1),
+              [none] "v"(0xFFFFu), [zrl] "v"(kR4Zrl), [noz] "v"(kR4NoZero), [ss] "s"(ss), [se] "s"(se), [pos0] "s"(blockpos),
+              [cur0] "s"(cur0), [wmask] "s"(wmask), [ring] "s"(ring_lds), [resume] "s"(uni(resume))
+            : "vcc", "scc", "memory");
+        resume = 0;
+        if (uni(status) != 0) {
+            // ---- handed back: the window is used up, or one symbol by hand
+            cur = uni(cur);
+            zq = uni(zq);
+            symbits = uni(symbits);
+            kprev = uni(kprev);
+            resume = 1;
+            if (cur > 63u) {
+                d.pos = winpos + cur;
+                w_refresh<true>(d, lane, hac);
+                d.ent2 = r4_digest(d.ent, d.peek, p1, m1);
+                winpos = uni(d.pos);
+                base -= cur;
+                cur = 0;
+            } else {
+                // a code longer than the lookup (EOBn among them), or a run that outlasts the band
+                const uint32_t pk = lane_get(d.peek, cur);
+                uint32_t raw = lane_get(d.ent, cur);
+                if ((raw >> 8) == 0) raw = w_huff_scalar(hac, pk >> 16);
+                const uint32_t e2 = r4_digest(raw, pk, p1, m1);
+                const uint32_t size = raw >> 8, r2 = (raw >> 4) & 15u;
+                if (raw >= kPsBadCode) {
+                    fail = kDetailInvalidHuffmanCode;
+                    resume = 0;
+                } else if (e2 >= kR4Special) {  // EOBn (:337-350): the run's low bits follow the code; the tail's lanes come behind all of it
+                    eobv = (1u << r2) + (uint32_t)(((uint64_t)(pk << size) << r2) >> 32);
+                    symbits += size + r2;
+                    if (lane > kprev) bits = symbits;
+                    resume = 2;
+                } else {
+                    const uint32_t adv2 = e2 & 63u, tgt2 = zq + 1u + r2;
+                    const uint32_t n2 = lane_get(ntab, tgt2 < 63u ? tgt2 : 63u);
+                    symbits += adv2;
+                    if (lane > kprev) bits = symbits;
+                    const uint32_t stop2 = n2 >= 64u ? se + 1u : tgt2 + n2;  // no such zero: the new coefficient lands behind Se (:363-367)
+                    if ((e2 & kR4Zrl) == 0 && lane == stop2) cv = (e2 >> 14) & 0xFFFFu;
+                    const bool on = n2 < 64u && stop2 < se;  // (else every non-zero coefficient left has been passed)
+                    cur = on ? base + symbits + n2 : cur;
+                    zq = on ? tgt2 : zq;
+                    kprev = on ? stop2 : kprev;
+                    resume = on ? 1u : 2u;
+                }
+            }
+        }
+    } while (resume != 0);
+    if (fail != 0) return fail;
+    eobrun = uni(eobv);
+    d.pos = blockpos + uni(consumed);
+    d.cur = d.pos - winpos;
+    mine = (int32_t)cn != c;  // a new coefficient is never 0, a correction never leaves the value alone
+    c = (int32_t)cn;
     return 0;
 }
 constexpr int32_t kPsFastBits = 2560;  // more than any block can consume: 63 x (16 + 16) + 14 (first), 63 x 17 + 63 + 14 (refinement)
@@ -2924,6 +3216,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
         const int32_t p1 = (int32_t)(int16_t)(1u << al), m1 = (int32_t)(int16_t)(0xFFFFFFFFu << al);
         const uint64_t band = (se >= 63u ? ~0ull : ((1ull << (se + 1u)) - 1ull)) & ~((1ull << ss) - 1ull);
         const uint64_t lane_bit = 1ull << lane;
+        const uint32_t inband = (band & lane_bit) != 0 ? 0xFFFFFFFFu : 0u;
         uint32_t eobrun = 0;
         if (ah == 0) {
             ProgWalk w;
@@ -3014,7 +3307,11 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                             uint32_t eob4 = eobrun;
                             int32_t c4 = c;
                             bool mine4 = false;
+#ifdef JPGPU_PS_REFINE4
                             const uint32_t e4 = w_ac_refine_v4(d4, lane, hac, ss, se, p1, m1, band, nz, eob4, c4, mine4);
+#else
+                            const uint32_t e4 = w_ac_refine_v5(d4, lane, hac, ss, se, p1, m1, inband, eob4, c4, mine4);
+#endif
                             const bool bad = e3 != e4 || d3.pos != d4.pos || eob3 != eob4;
                             const uint64_t cbad = __ballot(((nz >> lane) & 1ull) != 0 && c3 != c4);
                             if ((bad || cbad != 0) && lane == 0)
@@ -3023,7 +3320,11 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                                        (unsigned long long)cbad);
                         }
 #endif
+#ifdef JPGPU_PS_REFINE4
                         err = w_ac_refine_v4(d, lane, hac, ss, se, p1, m1, band, nz, eobrun, c, mine);
+#else
+                        err = w_ac_refine_v5(d, lane, hac, ss, se, p1, m1, inband, eobrun, c, mine);
+#endif
 #endif
                         d.rem -= (int32_t)(d.pos - pos0);
                     } else {
