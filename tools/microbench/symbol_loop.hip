@@ -141,6 +141,68 @@ __device__ __forceinline__ uint32_t run(uint32_t lane, uint32_t ent2, uint32_t n
     return cur + zq + symbits + bits + cv + stop + kprev;
 }
 
+// The chain on the SCALAR unit: the two v_readlane results are consumed by scalar instructions (a scalar instruction that
+// reads an SGPR the vector unit has just written waits ~22 cycles), the windows behind the v_readlane are filled with the
+// previous symbol's per-lane commits (vector) and with scalar work that does not need the result.  No wait states are owed
+// (lane selects written by the scalar unit), nothing is decided by a branch but the loop.
+__device__ __forceinline__ uint32_t run_scalar(uint32_t lane, uint32_t ent2, uint32_t ntab, uint32_t zq0, uint32_t se, uint32_t &trips) {
+    auto shide = [](uint32_t v) {  // (see run(): no two operands may be known to hold the same value)
+        uint32_t r;
+        asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "s"(v));
+        return r;
+    };
+    auto vhide = [](uint32_t x) {
+        asm volatile("" : "+v"(x));
+        return x;
+    };
+    uint32_t cur = shide(0), zq = zq0, symbits = shide(0), kprev = shide(0), stop = shide(0xFFFFu), base = shide(0), ntrips = shide(0);
+    uint32_t bits = vhide(0), cv = vhide(0), pl, sg = vhide(0), ze;
+    uint32_t e, rr, t, tm, sn, adv, symn, stopr, curn, u, zf = shide(0);
+    uint64_t spp, spb;
+    asm volatile(
+        "1:\n\t"
+        "s_add_u32 %[ntrips], %[ntrips], 1\n\t"
+        "v_readlane_b32 %[e], %[ent2], %[cur]\n\t"
+        // previous symbol's per-lane commits (values in SGPRs written by the scalar unit: no hazard)
+        "v_mov_b32_e32 %[pl], %[stop]\n\t"
+        "v_or_b32_e32 %[pl], %[zf], %[pl]\n\t"
+        "v_cmp_eq_u32_e64 %[spp], %[lane], %[pl]\n\t"
+        "v_cmp_gt_u32_e64 %[spb], %[lane], %[kprev]\n\t"
+        "v_mov_b32_e32 %[ze], %[symbits]\n\t"
+        "s_bfe_u32 %[rr], %[e], 0x70006\n\t"
+        "s_add_u32 %[t], %[zq], %[rr]\n\t"
+        "s_min_u32 %[tm], %[t], 63\n\t"
+        "v_readlane_b32 %[sn], %[ntab], %[tm]\n\t"
+        "v_cndmask_b32_e64 %[cv], %[cv], %[sg], %[spp]\n\t"
+        "v_cndmask_b32_e64 %[bits], %[bits], %[ze], %[spb]\n\t"
+        "s_and_b32 %[adv], %[e], 63\n\t"
+        "s_add_u32 %[symn], %[symbits], %[adv]\n\t"
+        "s_and_b32 %[zf], %[e], 0x2000\n\t"
+        "s_bfe_u32 %[u], %[e], 0x10000e\n\t"
+        "v_mov_b32_e32 %[sg], %[u]\n\t"
+        "s_or_b32 %[u], %[t], %[cur]\n\t"
+        "s_add_u32 %[curn], %[symn], %[base]\n\t"
+        "s_add_u32 %[stopr], %[sn], %[t]\n\t"
+        "s_add_u32 %[curn], %[curn], %[sn]\n\t"
+        "s_or_b32 %[u], %[u], %[sn]\n\t"
+        "s_cmp_lt_u32 %[u], 64\n\t"
+        "s_cselect_b32 %[cur], %[curn], %[cur]\n\t"
+        "s_cselect_b32 %[zq], %[t], %[zq]\n\t"
+        "s_cselect_b32 %[symbits], %[symn], %[symbits]\n\t"
+        "s_cselect_b32 %[kprev], %[stopr], %[kprev]\n\t"
+        "s_cselect_b32 %[stop], %[stopr], 0xffff\n\t"
+        "s_cmp_lt_u32 %[stop], %[se]\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        : [cur] "+s"(cur), [zq] "+s"(zq), [symbits] "+s"(symbits), [kprev] "+s"(kprev), [stop] "+s"(stop), [ntrips] "+s"(ntrips),
+          [bits] "+v"(bits), [cv] "+v"(cv), [sg] "+v"(sg), [zf] "+s"(zf), [e] "=&s"(e), [rr] "=&s"(rr), [t] "=&s"(t), [tm] "=&s"(tm),
+          [sn] "=&s"(sn), [adv] "=&s"(adv), [symn] "=&s"(symn), [stopr] "=&s"(stopr), [curn] "=&s"(curn), [u] "=&s"(u), [pl] "=&v"(pl),
+          [ze] "=&v"(ze), [spp] "=&s"(spp), [spb] "=&s"(spb)
+        : [ent2] "v"(ent2), [ntab] "v"(ntab), [lane] "v"(lane), [base] "s"(base), [se] "s"(se)
+        : "scc", "memory");
+    trips += ntrips;
+    return cur + zq + symbits + bits + cv + stop + kprev;
+}
+
 template <int kVariant>
 __global__ void k(uint64_t *out, uint32_t seed) {
     const uint32_t lane = threadIdx.x;
@@ -153,7 +215,8 @@ __global__ void k(uint64_t *out, uint32_t seed) {
         for (int which = 0; which < 2; which++) {
             const uint32_t zq0 = which == 0 ? 31u : 0xFFFFFFFFu;  // 32 trips or 64
             const uint64_t t0 = tick();
-            for (int rep = 0; rep < 64; rep++) sink += run<kVariant>(lane, ent2, ntab, zq0 + (sink & 0u), 200u, trips[which]);
+            for (int rep = 0; rep < 64; rep++) sink += kVariant == 3 ? run_scalar(lane, ent2, ntab, __builtin_amdgcn_readfirstlane(zq0), 200u, trips[which])
+                                                                   : run<kVariant>(lane, ent2, ntab, zq0 + (sink & 0u), 200u, trips[which]);
             dt[which] = tick() - t0;
         }
     if (lane == 0) {
@@ -168,11 +231,12 @@ __global__ void k(uint64_t *out, uint32_t seed) {
 int main() {
     uint64_t *d, h[5];
     hipMalloc(&d, sizeof h);
-    const char *names[3] = {"full loop (as shipped)", "chain only, gaps as s_nop", "chain through ds_bpermute"};
-    for (int v = 0; v < 3; v++) {
+    const char *names[4] = {"full loop (as shipped)", "chain only, gaps as s_nop", "chain through ds_bpermute", "chain on the scalar unit"};
+    for (int v = 0; v < 4; v++) {
         if (v == 0) k<0><<<1, 64>>>(d, 5);
         if (v == 1) k<1><<<1, 64>>>(d, 5);
         if (v == 2) k<2><<<1, 64>>>(d, 5);
+        if (v == 3) k<3><<<1, 64>>>(d, 5);
         hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
         // 64 entries of (fixed cost + n trips); the trip counts differ by 32 (+ the one that fails: the same in both)
         // two timed passes of 64 loop entries each (the counters run over both)

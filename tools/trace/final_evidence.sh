@@ -17,14 +17,14 @@ if [ "${1:-}" = "headline" ]; then
   cut -c1-200 gpurun_out/${TAG}_headline/bench.json
   exit 0
 fi
-bash tools/profile_pmc.sh $TAG --images 128 --steps 2 --warmup 1 --no-cpu-baseline --no-ingest --no-planar-pass > gpurun_out/pmc_$TAG.log 2>&1
+bash tools/trace/evidence_all.sh $TAG 2>&1 | tail -1   # (runs the PMC passes: tools/profile_pmc.sh)
 cp gpurun_out/pmc_$TAG/idct_traffic_entry.json profiles/idct_traffic.json
-bash tools/trace/evidence_all.sh $TAG 2>&1 | tail -1
 python3 tools/bench_encode.py --images 256 > gpurun_out/all_$TAG/bench_encode_256.json 2>/dev/null
 python3 tools/bench_encode.py --images 256 --dri 4 > gpurun_out/all_$TAG/bench_encode_256_dri4.json 2>/dev/null
 python3 tools/bench_optimize.py --images 256 > gpurun_out/all_$TAG/bench_optimize_256.json 2>/dev/null
 bash tools/trace/progressive_by_scan.sh 256 $R/gpurun_out/all_$TAG/progressive_by_scan_256.txt > /dev/null 2>&1
 bash tools/trace/progressive_by_scan.sh 2048 $R/gpurun_out/all_$TAG/progressive_by_scan_2048.txt > /dev/null 2>&1
 python3 tools/trace/multi_slots.py 256 3 $R/gpurun_out/all_$TAG/multi_slots.jsonl > gpurun_out/all_$TAG/multi_slots.txt 2>&1
-( cd tools/microbench && ./issue_latency > $R/gpurun_out/all_$TAG/issue_latency.txt 2>&1 )
+( cd tools/microbench && ./issue_latency > $R/gpurun_out/all_$TAG/issue_latency.txt 2>&1; ./fetch_rate 1 > $R/gpurun_out/all_$TAG/fetch_rate.txt 2>&1; ./symbol_loop > $R/gpurun_out/all_$TAG/symbol_loop.txt 2>&1 )
+timeout 600 bash tools/trace/progressive_pmc.sh 64 $R/gpurun_out/all_$TAG/progressive_pmc_64.txt > /dev/null 2>&1
 sha256sum jpeglibrary_amd/libjpgpu.so
