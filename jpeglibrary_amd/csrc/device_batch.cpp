@@ -1396,6 +1396,45 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         prog_work.insert(prog_work.end(), w.begin(), w.end());
         prog_stream_begin_.push_back((int)prog_work.size());
     }
+    // The pipelined launch's list.  Fewer waves is faster once there are more streams than SIMDs (256 x 4K frames x 10 scans on
+    // 1024 SIMDs: the long scans share their SIMD's issue slots with two or three others; 32 frames take 165 ms, 256 took 216):
+    // a scan whose ONLY producer is a cheap scan, and that is cheap itself, runs behind its producer in the same wave -- it
+    // could not have overtaken it anyway.  "Cheap": the wave's entropy bytes stay under half of the frame's largest scan (the
+    // long pole is left alone, and so is everything upstream of it that has two producers) and under 1 MiB (a follower in
+    // another wave waits for the whole producer now, inside its spin budget).  libjpeg's script: DC first -> DC refinement,
+    // Cr first -> Cr refinement, Cb first -> Cb refinement: 7 waves per frame instead of 10.
+    prog_pipe_begin_ = (int)prog_work.size();
+    {
+        static const bool no_wave_chains = getenv("JPGPU_PROG_NO_WAVE_CHAINS") != nullptr;
+        std::vector<uint8_t> is_tail(h_scans_.size(), 0);
+        for (const ImagePlan &img : images_) {
+            if (img.jobs.size() < 2 || no_wave_chains) continue;
+            const int j0 = img.jobs[0] + 1, n = (int)img.jobs.size() - 1;  // the frame job precedes its scans
+            uint64_t largest = 0;
+            for (int k = 0; k < n; k++)
+                if (jobs_[(size_t)(j0 + k)].kind == kScanProgressive) largest = std::max<uint64_t>(largest, jobs_[(size_t)(j0 + k)].entropy_len);
+            std::vector<uint64_t> wave_bytes((size_t)n, 0);  // of the wave that ENDS with scan k
+            std::vector<uint8_t> has_next((size_t)n, 0);
+            for (int k = 0; k < n; k++) {
+                const ScanJob &job = jobs_[(size_t)(j0 + k)];
+                if (job.kind != kScanProgressive) continue;
+                wave_bytes[(size_t)k] = job.entropy_len;
+                if (job.n_deps != 1 || job.deps[0] < 0 || job.deps[0] >= k) continue;
+                const int a = job.deps[0];
+                if (jobs_[(size_t)(j0 + a)].kind != kScanProgressive || has_next[(size_t)a] || k - a > 255) continue;
+                const uint64_t together = wave_bytes[(size_t)a] + job.entropy_len;
+                if (together > largest / 2 || together > (1u << 20)) continue;
+                h_scans_[(size_t)(j0 + a)].wave_next = (uint8_t)(k - a);
+                has_next[(size_t)a] = 1;
+                is_tail[(size_t)(j0 + k)] = 1;
+                wave_bytes[(size_t)k] = together;
+            }
+        }
+        for (const std::vector<HuffWork> &w : prog_streams_by_ordinal)
+            for (const HuffWork &hw : w)
+                if (!is_tail[hw.scan]) prog_work.push_back(hw);
+    }
+    prog_pipe_count_ = (int)prog_work.size() - prog_pipe_begin_;
     for (int x = 0; x < jpgpu_ctx::kProgChains; x++) {
         prog_chain_begin_[x].assign(1, (int)prog_work.size());
         for (const std::vector<HuffWork> &w : prog_chain_work[x]) {
@@ -1620,11 +1659,12 @@ int DeviceBatch::run_progressive() {
     //  - beyond: level by level (1024 frames: 832 vs 790-885 pipelined, run to run; 2048 frames: 1295 vs 1426 -- by then
     //    every level fills the machine on its own).
     const int n_streams = prog_stream_begin_.back() - prog_stream_begin_.front();
+    const int n_waves = prog_pipe_count_;  // of the pipelined launch (<= n_streams)
     const size_t lds_per_wg = (progressive_stream_lds_bytes(n_huff_slots_) + 1023) / 1024 * 1024;
     const int cus = ctx_->num_cus > 0 ? ctx_->num_cus : 256;
     const int per_cu = (int)std::min<size_t>(32, (160u << 10) / lds_per_wg);
     const bool force = getenv("JPGPU_PROG_FORCE_PIPELINE") != nullptr;  // experiments: pipelined without the gate, any size
-    const bool resident = n_streams <= per_cu * 3 / 4 * cus;
+    const bool resident = n_waves <= per_cu * 3 / 4 * cus;
     // (round 3, ADVICE r2: the ungated pipelined launch of grids up to 1.5 x what the CUs hold relied on workgroups starting in
     // list order; it is opt-in now -- JPGPU_PROG_FORCE_PIPELINE -- and larger batches take the chain launches below)
     const bool fits = resident || force;
@@ -1673,9 +1713,9 @@ int DeviceBatch::run_progressive() {
         // every scan is one stream: one launch, the work list ordered by level; dependent scans follow their producers' progress
         hipError_t e0 = hipMemsetAsync(d_prog_sync_.ptr, 0, 256, ctx_->stream);
         if (e0 != hipSuccess) return hip_fail(e0, "hipMemsetAsync(progressive sync)");
-        const int n = n_streams;
+        const int n = n_waves;
         hipError_t e = launch_progressive_streams(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr,
-                                                  (const HuffWork *)d_prog_work_.ptr + prog_stream_begin_.front(), n,
+                                                  (const HuffWork *)d_prog_work_.ptr + prog_pipe_begin_, n,
                                                   (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr,
                                                   (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, launch_mode, prog_spin_budget_, (uint32_t *)d_prog_sync_.ptr);
         if (e != hipSuccess) return hip_fail(e, "progressive_stream_kernel");

@@ -226,6 +226,9 @@ class DeviceBatch {
     std::vector<int> prog_begin_;
     // ... and the scans with few, long intervals (one wave per interval): prog_work[prog_stream_begin_[k] .. [k + 1])
     std::vector<int> prog_stream_begin_;
+    // ... and the pipelined launch's own list: one entry per WAVE (a scan that only follows one cheap scan runs behind it in
+    // that scan's wave, DevScan::wave_next): prog_work[prog_pipe_begin_ .. prog_pipe_begin_ + prog_pipe_count_)
+    int prog_pipe_begin_ = 0, prog_pipe_count_ = 0;
     // ... and the same stream work once more, grouped by chain (0 = DC scans, 1 + c = the AC scans of frame component c) and by
     // the scan's ordinal inside its frame's chain: prog_work[prog_chain_begin_[x][j] .. [x][j + 1])
     std::vector<int> prog_chain_begin_[jpgpu_ctx::kProgChains];

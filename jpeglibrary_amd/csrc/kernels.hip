@@ -1520,6 +1520,12 @@ constexpr uint32_t kPsNoBlock = 0xFFFFFFFFu;
 constexpr uint32_t kPsBadCode = 17u << 8;  // window entry: no code of 16 bits or less matches
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// the wave's LDS accesses so far are complete before those behind this line start (one wave per workgroup: no s_barrier)
+#define PS_WAVE_SYNC()                                        \
+    do {                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+        __builtin_amdgcn_wave_barrier();                      \
+    } while (0)
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -2542,9 +2548,170 @@ __device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, cons
 // correction bits (~25).  What it does not do -- rebuild the window, decode a code longer than the lookup, a run that
 // outlasts the band -- it hands back (status 1) with all of its state in registers, and is re-entered at the loop (`resume`
 // 1) or at the correction bits (2) once the C++ below has dealt with it.
-__device__ __forceinline__ uint32_t w_ac_refine_v5(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, int32_t p1,
-                                                   int32_t m1, uint32_t inband /* all ones in the lanes Ss..Se */, uint32_t &eobrun,
-                                                   int32_t &c, bool &mine) {
+// the per-lane constants of the sequence, made once per stream and held in registers (hipcc would otherwise re-materialise
+// them in front of every block)
+struct R5Consts {
+    uint32_t lane, inband /* all ones in the lanes Ss..Se */, p1, m1, none, zrl, noz;
+};
+__device__ __forceinline__ R5Consts r5_consts(uint32_t lane, uint64_t band, int32_t p1, int32_t m1) {
+    R5Consts k;
+    k.lane = lane;
+    k.inband = ((band >> lane) & 1ull) != 0 ? 0xFFFFFFFFu : 0u;
+    k.p1 = (uint32_t)p1;
+    k.m1 = (uint32_t)m1;
+    k.none = 0xFFFFu;
+    k.zrl = kR4Zrl;
+    k.noz = kR4NoZero;
+    asm volatile("" : "+v"(k.lane), "+v"(k.inband), "+v"(k.p1), "+v"(k.m1), "+v"(k.none), "+v"(k.zrl), "+v"(k.noz));
+    return k;
+}
+#define JPGPU_R5_PROLOGUE \
+    /* ---- prologue: the band's non-zero coefficients (ranks, count) and its zeros (ranks, count); the zero table -- */ \
+    /* lane r: Ss + the number of non-zero coefficients below the r-th zero -- by one ds_permute */ \
+    "v_and_b32_e32 %[x0], %[c], %[inb]\n\t" \
+    "v_not_b32_e32 %[x1], %[inb]\n\t" \
+    "v_or_b32_e32 %[x1], %[x1], %[c]\n\t" \
+    "v_cmp_ne_u32_e32 vcc, 0, %[x0]\n\t" \
+    "v_mov_b32_e32 %[cv], %[c]\n\t" \
+    "v_mov_b32_e32 %[symbits], 0\n\t" \
+    "v_mbcnt_lo_u32_b32 %[nrank], vcc_lo, 0\n\t" \
+    "v_mbcnt_hi_u32_b32 %[nrank], vcc_hi, %[nrank]\n\t" \
+    "v_bcnt_u32_b32 %[nnz], vcc_lo, 0\n\t" \
+    "v_bcnt_u32_b32 %[nnz], vcc_hi, %[nnz]\n\t" \
+    "v_cmp_eq_u32_e32 vcc, 0, %[x1]\n\t" \
+    "v_mov_b32_e32 %[bits], 0\n\t" \
+    "v_add_u32_e32 %[x3], %[ss], %[nrank]\n\t" \
+    "v_mbcnt_lo_u32_b32 %[x0], vcc_lo, 0\n\t" \
+    "v_mbcnt_hi_u32_b32 %[x0], vcc_hi, %[x0]\n\t"  /* rank among the zeros */ \
+    "v_bcnt_u32_b32 %[x1], vcc_lo, 0\n\t" \
+    "v_bcnt_u32_b32 %[x1], vcc_hi, %[x1]\n\t"  /* zeros in the band */ \
+    "v_sub_u32_e32 %[x2], %[lane], %[x0]\n\t" \
+    "v_add_u32_e32 %[x2], %[x2], %[x1]\n\t" \
+    "v_cndmask_b32_e32 %[x2], %[x2], %[x0], vcc\n\t"  /* r-th zero -> lane r, the others behind (a permutation) */ \
+    "v_lshlrev_b32_e32 %[x2], 2, %[x2]\n\t" \
+    "ds_permute_b32 %[ntab], %[x2], %[x3]\n\t" \
+    "v_mov_b32_e32 %[cur], %[cur0]\n\t" \
+    "v_subrev_u32_e32 %[base], %[ss], %[cur]\n\t"  /* a symbol's window offset = base + code bits before it + ntab[zeros before it] */ \
+    "v_mov_b32_e32 %[zq], -1\n\t" \
+    "v_add_u32_e64 %[kprev], %[ss], -1\n\t" \
+    "v_cmp_gt_u32_e32 vcc, %[x1], %[lane]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_cndmask_b32_e32 %[ntab], %[noz], %[ntab], vcc\n\t"  /* no such zero: the run outlasts the band */ \
+    "v_cmp_ne_u32_e32 vcc, 0, %[eobv]\n\t"  /* inside an end-of-band run: correction bits only */ \
+    "s_cbranch_vccnz 5f\n\t"
+#define JPGPU_R5_LOOP_TAIL_END \
+    /* ---- the symbol loop (fourth form): one symbol per trip; the previous symbol's commits fill the hazard gaps */ \
+    "2:\n\t" \
+    "v_mov_b32_e32 %[stop], %[none]\n\t" \
+    "s_mov_b32 %[se_], 0\n\t" \
+    "s_mov_b64 %[sok], 0\n\t" \
+    "s_mov_b64 %[spb], 0\n\t" \
+    "1:\n\t" \
+    "v_readfirstlane_b32 %[scur], %[cur]\n\t" \
+    "v_and_or_b32 %[x5], %[se_], %[zrl], %[stop]\n\t" \
+    "v_cndmask_b32_e64 %[symbits], %[symbits], %[x3], %[sok]\n\t" \
+    "v_cmp_eq_u32_e64 %[spp], %[lane], %[x5]\n\t" \
+    "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t" \
+    "v_readlane_b32 %[se_], %[ent2], %[scur]\n\t" \
+    "v_cndmask_b32_e64 %[kprev], %[kprev], %[x9], %[sok]\n\t" \
+    "v_cndmask_b32_e64 %[zq], %[zq], %[x2], %[sok]\n\t" \
+    "v_bfe_u32 %[x0], %[se_], 6, 7\n\t" \
+    "v_cndmask_b32_e64 %[cv], %[cv], %[x8], %[spp]\n\t" \
+    "v_add_u32_e32 %[x2], %[zq], %[x0]\n\t"  /* x2 = t: rank of the zero the symbol's run ends on */ \
+    "v_min_u32_e32 %[x1], 63, %[x2]\n\t" \
+    "v_and_b32_e64 %[x4], 63, %[se_]\n\t" \
+    "v_readfirstlane_b32 %[st], %[x1]\n\t" \
+    "v_add_u32_e32 %[x3], %[symbits], %[x4]\n\t"  /* x3 = symn */ \
+    "v_bfe_u32 %[x8], %[se_], 14, 16\n\t"  /* x8 = the new coefficient */ \
+    "v_cmp_gt_u32_e64 %[spb], %[lane], %[kprev]\n\t" \
+    "s_nop 0\n\t" \
+    "v_readlane_b32 %[sn], %[ntab], %[st]\n\t" \
+    "s_nop 1\n\t" \
+    "v_add3_u32 %[x6], %[base], %[x3], %[sn]\n\t"  /* x6 = curn */ \
+    "v_or3_b32 %[x7], %[x2], %[cur], %[sn]\n\t" \
+    "v_cmp_gt_u32_e64 %[sok], 64, %[x7]\n\t" \
+    "v_add_u32_e32 %[x9], %[sn], %[x2]\n\t"  /* x9 = stopr */ \
+    "s_nop 0\n\t" \
+    "v_cndmask_b32_e64 %[cur], %[cur], %[x6], %[sok]\n\t" \
+    "v_cndmask_b32_e64 %[stop], %[none], %[x9], %[sok]\n\t" \
+    "v_cmp_gt_u32_e32 vcc, %[se], %[stop]\n\t" \
+    "s_cbranch_vccnz 1b\n\t" \
+    "v_and_or_b32 %[x5], %[se_], %[zrl], %[stop]\n\t" \
+    "v_cndmask_b32_e64 %[symbits], %[symbits], %[x3], %[sok]\n\t" \
+    "v_cmp_eq_u32_e64 %[spp], %[lane], %[x5]\n\t" \
+    "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t" \
+    "v_cndmask_b32_e64 %[kprev], %[kprev], %[x9], %[sok]\n\t" \
+    "v_cndmask_b32_e64 %[zq], %[zq], %[x2], %[sok]\n\t" \
+    "v_cndmask_b32_e64 %[cv], %[cv], %[x8], %[spp]\n\t" \
+    /* what stopped the loop?  EOBn found in the lookup is applied here (fourth form's tail) */ \
+    "v_readlane_b32 %[sn], %[peek], %[scur]\n\t" \
+    "v_bfe_u32 %[x0], %[se_], 6, 5\n\t" \
+    "v_and_b32_e64 %[x4], 63, %[se_]\n\t" \
+    "v_add_u32_e32 %[x0], -1, %[x0]\n\t" \
+    "v_lshlrev_b32_e64 %[x7], %[x4], %[sn]\n\t" \
+    "v_sub_u32_e32 %[x1], 32, %[x0]\n\t" \
+    "v_bfe_u32 %[x7], %[x7], %[x1], %[x0]\n\t" \
+    "v_lshlrev_b32_e64 %[x6], %[x0], 1\n\t" \
+    "v_add_u32_e32 %[x6], %[x6], %[x7]\n\t"  /* the end-of-band run */ \
+    "v_add3_u32 %[x3], %[symbits], %[x4], %[x0]\n\t" \
+    "v_lshrrev_b32_e32 %[x5], 6, %[cur]\n\t" \
+    "v_bfe_u32 %[x7], %[se_], 30, 1\n\t" \
+    "v_xor_b32_e32 %[x7], 1, %[x7]\n\t" \
+    "v_or_b32_e32 %[x5], %[x5], %[x7]\n\t" \
+    "v_cmp_eq_u32_e64 %[spp], %[stop], %[none]\n\t" \
+    "v_cmp_gt_u32_e64 %[spb], %[lane], %[kprev]\n\t" \
+    "s_nop 0\n\t" \
+    "v_cndmask_b32_e64 %[slow], 0, %[x5], %[spp]\n\t" \
+    "v_cndmask_b32_e64 %[x5], 1, %[x5], %[spp]\n\t" \
+    "v_cmp_eq_u32_e64 %[sok], 0, %[x5]\n\t" \
+    "v_cmp_ne_u32_e32 vcc, 0, %[slow]\n\t" \
+    "s_nop 0\n\t" \
+    "v_cndmask_b32_e64 %[symbits], %[symbits], %[x3], %[sok]\n\t" \
+    "v_cndmask_b32_e64 %[eobv], 0, %[x6], %[sok]\n\t" \
+    "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t" \
+    "v_mov_b32_e32 %[status], 1\n\t" \
+    "s_cbranch_vccnz 9f\n\t"  /* something for the C++ below */ \
+    /* ---- the block's end: this block counts against the run; every coefficient of the band that was non-zero takes */ \
+    /* exactly one correction bit, behind the code bits noted for its lane, in rank order */ \
+    "5:\n\t" \
+    "v_sub_u32_e64 %[eobv], %[eobv], 1 clamp\n\t" \
+    "v_add3_u32 %[x0], %[pos0], %[bits], %[nrank]\n\t" \
+    "v_lshrrev_b32_e32 %[x1], 5, %[x0]\n\t" \
+    "v_and_b32_e32 %[x1], %[wmask], %[x1]\n\t" \
+    "v_lshl_add_u32 %[x1], %[x1], 2, %[ring]\n\t" \
+    "ds_read_b32 %[x1], %[x1]\n\t" \
+    "v_not_b32_e32 %[x0], %[x0]\n\t" \
+    "v_and_b32_e32 %[x2], %[c], %[inb]\n\t" \
+    "v_and_b32_e32 %[x3], %[p1v], %[c]\n\t" \
+    "v_cmp_ne_u32_e64 %[spp], 0, %[x2]\n\t"  /* was non-zero, in the band */ \
+    "v_cmp_eq_u32_e64 %[sok], 0, %[x3]\n\t"  /* this bit not set yet */ \
+    "v_cmp_gt_i32_e64 %[spb], 0, %[c]\n\t" \
+    "v_add_u32_e32 %[consumed], %[symbits], %[nnz]\n\t" \
+    "v_mov_b32_e32 %[status], 0\n\t" \
+    "v_cndmask_b32_e64 %[x2], %[p1v], %[m1v], %[spb]\n\t" \
+    "v_cndmask_b32_e64 %[x2], 0, %[x2], %[sok]\n\t" \
+    "v_cndmask_b32_e64 %[x2], 0, %[x2], %[spp]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_lshrrev_b32_e32 %[x1], %[x0], %[x1]\n\t" \
+    "v_bfe_i32 %[x1], %[x1], 0, 1\n\t" \
+    "v_and_b32_e32 %[x2], %[x2], %[x1]\n\t" \
+    "v_add_u32_e32 %[cn], %[cv], %[x2]\n\t" \
+    "v_bfe_i32 %[cn], %[cn], 0, 16\n\t" \
+    "9:\n\t"
+#define JPGPU_R5_OPERANDS \
+    : [cv] "+v"(cv), [eobv] "+v"(eobv), [cur] "+v"(cur), [zq] "+v"(zq), [symbits] "+v"(symbits), [kprev] "+v"(kprev), \
+    [bits] "+v"(bits), [ntab] "+v"(ntab), [nrank] "+v"(nrank), [nnz] "+v"(nnz), [base] "+v"(base), [stop] "=&v"(stop), \
+    [slow] "=&v"(slow), [status] "=&v"(status), [consumed] "=&v"(consumed), [cn] "=&v"(cn), [scur] "=&s"(scur), [st] "=&s"(st), \
+    [sn] "=&s"(sn), [se_] "=&s"(se_), [sok] "=&s"(sok), [spb] "=&s"(spb), [spp] "=&s"(spp), [x0] "=&v"(x0), [x1] "=&v"(x1), \
+    [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [x5] "=&v"(x5), [x6] "=&v"(x6), [x7] "=&v"(x7), [x8] "=&v"(x8), [x9] "=&v"(x9) \
+    : [c] "v"(c), [inb] "v"(k.inband), [ent2] "v"(d.ent2), [peek] "v"(d.peek), [lane] "v"(k.lane), [p1v] "v"(k.p1), [m1v] "v"(k.m1), \
+    [none] "v"(k.none), [zrl] "v"(k.zrl), [noz] "v"(k.noz), [ss] "s"(ss), [se] "s"(se), [pos0] "s"(blockpos), \
+    [cur0] "s"(cur0), [wmask] "s"(wmask), [ring] "s"(ring_lds), [resume] "s"(resume_s)
+
+// `eobv`: the end-of-band run, kept in a vector register from block to block (the same in all lanes).
+__device__ __forceinline__ uint32_t w_ac_refine_v5(WBits &d, const R5Consts &k, const LdsHuff &hac, uint32_t ss, uint32_t se, int32_t p1,
+                                                   int32_t m1, uint32_t &eobv, int32_t &c, bool &mine) {
+    const uint32_t lane = k.lane;
     ss = uni(ss);
     se = uni(se);
     const uint32_t blockpos = uni(d.pos), cur0 = uni(d.cur), wmask = uni(d.wmask);
@@ -2555,163 +2722,21 @@ __device__ __forceinline__ uint32_t w_ac_refine_v5(WBits &d, uint32_t lane, cons
         asm volatile("" : "=v"(x));  // (a register, no instruction: the sequence below sets it)
         return x;
     };
-    uint32_t cv = undefined(), eobv = eobrun, cur = undefined(), zq = undefined(), symbits = undefined(), kprev = undefined(),
-             bits = undefined(), ntab = undefined(), nrank = undefined(), nnz = undefined(), base = undefined();
-    uint32_t status, consumed, cn;
-    // (one way round the loop and one way out of it: with a `return` or a `break` in the middle hipcc turns the exits into a
-    // state variable and a dozen scalar branches that every block would walk through)
-    uint32_t resume = 0, fail = 0;
-    do {
+    uint32_t cv = undefined(), cur = undefined(), zq = undefined(), symbits = undefined(), kprev = undefined(), bits = undefined(),
+             ntab = undefined(), nrank = undefined(), nnz = undefined(), base = undefined();
+    uint32_t status, consumed, cn, fail = 0;
+    {
         uint32_t stop, slow, scur, st, sn, se_, x0, x1, x2, x3, x4, x5, x6, x7, x8, x9;
         uint64_t sok, spb, spp;
-        asm volatile(
-            "s_cmp_eq_u32 %[resume], 1\n\t"
-            "s_cbranch_scc1 2f\n\t"
-            "s_cmp_eq_u32 %[resume], 2\n\t"
-            "s_cbranch_scc1 5f\n\t"
-            // ---- prologue: the band's non-zero coefficients (ranks, count) and its zeros (ranks, count); the zero table --
-            // lane r: Ss + the number of non-zero coefficients below the r-th zero -- by one ds_permute
-            "v_and_b32_e32 %[x0], %[c], %[inb]\n\t"
-            "v_not_b32_e32 %[x1], %[inb]\n\t"
-            "v_or_b32_e32 %[x1], %[x1], %[c]\n\t"
-            "v_cmp_ne_u32_e32 vcc, 0, %[x0]\n\t"
-            "v_mov_b32_e32 %[cv], %[c]\n\t"
-            "v_mov_b32_e32 %[symbits], 0\n\t"
-            "v_mbcnt_lo_u32_b32 %[nrank], vcc_lo, 0\n\t"
-            "v_mbcnt_hi_u32_b32 %[nrank], vcc_hi, %[nrank]\n\t"
-            "v_bcnt_u32_b32 %[nnz], vcc_lo, 0\n\t"
-            "v_bcnt_u32_b32 %[nnz], vcc_hi, %[nnz]\n\t"
-            "v_cmp_eq_u32_e32 vcc, 0, %[x1]\n\t"
-            "v_mov_b32_e32 %[bits], 0\n\t"
-            "v_add_u32_e32 %[x3], %[ss], %[nrank]\n\t"
-            "v_mbcnt_lo_u32_b32 %[x0], vcc_lo, 0\n\t"
-            "v_mbcnt_hi_u32_b32 %[x0], vcc_hi, %[x0]\n\t"        // rank among the zeros
-            "v_bcnt_u32_b32 %[x1], vcc_lo, 0\n\t"
-            "v_bcnt_u32_b32 %[x1], vcc_hi, %[x1]\n\t"            // zeros in the band
-            "v_sub_u32_e32 %[x2], %[lane], %[x0]\n\t"
-            "v_add_u32_e32 %[x2], %[x2], %[x1]\n\t"
-            "v_cndmask_b32_e32 %[x2], %[x2], %[x0], vcc\n\t"      // r-th zero -> lane r, the others behind (a permutation)
-            "v_lshlrev_b32_e32 %[x2], 2, %[x2]\n\t"
-            "ds_permute_b32 %[ntab], %[x2], %[x3]\n\t"
-            "v_mov_b32_e32 %[cur], %[cur0]\n\t"
-            "v_subrev_u32_e32 %[base], %[ss], %[cur]\n\t"         // a symbol's window offset = base + code bits before it + ntab[zeros before it]
-            "v_mov_b32_e32 %[zq], -1\n\t"
-            "v_add_u32_e64 %[kprev], %[ss], -1\n\t"
-            "v_cmp_gt_u32_e32 vcc, %[x1], %[lane]\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_cndmask_b32_e32 %[ntab], %[noz], %[ntab], vcc\n\t"  // no such zero: the run outlasts the band
-            "v_cmp_ne_u32_e32 vcc, 0, %[eobv]\n\t"                 // inside an end-of-band run: correction bits only
-            "s_cbranch_vccnz 5f\n\t"
-            // ---- the symbol loop (fourth form): one symbol per trip; the previous symbol's commits fill the hazard gaps
-            "2:\n\t"
-            "v_mov_b32_e32 %[stop], %[none]\n\t"
-            "s_mov_b32 %[se_], 0\n\t"
-            "s_mov_b64 %[sok], 0\n\t"
-            "s_mov_b64 %[spb], 0\n\t"
-            "1:\n\t"
-            "v_readfirstlane_b32 %[scur], %[cur]\n\t"
-            "v_and_or_b32 %[x5], %[se_], %[zrl], %[stop]\n\t"
-            "v_cndmask_b32_e64 %[symbits], %[symbits], %[x3], %[sok]\n\t"
-            "v_cmp_eq_u32_e64 %[spp], %[lane], %[x5]\n\t"
-            "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t"
-            "v_readlane_b32 %[se_], %[ent2], %[scur]\n\t"
-            "v_cndmask_b32_e64 %[kprev], %[kprev], %[x9], %[sok]\n\t"
-            "v_cndmask_b32_e64 %[zq], %[zq], %[x2], %[sok]\n\t"
-            "v_bfe_u32 %[x0], %[se_], 6, 7\n\t"
-            "v_cndmask_b32_e64 %[cv], %[cv], %[x8], %[spp]\n\t"
-            "v_add_u32_e32 %[x2], %[zq], %[x0]\n\t"               // x2 = t: rank of the zero the symbol's run ends on
-            "v_min_u32_e32 %[x1], 63, %[x2]\n\t"
-            "v_and_b32_e64 %[x4], 63, %[se_]\n\t"
-            "v_readfirstlane_b32 %[st], %[x1]\n\t"
-            "v_add_u32_e32 %[x3], %[symbits], %[x4]\n\t"          // x3 = symn
-            "v_bfe_u32 %[x8], %[se_], 14, 16\n\t"                 // x8 = the new coefficient
-            "v_cmp_gt_u32_e64 %[spb], %[lane], %[kprev]\n\t"
-            "s_nop 0\n\t"
-            "v_readlane_b32 %[sn], %[ntab], %[st]\n\t"
-            "s_nop 1\n\t"
-            "v_add3_u32 %[x6], %[base], %[x3], %[sn]\n\t"         // x6 = curn
-            "v_or3_b32 %[x7], %[x2], %[cur], %[sn]\n\t"
-            "v_cmp_gt_u32_e64 %[sok], 64, %[x7]\n\t"
-            "v_add_u32_e32 %[x9], %[sn], %[x2]\n\t"               // x9 = stopr
-            "s_nop 0\n\t"
-            "v_cndmask_b32_e64 %[cur], %[cur], %[x6], %[sok]\n\t"
-            "v_cndmask_b32_e64 %[stop], %[none], %[x9], %[sok]\n\t"
-            "v_cmp_gt_u32_e32 vcc, %[se], %[stop]\n\t"
-            "s_cbranch_vccnz 1b\n\t"
-            "v_and_or_b32 %[x5], %[se_], %[zrl], %[stop]\n\t"
-            "v_cndmask_b32_e64 %[symbits], %[symbits], %[x3], %[sok]\n\t"
-            "v_cmp_eq_u32_e64 %[spp], %[lane], %[x5]\n\t"
-            "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t"
-            "v_cndmask_b32_e64 %[kprev], %[kprev], %[x9], %[sok]\n\t"
-            "v_cndmask_b32_e64 %[zq], %[zq], %[x2], %[sok]\n\t"
-            "v_cndmask_b32_e64 %[cv], %[cv], %[x8], %[spp]\n\t"
-            // what stopped the loop?  EOBn found in the lookup is applied here (fourth form's tail)
-            "v_readlane_b32 %[sn], %[peek], %[scur]\n\t"
-            "v_bfe_u32 %[x0], %[se_], 6, 5\n\t"
-            "v_and_b32_e64 %[x4], 63, %[se_]\n\t"
-            "v_add_u32_e32 %[x0], -1, %[x0]\n\t"
-            "v_lshlrev_b32_e64 %[x7], %[x4], %[sn]\n\t"
-            "v_sub_u32_e32 %[x1], 32, %[x0]\n\t"
-            "v_bfe_u32 %[x7], %[x7], %[x1], %[x0]\n\t"
-            "v_lshlrev_b32_e64 %[x6], %[x0], 1\n\t"
-            "v_add_u32_e32 %[x6], %[x6], %[x7]\n\t"               // the end-of-band run
-            "v_add3_u32 %[x3], %[symbits], %[x4], %[x0]\n\t"
-            "v_lshrrev_b32_e32 %[x5], 6, %[cur]\n\t"
-            "v_bfe_u32 %[x7], %[se_], 30, 1\n\t"
-            "v_xor_b32_e32 %[x7], 1, %[x7]\n\t"
-            "v_or_b32_e32 %[x5], %[x5], %[x7]\n\t"
-            "v_cmp_eq_u32_e64 %[spp], %[stop], %[none]\n\t"
-            "v_cmp_gt_u32_e64 %[spb], %[lane], %[kprev]\n\t"
-            "s_nop 0\n\t"
-            "v_cndmask_b32_e64 %[slow], 0, %[x5], %[spp]\n\t"
-            "v_cndmask_b32_e64 %[x5], 1, %[x5], %[spp]\n\t"
-            "v_cmp_eq_u32_e64 %[sok], 0, %[x5]\n\t"
-            "v_cmp_ne_u32_e32 vcc, 0, %[slow]\n\t"
-            "s_nop 0\n\t"
-            "v_cndmask_b32_e64 %[symbits], %[symbits], %[x3], %[sok]\n\t"
-            "v_cndmask_b32_e64 %[eobv], 0, %[x6], %[sok]\n\t"
-            "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t"
-            "v_mov_b32_e32 %[status], 1\n\t"
-            "s_cbranch_vccnz 9f\n\t"                               // something for the C++ below
-            // ---- the block's end: this block counts against the run; every coefficient of the band that was non-zero takes
-            // exactly one correction bit, behind the code bits noted for its lane, in rank order
-            "5:\n\t"
-            "v_sub_u32_e64 %[eobv], %[eobv], 1 clamp\n\t"
-            "v_add3_u32 %[x0], %[pos0], %[bits], %[nrank]\n\t"
-            "v_lshrrev_b32_e32 %[x1], 5, %[x0]\n\t"
-            "v_and_b32_e32 %[x1], %[wmask], %[x1]\n\t"
-            "v_lshl_add_u32 %[x1], %[x1], 2, %[ring]\n\t"
-            "ds_read_b32 %[x1], %[x1]\n\t"
-            "v_not_b32_e32 %[x0], %[x0]\n\t"
-            "v_and_b32_e32 %[x2], %[c], %[inb]\n\t"
-            "v_and_b32_e32 %[x3], %[p1v], %[c]\n\t"
-            "v_cmp_ne_u32_e64 %[spp], 0, %[x2]\n\t"               // was non-zero, in the band
-            "v_cmp_eq_u32_e64 %[sok], 0, %[x3]\n\t"               // this bit not set yet
-            "v_cmp_gt_i32_e64 %[spb], 0, %[c]\n\t"
-            "v_add_u32_e32 %[consumed], %[symbits], %[nnz]\n\t"
-            "v_mov_b32_e32 %[status], 0\n\t"
-            "v_cndmask_b32_e64 %[x2], %[p1v], %[m1v], %[spb]\n\t"
-            "v_cndmask_b32_e64 %[x2], 0, %[x2], %[sok]\n\t"
-            "v_cndmask_b32_e64 %[x2], 0, %[x2], %[spp]\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_lshrrev_b32_e32 %[x1], %[x0], %[x1]\n\t"
-            "v_bfe_i32 %[x1], %[x1], 0, 1\n\t"
-            "v_and_b32_e32 %[x2], %[x2], %[x1]\n\t"
-            "v_add_u32_e32 %[cn], %[cv], %[x2]\n\t"
-            "v_bfe_i32 %[cn], %[cn], 0, 16\n\t"
-            "9:\n\t"
-            : [cv] "+v"(cv), [eobv] "+v"(eobv), [cur] "+v"(cur), [zq] "+v"(zq), [symbits] "+v"(symbits), [kprev] "+v"(kprev),
-              [bits] "+v"(bits), [ntab] "+v"(ntab), [nrank] "+v"(nrank), [nnz] "+v"(nnz), [base] "+v"(base), [stop] "=&v"(stop),
-              [slow] "=&v"(slow), [status] "=&v"(status), [consumed] "=&v"(consumed), [cn] "=&v"(cn), [scur] "=&s"(scur), [st] "=&s"(st),
-              [sn] "=&s"(sn), [se_] "=&s"(se_), [sok] "=&s"(sok), [spb] "=&s"(spb), [spp] "=&s"(spp), [x0] "=&v"(x0), [x1] "=&v"(x1),
-              [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [x5] "=&v"(x5), [x6] "=&v"(x6), [x7] "=&v"(x7), [x8] "=&v"(x8), [x9] "=&v"(x9)
-            : [c] "v"(c), [inb] "v"(inband), [ent2] "v"(d.ent2), [peek] "v"(d.peek), [lane] "v"(lane), [p1v] "v"(p1), [m1v] "v"(m1),
-              [none] "v"(0xFFFFu), [zrl] "v"(kR4Zrl), [noz] "v"(kR4NoZero), [ss] "s"(ss), [se] "s"(se), [pos0] "s"(blockpos),
-              [cur0] "s"(cur0), [wmask] "s"(wmask), [ring] "s"(ring_lds), [resume] "s"(uni(resume))
-            : "vcc", "scc", "memory");
-        resume = 0;
-        if (uni(status) != 0) {
-            // ---- handed back: the window is used up, or one symbol by hand
+        const uint32_t resume_s = 0;  // (not read on this path)
+        asm volatile(JPGPU_R5_PROLOGUE JPGPU_R5_LOOP_TAIL_END JPGPU_R5_OPERANDS : "vcc", "scc", "memory");
+    }
+    if (uni(status) != 0) {
+        // ---- handed back (about one block in five): the window is used up, or one symbol by hand; then in again at the loop
+        // (1) or at the correction bits (2).  One way round this loop and one way out of it: with a `return` or a `break` in the
+        // middle hipcc turns the exits into a state variable and a dozen scalar branches.
+        uint32_t resume = 1;
+        do {
             cur = uni(cur);
             zq = uni(zq);
             symbits = uni(symbits);
@@ -2733,7 +2758,7 @@ __device__ __forceinline__ uint32_t w_ac_refine_v5(WBits &d, uint32_t lane, cons
                 const uint32_t size = raw >> 8, r2 = (raw >> 4) & 15u;
                 if (raw >= kPsBadCode) {
                     fail = kDetailInvalidHuffmanCode;
-                    resume = 0;
+                    resume = 2;  // (out through the block's end; the result is not used)
                 } else if (e2 >= kR4Special) {  // EOBn (:337-350): the run's low bits follow the code; the tail's lanes come behind all of it
                     eobv = (1u << r2) + (uint32_t)(((uint64_t)(pk << size) << r2) >> 32);
                     symbits += size + r2;
@@ -2753,10 +2778,17 @@ __device__ __forceinline__ uint32_t w_ac_refine_v5(WBits &d, uint32_t lane, cons
                     resume = on ? 1u : 2u;
                 }
             }
-        }
-    } while (resume != 0);
+            uint32_t stop, slow, scur, st, sn, se_, x0, x1, x2, x3, x4, x5, x6, x7, x8, x9;
+            uint64_t sok, spb, spp;
+            const uint32_t resume_s = uni(resume);
+            asm volatile(
+                "s_cmp_eq_u32 %[resume], 2\n\t"
+                "s_cbranch_scc1 5f\n\t"
+                JPGPU_R5_LOOP_TAIL_END JPGPU_R5_OPERANDS
+                : "vcc", "scc", "memory");
+        } while (uni(status) != 0);
+    }
     if (fail != 0) return fail;
-    eobrun = uni(eobv);
     d.pos = blockpos + uni(consumed);
     d.cur = d.pos - winpos;
     mine = (int32_t)cn != c;  // a new coefficient is never 0, a correction never leaves the value alone
@@ -2766,12 +2798,13 @@ __device__ __forceinline__ uint32_t w_ac_refine_v5(WBits &d, uint32_t lane, cons
 constexpr int32_t kPsFastBits = 2560;  // more than any block can consume: 63 x (16 + 16) + 14 (first), 63 x 17 + 63 + 14 (refinement)
 
 
-__global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
-                                                                const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
-                                                                DevScanStatus *__restrict__ status,
-                                                                const DevHuffTable *__restrict__ huff_pool, int16_t *__restrict__ coefs,
-                                                                int n_slots, int pipelined, uint32_t spin_budget, uint32_t ring_bytes,
-                                                                uint32_t chunk_blocks, uint32_t *__restrict__ started) {
+// One scan (one restart interval of it) on the calling wave; the kernel below runs it for its work item and, in the pipelined
+// launch, for the scans chained behind that one (DevScan::wave_next).
+__device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans, HuffWork wk,
+                                            const uint32_t *__restrict__ ends_u, DevScanStatus *__restrict__ status,
+                                            const DevHuffTable *__restrict__ huff_pool, int16_t *__restrict__ coefs, int n_slots,
+                                            int pipelined, uint32_t spin_budget, uint32_t ring_bytes, uint32_t chunk_blocks,
+                                            uint32_t *__restrict__ started, bool first_in_wave) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *tabs = smem;  // n_slots * sizeof(DevHuffTable)
     uint8_t *base = smem + (size_t)n_slots * sizeof(DevHuffTable);
@@ -2780,9 +2813,9 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
     int16_t *stage = reinterpret_cast<int16_t *>(base + kPsRingBytes);
     uint32_t *idx = reinterpret_cast<uint32_t *>(base + kPsRingBytes + kPsChunk * 128);
 
-    const HuffWork wk = work[blockIdx.x];
     const DevScan &s = scans[wk.scan];
     const uint32_t lane = threadIdx.x;
+    PS_WAVE_SYNC();  // (a chained scan: the previous one's LDS reads are done)
     for (int slot = 0; slot < kMaxHuffSlots && slot < n_slots; slot++) {
         const uint32_t pi = s.huff_pool[slot];
         if (pi == 0xFFFF) continue;
@@ -2894,7 +2927,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
     // (Larger grids do work on MI355X as dispatched today -- workgroups start in work-list order, producers first -- and
     // JPGPU_PROG_FORCE_PIPELINE=1 runs them that way, skipping the count-in; measured no faster than level by level.)
     if (pipelined != 0) {
-        if (lane == 0) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && first_in_wave) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (dep_scan[0] != kNoDep && pipelined != 2) {  // pipelined == 2: a grid that is not resident (JPGPU_PROG_FORCE_PIPELINE)
             uint32_t polls = spin_budget < 4096u ? spin_budget : 4096u;
             for (;;) {
@@ -2943,7 +2976,23 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
         if (lane == 0) __hip_atomic_store(my_progress, (units_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   \
     }
-    constexpr uint32_t kPsPublishEvery = 64;
+    // How often?  A release is a write-back of the XCD's L2 -- of every wave's dirty lines, not only the publisher's -- so its
+    // cost grows with the batch: with the first scans and the DC scans publishing every 64 units a 256-frame launch took 214 ms
+    // against 165 ms for 32 frames; at 512 it takes 178 (tools/trace/progressive_ablation.sh, PIPELINED=1).  A follower only
+    // needs whole MCU rows (480 luma blocks in a 4K frame), so it loses nothing but a row of lag.
+    // The REFINEMENT scans keep their 32 blocks: they are one publisher in ten and cost nothing measurable (178.7 vs 178.4 ms),
+    // and with 256 the forced, oversubscribed launch of tests/...test_dc_refinement_beside_ac_scans_of_the_same_frame (1024
+    // frames, tools/trace/race_probe.sh) decodes 1-7 of its last hundred frames wrongly in most passes -- the frames that start
+    // as the machine drains, their scans neck and neck.  NOT UNDERSTOOD: agent-scope (sc1) loads and stores of the coefficients,
+    // a write-back in front of the follower's invalidate and 140 us between the producer's write-back and its progress word all
+    // left it as it was; with 32 blocks twelve passes of the same probe (and every earlier round's runs) are clean.
+#ifndef JPGPU_PS_PUBLISH_EVERY
+#define JPGPU_PS_PUBLISH_EVERY 512
+#endif
+#ifndef JPGPU_PS_PUBLISH_REFINE
+#define JPGPU_PS_PUBLISH_REFINE 32
+#endif
+    constexpr uint32_t kPsPublishEvery = JPGPU_PS_PUBLISH_EVERY;  // (a power of two)
     // the scans at the end of the dependency chains are the long poles (the last refinement carries most of the bits):
     // they win the issue arbitration against the scans sharing their SIMD
     if (pipelined != 0) {
@@ -2981,7 +3030,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                 JPGPU_ENSURE_STAGED()
                 if (rows_ready != 0xFFFFFFFFu) JPGPU_FOLLOW((first_unit + u0 + group - 1u) / my_units_per_row)
                 if (err != 0) break;
-                if ((passes++ & 7u) == 7u) JPGPU_PUBLISH(u0)
+                if ((passes++ & (kPsPublishEvery / 8u - 1u)) == kPsPublishEvery / 8u - 1u) JPGPU_PUBLISH(u0)
                 d.cur = 64;
                 w_refresh<false>(d, lane, lds_huff(tabs, dc_slot[0]));
                 const uint32_t nb = group * bpu;
@@ -3061,7 +3110,7 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                 JPGPU_ENSURE_STAGED()
                 if (rows_ready != 0xFFFFFFFFu) JPGPU_FOLLOW((first_unit + u0 + group - 1u) / my_units_per_row)
                 if (err != 0) break;
-                if ((passes++ & 7u) == 7u) JPGPU_PUBLISH(u0)
+                if ((passes++ & (kPsPublishEvery / 8u - 1u)) == kPsPublishEvery / 8u - 1u) JPGPU_PUBLISH(u0)
                 const uint32_t pos0 = uni(d.pos);
                 uint32_t cur = uni(d.cur), winpos = pos0 - cur;
                 uint32_t rec = 0;   // lane n: (category << 6 | code + magnitude bits) << 16 | ring position behind block n's magnitude
@@ -3216,7 +3265,6 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
         const int32_t p1 = (int32_t)(int16_t)(1u << al), m1 = (int32_t)(int16_t)(0xFFFFFFFFu << al);
         const uint64_t band = (se >= 63u ? ~0ull : ((1ull << (se + 1u)) - 1ull)) & ~((1ull << ss) - 1ull);
         const uint64_t lane_bit = 1ull << lane;
-        const uint32_t inband = (band & lane_bit) != 0 ? 0xFFFFFFFFu : 0u;
         uint32_t eobrun = 0;
         if (ah == 0) {
             ProgWalk w;
@@ -3250,32 +3298,61 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
             }
         } else {
             unsigned long long ps_stage = 0, ps_wait = 0, ps_blocks = 0, ps_t0 = PS_TICK();
+            const R5Consts k5 = r5_consts(lane, band, p1, m1);
+            uint32_t eobv = 0;  // the end-of-band run, in a vector register (the same in all lanes)
+            // The next chunk's blocks are fetched while this one is parsed (two 16-byte pieces per lane in registers; their block
+            // indices in the other half of idx[]) -- when the rows they lie in are already known to be complete.
+            uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0;
+            bool have_pre = false;
+            uint32_t ihalf = 0;  // which half of idx[] holds the current chunk's indices
+            auto chunk_indices = [&](uint32_t first, uint32_t n_, uint32_t *dst) {
+                if (lane < n_) {
+                    ProgWalk w;
+                    prog_walk_init(w, p, first_unit + first + lane, units_per_line);
+                    uint64_t index = 0;
+                    const bool real = prog_walk_index(fr, p, w, index);
+                    dst[lane] = real ? (uint32_t)index : kPsNoBlock;
+                }
+            };
+            auto piece = [&](uint32_t q, const uint32_t *ix_) {
+                const uint32_t b = q >> 3, part = q & 7u, ix = ix_[b];
+                return *reinterpret_cast<const uint4 *>(coefs + (ix != kPsNoBlock ? (uint64_t)ix : fr.coef_off) * 64 + part * 8u);
+            };
             for (uint32_t done = 0; done < my_units && err == 0;) {
                 const uint32_t n = my_units - done < (uint32_t)kPsChunk ? my_units - done : (uint32_t)kPsChunk;
                 const unsigned long long ps_a = PS_TICK();
-                if (done != 0 && (done & 31u) == 0) JPGPU_PUBLISH(done)  // a release fence costs microseconds: every 32 blocks
+                if (done != 0 && (done & (JPGPU_PS_PUBLISH_REFINE - 1u)) == 0) JPGPU_PUBLISH(done)  // (a release fence costs microseconds)
                 JPGPU_FOLLOW((first_unit + done + n - 1u) / my_units_per_row)
                 if (err != 0) break;  // gave up waiting (kDetailSpinTimeout)
                 const unsigned long long ps_b = PS_TICK();
                 ps_wait += ps_b - ps_a;
-                if (lane < n) {
-                    ProgWalk w;
-                    prog_walk_init(w, p, first_unit + done + lane, units_per_line);
-                    uint64_t index = 0;
-                    const bool real = prog_walk_index(fr, p, w, index);
-                    idx[lane] = real ? (uint32_t)index : kPsNoBlock;
+                uint32_t *idx_cur = idx + ihalf * kPsChunk;
+                if (have_pre) {
+                    if (lane < n * 8u) reinterpret_cast<uint4 *>(stage)[lane] = pre0;
+                    if (lane + 64u < n * 8u) reinterpret_cast<uint4 *>(stage)[lane + 64u] = pre1;
+                } else {
+                    chunk_indices(done, n, idx_cur);
+                    __syncthreads();
+                    for (uint32_t q = lane; q < n * 8u; q += 64u) reinterpret_cast<uint4 *>(stage)[q] = piece(q, idx_cur);
                 }
                 __syncthreads();
-                for (uint32_t q = lane; q < n * 8u; q += 64u) {
-                    const uint32_t b = q >> 3, part = q & 7u, ix = idx[b];
-                    const int16_t *src = coefs + (ix != kPsNoBlock ? (uint64_t)ix : fr.coef_off) * 64 + part * 8u;
-                    reinterpret_cast<uint4 *>(stage)[q] = *reinterpret_cast<const uint4 *>(src);
+                have_pre = false;
+                if (kPsChunk <= 16u && done + n < my_units) {
+                    const uint32_t first2 = done + n, n2 = my_units - first2 < (uint32_t)kPsChunk ? my_units - first2 : (uint32_t)kPsChunk;
+                    if ((first_unit + first2 + n2 - 1u) / my_units_per_row < rows_ready) {
+                        uint32_t *idx_next = idx + (ihalf ^ 1u) * kPsChunk;
+                        chunk_indices(first2, n2, idx_next);
+                        __syncthreads();
+                        if (lane < n2 * 8u) pre0 = piece(lane, idx_next);
+                        if (lane + 64u < n2 * 8u) pre1 = piece(lane + 64u, idx_next);
+                        have_pre = true;
+                    }
                 }
-                __syncthreads();
+                ihalf ^= have_pre ? 1u : 0u;  // (the next chunk reads the half just filled; else it refills this one)
                 const unsigned long long ps_c = PS_TICK();
                 ps_stage += ps_c - ps_b;
                 int32_t c_next = stage[lane];
-                uint32_t ix_next = idx[0];
+                uint32_t ix_next = idx_cur[0];
                 for (uint32_t b = 0; b < n && err == 0; b++) {
                     JPGPU_ENSURE_STAGED()
                     int32_t c = c_next;
@@ -3283,53 +3360,55 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
                     {  // the next block's coefficients are on their way while this one is parsed
                         const uint32_t bn = b + 1u < n ? b + 1u : b;
                         c_next = stage[bn * 64u + lane];
-                        ix_next = idx[bn];
+                        ix_next = idx_cur[bn];
                     }
-                    const uint64_t nz = __ballot(c != 0);
                     bool mine = false;  // this lane's coefficient changed
                     if (d.rem >= kPsFastBits) {
                         const uint32_t pos0 = d.pos;
+#if defined(JPGPU_PS_OLD_REFINE) || defined(JPGPU_PS_REFINE3) || defined(JPGPU_PS_REFINE4)
+                        const uint64_t nz = __ballot(c != 0);
+                        uint32_t eobrun = uni(eobv);
 #ifdef JPGPU_PS_OLD_REFINE
                         err = w_ac_refine_fast(d, lane, hac, ss, se, p1, m1, band, nz, eobrun, c, mine);
 #elif defined(JPGPU_PS_REFINE3)
                         err = w_ac_refine_parse(d, lane, hac, ss, se, p1, m1, band, nz, eobrun, c, mine,
                                                 ix != kPsNoBlock ? coefs + (uint64_t)ix * 64 : nullptr);
 #else
+                        err = w_ac_refine_v4(d, lane, hac, ss, se, p1, m1, band, nz, eobrun, c, mine);
+#endif
+                        eobv = eobrun;
+#else
 #ifdef JPGPU_PS_CHECK
                         {
+                            const uint64_t nz = __ballot(c != 0);
                             WBits d3 = d;
                             d3.ent2 = r2_digest(d3.ent);  // (the window entries as the third form wants them)
-                            uint32_t eob3 = eobrun;
+                            uint32_t eob3 = uni(eobv);
                             int32_t c3 = c;
                             bool mine3 = false;
                             const uint32_t e3 = w_ac_refine_parse(d3, lane, hac, ss, se, p1, m1, band, nz, eob3, c3, mine3, nullptr);
                             WBits d4 = d;
-                            uint32_t eob4 = eobrun;
+                            uint32_t eob4 = eobv;
                             int32_t c4 = c;
                             bool mine4 = false;
-#ifdef JPGPU_PS_REFINE4
-                            const uint32_t e4 = w_ac_refine_v4(d4, lane, hac, ss, se, p1, m1, band, nz, eob4, c4, mine4);
-#else
-                            const uint32_t e4 = w_ac_refine_v5(d4, lane, hac, ss, se, p1, m1, inband, eob4, c4, mine4);
-#endif
-                            const bool bad = e3 != e4 || d3.pos != d4.pos || eob3 != eob4;
+                            const uint32_t e4 = w_ac_refine_v5(d4, k5, hac, ss, se, p1, m1, eob4, c4, mine4);
+                            const bool bad = e3 != e4 || d3.pos != d4.pos || eob3 != uni(eob4);
                             const uint64_t cbad = __ballot(((nz >> lane) & 1ull) != 0 && c3 != c4);
                             if ((bad || cbad != 0) && lane == 0)
-                                printf("refine mismatch: block %u pos0 %u cur0 %u eobrun0 %u nz %llx band %llx | v3 err %u pos %u eob %u | v4 err %u pos %u eob %u | corr lanes %llx\n",
-                                       done, d.pos, d.cur, eobrun, (unsigned long long)nz, (unsigned long long)band, e3, d3.pos, eob3, e4, d4.pos, eob4,
-                                       (unsigned long long)cbad);
+                                printf("refine mismatch: block %u pos0 %u cur0 %u eobrun0 %u nz %llx band %llx | v3 err %u pos %u eob %u | v5 err %u pos %u eob %u | corr lanes %llx\n",
+                                       done, d.pos, d.cur, uni(eobv), (unsigned long long)nz, (unsigned long long)band, e3, d3.pos, eob3, e4, d4.pos,
+                                       uni(eob4), (unsigned long long)cbad);
                         }
 #endif
-#ifdef JPGPU_PS_REFINE4
-                        err = w_ac_refine_v4(d, lane, hac, ss, se, p1, m1, band, nz, eobrun, c, mine);
-#else
-                        err = w_ac_refine_v5(d, lane, hac, ss, se, p1, m1, inband, eobrun, c, mine);
-#endif
+                        err = w_ac_refine_v5(d, k5, hac, ss, se, p1, m1, eobv, c, mine);
 #endif
                         d.rem -= (int32_t)(d.pos - pos0);
                     } else {
+                        const uint64_t nz = __ballot(c != 0);
+                        uint32_t eobrun = uni(eobv);
                         err = w_ac_refine_block<false>(d, lane, hac, ss, se, p1, m1, band, nz, eobrun, c, mine);
                         JPGPU_SETTLE()
+                        eobv = eobrun;
                     }
                     if (ix != kPsNoBlock && mine) coefs[(uint64_t)ix * 64 + lane] = (int16_t)c;
                     if (err == 0) done++;
@@ -3364,6 +3443,24 @@ __global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *_
     if (lane == 0) {
         const uint32_t code = restart_check(s, st, &status[wk.scan], interval, n_ends, n_intervals, dri_eff, d.rem, err);
         if (code != kNoError) atomicMin(&status[wk.scan].first_error, code);
+    }
+}
+
+__global__ __launch_bounds__(64) void progressive_stream_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+                                                                const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
+                                                                DevScanStatus *__restrict__ status,
+                                                                const DevHuffTable *__restrict__ huff_pool, int16_t *__restrict__ coefs,
+                                                                int n_slots, int pipelined, uint32_t spin_budget, uint32_t ring_bytes,
+                                                                uint32_t chunk_blocks, uint32_t *__restrict__ started) {
+    HuffWork wk = work[blockIdx.x];
+    bool first_in_wave = true;
+    for (;;) {
+        ps_run_scan(udata, scans, wk, ends_u, status, huff_pool, coefs, n_slots, pipelined, spin_budget, ring_bytes, chunk_blocks, started,
+                    first_in_wave);
+        const uint32_t next = pipelined != 0 ? uni(scans[wk.scan].wave_next) : 0u;
+        if (next == 0) break;
+        wk.scan += next;  // (the launch's list holds one-interval scans only: first_interval stays 0)
+        first_in_wave = false;
     }
 }
 
@@ -4601,7 +4698,7 @@ static void ps_lds_shape(uint32_t &ring, uint32_t &chunk) {
 size_t progressive_stream_lds_bytes(int n_slots) {
     uint32_t ring, chunk;
     ps_lds_shape(ring, chunk);
-    return (size_t)n_slots * sizeof(DevHuffTable) + ring + (size_t)chunk * 128 + chunk * 4;
+    return (size_t)n_slots * sizeof(DevHuffTable) + ring + (size_t)chunk * 128 + chunk * 8;  // (idx[]: two halves)
 }
 
 // The same, one wave per (scan, restart interval): for scans with few, long intervals.
