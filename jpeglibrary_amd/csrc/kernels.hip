@@ -2983,9 +2983,10 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
     // The REFINEMENT scans keep their 32 blocks: they are one publisher in ten and cost nothing measurable (178.7 vs 178.4 ms),
     // and with 256 the forced, oversubscribed launch of tests/...test_dc_refinement_beside_ac_scans_of_the_same_frame (1024
     // frames, tools/trace/race_probe.sh) decodes 1-7 of its last hundred frames wrongly in most passes -- the frames that start
-    // as the machine drains, their scans neck and neck.  NOT UNDERSTOOD: agent-scope (sc1) loads and stores of the coefficients,
-    // a write-back in front of the follower's invalidate and 140 us between the producer's write-back and its progress word all
-    // left it as it was; with 32 blocks twelve passes of the same probe (and every earlier round's runs) are clean.
+    // as the machine drains, their scans neck and neck.  NOT UNDERSTOOD (lists what was tried: sc1 loads
+    // and stores, stronger fences, delays, the DC refinement held back, a total order of the scans of a component); with 32
+    // blocks 48 passes of the same probe over three LDS shapes (and every earlier round's runs) are clean.  Do not raise it
+    // without a model of the hand-over that explains the probe.
 #ifndef JPGPU_PS_PUBLISH_EVERY
 #define JPGPU_PS_PUBLISH_EVERY 512
 #endif
