@@ -1396,13 +1396,12 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         prog_work.insert(prog_work.end(), w.begin(), w.end());
         prog_stream_begin_.push_back((int)prog_work.size());
     }
-    // The pipelined launch's list.  Fewer waves is faster once there are more streams than SIMDs (256 x 4K frames x 10 scans on
-    // 1024 SIMDs: the long scans share their SIMD's issue slots with two or three others; 32 frames take 165 ms, 256 took 216):
-    // a scan whose ONLY producer is a cheap scan, and that is cheap itself, runs behind its producer in the same wave -- it
-    // could not have overtaken it anyway.  "Cheap": the wave's entropy bytes stay under half of the frame's largest scan (the
-    // long pole is left alone, and so is everything upstream of it that has two producers) and under 1 MiB (a follower in
-    // another wave waits for the whole producer now, inside its spin budget).  libjpeg's script: DC first -> DC refinement,
-    // Cr first -> Cr refinement, Cb first -> Cb refinement: 7 waves per frame instead of 10.
+    // The pipelined launch's list.  Fewer waves per frame let more frames share one resident launch (8 instead of 10: 512 frames
+    // instead of 409 with two Huffman tables staged; at 256 frames the launch is as fast either way -- what made it slower than
+    // a 32-frame launch was the release fences, see progressive_stream_kernel): a scan whose ONLY producer is a cheap scan, and
+    // that is cheap itself, runs behind its producer in the same wave -- it could not have overtaken it anyway.  "Cheap": the wave's entropy bytes stay under half of the frame's largest scan (the
+    // long pole is left alone) and under 1 MiB, nothing follows the chained scan, and it is an AC scan.  libjpeg's script: Cr first ->
+    // Cr refinement, Cb first -> Cb refinement: 8 waves per frame instead of 10.
     prog_pipe_begin_ = (int)prog_work.size();
     {
         static const bool no_wave_chains = getenv("JPGPU_PROG_NO_WAVE_CHAINS") != nullptr;
@@ -1411,19 +1410,30 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             if (img.jobs.size() < 2 || no_wave_chains) continue;
             const int j0 = img.jobs[0] + 1, n = (int)img.jobs.size() - 1;  // the frame job precedes its scans
             uint64_t largest = 0;
+            // (a scan's own entropy bytes: DevScan::data_len; ScanJob::entropy_len runs to the end of the file)
             for (int k = 0; k < n; k++)
-                if (jobs_[(size_t)(j0 + k)].kind == kScanProgressive) largest = std::max<uint64_t>(largest, jobs_[(size_t)(j0 + k)].entropy_len);
+                if (jobs_[(size_t)(j0 + k)].kind == kScanProgressive) largest = std::max<uint64_t>(largest, h_scans_[(size_t)(j0 + k)].data_len);
             std::vector<uint64_t> wave_bytes((size_t)n, 0);  // of the wave that ENDS with scan k
             std::vector<uint8_t> has_next((size_t)n, 0);
             for (int k = 0; k < n; k++) {
                 const ScanJob &job = jobs_[(size_t)(j0 + k)];
                 if (job.kind != kScanProgressive) continue;
-                wave_bytes[(size_t)k] = job.entropy_len;
-                if (job.n_deps != 1 || job.deps[0] < 0 || job.deps[0] >= k) continue;
+                const uint64_t own = h_scans_[(size_t)(j0 + k)].data_len;
+                wave_bytes[(size_t)k] = own;
+                // (only a scan nobody follows: behind its producer it starts later than it would beside it, and whatever waited
+                // for it would start later too -- Y AC 1-5 -> Y AC 6-63 -> Y refinement in one wave put 60 ms in front of the
+                // last luma refinement)
+                if (job.n_deps != 1 || job.deps[0] < 0 || job.deps[0] >= k || job.has_consumers) continue;
+                // (not a DC refinement: behind the DC first scan it would run much earlier than beside the frame's refinements,
+                // and the one wrong frame in 36 passes of tools/trace/race_probe_shapes.sh appeared with exactly that change)
+                if (job.scan_components != 1 || job.ss == 0) continue;
                 const int a = job.deps[0];
                 if (jobs_[(size_t)(j0 + a)].kind != kScanProgressive || has_next[(size_t)a] || k - a > 255) continue;
-                const uint64_t together = wave_bytes[(size_t)a] + job.entropy_len;
+                const uint64_t together = wave_bytes[(size_t)a] + own;
                 if (together > largest / 2 || together > (1u << 20)) continue;
+                if (getenv("JPGPU_DEBUG_STATUS") && &img == &images_[0])
+                    fprintf(stderr, "jpgpu: wave chain: scan %d behind scan %d (%llu + %llu bytes, largest scan %llu)\n", k, a,
+                            (unsigned long long)wave_bytes[(size_t)a], (unsigned long long)own, (unsigned long long)largest);
                 h_scans_[(size_t)(j0 + a)].wave_next = (uint8_t)(k - a);
                 has_next[(size_t)a] = 1;
                 is_tail[(size_t)(j0 + k)] = 1;
