@@ -2590,11 +2590,11 @@ __device__ __forceinline__ R5Consts r5_consts(uint32_t lane, uint64_t band, int3
     "v_cndmask_b32_e32 %[x2], %[x2], %[x0], vcc\n\t"  /* r-th zero -> lane r, the others behind (a permutation) */ \
     "v_lshlrev_b32_e32 %[x2], 2, %[x2]\n\t" \
     "ds_permute_b32 %[ntab], %[x2], %[x3]\n\t" \
+    "v_cmp_gt_u32_e32 vcc, %[x1], %[lane]\n\t"  /* (two wait states before the select below reads VCC, however soon the permute is back) */ \
     "v_mov_b32_e32 %[cur], %[cur0]\n\t" \
     "v_subrev_u32_e32 %[base], %[ss], %[cur]\n\t"  /* a symbol's window offset = base + code bits before it + ntab[zeros before it] */ \
     "v_mov_b32_e32 %[zq], -1\n\t" \
     "v_add_u32_e64 %[kprev], %[ss], -1\n\t" \
-    "v_cmp_gt_u32_e32 vcc, %[x1], %[lane]\n\t" \
     "s_waitcnt lgkmcnt(0)\n\t" \
     "v_cndmask_b32_e32 %[ntab], %[noz], %[ntab], vcc\n\t"  /* no such zero: the run outlasts the band */ \
     "v_cmp_ne_u32_e32 vcc, 0, %[eobv]\n\t"  /* inside an end-of-band run: correction bits only */ \
