@@ -4425,7 +4425,16 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
 
     // phase B1: dequantise this lane's block out of the staging into registers
     float f[64];
-    if (have_block) block_dequant(sh + tid * 128, (tid >> 1) & 7, sh_q[ci_early], f);
+    {
+        // The lane's eight swizzled staging addresses do not change from tile to tile; hipcc computes them in front of the tile
+        // loop -- and in the three variants with the most state in their output assembly spills five of them to scratch for
+        // the length of the transform.  There they are derived again in every tile (sixteen instructions) from a copy of the
+        // lane id the compiler cannot see through.
+        constexpr bool kPerTile = (FMT == kFmtRgbU8 && (LAY == kLayYccH2V1 || LAY == kLayYccH2V2)) || (FMT == kFmtInterleavedU8 && LAY == kLayGeneric);
+        uint32_t t_ = tid;
+        if (kPerTile) asm volatile("" : "+v"(t_));
+        if (have_block) block_dequant(sh + t_ * 128, (t_ >> 1) & 7, sh_q[ci_early], f);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every lane holds its coefficients: the staging can be refilled
     if (have_next) dma_tile(next_first);  // in flight during the whole transform below
