@@ -1563,6 +1563,21 @@ extern "C" int jpgpu_debug_ps_profile(unsigned long long *out, int reset) {
 #define PS_COUNT(i) do { } while (0)
 #endif
 
+#ifdef JPGPU_PS_TRACE
+// What every luma AC refinement block was given and what it made of it (diagnostic build only, tools/trace/refine_trace.py): per
+// (image >= first, scan kind, block) four words -- which of the 64 coefficients the scan found non-zero, its bit position in front
+// of the block, the bits it consumed and the end-of-band run it left.  Copies of one source image must agree word for word; where
+// a failing copy first differs says whether it READ something else or PARSED differently.
+__device__ uint32_t *ps_trace_buf;
+__device__ uint32_t ps_trace_first_image, ps_trace_images, ps_trace_units;
+extern "C" int jpgpu_debug_ps_trace(uint32_t *device_buffer, uint32_t first_image, uint32_t images, uint32_t units) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(ps_trace_buf), &device_buffer, sizeof device_buffer) != hipSuccess ||
+           hipMemcpyToSymbol(HIP_SYMBOL(ps_trace_first_image), &first_image, 4) != hipSuccess ||
+           hipMemcpyToSymbol(HIP_SYMBOL(ps_trace_images), &images, 4) != hipSuccess ||
+           hipMemcpyToSymbol(HIP_SYMBOL(ps_trace_units), &units, 4) != hipSuccess;
+}
+#endif
+
 struct WBits {
     const uint32_t *ring;  // MSB-first words of the stream; ring byte 0 = the 16-byte aligned address at or below its first byte
     uint32_t wmask;        // uniform: ring size in words - 1
@@ -3364,6 +3379,11 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
                         ix_next = idx_cur[bn];
                     }
                     bool mine = false;  // this lane's coefficient changed
+#ifdef JPGPU_PS_TRACE
+                    // (as little as possible: the failures are shy -- a hash of the 64 values in front of every block made them go away)
+                    const uint64_t trace_nz = __ballot(c != 0);
+                    const uint32_t trace_pos = d.pos;
+#endif
                     if (d.rem >= kPsFastBits) {
                         const uint32_t pos0 = d.pos;
 #if defined(JPGPU_PS_OLD_REFINE) || defined(JPGPU_PS_REFINE3) || defined(JPGPU_PS_REFINE4)
@@ -3411,6 +3431,18 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
                         JPGPU_SETTLE()
                         eobv = eobrun;
                     }
+#ifdef JPGPU_PS_TRACE
+                    if (ps_trace_buf != nullptr && s.comp[0].component_index == 0 && s.image_index >= ps_trace_first_image &&
+                        s.image_index - ps_trace_first_image < ps_trace_images && done < ps_trace_units) {
+                        uint32_t *t = ps_trace_buf + (((uint64_t)(s.image_index - ps_trace_first_image) * 2u + (al == 0 ? 1u : 0u)) * ps_trace_units + done) * 4u;
+                        if (lane == 0) {
+                            t[0] = (uint32_t)trace_nz;
+                            t[1] = (uint32_t)(trace_nz >> 32);
+                            t[2] = trace_pos;
+                            t[3] = (uni(eobv) << 16) | (d.pos - trace_pos);
+                        }
+                    }
+#endif
                     if (ix != kPsNoBlock && mine) coefs[(uint64_t)ix * 64 + lane] = (int16_t)c;
                     if (err == 0) done++;
                 }
