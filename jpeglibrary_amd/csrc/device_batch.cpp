@@ -1302,6 +1302,12 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 // the frame job precedes its scans in the job list: scan k of the frame is job img.jobs[0] + 1 + k
                 for (int d = 0; d < 3; d++) s.dep[d] = d < job.n_deps && job.deps[d] >= 0 ? (uint32_t)(img.jobs[0] + 1 + job.deps[d]) : kNoDep;
                 s.publishes = job.has_consumers ? 1 : 0;
+                // test hook: "k:ms" delays the start of scan k (0-based, in file order) of every progressive frame -- a producer that is
+                // late for a reason of its own, which is what the forced oversubscribed launch only produces by chance
+                if (const char *dd = getenv("JPGPU_DEBUG_DELAY_SCAN")) {
+                    int k = -1, ms = 0;
+                    if (sscanf(dd, "%d:%d", &k, &ms) == 2 && k == j - img.jobs[0] - 1) s.debug_delay_ms = (uint8_t)std::min(255, std::max(0, ms));
+                }
                 if (job.n_deps > 3 || s.n_intervals != 1 || s.n_intervals > stream_max_intervals) prog_pipelined_ = false;
                 if (s.n_intervals <= stream_max_intervals) {
                     for (uint32_t i = 0; i < s.n_intervals; i++) prog_streams_by_ordinal[ordinal].push_back({(uint32_t)j, i});
@@ -1424,8 +1430,8 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 // for it would start later too -- Y AC 1-5 -> Y AC 6-63 -> Y refinement in one wave put 60 ms in front of the
                 // last luma refinement)
                 if (job.n_deps != 1 || job.deps[0] < 0 || job.deps[0] >= k || job.has_consumers) continue;
-                // (not a DC refinement: behind the DC first scan it would run much earlier than beside the frame's refinements,
-                // and the one wrong frame in 36 passes of tools/trace/race_probe_shapes.sh appeared with exactly that change)
+                // (not a DC refinement: 7 waves per frame instead of 8 only helps batches of 513-585 frames and has not been
+                // measured since the wrong frame once seen with it turned out to be the end-of-band skip in the stream kernel)
                 if (job.scan_components != 1 || job.ss == 0) continue;
                 const int a = job.deps[0];
                 if (jobs_[(size_t)(j0 + a)].kind != kScanProgressive || has_next[(size_t)a] || k - a > 255) continue;

@@ -2957,6 +2957,8 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
             }
         }
     }
+    if (s.debug_delay_ms != 0)  // (tests: JPGPU_DEBUG_DELAY_SCAN)
+        for (uint32_t i = 0; i < (uint32_t)s.debug_delay_ms * 256u; i++) __builtin_amdgcn_s_sleep(127);  // ~4 us each
     // wait until the producers have finished MCU row `row_`
 #define JPGPU_FOLLOW(row_)                                                                                      \
     if ((row_) >= rows_ready) {                                                                                 \
@@ -2995,13 +2997,11 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
     // cost grows with the batch: with the first scans and the DC scans publishing every 64 units a 256-frame launch took 214 ms
     // against 165 ms for 32 frames; at 512 it takes 178 (tools/trace/progressive_ablation.sh, PIPELINED=1).  A follower only
     // needs whole MCU rows (480 luma blocks in a 4K frame), so it loses nothing but a row of lag.
-    // The REFINEMENT scans keep their 32 blocks: they are one publisher in ten and cost nothing measurable (178.7 vs 178.4 ms),
-    // and with 256 the forced, oversubscribed launch of tests/...test_dc_refinement_beside_ac_scans_of_the_same_frame (1024
-    // frames, tools/trace/race_probe.sh) decodes 1-7 of its last hundred frames wrongly in most passes -- the frames that start
-    // as the machine drains, their scans neck and neck.  NOT UNDERSTOOD (lists what was tried: sc1 loads
-    // and stores, stronger fences, delays, the DC refinement held back, a total order of the scans of a component); with 32
-    // blocks 48 passes of the same probe over three LDS shapes (and every earlier round's runs) are clean.  Do not raise it
-    // without a model of the hand-over that explains the probe.
+    // The REFINEMENT scans keep their 32 blocks: they are one publisher in ten and cost nothing measurable (178.7 vs 178.4 ms).
+    // (A cost setting only.  For a while 32 looked load-bearing -- with 256 the forced oversubscribed launch decoded a few frames
+    // per thousand wrongly -- but that was an AC first scan announcing blocks of an end-of-band run without following its own
+    // producer, see the loop below and DESIGN.md "A scan that skipped its producer"; tools/trace/race_probe.sh is clean at any
+    // cadence since.)
 #ifndef JPGPU_PS_PUBLISH_EVERY
 #define JPGPU_PS_PUBLISH_EVERY 512
 #endif
@@ -3287,13 +3287,19 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
             prog_walk_init(w, p, first_unit, units_per_line);
             for (uint32_t u = 0; u < my_units && err == 0; u++, prog_walk_next(w, p, units_per_line)) {
                 if ((u & (kPsPublishEvery - 1u)) == 0 && u != 0) JPGPU_PUBLISH(u)
+                // BEFORE the end-of-band skip: a scan must not announce units its own producers have not reached.  The host
+                // drops a dependency that another one implies (the Y refinement follows Y AC 6-63 only, which follows Y AC 1-5);
+                // a first scan that is one long end-of-band run -- 15 bytes for a whole 4K frame -- used to skip its blocks
+                // without looking at its producer, announced them, and the refinement behind it went ahead of Y AC 1-5
+                // whenever that scan was the slower one: the last hundred frames of the forced, oversubscribed launch, where
+                // the scans of a frame start in any order ("invalid Huffman code", round 3's long hunt in DESIGN.md).
+                JPGPU_FOLLOW(w.my)
+                if (err != 0) break;  // gave up waiting (kDetailSpinTimeout)
                 if (eobrun != 0) {
                     eobrun--;
                     continue;
                 }
                 JPGPU_ENSURE_STAGED()
-                JPGPU_FOLLOW(w.my)
-                if (err != 0) break;  // gave up waiting (kDetailSpinTimeout)
                 uint64_t index = 0;
                 const bool real = prog_walk_index(fr, p, w, index);
                 int32_t c = 0;

@@ -626,6 +626,48 @@ def test_dc_refinement_beside_ac_scans_of_the_same_frame():
     assert [got.get(i) for i in range(16)] == want
 
 
+def _scan_lengths(data):
+    """bytes from each SOS marker to the next marker segment (FF DA cannot occur inside entropy-coded data)"""
+    at = [i for i in range(len(data) - 1) if data[i] == 0xFF and data[i + 1] == 0xDA]
+    ends = at[1:] + [len(data)]
+    return [e - a for a, e in zip(at, ends)]
+
+
+@pytest.mark.parametrize("late_scan", [1, 4, 5])
+def test_a_scan_inside_an_end_of_band_run_still_follows_its_producers(late_scan, monkeypatch):
+    """libjpeg's 10-scan script on a smooth frame: scan 4 (Y AC 6-63, first pass, Al = 2) is ONE end-of-band run over the whole
+    frame -- a few bytes.  The host keeps only direct dependencies: scan 5 (the Y AC 1-63 refinement) follows scan 4 alone,
+    which follows scan 1 (Y AC 1-5), so scan 4 has to pass scan 1's progress on.  Its skip of a block inside an end-of-band
+    run once came BEFORE it looked at its producer: with scan 1 late, scan 4 announced the whole frame at once and the
+    refinement ran over coefficients 1-5 that were not there yet (wrong samples, or "invalid Huffman code" one scan later;
+    in production only the forced oversubscribed launch hit it, a few frames per thousand).  JPGPU_DEBUG_DELAY_SCAN makes one
+    scan of every frame start late, which turns the rare interleaving into a certain one."""
+    import time
+
+    from bench import progressive_batch
+    files = progressive_batch(6, 1024, 768, 75, 900, 6)
+    for f in files:
+        lens = _scan_lengths(f)
+        assert len(lens) == 10 and lens[4] < 64, lens  # the precondition: scan 4 is one end-of-band run
+    refs = [po.decode_8bit(f)[0] for f in files]
+    monkeypatch.delenv("JPGPU_PROG_NO_PIPELINE", raising=False)
+    b0 = jl.Batch().upload(files).decode().sync()  # (first decode of the process: module load, LDS shape ...)
+    t0 = time.perf_counter()
+    b0.decode().sync()
+    undelayed = time.perf_counter() - t0
+    b0.close()
+    monkeypatch.setenv("JPGPU_DEBUG_DELAY_SCAN", "%d:30" % late_scan)
+    b = jl.Batch().upload(files)
+    t0 = time.perf_counter()
+    b.decode().sync()
+    delayed = time.perf_counter() - t0
+    assert delayed > undelayed + 0.015, (undelayed, delayed)  # the hook is live: a scan slept ~30 ms
+    bad = [i for i in range(len(files)) if b.result(i).status != 0 or not np.array_equal(b.output(i), refs[i])]
+    assert not bad, (bad, [b.result(i).detail for i in bad])
+    assert b.progressive_fallbacks() == 0
+    b.close()
+
+
 def test_progressive_spin_budget_exhausted_falls_back_level_by_level(monkeypatch):
     """With no polls to spend (JPGPU_PROG_SPIN_BUDGET=0) every follower that is not already satisfied gives up; the host
     sees the internal time-out status and re-issues the step scan level by scan level in fresh launches: same samples."""
