@@ -92,7 +92,7 @@ struct alignas(16) DevScan {
     uint8_t publishes;         // pipelined launch: other scans follow this one's progress (DevScanStatus::progress)
     uint8_t sub_shift;         // DRI = 0 scans: log2 of the subsequence length in bits (10..12), see K2S
     uint8_t wave_next;         // pipelined launch: the wave that has finished this scan goes on with scan job (this + wave_next); 0 = none
-    uint8_t debug_delay_ms;    // tests only (JPGPU_DEBUG_DELAY_SCAN): the stream kernel idles this long before it starts the scan
+    uint8_t debug_delay_ms;    // tests only (JPGPU_DEBUG_DELAY_SCAN): the stream kernel idles this long before the scan and after each progress word
     uint8_t pad1[2];
     uint16_t hblocks[kMaxScanComponents];   // the component's own block grid (ref: JpegBlockAllocator.cs:35-84);
     uint16_t vblocks[kMaxScanComponents];   // blocks outside it go to the allocator's dummy block, i.e. nowhere

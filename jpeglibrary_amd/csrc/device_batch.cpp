@@ -1302,8 +1302,8 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 // the frame job precedes its scans in the job list: scan k of the frame is job img.jobs[0] + 1 + k
                 for (int d = 0; d < 3; d++) s.dep[d] = d < job.n_deps && job.deps[d] >= 0 ? (uint32_t)(img.jobs[0] + 1 + job.deps[d]) : kNoDep;
                 s.publishes = job.has_consumers ? 1 : 0;
-                // test hook: "k:ms" delays the start of scan k (0-based, in file order) of every progressive frame -- a producer that is
-                // late for a reason of its own, which is what the forced oversubscribed launch only produces by chance
+                // test hook: "k:ms" makes scan k (0-based, in file order) of every progressive frame slow: it idles ms at its start and
+                // after every progress word -- a producer its followers catch up with, which the launches only produce by chance
                 if (const char *dd = getenv("JPGPU_DEBUG_DELAY_SCAN")) {
                     int k = -1, ms = 0;
                     if (sscanf(dd, "%d:%d", &k, &ms) == 2 && k == j - img.jobs[0] - 1) s.debug_delay_ms = (uint8_t)std::min(255, std::max(0, ms));

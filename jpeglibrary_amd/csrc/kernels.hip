@@ -2957,8 +2957,12 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
             }
         }
     }
-    if (s.debug_delay_ms != 0)  // (tests: JPGPU_DEBUG_DELAY_SCAN)
-        for (uint32_t i = 0; i < (uint32_t)s.debug_delay_ms * 256u; i++) __builtin_amdgcn_s_sleep(127);  // ~4 us each
+    // (tests: JPGPU_DEBUG_DELAY_SCAN makes a scan slow -- it idles this long at its start and after every progress word)
+    const uint32_t debug_delay = uni((uint32_t)s.debug_delay_ms * 256u);
+#define JPGPU_DEBUG_DELAY() \
+    if (debug_delay != 0)   \
+        for (uint32_t i_ = 0; i_ < debug_delay; i_++) __builtin_amdgcn_s_sleep(127);  // ~4 us each
+    JPGPU_DEBUG_DELAY()
     // wait until the producers have finished MCU row `row_`
 #define JPGPU_FOLLOW(row_)                                                                                      \
     if ((row_) >= rows_ready) {                                                                                 \
@@ -2992,6 +2996,15 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, JPGPU_PS_SCOPE);                                               \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
         if (lane == 0) __hip_atomic_store(my_progress, (units_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   \
+        JPGPU_DEBUG_DELAY()                                                                                     \
+    }
+    // ... and without the write-back, for a scan that has stored nothing since its last progress word (blocks inside an
+    // end-of-band run): what it passes on is its producers' progress, and their stores were written back before THEIR progress
+    // words, which this wave has read -- the order a follower needs is already there.
+#define JPGPU_PUBLISH_NOTHING_STORED(units_)                                                                    \
+    if (publishes) {                                                                                            \
+        if (lane == 0) __hip_atomic_store(my_progress, (units_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   \
+        JPGPU_DEBUG_DELAY()                                                                                     \
     }
     // How often?  A release is a write-back of the XCD's L2 -- of every wave's dirty lines, not only the publisher's -- so its
     // cost grows with the batch: with the first scans and the DC scans publishing every 64 units a 256-frame launch took 214 ms
@@ -3285,8 +3298,16 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
         if (ah == 0) {
             ProgWalk w;
             prog_walk_init(w, p, first_unit, units_per_line);
+            bool stored = false;  // since the last progress word
             for (uint32_t u = 0; u < my_units && err == 0; u++, prog_walk_next(w, p, units_per_line)) {
-                if ((u & (kPsPublishEvery - 1u)) == 0 && u != 0) JPGPU_PUBLISH(u)
+                if ((u & (kPsPublishEvery - 1u)) == 0 && u != 0) {
+#ifndef JPGPU_PS_ALWAYS_WRITE_BACK
+                    if (!stored) JPGPU_PUBLISH_NOTHING_STORED(u)
+                    else
+#endif
+                        JPGPU_PUBLISH(u)
+                    stored = false;
+                }
                 // BEFORE the end-of-band skip: a scan must not announce units its own producers have not reached.  The host
                 // drops a dependency that another one implies (the Y refinement follows Y AC 6-63 only, which follows Y AC 1-5);
                 // a first scan that is one long end-of-band run -- 15 bytes for a whole 4K frame -- used to skip its blocks
@@ -3299,6 +3320,7 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
                     eobrun--;
                     continue;
                 }
+                stored = true;
                 JPGPU_ENSURE_STAGED()
                 uint64_t index = 0;
                 const bool real = prog_walk_index(fr, p, w, index);
@@ -3477,6 +3499,8 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
 #undef JPGPU_ENSURE_STAGED
 #undef JPGPU_SETTLE
 #undef JPGPU_FOLLOW
+#undef JPGPU_DEBUG_DELAY
+#undef JPGPU_PUBLISH_NOTHING_STORED
 #undef JPGPU_PUBLISH
 
     if (lane == 0) {
