@@ -2998,14 +2998,6 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
         if (lane == 0) __hip_atomic_store(my_progress, (units_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   \
         JPGPU_DEBUG_DELAY()                                                                                     \
     }
-    // ... and without the write-back, for a scan that has stored nothing since its last progress word (blocks inside an
-    // end-of-band run): what it passes on is its producers' progress, and their stores were written back before THEIR progress
-    // words, which this wave has read -- the order a follower needs is already there.
-#define JPGPU_PUBLISH_NOTHING_STORED(units_)                                                                    \
-    if (publishes) {                                                                                            \
-        if (lane == 0) __hip_atomic_store(my_progress, (units_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   \
-        JPGPU_DEBUG_DELAY()                                                                                     \
-    }
     // How often?  A release is a write-back of the XCD's L2 -- of every wave's dirty lines, not only the publisher's -- so its
     // cost grows with the batch: with the first scans and the DC scans publishing every 64 units a 256-frame launch took 214 ms
     // against 165 ms for 32 frames; at 512 it takes 178 (tools/trace/progressive_ablation.sh, PIPELINED=1).  A follower only
@@ -3298,16 +3290,11 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
         if (ah == 0) {
             ProgWalk w;
             prog_walk_init(w, p, first_unit, units_per_line);
-            bool stored = false;  // since the last progress word
             for (uint32_t u = 0; u < my_units && err == 0; u++, prog_walk_next(w, p, units_per_line)) {
-                if ((u & (kPsPublishEvery - 1u)) == 0 && u != 0) {
-#ifndef JPGPU_PS_ALWAYS_WRITE_BACK
-                    if (!stored) JPGPU_PUBLISH_NOTHING_STORED(u)
-                    else
-#endif
-                        JPGPU_PUBLISH(u)
-                    stored = false;
-                }
+                // (with the write-back also where nothing was stored since the last word, inside an end-of-band run: leaving it out
+                // there is legal -- the producers' stores were written back before THEIR words -- and measured slower, 186 vs 181 ms
+                // per 256 frames)
+                if ((u & (kPsPublishEvery - 1u)) == 0 && u != 0) JPGPU_PUBLISH(u)
                 // BEFORE the end-of-band skip: a scan must not announce units its own producers have not reached.  The host
                 // drops a dependency that another one implies (the Y refinement follows Y AC 6-63 only, which follows Y AC 1-5);
                 // a first scan that is one long end-of-band run -- 15 bytes for a whole 4K frame -- used to skip its blocks
@@ -3320,7 +3307,6 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
                     eobrun--;
                     continue;
                 }
-                stored = true;
                 JPGPU_ENSURE_STAGED()
                 uint64_t index = 0;
                 const bool real = prog_walk_index(fr, p, w, index);
@@ -3500,7 +3486,6 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
 #undef JPGPU_SETTLE
 #undef JPGPU_FOLLOW
 #undef JPGPU_DEBUG_DELAY
-#undef JPGPU_PUBLISH_NOTHING_STORED
 #undef JPGPU_PUBLISH
 
     if (lane == 0) {

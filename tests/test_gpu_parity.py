@@ -665,7 +665,8 @@ def test_a_scan_inside_an_end_of_band_run_still_follows_its_producers(slow_scan,
     delayed = time.perf_counter() - t0
     assert delayed > undelayed + 0.002, (undelayed, delayed)  # the hook is live: ~4 ms at the start and per progress word of that scan
     bad = [i for i in range(len(files)) if b.result(i).status != 0 or not np.array_equal(b.output(i), refs[i])]
-    assert not bad, (bad, [b.result(i).detail for i in bad])
+    where = [(i, b.result(i).detail, [int(x) for x in np.argwhere((b.output(i) != refs[i]).any(axis=2))[0]] if b.result(i).status == 0 else None) for i in bad]
+    assert not bad, (where, b.progressive_fallbacks())
     assert b.progressive_fallbacks() == 0
     b.close()
 
