@@ -395,9 +395,18 @@ int EncodeBatch::encode() {
     std::vector<EncWork> work_chunk;
     uint64_t raw_off = 0, out_off = 0;
     uint32_t chunk_off = 0;
+    // E3's LDS buffer: twice the largest average stretch a workgroup (256 blocks or restart intervals) of any image writes,
+    // in steps of 4 KB -- the smaller it is the more workgroups share a CU; a workgroup whose stretch does not fit falls back
+    // to atomics in HBM (launch_emit clamps to 8-32 KB).  Images whose AVERAGE stretch is beyond 32 KB (restart intervals of
+    // several MCUs: every lane then writes a stretch of its own and the atomics do not collide) do not count; a batch of
+    // nothing else asks for no LDS at all.
+    uint64_t emit_words = 0;
     for (int i = 0; i < n; i++) {
         DevEncImage &im = images_[i];
         const uint64_t raw_len = (raw_bits[i] + 7) / 8;
+        const uint64_t wgs = ((uint64_t)im.n_units + 255) / 256;
+        const uint64_t avg_words = raw_bits[i] / 32 / std::max<uint64_t>(wgs, 1) + 1;
+        if (avg_words <= kEmitLdsWordsMax) emit_words = std::max<uint64_t>(emit_words, 2 * avg_words);
         im.raw_off = raw_off;
         im.out_off = out_off;
         im.chunk_off = chunk_off;
@@ -430,7 +439,7 @@ int EncodeBatch::encode() {
     (void)hipEventRecord(ev_[3], ctx_->stream);
     e = launch_emit(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_blk_.ptr, n_work_blk_, (const EncHuffTable *)d_tables_.ptr,
                     (const int16_t *)d_coefs_.ptr, (const uint32_t *)d_bits_.ptr, (const uint64_t *)d_bit_off_.ptr, (const uint64_t *)d_raw_bits_.ptr,
-                    (uint8_t *)d_raw_.ptr, (uint32_t *)d_marks_.ptr);
+                    (uint8_t *)d_raw_.ptr, (uint32_t *)d_marks_.ptr, (uint32_t)std::min<uint64_t>((emit_words + 1023) & ~1023ull, kEmitLdsWordsMax));
     if (e != hipSuccess) return hip_fail(e, "emit_kernel");
     (void)hipEventRecord(ev_[4], ctx_->stream);
     e = launch_stuff(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_chunk_.ptr, n_work_chunk_, (const uint64_t *)d_raw_bits_.ptr,

@@ -57,7 +57,9 @@ hipError_t launch_block_stats(hipStream_t stream, const DevEncImage *images, con
                               uint32_t *hist);
 hipError_t launch_emit(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
                        const int16_t *coefs, const uint32_t *bits, const uint64_t *wg_base, const uint64_t *raw_bits, uint8_t *raw,
-                       uint32_t *marks);
+                       uint32_t *marks, uint32_t lds_words);
+// the LDS buffer a workgroup of emit_kernel assembles its stretch of the stream in, in 32-bit words (launch_emit clamps to these)
+constexpr uint32_t kEmitLdsWordsMin = 2048, kEmitLdsWordsMax = 8192;
 constexpr uint32_t kEncStuffChunk = 4096;
 // marks: one bit per raw byte (word (raw_off >> 5) + (j >> 5), bit j & 31 for byte j of the image): a restart marker follows it
 hipError_t launch_stuff(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const uint64_t *raw_bits,

@@ -12,6 +12,7 @@
 //   E4 stuff_*_kernel       FF -> FF 00 (JpegWriter.FlushRegister), the final one-bits padding, EOI behind the data
 // MUST be compiled with -ffp-contract=off (the reference's Vector4 arithmetic never fuses a*b+c).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 
 #include "encode_kernels.h"
@@ -540,15 +541,16 @@ __global__ __launch_bounds__(1024) void block_offsets_kernel(const DevEncImage *
 // and the workgroup writes it out with plain coalesced stores; only its first and last word can be shared with a
 // neighbouring workgroup and go out as atomicOr on the zeroed buffer.  Before, every completed word of every lane was an
 // atomicOr in HBM (150 M of them per 256 x 4K: emit_kernel 5.05 ms against 2.2 ms for the same walk in block_bits_kernel).
-// A stretch longer than the LDS buffer (32 KB = 1 024 bits per block on average: restart intervals of many MCUs at high
-// quality) falls back to the global atomics.
-constexpr uint32_t kEmitLdsWords = 8192;
+// A stretch longer than the LDS buffer falls back to the global atomics.  The buffer is sized per launch (lds_words, dynamic
+// LDS): the host has the images' bit totals by now and asks for twice the batch's largest AVERAGE stretch, between 8 and
+// 32 KB -- with the 32 KB it used to hold always, four workgroups fitted a CU and the kernel ran at 4 waves per SIMD:
+// 2.74 ms per 256 x 4K at Q75, 2.04 ms with the 16 KB that batch needs (the walk alone, block_bits_kernel, takes 1.6).
 __global__ __launch_bounds__(256) void emit_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
                                                    const EncHuffTable *__restrict__ tables, const int16_t *__restrict__ coefs,
                                                    const uint32_t *__restrict__ bits, const uint64_t *__restrict__ wg_base,
                                                    const uint64_t *__restrict__ raw_bits, uint8_t *__restrict__ raw,
-                                                   uint32_t *__restrict__ marks) {
-    __shared__ uint32_t sh_words[kEmitLdsWords];
+                                                   uint32_t *__restrict__ marks, uint32_t lds_words) {
+    extern __shared__ uint32_t sh_words[];
     __shared__ EncHuffTable sh_tab[4];
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
@@ -563,27 +565,29 @@ __global__ __launch_bounds__(256) void emit_kernel(const DevEncImage *__restrict
     const uint64_t wg_end = last_wg ? ((raw_bits[wk.image] + 7ull) & ~7ull) : wg_base[blockIdx.x + 1];
     const uint64_t first_word = wg_start >> 5;
     const uint64_t span_bits = wg_end - (first_word << 5);
-    const bool use_lds = span_bits <= (uint64_t)kEmitLdsWords * 32u;  // the same for every lane
+    const bool use_lds = span_bits <= (uint64_t)lds_words * 32u;  // the same for every lane
     const uint32_t n_words = use_lds ? (uint32_t)((span_bits + 31u) >> 5) : 0u;
     for (uint32_t w = threadIdx.x; w < n_words; w += 256u) sh_words[w] = 0;
     __syncthreads();
     const uint64_t start = wg_start + (active ? bits[im.coef_off + blk] : 0u);
-    uint64_t wi = start >> 5;            // current word
-    uint32_t fill = (uint32_t)(start & 31);  // bits already taken in it (by earlier blocks): always < 32 between calls
-    uint64_t acc = 0;                    // the current word in the high half, what spills over in the low half
+    uint32_t wi = (uint32_t)((start >> 5) - first_word);  // current word, counted from the workgroup's first
+    uint32_t fill = (uint32_t)(start & 31);               // bits already taken in it (by earlier blocks): always < 32 between calls
+    uint32_t cur = 0;                                     // the current word, MSB first
     auto flush_word = [&](uint32_t w) {
-        if (use_lds) atomicOr(&sh_words[(uint32_t)(wi - first_word)], w);
-        else atomicOr(&words[wi], __builtin_bswap32(w));
+        if (use_lds) atomicOr(&sh_words[wi], w);
+        else atomicOr(&words[first_word + wi], __builtin_bswap32(w));  // (plain stores for the words in between: measured slower)
     };
-    auto flush = [&]() { flush_word((uint32_t)(acc >> 32)); };
+    auto flush = [&]() { flush_word(cur); };
     auto put = [&](uint32_t code, uint32_t len) {  // len <= 32 (31 from enc_block_symbols), code < 2^len
         if (len == 0) return;  // a symbol the table has no code for (and the reference writes nothing for)
-        acc |= (uint64_t)code << (64u - fill - len);
+        const uint32_t left = code << (32u - len);  // the field with its first bit at bit 31
+        cur |= left >> fill;
+        const uint32_t before = fill;
         fill += len;
         if (fill >= 32u) {
             flush();
             wi++;
-            acc <<= 32;
+            cur = __builtin_amdgcn_alignbit(left, 0u, before);  // what did not fit: left << (32 - before), 0 when before == 0
             fill -= 32u;
         }
     };
@@ -783,9 +787,11 @@ hipError_t launch_block_stats(hipStream_t stream, const DevEncImage *images, con
 }
 hipError_t launch_emit(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
                        const int16_t *coefs, const uint32_t *bits, const uint64_t *wg_base, const uint64_t *raw_bits, uint8_t *raw,
-                       uint32_t *marks) {
+                       uint32_t *marks, uint32_t lds_words) {
     if (n_work <= 0) return hipSuccess;
-    hipLaunchKernelGGL(emit_kernel, dim3(n_work), dim3(256), 0, stream, images, work, tables, coefs, bits, wg_base, raw_bits, raw, marks);
+    if (lds_words != 0) lds_words = std::min(std::max(lds_words, kEmitLdsWordsMin), kEmitLdsWordsMax);  // 0: no workgroup's stretch would fit
+    hipLaunchKernelGGL(emit_kernel, dim3(n_work), dim3(256), (size_t)lds_words * 4, stream, images, work, tables, coefs, bits, wg_base, raw_bits, raw,
+                       marks, lds_words);
     return hipGetLastError();
 }
 hipError_t launch_stuff(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const uint64_t *raw_bits,
