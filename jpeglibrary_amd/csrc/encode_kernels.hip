@@ -137,6 +137,26 @@ __device__ __forceinline__ void fdct_quantize(const int32_t (&smp)[64], const ui
     }
 }
 
+// The same, one row of eight quantised coefficients at a time (zig-zag positions 8r .. 8r + 7), handed to `row(r, values)`
+// as soon as they exist: the 64 results never stand in registers together.
+template <typename Row>
+__device__ __forceinline__ void fdct_quantize_rows(const int32_t (&smp)[64], const uint16_t *quant, Row row) {
+    float f[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) f[i] = (float)(smp[i] - 128);
+    block_fdct(f);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int32_t q[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float v = f[kEncNat[r * 8 + i]] / (float)quant[r * 8 + i];
+            q[i] = (int32_t)(int16_t)(int32_t)__builtin_rintf(v);  // half to even; (short) wraps
+        }
+        row(r, q);
+    }
+}
+
 __device__ __forceinline__ uint4 pack8_i16(const int32_t (&v)[8]) {
     return uint4{((uint32_t)v[0] & 0xFFFFu) | ((uint32_t)v[1] << 16), ((uint32_t)v[2] & 0xFFFFu) | ((uint32_t)v[3] << 16),
                  ((uint32_t)v[4] & 0xFFFFu) | ((uint32_t)v[5] << 16), ((uint32_t)v[6] & 0xFFFFu) | ((uint32_t)v[7] << 16)};
@@ -252,9 +272,16 @@ __global__ __launch_bounds__(8 * kEncMcusPerWg) void enc_gather_kernel(const uin
 // own zeroed allocator slot (TransformBlocks :414-485) and nothing carries over.
 // (First version: one kernel, the gather inside the block loop row by row through LDS -- 211 VGPRs and 33 KB of LDS kept
 // it at 2 waves per SIMD with a load-use wait per pixel row: 2.4 ms per 64 x 4K, 47 % of the wave cycles waiting.)
-__global__ __launch_bounds__(kEncMcusPerWg) void fdct_quant_kernel(const uint8_t *__restrict__ samples, const DevEncImage *__restrict__ images,
+#ifndef JPGPU_E1B_WAVES
+#define JPGPU_E1B_WAVES 1
+#endif
+__global__ __launch_bounds__(kEncMcusPerWg, JPGPU_E1B_WAVES) void fdct_quant_kernel(const uint8_t *__restrict__ samples, const DevEncImage *__restrict__ images,
                                                                    const EncWork *__restrict__ work, int16_t *__restrict__ coefs) {
     __shared__ uint16_t sh_q[2][64];
+    // a wave's 64 blocks (one per lane, 128 bytes each) on their way out: every lane's eight 16-byte rows, then eight lanes per
+    // block write it as ONE 128-byte line -- a lane storing its own block touches 64 lines with every store instruction and
+    // each of them eight times
+    __shared__ __attribute__((aligned(16))) uint8_t sh_blk[kEncMcusPerWg * 128];
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
     const uint32_t lane = threadIdx.x;
@@ -263,14 +290,14 @@ __global__ __launch_bounds__(kEncMcusPerWg) void fdct_quant_kernel(const uint8_t
         sh_q[1][lane] = im.quant[1][lane];
     }
     __syncthreads();
-    const uint32_t mcu = wk.first + lane;
-    if (mcu >= im.mcus_per_line * im.mcus_per_column) return;
+    const uint32_t n_mcus = im.mcus_per_line * im.mcus_per_column;
+    if (wk.first + (lane & ~63u) >= n_mcus) return;  // (whole waves only: the lanes of a wave write each other's blocks)
+    const uint32_t mcu = wk.first + lane < n_mcus ? wk.first + lane : n_mcus - 1;  // lanes behind the last MCU redo it, and store nothing
     const uint32_t components = im.components, bpm = im.bpm;
     const uint32_t H = im.luma_h, V = im.luma_v, ny = H * V;
     const uint32_t total = (31 - __builtin_clz(H)) + (31 - __builtin_clz(V));  // rounding shift of a chroma sample
     const bool own_blocks = im.table_base != 0;
     const uint8_t *in = samples + (uint64_t)im.smp_off_256 * 256u + (uint64_t)mcu * enc_sample_stride(H, V, components);
-    int16_t *out = coefs + (im.coef_off + (uint64_t)mcu * bpm) * 64;
     uint4 prev[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) prev[r] = uint4{0, 0, 0, 0};
@@ -285,10 +312,15 @@ __global__ __launch_bounds__(kEncMcusPerWg) void fdct_quant_kernel(const uint8_t
             for (int v4 = 4; v4 < 8; v4++) dst[v4] = p[v4];
         }
     };
+#ifndef JPGPU_E1B_NO_PREFETCH
     fetch(0, raw);
+#endif
 #pragma unroll 1
     for (uint32_t b = 0; b < bpm; b++) {
-        int32_t smp[64], q[64];
+        int32_t smp[64];
+#ifdef JPGPU_E1B_NO_PREFETCH
+        fetch(b, raw);
+#endif
         if (b < ny) {
 #pragma unroll
             for (int v4 = 0; v4 < 4; v4++) {
@@ -309,18 +341,27 @@ __global__ __launch_bounds__(kEncMcusPerWg) void fdct_quant_kernel(const uint8_t
                 }
             }
         }
+#ifndef JPGPU_E1B_NO_PREFETCH
         if (b + 1 < bpm) fetch(b + 1, raw);
-        fdct_quantize(smp, sh_q[b < ny ? 0 : 1], q);
-        uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)b * 64);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            int32_t row[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) row[i] = q[r * 8 + i];
+#endif
+        uint8_t *mine = sh_blk + lane * 128u;
+        fdct_quantize_rows(smp, sh_q[b < ny ? 0 : 1], [&](int r, const int32_t (&row)[8]) {
             const uint4 pk = pack8_i16(row);
-            dst[r] = pk;
+            *reinterpret_cast<uint4 *>(mine + (((uint32_t)r ^ (lane & 7u)) * 16u)) = pk;  // (swizzled: eight lanes, eight columns)
             if (!own_blocks) prev[r] = pk;  // ZigZagAndQuantizeBlock writes into the buffer the next ReadBlock starts from
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes (no other wave touches its 8 KB)
+        {
+            const uint32_t w0 = lane & ~63u, sub = (lane & 63u) >> 3, piece = lane & 7u;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t owner = w0 + k * 8u + sub;  // the lane whose block this is
+                const uint4 v = *reinterpret_cast<const uint4 *>(sh_blk + owner * 128u + ((piece ^ (owner & 7u)) * 16u));
+                if (wk.first + owner < n_mcus)
+                    *reinterpret_cast<uint4 *>(coefs + (im.coef_off + (uint64_t)(wk.first + owner) * bpm + b) * 64 + piece * 8u) = v;
+            }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read before the next block's rows overwrite it
     }
 }
 
