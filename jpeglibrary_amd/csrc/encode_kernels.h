@@ -48,7 +48,7 @@ struct EncWork {
 
 // E1a (pixel pass into `samples`, enc_sample_stride bytes per MCU) + E1b (FDCT + quantisation)
 hipError_t launch_fdct_quant(hipStream_t stream, const uint8_t *pixels, const DevEncImage *images, const EncWork *work, int n_work,
-                             uint8_t *samples, int16_t *coefs);
+                             uint8_t *samples, int16_t *coefs, size_t max_record_bytes);  // (the largest enc_sample_bytes_per_mcu of the batch)
 size_t enc_sample_bytes_per_mcu(uint32_t luma_h, uint32_t luma_v, uint32_t components);
 hipError_t launch_block_bits(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
                              const int16_t *coefs, uint32_t *bits, int n_images, uint32_t *wg_bits, uint64_t *wg_base, uint64_t *raw_bits);

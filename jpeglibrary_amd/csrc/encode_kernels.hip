@@ -193,9 +193,50 @@ __host__ __device__ constexpr uint32_t enc_sample_stride(uint32_t luma_h, uint32
 
 // The luma_v pixel rows behind chroma row k of one MCU, HS = luma_h blocks of 8 pixels each: luma samples to their blocks,
 // chroma values summed per chroma sample (8 / HS of them per block of 8 pixels: with HS fixed the sums stay in registers).
-template <int HS>
+template <int HS, typename OutPtr>
 __device__ __forceinline__ void enc_gather_rows(const EncSrc &src, uint32_t x0, uint32_t ymcu, uint32_t k, uint32_t V, uint32_t components,
-                                                bool rows_aligned, uint8_t *out, int32_t (&sum1)[8], int32_t (&sum2)[8]) {
+                                                bool rows_aligned, OutPtr out, int32_t (&sum1)[8], int32_t (&sum2)[8]) {
+    // The usual case -- RGB rows, the lane's pixels all inside the image, at most two pixel rows of at most two blocks --
+    // loads everything first (up to 96 bytes per lane in flight instead of 24) and converts afterwards.
+    if (HS <= 2 && V <= 2 && src.comps == 3 && components == 3 && rows_aligned && x0 + 8 * HS <= src.width && ymcu + k * V + V <= src.height) {
+        uint32_t w[2][HS][6];
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+            if ((uint32_t)dy < V) {
+                const uint8_t *rowp = src.px + ((size_t)(ymcu + k * V + dy) * src.width + x0) * 3;
+#pragma unroll
+                for (int bx = 0; bx < HS; bx++) __builtin_memcpy(w[dy][bx], __builtin_assume_aligned(rowp + bx * 24, 4), 24);
+            }
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+            if ((uint32_t)dy < V) {
+                const uint32_t ry = k * V + dy, by = ry >> 3, r = ry & 7u;
+#pragma unroll
+                for (int bx = 0; bx < HS; bx++) {
+                    int32_t c0[8], c1[8], c2[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int32_t b0 = (w[dy][bx][(3 * i) >> 2] >> (8 * ((3 * i) & 3))) & 0xFF;
+                        const int32_t b1 = (w[dy][bx][(3 * i + 1) >> 2] >> (8 * ((3 * i + 1) & 3))) & 0xFF;
+                        const int32_t b2 = (w[dy][bx][(3 * i + 2) >> 2] >> (8 * ((3 * i + 2) & 3))) & 0xFF;
+                        c0[i] = enc_convert(src, 0, b0, b1, b2);
+                        c1[i] = enc_convert(src, 1, b0, b1, b2);
+                        c2[i] = enc_convert(src, 2, b0, b1, b2);
+                    }
+                    uint2 pk;
+                    pk.x = (uint32_t)c0[0] | ((uint32_t)c0[1] << 8) | ((uint32_t)c0[2] << 16) | ((uint32_t)c0[3] << 24);
+                    pk.y = (uint32_t)c0[4] | ((uint32_t)c0[5] << 8) | ((uint32_t)c0[6] << 16) | ((uint32_t)c0[7] << 24);
+                    *reinterpret_cast<uint2 *>(out + (by * HS + (uint32_t)bx) * 64 + r * 8) = pk;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        constexpr int kShift = HS == 1 ? 0 : (HS == 2 ? 1 : 2);
+                        sum1[(bx * 8 + i) >> kShift] += c1[i];
+                        sum2[(bx * 8 + i) >> kShift] += c2[i];
+                    }
+                }
+            }
+        return;
+    }
     for (uint32_t dy = 0; dy < V; dy++) {
         const uint32_t ry = k * V + dy;  // pixel row inside the MCU
         const uint32_t y = ymcu + ry;
@@ -233,35 +274,58 @@ __device__ __forceinline__ void enc_gather_rows(const EncSrc &src, uint32_t x0, 
 // E1a: the pixel pass.  One lane per (MCU, chroma row k of the MCU): the luma_v pixel rows behind that chroma row, 8 x luma_h
 // pixels each -- converted once (RGB -> YCbCr when asked to), luma samples to their blocks, chroma values summed.  Lanes of
 // a wave are consecutive MCUs of one k, so a wave reads whole contiguous stretches of a pixel row.
+// STAGE: the workgroup's 128 MCU records (enc_sample_stride bytes each, contiguous in `samples`) are put together in LDS and
+// go out as one contiguous stretch, 16 bytes per lane.  Written where they are produced they are 8- and 16-byte pieces 512
+// bytes apart, eight waves contributing to every line at eight different times: WRITE_SIZE showed 2.5 GB leaving the L2
+// for the 0.27 GB of samples of 64 images (tools/trace/encoder_pmc.sh).  Not STAGE: records too large for 64 KB of LDS.
+template <bool STAGE>
 __global__ __launch_bounds__(8 * kEncMcusPerWg) void enc_gather_kernel(const uint8_t *__restrict__ pixels, const DevEncImage *__restrict__ images,
                                                                        const EncWork *__restrict__ work, uint8_t *__restrict__ samples) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t sh_records[];
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
     const uint32_t m = threadIdx.x % kEncMcusPerWg, k = threadIdx.x / kEncMcusPerWg;
-    const uint32_t mcu = wk.first + m;
     const uint32_t mcus_per_line = im.mcus_per_line;
-    if (mcu >= mcus_per_line * im.mcus_per_column) return;
-    EncSrc src;
-    src.px = pixels + im.px_off;
-    src.width = im.width;
-    src.height = im.height;
-    src.comps = im.in_components;
-    src.rgb = im.input_rgb != 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) src.k[i] = im.r2y[i];
+    const uint32_t n_mcus = mcus_per_line * im.mcus_per_column;
+    const bool active = wk.first + m < n_mcus;
+    if (!STAGE && !active) return;
+    const uint32_t mcu = active ? wk.first + m : n_mcus - 1;
     const uint32_t H = im.luma_h, V = im.luma_v, components = im.components;
-    const uint32_t mx = mcu % mcus_per_line, my = mcu / mcus_per_line;
-    const uint32_t x0 = mx * 8 * H;
-    const bool rows_aligned = ((src.width * src.comps) & 3u) == 0;
-    uint8_t *out = samples + (uint64_t)im.smp_off_256 * 256u + (uint64_t)mcu * enc_sample_stride(H, V, components);
-    int32_t sum1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sum2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (H == 1) enc_gather_rows<1>(src, x0, my * 8 * V, k, V, components, rows_aligned, out, sum1, sum2);
-    else if (H == 2) enc_gather_rows<2>(src, x0, my * 8 * V, k, V, components, rows_aligned, out, sum1, sum2);
-    else enc_gather_rows<4>(src, x0, my * 8 * V, k, V, components, rows_aligned, out, sum1, sum2);
-    if (components > 1) {
-        uint8_t *cb = out + H * V * 64 + k * 16;
-        *reinterpret_cast<uint4 *>(cb) = pack8_i16(sum1);
-        *reinterpret_cast<uint4 *>(cb + 128) = pack8_i16(sum2);
+    const uint32_t stride = enc_sample_stride(H, V, components);
+    uint8_t *global_base = samples + (uint64_t)im.smp_off_256 * 256u;
+    if (active) {
+        EncSrc src;
+        src.px = pixels + im.px_off;
+        src.width = im.width;
+        src.height = im.height;
+        src.comps = im.in_components;
+        src.rgb = im.input_rgb != 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) src.k[i] = im.r2y[i];
+        const uint32_t mx = mcu % mcus_per_line, my = mcu / mcus_per_line;
+        const uint32_t x0 = mx * 8 * H;
+        const bool rows_aligned = ((src.width * src.comps) & 3u) == 0;
+        int32_t sum1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sum2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto rows = [&](auto *out) {
+            if (H == 1) enc_gather_rows<1>(src, x0, my * 8 * V, k, V, components, rows_aligned, out, sum1, sum2);
+            else if (H == 2) enc_gather_rows<2>(src, x0, my * 8 * V, k, V, components, rows_aligned, out, sum1, sum2);
+            else enc_gather_rows<4>(src, x0, my * 8 * V, k, V, components, rows_aligned, out, sum1, sum2);
+            if (components > 1) {
+                auto *cb = out + H * V * 64 + k * 16;
+                *reinterpret_cast<uint4 *>(cb) = pack8_i16(sum1);
+                *reinterpret_cast<uint4 *>(cb + 128) = pack8_i16(sum2);
+            }
+        };
+        if (STAGE) rows(sh_records + m * stride);
+        else rows(global_base + (uint64_t)mcu * stride);
+    }
+    if (STAGE) {
+        __syncthreads();
+        const uint32_t n_here = n_mcus - wk.first < (uint32_t)kEncMcusPerWg ? n_mcus - wk.first : (uint32_t)kEncMcusPerWg;
+        const uint32_t bytes = n_here * stride;  // a multiple of 64
+        uint8_t *dst = global_base + (uint64_t)wk.first * stride;
+        for (uint32_t o = threadIdx.x * 16u; o < bytes; o += 8u * kEncMcusPerWg * 16u)
+            *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(sh_records + o);
     }
 }
 
@@ -807,9 +871,11 @@ __global__ __launch_bounds__(256) void stuff_write_kernel(const DevEncImage *__r
 size_t enc_sample_bytes_per_mcu(uint32_t luma_h, uint32_t luma_v, uint32_t components) { return enc_sample_stride(luma_h, luma_v, components); }
 
 hipError_t launch_fdct_quant(hipStream_t stream, const uint8_t *pixels, const DevEncImage *images, const EncWork *work, int n_work,
-                             uint8_t *samples, int16_t *coefs) {
+                             uint8_t *samples, int16_t *coefs, size_t max_record_bytes) {
     if (n_work <= 0) return hipSuccess;
-    hipLaunchKernelGGL(enc_gather_kernel, dim3(n_work), dim3(8 * kEncMcusPerWg), 0, stream, pixels, images, work, samples);
+    const size_t lds = max_record_bytes * (size_t)kEncMcusPerWg;
+    if (lds <= 64 * 1024) hipLaunchKernelGGL(enc_gather_kernel<true>, dim3(n_work), dim3(8 * kEncMcusPerWg), lds, stream, pixels, images, work, samples);
+    else hipLaunchKernelGGL(enc_gather_kernel<false>, dim3(n_work), dim3(8 * kEncMcusPerWg), 0, stream, pixels, images, work, samples);
     hipLaunchKernelGGL(fdct_quant_kernel, dim3(n_work), dim3(kEncMcusPerWg), 0, stream, samples, images, work, coefs);
     return hipGetLastError();
 }
