@@ -398,11 +398,13 @@ __global__ __launch_bounds__(kEncMcusPerWg, JPGPU_E1B_WAVES) void fdct_quant_ker
                 int32_t sum[8], base[8];
                 unpack8_i16(raw[r], sum);
                 unpack8_i16(prev[r], base);
+                // (branch-free: as `if (total == 0) ... else ...` this was a scalar branch per sample, 128 of them per chroma block)
+                // (and `total == 0 ? a : b` on a uniform condition becomes a branch again: without sub-sampling the block does not
+                // start from the previous one, which is the same as a previous block of zeros)
+                const int32_t half = total == 0 ? 0 : 1 << (total - 1), keep = total == 0 ? 0 : -1;
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    if (total == 0) smp[r * 8 + i] = sum[i];
-                    else smp[r * 8 + i] = (int32_t)(int16_t)(((int32_t)(int16_t)(base[i] + sum[i]) + (1 << (total - 1))) >> total);
-                }
+                for (int i = 0; i < 8; i++)
+                    smp[r * 8 + i] = (int32_t)(int16_t)(((int32_t)(int16_t)((base[i] & keep) + sum[i]) + half) >> total);
             }
         }
 #ifndef JPGPU_E1B_NO_PREFETCH
