@@ -3616,7 +3616,9 @@ __device__ __forceinline__ int32_t k2_open_at_bit(const uint8_t *ubase, uint32_t
 // The stream comes through the word reader (UBits): staging it in LDS was measured and lost -- the rounds are latency
 // bound and need the occupancy more than the shorter instruction stream (13.1 vs 11.1 ms per 256 x 4K).
 
-__global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+// (96 scalar registers: with the 102 hipcc takes by itself seven waves fit a SIMD instead of eight, and the rounds live on
+// occupancy -- 29.83 -> 29.28 ms per 1024 x 4K step; six scalars go to a vector register's lanes)
+__attribute__((amdgpu_num_sgpr(96))) __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
                                                             const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
                                                             const DevScanStatus *__restrict__ status, const DevHuffTable *__restrict__ huff_pool,
                                                             const uint32_t *__restrict__ lut_pool,
