@@ -565,6 +565,72 @@ __device__ __forceinline__ void ub_init(UBits &r, const uint8_t *ubase, uint32_t
     r.rem = (int32_t)((uend - ustart) * 8u);
 }
 
+// The round kernel's reader: UBits with the refill load issued BY HAND.  hipcc copies a loaded chunk into the queue right
+// behind the load -- s_waitcnt vmcnt(0) inside the refill branch, which some lane of a wave takes in nine steps of ten
+// (64 lanes, a chunk every ~24 symbols each): every step of the rounds paid a memory round trip.  Here the load writes
+// the queue's own registers and nothing waits for it until the next refill (of any lane: a step later at the earliest).
+// The compiler does not know a load is in flight, so the waits are spelled out: in front of the next read of nx, and
+// behind the loop (ub_async_drain) before the registers can be given to something else.  K2S 18.6 -> 17.6 ms per 1024 x 4K.
+typedef uint32_t jpgpu_u32x4 __attribute__((ext_vector_type(4)));
+struct UBitsA {
+    const uint8_t *p;
+    jpgpu_u32x4 qw;
+    uint32_t nx0, nx1, nx2, nx3;
+    uint32_t qn;
+    uint32_t hi, lo;
+    int32_t lcnt;
+    int32_t rem;
+};
+__device__ __forceinline__ uint32_t uba_next_word(UBitsA &r) {
+    const uint32_t w = r.qw.x;
+    r.qw.x = r.qw.y;
+    r.qw.y = r.qw.z;
+    r.qw.z = r.qw.w;
+    r.qn--;
+    if (r.qn == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loads of earlier steps (this lane's: a whole chunk ago)
+        r.qw = jpgpu_u32x4{r.nx0, r.nx1, r.nx2, r.nx3};
+        // (four dword loads: a four-register tuple makes hipcc gather nx into consecutive registers and copy it back -- out of
+        // registers the load has not reached yet)
+        asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %4, off offset:4\n\tglobal_load_dword %2, %4, off offset:8\n\t"
+                     "global_load_dword %3, %4, off offset:12"
+                     : "+v"(r.nx0), "+v"(r.nx1), "+v"(r.nx2), "+v"(r.nx3)
+                     : "v"(r.p)
+                     : "memory");
+        r.p += 16;
+        r.qn = 4;
+    }
+    return __builtin_bswap32(w);
+}
+__device__ __forceinline__ void uba_drain(UBitsA &r) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.nx0), "+v"(r.nx1), "+v"(r.nx2), "+v"(r.nx3) : : "memory");
+}
+__device__ __forceinline__ void uba_consume(UBitsA &r, uint32_t n) {
+    r.hi = __builtin_amdgcn_alignbit(r.hi, r.lo, (32u - n) & 31u);
+    r.lo = n >= 32u ? 0u : (r.lo << n);
+    r.lcnt -= (int32_t)n;
+    if (r.lcnt < 0) {
+        const uint32_t d = (uint32_t)(-r.lcnt);
+        const uint32_t w = uba_next_word(r);
+        r.hi |= w >> ((32u - d) & 31u);
+        r.lo = d >= 32u ? 0u : (w << d);
+        r.lcnt = 32 - (int32_t)d;
+    }
+}
+__device__ __forceinline__ void uba_from(UBitsA &a, const UBits &r) {
+    a.p = r.p;
+    a.qw = jpgpu_u32x4{r.qw.x, r.qw.y, r.qw.z, r.qw.w};
+    a.nx0 = r.nx.x;
+    a.nx1 = r.nx.y;
+    a.nx2 = r.nx.z;
+    a.nx3 = r.nx.w;
+    a.qn = r.qn;
+    a.hi = r.hi;
+    a.lo = r.lo;
+    a.lcnt = r.lcnt;
+    a.rem = r.rem;
+}
+
 // LDS image of a staged DevHuffTable
 struct LdsHuff {
     const uint16_t *lut;
@@ -3692,10 +3758,12 @@ __attribute__((amdgpu_num_sgpr(96))) __global__ __launch_bounds__(256) void subs
     if (start_bit >= total_bits) {
         ex = sub_pack(0, b_in_mcu, i2 >> 1) | kSubBad;
     } else {
-        UBits r;
-        ub_init(r, udata + s.data_off, start_bit >> 3, (total_bits + 7) >> 3);
-        if (start_bit & 7u) ub_consume(r, start_bit & 7u);
-        r.rem = (int32_t)total_bits - (int32_t)start_bit;
+        UBits r0;
+        ub_init(r0, udata + s.data_off, start_bit >> 3, (total_bits + 7) >> 3);
+        if (start_bit & 7u) ub_consume(r0, start_bit & 7u);
+        r0.rem = (int32_t)total_bits - (int32_t)start_bit;
+        UBitsA r;  // (from here on the refill loads are not the compiler's: uba_next_word)
+        uba_from(r, r0);
         uint32_t pos = start_bit;
         uint32_t info = blk_info[b_in_mcu];
         while (pos < end_bit && r.rem > 0) {
@@ -3757,9 +3825,10 @@ __attribute__((amdgpu_num_sgpr(96))) __global__ __launch_bounds__(256) void subs
                 info = blk_info[b_in_mcu];
             }
             r.rem -= (int32_t)n;
-            ub_consume(r, n);
+            uba_consume(r, n);
             pos += n;
         }
+        uba_drain(r);  // nothing in flight into registers the compiler will reuse
         const uint32_t over = pos > end_bit ? pos - end_bit : 0u;
         ex = sub_pack(over < 63u ? over : 63u, b_in_mcu, i2 >> 1);
         if (bad) ex = sub_pack(0, b_in_mcu, i2 >> 1) | kSubBad;
