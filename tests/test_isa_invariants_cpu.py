@@ -59,3 +59,27 @@ def test_nothing_reads_the_refill_registers_behind_the_hand_issued_load(tmp_path
         if t.endswith(":") or t.startswith("s_branch") or t.startswith("s_cbranch") or t.startswith("s_endpgm"):
             break
         assert not (_regs(t) & loaded), "touches a register the refill load is still writing: " + t
+    # ... and anywhere in the loop around it (the registers are loop-carried: nothing else may live in them), whoever touches
+    # them does so in a basic block that has waited for ALL outstanding loads first and has not issued one since
+    header = max(k for k in range(i) if "=>This Loop Header: Depth=1" in body[k])
+    name = re.match(r"\.L(BB\d+_\d+):", body[header]).group(1)  # e.g. BB8_59, as the block comments name the loop
+    last = max(k for k in range(header, len(body)) if ("Header=" + name) in body[k] or ("Parent Loop " + name) in body[k])
+    stop = next((k for k in range(last + 1, len(body)) if re.match(r"\.LBB\d+_\d+:", body[k])), len(body))
+    waited = False
+    for k in range(header, stop):
+        t = body[k].strip()
+        if not t or t.startswith(";"):
+            continue
+        if re.match(r"\.LBB\d+_\d+:", t) or t.startswith("s_branch") or t.startswith("s_cbranch"):
+            waited = False
+            continue
+        if t.startswith("s_waitcnt vmcnt(0)"):
+            waited = True
+            continue
+        if t.startswith("global_load") or t.startswith("buffer_load") or t.startswith("flat_load"):
+            if i < k < i + 5:
+                waited = False  # the hand-issued loads themselves
+                continue
+            waited = False
+        if _regs(t) & loaded:
+            assert waited, "line %d of the kernel touches a refill register without a full wait in its block: %s" % (k, t)
