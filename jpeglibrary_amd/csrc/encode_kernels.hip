@@ -137,10 +137,36 @@ __device__ __forceinline__ void fdct_quantize(const int32_t (&smp)[64], const ui
     }
 }
 
-// The same, one row of eight quantised coefficients at a time (zig-zag positions 8r .. 8r + 7), handed to `row(r, values)`
-// as soon as they exist: the 64 results never stand in registers together.
+// F / Q as the hardware's own IEEE division computes it, with the part that depends on Q alone taken out of the block.
+// hipcc expands a / b into v_div_scale x 2, v_rcp, one Newton step on the reciprocal (fma, fma), q0 = a * r, two
+// residual corrections (fma, fma, fma, then v_div_fmas = one more fma) and v_div_fixup -- eleven dependent instructions,
+// and because the second v_div_scale hands a flag to v_div_fmas through VCC it does not interleave two divisions: 64 of them
+// were a third of the kernel's instructions and most of its stalls.  For a divisor in [1, 65535] and a dividend that is zero
+// or not smaller than ~1e-6 in magnitude the scaling steps are the identity and the fix-up returns its first operand, so
+// the quotient is exactly  r = rcp(b) refined once;  q0 = a r;  q1 = fma(fma(-b, q0, a), r, q0);  q = fma(fma(-b, q1, a), r, q1)
+// -- the same instructions on the same operands, bit for bit (byte-exact encoder tests, tools/stress_parity.py).  b and r
+// come from LDS (quant_pair: once per workgroup), the five that remain are independent from coefficient to coefficient.
+struct QuantPair {
+    float d, r;
+};
+__device__ __forceinline__ QuantPair quant_pair(uint32_t q) {
+    QuantPair p;
+    p.d = (float)q;
+    float r0;
+    asm("v_rcp_f32 %0, %1" : "=v"(r0) : "v"(p.d));  // (the builtin becomes v_rcp_iflag_f32 behind an integer conversion)
+    p.r = __builtin_fmaf(__builtin_fmaf(-p.d, r0, 1.0f), r0, r0);
+    return p;
+}
+__device__ __forceinline__ float quant_divide(float a, const QuantPair &p) {
+    const float q0 = a * p.r;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-p.d, q0, a), p.r, q0);
+    return __builtin_fmaf(__builtin_fmaf(-p.d, q1, a), p.r, q1);
+}
+
+// ShiftDataLevel + TransformFDCT + ZigZagAndQuantizeBlock, one row of eight quantised coefficients at a time (zig-zag
+// positions 8r .. 8r + 7), handed to `row(r, values)` as soon as they exist: the 64 results never stand in registers together.
 template <typename Row>
-__device__ __forceinline__ void fdct_quantize_rows(const int32_t (&smp)[64], const uint16_t *quant, Row row) {
+__device__ __forceinline__ void fdct_quantize_rows(const int32_t (&smp)[64], const QuantPair *quant, Row row) {
     float f[64];
 #pragma unroll
     for (int i = 0; i < 64; i++) f[i] = (float)(smp[i] - 128);
@@ -150,7 +176,7 @@ __device__ __forceinline__ void fdct_quantize_rows(const int32_t (&smp)[64], con
         int32_t q[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float v = f[kEncNat[r * 8 + i]] / (float)quant[r * 8 + i];
+            const float v = quant_divide(f[kEncNat[r * 8 + i]], quant[r * 8 + i]);
             q[i] = (int32_t)(int16_t)(int32_t)__builtin_rintf(v);  // half to even; (short) wraps
         }
         row(r, q);
@@ -341,7 +367,7 @@ __global__ __launch_bounds__(8 * kEncMcusPerWg) void enc_gather_kernel(const uin
 #endif
 __global__ __launch_bounds__(kEncMcusPerWg, JPGPU_E1B_WAVES) void fdct_quant_kernel(const uint8_t *__restrict__ samples, const DevEncImage *__restrict__ images,
                                                                    const EncWork *__restrict__ work, int16_t *__restrict__ coefs) {
-    __shared__ uint16_t sh_q[2][64];
+    __shared__ QuantPair sh_q[2][64];  // the two quantisation tables as (divisor, refined reciprocal)
     // a wave's 64 blocks (one per lane, 128 bytes each) on their way out: every lane's eight 16-byte rows, then eight lanes per
     // block write it as ONE 128-byte line -- a lane storing its own block touches 64 lines with every store instruction and
     // each of them eight times
@@ -350,8 +376,8 @@ __global__ __launch_bounds__(kEncMcusPerWg, JPGPU_E1B_WAVES) void fdct_quant_ker
     const DevEncImage &im = images[wk.image];
     const uint32_t lane = threadIdx.x;
     if (lane < 64) {
-        sh_q[0][lane] = im.quant[0][lane];
-        sh_q[1][lane] = im.quant[1][lane];
+        sh_q[0][lane] = quant_pair(im.quant[0][lane]);
+        sh_q[1][lane] = quant_pair(im.quant[1][lane]);
     }
     __syncthreads();
     const uint32_t n_mcus = im.mcus_per_line * im.mcus_per_column;

@@ -1544,6 +1544,23 @@ def test_jpeg_encoder_mirror_runs_the_encode_action_sequence(quality, optimize_c
     assert out == po.encode_8bit(ycc, 2, 2, quality, optimize_coding=(2 if most_optimal else 1) if optimize_coding else 0)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_quantisation_quotients_on_random_tables_and_full_range_samples(seed):
+    """E1b does not divide: it runs the five instructions hipcc's IEEE division ends in, with the divisor's refined reciprocal
+    taken from LDS (quant_pair / quant_divide, encode_kernels.hip).  White noise puts the DCT coefficients all over their
+    range, random tables put every divisor 1..255 under them: 390 000 quotients per case, each rounded half-to-even right
+    behind the division -- one quotient an ulp off near a tie changes a coefficient and the bytes of the stream."""
+    rng = np.random.default_rng(1000 + seed)
+    img = rng.integers(0, 256, (512, 512, 3)).astype(np.uint8)
+    img[:64] = (img[:64] // 128) * 255  # and some blocks at the extremes
+    lum, chr_ = rng.integers(1, 256, 64), rng.integers(1, 256, 64)
+    if seed == 4:
+        lum, chr_ = np.full(64, 255), np.arange(1, 65)
+    for luma in ((2, 2), (1, 1)):
+        ref = po.encode_8bit(img, luma[0], luma[1], 50, optimize_coding=False, quant_tables=(lum, chr_))
+        assert _encode_action(img, 50, False, luma=luma, tables=(lum.tolist(), chr_.tolist())) == ref
+
+
 def test_jpeg_encoder_mirror_takes_the_callers_quantization_tables():
     """SetQuantizationTable with tables that are no scaled standard table: flat, steep, and libjpeg's quality-100 all-ones."""
     ycc = po.rgb_to_ycbcr8(_enc_image(97, 61, 3))
