@@ -654,9 +654,11 @@ def test_a_scan_inside_an_end_of_band_run_still_follows_its_producers(slow_scan,
     refs = [po.decode_8bit(f)[0] for f in files]
     monkeypatch.delenv("JPGPU_PROG_NO_PIPELINE", raising=False)
     b0 = jl.Batch().upload(files).decode().sync()  # (first decode of the process: module load, LDS shape ...)
-    t0 = time.perf_counter()
-    b0.decode().sync()
-    undelayed = time.perf_counter() - t0
+    undelayed = 1e9
+    for _ in range(3):  # (the fastest of three: a hiccup here must not pass for the hook being dead)
+        t0 = time.perf_counter()
+        b0.decode().sync()
+        undelayed = min(undelayed, time.perf_counter() - t0)
     b0.close()
     monkeypatch.setenv("JPGPU_DEBUG_DELAY_SCAN", "%d:4" % slow_scan)
     b = jl.Batch().upload(files)
