@@ -303,7 +303,7 @@ __device__ __forceinline__ void enc_gather_rows(const EncSrc &src, uint32_t x0, 
 // STAGE: the workgroup's 128 MCU records (enc_sample_stride bytes each, contiguous in `samples`) are put together in LDS and
 // go out as one contiguous stretch, 16 bytes per lane.  Written where they are produced they are 8- and 16-byte pieces 512
 // bytes apart, eight waves contributing to every line at eight different times: WRITE_SIZE showed 2.5 GB leaving the L2
-// for the 0.27 GB of samples of 64 images (tools/trace/encoder_pmc.sh).  Not STAGE: records too large for 64 KB of LDS.
+// for the 1.06 GB of samples of 64 images (tools/trace/encoder_pmc.sh).  Not STAGE: records too large for 64 KB of LDS.
 template <bool STAGE>
 __global__ __launch_bounds__(8 * kEncMcusPerWg) void enc_gather_kernel(const uint8_t *__restrict__ pixels, const DevEncImage *__restrict__ images,
                                                                        const EncWork *__restrict__ work, uint8_t *__restrict__ samples) {
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(1024) void block_offsets_kernel(const DevEncImage *
 // A stretch longer than the LDS buffer falls back to the global atomics.  The buffer is sized per launch (lds_words, dynamic
 // LDS): the host has the images' bit totals by now and asks for twice the batch's largest AVERAGE stretch, between 8 and
 // 32 KB -- with the 32 KB it used to hold always, four workgroups fitted a CU and the kernel ran at 4 waves per SIMD:
-// 2.74 ms per 256 x 4K at Q75, 2.04 ms with the 16 KB that batch needs (the walk alone, block_bits_kernel, takes 1.6).
+// 2.74 ms per 256 x 4K at Q75, 2.04 ms with 16 KB, 1.94 with the 8 KB the rule picks there (the walk alone, block_bits_kernel: 1.6).
 __global__ __launch_bounds__(256) void emit_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
                                                    const EncHuffTable *__restrict__ tables, const int16_t *__restrict__ coefs,
                                                    const uint32_t *__restrict__ bits, const uint64_t *__restrict__ wg_base,
