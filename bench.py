@@ -34,7 +34,12 @@ WORKLOADS = {
     "512_444": (512, 512, "444", 75, 0, 1),
     # BASELINE.json configs[4]: progressive (SOF2) 4K 4:2:0, libjpeg's default 10-scan script, DRI = 0 (made with Pillow)
     "4k_progressive": (3840, 2160, "420p", 75, 0, 256),
+    # the reference's OWN benchmark input (tests/JpegLibrary.Benchmarks/DecoderBenchmark.cs:19-43): an 8192 x 8192 canvas with
+    # HETissueSlide.jpg (2048 x 2048, tests/golden) drawn at (0,0), (0,H), (W,0), (W,H), saved as a baseline 4:2:0 Q75 JPEG
+    # without restart markers (ImageSharp's defaults; made with Pillow here); timed there: Identify + Decode + RGBA conversion
+    "het_8192": (8192, 8192, "420het", 75, 0, 16),
 }
+DEFAULT_FORMAT = {"het_8192": "rgba_u8"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
@@ -57,6 +62,23 @@ def progressive_image(width, height, quality, seed):
     out = io.BytesIO()
     Image.fromarray(np.clip(np.rint(img), 0, 255).astype(np.uint8)).save(out, format="JPEG", quality=quality, progressive=True,
                                                                           subsampling="4:2:0")
+    return out.getvalue()
+
+
+def het_canvas(quality):
+    """DecoderBenchmark.cs:19-43 with Pillow: `new Image<Rgba32>(4 W, 4 H)` is transparent black, the base image is drawn four
+    times into its top-left quarter, SaveAsJpeg drops the alpha: baseline, 4:2:0, quality 75, DRI = 0."""
+    import io
+
+    from PIL import Image
+
+    base = Image.open(os.path.join(ROOT, "tests", "golden", "HETissueSlide.jpg")).convert("RGB")
+    w, h = base.size
+    canvas = Image.new("RGB", (4 * w, 4 * h))
+    for pos in ((0, 0), (0, h), (w, 0), (w, h)):
+        canvas.paste(base, pos)
+    out = io.BytesIO()
+    canvas.save(out, format="JPEG", quality=quality, subsampling="4:2:0")
     return out.getvalue()
 
 
@@ -94,7 +116,7 @@ def host_cpu_budget():
     return info
 
 
-def cpu_baseline(files, width, height, max_threads):
+def cpu_baseline(files, width, height, max_threads, rgba=False, per_thread=8, thread_cap=0):
     """Reference-equivalent CPU path (oracle/jpegref.c, jref_decode_batch_mt): Identify + Decode into a
     JpegBufferOutputWriter8Bit-style YCbCr8 buffer, mirroring tests/JpegLibrary.Benchmarks/DecoderBenchmark.cs:51-73, one
     independent decoder per native host thread (pthreads; per-thread output buffer allocated and touched before the clock
@@ -105,18 +127,19 @@ def cpu_baseline(files, width, height, max_threads):
 
     budget = host_cpu_budget()
     hw = max(1, min(max_threads, budget["cpu_count"]))
+    if thread_cap:
+        hw = min(hw, thread_cap)
     n = len(files)
     # single thread: ~3-6 s of work
     n1 = max(1, min(n, int(4.0 * 100e6 / (width * height)) or 1))
-    s1, px1 = po.decode_batch_mt(files[:n1], 3, 1, warm=True)
+    s1, px1 = po.decode_batch_mt(files[:n1], 3, 1, warm=True, rgba=rgba)
     single = px1 / 1e6 / s1
     counts = sorted({min(hw, c) for c in (8, 16, 32, 64, 128, 256, hw)})
     sweep, spent = [], 0.0
     best = None
     for threads in counts:
-        per_thread = 8
         sample = [files[i % n] for i in range(threads * per_thread)]
-        sec, px = po.decode_batch_mt(sample, 3, threads, warm=True)
+        sec, px = po.decode_batch_mt(sample, 3, threads, warm=True, rgba=rgba)
         rate = px / 1e6 / sec
         sweep.append({"threads": threads, "Mpixels/s": round(rate, 1), "wall_s": round(sec, 2), "decodes": len(sample)})
         spent += sec
@@ -135,7 +158,8 @@ def cpu_baseline(files, width, height, max_threads):
         "cores": cores,
         "threads": threads_best,
         "kind": "port",
-        "sample": f"{decodes} decodes (8 per thread) of the benchmark's images, Identify+Decode into an interleaved YCbCr8 buffer, one "
+        "sample": f"{decodes} decodes ({per_thread} per thread) of the benchmark's images, Identify+Decode into an interleaved YCbCr8 buffer"
+                  f"{' + ConvertYCbCr8ToRgba32' if rgba else ''}, one "
                   f"decoder per native thread, buffers pre-touched, one warm decode per thread ({sall:.2f} s wall); best of the thread "
                   f"sweep; single thread: {single:.1f} Mpixels/s over {n1} images",
         "single_core_value": round(single, 2),
@@ -197,16 +221,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--images", type=int, default=0, help="images per GPU (default: the workload's batch size)")
     ap.add_argument("--workload", default="4k_dri4", choices=sorted(WORKLOADS))
-    ap.add_argument("--format", default="interleaved_u8", choices=["interleaved_u8", "planar_u8", "rgb_u8", "rgba_u8"])
+    ap.add_argument("--format", default=None, choices=["interleaved_u8", "planar_u8", "rgb_u8", "rgba_u8"],
+                    help="output layout (default: interleaved_u8; het_8192: rgba_u8, the reference benchmark's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ingest", action="store_true", help="skip the ingest-inclusive (upload beside decode) measurement")
     ap.add_argument("--no-planar-pass", action="store_true", help="skip the short PLANAR_U8 pass behind roofline.read_frac_planar")
+    ap.add_argument("--latency", action="store_true", help="also time one image per call (always on for het_8192)")
     ap.add_argument("--gen-threads", type=int, default=0)
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (RCCL) even for a single rank: runs the barrier / "
                                                          "MAX-reduce path of the multi-GPU launch on a one-GPU box")
     ap.add_argument("--distinct", type=int, default=0, help="experiments only: synthesise this many distinct images and repeat them "
                                                             "to fill the batch (default: every image of the batch is distinct)")
     args = ap.parse_args()
+    if args.format is None:
+        args.format = DEFAULT_FORMAT.get(args.workload, "interleaved_u8")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -240,7 +268,7 @@ def main():
     from tools import jpegsynth
 
     width, height, ss, quality, dri, default_images = WORKLOADS[args.workload]
-    kind = "progressive (SOF2, 10 scans)" if ss == "420p" else "baseline"
+    kind = "progressive (SOF2, 10 scans)" if ss == "420p" else ("baseline (HETissueSlide canvas, DecoderBenchmark.cs)" if ss == "420het" else "baseline")
     n_images = args.images or default_images
     fmt = {"interleaved_u8": jl.FMT_INTERLEAVED_U8, "planar_u8": jl.FMT_PLANAR_U8, "rgb_u8": jl.FMT_RGB_U8, "rgba_u8": jl.FMT_RGBA_U8}[args.format]
 
@@ -251,9 +279,13 @@ def main():
     granted = granted_cpus(budget)
     gen_threads = args.gen_threads or max(1, granted // max(1, world))
     t0 = time.perf_counter()
-    if ss == "420p":
+    if ss in ("420p", "420het"):
+        if ss == "420het":
+            files_b = [het_canvas(quality)]  # the reference benchmark decodes ONE input over and over: so does every slot of the batch
+            args.distinct = 1
+        else:
+            files_b = progressive_batch(min(n_images, args.distinct or n_images), width, height, quality, sharding.rank_seed_base(rank), gen_threads)
         ss = "420"
-        files_b = progressive_batch(min(n_images, args.distinct or n_images), width, height, quality, sharding.rank_seed_base(rank), gen_threads)
         files_b = [files_b[i % len(files_b)] for i in range(n_images)]
         sizes = np.array([len(f) for f in files_b], dtype=np.int64)
         stride = int(sizes.max())
@@ -311,6 +343,41 @@ def main():
     if dist is not None:
         elapsed = sharding.max_over_ranks(dist, elapsed, device="cuda")
     value = sharding.aggregate_throughput(n_images * width * height, n_gpus, args.steps, elapsed)
+
+    # ---- single-image latency (the reference benchmark decodes ONE image per call): decode alone with the file resident in
+    # HBM; SetInput + Identify + Decode from host memory; and the same with the pixels copied back to the host
+    latency = None
+    if rank == 0 and (args.workload == "het_8192" or args.latency):
+        one = jl.Batch(ctx)
+        one.upload(files[:1], fmt)
+        one.decode().sync()
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one.decode().sync()
+        t_dec = (time.perf_counter() - t0) / reps
+        one.stage_ms()
+        for _ in range(reps):
+            one.decode()
+        one.sync()
+        st1 = one.stage_ms()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one.upload(files[:1], fmt)
+            one.decode().sync()
+        t_up = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(3):
+            one.upload(files[:1], fmt)
+            one.decode().sync()
+            one.output(0)
+        t_all = (time.perf_counter() - t0) / 3
+        latency = {"decode_ms": round(t_dec * 1e3, 3), "upload_decode_ms": round(t_up * 1e3, 3), "upload_decode_download_ms": round(t_all * 1e3, 3),
+                   "single_image_Mpixels/s": round(width * height / 1e6 / t_dec, 1), "stage_ms": {k: round(v, 4) for k, v in st1.items()},
+                   "subseq_rounds": one.subseq_rounds(),
+                   "note": "one image per call, 10 calls each: decode with the file resident in HBM; jpgpu_batch_upload (SetInput + Identify + "
+                           "header parse + H2D, pageable memory) + decode; the same + D2H of the pixels into pageable memory"}
+        one.close()
 
     # ---- the same workload with the host in the loop (never `value`): upload of batch k+1 beside the decode of batch k, on
     # every rank at once (the ranks' crews share the host), the slowest rank's time per batch; from pageable memory through
@@ -399,6 +466,7 @@ def main():
                 "sharding": "image-per-GPU, no collective",
             },
             "stage_ms": {k: round(v, 4) for k, v in stage.items()},
+            **({"subseq_rounds": batch.subseq_rounds()} if dri == 0 and "prog" not in args.workload else {}),
             "roofline": {
                 "kernel": f"idct_output_kernel<{kfmt},{klay}>",
                 "bound": "hbm",
@@ -415,6 +483,8 @@ def main():
                      "cpu_count": cpu, "granted_cpus": granted,
                      "ingest": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in ingest.items()}},
         }
+        if latency is not None:
+            out["latency"] = latency
         for key, name in (("pageable", "value_ingest_inclusive"), ("pinned", "value_ingest_inclusive_pinned")):
             if key not in ingest_res:
                 continue
@@ -484,7 +554,9 @@ def main():
             out["parity_spot_check"] = "oracle unavailable"
         # rank 0 alone, the other ranks parked in the host-side barrier below (blocked in a socket read, not spinning)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(files, width, height, cpu)
+            big = width * height > 32e6  # 67-Mpixel frames: two decodes per thread, no more threads than CPUs granted (0.5 GB of buffers each)
+            out["cpu_baseline"] = cpu_baseline(files, width, height, cpu, rgba=(args.format == "rgba_u8"), per_thread=2 if big else 8,
+                                               thread_cap=granted if big else 0)
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
 

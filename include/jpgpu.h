@@ -307,7 +307,9 @@ int jpgpu_multi_decode(jpgpu_multi *m, const uint8_t *const *jpeg, const size_t 
  * host parse + H2D beside call k's decode (upload stream / decode stream of each context); at most two calls may be in
  * flight, and a ticket's outputs stay valid until the second submit after it.  flags: JPGPU_UPLOAD_PINNED as in
  * jpgpu_batch_upload_segments (every file one page-locked segment).  The host crew of slot s is (CPUs granted to the
- * process) / G threads -- G slots share the machine -- unless jpgpu_set_host_threads / JPGPU_HOST_THREADS says otherwise. */
+ * process) / G threads -- G slots share the machine -- unless jpgpu_set_host_threads / JPGPU_HOST_THREADS says otherwise.
+ * A submit that fails (any slot's upload or launch) takes no ticket (*ticket = -1): the slots that did launch are waited
+ * for before it returns, nothing stays in flight and the next submit may use the same batches. */
 int jpgpu_multi_submit(jpgpu_multi *m, const uint8_t *const *jpeg, const size_t *len, int n, int format, unsigned flags, int *ticket);
 int jpgpu_multi_wait(jpgpu_multi *m, int ticket, double *upload_ms, double *decode_ms);
 jpgpu_batch *jpgpu_multi_batch_of(jpgpu_multi *m, int ticket, int slot);

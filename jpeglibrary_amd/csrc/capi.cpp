@@ -250,19 +250,27 @@ int jpgpu_multi_submit(jpgpu_multi *m, const uint8_t *const *jpeg, const size_t 
         run(&m->slots[0]);
         for (int s = started; s < world; s++) run(&m->slots[(size_t)s]);
     }
-    m->n_items[k] = n;
-    m->pending[k] = true;
-    m->ticket_in[k] = t;
-    m->last_ticket = t;
-    m->next_ticket++;
-    if (ticket) *ticket = t;
     int rc = JPGPU_OK;
     for (int s = 0; s < world && rc == JPGPU_OK; s++)
         if (m->slots[(size_t)s].status[k] != JPGPU_OK) {
             rc = m->slots[(size_t)s].status[k];
             m->last_error = std::string("device slot ") + std::to_string(s) + ": " + jpgpu_last_error(m->slots[(size_t)s].ctx);
         }
-    return rc;
+    if (rc != JPGPU_OK) {
+        // a failed call takes no ticket: the slots that did launch are waited for here, so that nothing the caller cannot
+        // address stays in flight and batch k is free for the next submit
+        for (int s = 0; s < world; s++)
+            if (m->slots[(size_t)s].status[k] == JPGPU_OK) (void)jpgpu_batch_sync(m->slots[(size_t)s].batch[k]);
+        if (ticket) *ticket = -1;
+        return rc;
+    }
+    m->n_items[k] = n;
+    m->pending[k] = true;
+    m->ticket_in[k] = t;
+    m->last_ticket = t;
+    m->next_ticket++;
+    if (ticket) *ticket = t;
+    return JPGPU_OK;
 }
 
 int jpgpu_multi_wait(jpgpu_multi *m, int ticket, double *upload_ms, double *decode_ms) {

@@ -1126,6 +1126,12 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     }
     hipStream_t up = ctx_->upload_stream;  // everything an upload does stays off the decode stream
 
+    // debugging switches, read once per upload (not per scan job; not once per process: tests set them between calls)
+    int dbg_delay_scan = -1, dbg_delay_ms = 0;
+    if (const char *dd = getenv("JPGPU_DEBUG_DELAY_SCAN")) {
+        if (sscanf(dd, "%d:%d", &dbg_delay_scan, &dbg_delay_ms) != 2) dbg_delay_scan = -1;
+    }
+    const bool dbg_status = getenv("JPGPU_DEBUG_STATUS") != nullptr;
     // ---- per-image output / coefficient layout, scan descriptors, pools, work lists
     huff_pool_.clear();
     quant_pool_.clear();
@@ -1304,10 +1310,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 s.publishes = job.has_consumers ? 1 : 0;
                 // test hook: "k:ms" makes scan k (0-based, in file order) of every progressive frame slow: it idles ms at its start and
                 // after every progress word -- a producer its followers catch up with, which the launches only produce by chance
-                if (const char *dd = getenv("JPGPU_DEBUG_DELAY_SCAN")) {
-                    int k = -1, ms = 0;
-                    if (sscanf(dd, "%d:%d", &k, &ms) == 2 && k == j - img.jobs[0] - 1) s.debug_delay_ms = (uint8_t)std::min(255, std::max(0, ms));
-                }
+                if (dbg_delay_scan >= 0 && dbg_delay_scan == j - img.jobs[0] - 1) s.debug_delay_ms = (uint8_t)std::min(255, std::max(0, dbg_delay_ms));
                 if (job.n_deps > 3 || s.n_intervals != 1 || s.n_intervals > stream_max_intervals) prog_pipelined_ = false;
                 if (s.n_intervals <= stream_max_intervals) {
                     for (uint32_t i = 0; i < s.n_intervals; i++) prog_streams_by_ordinal[ordinal].push_back({(uint32_t)j, i});
@@ -1437,7 +1440,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 if (jobs_[(size_t)(j0 + a)].kind != kScanProgressive || has_next[(size_t)a] || k - a > 255) continue;
                 const uint64_t together = wave_bytes[(size_t)a] + own;
                 if (together > largest / 2 || together > (1u << 20)) continue;
-                if (getenv("JPGPU_DEBUG_STATUS") && &img == &images_[0])
+                if (dbg_status && &img == &images_[0])
                     fprintf(stderr, "jpgpu: wave chain: scan %d behind scan %d (%llu + %llu bytes, largest scan %llu)\n", k, a,
                             (unsigned long long)wave_bytes[(size_t)a], (unsigned long long)own, (unsigned long long)largest);
                 h_scans_[(size_t)(j0 + a)].wave_next = (uint8_t)(k - a);
@@ -1678,7 +1681,18 @@ int DeviceBatch::run_progressive() {
     const int n_waves = prog_pipe_count_;  // of the pipelined launch (<= n_streams)
     const size_t lds_per_wg = (progressive_stream_lds_bytes(n_huff_slots_) + 1023) / 1024 * 1024;
     const int cus = ctx_->num_cus > 0 ? ctx_->num_cus : 256;
-    const int per_cu = (int)std::min<size_t>(32, (160u << 10) / lds_per_wg);
+    int per_cu = (int)std::min<size_t>(32, (160u << 10) / lds_per_wg);
+    {
+        // what the runtime says a CU holds of this kernel (registers as well as LDS), asked once per table-slot count
+        static std::atomic<int> cached[kMaxHuffSlots + 1];
+        const int slot_key = std::min(std::max(n_huff_slots_, 0), kMaxHuffSlots);
+        int occ = cached[slot_key].load(std::memory_order_relaxed);
+        if (occ == 0) {
+            occ = progressive_stream_blocks_per_cu(n_huff_slots_);
+            cached[slot_key].store(occ > 0 ? occ : -1, std::memory_order_relaxed);
+        }
+        if (occ > 0) per_cu = std::min(per_cu, occ);
+    }
     const bool force = getenv("JPGPU_PROG_FORCE_PIPELINE") != nullptr;  // experiments: pipelined without the gate, any size
     const bool resident = n_waves <= per_cu * 3 / 4 * cus;
     // (round 3, ADVICE r2: the ungated pipelined launch of grids up to 1.5 x what the CUs hold relied on workgroups starting in

@@ -57,6 +57,7 @@ hipError_t launch_progressive_streams(hipStream_t stream, const uint8_t *udata, 
                                       const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
                                       int n_slots, int pipelined, uint32_t spin_budget, uint32_t *started);
 size_t progressive_stream_lds_bytes(int n_slots);  // LDS of one stream workgroup (residency estimate of the pipelined launch)
+int progressive_stream_blocks_per_cu(int n_slots);  // stream workgroups a CU holds at once by the runtime's occupancy query (0 = unknown)
 
 // "O3": PLANAR_I16 planes -> the test writer's uint16 x 4 form (extend_u16_kernel)
 hipError_t launch_extend_u16(hipStream_t stream, const uint8_t *planes, uint8_t *out_base, const ExtendPlanes *images, int n_images,

@@ -565,72 +565,6 @@ __device__ __forceinline__ void ub_init(UBits &r, const uint8_t *ubase, uint32_t
     r.rem = (int32_t)((uend - ustart) * 8u);
 }
 
-// The round kernel's reader: UBits with the refill load issued BY HAND.  hipcc copies a loaded chunk into the queue right
-// behind the load -- s_waitcnt vmcnt(0) inside the refill branch, which some lane of a wave takes in nine steps of ten
-// (64 lanes, a chunk every ~24 symbols each): every step of the rounds paid a memory round trip.  Here the load writes
-// the queue's own registers and nothing waits for it until the next refill (of any lane: a step later at the earliest).
-// The compiler does not know a load is in flight, so the waits are spelled out: in front of the next read of nx, and
-// behind the loop (ub_async_drain) before the registers can be given to something else.  K2S 18.6 -> 17.6 ms per 1024 x 4K.
-typedef uint32_t jpgpu_u32x4 __attribute__((ext_vector_type(4)));
-struct UBitsA {
-    const uint8_t *p;
-    jpgpu_u32x4 qw;
-    uint32_t nx0, nx1, nx2, nx3;
-    uint32_t qn;
-    uint32_t hi, lo;
-    int32_t lcnt;
-    int32_t rem;
-};
-__device__ __forceinline__ uint32_t uba_next_word(UBitsA &r) {
-    const uint32_t w = r.qw.x;
-    r.qw.x = r.qw.y;
-    r.qw.y = r.qw.z;
-    r.qw.z = r.qw.w;
-    r.qn--;
-    if (r.qn == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loads of earlier steps (this lane's: a whole chunk ago)
-        r.qw = jpgpu_u32x4{r.nx0, r.nx1, r.nx2, r.nx3};
-        // (four dword loads: a four-register tuple makes hipcc gather nx into consecutive registers and copy it back -- out of
-        // registers the load has not reached yet)
-        asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %4, off offset:4\n\tglobal_load_dword %2, %4, off offset:8\n\t"
-                     "global_load_dword %3, %4, off offset:12"
-                     : "+v"(r.nx0), "+v"(r.nx1), "+v"(r.nx2), "+v"(r.nx3)
-                     : "v"(r.p)
-                     : "memory");
-        r.p += 16;
-        r.qn = 4;
-    }
-    return __builtin_bswap32(w);
-}
-__device__ __forceinline__ void uba_drain(UBitsA &r) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.nx0), "+v"(r.nx1), "+v"(r.nx2), "+v"(r.nx3) : : "memory");
-}
-__device__ __forceinline__ void uba_consume(UBitsA &r, uint32_t n) {
-    r.hi = __builtin_amdgcn_alignbit(r.hi, r.lo, (32u - n) & 31u);
-    r.lo = n >= 32u ? 0u : (r.lo << n);
-    r.lcnt -= (int32_t)n;
-    if (r.lcnt < 0) {
-        const uint32_t d = (uint32_t)(-r.lcnt);
-        const uint32_t w = uba_next_word(r);
-        r.hi |= w >> ((32u - d) & 31u);
-        r.lo = d >= 32u ? 0u : (w << d);
-        r.lcnt = 32 - (int32_t)d;
-    }
-}
-__device__ __forceinline__ void uba_from(UBitsA &a, const UBits &r) {
-    a.p = r.p;
-    a.qw = jpgpu_u32x4{r.qw.x, r.qw.y, r.qw.z, r.qw.w};
-    a.nx0 = r.nx.x;
-    a.nx1 = r.nx.y;
-    a.nx2 = r.nx.z;
-    a.nx3 = r.nx.w;
-    a.qn = r.qn;
-    a.hi = r.hi;
-    a.lo = r.lo;
-    a.lcnt = r.lcnt;
-    a.rem = r.rem;
-}
-
 // LDS image of a staged DevHuffTable
 struct LdsHuff {
     const uint16_t *lut;
@@ -905,7 +839,10 @@ __device__ __forceinline__ uint32_t k2_symbol(uint8_t *ring, K2Feed &f, K2Pos &p
 // kK2Miss / kK2BadCategory) for every table of the pool, both as a DC and as an AC table: the round kernel's workgroups
 // are short-lived, so they copy the lookup instead of deriving it.  Entry (table * 2 + is_dc) * 2048 + prefix.
 constexpr int kLutPoolBits = 11;  // K2 copies the pooled lookup as it is
-constexpr int kSrLutBits = 10;    // the round kernel keeps every other entry (a 10-bit prefix decides codes of up to 10 bits)
+#ifndef JPGPU_SR_LB
+#define JPGPU_SR_LB 10
+#endif
+constexpr int kSrLutBits = JPGPU_SR_LB;  // lookup width of the round kernel (a 10-bit prefix decides codes of up to 10 bits)
 __global__ __launch_bounds__(256) void lut_pool_kernel(const DevHuffTable *__restrict__ pool, uint32_t *__restrict__ lut_pool) {
     const DevHuffTable &h = pool[blockIdx.x >> 1];
     const bool is_dc = (blockIdx.x & 1) != 0;
@@ -3679,12 +3616,202 @@ __device__ __forceinline__ int32_t k2_open_at_bit(const uint8_t *ubase, uint32_t
 // One synchronisation round.  exit_in/exit_out are double-buffered per-subsequence state words (index sub_off + sub).
 // A round only has to follow the symbol structure: code and magnitude LENGTHS, zig-zag advance, block and MCU phase, and
 // the DC differences (their per-component sums feed the predictor prefix); AC magnitudes are skipped, not extracted.
-// The stream comes through the word reader (UBits): staging it in LDS was measured and lost -- the rounds are latency
-// bound and need the occupancy more than the shorter instruction stream (13.1 vs 11.1 ms per 256 x 4K).
+//
+// Round 4 form.  64 lanes stand at 64 different places of their blocks, so whatever a lane does "sometimes" the wave does
+// in every step; the step is therefore ONE straight line for every lane, and what cannot be decided by one lookup is not
+// branched to but PARKED:
+//  * bit source = K2's scheme on a small ring: the lane's position and the three stream words around it in registers, the
+//    word that will be missing after the step read from a private 8-word LDS ring at the start of the step, off the chain;
+//    the ring is topped up (16 bytes, prefetched a burst earlier) between bursts of kSrBurst steps, not inside them;
+//  * one lookup of the next kSrLutBits bits gives `total bits | zig-zag advance << 6 | DC difference << 16`: a DC symbol
+//    whose magnitude lies inside the looked-up prefix carries its EXTENDED value in the entry (an AC entry carries zero), so
+//    the step adds the entry's upper half to the lane's component sum (one ds_add into 16 bytes of LDS per lane) whatever
+//    the symbol is; DC entries advance the zig-zag position by one, EOB by 64: no DC / AC distinction but the table choice;
+//  * a lane whose symbol needs more (a code longer than the lookup, a DC magnitude that does not fit the prefix, a bad
+//    category, bits beyond what the ring holds or beyond the data) commits NOTHING in that step -- its entry is replaced by
+//    zero: no bits, no advance, no difference -- and repeats it until the burst is over; then the stuck lanes take the exact
+//    path (sr_service: the reference's maxcode walk and "bits available" rules) under one branch per burst;
+//  * a lane that has passed the end of its subsequence is parked for good by its limit.
+// Before: ~55 vector + ~25 scalar instructions and five branches per symbol step (the word reader's refill branches and the
+// exact path, taken by some lane in nearly every step); the step below is ~37 vector instructions and no branch.
+constexpr int kSrRingStride = 36;  // bytes per lane: 8 stream words + 1 (lanes reading the same word index hit distinct banks)
+#ifndef JPGPU_SR_BURST
+#define JPGPU_SR_BURST 8
+#endif
+constexpr int kSrBurst = JPGPU_SR_BURST;  // fast steps between two service / top-up points
+constexpr uint32_t kSrFlag = 0x8000u;              // entry: not decidable by the lookup
+constexpr uint32_t kSrMiss = kSrFlag;              //   code longer than the lookup (or a prefix it shares with another code)
+constexpr uint32_t kSrBadCat = kSrFlag | 0x2000u;  //   DC category above 16
+constexpr uint32_t kSrDcWide = kSrFlag | 0x4000u;  //   DC symbol whose magnitude leaves the prefix: code size | category << 6
+constexpr int32_t kSrParked = -0x40000000;         // limit of a lane that is finished: nothing commits any more
 
-// (96 scalar registers: with the 102 hipcc takes by itself seven waves fit a SIMD instead of eight, and the rounds live on
-// occupancy -- 29.83 -> 29.28 ms per 1024 x 4K step; six scalars go to a vector register's lanes)
-__attribute__((amdgpu_num_sgpr(96))) __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+struct SrLane {
+    int32_t pm1;  // bit position - 1, relative to the lane's 4-byte aligned origin
+    uint32_t w0, w1, w2;  // the stream words holding bit pm1 and behind it
+    uint32_t k;           // zig-zag index of the next coefficient; 0 = the block's DC symbol comes next
+    uint32_t b;           // block inside the MCU
+    uint32_t nblk;        // blocks completed
+    uint32_t tabdc, tabac, dcaddr;  // LDS byte offsets: the block's two lookups, its component's DC sum
+    int32_t limm;                   // fast-path limit - 1: a symbol of n bits commits while pm1 + n <= limm
+    uint32_t wrw;                   // stream words written to the ring so far (it holds words wrw-8 .. wrw-1)
+    uint4 nx;                       // the next 16 bytes of the stream, loaded a burst ago
+    const uint8_t *gp;              // address of the 16 bytes behind them
+};
+
+// the block's lookups and DC sum after a block end (branch-free: read in every step, taken when `end`)
+__device__ __forceinline__ void sr_block_info(SrLane &L, const uint8_t *smem, uint32_t info_off, uint32_t dc_lane, uint32_t b, bool end) {
+    const uint4 inf = *reinterpret_cast<const uint4 *>(smem + info_off + b * 16u);
+    L.tabdc = end ? inf.x : L.tabdc;
+    L.tabac = end ? inf.y : L.tabac;
+    L.dcaddr = end ? dc_lane + inf.z : L.dcaddr;
+}
+
+// what a committed symbol does to the lane: position and stream words, zig-zag index, block end, DC sum
+__device__ __forceinline__ void sr_commit(SrLane &L, uint8_t *smem, uint32_t info_off, uint32_t dc_lane, uint32_t bpm, int32_t endsub_m1, int32_t np,
+                                          uint32_t adv, int32_t v, uint32_t nxt) {
+    __hip_atomic_fetch_add(reinterpret_cast<int32_t *>(smem + L.dcaddr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t k = L.k + adv;
+    const bool end = k >= 64u;
+    L.nblk += end ? 1u : 0u;
+    L.k = end ? 0u : k;
+    uint32_t b = L.b + (end ? 1u : 0u);
+    b = b == bpm ? 0u : b;
+    L.b = b;
+    sr_block_info(L, smem, info_off, dc_lane, b, end);
+    const bool step = ((uint32_t)(np ^ L.pm1) >> 5) != 0;
+    L.pm1 = np;
+    L.w0 = step ? L.w1 : L.w0;
+    L.w1 = step ? L.w2 : L.w1;
+    L.w2 = step ? nxt : L.w2;
+    L.limm = np >= endsub_m1 ? kSrParked : L.limm;  // the subsequence's end passed: the lane is finished
+}
+
+// One fast step for every lane.  Returns "this lane could not commit" (it stands where it stood).
+template <int LB>
+__device__ __forceinline__ bool sr_step(SrLane &L, uint8_t *smem, uint32_t ring_off, uint32_t info_off, uint32_t dc_lane, uint32_t bpm,
+                                        int32_t endsub_m1) {
+    const uint32_t nxt = *reinterpret_cast<const uint32_t *>(smem + ring_off + __builtin_amdgcn_ubfe((uint32_t)(L.pm1 + 96), 5, 3) * 4u);
+    const uint32_t hi = __builtin_amdgcn_alignbit(L.w0, L.w1, ~(uint32_t)L.pm1);
+    const uint32_t tab = L.k == 0 ? L.tabdc : L.tabac;
+    const uint32_t e = *reinterpret_cast<const uint32_t *>(smem + tab + (hi >> (32 - LB)) * 4u);
+    int32_t np = L.pm1 + (int32_t)(e & 63u);
+    // flagged entry (bit 15 -> sign) or the symbol's last bit beyond the limit: one signed test
+    const bool slow = (int32_t)((e << 16) | (uint32_t)(L.limm - np)) < 0;
+    const uint32_t ee = slow ? 0u : e;
+    np = slow ? L.pm1 : np;
+    sr_commit(L, smem, info_off, dc_lane, bpm, endsub_m1, np, __builtin_amdgcn_ubfe(ee, 6, 7), (int32_t)ee >> 16, nxt);
+    return slow;
+}
+
+// the prefetched 16 bytes go to the ring (slot wrw & 7: the words it replaces are behind the lane's registers), the next
+// ones are requested; the limit follows
+__device__ __forceinline__ void sr_topup(SrLane &L, uint8_t *smem, uint32_t ring_off, int32_t endpos) {
+    uint32_t *rp = reinterpret_cast<uint32_t *>(smem + ring_off + (L.wrw & 4u) * 4u);
+    rp[0] = __builtin_bswap32(L.nx.x);
+    rp[1] = __builtin_bswap32(L.nx.y);
+    rp[2] = __builtin_bswap32(L.nx.z);
+    rp[3] = __builtin_bswap32(L.nx.w);
+    L.wrw += 4;
+    __builtin_memcpy(&L.nx, L.gp, 16);
+    L.gp += 16;
+    const int32_t loaded = (int32_t)(L.wrw * 32u) - 96;  // a position up to here leaves the next step's ring read inside the ring
+    L.limm = (endpos < loaded ? endpos : loaded) - 1;
+}
+
+// Exact path for a lane the fast step could not serve: DecodeHuffmanCode + ReceiveAndExtend lengths with the reference's
+// "bits available" rules, the same decisions as ub_symbol (ref: JpegHuffmanDecodingTable.cs:73-113,
+// ScanDecoder/JpegHuffmanScanDecoder.cs:81-115).  Commits the symbol, or finishes the lane (bad = 1: invalid code / the data
+// ends inside the symbol).
+template <int LB>
+__device__ __forceinline__ void sr_service(SrLane &L, uint8_t *smem, uint32_t ring_off, uint32_t info_off, uint32_t dc_lane, uint32_t small_off,
+                                           uint32_t bpm, int32_t endsub_m1, int32_t endpos, uint32_t &bad) {
+    const int32_t pos = L.pm1 + 1;
+    if (pos >= endpos) {  // no data bit left: the loop's other exit (not a failure)
+        L.limm = kSrParked;
+        return;
+    }
+    const int32_t q = L.pm1 >> 5;
+    while ((int32_t)L.wrw <= q + 7) {  // the ring as full as it gets (at most three chunks behind)
+        sr_topup(L, smem, ring_off, endpos);
+    }
+    const uint32_t nxt = *reinterpret_cast<const uint32_t *>(smem + ring_off + __builtin_amdgcn_ubfe((uint32_t)(L.pm1 + 96), 5, 3) * 4u);
+    const uint32_t hi = __builtin_amdgcn_alignbit(L.w0, L.w1, ~(uint32_t)L.pm1);
+    const int32_t rem = endpos - pos;
+    const bool is_dc = L.k == 0;
+    const uint32_t tab = is_dc ? L.tabdc : L.tabac;
+    const uint32_t e = *reinterpret_cast<const uint32_t *>(smem + tab + (hi >> (32 - LB)) * 4u);
+    uint32_t n, adv;
+    int32_t v = 0;
+    if (e & kSrFlag) {
+        uint32_t size = 0, cat = 0;
+        adv = 0;
+        if ((e & 0x6000u) == (kSrBadCat & 0x6000u)) {
+            bad = 1;
+        } else if ((e & 0x6000u) == (kSrDcWide & 0x6000u)) {
+            size = e & 63u;
+            cat = __builtin_amdgcn_ubfe(e, 6, 7);
+        } else {
+            const uint8_t *sm = smem + small_off + (tab >> (LB + 2)) * kK2SmallBytes;
+            const uint16_t *maxcode = reinterpret_cast<const uint16_t *>(sm);
+            const uint32_t code16 = hi >> 16;
+            size = LB + 1;
+            while (code16 > maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
+            if (size > 16) {
+                bad = 1;
+            } else {
+                const uint32_t sym = sm[56 + ((sm[36 + size] + (code16 >> (16 - size))) & 0xFF)];
+                cat = is_dc ? sym : (sym & 15u);
+                adv = (sym & 15u) ? (sym >> 4) + 1u : ((sym >> 4) ? 16u : 64u);
+                if (cat > 16u) bad = 1;
+            }
+        }
+        if (bad) {
+            L.limm = kSrParked;
+            return;
+        }
+        n = size + cat;
+        if (is_dc) {
+            adv = 1;
+            if ((int32_t)n <= rem) {
+                const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - n, cat);
+                v = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));  // Extend(v, nbits)
+            }
+        }
+    } else {  // decided by the lookup; it was the limit that held it back
+        n = e & 63u;
+        adv = __builtin_amdgcn_ubfe(e, 6, 7);
+        v = (int32_t)e >> 16;
+    }
+    if ((int32_t)n > rem) {  // the data ends inside the symbol: nothing after it can be right
+        bad = 1;
+        L.limm = kSrParked;
+        return;
+    }
+    sr_commit(L, smem, info_off, dc_lane, bpm, endsub_m1, L.pm1 + (int32_t)n, adv, v, nxt);
+}
+
+// lookups of the round kernel out of the pooled 11-bit ones (lut_pool_kernel): entry i of an LB-bit lookup covers pooled
+// prefixes i << (11 - LB) ..; it is decided when the code has at most LB bits
+template <int LB>
+__device__ __forceinline__ uint32_t sr_entry(const uint32_t *src, uint32_t i, bool is_dc) {
+    const uint32_t e = src[i << (kLutPoolBits - LB)];
+    if (e == kK2BadCategory) {  // (the pooled entry does not say how long the code is: every pooled prefix under i must agree)
+        for (uint32_t j = 1; j < (1u << (kLutPoolBits - LB)); j++)
+            if (src[(i << (kLutPoolBits - LB)) + j] != kK2BadCategory) return kSrMiss;
+        return kSrBadCat;
+    }
+    const uint32_t n = e & 0xFFu, size = (e >> 8) & 0xFFu, cat = (e >> 16) & 0xFFu, adv2 = e >> 24;
+    if ((e & 0x80000000u) || size > (uint32_t)LB) return kSrMiss;
+    if (is_dc) {
+        if (n > (uint32_t)LB) return kSrDcWide | size | (cat << 6);
+        const int32_t raw = (int32_t)((i >> (LB - n)) & ((1u << cat) - 1u));
+        const int32_t v = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));
+        return n | (1u << 6) | ((uint32_t)v << 16);
+    }
+    return n | ((adv2 == 127u ? 64u : adv2 >> 1) << 6);
+}
+
+__global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
                                                             const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
                                                             const DevScanStatus *__restrict__ status, const DevHuffTable *__restrict__ huff_pool,
                                                             const uint32_t *__restrict__ lut_pool,
@@ -3692,10 +3819,13 @@ __attribute__((amdgpu_num_sgpr(96))) __global__ __launch_bounds__(256) void subs
                                                             uint32_t *__restrict__ nblk_out, uint32_t *__restrict__ entry_used,
                                                             int4 *__restrict__ dcsum_out, uint32_t *__restrict__ changed, int round,
                                                             int n_slots, uint32_t warm_bits) {
+    constexpr int LB = kSrLutBits;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t *luts = reinterpret_cast<uint32_t *>(smem);                                     // n_slots << kSrLutBits
-    uint8_t *small = smem + ((size_t)n_slots << (kSrLutBits + 2));                           // n_slots * kK2SmallBytes
-    uint32_t *blk_info = reinterpret_cast<uint32_t *>(small + (size_t)n_slots * kK2SmallBytes);  // [kMaxBlocksPerMcu]
+    // LDS: lookups (n_slots << (LB + 2), at offset 0) | small arrays | block info [kMaxBlocksPerMcu] x 16 | rings | DC sums
+    const uint32_t small_off = (uint32_t)n_slots << (LB + 2);
+    const uint32_t info_off = small_off + (uint32_t)n_slots * kK2SmallBytes;
+    const uint32_t rings_off = info_off + kMaxBlocksPerMcu * 16u;
+    const uint32_t dcs_off = rings_off + 256u * kSrRingStride;
     const HuffWork wk = work[blockIdx.x];  // first_interval holds the first subsequence of this workgroup
     const DevScan &s = scans[wk.scan];
     const DevScanStatus st = status[wk.scan];
@@ -3724,19 +3854,19 @@ __attribute__((amdgpu_num_sgpr(96))) __global__ __launch_bounds__(256) void subs
         bool is_dc = false;
         for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
         const uint32_t *src = lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * (1u << kLutPoolBits);
-        uint32_t *dst = luts + ((size_t)sl << kSrLutBits);
-        for (uint32_t i = tid; i < (1u << kSrLutBits); i += 256) {
-            const uint32_t e = src[2 * i];  // prefixes 2i and 2i+1 agree whenever the code has at most 10 bits
-            dst[i] = (e != kK2BadCategory && ((e & 0x80000000u) || ((e >> 8) & 0xFFu) > (uint32_t)kSrLutBits)) ? kK2Miss : e;
-        }
+        uint32_t *dst = reinterpret_cast<uint32_t *>(smem) + ((size_t)sl << LB);
+        for (uint32_t i = tid; i < (1u << LB); i += 256) dst[i] = sr_entry<LB>(src, i, is_dc);
         const uint4 *ssrc = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&huff_pool[pi]) + offsetof(DevHuffTable, maxcode));
-        uint4 *sdst = reinterpret_cast<uint4 *>(small + sl * kK2SmallBytes);
+        uint4 *sdst = reinterpret_cast<uint4 *>(smem + small_off + sl * kK2SmallBytes);
         if (tid < kK2SmallBytes / 16) sdst[tid] = ssrc[tid];
     }
     if (tid < kMaxBlocksPerMcu) {
         const uint32_t ci = s.blk_comp[tid];
-        blk_info[tid] = ci | ((uint32_t)s.comp[ci].dc_slot << 8) | ((uint32_t)s.comp[ci].ac_slot << 16);
+        *reinterpret_cast<uint4 *>(smem + info_off + tid * 16u) =
+            make_uint4((uint32_t)s.comp[ci].dc_slot << (LB + 2), (uint32_t)s.comp[ci].ac_slot << (LB + 2), (ci & 3u) * 4u, 0u);
     }
+    const uint32_t dc_lane = dcs_off + tid * 16u;
+    *reinterpret_cast<uint4 *>(smem + dc_lane) = make_uint4(0, 0, 0, 0);
     __syncthreads();
     if (!need) return;
     // ROUND 0 IS A WARM-UP.  Its entry state is a guess for every lane but the first, so all it can deliver is a plausible
@@ -3751,96 +3881,79 @@ __attribute__((amdgpu_num_sgpr(96))) __global__ __launch_bounds__(256) void subs
     const uint32_t bpm = s.blocks_per_mcu;
     const uint32_t end_bit = (sub + 1) << s.sub_shift;
     const uint32_t start_bit = warm ? end_bit - warm_bits : (sub << s.sub_shift) + (entry & 63u);
-    uint32_t b_in_mcu = (entry >> 6) & 31u, i2 = ((entry >> 11) & 127u) * 2u;
-    uint32_t nblk = 0, bad = 0;
-    int32_t dc0 = 0, dc1 = 0, dc2 = 0, dc3 = 0;
     uint32_t ex;
+    int4 dcs = make_int4(0, 0, 0, 0);
+    uint32_t nblk = 0;
     if (start_bit >= total_bits) {
-        ex = sub_pack(0, b_in_mcu, i2 >> 1) | kSubBad;
+        ex = sub_pack(0, (entry >> 6) & 31u, (entry >> 11) & 127u) | kSubBad;
     } else {
-        UBits r0;
-        ub_init(r0, udata + s.data_off, start_bit >> 3, (total_bits + 7) >> 3);
-        if (start_bit & 7u) ub_consume(r0, start_bit & 7u);
-        r0.rem = (int32_t)total_bits - (int32_t)start_bit;
-        UBitsA r;  // (from here on the refill loads are not the compiler's: uba_next_word)
-        uba_from(r, r0);
-        uint32_t pos = start_bit;
-        uint32_t info = blk_info[b_in_mcu];
-        while (pos < end_bit && r.rem > 0) {
-            const bool is_dc = i2 == 0;
-            const uint32_t sl = is_dc ? ((info >> 8) & 0xFFu) : (info >> 16);
-            const uint32_t hi = r.hi;
-            uint32_t e = luts[(sl << kSrLutBits) + (hi >> (32 - kSrLutBits))];
-            uint32_t n = e & 0xFFu, cat = (e >> 16) & 0xFFu, adv = e >> 24;
-            if ((int32_t)(e | (uint32_t)(r.rem - (int32_t)n)) < 0) {
-                // exact path: long code, bad category, or the last bits of the stream (same decisions as ub_symbol)
-                const uint16_t *maxcode = reinterpret_cast<const uint16_t *>(small + sl * kK2SmallBytes);
-                const uint8_t *valoffset = small + sl * kK2SmallBytes + 36, *values = small + sl * kK2SmallBytes + 56;
-                uint32_t size;
-                if (e == kK2BadCategory) {
-                    bad = 1;
-                    break;
-                }
-                const uint32_t code16 = hi >> 16;
-                if (e & 0x80000000u) {
-                    size = kSrLutBits + 1;
-                    while (code16 > maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
-                    if (size > 16) {
-                        bad = 1;
-                        break;
-                    }
-                    const uint32_t sym = values[(valoffset[size] + (code16 >> (16 - size))) & 0xFF];
-                    cat = is_dc ? sym : (sym & 15u);
-                    adv = k2_ac_advance(sym);
-                    if (cat > 16u) {
-                        bad = 1;
-                        break;
-                    }
-                } else {
-                    size = (e >> 8) & 0xFFu;
-                }
-                // the stream ends inside the symbol: nothing after it can be right
-                if ((int32_t)(size + cat) > r.rem) {
-                    bad = 1;
-                    break;
-                }
-                n = size + cat;
-            }
-            if (is_dc) {
-                const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - n, cat);
-                const int32_t v = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));  // Extend(v, nbits)
-                const uint32_t ci = info & 0xFFu;
-                if (ci == 0) dc0 += v;
-                else if (ci == 1) dc1 += v;
-                else if (ci == 2) dc2 += v;
-                else dc3 += v;
-                i2 = 2;
-            } else {
-                i2 += adv;
-            }
-            if (i2 >= 128u) {
-                nblk++;
-                b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
-                i2 = 0;
-                info = blk_info[b_in_mcu];
-            }
-            r.rem -= (int32_t)n;
-            uba_consume(r, n);
-            pos += n;
+        SrLane L;
+        const uint32_t ring_off = rings_off + tid * kSrRingStride;
+        const uint32_t u0 = start_bit >> 3;
+        const int32_t pm1_0 = (int32_t)((u0 & 3u) * 8u + (start_bit & 7u)) - 1;
+        // (positions are relative to the lane's own start: the distance to the end of the data is only ever compared, so a
+        // stream longer than 2^30 bits behind the lane may as well end there)
+        const uint32_t left = total_bits - start_bit;
+        const int32_t endpos = pm1_0 + 1 + (int32_t)(left < 0x3FFFFFFFu ? left : 0x3FFFFFFFu);
+        const int32_t endsub_m1 = pm1_0 + (int32_t)(end_bit - start_bit);
+        {
+            const uint8_t *g = udata + s.data_off + (u0 & ~3u);  // 4-byte aligned 16-byte loads; buffers are padded
+            uint4 c0, c1;
+            __builtin_memcpy(&c0, g, 16);
+            __builtin_memcpy(&c1, g + 16, 16);
+            __builtin_memcpy(&L.nx, g + 32, 16);
+            L.gp = g + 48;
+            uint32_t *rp = reinterpret_cast<uint32_t *>(smem + ring_off);
+            rp[0] = __builtin_bswap32(c0.x);
+            rp[1] = __builtin_bswap32(c0.y);
+            rp[2] = __builtin_bswap32(c0.z);
+            rp[3] = __builtin_bswap32(c0.w);
+            rp[4] = __builtin_bswap32(c1.x);
+            rp[5] = __builtin_bswap32(c1.y);
+            rp[6] = __builtin_bswap32(c1.z);
+            rp[7] = __builtin_bswap32(c1.w);
+            L.wrw = 8;
+            const int32_t q = pm1_0 >> 5;  // -1 or 0 (w0 of q = -1 is never looked at: the shift is 0 then)
+            L.w0 = rp[q & 7];
+            L.w1 = rp[(q + 1) & 7];
+            L.w2 = rp[(q + 2) & 7];
         }
-        uba_drain(r);  // nothing in flight into registers the compiler will reuse
-        const uint32_t over = pos > end_bit ? pos - end_bit : 0u;
-        ex = sub_pack(over < 63u ? over : 63u, b_in_mcu, i2 >> 1);
-        if (bad) ex = sub_pack(0, b_in_mcu, i2 >> 1) | kSubBad;
+        L.pm1 = pm1_0;
+        L.k = (entry >> 11) & 127u;
+        L.b = (entry >> 6) & 31u;
+        L.nblk = 0;
+        {
+            const int32_t loaded = (int32_t)(L.wrw * 32u) - 96;
+            L.limm = (endpos < loaded ? endpos : loaded) - 1;
+        }
+        L.tabdc = L.tabac = 0;
+        L.dcaddr = dc_lane;
+        sr_block_info(L, smem, info_off, dc_lane, L.b, true);
+        uint32_t bad = 0;
+        for (;;) {
+            bool stuck = false;
+#pragma unroll
+            for (int t = 0; t < kSrBurst; t++) stuck = sr_step<LB>(L, smem, ring_off, info_off, dc_lane, bpm, endsub_m1);
+            // a stuck lane repeats its step, so the last step of the burst says who is stuck; finished lanes are not served
+            stuck = stuck && L.limm != kSrParked;
+            if (stuck) sr_service<LB>(L, smem, ring_off, info_off, dc_lane, small_off, bpm, endsub_m1, endpos, bad);
+            if (L.limm != kSrParked && (int32_t)L.wrw <= (L.pm1 >> 5) + 7) sr_topup(L, smem, ring_off, endpos);
+            if (__ballot(L.limm != kSrParked) == 0) break;
+        }
+        const int32_t over = L.pm1 - endsub_m1;  // bits past the nominal end
+        ex = sub_pack(over > 0 ? (over < 63 ? (uint32_t)over : 63u) : 0u, L.b, L.k);
+        if (bad) ex = sub_pack(0, L.b, L.k) | kSubBad;
+        nblk = L.nblk;
+        dcs = *reinterpret_cast<const int4 *>(smem + dc_lane);
     }
     if (round == 0 || ex != exit_in[slot]) atomicOr(changed, 1u);
     exit_out[slot] = ex;
     nblk_out[slot] = nblk;
-    dcsum_out[slot] = make_int4(dc0, dc1, dc2, dc3);
+    dcsum_out[slot] = dcs;
 }
-// (A version on K2's per-lane LDS ring -- the bit source of the final pass below -- was built and measured in round 2: 2.45 ms
-// per round against 1.92 ms for this one at 1024 x 4K; the ring's 17 KB per workgroup halve the occupancy, and the rounds
-// need the occupancy more.)
+// (Earlier forms: the word reader with the symbol step as per-lane branches, 1.9 ms per round on average at 1024 x 4K; K2's
+// 68-byte ring with a top-up per block, round 2: 2.45 ms -- the rings halved the occupancy; the word reader with its refill load
+// issued by hand, round 3: 1.55 ms.)
 // Exclusive prefix sums over a scan's subsequences: first block and DC predictors at the entry of every subsequence.
 // One workgroup per scan.
 __global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__restrict__ scans, const uint32_t *__restrict__ scan_ids,
@@ -3887,17 +4000,20 @@ __global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__rest
     }
 }
 
-// Final pass.  The converged entry states say where every subsequence's first block begins: lane i decodes the WHOLE
-// blocks that start inside subsequence i (it first skips the tail of a block the previous lane is finishing, and runs
-// past its own end to finish its last block), so every block has exactly one owner.  Lanes of a wave then work like K2
-// -- the same ring, lookups and symbol step, with the tables picked per lane because the lanes stand at different blocks of
-// their MCUs: block j of every lane is decoded into the wave's LDS staging in lock-step and flushed as whole 128-byte
-// lines; the coefficient buffer needs no clearing.  The DC predictor chain starts from the prefix sums of
-// subseq_scan_kernel.  (First version: the generic word reader and symbol decoder, 11.0 ms per 1024 x 4K against K2's 5.7.)
+// Final pass.  The converged entry states say where every subsequence's first block begins: lane i decodes the whole MCUs
+// that START inside subsequence i (it first parses, without storing, the blocks between its entry and that MCU -- the rest
+// of an MCU the previous lane owns -- and runs past its own end to finish its last MCU), so every MCU has exactly one owner
+// and EVERY LANE OF A WAVE STANDS AT THE SAME BLOCK OF ITS MCU: from there on this is K2 -- block b of every lane decoded
+// in lock-step with wave-uniform tables into the wave's LDS staging and flushed as whole 128-byte lines; the coefficient
+// buffer needs no clearing.  The DC predictor chain starts from the prefix sums of subseq_scan_kernel plus the DC
+// differences of the blocks parsed on the way to the first MCU.
+// (First version: the generic word reader and symbol decoder, 11.0 ms per 1024 x 4K against K2's 5.7.  Second, rounds 2-3:
+// K2's ring and symbol step with BLOCK-aligned ownership -- lanes at different blocks of their MCUs, so the tables were
+// picked per lane and a lock-step iteration mixed long luma with short chroma blocks: 8.3 ms.)
 constexpr int kSubFinalMaxWaves = 4;  // the launch picks subseq_final_waves(n_slots)
 constexpr int kSfLB = 10;
 constexpr uint32_t kSfTabBytes = (4u << kSfLB) + kK2SmallBytes;
-constexpr int kSfWaveBytes = kK2WaveBytes + 64 * 2 * (int)sizeof(uint32_t);  // K2's staging + rings, then (first block, count) per lane
+constexpr int kSfWaveBytes = kK2WaveBytes + 64 * 2 * (int)sizeof(uint32_t);  // K2's staging + rings, then (first MCU, count) per lane
 __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
                                                                            const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
                                                                            DevScanStatus *__restrict__ status,
@@ -3931,7 +4047,7 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
     const uint32_t total_bits = ulen * 8;
     const uint32_t sub = wk.first_interval + tid;
     const uint32_t slot = s.sub_off + (sub < s.n_subs ? sub : 0);
-    const uint32_t total_blocks = s.total_mcus * s.blocks_per_mcu;
+    const uint32_t total_mcus = s.total_mcus;
     const uint32_t bpm = s.blocks_per_mcu;
     const uint64_t coef_off = s.coef_off;
     const bool closed_by_marker = st.terminator != 0;
@@ -3945,14 +4061,19 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
     }
     uint32_t b_in_mcu = (entry >> 6) & 31u;
     uint32_t i2 = ((entry >> 11) & 127u) * 2u;  // 2 x zig-zag position inside the block in progress at the entry
-    uint32_t my_first = total_blocks, my_end = total_blocks;
+    // first_block = blocks completed before the entry = index of the block in progress (i2 != 0: the previous lane's) or
+    // about to start there.  This lane owns the MCUs from the first one that starts at or behind its entry ...
+    uint32_t my_first = total_mcus, my_end = total_mcus, skip = 0;
     if (live) {
-        my_first = first_block[slot] + (i2 != 0 ? 1u : 0u);
+        const uint32_t at = first_block[slot];
+        my_first = (at + (i2 != 0 ? 1u : 0u) + bpm - 1) / bpm;
+        skip = my_first * bpm - at;  // block ends between the entry and that MCU (the first of them may be half a block away)
+        // ... up to the first one that starts at or behind the next lane's entry
         if (sub + 1 < s.n_subs) {
             const uint32_t ex = exit_state[slot];
-            if (!(ex & kSubBad)) my_end = first_block[slot + 1] + ((((ex >> 11) & 127u) != 0) ? 1u : 0u);
+            if (!(ex & kSubBad)) my_end = (first_block[slot + 1] + ((((ex >> 11) & 127u) != 0) ? 1u : 0u) + bpm - 1) / bpm;
         }
-        if (my_end > total_blocks) my_end = total_blocks;  // the reference stops after the last MCU
+        if (my_end > total_mcus) my_end = total_mcus;  // the reference stops after the last MCU
         if (my_first > my_end) my_first = my_end;
     }
     const uint32_t count = my_end - my_first;
@@ -3965,7 +4086,7 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
     K2Feed feed;
     K2Pos pos;
     int32_t endpos = 0;
-    // A lane that owns blocks but starts behind the data (the stream ran out at a symbol boundary in an earlier subsequence)
+    // A lane that owns MCUs but starts behind the data (the stream ran out at a symbol boundary in an earlier subsequence)
     // decodes them the way the reference does: from the all-ones padding, i.e. with no data bits at all (its loads still
     // have to stay inside the buffer: it opens the stream at bit 0 and sees it as empty).
     const bool behind_data = start_bit >= total_bits;
@@ -3974,7 +4095,6 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
     int32_t lim = k2_limit(endpos, feed.wr);
     uint32_t err = 0;
     int32_t pred0 = 0, pred1 = 0, pred2 = 0, pred3 = 0;
-    uint32_t info = blk_info[b_in_mcu];
     if (decodes) {
         const int4 de = dc_entry[slot];
         pred0 = de.x;
@@ -3982,18 +4102,30 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
         pred2 = de.z;
         pred3 = de.w;
     }
-    // the tail of the block the previous lane owns: parsed, not stored
+    // the blocks in front of the lane's first MCU (the previous lane's): parsed, not stored; their DC differences count.
+    // The only stretch where the lanes of a wave stand at different blocks of their MCUs (tables picked per lane).
     {
-        bool tail = decodes && i2 != 0;
+        uint32_t left = decodes ? skip : 0u;
+        uint32_t info = blk_info[b_in_mcu];
         uint32_t it = 0;
-        while (__ballot(tail) != 0) {
-            if (tail) {
+        while (__ballot(left != 0) != 0) {
+            if (left != 0) {
+                const bool is_dc = i2 == 0;
                 int32_t v;
                 uint32_t adv;
-                err = k2_symbol<kSfLB>(ring, feed, pos, endpos, lim, k2_tab<kSfLB>(tabs, info >> 16), false, closed_by_marker, v, adv);
+                err = k2_symbol<kSfLB>(ring, feed, pos, endpos, lim, k2_tab<kSfLB>(tabs, is_dc ? ((info >> 8) & 0xFFu) : (info >> 16)), is_dc,
+                                       closed_by_marker, v, adv);
+                if (is_dc) {
+                    const uint32_t ci = info & 0xFFu;
+                    if (ci == 0) pred0 += v;
+                    else if (ci == 1) pred1 += v;
+                    else if (ci == 2) pred2 += v;
+                    else pred3 += v;
+                    adv = 2;
+                }
                 i2 += adv;
                 if (err != 0 || i2 >= 128u) {
-                    tail = false;
+                    left = err != 0 ? 0u : left - 1;
                     i2 = 0;
                     b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
                     info = blk_info[b_in_mcu];
@@ -4010,59 +4142,60 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
     const uint32_t swz16 = ((lane >> 1) & 7u) << 4;
 
     for (uint32_t j = 0; j < wave_count; j++) {
-        lim = k2_limit(endpos, feed.wr);
-        if (j < count && err == 0) {
-            // ReadBlockBaseline (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:179-222)
-            const uint32_t ci = info & 0xFFu;
-            const K2Tab hdc = k2_tab<kSfLB>(tabs, (info >> 8) & 0xFFu);
-            const K2Tab hac = k2_tab<kSfLB>(tabs, info >> 16);
-            int32_t v;
-            uint32_t adv = 0;
-            err = k2_symbol<kSfLB>(ring, feed, pos, endpos, lim, hdc, true, closed_by_marker, v, adv);
-            const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
-            v += pred;
-            if (ci == 0) pred0 = v;
-            else if (ci == 1) pred1 = v;
-            else if (ci == 2) pred2 = v;
-            else pred3 = v;
-            *reinterpret_cast<int16_t *>(my_stage + swz16) = (int16_t)v;  // zig-zag index 0
-            uint32_t k2i = err == 0 ? 2u : 128u;
-            while (k2i < 128u) {
-                const uint32_t e2 = k2_symbol<kSfLB>(ring, feed, pos, endpos, lim, hac, false, closed_by_marker, v, adv);
-                err |= e2;
-                k2i += adv;
-                // Math.Min(i++, 63) for a coefficient; EOB / ZRL store a zero at a position nothing was written to yet
-                const uint32_t at = k2i - 2u < 126u ? k2i - 2u : 126u;
-                *reinterpret_cast<int16_t *>(my_stage + (at ^ swz16)) = (int16_t)v;
+        for (uint32_t b = 0; b < bpm; b++) {
+            const uint32_t bi = __builtin_amdgcn_readfirstlane(blk_info[b]);  // wave-uniform
+            const uint32_t ci = bi & 0xFFu;
+            const K2Tab hdc = k2_tab<kSfLB>(tabs, (bi >> 8) & 0xFFu);
+            const K2Tab hac = k2_tab<kSfLB>(tabs, bi >> 16);
+            lim = k2_limit(endpos, feed.wr);
+            if (j < count && err == 0) {
+                // ReadBlockBaseline (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:179-222)
+                int32_t v;
+                uint32_t adv = 0;
+                err = k2_symbol<kSfLB>(ring, feed, pos, endpos, lim, hdc, true, closed_by_marker, v, adv);
+                const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
+                v += pred;
+                if (ci == 0) pred0 = v;
+                else if (ci == 1) pred1 = v;
+                else if (ci == 2) pred2 = v;
+                else pred3 = v;
+                *reinterpret_cast<int16_t *>(my_stage + swz16) = (int16_t)v;  // zig-zag index 0
+                uint32_t k2i = err == 0 ? 2u : 128u;
+                while (k2i < 128u) {
+                    const uint32_t e2 = k2_symbol<kSfLB>(ring, feed, pos, endpos, lim, hac, false, closed_by_marker, v, adv);
+                    err |= e2;
+                    k2i += adv;
+                    // Math.Min(i++, 63) for a coefficient; EOB / ZRL store a zero at a position nothing was written to yet
+                    const uint32_t at = k2i - 2u < 126u ? k2i - 2u : 126u;
+                    *reinterpret_cast<int16_t *>(my_stage + (at ^ swz16)) = (int16_t)v;
+                }
             }
-            b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
-            info = blk_info[b_in_mcu];
-        }
-        k2_topup(ring, feed, pos.pm1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            k2_topup(ring, feed, pos.pm1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const uint32_t blk = it * 8 + (lane >> 3);
-            const uint32_t chunk = lane & 7;
-            uint4 *src = reinterpret_cast<uint4 *>(stage + blk * 128 + ((chunk ^ ((blk >> 1) & 7)) * 16));
-            const uint4 v = *src;
-            const uint4 z = {0, 0, 0, 0};
-            *src = z;
-            const uint32_t owner_first = meta[blk * 2], owner_count = meta[blk * 2 + 1];
-            if (j < owner_count) *reinterpret_cast<uint4 *>(coefs + (coef_off + owner_first + j) * 64 + chunk * 8) = v;
+            for (int it = 0; it < 8; it++) {
+                const uint32_t blk = it * 8 + (lane >> 3);
+                const uint32_t chunk = lane & 7;
+                uint4 *src = reinterpret_cast<uint4 *>(stage + blk * 128 + ((chunk ^ ((blk >> 1) & 7)) * 16));
+                const uint4 v = *src;
+                const uint4 z = {0, 0, 0, 0};
+                *src = z;
+                const uint32_t owner_first = meta[blk * 2], owner_count = meta[blk * 2 + 1];
+                if (j < owner_count) *reinterpret_cast<uint4 *>(coefs + (coef_off + ((uint64_t)owner_first + j) * bpm + b) * 64 + chunk * 8) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (live && err != 0) {
         // failure on the true path: same detail codes as the interval decoder; "interval" field carries the subsequence
         atomicMin(&status[wk.scan].first_error, (sub << 8) | err);
     }
     // bits left behind the scan's last block (see restart_check)
-    if (live && err == 0 && count != 0 && my_end == total_blocks) {
+    if (live && err == 0 && count != 0 && my_end == total_mcus) {
         const int32_t rem = endpos - (pos.pm1 + 1);
         status[wk.scan].pad[2] = rem > 0 ? (uint32_t)rem : 0u;
     }
@@ -4829,6 +4962,17 @@ size_t progressive_stream_lds_bytes(int n_slots) {
     return (size_t)n_slots * sizeof(DevHuffTable) + ring + (size_t)chunk * 128 + chunk * 8;  // (idx[]: two halves)
 }
 
+// Stream workgroups (one wave each) a CU really holds at once: LDS AND registers (the residency gate of the
+// pipelined launch counted LDS alone; a few more VGPRs would have made "resident" grids non-resident).  0 = unknown.
+int progressive_stream_blocks_per_cu(int n_slots) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, progressive_stream_kernel, 64, progressive_stream_lds_bytes(n_slots)) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
 // The same, one wave per (scan, restart interval): for scans with few, long intervals.
 hipError_t launch_progressive_streams(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                                       const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
@@ -4853,7 +4997,7 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
                               int *rounds_used, const uint32_t *lut_pool, const uint32_t **final_state_out) {
     *final_state_out = exit_a;
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
-    const size_t lds_round = ((size_t)n_slots << (kSrLutBits + 2)) + (size_t)n_slots * kK2SmallBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
+    const size_t lds_round = ((size_t)n_slots << (kSrLutBits + 2)) + (size_t)n_slots * kK2SmallBytes + kMaxBlocksPerMcu * 16 + 256 * (kSrRingStride + 16);
 
     static const uint32_t warm_bits = [] {  // bits of a subsequence round 0 decodes (0 = all of it); see subseq_round_kernel
         const char *ev = getenv("JPGPU_SUBSEQ_WARM_BITS");

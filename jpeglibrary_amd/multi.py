@@ -27,12 +27,16 @@ class MultiDecoder:
         self._tickets = {}
 
     @staticmethod
-    def _pointers(files):
+    def _pointers(files, pinned=False):
         n = len(files)
         ptrs = (C.c_void_p * max(1, n))()
         lens = (C.c_size_t * max(1, n))()
         keep = []
         for i, f in enumerate(files):
+            if pinned and not (isinstance(f, np.ndarray) and f.dtype == np.uint8 and f.flags.c_contiguous):
+                # the device reads page-locked memory where it lies: a bytes object is pageable and a copy made here would be
+                # too (same rule as Batch.upload_segments)
+                raise ValueError("pinned=True needs contiguous uint8 arrays inside page-locked memory (Context.host_alloc / host_register)")
             a = np.frombuffer(f, dtype=np.uint8) if not isinstance(f, np.ndarray) else np.ascontiguousarray(f)
             keep.append(a)
             ptrs[i] = a.ctypes.data
@@ -55,7 +59,7 @@ class MultiDecoder:
     def submit(self, files, fmt=FMT_INTERLEAVED_U8, pinned=False) -> int:
         """Uploads every shard into its slot's idle batch and launches the decodes; returns a ticket while the devices work.
         Submitting call k + 1 before wait(k) puts its host parse + H2D beside call k's decode (two calls in flight at most)."""
-        ptrs, lens, keep = self._pointers(files)
+        ptrs, lens, keep = self._pointers(files, pinned=pinned)
         t = C.c_int(-1)
         raise_for_status(_lib.jpgpu_multi_submit(self._h, ptrs, lens, len(files), fmt, _capi.UPLOAD_PINNED if pinned else 0, C.byref(t)),
                          _lib.jpgpu_multi_last_error(self._h))

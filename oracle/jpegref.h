@@ -119,6 +119,10 @@ int jref_decode_to_16bit(const uint8_t *data, size_t len, int component_count, u
  * is done; *pixels = pixels decoded inside that time.  Returns 0, or the status of the first failing image. */
 int jref_decode_batch_mt(const uint8_t *const *files, const size_t *lens, int n, int component_count, int threads, int warm,
                          double *seconds, uint64_t *pixels, char *err, size_t errcap);
+/* rgba != 0: the benchmark's whole sequence -- ConvertYCbCr8ToRgba32 (DecoderBenchmark.cs:67) into a second per-thread buffer
+ * behind every Decode() (component_count 3 only) */
+int jref_decode_batch_mt_ex(const uint8_t *const *files, const size_t *lens, int n, int component_count, int threads, int warm, int rgba,
+                            double *seconds, uint64_t *pixels, char *err, size_t errcap);
 
 /* ---- primitives exported for unit parity tests ---- */
 /* ref: ScanDecoder/JpegScanDecoder.cs:50-73 + FastFloatingPointDCT.cs:54-70: one block, zig-zag int16 in,

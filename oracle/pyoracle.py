@@ -369,21 +369,22 @@ def build_optimal_table(freq: np.ndarray, most_optimal: bool = False):
     return bits, values[:n.value].copy(), code, length
 
 
-def decode_batch_mt(files, component_count=3, threads=1, warm=True):
+def decode_batch_mt(files, component_count=3, threads=1, warm=True, rgba=False):
     """bench.py's CPU baseline (jref_decode_batch_mt): Identify + Decode into a YCbCr8 buffer, one decoder per native
     thread, thread t taking images t, t + threads, ...  files: list of numpy uint8 arrays (views are fine).
+    rgba=True: ConvertYCbCr8ToRgba32 behind every Decode(), the reference benchmark's whole sequence (DecoderBenchmark.cs:51-73).
     Returns (seconds, pixels)."""
     L = lib()
-    L.jref_decode_batch_mt.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, C.c_int,
-                                       C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
-    L.jref_decode_batch_mt.restype = C.c_int
+    L.jref_decode_batch_mt_ex.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+    L.jref_decode_batch_mt_ex.restype = C.c_int
     n = len(files)
     keep = [np.ascontiguousarray(np.frombuffer(f, np.uint8) if not isinstance(f, np.ndarray) else f) for f in files]
     ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in keep])
     lens = (C.c_size_t * n)(*[a.size for a in keep])
     sec, px = C.c_double(), C.c_uint64()
     err = C.create_string_buffer(256)
-    rc = L.jref_decode_batch_mt(ptrs, lens, n, component_count, threads, 1 if warm else 0, C.byref(sec), C.byref(px), err, 256)
+    rc = L.jref_decode_batch_mt_ex(ptrs, lens, n, component_count, threads, 1 if warm else 0, 1 if rgba else 0, C.byref(sec), C.byref(px), err, 256)
     if rc != 0:
         raise OracleError(rc, err.value.decode("utf-8", "replace"))
     return sec.value, px.value

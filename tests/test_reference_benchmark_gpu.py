@@ -1,0 +1,47 @@
+"""The reference's own benchmark input (tests/JpegLibrary.Benchmarks/DecoderBenchmark.cs:19-43, rebuilt by bench.het_canvas):
+an 8192 x 8192 baseline 4:2:0 Q75 frame without restart markers -- ONE 67-Mpixel scan, i.e. one K2S chain, of real content
+(HETissueSlide.jpg) beside three quarters of black -- decoded the way the benchmark does it (Identify + Decode + RGBA)."""
+import numpy as np
+import pytest
+
+import bench
+import jpeglibrary_amd as jl
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def canvas():
+    return bench.het_canvas(75)
+
+
+def test_the_benchmark_canvas_is_what_the_reference_builds(canvas):
+    info, _ = po.identify(canvas)
+    assert (info.width, info.height, info.ncomp) == (8192, 8192, 3)
+    assert info.sof == 0xC0 and info.restart_interval == 0  # baseline, one entropy-coded segment for the whole frame
+    assert [(info.comp[c].h, info.comp[c].v) for c in range(3)] == [(2, 2), (1, 1), (1, 1)]  # 4:2:0
+
+
+def test_the_benchmark_canvas_decodes_bit_exact_as_rgba_and_as_ycbcr(canvas):
+    ref, _ = po.decode_8bit(canvas)
+    outs, res = jl.decode_batch([canvas], jl.FMT_RGBA_U8)
+    assert res[0].status == 0, (res[0].status, res[0].detail)
+    assert np.array_equal(outs[0], po.ycbcr8_to_rgb(ref, rgba=True))
+    del outs
+    outs, res = jl.decode_batch([canvas], jl.FMT_INTERLEAVED_U8)
+    assert res[0].status == 0
+    assert np.array_equal(outs[0], ref)
+
+
+def test_a_batch_of_benchmark_canvases_beside_small_frames(canvas):
+    """the 67-Mpixel scan (tens of thousands of subsequences) in one batch with frames of a few subsequences"""
+    from tools import jpegsynth
+
+    small = [jpegsynth.encode(640, 368, "420", 75, 0, seed=5), jpegsynth.encode(96, 64, "444", 90, 0, seed=6)]
+    files = [small[0], canvas, small[1], canvas]
+    b = jl.Batch().upload(files, jl.FMT_INTERLEAVED_U8).decode().sync()
+    ref = po.decode_8bit(canvas)[0]
+    for i, f in enumerate(files):
+        assert b.result(i).status == 0, i
+        assert np.array_equal(b.output(i), ref if f is canvas else po.decode_8bit(f)[0]), i
