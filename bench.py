@@ -230,6 +230,11 @@ def main():
     ap.add_argument("--gen-threads", type=int, default=0)
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (RCCL) even for a single rank: runs the barrier / "
                                                          "MAX-reduce path of the multi-GPU launch on a one-GPU box")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL): one rank per GPU, the driver's launch.  gloo: REHEARSAL of a world > 1 launch on a box with fewer GPUs "
+                         "than ranks -- rank r uses device r mod (devices present), barriers and the MAX-reduce run on the host group; "
+                         "everything else (input generation at granted // world threads, crews, the parked CPU baseline, the slowest-rank "
+                         "ingest figures, the JSON line) is the code path of the real launch.  Its `value` is NOT a scaling point: the ranks share a device")
     ap.add_argument("--distinct", type=int, default=0, help="experiments only: synthesise this many distinct images and repeat them "
                                                             "to fill the batch (default: every image of the batch is distinct)")
     args = ap.parse_args()
@@ -247,6 +252,10 @@ def main():
 
     dist = None
     host_group = None
+    rehearsal = args.dist_backend == "gloo"
+    reduce_device = "cpu" if rehearsal else "cuda"
+    if rehearsal:
+        local_rank = local_rank % max(1, torch.cuda.device_count())  # ranks share the devices there are
     if world > 1 or args.dist:
         import torch.distributed as dist_
 
@@ -256,10 +265,14 @@ def main():
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        # host-side rendezvous (gloo): ranks that wait here block in a socket read and leave their CPUs to the rank that is
-        # measuring something on the host (the CPU baseline) -- an RCCL barrier would keep a core per waiting rank spinning
-        host_group = dist.new_group(backend="gloo")
+        if rehearsal:
+            dist.init_process_group("gloo")
+            host_group = dist.group.WORLD
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # host-side rendezvous (gloo): ranks that wait here block in a socket read and leave their CPUs to the rank that is
+            # measuring something on the host (the CPU baseline) -- an RCCL barrier would keep a core per waiting rank spinning
+            host_group = dist.new_group(backend="gloo")
     else:
         torch.cuda.set_device(local_rank)
 
@@ -341,7 +354,7 @@ def main():
     stage = batch.stage_ms()  # HIP-event averages over exactly the timed steps, on the stream the kernels ran on
 
     if dist is not None:
-        elapsed = sharding.max_over_ranks(dist, elapsed, device="cuda")
+        elapsed = sharding.max_over_ranks(dist, elapsed, device=reduce_device)
     value = sharding.aggregate_throughput(n_images * width * height, n_gpus, args.steps, elapsed)
 
     # ---- single-image latency (the reference benchmark decodes ONE image per call): decode alone with the file resident in
@@ -412,7 +425,7 @@ def main():
                 if not met[0]:
                     barrier()  # the other ranks are waiting at the start line
             if dist is not None:
-                per_batch_s = sharding.max_over_ranks(dist, per_batch_s, device="cuda")
+                per_batch_s = sharding.max_over_ranks(dist, per_batch_s, device=reduce_device)
             ingest_res[key] = (per_batch_s, st, err)
         batch.upload(files, fmt)  # leave the batch as the timed region had it (the spot check below reads it)
         batch.decode().sync()
@@ -458,6 +471,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            **({"rehearsal": f"{world} ranks over gloo sharing {torch.cuda.device_count()} device(s): plumbing check of the world > 1 launch, "
+                             "not a scaling point"} if rehearsal and world > 1 else {}),
             "config": {
                 "workload": f"{n_images} x {width}x{height} {ss} {kind} Q{quality} DRI={dri} per GPU, output {args.format} resident in HBM",
                 "images_per_gpu": n_images,

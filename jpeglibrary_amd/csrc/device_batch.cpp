@@ -1172,6 +1172,9 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     compressed_bytes_ = 0;
     total_pixels_ = 0;
     n_huff_slots_ = 1;
+    // (known before any work list is cut: the Huffman workgroup's size -- intervals per work entry -- follows from it)
+    for (const ScanJob &job : jobs_) n_huff_slots_ = std::max(n_huff_slots_, job.n_huff);
+    const uint32_t huff_intervals_per_wg = 64u * (uint32_t)huffman_waves(n_huff_slots_);
     // the device image of a table depends on BITS / HUFFVAL alone: look those up before building it (a batch of
     // camera files carries the same four tables a thousand times)
     struct HuffKey {
@@ -1352,7 +1355,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 sub_scan_ids_.push_back((uint32_t)j);
                 for (uint32_t first = 0; first < s.n_subs; first += 256) sub_work.push_back({(uint32_t)j, first});
             } else {
-                for (uint32_t first = 0; first < s.n_intervals; first += kHuffIntervalsPerWg) huff_work.push_back({(uint32_t)j, first});
+                for (uint32_t first = 0; first < s.n_intervals; first += huff_intervals_per_wg) huff_work.push_back({(uint32_t)j, first});
             }
             if (s.blocks_per_mcu == 0) continue;  // cannot happen for a resolved scan (sampling factors are checked); no blocks, no work
             uint32_t mcus_per_wg = (uint32_t)kIdctBlocksPerWg / s.blocks_per_mcu;
@@ -1391,7 +1394,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     n_sub_work_ = (int)sub_work.size();
     std::vector<HuffWork> sub_final_work;  // the final pass takes larger workgroups than the rounds (kernels.h: subseq_final_waves)
     for (uint32_t j : sub_scan_ids_)
-        for (uint32_t first = 0; first < h_scans_[j].n_subs; first += 64u * (uint32_t)subseq_final_waves(n_huff_slots_)) sub_final_work.push_back({j, first});
+        for (uint32_t first = 0; first < h_scans_[j].n_subs; first += 64u * (uint32_t)subseq_final_waves(n_huff_slots_) * (uint32_t)kSubFinalSubsPerLane) sub_final_work.push_back({j, first});
     n_sub_final_work_ = (int)sub_final_work.size();
     n_sub_scans_ = (int)sub_scan_ids_.size();
     std::vector<HuffWork> prog_work;
@@ -1588,7 +1591,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(descriptors)");
         }
     }
-    e = launch_lut_pool(up, (const DevHuffTable *)d_huff_pool_.ptr, (int)huff_pool_.size(), (uint32_t *)d_lut_pool_.ptr);
+    e = launch_lut_pool(up, (const DevHuffTable *)d_huff_pool_.ptr, (int)huff_pool_.size(), (uint8_t *)d_lut_pool_.ptr);
     if (e != hipSuccess) return hip_fail(e, "lut_pool_kernel");
     if (!files_resident_) {
         // single scan jobs / frames handed over by the decoder mirror: small, copied as they are
@@ -1627,7 +1630,7 @@ int DeviceBatch::run_huffman() {
     status_valid_ = false;
     hipError_t e = launch_huffman(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_huff_work_.ptr,
                                   n_huff_work_, (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr,
-                                  (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (const uint32_t *)d_lut_pool_.ptr);
+                                  (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (const uint8_t *)d_lut_pool_.ptr);
     if (e != hipSuccess) return hip_fail(e, "huffman_decode_kernel");
     if (n_sub_work_ > 0) {
         // DRI = 0 scans: the final pass writes every block of the scan as whole lines (nothing to clear)
@@ -1636,7 +1639,7 @@ int DeviceBatch::run_huffman() {
                                  (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (uint32_t *)d_sub_exit_a_.ptr,
                                  (uint32_t *)d_sub_exit_b_.ptr, (uint32_t *)d_sub_nblk_.ptr, (uint32_t *)d_sub_first_.ptr,
                                  (uint32_t *)d_sub_entry_.ptr, d_sub_dcsum_.ptr, d_sub_dcentry_.ptr, (uint32_t *)d_sub_changed_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (int)max_subs_per_scan_ + 2,
-                                 &last_subseq_rounds_, (const uint32_t *)d_lut_pool_.ptr, (const HuffWork *)d_sub_final_work_.ptr, n_sub_final_work_);
+                                 &last_subseq_rounds_, (const uint8_t *)d_lut_pool_.ptr, (const HuffWork *)d_sub_final_work_.ptr, n_sub_final_work_);
         if (e != hipSuccess) return hip_fail(e, "subsequence decode");
     }
     const int rc = run_progressive();
@@ -1653,7 +1656,7 @@ int DeviceBatch::run_subseq_sync(const uint32_t **final_state, const uint32_t **
                                       (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (uint32_t *)d_sub_exit_a_.ptr,
                                       (uint32_t *)d_sub_exit_b_.ptr, (uint32_t *)d_sub_nblk_.ptr, (uint32_t *)d_sub_first_.ptr,
                                       (uint32_t *)d_sub_entry_.ptr, d_sub_dcsum_.ptr, d_sub_dcentry_.ptr, (uint32_t *)d_sub_changed_.ptr,
-                                      n_huff_slots_, (int)max_subs_per_scan_ + 2, &last_subseq_rounds_, (const uint32_t *)d_lut_pool_.ptr,
+                                      n_huff_slots_, (int)max_subs_per_scan_ + 2, &last_subseq_rounds_, (const uint8_t *)d_lut_pool_.ptr,
                                       final_state);
     if (e != hipSuccess) return hip_fail(e, "subsequence synchronisation");
     return mark_work();
@@ -1883,7 +1886,7 @@ int DeviceBatch::decode() {
         auto k2 = [&](hipStream_t st, int first, int n) {
             return launch_huffman(st, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_huff_work_.ptr + first, n,
                                   (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr,
-                                  (int16_t *)d_coefs_.ptr, n_huff_slots_, (const uint32_t *)d_lut_pool_.ptr);
+                                  (int16_t *)d_coefs_.ptr, n_huff_slots_, (const uint8_t *)d_lut_pool_.ptr);
         };
         auto k3 = [&](hipStream_t st, int half) {
             return launch_idct(st, (const int16_t *)d_coefs_.ptr, (const DevScan *)d_scans_.ptr, (const IdctWork *)d_idct_work_split_.ptr,

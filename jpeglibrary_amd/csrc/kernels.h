@@ -8,8 +8,10 @@
 
 namespace jpgpu {
 
-constexpr int kHuffWaves = 10;                // wavefronts per Huffman workgroup
-constexpr int kHuffIntervalsPerWg = 64 * kHuffWaves;  // restart intervals per workgroup (one per lane)
+constexpr int kHuffWaves = 11;                // wavefronts per Huffman workgroup (scans that stage up to 5 tables)
+constexpr int kHuffWavesManyTables = 9;       // ... with 6-8 tables staged (4.8 KB of LDS each)
+constexpr int huffman_waves(int n_slots) { return n_slots <= 5 ? kHuffWaves : kHuffWavesManyTables; }
+// restart intervals per Huffman workgroup (one per lane): 64 * huffman_waves(table slots of the batch)
 constexpr int kIdctBlocksPerWg = 256;         // 8x8 blocks per IDCT tile (one per lane)
 constexpr int kIdctTilesPerWg = 16;           // consecutive tiles walked by one IDCT workgroup (prefetch pipeline)
 
@@ -24,9 +26,9 @@ hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const De
                                int n_chunks, ChunkSum *sums, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u);
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                           const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
-                          int n_slots, const uint32_t *lut_pool);
+                          int n_slots, const uint8_t *lut_pool);
 // lut_pool: kLutPoolBytesPerTable per pool table, filled by launch_lut_pool (K2 and the K2S round kernel copy from it)
-hipError_t launch_lut_pool(hipStream_t stream, const DevHuffTable *huff_pool, int n_tables, uint32_t *lut_pool);
+hipError_t launch_lut_pool(hipStream_t stream, const DevHuffTable *huff_pool, int n_tables, uint8_t *lut_pool);
 constexpr int kNumIdctLayoutClasses = 5;
 // Output layout class of a scan for INTERLEAVED_U8 (0 = generic bytewise path, else a specialised kernel).
 int idct_layout_class(const DevScan &s);
@@ -44,11 +46,16 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
-                                int max_rounds, int *rounds_used, const uint32_t *lut_pool, const HuffWork *final_work, int n_final_work);
+                                int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work);
 // waves (of 64 subsequences) per workgroup of the K2S final pass.  4 = two workgroups per CU; one workgroup of 10 waves (K2's
 // shape, 25 % more waves per CU) was measured slower: 21.1 vs 19.6 ms K2S per 1024 x 4K -- a workgroup waits for its slowest wave
 constexpr int subseq_final_waves(int n_slots) { return n_slots <= 8 ? 4 : 4; }
-constexpr size_t kLutPoolBytesPerTable = 2 * 2048 * sizeof(uint32_t);  // fused DC + AC lookups of one pool table (lut_pool_kernel)
+// subsequences per lane of the K2S final pass (1: 8.1 ms per 1024 x 4K; 2: see DESIGN.md)
+#ifndef JPGPU_SF_SUBS
+#define JPGPU_SF_SUBS 2
+#endif
+constexpr int kSubFinalSubsPerLane = JPGPU_SF_SUBS;
+constexpr size_t kLutPoolBytesPerTable = 2 * (4096 + 512 + 16 + 320);  // DC + AC images of one pool table: 2^11 + 256 u16 entries, header, the reference's arrays (lut_pool_kernel)
 
 // progressive frames (K2P): the scans of one ordinal (position inside their frame) of every progressive frame in the batch
 hipError_t launch_progressive(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
@@ -82,7 +89,7 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
                               const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                               const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                               uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int n_slots, int max_rounds,
-                              int *rounds_used, const uint32_t *lut_pool, const uint32_t **final_state_out);
+                              int *rounds_used, const uint8_t *lut_pool, const uint32_t **final_state_out);
 hipError_t launch_subseq_transcode(hipStream_t stream, int mode, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                                    const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, const uint32_t *exit_state,
                                    const uint32_t *first_block, uint32_t *hist, const EncHuffTable *enc, uint32_t *sub_bits,

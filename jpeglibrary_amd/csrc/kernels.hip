@@ -672,26 +672,44 @@ __device__ __forceinline__ uint32_t restart_check(const DevScan &s, const DevSca
 //    exec-masked exact path (k2_slow_symbol), the same decisions as ub_symbol.
 constexpr int kK2RingStride = 68;                         // bytes per lane: 16 words + mirror of word 0
 constexpr int kK2WaveBytes = 8192 + 64 * kK2RingStride;   // coefficient staging + rings
-constexpr int kK2SmallBytes = 320;                        // maxcode[18] + valoffset[20] + values[256] + pad
-constexpr uint32_t kK2Miss = 0x80000000u;                 // lookup entry: code longer than the lookup width
-constexpr uint32_t kK2BadCategory = 0x80000001u;          // lookup entry: DC category above 16
+constexpr int kK2SmallBytes = 320;                        // maxcode[18] + valoffset[20] + values[256] + pad (round kernel's exact path)
+
+// Lookups of the K2 family (K2, the K2S final pass), built once per upload for every table of the pool, as a DC and as an AC
+// table (lut_pool_kernel), copied to LDS as they are:
+//   L1  2^11 x u16, the next 11 bits:  AC  total bits | zig-zag advance << 6 | category << 12   (advance in coefficients: r + 1;
+//                                          16 for any r != 0 with category 0; 63 = EOB, past the end from any position)
+//                                      DC  total bits | category << 6
+//                                      0 = not decided by 11 bits (a longer code); DC: 0x8000 = a category above 16
+//   L2  256 x u16, the LONG codes:     entry j = the reference's maxcode walk on the 16 bits t16 + j, same format, 0 = no code.
+//                                      Codes longer than the first level are the numerically largest ones of a canonical
+//                                      table: for the standard tables the last 192 of the 65 536 16-bit values hold them all.
+//                                      t16 = max(first value L1 does not decide, 65536 - 256).
+//   header  t16
+//   the reference's maxcode / valoffset / values (the exact walk: invalid codes, tables whose long codes leave the second level)
+// Round 4: 32-bit entries took 34 KB of LDS for four tables and a long code cost the maxcode walk (six dependent LDS reads
+// with 63 lanes waiting); now 19.8 KB, one more lookup for a long code, and the eleventh wave per workgroup.
+// (Everything the symbol loop may touch stays in LDS: with the walk's arrays in global memory hipcc put a `s_waitcnt vmcnt(0)`
+// at the head of the symbol loop -- every symbol waited for the previous block's coefficient stores: K2S final pass 7.8 -> 8.8 ms.)
+constexpr int kK2LutBits = 11;
+constexpr uint32_t kK2L1Bytes = 2u << kK2LutBits;
+constexpr uint32_t kK2L2Entries = 256;
+constexpr uint32_t kK2BadCat = 0x8000u;
+constexpr uint32_t kK2TabBytes = kK2L1Bytes + 2u * kK2L2Entries + 16u + kK2SmallBytes;  // == kLutPoolBytesPerTable / 2 (kernels.h)
 
 struct K2Tab {
-    const uint32_t *lut;
-    const uint16_t *maxcode;
-    const uint8_t *valoffset;
-    const uint8_t *values;
+    const uint16_t *lut;
+    const uint16_t *l2;
+    const uint32_t *hdr;  // {t16, 0, 0, 0}
+    const uint8_t *small;  // maxcode[18] | valoffset[20] | values[256]
 };
 
-template <int LB>
 __device__ __forceinline__ K2Tab k2_tab(const uint8_t *tabs, uint32_t slot) {
-    constexpr uint32_t kBytes = (4u << LB) + kK2SmallBytes;
-    const uint8_t *t = tabs + slot * kBytes;
+    const uint8_t *t = tabs + slot * kK2TabBytes;
     K2Tab h;
-    h.lut = reinterpret_cast<const uint32_t *>(t);
-    h.maxcode = reinterpret_cast<const uint16_t *>(t + (4u << LB));
-    h.valoffset = t + (4u << LB) + 36;
-    h.values = t + (4u << LB) + 56;
+    h.lut = reinterpret_cast<const uint16_t *>(t);
+    h.l2 = reinterpret_cast<const uint16_t *>(t + kK2L1Bytes);
+    h.hdr = reinterpret_cast<const uint32_t *>(t + kK2L1Bytes + 2u * kK2L2Entries);
+    h.small = t + kK2L1Bytes + 2u * kK2L2Entries + 16u;
     return h;
 }
 
@@ -746,8 +764,7 @@ __device__ __forceinline__ int32_t k2_limit(int32_t endpos, uint32_t wr) {
 }
 
 // Exact symbol decode: DecodeHuffmanCode + ReceiveAndExtend with the reference's "bits available" rules (same decisions
-// as ub_symbol).  Returns 0 or the failure detail; n = bits consumed, value, adv = zig-zag advance (AC).
-template <int LB>
+// as ub_symbol).  Returns 0 or the failure detail; n = bits consumed, value, adv = zig-zag advance (AC, in coefficients).
 __device__ __forceinline__ uint32_t k2_slow_symbol(uint8_t *ring, K2Feed &f, int32_t pm1, int32_t endpos, const K2Tab &h, bool is_dc,
                                                 bool closed_by_marker, uint32_t &n, int32_t &value, uint32_t &adv) {
     const int32_t pos = pm1 + 1;
@@ -756,21 +773,29 @@ __device__ __forceinline__ uint32_t k2_slow_symbol(uint8_t *ring, K2Feed &f, int
     int32_t rem = endpos - pos;
     if (rem < 0) rem = 0;
     const uint32_t code16 = rem > 0 ? (hi >> 16) : 0xFFFFu;
-    const uint32_t e = h.lut[code16 >> (16 - LB)];
+    uint32_t e = h.lut[code16 >> (16 - kK2LutBits)];
+    if (is_dc && (e & kK2BadCat) != 0) return kDetailInvalidHuffmanCode;  // categories above 16 are outside the verified envelope
+    const uint32_t t16 = h.hdr[0];
+    if (e == 0 && code16 >= t16) {  // a long code: the second level (t16 >= 65536 - 256)
+        e = h.l2[code16 - t16];
+        if (is_dc && (e & kK2BadCat) != 0) return kDetailInvalidHuffmanCode;
+    }
     uint32_t size, s;
-    if (e & 0x80000000u) {
-        if (e == kK2BadCategory) return kDetailInvalidHuffmanCode;
-        size = LB + 1;
-        while (code16 > h.maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
+    if (e == 0) {
+        // longer than the first level decides and not in the second: the reference's walk (an entry of the first level is empty
+        // exactly when the code has more than 11 bits, so the walk may start there)
+        const uint16_t *maxcode = reinterpret_cast<const uint16_t *>(h.small);
+        size = kK2LutBits + 1;
+        while (code16 > maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
         if (size > 16) return kDetailInvalidHuffmanCode;
-        const uint32_t sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
+        const uint32_t sym = h.small[56 + ((h.small[36 + size] + (code16 >> (16 - size))) & 0xFF)];
         s = is_dc ? sym : (sym & 15u);
-        adv = k2_ac_advance(sym);
-        if (s > 16u) return kDetailInvalidHuffmanCode;  // categories above 16 are outside the verified envelope
+        adv = (sym & 15u) ? (sym >> 4) + 1u : ((sym >> 4) ? 16u : 63u);
+        if (s > 16u) return kDetailInvalidHuffmanCode;
     } else {
-        size = (e >> 8) & 0xFFu;
-        s = (e >> 16) & 0xFFu;
-        adv = e >> 24;
+        s = is_dc ? ((e >> 6) & 31u) : (e >> 12);
+        size = (e & 63u) - s;
+        adv = (e >> 6) & 63u;
     }
     rem = rem > (int32_t)size ? rem - (int32_t)size : 0;  // advance Math.Min(entry.CodeSize, bitsRead)
     value = 0;
@@ -800,30 +825,66 @@ __device__ __forceinline__ void k2_pos_init(K2Pos &p, const uint8_t *ring, int32
     p.w2 = r[(q + 2) & 15];
 }
 
-// One symbol, fast path for every lane, then ONE branch the wave skips unless some lane needs the exact path for the lanes that need it (a
-// code longer than the lookup, the last bits of the interval, a ring that ran dry); advances the position.
-// On failure the lane gets adv = 255 (leaves the AC loop), n = 0, value = 0 and the detail code is returned.
-template <int LB>
-__device__ __forceinline__ uint32_t k2_symbol(uint8_t *ring, K2Feed &f, K2Pos &p, int32_t endpos, int32_t &lim, const K2Tab &h, bool is_dc,
-                                              bool closed_by_marker, int32_t &value, uint32_t &adv) {
+// One symbol, fast path for every lane, then ONE branch the wave skips unless some lane needs more: a long code (second
+// level), the last bits of the interval, a ring that ran dry (exact path); advances the position.
+// adv2 = zig-zag advance in int16 BYTES (2 x coefficients; 126 = EOB: past the end from any AC position).
+// On failure the lane gets adv2 = 254 (leaves the AC loop), n = 0, value = 0 and the detail code is returned.
+template <bool IS_DC>
+__device__ __forceinline__ uint32_t k2_symbol(uint8_t *ring, K2Feed &f, K2Pos &p, int32_t endpos, int32_t &lim, const K2Tab &h, bool closed_by_marker,
+                                              int32_t &value, uint32_t &adv2) {
     const uint32_t nxt = *reinterpret_cast<const uint32_t *>(ring + __builtin_amdgcn_ubfe((uint32_t)(p.pm1 + 96), 5, 4) * 4);
     const uint32_t hi = __builtin_amdgcn_alignbit(p.w0, p.w1, ~(uint32_t)p.pm1);
-    const uint32_t e = h.lut[hi >> (32 - LB)];
-    uint32_t n = e & 0xFFu;
-    const uint32_t cat = (e >> 16) & 0xFFu;
+    const uint32_t e = h.lut[hi >> (32 - kK2LutBits)];
+    uint32_t n = e & 63u;
+    const uint32_t cat = IS_DC ? ((e >> 6) & 31u) : (e >> 12);
     const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - n, cat);
     value = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));  // Extend(v, nbits)
-    adv = e >> 24;
+    adv2 = (e >> 5) & 0x7Eu;
     uint32_t err = 0;
-    // slow: the entry is flagged (sign bit) or the symbol does not fit below the limit -- one signed test
-    const bool slow = (int32_t)(e | (uint32_t)(lim - (p.pm1 + 1) - (int32_t)n)) < 0;
+    // slow: the entry is empty (e - 1 is negative), a DC category above 16 (bit 15), or the symbol does not fit below the
+    // limit -- one signed test
+    const bool slow = (int32_t)((e - 1u) | (IS_DC ? e << 16 : 0u) | (uint32_t)(lim - (p.pm1 + 1) - (int32_t)n)) < 0;
     if (slow) {  // exec-masked; the wave skips it when no lane is flagged
-        err = k2_slow_symbol<LB>(ring, f, p.pm1, endpos, h, is_dc, closed_by_marker, n, value, adv);
+        uint32_t adv = 0;
+        err = k2_slow_symbol(ring, f, p.pm1, endpos, h, IS_DC, closed_by_marker, n, value, adv);
+        adv2 = adv * 2u;
         lim = k2_limit(endpos, f.wr);
         if (err != 0) {
             n = 0;
             value = 0;
-            adv = 255;
+            adv2 = 254;
+        }
+    }
+    const int32_t np = p.pm1 + (int32_t)n;
+    const bool step = ((uint32_t)(np ^ p.pm1) >> 5) != 0;
+    p.pm1 = np;
+    p.w0 = step ? p.w1 : p.w0;
+    p.w1 = step ? p.w2 : p.w1;
+    p.w2 = step ? nxt : p.w2;
+    return err;
+}
+// (the same with the table kind known only per lane: the K2S final pass on its way to its first MCU)
+__device__ __forceinline__ uint32_t k2_symbol_any(uint8_t *ring, K2Feed &f, K2Pos &p, int32_t endpos, int32_t &lim, const K2Tab &h, bool is_dc,
+                                                  bool closed_by_marker, int32_t &value, uint32_t &adv2) {
+    const uint32_t nxt = *reinterpret_cast<const uint32_t *>(ring + __builtin_amdgcn_ubfe((uint32_t)(p.pm1 + 96), 5, 4) * 4);
+    const uint32_t hi = __builtin_amdgcn_alignbit(p.w0, p.w1, ~(uint32_t)p.pm1);
+    const uint32_t e = h.lut[hi >> (32 - kK2LutBits)];
+    uint32_t n = e & 63u;
+    const uint32_t cat = is_dc ? ((e >> 6) & 31u) : (e >> 12);
+    const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - n, cat);
+    value = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));
+    adv2 = is_dc ? 0u : ((e >> 5) & 0x7Eu);
+    uint32_t err = 0;
+    const bool slow = (int32_t)((e - 1u) | (is_dc ? e << 16 : 0u) | (uint32_t)(lim - (p.pm1 + 1) - (int32_t)n)) < 0;
+    if (slow) {
+        uint32_t adv = 0;
+        err = k2_slow_symbol(ring, f, p.pm1, endpos, h, is_dc, closed_by_marker, n, value, adv);
+        adv2 = is_dc ? 0u : adv * 2u;
+        lim = k2_limit(endpos, f.wr);
+        if (err != 0) {
+            n = 0;
+            value = 0;
+            adv2 = 254;
         }
     }
     const int32_t np = p.pm1 + (int32_t)n;
@@ -835,33 +896,53 @@ __device__ __forceinline__ uint32_t k2_symbol(uint8_t *ring, K2Feed &f, K2Pos &p
     return err;
 }
 
-// Fused lookups (the format K2 builds per workgroup: total bits | code bits << 8 | category << 16 | zig-zag advance << 24,
-// kK2Miss / kK2BadCategory) for every table of the pool, both as a DC and as an AC table: the round kernel's workgroups
-// are short-lived, so they copy the lookup instead of deriving it.  Entry (table * 2 + is_dc) * 2048 + prefix.
-constexpr int kLutPoolBits = 11;  // K2 copies the pooled lookup as it is
+// The K2 family's lookups (format above) for every table of the pool, as a DC table (odd blocks) and as an AC table.
+// Image (table * 2 + is_dc) * kK2TabBytes: L1 | L2 | header.
+constexpr int kLutPoolBits = kK2LutBits;
 #ifndef JPGPU_SR_LB
 #define JPGPU_SR_LB 10
 #endif
 constexpr int kSrLutBits = JPGPU_SR_LB;  // lookup width of the round kernel (a 10-bit prefix decides codes of up to 10 bits)
-__global__ __launch_bounds__(256) void lut_pool_kernel(const DevHuffTable *__restrict__ pool, uint32_t *__restrict__ lut_pool) {
+__device__ __forceinline__ uint32_t k2_entry_of(const DevHuffTable &h, uint32_t code16, bool is_dc, uint32_t max_size) {
+    // the reference's Lookup on these 16 bits (JpegHuffmanDecodingTable.cs:73-113): first-level table, then the maxcode walk
+    const uint32_t e9 = h.lut[code16 >> (16 - kHuffLutBits)];
+    uint32_t size = e9 >> 8, sym = e9 & 0xFFu;
+    if (size == 0) {
+        size = kHuffLutBits + 1;
+        while (code16 > h.maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
+        if (size > 16) return 0;
+        sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
+    }
+    if (size > max_size) return 0;
+    const uint32_t cat = is_dc ? sym : (sym & 15u);
+    if (cat > 16u) return kK2BadCat;  // (the exact path reports it)
+    if (is_dc) return (size + cat) | (cat << 6);
+    const uint32_t adv = (sym & 15u) ? (sym >> 4) + 1u : ((sym >> 4) ? 16u : 63u);
+    return (size + cat) | (adv << 6) | (cat << 12);
+}
+__global__ __launch_bounds__(256) void lut_pool_kernel(const DevHuffTable *__restrict__ pool, uint8_t *__restrict__ lut_pool) {
     const DevHuffTable &h = pool[blockIdx.x >> 1];
     const bool is_dc = (blockIdx.x & 1) != 0;
-    for (uint32_t i = threadIdx.x; i < (1u << kLutPoolBits); i += 256) {
-        const uint32_t code16 = (i << (16 - kLutPoolBits)) | ((1u << (16 - kLutPoolBits)) - 1u);
-        const uint32_t e9 = h.lut[i >> (kLutPoolBits - kHuffLutBits)];
-        uint32_t size = e9 >> 8, sym = e9 & 0xFFu;
-        if (size == 0) {
-            size = kHuffLutBits + 1;
-            while (code16 > h.maxcode[size]) size++;
-            if (size <= (uint32_t)kLutPoolBits) sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
-        }
-        uint32_t e = kK2Miss;
-        if (size <= (uint32_t)kLutPoolBits) {
-            const uint32_t cat = is_dc ? sym : (sym & 15u);
-            e = cat > 16u ? kK2BadCategory : ((size + cat) | (size << 8) | (cat << 16) | ((is_dc ? 0u : k2_ac_advance(sym)) << 24));
-        }
-        lut_pool[(size_t)blockIdx.x * (1u << kLutPoolBits) + i] = e;
+    uint8_t *img = lut_pool + (size_t)blockIdx.x * kK2TabBytes;
+    uint16_t *l1 = reinterpret_cast<uint16_t *>(img);
+    uint16_t *l2 = reinterpret_cast<uint16_t *>(img + kK2L1Bytes);
+    __shared__ uint32_t first_miss;
+    if (threadIdx.x == 0) first_miss = 1u << kK2LutBits;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (1u << kK2LutBits); i += 256) {
+        // a code of at most 11 bits is decided by the prefix alone (maxcode[l] has its low 16 - l bits set): evaluate with ones behind it
+        const uint32_t e = k2_entry_of(h, (i << (16 - kK2LutBits)) | ((1u << (16 - kK2LutBits)) - 1u), is_dc, kK2LutBits);
+        l1[i] = (uint16_t)e;
+        if (e == 0) atomicMin(&first_miss, i);  // (a bad category is an answer, not a miss)
     }
+    __syncthreads();
+    const uint32_t lo = first_miss << (16 - kK2LutBits);
+    const uint32_t t16 = lo > 65536u - kK2L2Entries ? lo : 65536u - kK2L2Entries;
+    for (uint32_t j = threadIdx.x; j < kK2L2Entries; j += 256) l2[j] = t16 + j < 65536u ? (uint16_t)k2_entry_of(h, t16 + j, is_dc, 16) : (uint16_t)0;
+    if (threadIdx.x < 4) reinterpret_cast<uint32_t *>(img + kK2L1Bytes + 2u * kK2L2Entries)[threadIdx.x] = threadIdx.x == 0 ? t16 : 0u;
+    if (threadIdx.x < kK2SmallBytes / 16)
+        reinterpret_cast<uint4 *>(img + kK2L1Bytes + 2u * kK2L2Entries + 16u)[threadIdx.x] =
+            reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&h) + offsetof(DevHuffTable, maxcode))[threadIdx.x];
 }
 
 #ifdef JPGPU_K2_PROFILE
@@ -878,7 +959,28 @@ extern "C" int jpgpu_debug_k2_profile(unsigned long long *out, int reset) {
 #define K2_PROF_ADD(i, v) do { (void)(v); } while (0)
 #endif
 
-template <int WAVES, int LB>
+// the scan's tables as the K2 family keeps them in LDS: the pooled images (lut_pool_kernel) copied as they are
+__device__ __forceinline__ void k2_stage_scan_tables(const DevScan &s, const uint8_t *lut_pool, uint8_t *tabs, uint32_t *blk_info, int n_slots,
+                                                     uint32_t nthreads) {
+    const uint32_t tid = threadIdx.x;
+    for (int sl = 0; sl < kMaxHuffSlots && sl < n_slots; sl++) {
+        const uint32_t pi = s.huff_pool[sl];
+        if (pi == 0xFFFF) continue;
+        bool is_dc = false;
+        for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
+        const uint4 *src = reinterpret_cast<const uint4 *>(lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * kK2TabBytes);
+        uint4 *dst = reinterpret_cast<uint4 *>(tabs + sl * kK2TabBytes);
+        for (uint32_t i = tid; i < kK2TabBytes / 16; i += nthreads) dst[i] = src[i];
+    }
+    // per block-in-MCU: scan component | DC slot << 8 | AC slot << 16 (kept in LDS: the block loop must not touch global
+    // memory for it, a vector load there would wait for the coefficient stores of the previous block)
+    if (tid < kMaxBlocksPerMcu) {
+        const uint32_t ci = s.blk_comp[tid];
+        blk_info[tid] = ci | ((uint32_t)s.comp[ci].dc_slot << 8) | ((uint32_t)s.comp[ci].ac_slot << 16);
+    }
+}
+
+template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_t *__restrict__ udata,
                                                                     const DevScan *__restrict__ scans,
                                                                     const HuffWork *__restrict__ work,
@@ -886,11 +988,10 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
                                                                     DevScanStatus *__restrict__ status,
                                                                     const DevHuffTable *__restrict__ huff_pool,
                                                                     int16_t *__restrict__ coefs, int n_slots,
-                                                                    const uint32_t *__restrict__ lut_pool) {
-    constexpr uint32_t kTabBytes = (4u << LB) + kK2SmallBytes;
+                                                                    const uint8_t *__restrict__ lut_pool) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *tabs = smem;                                    // n_slots * kTabBytes
-    uint8_t *wave_all = smem + (size_t)n_slots * kTabBytes;  // WAVES * kK2WaveBytes
+    uint8_t *tabs = smem;                                      // n_slots * kK2TabBytes
+    uint8_t *wave_all = smem + (size_t)n_slots * kK2TabBytes;  // WAVES * kK2WaveBytes
     uint32_t *blk_info = reinterpret_cast<uint32_t *>(wave_all + WAVES * kK2WaveBytes);  // [kMaxBlocksPerMcu]
 
     const HuffWork wk = work[blockIdx.x];
@@ -900,57 +1001,14 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
     const uint32_t wave = tid >> 6;
     const unsigned long long k2_t0 = K2_TICK();
 
-    // stage this scan's Huffman tables (ref: InitDecodeComponents resolves them per scan, JpegHuffmanScanDecoder.cs:63-64):
-    // the reference's maxcode / valoffset / values verbatim, then the fused lookup derived from them
-    for (int slot = 0; slot < kMaxHuffSlots && slot < n_slots; slot++) {
-        const uint32_t pi = s.huff_pool[slot];
-        if (pi == 0xFFFF) continue;
-        const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&huff_pool[pi]) + offsetof(DevHuffTable, maxcode));
-        uint4 *dst = reinterpret_cast<uint4 *>(tabs + slot * kTabBytes + (4u << LB));
-        for (uint32_t i = tid; i < kK2SmallBytes / 16; i += 64 * WAVES) dst[i] = src[i];
-    }
-    // per block-in-MCU: scan component | DC slot << 8 | AC slot << 16 (kept in LDS: the block loop must not touch global
-    // memory for it, a vector load there would wait for the coefficient stores of the previous block)
-    if (tid < kMaxBlocksPerMcu) {
-        const uint32_t ci = s.blk_comp[tid];
-        blk_info[tid] = ci | ((uint32_t)s.comp[ci].dc_slot << 8) | ((uint32_t)s.comp[ci].ac_slot << 16);
-    }
+    // stage this scan's Huffman tables (ref: InitDecodeComponents resolves them per scan, JpegHuffmanScanDecoder.cs:63-64)
+    k2_stage_scan_tables(s, lut_pool, tabs, blk_info, n_slots, 64 * WAVES);
     uint8_t *stage = wave_all + wave * kK2WaveBytes;
     uint8_t *ring = stage + 8192 + lane * kK2RingStride;
     {
         const uint4 z = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(stage)[i * 64 + lane] = z;
-    }
-    __syncthreads();
-    for (int slot = 0; slot < kMaxHuffSlots && slot < n_slots; slot++) {
-        const uint32_t pi = s.huff_pool[slot];
-        if (pi == 0xFFFF) continue;
-        bool is_dc = false;
-        for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == slot;
-        const K2Tab h = k2_tab<LB>(tabs, slot);
-        uint32_t *lut = const_cast<uint32_t *>(h.lut);
-        if (LB == kLutPoolBits) {  // the lookup was derived once for the whole batch (lut_pool_kernel)
-            const uint4 *src = reinterpret_cast<const uint4 *>(lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * (1u << kLutPoolBits));
-            for (uint32_t i = tid; i < (1u << LB) / 4; i += 64 * WAVES) reinterpret_cast<uint4 *>(lut)[i] = src[i];
-            continue;
-        }
-        for (uint32_t i = tid; i < (1u << LB); i += 64 * WAVES) {
-            const uint32_t code16 = (i << (16 - LB)) | ((1u << (16 - LB)) - 1u);
-            const uint32_t e9 = huff_pool[pi].lut[i >> (LB - kHuffLutBits)];
-            uint32_t size = e9 >> 8, sym = e9 & 0xFFu;
-            if (size == 0) {
-                size = kHuffLutBits + 1;
-                while (code16 > h.maxcode[size]) size++;
-                if (size <= (uint32_t)LB) sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
-            }
-            uint32_t e = kK2Miss;
-            if (size <= (uint32_t)LB) {
-                const uint32_t cat = is_dc ? sym : (sym & 15u);
-                e = cat > 16u ? kK2BadCategory : ((size + cat) | (size << 8) | (cat << 16) | ((is_dc ? 0u : k2_ac_advance(sym)) << 24));
-            }
-            lut[i] = e;
-        }
     }
     __syncthreads();
 
@@ -1018,15 +1076,15 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
         for (uint32_t b = 0; b < bpm; b++) {
             const uint32_t bi = __builtin_amdgcn_readfirstlane(blk_info[b]);  // wave-uniform
             const uint32_t ci = bi & 0xFFu;
-            const K2Tab hdc = k2_tab<LB>(tabs, (bi >> 8) & 0xFFu);
-            const K2Tab hac = k2_tab<LB>(tabs, bi >> 16);
+            const K2Tab hdc = k2_tab(tabs, (bi >> 8) & 0xFFu);
+            const K2Tab hac = k2_tab(tabs, bi >> 16);
             const unsigned long long k2_a = K2_TICK();
             int32_t lim = k2_limit(endpos, feed.wr);
             if (active && err == 0 && mcu < my_mcus) {
                 // ReadBlockBaseline (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:179-222)
                 int32_t v;
                 uint32_t adv = 0;
-                err = k2_symbol<LB>(ring, feed, pos, endpos, lim, hdc, true, closed_by_marker, v, adv);
+                err = k2_symbol<true>(ring, feed, pos, endpos, lim, hdc, closed_by_marker, v, adv);
                 const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
                 v += pred;
                 if (ci == 0) pred0 = v;
@@ -1036,7 +1094,7 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
                 *reinterpret_cast<int16_t *>(my_stage + swz16) = (int16_t)v;  // zig-zag index 0
                 uint32_t i2 = err == 0 ? 2u : 128u;  // 2 x zig-zag index of the next coefficient
                 while (i2 < 128u) {
-                    const uint32_t e2 = k2_symbol<LB>(ring, feed, pos, endpos, lim, hac, false, closed_by_marker, v, adv);
+                    const uint32_t e2 = k2_symbol<false>(ring, feed, pos, endpos, lim, hac, closed_by_marker, v, adv);
                     err |= e2;
                     i2 += adv;
                     // Math.Min(i++, 63) for a coefficient; EOB / ZRL store a zero at a position nothing was written to yet
@@ -3293,7 +3351,7 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
         if (ah == 0) {
             ProgWalk w;
             prog_walk_init(w, p, first_unit, units_per_line);
-            for (uint32_t u = 0; u < my_units && err == 0; u++, prog_walk_next(w, p, units_per_line)) {
+            for (uint32_t u = 0; u < my_units && err == 0;) {
                 // (with the write-back also where nothing was stored since the last word, inside an end-of-band run: leaving it out
                 // there is legal -- the producers' stores were written back before THEIR words -- and measured slower, 186 vs 181 ms
                 // per 256 frames)
@@ -3307,7 +3365,18 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
                 JPGPU_FOLLOW(w.my)
                 if (err != 0) break;  // gave up waiting (kDetailSpinTimeout)
                 if (eobrun != 0) {
-                    eobrun--;
+                    // blocks inside an end-of-band run are not touched: to the end of the block row in one step (the next row is
+                    // followed and announced like any other), never across a progress word.  (Round 3 walked them one by one:
+                    // the Y AC 6-63 first scan of a smooth 4K frame is ONE run of 129 600 blocks, 17.8 ms per 256 frames.)
+                    uint32_t skip = eobrun;
+                    const uint32_t row_left = units_per_line - w.bx, pub_left = kPsPublishEvery - (u & (kPsPublishEvery - 1u)), left = my_units - u;
+                    skip = skip < row_left ? skip : row_left;
+                    skip = skip < pub_left ? skip : pub_left;
+                    skip = skip < left ? skip : left;
+                    eobrun -= skip;
+                    u += skip;
+                    if (skip == 1) prog_walk_next(w, p, units_per_line);
+                    else prog_walk_init(w, p, first_unit + u, units_per_line);
                     continue;
                 }
                 JPGPU_ENSURE_STAGED()
@@ -3328,6 +3397,8 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
                     JPGPU_SETTLE()
                 }
                 if (real && (changed & lane_bit) != 0) coefs[index * 64 + lane] = (int16_t)c;
+                u++;
+                prog_walk_next(w, p, units_per_line);
             }
         } else {
             unsigned long long ps_stage = 0, ps_wait = 0, ps_blocks = 0, ps_t0 = PS_TICK();
@@ -3556,39 +3627,6 @@ __device__ __forceinline__ void sub_stage_tables(const DevScan &s, const DevHuff
     __syncthreads();
 }
 
-// Tables of a scan staged the way K2 lays them out (fused lookup of 1 << LB entries, then the reference's small arrays),
-// for the subsequence kernels.  The lookups come from the pool built once per upload (lut_pool_kernel, 11-bit prefixes);
-// LB = 10 keeps every other entry (prefixes 2i and 2i + 1 agree whenever the code has at most 10 bits).
-template <int LB>
-__device__ __forceinline__ void k2_stage_scan_tables(const DevScan &s, const DevHuffTable *huff_pool, const uint32_t *lut_pool, uint8_t *tabs,
-                                                     uint32_t *blk_info, int n_slots, uint32_t nthreads) {
-    constexpr uint32_t kTabBytes = (4u << LB) + kK2SmallBytes;
-    const uint32_t tid = threadIdx.x;
-    for (int sl = 0; sl < kMaxHuffSlots && sl < n_slots; sl++) {
-        const uint32_t pi = s.huff_pool[sl];
-        if (pi == 0xFFFF) continue;
-        bool is_dc = false;
-        for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
-        const uint32_t *src = lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * (1u << kLutPoolBits);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(tabs + sl * kTabBytes);
-        if (LB == kLutPoolBits) {
-            for (uint32_t i = tid; i < (1u << LB) / 4; i += nthreads) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
-        } else {
-            for (uint32_t i = tid; i < (1u << LB); i += nthreads) {
-                const uint32_t e = src[i << (kLutPoolBits - LB)];
-                dst[i] = (e != kK2BadCategory && ((e & 0x80000000u) || ((e >> 8) & 0xFFu) > (uint32_t)LB)) ? kK2Miss : e;
-            }
-        }
-        const uint4 *ssrc = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&huff_pool[pi]) + offsetof(DevHuffTable, maxcode));
-        uint4 *sdst = reinterpret_cast<uint4 *>(tabs + sl * kTabBytes + (4u << LB));
-        if (tid < kK2SmallBytes / 16) sdst[tid] = ssrc[tid];
-    }
-    if (tid < kMaxBlocksPerMcu) {
-        const uint32_t ci = s.blk_comp[tid];
-        blk_info[tid] = ci | ((uint32_t)s.comp[ci].dc_slot << 8) | ((uint32_t)s.comp[ci].ac_slot << 16);
-    }
-}
-
 // A lane's stream positioned at bit `start_bit` of the scan's unstuffed data: K2's ring + feed + position (64 bytes staged,
 // the next 16 prefetched).  Returns pm1 of the start; *endpos = position of the first bit behind the data.
 __device__ __forceinline__ int32_t k2_open_at_bit(const uint8_t *ubase, uint32_t start_bit, uint32_t total_bits, uint8_t *ring, K2Feed &feed,
@@ -3620,201 +3658,229 @@ __device__ __forceinline__ int32_t k2_open_at_bit(const uint8_t *ubase, uint32_t
 // Round 4 form.  64 lanes stand at 64 different places of their blocks, so whatever a lane does "sometimes" the wave does
 // in every step; the step is therefore ONE straight line for every lane, and what cannot be decided by one lookup is not
 // branched to but PARKED:
-//  * bit source = K2's scheme on a small ring: the lane's position and the three stream words around it in registers, the
-//    word that will be missing after the step read from a private 8-word LDS ring at the start of the step, off the chain;
-//    the ring is topped up (16 bytes, prefetched a burst earlier) between bursts of kSrBurst steps, not inside them;
+//  * bit source = a bit position into a private 8-word LDS ring of the lane's unstuffed stream (9 words per lane: the ring
+//    stored MSB-first + a mirror of word 0, so the two words around the position are always one ds_read2; stride 9 keeps
+//    lanes on distinct banks); the ring is topped up (16 bytes, prefetched a burst earlier) between bursts of kSrBurst steps;
 //  * one lookup of the next kSrLutBits bits gives `total bits | zig-zag advance << 6 | DC difference << 16`: a DC symbol
 //    whose magnitude lies inside the looked-up prefix carries its EXTENDED value in the entry (an AC entry carries zero), so
 //    the step adds the entry's upper half to the lane's component sum (one ds_add into 16 bytes of LDS per lane) whatever
 //    the symbol is; DC entries advance the zig-zag position by one, EOB by 64: no DC / AC distinction but the table choice;
-//  * a lane whose symbol needs more (a code longer than the lookup, a DC magnitude that does not fit the prefix, a bad
-//    category, bits beyond what the ring holds or beyond the data) commits NOTHING in that step -- its entry is replaced by
-//    zero: no bits, no advance, no difference -- and repeats it until the burst is over; then the stuck lanes take the exact
-//    path (sr_service: the reference's maxcode walk and "bits available" rules) under one branch per burst;
-//  * a lane that has passed the end of its subsequence is parked for good by its limit.
+//  * an entry WITHOUT BITS means "not here": no bits, no advance, no difference -- the lane stands where it stood.  That is what a
+//    prefix the lookup cannot decide holds (a code longer than the lookup, a DC magnitude that leaves the prefix, a bad
+//    category: the reason sits in bits 13-14, which the step does not look at), and it is what a lane reads whose position is
+//    beyond its limit -- the end of its subsequence, 64 bits in front
+//    of what the ring holds, 32 bits in front of the end of the data: its lookup address is replaced by the address of a
+//    zero word BEFORE the lookup, so the step has no test behind it.  A lane that stands repeats its step until the burst is
+//    over; then the standing lanes take the exact path (sr_service: the reference's maxcode walk and "bits available" rules,
+//    the ring's top-up, the end of the subsequence) under one branch per burst.
 // Before: ~55 vector + ~25 scalar instructions and five branches per symbol step (the word reader's refill branches and the
-// exact path, taken by some lane in nearly every step); the step below is ~37 vector instructions and no branch.
-constexpr int kSrRingStride = 36;  // bytes per lane: 8 stream words + 1 (lanes reading the same word index hit distinct banks)
+// exact path, taken by some lane in nearly every step); the first round-4 form (three stream words in registers, a flagged
+// entry and a limit test behind the lookup) ~42 vector instructions, 1.56 -> 1.20 ms per round; the step below ~27.
+constexpr int kSrRingStride = 36;  // bytes per lane: 8 stream words + the mirror of word 0
 #ifndef JPGPU_SR_BURST
-#define JPGPU_SR_BURST 8
+#define JPGPU_SR_BURST 16
 #endif
 constexpr int kSrBurst = JPGPU_SR_BURST;  // fast steps between two service / top-up points
-constexpr uint32_t kSrFlag = 0x8000u;              // entry: not decidable by the lookup
-constexpr uint32_t kSrMiss = kSrFlag;              //   code longer than the lookup (or a prefix it shares with another code)
-constexpr uint32_t kSrBadCat = kSrFlag | 0x2000u;  //   DC category above 16
-constexpr uint32_t kSrDcWide = kSrFlag | 0x4000u;  //   DC symbol whose magnitude leaves the prefix: code size | category << 6
 constexpr int32_t kSrParked = -0x40000000;         // limit of a lane that is finished: nothing commits any more
+// entries without bits (the lane stands), by reason:
+constexpr uint32_t kSrStandMiss = 0x2000u;    // a code longer than the lookup: the reference's walk, from there
+constexpr uint32_t kSrStandBadCat = 0x4000u;  // a DC category above 16
+constexpr uint32_t kSrStandDcWide = 0x6000u;  // a DC symbol whose magnitude leaves the prefix (code and category: the pooled first level)
+
 
 struct SrLane {
-    int32_t pm1;  // bit position - 1, relative to the lane's 4-byte aligned origin
-    uint32_t w0, w1, w2;  // the stream words holding bit pm1 and behind it
-    uint32_t k;           // zig-zag index of the next coefficient; 0 = the block's DC symbol comes next
-    uint32_t b;           // block inside the MCU
-    uint32_t nblk;        // blocks completed
+    int32_t pm1;    // bit position - 1, relative to the lane's 4-byte aligned origin
+    uint32_t k;     // zig-zag index of the next coefficient; 0 = the block's DC symbol comes next
+    uint32_t ip;    // LDS offset of the block's entry in the block-info table ({DC lookup, AC lookup, DC sum offset, 0} per block of the MCU)
+    uint32_t nblk;  // blocks completed
     uint32_t tabdc, tabac, dcaddr;  // LDS byte offsets: the block's two lookups, its component's DC sum
-    int32_t limm;                   // fast-path limit - 1: a symbol of n bits commits while pm1 + n <= limm
+    int32_t slim;                   // a symbol may be looked up while pm1 < slim (kSrParked: never again)
     uint32_t wrw;                   // stream words written to the ring so far (it holds words wrw-8 .. wrw-1)
     uint4 nx;                       // the next 16 bytes of the stream, loaded a burst ago
     const uint8_t *gp;              // address of the 16 bytes behind them
 };
 
-// the block's lookups and DC sum after a block end (branch-free: read in every step, taken when `end`)
-__device__ __forceinline__ void sr_block_info(SrLane &L, const uint8_t *smem, uint32_t info_off, uint32_t dc_lane, uint32_t b, bool end) {
-    const uint4 inf = *reinterpret_cast<const uint4 *>(smem + info_off + b * 16u);
+// LDS by absolute 32-bit address (the low half of the flat address of a __shared__ object is its LDS address): every address
+// the step selects between -- lookups, the zero word, DC sums, block info -- is kept ready-made, so that no base has to be
+// added behind a select
+typedef __attribute__((address_space(3))) uint32_t sr_lds_u32;
+typedef __attribute__((address_space(3))) int32_t sr_lds_i32;
+typedef uint32_t sr_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) sr_u32x4 sr_lds_u128;
+__device__ __forceinline__ uint32_t sr_lds_addr(const void *p) { return (uint32_t)reinterpret_cast<uintptr_t>(p); }
+__device__ __forceinline__ uint32_t sr_ld32(uint32_t a) { return *reinterpret_cast<const sr_lds_u32 *>((uintptr_t)a); }
+__device__ __forceinline__ uint4 sr_ld128(uint32_t a) {
+    const sr_u32x4 v = *reinterpret_cast<const sr_lds_u128 *>((uintptr_t)a);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void sr_st128(uint32_t a, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+    *reinterpret_cast<sr_lds_u128 *>((uintptr_t)a) = sr_u32x4{x, y, z, w};
+}
+__device__ __forceinline__ void sr_st32(uint32_t a, uint32_t v) { *reinterpret_cast<sr_lds_u32 *>((uintptr_t)a) = v; }
+
+// what a symbol does to the lane: position, zig-zag index, block end (next block's lookups and DC sum), DC sum
+__device__ __forceinline__ void sr_commit(SrLane &L, uint32_t info_off, uint32_t info_end, uint32_t dc_lane, uint32_t n, uint32_t adv, int32_t v) {
+    __hip_atomic_fetch_add(reinterpret_cast<sr_lds_i32 *>((uintptr_t)L.dcaddr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    L.pm1 += (int32_t)n;
+    const uint32_t k = L.k + adv;
+    const bool end = k >= 64u;
+    L.nblk += end ? 1u : 0u;
+    L.k = end ? 0u : k;
+    uint32_t ip = L.ip + (end ? 16u : 0u);
+    ip = ip == info_end ? info_off : ip;
+    L.ip = ip;
+    const uint4 inf = sr_ld128(ip);
     L.tabdc = end ? inf.x : L.tabdc;
     L.tabac = end ? inf.y : L.tabac;
     L.dcaddr = end ? dc_lane + inf.z : L.dcaddr;
 }
 
-// what a committed symbol does to the lane: position and stream words, zig-zag index, block end, DC sum
-__device__ __forceinline__ void sr_commit(SrLane &L, uint8_t *smem, uint32_t info_off, uint32_t dc_lane, uint32_t bpm, int32_t endsub_m1, int32_t np,
-                                          uint32_t adv, int32_t v, uint32_t nxt) {
-    __hip_atomic_fetch_add(reinterpret_cast<int32_t *>(smem + L.dcaddr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    uint32_t k = L.k + adv;
-    const bool end = k >= 64u;
-    L.nblk += end ? 1u : 0u;
-    L.k = end ? 0u : k;
-    uint32_t b = L.b + (end ? 1u : 0u);
-    b = b == bpm ? 0u : b;
-    L.b = b;
-    sr_block_info(L, smem, info_off, dc_lane, b, end);
-    const bool step = ((uint32_t)(np ^ L.pm1) >> 5) != 0;
-    L.pm1 = np;
-    L.w0 = step ? L.w1 : L.w0;
-    L.w1 = step ? L.w2 : L.w1;
-    L.w2 = step ? nxt : L.w2;
-    L.limm = np >= endsub_m1 ? kSrParked : L.limm;  // the subsequence's end passed: the lane is finished
+__device__ __forceinline__ uint32_t sr_peek(const SrLane &L, uint32_t ring_off) {
+    const sr_lds_u32 *p = reinterpret_cast<const sr_lds_u32 *>((uintptr_t)(ring_off + __builtin_amdgcn_ubfe((uint32_t)L.pm1, 5, 3) * 4u));
+    return __builtin_amdgcn_alignbit(p[0], p[1], ~(uint32_t)L.pm1);
 }
 
-// One fast step for every lane.  Returns "this lane could not commit" (it stands where it stood).
+// One fast step for every lane.  Returns the entry it committed (0: the lane stands where it stood).
 template <int LB>
-__device__ __forceinline__ bool sr_step(SrLane &L, uint8_t *smem, uint32_t ring_off, uint32_t info_off, uint32_t dc_lane, uint32_t bpm,
-                                        int32_t endsub_m1) {
-    const uint32_t nxt = *reinterpret_cast<const uint32_t *>(smem + ring_off + __builtin_amdgcn_ubfe((uint32_t)(L.pm1 + 96), 5, 3) * 4u);
-    const uint32_t hi = __builtin_amdgcn_alignbit(L.w0, L.w1, ~(uint32_t)L.pm1);
+__device__ __forceinline__ uint32_t sr_step(SrLane &L, uint32_t ring_off, uint32_t info_off, uint32_t info_end, uint32_t dc_lane, uint32_t zero_addr) {
+    const uint32_t hi = sr_peek(L, ring_off);
     const uint32_t tab = L.k == 0 ? L.tabdc : L.tabac;
-    const uint32_t e = *reinterpret_cast<const uint32_t *>(smem + tab + (hi >> (32 - LB)) * 4u);
-    int32_t np = L.pm1 + (int32_t)(e & 63u);
-    // flagged entry (bit 15 -> sign) or the symbol's last bit beyond the limit: one signed test
-    const bool slow = (int32_t)((e << 16) | (uint32_t)(L.limm - np)) < 0;
-    const uint32_t ee = slow ? 0u : e;
-    np = slow ? L.pm1 : np;
-    sr_commit(L, smem, info_off, dc_lane, bpm, endsub_m1, np, __builtin_amdgcn_ubfe(ee, 6, 7), (int32_t)ee >> 16, nxt);
-    return slow;
+    uint32_t la = tab + (hi >> (32 - LB)) * 4u;
+    la = L.pm1 < L.slim ? la : zero_addr;
+    const uint32_t e = sr_ld32(la);
+    sr_commit(L, info_off, info_end, dc_lane, e & 63u, __builtin_amdgcn_ubfe(e, 6, 7), (int32_t)e >> 16);
+    return e;
 }
 
-// the prefetched 16 bytes go to the ring (slot wrw & 7: the words it replaces are behind the lane's registers), the next
-// ones are requested; the limit follows
-__device__ __forceinline__ void sr_topup(SrLane &L, uint8_t *smem, uint32_t ring_off, int32_t endpos) {
-    uint32_t *rp = reinterpret_cast<uint32_t *>(smem + ring_off + (L.wrw & 4u) * 4u);
-    rp[0] = __builtin_bswap32(L.nx.x);
-    rp[1] = __builtin_bswap32(L.nx.y);
-    rp[2] = __builtin_bswap32(L.nx.z);
-    rp[3] = __builtin_bswap32(L.nx.w);
+__device__ __forceinline__ int32_t sr_limit(uint32_t wrw, int32_t endsub, int32_t endpos) {
+    // pos = pm1 + 1 <= min(endsub - 1, ring - 64, data - 32): the symbol starts inside the subsequence; whatever it is (at most
+    // 32 bits) it ends inside the data, and the 32 bits behind it -- the next step's peek -- are inside the ring
+    int32_t s = endsub - 1;
+    const int32_t r = (int32_t)(wrw * 32u) - 64, d = endpos - 32;
+    s = s < r ? s : r;
+    return s < d ? s : d;
+}
+
+// the prefetched 16 bytes go to the ring (slot wrw & 7: the words they replace lie in front of the lane's position), the next
+// ones are requested
+__device__ __forceinline__ void sr_topup(SrLane &L, uint32_t ring_off) {
+    const uint32_t w0 = __builtin_bswap32(L.nx.x);
+    const uint32_t at = ring_off + (L.wrw & 4u) * 4u;
+    sr_st32(at, w0);
+    sr_st32(at + 4, __builtin_bswap32(L.nx.y));
+    sr_st32(at + 8, __builtin_bswap32(L.nx.z));
+    sr_st32(at + 12, __builtin_bswap32(L.nx.w));
+    if ((L.wrw & 4u) == 0) sr_st32(ring_off + 32, w0);
     L.wrw += 4;
     __builtin_memcpy(&L.nx, L.gp, 16);
     L.gp += 16;
-    const int32_t loaded = (int32_t)(L.wrw * 32u) - 96;  // a position up to here leaves the next step's ring read inside the ring
-    L.limm = (endpos < loaded ? endpos : loaded) - 1;
 }
 
-// Exact path for a lane the fast step could not serve: DecodeHuffmanCode + ReceiveAndExtend lengths with the reference's
-// "bits available" rules, the same decisions as ub_symbol (ref: JpegHuffmanDecodingTable.cs:73-113,
-// ScanDecoder/JpegHuffmanScanDecoder.cs:81-115).  Commits the symbol, or finishes the lane (bad = 1: invalid code / the data
-// ends inside the symbol).
+// Exact path for a lane that stands: the end of its subsequence or of the data (finished), a ring that wants its top-up, or a
+// symbol the lookup does not decide -- DecodeHuffmanCode + ReceiveAndExtend lengths with the reference's "bits available"
+// rules, the same decisions as ub_symbol (ref: JpegHuffmanDecodingTable.cs:73-113, ScanDecoder/JpegHuffmanScanDecoder.cs:81-115).
+// Commits the symbol, or finishes the lane (bad = 1: invalid code / the data ends inside the symbol).
 template <int LB>
-__device__ __forceinline__ void sr_service(SrLane &L, uint8_t *smem, uint32_t ring_off, uint32_t info_off, uint32_t dc_lane, uint32_t small_off,
-                                           uint32_t bpm, int32_t endsub_m1, int32_t endpos, uint32_t &bad) {
+__device__ __forceinline__ void sr_service(SrLane &L, const uint8_t *smem, uint32_t lut0, uint32_t ring_off, uint32_t info_off, uint32_t info_end,
+                                           uint32_t dc_lane, uint32_t small_off, const uint8_t *lut_pool, const uint32_t *pool_off, int32_t endsub,
+                                           int32_t endpos, uint32_t &bad) {
     const int32_t pos = L.pm1 + 1;
-    if (pos >= endpos) {  // no data bit left: the loop's other exit (not a failure)
-        L.limm = kSrParked;
+    if (pos >= endsub || pos >= endpos) {  // the loop's two exits: the subsequence's end passed / no data bit left (not a failure)
+        L.slim = kSrParked;
         return;
     }
     const int32_t q = L.pm1 >> 5;
-    while ((int32_t)L.wrw <= q + 7) {  // the ring as full as it gets (at most three chunks behind)
-        sr_topup(L, smem, ring_off, endpos);
-    }
-    const uint32_t nxt = *reinterpret_cast<const uint32_t *>(smem + ring_off + __builtin_amdgcn_ubfe((uint32_t)(L.pm1 + 96), 5, 3) * 4u);
-    const uint32_t hi = __builtin_amdgcn_alignbit(L.w0, L.w1, ~(uint32_t)L.pm1);
-    const int32_t rem = endpos - pos;
+    while ((int32_t)L.wrw <= q + 4) sr_topup(L, ring_off);  // the ring as full as it gets
+    L.slim = sr_limit(L.wrw, endsub, endpos);
+    const uint32_t hi = sr_peek(L, ring_off);
     const bool is_dc = L.k == 0;
     const uint32_t tab = is_dc ? L.tabdc : L.tabac;
-    const uint32_t e = *reinterpret_cast<const uint32_t *>(smem + tab + (hi >> (32 - LB)) * 4u);
+    const uint32_t e = sr_ld32(tab + (hi >> (32 - LB)) * 4u);
+    const int32_t rem = endpos - pos;
+    if ((e & 63u) != 0 && L.pm1 < L.slim) return;  // it was the ring: the next fast step takes it
     uint32_t n, adv;
-    int32_t v = 0;
-    if (e & kSrFlag) {
-        uint32_t size = 0, cat = 0;
-        adv = 0;
-        if ((e & 0x6000u) == (kSrBadCat & 0x6000u)) {
+    int32_t v;
+    if ((e & 63u) != 0) {  // decided by the lookup, but inside the last 32 bits of the data
+        n = e & 63u;
+        adv = __builtin_amdgcn_ubfe(e, 6, 7);
+        v = (int32_t)e >> 16;
+    } else {
+        const uint32_t sl = (tab - lut0) >> (LB + 2);
+        const uint32_t code16 = hi >> 16;
+        uint32_t size, cat;
+        if (e == kSrStandBadCat) {  // categories above 16 are outside the verified envelope
             bad = 1;
-        } else if ((e & 0x6000u) == (kSrDcWide & 0x6000u)) {
-            size = e & 63u;
-            cat = __builtin_amdgcn_ubfe(e, 6, 7);
+            L.slim = kSrParked;
+            return;
+        }
+        adv = 1;
+        if (e == kSrStandDcWide) {
+            // the code has at most LB bits: its length and category are in the pooled first level (global memory: a DC difference
+            // of 2^(LB - code length) and more, once in a while)
+            const uint32_t e11 = reinterpret_cast<const uint16_t *>(lut_pool + pool_off[sl])[code16 >> (16 - kLutPoolBits)];
+            cat = (e11 >> 6) & 31u;
+            size = (e11 & 63u) - cat;
         } else {
-            const uint8_t *sm = smem + small_off + (tab >> (LB + 2)) * kK2SmallBytes;
+            const uint8_t *sm = smem + small_off + sl * kK2SmallBytes;
             const uint16_t *maxcode = reinterpret_cast<const uint16_t *>(sm);
-            const uint32_t code16 = hi >> 16;
             size = LB + 1;
             while (code16 > maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
             if (size > 16) {
                 bad = 1;
-            } else {
-                const uint32_t sym = sm[56 + ((sm[36 + size] + (code16 >> (16 - size))) & 0xFF)];
-                cat = is_dc ? sym : (sym & 15u);
-                adv = (sym & 15u) ? (sym >> 4) + 1u : ((sym >> 4) ? 16u : 64u);
-                if (cat > 16u) bad = 1;
+                L.slim = kSrParked;
+                return;
             }
-        }
-        if (bad) {
-            L.limm = kSrParked;
-            return;
+            const uint32_t sym = sm[56 + ((sm[36 + size] + (code16 >> (16 - size))) & 0xFF)];
+            cat = is_dc ? sym : (sym & 15u);
+            if (cat > 16u) {
+                bad = 1;
+                L.slim = kSrParked;
+                return;
+            }
+            if (!is_dc) adv = (sym & 15u) ? (sym >> 4) + 1u : ((sym >> 4) ? 16u : 64u);
         }
         n = size + cat;
-        if (is_dc) {
-            adv = 1;
-            if ((int32_t)n <= rem) {
-                const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - n, cat);
-                v = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));  // Extend(v, nbits)
-            }
+        v = 0;
+        if (is_dc && (int32_t)n <= rem) {
+            const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - n, cat);
+            v = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));  // Extend(v, nbits)
         }
-    } else {  // decided by the lookup; it was the limit that held it back
-        n = e & 63u;
-        adv = __builtin_amdgcn_ubfe(e, 6, 7);
-        v = (int32_t)e >> 16;
     }
     if ((int32_t)n > rem) {  // the data ends inside the symbol: nothing after it can be right
         bad = 1;
-        L.limm = kSrParked;
+        L.slim = kSrParked;
         return;
     }
-    sr_commit(L, smem, info_off, dc_lane, bpm, endsub_m1, L.pm1 + (int32_t)n, adv, v, nxt);
+    sr_commit(L, info_off, info_end, dc_lane, n, adv, v);
 }
 
 // lookups of the round kernel out of the pooled 11-bit ones (lut_pool_kernel): entry i of an LB-bit lookup covers pooled
-// prefixes i << (11 - LB) ..; it is decided when the code has at most LB bits
+// prefixes i << (11 - LB) ..; it is decided when the code has at most LB bits (and, for a DC symbol, the magnitude fits too)
 template <int LB>
-__device__ __forceinline__ uint32_t sr_entry(const uint32_t *src, uint32_t i, bool is_dc) {
-    const uint32_t e = src[i << (kLutPoolBits - LB)];
-    if (e == kK2BadCategory) {  // (the pooled entry does not say how long the code is: every pooled prefix under i must agree)
+__device__ __forceinline__ uint32_t sr_entry(const uint16_t *l1, uint32_t i, bool is_dc) {
+    const uint32_t e = l1[i << (kLutPoolBits - LB)];
+    if (e == 0) return kSrStandMiss;
+    if (is_dc && (e & kK2BadCat) != 0) {  // (the pooled entry does not say how long the code is: every pooled prefix under i must agree)
         for (uint32_t j = 1; j < (1u << (kLutPoolBits - LB)); j++)
-            if (src[(i << (kLutPoolBits - LB)) + j] != kK2BadCategory) return kSrMiss;
-        return kSrBadCat;
+            if ((l1[(i << (kLutPoolBits - LB)) + j] & kK2BadCat) == 0) return kSrStandMiss;
+        return kSrStandBadCat;
     }
-    const uint32_t n = e & 0xFFu, size = (e >> 8) & 0xFFu, cat = (e >> 16) & 0xFFu, adv2 = e >> 24;
-    if ((e & 0x80000000u) || size > (uint32_t)LB) return kSrMiss;
+    const uint32_t n = e & 63u, cat = is_dc ? ((e >> 6) & 31u) : (e >> 12);
+    if (n - cat > (uint32_t)LB) return kSrStandMiss;
     if (is_dc) {
-        if (n > (uint32_t)LB) return kSrDcWide | size | (cat << 6);
+        if (n > (uint32_t)LB) return kSrStandDcWide;
         const int32_t raw = (int32_t)((i >> (LB - n)) & ((1u << cat) - 1u));
         const int32_t v = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));
         return n | (1u << 6) | ((uint32_t)v << 16);
     }
-    return n | ((adv2 == 127u ? 64u : adv2 >> 1) << 6);
+    const uint32_t adv = (e >> 6) & 63u;
+    return n | ((adv == 63u ? 64u : adv) << 6);
 }
 
 __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
                                                             const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
                                                             const DevScanStatus *__restrict__ status, const DevHuffTable *__restrict__ huff_pool,
-                                                            const uint32_t *__restrict__ lut_pool,
+                                                            const uint8_t *__restrict__ lut_pool,
                                                             const uint32_t *__restrict__ exit_in, uint32_t *__restrict__ exit_out,
                                                             uint32_t *__restrict__ nblk_out, uint32_t *__restrict__ entry_used,
                                                             int4 *__restrict__ dcsum_out, uint32_t *__restrict__ changed, int round,
@@ -3822,10 +3888,13 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
     constexpr int LB = kSrLutBits;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // LDS: lookups (n_slots << (LB + 2), at offset 0) | small arrays | block info [kMaxBlocksPerMcu] x 16 | rings | DC sums
+    // (small_off is relative to smem; info_off, rings_off, dcs_off and what derives from them are absolute LDS addresses)
+    const uint32_t lut0 = sr_lds_addr(smem);
     const uint32_t small_off = (uint32_t)n_slots << (LB + 2);
-    const uint32_t info_off = small_off + (uint32_t)n_slots * kK2SmallBytes;
+    const uint32_t info_off = lut0 + small_off + (uint32_t)n_slots * kK2SmallBytes;
     const uint32_t rings_off = info_off + kMaxBlocksPerMcu * 16u;
     const uint32_t dcs_off = rings_off + 256u * kSrRingStride;
+    uint32_t *pool_off = reinterpret_cast<uint32_t *>(smem + (dcs_off - lut0) + 256u * 16u);  // [kMaxHuffSlots]: byte offset of the slot's pooled image
     const HuffWork wk = work[blockIdx.x];  // first_interval holds the first subsequence of this workgroup
     const DevScan &s = scans[wk.scan];
     const DevScanStatus st = status[wk.scan];
@@ -3853,7 +3922,8 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
         if (pi == 0xFFFF) continue;
         bool is_dc = false;
         for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
-        const uint32_t *src = lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * (1u << kLutPoolBits);
+        const uint16_t *src = reinterpret_cast<const uint16_t *>(lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * kK2TabBytes);
+        if (tid == 0) pool_off[sl] = (uint32_t)(((size_t)pi * 2 + (is_dc ? 1 : 0)) * kK2TabBytes);
         uint32_t *dst = reinterpret_cast<uint32_t *>(smem) + ((size_t)sl << LB);
         for (uint32_t i = tid; i < (1u << LB); i += 256) dst[i] = sr_entry<LB>(src, i, is_dc);
         const uint4 *ssrc = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&huff_pool[pi]) + offsetof(DevHuffTable, maxcode));
@@ -3862,11 +3932,10 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
     }
     if (tid < kMaxBlocksPerMcu) {
         const uint32_t ci = s.blk_comp[tid];
-        *reinterpret_cast<uint4 *>(smem + info_off + tid * 16u) =
-            make_uint4((uint32_t)s.comp[ci].dc_slot << (LB + 2), (uint32_t)s.comp[ci].ac_slot << (LB + 2), (ci & 3u) * 4u, 0u);
+        sr_st128(info_off + tid * 16u, lut0 + ((uint32_t)s.comp[ci].dc_slot << (LB + 2)), lut0 + ((uint32_t)s.comp[ci].ac_slot << (LB + 2)), (ci & 3u) * 4u, 0u);
     }
     const uint32_t dc_lane = dcs_off + tid * 16u;
-    *reinterpret_cast<uint4 *>(smem + dc_lane) = make_uint4(0, 0, 0, 0);
+    sr_st128(dc_lane, 0, 0, 0, 0);
     __syncthreads();
     if (!need) return;
     // ROUND 0 IS A WARM-UP.  Its entry state is a guess for every lane but the first, so all it can deliver is a plausible
@@ -3889,13 +3958,15 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
     } else {
         SrLane L;
         const uint32_t ring_off = rings_off + tid * kSrRingStride;
+        const uint32_t info_end = info_off + bpm * 16u;
+        const uint32_t zero_addr = info_off + 12u;  // (the fourth word of a block-info entry)
         const uint32_t u0 = start_bit >> 3;
         const int32_t pm1_0 = (int32_t)((u0 & 3u) * 8u + (start_bit & 7u)) - 1;
         // (positions are relative to the lane's own start: the distance to the end of the data is only ever compared, so a
         // stream longer than 2^30 bits behind the lane may as well end there)
         const uint32_t left = total_bits - start_bit;
         const int32_t endpos = pm1_0 + 1 + (int32_t)(left < 0x3FFFFFFFu ? left : 0x3FFFFFFFu);
-        const int32_t endsub_m1 = pm1_0 + (int32_t)(end_bit - start_bit);
+        const int32_t endsub = pm1_0 + 1 + (int32_t)(end_bit - start_bit);
         {
             const uint8_t *g = udata + s.data_off + (u0 & ~3u);  // 4-byte aligned 16-byte loads; buffers are padded
             uint4 c0, c1;
@@ -3903,48 +3974,50 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
             __builtin_memcpy(&c1, g + 16, 16);
             __builtin_memcpy(&L.nx, g + 32, 16);
             L.gp = g + 48;
-            uint32_t *rp = reinterpret_cast<uint32_t *>(smem + ring_off);
-            rp[0] = __builtin_bswap32(c0.x);
-            rp[1] = __builtin_bswap32(c0.y);
-            rp[2] = __builtin_bswap32(c0.z);
-            rp[3] = __builtin_bswap32(c0.w);
-            rp[4] = __builtin_bswap32(c1.x);
-            rp[5] = __builtin_bswap32(c1.y);
-            rp[6] = __builtin_bswap32(c1.z);
-            rp[7] = __builtin_bswap32(c1.w);
+            const uint32_t w0 = __builtin_bswap32(c0.x);
+            sr_st32(ring_off, w0);
+            sr_st32(ring_off + 4, __builtin_bswap32(c0.y));
+            sr_st32(ring_off + 8, __builtin_bswap32(c0.z));
+            sr_st32(ring_off + 12, __builtin_bswap32(c0.w));
+            sr_st32(ring_off + 16, __builtin_bswap32(c1.x));
+            sr_st32(ring_off + 20, __builtin_bswap32(c1.y));
+            sr_st32(ring_off + 24, __builtin_bswap32(c1.z));
+            sr_st32(ring_off + 28, __builtin_bswap32(c1.w));
+            sr_st32(ring_off + 32, w0);
             L.wrw = 8;
-            const int32_t q = pm1_0 >> 5;  // -1 or 0 (w0 of q = -1 is never looked at: the shift is 0 then)
-            L.w0 = rp[q & 7];
-            L.w1 = rp[(q + 1) & 7];
-            L.w2 = rp[(q + 2) & 7];
         }
         L.pm1 = pm1_0;
         L.k = (entry >> 11) & 127u;
-        L.b = (entry >> 6) & 31u;
+        L.ip = info_off + ((entry >> 6) & 31u) * 16u;
         L.nblk = 0;
+        L.slim = sr_limit(L.wrw, endsub, endpos);
         {
-            const int32_t loaded = (int32_t)(L.wrw * 32u) - 96;
-            L.limm = (endpos < loaded ? endpos : loaded) - 1;
+            const uint4 inf = sr_ld128(L.ip);
+            L.tabdc = inf.x;
+            L.tabac = inf.y;
+            L.dcaddr = dc_lane + inf.z;
         }
-        L.tabdc = L.tabac = 0;
-        L.dcaddr = dc_lane;
-        sr_block_info(L, smem, info_off, dc_lane, L.b, true);
         uint32_t bad = 0;
         for (;;) {
-            bool stuck = false;
+            uint32_t e = 0;
 #pragma unroll
-            for (int t = 0; t < kSrBurst; t++) stuck = sr_step<LB>(L, smem, ring_off, info_off, dc_lane, bpm, endsub_m1);
-            // a stuck lane repeats its step, so the last step of the burst says who is stuck; finished lanes are not served
-            stuck = stuck && L.limm != kSrParked;
-            if (stuck) sr_service<LB>(L, smem, ring_off, info_off, dc_lane, small_off, bpm, endsub_m1, endpos, bad);
-            if (L.limm != kSrParked && (int32_t)L.wrw <= (L.pm1 >> 5) + 7) sr_topup(L, smem, ring_off, endpos);
-            if (__ballot(L.limm != kSrParked) == 0) break;
+            for (int t = 0; t < kSrBurst; t++) e = sr_step<LB>(L, ring_off, info_off, info_end, dc_lane, zero_addr);
+            // a lane that stands repeats its step, so the last step of the burst says who stands; finished lanes are not served
+            if ((e & 63u) == 0 && L.slim != kSrParked)
+                sr_service<LB>(L, smem, lut0, ring_off, info_off, info_end, dc_lane, small_off, lut_pool, pool_off, endsub, endpos, bad);
+            if (L.slim != kSrParked && (int32_t)L.wrw <= (L.pm1 >> 5) + 4) {
+                sr_topup(L, ring_off);
+                L.slim = sr_limit(L.wrw, endsub, endpos);
+            }
+            if (__ballot(L.slim != kSrParked) == 0) break;
         }
-        const int32_t over = L.pm1 - endsub_m1;  // bits past the nominal end
-        ex = sub_pack(over > 0 ? (over < 63 ? (uint32_t)over : 63u) : 0u, L.b, L.k);
-        if (bad) ex = sub_pack(0, L.b, L.k) | kSubBad;
+        const int32_t over = L.pm1 + 1 - endsub;  // bits past the nominal end
+        const uint32_t b_exit = (L.ip - info_off) >> 4;
+        ex = sub_pack(over > 0 ? (over < 63 ? (uint32_t)over : 63u) : 0u, b_exit, L.k);
+        if (bad) ex = sub_pack(0, b_exit, L.k) | kSubBad;
         nblk = L.nblk;
-        dcs = *reinterpret_cast<const int4 *>(smem + dc_lane);
+        const uint4 dsum = sr_ld128(dc_lane);
+        dcs = make_int4((int)dsum.x, (int)dsum.y, (int)dsum.z, (int)dsum.w);
     }
     if (round == 0 || ex != exit_in[slot]) atomicOr(changed, 1u);
     exit_out[slot] = ex;
@@ -4011,28 +4084,26 @@ __global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__rest
 // K2's ring and symbol step with BLOCK-aligned ownership -- lanes at different blocks of their MCUs, so the tables were
 // picked per lane and a lock-step iteration mixed long luma with short chroma blocks: 8.3 ms.)
 constexpr int kSubFinalMaxWaves = 4;  // the launch picks subseq_final_waves(n_slots)
-constexpr int kSfLB = 10;
-constexpr uint32_t kSfTabBytes = (4u << kSfLB) + kK2SmallBytes;
 constexpr int kSfWaveBytes = kK2WaveBytes + 64 * 2 * (int)sizeof(uint32_t);  // K2's staging + rings, then (first MCU, count) per lane
 __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
                                                                            const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
                                                                            DevScanStatus *__restrict__ status,
                                                                            const DevHuffTable *__restrict__ huff_pool,
-                                                                           const uint32_t *__restrict__ lut_pool,
+                                                                           const uint8_t *__restrict__ lut_pool,
                                                                            const uint32_t *__restrict__ exit_state,
                                                                            const uint32_t *__restrict__ first_block,
                                                                            const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs,
                                                                            int n_slots) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t n_waves = blockDim.x >> 6;
-    uint8_t *tabs = smem;                                                    // n_slots * kSfTabBytes
-    uint8_t *wave_all = smem + (size_t)n_slots * kSfTabBytes;                // n_waves * kSfWaveBytes
+    uint8_t *tabs = smem;                                                    // n_slots * kK2TabBytes
+    uint8_t *wave_all = smem + (size_t)n_slots * kK2TabBytes;                // n_waves * kSfWaveBytes
     uint32_t *blk_info = reinterpret_cast<uint32_t *>(wave_all + n_waves * kSfWaveBytes);  // [kMaxBlocksPerMcu]
     const HuffWork wk = work[blockIdx.x];
     const DevScan &s = scans[wk.scan];
     const DevScanStatus st = status[wk.scan];
     if (st.n_ends == 0) return;
-    k2_stage_scan_tables<kSfLB>(s, huff_pool, lut_pool, tabs, blk_info, n_slots, blockDim.x);
+    k2_stage_scan_tables(s, lut_pool, tabs, blk_info, n_slots, blockDim.x);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t *stage = wave_all + wave * kSfWaveBytes;
     uint8_t *ring = stage + 8192 + lane * kK2RingStride;
@@ -4045,7 +4116,9 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
     __syncthreads();
     const uint32_t ulen = ends_u[s.ends_off];
     const uint32_t total_bits = ulen * 8;
-    const uint32_t sub = wk.first_interval + tid;
+    // a lane takes kSubFinalSubsPerLane consecutive subsequences: half the lanes, but half the parsed-not-stored blocks and a
+    // narrower spread of MCU counts inside a wave (the wave iterates to its largest)
+    const uint32_t sub = wk.first_interval + tid * (uint32_t)kSubFinalSubsPerLane;
     const uint32_t slot = s.sub_off + (sub < s.n_subs ? sub : 0);
     const uint32_t total_mcus = s.total_mcus;
     const uint32_t bpm = s.blocks_per_mcu;
@@ -4068,11 +4141,16 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
         const uint32_t at = first_block[slot];
         my_first = (at + (i2 != 0 ? 1u : 0u) + bpm - 1) / bpm;
         skip = my_first * bpm - at;  // block ends between the entry and that MCU (the first of them may be half a block away)
-        // ... up to the first one that starts at or behind the next lane's entry
-        if (sub + 1 < s.n_subs) {
-            const uint32_t ex = exit_state[slot];
-            if (!(ex & kSubBad)) my_end = (first_block[slot + 1] + ((((ex >> 11) & 127u) != 0) ? 1u : 0u) + bpm - 1) / bpm;
+        // ... up to the first one that starts at or behind the next lane's entry (a stream that failed or ran out inside this
+        // lane's subsequences leaves it everything that remains)
+        const uint32_t n_mine = s.n_subs - sub < (uint32_t)kSubFinalSubsPerLane ? s.n_subs - sub : (uint32_t)kSubFinalSubsPerLane;
+        bool open_end = sub + n_mine >= s.n_subs;
+        uint32_t ex = 0;
+        for (uint32_t q = 0; q < n_mine; q++) {
+            ex = exit_state[slot + q];
+            open_end |= (ex & kSubBad) != 0;
         }
+        if (!open_end) my_end = (first_block[slot + n_mine] + ((((ex >> 11) & 127u) != 0) ? 1u : 0u) + bpm - 1) / bpm;
         if (my_end > total_mcus) my_end = total_mcus;  // the reference stops after the last MCU
         if (my_first > my_end) my_first = my_end;
     }
@@ -4113,8 +4191,8 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
                 const bool is_dc = i2 == 0;
                 int32_t v;
                 uint32_t adv;
-                err = k2_symbol<kSfLB>(ring, feed, pos, endpos, lim, k2_tab<kSfLB>(tabs, is_dc ? ((info >> 8) & 0xFFu) : (info >> 16)), is_dc,
-                                       closed_by_marker, v, adv);
+                err = k2_symbol_any(ring, feed, pos, endpos, lim, k2_tab(tabs, is_dc ? ((info >> 8) & 0xFFu) : (info >> 16)), is_dc, closed_by_marker,
+                                    v, adv);
                 if (is_dc) {
                     const uint32_t ci = info & 0xFFu;
                     if (ci == 0) pred0 += v;
@@ -4145,14 +4223,14 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
         for (uint32_t b = 0; b < bpm; b++) {
             const uint32_t bi = __builtin_amdgcn_readfirstlane(blk_info[b]);  // wave-uniform
             const uint32_t ci = bi & 0xFFu;
-            const K2Tab hdc = k2_tab<kSfLB>(tabs, (bi >> 8) & 0xFFu);
-            const K2Tab hac = k2_tab<kSfLB>(tabs, bi >> 16);
+            const K2Tab hdc = k2_tab(tabs, (bi >> 8) & 0xFFu);
+            const K2Tab hac = k2_tab(tabs, bi >> 16);
             lim = k2_limit(endpos, feed.wr);
             if (j < count && err == 0) {
                 // ReadBlockBaseline (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:179-222)
                 int32_t v;
                 uint32_t adv = 0;
-                err = k2_symbol<kSfLB>(ring, feed, pos, endpos, lim, hdc, true, closed_by_marker, v, adv);
+                err = k2_symbol<true>(ring, feed, pos, endpos, lim, hdc, closed_by_marker, v, adv);
                 const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
                 v += pred;
                 if (ci == 0) pred0 = v;
@@ -4162,7 +4240,7 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
                 *reinterpret_cast<int16_t *>(my_stage + swz16) = (int16_t)v;  // zig-zag index 0
                 uint32_t k2i = err == 0 ? 2u : 128u;
                 while (k2i < 128u) {
-                    const uint32_t e2 = k2_symbol<kSfLB>(ring, feed, pos, endpos, lim, hac, false, closed_by_marker, v, adv);
+                    const uint32_t e2 = k2_symbol<false>(ring, feed, pos, endpos, lim, hac, closed_by_marker, v, adv);
                     err |= e2;
                     k2i += adv;
                     // Math.Min(i++, 63) for a coefficient; EOB / ZRL store a zero at a position nothing was written to yet
@@ -4822,10 +4900,10 @@ hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const De
 }
 
 // K2 lookup width: 11 bits when the scan stages at most 4 tables, 10 bits for up to 8 (LDS budget: 160 KB per CU)
-static size_t k2_lds_bytes(int n_slots, int lb) {
-    return (size_t)n_slots * ((4u << lb) + kK2SmallBytes) + (size_t)kHuffWaves * kK2WaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
+static size_t k2_lds_bytes(int n_slots, int waves) {
+    return (size_t)n_slots * kK2TabBytes + (size_t)waves * kK2WaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
 }
-size_t huffman_lds_bytes(int n_slots) { return k2_lds_bytes(n_slots, n_slots <= 4 ? 11 : 10); }
+size_t huffman_lds_bytes(int n_slots) { return k2_lds_bytes(n_slots, huffman_waves(n_slots)); }
 
 // More than 64 KB of dynamic LDS has to be allowed per kernel -- and per DEVICE: a process that drives several devices (one
 // jpgpu_ctx each) must do it on each of them.  done: one bit per device ordinal.
@@ -4841,30 +4919,31 @@ static hipError_t allow_dynamic_lds(const void *kernel, int bytes, std::atomic<u
     return hipSuccess;
 }
 
-template <int LB>
-static hipError_t launch_huffman_lb(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
-                                    const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
-                                    int n_slots, const uint32_t *lut_pool) {
-    const size_t lds = k2_lds_bytes(n_slots, LB);
+template <int WAVES>
+static hipError_t launch_huffman_w(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
+                                   const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
+                                   int n_slots, const uint8_t *lut_pool) {
+    const size_t lds = k2_lds_bytes(n_slots, WAVES);
     static std::atomic<uint64_t> configured{0};
-    const hipError_t ea = allow_dynamic_lds(reinterpret_cast<const void *>(&huffman_decode_kernel<kHuffWaves, LB>),
-                                            (int)k2_lds_bytes(LB == 11 ? 4 : kMaxHuffSlots, LB), configured);
+    const hipError_t ea = allow_dynamic_lds(reinterpret_cast<const void *>(&huffman_decode_kernel<WAVES>), 160 * 1024, configured);
     if (ea != hipSuccess) return ea;
-    hipLaunchKernelGGL((huffman_decode_kernel<kHuffWaves, LB>), dim3(n_work), dim3(64 * kHuffWaves), lds, stream, data, scans, work,
-                       ends, status, huff_pool, coefs, n_slots, lut_pool);
+    hipLaunchKernelGGL((huffman_decode_kernel<WAVES>), dim3(n_work), dim3(64 * WAVES), lds, stream, data, scans, work, ends, status, huff_pool, coefs,
+                       n_slots, lut_pool);
     return hipGetLastError();
 }
 
+// `work` holds one entry per huffman_waves(n_slots) * 64 restart intervals (DeviceBatch builds it with the same function)
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                           const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
-                          int n_slots, const uint32_t *lut_pool) {
+                          int n_slots, const uint8_t *lut_pool) {
     if (n_work <= 0) return hipSuccess;
-    if (n_slots <= 4) return launch_huffman_lb<11>(stream, data, scans, work, n_work, ends, status, huff_pool, coefs, n_slots, lut_pool);
-    return launch_huffman_lb<10>(stream, data, scans, work, n_work, ends, status, huff_pool, coefs, n_slots, lut_pool);
+    if (huffman_waves(n_slots) == kHuffWaves)
+        return launch_huffman_w<kHuffWaves>(stream, data, scans, work, n_work, ends, status, huff_pool, coefs, n_slots, lut_pool);
+    return launch_huffman_w<kHuffWavesManyTables>(stream, data, scans, work, n_work, ends, status, huff_pool, coefs, n_slots, lut_pool);
 }
 
 // Fused lookups of every table of the pool (once per upload: the tables of a batch do not change between decodes).
-hipError_t launch_lut_pool(hipStream_t stream, const DevHuffTable *huff_pool, int n_tables, uint32_t *lut_pool) {
+hipError_t launch_lut_pool(hipStream_t stream, const DevHuffTable *huff_pool, int n_tables, uint8_t *lut_pool) {
     if (n_tables <= 0) return hipSuccess;
     hipLaunchKernelGGL(lut_pool_kernel, dim3(2 * n_tables), dim3(256), 0, stream, huff_pool, lut_pool);
     return hipGetLastError();
@@ -4994,10 +5073,11 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
                               const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                               const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                               uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int n_slots, int max_rounds,
-                              int *rounds_used, const uint32_t *lut_pool, const uint32_t **final_state_out) {
+                              int *rounds_used, const uint8_t *lut_pool, const uint32_t **final_state_out) {
     *final_state_out = exit_a;
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
-    const size_t lds_round = ((size_t)n_slots << (kSrLutBits + 2)) + (size_t)n_slots * kK2SmallBytes + kMaxBlocksPerMcu * 16 + 256 * (kSrRingStride + 16);
+    const size_t lds_round = ((size_t)n_slots << (kSrLutBits + 2)) + (size_t)n_slots * kK2SmallBytes + kMaxBlocksPerMcu * 16 + 256 * (kSrRingStride + 16) +
+                             kMaxHuffSlots * sizeof(uint32_t);
 
     static const uint32_t warm_bits = [] {  // bits of a subsequence round 0 decodes (0 = all of it); see subseq_round_kernel
         const char *ev = getenv("JPGPU_SUBSEQ_WARM_BITS");
@@ -5042,7 +5122,7 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
-                                int max_rounds, int *rounds_used, const uint32_t *lut_pool, const HuffWork *final_work, int n_final_work) {
+                                int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work) {
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const uint32_t *final_state = nullptr;
     hipError_t e = launch_subseq_sync(stream, udata, scans, work, n_work, scan_ids, n_scans, ends_u, status, huff_pool, exit_a, exit_b, nblk,
@@ -5050,7 +5130,7 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                       &final_state);
     if (e != hipSuccess) return e;
     const int waves = subseq_final_waves(n_slots);
-    const size_t lds_final = (size_t)n_slots * kSfTabBytes + (size_t)waves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
+    const size_t lds_final = (size_t)n_slots * kK2TabBytes + (size_t)waves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
     static std::atomic<uint64_t> configured{0};
     const hipError_t ea = allow_dynamic_lds(reinterpret_cast<const void *>(&subseq_final_kernel), 160 * 1024, configured);
     if (ea != hipSuccess) return ea;

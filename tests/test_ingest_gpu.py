@@ -273,6 +273,31 @@ def test_bench_runs_its_rccl_path_under_torchrun_with_one_rank():
     assert out["host"]["ingest_pinned"]["n_pinned_dma"] >= 1 and out["host"]["gen_s_per_rank"] and out["roofline"]["read_frac_planar"] > 0
 
 
+def test_bench_rehearses_a_two_rank_launch_on_one_device():
+    """No 8-GPU node has ever run bench.py's world > 1 branch.  The rehearsal mode (--dist-backend gloo) runs exactly that branch
+    with two ranks that share the one device there is: input generation and ingest crews at granted // world threads, the
+    barrier / MAX-reduce around the timed region, the slowest-rank ingest figures, the CPU baseline on rank 0 with rank 1 parked
+    in the host barrier, one JSON line from rank 0 with the whole-job aggregate."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--workload", "1080p_q90", "--images", "8", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the line"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak" and "rehearsal" in out
+    assert out["config"]["images_per_gpu"] == 8 and out["parity_spot_check"] == "bit-exact vs oracle"
+    assert len(out["host"]["gen_s_per_rank"]) == 2 and out["host"]["gen_threads_per_rank"] == max(1, out["host"]["granted_cpus"] // 2)
+    assert out["cpu_baseline"]["value"] > 0 and out["value_ingest_inclusive"] > 0 and out["value_ingest_inclusive_pinned"] > 0
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["read_frac_planar"] > 0
+
+
 def test_multi_device_driver_shards_round_robin_and_matches_the_oracle():
     """jpgpu_multi_*: the in-library driver of SURVEY 8e.  One MI355X here, so the device is listed three times (three
     independent contexts, three host threads uploading and decoding at once): image i lands on slot i mod 3 at local index

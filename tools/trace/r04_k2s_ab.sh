@@ -14,6 +14,6 @@ i=0
 for FLAGS in "$@"; do
   i=$((i+1))
   echo "== variant $i: $FLAGS"
-  rm -rf /tmp/ab$i && cp -r $R /tmp/ab$i && ( cd /tmp/ab$i/jpeglibrary_amd/csrc && touch kernels.hip && make -s CXXFLAGS="-O3 -std=c++17 -fPIC -Wno-unused-parameter -ffp-contract=off -fno-fast-math $FLAGS" > /tmp/ab$i/build.log 2>&1 ) || { tail -5 /tmp/ab$i/build.log; continue; }
+  rm -rf /tmp/ab$i && cp -r $R /tmp/ab$i && ( cd /tmp/ab$i/jpeglibrary_amd/csrc && touch *.hip *.cpp && make -s -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -Wno-unused-parameter -ffp-contract=off -fno-fast-math $FLAGS" > /tmp/ab$i/build.log 2>&1 ) || { tail -5 /tmp/ab$i/build.log; continue; }
   run v$i /tmp/ab$i
 done
