@@ -215,7 +215,8 @@ class DeviceBatch {
 
     // DRI = 0 scans: self-synchronising subsequence decode (K2S)
     DevBuffer d_lut_pool_;  // fused lookups of every pool table (K2S round kernel)
-    DevBuffer d_sub_work_, d_sub_scan_ids_, d_sub_exit_a_, d_sub_exit_b_, d_sub_nblk_, d_sub_first_, d_sub_entry_, d_sub_dcsum_, d_sub_dcentry_, d_sub_changed_;
+    DevBuffer d_sub_work_, d_sub_scan_ids_, d_sub_exit_a_, d_sub_exit_b_, d_sub_nblk_, d_sub_first_, d_sub_entry_, d_sub_dcsum_, d_sub_dcentry_, d_sub_changed_, d_sub_same_;
+    bool sub_same_valid_ = false;  // d_sub_same_ holds the twins of this upload's subsequences (subseq_same_kernel)
     int n_sub_work_ = 0, n_sub_scans_ = 0, n_sub_final_work_ = 0;
     DevBuffer d_sub_final_work_;
     uint32_t total_subs_ = 0, max_subs_per_scan_ = 0;

@@ -46,7 +46,8 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
-                                int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work);
+                                int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work,
+                                uint32_t *same_dist, bool *same_valid);
 // waves (of 64 subsequences) per workgroup of the K2S final pass.  4 = two workgroups per CU; one workgroup of 10 waves (K2's
 // shape, 25 % more waves per CU) was measured slower: 21.1 vs 19.6 ms K2S per 1024 x 4K -- a workgroup waits for its slowest wave
 constexpr int subseq_final_waves(int n_slots) { return n_slots <= 8 ? 4 : 4; }
@@ -89,7 +90,8 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
                               const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                               const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                               uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int n_slots, int max_rounds,
-                              int *rounds_used, const uint8_t *lut_pool, const uint32_t **final_state_out);
+                              int *rounds_used, const uint8_t *lut_pool, const uint32_t **final_state_out, uint32_t *same_dist, bool *same_valid);
+// (same_dist: one uint32 per subsequence, *same_valid: "filled for this upload" -- the flat-region twins, kernels.hip)
 hipError_t launch_subseq_transcode(hipStream_t stream, int mode, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                                    const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, const uint32_t *exit_state,
                                    const uint32_t *first_block, uint32_t *hist, const EncHuffTable *enc, uint32_t *sub_bits,

@@ -4027,6 +4027,131 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
 // (Earlier forms: the word reader with the symbol step as per-lane branches, 1.9 ms per round on average at 1024 x 4K; K2's
 // 68-byte ring with a top-up per block, round 2: 2.45 ms -- the rings halved the occupancy; the word reader with its refill load
 // issued by hand, round 3: 1.55 ms.)
+// ---- Flat regions.  Self-synchronisation lives on the randomness of the data: a constant region of the image is the same
+// few bits over and over (a black 4:2:0 MCU under the standard tables is 32 bits: 00 1010 x 4, 00 00 x 2), a decoder that enters
+// it with the wrong state parses it in a wrong but self-consistent way for ever, and the right state only advances one
+// subsequence per round from the region's left edge.  The reference's OWN benchmark input (DecoderBenchmark.cs: three quarters
+// of an 8192 x 8192 canvas are black) took 4 107 rounds, 281 ms per image.
+// What such a region offers instead: subsequence i has exactly the bits of subsequence i - m (m * length = a multiple of the
+// period), and a decoder is a function of (bits, entry state) -- so once subsequence i - m has been decoded from state s, the
+// answer for subsequence i entered in state s is known without decoding: exit, block count and DC sums are those of i - m.
+//   subseq_same_kernel       (once per upload, when a batch has not converged after a few rounds) finds for every subsequence
+//                            the smallest m <= 64 with identical bits (the subsequence itself + the 128 bits behind it that a
+//                            decode of it can look at), by comparison, not by hash;
+//   subseq_propagate_kernel  walks a scan's subsequences once, in order, one wave per scan: where the predecessor's exit is
+//                            not the state a subsequence was last decoded from, but IS the state its twin i - m was decoded
+//                            from, the twin's results are copied.  Every statement it writes down is a true statement about the
+//                            decoder ("entered like this, it leaves like that"), so the rounds and it can alternate freely;
+//                            in a flat region the states repeat with period m, and the whole region resolves in one walk
+//                            once its first m subsequences have been decoded from the right state.
+__global__ __launch_bounds__(256) void subseq_same_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+                                                          const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
+                                                          const DevScanStatus *__restrict__ status, uint32_t *__restrict__ same_dist) {
+    const HuffWork wk = work[blockIdx.x];  // (the rounds' work list: 256 subsequences per entry)
+    const DevScan &s = scans[wk.scan];
+    if (status[wk.scan].n_ends == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t total_bits = ends_u[s.ends_off] * 8u;
+    const uint32_t sub_bytes = (1u << s.sub_shift) >> 3, n_words = sub_bytes / 4u + 4u;
+    const uint8_t *base = udata + s.data_off;
+    for (uint32_t q = wave; q < 256u; q += 4u) {
+        const uint32_t sub = wk.first_interval + q;
+        if (sub >= s.n_subs) break;
+        uint32_t result = 0;
+        // (a subsequence near the end of the data also depends on where the data ends: no twin for it)
+        if ((uint64_t)(sub + 1u) * sub_bytes * 8u + 128u <= total_bits) {
+            const uint8_t *mine = base + (size_t)sub * sub_bytes;
+            uint32_t w0, wc = 0;
+            __builtin_memcpy(&w0, mine, 4);
+            const uint32_t m_lane = lane + 1u;
+            if (m_lane <= sub) __builtin_memcpy(&wc, mine - (size_t)m_lane * sub_bytes, 4);
+            uint64_t cand = __ballot(m_lane <= sub && wc == w0);
+            while (cand != 0) {
+                const uint32_t m = (uint32_t)__builtin_ctzll(cand) + 1u;
+                const uint8_t *twin = mine - (size_t)m * sub_bytes;
+                bool diff = false;
+                for (uint32_t t = lane; t < n_words; t += 64u) {
+                    uint32_t a, b;
+                    __builtin_memcpy(&a, mine + t * 4u, 4);
+                    __builtin_memcpy(&b, twin + t * 4u, 4);
+                    diff |= a != b;
+                }
+                if (__ballot(diff) == 0) {
+                    result = m;
+                    break;
+                }
+                cand &= cand - 1;
+            }
+        }
+        if (lane == 0) same_dist[s.sub_off + sub] = result;
+    }
+}
+
+// one wave per scan; exit = the buffer the last round wrote
+__global__ __launch_bounds__(64) void subseq_propagate_kernel(const DevScan *__restrict__ scans, const uint32_t *__restrict__ scan_ids,
+                                                              const uint32_t *__restrict__ same_dist, uint32_t *__restrict__ exit_state,
+                                                              uint32_t *__restrict__ entry_used, uint32_t *__restrict__ nblk,
+                                                              int4 *__restrict__ dcsum, uint32_t *__restrict__ n_copied) {
+    const DevScan &s = scans[scan_ids[blockIdx.x]];
+    const uint32_t lane = threadIdx.x;
+    uint32_t e_prev = 0xFFFFFFFFu, x_prev = 0;  // the chunk before (lane l = subsequence base - 64 + l)
+    uint32_t copied = 0;
+    for (uint32_t base = 0; base < s.n_subs; base += 64u) {
+        const uint32_t sub = base + lane;
+        const bool in = sub < s.n_subs;
+        const uint32_t slot = s.sub_off + (in ? sub : 0u);
+        uint32_t e = in ? entry_used[slot] : 0xFFFFFFFFu, x = in ? exit_state[slot] : 0u;
+        const uint32_t d = in ? same_dist[slot] : 0u;
+        uint32_t src = 0;  // lane l: the twin whose results it takes (distance), 0 = none
+        // what the rounds give a subsequence as its entry: the predecessor's exit, or the start state behind a failed one
+        auto expected = [](uint32_t prev_exit) { return (prev_exit & kSubBad) ? 0u : prev_exit; };
+        // whole chunk consistent already?  (lane 0 against the previous chunk's last)
+        const uint32_t xl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 63u) & 63u) * 4u), (int)x);
+        const uint32_t before = lane == 0 ? lane_get(x_prev, 63) : xl;
+        const bool first = sub == 0;
+        if (__ballot(in && !first && e != expected(before)) != 0) {
+            const uint32_t n_here = s.n_subs - base < 64u ? s.n_subs - base : 64u;
+            for (uint32_t l = (base == 0 ? 1u : 0u); l < n_here; l++) {
+                const uint32_t want = expected(l == 0 ? lane_get(x_prev, 63) : lane_get(x, l - 1u));
+                if (lane_get(e, l) == want) continue;
+                const uint32_t m = lane_get(d, l);
+                if (m == 0) continue;
+                uint32_t te, tx;
+                if (m <= l) {
+                    te = lane_get(e, l - m);
+                    tx = lane_get(x, l - m);
+                } else {
+                    if (base == 0) continue;
+                    te = lane_get(e_prev, 64u + l - m);
+                    tx = lane_get(x_prev, 64u + l - m);
+                }
+                if (te != want) continue;
+                // a twin that took ITS results from a twin in this very chunk has not stored them yet: go to where they lie
+                const uint32_t via = m <= l ? lane_get(src, l - m) : 0u;
+                if (lane == l) {  // (uniform values, one lane's registers)
+                    e = want;
+                    x = tx;
+                    src = m + via;
+                }
+            }
+            const bool took = src != 0;
+            if (took) {
+                entry_used[slot] = e;
+                exit_state[slot] = x;
+                nblk[slot] = nblk[slot - src];
+                dcsum[slot] = dcsum[slot - src];
+            }
+            if (__ballot(took) != 0) {
+                copied += (uint32_t)__builtin_popcountll(__ballot(took));
+                __threadfence();  // the next chunks read what this one stored
+            }
+        }
+        e_prev = e;
+        x_prev = x;
+    }
+    if (lane == 0 && copied != 0) atomicAdd(n_copied, copied);
+}
+
 // Exclusive prefix sums over a scan's subsequences: first block and DC predictors at the entry of every subsequence.
 // One workgroup per scan.
 __global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__restrict__ scans, const uint32_t *__restrict__ scan_ids,
@@ -5073,7 +5198,8 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
                               const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                               const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                               uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int n_slots, int max_rounds,
-                              int *rounds_used, const uint8_t *lut_pool, const uint32_t **final_state_out) {
+                              int *rounds_used, const uint8_t *lut_pool, const uint32_t **final_state_out, uint32_t *same_dist,
+                              bool *same_valid) {
     *final_state_out = exit_a;
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const size_t lds_round = ((size_t)n_slots << (kSrLutBits + 2)) + (size_t)n_slots * kK2SmallBytes + kMaxBlocksPerMcu * 16 + 256 * (kSrRingStride + 16) +
@@ -5083,8 +5209,13 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
         const char *ev = getenv("JPGPU_SUBSEQ_WARM_BITS");
         return ev ? (uint32_t)atoi(ev) : 2048u;
     }();
+    static const int propagate_from = [] {  // rounds without convergence before the flat-region walk joins in (0 = never)
+        const char *ev = getenv("JPGPU_SUBSEQ_PROPAGATE_FROM");
+        return ev ? atoi(ev) : 7;  // (7: behind the third batch of three rounds -- a batch that converges in six never pays for it)
+    }();
     uint32_t *bufs[2] = {exit_a, exit_b};
-    // changed_dev[r] is set by round r; the host looks at the flags only every kCheckEvery rounds (one sync per check)
+    // changed_dev[r] is set by round r; the host looks at the flags only every kCheckEvery rounds (one sync per check);
+    // changed_dev[63] counts what the flat-region walks copied
     constexpr int kCheckEvery = 3;
     hipError_t e = hipMemsetAsync(changed_dev, 0, 64 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
@@ -5096,7 +5227,17 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
             const uint32_t *in = bufs[(round + 1) & 1];
             uint32_t *out = bufs[round & 1];
             hipLaunchKernelGGL(subseq_round_kernel, dim3(n_work), dim3(256), lds_round, stream, udata, scans, work, ends_u, status, huff_pool,
-                               lut_pool, in, out, nblk, entry_used, (int4 *)dcsum, changed_dev + (round & 63), round, n_slots, warm_bits);
+                               lut_pool, in, out, nblk, entry_used, (int4 *)dcsum, changed_dev + (round % 62), round, n_slots, warm_bits);
+        }
+        if (propagate_from > 0 && round >= propagate_from && same_dist != nullptr) {
+            // not converged by now (the previous check said so): flat regions?  Twins once per upload, then a walk behind every
+            // batch of rounds (it patches the buffer the last round wrote: the next round reads that one)
+            if (!*same_valid) {
+                hipLaunchKernelGGL(subseq_same_kernel, dim3(n_work), dim3(256), 0, stream, udata, scans, work, ends_u, status, same_dist);
+                *same_valid = true;
+            }
+            hipLaunchKernelGGL(subseq_propagate_kernel, dim3(n_scans), dim3(64), 0, stream, scans, scan_ids, same_dist, bufs[(round + 1) & 1], entry_used, nblk,
+                               (int4 *)dcsum, changed_dev + 63);
         }
         uint32_t flags[64];
         e = hipMemcpyAsync(flags, changed_dev, sizeof flags, hipMemcpyDeviceToHost, stream);
@@ -5105,7 +5246,7 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
         if (e != hipSuccess) return e;
         // converged as soon as one round (other than round 0) changed nothing: later rounds are then no-ops
         for (int r2 = batch_first; r2 < round; r2++)
-            if (r2 > 0 && flags[r2 & 63] == 0) converged = true;
+            if (r2 > 0 && flags[r2 % 62] == 0) converged = true;
         if (!converged) {
             e = hipMemsetAsync(changed_dev, 0, 64 * sizeof(uint32_t), stream);
             if (e != hipSuccess) return e;
@@ -5122,12 +5263,13 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
-                                int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work) {
+                                int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work,
+                                uint32_t *same_dist, bool *same_valid) {
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const uint32_t *final_state = nullptr;
     hipError_t e = launch_subseq_sync(stream, udata, scans, work, n_work, scan_ids, n_scans, ends_u, status, huff_pool, exit_a, exit_b, nblk,
                                       first_block, entry_used, dcsum, dc_entry, changed_dev, n_slots, max_rounds, rounds_used, lut_pool,
-                                      &final_state);
+                                      &final_state, same_dist, same_valid);
     if (e != hipSuccess) return e;
     const int waves = subseq_final_waves(n_slots);
     const size_t lds_final = (size_t)n_slots * kK2TabBytes + (size_t)waves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);

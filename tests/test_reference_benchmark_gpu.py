@@ -45,3 +45,33 @@ def test_a_batch_of_benchmark_canvases_beside_small_frames(canvas):
     for i, f in enumerate(files):
         assert b.result(i).status == 0, i
         assert np.array_equal(b.output(i), ref if f is canvas else po.decode_8bit(f)[0]), i
+
+
+@pytest.mark.parametrize("subsampling,optimize,mode", [("4:2:0", False, "RGB"), ("4:4:4", False, "RGB"), ("4:2:2", True, "RGB"), ("4:4:4", True, "L")])
+def test_flat_regions_do_not_cost_a_round_per_subsequence(subsampling, optimize, mode):
+    """A constant region is the same few bits over and over: nothing for a self-synchronising decoder to lock on to, so the
+    right state used to advance one subsequence per round (4 107 rounds on the benchmark canvas).  Twin subsequences (identical
+    bits, the same entry state: the same result without decoding) resolve such a region in one walk, whatever the period of the
+    flat MCU is against the subsequence length (32 bits for 4:2:0 under the standard tables, 14 for 4:4:4, other values under
+    optimised tables): bit-exact, and in a bounded number of rounds."""
+    import io
+
+    from PIL import Image
+
+    rng = np.random.default_rng(7)
+    px = np.full((1536, 2048, 3), (200, 30, 90), np.uint8)
+    px[:192, :320] = rng.integers(0, 256, (192, 320, 3), dtype=np.uint8)      # content, then a long flat stretch in every MCU row
+    px[700:760, 900:1500] = rng.integers(0, 256, (60, 600, 3), dtype=np.uint8)  # an island inside the flat region
+    img = Image.fromarray(px).convert(mode)
+    buf = io.BytesIO()
+    kw = {} if mode == "L" else {"subsampling": subsampling}
+    img.save(buf, format="JPEG", quality=75, optimize=optimize, **kw)
+    data = buf.getvalue()
+    fmt = jl.FMT_INTERLEAVED_U8
+    b = jl.Batch().upload([data], fmt).decode().sync()
+    assert b.result(0).status == 0
+    ref = po.decode_8bit(data)[0]
+    assert np.array_equal(b.output(0), ref)
+    assert b.subseq_rounds() <= 48, b.subseq_rounds()
+    # the optimizer's symbol transcode rides on the same synchronisation
+    assert jl.optimize_batch([data], strip=False)[0] == po.optimize(data, False)
