@@ -1592,9 +1592,9 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 __device__ __forceinline__ uint32_t lane_put(uint32_t old, uint32_t v, uint32_t l) {
-    // (no clang builtin for it in ROCm 7.2; gfx9 allows one SGPR on the constant bus: the lane select travels in M0)
-    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(v), "s"(l) : "m0");
-    return old;
+    // (no clang builtin for v_writelane in ROCm 7.2, and two scalar operands need M0 on gfx9; this runs once per long code:
+    // a compare and a select instead of hand-written M0 traffic)
+    return __lane_id() == l ? v : old;
 }
 
 // Scope of the release / acquire pair of the pipelined progressive launch: "agent" (buffer_wbl2 sc1 / buffer_inv sc1), what the
@@ -1858,139 +1858,6 @@ __device__ __forceinline__ uint32_t w_ac_refine_block(WBits &d, uint32_t lane, c
     }
     return 0;
 }
-// ---- the same two block decoders for the bulk of the stream (more than kPsFastBits left: nothing can run dry), written
-// for the scalar unit: a taken branch costs this one wave as much as ~8 instructions, so symbol classes are resolved with
-// selects, the sign / EOB-run / correction bits are cut from the symbol's own 32-bit peek whenever they fit, and the only
-// branches per symbol are the loop itself, the window rebuild and the rare cases (long code, wide correction field).
-__device__ __forceinline__ uint32_t w_ac_first_fast(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, uint32_t al,
-                                                    uint32_t &eobrun, int32_t &c, uint64_t &changed) {
-    uint32_t i = ss;
-    for (;;) {
-        if (d.cur > 63u) w_refresh<true>(d, lane, hac);
-        const uint32_t pk = lane_get(d.peek, d.cur);
-        uint32_t e = lane_get(d.ent, d.cur);
-        if ((e >> 8) == 0) {
-            e = w_huff_scalar(hac, pk >> 16);
-            if (e >= kPsBadCode) return kDetailInvalidHuffmanCode;
-        }
-        const uint32_t size = e >> 8, rr = (e >> 4) & 15u, sz = e & 15u;
-        const uint32_t rest = pk << size;  // the bits after the code: magnitude, or the EOB run's low bits
-        if (sz == 0 && rr != 15u) {
-            eobrun = (1u << rr) - 1u + (uint32_t)(((uint64_t)rest << rr) >> 32);  // rr = 0 reads nothing
-            d.pos += size + rr;
-            d.cur += size + rr;
-            return 0;
-        }
-        i += rr;
-        const int32_t v = (int32_t)(uint32_t)(((uint64_t)rest << sz) >> 32);  // sz = 0 (ZRL): 0
-        const int32_t value = v - ((((v + v) >> sz) - 1) & ((1 << sz) - 1));   // Extend(v, nbits)
-        const uint32_t at = i < 63u ? i : 63u;
-        if (sz != 0 && lane == at) c = (int32_t)((uint32_t)value << al);
-        changed |= (uint64_t)(sz != 0 ? 1u : 0u) << at;
-        d.pos += size + sz;
-        d.cur += size + sz;
-        if (++i > se) return 0;
-    }
-}
-
-__device__ __forceinline__ uint32_t w_ac_refine_fast(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, int32_t p1,
-                                                     int32_t m1, uint64_t band, uint64_t nz, uint32_t &eobrun, int32_t &c, bool &mine) {
-    const uint64_t zeros = ~nz & band, nzb = nz & band;
-    const uint32_t zrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(zeros >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)zeros, 0u));
-    const uint32_t nrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzb, 0u));
-    const bool was_nz = ((nzb >> lane) & 1ull) != 0;
-    uint32_t k = ss;
-    uint32_t below = 0;  // zeros of the band below k
-    uint32_t nbelow = 0; // non-zero coefficients of the band below k
-    if (eobrun == 0) {
-        for (;;) {
-            PS_COUNT(6);
-            if (d.cur > 63u) w_refresh<true>(d, lane, hac);
-            const uint32_t pk = lane_get(d.peek, d.cur);
-            uint32_t e = lane_get(d.ent, d.cur);
-            if ((e >> 8) == 0) {
-                e = w_huff_scalar(hac, pk >> 16);
-                if (e >= kPsBadCode) return kDetailInvalidHuffmanCode;
-            }
-            const uint32_t size = e >> 8, rr = (e >> 4) & 15u;
-            const uint32_t nonzero = (e & 15u) != 0 ? 1u : 0u;
-            if ((nonzero | (rr == 15u ? 1u : 0u)) == 0) {
-                eobrun = (1u << rr) + (uint32_t)(((uint64_t)(pk << size) << rr) >> 32);
-                d.pos += size + rr;
-                d.cur += size + rr;
-                break;
-            }
-            const uint32_t sign = (pk >> (31u - size)) & 1u;
-            uint32_t used = size + nonzero;
-            // the lane that is the (rr + 1)-th zero from k on; none = the run outlasts the band
-            const uint64_t hit = __ballot(zrank == below + rr) & zeros;
-            const bool found = hit != 0;
-            const uint32_t stop = found ? (uint32_t)__builtin_ctzll(hit) : se + 1u;
-            // non-zero coefficients in [k, stop): their correction bits follow, in order
-            const uint32_t count = found ? stop - k - rr : (uint32_t)__builtin_popcountll(nzb) - nbelow;
-            if (count != 0) {
-                const uint32_t r = nrank - nbelow;  // this lane's place in the field (when it is one of them)
-                if (used + count <= 32u) {
-                    const uint32_t field = (pk << used) >> (32u - count);
-                    used += count;
-                    if (was_nz && r < count && ((field >> (count - 1u - r)) & 1u) != 0 && (c & p1) == 0) {
-                        c += c >= 0 ? p1 : m1;
-                        mine = true;
-                    }
-                } else {
-                    d.pos += used;
-                    d.cur += used;
-                    used = 0;
-                    uint32_t taken = 0, left = count;
-                    while (left != 0) {
-                        const uint32_t n = left < 32u ? left : 32u;
-                        uint32_t field;
-                        w_read_bits<true, true>(d, lane, hac, n, field);
-                        const uint32_t rn = r - taken;
-                        if (was_nz && rn < n && ((field >> (n - 1u - rn)) & 1u) != 0 && (c & p1) == 0) {
-                            c += c >= 0 ? p1 : m1;
-                            mine = true;
-                        }
-                        taken += n;
-                        left -= n;
-                    }
-                }
-            }
-            d.pos += used;
-            d.cur += used;
-            if (nonzero != 0 && lane == stop) {  // stop = 64 (band to 63, run outlasts it): no lane
-                c = sign ? p1 : m1;
-                mine = true;
-            }
-            k = stop + 1u;
-            below += rr + 1u;
-            nbelow += count;
-            if (k > se) break;
-        }
-    }
-    if (eobrun > 0) {
-        if (k <= se) {
-            const uint32_t count = (uint32_t)__builtin_popcountll(nzb) - nbelow;
-            const uint32_t r = nrank - nbelow;
-            uint32_t taken = 0, left = count;
-            while (left != 0) {
-                const uint32_t n = left < 32u ? left : 32u;
-                uint32_t field;
-                w_read_bits<true, true>(d, lane, hac, n, field);
-                const uint32_t rn = r - taken;
-                if (was_nz && rn < n && ((field >> (n - 1u - rn)) & 1u) != 0 && (c & p1) == 0) {
-                    c += c > 0 ? p1 : m1;
-                    mine = true;
-                }
-                taken += n;
-                left -= n;
-            }
-        }
-        eobrun--;
-    }
-    return 0;
-}
-
 // ---- AC first pass, bulk path, parse-only form (same idea as w_ac_refine_parse): the serial loop reads the pre-digested window
 // entry, advances the zig-zag index and the position, and writes down in lane n where symbol n's coefficient goes, how many
 // magnitude bits it has and where the symbol ends; afterwards every symbol lane cuts its own magnitude out of the LDS ring, extends
@@ -2001,6 +1868,12 @@ __device__ __forceinline__ uint32_t f2_digest(uint32_t e /* (code size << 8) | s
     const uint32_t special = (size == 0 || (sz == 0 && rr != 15u)) ? kF2Special : 0u;
     return special | (rr << 12) | (sz << 6) | (size + sz);  // bits 0-5: code + magnitude bits, 6-10: magnitude bits, 12-15: run
 }
+// (The loop below writes M0 itself -- v_writelane with two scalar operands needs the lane select there on gfx9 -- and says so in
+// its clobber list; clang warns that M0 is reserved.  It is safe here: this kernel issues no LDS-DMA and no other instruction that
+// reads M0 implicitly, and hipcc re-materialises M0 in front of every use of its own (it never keeps a value there across
+// statements).  K3, the one kernel whose global_load_lds reads M0, contains no inline asm that touches it.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ uint32_t w_ac_first_parse(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, uint32_t al,
                                                      uint32_t &eobrun, int16_t *blk /* nullptr = the dummy block */) {
     se = uni(se);
@@ -2100,230 +1973,7 @@ __device__ __forceinline__ uint32_t w_ac_first_parse(WBits &d, uint32_t lane, co
     return 0;
 }
 
-// ---- AC refinement, bulk path, third form (round 3).  What bounds this kernel is the scalar instruction stream of ONE wave
-// (~5 cycles per instruction, ~30 per taken branch), and the form above spends 75-100 instructions and 8-10 branches per
-// symbol because every symbol also APPLIES its effects: correction fields cut and spread over the lanes, the new coefficient
-// placed, wide fields looped over.  Here the serial loop only PARSES -- per symbol: the pre-digested window entry, the stop
-// position (the (r + 1)-th zero from k on: one compare against the lanes' zero-ranks), three additions for the position --
-// and writes down, in lane i of two record registers, where symbol i stopped and how many code / sign bits the block had
-// consumed by then.  Everything else is done once per block by all lanes at the same time:
-//   * every coefficient that was non-zero before the scan takes exactly ONE correction bit in its block (while a run passes
-//     it, :349-361, or in the tail behind an end-of-band, :396-413): its position is
-//         block start + (code and sign bits of the symbols up to the one whose run passes it) + (its rank among the non-zero
-//         coefficients of the band),
-//     the symbol being the number of recorded stops below the lane (mbcnt of the stop mask), its bits fetched from the record
-//     register of that symbol lane (ds_bpermute), the bit itself from the LDS ring;
-//   * the new coefficient of symbol i (sign bit right behind its code) is stored by lane i straight to the block.
-// Same stream positions, same stores as the coefficient-by-coefficient walk of the reference.
-constexpr uint32_t kR2Special = 1u << 16;  // window entry: code longer than the lookup, or an end-of-band symbol
-__device__ __forceinline__ uint32_t r2_digest(uint32_t e /* (code size << 8) | symbol; code size 0 = not in the lookup */) {
-    const uint32_t size = e >> 8, rr = (e >> 4) & 15u, nonzero = (e & 15u) != 0 ? 1u : 0u;
-    const uint32_t special = (size == 0 || (nonzero == 0 && rr != 15u)) ? kR2Special : 0u;
-    return special | (rr << 8) | (nonzero << 7) | (size + nonzero);  // bits 0-5: code + sign bits, 7: sign follows, 8-11: run
-}
-
-__device__ __forceinline__ uint32_t w_ac_refine_parse(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, int32_t p1,
-                                                      int32_t m1, uint64_t band, uint64_t nz, uint32_t &eobrun, int32_t &c, bool &mine,
-                                                      int16_t *blk /* the block in the store; nullptr = the dummy block */) {
-#ifdef JPGPU_PS_PROFILE
-    const unsigned long long t_a = PS_TICK();
-    unsigned long long t_r = 0;
-#endif
-    // (uniform values all of them, but the compiler cannot always tell after the divergent exact path: the asm below takes SGPRs)
-    auto uni64 = [](uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); };
-    ss = uni(ss);
-    se = uni(se);
-    eobrun = uni(eobrun);
-    const uint64_t zeros = uni64(~nz & band), nzb = uni64(nz & band);
-    const uint32_t zrank = mbcnt64(zeros), nrank = mbcnt64(nzb);
-    const uint32_t blockpos = uni(d.pos);
-    const uint32_t ringbits = uni((d.wmask + 1u) * 32u - 1u);
-    uint32_t rec_bits = 0;  // lane i: code + sign bits of the block's symbols 0 .. i
-    uint32_t rec_stop = 0;  // lane i: stop position | sign follows << 7 | ring bit position of the sign << 8
-    uint32_t nsym = 0, symbits = 0;
-    uint32_t k = ss, zc = 0;  // next position, zeros of the band below it
-    uint64_t stopmask = 0;
-#ifdef JPGPU_PS_PROFILE
-    const unsigned long long t_b = PS_TICK();
-#endif
-    if (eobrun == 0) {
-        uint32_t cur = uni(d.cur);
-        uint32_t winpos = uni(d.pos) - cur;
-        for (;;) {
-            // The straight path -- window entry in the lookup, a plain (run, +-1) or ZRL symbol, its stop inside the band -- is
-            // hand-written: hipcc turns any C++ phrasing of this loop into a state machine of 50-100 scalar instructions and
-            // 5-10 branches per symbol, and one wave issues an instruction every ~5 cycles.  ~33 instructions,
-            // one taken branch per symbol.  It leaves for everything else with a reason code:
-            //   0 the band is done (k > Se)   1 the window has to be rebuilt   2 long code or end-of-band symbol
-            //   3 the run outlasts the band -- for 2 and 3 nothing of the symbol has been applied yet.
-            uint32_t reason, e, rr, adv, tgt, stop, t;
-            uint64_t hit;
-            cur = uni(cur);
-            k = uni(k);
-            zc = uni(zc);
-            symbits = uni(symbits);
-            nsym = uni(nsym);
-            stopmask = uni64(stopmask);
-            asm volatile(
-                "1:\n\t"
-                "s_cmp_gt_u32 %[cur], 63\n\t"
-                "s_cbranch_scc1 2f\n\t"
-                "v_readlane_b32 %[e], %[ent2], %[cur]\n\t"
-                "s_cmp_ge_u32 %[e], 0x10000\n\t"
-                "s_cbranch_scc1 3f\n\t"
-                "s_bfe_u32 %[rr], %[e], 0x40008\n\t"
-                "s_and_b32 %[adv], %[e], 63\n\t"
-                "s_add_u32 %[tgt], %[zc], %[rr]\n\t"
-                "v_cmp_eq_u32_e32 vcc, %[tgt], %[zrank]\n\t"
-                "s_and_b64 %[hit], vcc, %[zeros]\n\t"
-                "s_cbranch_scc0 4f\n\t"
-                "s_ff1_i32_b64 %[stop], %[hit]\n\t"
-                "s_add_u32 %[symbits], %[symbits], %[adv]\n\t"
-                "s_mov_b32 m0, %[nsym]\n\t"
-                "v_writelane_b32 %[recb], %[symbits], m0\n\t"
-                "s_add_u32 %[t], %[winpos], %[cur]\n\t"
-                "s_add_u32 %[t], %[t], %[adv]\n\t"
-                "s_add_u32 %[t], %[t], -1\n\t"
-                "s_and_b32 %[t], %[t], %[ringbits]\n\t"
-                "s_lshl_b32 %[t], %[t], 8\n\t"
-                "s_and_b32 %[e], %[e], 0x80\n\t"
-                "s_or_b32 %[t], %[t], %[e]\n\t"
-                "s_or_b32 %[t], %[t], %[stop]\n\t"
-                "v_writelane_b32 %[recs], %[t], m0\n\t"
-                "s_add_u32 %[nsym], %[nsym], 1\n\t"
-                "s_bitset1_b64 %[stopmask], %[stop]\n\t"
-                "s_add_u32 %[cur], %[cur], %[adv]\n\t"
-                "s_add_u32 %[cur], %[cur], %[stop]\n\t"
-                "s_sub_u32 %[cur], %[cur], %[k]\n\t"
-                "s_sub_u32 %[cur], %[cur], %[rr]\n\t"
-                "s_add_u32 %[k], %[stop], 1\n\t"
-                "s_add_u32 %[zc], %[tgt], 1\n\t"
-                "s_cmp_le_u32 %[k], %[se]\n\t"
-                "s_cbranch_scc1 1b\n\t"
-                "s_mov_b32 %[reason], 0\n\t"
-                "s_branch 5f\n"
-                "2:\n\t"
-                "s_mov_b32 %[reason], 1\n\t"
-                "s_branch 5f\n"
-                "3:\n\t"
-                "s_mov_b32 %[reason], 2\n\t"
-                "s_branch 5f\n"
-                "4:\n\t"
-                "s_mov_b32 %[reason], 3\n"
-                "5:\n\t"
-                : [cur] "+s"(cur), [k] "+s"(k), [zc] "+s"(zc), [symbits] "+s"(symbits), [nsym] "+s"(nsym), [stopmask] "+s"(stopmask),
-                  [recb] "+v"(rec_bits), [recs] "+v"(rec_stop), [reason] "=&s"(reason), [e] "=&s"(e), [rr] "=&s"(rr), [adv] "=&s"(adv),
-                  [tgt] "=&s"(tgt), [stop] "=&s"(stop), [t] "=&s"(t), [hit] "=&s"(hit)
-                : [winpos] "s"(winpos), [ringbits] "s"(ringbits), [se] "s"(se), [zeros] "s"(zeros), [ent2] "v"(d.ent2), [zrank] "v"(zrank)
-                : "vcc", "scc", "m0", "memory");
-            // (SGPR results: said again, the divergence analysis gives up on an asm statement with this many outputs)
-            cur = uni(cur);
-            k = uni(k);
-            zc = uni(zc);
-            symbits = uni(symbits);
-            nsym = uni(nsym);
-            stopmask = uni64(stopmask);
-            reason = uni(reason);
-#ifdef JPGPU_PS_PROFILE
-            d.n_exits++;
-#endif
-            if (reason == 0) break;
-            if (reason == 1) {
-#ifdef JPGPU_PS_PROFILE
-                const unsigned long long t_x = PS_TICK();
-#endif
-                d.pos = winpos + cur;
-                w_refresh<true>(d, lane, hac);
-                d.ent2 = r2_digest(d.ent);
-                winpos = uni(d.pos);
-                cur = 0;
-#ifdef JPGPU_PS_PROFILE
-                t_r += PS_TICK() - t_x;
-#endif
-                continue;
-            }
-            // one symbol outside the straight path
-            PS_COUNT(6);
-            const uint32_t pk = lane_get(d.peek, cur);
-            uint32_t raw = lane_get(d.ent, cur);
-            if ((raw >> 8) == 0) {
-                raw = w_huff_scalar(hac, pk >> 16);
-                if (raw >= kPsBadCode) return kDetailInvalidHuffmanCode;
-            }
-            const uint32_t e2 = r2_digest(raw);
-            if (e2 >= kR2Special) {  // EOBn (:337-350): the run's low bits follow the code
-                const uint32_t size = raw >> 8, r2 = (raw >> 4) & 15u;
-                eobrun = (1u << r2) + (uint32_t)(((uint64_t)(pk << size) << r2) >> 32);
-                symbits += size + r2;
-                cur += size + r2;
-                break;
-            }
-            const uint32_t rr2 = (e2 >> 8) & 15u, adv2 = e2 & 63u;
-            const uint32_t tgt2 = zc + rr2;
-            const uint64_t hit2 = __ballot(zrank == tgt2) & zeros;  // the lane that is the (rr + 1)-th zero from k on
-            symbits += adv2;
-            rec_bits = lane_put(rec_bits, symbits, nsym);
-            const uint32_t signpos = (winpos + cur + adv2 - 1u) & ringbits;
-            if (hit2 == 0) {  // the run outlasts the band: every non-zero coefficient left is passed, the new one lands behind Se
-                rec_stop = lane_put(rec_stop, (signpos << 8) | (e2 & 0x80u) | (se + 1u), nsym);
-                nsym++;
-                cur += adv2 + (uint32_t)__builtin_popcountll(nzb) - (k - ss - zc);
-                k = se + 1u;
-                zc = (uint32_t)__builtin_popcountll(zeros);
-                break;
-            }
-            const uint32_t stop2 = (uint32_t)__builtin_ctzll(hit2);
-            rec_stop = lane_put(rec_stop, (signpos << 8) | (e2 & 0x80u) | stop2, nsym);
-            nsym++;
-            stopmask |= 1ull << stop2;
-            cur += adv2 + (stop2 - k - rr2);  // the non-zero coefficients in [k, stop): their correction bits follow
-            k = stop2 + 1u;
-            zc = tgt2 + 1u;
-            if (k > se) break;
-        }
-        d.cur = cur;
-        d.pos = winpos + cur;
-    }
-    if (eobrun > 0) {
-        // the tail (:396-413): every non-zero coefficient from k on takes one correction bit
-        const uint32_t tail = (uint32_t)__builtin_popcountll(nzb) - (k - ss - zc);
-        d.pos += tail;
-        d.cur += tail;
-        eobrun--;
-    }
-#ifdef JPGPU_PS_PROFILE
-    const unsigned long long t_c = PS_TICK();
-#endif
-    symbits = uni(symbits);
-    nsym = uni(nsym);
-    stopmask = uni64(stopmask);
-    rec_bits = lane_put(rec_bits, symbits, nsym);  // the tail's lanes look at "symbol" nsym: all of the block's code bits
-    if (nzb != 0) {
-        // the correction bits, all at once
-        const uint32_t sym_of_lane = mbcnt64(stopmask);  // recorded stops below this lane = the symbol whose run passes it
-        const uint32_t bits_before = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sym_of_lane << 2), (int)rec_bits);
-        const uint32_t bp = blockpos + bits_before + nrank;
-        const uint32_t w = d.ring[(bp >> 5) & d.wmask];
-        if (((nzb >> lane) & 1ull) != 0 && ((w >> (31u - (bp & 31u))) & 1u) != 0 && (c & p1) == 0) {
-            c += c >= 0 ? p1 : m1;  // (the tail's test is c > 0: the same thing for a coefficient that is not zero)
-            mine = true;
-        }
-    }
-    if (lane < nsym && (rec_stop & 0x80u) != 0 && (rec_stop & 0x7Fu) < 64u && blk != nullptr) {
-        // the new coefficients (:363-367): symbol lanes store them where their runs stopped
-        const uint32_t sp = rec_stop >> 8;
-        const uint32_t w = d.ring[(sp >> 5) & d.wmask];
-        blk[rec_stop & 0x7Fu] = (int16_t)(((w >> (31u - (sp & 31u))) & 1u) != 0 ? p1 : m1);
-    }
-#ifdef JPGPU_PS_PROFILE
-    d.t_pro += t_b - t_a;
-    d.t_loop += t_c - t_b - t_r;
-    d.t_refresh += t_r;
-    d.t_epi += PS_TICK() - t_c;
-#endif
-    return 0;
-}
-
+#pragma clang diagnostic pop
 // ---- AC refinement, bulk path, fourth form: the symbol loop in the VECTOR unit's instruction stream.
 // tools/microbench/issue_latency.hip (one wave, cycles per instruction): any simple instruction ~4.2; a SALU instruction that
 // reads an SGPR the VALU has just written (v_readlane -> s_cmp, v_cmp -> s_and) stalls ~20 more; a conditional branch costs ~15
@@ -2354,265 +2004,11 @@ __device__ __forceinline__ uint32_t r4_digest(uint32_t e /* (code size << 8) | s
            (size + nonzero);
 }
 
-// the block's zero table: lane r holds Ss + (the number of non-zero coefficients of the band below its r-th zero)
 constexpr uint32_t kR4NoZero = 0xFFu;  // zero-table entry: no such zero, the run outlasts the band
-__device__ __forceinline__ uint32_t r4_zero_table(uint32_t lane, uint32_t ss, uint64_t band, uint64_t nz) {
-    const uint64_t zeros = ~nz & band, nzb = nz & band;
-    const uint32_t zrank = mbcnt64(zeros), nrank = mbcnt64(nzb);
-    const uint32_t nzeros = (uint32_t)__builtin_popcountll(zeros);
-    const bool is_zero = ((zeros >> lane) & 1ull) != 0;
-    // lane r <- the r-th zero of the band (the other lanes fill the remaining slots: a permutation, nothing collides)
-    const uint32_t slot = is_zero ? zrank : nzeros + (lane - zrank);
-    const uint32_t t = (uint32_t)__builtin_amdgcn_ds_permute((int)(slot << 2), (int)(ss + nrank));
-    return lane < nzeros ? t : kR4NoZero;
-}
-
-__device__ __forceinline__ uint32_t w_ac_refine_v4(WBits &d, uint32_t lane, const LdsHuff &hac, uint32_t ss, uint32_t se, int32_t p1,
-                                                   int32_t m1, uint64_t band, uint64_t nz, uint32_t &eobrun, int32_t &c, bool &mine) {
-#ifdef JPGPU_PS_PROFILE
-    const unsigned long long t_a = PS_TICK();
-    unsigned long long t_r = 0;
+// (the first, third and fourth forms of the refinement decoder: tools/microbench/refine_forms.inc, ablation builds only)
+#ifdef JPGPU_PS_EARLIER_FORMS
+#include "../../tools/microbench/refine_forms.inc"
 #endif
-    auto uni64 = [](uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); };
-    ss = uni(ss);
-    se = uni(se);
-    eobrun = uni(eobrun);
-    const uint64_t nzb = uni64(nz & band);
-    const uint32_t nrank = mbcnt64(nzb);
-    const uint32_t blockpos = uni(d.pos);
-    const uint32_t nnz = (uint32_t)__builtin_popcountll(nzb);
-    uint32_t bits = 0;     // per lane: code / sign / run bits of the block consumed before this lane's correction bit
-    uint32_t symbits = 0;  // ... by the symbols so far
-    uint32_t cv = (uint32_t)c;
-    uint32_t winpos = blockpos - uni(d.cur);  // stream position of the window's first bit
-#ifdef JPGPU_PS_ABLATE_LOOP  // timing experiment (tools/trace/progressive_ablation.sh): no block is parsed, the rest runs
-    eobrun = 0x40000000u;
-#endif
-    if (eobrun == 0) {
-        const uint32_t ntab = r4_zero_table(lane, ss, band, nz);
-        uint32_t cur = uni(d.cur);
-        uint32_t base = cur - ss;   // a symbol's offset in the window = base + code bits before it + ntab[zeros consumed before it]
-        uint32_t zq = 0xFFFFFFFFu;  // zeros of the band consumed so far, minus one
-        uint32_t kprev = ss - 1u;   // position in front of the next symbol's first one
-#ifdef JPGPU_PS_PROFILE
-        d.t_pro += PS_TICK() - t_a;
-#endif
-        bool again;
-        do {
-            again = false;
-            uint32_t stop, slow, eobv;
-#ifdef JPGPU_R4_CXX
-            // the loop below, spelled in C++ (debugging aid: same operations, the compiler's schedule)
-            uint32_t se_ = 0;
-            for (;;) {
-                const uint32_t ve = se_ = lane_get(d.ent2, cur);
-                const uint32_t t = zq + ((ve >> 6) & 127u);
-                const uint32_t symn = symbits + (ve & 63u);
-                const uint32_t sn = lane_get(ntab, t < 63u ? t : 63u);
-                const bool ok = (t | cur | sn) < 64u;
-                if (ok) symbits = symn;
-                if (lane > kprev) bits = symbits;
-                stop = ok ? sn + t : 0xFFFFu;
-                if (ok) {
-                    kprev = stop;
-                    cur = base + symn + sn;
-                    zq = t;
-                }
-                if (lane == ((ve & kR4Zrl) | stop)) cv = (ve >> 14) & 0xFFFFu;
-                if (!(se > stop)) break;
-            }
-            slow = eobv = 0;
-            if (stop == 0xFFFFu) {
-                if (cur <= 63u && (se_ & kR4Eob) != 0) {
-                    const uint32_t size = se_ & 63u, r2 = ((se_ >> 6) & 31u) - 1u;
-                    eobv = (1u << r2) + (uint32_t)(((uint64_t)(lane_get(d.peek, cur) << size) << r2) >> 32);
-                    symbits += size + r2;
-                } else {
-                    slow = 1;
-                }
-            }
-            if (lane > kprev) bits = symbits;
-#else
-            uint32_t scur, st, sn, se_, rr, t, tm, adv, symn, u, curn, pl, sg, stopr;
-            uint64_t sok, spb, spp;
-            asm volatile(
-                // One symbol per trip, 27 instructions and three fillers.  gfx940-family hazards the assembler does not fix in
-                // inline asm (LLVM's GCNHazardRecognizer does, for compiled code): a VALU instruction may read an SGPR / VCC
-                // another VALU instruction wrote only 2 wait states later, a lane select 4, v_readlane / v_readfirstlane a VGPR
-                // written by the VALU 1 later.  The gaps are filled with the PREVIOUS symbol's commits, none of which the
-                // chain cur -> entry -> zero rank -> ntab -> cur needs: they run at the top of the next trip (all of them no-ops in
-                // the first: sok = spb = 0, pl = none) and once more behind the loop.
-                // (Nothing comes in through a tied operand that could come in as a constant: hipcc lets a tied operand and
-                // an input that hold the same known value share ONE register, which the loop then overwrites under the input.)
-                "v_mov_b32_e32 %[stop], %[none]\n\t"
-                "s_mov_b32 %[se_], 0\n\t"
-                "s_mov_b64 %[sok], 0\n\t"
-                "s_mov_b64 %[spb], 0\n\t"
-                "1:\n\t"
-#if defined(JPGPU_PS_PROFILE) && JPGPU_PS_PROFILE > 1
-                "v_add_u32_e32 %[trips], 1, %[trips]\n\t"
-#endif
-                "v_readfirstlane_b32 %[scur], %[cur]\n\t"
-                "v_and_or_b32 %[pl], %[se_], %[zrl], %[stop]\n\t"                // previous symbol: where its coefficient goes (nowhere for ZRL)
-                "v_cndmask_b32_e64 %[symbits], %[symbits], %[symn], %[sok]\n\t"  // ... its code bits
-                "v_cmp_eq_u32_e64 %[spp], %[lane], %[pl]\n\t"
-                "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t"     // ... noted by the lanes from its first position on
-                "v_readlane_b32 %[se_], %[ent2], %[scur]\n\t"
-                "v_cndmask_b32_e64 %[kprev], %[kprev], %[stopr], %[sok]\n\t"
-                "v_cndmask_b32_e64 %[zq], %[zq], %[t], %[sok]\n\t"
-                "v_bfe_u32 %[rr], %[se_], 6, 7\n\t"
-                "v_cndmask_b32_e64 %[cv], %[cv], %[sg], %[spp]\n\t"
-                "v_add_u32_e32 %[t], %[zq], %[rr]\n\t"
-                "v_min_u32_e32 %[tm], 63, %[t]\n\t"
-                "v_and_b32_e64 %[adv], 63, %[se_]\n\t"
-                "v_readfirstlane_b32 %[st], %[tm]\n\t"
-                "v_add_u32_e32 %[symn], %[symbits], %[adv]\n\t"
-                "v_bfe_u32 %[sg], %[se_], 14, 16\n\t"
-                "v_cmp_gt_u32_e64 %[spb], %[lane], %[kprev]\n\t"
-                "s_nop 0\n\t"
-                "v_readlane_b32 %[sn], %[ntab], %[st]\n\t"
-                "s_nop 1\n\t"
-                "v_add3_u32 %[curn], %[base], %[symn], %[sn]\n\t"
-                "v_or3_b32 %[u], %[t], %[cur], %[sn]\n\t"
-                "v_cmp_gt_u32_e64 %[sok], 64, %[u]\n\t"
-                "v_add_u32_e32 %[stopr], %[sn], %[t]\n\t"
-                "s_nop 0\n\t"
-                "v_cndmask_b32_e64 %[cur], %[cur], %[curn], %[sok]\n\t"
-                "v_cndmask_b32_e64 %[stop], %[none], %[stopr], %[sok]\n\t"
-                "v_cmp_gt_u32_e32 vcc, %[se], %[stop]\n\t"
-                "s_cbranch_vccnz 1b\n\t"
-                // the last symbol's commits
-                "v_and_or_b32 %[pl], %[se_], %[zrl], %[stop]\n\t"
-                "v_cndmask_b32_e64 %[symbits], %[symbits], %[symn], %[sok]\n\t"
-                "v_cmp_eq_u32_e64 %[spp], %[lane], %[pl]\n\t"
-                "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t"
-                "v_cndmask_b32_e64 %[kprev], %[kprev], %[stopr], %[sok]\n\t"
-                "v_cndmask_b32_e64 %[zq], %[zq], %[t], %[sok]\n\t"
-                "v_cndmask_b32_e64 %[cv], %[cv], %[sg], %[spp]\n\t"
-                // What stopped the loop?  Nearly always EOBn (:337-350), found in the lookup: se_ is that entry, scur its offset
-                // in the window.  Applied here, without a branch: the run's low bits follow the code, the tail's lanes come
-                // behind all of it.  slow != 0: something else (window used up, code longer than the lookup, run past the band).
-                "v_readlane_b32 %[sn], %[peek], %[scur]\n\t"
-                "v_bfe_u32 %[rr], %[se_], 6, 5\n\t"              // run + 1
-                "v_and_b32_e64 %[adv], 63, %[se_]\n\t"           // code size
-                "v_add_u32_e32 %[rr], -1, %[rr]\n\t"
-                "v_lshlrev_b32_e64 %[u], %[adv], %[sn]\n\t"      // the bits behind the code
-                "v_sub_u32_e32 %[tm], 32, %[rr]\n\t"
-                "v_bfe_u32 %[u], %[u], %[tm], %[rr]\n\t"         // ... the first `run` of them (none: 0)
-                "v_lshlrev_b32_e64 %[curn], %[rr], 1\n\t"
-                "v_add_u32_e32 %[eobv], %[curn], %[u]\n\t"       // the end-of-band run
-                "v_add3_u32 %[symn], %[symbits], %[adv], %[rr]\n\t"
-                "v_lshrrev_b32_e32 %[pl], 6, %[cur]\n\t"         // window used up?
-                "v_bfe_u32 %[u], %[se_], 30, 1\n\t"              // an EOBn entry?
-                "v_xor_b32_e32 %[u], 1, %[u]\n\t"
-                "v_or_b32_e32 %[pl], %[pl], %[u]\n\t"
-                "v_cmp_eq_u32_e64 %[spp], %[stop], %[none]\n\t"  // the loop stopped on an entry it could not apply
-                "v_cmp_gt_u32_e64 %[spb], %[lane], %[kprev]\n\t"
-                "s_nop 0\n\t"
-                "v_cndmask_b32_e64 %[slow], 0, %[pl], %[spp]\n\t"
-                "v_cndmask_b32_e64 %[pl], 1, %[pl], %[spp]\n\t"
-                "v_cmp_eq_u32_e64 %[sok], 0, %[pl]\n\t"          // ... and it is an EOBn
-                "s_nop 1\n\t"
-                "v_cndmask_b32_e64 %[symbits], %[symbits], %[symn], %[sok]\n\t"
-                "v_cndmask_b32_e64 %[eobv], 0, %[eobv], %[sok]\n\t"
-                "v_cndmask_b32_e64 %[bits], %[bits], %[symbits], %[spb]\n\t"
-                : [cur] "+v"(cur), [zq] "+v"(zq), [symbits] "+v"(symbits), [kprev] "+v"(kprev), [bits] "+v"(bits), [cv] "+v"(cv),
-                  [stop] "=&v"(stop), [slow] "=&v"(slow), [eobv] "=&v"(eobv), [se_] "=&s"(se_), [sok] "=&s"(sok), [spb] "=&s"(spb),
-                  [t] "=&v"(t), [symn] "=&v"(symn), [sg] "=&v"(sg), [stopr] "=&v"(stopr), [scur] "=&s"(scur), [st] "=&s"(st),
-                  [sn] "=&s"(sn), [spp] "=&s"(spp), [rr] "=&v"(rr), [tm] "=&v"(tm), [adv] "=&v"(adv), [u] "=&v"(u), [curn] "=&v"(curn),
-                  [pl] "=&v"(pl)
-#if defined(JPGPU_PS_PROFILE) && JPGPU_PS_PROFILE > 1
-                  , [trips] "+v"(d.n_trips)
-#endif
-                : [ent2] "v"(d.ent2), [ntab] "v"(ntab), [peek] "v"(d.peek), [lane] "v"(lane), [base] "v"(base), [none] "v"(0xFFFFu),
-                  [zrl] "v"(kR4Zrl), [se] "s"(se)
-                : "vcc", "memory");
-#endif
-#ifdef JPGPU_PS_PROFILE
-            d.n_exits++;
-#endif
-            eobrun = uni(eobv);  // (0 unless the loop ended on an EOBn entry)
-            if (uni(slow) != 0) {
-                cur = uni(cur);
-                zq = uni(zq);
-                symbits = uni(symbits);
-                kprev = uni(kprev);
-                if (cur > 63u) {
-#ifdef JPGPU_PS_PROFILE
-                    const unsigned long long t_x = PS_TICK();
-#endif
-                    d.pos = winpos + cur;
-                    w_refresh<true>(d, lane, hac);
-                    d.ent2 = r4_digest(d.ent, d.peek, p1, m1);
-                    winpos = uni(d.pos);
-                    base -= cur;
-                    cur = 0;
-                    again = true;
-#ifdef JPGPU_PS_PROFILE
-                    t_r += PS_TICK() - t_x;
-#endif
-                } else {
-                    // one symbol by hand: a code longer than the lookup (EOBn among them), or a run that outlasts the band
-                    PS_COUNT(6);
-                    const uint32_t pk = lane_get(d.peek, cur);
-                    uint32_t raw = lane_get(d.ent, cur);
-                    if ((raw >> 8) == 0) {
-                        raw = w_huff_scalar(hac, pk >> 16);
-                        if (raw >= kPsBadCode) return kDetailInvalidHuffmanCode;
-                    }
-                    const uint32_t e2 = r4_digest(raw, pk, p1, m1);
-                    const uint32_t size = raw >> 8, r2 = (raw >> 4) & 15u;
-                    if (e2 >= kR4Special) {  // EOBn (:337-350): the run's low bits follow the code; the tail's lanes come behind all of it
-                        eobrun = (1u << r2) + (uint32_t)(((uint64_t)(pk << size) << r2) >> 32);
-                        symbits += size + r2;
-                        if (lane > kprev) bits = symbits;
-                    } else {
-                        const uint32_t adv2 = e2 & 63u, tgt2 = zq + 1u + r2;
-                        const uint32_t n2 = lane_get(ntab, tgt2 < 63u ? tgt2 : 63u);
-                        symbits += adv2;
-                        if (lane > kprev) bits = symbits;
-                        const uint32_t stop2 = n2 >= 64u ? se + 1u : tgt2 + n2;  // no such zero: the new coefficient lands behind Se (:363-367)
-                        if ((e2 & kR4Zrl) == 0 && lane == stop2) cv = (e2 >> 14) & 0xFFFFu;
-                        if (n2 < 64u && stop2 < se) {  // (else every non-zero coefficient left has been passed)
-                            cur = base + symbits + n2;
-                            zq = tgt2;
-                            kprev = stop2;
-                            again = true;
-                        }
-                    }
-                }
-            }
-        } while (again);
-    }
-#ifdef JPGPU_PS_PROFILE
-    const unsigned long long t_c = PS_TICK();
-#endif
-    symbits = uni(symbits);
-    if (eobrun > 0) eobrun--;
-    // every coefficient that was non-zero takes exactly one correction bit: behind the code bits noted for its lane, in rank order
-    int32_t cn = (int32_t)(int16_t)cv;
-#ifdef JPGPU_PS_ABLATE_EPILOGUE  // timing experiment: no correction bits
-    if (false) {
-#else
-    if (nzb != 0) {
-#endif
-        const uint32_t bp = blockpos + bits + nrank;
-        const uint32_t w = d.ring[(bp >> 5) & d.wmask];
-        if (((nzb >> lane) & 1ull) != 0 && ((w >> (31u - (bp & 31u))) & 1u) != 0 && (cn & p1) == 0)
-            cn += cn >= 0 ? p1 : m1;  // (the tail's test is c > 0: the same thing for a coefficient that is not zero)
-    }
-    const uint32_t consumed = symbits + nnz;
-    d.pos = blockpos + consumed;
-    d.cur = d.pos - winpos;
-    mine = cn != c;  // a new coefficient is never 0, a correction never leaves the value alone
-    c = cn;
-#ifdef JPGPU_PS_PROFILE
-    d.t_loop += t_c - t_a - t_r;  // (includes the prologue, reported separately in t_pro)
-    d.t_refresh += t_r;
-    d.t_epi += PS_TICK() - t_c;
-#endif
-    return 0;
-}
 // ---- AC refinement, bulk path, fifth form: the WHOLE block in one instruction sequence.
 // rocprofv3's counters on the fourth form (tools/trace/progressive_pmc.sh, per block of the last luma refinement): 480 wave
 // instructions of which the symbol loop is ~200, 30 branches, and as many wave cycles waiting as issuing -- one wave issues one
