@@ -1069,6 +1069,9 @@ int jpgpu_progressive_scan(jpgpu_progressive *p, const jpgpu_scan *scan, const u
 namespace {
 int progressive_idct_pass(jpgpu_progressive *p, int format) {
     int rc = p->batch.upload_progressive_dispose(p->frame, format);
+    // Dispose() without a ProcessScan before it: the allocator's zeroed blocks go to the writer untransformed (the decoder's
+    // component slots still have sampling factors 0: JpegHuffmanProgressiveScanDecoder.cs:52-56, 425-447)
+    if (rc == JPGPU_OK && p->n_scans == 0) rc = p->batch.clear_progressive_stores();
     if (rc == JPGPU_OK) rc = p->batch.run_idct();
     if (rc == JPGPU_OK) rc = p->batch.sync();
     if (rc != JPGPU_OK) return rc;
@@ -1086,7 +1089,6 @@ int jpgpu_progressive_dispose(jpgpu_progressive *p, int format, void *out, size_
         return JPGPU_ERR_ARGUMENT;
     }
     return guarded_ctx(p->ctx, nullptr, [&] {
-        if (p->n_scans == 0) return (int)JPGPU_OK;  // Dispose() of an untouched store writes zero-coefficient blocks; nothing decoded, nothing delivered
         int rc = progressive_idct_pass(p, format);
         if (rc != JPGPU_OK) return rc;
         return p->batch.download_output(0, out, cap);
@@ -1100,7 +1102,6 @@ int jpgpu_progressive_dispose_to_writer(jpgpu_progressive *p, jpgpu_write_block_
         return JPGPU_ERR_ARGUMENT;
     }
     return guarded_ctx(p->ctx, nullptr, [&] {
-        if (p->n_scans == 0) return (int)JPGPU_OK;
         int rc = progressive_idct_pass(p, JPGPU_FMT_PLANAR_I16);
         if (rc != JPGPU_OK) return rc;
         const ImagePlan &img = *p->batch.image(0);

@@ -76,7 +76,7 @@ struct alignas(16) DevScan {
     uint8_t blk_y[kMaxBlocksPerMcu];
     uint16_t huff_pool[kMaxHuffSlots];   // pool indices of the tables this scan stages (0xFFFF = unused)
     uint16_t quant_pool[kMaxScanComponents];
-    uint64_t reserved0;  // (was: token pipeline slot base; the pipeline was removed in round 2)
+    uint64_t reserved0;  // bit 0 (kScanStoreHoldsSamples): the frame's store holds samples by the time K3 runs (generic Dispose() pass)
     uint32_t chunk_off;  // first entry of this scan in the chunk-summary array (K1)
     uint32_t n_chunks;   // 4 KiB chunks covering the entropy segment (from its 16-byte aligned base)
     uint32_t sub_off;    // DRI = 0 scans: first slot of this scan in the subsequence state arrays (K2S)
@@ -100,6 +100,18 @@ struct alignas(16) DevScan {
     uint32_t dep[3];           // pipelined launch: scan jobs this scan follows (kNoDep = none), see progressive_stream_kernel
 };
 constexpr uint32_t kNoDep = 0xFFFFFFFFu;
+constexpr uint64_t kScanStoreHoldsSamples = 1;
+// The reference's Dispose() taken literally for one progressive frame (dispose_pass_kernel): component c of the frame is
+// transformed n[c] times in place, with the quantisation tables of the decoder's component slots that point at it, in slot order.
+struct alignas(16) DisposeJob {
+    uint64_t coef_off;   // the frame's first block
+    uint32_t n_blocks;   // total MCUs * blocks per MCU
+    uint32_t bpm, level_shift;
+    uint8_t blk_comp[kMaxBlocksPerMcu];       // block in MCU -> frame component
+    uint8_t n[kMaxScanComponents];            // transforms per component
+    uint16_t quant[kMaxScanComponents][kMaxScanComponents];  // pool indices of their tables, in slot order
+    uint32_t pad[3];
+};
 constexpr uint8_t kKeepUnreachedMcus = 0x80;
 enum ScanKind : uint8_t { kScanSequential = 0, kScanFrameOnly = 1, kScanProgressive = 2 };
 static_assert(sizeof(DevScan) % 16 == 0, "DevScan must be a multiple of 16 bytes");

@@ -46,7 +46,7 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_sub_work_, &d_sub_final_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_sub_same_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_prog_sync_, &d_planes_, &d_extend_desc_, &d_gather_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_sub_work_, &d_sub_final_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_sub_same_, &d_dispose_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_prog_sync_, &d_planes_, &d_extend_desc_, &d_gather_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
@@ -1165,6 +1165,8 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     total_subs_ = 0;
     max_subs_per_scan_ = 0;
     sub_same_valid_ = false;
+    dispose_jobs_.clear();
+    dispose_max_blocks_ = 0;
     std::vector<IdctWork> idct_work;
     std::vector<IdctWork> idct_work_by_class[kNumIdctLayoutClasses];
     const bool tile_align = !(getenv("JPGPU_TILE_ALIGN") && atoi(getenv("JPGPU_TILE_ALIGN")) == 0);  // A/B switch, default on
@@ -1298,6 +1300,22 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             memcpy(s.blk_comp, job.blk_comp, sizeof s.blk_comp);
             memcpy(s.blk_x, job.blk_x, sizeof s.blk_x);
             memcpy(s.blk_y, job.blk_y, sizeof s.blk_y);
+            if (job.kind == kScanFrameOnly && job.dispose_generic) {
+                // Dispose() as the reference runs it (dispose_pass_kernel), then the store goes to the writer as it is
+                s.reserved0 |= kScanStoreHoldsSamples;
+                DisposeJob dj;
+                memset(&dj, 0, sizeof dj);
+                dj.bpm = (uint32_t)job.blocks_per_mcu;
+                dj.level_shift = 1u << (g.frame.precision - 1);
+                memcpy(dj.blk_comp, job.blk_comp, sizeof dj.blk_comp);
+                for (int c = 0; c < kMaxScanComponents; c++) {
+                    dj.n[c] = job.dispose_n[c];
+                    for (int t = 0; t < job.dispose_n[c]; t++) dj.quant[c][t] = quant_index(job.dispose_q[c][t]);
+                }
+                dj.n_blocks = 0xFFFFFFFFu;  // (marks "scan index in coef_off": resolved below, once the store's place is known)
+                dj.coef_off = (uint64_t)j;
+                dispose_jobs_.push_back(dj);
+            }
 
             if (job.kind == kScanProgressive) {
                 // launch groups: dependency levels; JPGPU_PROG_BY_SCAN=1 (profiling aid): scan k of every frame in a launch of its
@@ -1374,8 +1392,9 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                         break;
                     }
             }
-            const int cls = fmt_is_interleaved(format_) ? idct_layout_class(s) : 0;
-            if (cls == 0 && (format_ == JPGPU_FMT_RGB_U8 || format_ == JPGPU_FMT_RGBA_U8)) {
+            const bool holds_samples = (s.reserved0 & kScanStoreHoldsSamples) != 0;
+            const int cls = holds_samples ? kIdctClassStoreHoldsSamples : (fmt_is_interleaved(format_) ? idct_layout_class(s) : 0);
+            if ((cls == 0 || holds_samples) && (format_ == JPGPU_FMT_RGB_U8 || format_ == JPGPU_FMT_RGBA_U8)) {
                 // no fused conversion for this layout: samples go to the scratch image, then ycc_to_rgb_kernel
                 bool listed = false;
                 for (const RgbConvert &rc : rgb_convert_) listed |= rc.image == (uint32_t)ii;
@@ -1385,6 +1404,12 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             for (uint32_t first = 0; first < s.total_mcus; first += run)
                 idct_work_by_class[cls].push_back({(uint32_t)j, first, std::min(run, s.total_mcus - first), mcus_per_wg});
         }
+    }
+    for (DisposeJob &dj : dispose_jobs_) {  // the frames' stores have their places now
+        const DevScan &fs = h_scans_[(size_t)dj.coef_off];
+        dj.coef_off = fs.coef_off;
+        dj.n_blocks = fs.total_mcus * (uint32_t)fs.blocks_per_mcu;
+        dispose_max_blocks_ = std::max(dispose_max_blocks_, dj.n_blocks);
     }
     total_blocks_ = coef_off;
     out_bytes_ = out_off;
@@ -1506,7 +1531,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         // and cannot share a CU (K2 takes 159 KB of its 160 KB LDS), so the halves time-slice instead of overlapping:
         // 16.39-16.52 ms overlapped vs 16.16-16.37 ms serial per 1024 x 4K (gpurun r02e, both issue orders below)
         const char *ev = getenv("JPGPU_OVERLAP");
-        const bool wanted = ev && atoi(ev) != 0;
+        const bool wanted = ev && atoi(ev) != 0 && dispose_jobs_.empty();  // (the generic Dispose() pass is issued by run_idct alone)
         uint32_t split_image = 0;
         uint64_t acc = 0;
         for (size_t ii = 0; ii < images_.size() && acc * 2 < total_blocks_; ii++) {
@@ -1571,6 +1596,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_sub_dcsum_, nullptr, 0, (size_t)total_subs_ * 16 + 256},
         {&d_sub_dcentry_, nullptr, 0, (size_t)total_subs_ * 16 + 256},
         {&d_sub_changed_, nullptr, 0, 64 * sizeof(uint32_t)},
+        {&d_dispose_, dispose_jobs_.data(), dispose_jobs_.size() * sizeof(DisposeJob), 0},
         {&d_sub_same_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
         {&d_lut_pool_, nullptr, 0, huff_pool_.size() * kLutPoolBytesPerTable},
         {&d_chunk_sums_, nullptr, 0, (size_t)total_chunks * sizeof(ChunkSum) + 256},
@@ -1785,10 +1811,27 @@ int DeviceBatch::clear_partial_outputs() {
     return JPGPU_OK;
 }
 
+// the frames' coefficient stores back to zero (JpegBlockAllocator.Allocate clears it): a Dispose() without any scan before it
+int DeviceBatch::clear_progressive_stores() {
+    for (const auto &c : prog_clear_) {
+        hipError_t e = hipMemsetAsync((int16_t *)d_coefs_.ptr + c.first * 64, 0, (size_t)c.second * 128, ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(progressive store)");
+    }
+    return JPGPU_OK;
+}
+
+int DeviceBatch::run_dispose_passes(hipStream_t stream) {
+    if (dispose_jobs_.empty()) return JPGPU_OK;
+    const hipError_t e = launch_dispose_pass(stream, (int16_t *)d_coefs_.ptr, (const DisposeJob *)d_dispose_.ptr, (int)dispose_jobs_.size(), dispose_max_blocks_,
+                                             (const DevQuantTable *)d_quant_pool_.ptr);
+    return e == hipSuccess ? JPGPU_OK : hip_fail(e, "dispose_pass_kernel");
+}
+
 int DeviceBatch::run_idct() {
     const YccRgbFactors kf = ycc_rgb_factors();
     int rc0 = clear_partial_outputs();
     if (rc0 != JPGPU_OK) return rc0;
+    if ((rc0 = run_dispose_passes(ctx_->stream)) != JPGPU_OK) return rc0;
     const bool extended = format_ == JPGPU_FMT_EXTENDED_U16;
     hipError_t e = launch_idct(ctx_->stream, (const int16_t *)d_coefs_.ptr, (const DevScan *)d_scans_.ptr, (const IdctWork *)d_idct_work_.ptr,
                                idct_class_begin_, (const DevScanStatus *)d_status_.ptr, (const DevQuantTable *)d_quant_pool_.ptr,

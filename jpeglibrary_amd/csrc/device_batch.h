@@ -216,6 +216,13 @@ class DeviceBatch {
     // DRI = 0 scans: self-synchronising subsequence decode (K2S)
     DevBuffer d_lut_pool_;  // fused lookups of every pool table (K2S round kernel)
     DevBuffer d_sub_work_, d_sub_scan_ids_, d_sub_exit_a_, d_sub_exit_b_, d_sub_nblk_, d_sub_first_, d_sub_entry_, d_sub_dcsum_, d_sub_dcentry_, d_sub_changed_, d_sub_same_;
+    DevBuffer d_dispose_;  // DisposeJob per frame that takes the generic Dispose() pass
+    std::vector<DisposeJob> dispose_jobs_;
+    uint32_t dispose_max_blocks_ = 0;
+    int run_dispose_passes(hipStream_t stream);
+  public:
+    int clear_progressive_stores();
+  private:
     bool sub_same_valid_ = false;  // d_sub_same_ holds the twins of this upload's subsequences (subseq_same_kernel)
     int n_sub_work_ = 0, n_sub_scans_ = 0, n_sub_final_work_ = 0;
     DevBuffer d_sub_final_work_;

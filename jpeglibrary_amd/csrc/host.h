@@ -227,6 +227,11 @@ struct ScanJob {
     uint16_t hblocks[kMaxScanComponents] = {}, vblocks[kMaxScanComponents] = {};
     uint32_t units_per_line = 0, total_units = 0;
     std::string refuse;  // frame job: non-empty = report NotSupported once every scan of the frame decoded cleanly
+    // frame job: the decoder's component slots do not map one to one onto the frame's components (or no scan was processed):
+    // Dispose() as the reference runs it -- component c is transformed dispose_n[c] times with these tables, in slot order
+    bool dispose_generic = false;
+    uint8_t dispose_n[kMaxScanComponents] = {};
+    QuantTable dispose_q[kMaxScanComponents][kMaxScanComponents];
 };
 // Builds a ScanJob (validates tables like ProcessScan :69-82). Throws DecodeError with the reference's messages.
 // optimizer_rules: JpegOptimizer's view of the same scan (JpegOptimizer.cs:381-413): quantisation tables play no part, and a

@@ -862,9 +862,10 @@ ScanJob ProgressiveFrame::make_frame_job() const {
         else if (slot_of_component[slot_[i].component_index] >= 0) ok = false;
         else slot_of_component[slot_[i].component_index] = i;
     }
-    // Not reproduced; but a failure inside one of the scans comes first in the reference (it happens before Dispose), so
-    // the refusal is only attached to the job and reported when every scan decoded cleanly.
-    const bool refuse = !ok;
+    // Slots that do not map one to one onto the components: the reference transforms a component once per slot that points at
+    // it, in slot order and in place -- twice, or never (ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs:425-447; a slot no
+    // scan ever filled has sampling factors 0 and does nothing).  Reproduced literally by dispose_pass_kernel.
+    const bool generic = !ok;
     // a sequential-style job over ALL frame components in frame order with the slots' quantisation tables
     HostDecoder tmp;
     FrameHeader f2 = fh;
@@ -875,7 +876,7 @@ ScanJob ProgressiveFrame::make_frame_job() const {
         f2.components[c].tq = (uint8_t)c;
         QuantTable q;
         if (slot_of_component[c] >= 0 && slot_set_[slot_of_component[c]]) q = slot_quant_[slot_of_component[c]];
-        else for (uint16_t &e : q.elements) e = 1;  // refused frame: the pass still runs, its output is not delivered
+        else for (uint16_t &e : q.elements) e = 1;  // (generic Dispose(): K3 does not transform, the table is not looked at)
         q.identifier = (uint8_t)c;
         tmp.set_quantization_table(q);
         sh.components.push_back({fh.components[c].identifier, 0, 0});
@@ -891,9 +892,15 @@ ScanJob ProgressiveFrame::make_frame_job() const {
     BaselineGeometry g = BaselineGeometry::latch(tmp, f2);
     ScanJob job = make_scan_job(tmp, g, sh, nullptr, 0);
     job.kind = kScanFrameOnly;
-    if (refuse)
-        job.refuse = "Progressive scan order leaves the decoder's component slots without one entry per frame component; "
-                     "the reference's output for such files is an artefact of its Dispose() pass and is not reproduced.";
+    if (generic) {
+        job.dispose_generic = true;
+        for (int i = 0; i < slots_alloc_; i++) {
+            if (!slot_set_[i]) continue;
+            const int c = slot_[i].component_index;
+            if (c < 0 || c >= kMaxScanComponents || job.dispose_n[c] >= kMaxScanComponents) continue;
+            job.dispose_q[c][job.dispose_n[c]++] = slot_quant_[i];
+        }
+    }
     return job;
 }
 

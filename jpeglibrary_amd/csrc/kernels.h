@@ -29,7 +29,8 @@ hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan
                           int n_slots, const uint8_t *lut_pool);
 // lut_pool: kLutPoolBytesPerTable per pool table, filled by launch_lut_pool (K2 and the K2S round kernel copy from it)
 hipError_t launch_lut_pool(hipStream_t stream, const DevHuffTable *huff_pool, int n_tables, uint8_t *lut_pool);
-constexpr int kNumIdctLayoutClasses = 5;
+constexpr int kNumIdctLayoutClasses = 6;
+constexpr int kIdctClassStoreHoldsSamples = 5;  // frames whose generic Dispose() pass has run (any format): flush_output_kernel
 // Output layout class of a scan for INTERLEAVED_U8 (0 = generic bytewise path, else a specialised kernel).
 int idct_layout_class(const DevScan &s);
 // work is sorted by layout class; class_begin[c]..class_begin[c+1] are the workgroups of class c.
@@ -38,6 +39,8 @@ int idct_layout_class(const DevScan &s);
 hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *scans, const IdctWork *work,
                        const int class_begin[kNumIdctLayoutClasses + 1], const DevScanStatus *status,
                        const DevQuantTable *quant_pool, uint8_t *out, int format, const YccRgbFactors &kf, uint8_t *generic_out);
+// the reference's Dispose() taken literally (frames whose component slots do not map one to one onto their components)
+hipError_t launch_dispose_pass(hipStream_t stream, int16_t *coefs, const DisposeJob *jobs, int n_jobs, uint32_t max_blocks, const DevQuantTable *quant_pool);
 hipError_t launch_ycc_to_rgb(hipStream_t stream, const uint8_t *src, uint8_t *dst, uint64_t n_pixels, int comps, int bpp, const YccRgbFactors &kf);
 
 // DRI = 0 scans (K2S): self-synchronising subsequence decode into the (zeroed) coefficient buffer; synchronises the stream.

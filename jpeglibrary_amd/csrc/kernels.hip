@@ -4201,8 +4201,10 @@ __device__ __forceinline__ void interleaved_output_from_tile(const uint8_t *sh_p
 typedef __attribute__((address_space(3))) void jpgpu_lds_void;
 typedef const __attribute__((address_space(1))) void jpgpu_gbl_void;
 
-template <int FMT, int LAY>
-__global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void idct_output_kernel(
+// PRE: the store already holds SAMPLES (the generic Dispose() pass of a progressive frame whose component slots do not map one
+// to one onto its components, dispose_pass_kernel below): no dequantisation, no transform -- the block goes to the writer as it lies
+template <int FMT, int LAY, bool PRE>
+__device__ __forceinline__ void idct_output_body(
     const int16_t *__restrict__ coefs, const DevScan *__restrict__ scans, const IdctWork *__restrict__ work,
     const DevScanStatus *__restrict__ status, const DevQuantTable *__restrict__ quant_pool, uint8_t *__restrict__ out, YccRgbFactors kf) {
     constexpr int CONV = FMT == kFmtRgbU8 ? 3 : (FMT == kFmtRgbaU8 ? 4 : 0);  // fused YCbCr -> RGB(A), fast layouts and gray only
@@ -4275,7 +4277,19 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
 
     // phase B1: dequantise this lane's block out of the staging into registers
     float f[64];
-    {
+    uint32_t px[32];  // int16 sample pairs
+    if (PRE) {
+        if (have_block) {
+#pragma unroll
+            for (int piece = 0; piece < 8; piece++) {
+                const uint4 cv = *reinterpret_cast<const uint4 *>(sh + tid * 128 + ((piece ^ ((tid >> 1) & 7)) * 16));
+                px[piece * 4] = cv.x;
+                px[piece * 4 + 1] = cv.y;
+                px[piece * 4 + 2] = cv.z;
+                px[piece * 4 + 3] = cv.w;
+            }
+        }
+    } else {
         // The lane's eight swizzled staging addresses do not change from tile to tile; hipcc computes them in front of the tile
         // loop -- and in the three variants with the most state in their output assembly spills five of them to scratch for
         // the length of the transform.  There they are derived again in every tile (sixteen instructions) from a copy of the
@@ -4290,8 +4304,7 @@ __global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void 
     if (have_next) dma_tile(next_first);  // in flight during the whole transform below
 
     // phase B2: IDCT entirely in registers
-    uint32_t px[32];  // int16 sample pairs
-    if (have_block) block_idct(f, (int32_t)s.level_shift, px);
+    if (!PRE && have_block) block_idct(f, (int32_t)s.level_shift, px);
     if (mcu >= decoded) {
 #pragma unroll
         for (int i = 0; i < 32; i++) px[i] = 0;
@@ -4471,6 +4484,59 @@ hipError_t launch_lut_pool(hipStream_t stream, const DevHuffTable *huff_pool, in
 }
 
 template <int FMT, int LAY>
+__global__ __launch_bounds__(kIdctThreads, (FMT == kFmtPlanarI16 ? 2 : 3)) void idct_output_kernel(
+    const int16_t *__restrict__ coefs, const DevScan *__restrict__ scans, const IdctWork *__restrict__ work,
+    const DevScanStatus *__restrict__ status, const DevQuantTable *__restrict__ quant_pool, uint8_t *__restrict__ out, YccRgbFactors kf) {
+    idct_output_body<FMT, LAY, false>(coefs, scans, work, status, quant_pool, out, kf);
+}
+template <int FMT>
+__global__ __launch_bounds__(kIdctThreads, 2) void flush_output_kernel(
+    const int16_t *__restrict__ coefs, const DevScan *__restrict__ scans, const IdctWork *__restrict__ work,
+    const DevScanStatus *__restrict__ status, const DevQuantTable *__restrict__ quant_pool, uint8_t *__restrict__ out, YccRgbFactors kf) {
+    idct_output_body<FMT, kLayGeneric, true>(coefs, scans, work, status, quant_pool, out, kf);
+}
+
+// The reference's Dispose() as it is written (ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs:421-470): every component SLOT of
+// the scan decoder, as the last scans left it, dequantises + transforms + level-shifts the blocks of its component IN PLACE.  For
+// files in the usual scan order that is one transform per component and K3 does it on the way to the writer.  When the slots
+// do not map one to one onto the components (a file whose last scan of slot 0 is not the first component: e.g. slots
+// {Cb, Cb, Cr}) a component is transformed twice -- the second time reading its own samples as zig-zag coefficients -- and
+// another never (its quantised coefficients reach the writer as samples); a file without any scan flushes zeros.  This kernel
+// does literally that to the frame's store, one lane per block, `n` transforms with the slots' tables in slot order;
+// flush_output_kernel then writes the store out.  (Both also serve the partial flush of a progressive file that failed.)
+__global__ __launch_bounds__(64) void dispose_pass_kernel(int16_t *__restrict__ coefs, const DisposeJob *__restrict__ jobs,
+                                                          const DevQuantTable *__restrict__ quant_pool) {
+    const DisposeJob &j = jobs[blockIdx.y];
+    const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+    if (g >= j.n_blocks) return;
+    const uint32_t c = j.blk_comp[g % j.bpm];
+    const uint32_t n = j.n[c];
+    if (n == 0) return;
+    int16_t *blk = coefs + (j.coef_off + g) * 64;
+    uint32_t w[32];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint4 v = reinterpret_cast<const uint4 *>(blk)[i];
+        w[i * 4] = v.x;
+        w[i * 4 + 1] = v.y;
+        w[i * 4 + 2] = v.z;
+        w[i * 4 + 3] = v.w;
+    }
+    for (uint32_t t = 0; t < n; t++) {
+        const uint16_t *q = quant_pool[j.quant[c][t]].q;
+        float f[64];
+#pragma unroll
+        for (int k = 0; k < 64; k++) {
+            const int32_t cv = (k & 1) ? ((int32_t)w[k >> 1] >> 16) : (int32_t)(int16_t)(w[k >> 1] & 0xFFFFu);
+            f[kNat[k]] = (float)((int32_t)q[k] * cv);  // ushort * short -> int -> float (DequantizeBlockAndUnZigZag)
+        }
+        block_idct(f, (int32_t)j.level_shift, w);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(blk)[i] = make_uint4(w[i * 4], w[i * 4 + 1], w[i * 4 + 2], w[i * 4 + 3]);
+}
+
+template <int FMT, int LAY>
 static void launch_idct_one(hipStream_t stream, const int16_t *coefs, const DevScan *scans, const IdctWork *work, int n_work,
                             const DevScanStatus *status, const DevQuantTable *quant_pool, uint8_t *out,
                             YccRgbFactors kf = YccRgbFactors{0, 0, 0, 0}) {
@@ -4486,7 +4552,12 @@ hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *
         const int n = class_begin[c + 1] - class_begin[c];
         if (n <= 0) continue;
         const IdctWork *w = work + class_begin[c];
-        if (format == kFmtPlanarI16) {
+        if (c == kIdctClassStoreHoldsSamples) {  // the generic Dispose() pass has run: the store goes to the writer as it is
+            if (format == kFmtPlanarI16) hipLaunchKernelGGL((flush_output_kernel<kFmtPlanarI16>), dim3(n), dim3(kIdctThreads), 0, stream, coefs, scans, w, status, quant_pool, out, kf);
+            else if (format == kFmtPlanarU8) hipLaunchKernelGGL((flush_output_kernel<kFmtPlanarU8>), dim3(n), dim3(kIdctThreads), 0, stream, coefs, scans, w, status, quant_pool, out, kf);
+            else hipLaunchKernelGGL((flush_output_kernel<kFmtInterleavedU8>), dim3(n), dim3(kIdctThreads), 0, stream, coefs, scans, w, status, quant_pool,
+                                    (format == kFmtRgbU8 || format == kFmtRgbaU8) ? generic_out : out, kf);
+        } else if (format == kFmtPlanarI16) {
             launch_idct_one<kFmtPlanarI16, kLayGeneric>(stream, coefs, scans, w, n, status, quant_pool, out);
         } else if (format == kFmtPlanarU8) {
             launch_idct_one<kFmtPlanarU8, kLayGeneric>(stream, coefs, scans, w, n, status, quant_pool, out);
@@ -4675,6 +4746,12 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
     // final_work: (scan, first subsequence) per workgroup of waves * 64 lanes (the rounds' work list is per 256)
     hipLaunchKernelGGL(subseq_final_kernel, dim3(n_final_work), dim3(64 * waves), lds_final, stream, udata, scans, final_work, ends_u, status,
                        huff_pool, lut_pool, final_state, first_block, (const int4 *)dc_entry, coefs, n_slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_dispose_pass(hipStream_t stream, int16_t *coefs, const DisposeJob *jobs, int n_jobs, uint32_t max_blocks, const DevQuantTable *quant_pool) {
+    if (n_jobs <= 0 || max_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(dispose_pass_kernel, dim3((max_blocks + 63u) / 64u, n_jobs), dim3(64), 0, stream, coefs, jobs, quant_pool);
     return hipGetLastError();
 }
 
