@@ -53,7 +53,10 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 uint32_t *same_dist, bool *same_valid);
 // waves (of 64 subsequences) per workgroup of the K2S final pass.  4 = two workgroups per CU; one workgroup of 10 waves (K2's
 // shape, 25 % more waves per CU) was measured slower: 21.1 vs 19.6 ms K2S per 1024 x 4K -- a workgroup waits for its slowest wave
-constexpr int subseq_final_waves(int n_slots) { return n_slots <= 8 ? 4 : 4; }
+#ifndef JPGPU_SF_WAVES
+#define JPGPU_SF_WAVES 4
+#endif
+constexpr int subseq_final_waves(int n_slots) { return n_slots <= 5 ? JPGPU_SF_WAVES : 4; }
 // subsequences per lane of the K2S final pass (1: 8.1 ms per 1024 x 4K; 2: see DESIGN.md)
 #ifndef JPGPU_SF_SUBS
 #define JPGPU_SF_SUBS 2

@@ -3604,7 +3604,7 @@ __global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__rest
 // (First version: the generic word reader and symbol decoder, 11.0 ms per 1024 x 4K against K2's 5.7.  Second, rounds 2-3:
 // K2's ring and symbol step with BLOCK-aligned ownership -- lanes at different blocks of their MCUs, so the tables were
 // picked per lane and a lock-step iteration mixed long luma with short chroma blocks: 8.3 ms.)
-constexpr int kSubFinalMaxWaves = 4;  // the launch picks subseq_final_waves(n_slots)
+constexpr int kSubFinalMaxWaves = JPGPU_SF_WAVES > 4 ? JPGPU_SF_WAVES : 4;  // the launch picks subseq_final_waves(n_slots)
 constexpr int kSfWaveBytes = kK2WaveBytes + 64 * 2 * (int)sizeof(uint32_t);  // K2's staging + rings, then (first MCU, count) per lane
 __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
                                                                            const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
