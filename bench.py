@@ -396,7 +396,7 @@ def main():
     # Two batches in flight (two contexts = two streams, inputs of both resident) is what a caller who has more than one
     # batch does about it; reported beside `value`, never as `value`
     two_in_flight = None
-    if rank == 0 and args.workload == "4k_progressive":
+    if rank == 0 and args.workload == "4k_progressive" and not os.environ.get("JPGPU_PROG_BY_SCAN"):  # (not under the per-scan profiling switch)
         try:
             ctx2 = jl.Context(local_rank)
             other = jl.Batch(ctx2).upload(files, fmt)
