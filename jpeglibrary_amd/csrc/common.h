@@ -98,6 +98,9 @@ struct alignas(16) DevScan {
     uint16_t vblocks[kMaxScanComponents];   // blocks outside it go to the allocator's dummy block, i.e. nowhere
     uint32_t units_per_line;   // non-interleaved scan: blocks per line walked by the scan (:146-147)
     uint32_t dep[3];           // pipelined launch: scan jobs this scan follows (kNoDep = none), see progressive_stream_kernel
+    uint32_t last_interval;    // progressive_scan_kernel: restart intervals behind this one are not decoded (0xFFFFFFFF: all; the
+                               // replay of a failed file stops where the reference threw)
+    uint32_t pad2[3];
 };
 constexpr uint32_t kNoDep = 0xFFFFFFFFu;
 constexpr uint64_t kScanStoreHoldsSamples = 1;

@@ -149,7 +149,7 @@ class PlanHandler final : public ScanHandler {
     // Dispose() of the progressive scan decoder: the frame's IDCT pass, then its entropy scans in file order
     void flush_progressive() {
         if (!prog_.active()) return;
-        if (!prog_.scans().empty() && jobs_) {
+        if (jobs_) {  // (also without a single recorded scan: Dispose() still flushes the allocator's blocks)
             jobs_->push_back(prog_.make_frame_job());
             for (ScanJob &j : prog_.scans()) jobs_->push_back(std::move(j));
             prog_geo_ = prog_.geo();
@@ -728,9 +728,12 @@ int DeviceBatch::upload_segments(const jpgpu_segment *segments, const int *segme
         if (img.swallow_job >= 0) img.swallow_job += (int)first_job;
     }
     plans.clear();
+    replay_done_ = false;
+    prog_by_scan_ = false;
     files_resident_ = true;
     rc = layout_and_upload(file_ptr, file_len);
     files_resident_ = false;
+    replay_possible_ = rc == JPGPU_OK && !entropy_only_;
     ingest_.layout_ms = ms_since(t0);
     ingest_.total_ms = ms_since(t_begin);
     return rc;
@@ -1226,6 +1229,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             memset(&s, 0, sizeof s);
             const BaselineGeometry &g = job.geo;
             s.kind = (uint8_t)job.kind;
+            s.last_interval = job.last_interval;
             s.data_off = img.file_offset + job_entropy_off_[j];
             s.data_len = (uint32_t)(file_len[ii] - job_entropy_off_[j]);
             if (job.kind == kScanFrameOnly) s.data_len = 0;
@@ -1320,7 +1324,9 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             if (job.kind == kScanProgressive) {
                 // launch groups: dependency levels; JPGPU_PROG_BY_SCAN=1 (profiling aid): scan k of every frame in a launch of its
                 // own, in file order -- one kernel duration per scan kind of the script (tools/trace/progressive_by_scan.sh)
-                static const bool by_scan = getenv("JPGPU_PROG_BY_SCAN") != nullptr;
+                static const bool by_scan_env = getenv("JPGPU_PROG_BY_SCAN") != nullptr;
+                const bool by_scan = by_scan_env || prog_by_scan_;
+                if (job.disabled) continue;  // (replay of a failed file: the reference never got to this scan; K1 still indexes it)
                 const int ordinal = by_scan ? j - img.jobs[0] - 1 : job.ordinal;
                 if (by_scan) prog_pipelined_ = false;
                 if ((size_t)ordinal >= prog_work_by_ordinal.size()) {
@@ -1334,7 +1340,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 // after every progress word -- a producer its followers catch up with, which the launches only produce by chance
                 if (dbg_delay_scan >= 0 && dbg_delay_scan == j - img.jobs[0] - 1) s.debug_delay_ms = (uint8_t)std::min(255, std::max(0, dbg_delay_ms));
                 if (job.n_deps > 3 || s.n_intervals != 1 || s.n_intervals > stream_max_intervals) prog_pipelined_ = false;
-                if (s.n_intervals <= stream_max_intervals) {
+                if (s.n_intervals <= stream_max_intervals && !job.force_lane) {
                     for (uint32_t i = 0; i < s.n_intervals; i++) prog_streams_by_ordinal[ordinal].push_back({(uint32_t)j, i});
                     // chain of the scan: DC scans (interleaved, or Ss = 0) touch coefficient 0 only, an AC scan the band of ONE
                     // component (what it may write beyond its header stays inside that component's AC coefficients)
@@ -1691,7 +1697,7 @@ int DeviceBatch::run_subseq_sync(const uint32_t **final_state, const uint32_t **
     return mark_work();
 }
 int DeviceBatch::run_progressive() {
-    if (prog_begin_.size() <= 1) return JPGPU_OK;
+    if (prog_begin_.size() <= 1 && prog_clear_.empty()) return JPGPU_OK;
     status_valid_ = false;
     // every frame's store starts from zero (JpegBlockAllocator.Allocate clears it, JpegBlockAllocator.cs:81-83)
     for (const auto &c : prog_clear_) {
@@ -1699,6 +1705,7 @@ int DeviceBatch::run_progressive() {
         hipError_t e = hipMemsetAsync((int16_t *)d_coefs_.ptr + c.first * 64, 0, (size_t)c.second * 128, ctx_->stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(progressive store)");
     }
+    if (prog_begin_.size() <= 1) return JPGPU_OK;  // (frames without a single scan to run: their stores are zero now, that is all)
     const char *dbg_max = getenv("JPGPU_DEBUG_MAX_PROGRESSIVE_SCANS");  // debugging aid: stop after N scans per frame
     // One pipelined launch, or one launch per level?  One wave per workgroup, LDS bounds them per CU.
     //  - up to three quarters of what the CUs hold: pipelined with the count-in gate (every workgroup resident, see the
@@ -1732,7 +1739,7 @@ int DeviceBatch::run_progressive() {
     const bool fits = resident || force;
     const int launch_mode = resident && !force ? 1 : 2;
     const bool no_chains = getenv("JPGPU_PROG_NO_CHAINS") != nullptr;  // A/B switch: level-by-level launches instead
-    if (!(prog_pipelined_ && fits) && prog_chains_ok_ && !no_chains && !dbg_max && getenv("JPGPU_PROG_BY_SCAN") == nullptr && n_streams > 0) {
+    if (!(prog_pipelined_ && fits) && prog_chains_ok_ && !no_chains && !dbg_max && getenv("JPGPU_PROG_BY_SCAN") == nullptr && !prog_by_scan_ && n_streams > 0) {
         // Batches that do not fit one resident launch.  Scans of different chains -- the DC scans; the AC scans of component 0,
         // 1, 2, 3 -- never touch the same coefficients, scans of one chain follow each other in file order: every chain gets a
         // stream of its own and one launch per ordinal (the j-th scan of the chain in every frame).  No waiting inside a
@@ -2025,7 +2032,79 @@ int DeviceBatch::fetch_status() {
         }
     }
     status_valid_ = true;
+    if (replay_possible_ && !replay_done_ && in_decode_request_) return replay_failed_progressive();
     return JPGPU_OK;
+}
+
+// The partial flush.  A progressive file that fails in the reference still reaches the writer: Decode()'s `finally` runs the scan
+// decoder's Dispose() (JpegDecoder.cs:545-549) over whatever the store holds at that moment -- the scans before the failing one
+// complete, the failing one up to where it threw, the later ones never -- with the component slots as the failing scan's
+// InitDecodeComponents left them (ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs:60, 421-470), and only then the exception leaves.
+// The batch decodes the scans of a frame side by side, so after a failure its store is not that store.  Once per upload, when
+// a frame has failed, the step is issued again for the whole batch with: the scans of every frame one after the other in file
+// order; in a failed frame the scans behind the failing one left out and the failing one on the kernel that walks and stores
+// coefficient by coefficient like the reference (progressive_scan_kernel); the failed frames' Dispose() taken literally
+// (dispose_pass_kernel, slots as of the failing scan).  The status of the images does not change; their output is the partial flush.
+int DeviceBatch::replay_failed_progressive() {
+    struct Failed {
+        size_t image;
+        int failing;  // index of the failing scan in file order; = number of scans when the marker walk failed behind all of them
+    };
+    std::vector<Failed> failed;
+    for (size_t ii = 0; ii < images_.size(); ii++) {
+        const ImagePlan &img = images_[ii];
+        if (img.status != JPGPU_OK || img.jobs.size() < 1 || jobs_[img.jobs[0]].kind != kScanFrameOnly) continue;
+        int failing = -1;
+        for (size_t k = 1; k < img.jobs.size(); k++)
+            if (h_status_[(size_t)img.jobs[k]].first_error != kNoError) {
+                failing = (int)k - 1;
+                break;
+            }
+        if (failing < 0 && img.late_status != JPGPU_OK) failing = (int)img.jobs.size() - 1;
+        if (failing >= 0) failed.push_back({ii, failing});
+    }
+    replay_done_ = true;
+    if (failed.empty()) return JPGPU_OK;
+    for (const Failed &f : failed) {
+        const ImagePlan &img = images_[f.image];
+        const int n_scans = (int)img.jobs.size() - 1;
+        ScanJob &frame = jobs_[(size_t)img.jobs[0]];
+        // the decoder's component slots as of the failing scan (a slot keeps what the last scan with that many components put there)
+        int slot_comp[kMaxScanComponents];
+        QuantTable slot_q[kMaxScanComponents];
+        for (int i = 0; i < kMaxScanComponents; i++) slot_comp[i] = -1;
+        for (int k = 0; k < n_scans; k++) {
+            ScanJob &job = jobs_[(size_t)img.jobs[(size_t)k + 1]];
+            job.disabled = k > f.failing;
+            job.force_lane = k == f.failing;
+            if (k == f.failing) job.last_interval = h_status_[(size_t)img.jobs[(size_t)k + 1]].first_error >> 8;  // (the lowest failing interval)
+            if (k > f.failing) continue;
+            for (int i = 0; i < job.scan_components && i < kMaxScanComponents; i++) {
+                slot_comp[i] = job.comp[i].component_index;
+                slot_q[i] = job.quant_copy[i];
+            }
+        }
+        frame.dispose_generic = true;
+        frame.refuse.clear();
+        if (f.failing >= n_scans) continue;  // the marker walk failed behind every recorded scan: the slots are as the walk left them (make_frame_job)
+        for (int c = 0; c < kMaxScanComponents; c++) frame.dispose_n[c] = 0;
+        for (int i = 0; i < frame.geo.frame.num_components && i < kMaxScanComponents; i++) {
+            const int c = slot_comp[i];
+            if (c < 0 || c >= kMaxScanComponents || frame.dispose_n[c] >= kMaxScanComponents) continue;
+            frame.dispose_q[c][frame.dispose_n[c]++] = slot_q[i];
+        }
+    }
+    prog_by_scan_ = true;
+    prog_replays_++;
+    std::vector<const uint8_t *> fp(images_.size(), nullptr);
+    std::vector<size_t> fl(images_.size(), 0);
+    for (size_t ii = 0; ii < images_.size(); ii++) fl[ii] = images_[ii].file_len;
+    files_resident_ = true;
+    int rc = layout_and_upload(fp, fl);
+    files_resident_ = false;
+    if (rc != JPGPU_OK) return rc;
+    if ((rc = decode()) != JPGPU_OK) return rc;
+    return fetch_status();
 }
 
 int DeviceBatch::result(int i, jpgpu_image_result *res) {

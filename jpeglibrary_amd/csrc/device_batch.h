@@ -149,6 +149,7 @@ class DeviceBatch {
     void note_entropy_only_request() { in_decode_request_ = false; }
     int last_subseq_rounds() const { return last_subseq_rounds_; }
     int progressive_fallbacks() const { return prog_fallbacks_; }
+    int progressive_replays() const { return prog_replays_; }
     // the optimizer path only needs the files, the scan descriptors and the marker index: no coefficient / sample buffers
     void set_entropy_only(bool on) { entropy_only_ = on; }
     void set_preset_restart_intervals(std::vector<int> v) { preset_dri_ = std::move(v); }
@@ -220,6 +221,9 @@ class DeviceBatch {
     std::vector<DisposeJob> dispose_jobs_;
     uint32_t dispose_max_blocks_ = 0;
     int run_dispose_passes(hipStream_t stream);
+    int replay_failed_progressive();
+    bool replay_done_ = false, replay_possible_ = false, prog_by_scan_ = false;
+    int prog_replays_ = 0;
   public:
     int clear_progressive_stores();
   private:

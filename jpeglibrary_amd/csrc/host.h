@@ -221,6 +221,10 @@ struct ScanJob {
     int n_deps = 0;           // > 3: the frame's scans run level by level
     uint64_t dep_closure = 0; // every scan this one transitively depends on (bit = index in the frame's scan list)
     bool has_consumers = false;
+    // the partial flush of a progressive file that failed (DeviceBatch::replay_failed_progressive): scans behind the failing one
+    // never ran in the reference (disabled); the failing one runs on the kernel that walks and stores the way the reference does
+    bool disabled = false, force_lane = false;
+    uint32_t last_interval = 0xFFFFFFFFu;  // ... and not behind the restart interval in which it threw
     uint16_t scan_dri = 0;        // DRI as read at ProcessScan time (ref: ...ProgressiveScanDecoder.cs:78), not at SOF
     uint8_t frame_bpm = 0;
     uint8_t fblk_base[kMaxScanComponents] = {};
@@ -265,6 +269,7 @@ class ProgressiveFrame {
     BaselineGeometry geo_;
     int slots_alloc_ = 0;
     bool slot_set_[kMaxScanComponents] = {};
+    bool slot_noquant_[kMaxScanComponents] = {};  // the slot's component has no quantisation table (ProcessScan throws right behind InitDecodeComponents)
     ResolvedScanComponent slot_[kMaxScanComponents];
     QuantTable slot_quant_[kMaxScanComponents];
     uint16_t hblocks_[kMaxScanComponents] = {}, vblocks_[kMaxScanComponents] = {};

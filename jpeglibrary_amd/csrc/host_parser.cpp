@@ -724,7 +724,7 @@ void ProgressiveFrame::begin(const HostDecoder &dec, const FrameHeader &fh) {
     geo_ = BaselineGeometry::latch(dec, fh);
     geo_.restart_interval = 0;  // progressive scans read DRI per scan
     slots_alloc_ = fh.num_components;
-    for (int i = 0; i < kMaxScanComponents; i++) slot_set_[i] = false;
+    for (int i = 0; i < kMaxScanComponents; i++) slot_set_[i] = slot_noquant_[i] = false;
     // JpegBlockAllocator.Allocate: block grid of every component (ref: JpegBlockAllocator.cs:35-84)
     const int hb = (fh.samples_per_line + 7) / 8, vb = (fh.lines + 7) / 8;
     int base = 0;
@@ -765,7 +765,27 @@ void ProgressiveFrame::add_scan(const HostDecoder &dec, const ScanHeader &scan, 
         throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "A progressive scan without components is not supported.", kDetailUnsupportedFrame);
     if (scan.se > 63 || scan.ss > 63)  // the reference's block readers then walk into the next blocks of its store
         throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "A spectral selection beyond coefficient 63 is not supported.", kDetailUnsupportedFrame);
-    job.scan_components = dec.resolve_scan(fh, scan, job.comp);  // InitDecodeComponents (:60)
+    // InitDecodeComponents (:60) fills the decoder's component slots one by one, BEFORE any of ProcessScan's own checks: whatever
+    // fails afterwards (or half-way through it), Dispose() -- which Decode()'s `finally` still runs -- iterates the slots as they
+    // stand then
+    for (int i = 0; i < kMaxScanComponents; i++) job.comp[i].component_index = -1;
+    auto record_slots = [&] {
+        for (int i = 0; i < kMaxScanComponents; i++) {
+            const ResolvedScanComponent &c = job.comp[i];
+            if (c.component_index < 0) continue;
+            slot_[i] = c;
+            slot_noquant_[i] = c.quant == nullptr;
+            if (c.quant) slot_quant_[i] = *c.quant;
+            slot_set_[i] = true;
+        }
+    };
+    try {
+        job.scan_components = dec.resolve_scan(fh, scan, job.comp);
+    } catch (...) {
+        record_slots();
+        throw;
+    }
+    record_slots();
     for (int i = 0; i < job.scan_components; i++) {  // :63-69
         if (!job.comp[i].quant)
             throw_invalid_data("Failed to decode JPEG data. Quantization table of component " + std::to_string(job.comp[i].component_index) + " is not defined.",
@@ -801,10 +821,6 @@ void ProgressiveFrame::add_scan(const HostDecoder &dec, const ScanHeader &scan, 
         job.fblk_base[i] = fblk_base_[c.component_index];
         job.hblocks[i] = hblocks_[c.component_index];
         job.vblocks[i] = vblocks_[c.component_index];
-        // the decoder's component slots as the Dispose() pass will find them
-        slot_[i] = c;
-        slot_quant_[i] = *c.quant;
-        slot_set_[i] = true;
     }
     if (interleaved) {
         job.units_per_line = (uint32_t)geo_.mcus_per_line;
@@ -858,7 +874,7 @@ ScanJob ProgressiveFrame::make_frame_job() const {
     for (int i = 0; i < kMaxScanComponents; i++) slot_of_component[i] = -1;
     bool ok = true;
     for (int i = 0; i < slots_alloc_; i++) {
-        if (!slot_set_[i]) ok = false;
+        if (!slot_set_[i] || slot_noquant_[i]) ok = false;
         else if (slot_of_component[slot_[i].component_index] >= 0) ok = false;
         else slot_of_component[slot_[i].component_index] = i;
     }
@@ -892,10 +908,10 @@ ScanJob ProgressiveFrame::make_frame_job() const {
     BaselineGeometry g = BaselineGeometry::latch(tmp, f2);
     ScanJob job = make_scan_job(tmp, g, sh, nullptr, 0);
     job.kind = kScanFrameOnly;
-    if (generic) {
-        job.dispose_generic = true;
+    job.dispose_generic = generic;
+    {   // (always written down: the partial flush of a file that fails later takes the slots as the host's walk left them)
         for (int i = 0; i < slots_alloc_; i++) {
-            if (!slot_set_[i]) continue;
+            if (!slot_set_[i] || slot_noquant_[i]) continue;  // (a slot without a table: the reference's Debug.Assert; the checker skips it)
             const int c = slot_[i].component_index;
             if (c < 0 || c >= kMaxScanComponents || job.dispose_n[c] >= kMaxScanComponents) continue;
             job.dispose_q[c][job.dispose_n[c]++] = slot_quant_[i];

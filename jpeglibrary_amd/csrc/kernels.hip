@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(kProgThreads) void progressive_scan_kernel(const ui
     const uint32_t total_units = s.total_mcus;
     const uint32_t dri_eff = s.dri ? s.dri : total_units;
     const uint32_t interval = wk.first_interval + tid;
-    if (interval >= n_ends) return;  // nothing after the last barrier: lanes may leave
+    if (interval >= n_ends || interval > s.last_interval) return;  // nothing after the last barrier: lanes may leave
     const uint32_t *eu = ends_u + s.ends_off;
     const uint32_t ustart = interval == 0 ? 0u : eu[interval - 1] + 2u;
     UBits r;
@@ -1451,12 +1451,14 @@ __global__ __launch_bounds__(kProgThreads) void progressive_scan_kernel(const ui
         uint64_t mm_ = (m_);                                                                            \
         uint32_t left_ = (uint32_t)__builtin_popcountll(mm_);                                           \
         while (left_ != 0 && err == 0) {                                                                \
-            const uint32_t n_ = left_ < 16u ? left_ : 16u;                                              \
-            uint32_t field_;                                                                            \
-            if (!ub_try_read_bits(r, n_, field_)) {                                                     \
-                err = kDetailUnexpectedEnd;                                                             \
-                break;                                                                                  \
-            }                                                                                           \
+            uint32_t n_ = left_ < 16u ? left_ : 16u;                                                    \
+            uint32_t field_ = 0;                                                                        \
+            /* the reference reads these one at a time: when the data ends inside the field, the corrections in   */ \
+            /* front of the end are applied before it throws (the partial flush of a failing file shows them)      */ \
+            const bool short_ = (int32_t)n_ > r.rem;                                                    \
+            if (short_) n_ = r.rem > 0 ? (uint32_t)r.rem : 0u;                                          \
+            if (n_ != 0) (void)ub_try_read_bits(r, n_, field_);                                         \
+            if (short_) err = kDetailUnexpectedEnd;                                                     \
             for (uint32_t i_ = 0; i_ < n_; i_++) {                                                      \
                 const uint32_t pos_ = (uint32_t)__builtin_ctzll(mm_);                                   \
                 mm_ &= mm_ - 1;                                                                         \

@@ -110,6 +110,19 @@ def decode_8bit(data: bytes, component_count=None):
     return out, info
 
 
+def decode_8bit_partial(data: bytes, component_count=None):
+    """decode_8bit that also hands back what a FAILING decode left in the writer's buffer: Decode()'s `finally` disposes the scan
+    decoder, and a progressive one then flushes whatever its store holds (JpegDecoder.cs:545-549).  Returns (array, Info, error):
+    error is None for a clean decode, else the OracleError that decode_8bit would have raised."""
+    L = lib()
+    info, _ = identify(data)
+    cc = component_count or info.ncomp
+    out = np.zeros((info.height, info.width, cc), dtype=np.uint8)
+    err = C.create_string_buffer(256)
+    rc = L.jref_decode_to_8bit(data, len(data), cc, out.ctypes.data, out.size, C.byref(info), err, 256)
+    return out, info, (OracleError(rc, err.value.decode()) if rc != 0 else None)
+
+
 def decode_16bit(data: bytes, component_count=4):
     """Identify + Decode into the xunit test writer's u16 x4 buffer (O3). Returns (array[H,W,C] u16, Info)."""
     L = lib()
