@@ -248,6 +248,10 @@ int jpgpu_batch_upload_frames(jpgpu_batch *b, const jpgpu_frame *frames, const u
  * jpgpu_batch_stage_ms query and every 8th after it still run serially so that stage times exist.  Off by default: it
  * stopped paying once both stages became HBM-heavy.  Results do not depend on the issue order. */
 int jpgpu_batch_decode(jpgpu_batch *b);
+/* A progressive (SOF2) file that FAILS still leaves what the reference leaves in the writer's buffer: Decode()'s finally disposes the
+ * scan decoder, which transforms and flushes the partial store (JpegDecoder.cs:545-549).  jpgpu_batch_result reports the failure,
+ * jpgpu_batch_download_output of that image returns the partial picture (the step is issued a second time for such a batch, once
+ * per upload; sequential files write nothing on failure that the reference would not). */
 /* Individual stages, for stage-level parity tests and profiling. */
 int jpgpu_batch_run_entropy(jpgpu_batch *b); /* marker index + Huffman -> coefficient buffer */
 int jpgpu_batch_run_idct(jpgpu_batch *b);    /* coefficient buffer -> output */
@@ -354,10 +358,12 @@ int jpgpu_decode_scan(jpgpu_ctx *ctx, const jpgpu_frame *frame, const jpgpu_scan
  *                              the LAST scans left in the decoder's component slots, then
  *                              JpegBlockAllocator.Flush (JpegBlockAllocator.cs:120-190) into `out` in `format`
  *                              (jpgpu_progressive_output_size says how large), or, _to_writer, as WriteBlock calls in Flush's order.
- *                              Scan orders whose slots do not cover every component once return JPGPU_ERR_NOT_SUPPORTED.
- *                              After a failing scan the store holds what the kernels wrote before they stopped (the reference
- *                              flushes its partial store from Decode's finally; the blocks in front of the failing restart
- *                              interval are the same, the rest is not reproduced).
+ *                              Scan orders whose slots do not cover every component once are disposed the way the reference does it
+ *                              (a component transformed twice, another never: dispose_pass_kernel); a session without any scan
+ *                              flushes the zeroed store.  After a FAILING jpgpu_progressive_scan the store of this per-scan session
+ *                              holds what the kernels wrote before they stopped: the blocks in front of the failing restart
+ *                              interval are the reference's, the rest is not (the batch entry points, which see the whole file,
+ *                              do reproduce the reference's partial flush: jpgpu_batch_decode below).
  */
 typedef struct jpgpu_progressive jpgpu_progressive;
 int jpgpu_progressive_begin(jpgpu_ctx *ctx, const jpgpu_frame *frame, jpgpu_progressive **out);
