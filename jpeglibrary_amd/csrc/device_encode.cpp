@@ -326,10 +326,16 @@ int EncodeBatch::encode() {
     e = hipMemcpyAsync(d_images_.ptr, images_.data(), (size_t)n * sizeof(DevEncImage), hipMemcpyHostToDevice, ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(images)");
     size_t max_record = 0;
-    for (const DevEncImage &im : images_) max_record = std::max(max_record, enc_sample_bytes_per_mcu(im.luma_h, im.luma_v, im.components));
+    bool any_fused = false, any_other = false;
+    static const bool no_fused = getenv("JPGPU_ENC_NO_FUSED") != nullptr;  // (measurement: E1 as its two kernels for every image)
+    for (const DevEncImage &im : images_) {
+        max_record = std::max(max_record, enc_sample_bytes_per_mcu(im.luma_h, im.luma_v, im.components));
+        if (!no_fused && enc_image_fused(im)) any_fused = true;
+        else any_other = true;
+    }
     (void)hipEventRecord(ev_[0], ctx_->stream);
     e = launch_fdct_quant(ctx_->stream, (const uint8_t *)d_pixels_.ptr, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_mcu_.ptr, n_work_mcu_,
-                          (uint8_t *)d_samples_.ptr, (int16_t *)d_coefs_.ptr, max_record);
+                          (uint8_t *)d_samples_.ptr, (int16_t *)d_coefs_.ptr, max_record, any_fused, any_other);
     if (e != hipSuccess) return hip_fail(e, "fdct_quant_kernel");
     if (!optimized_.empty()) {
         // optimizeCoding: BuildHuffmanTables (:491-550) -- statistics on the device, JpegHuffmanEncodingTableBuilder.Build on the host

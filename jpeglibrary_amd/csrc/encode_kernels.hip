@@ -28,22 +28,26 @@ __device__ constexpr uint8_t kEncNat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 
 
 // FDCT8x4_LeftPart / RightPart for one column of eight values (ref: FastFloatingPointDCT.cs:194-311).
 // Operation order and parenthesisation are normative.
-__device__ __forceinline__ void fdct8(float &s0, float &s1, float &s2, float &s3, float &s4, float &s5, float &s6, float &s7) {
-    float c0 = s0, c1 = s7;
-    const float t0 = c0 + c1, t7 = c0 - c1;
+// T = float, or two floats side by side (EncF2: the same row or column of two blocks, one v_pk_* instruction for both --
+// every component one IEEE operation, never fused).
+typedef float EncF2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ void fdct8(T &s0, T &s1, T &s2, T &s3, T &s4, T &s5, T &s6, T &s7) {
+    T c0 = s0, c1 = s7;
+    const T t0 = c0 + c1, t7 = c0 - c1;
     c1 = s6;
     c0 = s1;
-    const float t1 = c0 + c1, t6 = c0 - c1;
+    const T t1 = c0 + c1, t6 = c0 - c1;
     c1 = s5;
     c0 = s2;
-    const float t2 = c0 + c1, t5 = c0 - c1;
+    const T t2 = c0 + c1, t5 = c0 - c1;
     c0 = s3;
     c1 = s4;
-    const float t3 = c0 + c1, t4 = c0 - c1;
+    const T t3 = c0 + c1, t4 = c0 - c1;
     c0 = t0 + t3;
-    float c3 = t0 - t3;
+    T c3 = t0 - t3;
     c1 = t1 + t2;
-    float c2 = t1 - t2;
+    T c2 = t1 - t2;
     s0 = c0 + c1;
     s4 = c0 - c1;
     float w0 = 0.541196f, w1 = 1.306563f;
@@ -75,6 +79,11 @@ __device__ __forceinline__ void block_fdct(float (&f)[64]) {
     for (int c = 0; c < 8; c++) fdct8(f[0 * 8 + c], f[1 * 8 + c], f[2 * 8 + c], f[3 * 8 + c], f[4 * 8 + c], f[5 * 8 + c], f[6 * 8 + c], f[7 * 8 + c]);
 #pragma unroll
     for (int i = 0; i < 64; i++) f[i] = f[i] * 0.1250f;
+}
+
+// The shape fdct_fused_kernel takes (E1 as one kernel); every other shape goes through E1a + E1b.
+__host__ __device__ inline bool enc_fused_ok(const DevEncImage &im) {
+    return im.components == 3 && im.in_components == 3 && im.luma_h == 2 && im.luma_v == 2;
 }
 
 // What the sample reader needs from the image descriptor, held in registers (the descriptor is read once).
@@ -306,10 +315,11 @@ __device__ __forceinline__ void enc_gather_rows(const EncSrc &src, uint32_t x0, 
 // for the 1.06 GB of samples of 64 images (tools/trace/encoder_pmc.sh).  Not STAGE: records too large for 64 KB of LDS.
 template <bool STAGE>
 __global__ __launch_bounds__(8 * kEncMcusPerWg) void enc_gather_kernel(const uint8_t *__restrict__ pixels, const DevEncImage *__restrict__ images,
-                                                                       const EncWork *__restrict__ work, uint8_t *__restrict__ samples) {
+                                                                       const EncWork *__restrict__ work, uint8_t *__restrict__ samples, bool skip_fused) {
     extern __shared__ __attribute__((aligned(16))) uint8_t sh_records[];
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
+    if (skip_fused && enc_fused_ok(im)) return;  // (uniform: fdct_fused_kernel takes the image)
     const uint32_t m = threadIdx.x % kEncMcusPerWg, k = threadIdx.x / kEncMcusPerWg;
     const uint32_t mcus_per_line = im.mcus_per_line;
     const uint32_t n_mcus = mcus_per_line * im.mcus_per_column;
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(8 * kEncMcusPerWg) void enc_gather_kernel(const uin
 #define JPGPU_E1B_WAVES 1
 #endif
 __global__ __launch_bounds__(kEncMcusPerWg, JPGPU_E1B_WAVES) void fdct_quant_kernel(const uint8_t *__restrict__ samples, const DevEncImage *__restrict__ images,
-                                                                   const EncWork *__restrict__ work, int16_t *__restrict__ coefs) {
+                                                                   const EncWork *__restrict__ work, int16_t *__restrict__ coefs, bool skip_fused) {
     __shared__ QuantPair sh_q[2][64];  // the two quantisation tables as (divisor, refined reciprocal)
     // a wave's 64 blocks (one per lane, 128 bytes each) on their way out: every lane's eight 16-byte rows, then eight lanes per
     // block write it as ONE 128-byte line -- a lane storing its own block touches 64 lines with every store instruction and
@@ -374,6 +384,7 @@ __global__ __launch_bounds__(kEncMcusPerWg, JPGPU_E1B_WAVES) void fdct_quant_ker
     __shared__ __attribute__((aligned(16))) uint8_t sh_blk[kEncMcusPerWg * 128];
     const EncWork wk = work[blockIdx.x];
     const DevEncImage &im = images[wk.image];
+    if (skip_fused && enc_fused_ok(im)) return;
     const uint32_t lane = threadIdx.x;
     if (lane < 64) {
         sh_q[0][lane] = quant_pair(im.quant[0][lane]);
@@ -454,6 +465,239 @@ __global__ __launch_bounds__(kEncMcusPerWg, JPGPU_E1B_WAVES) void fdct_quant_ker
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read before the next block's rows overwrite it
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ E1 fused
+//
+// E1 as ONE kernel for the usual shape (three components from three-sample pixels, luma 2 x 2: enc_fused_ok): pixels in,
+// quantised blocks out, nothing in between leaves the CU.  E1a + E1b move the gathered samples through HBM (4.2 GB out and
+// in again per 256 x 4K) and E1b holds a whole block per lane (245 registers, two waves per SIMD).  Here a WAVE owns 16
+// consecutive MCUs and every step runs on all 64 lanes, two rows / columns per lane as one packed float pair:
+//   gather (2 rounds of 8 MCUs)  lane = (MCU, chroma row k): two pixel rows of 16 pixels, converted once; chroma 2 x 2 sums to
+//                                LDS; the four luma rows it holds go through pass 1 (rows) in registers -> transpose buffer
+//   luma pass 2 (2 per gather)   lane = (column c, blocks A and A + 8): pass 2, x 0.125, quantise, (short) -> the block's
+//                                zig-zag position in the staging buffer; 16 finished blocks leave as whole 128-byte lines
+//   Cb, then Cr                  pass 1: lane = (row, MCUs m and m + 8), the sample = box average started from the PREVIOUS
+//                                block's quantised coefficients (ReadBlockWithSubsample adds into the one buffer
+//                                WriteScanData reuses: Cb from Y3, Cr from Cb; not with optimizeCoding); pass 2 as for luma
+// A wave never waits for another one (LDS operations of one wave complete in order): no barrier in the kernel.
+// Arithmetic is E1a's and E1b's, operation for operation (the FDCT butterflies as v_pk_add_f32 / v_pk_mul_f32, the quotient
+// of quant_divide as v_pk_mul_f32 + 4 v_pk_fma_f32 on the same operands).
+
+// natural index (8 r + c) -> zig-zag position: the inverse of kEncNat
+__device__ constexpr uint8_t kEncZig[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
+                                            41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
+                                            46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+
+constexpr int kEfMcus = 16;                     // MCUs per wave (= workgroup)
+constexpr uint32_t kEfBlkStride = 72u * 4u;     // transpose buffer: bytes from block to block (72 floats: the columns of eight
+                                                // blocks, eight lanes each, fall on 64 different banks)
+constexpr uint32_t kEfT = 0;                    // 32 luma blocks of 8 MCUs after pass 1 (later: 16 chroma blocks)
+constexpr uint32_t kEfSums = kEfT + 32u * kEfBlkStride;  // chroma 2 x 2 sums: [MCU][Cb, Cr][row] x 8 int16
+constexpr uint32_t kEfStage = kEfSums + kEfMcus * 2u * 128u;  // 16 finished blocks (zig-zag int16) on their way out
+constexpr uint32_t kEfCarry = kEfStage + 16u * 128u;     // block Y3 of every MCU: what its Cb block starts from
+constexpr uint32_t kEfLdsBytes = kEfCarry + kEfMcus * 128u;
+
+typedef uint32_t EncU4 __attribute__((ext_vector_type(4)));
+
+// pass 2 of 16 blocks in the transpose buffer: lane (c, p) takes column c of blocks first + p and first + 8 + p
+__device__ __forceinline__ void ef_pass2(uint8_t *sh, uint32_t first, uint32_t c, uint32_t p, const EncF2 (&qp)[8], const uint32_t (&zz)[8]) {
+    const float *ta = reinterpret_cast<const float *>(sh + kEfT + (first + p) * kEfBlkStride) + c;
+    const float *tb = reinterpret_cast<const float *>(sh + kEfT + (first + 8u + p) * kEfBlkStride) + c;
+    EncF2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = EncF2{ta[r * 8], tb[r * 8]};
+    fdct8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    uint8_t *oa = sh + kEfStage + p * 128u, *ob = oa + 8u * 128u;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const EncF2 a = v[r] * 0.1250f;
+        const EncF2 D = EncF2{qp[r].x, qp[r].x}, R = EncF2{qp[r].y, qp[r].y};
+        const EncF2 q0 = a * R;
+        const EncF2 q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-D, q0, a), R, q0);
+        const EncF2 q = __builtin_elementwise_fma(__builtin_elementwise_fma(-D, q1, a), R, q1);  // quant_divide, both halves
+        *reinterpret_cast<uint16_t *>(oa + zz[r]) = (uint16_t)(int32_t)__builtin_rintf(q.x);  // half to even; (short) wraps
+        *reinterpret_cast<uint16_t *>(ob + zz[r]) = (uint16_t)(int32_t)__builtin_rintf(q.y);
+    }
+}
+
+__global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restrict__ pixels, const DevEncImage *__restrict__ images,
+                                                        const EncWork *__restrict__ work, int16_t *__restrict__ coefs) {
+    __shared__ __attribute__((aligned(16))) uint8_t sh[kEfLdsBytes];
+    constexpr uint32_t kPerItem = kEncMcusPerWg / kEfMcus;
+    const EncWork wk = work[blockIdx.x / kPerItem];
+    const DevEncImage &im = images[wk.image];
+    if (!enc_fused_ok(im)) return;  // (E1a + E1b take these)
+    const uint32_t mcus_per_line = im.mcus_per_line;
+    const uint32_t n_mcus = mcus_per_line * im.mcus_per_column;
+    const uint32_t base = wk.first + (blockIdx.x % kPerItem) * kEfMcus;
+    if (base >= n_mcus) return;
+    const uint32_t lane = threadIdx.x, lo = lane & 7u, hi = lane >> 3;
+    const uint32_t width = im.width, height = im.height;
+    const uint8_t *px = pixels + im.px_off;
+    const bool own_blocks = im.table_base != 0;
+    int16_t *out = coefs + im.coef_off * 64;
+
+    // what a lane needs for its column lo of a block: the zig-zag positions of the eight rows, the two tables' divisors there
+    EncF2 qy[8], qc[8];
+    uint32_t zz[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t z = kEncZig[r * 8 + lo];
+        zz[r] = z * 2u;
+        const QuantPair a = quant_pair(im.quant[0][z]), b = quant_pair(im.quant[1][z]);
+        qy[r] = EncF2{a.d, a.r};
+        qc[r] = EncF2{b.d, b.r};
+    }
+    // JpegRgbToYCbCrConverter as nine factors and two offsets; pixels that are Y, Cb, Cr already pass through the same lines.
+    // (the luma offset carries ShiftDataLevel's -128: subtracting 128 << 16 in front of >> 16 is subtracting 128 behind it)
+    int32_t fy[3], fb[3], fr[3], oy, oc;
+    if (im.input_rgb != 0) {
+        fy[0] = im.r2y[0], fy[1] = im.r2y[1], fy[2] = im.r2y[2];
+        fb[0] = -im.r2y[3], fb[1] = -im.r2y[4], fb[2] = im.r2y[5];
+        fr[0] = im.r2y[5], fr[1] = -im.r2y[6], fr[2] = -im.r2y[7];
+        oy = 32768 - (128 << 16), oc = (128 << 16) + 32767;
+    } else {
+        fy[0] = 65536, fy[1] = 0, fy[2] = 0;
+        fb[0] = 0, fb[1] = 65536, fb[2] = 0;
+        fr[0] = 0, fr[1] = 0, fr[2] = 65536;
+        oy = -(128 << 16), oc = 0;
+    }
+    const bool rows_aligned = ((width * 3u) & 3u) == 0;
+
+#pragma unroll 1
+    for (uint32_t g = 0; g < 2; g++) {
+        // ---- gather: lane = (MCU lo of this round, chroma row hi)
+        {
+            const uint32_t mloc = g * 8u + lo, k = hi;
+            const uint32_t mcu = base + mloc < n_mcus ? base + mloc : n_mcus - 1;  // lanes behind the last MCU redo it, and store nothing
+            const uint32_t x0 = (mcu % mcus_per_line) * 16u, y0 = (mcu / mcus_per_line) * 16u + 2u * k;
+            uint32_t w[2][12];
+            uint32_t inside[2] = {0xFFFFu, 0xFFFFu};  // the row's pixels that lie inside the image
+            const bool whole = x0 + 16 <= width && y0 + 2 <= height && rows_aligned;
+            if (whole) {
+#pragma unroll
+                for (int dy = 0; dy < 2; dy++) __builtin_memcpy(w[dy], __builtin_assume_aligned(px + ((size_t)(y0 + dy) * width + x0) * 3, 4), 48);
+            } else {
+                // the edge of the image: outside it the reader leaves zeros (JpegBufferInputReader.cs:27-52); any row alignment
+#pragma unroll
+                for (int dy = 0; dy < 2; dy++) {
+#pragma unroll
+                    for (int j = 0; j < 12; j++) w[dy][j] = 0;
+                    inside[dy] = 0;
+                    if (y0 + dy < height) {
+                        const uint8_t *rowp = px + ((size_t)(y0 + dy) * width + x0) * 3;
+                        const uint32_t np = x0 >= width ? 0u : (width - x0 < 16u ? width - x0 : 16u), nb = np * 3u;
+                        inside[dy] = (1u << np) - 1u;
+                        for (uint32_t j = 0; j < nb; j++) {
+                            const uint32_t bv = (uint32_t)rowp[j] << (8u * (j & 3u));
+#pragma unroll
+                            for (int q = 0; q < 12; q++)
+                                if ((j >> 2) == (uint32_t)q) w[dy][q] |= bv;
+                        }
+                    }
+                }
+            }
+            int32_t sb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            EncF2 v[2][8];
+#pragma unroll
+            for (int dy = 0; dy < 2; dy++) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int32_t b0 = (w[dy][(3 * i) >> 2] >> (8 * ((3 * i) & 3))) & 0xFF;
+                    const int32_t b1 = (w[dy][(3 * i + 1) >> 2] >> (8 * ((3 * i + 1) & 3))) & 0xFF;
+                    const int32_t b2 = (w[dy][(3 * i + 2) >> 2] >> (8 * ((3 * i + 2) & 3))) & 0xFF;
+                    const int32_t yv = (__mul24(fy[0], b0) + (__mul24(fy[1], b1) + (__mul24(fy[2], b2) + oy))) >> 16;
+                    sb[i >> 1] += (__mul24(fb[0], b0) + (__mul24(fb[1], b1) + (__mul24(fb[2], b2) + oc))) >> 16;
+                    sr[i >> 1] += (__mul24(fr[0], b0) + (__mul24(fr[1], b1) + (__mul24(fr[2], b2) + oc))) >> 16;
+                    if (i < 8) v[dy][i].x = (float)yv;
+                    else v[dy][i - 8].y = (float)yv;
+                }
+            }
+            if (!whole) {
+                // a pixel outside the image is the SAMPLE zero in every component, not the conversion of a black pixel: the
+                // zero bytes above gave luma 0 (- 128) but chroma `oc >> 16` (128 from RGB) -- taken out of the sums again
+                const int32_t off = oc >> 16;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int32_t n_out = 4 - (int32_t)__builtin_popcount((inside[0] >> (2 * j)) & 3u) - (int32_t)__builtin_popcount((inside[1] >> (2 * j)) & 3u);
+                    sb[j] -= n_out * off;
+                    sr[j] -= n_out * off;
+                }
+            }
+            *reinterpret_cast<uint4 *>(sh + kEfSums + ((mloc * 2u + 0u) * 8u + k) * 16u) = pack8_i16(sb);
+            *reinterpret_cast<uint4 *>(sh + kEfSums + ((mloc * 2u + 1u) * 8u + k) * 16u) = pack8_i16(sr);
+            // pass 1 of the lane's four luma rows: rows 2k and 2k + 1 of the MCU, left and right block side by side
+#pragma unroll
+            for (int dy = 0; dy < 2; dy++) {
+                fdct8(v[dy][0], v[dy][1], v[dy][2], v[dy][3], v[dy][4], v[dy][5], v[dy][6], v[dy][7]);
+                const uint32_t ry = 2u * k + (uint32_t)dy;
+                float *t = reinterpret_cast<float *>(sh + kEfT + (lo * 4u + (ry >> 3) * 2u) * kEfBlkStride) + (ry & 7u) * 8u;
+                *reinterpret_cast<float4 *>(t) = float4{v[dy][0].x, v[dy][1].x, v[dy][2].x, v[dy][3].x};
+                *reinterpret_cast<float4 *>(t + 4) = float4{v[dy][4].x, v[dy][5].x, v[dy][6].x, v[dy][7].x};
+                float *t1 = t + kEfBlkStride / 4u;
+                *reinterpret_cast<float4 *>(t1) = float4{v[dy][0].y, v[dy][1].y, v[dy][2].y, v[dy][3].y};
+                *reinterpret_cast<float4 *>(t1 + 4) = float4{v[dy][4].y, v[dy][5].y, v[dy][6].y, v[dy][7].y};
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- luma pass 2: the 32 blocks of this round, 16 at a time
+#pragma unroll 1
+        for (uint32_t h = 0; h < 2; h++) {
+            ef_pass2(sh, h * 16u, lo, hi, qy, zz);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (uint32_t j = 0; j < 2; j++) {
+                const uint32_t i = lane + 64u * j, q = i >> 3, piece = i & 7u;
+                const uint32_t tblk = h * 16u + q, mloc = g * 8u + (tblk >> 2), yb = tblk & 3u;
+                const uint4 val = *reinterpret_cast<const uint4 *>(sh + kEfStage + i * 16u);
+                if (base + mloc < n_mcus) *reinterpret_cast<uint4 *>(out + ((uint64_t)(base + mloc) * 6u + yb) * 64u + piece * 8u) = val;
+                if (yb == 3u) *reinterpret_cast<uint4 *>(sh + kEfCarry + mloc * 128u + piece * 16u) = val;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    // ---- chroma: Cb of the 16 MCUs, then Cr
+    const int32_t keep = own_blocks ? 0 : -1;
+#pragma unroll 1
+    for (uint32_t comp = 0; comp < 2; comp++) {
+        {
+            // pass 1: lane = (row lo, MCUs hi and hi + 8)
+            const uint8_t *from = sh + (comp == 0 ? kEfCarry : kEfStage);
+            EncF2 v[8];
+#pragma unroll
+            for (uint32_t side = 0; side < 2; side++) {
+                const uint32_t m = hi + 8u * side;
+                int32_t sum[8], prev[8];
+                unpack8_i16(*reinterpret_cast<const uint4 *>(sh + kEfSums + ((m * 2u + comp) * 8u + lo) * 16u), sum);
+                unpack8_i16(*reinterpret_cast<const uint4 *>(from + m * 128u + lo * 16u), prev);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int32_t smp = (int32_t)(int16_t)(((int32_t)(int16_t)((prev[i] & keep) + sum[i]) + 2) >> 2);
+                    if (side == 0) v[i].x = (float)(smp - 128);
+                    else v[i].y = (float)(smp - 128);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            fdct8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            float *t = reinterpret_cast<float *>(sh + kEfT + hi * kEfBlkStride) + lo * 8u;
+            *reinterpret_cast<float4 *>(t) = float4{v[0].x, v[1].x, v[2].x, v[3].x};
+            *reinterpret_cast<float4 *>(t + 4) = float4{v[4].x, v[5].x, v[6].x, v[7].x};
+            float *t1 = t + 8u * (kEfBlkStride / 4u);
+            *reinterpret_cast<float4 *>(t1) = float4{v[0].y, v[1].y, v[2].y, v[3].y};
+            *reinterpret_cast<float4 *>(t1 + 4) = float4{v[4].y, v[5].y, v[6].y, v[7].y};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ef_pass2(sh, 0, lo, hi, qc, zz);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (uint32_t j = 0; j < 2; j++) {
+            const uint32_t i = lane + 64u * j, m = i >> 3, piece = i & 7u;
+            const uint4 val = *reinterpret_cast<const uint4 *>(sh + kEfStage + i * 16u);
+            if (base + m < n_mcus) *reinterpret_cast<uint4 *>(out + ((uint64_t)(base + m) * 6u + 4u + comp) * 64u + piece * 8u) = val;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
@@ -898,13 +1142,19 @@ __global__ __launch_bounds__(256) void stuff_write_kernel(const DevEncImage *__r
 
 size_t enc_sample_bytes_per_mcu(uint32_t luma_h, uint32_t luma_v, uint32_t components) { return enc_sample_stride(luma_h, luma_v, components); }
 
+bool enc_image_fused(const DevEncImage &im) { return enc_fused_ok(im); }
+
 hipError_t launch_fdct_quant(hipStream_t stream, const uint8_t *pixels, const DevEncImage *images, const EncWork *work, int n_work,
-                             uint8_t *samples, int16_t *coefs, size_t max_record_bytes) {
+                             uint8_t *samples, int16_t *coefs, size_t max_record_bytes, bool any_fused, bool any_other) {
     if (n_work <= 0) return hipSuccess;
-    const size_t lds = max_record_bytes * (size_t)kEncMcusPerWg;
-    if (lds <= 64 * 1024) hipLaunchKernelGGL(enc_gather_kernel<true>, dim3(n_work), dim3(8 * kEncMcusPerWg), lds, stream, pixels, images, work, samples);
-    else hipLaunchKernelGGL(enc_gather_kernel<false>, dim3(n_work), dim3(8 * kEncMcusPerWg), 0, stream, pixels, images, work, samples);
-    hipLaunchKernelGGL(fdct_quant_kernel, dim3(n_work), dim3(kEncMcusPerWg), 0, stream, samples, images, work, coefs);
+    if (any_fused) hipLaunchKernelGGL(fdct_fused_kernel, dim3(n_work * (kEncMcusPerWg / kEfMcus)), dim3(64), 0, stream, pixels, images, work, coefs);
+    if (any_other) {
+        const size_t lds = max_record_bytes * (size_t)kEncMcusPerWg;
+        if (lds <= 64 * 1024)
+            hipLaunchKernelGGL(enc_gather_kernel<true>, dim3(n_work), dim3(8 * kEncMcusPerWg), lds, stream, pixels, images, work, samples, any_fused);
+        else hipLaunchKernelGGL(enc_gather_kernel<false>, dim3(n_work), dim3(8 * kEncMcusPerWg), 0, stream, pixels, images, work, samples, any_fused);
+        hipLaunchKernelGGL(fdct_quant_kernel, dim3(n_work), dim3(kEncMcusPerWg), 0, stream, samples, images, work, coefs, any_fused);
+    }
     return hipGetLastError();
 }
 hipError_t launch_block_bits(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
