@@ -474,11 +474,12 @@ __global__ __launch_bounds__(kEncMcusPerWg, JPGPU_E1B_WAVES) void fdct_quant_ker
 // quantised blocks out, nothing in between leaves the CU.  E1a + E1b move the gathered samples through HBM (4.2 GB out and
 // in again per 256 x 4K) and E1b holds a whole block per lane (245 registers, two waves per SIMD).  Here a WAVE owns 16
 // consecutive MCUs and every step runs on all 64 lanes, two rows / columns per lane as one packed float pair:
-//   gather (2 rounds of 8 MCUs)  lane = (MCU, chroma row k): two pixel rows of 16 pixels, converted once; chroma 2 x 2 sums to
-//                                LDS; the four luma rows it holds go through pass 1 (rows) in registers -> transpose buffer
-//   luma pass 2 (2 per gather)   lane = (column c, blocks A and A + 8): pass 2, x 0.125, quantise, (short) -> the block's
-//                                zig-zag position in the staging buffer; 16 finished blocks leave as whole 128-byte lines
-//   Cb, then Cr                  pass 1: lane = (row, MCUs m and m + 8), the sample = box average started from the PREVIOUS
+//   gather (4 rounds of 4 MCUs)  lane = (MCU, pixel row): 16 pixels converted once; chroma: pairs summed in the lane, the row
+//                                below added from the neighbour lane (DPP), to LDS; the lane's luma row of the left and the
+//                                right block goes through pass 1 (rows) as one packed pair -> transpose buffer
+//   luma pass 2 (1 per gather)   lane = (block, columns 2c and 2c + 1): pass 2, x 0.125, quantise, (short) -> the block's
+//                                zig-zag positions in the staging buffer; 16 finished blocks leave as whole 128-byte lines
+//   Cb, then Cr                  pass 1: lane = (row, MCUs 2m and 2m + 1), the sample = box average started from the PREVIOUS
 //                                block's quantised coefficients (ReadBlockWithSubsample adds into the one buffer
 //                                WriteScanData reuses: Cb from Y3, Cr from Cb; not with optimizeCoding); pass 2 as for luma
 // A wave never waits for another one (LDS operations of one wave complete in order): no barrier in the kernel.
@@ -490,35 +491,125 @@ __device__ constexpr uint8_t kEncZig[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  
                                             41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
                                             46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
 
-constexpr int kEfMcus = 16;                     // MCUs per wave (= workgroup)
-constexpr uint32_t kEfBlkStride = 72u * 4u;     // transpose buffer: bytes from block to block (72 floats: the columns of eight
-                                                // blocks, eight lanes each, fall on 64 different banks)
-constexpr uint32_t kEfT = 0;                    // 32 luma blocks of 8 MCUs after pass 1 (later: 16 chroma blocks)
-constexpr uint32_t kEfSums = kEfT + 32u * kEfBlkStride;  // chroma 2 x 2 sums: [MCU][Cb, Cr][row] x 8 int16
+constexpr int kEfMcus = 16;                 // MCUs per wave (= workgroup)
+constexpr uint32_t kEfS = 72u;              // transpose buffer: dwords from block to block (72: the column pairs of eight
+                                            // blocks, four lanes each, fall on 64 different banks)
+constexpr uint32_t kEfQuant = 0;            // the table in use as {d(2c), d(2c+1), r(2c), r(2c+1)} per (row, column pair)
+constexpr uint32_t kEfT = kEfQuant + 512u;  // 16 blocks after pass 1, row-major
+constexpr uint32_t kEfSums = kEfT + 16u * kEfS * 4u;          // chroma 2 x 2 sums: [MCU][Cb, Cr][row] x 8 int16
 constexpr uint32_t kEfStage = kEfSums + kEfMcus * 2u * 128u;  // 16 finished blocks (zig-zag int16) on their way out
-constexpr uint32_t kEfCarry = kEfStage + 16u * 128u;     // block Y3 of every MCU: what its Cb block starts from
-constexpr uint32_t kEfLdsBytes = kEfCarry + kEfMcus * 128u;
+constexpr uint32_t kEfCarry = kEfStage + 16u * 128u;          // block Y3 of every MCU: what its Cb block starts from
+constexpr uint32_t kEfLdsBytes = kEfCarry + kEfMcus * 128u;   // 13 312: twelve waves per CU
 
-typedef uint32_t EncU4 __attribute__((ext_vector_type(4)));
+// the lane's entry of the quantisation table in use (lane = natural index): divisor and refined reciprocal
+__device__ __forceinline__ void ef_quant_table(uint8_t *sh, const uint16_t *quant_zigzag, uint32_t lane) {
+    const QuantPair a = quant_pair(quant_zigzag[kEncZig[lane]]);
+    float *e = reinterpret_cast<float *>(sh + kEfQuant + (lane >> 1) * 16u) + (lane & 1u);
+    e[0] = a.d;
+    e[2] = a.r;
+}
 
-// pass 2 of 16 blocks in the transpose buffer: lane (c, p) takes column c of blocks first + p and first + 8 + p
-__device__ __forceinline__ void ef_pass2(uint8_t *sh, uint32_t first, uint32_t c, uint32_t p, const EncF2 (&qp)[8], const uint32_t (&zz)[8]) {
-    const float *ta = reinterpret_cast<const float *>(sh + kEfT + (first + p) * kEfBlkStride) + c;
-    const float *tb = reinterpret_cast<const float *>(sh + kEfT + (first + 8u + p) * kEfBlkStride) + c;
+// x + 1.5 * 2^23 for |x| < 2^22: the sum lies where floats are 1 apart, so the addition itself rounds x to the nearest integer,
+// ties to even (MathF.Round), and the low 16 bits of the result are that integer as a (short) -- rint + convert in one addition
+constexpr float kEfRound = 12582912.0f;
+__device__ __forceinline__ EncF2 ef_floor(EncF2 a) { return EncF2{__builtin_floorf(a.x), __builtin_floorf(a.y)}; }
+
+// pass 2 of the 16 blocks in the transpose buffer: lane (q, c2) takes columns 2 c2 and 2 c2 + 1 of block q
+__device__ __forceinline__ void ef_pass2(uint8_t *sh, uint32_t q, uint32_t c2, const uint32_t (&za)[8], const uint32_t (&zb)[8]) {
+    const EncF2 *t = reinterpret_cast<const EncF2 *>(sh + kEfT + (q * kEfS + 2u * c2) * 4u);
     EncF2 v[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = EncF2{ta[r * 8], tb[r * 8]};
+    for (int r = 0; r < 8; r++) v[r] = t[r * 4];
     fdct8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-    uint8_t *oa = sh + kEfStage + p * 128u, *ob = oa + 8u * 128u;
+    const float4 *qt = reinterpret_cast<const float4 *>(sh + kEfQuant + c2 * 16u);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
+        const float4 dr = qt[r * 4];
         const EncF2 a = v[r] * 0.1250f;
-        const EncF2 D = EncF2{qp[r].x, qp[r].x}, R = EncF2{qp[r].y, qp[r].y};
+        const EncF2 D = EncF2{dr.x, dr.y}, R = EncF2{dr.z, dr.w};
         const EncF2 q0 = a * R;
         const EncF2 q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-D, q0, a), R, q0);
-        const EncF2 q = __builtin_elementwise_fma(__builtin_elementwise_fma(-D, q1, a), R, q1);  // quant_divide, both halves
-        *reinterpret_cast<uint16_t *>(oa + zz[r]) = (uint16_t)(int32_t)__builtin_rintf(q.x);  // half to even; (short) wraps
-        *reinterpret_cast<uint16_t *>(ob + zz[r]) = (uint16_t)(int32_t)__builtin_rintf(q.y);
+        const EncF2 qq = __builtin_elementwise_fma(__builtin_elementwise_fma(-D, q1, a), R, q1);  // quant_divide, both halves
+        const float rx = qq.x + kEfRound, ry = qq.y + kEfRound;  // (short)MathF.Round(.)
+        *reinterpret_cast<uint16_t *>(sh + za[r]) = (uint16_t)(__builtin_bit_cast(uint32_t, rx) & 0xFFFFu);
+        *reinterpret_cast<uint16_t *>(sh + zb[r]) = (uint16_t)(__builtin_bit_cast(uint32_t, ry) & 0xFFFFu);
+    }
+}
+
+// JpegRgbToYCbCrConverter in float: the tables are i * Fix(x) (+ rounding / offset terms) >> 16 with Fix(x) < 2^17 and i < 2^8.
+// Scaled by 2^-16 every factor, product and partial sum (taken in the order below: below 256 in magnitude, 16 fractional bits)
+// is exact in a float's 24 bits, so floor(.) is the table lookup's integer -- and v_cvt_f32_ubyteN takes the byte out of its
+// dword for free.  The luma offset carries ShiftDataLevel's -128.  Pixels that are Y, Cb, Cr already: factors 1 / 0.
+struct EfConvert {
+    float y[3], b[3], r[3], oy, oc;  // luma: R G B; Cb: R G B; Cr: R G B (the negative ones first in the chain)
+};
+
+// One pixel row of an MCU (16 pixels, 48 bytes in w): luma row through pass 1 into the transpose buffer, chroma pair sums
+// combined with the neighbour lane's row into the sums buffer.  EDGE: pixels outside the image (`inside`: one bit per pixel).
+template <bool EDGE>
+__device__ __forceinline__ void ef_row(uint8_t *sh, const uint32_t (&w)[12], uint32_t inside, const EfConvert &cv, uint32_t mloc, uint32_t gk,
+                                       uint32_t gm, uint32_t gdy, uint32_t ry) {
+    float sb[8], sr[8];
+    EncF2 v[8];
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        EncF2 c[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const int b0 = 3 * i + ch, b1 = 3 * (i + 1) + ch;
+            c[ch] = EncF2{(float)((w[b0 >> 2] >> (8 * (b0 & 3))) & 0xFFu), (float)((w[b1 >> 2] >> (8 * (b1 & 3))) & 0xFFu)};
+        }
+        const EncF2 yv = ef_floor(__builtin_elementwise_fma(EncF2{cv.y[0], cv.y[0]}, c[0],
+                             __builtin_elementwise_fma(EncF2{cv.y[1], cv.y[1]}, c[1],
+                             __builtin_elementwise_fma(EncF2{cv.y[2], cv.y[2]}, c[2], EncF2{cv.oy, cv.oy}))));
+        const EncF2 bv = ef_floor(__builtin_elementwise_fma(EncF2{cv.b[2], cv.b[2]}, c[2],
+                             __builtin_elementwise_fma(EncF2{cv.b[1], cv.b[1]}, c[1],
+                             __builtin_elementwise_fma(EncF2{cv.b[0], cv.b[0]}, c[0], EncF2{cv.oc, cv.oc}))));
+        const EncF2 rv = ef_floor(__builtin_elementwise_fma(EncF2{cv.r[0], cv.r[0]}, c[0],
+                             __builtin_elementwise_fma(EncF2{cv.r[2], cv.r[2]}, c[2],
+                             __builtin_elementwise_fma(EncF2{cv.r[1], cv.r[1]}, c[1], EncF2{cv.oc, cv.oc}))));
+        if (i < 8) v[i].x = yv.x, v[i + 1].x = yv.y;
+        else v[i - 8].y = yv.x, v[i - 7].y = yv.y;
+        sb[i >> 1] = bv.x + bv.y;
+        sr[i >> 1] = rv.x + rv.y;
+    }
+    if (EDGE) {
+        // a pixel outside the image is the SAMPLE zero in every component, not the conversion of a black pixel: the zero
+        // bytes gave luma 0 (- 128) but chroma floor(oc) (128 from RGB) -- taken out of the sums again
+        const float off = __builtin_floorf(cv.oc);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float n_out = (float)(2 - (int32_t)__builtin_popcount((inside >> (2 * j)) & 3u));
+            sb[j] -= n_out * off;
+            sr[j] -= n_out * off;
+        }
+    }
+    // the pixel row below (above) is the neighbour lane's: the even lane keeps Cb, the odd lane Cr
+    uint32_t both[4];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        EncF2 tot;
+        {
+            const float mine = gdy ? sr[j] : sb[j], give = gdy ? sb[j] : sr[j];
+            tot.x = mine + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+        }
+        {
+            const float mine = gdy ? sr[j + 1] : sb[j + 1], give = gdy ? sb[j + 1] : sr[j + 1];
+            tot.y = mine + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
+        }
+        // + 2^23: the low bits are the (small, non-negative) integer.  (scalar copies: __builtin_bit_cast of a vector ELEMENT
+        // reads the vector's first one)
+        const float lo = tot.x + 8388608.0f, hi = tot.y + 8388608.0f;
+        both[j >> 1] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x05040100u);
+    }
+    *reinterpret_cast<uint4 *>(sh + kEfSums + ((mloc * 2u + gdy) * 8u + gk) * 16u) = uint4{both[0], both[1], both[2], both[3]};
+    // pass 1 of the lane's luma row: left and right block side by side
+    fdct8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    float *t = reinterpret_cast<float *>(sh + kEfT) + (gm * 4u + (ry >> 3) * 2u) * kEfS + (ry & 7u) * 8u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        t[i] = v[i].x;
+        t[kEfS + i] = v[i].y;
     }
 }
 
@@ -533,163 +624,132 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
     const uint32_t n_mcus = mcus_per_line * im.mcus_per_column;
     const uint32_t base = wk.first + (blockIdx.x % kPerItem) * kEfMcus;
     if (base >= n_mcus) return;
-    const uint32_t lane = threadIdx.x, lo = lane & 7u, hi = lane >> 3;
+    const uint32_t lane = threadIdx.x;
     const uint32_t width = im.width, height = im.height;
     const uint8_t *px = pixels + im.px_off;
     const bool own_blocks = im.table_base != 0;
     int16_t *out = coefs + im.coef_off * 64;
 
-    // what a lane needs for its column lo of a block: the zig-zag positions of the eight rows, the two tables' divisors there
-    EncF2 qy[8], qc[8];
-    uint32_t zz[8];
+    ef_quant_table(sh, im.quant[0], lane);
+    // pass 2: the lane's block and column pair, and where its 16 results go in the staging buffer
+    const uint32_t p2q = lane >> 2, p2c = lane & 3u;
+    uint32_t za[8], zb[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const uint32_t z = kEncZig[r * 8 + lo];
-        zz[r] = z * 2u;
-        const QuantPair a = quant_pair(im.quant[0][z]), b = quant_pair(im.quant[1][z]);
-        qy[r] = EncF2{a.d, a.r};
-        qc[r] = EncF2{b.d, b.r};
+        za[r] = kEfStage + p2q * 128u + 2u * kEncZig[r * 8 + 2 * p2c];
+        zb[r] = kEfStage + p2q * 128u + 2u * kEncZig[r * 8 + 2 * p2c + 1];
     }
-    // JpegRgbToYCbCrConverter as nine factors and two offsets; pixels that are Y, Cb, Cr already pass through the same lines.
-    // (the luma offset carries ShiftDataLevel's -128: subtracting 128 << 16 in front of >> 16 is subtracting 128 behind it)
-    int32_t fy[3], fb[3], fr[3], oy, oc;
+    EfConvert cv;
     if (im.input_rgb != 0) {
-        fy[0] = im.r2y[0], fy[1] = im.r2y[1], fy[2] = im.r2y[2];
-        fb[0] = -im.r2y[3], fb[1] = -im.r2y[4], fb[2] = im.r2y[5];
-        fr[0] = im.r2y[5], fr[1] = -im.r2y[6], fr[2] = -im.r2y[7];
-        oy = 32768 - (128 << 16), oc = (128 << 16) + 32767;
+        constexpr float k = 1.0f / 65536.0f;
+        cv.y[0] = (float)im.r2y[0] * k, cv.y[1] = (float)im.r2y[1] * k, cv.y[2] = (float)im.r2y[2] * k;
+        cv.b[0] = (float)-im.r2y[3] * k, cv.b[1] = (float)-im.r2y[4] * k, cv.b[2] = (float)im.r2y[5] * k;
+        cv.r[0] = (float)im.r2y[5] * k, cv.r[1] = (float)-im.r2y[6] * k, cv.r[2] = (float)-im.r2y[7] * k;
+        cv.oy = (float)(32768 - (128 << 16)) * k, cv.oc = (float)((128 << 16) + 32767) * k;
     } else {
-        fy[0] = 65536, fy[1] = 0, fy[2] = 0;
-        fb[0] = 0, fb[1] = 65536, fb[2] = 0;
-        fr[0] = 0, fr[1] = 0, fr[2] = 65536;
-        oy = -(128 << 16), oc = 0;
+        cv.y[0] = 1.0f, cv.y[1] = 0.0f, cv.y[2] = 0.0f;
+        cv.b[0] = 0.0f, cv.b[1] = 1.0f, cv.b[2] = 0.0f;
+        cv.r[0] = 0.0f, cv.r[1] = 0.0f, cv.r[2] = 1.0f;
+        cv.oy = -128.0f, cv.oc = 0.0f;
     }
-    const bool rows_aligned = ((width * 3u) & 3u) == 0;
+    const uint32_t row_bytes = width * 3u;
+    const bool rows16 = (row_bytes & 15u) == 0, rows4 = (row_bytes & 3u) == 0;
 
+    // ---- luma: four rounds of gather + pass 1, pass 2, leave
+    const uint32_t gk = lane >> 3, gm = (lane >> 1) & 3u, gdy = lane & 1u;  // gather: chroma row, MCU of the round, row of the pair
+    const uint32_t ry = 2u * gk + gdy;                                      // pixel row inside the MCU
 #pragma unroll 1
-    for (uint32_t g = 0; g < 2; g++) {
-        // ---- gather: lane = (MCU lo of this round, chroma row hi)
+    for (uint32_t g = 0; g < 4; g++) {
         {
-            const uint32_t mloc = g * 8u + lo, k = hi;
+            const uint32_t mloc = g * 4u + gm;
             const uint32_t mcu = base + mloc < n_mcus ? base + mloc : n_mcus - 1;  // lanes behind the last MCU redo it, and store nothing
-            const uint32_t x0 = (mcu % mcus_per_line) * 16u, y0 = (mcu / mcus_per_line) * 16u + 2u * k;
-            uint32_t w[2][12];
-            uint32_t inside[2] = {0xFFFFu, 0xFFFFu};  // the row's pixels that lie inside the image
-            const bool whole = x0 + 16 <= width && y0 + 2 <= height && rows_aligned;
-            if (whole) {
+            const uint32_t x0 = (mcu % mcus_per_line) * 16u, y = (mcu / mcus_per_line) * 16u + ry;
+            const bool whole = x0 + 16 <= width && y < height;
+            const uint8_t *rowp = px + ((size_t)y * width + x0) * 3;
+            if (rows16 && __builtin_amdgcn_ballot_w64(!whole) == 0) {
+                uint32_t w[12];
 #pragma unroll
-                for (int dy = 0; dy < 2; dy++) __builtin_memcpy(w[dy], __builtin_assume_aligned(px + ((size_t)(y0 + dy) * width + x0) * 3, 4), 48);
+                for (int j = 0; j < 3; j++) {
+                    const uint4 t = reinterpret_cast<const uint4 *>(rowp)[j];
+                    w[4 * j] = t.x, w[4 * j + 1] = t.y, w[4 * j + 2] = t.z, w[4 * j + 3] = t.w;
+                }
+                ef_row<false>(sh, w, 0xFFFFu, cv, mloc, gk, gm, gdy, ry);
             } else {
-                // the edge of the image: outside it the reader leaves zeros (JpegBufferInputReader.cs:27-52); any row alignment
+                // the edge of the image (outside it the reader leaves zeros, JpegBufferInputReader.cs:27-52), or rows that do
+                // not start on 16 bytes
+                uint32_t w[12];
+                uint32_t inside = 0xFFFFu;  // the row's pixels that lie inside the image
+                if (whole && rows4) {
+                    __builtin_memcpy(w, __builtin_assume_aligned(rowp, 4), 48);
+                } else {
 #pragma unroll
-                for (int dy = 0; dy < 2; dy++) {
-#pragma unroll
-                    for (int j = 0; j < 12; j++) w[dy][j] = 0;
-                    inside[dy] = 0;
-                    if (y0 + dy < height) {
-                        const uint8_t *rowp = px + ((size_t)(y0 + dy) * width + x0) * 3;
+                    for (int j = 0; j < 12; j++) w[j] = 0;
+                    inside = 0;
+                    if (y < height) {
                         const uint32_t np = x0 >= width ? 0u : (width - x0 < 16u ? width - x0 : 16u), nb = np * 3u;
-                        inside[dy] = (1u << np) - 1u;
+                        inside = (1u << np) - 1u;
                         for (uint32_t j = 0; j < nb; j++) {
                             const uint32_t bv = (uint32_t)rowp[j] << (8u * (j & 3u));
 #pragma unroll
                             for (int q = 0; q < 12; q++)
-                                if ((j >> 2) == (uint32_t)q) w[dy][q] |= bv;
+                                if ((j >> 2) == (uint32_t)q) w[q] |= bv;
                         }
                     }
                 }
-            }
-            int32_t sb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            EncF2 v[2][8];
-#pragma unroll
-            for (int dy = 0; dy < 2; dy++) {
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int32_t b0 = (w[dy][(3 * i) >> 2] >> (8 * ((3 * i) & 3))) & 0xFF;
-                    const int32_t b1 = (w[dy][(3 * i + 1) >> 2] >> (8 * ((3 * i + 1) & 3))) & 0xFF;
-                    const int32_t b2 = (w[dy][(3 * i + 2) >> 2] >> (8 * ((3 * i + 2) & 3))) & 0xFF;
-                    const int32_t yv = (__mul24(fy[0], b0) + (__mul24(fy[1], b1) + (__mul24(fy[2], b2) + oy))) >> 16;
-                    sb[i >> 1] += (__mul24(fb[0], b0) + (__mul24(fb[1], b1) + (__mul24(fb[2], b2) + oc))) >> 16;
-                    sr[i >> 1] += (__mul24(fr[0], b0) + (__mul24(fr[1], b1) + (__mul24(fr[2], b2) + oc))) >> 16;
-                    if (i < 8) v[dy][i].x = (float)yv;
-                    else v[dy][i - 8].y = (float)yv;
-                }
-            }
-            if (!whole) {
-                // a pixel outside the image is the SAMPLE zero in every component, not the conversion of a black pixel: the
-                // zero bytes above gave luma 0 (- 128) but chroma `oc >> 16` (128 from RGB) -- taken out of the sums again
-                const int32_t off = oc >> 16;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int32_t n_out = 4 - (int32_t)__builtin_popcount((inside[0] >> (2 * j)) & 3u) - (int32_t)__builtin_popcount((inside[1] >> (2 * j)) & 3u);
-                    sb[j] -= n_out * off;
-                    sr[j] -= n_out * off;
-                }
-            }
-            *reinterpret_cast<uint4 *>(sh + kEfSums + ((mloc * 2u + 0u) * 8u + k) * 16u) = pack8_i16(sb);
-            *reinterpret_cast<uint4 *>(sh + kEfSums + ((mloc * 2u + 1u) * 8u + k) * 16u) = pack8_i16(sr);
-            // pass 1 of the lane's four luma rows: rows 2k and 2k + 1 of the MCU, left and right block side by side
-#pragma unroll
-            for (int dy = 0; dy < 2; dy++) {
-                fdct8(v[dy][0], v[dy][1], v[dy][2], v[dy][3], v[dy][4], v[dy][5], v[dy][6], v[dy][7]);
-                const uint32_t ry = 2u * k + (uint32_t)dy;
-                float *t = reinterpret_cast<float *>(sh + kEfT + (lo * 4u + (ry >> 3) * 2u) * kEfBlkStride) + (ry & 7u) * 8u;
-                *reinterpret_cast<float4 *>(t) = float4{v[dy][0].x, v[dy][1].x, v[dy][2].x, v[dy][3].x};
-                *reinterpret_cast<float4 *>(t + 4) = float4{v[dy][4].x, v[dy][5].x, v[dy][6].x, v[dy][7].x};
-                float *t1 = t + kEfBlkStride / 4u;
-                *reinterpret_cast<float4 *>(t1) = float4{v[dy][0].y, v[dy][1].y, v[dy][2].y, v[dy][3].y};
-                *reinterpret_cast<float4 *>(t1 + 4) = float4{v[dy][4].y, v[dy][5].y, v[dy][6].y, v[dy][7].y};
+                ef_row<true>(sh, w, inside, cv, mloc, gk, gm, gdy, ry);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // ---- luma pass 2: the 32 blocks of this round, 16 at a time
-#pragma unroll 1
-        for (uint32_t h = 0; h < 2; h++) {
-            ef_pass2(sh, h * 16u, lo, hi, qy, zz);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ef_pass2(sh, p2q, p2c, za, zb);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (uint32_t j = 0; j < 2; j++) {
-                const uint32_t i = lane + 64u * j, q = i >> 3, piece = i & 7u;
-                const uint32_t tblk = h * 16u + q, mloc = g * 8u + (tblk >> 2), yb = tblk & 3u;
-                const uint4 val = *reinterpret_cast<const uint4 *>(sh + kEfStage + i * 16u);
-                if (base + mloc < n_mcus) *reinterpret_cast<uint4 *>(out + ((uint64_t)(base + mloc) * 6u + yb) * 64u + piece * 8u) = val;
-                if (yb == 3u) *reinterpret_cast<uint4 *>(sh + kEfCarry + mloc * 128u + piece * 16u) = val;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (uint32_t j = 0; j < 2; j++) {
+            const uint32_t i = lane + 64u * j, q = i >> 3, piece = i & 7u;
+            const uint32_t mloc = g * 4u + (q >> 2), yb = q & 3u;
+            const uint4 val = *reinterpret_cast<const uint4 *>(sh + kEfStage + i * 16u);
+            if (base + mloc < n_mcus) *reinterpret_cast<uint4 *>(out + ((uint64_t)(base + mloc) * 6u + yb) * 64u + piece * 8u) = val;
+            if (yb == 3u) *reinterpret_cast<uint4 *>(sh + kEfCarry + mloc * 128u + piece * 16u) = val;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // ---- chroma: Cb of the 16 MCUs, then Cr
-    const int32_t keep = own_blocks ? 0 : -1;
+    ef_quant_table(sh, im.quant[1], lane);
+    const uint32_t keep = own_blocks ? 0u : 0xFFFFFFFFu;
+    const uint32_t cr = lane & 7u, cm = (lane >> 3) * 2u;  // pass 1: row, first MCU of the pair
 #pragma unroll 1
     for (uint32_t comp = 0; comp < 2; comp++) {
         {
-            // pass 1: lane = (row lo, MCUs hi and hi + 8)
             const uint8_t *from = sh + (comp == 0 ? kEfCarry : kEfStage);
             EncF2 v[8];
 #pragma unroll
             for (uint32_t side = 0; side < 2; side++) {
-                const uint32_t m = hi + 8u * side;
-                int32_t sum[8], prev[8];
-                unpack8_i16(*reinterpret_cast<const uint4 *>(sh + kEfSums + ((m * 2u + comp) * 8u + lo) * 16u), sum);
-                unpack8_i16(*reinterpret_cast<const uint4 *>(from + m * 128u + lo * 16u), prev);
+                const uint32_t m = cm + side;
+                const uint4 sum = *reinterpret_cast<const uint4 *>(sh + kEfSums + ((m * 2u + comp) * 8u + cr) * 16u);
+                const uint4 prev = *reinterpret_cast<const uint4 *>(from + m * 128u + cr * 16u);
+                const uint32_t sw[4] = {sum.x, sum.y, sum.z, sum.w}, pw[4] = {prev.x, prev.y, prev.z, prev.w};
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int32_t smp = (int32_t)(int16_t)(((int32_t)(int16_t)((prev[i] & keep) + sum[i]) + 2) >> 2);
-                    if (side == 0) v[i].x = (float)(smp - 128);
-                    else v[i].y = (float)(smp - 128);
+                for (int i = 0; i < 8; i += 2) {
+                    // (short)(previous + sum): 16-bit wrap-around add on both halves; then ((int)t + 2) >> 2, - 128, as
+                    // floor(t / 4 + 0.5 - 128) -- exact in float
+                    typedef short S2 __attribute__((ext_vector_type(2)));
+                    typedef unsigned short U2 __attribute__((ext_vector_type(2)));
+                    const S2 t = __builtin_bit_cast(S2, __builtin_bit_cast(U2, pw[i >> 1] & keep) + __builtin_bit_cast(U2, sw[i >> 1]));
+                    const EncF2 f = ef_floor(__builtin_elementwise_fma(EncF2{(float)t.x, (float)t.y}, EncF2{0.25f, 0.25f}, EncF2{-127.5f, -127.5f}));
+                    if (side == 0) v[i].x = f.x, v[i + 1].x = f.y;
+                    else v[i].y = f.x, v[i + 1].y = f.y;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             fdct8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-            float *t = reinterpret_cast<float *>(sh + kEfT + hi * kEfBlkStride) + lo * 8u;
-            *reinterpret_cast<float4 *>(t) = float4{v[0].x, v[1].x, v[2].x, v[3].x};
-            *reinterpret_cast<float4 *>(t + 4) = float4{v[4].x, v[5].x, v[6].x, v[7].x};
-            float *t1 = t + 8u * (kEfBlkStride / 4u);
-            *reinterpret_cast<float4 *>(t1) = float4{v[0].y, v[1].y, v[2].y, v[3].y};
-            *reinterpret_cast<float4 *>(t1 + 4) = float4{v[4].y, v[5].y, v[6].y, v[7].y};
+            float *t = reinterpret_cast<float *>(sh + kEfT) + cm * kEfS + cr * 8u;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                t[i] = v[i].x;
+                t[kEfS + i] = v[i].y;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ef_pass2(sh, 0, lo, hi, qc, zz);
+        ef_pass2(sh, p2q, p2c, za, zb);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (uint32_t j = 0; j < 2; j++) {
