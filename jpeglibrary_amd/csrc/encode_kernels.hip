@@ -497,9 +497,10 @@ constexpr uint32_t kEfS = 72u;              // transpose buffer: dwords from blo
 constexpr uint32_t kEfQuant = 0;            // the table in use as {d(2c), d(2c+1), r(2c), r(2c+1)} per (row, column pair)
 constexpr uint32_t kEfT = kEfQuant + 512u;  // 16 blocks after pass 1, row-major
 constexpr uint32_t kEfSums = kEfT + 16u * kEfS * 4u;          // chroma 2 x 2 sums: [MCU][Cb, Cr][row] x 8 int16
-constexpr uint32_t kEfStage = kEfSums + kEfMcus * 2u * 128u;  // 16 finished blocks (zig-zag int16) on their way out
-constexpr uint32_t kEfCarry = kEfStage + 16u * 128u;          // block Y3 of every MCU: what its Cb block starts from
-constexpr uint32_t kEfLdsBytes = kEfCarry + kEfMcus * 128u;   // 13 312: twelve waves per CU
+constexpr uint32_t kEfStage = kEfSums + kEfMcus * 2u * 128u;  // 16 finished blocks (zig-zag int16) on their way out,
+constexpr uint32_t kEfStageStride = 144u;                     // 144 bytes apart: a coefficient position of eight blocks on eight banks
+constexpr uint32_t kEfCarry = kEfStage + 16u * kEfStageStride;  // block Y3 of every MCU: what its Cb block starts from
+constexpr uint32_t kEfLdsBytes = kEfCarry + kEfMcus * 128u;   // 13 568: twelve waves per CU
 
 // the lane's entry of the quantisation table in use (lane = natural index): divisor and refined reciprocal
 __device__ __forceinline__ void ef_quant_table(uint8_t *sh, const uint16_t *quant_zigzag, uint32_t lane) {
@@ -522,17 +523,27 @@ __device__ __forceinline__ void ef_pass2(uint8_t *sh, uint32_t q, uint32_t c2, c
     for (int r = 0; r < 8; r++) v[r] = t[r * 4];
     fdct8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
     const float4 *qt = reinterpret_cast<const float4 *>(sh + kEfQuant + c2 * 16u);
+    float4 dr[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const float4 dr = qt[r * 4];
-        const EncF2 a = v[r] * 0.1250f;
-        const EncF2 D = EncF2{dr.x, dr.y}, R = EncF2{dr.z, dr.w};
-        const EncF2 q0 = a * R;
-        const EncF2 q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-D, q0, a), R, q0);
-        const EncF2 qq = __builtin_elementwise_fma(__builtin_elementwise_fma(-D, q1, a), R, q1);  // quant_divide, both halves
-        const float rx = qq.x + kEfRound, ry = qq.y + kEfRound;  // (short)MathF.Round(.)
-        *reinterpret_cast<uint16_t *>(sh + za[r]) = (uint16_t)(__builtin_bit_cast(uint32_t, rx) & 0xFFFFu);
-        *reinterpret_cast<uint16_t *>(sh + zb[r]) = (uint16_t)(__builtin_bit_cast(uint32_t, ry) & 0xFFFFu);
+    for (int r = 0; r < 8; r++) dr[r] = qt[r * 4];
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+        // quant_divide on both halves; rows r and r + 1 statement by statement side by side (a packed operation waits a cycle
+        // for the one before it when it needs its result)
+        const EncF2 a0 = v[r] * 0.1250f, a1 = v[r + 1] * 0.1250f;
+        const EncF2 D0 = EncF2{dr[r].x, dr[r].y}, R0 = EncF2{dr[r].z, dr[r].w}, D1 = EncF2{dr[r + 1].x, dr[r + 1].y}, R1 = EncF2{dr[r + 1].z, dr[r + 1].w};
+        const EncF2 q00 = a0 * R0, q01 = a1 * R1;
+        const EncF2 e00 = __builtin_elementwise_fma(-D0, q00, a0), e01 = __builtin_elementwise_fma(-D1, q01, a1);
+        const EncF2 q10 = __builtin_elementwise_fma(e00, R0, q00), q11 = __builtin_elementwise_fma(e01, R1, q01);
+        const EncF2 e10 = __builtin_elementwise_fma(-D0, q10, a0), e11 = __builtin_elementwise_fma(-D1, q11, a1);
+        const EncF2 qq0 = __builtin_elementwise_fma(e10, R0, q10), qq1 = __builtin_elementwise_fma(e11, R1, q11);
+        // (short)MathF.Round(.)  (scalar copies: __builtin_bit_cast of a vector ELEMENT reads the vector's first one)
+        const EncF2 r0 = qq0 + EncF2{kEfRound, kEfRound}, r1 = qq1 + EncF2{kEfRound, kEfRound};
+        const float x0 = r0.x, y0 = r0.y, x1 = r1.x, y1 = r1.y;
+        *reinterpret_cast<uint16_t *>(sh + za[r]) = (uint16_t)(__builtin_bit_cast(uint32_t, x0) & 0xFFFFu);
+        *reinterpret_cast<uint16_t *>(sh + zb[r]) = (uint16_t)(__builtin_bit_cast(uint32_t, y0) & 0xFFFFu);
+        *reinterpret_cast<uint16_t *>(sh + za[r + 1]) = (uint16_t)(__builtin_bit_cast(uint32_t, x1) & 0xFFFFu);
+        *reinterpret_cast<uint16_t *>(sh + zb[r + 1]) = (uint16_t)(__builtin_bit_cast(uint32_t, y1) & 0xFFFFu);
     }
 }
 
@@ -636,8 +647,8 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
     uint32_t za[8], zb[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        za[r] = kEfStage + p2q * 128u + 2u * kEncZig[r * 8 + 2 * p2c];
-        zb[r] = kEfStage + p2q * 128u + 2u * kEncZig[r * 8 + 2 * p2c + 1];
+        za[r] = kEfStage + p2q * kEfStageStride + 2u * kEncZig[r * 8 + 2 * p2c];
+        zb[r] = kEfStage + p2q * kEfStageStride + 2u * kEncZig[r * 8 + 2 * p2c + 1];
     }
     EfConvert cv;
     if (im.input_rgb != 0) {
@@ -656,8 +667,28 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
     const bool rows16 = (row_bytes & 15u) == 0, rows4 = (row_bytes & 3u) == 0;
 
     // ---- luma: four rounds of gather + pass 1, pass 2, leave
-    const uint32_t gk = lane >> 3, gm = (lane >> 1) & 3u, gdy = lane & 1u;  // gather: chroma row, MCU of the round, row of the pair
-    const uint32_t ry = 2u * gk + gdy;                                      // pixel row inside the MCU
+    // gather: lane = (MCU of the round, pixel row inside the MCU); chroma row, row of the pair.  (Eight neighbouring lanes put
+    // eight different rows of one block column into the transpose buffer: two lanes per bank group instead of four.)
+    const uint32_t gm = lane >> 4, ry = lane & 15u, gk = ry >> 1, gdy = lane & 1u;
+    // The usual case -- rows that start on 16 bytes -- fetches the pixels of round g + 1 while round g goes through pass 2:
+    // three 16-byte loads from an address clamped into the image, so that they can be issued before anybody knows whether
+    // the round touches the image's edge (then they are dropped and the edge variant reads byte by byte).
+    const bool ahead = rows16 && width >= 16 && height >= 1;
+    uint32_t w[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto fetch = [&](uint32_t g) {
+        const uint32_t mloc = g * 4u + gm;
+        const uint32_t mcu = base + mloc < n_mcus ? base + mloc : n_mcus - 1;
+        uint32_t x0 = (mcu % mcus_per_line) * 16u, y = (mcu / mcus_per_line) * 16u + ry;
+        x0 = x0 + 16 <= width ? x0 : width - 16;
+        y = y < height ? y : height - 1;
+        const uint4 *rowp = reinterpret_cast<const uint4 *>(px + ((size_t)y * width + x0) * 3);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint4 t = rowp[j];
+            w[4 * j] = t.x, w[4 * j + 1] = t.y, w[4 * j + 2] = t.z, w[4 * j + 3] = t.w;
+        }
+    };
+    if (ahead) fetch(0);
 #pragma unroll 1
     for (uint32_t g = 0; g < 4; g++) {
         {
@@ -665,25 +696,19 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
             const uint32_t mcu = base + mloc < n_mcus ? base + mloc : n_mcus - 1;  // lanes behind the last MCU redo it, and store nothing
             const uint32_t x0 = (mcu % mcus_per_line) * 16u, y = (mcu / mcus_per_line) * 16u + ry;
             const bool whole = x0 + 16 <= width && y < height;
-            const uint8_t *rowp = px + ((size_t)y * width + x0) * 3;
-            if (rows16 && __builtin_amdgcn_ballot_w64(!whole) == 0) {
-                uint32_t w[12];
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const uint4 t = reinterpret_cast<const uint4 *>(rowp)[j];
-                    w[4 * j] = t.x, w[4 * j + 1] = t.y, w[4 * j + 2] = t.z, w[4 * j + 3] = t.w;
-                }
+            if (ahead && __builtin_amdgcn_ballot_w64(!whole) == 0) {
                 ef_row<false>(sh, w, 0xFFFFu, cv, mloc, gk, gm, gdy, ry);
             } else {
                 // the edge of the image (outside it the reader leaves zeros, JpegBufferInputReader.cs:27-52), or rows that do
                 // not start on 16 bytes
-                uint32_t w[12];
+                const uint8_t *rowp = px + ((size_t)y * width + x0) * 3;
+                uint32_t we[12];
                 uint32_t inside = 0xFFFFu;  // the row's pixels that lie inside the image
                 if (whole && rows4) {
-                    __builtin_memcpy(w, __builtin_assume_aligned(rowp, 4), 48);
+                    __builtin_memcpy(we, __builtin_assume_aligned(rowp, 4), 48);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 12; j++) w[j] = 0;
+                    for (int j = 0; j < 12; j++) we[j] = 0;
                     inside = 0;
                     if (y < height) {
                         const uint32_t np = x0 >= width ? 0u : (width - x0 < 16u ? width - x0 : 16u), nb = np * 3u;
@@ -692,12 +717,13 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
                             const uint32_t bv = (uint32_t)rowp[j] << (8u * (j & 3u));
 #pragma unroll
                             for (int q = 0; q < 12; q++)
-                                if ((j >> 2) == (uint32_t)q) w[q] |= bv;
+                                if ((j >> 2) == (uint32_t)q) we[q] |= bv;
                         }
                     }
                 }
-                ef_row<true>(sh, w, inside, cv, mloc, gk, gm, gdy, ry);
+                ef_row<true>(sh, we, inside, cv, mloc, gk, gm, gdy, ry);
             }
+            if (ahead && g < 3) fetch(g + 1);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         ef_pass2(sh, p2q, p2c, za, zb);
@@ -706,7 +732,7 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
         for (uint32_t j = 0; j < 2; j++) {
             const uint32_t i = lane + 64u * j, q = i >> 3, piece = i & 7u;
             const uint32_t mloc = g * 4u + (q >> 2), yb = q & 3u;
-            const uint4 val = *reinterpret_cast<const uint4 *>(sh + kEfStage + i * 16u);
+            const uint4 val = *reinterpret_cast<const uint4 *>(sh + kEfStage + q * kEfStageStride + piece * 16u);
             if (base + mloc < n_mcus) *reinterpret_cast<uint4 *>(out + ((uint64_t)(base + mloc) * 6u + yb) * 64u + piece * 8u) = val;
             if (yb == 3u) *reinterpret_cast<uint4 *>(sh + kEfCarry + mloc * 128u + piece * 16u) = val;
         }
@@ -720,12 +746,13 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
     for (uint32_t comp = 0; comp < 2; comp++) {
         {
             const uint8_t *from = sh + (comp == 0 ? kEfCarry : kEfStage);
+            const uint32_t from_stride = comp == 0 ? 128u : kEfStageStride;
             EncF2 v[8];
 #pragma unroll
             for (uint32_t side = 0; side < 2; side++) {
                 const uint32_t m = cm + side;
                 const uint4 sum = *reinterpret_cast<const uint4 *>(sh + kEfSums + ((m * 2u + comp) * 8u + cr) * 16u);
-                const uint4 prev = *reinterpret_cast<const uint4 *>(from + m * 128u + cr * 16u);
+                const uint4 prev = *reinterpret_cast<const uint4 *>(from + m * from_stride + cr * 16u);
                 const uint32_t sw[4] = {sum.x, sum.y, sum.z, sum.w}, pw[4] = {prev.x, prev.y, prev.z, prev.w};
 #pragma unroll
                 for (int i = 0; i < 8; i += 2) {
@@ -754,7 +781,7 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
 #pragma unroll
         for (uint32_t j = 0; j < 2; j++) {
             const uint32_t i = lane + 64u * j, m = i >> 3, piece = i & 7u;
-            const uint4 val = *reinterpret_cast<const uint4 *>(sh + kEfStage + i * 16u);
+            const uint4 val = *reinterpret_cast<const uint4 *>(sh + kEfStage + m * kEfStageStride + piece * 16u);
             if (base + m < n_mcus) *reinterpret_cast<uint4 *>(out + ((uint64_t)(base + m) * 6u + 4u + comp) * 64u + piece * 8u) = val;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -891,6 +891,36 @@ def test_encoder_matches_the_reference_restatement_byte_for_byte(w, h, luma, q):
     assert results[0].status == 0 and np.array_equal(outs[0], po.decode_8bit(ref)[0])
 
 
+FUSED_SHAPES = [(100, 80), (20, 16), (12, 40), (48, 1), (16, 16), (272, 33), (1600, 48)]
+
+
+@pytest.mark.parametrize("w,h", FUSED_SHAPES)
+@pytest.mark.parametrize("opt", [False, True])
+def test_encoder_fused_e1_row_alignments_and_edges(w, h, opt):
+    """fdct_fused_kernel (three components, 4:2:0) on the shapes its paths split by: rows that start on 16 bytes / on 4 / on
+    nothing, images narrower than one MCU, partial MCUs right and below, more than 16 MCUs -- coefficients and stream equal
+    the checker's for YCbCr and for RGB pixels, with the standard tables and with optimizeCoding (no carry-over from the
+    previous block, JpegEncoder.cs:414-485)."""
+    rgb = _enc_image(w, h, 3 * w + h)
+    ycc = po.rgb_to_ycbcr8(rgb)
+    ref, ref_coefs = po.encode_8bit(ycc, 2, 2, 77, want_coefficients=True, optimize_coding=opt)
+    b = jl.EncodeBatch().upload([ycc], (2, 2), 77, optimize_coding=opt).encode()
+    assert np.array_equal(b.coefficients(0), ref_coefs)
+    assert b.output(0) == ref
+    assert jl.encode_batch([rgb], (2, 2), 77, rgb=True, optimize_coding=opt)[0] == ref
+
+
+def test_encoder_fused_and_two_kernel_images_in_one_batch():
+    """A batch whose images go two ways through E1: colour images (fdct_fused_kernel) between gray ones (E1a + E1b), each
+    kernel leaving the other's images alone."""
+    col = [po.rgb_to_ycbcr8(_enc_image(w, h, w)) for (w, h) in [(160, 96), (33, 47), (640, 64)]]
+    gray = [po.rgb_to_ycbcr8(_enc_image(w, h, h))[..., 0] for (w, h) in [(64, 64), (50, 30)]]
+    imgs = [col[0], gray[0], col[1], gray[1], col[2]]
+    outs = jl.encode_batch(imgs, (2, 2), 70)
+    for im, o in zip(imgs, outs):
+        assert o == po.encode_8bit(im, 2, 2, 70)
+
+
 def test_encoder_batch_gray_and_mixed_sizes():
     imgs = [_enc_image(96, 64, 1), _enc_image(50, 70, 2), _enc_image(256, 256, 3)]
     outs = jl.encode_batch([po.rgb_to_ycbcr8(i) for i in imgs], (2, 2), 80)

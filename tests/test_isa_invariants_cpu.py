@@ -4,7 +4,10 @@
   multiply and add of the reference is one IEEE operation (`-ffp-contract=off`); the headline variant is 256 v_pk_add_f32 +
   128 v_pk_mul_f32 + 64 v_rndne_f32 per block and no fused multiply-add but the one of the address set-up's division;
 * no hot kernel spills vector registers or uses scratch;
-* the K2S round kernel's burst of symbol steps is straight-line code: no branch between its first and last ds_add."""
+* the K2S round kernel's burst of symbol steps is straight-line code: no branch between its first and last ds_add;
+* the encoder's fused E1 kernel (fdct_fused_kernel) keeps the FDCT un-contracted too: its only fused multiply-adds are the
+  exact ones (colour conversion on 24-bit operands, the quotient's correction steps that reproduce the hardware division,
+  the chroma sample's t / 4 - 127.5), it stays under 168 registers (three waves per SIMD) and does not spill."""
 import os
 import re
 import subprocess
@@ -68,3 +71,42 @@ def test_the_round_kernels_burst_is_straight_line_code(isa):
     assert len(adds) >= 8
     burst = body[adds[0]:adds[7] + 1]
     assert not any(ln.startswith(("s_cbranch", "s_branch", "s_setpc")) for ln in burst), [ln for ln in burst if ln.startswith("s_")]
+
+
+@pytest.fixture(scope="module")
+def enc_isa(tmp_path_factory):
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    flags = open(os.path.join(ROOT, "jpeglibrary_amd", "csrc", "Makefile")).read()
+    m = re.search(r"^CXXFLAGS\s*[:?]?=\s*(.*)$", flags, re.M)
+    cxxflags = m.group(1).split() if m else ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"]
+    asm = tmp_path_factory.mktemp("isa") / "encode_kernels.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", *[f for f in cxxflags if not f.startswith("-W")], "-S", "--cuda-device-only", "-o", str(asm),
+                           os.path.join(ROOT, "jpeglibrary_amd", "csrc", "encode_kernels.hip")], stderr=subprocess.DEVNULL)
+    return asm.read_text()
+
+
+@pytest.mark.timeout(600)
+def test_the_fused_encoder_kernel_keeps_the_fdct_in_ieee_steps(enc_isa):
+    """FastFloatingPointDCT.TransformFDCT (FastFloatingPointDCT.cs:194-362) has 14 multiplications and 26 additions per
+    8-point butterfly and no fused step; the kernel runs it on packed pairs.  Per luma round it holds one pass-1 and one
+    pass-2 butterfly, per chroma round the same: every v_pk_fma_f32 must belong to one of the three exact uses."""
+    body = _body(enc_isa, "_ZN5jpgpu17fdct_fused_kernel")
+    op = lambda ln: re.sub(r"_(e32|e64|sdwa|dpp)$", "", ln.split()[0])
+    count = lambda name: sum(1 for ln in body if op(ln) == name)
+    # no scalar fused multiply-add outside quant_pair's two (the refined reciprocal, computed once per table entry)
+    assert count("v_fma_f32") + count("v_fmac_f32") <= 2 * 2
+    # butterflies: 4 packed ones in the edge variant + fast variant of pass 1 (2), pass 2 of luma (1) and chroma (2 in the loop body: pass 1 + pass 2)
+    n_butterflies = 2 + 1 + 2
+    assert count("v_pk_mul_f32") >= 14 * n_butterflies
+    assert count("v_pk_add_f32") >= 26 * n_butterflies
+    names = re.findall(r"\.name:\s+(\S+)", enc_isa)
+    vgprs = dict(zip(names, re.findall(r"\.vgpr_count:\s+(\d+)", enc_isa)))
+    spills = dict(zip(names, re.findall(r"\.vgpr_spill_count:\s+(\d+)", enc_isa)))
+    sspills = dict(zip(names, re.findall(r"\.sgpr_spill_count:\s+(\d+)", enc_isa)))
+    scratch = dict(zip(names, re.findall(r"\.private_segment_fixed_size:\s+(\d+)", enc_isa)))
+    lds = dict(zip(names, re.findall(r"\.group_segment_fixed_size:\s+(\d+)", enc_isa)))
+    n = next(x for x in names if "fdct_fused_kernel" in x)
+    assert int(vgprs[n]) <= 168 and spills[n] == "0" and sspills[n] == "0" and scratch[n] == "0"
+    assert int(lds[n]) * 12 <= 160 * 1024  # twelve waves per CU

@@ -79,10 +79,10 @@ def main():
     print(json.dumps({"metric": "Mpixels/s encoded (RGB 4:2:0 baseline, standard tables)", "value": round(px / dt / 1e6, 1), "unit": "Mpixels/s",
                       "ms_per_step": round(dt * 1e3, 2), "images": args.images, "restart_interval": args.dri, "bytes_per_image": len(out0),
                       "byte_exact_vs_oracle": out0 == ref, "stage_ms": {k: round(v, 3) for k, v in stage.items()},
-                      "roofline": {"kernel": {"fdct_quant": "enc_gather_kernel + fdct_quant_kernel", "block_bits": "block_bits_kernel", "emit": "emit_kernel",
+                      "roofline": {"kernel": {"fdct_quant": "enc_gather_kernel + fdct_quant_kernel" if os.environ.get("JPGPU_ENC_NO_FUSED") else "fdct_fused_kernel", "block_bits": "block_bits_kernel", "emit": "emit_kernel",
                                               "stuff": "stuff_count_kernel + stuff_write_kernel"}[dom], "bound": "hbm", "achieved": round(achieved, 1),
                                    "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "algorithmic_bytes": int(algo[dom]), "traffic": None,
-                                   "note": "stage time by HIP events on the library's stream; E1 is VALU / latency bound (64 IEEE divisions per block), not a bandwidth problem"},
+                                   "note": "stage time by HIP events on the library's stream; E1 (fdct_fused_kernel) is VALU bound: ~76 % of the SIMD cycles issue a vector instruction (tools/trace/encoder_pmc.sh)"},
                       "cpu_baseline": {"value": round(cpu, 1), "unit": "Mpixels/s", "cores": cores, "kind": "port",
                                        "sample": f"{n_cpu} encodes of 4 of the images, one encoder per native thread ({cpu_dt:.1f} s wall); single thread {single:.1f} Mpixels/s",
                                        "host_cpu_budget": budget, "gpu_over_cpu": round(px / dt / 1e6 / cpu, 1)}}))
