@@ -52,7 +52,8 @@ class EncodeBatch {
     int n_work_mcu_ = 0, n_work_blk_ = 0, n_work_stat_ = 0, n_work_chunk_ = 0;
     DevBuffer d_samples_;  // E1a -> E1b: gathered samples, enc_sample_bytes_per_mcu per MCU
     DevBuffer d_pixels_, d_images_, d_tables_, d_work_mcu_, d_work_blk_, d_work_stat_, d_work_chunk_, d_coefs_, d_bits_, d_bit_off_, d_raw_bits_, d_raw_, d_marks_,
-        d_chunk_ff_, d_out_, d_out_len_;
+        d_chunk_ff_, d_out_, d_out_len_, d_headers_;
+    std::vector<uint8_t> header_bytes_;  // every image's SOI..SOS, concatenated (one upload per encode)
 };
 
 }  // namespace jpgpu

@@ -28,6 +28,8 @@ struct alignas(16) DevEncImage {
     uint32_t smp_off_256; // gathered samples of the image (E1a -> E1b), offset into the sample buffer in units of 256 bytes
     uint32_t restart_interval;  // MCUs per restart interval, 0 = none (see jpgpu_encode_params)
     uint32_t n_units;     // lanes of block_bits / emit for this image: its blocks, or its restart intervals
+    uint32_t hdr_off;     // the image's SOI..SOS bytes in the batch's header buffer (place_headers_kernel puts them at out_off)
+    uint32_t reserved0;
     int32_t r2y[8];       // Fix() factors of the RGB -> YCbCr tables (host: rgb_ycc_factors)
     uint16_t quant[2][64];  // zig-zag quantisation tables: luma, chroma
 };
@@ -64,6 +66,8 @@ hipError_t launch_emit(hipStream_t stream, const DevEncImage *images, const EncW
 // the LDS buffer a workgroup of emit_kernel assembles its stretch of the stream in, in 32-bit words (launch_emit clamps to these)
 constexpr uint32_t kEmitLdsWordsMin = 2048, kEmitLdsWordsMax = 8192;
 constexpr uint32_t kEncStuffChunk = 4096;
+// the headers (one upload for the batch) to the front of every image's stream
+hipError_t launch_place_headers(hipStream_t stream, const DevEncImage *images, int n_images, const uint8_t *headers, uint8_t *out);
 // marks: one bit per raw byte (word (raw_off >> 5) + (j >> 5), bit j & 31 for byte j of the image): a restart marker follows it
 hipError_t launch_stuff(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const uint64_t *raw_bits,
                         const uint8_t *raw, const uint32_t *marks, uint32_t *chunk_ff, uint8_t *out, uint64_t *out_len);

@@ -1225,6 +1225,16 @@ __global__ __launch_bounds__(256) void stuff_write_kernel(const DevEncImage *__r
     }
 }
 
+// SOI .. SOS of every image in front of its stream (where that is depends on the sizes block_bits_kernel found: one upload of
+// all headers + this kernel instead of one small copy per image, which cost ~5 us each on the stream)
+__global__ __launch_bounds__(256) void place_headers_kernel(const DevEncImage *__restrict__ images, const uint8_t *__restrict__ headers,
+                                                            uint8_t *__restrict__ out) {
+    const DevEncImage &im = images[blockIdx.x];
+    const uint8_t *src = headers + im.hdr_off;
+    uint8_t *dst = out + im.out_off;
+    for (uint32_t j = threadIdx.x; j < im.header_len; j += 256) dst[j] = src[j];
+}
+
 // ------------------------------------------------------------------------------------------------ launch wrappers
 
 size_t enc_sample_bytes_per_mcu(uint32_t luma_h, uint32_t luma_v, uint32_t components) { return enc_sample_stride(luma_h, luma_v, components); }
@@ -1264,6 +1274,11 @@ hipError_t launch_emit(hipStream_t stream, const DevEncImage *images, const EncW
     if (lds_words != 0) lds_words = std::min(std::max(lds_words, kEmitLdsWordsMin), kEmitLdsWordsMax);  // 0: no workgroup's stretch would fit
     hipLaunchKernelGGL(emit_kernel, dim3(n_work), dim3(256), (size_t)lds_words * 4, stream, images, work, tables, coefs, bits, wg_base, raw_bits, raw,
                        marks, lds_words);
+    return hipGetLastError();
+}
+hipError_t launch_place_headers(hipStream_t stream, const DevEncImage *images, int n_images, const uint8_t *headers, uint8_t *out) {
+    if (n_images <= 0) return hipSuccess;
+    hipLaunchKernelGGL(place_headers_kernel, dim3(n_images), dim3(256), 0, stream, images, headers, out);
     return hipGetLastError();
 }
 hipError_t launch_stuff(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const uint64_t *raw_bits,
