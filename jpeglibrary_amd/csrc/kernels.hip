@@ -4053,7 +4053,9 @@ __global__ __launch_bounds__(256) void extend_u16_kernel(const uint8_t *__restri
     const uint32_t y = (uint32_t)(px / g.width), x = (uint32_t)(px - (uint64_t)y * g.width);
     const uint32_t p = g.precision, mx = (1u << p) - 1u;
     uint16_t v4[4] = {0, 0, 0, 0};
-    for (uint32_t c = 0; c < g.ncomp && c < 4u; c++) {
+#pragma unroll  // (compile-time component index: the descriptor's arrays stay in registers, no scratch)
+    for (uint32_t c = 0; c < 4u; c++) {
+        if (c >= g.ncomp) continue;
         const int16_t *pl = reinterpret_cast<const int16_t *>(planes + g.plane_off[c]);
         const uint32_t s = (uint32_t)(uint16_t)pl[(uint64_t)(y >> g.vshift[c]) * g.pitch[c] + (x >> g.hshift[c])];
         uint32_t bits = s < mx ? s : mx;  // Clamp((ushort)sample, max)
