@@ -15,6 +15,13 @@ if [ "${1:-}" = "headline" ]; then
   ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ingest > /tmp/ks.log 2>&1; cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_headline/kernel_stats_1024img.csv )
   python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_headline/bench.json 2>/dev/null
   cut -c1-200 gpurun_out/${TAG}_headline/bench.json
+  # the reference's own benchmark input (DecoderBenchmark.cs): line + kernel statistics
+  python3 bench.py --workload het_8192 --steps 5 --warmup 2 > gpurun_out/${TAG}_headline/bench_het_8192.json 2>/dev/null
+  cut -c1-200 gpurun_out/${TAG}_headline/bench_het_8192.json
+  ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kh && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kh -- python3 $R/bench.py --workload het_8192 --steps 5 --warmup 2 --no-cpu-baseline --no-ingest > /tmp/kh.log 2>&1; cp $(find /tmp/kh -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_headline/kernel_stats_het_8192.csv )
+  # random corpora through every GPU path against the checker (decode incl. partial flushes, optimizer, encoder)
+  for seed in 41 42 43; do python3 tools/stress_parity.py 1500 $seed 2>/dev/null | tail -1; done > gpurun_out/${TAG}_headline/stress.txt
+  cat gpurun_out/${TAG}_headline/stress.txt
   exit 0
 fi
 bash tools/trace/evidence_all.sh $TAG 2>&1 | tail -1   # (runs the PMC passes: tools/profile_pmc.sh)
@@ -26,5 +33,6 @@ bash tools/trace/progressive_by_scan.sh 256 $R/gpurun_out/all_$TAG/progressive_b
 bash tools/trace/progressive_by_scan.sh 2048 $R/gpurun_out/all_$TAG/progressive_by_scan_2048.txt > /dev/null 2>&1
 python3 tools/trace/multi_slots.py 256 3 $R/gpurun_out/all_$TAG/multi_slots.jsonl > gpurun_out/all_$TAG/multi_slots.txt 2>&1
 ( cd tools/microbench && ./issue_latency > $R/gpurun_out/all_$TAG/issue_latency.txt 2>&1; ./fetch_rate 1 > $R/gpurun_out/all_$TAG/fetch_rate.txt 2>&1; ./symbol_loop > $R/gpurun_out/all_$TAG/symbol_loop.txt 2>&1 )
+bash tools/trace/encoder_pmc.sh ${TAG}enc --images 64 > /dev/null 2>&1; cp gpurun_out/pmc_${TAG}enc/summary.txt gpurun_out/all_$TAG/encoder_pmc_summary_64img.txt
 timeout 600 bash tools/trace/progressive_pmc.sh 64 $R/gpurun_out/all_$TAG/progressive_pmc_64.txt > /dev/null 2>&1
 sha256sum jpeglibrary_amd/libjpgpu.so
