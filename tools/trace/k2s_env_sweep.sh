@@ -1,0 +1,11 @@
+R=$GRAFT_REPO_ROOT
+run() { echo "== $*"; ( cd $R && env "$@" python3 bench.py --workload 4k_dri0 --steps 8 --warmup 2 --no-cpu-baseline --no-ingest --no-planar-pass 2>/dev/null | python3 -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['value'], j['ms_per_step'], j['stage_ms'], j.get('subseq_rounds'))" ); }
+run A=1
+run JPGPU_SUBSEQ_SHIFT=13
+run JPGPU_SUBSEQ_SHIFT=13 JPGPU_SUBSEQ_WARM_BITS=4096
+run JPGPU_SUBSEQ_SHIFT=13 JPGPU_SUBSEQ_WARM_BITS=0
+run JPGPU_SUBSEQ_WARM_BITS=0
+run JPGPU_SUBSEQ_WARM_BITS=3072
+run JPGPU_SUBSEQ_WARM_BITS=1024
+run JPGPU_SUBSEQ_SHIFT=11
+run JPGPU_SUBSEQ_SHIFT=14 JPGPU_SUBSEQ_WARM_BITS=4096
