@@ -3417,7 +3417,12 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
         const uint4 dsum = sr_ld128(dc_lane);
         dcs = make_int4((int)dsum.x, (int)dsum.y, (int)dsum.z, (int)dsum.w);
     }
-    if (round == 0 || ex != exit_in[slot]) atomicOr(changed, 1u);
+    {
+        // how many exits this round changed (the host's convergence test; one atomic per wave that changed anything)
+        const bool ch = round == 0 || ex != exit_in[slot];
+        const uint64_t m = __ballot(ch);
+        if (ch && (uint32_t)__builtin_ctzll(m) == (threadIdx.x & 63u)) atomicAdd(changed, (uint32_t)__builtin_popcountll(m));
+    }
     exit_out[slot] = ex;
     nblk_out[slot] = nblk;
     dcsum_out[slot] = dcs;
@@ -4682,33 +4687,27 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
     }();
     static const int propagate_from = [] {  // rounds without convergence before the flat-region walk joins in (0 = never)
         const char *ev = getenv("JPGPU_SUBSEQ_PROPAGATE_FROM");
-        return ev ? atoi(ev) : 7;  // (7: behind the third batch of three rounds -- a batch that converges in six never pays for it)
+        return ev ? atoi(ev) : 6;  // (6: behind the second check -- a batch that converges in six rounds never pays for it)
     }();
     uint32_t *bufs[2] = {exit_a, exit_b};
-    // changed_dev[r] is set by round r; the host looks at the flags only every kCheckEvery rounds (one sync per check);
+    // changed_dev[r] = exits round r changed; the host looks at the counts only every kCheckEvery rounds (one sync per check),
+    // after every round once a round has changed no more than a few exits per scan (the end is then a round or two away);
     // changed_dev[63] counts what the flat-region walks copied
     constexpr int kCheckEvery = 3;
+    const uint32_t few_changes = 8u * (uint32_t)n_scans;
     hipError_t e = hipMemsetAsync(changed_dev, 0, 64 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     int round = 0;
     bool converged = false;
+    uint32_t last_count = 0xFFFFFFFFu, count_before = 0xFFFFFFFFu;  // exits the last two rounds changed
     while (!converged && round < max_rounds) {
         const int batch_first = round;
-        for (int i = 0; i < kCheckEvery && round < max_rounds; i++, round++) {
+        const int batch = last_count <= few_changes ? 1 : kCheckEvery;
+        for (int i = 0; i < batch && round < max_rounds; i++, round++) {
             const uint32_t *in = bufs[(round + 1) & 1];
             uint32_t *out = bufs[round & 1];
             hipLaunchKernelGGL(subseq_round_kernel, dim3(n_work), dim3(256), lds_round, stream, udata, scans, work, ends_u, status, huff_pool,
                                lut_pool, in, out, nblk, entry_used, (int4 *)dcsum, changed_dev + (round % 62), round, n_slots, warm_bits);
-        }
-        if (propagate_from > 0 && round >= propagate_from && same_dist != nullptr) {
-            // not converged by now (the previous check said so): flat regions?  Twins once per upload, then a walk behind every
-            // batch of rounds (it patches the buffer the last round wrote: the next round reads that one)
-            if (!*same_valid) {
-                hipLaunchKernelGGL(subseq_same_kernel, dim3(n_work), dim3(256), 0, stream, udata, scans, work, ends_u, status, same_dist);
-                *same_valid = true;
-            }
-            hipLaunchKernelGGL(subseq_propagate_kernel, dim3(n_scans), dim3(64), 0, stream, scans, scan_ids, same_dist, bufs[(round + 1) & 1], entry_used, nblk,
-                               (int4 *)dcsum, changed_dev + 63);
         }
         uint32_t flags[64];
         e = hipMemcpyAsync(flags, changed_dev, sizeof flags, hipMemcpyDeviceToHost, stream);
@@ -4716,11 +4715,33 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
         e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return e;
         // converged as soon as one round (other than round 0) changed nothing: later rounds are then no-ops
-        for (int r2 = batch_first; r2 < round; r2++)
+        for (int r2 = batch_first; r2 < round; r2++) {
             if (r2 > 0 && flags[r2 % 62] == 0) converged = true;
+            count_before = last_count;
+            last_count = flags[r2 % 62];
+        }
+        static const bool trace = getenv("JPGPU_SUBSEQ_TRACE") != nullptr;  // subsequences whose exit changed, per round
+        if (trace) {
+            for (int r2 = batch_first; r2 < round; r2++) fprintf(stderr, "K2S round %d: %u changed\n", r2, flags[r2 % 62]);
+            fprintf(stderr, "K2S walks copied so far: %u\n", flags[63]);
+        }
         if (!converged) {
             e = hipMemsetAsync(changed_dev, 0, 64 * sizeof(uint32_t), stream);
             if (e != hipSuccess) return e;
+            // Ordinary synchronisation dies out geometrically (a round changes a third to a tenth of what the one before it
+            // changed); a flat region changes as many exits round after round (one per run).  The walk is for the second kind.
+            const bool plateau = count_before == 0xFFFFFFFFu || (uint64_t)last_count * 2 > count_before;
+            if (propagate_from > 0 && round >= propagate_from && same_dist != nullptr && round < max_rounds && plateau) {
+                // still not converged (this check said so), and not about to: flat regions?  Twins once per upload, then a walk
+                // (it patches the buffer the last round wrote: the next round reads that one).  Decided AFTER the check: a batch
+                // that has just converged, or is converging, does not pay for the walk (0.66 ms per 16 benchmark canvases)
+                if (!*same_valid) {
+                    hipLaunchKernelGGL(subseq_same_kernel, dim3(n_work), dim3(256), 0, stream, udata, scans, work, ends_u, status, same_dist);
+                    *same_valid = true;
+                }
+                hipLaunchKernelGGL(subseq_propagate_kernel, dim3(n_scans), dim3(64), 0, stream, scans, scan_ids, same_dist, bufs[(round + 1) & 1], entry_used,
+                                   nblk, (int4 *)dcsum, changed_dev + 63);
+            }
         }
     }
     if (rounds_used) *rounds_used = round;
