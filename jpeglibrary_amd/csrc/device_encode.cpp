@@ -197,7 +197,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         if ((smp_off >> 8) > 0xFFFFFFFFull) return fail(JPGPU_ERR_OUT_OF_MEMORY, "sample buffer beyond 1 TiB");
         im.smp_off_256 = (uint32_t)(smp_off >> 8);
         // (an image fdct_fused_kernel takes has no gathered samples: 4.2 GB less per 256 x 4K)
-        if (!enc_fused_enabled() || !enc_image_fused(im))
+        if (!enc_fused_enabled() || enc_image_fused_shape(im) == 0)
             smp_off = align_up64(smp_off + (uint64_t)total_mcus * enc_sample_bytes_per_mcu(im.luma_h, im.luma_v, im.components), 256);
         for (uint32_t f = 0; f < total_mcus; f += kEncMcusPerWg) work_mcu.push_back({(uint32_t)i, f});
         im.work_first = (uint32_t)work_blk.size();
@@ -335,16 +335,18 @@ int EncodeBatch::encode() {
     e = hipMemcpyAsync(d_images_.ptr, images_.data(), (size_t)n * sizeof(DevEncImage), hipMemcpyHostToDevice, ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(images)");
     size_t max_record = 0;
-    bool any_fused = false, any_other = false;
+    uint32_t fused_shapes = 0;
+    bool any_other = false;
     const bool no_fused = !enc_fused_enabled();
     for (const DevEncImage &im : images_) {
         max_record = std::max(max_record, enc_sample_bytes_per_mcu(im.luma_h, im.luma_v, im.components));
-        if (!no_fused && enc_image_fused(im)) any_fused = true;
+        const int shape = no_fused ? 0 : enc_image_fused_shape(im);
+        if (shape != 0) fused_shapes |= 1u << shape;
         else any_other = true;
     }
     (void)hipEventRecord(ev_[0], ctx_->stream);
     e = launch_fdct_quant(ctx_->stream, (const uint8_t *)d_pixels_.ptr, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_mcu_.ptr, n_work_mcu_,
-                          (uint8_t *)d_samples_.ptr, (int16_t *)d_coefs_.ptr, max_record, any_fused, any_other);
+                          (uint8_t *)d_samples_.ptr, (int16_t *)d_coefs_.ptr, max_record, fused_shapes, any_other);
     if (e != hipSuccess) return hip_fail(e, "fdct_quant_kernel");
     if (!optimized_.empty()) {
         // optimizeCoding: BuildHuffmanTables (:491-550) -- statistics on the device, JpegHuffmanEncodingTableBuilder.Build on the host

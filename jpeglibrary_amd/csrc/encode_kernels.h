@@ -48,12 +48,13 @@ struct EncWork {
     uint32_t first;  // first MCU (kEncMcusPerWg per workgroup) / block (256) / stuffing chunk index
 };
 
-// E1: fdct_fused_kernel for the images enc_image_fused() names (any_fused: the batch holds such images), for the others
-// (any_other) E1a (pixel pass into `samples`, enc_sample_stride bytes per MCU) + E1b (FDCT + quantisation)
+// E1: fdct_fused_kernel<H, V> for the images enc_image_fused_shape() gives a shape (1: 2 x 2, 2: 2 x 1, 3: 1 x 1; fused_shapes:
+// bit s set = the batch holds images of shape s), for the others (shape 0; any_other) E1a (pixel pass into `samples`,
+// enc_sample_stride bytes per MCU) + E1b (FDCT + quantisation)
 hipError_t launch_fdct_quant(hipStream_t stream, const uint8_t *pixels, const DevEncImage *images, const EncWork *work, int n_work,
                              uint8_t *samples, int16_t *coefs, size_t max_record_bytes,  // (the largest enc_sample_bytes_per_mcu of the batch)
-                             bool any_fused, bool any_other);
-bool enc_image_fused(const DevEncImage &im);
+                             uint32_t fused_shapes, bool any_other);
+int enc_image_fused_shape(const DevEncImage &im);
 size_t enc_sample_bytes_per_mcu(uint32_t luma_h, uint32_t luma_v, uint32_t components);
 hipError_t launch_block_bits(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
                              const int16_t *coefs, uint32_t *bits, int n_images, uint32_t *wg_bits, uint64_t *wg_base, uint64_t *raw_bits);

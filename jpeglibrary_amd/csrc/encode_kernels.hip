@@ -81,10 +81,16 @@ __device__ __forceinline__ void block_fdct(float (&f)[64]) {
     for (int i = 0; i < 64; i++) f[i] = f[i] * 0.1250f;
 }
 
-// The shape fdct_fused_kernel takes (E1 as one kernel); every other shape goes through E1a + E1b.
-__host__ __device__ inline bool enc_fused_ok(const DevEncImage &im) {
-    return im.components == 3 && im.in_components == 3 && im.luma_h == 2 && im.luma_v == 2;
+// The shapes fdct_fused_kernel takes (E1 as one kernel: three components from three-sample pixels, luma 2 x 2, 2 x 1 or
+// 1 x 1 -> instance 1, 2, 3); every other shape (0) goes through E1a + E1b.
+__host__ __device__ inline int enc_fused_shape(const DevEncImage &im) {
+    if (im.components != 3 || im.in_components != 3) return 0;
+    if (im.luma_h == 2 && im.luma_v == 2) return 1;
+    if (im.luma_h == 2 && im.luma_v == 1) return 2;
+    if (im.luma_h == 1 && im.luma_v == 1) return 3;
+    return 0;
 }
+__host__ __device__ inline bool enc_fused_ok(const DevEncImage &im) { return enc_fused_shape(im) != 0; }
 
 // What the sample reader needs from the image descriptor, held in registers (the descriptor is read once).
 struct EncSrc {
@@ -470,7 +476,8 @@ __global__ __launch_bounds__(kEncMcusPerWg, JPGPU_E1B_WAVES) void fdct_quant_ker
 
 // ------------------------------------------------------------------------------------------------ E1 fused
 //
-// E1 as ONE kernel for the usual shape (three components from three-sample pixels, luma 2 x 2: enc_fused_ok): pixels in,
+// E1 as ONE kernel for the usual shapes (three components from three-sample pixels, luma 2 x 2, 2 x 1 or 1 x 1:
+// enc_fused_shape; described for 2 x 2, the others differ in how many MCUs a gather round takes): pixels in,
 // quantised blocks out, nothing in between leaves the CU.  E1a + E1b move the gathered samples through HBM (4.2 GB out and
 // in again per 256 x 4K) and E1b holds a whole block per lane (245 registers, two waves per SIMD).  Here a WAVE owns 16
 // consecutive MCUs and every step runs on all 64 lanes, two rows / columns per lane as one packed float pair:
@@ -555,15 +562,16 @@ struct EfConvert {
     float y[3], b[3], r[3], oy, oc;  // luma: R G B; Cb: R G B; Cr: R G B (the negative ones first in the chain)
 };
 
-// One pixel row of an MCU (16 pixels, 48 bytes in w): luma row through pass 1 into the transpose buffer, chroma pair sums
-// combined with the neighbour lane's row into the sums buffer.  EDGE: pixels outside the image (`inside`: one bit per pixel).
-template <bool EDGE>
-__device__ __forceinline__ void ef_row(uint8_t *sh, const uint32_t (&w)[12], uint32_t inside, const EfConvert &cv, uint32_t mloc, uint32_t gk,
-                                       uint32_t gm, uint32_t gdy, uint32_t ry) {
+// One pixel row of an MCU (8 H pixels in w): luma row through pass 1 into the transpose buffer (block tblk, and tblk + 1 for
+// the right half when H = 2), chroma sums into the sums buffer -- pairs summed in the lane when H = 2, the row below (above)
+// added from the neighbour lane when V = 2.  EDGE: pixels outside the image (`inside`: one bit per pixel).
+template <int H, int V, bool EDGE>
+__device__ __forceinline__ void ef_row(uint8_t *sh, const uint32_t (&w)[6 * H], uint32_t inside, const EfConvert &cv, uint32_t mloc, uint32_t gk,
+                                       uint32_t tblk, uint32_t gdy, uint32_t ry) {
     float sb[8], sr[8];
-    EncF2 v[8];
+    EncF2 v[8];  // H = 2: left block in .x, right block in .y; H = 1: .x
 #pragma unroll
-    for (int i = 0; i < 16; i += 2) {
+    for (int i = 0; i < 8 * H; i += 2) {
         EncF2 c[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
@@ -579,10 +587,16 @@ __device__ __forceinline__ void ef_row(uint8_t *sh, const uint32_t (&w)[12], uin
         const EncF2 rv = ef_floor(__builtin_elementwise_fma(EncF2{cv.r[0], cv.r[0]}, c[0],
                              __builtin_elementwise_fma(EncF2{cv.r[2], cv.r[2]}, c[2],
                              __builtin_elementwise_fma(EncF2{cv.r[1], cv.r[1]}, c[1], EncF2{cv.oc, cv.oc}))));
-        if (i < 8) v[i].x = yv.x, v[i + 1].x = yv.y;
-        else v[i - 8].y = yv.x, v[i - 7].y = yv.y;
-        sb[i >> 1] = bv.x + bv.y;
-        sr[i >> 1] = rv.x + rv.y;
+        if (H == 2) {
+            if (i < 8) v[i & 7].x = yv.x, v[(i + 1) & 7].x = yv.y;
+            else v[i & 7].y = yv.x, v[(i + 1) & 7].y = yv.y;
+            sb[(i >> 1) & 7] = bv.x + bv.y;
+            sr[(i >> 1) & 7] = rv.x + rv.y;
+        } else {
+            v[i & 7].x = yv.x, v[(i + 1) & 7].x = yv.y;
+            sb[i & 7] = bv.x, sb[(i + 1) & 7] = bv.y;
+            sr[i & 7] = rv.x, sr[(i + 1) & 7] = rv.y;
+        }
     }
     if (EDGE) {
         // a pixel outside the image is the SAMPLE zero in every component, not the conversion of a black pixel: the zero
@@ -590,47 +604,72 @@ __device__ __forceinline__ void ef_row(uint8_t *sh, const uint32_t (&w)[12], uin
         const float off = __builtin_floorf(cv.oc);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const float n_out = (float)(2 - (int32_t)__builtin_popcount((inside >> (2 * j)) & 3u));
+            const float n_out = H == 2 ? (float)(2 - (int32_t)__builtin_popcount((inside >> (2 * j)) & 3u)) : (float)(1u - ((inside >> j) & 1u));
             sb[j] -= n_out * off;
             sr[j] -= n_out * off;
         }
     }
-    // the pixel row below (above) is the neighbour lane's: the even lane keeps Cb, the odd lane Cr
-    uint32_t both[4];
+    // sums -> int16 (x + 2^23: the low bits are the small, non-negative integer.  Scalar copies: __builtin_bit_cast of a vector
+    // ELEMENT reads the vector's first one)
+    auto pack2 = [](float a, float b) {
+        const float lo = a + 8388608.0f, hi = b + 8388608.0f;
+        return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x05040100u);
+    };
+    if (V == 2) {
+        // the pixel row below (above) is the neighbour lane's: the even lane keeps Cb, the odd lane Cr
+        uint32_t both[4];
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        EncF2 tot;
-        {
-            const float mine = gdy ? sr[j] : sb[j], give = gdy ? sb[j] : sr[j];
-            tot.x = mine + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+        for (int j = 0; j < 8; j += 2) {
+            float tot[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const float mine = gdy ? sr[j + u] : sb[j + u], give = gdy ? sb[j + u] : sr[j + u];
+                tot[u] = mine + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+            }
+            both[j >> 1] = pack2(tot[0], tot[1]);
         }
-        {
-            const float mine = gdy ? sr[j + 1] : sb[j + 1], give = gdy ? sb[j + 1] : sr[j + 1];
-            tot.y = mine + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
-        }
-        // + 2^23: the low bits are the (small, non-negative) integer.  (scalar copies: __builtin_bit_cast of a vector ELEMENT
-        // reads the vector's first one)
-        const float lo = tot.x + 8388608.0f, hi = tot.y + 8388608.0f;
-        both[j >> 1] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x05040100u);
+        *reinterpret_cast<uint4 *>(sh + kEfSums + ((mloc * 2u + gdy) * 8u + gk) * 16u) = uint4{both[0], both[1], both[2], both[3]};
+    } else {
+        *reinterpret_cast<uint4 *>(sh + kEfSums + ((mloc * 2u + 0u) * 8u + gk) * 16u) =
+            uint4{pack2(sb[0], sb[1]), pack2(sb[2], sb[3]), pack2(sb[4], sb[5]), pack2(sb[6], sb[7])};
+        *reinterpret_cast<uint4 *>(sh + kEfSums + ((mloc * 2u + 1u) * 8u + gk) * 16u) =
+            uint4{pack2(sr[0], sr[1]), pack2(sr[2], sr[3]), pack2(sr[4], sr[5]), pack2(sr[6], sr[7])};
     }
-    *reinterpret_cast<uint4 *>(sh + kEfSums + ((mloc * 2u + gdy) * 8u + gk) * 16u) = uint4{both[0], both[1], both[2], both[3]};
-    // pass 1 of the lane's luma row: left and right block side by side
-    fdct8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-    float *t = reinterpret_cast<float *>(sh + kEfT) + (gm * 4u + (ry >> 3) * 2u) * kEfS + (ry & 7u) * 8u;
+    // pass 1 of the lane's luma row (H = 2: left and right block side by side)
+    float *t = reinterpret_cast<float *>(sh + kEfT) + tblk * kEfS + (ry & 7u) * 8u;
+    if (H == 2) {
+        fdct8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        t[i] = v[i].x;
-        t[kEfS + i] = v[i].y;
+        for (int i = 0; i < 8; i++) {
+            t[i] = v[i].x;
+            t[kEfS + i] = v[i].y;
+        }
+    } else {
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) f[i] = v[i].x;
+        fdct8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) t[i] = f[i];
     }
 }
 
+// H x V = the luma sampling factors: 2 x 2 (4:2:0), 2 x 1 (4:2:2), 1 x 1 (4:4:4); enc_fused_shape() names the instance.
+template <int H, int V>
 __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restrict__ pixels, const DevEncImage *__restrict__ images,
                                                         const EncWork *__restrict__ work, int16_t *__restrict__ coefs) {
+    constexpr uint32_t kRows = 8 * V;                    // pixel rows of an MCU
+    constexpr uint32_t kPerRound = 64 / kRows;           // MCUs a gather round takes (one lane per pixel row)
+    constexpr uint32_t kRounds = kEfMcus / kPerRound;
+    constexpr uint32_t kNY = H * V, kBpm = kNY + 2;      // luma blocks / blocks per MCU
+    constexpr uint32_t kRoundsPerPass = 16 / (kPerRound * kNY);  // gather rounds that fill the transpose buffer's 16 blocks
+    constexpr uint32_t kMcuW = 8 * H, kMcuH = 8 * V, kWords = 6 * H;
+    constexpr int kShift = (H == 2 ? 1 : 0) + (V == 2 ? 1 : 0);  // pixels per chroma sample = 1 << kShift
     __shared__ __attribute__((aligned(16))) uint8_t sh[kEfLdsBytes];
     constexpr uint32_t kPerItem = kEncMcusPerWg / kEfMcus;
     const EncWork wk = work[blockIdx.x / kPerItem];
     const DevEncImage &im = images[wk.image];
-    if (!enc_fused_ok(im)) return;  // (E1a + E1b take these)
+    if (enc_fused_shape(im) != (H == 2 ? (V == 2 ? 1 : 2) : 3)) return;  // (another instance, or E1a + E1b, takes the image)
     const uint32_t mcus_per_line = im.mcus_per_line;
     const uint32_t n_mcus = mcus_per_line * im.mcus_per_column;
     const uint32_t base = wk.first + (blockIdx.x % kPerItem) * kEfMcus;
@@ -664,83 +703,99 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
         cv.oy = -128.0f, cv.oc = 0.0f;
     }
     const uint32_t row_bytes = width * 3u;
-    const bool rows16 = (row_bytes & 15u) == 0, rows4 = (row_bytes & 3u) == 0;
+    const bool rows4 = (row_bytes & 3u) == 0;
 
-    // ---- luma: four rounds of gather + pass 1, pass 2, leave
+    // ---- luma: rounds of gather + pass 1; pass 2 and out whenever the transpose buffer holds 16 blocks
     // gather: lane = (MCU of the round, pixel row inside the MCU); chroma row, row of the pair.  (Eight neighbouring lanes put
     // eight different rows of one block column into the transpose buffer: two lanes per bank group instead of four.)
-    const uint32_t gm = lane >> 4, ry = lane & 15u, gk = ry >> 1, gdy = lane & 1u;
-    // The usual case -- rows that start on 16 bytes -- fetches the pixels of round g + 1 while round g goes through pass 2:
-    // three 16-byte loads from an address clamped into the image, so that they can be issued before anybody knows whether
-    // the round touches the image's edge (then they are dropped and the edge variant reads byte by byte).
-    const bool ahead = rows16 && width >= 16 && height >= 1;
-    uint32_t w[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto fetch = [&](uint32_t g) {
-        const uint32_t mloc = g * 4u + gm;
-        const uint32_t mcu = base + mloc < n_mcus ? base + mloc : n_mcus - 1;
-        uint32_t x0 = (mcu % mcus_per_line) * 16u, y = (mcu / mcus_per_line) * 16u + ry;
-        x0 = x0 + 16 <= width ? x0 : width - 16;
-        y = y < height ? y : height - 1;
-        const uint4 *rowp = reinterpret_cast<const uint4 *>(px + ((size_t)y * width + x0) * 3);
+    const uint32_t gm = lane / kRows, ry = lane % kRows, gk = ry >> (V - 1), gdy = V == 2 ? (lane & 1u) : 0u;
+    // The usual case -- pixel rows of an MCU that start on 16 (8 for H = 1) bytes -- fetches the pixels of round g + 1 while
+    // round g goes through pass 2: loads from an address clamped into the image, so that they can be issued before anybody
+    // knows whether the round touches the image's edge (then they are dropped and the edge variant reads byte by byte).
+    const bool ahead = (row_bytes & (H == 2 ? 15u : 7u)) == 0 && width >= kMcuW && height >= 1;
+    uint32_t w[kWords];
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const uint4 t = rowp[j];
-            w[4 * j] = t.x, w[4 * j + 1] = t.y, w[4 * j + 2] = t.z, w[4 * j + 3] = t.w;
+    for (uint32_t j = 0; j < kWords; j++) w[j] = 0;
+    auto fetch = [&](uint32_t g) {
+        const uint32_t mloc = g * kPerRound + gm;
+        const uint32_t mcu = base + mloc < n_mcus ? base + mloc : n_mcus - 1;
+        uint32_t x0 = (mcu % mcus_per_line) * kMcuW, y = (mcu / mcus_per_line) * kMcuH + ry;
+        x0 = x0 + kMcuW <= width ? x0 : width - kMcuW;
+        y = y < height ? y : height - 1;
+        const uint8_t *rowp = px + ((size_t)y * width + x0) * 3;
+        if constexpr (H == 2) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const uint4 t = reinterpret_cast<const uint4 *>(rowp)[j];
+                w[4 * j] = t.x, w[4 * j + 1] = t.y, w[4 * j + 2] = t.z, w[4 * j + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const uint2 t = reinterpret_cast<const uint2 *>(rowp)[j];
+                w[2 * j] = t.x, w[2 * j + 1] = t.y;
+            }
         }
     };
     if (ahead) fetch(0);
 #pragma unroll 1
-    for (uint32_t g = 0; g < 4; g++) {
+    for (uint32_t g = 0; g < kRounds; g++) {
         {
-            const uint32_t mloc = g * 4u + gm;
+            const uint32_t mloc = g * kPerRound + gm;
             const uint32_t mcu = base + mloc < n_mcus ? base + mloc : n_mcus - 1;  // lanes behind the last MCU redo it, and store nothing
-            const uint32_t x0 = (mcu % mcus_per_line) * 16u, y = (mcu / mcus_per_line) * 16u + ry;
-            const bool whole = x0 + 16 <= width && y < height;
+            const uint32_t x0 = (mcu % mcus_per_line) * kMcuW, y = (mcu / mcus_per_line) * kMcuH + ry;
+            const uint32_t tblk = (g % kRoundsPerPass) * (kPerRound * kNY) + gm * kNY + (V == 2 ? (ry >> 3) * H : 0u);
+            const bool whole = x0 + kMcuW <= width && y < height;
             if (ahead && __builtin_amdgcn_ballot_w64(!whole) == 0) {
-                ef_row<false>(sh, w, 0xFFFFu, cv, mloc, gk, gm, gdy, ry);
+                ef_row<H, V, false>(sh, w, 0xFFFFu, cv, mloc, gk, tblk, gdy, ry);
             } else {
                 // the edge of the image (outside it the reader leaves zeros, JpegBufferInputReader.cs:27-52), or rows that do
-                // not start on 16 bytes
+                // not start where the wide loads want them
                 const uint8_t *rowp = px + ((size_t)y * width + x0) * 3;
-                uint32_t we[12];
+                uint32_t we[kWords];
                 uint32_t inside = 0xFFFFu;  // the row's pixels that lie inside the image
                 if (whole && rows4) {
-                    __builtin_memcpy(we, __builtin_assume_aligned(rowp, 4), 48);
+                    __builtin_memcpy(we, __builtin_assume_aligned(rowp, 4), kWords * 4);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 12; j++) we[j] = 0;
+                    for (uint32_t j = 0; j < kWords; j++) we[j] = 0;
                     inside = 0;
                     if (y < height) {
-                        const uint32_t np = x0 >= width ? 0u : (width - x0 < 16u ? width - x0 : 16u), nb = np * 3u;
+                        const uint32_t np = x0 >= width ? 0u : (width - x0 < kMcuW ? width - x0 : kMcuW), nb = np * 3u;
                         inside = (1u << np) - 1u;
                         for (uint32_t j = 0; j < nb; j++) {
                             const uint32_t bv = (uint32_t)rowp[j] << (8u * (j & 3u));
 #pragma unroll
-                            for (int q = 0; q < 12; q++)
-                                if ((j >> 2) == (uint32_t)q) we[q] |= bv;
+                            for (uint32_t q = 0; q < kWords; q++)
+                                if ((j >> 2) == q) we[q] |= bv;
                         }
                     }
                 }
-                ef_row<true>(sh, we, inside, cv, mloc, gk, gm, gdy, ry);
+                ef_row<H, V, true>(sh, we, inside, cv, mloc, gk, tblk, gdy, ry);
             }
-            if (ahead && g < 3) fetch(g + 1);
+            if (ahead && g + 1 < kRounds) fetch(g + 1);
         }
+        if ((g + 1) % kRoundsPerPass != 0) continue;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         ef_pass2(sh, p2q, p2c, za, zb);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t pass_first = (g + 1 - kRoundsPerPass) * kPerRound;  // first MCU (of the wave's 16) in the transpose buffer
 #pragma unroll
         for (uint32_t j = 0; j < 2; j++) {
             const uint32_t i = lane + 64u * j, q = i >> 3, piece = i & 7u;
-            const uint32_t mloc = g * 4u + (q >> 2), yb = q & 3u;
+            const uint32_t mloc = pass_first + q / kNY, yb = q % kNY;
             const uint4 val = *reinterpret_cast<const uint4 *>(sh + kEfStage + q * kEfStageStride + piece * 16u);
-            if (base + mloc < n_mcus) *reinterpret_cast<uint4 *>(out + ((uint64_t)(base + mloc) * 6u + yb) * 64u + piece * 8u) = val;
-            if (yb == 3u) *reinterpret_cast<uint4 *>(sh + kEfCarry + mloc * 128u + piece * 16u) = val;
+            if (base + mloc < n_mcus) *reinterpret_cast<uint4 *>(out + ((uint64_t)(base + mloc) * kBpm + yb) * 64u + piece * 8u) = val;
+            if (kShift > 0 && yb == kNY - 1) *reinterpret_cast<uint4 *>(sh + kEfCarry + mloc * 128u + piece * 16u) = val;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // ---- chroma: Cb of the 16 MCUs, then Cr
     ef_quant_table(sh, im.quant[1], lane);
-    const uint32_t keep = own_blocks ? 0u : 0xFFFFFFFFu;
+    // a sub-sampled component's block starts from the previous block's coefficients (not with optimizeCoding); a component
+    // that is not sub-sampled is read like a luma block (ReadBlock: nothing carried over, nothing to round)
+    const uint32_t keep = (own_blocks || kShift == 0) ? 0u : 0xFFFFFFFFu;
+    constexpr float kScale = 1.0f / (float)(1 << kShift), kOffset = (kShift > 0 ? 0.5f : 0.0f) - 128.0f;
     const uint32_t cr = lane & 7u, cm = (lane >> 3) * 2u;  // pass 1: row, first MCU of the pair
 #pragma unroll 1
     for (uint32_t comp = 0; comp < 2; comp++) {
@@ -756,12 +811,12 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
                 const uint32_t sw[4] = {sum.x, sum.y, sum.z, sum.w}, pw[4] = {prev.x, prev.y, prev.z, prev.w};
 #pragma unroll
                 for (int i = 0; i < 8; i += 2) {
-                    // (short)(previous + sum): 16-bit wrap-around add on both halves; then ((int)t + 2) >> 2, - 128, as
-                    // floor(t / 4 + 0.5 - 128) -- exact in float
+                    // (short)(previous + sum): 16-bit wrap-around add on both halves; then ((int)t + half) >> shift, - 128, as
+                    // floor(t / 2^shift + 0.5 - 128) -- exact in float
                     typedef short S2 __attribute__((ext_vector_type(2)));
                     typedef unsigned short U2 __attribute__((ext_vector_type(2)));
                     const S2 t = __builtin_bit_cast(S2, __builtin_bit_cast(U2, pw[i >> 1] & keep) + __builtin_bit_cast(U2, sw[i >> 1]));
-                    const EncF2 f = ef_floor(__builtin_elementwise_fma(EncF2{(float)t.x, (float)t.y}, EncF2{0.25f, 0.25f}, EncF2{-127.5f, -127.5f}));
+                    const EncF2 f = ef_floor(__builtin_elementwise_fma(EncF2{(float)t.x, (float)t.y}, EncF2{kScale, kScale}, EncF2{kOffset, kOffset}));
                     if (side == 0) v[i].x = f.x, v[i + 1].x = f.y;
                     else v[i].y = f.x, v[i + 1].y = f.y;
                 }
@@ -782,7 +837,7 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
         for (uint32_t j = 0; j < 2; j++) {
             const uint32_t i = lane + 64u * j, m = i >> 3, piece = i & 7u;
             const uint4 val = *reinterpret_cast<const uint4 *>(sh + kEfStage + m * kEfStageStride + piece * 16u);
-            if (base + m < n_mcus) *reinterpret_cast<uint4 *>(out + ((uint64_t)(base + m) * 6u + 4u + comp) * 64u + piece * 8u) = val;
+            if (base + m < n_mcus) *reinterpret_cast<uint4 *>(out + ((uint64_t)(base + m) * kBpm + kNY + comp) * 64u + piece * 8u) = val;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -1250,18 +1305,22 @@ __global__ __launch_bounds__(256) void place_headers_kernel(const DevEncImage *_
 
 size_t enc_sample_bytes_per_mcu(uint32_t luma_h, uint32_t luma_v, uint32_t components) { return enc_sample_stride(luma_h, luma_v, components); }
 
-bool enc_image_fused(const DevEncImage &im) { return enc_fused_ok(im); }
+int enc_image_fused_shape(const DevEncImage &im) { return enc_fused_shape(im); }
 
 hipError_t launch_fdct_quant(hipStream_t stream, const uint8_t *pixels, const DevEncImage *images, const EncWork *work, int n_work,
-                             uint8_t *samples, int16_t *coefs, size_t max_record_bytes, bool any_fused, bool any_other) {
+                             uint8_t *samples, int16_t *coefs, size_t max_record_bytes, uint32_t fused_shapes, bool any_other) {
     if (n_work <= 0) return hipSuccess;
-    if (any_fused) hipLaunchKernelGGL(fdct_fused_kernel, dim3(n_work * (kEncMcusPerWg / kEfMcus)), dim3(64), 0, stream, pixels, images, work, coefs);
+    const dim3 grid(n_work * (kEncMcusPerWg / kEfMcus));
+    if (fused_shapes & 2u) hipLaunchKernelGGL((fdct_fused_kernel<2, 2>), grid, dim3(64), 0, stream, pixels, images, work, coefs);
+    if (fused_shapes & 4u) hipLaunchKernelGGL((fdct_fused_kernel<2, 1>), grid, dim3(64), 0, stream, pixels, images, work, coefs);
+    if (fused_shapes & 8u) hipLaunchKernelGGL((fdct_fused_kernel<1, 1>), grid, dim3(64), 0, stream, pixels, images, work, coefs);
     if (any_other) {
+        const bool skip = fused_shapes != 0;
         const size_t lds = max_record_bytes * (size_t)kEncMcusPerWg;
         if (lds <= 64 * 1024)
-            hipLaunchKernelGGL(enc_gather_kernel<true>, dim3(n_work), dim3(8 * kEncMcusPerWg), lds, stream, pixels, images, work, samples, any_fused);
-        else hipLaunchKernelGGL(enc_gather_kernel<false>, dim3(n_work), dim3(8 * kEncMcusPerWg), 0, stream, pixels, images, work, samples, any_fused);
-        hipLaunchKernelGGL(fdct_quant_kernel, dim3(n_work), dim3(kEncMcusPerWg), 0, stream, samples, images, work, coefs, any_fused);
+            hipLaunchKernelGGL(enc_gather_kernel<true>, dim3(n_work), dim3(8 * kEncMcusPerWg), lds, stream, pixels, images, work, samples, skip);
+        else hipLaunchKernelGGL(enc_gather_kernel<false>, dim3(n_work), dim3(8 * kEncMcusPerWg), 0, stream, pixels, images, work, samples, skip);
+        hipLaunchKernelGGL(fdct_quant_kernel, dim3(n_work), dim3(kEncMcusPerWg), 0, stream, samples, images, work, coefs, skip);
     }
     return hipGetLastError();
 }

@@ -896,18 +896,19 @@ FUSED_SHAPES = [(100, 80), (20, 16), (12, 40), (48, 1), (16, 16), (272, 33), (16
 
 @pytest.mark.parametrize("w,h", FUSED_SHAPES)
 @pytest.mark.parametrize("opt", [False, True])
-def test_encoder_fused_e1_row_alignments_and_edges(w, h, opt):
-    """fdct_fused_kernel (three components, 4:2:0) on the shapes its paths split by: rows that start on 16 bytes / on 4 / on
+@pytest.mark.parametrize("luma", [(2, 2), (2, 1), (1, 1)])
+def test_encoder_fused_e1_row_alignments_and_edges(w, h, opt, luma):
+    """fdct_fused_kernel<H, V> (three components; 4:2:0, 4:2:2, 4:4:4) on the shapes its paths split by: rows that start on 16 bytes / on 4 / on
     nothing, images narrower than one MCU, partial MCUs right and below, more than 16 MCUs -- coefficients and stream equal
     the checker's for YCbCr and for RGB pixels, with the standard tables and with optimizeCoding (no carry-over from the
     previous block, JpegEncoder.cs:414-485)."""
     rgb = _enc_image(w, h, 3 * w + h)
     ycc = po.rgb_to_ycbcr8(rgb)
-    ref, ref_coefs = po.encode_8bit(ycc, 2, 2, 77, want_coefficients=True, optimize_coding=opt)
-    b = jl.EncodeBatch().upload([ycc], (2, 2), 77, optimize_coding=opt).encode()
+    ref, ref_coefs = po.encode_8bit(ycc, luma[0], luma[1], 77, want_coefficients=True, optimize_coding=opt)
+    b = jl.EncodeBatch().upload([ycc], luma, 77, optimize_coding=opt).encode()
     assert np.array_equal(b.coefficients(0), ref_coefs)
     assert b.output(0) == ref
-    assert jl.encode_batch([rgb], (2, 2), 77, rgb=True, optimize_coding=opt)[0] == ref
+    assert jl.encode_batch([rgb], luma, 77, rgb=True, optimize_coding=opt)[0] == ref
 
 
 def test_encoder_fused_and_two_kernel_images_in_one_batch():
