@@ -12,12 +12,18 @@ for f in bench_4k_dri0.json bench_1080p_q90.json bench_planar_u8.json bench_rgb_
          bench_4k_progressive_1024.json bench_4k_progressive_2048.json bench_encode_256.json bench_encode_256_dri4.json bench_optimize_256.json \
          kernel_stats_1080p_q90.csv kernel_stats_4k_dri0.csv kernel_stats_4k_progressive.csv kernel_stats_planar_u8.csv pmc_summary_128img.txt \
          progressive_by_scan_256.txt progressive_by_scan_2048.txt progressive_pmc_64.txt symbol_loop.txt fetch_rate.txt issue_latency.txt \
-         multi_slots.jsonl library.sha256; do cp $S/$f $R/profiles/${TAG}_$f; done
-cp $S/bench.json $R/profiles/${TAG}_bench_busy_box.json
-cp $S/kernel_stats_1024img.csv $R/profiles/${TAG}_kernel_stats_1024img_busy_box.csv
+         kernel_stats_rgb_u8.csv kernel_stats_rgba_u8.csv multi_slots.jsonl multi_slots.txt encoder_pmc_summary_64img.txt library.sha256; do
+  [ -e $S/$f ] && cp $S/$f $R/profiles/${TAG}_$f
+done
+# the headline line and its kernel statistics inside the long evidence call (a box under load for minutes) ...
+cp $S/bench.json $R/profiles/${TAG}_bench_evidence_call.json
+cp $S/kernel_stats_1024img.csv $R/profiles/${TAG}_kernel_stats_1024img_evidence_call.csv
+# ... and in a call of their own, with the reference's benchmark input and the stress sweeps (final_evidence.sh headline)
 if [ -d $R/gpurun_out/${TAG}_headline ]; then
-  cp $R/gpurun_out/${TAG}_headline/bench.json $R/profiles/${TAG}_bench.json
-  cp $R/gpurun_out/${TAG}_headline/kernel_stats_1024img.csv $R/profiles/${TAG}_kernel_stats_1024img.csv
+  H=$R/gpurun_out/${TAG}_headline
+  cp $H/bench.json $R/profiles/${TAG}_bench.json
+  cp $H/kernel_stats_1024img.csv $R/profiles/${TAG}_kernel_stats_1024img.csv
+  for f in bench_het_8192.json kernel_stats_het_8192.csv stress.txt; do [ -e $H/$f ] && cp $H/$f $R/profiles/${TAG}_$f; done
 fi
 ( cd $R && bash tools/trace/kernel_resources.sh > profiles/${TAG}_kernel_resources.txt 2>/dev/null )
 python3 - $S $R/gpurun_out/${TAG}_headline <<'PY'
