@@ -1339,8 +1339,12 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 // test hook: "k:ms" makes scan k (0-based, in file order) of every progressive frame slow: it idles ms at its start and
                 // after every progress word -- a producer its followers catch up with, which the launches only produce by chance
                 if (dbg_delay_scan >= 0 && dbg_delay_scan == j - img.jobs[0] - 1) s.debug_delay_ms = (uint8_t)std::min(255, std::max(0, dbg_delay_ms));
-                if (job.n_deps > 3 || s.n_intervals != 1 || s.n_intervals > stream_max_intervals) prog_pipelined_ = false;
-                if (s.n_intervals <= stream_max_intervals && !job.force_lane) {
+                // an AC scan whose band is empty (Ss > Se: a corrupted header; the reference's loops over the band then never run and
+                // the scan reads no bit) goes to the lane kernel, whose loops are the reference's: the stream kernel's block decoders
+                // are written for a band of at least one coefficient (tests/golden/stress/progressive_se_below_ss_122.jpg)
+                const bool empty_band = job.ss != 0 && job.ss > job.se;
+                if (job.n_deps > 3 || s.n_intervals != 1 || s.n_intervals > stream_max_intervals || empty_band) prog_pipelined_ = false;
+                if (s.n_intervals <= stream_max_intervals && !job.force_lane && !empty_band) {
                     for (uint32_t i = 0; i < s.n_intervals; i++) prog_streams_by_ordinal[ordinal].push_back({(uint32_t)j, i});
                     // chain of the scan: DC scans (interleaved, or Ss = 0) touch coefficient 0 only, an AC scan the band of ONE
                     // component (what it may write beyond its header stays inside that component's AC coefficients)

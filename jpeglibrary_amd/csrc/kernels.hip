@@ -2492,6 +2492,16 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
         }
         int32_t pred[kMaxScanComponents] = {0, 0, 0, 0};
         uint32_t u0 = 0;
+        // A scan header may name one frame component twice (InitDecodeComponents keeps both entries, each with its own
+        // predictor): the two blocks of a unit are then the SAME block of the store, written one after the other.  The passes
+        // below take 64 blocks at once -- two lanes with one address in one store, or one read-modify-write -- so such a scan
+        // goes block by block (tests/golden/stress/progressive_duplicate_component_*.jpg: corrupted headers do this)
+        bool aliased = false;
+#pragma unroll
+        for (uint32_t c = 0; c < kMaxScanComponents; c++)
+#pragma unroll
+            for (uint32_t c2 = c + 1; c2 < kMaxScanComponents; c2++)
+                if (c2 < ncomp && s.comp[c].component_index == s.comp[c2].component_index) aliased = true;
         if (ah != 0) {
             // DC refinement (ReadBlockProgressiveDC, the Ah != 0 arm, :240-252): ONE bit per block and nothing else in the
             // stream, so block n of the interval owns stream bit n -- no serial parse at all.  64 blocks per pass, one per lane:
@@ -2504,7 +2514,7 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
                 if (c < ncomp) bpu += ncomp == 1 ? 1u : pc[c].h * pc[c].v;
             }
             cbase[kMaxScanComponents] = bpu;
-            const uint32_t group = bpu != 0 && bpu <= 64u ? 64u / bpu : 0u;
+            const uint32_t group = !aliased && bpu != 0 && bpu <= 64u ? 64u / bpu : 0u;
             uint32_t passes = 0;
             while (group != 0 && u0 + group <= my_units && err == 0 && d.rem >= 128) {
                 JPGPU_ENSURE_STAGED()
@@ -2560,7 +2570,7 @@ __device__ __forceinline__ void ps_run_scan(const uint8_t *__restrict__ udata, c
                     if (slot_b == slot_a) slot_b = dc_slot[c];
                     else if (dc_slot[c] != slot_b) two_tables = false;
                 }
-            const uint32_t group = two_tables && bpu != 0 && bpu <= 64u ? 64u / bpu : 0u;
+            const uint32_t group = !aliased && two_tables && bpu != 0 && bpu <= 64u ? 64u / bpu : 0u;
             const uint32_t nb = group * bpu;
             // component of the block this lane stands for in a pass, and its place inside the MCU
             const uint32_t within = bpu != 0 ? lane - (lane / bpu) * bpu : 0u;
