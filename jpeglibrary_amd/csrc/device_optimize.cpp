@@ -415,7 +415,25 @@ void OptimizeBatch::plan_file(Plan &p, const uint8_t *data, size_t len, bool str
                 refuse(JPGPU_ERR_INVALID_DATA,
                        at_offset(r.consumed_byte_count(), ("This type of JPEG stream is not supported (StartOfFrame" + std::to_string(marker - 0xC0) + ").").c_str()),
                        kDetailUnsupportedFrame);
-            case 0xC4: segment(); break;  // the decoding tables are the decoder-side parser's business (batch_)
+            case 0xC4: {
+                // The decoding tables themselves are the decoder-side parser's business (batch_), but a table that does not parse
+                // ends Scan() HERE (JpegOptimizer.cs ProcessDefineHuffmanTable), in front of whatever a later marker would have
+                // thrown -- e.g. the missing frame header at SOS when a bit flip made the SOF marker a DHT
+                // (tests/golden/stress/optimizer_dht_in_place_of_sof_*.jpg)
+                segment();
+                const uint8_t *tb = buf;
+                size_t rem = length;
+                int off = r.consumed_byte_count() - length;
+                while (rem != 0) {
+                    HuffTable t;
+                    int consumed = 0;
+                    if (!HuffTable::try_parse(tb, rem, &t, &consumed)) refuse(JPGPU_ERR_INVALID_DATA, at_offset(off, "Failed to parse Huffman table."));
+                    tb += consumed;
+                    rem -= (size_t)consumed;
+                    off += consumed;
+                }
+                break;
+            }
             case 0xDB: {
                 segment();
                 const int base = r.consumed_byte_count() - length;
