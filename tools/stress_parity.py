@@ -4,7 +4,7 @@
 Pillow / libjpeg-turbo files of random size, quality, sampling, restart interval, progressive / optimize flags:
 decode (YCbCr8 + RGBA) and, for the single-scan baseline ones, the optimizer (both strip settings).  Prints a summary;
 exit code 1 on any mismatch.  Not part of the test suite (it takes minutes with large n).  STRESS_SCALE=k multiplies the image
-dimensions (1..300 -> k..300k pixels a side)."""
+dimensions (1..300 -> k..300k pixels a side).  STRESS_HEADER=1: every corrupted file has its flipped bit(s) in a header."""
 import io
 import os
 import sys
@@ -21,6 +21,7 @@ from oracle import pyoracle as po
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 scale = int(os.environ.get("STRESS_SCALE", "1"))
+HEADER_ONLY = os.environ.get("STRESS_HEADER") is not None
 files, kinds = [], []
 for i in range(n):
     w, h = int(rng.integers(1, 301)), int(rng.integers(1, 301))
@@ -97,7 +98,36 @@ for strip in (True, False):
                 print("optimize bytes", i, strip, kinds[i])
     b.close()
 # ---- corrupted streams: random edits of the entropy-coded part (and sometimes of a header byte) of baseline files
+def header_bytes(data):
+    """positions of every byte of every marker segment (all SOS headers of a progressive file too), entropy data left out"""
+    pos, i, n = [], 2, len(data)
+    while i + 4 <= n:
+        if data[i] != 0xFF:
+            i += 1
+            continue
+        m = data[i + 1]
+        if m in (0x00, 0xFF) or 0xD0 <= m <= 0xD7:
+            i += 2
+            continue
+        if m == 0xD9:
+            break
+        ln = (data[i + 2] << 8) | data[i + 3]
+        pos.extend(range(i + 1, min(i + 2 + ln, n)))
+        i += 2 + ln
+        if m == 0xDA:  # entropy-coded data: up to the next marker that is not a restart marker
+            while i + 1 < n and not (data[i] == 0xFF and data[i + 1] not in (0x00, 0xFF) and not 0xD0 <= data[i + 1] <= 0xD7):
+                i += 1
+    return pos
+
+
 def mutate(data, rng):
+    if HEADER_ONLY:
+        b = bytearray(data)
+        hb = header_bytes(data)
+        for _ in range(2 if rng.random() < 0.3 else 1):
+            if hb:
+                b[hb[int(rng.integers(0, len(hb)))]] ^= 1 << int(rng.integers(0, 8))
+        return bytes(b)
     sos = data.index(b"\xff\xda")
     lo = sos + 4 + data[sos + 3]
     b = bytearray(data)
