@@ -782,13 +782,19 @@ int OptimizeBatch::run() {
             std::vector<OptimalCode> codes;
             const uint32_t *freq = &h_hist_[((size_t)p.job * kMaxHuffSlots + t) * 256];
             if (!build_optimal_table(freq, &codes, most_optimal_)) {
-                // no symbol counted: a failing scan, reported from the device status below.  Symbols counted and no table: the
-                // reference's byte counters overflowed (build_optimal_table) -- its Build() dies with IndexOutOfRangeException
+                // No symbol counted: a failing scan (reported from the device status below, which comes first), or a component
+                // without blocks -- a sampling factor of zero, which JpegOptimizer never divides by -- whose builders stay empty:
+                // Build() throws "No symbol is recorded." (tests/golden/stress/optimizer_component_without_blocks_421.jpg).
+                // Symbols counted and no table: the reference's byte counters overflowed (build_optimal_table) -- its Build() dies
+                // with IndexOutOfRangeException.
                 bool any = false;
                 for (int sym = 0; sym < 256; sym++) any |= freq[sym] != 0;
-                if (any && p.late_status == JPGPU_OK) {  // behind the scan's own failures: BuildTables runs after ProcessScanBaseline (:462)
+                if (!p.build_failed) {  // behind the scan's own failures (BuildTables runs after ProcessScanBaseline, :462), in front of
+                                        // what the markers behind the scan throw (late_status as the walk left it); first builder wins
+                    p.build_failed = true;
                     p.late_status = JPGPU_ERR_INVALID_OPERATION;
-                    p.late_error = "Index was outside the bounds of the array.";
+                    p.late_detail = 0;
+                    p.late_error = any ? "Index was outside the bounds of the array." : "No symbol is recorded.";
                 }
                 continue;
             }

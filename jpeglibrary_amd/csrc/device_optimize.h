@@ -48,6 +48,7 @@ class OptimizeBatch {
         // failures of the marker walks BEHIND the scan: the reference meets them only once the scan itself went through
         // (Scan() throws from ProcessScanBaseline first), so they are reported after the device-side status
         int late_status = JPGPU_OK, late_detail = 0;
+        bool build_failed = false;  // BuildTables threw (it runs at the end of the scan: in front of anything a later marker throws)
         std::string late_error;
         // ... and what the walks end in instead when the scan leaves exactly one whole byte unread: the reference's reader
         // then resumes one byte INTO the terminating marker (DeviceBatch::plan_swallowed_terminator has the mechanism)

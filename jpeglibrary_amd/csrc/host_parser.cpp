@@ -733,6 +733,10 @@ void ProgressiveFrame::begin(const HostDecoder &dec, const FrameHeader &fh) {
         if (c.h == 0 || c.v == 0) throw_invalid_data("Failed to decode JPEG data. Attempted to divide by zero.", kDetailBadHeader);
         const int hs = geo_.max_h / c.h, vs = geo_.max_v / c.v;
         if (hs == 0 || vs == 0) throw_invalid_data("Failed to decode JPEG data. Attempted to divide by zero.", kDetailBadHeader);
+        // the same fence as resolve_scan's, where the checker has it for a progressive frame (its allocator): in front of whatever
+        // the frame's scans would run into (tools/stress_parity.py STRESS_HEADER=1, seed 403)
+        if ((hs & (hs - 1)) != 0 || (vs & (vs - 1)) != 0)
+            throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "Sampling factor ratios that are not powers of two are not supported.", kDetailUnsupportedFrame);
         hblocks_[i] = (uint16_t)((hb + hs - 1) / hs);
         vblocks_[i] = (uint16_t)((vb + vs - 1) / vs);
         fblk_base_[i] = (uint8_t)base;
