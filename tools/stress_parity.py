@@ -22,6 +22,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 scale = int(os.environ.get("STRESS_SCALE", "1"))
 HEADER_ONLY = os.environ.get("STRESS_HEADER") is not None
+CMYK = os.environ.get("STRESS_CMYK") is not None
 files, kinds = [], []
 for i in range(n):
     w, h = int(rng.integers(1, 301)), int(rng.integers(1, 301))
@@ -30,7 +31,8 @@ for i in range(n):
     if scale > 1:  # STRESS_SCALE=n: large images (scans of many workgroups / subsequences / streams); use a small n
         w, h = w * scale, h * scale
     gray = rng.random() < 0.2
-    base = rng.integers(0, 256, (h, w, 1 if gray else 3))
+    cmyk = CMYK and not gray and rng.random() < 0.35  # STRESS_CMYK=1: four components (Adobe CMYK as Pillow writes it)
+    base = rng.integers(0, 256, (h, w, 1 if gray else (4 if cmyk else 3)))
     smooth = rng.random() < 0.6
     if smooth:
         yy, xx = np.mgrid[0:h, 0:w]
@@ -47,7 +49,7 @@ for i in range(n):
     if rng.random() < 0.3:
         kw["optimize"] = True
     out = io.BytesIO()
-    Image.fromarray(img[..., 0] if gray else img).save(out, **kw)
+    (Image.fromarray(img, "CMYK") if cmyk else Image.fromarray(img[..., 0] if gray else img)).save(out, **kw)
     files.append(out.getvalue())
     kinds.append((w, h, gray, prog, kw))
 
@@ -72,7 +74,7 @@ for i, ((kind, ref), out, res, out4, res4) in enumerate(zip(refs, outs, results,
         if not np.array_equal(np.asarray(out), px):
             bad += 1
             print("decode pixels", i, kinds[i])
-        if res4.status != 0 or not np.array_equal(np.asarray(out4), po.ycbcr8_to_rgb(px, rgba=True, gray=(info.ncomp == 1))):
+        if info.ncomp in (1, 3) and (res4.status != 0 or not np.array_equal(np.asarray(out4), po.ycbcr8_to_rgb(px, rgba=True, gray=(info.ncomp == 1)))):
             bad += 1
             print("decode rgba", i, kinds[i])
 # ---- optimizer
