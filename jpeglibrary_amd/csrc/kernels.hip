@@ -3509,12 +3509,25 @@ __global__ __launch_bounds__(64) void subseq_propagate_kernel(const DevScan *__r
     const uint32_t lane = threadIdx.x;
     uint32_t e_prev = 0xFFFFFFFFu, x_prev = 0;  // the chunk before (lane l = subsequence base - 64 + l)
     uint32_t copied = 0;
+    // the next chunk's three words are asked for while this one is looked at (a chunk only ever stores its OWN entries, and most
+    // chunks are consistent already: the walk is a chain of load latencies otherwise -- 483 chunks for one benchmark canvas)
+    uint32_t e_next = 0xFFFFFFFFu, x_next = 0, d_next = 0;
+    auto fetch = [&](uint32_t base) {
+        const uint32_t sub = base + lane;
+        const bool in = sub < s.n_subs;
+        const uint32_t slot = s.sub_off + (in ? sub : 0u);
+        e_next = in ? entry_used[slot] : 0xFFFFFFFFu;
+        x_next = in ? exit_state[slot] : 0u;
+        d_next = in ? same_dist[slot] : 0u;
+    };
+    fetch(0);
     for (uint32_t base = 0; base < s.n_subs; base += 64u) {
         const uint32_t sub = base + lane;
         const bool in = sub < s.n_subs;
         const uint32_t slot = s.sub_off + (in ? sub : 0u);
-        uint32_t e = in ? entry_used[slot] : 0xFFFFFFFFu, x = in ? exit_state[slot] : 0u;
-        const uint32_t d = in ? same_dist[slot] : 0u;
+        uint32_t e = e_next, x = x_next;
+        const uint32_t d = d_next;
+        if (base + 64u < s.n_subs) fetch(base + 64u);
         uint32_t src = 0;  // lane l: the twin whose results it takes (distance), 0 = none
         // what the rounds give a subsequence as its entry: the predecessor's exit, or the start state behind a failed one
         auto expected = [](uint32_t prev_exit) { return (prev_exit & kSubBad) ? 0u : prev_exit; };
