@@ -68,7 +68,10 @@ int jpgpu_create(int device, jpgpu_ctx **out) {
         return JPGPU_ERR_DEVICE;
     }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->num_cus = prop.multiProcessorCount;
+        ctx->device_bytes = (uint64_t)prop.totalGlobalMem;
+    }
     if (const char *ev = getenv("JPGPU_STAGING_SLOTS")) ctx->staging.n_slots = std::min((int)StagingRing::kMaxSlots, std::max(2, atoi(ev)));
     if (const char *ev = getenv("JPGPU_STAGING_SLOT_MB")) ctx->staging.slot_bytes = (size_t)std::min(256, std::max(1, atoi(ev))) << 20;
     *out = ctx.release();

@@ -208,6 +208,12 @@ void DeviceBatch::plan_image_geometry(ImagePlan &img, const BaselineGeometry &ge
             img.out_bytes = (uint64_t)img.width * img.height * 4 * sizeof(uint16_t);
         }
     }
+    // A frame header is two 16-bit sizes and a component count: a corrupted one can ask for hundreds of gigabytes (the
+    // reference's caller would fail allocating the writer's buffer).  Such an image fails BY ITSELF instead of taking the
+    // batch's allocation, and every other image, with it (tools/stress_parity.py STRESS_HEADER=1, seed 460).
+    if (ctx_ && ctx_->device_bytes != 0 && img.out_bytes + img.planes_bytes > ctx_->device_bytes)
+        throw DecodeError(JPGPU_ERR_OUT_OF_MEMORY, "The frame's output (" + std::to_string(img.out_bytes + img.planes_bytes) +
+                                                        " bytes) is larger than the device's memory.", kDetailUnsupportedFrame);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- ingest

@@ -44,6 +44,7 @@ struct jpgpu_ctx {
     int host_threads = 0;                 // crew size of jpgpu_batch_upload; 0 = min(CPUs granted to the process, 16)
     std::string last_error;
     int num_cus = 0;
+    uint64_t device_bytes = 0;            // the device's memory: a frame whose output alone is beyond it fails by itself (status 7)
 };
 
 namespace jpgpu {

@@ -1358,6 +1358,20 @@ def test_optimizer_low_quality_tables_with_ff_bytes():
 
 # ------------------------------------------------------------------------------------------------ stress reproducers
 
+def test_a_frame_beyond_the_devices_memory_fails_by_itself():
+    """A corrupted header (here: an APP0 length that makes the parser find `FF C1` inside the quantisation tables) can declare a
+    frame of 62 868 x 62 968 x 183 components.  The reference's caller would fail allocating the writer's buffer; here the
+    image gets status 7 and the rest of the batch decodes (it used to take the batch's allocation, and every image, with it)."""
+    big = read_jpeg("stress_oversize_frame_460.jpg")
+    good = jpegsynth.encode(64, 48, "420", 75, 2, seed=3)
+    outs, results = jl.decode_batch([good, big, good], jl.FMT_INTERLEAVED_U8)
+    assert results[0].status == 0 and results[2].status == 0
+    assert results[1].status == 7, results[1].status
+    ref = po.decode_8bit(good)[0]
+    assert np.array_equal(outs[0], ref) and np.array_equal(outs[2], ref)
+
+
+
 def _stress_files():
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stress")
     return sorted(f for f in os.listdir(d) if f.endswith(".jpg"))

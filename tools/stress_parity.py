@@ -184,6 +184,16 @@ def dc_category_above_16(data):
     return False
 
 
+def frame_beyond_any_buffer(data):
+    """A corrupted frame header can ask for hundreds of gigabytes (two 16-bit sizes x up to 255 components): neither the
+    checker's numpy buffer nor the device has them.  The library fails such an image by itself (status 7); nothing to compare."""
+    try:
+        info, _ = po.identify(data)
+    except po.OracleError:
+        return False
+    return info.width * info.height * max(info.ncomp, 1) > (1 << 31)
+
+
 def keep(tag, i, data):
     """Mismatching inputs go to gpurun_out/stress/ (merged back from the GPU box) for a CPU-side look."""
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "stress")
@@ -194,7 +204,7 @@ def keep(tag, i, data):
 
 n_mut = 0
 mut = [mutate(f, rng) for f, k in zip(files, kinds) if not k[3]][: max(100, n // 3)]
-mut = [f for f in mut if not dc_category_above_16(f)]
+mut = [f for f in mut if not dc_category_above_16(f) and not frame_beyond_any_buffer(f)]
 refs = []
 for f in mut:
     try:
@@ -237,7 +247,7 @@ b.close()
 
 # ---- corrupted progressive streams: the same edits anywhere behind the first SOS (entropy data, later DHT / SOS headers)
 pmut = [mutate(f, rng) for f, k in zip(files, kinds) if k[3]][: max(60, n // 6)]
-pmut = [f for f in pmut if not dc_category_above_16(f)]
+pmut = [f for f in pmut if not dc_category_above_16(f) and not frame_beyond_any_buffer(f)]
 prefs = []
 for f in pmut:
     # (a failing progressive decode still flushes its partial store to the writer: the buffer is compared too, round 4)
