@@ -53,6 +53,18 @@ for i in range(n):
     files.append(out.getvalue())
     kinds.append((w, h, gray, prog, kw))
 
+if os.environ.get("STRESS_SYNTH") is not None:
+    # STRESS_SYNTH=1: every third file comes from the tree's own generator instead (tools/jpegsynth): baseline with restart
+    # intervals of any length, 4:4:4 as three single-component scans (a multi-scan baseline frame: Pillow writes none)
+    from tools import jpegsynth
+    for i in range(0, n, 3):
+        sub = str(rng.choice(["420", "422", "444", "444"]))
+        w, h = int(rng.integers(1, 260)) * scale, int(rng.integers(1, 260)) * scale
+        non = sub == "444" and rng.random() < 0.6
+        files[i] = jpegsynth.encode(w, h, sub, int(rng.integers(5, 101)), int(rng.integers(0, 40)) if rng.random() < 0.6 else 0,
+                                    seed=int(rng.integers(0, 1 << 30)), noninterleaved=non)
+        kinds[i] = (w, h, False, False, {"synth": sub, "noninterleaved": non})
+
 bad = 0
 names = {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException", 4: "ArgumentException"}
 # ---- decode
