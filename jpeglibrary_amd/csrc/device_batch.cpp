@@ -1416,8 +1416,29 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 for (const RgbConvert &rc : rgb_convert_) listed |= rc.image == (uint32_t)ii;
                 if (!listed) rgb_convert_.push_back({(uint32_t)ii, img.out_offset, (uint64_t)img.width * img.height, img.num_components});
             }
+            // A baseline frame of several scans whose LATER scans cover every component this one covers (a corrupted selector:
+            // one component scanned twice, another never): every sample this scan's blocks would write is written again by a
+            // later WriteBlock -- the later one wins in the reference, and two scans' tiles in one launch have no order.  The
+            // scan is decoded (its errors count) and its transform left out.  (A later scan covering only SOME of an interleaved
+            // scan's components is not ordered: no encoder writes such a frame, and no header bit flip makes one.)
+            bool overwritten = false;
+            if (job.kind == kScanSequential && img.jobs.size() > 1) {
+                uint32_t mine = 0, later = 0;
+                for (int c = 0; c < job.scan_components; c++) mine |= 1u << job.comp[c].component_index;
+                bool behind = false;
+                for (int j2 : img.jobs) {
+                    if (j2 == j) {
+                        behind = true;
+                        continue;
+                    }
+                    const ScanJob &o = jobs_[(size_t)j2];
+                    if (!behind || o.kind != kScanSequential || o.disabled) continue;
+                    for (int c = 0; c < o.scan_components; c++) later |= 1u << o.comp[c].component_index;
+                }
+                overwritten = (mine & ~later) == 0;
+            }
             const uint32_t run = mcus_per_wg * (uint32_t)kIdctTilesPerWg;
-            for (uint32_t first = 0; first < s.total_mcus; first += run)
+            for (uint32_t first = 0; first < s.total_mcus && !overwritten; first += run)
                 idct_work_by_class[cls].push_back({(uint32_t)j, first, std::min(run, s.total_mcus - first), mcus_per_wg});
         }
     }
