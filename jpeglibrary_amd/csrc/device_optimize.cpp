@@ -5,7 +5,7 @@
 // again, copying the segments it keeps, writing the new DHT in place of the first one and re-writing the scan symbol by
 // symbol with the new codes (:540-880).  Here the marker walks run on the host (they touch a few hundred bytes), the
 // symbol passes on the GPU: K1 (marker index + unstuffing, shared with the decoder) then KT count -> host table build ->
-// KT measure -> exclusive scan -> KT emit (kernels.hip).  The output is assembled from the host pieces and the
+// KT measure -> exclusive scan -> KT emit (kt_transcode.hip).  The output is assembled from the host pieces and the
 // device-resident scan data at download time.
 //
 // Fences (reported as JPGPU_ERR_NOT_SUPPORTED): files with more than one scan (the reference builds its tables from the

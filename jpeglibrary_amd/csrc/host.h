@@ -4,7 +4,7 @@
 //   JpegReader.cs (marker sync, lengths), JpegFrameHeader.cs / JpegScanHeader.cs (SOF / SOS payloads),
 //   JpegQuantizationTable.cs / JpegHuffmanDecodingTable.cs (DQT / DHT parse + canonical code build),
 //   JpegDecoder.cs (Identify / Decode marker loops, table registry, DRI latch).
-// The per-block arithmetic is NOT here: it runs in the HIP kernels (kernels.hip).
+// The per-block arithmetic is NOT here: it runs in the HIP kernels (k1_markers.hip ... k3_idct.hip).
 #pragma once
 #include <stddef.h>
 #include <stdint.h>

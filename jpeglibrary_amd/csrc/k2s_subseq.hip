@@ -1,0 +1,915 @@
+// jpeglibrary_amd/csrc/k2s_subseq.hip -- K2S: self-synchronising subsequence decode of scans without restart intervals (DRI = 0)
+//
+// MUST be compiled with -ffp-contract=off: the reference's Vector4 arithmetic never fuses a*b+c
+// (FastFloatingPointDCT.cs:79-185).  No fast-math.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+
+#include "common.h"
+#include "kernels.h"
+#include "encode_kernels.h"
+#include "kernels_device.h"
+
+namespace jpgpu {
+
+// ------------------------------------------------------------------------------------------------
+// K2S: self-synchronising subsequence decode for scans WITHOUT restart intervals (DRI = 0).
+//
+// One restart interval = one lane does not scale when the whole scan is a single interval.  The unstuffed stream is cut
+// into subsequences of 1 << sub_shift bits; lane i decodes subsequence i.  Its entry state (bit position, block-in-MCU,
+// zig-zag position) is unknown a priori, so round 0 guesses (start of a block of component 0) and every later round
+// restarts lane i from the exit state lane i-1 reached in the previous round.  Huffman streams self-synchronise, so the
+// exit states stop changing after a few rounds; lane 0 is exact from the start, hence a fixed point reached from it is
+// the serial decoder's own sequence of states (Klein/Wiseman, Weissenberger/Schmidt).  After convergence the block
+// counts are prefix-summed and a final pass writes the coefficients (DC as DIFFERENCE) into the zeroed coefficient
+// buffer; a per-component prefix sum then turns the DC differences into the reference's predictor chain
+// (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:186-195).
+// ------------------------------------------------------------------------------------------------
+
+
+// One synchronisation round.  exit_in/exit_out are double-buffered per-subsequence state words (index sub_off + sub).
+// A round only has to follow the symbol structure: code and magnitude LENGTHS, zig-zag advance, block and MCU phase, and
+// the DC differences (their per-component sums feed the predictor prefix); AC magnitudes are skipped, not extracted.
+//
+// Round 4 form.  64 lanes stand at 64 different places of their blocks, so whatever a lane does "sometimes" the wave does
+// in every step; the step is therefore ONE straight line for every lane, and what cannot be decided by one lookup is not
+// branched to but PARKED:
+//  * bit source = a bit position into a private 8-word LDS ring of the lane's unstuffed stream (9 words per lane: the ring
+//    stored MSB-first + a mirror of word 0, so the two words around the position are always one ds_read2; stride 9 keeps
+//    lanes on distinct banks); the ring is topped up (16 bytes, prefetched a burst earlier) between bursts of kSrBurst steps;
+//  * one lookup of the next kSrLutBits bits gives `total bits | zig-zag advance << 6 | DC difference << 16`: a DC symbol
+//    whose magnitude lies inside the looked-up prefix carries its EXTENDED value in the entry (an AC entry carries zero), so
+//    the step adds the entry's upper half to the lane's component sum (one ds_add into 16 bytes of LDS per lane) whatever
+//    the symbol is; DC entries advance the zig-zag position by one, EOB by 64: no DC / AC distinction but the table choice;
+//  * an entry WITHOUT BITS means "not here": no bits, no advance, no difference -- the lane stands where it stood.  That is what a
+//    prefix the lookup cannot decide holds (a code longer than the lookup, a DC magnitude that leaves the prefix, a bad
+//    category: the reason sits in bits 13-14, which the step does not look at), and it is what a lane reads whose position is
+//    beyond its limit -- the end of its subsequence, 64 bits in front
+//    of what the ring holds, 32 bits in front of the end of the data: its lookup address is replaced by the address of a
+//    zero word BEFORE the lookup, so the step has no test behind it.  A lane that stands repeats its step until the burst is
+//    over; then the standing lanes take the exact path (sr_service: the reference's maxcode walk and "bits available" rules,
+//    the ring's top-up, the end of the subsequence) under one branch per burst.
+// Before: ~55 vector + ~25 scalar instructions and five branches per symbol step (the word reader's refill branches and the
+// exact path, taken by some lane in nearly every step); the first round-4 form (three stream words in registers, a flagged
+// entry and a limit test behind the lookup) ~42 vector instructions, 1.56 -> 1.20 ms per round; the step below ~27.
+constexpr int kSrRingStride = 36;  // bytes per lane: 8 stream words + the mirror of word 0
+#ifndef JPGPU_SR_BURST
+#define JPGPU_SR_BURST 16
+#endif
+constexpr int kSrBurst = JPGPU_SR_BURST;  // fast steps between two service / top-up points
+constexpr int32_t kSrParked = -0x40000000;         // limit of a lane that is finished: nothing commits any more
+// entries without bits (the lane stands), by reason:
+constexpr uint32_t kSrStandMiss = 0x2000u;    // a code longer than the lookup: the reference's walk, from there
+constexpr uint32_t kSrStandBadCat = 0x4000u;  // a DC category above 16
+constexpr uint32_t kSrStandDcWide = 0x6000u;  // a DC symbol whose magnitude leaves the prefix (code and category: the pooled first level)
+
+
+struct SrLane {
+    int32_t pm1;    // bit position - 1, relative to the lane's 4-byte aligned origin
+    uint32_t k;     // zig-zag index of the next coefficient; 0 = the block's DC symbol comes next
+    uint32_t ip;    // LDS offset of the block's entry in the block-info table ({DC lookup, AC lookup, DC sum offset, 0} per block of the MCU)
+    uint32_t nblk;  // blocks completed
+    uint32_t tabdc, tabac, dcaddr;  // LDS byte offsets: the block's two lookups, its component's DC sum
+    int32_t slim;                   // a symbol may be looked up while pm1 < slim (kSrParked: never again)
+    uint32_t wrw;                   // stream words written to the ring so far (it holds words wrw-8 .. wrw-1)
+    uint4 nx;                       // the next 16 bytes of the stream, loaded a burst ago
+    const uint8_t *gp;              // address of the 16 bytes behind them
+};
+
+// LDS by absolute 32-bit address (the low half of the flat address of a __shared__ object is its LDS address): every address
+// the step selects between -- lookups, the zero word, DC sums, block info -- is kept ready-made, so that no base has to be
+// added behind a select
+typedef __attribute__((address_space(3))) uint32_t sr_lds_u32;
+typedef __attribute__((address_space(3))) int32_t sr_lds_i32;
+typedef uint32_t sr_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) sr_u32x4 sr_lds_u128;
+__device__ __forceinline__ uint32_t sr_lds_addr(const void *p) { return (uint32_t)reinterpret_cast<uintptr_t>(p); }
+__device__ __forceinline__ uint32_t sr_ld32(uint32_t a) { return *reinterpret_cast<const sr_lds_u32 *>((uintptr_t)a); }
+__device__ __forceinline__ uint4 sr_ld128(uint32_t a) {
+    const sr_u32x4 v = *reinterpret_cast<const sr_lds_u128 *>((uintptr_t)a);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void sr_st128(uint32_t a, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+    *reinterpret_cast<sr_lds_u128 *>((uintptr_t)a) = sr_u32x4{x, y, z, w};
+}
+__device__ __forceinline__ void sr_st32(uint32_t a, uint32_t v) { *reinterpret_cast<sr_lds_u32 *>((uintptr_t)a) = v; }
+
+// what a symbol does to the lane: position, zig-zag index, block end (next block's lookups and DC sum), DC sum
+__device__ __forceinline__ void sr_commit(SrLane &L, uint32_t info_off, uint32_t info_end, uint32_t dc_lane, uint32_t n, uint32_t adv, int32_t v) {
+    __hip_atomic_fetch_add(reinterpret_cast<sr_lds_i32 *>((uintptr_t)L.dcaddr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    L.pm1 += (int32_t)n;
+    const uint32_t k = L.k + adv;
+    const bool end = k >= 64u;
+    L.nblk += end ? 1u : 0u;
+    L.k = end ? 0u : k;
+    uint32_t ip = L.ip + (end ? 16u : 0u);
+    ip = ip == info_end ? info_off : ip;
+    L.ip = ip;
+    const uint4 inf = sr_ld128(ip);
+    L.tabdc = end ? inf.x : L.tabdc;
+    L.tabac = end ? inf.y : L.tabac;
+    L.dcaddr = end ? dc_lane + inf.z : L.dcaddr;
+}
+
+__device__ __forceinline__ uint32_t sr_peek(const SrLane &L, uint32_t ring_off) {
+    const sr_lds_u32 *p = reinterpret_cast<const sr_lds_u32 *>((uintptr_t)(ring_off + __builtin_amdgcn_ubfe((uint32_t)L.pm1, 5, 3) * 4u));
+    return __builtin_amdgcn_alignbit(p[0], p[1], ~(uint32_t)L.pm1);
+}
+
+// One fast step for every lane.  Returns the entry it committed (0: the lane stands where it stood).
+template <int LB>
+__device__ __forceinline__ uint32_t sr_step(SrLane &L, uint32_t ring_off, uint32_t info_off, uint32_t info_end, uint32_t dc_lane, uint32_t zero_addr) {
+    const uint32_t hi = sr_peek(L, ring_off);
+    const uint32_t tab = L.k == 0 ? L.tabdc : L.tabac;
+    uint32_t la = tab + (hi >> (32 - LB)) * 4u;
+    la = L.pm1 < L.slim ? la : zero_addr;
+    const uint32_t e = sr_ld32(la);
+    sr_commit(L, info_off, info_end, dc_lane, e & 63u, __builtin_amdgcn_ubfe(e, 6, 7), (int32_t)e >> 16);
+    return e;
+}
+
+__device__ __forceinline__ int32_t sr_limit(uint32_t wrw, int32_t endsub, int32_t endpos) {
+    // pos = pm1 + 1 <= min(endsub - 1, ring - 64, data - 32): the symbol starts inside the subsequence; whatever it is (at most
+    // 32 bits) it ends inside the data, and the 32 bits behind it -- the next step's peek -- are inside the ring
+    int32_t s = endsub - 1;
+    const int32_t r = (int32_t)(wrw * 32u) - 64, d = endpos - 32;
+    s = s < r ? s : r;
+    return s < d ? s : d;
+}
+
+// the prefetched 16 bytes go to the ring (slot wrw & 7: the words they replace lie in front of the lane's position), the next
+// ones are requested
+__device__ __forceinline__ void sr_topup(SrLane &L, uint32_t ring_off) {
+    const uint32_t w0 = __builtin_bswap32(L.nx.x);
+    const uint32_t at = ring_off + (L.wrw & 4u) * 4u;
+    sr_st32(at, w0);
+    sr_st32(at + 4, __builtin_bswap32(L.nx.y));
+    sr_st32(at + 8, __builtin_bswap32(L.nx.z));
+    sr_st32(at + 12, __builtin_bswap32(L.nx.w));
+    if ((L.wrw & 4u) == 0) sr_st32(ring_off + 32, w0);
+    L.wrw += 4;
+    __builtin_memcpy(&L.nx, L.gp, 16);
+    L.gp += 16;
+}
+
+// Exact path for a lane that stands: the end of its subsequence or of the data (finished), a ring that wants its top-up, or a
+// symbol the lookup does not decide -- DecodeHuffmanCode + ReceiveAndExtend lengths with the reference's "bits available"
+// rules, the same decisions as ub_symbol (ref: JpegHuffmanDecodingTable.cs:73-113, ScanDecoder/JpegHuffmanScanDecoder.cs:81-115).
+// Commits the symbol, or finishes the lane (bad = 1: invalid code / the data ends inside the symbol).
+template <int LB>
+__device__ __forceinline__ void sr_service(SrLane &L, const uint8_t *smem, uint32_t lut0, uint32_t ring_off, uint32_t info_off, uint32_t info_end,
+                                           uint32_t dc_lane, uint32_t small_off, const uint8_t *lut_pool, const uint32_t *pool_off, int32_t endsub,
+                                           int32_t endpos, uint32_t &bad) {
+    const int32_t pos = L.pm1 + 1;
+    if (pos >= endsub || pos >= endpos) {  // the loop's two exits: the subsequence's end passed / no data bit left (not a failure)
+        L.slim = kSrParked;
+        return;
+    }
+    const int32_t q = L.pm1 >> 5;
+    while ((int32_t)L.wrw <= q + 4) sr_topup(L, ring_off);  // the ring as full as it gets
+    L.slim = sr_limit(L.wrw, endsub, endpos);
+    const uint32_t hi = sr_peek(L, ring_off);
+    const bool is_dc = L.k == 0;
+    const uint32_t tab = is_dc ? L.tabdc : L.tabac;
+    const uint32_t e = sr_ld32(tab + (hi >> (32 - LB)) * 4u);
+    const int32_t rem = endpos - pos;
+    if ((e & 63u) != 0 && L.pm1 < L.slim) return;  // it was the ring: the next fast step takes it
+    uint32_t n, adv;
+    int32_t v;
+    if ((e & 63u) != 0) {  // decided by the lookup, but inside the last 32 bits of the data
+        n = e & 63u;
+        adv = __builtin_amdgcn_ubfe(e, 6, 7);
+        v = (int32_t)e >> 16;
+    } else {
+        const uint32_t sl = (tab - lut0) >> (LB + 2);
+        const uint32_t code16 = hi >> 16;
+        uint32_t size, cat;
+        if (e == kSrStandBadCat) {  // categories above 16 are outside the verified envelope
+            bad = 1;
+            L.slim = kSrParked;
+            return;
+        }
+        adv = 1;
+        if (e == kSrStandDcWide) {
+            // the code has at most LB bits: its length and category are in the pooled first level (global memory: a DC difference
+            // of 2^(LB - code length) and more, once in a while)
+            const uint32_t e11 = reinterpret_cast<const uint16_t *>(lut_pool + pool_off[sl])[code16 >> (16 - kLutPoolBits)];
+            cat = (e11 >> 6) & 31u;
+            size = (e11 & 63u) - cat;
+        } else {
+            const uint8_t *sm = smem + small_off + sl * kK2SmallBytes;
+            const uint16_t *maxcode = reinterpret_cast<const uint16_t *>(sm);
+            size = LB + 1;
+            while (code16 > maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
+            if (size > 16) {
+                bad = 1;
+                L.slim = kSrParked;
+                return;
+            }
+            const uint32_t sym = sm[56 + ((sm[36 + size] + (code16 >> (16 - size))) & 0xFF)];
+            cat = is_dc ? sym : (sym & 15u);
+            if (cat > 16u) {
+                bad = 1;
+                L.slim = kSrParked;
+                return;
+            }
+            if (!is_dc) adv = (sym & 15u) ? (sym >> 4) + 1u : ((sym >> 4) ? 16u : 64u);
+        }
+        n = size + cat;
+        v = 0;
+        if (is_dc && (int32_t)n <= rem) {
+            const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - n, cat);
+            v = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));  // Extend(v, nbits)
+        }
+    }
+    if ((int32_t)n > rem) {  // the data ends inside the symbol: nothing after it can be right
+        bad = 1;
+        L.slim = kSrParked;
+        return;
+    }
+    sr_commit(L, info_off, info_end, dc_lane, n, adv, v);
+}
+
+// lookups of the round kernel out of the pooled 11-bit ones (lut_pool_kernel): entry i of an LB-bit lookup covers pooled
+// prefixes i << (11 - LB) ..; it is decided when the code has at most LB bits (and, for a DC symbol, the magnitude fits too)
+template <int LB>
+__device__ __forceinline__ uint32_t sr_entry(const uint16_t *l1, uint32_t i, bool is_dc) {
+    const uint32_t e = l1[i << (kLutPoolBits - LB)];
+    if (e == 0) return kSrStandMiss;
+    if (is_dc && (e & kK2BadCat) != 0) {  // (the pooled entry does not say how long the code is: every pooled prefix under i must agree)
+        for (uint32_t j = 1; j < (1u << (kLutPoolBits - LB)); j++)
+            if ((l1[(i << (kLutPoolBits - LB)) + j] & kK2BadCat) == 0) return kSrStandMiss;
+        return kSrStandBadCat;
+    }
+    const uint32_t n = e & 63u, cat = is_dc ? ((e >> 6) & 31u) : (e >> 12);
+    if (n - cat > (uint32_t)LB) return kSrStandMiss;
+    if (is_dc) {
+        if (n > (uint32_t)LB) return kSrStandDcWide;
+        const int32_t raw = (int32_t)((i >> (LB - n)) & ((1u << cat) - 1u));
+        const int32_t v = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));
+        return n | (1u << 6) | ((uint32_t)v << 16);
+    }
+    const uint32_t adv = (e >> 6) & 63u;
+    return n | ((adv == 63u ? 64u : adv) << 6);
+}
+
+__global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+                                                            const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
+                                                            const DevScanStatus *__restrict__ status, const DevHuffTable *__restrict__ huff_pool,
+                                                            const uint8_t *__restrict__ lut_pool,
+                                                            const uint32_t *__restrict__ exit_in, uint32_t *__restrict__ exit_out,
+                                                            uint32_t *__restrict__ nblk_out, uint32_t *__restrict__ entry_used,
+                                                            int4 *__restrict__ dcsum_out, uint32_t *__restrict__ changed, int round,
+                                                            int n_slots, uint32_t warm_bits) {
+    constexpr int LB = kSrLutBits;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // LDS: lookups (n_slots << (LB + 2), at offset 0) | small arrays | block info [kMaxBlocksPerMcu] x 16 | rings | DC sums
+    // (small_off is relative to smem; info_off, rings_off, dcs_off and what derives from them are absolute LDS addresses)
+    const uint32_t lut0 = sr_lds_addr(smem);
+    const uint32_t small_off = (uint32_t)n_slots << (LB + 2);
+    const uint32_t info_off = lut0 + small_off + (uint32_t)n_slots * kK2SmallBytes;
+    const uint32_t rings_off = info_off + kMaxBlocksPerMcu * 16u;
+    const uint32_t dcs_off = rings_off + 256u * kSrRingStride;
+    uint32_t *pool_off = reinterpret_cast<uint32_t *>(smem + (dcs_off - lut0) + 256u * 16u);  // [kMaxHuffSlots]: byte offset of the slot's pooled image
+    const HuffWork wk = work[blockIdx.x];  // first_interval holds the first subsequence of this workgroup
+    const DevScan &s = scans[wk.scan];
+    const DevScanStatus st = status[wk.scan];
+    if (st.n_ends == 0) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ulen = ends_u[s.ends_off];  // DRI = 0: interval 0 starts at 0
+    const uint32_t total_bits = ulen * 8;
+    const uint32_t sub = wk.first_interval + tid;
+    const bool in_range = sub < s.n_subs;
+    const uint32_t slot = s.sub_off + (in_range ? sub : 0);
+    uint32_t entry = 0;  // start of a block of the first component, no overshoot
+    if (in_range && sub > 0 && round > 0) {
+        const uint32_t prev = exit_in[slot - 1];
+        if (!(prev & kSubBad)) entry = prev;
+    }
+    // a lane whose entry state did not change since it last decoded keeps its exit state (and block count);
+    // a workgroup with no lane left to decode leaves before staging anything (most workgroups after round 1)
+    const bool need = in_range && !(round > 0 && (sub == 0 || entry_used[slot] == entry));
+    if (in_range && !need) exit_out[slot] = exit_in[slot];
+    if (!__syncthreads_or(need ? 1 : 0)) return;
+
+    // ---- stage: lookups, the reference's small arrays (long codes), block info
+    for (int sl = 0; sl < kMaxHuffSlots && sl < n_slots; sl++) {
+        const uint32_t pi = s.huff_pool[sl];
+        if (pi == 0xFFFF) continue;
+        bool is_dc = false;
+        for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
+        const uint16_t *src = reinterpret_cast<const uint16_t *>(lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * kK2TabBytes);
+        if (tid == 0) pool_off[sl] = (uint32_t)(((size_t)pi * 2 + (is_dc ? 1 : 0)) * kK2TabBytes);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(smem) + ((size_t)sl << LB);
+        for (uint32_t i = tid; i < (1u << LB); i += 256) dst[i] = sr_entry<LB>(src, i, is_dc);
+        const uint4 *ssrc = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&huff_pool[pi]) + offsetof(DevHuffTable, maxcode));
+        uint4 *sdst = reinterpret_cast<uint4 *>(smem + small_off + sl * kK2SmallBytes);
+        if (tid < kK2SmallBytes / 16) sdst[tid] = ssrc[tid];
+    }
+    if (tid < kMaxBlocksPerMcu) {
+        const uint32_t ci = s.blk_comp[tid];
+        sr_st128(info_off + tid * 16u, lut0 + ((uint32_t)s.comp[ci].dc_slot << (LB + 2)), lut0 + ((uint32_t)s.comp[ci].ac_slot << (LB + 2)), (ci & 3u) * 4u, 0u);
+    }
+    const uint32_t dc_lane = dcs_off + tid * 16u;
+    sr_st128(dc_lane, 0, 0, 0, 0);
+    __syncthreads();
+    if (!need) return;
+    // ROUND 0 IS A WARM-UP.  Its entry state is a guess for every lane but the first, so all it can deliver is a plausible
+    // exit state (right when the decode re-synchronises before the subsequence ends) -- and every such lane is decoded again
+    // in round 1 anyway, from its predecessor's exit.  It therefore only decodes the LAST warm_bits bits of the subsequence:
+    // less work in round 0, more lanes to redo in rounds 2-3 (the block phase is what converges slowly: the total number of
+    // re-decodes is set by how far the nearest upstream synchronisation point is, not by round 0) -- a small net gain,
+    // 19.6 -> 19.2-19.4 ms per 1024 x 4K.  entry_used is poisoned so that round 1 decodes the lane whatever its entry turns out to be.
+    const bool warm = round == 0 && sub > 0 && warm_bits != 0 && warm_bits < (1u << s.sub_shift);
+    entry_used[slot] = warm ? 0xFFFFFFFFu : entry;
+
+    const uint32_t bpm = s.blocks_per_mcu;
+    const uint32_t end_bit = (sub + 1) << s.sub_shift;
+    const uint32_t start_bit = warm ? end_bit - warm_bits : (sub << s.sub_shift) + (entry & 63u);
+    uint32_t ex;
+    int4 dcs = make_int4(0, 0, 0, 0);
+    uint32_t nblk = 0;
+    if (start_bit >= total_bits) {
+        ex = sub_pack(0, (entry >> 6) & 31u, (entry >> 11) & 127u) | kSubBad;
+    } else {
+        SrLane L;
+        const uint32_t ring_off = rings_off + tid * kSrRingStride;
+        const uint32_t info_end = info_off + bpm * 16u;
+        const uint32_t zero_addr = info_off + 12u;  // (the fourth word of a block-info entry)
+        const uint32_t u0 = start_bit >> 3;
+        const int32_t pm1_0 = (int32_t)((u0 & 3u) * 8u + (start_bit & 7u)) - 1;
+        // (positions are relative to the lane's own start: the distance to the end of the data is only ever compared, so a
+        // stream longer than 2^30 bits behind the lane may as well end there)
+        const uint32_t left = total_bits - start_bit;
+        const int32_t endpos = pm1_0 + 1 + (int32_t)(left < 0x3FFFFFFFu ? left : 0x3FFFFFFFu);
+        const int32_t endsub = pm1_0 + 1 + (int32_t)(end_bit - start_bit);
+        {
+            const uint8_t *g = udata + s.data_off + (u0 & ~3u);  // 4-byte aligned 16-byte loads; buffers are padded
+            uint4 c0, c1;
+            __builtin_memcpy(&c0, g, 16);
+            __builtin_memcpy(&c1, g + 16, 16);
+            __builtin_memcpy(&L.nx, g + 32, 16);
+            L.gp = g + 48;
+            const uint32_t w0 = __builtin_bswap32(c0.x);
+            sr_st32(ring_off, w0);
+            sr_st32(ring_off + 4, __builtin_bswap32(c0.y));
+            sr_st32(ring_off + 8, __builtin_bswap32(c0.z));
+            sr_st32(ring_off + 12, __builtin_bswap32(c0.w));
+            sr_st32(ring_off + 16, __builtin_bswap32(c1.x));
+            sr_st32(ring_off + 20, __builtin_bswap32(c1.y));
+            sr_st32(ring_off + 24, __builtin_bswap32(c1.z));
+            sr_st32(ring_off + 28, __builtin_bswap32(c1.w));
+            sr_st32(ring_off + 32, w0);
+            L.wrw = 8;
+        }
+        L.pm1 = pm1_0;
+        L.k = (entry >> 11) & 127u;
+        L.ip = info_off + ((entry >> 6) & 31u) * 16u;
+        L.nblk = 0;
+        L.slim = sr_limit(L.wrw, endsub, endpos);
+        {
+            const uint4 inf = sr_ld128(L.ip);
+            L.tabdc = inf.x;
+            L.tabac = inf.y;
+            L.dcaddr = dc_lane + inf.z;
+        }
+        uint32_t bad = 0;
+        for (;;) {
+            uint32_t e = 0;
+#pragma unroll
+            for (int t = 0; t < kSrBurst; t++) e = sr_step<LB>(L, ring_off, info_off, info_end, dc_lane, zero_addr);
+            // a lane that stands repeats its step, so the last step of the burst says who stands; finished lanes are not served
+            if ((e & 63u) == 0 && L.slim != kSrParked)
+                sr_service<LB>(L, smem, lut0, ring_off, info_off, info_end, dc_lane, small_off, lut_pool, pool_off, endsub, endpos, bad);
+            if (L.slim != kSrParked && (int32_t)L.wrw <= (L.pm1 >> 5) + 4) {
+                sr_topup(L, ring_off);
+                L.slim = sr_limit(L.wrw, endsub, endpos);
+            }
+            if (__ballot(L.slim != kSrParked) == 0) break;
+        }
+        const int32_t over = L.pm1 + 1 - endsub;  // bits past the nominal end
+        const uint32_t b_exit = (L.ip - info_off) >> 4;
+        ex = sub_pack(over > 0 ? (over < 63 ? (uint32_t)over : 63u) : 0u, b_exit, L.k);
+        if (bad) ex = sub_pack(0, b_exit, L.k) | kSubBad;
+        nblk = L.nblk;
+        const uint4 dsum = sr_ld128(dc_lane);
+        dcs = make_int4((int)dsum.x, (int)dsum.y, (int)dsum.z, (int)dsum.w);
+    }
+    {
+        // how many exits this round changed (the host's convergence test; one atomic per wave that changed anything)
+        const bool ch = round == 0 || ex != exit_in[slot];
+        const uint64_t m = __ballot(ch);
+        if (ch && (uint32_t)__builtin_ctzll(m) == (threadIdx.x & 63u)) atomicAdd(changed, (uint32_t)__builtin_popcountll(m));
+    }
+    exit_out[slot] = ex;
+    nblk_out[slot] = nblk;
+    dcsum_out[slot] = dcs;
+}
+// (Earlier forms: the word reader with the symbol step as per-lane branches, 1.9 ms per round on average at 1024 x 4K; K2's
+// 68-byte ring with a top-up per block, round 2: 2.45 ms -- the rings halved the occupancy; the word reader with its refill load
+// issued by hand, round 3: 1.55 ms.)
+// ---- Flat regions.  Self-synchronisation lives on the randomness of the data: a constant region of the image is the same
+// few bits over and over (a black 4:2:0 MCU under the standard tables is 32 bits: 00 1010 x 4, 00 00 x 2), a decoder that enters
+// it with the wrong state parses it in a wrong but self-consistent way for ever, and the right state only advances one
+// subsequence per round from the region's left edge.  The reference's OWN benchmark input (DecoderBenchmark.cs: three quarters
+// of an 8192 x 8192 canvas are black) took 4 107 rounds, 281 ms per image.
+// What such a region offers instead: subsequence i has exactly the bits of subsequence i - m (m * length = a multiple of the
+// period), and a decoder is a function of (bits, entry state) -- so once subsequence i - m has been decoded from state s, the
+// answer for subsequence i entered in state s is known without decoding: exit, block count and DC sums are those of i - m.
+//   subseq_same_kernel       (once per upload, when a batch has not converged after a few rounds) finds for every subsequence
+//                            the smallest m <= 64 with identical bits (the subsequence itself + the 128 bits behind it that a
+//                            decode of it can look at), by comparison, not by hash;
+//   subseq_propagate_kernel  walks a scan's subsequences once, in order, one wave per scan: where the predecessor's exit is
+//                            not the state a subsequence was last decoded from, but IS the state its twin i - m was decoded
+//                            from, the twin's results are copied.  Every statement it writes down is a true statement about the
+//                            decoder ("entered like this, it leaves like that"), so the rounds and it can alternate freely;
+//                            in a flat region the states repeat with period m, and the whole region resolves in one walk
+//                            once its first m subsequences have been decoded from the right state.
+__global__ __launch_bounds__(256) void subseq_same_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+                                                          const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
+                                                          const DevScanStatus *__restrict__ status, uint32_t *__restrict__ same_dist) {
+    const HuffWork wk = work[blockIdx.x];  // (the rounds' work list: 256 subsequences per entry)
+    const DevScan &s = scans[wk.scan];
+    if (status[wk.scan].n_ends == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t total_bits = ends_u[s.ends_off] * 8u;
+    const uint32_t sub_bytes = (1u << s.sub_shift) >> 3, n_words = sub_bytes / 4u + 4u;
+    const uint8_t *base = udata + s.data_off;
+    for (uint32_t q = wave; q < 256u; q += 4u) {
+        const uint32_t sub = wk.first_interval + q;
+        if (sub >= s.n_subs) break;
+        uint32_t result = 0;
+        // (a subsequence near the end of the data also depends on where the data ends: no twin for it)
+        if ((uint64_t)(sub + 1u) * sub_bytes * 8u + 128u <= total_bits) {
+            const uint8_t *mine = base + (size_t)sub * sub_bytes;
+            uint32_t w0, wc = 0;
+            __builtin_memcpy(&w0, mine, 4);
+            const uint32_t m_lane = lane + 1u;
+            if (m_lane <= sub) __builtin_memcpy(&wc, mine - (size_t)m_lane * sub_bytes, 4);
+            uint64_t cand = __ballot(m_lane <= sub && wc == w0);
+            while (cand != 0) {
+                const uint32_t m = (uint32_t)__builtin_ctzll(cand) + 1u;
+                const uint8_t *twin = mine - (size_t)m * sub_bytes;
+                bool diff = false;
+                for (uint32_t t = lane; t < n_words; t += 64u) {
+                    uint32_t a, b;
+                    __builtin_memcpy(&a, mine + t * 4u, 4);
+                    __builtin_memcpy(&b, twin + t * 4u, 4);
+                    diff |= a != b;
+                }
+                if (__ballot(diff) == 0) {
+                    result = m;
+                    break;
+                }
+                cand &= cand - 1;
+            }
+        }
+        if (lane == 0) same_dist[s.sub_off + sub] = result;
+    }
+}
+
+// one wave per scan; exit = the buffer the last round wrote
+__global__ __launch_bounds__(64) void subseq_propagate_kernel(const DevScan *__restrict__ scans, const uint32_t *__restrict__ scan_ids,
+                                                              const uint32_t *__restrict__ same_dist, uint32_t *__restrict__ exit_state,
+                                                              uint32_t *__restrict__ entry_used, uint32_t *__restrict__ nblk,
+                                                              int4 *__restrict__ dcsum, uint32_t *__restrict__ n_copied) {
+    const DevScan &s = scans[scan_ids[blockIdx.x]];
+    const uint32_t lane = threadIdx.x;
+    uint32_t e_prev = 0xFFFFFFFFu, x_prev = 0;  // the chunk before (lane l = subsequence base - 64 + l)
+    uint32_t copied = 0;
+    // the next chunk's three words are asked for while this one is looked at (a chunk only ever stores its OWN entries, and most
+    // chunks are consistent already: the walk is a chain of load latencies otherwise -- 483 chunks for one benchmark canvas)
+    uint32_t e_next = 0xFFFFFFFFu, x_next = 0, d_next = 0;
+    auto fetch = [&](uint32_t base) {
+        const uint32_t sub = base + lane;
+        const bool in = sub < s.n_subs;
+        const uint32_t slot = s.sub_off + (in ? sub : 0u);
+        e_next = in ? entry_used[slot] : 0xFFFFFFFFu;
+        x_next = in ? exit_state[slot] : 0u;
+        d_next = in ? same_dist[slot] : 0u;
+    };
+    fetch(0);
+    for (uint32_t base = 0; base < s.n_subs; base += 64u) {
+        const uint32_t sub = base + lane;
+        const bool in = sub < s.n_subs;
+        const uint32_t slot = s.sub_off + (in ? sub : 0u);
+        uint32_t e = e_next, x = x_next;
+        const uint32_t d = d_next;
+        if (base + 64u < s.n_subs) fetch(base + 64u);
+        uint32_t src = 0;  // lane l: the twin whose results it takes (distance), 0 = none
+        // what the rounds give a subsequence as its entry: the predecessor's exit, or the start state behind a failed one
+        auto expected = [](uint32_t prev_exit) { return (prev_exit & kSubBad) ? 0u : prev_exit; };
+        // whole chunk consistent already?  (lane 0 against the previous chunk's last)
+        const uint32_t xl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 63u) & 63u) * 4u), (int)x);
+        const uint32_t before = lane == 0 ? lane_get(x_prev, 63) : xl;
+        const bool first = sub == 0;
+        if (__ballot(in && !first && e != expected(before)) != 0) {
+            const uint32_t n_here = s.n_subs - base < 64u ? s.n_subs - base : 64u;
+            for (uint32_t l = (base == 0 ? 1u : 0u); l < n_here; l++) {
+                const uint32_t want = expected(l == 0 ? lane_get(x_prev, 63) : lane_get(x, l - 1u));
+                if (lane_get(e, l) == want) continue;
+                const uint32_t m = lane_get(d, l);
+                if (m == 0) continue;
+                uint32_t te, tx;
+                if (m <= l) {
+                    te = lane_get(e, l - m);
+                    tx = lane_get(x, l - m);
+                } else {
+                    if (base == 0) continue;
+                    te = lane_get(e_prev, 64u + l - m);
+                    tx = lane_get(x_prev, 64u + l - m);
+                }
+                if (te != want) continue;
+                // a twin that took ITS results from a twin in this very chunk has not stored them yet: go to where they lie
+                const uint32_t via = m <= l ? lane_get(src, l - m) : 0u;
+                if (lane == l) {  // (uniform values, one lane's registers)
+                    e = want;
+                    x = tx;
+                    src = m + via;
+                }
+            }
+            const bool took = src != 0;
+            if (took) {
+                entry_used[slot] = e;
+                exit_state[slot] = x;
+                nblk[slot] = nblk[slot - src];
+                dcsum[slot] = dcsum[slot - src];
+            }
+            if (__ballot(took) != 0) {
+                copied += (uint32_t)__builtin_popcountll(__ballot(took));
+                __threadfence();  // the next chunks read what this one stored
+            }
+        }
+        e_prev = e;
+        x_prev = x;
+    }
+    if (lane == 0 && copied != 0) atomicAdd(n_copied, copied);
+}
+
+// Exclusive prefix sums over a scan's subsequences: first block and DC predictors at the entry of every subsequence.
+// One workgroup per scan.
+__global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__restrict__ scans, const uint32_t *__restrict__ scan_ids,
+                                                            const uint32_t *__restrict__ nblk, uint32_t *__restrict__ first_block,
+                                                            const int4 *__restrict__ dcsum, int4 *__restrict__ dc_entry) {
+    const DevScan &s = scans[scan_ids[blockIdx.x]];
+    __shared__ int32_t sh[5][1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (s.n_subs + 1023) / 1024;
+    const uint32_t lo = tid * per, hi = (lo + per) < s.n_subs ? (lo + per) : s.n_subs;
+    int32_t sum[5] = {0, 0, 0, 0, 0};
+    for (uint32_t i = lo; i < hi; i++) {
+        const int4 d = dcsum[s.sub_off + i];
+        sum[0] += (int32_t)nblk[s.sub_off + i];
+        sum[1] += d.x;
+        sum[2] += d.y;
+        sum[3] += d.z;
+        sum[4] += d.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 5; c++) sh[c][tid] = sum[c];
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+        int32_t v[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) v[c] = tid >= o ? sh[c][tid - o] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 5; c++) sh[c][tid] += v[c];
+        __syncthreads();
+    }
+    int32_t run[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) run[c] = sh[c][tid] - sum[c];
+    for (uint32_t i = lo; i < hi; i++) {
+        first_block[s.sub_off + i] = (uint32_t)run[0];
+        dc_entry[s.sub_off + i] = make_int4(run[1], run[2], run[3], run[4]);
+        const int4 d = dcsum[s.sub_off + i];
+        run[0] += (int32_t)nblk[s.sub_off + i];
+        run[1] += d.x;
+        run[2] += d.y;
+        run[3] += d.z;
+        run[4] += d.w;
+    }
+}
+
+// Final pass.  The converged entry states say where every subsequence's first block begins: lane i decodes the whole MCUs
+// that START inside subsequence i (it first parses, without storing, the blocks between its entry and that MCU -- the rest
+// of an MCU the previous lane owns -- and runs past its own end to finish its last MCU), so every MCU has exactly one owner
+// and EVERY LANE OF A WAVE STANDS AT THE SAME BLOCK OF ITS MCU: from there on this is K2 -- block b of every lane decoded
+// in lock-step with wave-uniform tables into the wave's LDS staging and flushed as whole 128-byte lines; the coefficient
+// buffer needs no clearing.  The DC predictor chain starts from the prefix sums of subseq_scan_kernel plus the DC
+// differences of the blocks parsed on the way to the first MCU.
+// (First version: the generic word reader and symbol decoder, 11.0 ms per 1024 x 4K against K2's 5.7.  Second, rounds 2-3:
+// K2's ring and symbol step with BLOCK-aligned ownership -- lanes at different blocks of their MCUs, so the tables were
+// picked per lane and a lock-step iteration mixed long luma with short chroma blocks: 8.3 ms.)
+constexpr int kSubFinalMaxWaves = JPGPU_SF_WAVES > 4 ? JPGPU_SF_WAVES : 4;  // the launch picks subseq_final_waves(n_slots)
+constexpr int kSfWaveBytes = kK2WaveBytes + 64 * 2 * (int)sizeof(uint32_t);  // K2's staging + rings, then (first MCU, count) per lane
+__global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+                                                                           const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
+                                                                           DevScanStatus *__restrict__ status,
+                                                                           const DevHuffTable *__restrict__ huff_pool,
+                                                                           const uint8_t *__restrict__ lut_pool,
+                                                                           const uint32_t *__restrict__ exit_state,
+                                                                           const uint32_t *__restrict__ first_block,
+                                                                           const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs,
+                                                                           int n_slots) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t n_waves = blockDim.x >> 6;
+    uint8_t *tabs = smem;                                                    // n_slots * kK2TabBytes
+    uint8_t *wave_all = smem + (size_t)n_slots * kK2TabBytes;                // n_waves * kSfWaveBytes
+    uint32_t *blk_info = reinterpret_cast<uint32_t *>(wave_all + n_waves * kSfWaveBytes);  // [kMaxBlocksPerMcu]
+    const HuffWork wk = work[blockIdx.x];
+    const DevScan &s = scans[wk.scan];
+    const DevScanStatus st = status[wk.scan];
+    if (st.n_ends == 0) return;
+    k2_stage_scan_tables(s, lut_pool, tabs, blk_info, n_slots, blockDim.x);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint8_t *stage = wave_all + wave * kSfWaveBytes;
+    uint8_t *ring = stage + 8192 + lane * kK2RingStride;
+    uint32_t *meta = reinterpret_cast<uint32_t *>(stage + kK2WaveBytes);
+    {
+        const uint4 z = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(stage)[i * 64 + lane] = z;
+    }
+    __syncthreads();
+    const uint32_t ulen = ends_u[s.ends_off];
+    const uint32_t total_bits = ulen * 8;
+    // a lane takes kSubFinalSubsPerLane consecutive subsequences: half the lanes, but half the parsed-not-stored blocks and a
+    // narrower spread of MCU counts inside a wave (the wave iterates to its largest)
+    const uint32_t sub = wk.first_interval + tid * (uint32_t)kSubFinalSubsPerLane;
+    const uint32_t slot = s.sub_off + (sub < s.n_subs ? sub : 0);
+    const uint32_t total_mcus = s.total_mcus;
+    const uint32_t bpm = s.blocks_per_mcu;
+    const uint64_t coef_off = s.coef_off;
+    const bool closed_by_marker = st.terminator != 0;
+
+    bool live = sub < s.n_subs;
+    uint32_t entry = 0;
+    if (live && sub > 0) {
+        const uint32_t prev = exit_state[slot - 1];
+        if (prev & kSubBad) live = false;  // the stream ended or failed in an earlier subsequence: reported by that lane
+        else entry = prev;
+    }
+    uint32_t b_in_mcu = (entry >> 6) & 31u;
+    uint32_t i2 = ((entry >> 11) & 127u) * 2u;  // 2 x zig-zag position inside the block in progress at the entry
+    // first_block = blocks completed before the entry = index of the block in progress (i2 != 0: the previous lane's) or
+    // about to start there.  This lane owns the MCUs from the first one that starts at or behind its entry ...
+    uint32_t my_first = total_mcus, my_end = total_mcus, skip = 0;
+    if (live) {
+        const uint32_t at = first_block[slot];
+        my_first = (at + (i2 != 0 ? 1u : 0u) + bpm - 1) / bpm;
+        skip = my_first * bpm - at;  // block ends between the entry and that MCU (the first of them may be half a block away)
+        // ... up to the first one that starts at or behind the next lane's entry (a stream that failed or ran out inside this
+        // lane's subsequences leaves it everything that remains)
+        const uint32_t n_mine = s.n_subs - sub < (uint32_t)kSubFinalSubsPerLane ? s.n_subs - sub : (uint32_t)kSubFinalSubsPerLane;
+        bool open_end = sub + n_mine >= s.n_subs;
+        uint32_t ex = 0;
+        for (uint32_t q = 0; q < n_mine; q++) {
+            ex = exit_state[slot + q];
+            open_end |= (ex & kSubBad) != 0;
+        }
+        if (!open_end) my_end = (first_block[slot + n_mine] + ((((ex >> 11) & 127u) != 0) ? 1u : 0u) + bpm - 1) / bpm;
+        if (my_end > total_mcus) my_end = total_mcus;  // the reference stops after the last MCU
+        if (my_first > my_end) my_first = my_end;
+    }
+    const uint32_t count = my_end - my_first;
+    meta[lane * 2] = my_first;
+    meta[lane * 2 + 1] = count;
+    const uint32_t wave_count = wave_reduce_max_i((int32_t)count);
+
+    const bool decodes = live && count != 0;
+    const uint32_t start_bit = decodes ? (sub << s.sub_shift) + (entry & 63u) : 0u;
+    K2Feed feed;
+    K2Pos pos;
+    int32_t endpos = 0;
+    // A lane that owns MCUs but starts behind the data (the stream ran out at a symbol boundary in an earlier subsequence)
+    // decodes them the way the reference does: from the all-ones padding, i.e. with no data bits at all (its loads still
+    // have to stay inside the buffer: it opens the stream at bit 0 and sees it as empty).
+    const bool behind_data = start_bit >= total_bits;
+    const int32_t pm1_0 = k2_open_at_bit(udata + s.data_off, behind_data ? 0u : start_bit, total_bits, ring, feed, pos, &endpos);
+    if (behind_data) endpos = pm1_0 + 1;
+    int32_t lim = k2_limit(endpos, feed.wr);
+    uint32_t err = 0;
+    int32_t pred0 = 0, pred1 = 0, pred2 = 0, pred3 = 0;
+    if (decodes) {
+        const int4 de = dc_entry[slot];
+        pred0 = de.x;
+        pred1 = de.y;
+        pred2 = de.z;
+        pred3 = de.w;
+    }
+    // the blocks in front of the lane's first MCU (the previous lane's): parsed, not stored; their DC differences count.
+    // The only stretch where the lanes of a wave stand at different blocks of their MCUs (tables picked per lane).
+    {
+        uint32_t left = decodes ? skip : 0u;
+        uint32_t info = blk_info[b_in_mcu];
+        uint32_t it = 0;
+        while (__ballot(left != 0) != 0) {
+            if (left != 0) {
+                const bool is_dc = i2 == 0;
+                int32_t v;
+                uint32_t adv;
+                err = k2_symbol_any(ring, feed, pos, endpos, lim, k2_tab(tabs, is_dc ? ((info >> 8) & 0xFFu) : (info >> 16)), is_dc, closed_by_marker,
+                                    v, adv);
+                if (is_dc) {
+                    const uint32_t ci = info & 0xFFu;
+                    if (ci == 0) pred0 += v;
+                    else if (ci == 1) pred1 += v;
+                    else if (ci == 2) pred2 += v;
+                    else pred3 += v;
+                    adv = 2;
+                }
+                i2 += adv;
+                if (err != 0 || i2 >= 128u) {
+                    left = err != 0 ? 0u : left - 1;
+                    i2 = 0;
+                    b_in_mcu = (b_in_mcu + 1 == bpm) ? 0u : b_in_mcu + 1;
+                    info = blk_info[b_in_mcu];
+                }
+            }
+            if ((++it & 3u) == 0) {
+                k2_topup(ring, feed, pos.pm1);
+                lim = k2_limit(endpos, feed.wr);
+            }
+        }
+    }
+    k2_topup(ring, feed, pos.pm1);
+    uint8_t *my_stage = stage + lane * 128;
+    const uint32_t swz16 = ((lane >> 1) & 7u) << 4;
+
+    for (uint32_t j = 0; j < wave_count; j++) {
+        for (uint32_t b = 0; b < bpm; b++) {
+            const uint32_t bi = __builtin_amdgcn_readfirstlane(blk_info[b]);  // wave-uniform
+            const uint32_t ci = bi & 0xFFu;
+            const K2Tab hdc = k2_tab(tabs, (bi >> 8) & 0xFFu);
+            const K2Tab hac = k2_tab(tabs, bi >> 16);
+            lim = k2_limit(endpos, feed.wr);
+            if (j < count && err == 0) {
+                // ReadBlockBaseline (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:179-222)
+                int32_t v;
+                uint32_t adv = 0;
+                err = k2_symbol<true>(ring, feed, pos, endpos, lim, hdc, closed_by_marker, v, adv);
+                const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
+                v += pred;
+                if (ci == 0) pred0 = v;
+                else if (ci == 1) pred1 = v;
+                else if (ci == 2) pred2 = v;
+                else pred3 = v;
+                *reinterpret_cast<int16_t *>(my_stage + swz16) = (int16_t)v;  // zig-zag index 0
+                uint32_t k2i = err == 0 ? 2u : 128u;
+                while (k2i < 128u) {
+                    const uint32_t e2 = k2_symbol<false>(ring, feed, pos, endpos, lim, hac, closed_by_marker, v, adv);
+                    err |= e2;
+                    k2i += adv;
+                    // Math.Min(i++, 63) for a coefficient; EOB / ZRL store a zero at a position nothing was written to yet
+                    const uint32_t at = k2i - 2u < 126u ? k2i - 2u : 126u;
+                    *reinterpret_cast<int16_t *>(my_stage + (at ^ swz16)) = (int16_t)v;
+                }
+            }
+            k2_topup(ring, feed, pos.pm1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const uint32_t blk = it * 8 + (lane >> 3);
+                const uint32_t chunk = lane & 7;
+                uint4 *src = reinterpret_cast<uint4 *>(stage + blk * 128 + ((chunk ^ ((blk >> 1) & 7)) * 16));
+                const uint4 v = *src;
+                const uint4 z = {0, 0, 0, 0};
+                *src = z;
+                const uint32_t owner_first = meta[blk * 2], owner_count = meta[blk * 2 + 1];
+                if (j < owner_count) *reinterpret_cast<uint4 *>(coefs + (coef_off + ((uint64_t)owner_first + j) * bpm + b) * 64 + chunk * 8) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    if (live && err != 0) {
+        // failure on the true path: same detail codes as the interval decoder; "interval" field carries the subsequence
+        atomicMin(&status[wk.scan].first_error, (sub << 8) | err);
+    }
+    // bits left behind the scan's last block (see restart_check)
+    if (live && err == 0 && count != 0 && my_end == total_mcus) {
+        const int32_t rem = endpos - (pos.pm1 + 1);
+        status[wk.scan].pad[2] = rem > 0 ? (uint32_t)rem : 0u;
+    }
+}
+
+
+// DRI = 0 scans: self-synchronising subsequence decode.  `work` lists (scan, first subsequence) per workgroup of 256 lanes;
+// `scan_ids` the scans concerned.  Runs synchronisation rounds until no exit state changes (host-checked flag).
+// The synchronisation part alone (rounds until the exit states stop changing, then the block / DC prefix sums); leaves the
+// converged exit states in *final_state.  Shared by the decoder (subseq_final_kernel) and the optimizer (subseq_transcode_kernel).
+hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
+                              const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
+                              const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
+                              uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int n_slots, int max_rounds,
+                              int *rounds_used, const uint8_t *lut_pool, const uint32_t **final_state_out, uint32_t *same_dist,
+                              bool *same_valid) {
+    *final_state_out = exit_a;
+    if (n_work <= 0 || n_scans <= 0) return hipSuccess;
+    const size_t lds_round = ((size_t)n_slots << (kSrLutBits + 2)) + (size_t)n_slots * kK2SmallBytes + kMaxBlocksPerMcu * 16 + 256 * (kSrRingStride + 16) +
+                             kMaxHuffSlots * sizeof(uint32_t);
+
+    static const uint32_t warm_bits = [] {  // bits of a subsequence round 0 decodes (0 = all of it); see subseq_round_kernel
+        const char *ev = getenv("JPGPU_SUBSEQ_WARM_BITS");
+        return ev ? (uint32_t)atoi(ev) : 2048u;
+    }();
+    static const int propagate_from = [] {  // rounds without convergence before the flat-region walk joins in (0 = never)
+        const char *ev = getenv("JPGPU_SUBSEQ_PROPAGATE_FROM");
+        return ev ? atoi(ev) : 6;  // (6: behind the second check -- a batch that converges in six rounds never pays for it)
+    }();
+    uint32_t *bufs[2] = {exit_a, exit_b};
+    // changed_dev[r] = exits round r changed; the host looks at the counts only every kCheckEvery rounds (one sync per check),
+    // after every round once a round has changed no more than a few exits per scan (the end is then a round or two away);
+    // changed_dev[63] counts what the flat-region walks copied
+    constexpr int kCheckEvery = 3;
+    const uint32_t few_changes = 8u * (uint32_t)n_scans;
+    hipError_t e = hipMemsetAsync(changed_dev, 0, 64 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    int round = 0;
+    bool converged = false;
+    uint32_t last_count = 0xFFFFFFFFu, count_before = 0xFFFFFFFFu;  // exits the last two rounds changed
+    while (!converged && round < max_rounds) {
+        const int batch_first = round;
+        const int batch = last_count <= few_changes ? 1 : kCheckEvery;
+        for (int i = 0; i < batch && round < max_rounds; i++, round++) {
+            const uint32_t *in = bufs[(round + 1) & 1];
+            uint32_t *out = bufs[round & 1];
+            hipLaunchKernelGGL(subseq_round_kernel, dim3(n_work), dim3(256), lds_round, stream, udata, scans, work, ends_u, status, huff_pool,
+                               lut_pool, in, out, nblk, entry_used, (int4 *)dcsum, changed_dev + (round % 62), round, n_slots, warm_bits);
+        }
+        uint32_t flags[64];
+        e = hipMemcpyAsync(flags, changed_dev, sizeof flags, hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        // converged as soon as one round (other than round 0) changed nothing: later rounds are then no-ops
+        for (int r2 = batch_first; r2 < round; r2++) {
+            if (r2 > 0 && flags[r2 % 62] == 0) converged = true;
+            count_before = last_count;
+            last_count = flags[r2 % 62];
+        }
+        static const bool trace = getenv("JPGPU_SUBSEQ_TRACE") != nullptr;  // subsequences whose exit changed, per round
+        if (trace) {
+            for (int r2 = batch_first; r2 < round; r2++) fprintf(stderr, "K2S round %d: %u changed\n", r2, flags[r2 % 62]);
+            fprintf(stderr, "K2S walks copied so far: %u\n", flags[63]);
+        }
+        if (!converged) {
+            e = hipMemsetAsync(changed_dev, 0, 64 * sizeof(uint32_t), stream);
+            if (e != hipSuccess) return e;
+            // Ordinary synchronisation dies out geometrically (a round changes a third to a tenth of what the one before it
+            // changed); a flat region changes as many exits round after round (one per run).  The walk is for the second kind.
+            const bool plateau = count_before == 0xFFFFFFFFu || (uint64_t)last_count * 2 > count_before;
+            if (propagate_from > 0 && round >= propagate_from && same_dist != nullptr && round < max_rounds && plateau) {
+                // still not converged (this check said so), and not about to: flat regions?  Twins once per upload, then a walk
+                // (it patches the buffer the last round wrote: the next round reads that one).  Decided AFTER the check: a batch
+                // that has just converged, or is converging, does not pay for the walk (0.66 ms per 16 benchmark canvases)
+                if (!*same_valid) {
+                    hipLaunchKernelGGL(subseq_same_kernel, dim3(n_work), dim3(256), 0, stream, udata, scans, work, ends_u, status, same_dist);
+                    *same_valid = true;
+                }
+                hipLaunchKernelGGL(subseq_propagate_kernel, dim3(n_scans), dim3(64), 0, stream, scans, scan_ids, same_dist, bufs[(round + 1) & 1], entry_used,
+                                   nblk, (int4 *)dcsum, changed_dev + 63);
+            }
+        }
+    }
+    if (rounds_used) *rounds_used = round;
+    *final_state_out = bufs[(round + 1) & 1];  // buffer written by the last round executed
+    hipLaunchKernelGGL(subseq_scan_kernel, dim3(n_scans), dim3(1024), 0, stream, scans, scan_ids, nblk, first_block, (const int4 *)dcsum,
+                       (int4 *)dc_entry);
+    return hipGetLastError();
+}
+
+hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
+                                const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
+                                const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
+                                uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
+                                int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work,
+                                uint32_t *same_dist, bool *same_valid) {
+    if (n_work <= 0 || n_scans <= 0) return hipSuccess;
+    const uint32_t *final_state = nullptr;
+    hipError_t e = launch_subseq_sync(stream, udata, scans, work, n_work, scan_ids, n_scans, ends_u, status, huff_pool, exit_a, exit_b, nblk,
+                                      first_block, entry_used, dcsum, dc_entry, changed_dev, n_slots, max_rounds, rounds_used, lut_pool,
+                                      &final_state, same_dist, same_valid);
+    if (e != hipSuccess) return e;
+    const int waves = subseq_final_waves(n_slots);
+    const size_t lds_final = (size_t)n_slots * kK2TabBytes + (size_t)waves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
+    static std::atomic<uint64_t> configured{0};
+    const hipError_t ea = allow_dynamic_lds(reinterpret_cast<const void *>(&subseq_final_kernel), 160 * 1024, configured);
+    if (ea != hipSuccess) return ea;
+    // final_work: (scan, first subsequence) per workgroup of waves * 64 lanes (the rounds' work list is per 256)
+    hipLaunchKernelGGL(subseq_final_kernel, dim3(n_final_work), dim3(64 * waves), lds_final, stream, udata, scans, final_work, ends_u, status,
+                       huff_pool, lut_pool, final_state, first_block, (const int4 *)dc_entry, coefs, n_slots);
+    return hipGetLastError();
+}
+
+}  // namespace jpgpu

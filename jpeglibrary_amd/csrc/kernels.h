@@ -83,7 +83,7 @@ hipError_t launch_gather_pinned(hipStream_t stream, const GatherPiece *pieces, i
 hipError_t launch_first_marker(hipStream_t stream, const uint8_t *data, const void *segs, const uint32_t *seg_hi, int n_segs,
                                uint32_t max_len, uint32_t *first);
 
-// KT: symbol-level Huffman transcode of baseline scans (JpegOptimizer): mode 0 count, 1 measure, 2 emit (kernels.hip)
+// KT: symbol-level Huffman transcode of baseline scans (JpegOptimizer): mode 0 count, 1 measure, 2 emit (kt_transcode.hip)
 struct EncHuffTable;
 hipError_t launch_transcode(hipStream_t stream, int mode, const uint8_t *udata, const uint8_t *input, const DevScan *scans,
                             const HuffWork *work, int n_work, const uint32_t *ends_u, const uint32_t *ends_raw, DevScanStatus *status,
@@ -91,13 +91,13 @@ hipError_t launch_transcode(hipStream_t stream, int mode, const uint8_t *udata, 
                             const uint64_t *offsets, uint8_t *out, int n_slots);
 hipError_t launch_transcode_offsets(hipStream_t stream, const DevScan *scans, const uint32_t *scan_ids, int n_scans, const uint32_t *sizes,
                                     const uint64_t *base, uint64_t *offsets, uint64_t *totals);
-// K2S synchronisation alone + KTS: transcode of DRI = 0 scans by subsequence (kernels.hip)
+// K2S synchronisation alone + KTS: transcode of DRI = 0 scans by subsequence (kt_transcode.hip)
 hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                               const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                               const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                               uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int n_slots, int max_rounds,
                               int *rounds_used, const uint8_t *lut_pool, const uint32_t **final_state_out, uint32_t *same_dist, bool *same_valid);
-// (same_dist: one uint32 per subsequence, *same_valid: "filled for this upload" -- the flat-region twins, kernels.hip)
+// (same_dist: one uint32 per subsequence, *same_valid: "filled for this upload" -- the flat-region twins, k2s_subseq.hip)
 hipError_t launch_subseq_transcode(hipStream_t stream, int mode, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                                    const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, const uint32_t *exit_state,
                                    const uint32_t *first_block, uint32_t *hist, const EncHuffTable *enc, uint32_t *sub_bits,

@@ -1,0 +1,598 @@
+// jpeglibrary_amd/csrc/kernels_device.h -- device-side helpers shared by the kernel translation units (k1_markers.hip,
+// k2_huffman.hip, k2s_subseq.hip, k2p_progressive.hip, k3_idct.hip, kt_transcode.hip): wave primitives, the unstuffed bit reader,
+// the K2 family's LDS ring / lookup primitives, the subsequence state word.  Everything here is __forceinline__.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <atomic>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace jpgpu {
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+__device__ __forceinline__ uint32_t wave_reduce_min(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t t = __shfl_xor(v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_reduce_max_i(int32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int32_t t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return (uint32_t)v;
+}
+// DPP forms of the wave-wide sums (all 64 lanes must be active): data-parallel-primitive operands move values between lanes
+// inside the VALU, no LDS crossbar round trip per step as with ds_bpermute (__shfl_*).  Control codes: row_shr:n = 0x110 + n,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143, wave_shl:1 = 0x130, wave_shr:1 = 0x138; lanes without a source receive 0.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += dpp0<0x111>(v);       // inside each row of 16 lanes
+    v += dpp0<0x112>(v);
+    v += dpp0<0x114>(v);
+    v += dpp0<0x118>(v);
+    v += dpp0<0x142, 0xA>(v);  // rows 1 and 3 take the total of the row before them
+    v += dpp0<0x143, 0xC>(v);  // rows 2 and 3 take the total of rows 0-1
+    return v;
+}
+// sum over the wave, the same value in every lane (as a scalar)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
+}
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ uint32_t lane_put(uint32_t old, uint32_t v, uint32_t l) {
+    // (no clang builtin for v_writelane in ROCm 7.2, and two scalar operands need M0 on gfx9; this runs once per long code:
+    // a compare and a select instead of hand-written M0 traffic)
+    return __lane_id() == l ? v : old;
+}
+
+
+// Bit source of one lane == a fresh JpegBitReader positioned at the start of its restart interval (ref: JpegBitReader.cs),
+// reading the UNSTUFFED copy written by K1: interval bytes [ustart, uend) followed by at least 16 one-bits.
+//   hi   : the next 32 bits of the stream (bit 31 first), always fully valid after ub_consume
+//   lo   : the bits after them, left aligned, lcnt of them valid (low bits zero)
+//   rem  : real data bits left in the interval == the reference's "bits available"; reads past them see the ones
+//          padding, which is exactly PeekBits(16)'s padding (JpegBitReader.cs:163-167); once rem is 0 every peek is 0xFFFF
+// Words come from a register queue of 2 x 16 bytes (qw current, nx prefetched a whole chunk ahead: memory latency is off
+// the critical path).  All arithmetic is 32-bit.
+struct UBits {
+    const uint8_t *p;  // address of the next 16-byte chunk to prefetch
+    uint4 qw, nx;
+    uint32_t qn;
+    uint32_t hi, lo;
+    int32_t lcnt;
+    int32_t rem;
+};
+
+__device__ __forceinline__ uint32_t ub_next_word(UBits &r) {
+    const uint32_t w = r.qw.x;
+    r.qw.x = r.qw.y;
+    r.qw.y = r.qw.z;
+    r.qw.z = r.qw.w;
+    r.qn--;
+    if (r.qn == 0) {
+        r.qw = r.nx;
+        __builtin_memcpy(&r.nx, r.p, 16);  // 4-byte aligned 16-byte load; buffers are padded
+        r.p += 16;
+        r.qn = 4;
+    }
+    return __builtin_bswap32(w);
+}
+
+// consume n bits, 1 <= n <= 32
+__device__ __forceinline__ void ub_consume(UBits &r, uint32_t n) {
+    r.hi = __builtin_amdgcn_alignbit(r.hi, r.lo, (32u - n) & 31u);  // n == 32 -> lo
+    r.lo = n >= 32u ? 0u : (r.lo << n);
+    r.lcnt -= (int32_t)n;
+    if (r.lcnt < 0) {
+        const uint32_t d = (uint32_t)(-r.lcnt);  // 1..32 low bits of hi are missing
+        const uint32_t w = ub_next_word(r);
+        r.hi |= w >> ((32u - d) & 31u);  // d == 32 -> w
+        r.lo = d >= 32u ? 0u : (w << d);
+        r.lcnt = 32 - (int32_t)d;
+    }
+}
+
+__device__ __forceinline__ void ub_init(UBits &r, const uint8_t *ubase, uint32_t ustart, uint32_t uend) {
+    const uint32_t a = ustart & ~3u;
+    __builtin_memcpy(&r.qw, ubase + a, 16);
+    __builtin_memcpy(&r.nx, ubase + a + 16, 16);
+    r.p = ubase + a + 32;
+    r.qn = 4;
+    r.hi = ub_next_word(r);
+    r.lo = ub_next_word(r);
+    r.lcnt = 32;
+    const uint32_t skip = (ustart & 3u) * 8;
+    if (skip) ub_consume(r, skip);
+    r.rem = (int32_t)((uend - ustart) * 8u);
+}
+
+// LDS image of a staged DevHuffTable
+struct LdsHuff {
+    const uint16_t *lut;
+    const uint16_t *maxcode;
+    const uint8_t *valoffset;
+    const uint8_t *values;
+};
+
+__device__ __forceinline__ LdsHuff lds_huff(const uint8_t *tabs, uint32_t slot) {
+    const uint8_t *t = tabs + slot * sizeof(DevHuffTable);
+    LdsHuff h;
+    h.lut = reinterpret_cast<const uint16_t *>(t);
+    h.maxcode = reinterpret_cast<const uint16_t *>(t + offsetof(DevHuffTable, maxcode));
+    h.valoffset = t + offsetof(DevHuffTable, valoffset);
+    h.values = t + offsetof(DevHuffTable, values);
+    return h;
+}
+
+__device__ __forceinline__ LdsHuff lds_huff16(const uint8_t *tabs, uint32_t off16) {
+    const uint8_t *t = tabs + off16 * 16;
+    LdsHuff h;
+    h.lut = reinterpret_cast<const uint16_t *>(t);
+    h.maxcode = reinterpret_cast<const uint16_t *>(t + offsetof(DevHuffTable, maxcode));
+    h.valoffset = t + offsetof(DevHuffTable, valoffset);
+    h.values = t + offsetof(DevHuffTable, values);
+    return h;
+}
+
+// One Huffman symbol and its magnitude bits:
+//   DecodeHuffmanCode (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:81-88, JpegHuffmanDecodingTable.cs:73-113) followed by
+//   ReceiveAndExtend (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:100-115) when the category s is non-zero
+//   (s = sym for a DC symbol, sym & 15 for an AC symbol).
+// Returns 0, or the failure detail.  value = extended magnitude (0 when s == 0).
+template <class R>
+__device__ __forceinline__ uint32_t ub_symbol(R &r, const LdsHuff &h, bool is_dc, bool closed_by_marker, uint32_t &sym_out,
+                                              int32_t &value) {
+    const uint32_t code16 = r.rem > 0 ? (r.hi >> 16) : 0xFFFFu;
+    const uint32_t e = h.lut[code16 >> (16 - kHuffLutBits)];
+    uint32_t size = e >> 8, sym = e & 0xFF;
+    if (size == 0) {
+        size = kHuffLutBits + 1;
+        while (code16 > h.maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
+        if (size > 16) return kDetailInvalidHuffmanCode;
+        sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
+    }
+    sym_out = sym;
+    const uint32_t s = is_dc ? sym : (sym & 15u);
+    // advance Math.Min(entry.CodeSize, bitsRead)
+    r.rem = r.rem > (int32_t)size ? r.rem - (int32_t)size : 0;
+    value = 0;
+    if (s != 0) {
+        if (s > 16u) return kDetailInvalidHuffmanCode;  // categories above 16 are outside the verified envelope
+        if ((int32_t)s > r.rem) return (r.rem == 0 && closed_by_marker) ? kDetailMarkerInData : kDetailStreamEnded;
+        const int32_t v = (int32_t)__builtin_amdgcn_ubfe(r.hi, 32u - size - s, s);
+        value = v - ((((v + v) >> s) - 1) & ((1 << s) - 1));  // Extend(v, nbits)
+        r.rem -= (int32_t)s;
+    }
+    ub_consume(r, size + s);
+    return 0;
+}
+
+// LDS staging of one wave: 64 blocks x 128 B, 16-byte chunks XOR-swizzled so that both the per-lane
+// scattered 2-byte stores and the block-major 16-byte flush reads are (nearly) bank-conflict free.
+__device__ __forceinline__ uint32_t stage_addr(uint32_t blk, uint32_t coef_index) {
+    const uint32_t chunk = (coef_index >> 3) ^ ((blk >> 1) & 7);
+    return blk * 128 + chunk * 16 + (coef_index & 7) * 2;
+}
+
+// Restart check after an interval (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:139-163): runs after every completed
+// interval except a final partial one.  AdvanceAlignByte + TryReadMarker: no whole byte may be left before the closing
+// marker, and the marker must be RSTn (continue) or EOI (return early).  Returns the error code word or kNoError.
+__device__ __forceinline__ uint32_t restart_check(const DevScan &s, const DevScanStatus &st, DevScanStatus *status_out, uint32_t interval,
+                                                  uint32_t n_ends, uint32_t n_intervals, uint32_t dri_eff, int32_t rem, uint32_t err) {
+    if (err != 0) return (interval << 8) | err;
+    // bits left behind the scan's last block when the scan's terminating marker closes that interval: the host needs the
+    // whole bytes among them for the reader position the reference resumes its marker walk from (:167-176)
+    if (interval == n_intervals - 1) status_out->pad[2] = rem > 0 ? (uint32_t)rem : 0u;
+    const bool needs_check = s.dri != 0 && (interval < n_intervals - 1 || s.restart_check_at_end);
+    if (!needs_check) return kNoError;
+    uint32_t closing = 0xD0;  // entries before the last indexed one are RSTn by construction
+    if (interval == n_ends - 1) closing = st.terminator;
+    if (rem >= 8) return (interval << 8) | kDetailExpectRestart;
+    if (closing == 0xD9) {
+        if (interval < n_intervals - 1) atomicMin(&status_out->decoded_mcus, (interval + 1) * dri_eff);
+        return kNoError;
+    }
+    if ((closing & 0xF8) != 0xD0) return (interval << 8) | kDetailExpectRestart;
+    return kNoError;
+}
+
+// K2: lanes of a wave decode block b of their MCU in lock-step into a shared LDS staging that is flushed per block as
+// whole 128-byte lines of the coefficient buffer (zig-zag int16, MCU scan order).
+//
+// With 64 lanes in lock-step anything a lane does "rarely" happens in almost every iteration of the wave, so the symbol
+// loop is written without per-lane state machines:
+//  * the lane's bit source is a bit POSITION into a private 64-byte LDS ring of its unstuffed stream (17 words per lane:
+//    16 ring words stored MSB-first + a mirror of word 0, so two consecutive words are always one ds_read2; stride 17
+//    words keeps lanes on distinct banks).  Peeking 32 bits is bfe + address + ds_read2 + v_alignbit; consuming n bits is
+//    one add.  The ring is topped up once per BLOCK (16 bytes, prefetched one block ahead into registers).
+//  * one lookup of the next kK2LutBits bits returns total length (code + magnitude), code length, category and the
+//    zig-zag advance in one 32-bit word; EOB and ZRL are ordinary entries whose "coefficient" is a zero stored where
+//    nothing has been written yet, so the AC loop has no run/EOB branches.
+//  * everything else -- codes longer than the lookup, the last bits of the interval where the reference's
+//    "bits available" rules matter (JpegBitReader.cs:157-204), a ring that ran dry inside one block -- takes one
+//    exec-masked exact path (k2_slow_symbol), the same decisions as ub_symbol.
+constexpr int kK2RingStride = 68;                         // bytes per lane: 16 words + mirror of word 0
+constexpr int kK2WaveBytes = 8192 + 64 * kK2RingStride;   // coefficient staging + rings
+constexpr int kK2SmallBytes = 320;                        // maxcode[18] + valoffset[20] + values[256] + pad (round kernel's exact path)
+
+// Lookups of the K2 family (K2, the K2S final pass), built once per upload for every table of the pool, as a DC and as an AC
+// table (lut_pool_kernel), copied to LDS as they are:
+//   L1  2^11 x u16, the next 11 bits:  AC  total bits | zig-zag advance << 6 | category << 12   (advance in coefficients: r + 1;
+//                                          16 for any r != 0 with category 0; 63 = EOB, past the end from any position)
+//                                      DC  total bits | category << 6
+//                                      0 = not decided by 11 bits (a longer code); DC: 0x8000 = a category above 16
+//   L2  256 x u16, the LONG codes:     entry j = the reference's maxcode walk on the 16 bits t16 + j, same format, 0 = no code.
+//                                      Codes longer than the first level are the numerically largest ones of a canonical
+//                                      table: for the standard tables the last 192 of the 65 536 16-bit values hold them all.
+//                                      t16 = max(first value L1 does not decide, 65536 - 256).
+//   header  t16
+//   the reference's maxcode / valoffset / values (the exact walk: invalid codes, tables whose long codes leave the second level)
+// Round 4: 32-bit entries took 34 KB of LDS for four tables and a long code cost the maxcode walk (six dependent LDS reads
+// with 63 lanes waiting); now 19.8 KB, one more lookup for a long code, and the eleventh wave per workgroup.
+// (Everything the symbol loop may touch stays in LDS: with the walk's arrays in global memory hipcc put a `s_waitcnt vmcnt(0)`
+// at the head of the symbol loop -- every symbol waited for the previous block's coefficient stores: K2S final pass 7.8 -> 8.8 ms.)
+constexpr int kK2LutBits = 11;
+constexpr uint32_t kK2L1Bytes = 2u << kK2LutBits;
+constexpr uint32_t kK2L2Entries = 256;
+constexpr uint32_t kK2BadCat = 0x8000u;
+constexpr uint32_t kK2TabBytes = kK2L1Bytes + 2u * kK2L2Entries + 16u + kK2SmallBytes;  // == kLutPoolBytesPerTable / 2 (kernels.h)
+
+struct K2Tab {
+    const uint16_t *lut;
+    const uint16_t *l2;
+    const uint32_t *hdr;  // {t16, 0, 0, 0}
+    const uint8_t *small;  // maxcode[18] | valoffset[20] | values[256]
+};
+
+__device__ __forceinline__ K2Tab k2_tab(const uint8_t *tabs, uint32_t slot) {
+    const uint8_t *t = tabs + slot * kK2TabBytes;
+    K2Tab h;
+    h.lut = reinterpret_cast<const uint16_t *>(t);
+    h.l2 = reinterpret_cast<const uint16_t *>(t + kK2L1Bytes);
+    h.hdr = reinterpret_cast<const uint32_t *>(t + kK2L1Bytes + 2u * kK2L2Entries);
+    h.small = t + kK2L1Bytes + 2u * kK2L2Entries + 16u;
+    return h;
+}
+
+// zig-zag advance (in int16 BYTES, i.e. 2 x coefficients) of an AC symbol: r + 1 coefficients for a non-zero category,
+// 16 for ANY r != 0 with category 0 (ref: ...BaselineScanDecoder.cs:212-220), and "past the end" for EOB.
+__device__ __forceinline__ uint32_t k2_ac_advance(uint32_t sym) {
+    const uint32_t rr = sym >> 4;
+    return (sym & 15u) ? 2u * (rr + 1u) : (rr ? 32u : 127u);
+}
+
+// next 32 bits of the lane's stream at bit position pm1 + 1
+__device__ __forceinline__ uint32_t k2_window(const uint8_t *ring, int32_t pm1) {
+    const uint32_t t = __builtin_amdgcn_ubfe((uint32_t)pm1, 5, 4);
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(ring + t * 4);
+    return __builtin_amdgcn_alignbit(p[0], p[1], ~(uint32_t)pm1);
+}
+
+struct K2Feed {
+    const uint8_t *gp;  // global address of the chunk after nx
+    uint4 nx;           // chunk number `wr`, already loaded
+    uint32_t wr;        // 16-byte chunks written to the ring so far (the ring holds chunks wr-4 .. wr-1)
+};
+
+__device__ __forceinline__ void k2_ring_write(uint8_t *ring, uint32_t slot, const uint4 &v) {
+    uint32_t *rp = reinterpret_cast<uint32_t *>(ring + slot * 16);
+    const uint32_t w0 = __builtin_bswap32(v.x);
+    rp[0] = w0;
+    rp[1] = __builtin_bswap32(v.y);
+    rp[2] = __builtin_bswap32(v.z);
+    rp[3] = __builtin_bswap32(v.w);
+    if (slot == 0) reinterpret_cast<uint32_t *>(ring)[16] = w0;
+}
+
+// moves the prefetched chunk into the ring when the slot it replaces is no longer needed (the word before the current
+// position must stay readable: k2_window reads it) and prefetches the next one
+__device__ __forceinline__ void k2_topup(uint8_t *ring, K2Feed &f, int32_t pm1) {
+    const int32_t rdc = (pm1 < 0 ? 0 : pm1) >> 7;
+    if ((int32_t)f.wr < rdc + 4) {
+        k2_ring_write(ring, f.wr & 3u, f.nx);
+        f.wr++;
+        __builtin_memcpy(&f.nx, f.gp, 16);
+        f.gp += 16;
+    }
+}
+
+// fast-path limit: a symbol of n bits at position pos may take the fast path when pos + n <= lim, which guarantees both
+// "n real bits are available" and "the words the NEXT symbol reads (k2_symbol: up to 3 words past the one holding the bit
+// before its position) are inside the ring"
+__device__ __forceinline__ int32_t k2_limit(int32_t endpos, uint32_t wr) {
+    const int32_t loaded = (int32_t)(wr * 128u) - 128;
+    return endpos < loaded ? endpos : loaded;
+}
+
+// Exact symbol decode: DecodeHuffmanCode + ReceiveAndExtend with the reference's "bits available" rules (same decisions
+// as ub_symbol).  Returns 0 or the failure detail; n = bits consumed, value, adv = zig-zag advance (AC, in coefficients).
+__device__ __forceinline__ uint32_t k2_slow_symbol(uint8_t *ring, K2Feed &f, int32_t pm1, int32_t endpos, const K2Tab &h, bool is_dc,
+                                                bool closed_by_marker, uint32_t &n, int32_t &value, uint32_t &adv) {
+    const int32_t pos = pm1 + 1;
+    while ((int32_t)(f.wr * 128u) < pos + 160) k2_topup(ring, f, pm1);  // always has room here
+    const uint32_t hi = k2_window(ring, pm1);
+    int32_t rem = endpos - pos;
+    if (rem < 0) rem = 0;
+    const uint32_t code16 = rem > 0 ? (hi >> 16) : 0xFFFFu;
+    uint32_t e = h.lut[code16 >> (16 - kK2LutBits)];
+    if (is_dc && (e & kK2BadCat) != 0) return kDetailInvalidHuffmanCode;  // categories above 16 are outside the verified envelope
+    const uint32_t t16 = h.hdr[0];
+    if (e == 0 && code16 >= t16) {  // a long code: the second level (t16 >= 65536 - 256)
+        e = h.l2[code16 - t16];
+        if (is_dc && (e & kK2BadCat) != 0) return kDetailInvalidHuffmanCode;
+    }
+    uint32_t size, s;
+    if (e == 0) {
+        // longer than the first level decides and not in the second: the reference's walk (an entry of the first level is empty
+        // exactly when the code has more than 11 bits, so the walk may start there)
+        const uint16_t *maxcode = reinterpret_cast<const uint16_t *>(h.small);
+        size = kK2LutBits + 1;
+        while (code16 > maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
+        if (size > 16) return kDetailInvalidHuffmanCode;
+        const uint32_t sym = h.small[56 + ((h.small[36 + size] + (code16 >> (16 - size))) & 0xFF)];
+        s = is_dc ? sym : (sym & 15u);
+        adv = (sym & 15u) ? (sym >> 4) + 1u : ((sym >> 4) ? 16u : 63u);
+        if (s > 16u) return kDetailInvalidHuffmanCode;
+    } else {
+        s = is_dc ? ((e >> 6) & 31u) : (e >> 12);
+        size = (e & 63u) - s;
+        adv = (e >> 6) & 63u;
+    }
+    rem = rem > (int32_t)size ? rem - (int32_t)size : 0;  // advance Math.Min(entry.CodeSize, bitsRead)
+    value = 0;
+    if (s != 0) {
+        if ((int32_t)s > rem) return (rem == 0 && closed_by_marker) ? kDetailMarkerInData : kDetailStreamEnded;
+        const int32_t v = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - size - s, s);
+        value = v - ((((v + v) >> s) - 1) & ((1 << s) - 1));  // Extend(v, nbits)
+    }
+    n = size + s;
+    return 0;
+}
+
+// The lane's position and the three stream words around it: w0 holds the bit BEFORE the position (word q = pm1 >> 5),
+// w1 and w2 follow.  A symbol is at most 32 bits, so q advances by at most one word per symbol; the word that would then
+// be missing (q + 3) is read from the ring at the START of the step, off the dependency chain.
+struct K2Pos {
+    int32_t pm1;  // bit position - 1, relative to the lane's 4-byte aligned origin
+    uint32_t w0, w1, w2;
+};
+
+__device__ __forceinline__ void k2_pos_init(K2Pos &p, const uint8_t *ring, int32_t pm1) {
+    const uint32_t *r = reinterpret_cast<const uint32_t *>(ring);
+    const int32_t q = pm1 >> 5;
+    p.pm1 = pm1;
+    p.w0 = r[q & 15];
+    p.w1 = r[(q + 1) & 15];
+    p.w2 = r[(q + 2) & 15];
+}
+
+// One symbol, fast path for every lane, then ONE branch the wave skips unless some lane needs more: a long code (second
+// level), the last bits of the interval, a ring that ran dry (exact path); advances the position.
+// adv2 = zig-zag advance in int16 BYTES (2 x coefficients; 126 = EOB: past the end from any AC position).
+// On failure the lane gets adv2 = 254 (leaves the AC loop), n = 0, value = 0 and the detail code is returned.
+template <bool IS_DC>
+__device__ __forceinline__ uint32_t k2_symbol(uint8_t *ring, K2Feed &f, K2Pos &p, int32_t endpos, int32_t &lim, const K2Tab &h, bool closed_by_marker,
+                                              int32_t &value, uint32_t &adv2) {
+    const uint32_t nxt = *reinterpret_cast<const uint32_t *>(ring + __builtin_amdgcn_ubfe((uint32_t)(p.pm1 + 96), 5, 4) * 4);
+    const uint32_t hi = __builtin_amdgcn_alignbit(p.w0, p.w1, ~(uint32_t)p.pm1);
+    const uint32_t e = h.lut[hi >> (32 - kK2LutBits)];
+    uint32_t n = e & 63u;
+    const uint32_t cat = IS_DC ? ((e >> 6) & 31u) : (e >> 12);
+    const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - n, cat);
+    value = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));  // Extend(v, nbits)
+    adv2 = (e >> 5) & 0x7Eu;
+    uint32_t err = 0;
+    // slow: the entry is empty (e - 1 is negative), a DC category above 16 (bit 15), or the symbol does not fit below the
+    // limit -- one signed test
+    const bool slow = (int32_t)((e - 1u) | (IS_DC ? e << 16 : 0u) | (uint32_t)(lim - (p.pm1 + 1) - (int32_t)n)) < 0;
+    if (slow) {  // exec-masked; the wave skips it when no lane is flagged
+        uint32_t adv = 0;
+        err = k2_slow_symbol(ring, f, p.pm1, endpos, h, IS_DC, closed_by_marker, n, value, adv);
+        adv2 = adv * 2u;
+        lim = k2_limit(endpos, f.wr);
+        if (err != 0) {
+            n = 0;
+            value = 0;
+            adv2 = 254;
+        }
+    }
+    const int32_t np = p.pm1 + (int32_t)n;
+    const bool step = ((uint32_t)(np ^ p.pm1) >> 5) != 0;
+    p.pm1 = np;
+    p.w0 = step ? p.w1 : p.w0;
+    p.w1 = step ? p.w2 : p.w1;
+    p.w2 = step ? nxt : p.w2;
+    return err;
+}
+// (the same with the table kind known only per lane: the K2S final pass on its way to its first MCU)
+__device__ __forceinline__ uint32_t k2_symbol_any(uint8_t *ring, K2Feed &f, K2Pos &p, int32_t endpos, int32_t &lim, const K2Tab &h, bool is_dc,
+                                                  bool closed_by_marker, int32_t &value, uint32_t &adv2) {
+    const uint32_t nxt = *reinterpret_cast<const uint32_t *>(ring + __builtin_amdgcn_ubfe((uint32_t)(p.pm1 + 96), 5, 4) * 4);
+    const uint32_t hi = __builtin_amdgcn_alignbit(p.w0, p.w1, ~(uint32_t)p.pm1);
+    const uint32_t e = h.lut[hi >> (32 - kK2LutBits)];
+    uint32_t n = e & 63u;
+    const uint32_t cat = is_dc ? ((e >> 6) & 31u) : (e >> 12);
+    const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - n, cat);
+    value = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));
+    adv2 = is_dc ? 0u : ((e >> 5) & 0x7Eu);
+    uint32_t err = 0;
+    const bool slow = (int32_t)((e - 1u) | (is_dc ? e << 16 : 0u) | (uint32_t)(lim - (p.pm1 + 1) - (int32_t)n)) < 0;
+    if (slow) {
+        uint32_t adv = 0;
+        err = k2_slow_symbol(ring, f, p.pm1, endpos, h, is_dc, closed_by_marker, n, value, adv);
+        adv2 = is_dc ? 0u : adv * 2u;
+        lim = k2_limit(endpos, f.wr);
+        if (err != 0) {
+            n = 0;
+            value = 0;
+            adv2 = 254;
+        }
+    }
+    const int32_t np = p.pm1 + (int32_t)n;
+    const bool step = ((uint32_t)(np ^ p.pm1) >> 5) != 0;
+    p.pm1 = np;
+    p.w0 = step ? p.w1 : p.w0;
+    p.w1 = step ? p.w2 : p.w1;
+    p.w2 = step ? nxt : p.w2;
+    return err;
+}
+
+// The K2 family's lookups (format above) for every table of the pool, as a DC table (odd blocks) and as an AC table.
+// Image (table * 2 + is_dc) * kK2TabBytes: L1 | L2 | header.
+constexpr int kLutPoolBits = kK2LutBits;
+#ifndef JPGPU_SR_LB
+#define JPGPU_SR_LB 10
+#endif
+constexpr int kSrLutBits = JPGPU_SR_LB;  // lookup width of the round kernel (a 10-bit prefix decides codes of up to 10 bits)
+__device__ __forceinline__ uint32_t k2_entry_of(const DevHuffTable &h, uint32_t code16, bool is_dc, uint32_t max_size) {
+    // the reference's Lookup on these 16 bits (JpegHuffmanDecodingTable.cs:73-113): first-level table, then the maxcode walk
+    const uint32_t e9 = h.lut[code16 >> (16 - kHuffLutBits)];
+    uint32_t size = e9 >> 8, sym = e9 & 0xFFu;
+    if (size == 0) {
+        size = kHuffLutBits + 1;
+        while (code16 > h.maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
+        if (size > 16) return 0;
+        sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
+    }
+    if (size > max_size) return 0;
+    const uint32_t cat = is_dc ? sym : (sym & 15u);
+    if (cat > 16u) return kK2BadCat;  // (the exact path reports it)
+    if (is_dc) return (size + cat) | (cat << 6);
+    const uint32_t adv = (sym & 15u) ? (sym >> 4) + 1u : ((sym >> 4) ? 16u : 63u);
+    return (size + cat) | (adv << 6) | (cat << 12);
+}
+// the scan's tables as the K2 family keeps them in LDS: the pooled images (lut_pool_kernel) copied as they are
+__device__ __forceinline__ void k2_stage_scan_tables(const DevScan &s, const uint8_t *lut_pool, uint8_t *tabs, uint32_t *blk_info, int n_slots,
+                                                     uint32_t nthreads) {
+    const uint32_t tid = threadIdx.x;
+    for (int sl = 0; sl < kMaxHuffSlots && sl < n_slots; sl++) {
+        const uint32_t pi = s.huff_pool[sl];
+        if (pi == 0xFFFF) continue;
+        bool is_dc = false;
+        for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
+        const uint4 *src = reinterpret_cast<const uint4 *>(lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * kK2TabBytes);
+        uint4 *dst = reinterpret_cast<uint4 *>(tabs + sl * kK2TabBytes);
+        for (uint32_t i = tid; i < kK2TabBytes / 16; i += nthreads) dst[i] = src[i];
+    }
+    // per block-in-MCU: scan component | DC slot << 8 | AC slot << 16 (kept in LDS: the block loop must not touch global
+    // memory for it, a vector load there would wait for the coefficient stores of the previous block)
+    if (tid < kMaxBlocksPerMcu) {
+        const uint32_t ci = s.blk_comp[tid];
+        blk_info[tid] = ci | ((uint32_t)s.comp[ci].dc_slot << 8) | ((uint32_t)s.comp[ci].ac_slot << 16);
+    }
+}
+
+// DecodeHuffmanCode alone (ref: ScanDecoder/JpegHuffmanScanDecoder.cs:81-88): the symbol, no magnitude bits.
+template <class R>
+__device__ __forceinline__ uint32_t ub_huff(R &r, const LdsHuff &h, uint32_t &sym_out) {
+    const uint32_t code16 = r.rem > 0 ? (r.hi >> 16) : 0xFFFFu;
+    const uint32_t e = h.lut[code16 >> (16 - kHuffLutBits)];
+    uint32_t size = e >> 8, sym = e & 0xFF;
+    if (size == 0) {
+        size = kHuffLutBits + 1;
+        while (code16 > h.maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
+        if (size > 16) return kDetailInvalidHuffmanCode;
+        sym = h.values[(h.valoffset[size] + (code16 >> (16 - size))) & 0xFF];
+    }
+    sym_out = sym;
+    r.rem = r.rem > (int32_t)size ? r.rem - (int32_t)size : 0;  // advance Math.Min(entry.CodeSize, bitsRead)
+    ub_consume(r, size);
+    return 0;
+}
+
+// TryReadBits(n), 1 <= n <= 16 (ref: JpegBitReader.cs:190-204): false when fewer than n bits are left
+template <class R>
+__device__ __forceinline__ bool ub_try_read_bits(R &r, uint32_t n, uint32_t &bits) {
+    if ((int32_t)n > r.rem) return false;
+    bits = r.hi >> (32u - n);
+    r.rem -= (int32_t)n;
+    ub_consume(r, n);
+    return true;
+}
+
+// subsequence length: (1 << DevScan::sub_shift) bits -- 1024 for small batches (more lanes), up to 4096 for large ones (a
+// longer subsequence re-synchronises more often inside itself: fewer rounds until the exit states stop changing)
+constexpr uint32_t kSubBad = 0x80000000u;  // the lane hit an invalid code / ran out of data under its entry state
+
+// exit state word: overshoot (bits past the nominal end, 0..63) | b << 6 | k << 11 | kSubBad
+__device__ __forceinline__ uint32_t sub_pack(uint32_t overshoot, uint32_t b, uint32_t k) { return overshoot | (b << 6) | (k << 11); }
+
+__device__ __forceinline__ void sub_stage_tables(const DevScan &s, const DevHuffTable *huff_pool, uint8_t *tabs, uint32_t *blk_info, int n_slots,
+                                                 uint32_t nthreads) {
+    const uint32_t tid = threadIdx.x;
+    for (int slot = 0; slot < kMaxHuffSlots && slot < n_slots; slot++) {
+        const uint32_t pi = s.huff_pool[slot];
+        if (pi == 0xFFFF) continue;
+        const uint4 *src = reinterpret_cast<const uint4 *>(&huff_pool[pi]);
+        uint4 *dst = reinterpret_cast<uint4 *>(tabs + slot * sizeof(DevHuffTable));
+        for (uint32_t i = tid; i < sizeof(DevHuffTable) / 16; i += nthreads) dst[i] = src[i];
+    }
+    if (tid < kMaxBlocksPerMcu) {
+        const uint32_t ci = s.blk_comp[tid];
+        const uint32_t dc_off = s.comp[ci].dc_slot * (uint32_t)(sizeof(DevHuffTable) / 16);
+        const uint32_t ac_off = s.comp[ci].ac_slot * (uint32_t)(sizeof(DevHuffTable) / 16);
+        blk_info[tid] = dc_off | (ac_off << 12) | (ci << 24);
+    }
+    __syncthreads();
+}
+
+// A lane's stream positioned at bit `start_bit` of the scan's unstuffed data: K2's ring + feed + position (64 bytes staged,
+// the next 16 prefetched).  Returns pm1 of the start; *endpos = position of the first bit behind the data.
+__device__ __forceinline__ int32_t k2_open_at_bit(const uint8_t *ubase, uint32_t start_bit, uint32_t total_bits, uint8_t *ring, K2Feed &feed,
+                                                  K2Pos &pos, int32_t *endpos) {
+    const uint32_t u0 = start_bit >> 3;
+    const int32_t pm1_0 = (int32_t)((u0 & 3u) * 8u + (start_bit & 7u)) - 1;
+    *endpos = pm1_0 + 1 + (int32_t)(total_bits - start_bit);
+    const uint8_t *g = ubase + (u0 & ~3u);  // 4-byte aligned 16-byte loads; buffers are padded
+    uint4 c0, c1, c2, c3;
+    __builtin_memcpy(&c0, g, 16);
+    __builtin_memcpy(&c1, g + 16, 16);
+    __builtin_memcpy(&c2, g + 32, 16);
+    __builtin_memcpy(&c3, g + 48, 16);
+    __builtin_memcpy(&feed.nx, g + 64, 16);
+    k2_ring_write(ring, 0, c0);
+    k2_ring_write(ring, 1, c1);
+    k2_ring_write(ring, 2, c2);
+    k2_ring_write(ring, 3, c3);
+    feed.wr = 4;
+    feed.gp = g + 80;
+    k2_pos_init(pos, ring, pm1_0);
+    return pm1_0;
+}
+
+// More than 64 KB of dynamic LDS has to be allowed per kernel -- and per DEVICE: a process that drives several devices (one
+// jpgpu_ctx each) must do it on each of them.  done: one bit per device ordinal.
+static inline hipError_t allow_dynamic_lds(const void *kernel, int bytes, std::atomic<uint64_t> &done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
+
+}  // namespace jpgpu

@@ -1,6 +1,6 @@
 """Huffman tables of unusual SHAPE through the K2 family's two-level lookups and the K2S round kernel's parked lanes.
 
-The lookups (kernels.hip, "Lookups of the K2 family") decide codes of up to 11 bits in one step, long codes through a second
+The lookups (kernels_device.h, "Lookups of the K2 family") decide codes of up to 11 bits in one step, long codes through a second
 level that covers the last 256 of the 65 536 sixteen-bit values -- where a canonical table's long codes sit when most of the
 code space is spent on short codes (the standard tables: 192 values) -- and everything else through the reference's maxcode
 walk.  The tables of libjpeg-turbo's files, standard or optimised, never leave the second level.  These do:

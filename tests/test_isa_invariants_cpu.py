@@ -15,7 +15,9 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "jpeglibrary_amd", "csrc", "kernels.hip")
+CSRC = os.path.join(ROOT, "jpeglibrary_amd", "csrc")
+# the decode kernels' translation units (round 5: kernels.hip split by stage)
+SRCS = [os.path.join(CSRC, f) for f in ("k1_markers.hip", "k2_huffman.hip", "k2s_subseq.hip", "k3_idct.hip")]
 
 
 @pytest.fixture(scope="module")
@@ -26,10 +28,17 @@ def isa(tmp_path_factory):
     flags = open(os.path.join(ROOT, "jpeglibrary_amd", "csrc", "Makefile")).read()
     m = re.search(r"^CXXFLAGS\s*[:?]?=\s*(.*)$", flags, re.M)
     cxxflags = m.group(1).split() if m else ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"]
-    asm = tmp_path_factory.mktemp("isa") / "kernels.s"
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", *[f for f in cxxflags if not f.startswith("-W")], "-S", "--cuda-device-only", "-o", str(asm), SRC],
-                          stderr=subprocess.DEVNULL)
-    return asm.read_text()
+    out = tmp_path_factory.mktemp("isa")
+    procs = []
+    for src in SRCS:
+        asm = out / (os.path.basename(src) + ".s")
+        procs.append((asm, subprocess.Popen([hipcc, "--offload-arch=gfx950", *[f for f in cxxflags if not f.startswith("-W")], "-S", "--cuda-device-only",
+                                             "-o", str(asm), src], stderr=subprocess.DEVNULL)))
+    text = []
+    for asm, p in procs:
+        assert p.wait() == 0, asm
+        text.append(asm.read_text())
+    return "\n".join(text)
 
 
 def _body(text, mangled_prefix):

@@ -1,5 +1,5 @@
 // tools/microbench/symbol_loop.hip -- cycles per trip of the AC-refinement symbol loop of progressive_stream_kernel
-// (w_ac_refine_v4 in jpeglibrary_amd/csrc/kernels.hip), alone on one wave with synthetic window entries: every entry a plain
+// (w_ac_refine_v4 in jpeglibrary_amd/csrc/k2p_progressive.hip), alone on one wave with synthetic window entries: every entry a plain
 // symbol with run 0, so a loop entry makes 63 - zq0 trips before the zero rank runs off the table.  Timed with s_memtime at two
 // trip counts; printed: the difference per trip.  Variants:
 //   full     the loop as shipped (rotated commits fill the hazard gaps)

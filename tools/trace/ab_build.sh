@@ -5,5 +5,5 @@ set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 FLAGS="$1"; shift
 rm -rf /tmp/ab && cp -r $R /tmp/ab && cd /tmp/ab/jpeglibrary_amd/csrc
-touch kernels.hip encode_kernels.hip && make -s -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math $FLAGS" > /tmp/ab/build.log 2>&1 || { tail -5 /tmp/ab/build.log; exit 1; }
+touch k*.hip encode_kernels.hip && make -s -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math $FLAGS" > /tmp/ab/build.log 2>&1 || { tail -5 /tmp/ab/build.log; exit 1; }
 cd /tmp/ab && GRAFT_REPO_ROOT=/tmp/ab "$@"

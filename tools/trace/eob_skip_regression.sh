@@ -12,7 +12,7 @@ echo "== shipped build"
 ( cd $R && timeout 600 python -m pytest $T -q -p no:cacheprovider 2>&1 | tail -4 )
 rm -rf /tmp/eob && cp -r $R /tmp/eob && rm -rf /tmp/eob/gpurun_out
 python3 - <<'EOF'
-p = "/tmp/eob/jpeglibrary_amd/csrc/kernels.hip"
+p = "/tmp/eob/jpeglibrary_amd/csrc/k2p_progressive.hip"
 s = open(p).read()
 follow = "                JPGPU_FOLLOW(w.my)\n                if (err != 0) break;  // gave up waiting (kDetailSpinTimeout)\n"
 skip = "                if (eobrun != 0) {\n                    eobrun--;\n                    continue;\n                }\n"

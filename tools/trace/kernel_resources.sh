@@ -1,8 +1,8 @@
 #!/bin/bash
-# Register / scratch / occupancy table of every kernel in kernels.hip and encode_kernels.hip as the compiler reports it
+# Register / scratch / occupancy table of every kernel in the k*.hip files and encode_kernels.hip as the compiler reports it
 # (-Rpass-analysis=kernel-resource-usage); no GPU needed.  usage: kernel_resources.sh > profiles/rNN_kernel_resources.txt
 R=$(cd "$(dirname "$0")/../.." && pwd)
-for f in kernels.hip encode_kernels.hip; do
+for f in k1_markers.hip k2_huffman.hip k2s_subseq.hip k2p_progressive.hip k3_idct.hip kt_transcode.hip encode_kernels.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -c --cuda-device-only -Rpass-analysis=kernel-resource-usage \
       -o /dev/null $R/jpeglibrary_amd/csrc/$f 2> /tmp/kres_$f.txt
   python3 - /tmp/kres_$f.txt <<'PY'

@@ -10,7 +10,7 @@ N=${1:-64}
 IFS=";" read -ra VS <<< "${VARIANTS:--DJPGPU_BASELINE=1;-DJPGPU_PS_EARLIER_FORMS -DJPGPU_PS_REFINE4;-DJPGPU_PS_EARLIER_FORMS -DJPGPU_PS_REFINE4 -DJPGPU_PS_ABLATE_EPILOGUE}"
 for v in "${VS[@]}"; do
   rm -rf /tmp/abl && cp -r $R /tmp/abl && rm -rf /tmp/abl/gpurun_out
-  ( cd /tmp/abl/jpeglibrary_amd/csrc && touch kernels.hip && make -s -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math $v" > /tmp/abl/build.log 2>&1 ) || { tail -5 /tmp/abl/build.log; exit 1; }
+  ( cd /tmp/abl/jpeglibrary_amd/csrc && touch k*.hip && make -s -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math $v" > /tmp/abl/build.log 2>&1 ) || { tail -5 /tmp/abl/build.log; exit 1; }
   echo "== build: $v"
   if [ -n "${PIPELINED:-}" ]; then
     ( cd /tmp/abl && timeout 300 python3 bench.py --workload 4k_progressive --images $N --distinct 64 --steps 2 --warmup 1 --no-cpu-baseline --no-ingest --no-planar-pass 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('pipelined launch, ms per step:', d['ms_per_step'])" )

@@ -4,7 +4,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/psprof && cp -r $R /tmp/psprof && cd /tmp/psprof/jpeglibrary_amd/csrc
-touch kernels.hip && make -s -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math -DJPGPU_PS_PROFILE=${PSP:-1} ${EXTRA:-}" > /tmp/psprof/build.log 2>&1 || { tail -5 /tmp/psprof/build.log; exit 1; }
+touch k*.hip && make -s -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math -DJPGPU_PS_PROFILE=${PSP:-1} ${EXTRA:-}" > /tmp/psprof/build.log 2>&1 || { tail -5 /tmp/psprof/build.log; exit 1; }
 cd /tmp/psprof && python3 - <<'PY'
 import ctypes as C, sys
 sys.path.insert(0, "/tmp/psprof")

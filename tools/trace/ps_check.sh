@@ -2,7 +2,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/pscheck && cp -r $R /tmp/pscheck && cd /tmp/pscheck/jpeglibrary_amd/csrc
-touch kernels.hip && make -s -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math -DJPGPU_PS_EARLIER_FORMS -DJPGPU_PS_CHECK ${EXTRA:-}" > /tmp/pscheck/build.log 2>&1 || { tail -5 /tmp/pscheck/build.log; exit 1; }
+touch k*.hip && make -s -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math -DJPGPU_PS_EARLIER_FORMS -DJPGPU_PS_CHECK ${EXTRA:-}" > /tmp/pscheck/build.log 2>&1 || { tail -5 /tmp/pscheck/build.log; exit 1; }
 cd /tmp/pscheck && python3 - <<'PY' 2>&1 | head -30
 import sys
 sys.path.insert(0, "/tmp/pscheck")

@@ -9,7 +9,7 @@ for r in $(seq $REPS); do ( cd $R && timeout 300 python -m pytest $T -q -p no:ca
 IFS=";" read -ra VS <<< "${VARIANTS:-}"
 for v in "${VS[@]}"; do
   rm -rf /tmp/ssp && cp -r $R /tmp/ssp && rm -rf /tmp/ssp/gpurun_out
-  ( cd /tmp/ssp/jpeglibrary_amd/csrc && touch kernels.hip && make -s -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math $v" > /tmp/ssp/build.log 2>&1 ) || { tail -5 /tmp/ssp/build.log; exit 1; }
+  ( cd /tmp/ssp/jpeglibrary_amd/csrc && touch k*.hip && make -s -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math $v" > /tmp/ssp/build.log 2>&1 ) || { tail -5 /tmp/ssp/build.log; exit 1; }
   echo "== build: $v"
   for r in $(seq $REPS); do ( cd /tmp/ssp && timeout 300 python -m pytest $T -q -p no:cacheprovider 2>&1 | grep -E "^E  +AssertionError|passed|failed" | cut -c1-240 ); done
 done
