@@ -279,8 +279,13 @@ int jpgpu_batch_upload_coefficients(jpgpu_batch *b, int i, const int16_t *src, s
  * ms[0] marker index, ms[1] Huffman, ms[2] IDCT+output, averaged over the calls that ran serially (see jpgpu_batch_decode);
  * ms[3] whole pipeline, averaged over all calls. */
 int jpgpu_batch_stage_ms(jpgpu_batch *b, float ms[4]);
-/* Synchronisation rounds the self-synchronising DRI = 0 decoder needed in the most recent decode (0 = not used). */
+/* Synchronisation rounds the self-synchronising DRI = 0 decoder needed in the most recent decode (0 = not used).  The rounds
+ * are enqueued ahead and checked on the device (jpgpu_batch_decode does not wait for them): valid after jpgpu_batch_sync /
+ * _result / _download_*. */
 int jpgpu_batch_subseq_rounds(const jpgpu_batch *b);
+/* Times the enqueued rounds did not reach the fixed point (the synchronising call then issued the step again with the host
+ * reading the counts between rounds, and the upload's later decodes stay that way).  Valid after jpgpu_batch_sync. */
+int jpgpu_batch_subseq_fallbacks(const jpgpu_batch *b);
 /* Times the single-launch progressive path gave up waiting inside the kernel (its scans follow each other's progress, which
  * relies on workgroups being dispatched in list order) and the step was re-issued scan level by scan level.  Valid after
  * jpgpu_batch_result. */

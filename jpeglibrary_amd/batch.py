@@ -138,6 +138,10 @@ class Batch:
         """Synchronisation rounds the DRI = 0 subsequence decoder needed in the last decode (0 = not used)."""
         return _lib.jpgpu_batch_subseq_rounds(self._h)
 
+    def subseq_fallbacks(self):
+        """Times the enqueued K2S rounds did not converge and the step was issued again with host-checked rounds."""
+        return _lib.jpgpu_batch_subseq_fallbacks(self._h)
+
     def totals(self):
         a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         _lib.jpgpu_batch_totals(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))

@@ -1174,6 +1174,9 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     total_subs_ = 0;
     max_subs_per_scan_ = 0;
     sub_same_valid_ = false;
+    k2s_budget_ = 0;
+    k2s_unchecked_ = k2s_idct_behind_ = false;
+    k2s_host_checked_ = getenv("JPGPU_SUBSEQ_HOST_CHECK") != nullptr;  // A/B switch: the host reads the counts between rounds
     dispose_jobs_.clear();
     dispose_max_blocks_ = 0;
     std::vector<IdctWork> idct_work;
@@ -1632,7 +1635,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_sub_entry_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
         {&d_sub_dcsum_, nullptr, 0, (size_t)total_subs_ * 16 + 256},
         {&d_sub_dcentry_, nullptr, 0, (size_t)total_subs_ * 16 + 256},
-        {&d_sub_changed_, nullptr, 0, 64 * sizeof(uint32_t)},
+        {&d_sub_changed_, nullptr, 0, kSubseqCtlWords * sizeof(uint32_t)},
         {&d_dispose_, dispose_jobs_.data(), dispose_jobs_.size() * sizeof(DisposeJob), 0},
         {&d_sub_same_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
         {&d_lut_pool_, nullptr, 0, huff_pool_.size() * kLutPoolBytesPerTable},
@@ -1656,6 +1659,8 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(descriptors)");
         }
     }
+    e = hipMemsetAsync(d_sub_changed_.ptr, 0, kSubseqCtlWords * sizeof(uint32_t), up);  // (word kSubseqCtlSameDone: no twins found for this upload yet)
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(K2S control)");
     e = launch_lut_pool(up, (const DevHuffTable *)d_huff_pool_.ptr, (int)huff_pool_.size(), (uint8_t *)d_lut_pool_.ptr);
     if (e != hipSuccess) return hip_fail(e, "lut_pool_kernel");
     if (!files_resident_) {
@@ -1698,14 +1703,21 @@ int DeviceBatch::run_huffman() {
                                   (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (const uint8_t *)d_lut_pool_.ptr);
     if (e != hipSuccess) return hip_fail(e, "huffman_decode_kernel");
     if (n_sub_work_ > 0) {
-        // DRI = 0 scans: the final pass writes every block of the scan as whole lines (nothing to clear)
+        // DRI = 0 scans: the final pass writes every block of the scan as whole lines (nothing to clear).  The rounds are
+        // enqueued ahead, as many as the last decode of this upload used (16 the first time); sync() reads whether they sufficed.
+        const int max_rounds = (int)max_subs_per_scan_ + 2;
+        const int first_budget = getenv("JPGPU_SUBSEQ_BUDGET") ? std::max(2, atoi(getenv("JPGPU_SUBSEQ_BUDGET"))) : kSubseqFirstBudget;  // (tests: force the fallback)
+        const int device_rounds = k2s_host_checked_ ? 0 : std::min(max_rounds, k2s_budget_ > 0 ? k2s_budget_ : first_budget);
+        k2s_issued_ = device_rounds;
+        k2s_unchecked_ = device_rounds > 0;
+        k2s_idct_behind_ = false;
         e = launch_subseq_decode(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_sub_work_.ptr,
                                  n_sub_work_, (const uint32_t *)d_sub_scan_ids_.ptr, n_sub_scans_, (const uint32_t *)d_ends_u_.ptr,
                                  (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr, (uint32_t *)d_sub_exit_a_.ptr,
                                  (uint32_t *)d_sub_exit_b_.ptr, (uint32_t *)d_sub_nblk_.ptr, (uint32_t *)d_sub_first_.ptr,
-                                 (uint32_t *)d_sub_entry_.ptr, d_sub_dcsum_.ptr, d_sub_dcentry_.ptr, (uint32_t *)d_sub_changed_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (int)max_subs_per_scan_ + 2,
+                                 (uint32_t *)d_sub_entry_.ptr, d_sub_dcsum_.ptr, d_sub_dcentry_.ptr, (uint32_t *)d_sub_changed_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, max_rounds,
                                  &last_subseq_rounds_, (const uint8_t *)d_lut_pool_.ptr, (const HuffWork *)d_sub_final_work_.ptr, n_sub_final_work_,
-                                 (uint32_t *)d_sub_same_.ptr, &sub_same_valid_);
+                                 (uint32_t *)d_sub_same_.ptr, &sub_same_valid_, device_rounds);
         if (e != hipSuccess) return hip_fail(e, "subsequence decode");
     }
     const int rc = run_progressive();
@@ -1723,7 +1735,7 @@ int DeviceBatch::run_subseq_sync(const uint32_t **final_state, const uint32_t **
                                       (uint32_t *)d_sub_exit_b_.ptr, (uint32_t *)d_sub_nblk_.ptr, (uint32_t *)d_sub_first_.ptr,
                                       (uint32_t *)d_sub_entry_.ptr, d_sub_dcsum_.ptr, d_sub_dcentry_.ptr, (uint32_t *)d_sub_changed_.ptr,
                                       n_huff_slots_, (int)max_subs_per_scan_ + 2, &last_subseq_rounds_, (const uint8_t *)d_lut_pool_.ptr,
-                                      final_state, (uint32_t *)d_sub_same_.ptr, &sub_same_valid_);
+                                      final_state, (uint32_t *)d_sub_same_.ptr, &sub_same_valid_, 0 /* host-checked: the optimizer waits for the host's table build anyway */);
     if (e != hipSuccess) return hip_fail(e, "subsequence synchronisation");
     return mark_work();
 }
@@ -1866,6 +1878,7 @@ int DeviceBatch::run_dispose_passes(hipStream_t stream) {
 }
 
 int DeviceBatch::run_idct() {
+    if (k2s_unchecked_) k2s_idct_behind_ = true;
     const YccRgbFactors kf = ycc_rgb_factors();
     int rc0 = clear_partial_outputs();
     if (rc0 != JPGPU_OK) return rc0;
@@ -1998,6 +2011,44 @@ int DeviceBatch::decode() {
 // decoding on the same stream -- jpgpu_multi_wait waits for call k while call k + 1 runs -- and is not waited for.
 int DeviceBatch::sync() {
     hipError_t e = work_in_flight_ && done_ev_ ? hipEventSynchronize(done_ev_) : hipStreamSynchronize(ctx_->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    work_in_flight_ = false;
+    return k2s_unchecked_ ? check_subseq_rounds() : JPGPU_OK;
+}
+
+// The device-driven K2S rounds of the decode that has just been waited for: did the enqueued rounds reach the fixed point?
+// (a round other than round 0 that changed no exit state).  Yes: the next decode of this upload enqueues exactly as many.
+// No (a flat region longer than the budget's walks resolve, a pathological stream): the entropy stage -- and the output stage
+// when it was issued behind it -- is issued again with the host reading the counts between rounds, and this upload stays that way.
+int DeviceBatch::check_subseq_rounds() {
+    k2s_unchecked_ = false;
+    uint32_t ctl[64];
+    hipError_t e = hipMemcpy(ctl, d_sub_changed_.ptr, sizeof ctl, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(K2S control)");
+    int used = 0;
+    for (int r = 1; r < k2s_issued_ && r < 62; r++)
+        if (ctl[r] == 0) {
+            used = r + 1;
+            break;
+        }
+    static const bool trace = getenv("JPGPU_SUBSEQ_TRACE") != nullptr;
+    if (trace) {
+        for (int r = 0; r < k2s_issued_ && r < 62; r++) fprintf(stderr, "K2S round %d: %u changed\n", r, ctl[r]);
+        fprintf(stderr, "K2S walks copied: %u; rounds issued %d, used %d\n", ctl[63], k2s_issued_, used);
+    }
+    if (used != 0 || k2s_issued_ >= (int)max_subs_per_scan_ + 2) {  // (n + 2 rounds always suffice: every round fixes one more subsequence)
+        last_subseq_rounds_ = used != 0 ? used : k2s_issued_;
+        k2s_budget_ = last_subseq_rounds_;
+        return JPGPU_OK;
+    }
+    k2s_host_checked_ = true;
+    k2s_fallbacks_++;
+    const bool with_idct = k2s_idct_behind_;
+    int rc = run_marker_index();
+    if (rc == JPGPU_OK) rc = run_huffman();
+    if (rc == JPGPU_OK && with_idct) rc = run_idct();
+    if (rc != JPGPU_OK) return rc;
+    e = work_in_flight_ && done_ev_ ? hipEventSynchronize(done_ev_) : hipStreamSynchronize(ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
     work_in_flight_ = false;
     return JPGPU_OK;

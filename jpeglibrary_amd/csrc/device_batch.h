@@ -150,6 +150,7 @@ class DeviceBatch {
     void note_entropy_only_request() { in_decode_request_ = false; }
     int last_subseq_rounds() const { return last_subseq_rounds_; }
     int progressive_fallbacks() const { return prog_fallbacks_; }
+    int subseq_fallbacks() const { return k2s_fallbacks_; }
     int progressive_replays() const { return prog_replays_; }
     // the optimizer path only needs the files, the scan descriptors and the marker index: no coefficient / sample buffers
     void set_entropy_only(bool on) { entropy_only_ = on; }
@@ -234,6 +235,14 @@ class DeviceBatch {
     uint32_t total_subs_ = 0, max_subs_per_scan_ = 0;
     std::vector<uint32_t> sub_scan_ids_;
     int last_subseq_rounds_ = 0;
+    // Device-driven K2S rounds (launch_subseq_sync): the host enqueues a budget of rounds and reads the counts when it next
+    // waits for the batch (sync()).  k2s_budget_: rounds the last checked decode of this upload used (0 = not known yet: the
+    // first decode takes kSubseqFirstBudget); k2s_unchecked_: such a decode is in flight; k2s_idct_behind_: the output stage
+    // was issued behind it (the fallback repeats it too); k2s_host_checked_: the rounds did not suffice once (or
+    // JPGPU_SUBSEQ_HOST_CHECK): this upload's decodes take the host-checked loop.
+    int k2s_budget_ = 0, k2s_issued_ = 0, k2s_fallbacks_ = 0;
+    bool k2s_unchecked_ = false, k2s_idct_behind_ = false, k2s_host_checked_ = false;
+    int check_subseq_rounds();
     // progressive frames: work of scan ordinal k is prog_work[prog_begin_[k] .. prog_begin_[k + 1])
     DevBuffer d_prog_work_, d_prog_sync_;  // d_prog_sync_: workgroups of the pipelined launch that have started
     std::vector<int> prog_begin_;

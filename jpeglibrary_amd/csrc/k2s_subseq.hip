@@ -265,9 +265,13 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
                                                             const uint32_t *__restrict__ exit_in, uint32_t *__restrict__ exit_out,
                                                             uint32_t *__restrict__ nblk_out, uint32_t *__restrict__ entry_used,
                                                             int4 *__restrict__ dcsum_out, uint32_t *__restrict__ changed, int round,
-                                                            int n_slots, uint32_t warm_bits) {
+                                                            int n_slots, uint32_t warm_bits, const uint32_t *__restrict__ prev_changed) {
     constexpr int LB = kSrLutBits;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // Device-side convergence (round 5): the rounds are enqueued ahead without the host looking at anything; once a round
+    // (other than round 0) has changed no exit state, every later round is a no-op -- and leaves at once.  Both exit buffers
+    // hold the same states then (a round writes every slot, changed or not), so whoever reads "the last one" may read either.
+    if (prev_changed != nullptr && *prev_changed == 0) return;
     // LDS: lookups (n_slots << (LB + 2), at offset 0) | small arrays | block info [kMaxBlocksPerMcu] x 16 | rings | DC sums
     // (small_off is relative to smem; info_off, rings_off, dcs_off and what derives from them are absolute LDS addresses)
     const uint32_t lut0 = sr_lds_addr(smem);
@@ -430,9 +434,46 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
 //                            decoder ("entered like this, it leaves like that"), so the rounds and it can alternate freely;
 //                            in a flat region the states repeat with period m, and the whole region resolves in one walk
 //                            once its first m subsequences have been decoded from the right state.
+// Control words of the device-driven rounds (d_sub_changed_): [0, 62) exits changed by round r, [63] copied by the walks, then
+// the state of the check below; kSubCtlSameDone outlives a decode (the twins are found once per upload).
+enum : uint32_t { kSubCtlArmed = 64, kSubCtlLast = 65, kSubCtlBefore = 66, kSubCtlNextCheck = 67, kSubCtlChecked = 68, kSubCtlConverged = 69,
+                  kSubCtlPerDecode = 96, kSubCtlSameDone = 96, kSubCtlWords = 128 };
+static_assert(kSubCtlSameDone == kSubseqCtlSameDone && kSubCtlWords == kSubseqCtlWords, "kernels.h describes this layout to the host");
+// What the host's loop decides between two rounds, decided on the device (one lane): after `n` rounds, is this one of the
+// points where the host would have looked at the counts (every third round; every round once a round changed only a few
+// exits), has the batch converged, and does the flat-region walk (subseq_same / subseq_propagate_kernel, which return at
+// once unless armed) join in -- not converged, not before round `propagate_from`, and on a PLATEAU: ordinary synchronisation
+// dies out geometrically (a round changes a third to a tenth of what the one before it changed), a flat region changes as
+// many exits round after round.
+__global__ __launch_bounds__(64) void subseq_check_kernel(uint32_t *__restrict__ ctl, uint32_t n, uint32_t few_changes, uint32_t propagate_from) {
+    if (threadIdx.x != 0) return;
+    ctl[kSubCtlArmed] = 0;
+    if (ctl[kSubCtlConverged] != 0) return;
+    const uint32_t next = ctl[kSubCtlNextCheck];
+    if (next != 0 && n < next) return;
+    const uint32_t checked = ctl[kSubCtlChecked];
+    uint32_t last = checked != 0 ? ctl[kSubCtlLast] : 0xFFFFFFFFu, before = checked != 0 ? ctl[kSubCtlBefore] : 0xFFFFFFFFu;
+    bool converged = false;
+    for (uint32_t r = checked; r < n; r++) {
+        const uint32_t c = ctl[r];
+        converged |= r > 0 && c == 0;
+        before = last;
+        last = c;
+    }
+    ctl[kSubCtlLast] = last;
+    ctl[kSubCtlBefore] = before;
+    ctl[kSubCtlChecked] = n;
+    ctl[kSubCtlConverged] = converged ? 1u : 0u;
+    ctl[kSubCtlNextCheck] = n + (last <= few_changes ? 1u : 3u);
+    const bool plateau = before == 0xFFFFFFFFu || (uint64_t)last * 2 > before;
+    ctl[kSubCtlArmed] = (!converged && n >= propagate_from && plateau) ? 1u : 0u;
+}
+
 __global__ __launch_bounds__(256) void subseq_same_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
                                                           const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
-                                                          const DevScanStatus *__restrict__ status, uint32_t *__restrict__ same_dist) {
+                                                          const DevScanStatus *__restrict__ status, uint32_t *__restrict__ same_dist,
+                                                          const uint32_t *__restrict__ ctl) {
+    if (ctl != nullptr && (ctl[kSubCtlArmed] == 0 || ctl[kSubCtlSameDone] != 0)) return;  // (device-driven rounds: not now / done for this upload)
     const HuffWork wk = work[blockIdx.x];  // (the rounds' work list: 256 subsequences per entry)
     const DevScan &s = scans[wk.scan];
     if (status[wk.scan].n_ends == 0) return;
@@ -477,7 +518,11 @@ __global__ __launch_bounds__(256) void subseq_same_kernel(const uint8_t *__restr
 __global__ __launch_bounds__(64) void subseq_propagate_kernel(const DevScan *__restrict__ scans, const uint32_t *__restrict__ scan_ids,
                                                               const uint32_t *__restrict__ same_dist, uint32_t *__restrict__ exit_state,
                                                               uint32_t *__restrict__ entry_used, uint32_t *__restrict__ nblk,
-                                                              int4 *__restrict__ dcsum, uint32_t *__restrict__ n_copied) {
+                                                              int4 *__restrict__ dcsum, uint32_t *__restrict__ n_copied, uint32_t *__restrict__ ctl) {
+    if (ctl != nullptr) {  // device-driven rounds: the walk runs where subseq_check_kernel armed it
+        if (ctl[kSubCtlArmed] == 0) return;
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctl[kSubCtlSameDone] = 1;  // (the twins were found in front of this launch)
+    }
     const DevScan &s = scans[scan_ids[blockIdx.x]];
     const uint32_t lane = threadIdx.x;
     uint32_t e_prev = 0xFFFFFFFFu, x_prev = 0;  // the chunk before (lane l = subsequence base - 64 + l)
@@ -805,15 +850,24 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
 
 
 // DRI = 0 scans: self-synchronising subsequence decode.  `work` lists (scan, first subsequence) per workgroup of 256 lanes;
-// `scan_ids` the scans concerned.  Runs synchronisation rounds until no exit state changes (host-checked flag).
-// The synchronisation part alone (rounds until the exit states stop changing, then the block / DC prefix sums); leaves the
-// converged exit states in *final_state.  Shared by the decoder (subseq_final_kernel) and the optimizer (subseq_transcode_kernel).
+// `scan_ids` the scans concerned.  The synchronisation part alone (rounds until the exit states stop changing, then the block /
+// DC prefix sums); leaves the converged exit states in *final_state.  Shared by the decoder (subseq_final_kernel) and the
+// optimizer (subseq_transcode_kernel).
+//
+// Two ways of knowing when to stop:
+//  * device_rounds > 0 (the decoder, round 5): exactly that many rounds are enqueued and the host looks at NOTHING -- no copy,
+//    no stream synchronisation.  A round behind the one that changed no exit leaves at once (subseq_round_kernel), the
+//    flat-region walk is armed or not by subseq_check_kernel; both exit buffers hold the converged states.  Whether the rounds
+//    sufficed is the caller's to read from changed_dev when it next waits for the stream anyway (DeviceBatch::sync): the
+//    first r >= 1 with changed_dev[r] == 0 says rounds r + 1 were used; none -> not converged, the step is issued again the
+//    host-checked way.  *rounds_used is left alone.
+//  * device_rounds == 0 (the optimizer, and the decoder's fallback): the host reads the counts every few rounds and stops.
 hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                               const uint32_t *scan_ids, int n_scans, const uint32_t *ends_u, DevScanStatus *status,
                               const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                               uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int n_slots, int max_rounds,
                               int *rounds_used, const uint8_t *lut_pool, const uint32_t **final_state_out, uint32_t *same_dist,
-                              bool *same_valid) {
+                              bool *same_valid, int device_rounds) {
     *final_state_out = exit_a;
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const size_t lds_round = ((size_t)n_slots << (kSrLutBits + 2)) + (size_t)n_slots * kK2SmallBytes + kMaxBlocksPerMcu * 16 + 256 * (kSrRingStride + 16) +
@@ -833,10 +887,26 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
     // changed_dev[63] counts what the flat-region walks copied
     constexpr int kCheckEvery = 3;
     const uint32_t few_changes = 8u * (uint32_t)n_scans;
-    hipError_t e = hipMemsetAsync(changed_dev, 0, 64 * sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(changed_dev, 0, (device_rounds > 0 ? (size_t)kSubCtlPerDecode : 64) * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     int round = 0;
-    bool converged = false;
+    if (device_rounds > 0) {
+        const int n_rounds = device_rounds < 62 ? device_rounds : 61;
+        for (; round < n_rounds; round++) {
+            hipLaunchKernelGGL(subseq_round_kernel, dim3(n_work), dim3(256), lds_round, stream, udata, scans, work, ends_u, status, huff_pool,
+                               lut_pool, bufs[(round + 1) & 1], bufs[round & 1], nblk, entry_used, (int4 *)dcsum, changed_dev + round, round, n_slots,
+                               warm_bits, round >= 2 ? changed_dev + (round - 1) : nullptr);
+            const int n = round + 1;  // rounds issued so far
+            if (n < n_rounds && propagate_from > 0 && n >= propagate_from && same_dist != nullptr) {
+                // where the host's loop would have checked (and perhaps walked): decided on the device, the walk gated by it
+                hipLaunchKernelGGL(subseq_check_kernel, dim3(1), dim3(64), 0, stream, changed_dev, (uint32_t)n, few_changes, (uint32_t)propagate_from);
+                hipLaunchKernelGGL(subseq_same_kernel, dim3(n_work), dim3(256), 0, stream, udata, scans, work, ends_u, status, same_dist, changed_dev);
+                hipLaunchKernelGGL(subseq_propagate_kernel, dim3(n_scans), dim3(64), 0, stream, scans, scan_ids, same_dist, bufs[(n + 1) & 1], entry_used,
+                                   nblk, (int4 *)dcsum, changed_dev + 63, changed_dev);
+            }
+        }
+    }
+    bool converged = device_rounds > 0;
     uint32_t last_count = 0xFFFFFFFFu, count_before = 0xFFFFFFFFu;  // exits the last two rounds changed
     while (!converged && round < max_rounds) {
         const int batch_first = round;
@@ -845,7 +915,8 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
             const uint32_t *in = bufs[(round + 1) & 1];
             uint32_t *out = bufs[round & 1];
             hipLaunchKernelGGL(subseq_round_kernel, dim3(n_work), dim3(256), lds_round, stream, udata, scans, work, ends_u, status, huff_pool,
-                               lut_pool, in, out, nblk, entry_used, (int4 *)dcsum, changed_dev + (round % 62), round, n_slots, warm_bits);
+                               lut_pool, in, out, nblk, entry_used, (int4 *)dcsum, changed_dev + (round % 62), round, n_slots, warm_bits,
+                               (const uint32_t *)nullptr);
         }
         uint32_t flags[64];
         e = hipMemcpyAsync(flags, changed_dev, sizeof flags, hipMemcpyDeviceToHost, stream);
@@ -874,16 +945,17 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
                 // (it patches the buffer the last round wrote: the next round reads that one).  Decided AFTER the check: a batch
                 // that has just converged, or is converging, does not pay for the walk (0.66 ms per 16 benchmark canvases)
                 if (!*same_valid) {
-                    hipLaunchKernelGGL(subseq_same_kernel, dim3(n_work), dim3(256), 0, stream, udata, scans, work, ends_u, status, same_dist);
+                    hipLaunchKernelGGL(subseq_same_kernel, dim3(n_work), dim3(256), 0, stream, udata, scans, work, ends_u, status, same_dist,
+                                       (const uint32_t *)nullptr);
                     *same_valid = true;
                 }
                 hipLaunchKernelGGL(subseq_propagate_kernel, dim3(n_scans), dim3(64), 0, stream, scans, scan_ids, same_dist, bufs[(round + 1) & 1], entry_used,
-                                   nblk, (int4 *)dcsum, changed_dev + 63);
+                                   nblk, (int4 *)dcsum, changed_dev + 63, (uint32_t *)nullptr);
             }
         }
     }
-    if (rounds_used) *rounds_used = round;
-    *final_state_out = bufs[(round + 1) & 1];  // buffer written by the last round executed
+    if (rounds_used && device_rounds <= 0) *rounds_used = round;
+    *final_state_out = bufs[(round + 1) & 1];  // buffer written by the last round executed (device-driven: both hold the converged states)
     hipLaunchKernelGGL(subseq_scan_kernel, dim3(n_scans), dim3(1024), 0, stream, scans, scan_ids, nblk, first_block, (const int4 *)dcsum,
                        (int4 *)dc_entry);
     return hipGetLastError();
@@ -894,12 +966,12 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
                                 int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work,
-                                uint32_t *same_dist, bool *same_valid) {
+                                uint32_t *same_dist, bool *same_valid, int device_rounds) {
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const uint32_t *final_state = nullptr;
     hipError_t e = launch_subseq_sync(stream, udata, scans, work, n_work, scan_ids, n_scans, ends_u, status, huff_pool, exit_a, exit_b, nblk,
                                       first_block, entry_used, dcsum, dc_entry, changed_dev, n_slots, max_rounds, rounds_used, lut_pool,
-                                      &final_state, same_dist, same_valid);
+                                      &final_state, same_dist, same_valid, device_rounds);
     if (e != hipSuccess) return e;
     const int waves = subseq_final_waves(n_slots);
     const size_t lds_final = (size_t)n_slots * kK2TabBytes + (size_t)waves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);

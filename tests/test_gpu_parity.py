@@ -402,6 +402,42 @@ def test_dri0_uses_self_synchronising_decoder():
     assert _status_of_gpu(cut)[0] == _status_of_oracle(cut) != "OK"
 
 
+def test_dri0_rounds_are_enqueued_ahead_and_checked_when_the_caller_waits(monkeypatch):
+    """Round 5: jpgpu_batch_decode does not wait for anything on a DRI = 0 batch.  The K2S rounds are enqueued ahead (16 the
+    first time, then as many as the upload's last decode used), a round behind the converged one leaves at once, and sync()
+    reads whether they sufficed; if not, it issues the step again with the host reading the counts between rounds.
+    Same coefficients and samples either way (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:99-134, 179-222)."""
+    files = [jpegsynth.encode(1024, 768, "420", 75, 0, seed=77 + i) for i in range(3)] + [jpegsynth.encode(640, 368, "420", 75, 4, seed=5),
+                                                                                      jpegsynth.encode(416, 240, "444", 90, 0, seed=6)]
+    refs = [po.decode_8bit(f)[0] for f in files]
+    b = jl.Batch().upload(files, jl.FMT_INTERLEAVED_U8).decode().decode().sync()  # two decodes in flight, one check
+    rounds = b.subseq_rounds()
+    assert 2 <= rounds <= 16 and b.subseq_fallbacks() == 0, (rounds, b.subseq_fallbacks())
+    for i, r in enumerate(refs):
+        assert b.result(i).status == 0 and np.array_equal(b.output(i), r), i
+    b.decode().sync()  # the learned budget: exactly `rounds` rounds, the last of them the one that changes nothing
+    assert b.subseq_rounds() == rounds and b.subseq_fallbacks() == 0
+    for i, r in enumerate(refs):
+        assert np.array_equal(b.output(i), r), i
+    # a budget that cannot suffice: noticed at the sync, the step repeated with host-checked rounds, the upload stays that way
+    monkeypatch.setenv("JPGPU_SUBSEQ_BUDGET", "2")
+    b2 = jl.Batch().upload(files, jl.FMT_INTERLEAVED_U8).decode().sync()
+    assert b2.subseq_fallbacks() == 1 and b2.subseq_rounds() >= rounds
+    for i, r in enumerate(refs):
+        assert b2.result(i).status == 0 and np.array_equal(b2.output(i), r), i
+    b2.decode().sync()
+    assert b2.subseq_fallbacks() == 1
+    assert np.array_equal(b2.output(0), refs[0])
+    # ... the entropy stage alone, and the output stage issued behind it without a sync in between
+    b3 = jl.Batch().upload(files, jl.FMT_PLANAR_I16).run_entropy().sync()
+    assert b3.subseq_fallbacks() == 1
+    assert np.array_equal(b3.coefficients(0), po.decode_coefficients(files[0])[0])
+    b4 = jl.Batch().upload(files, jl.FMT_INTERLEAVED_U8).run_entropy().run_idct().sync()
+    assert b4.subseq_fallbacks() == 1
+    for i, r in enumerate(refs):
+        assert np.array_equal(b4.output(i), r), i
+
+
 def test_full_size_properties_4k():
     """BASELINE config-2 geometry at full size: every image of a small 4K batch is bit-exact vs the oracle, and the
     DRI=4 and DRI=0 encodings of the same pixels decode to identical output (restart markers carry no information)."""
