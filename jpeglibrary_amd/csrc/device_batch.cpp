@@ -1458,10 +1458,44 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     n_huff_work_ = (int)huff_work.size();
     n_chunk_work_ = (int)chunk_work.size();
     n_sub_work_ = (int)sub_work.size();
-    std::vector<HuffWork> sub_final_work;  // the final pass takes larger workgroups than the rounds (kernels.h: subseq_final_waves)
+    // ... and the list of the rounds behind round 1 (a workgroup per kSubseqGatherSpan subsequences), behind it in the same buffer
     for (uint32_t j : sub_scan_ids_)
-        for (uint32_t first = 0; first < h_scans_[j].n_subs; first += 64u * (uint32_t)subseq_final_waves(n_huff_slots_) * (uint32_t)kSubFinalSubsPerLane) sub_final_work.push_back({j, first});
-    n_sub_final_work_ = (int)sub_final_work.size();
+        for (uint32_t first = 0; first < h_scans_[j].n_subs; first += kSubseqGatherSpan) sub_work.push_back({j, first});
+    n_sub_gather_ = (int)sub_work.size() - n_sub_work_;
+    // The final pass.  Runs of consecutive scans that stage the same tables in the same slots (all of a batch of files from one
+    // encoder, typically) are POOLED: one entry per wave of 64 lanes, taken from a counter by the waves of one workgroup per CU
+    // (k2s_subseq.hip).  Everything else takes a workgroup per subseq_final_waves() waves of one scan.
+    std::vector<HuffWork> sub_final_work;
+    sub_pools_.clear();
+    {
+        const bool no_pool = getenv("JPGPU_SF_NO_POOL") != nullptr || n_huff_slots_ > 4;  // (A/B switch; ten waves + more than four tables do not fit a CU)
+        auto same_tables = [&](const DevScan &a, const DevScan &b) {
+            return memcmp(a.huff_pool, b.huff_pool, sizeof a.huff_pool) == 0 && a.scan_components == b.scan_components &&
+                   a.blocks_per_mcu == b.blocks_per_mcu && memcmp(a.blk_comp, b.blk_comp, sizeof a.blk_comp) == 0 &&
+                   memcmp(a.comp, b.comp, sizeof a.comp) == 0;
+        };
+        const uint32_t lanes_subs = 64u * (uint32_t)kSubFinalSubsPerLane;
+        std::vector<HuffWork> pooled;
+        size_t i = 0;
+        while (i < sub_scan_ids_.size()) {
+            size_t k = i + 1;
+            uint64_t waves = (h_scans_[sub_scan_ids_[i]].n_subs + lanes_subs - 1) / lanes_subs;
+            while (k < sub_scan_ids_.size() && same_tables(h_scans_[sub_scan_ids_[i]], h_scans_[sub_scan_ids_[k]])) {
+                waves += (h_scans_[sub_scan_ids_[k]].n_subs + lanes_subs - 1) / lanes_subs;
+                k++;
+            }
+            const bool pool = !no_pool && waves >= (uint64_t)kSubFinalPoolMinChunks && (int)sub_pools_.size() < kSubFinalMaxPools && waves < 0x7FFFFFFFu;
+            if (pool) sub_pools_.push_back({(int)pooled.size(), (int)waves});
+            for (size_t q = i; q < k; q++) {
+                const uint32_t j = sub_scan_ids_[q];
+                const uint32_t step = pool ? lanes_subs : lanes_subs * (uint32_t)subseq_final_waves(n_huff_slots_);
+                for (uint32_t first = 0; first < h_scans_[j].n_subs; first += step) (pool ? pooled : sub_final_work).push_back({j, first});
+            }
+            i = k;
+        }
+        n_sub_final_work_ = (int)sub_final_work.size();
+        sub_final_work.insert(sub_final_work.end(), pooled.begin(), pooled.end());  // (one buffer: the pooled list behind the plain one)
+    }
     n_sub_scans_ = (int)sub_scan_ids_.size();
     std::vector<HuffWork> prog_work;
     prog_begin_.assign(1, 0);
@@ -1717,7 +1751,8 @@ int DeviceBatch::run_huffman() {
                                  (uint32_t *)d_sub_exit_b_.ptr, (uint32_t *)d_sub_nblk_.ptr, (uint32_t *)d_sub_first_.ptr,
                                  (uint32_t *)d_sub_entry_.ptr, d_sub_dcsum_.ptr, d_sub_dcentry_.ptr, (uint32_t *)d_sub_changed_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, max_rounds,
                                  &last_subseq_rounds_, (const uint8_t *)d_lut_pool_.ptr, (const HuffWork *)d_sub_final_work_.ptr, n_sub_final_work_,
-                                 (uint32_t *)d_sub_same_.ptr, &sub_same_valid_, device_rounds);
+                                 (uint32_t *)d_sub_same_.ptr, &sub_same_valid_, device_rounds, (const HuffWork *)d_sub_work_.ptr + n_sub_work_, n_sub_gather_,
+                                 (const HuffWork *)d_sub_final_work_.ptr + n_sub_final_work_, sub_pools_.data(), (int)sub_pools_.size(), ctx_->num_cus);
         if (e != hipSuccess) return hip_fail(e, "subsequence decode");
     }
     const int rc = run_progressive();
@@ -1735,7 +1770,8 @@ int DeviceBatch::run_subseq_sync(const uint32_t **final_state, const uint32_t **
                                       (uint32_t *)d_sub_exit_b_.ptr, (uint32_t *)d_sub_nblk_.ptr, (uint32_t *)d_sub_first_.ptr,
                                       (uint32_t *)d_sub_entry_.ptr, d_sub_dcsum_.ptr, d_sub_dcentry_.ptr, (uint32_t *)d_sub_changed_.ptr,
                                       n_huff_slots_, (int)max_subs_per_scan_ + 2, &last_subseq_rounds_, (const uint8_t *)d_lut_pool_.ptr,
-                                      final_state, (uint32_t *)d_sub_same_.ptr, &sub_same_valid_, 0 /* host-checked: the optimizer waits for the host's table build anyway */);
+                                      final_state, (uint32_t *)d_sub_same_.ptr, &sub_same_valid_, 0 /* host-checked: the optimizer waits for the host's table build anyway */,
+                                      (const HuffWork *)d_sub_work_.ptr + n_sub_work_, n_sub_gather_);
     if (e != hipSuccess) return hip_fail(e, "subsequence synchronisation");
     return mark_work();
 }

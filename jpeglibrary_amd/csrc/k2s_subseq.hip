@@ -258,80 +258,14 @@ __device__ __forceinline__ uint32_t sr_entry(const uint16_t *l1, uint32_t i, boo
     return n | ((adv == 63u ? 64u : adv) << 6);
 }
 
-__global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
-                                                            const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
-                                                            const DevScanStatus *__restrict__ status, const DevHuffTable *__restrict__ huff_pool,
-                                                            const uint8_t *__restrict__ lut_pool,
-                                                            const uint32_t *__restrict__ exit_in, uint32_t *__restrict__ exit_out,
-                                                            uint32_t *__restrict__ nblk_out, uint32_t *__restrict__ entry_used,
-                                                            int4 *__restrict__ dcsum_out, uint32_t *__restrict__ changed, int round,
-                                                            int n_slots, uint32_t warm_bits, const uint32_t *__restrict__ prev_changed) {
-    constexpr int LB = kSrLutBits;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // Device-side convergence (round 5): the rounds are enqueued ahead without the host looking at anything; once a round
-    // (other than round 0) has changed no exit state, every later round is a no-op -- and leaves at once.  Both exit buffers
-    // hold the same states then (a round writes every slot, changed or not), so whoever reads "the last one" may read either.
-    if (prev_changed != nullptr && *prev_changed == 0) return;
-    // LDS: lookups (n_slots << (LB + 2), at offset 0) | small arrays | block info [kMaxBlocksPerMcu] x 16 | rings | DC sums
-    // (small_off is relative to smem; info_off, rings_off, dcs_off and what derives from them are absolute LDS addresses)
-    const uint32_t lut0 = sr_lds_addr(smem);
-    const uint32_t small_off = (uint32_t)n_slots << (LB + 2);
-    const uint32_t info_off = lut0 + small_off + (uint32_t)n_slots * kK2SmallBytes;
-    const uint32_t rings_off = info_off + kMaxBlocksPerMcu * 16u;
-    const uint32_t dcs_off = rings_off + 256u * kSrRingStride;
-    uint32_t *pool_off = reinterpret_cast<uint32_t *>(smem + (dcs_off - lut0) + 256u * 16u);  // [kMaxHuffSlots]: byte offset of the slot's pooled image
-    const HuffWork wk = work[blockIdx.x];  // first_interval holds the first subsequence of this workgroup
-    const DevScan &s = scans[wk.scan];
-    const DevScanStatus st = status[wk.scan];
-    if (st.n_ends == 0) return;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t ulen = ends_u[s.ends_off];  // DRI = 0: interval 0 starts at 0
-    const uint32_t total_bits = ulen * 8;
-    const uint32_t sub = wk.first_interval + tid;
-    const bool in_range = sub < s.n_subs;
-    const uint32_t slot = s.sub_off + (in_range ? sub : 0);
-    uint32_t entry = 0;  // start of a block of the first component, no overshoot
-    if (in_range && sub > 0 && round > 0) {
-        const uint32_t prev = exit_in[slot - 1];
-        if (!(prev & kSubBad)) entry = prev;
-    }
-    // a lane whose entry state did not change since it last decoded keeps its exit state (and block count);
-    // a workgroup with no lane left to decode leaves before staging anything (most workgroups after round 1)
-    const bool need = in_range && !(round > 0 && (sub == 0 || entry_used[slot] == entry));
-    if (in_range && !need) exit_out[slot] = exit_in[slot];
-    if (!__syncthreads_or(need ? 1 : 0)) return;
-
-    // ---- stage: lookups, the reference's small arrays (long codes), block info
-    for (int sl = 0; sl < kMaxHuffSlots && sl < n_slots; sl++) {
-        const uint32_t pi = s.huff_pool[sl];
-        if (pi == 0xFFFF) continue;
-        bool is_dc = false;
-        for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
-        const uint16_t *src = reinterpret_cast<const uint16_t *>(lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * kK2TabBytes);
-        if (tid == 0) pool_off[sl] = (uint32_t)(((size_t)pi * 2 + (is_dc ? 1 : 0)) * kK2TabBytes);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(smem) + ((size_t)sl << LB);
-        for (uint32_t i = tid; i < (1u << LB); i += 256) dst[i] = sr_entry<LB>(src, i, is_dc);
-        const uint4 *ssrc = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&huff_pool[pi]) + offsetof(DevHuffTable, maxcode));
-        uint4 *sdst = reinterpret_cast<uint4 *>(smem + small_off + sl * kK2SmallBytes);
-        if (tid < kK2SmallBytes / 16) sdst[tid] = ssrc[tid];
-    }
-    if (tid < kMaxBlocksPerMcu) {
-        const uint32_t ci = s.blk_comp[tid];
-        sr_st128(info_off + tid * 16u, lut0 + ((uint32_t)s.comp[ci].dc_slot << (LB + 2)), lut0 + ((uint32_t)s.comp[ci].ac_slot << (LB + 2)), (ci & 3u) * 4u, 0u);
-    }
-    const uint32_t dc_lane = dcs_off + tid * 16u;
-    sr_st128(dc_lane, 0, 0, 0, 0);
-    __syncthreads();
-    if (!need) return;
-    // ROUND 0 IS A WARM-UP.  Its entry state is a guess for every lane but the first, so all it can deliver is a plausible
-    // exit state (right when the decode re-synchronises before the subsequence ends) -- and every such lane is decoded again
-    // in round 1 anyway, from its predecessor's exit.  It therefore only decodes the LAST warm_bits bits of the subsequence:
-    // less work in round 0, more lanes to redo in rounds 2-3 (the block phase is what converges slowly: the total number of
-    // re-decodes is set by how far the nearest upstream synchronisation point is, not by round 0) -- a small net gain,
-    // 19.6 -> 19.2-19.4 ms per 1024 x 4K.  entry_used is poisoned so that round 1 decodes the lane whatever its entry turns out to be.
-    const bool warm = round == 0 && sub > 0 && warm_bits != 0 && warm_bits < (1u << s.sub_shift);
-    entry_used[slot] = warm ? 0xFFFFFFFFu : entry;
-
+// One lane's round: subsequence `sub` of scan `s` decoded (structure only) from `entry`; exit state, block count and DC sums out.
+template <int LB>
+__device__ __forceinline__ void sr_decode_lane(const uint8_t *__restrict__ udata, const DevScan &s, const uint8_t *smem, uint32_t lut0, uint32_t small_off,
+                                               uint32_t info_off, uint32_t rings_off, uint32_t dc_lane, const uint8_t *__restrict__ lut_pool,
+                                               const uint32_t *pool_off, uint32_t tid, uint32_t sub, uint32_t slot, uint32_t entry, bool warm,
+                                               uint32_t warm_bits, uint32_t total_bits, int round, const uint32_t *__restrict__ exit_in,
+                                               uint32_t *__restrict__ exit_out, uint32_t *__restrict__ nblk_out, int4 *__restrict__ dcsum_out,
+                                               uint32_t *__restrict__ changed) {
     const uint32_t bpm = s.blocks_per_mcu;
     const uint32_t end_bit = (sub + 1) << s.sub_shift;
     const uint32_t start_bit = warm ? end_bit - warm_bits : (sub << s.sub_shift) + (entry & 63u);
@@ -405,7 +339,7 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
         dcs = make_int4((int)dsum.x, (int)dsum.y, (int)dsum.z, (int)dsum.w);
     }
     {
-        // how many exits this round changed (the host's convergence test; one atomic per wave that changed anything)
+        // how many exits this round changed (the convergence test; one atomic per wave that changed anything)
         const bool ch = round == 0 || ex != exit_in[slot];
         const uint64_t m = __ballot(ch);
         if (ch && (uint32_t)__builtin_ctzll(m) == (threadIdx.x & 63u)) atomicAdd(changed, (uint32_t)__builtin_popcountll(m));
@@ -413,6 +347,140 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
     exit_out[slot] = ex;
     nblk_out[slot] = nblk;
     dcsum_out[slot] = dcs;
+}
+
+// GATHER (rounds behind round 1, round 5): a late round re-decodes the few subsequences whose entry state changed -- a tenth
+// of them in round 2, a few per thousand in round 3 -- and cost nearly as much as a full one: they sat one here, one there in
+// the waves of every workgroup, and a wave runs as long as its slowest lane whatever the other 63 do.  A workgroup now looks at
+// kSrGatherSpan subsequences (four per lane), copies the exits of the ones that stand, GATHERS the others into its lowest
+// lanes and decodes those: a tenth of the waves, dense ones, and waves without a lane leave.  (Per-scan work LISTS built by
+// the round before, tried in round 4, were slower: the lists' atomics and a second launch shape; here nothing leaves the
+// workgroup.)  1.46 + 0.73 + 0.20 + 0.14 ms per 1024 x 4K for rounds 2-5 before.
+constexpr uint32_t kSrGatherSpan = kSubseqGatherSpan;
+template <bool GATHER>
+__global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+                                                            const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
+                                                            const DevScanStatus *__restrict__ status, const DevHuffTable *__restrict__ huff_pool,
+                                                            const uint8_t *__restrict__ lut_pool,
+                                                            const uint32_t *__restrict__ exit_in, uint32_t *__restrict__ exit_out,
+                                                            uint32_t *__restrict__ nblk_out, uint32_t *__restrict__ entry_used,
+                                                            int4 *__restrict__ dcsum_out, uint32_t *__restrict__ changed, int round,
+                                                            int n_slots, uint32_t warm_bits, const uint32_t *__restrict__ prev_changed) {
+    constexpr int LB = kSrLutBits;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // Device-side convergence (round 5): the rounds are enqueued ahead without the host looking at anything; once a round
+    // (other than round 0) has changed no exit state, every later round is a no-op -- and leaves at once.  Both exit buffers
+    // hold the same states then (a round writes every slot, changed or not), so whoever reads "the last one" may read either.
+    if (prev_changed != nullptr && *prev_changed == 0) return;
+    // LDS: lookups (n_slots << (LB + 2), at offset 0) | small arrays | block info [kMaxBlocksPerMcu] x 16 | rings | DC sums
+    // (small_off is relative to smem; info_off, rings_off, dcs_off and what derives from them are absolute LDS addresses)
+    const uint32_t lut0 = sr_lds_addr(smem);
+    const uint32_t small_off = (uint32_t)n_slots << (LB + 2);
+    const uint32_t info_off = lut0 + small_off + (uint32_t)n_slots * kK2SmallBytes;
+    const uint32_t rings_off = info_off + kMaxBlocksPerMcu * 16u;
+    const uint32_t dcs_off = rings_off + 256u * kSrRingStride;
+    uint32_t *pool_off = reinterpret_cast<uint32_t *>(smem + (dcs_off - lut0) + 256u * 16u);  // [kMaxHuffSlots]: byte offset of the slot's pooled image
+    const HuffWork wk = work[blockIdx.x];  // first_interval holds the first subsequence of this workgroup
+    const DevScan &s = scans[wk.scan];
+    const DevScanStatus st = status[wk.scan];
+    if (st.n_ends == 0) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ulen = ends_u[s.ends_off];  // DRI = 0: interval 0 starts at 0
+    const uint32_t total_bits = ulen * 8;
+    // what a lane decodes from: the exit its predecessor reached in the round before (round 0, subsequence 0 and behind a
+    // failed predecessor: the start of a block of the first component, no overshoot)
+    auto entry_of = [&](uint32_t sub, uint32_t slot) -> uint32_t {
+        if (sub == 0 || round == 0) return 0u;
+        const uint32_t prev = exit_in[slot - 1];
+        return (prev & kSubBad) ? 0u : prev;
+    };
+    uint32_t sub, slot, entry = 0;
+    bool need;
+    uint32_t n_gathered = 0;  // GATHER: subsequences this workgroup decodes (uniform)
+    __shared__ uint32_t gathered[GATHER ? kSrGatherSpan : 1];
+    __shared__ uint32_t wave_cnt[4];
+    if (!GATHER) {
+        sub = wk.first_interval + tid;
+        const bool in_range = sub < s.n_subs;
+        slot = s.sub_off + (in_range ? sub : 0);
+        if (in_range) entry = entry_of(sub, slot);
+        // a lane whose entry state did not change since it last decoded keeps its exit state (and block count);
+        // a workgroup with no lane left to decode leaves before staging anything (most workgroups after round 1)
+        need = in_range && !(round > 0 && (sub == 0 || entry_used[slot] == entry));
+        if (in_range && !need) exit_out[slot] = exit_in[slot];
+        if (!__syncthreads_or(need ? 1 : 0)) return;
+    } else {
+        const uint32_t lane = tid & 63u, wave = tid >> 6;
+#pragma unroll 1
+        for (uint32_t j = 0; j < kSrGatherSpan / 256u; j++) {
+            const uint32_t sub_j = wk.first_interval + j * 256u + tid;
+            const bool in_range = sub_j < s.n_subs;
+            const uint32_t slot_j = s.sub_off + (in_range ? sub_j : 0);
+            const bool need_j = in_range && sub_j != 0 && entry_used[slot_j] != entry_of(sub_j, slot_j);
+            if (in_range && !need_j) exit_out[slot_j] = exit_in[slot_j];
+            const uint64_t m = __ballot(need_j);
+            if (lane == 0) wave_cnt[wave] = (uint32_t)__builtin_popcountll(m);
+            __syncthreads();
+            uint32_t at = n_gathered;
+            for (uint32_t w = 0; w < wave; w++) at += wave_cnt[w];
+            if (need_j) gathered[at + mbcnt64(m)] = sub_j;
+            n_gathered += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            __syncthreads();
+        }
+        if (n_gathered == 0) return;
+        sub = 0;
+        slot = s.sub_off;
+        need = false;
+    }
+
+    // ---- stage: lookups, the reference's small arrays (long codes), block info
+    for (int sl = 0; sl < kMaxHuffSlots && sl < n_slots; sl++) {
+        const uint32_t pi = s.huff_pool[sl];
+        if (pi == 0xFFFF) continue;
+        bool is_dc = false;
+        for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
+        const uint16_t *src = reinterpret_cast<const uint16_t *>(lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * kK2TabBytes);
+        if (tid == 0) pool_off[sl] = (uint32_t)(((size_t)pi * 2 + (is_dc ? 1 : 0)) * kK2TabBytes);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(smem) + ((size_t)sl << LB);
+        for (uint32_t i = tid; i < (1u << LB); i += 256) dst[i] = sr_entry<LB>(src, i, is_dc);
+        const uint4 *ssrc = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&huff_pool[pi]) + offsetof(DevHuffTable, maxcode));
+        uint4 *sdst = reinterpret_cast<uint4 *>(smem + small_off + sl * kK2SmallBytes);
+        if (tid < kK2SmallBytes / 16) sdst[tid] = ssrc[tid];
+    }
+    if (tid < kMaxBlocksPerMcu) {
+        const uint32_t ci = s.blk_comp[tid];
+        sr_st128(info_off + tid * 16u, lut0 + ((uint32_t)s.comp[ci].dc_slot << (LB + 2)), lut0 + ((uint32_t)s.comp[ci].ac_slot << (LB + 2)), (ci & 3u) * 4u, 0u);
+    }
+    const uint32_t dc_lane = dcs_off + tid * 16u;
+    sr_st128(dc_lane, 0, 0, 0, 0);
+    __syncthreads();
+    if (!GATHER) {
+        if (!need) return;
+        // ROUND 0 IS A WARM-UP.  Its entry state is a guess for every lane but the first, so all it can deliver is a plausible
+        // exit state (right when the decode re-synchronises before the subsequence ends) -- and every such lane is decoded again
+        // in round 1 anyway, from its predecessor's exit.  It therefore only decodes the LAST warm_bits bits of the subsequence:
+        // less work in round 0, more lanes to redo in rounds 2-3 (the block phase is what converges slowly: the total number of
+        // re-decodes is set by how far the nearest upstream synchronisation point is, not by round 0) -- a small net gain,
+        // 19.6 -> 19.2-19.4 ms per 1024 x 4K.  entry_used is poisoned so that round 1 decodes the lane whatever its entry turns out to be.
+        const bool warm = round == 0 && sub > 0 && warm_bits != 0 && warm_bits < (1u << s.sub_shift);
+        entry_used[slot] = warm ? 0xFFFFFFFFu : entry;
+        sr_decode_lane<LB>(udata, s, smem, lut0, small_off, info_off, rings_off, dc_lane, lut_pool, pool_off, tid, sub, slot, entry, warm, warm_bits,
+                           total_bits, round, exit_in, exit_out, nblk_out, dcsum_out, changed);
+    } else {
+#pragma unroll 1
+        for (uint32_t base = 0; base < n_gathered; base += 256u) {
+            if (base + (tid & ~63u) >= n_gathered) break;  // (waves without a lane: nothing behind this needs them)
+            if (base + tid < n_gathered) {
+                sub = gathered[base + tid];
+                slot = s.sub_off + sub;
+                entry = entry_of(sub, slot);
+                entry_used[slot] = entry;
+                if (base != 0) sr_st128(dc_lane, 0, 0, 0, 0);
+                sr_decode_lane<LB>(udata, s, smem, lut0, small_off, info_off, rings_off, dc_lane, lut_pool, pool_off, tid, sub, slot, entry, false,
+                                   warm_bits, total_bits, round, exit_in, exit_out, nblk_out, dcsum_out, changed);
+            }
+        }
+    }
 }
 // (Earlier forms: the word reader with the symbol step as per-lane branches, 1.9 ms per round on average at 1024 x 4K; K2's
 // 68-byte ring with a top-up per block, round 2: 2.45 ms -- the rings halved the occupancy; the word reader with its refill load
@@ -652,42 +720,20 @@ __global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__rest
 // (First version: the generic word reader and symbol decoder, 11.0 ms per 1024 x 4K against K2's 5.7.  Second, rounds 2-3:
 // K2's ring and symbol step with BLOCK-aligned ownership -- lanes at different blocks of their MCUs, so the tables were
 // picked per lane and a lock-step iteration mixed long luma with short chroma blocks: 8.3 ms.)
-constexpr int kSubFinalMaxWaves = JPGPU_SF_WAVES > 4 ? JPGPU_SF_WAVES : 4;  // the launch picks subseq_final_waves(n_slots)
+constexpr int kSubFinalMaxWaves = JPGPU_SF_WAVES > kSubFinalPoolWaves ? JPGPU_SF_WAVES : kSubFinalPoolWaves;  // the launch picks subseq_final_waves(n_slots) / the pool's
 constexpr int kSfWaveBytes = kK2WaveBytes + 64 * 2 * (int)sizeof(uint32_t);  // K2's staging + rings, then (first MCU, count) per lane
-__global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
-                                                                           const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
-                                                                           DevScanStatus *__restrict__ status,
-                                                                           const DevHuffTable *__restrict__ huff_pool,
-                                                                           const uint8_t *__restrict__ lut_pool,
-                                                                           const uint32_t *__restrict__ exit_state,
-                                                                           const uint32_t *__restrict__ first_block,
-                                                                           const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs,
-                                                                           int n_slots) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t n_waves = blockDim.x >> 6;
-    uint8_t *tabs = smem;                                                    // n_slots * kK2TabBytes
-    uint8_t *wave_all = smem + (size_t)n_slots * kK2TabBytes;                // n_waves * kSfWaveBytes
-    uint32_t *blk_info = reinterpret_cast<uint32_t *>(wave_all + n_waves * kSfWaveBytes);  // [kMaxBlocksPerMcu]
-    const HuffWork wk = work[blockIdx.x];
-    const DevScan &s = scans[wk.scan];
-    const DevScanStatus st = status[wk.scan];
-    if (st.n_ends == 0) return;
-    k2_stage_scan_tables(s, lut_pool, tabs, blk_info, n_slots, blockDim.x);
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint8_t *stage = wave_all + wave * kSfWaveBytes;
-    uint8_t *ring = stage + 8192 + lane * kK2RingStride;
-    uint32_t *meta = reinterpret_cast<uint32_t *>(stage + kK2WaveBytes);
-    {
-        const uint4 z = {0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(stage)[i * 64 + lane] = z;
-    }
-    __syncthreads();
+// One wave's 64 lanes: subsequences wk.first_interval + lane * kSubFinalSubsPerLane .. of scan wk.scan (tables staged, the wave's
+// coefficient staging zero on entry and on exit).
+__device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const DevScan &s, const DevScanStatus &st, const HuffWork wk,
+                                        const uint32_t *__restrict__ ends_u, DevScanStatus *__restrict__ status,
+                                        const uint32_t *__restrict__ exit_state, const uint32_t *__restrict__ first_block,
+                                        const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs, const uint8_t *tabs,
+                                        const uint32_t *blk_info, uint8_t *stage, uint8_t *ring, uint32_t *meta, uint32_t lane) {
     const uint32_t ulen = ends_u[s.ends_off];
     const uint32_t total_bits = ulen * 8;
     // a lane takes kSubFinalSubsPerLane consecutive subsequences: half the lanes, but half the parsed-not-stored blocks and a
     // narrower spread of MCU counts inside a wave (the wave iterates to its largest)
-    const uint32_t sub = wk.first_interval + tid * (uint32_t)kSubFinalSubsPerLane;
+    const uint32_t sub = wk.first_interval + lane * (uint32_t)kSubFinalSubsPerLane;  // (wk: the WAVE's 64 lanes)
     const uint32_t slot = s.sub_off + (sub < s.n_subs ? sub : 0);
     const uint32_t total_mcus = s.total_mcus;
     const uint32_t bpm = s.blocks_per_mcu;
@@ -848,6 +894,57 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
     }
 }
 
+// POOL (round 5).  The pass is K2 with fewer waves per CU: a workgroup of the plain form is four waves of one scan (two
+// workgroups, eight waves per CU; K2 has eleven), because a workgroup waits for its slowest wave and the waves of this pass
+// own different numbers of MCUs -- one workgroup of ten waves was measured slower (21.1 vs 19.6 ms K2S per 1024 x 4K).  Where many
+// consecutive scans stage the same tables (every batch of files from one encoder with the standard tables), the waves need not
+// be tied to a scan: one workgroup of kSubFinalPoolWaves waves per CU stages the tables once and every WAVE takes the next 64
+// lanes of the run from a counter until there are none -- no wave waits for another, and nothing is restaged.
+template <bool POOL>
+__global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+                                                                           const HuffWork *__restrict__ work, const uint32_t *__restrict__ ends_u,
+                                                                           DevScanStatus *__restrict__ status,
+                                                                           const DevHuffTable *__restrict__ huff_pool,
+                                                                           const uint8_t *__restrict__ lut_pool,
+                                                                           const uint32_t *__restrict__ exit_state,
+                                                                           const uint32_t *__restrict__ first_block,
+                                                                           const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs,
+                                                                           int n_slots, uint32_t n_chunks, uint32_t *__restrict__ counter) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t n_waves = blockDim.x >> 6;
+    uint8_t *tabs = smem;                                                    // n_slots * kK2TabBytes
+    uint8_t *wave_all = smem + (size_t)n_slots * kK2TabBytes;                // n_waves * kSfWaveBytes
+    uint32_t *blk_info = reinterpret_cast<uint32_t *>(wave_all + n_waves * kSfWaveBytes);  // [kMaxBlocksPerMcu]
+    const HuffWork wk0 = work[POOL ? 0u : blockIdx.x];  // POOL: `work` lists the run's waves (scan, first subsequence), all with one set of tables
+    if (!POOL && status[wk0.scan].n_ends == 0) return;
+    k2_stage_scan_tables(scans[wk0.scan], lut_pool, tabs, blk_info, n_slots, blockDim.x);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint8_t *stage = wave_all + wave * kSfWaveBytes;
+    uint8_t *ring = stage + 8192 + lane * kK2RingStride;
+    uint32_t *meta = reinterpret_cast<uint32_t *>(stage + kK2WaveBytes);
+    {
+        const uint4 z = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(stage)[i * 64 + lane] = z;
+    }
+    __syncthreads();
+    if (!POOL) {
+        const HuffWork wk = {wk0.scan, wk0.first_interval + wave * 64u * (uint32_t)kSubFinalSubsPerLane};
+        sf_wave(udata, scans[wk.scan], status[wk.scan], wk, ends_u, status, exit_state, first_block, dc_entry, coefs, tabs, blk_info, stage, ring, meta, lane);
+    } else {
+        for (;;) {
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(counter, 1u);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+            if (c >= n_chunks) break;
+            const HuffWork wk = work[c];
+            const DevScanStatus st = status[wk.scan];
+            if (st.n_ends == 0) continue;
+            sf_wave(udata, scans[wk.scan], st, wk, ends_u, status, exit_state, first_block, dc_entry, coefs, tabs, blk_info, stage, ring, meta, lane);
+        }
+    }
+}
+
 
 // DRI = 0 scans: self-synchronising subsequence decode.  `work` lists (scan, first subsequence) per workgroup of 256 lanes;
 // `scan_ids` the scans concerned.  The synchronisation part alone (rounds until the exit states stop changing, then the block /
@@ -867,7 +964,7 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
                               const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                               uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int n_slots, int max_rounds,
                               int *rounds_used, const uint8_t *lut_pool, const uint32_t **final_state_out, uint32_t *same_dist,
-                              bool *same_valid, int device_rounds) {
+                              bool *same_valid, int device_rounds, const HuffWork *gather_work, int n_gather) {
     *final_state_out = exit_a;
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const size_t lds_round = ((size_t)n_slots << (kSrLutBits + 2)) + (size_t)n_slots * kK2SmallBytes + kMaxBlocksPerMcu * 16 + 256 * (kSrRingStride + 16) +
@@ -889,13 +986,21 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
     const uint32_t few_changes = 8u * (uint32_t)n_scans;
     hipError_t e = hipMemsetAsync(changed_dev, 0, (device_rounds > 0 ? (size_t)kSubCtlPerDecode : 64) * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
+    // round r reads the exits round r - 1 wrote; rounds behind round 1 gather their few lanes (subseq_round_kernel<true>)
+    static const bool no_gather = getenv("JPGPU_SUBSEQ_NO_GATHER") != nullptr;  // A/B switch
+    auto launch_round = [&](int r, uint32_t *count, const uint32_t *prev) {
+        if (r >= 2 && gather_work != nullptr && n_gather > 0 && !no_gather)
+            hipLaunchKernelGGL(subseq_round_kernel<true>, dim3(n_gather), dim3(256), lds_round, stream, udata, scans, gather_work, ends_u, status, huff_pool,
+                               lut_pool, bufs[(r + 1) & 1], bufs[r & 1], nblk, entry_used, (int4 *)dcsum, count, r, n_slots, warm_bits, prev);
+        else
+            hipLaunchKernelGGL(subseq_round_kernel<false>, dim3(n_work), dim3(256), lds_round, stream, udata, scans, work, ends_u, status, huff_pool,
+                               lut_pool, bufs[(r + 1) & 1], bufs[r & 1], nblk, entry_used, (int4 *)dcsum, count, r, n_slots, warm_bits, prev);
+    };
     int round = 0;
     if (device_rounds > 0) {
         const int n_rounds = device_rounds < 62 ? device_rounds : 61;
         for (; round < n_rounds; round++) {
-            hipLaunchKernelGGL(subseq_round_kernel, dim3(n_work), dim3(256), lds_round, stream, udata, scans, work, ends_u, status, huff_pool,
-                               lut_pool, bufs[(round + 1) & 1], bufs[round & 1], nblk, entry_used, (int4 *)dcsum, changed_dev + round, round, n_slots,
-                               warm_bits, round >= 2 ? changed_dev + (round - 1) : nullptr);
+            launch_round(round, changed_dev + round, round >= 2 ? changed_dev + (round - 1) : nullptr);
             const int n = round + 1;  // rounds issued so far
             if (n < n_rounds && propagate_from > 0 && n >= propagate_from && same_dist != nullptr) {
                 // where the host's loop would have checked (and perhaps walked): decided on the device, the walk gated by it
@@ -912,11 +1017,7 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
         const int batch_first = round;
         const int batch = last_count <= few_changes ? 1 : kCheckEvery;
         for (int i = 0; i < batch && round < max_rounds; i++, round++) {
-            const uint32_t *in = bufs[(round + 1) & 1];
-            uint32_t *out = bufs[round & 1];
-            hipLaunchKernelGGL(subseq_round_kernel, dim3(n_work), dim3(256), lds_round, stream, udata, scans, work, ends_u, status, huff_pool,
-                               lut_pool, in, out, nblk, entry_used, (int4 *)dcsum, changed_dev + (round % 62), round, n_slots, warm_bits,
-                               (const uint32_t *)nullptr);
+            launch_round(round, changed_dev + (round % 62), nullptr);
         }
         uint32_t flags[64];
         e = hipMemcpyAsync(flags, changed_dev, sizeof flags, hipMemcpyDeviceToHost, stream);
@@ -966,21 +1067,40 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
                                 int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work,
-                                uint32_t *same_dist, bool *same_valid, int device_rounds) {
+                                uint32_t *same_dist, bool *same_valid, int device_rounds, const HuffWork *gather_work, int n_gather,
+                                const HuffWork *pool_work, const SubseqPool *pools, int n_pools, int num_cus) {
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const uint32_t *final_state = nullptr;
     hipError_t e = launch_subseq_sync(stream, udata, scans, work, n_work, scan_ids, n_scans, ends_u, status, huff_pool, exit_a, exit_b, nblk,
                                       first_block, entry_used, dcsum, dc_entry, changed_dev, n_slots, max_rounds, rounds_used, lut_pool,
-                                      &final_state, same_dist, same_valid, device_rounds);
+                                      &final_state, same_dist, same_valid, device_rounds, gather_work, n_gather);
     if (e != hipSuccess) return e;
-    const int waves = subseq_final_waves(n_slots);
-    const size_t lds_final = (size_t)n_slots * kK2TabBytes + (size_t)waves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
-    static std::atomic<uint64_t> configured{0};
-    const hipError_t ea = allow_dynamic_lds(reinterpret_cast<const void *>(&subseq_final_kernel), 160 * 1024, configured);
-    if (ea != hipSuccess) return ea;
-    // final_work: (scan, first subsequence) per workgroup of waves * 64 lanes (the rounds' work list is per 256)
-    hipLaunchKernelGGL(subseq_final_kernel, dim3(n_final_work), dim3(64 * waves), lds_final, stream, udata, scans, final_work, ends_u, status,
-                       huff_pool, lut_pool, final_state, first_block, (const int4 *)dc_entry, coefs, n_slots);
+    static std::atomic<uint64_t> configured{0}, configured_pool{0};
+    if (n_final_work > 0) {
+        const int waves = subseq_final_waves(n_slots);
+        const size_t lds_final = (size_t)n_slots * kK2TabBytes + (size_t)waves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
+        const hipError_t ea = allow_dynamic_lds(reinterpret_cast<const void *>(&subseq_final_kernel<false>), 160 * 1024, configured);
+        if (ea != hipSuccess) return ea;
+        // final_work: (scan, first subsequence) per workgroup of waves * 64 lanes (the rounds' work list is per 256)
+        hipLaunchKernelGGL(subseq_final_kernel<false>, dim3(n_final_work), dim3(64 * waves), lds_final, stream, udata, scans, final_work, ends_u, status,
+                           huff_pool, lut_pool, final_state, first_block, (const int4 *)dc_entry, coefs, n_slots, 0u, (uint32_t *)nullptr);
+    }
+    if (n_pools > 0) {
+        // (the counters live in the control words every launch_subseq_sync clears; a host-checked launch clears the first 64 only)
+        if (device_rounds <= 0) {
+            e = hipMemsetAsync(changed_dev + kSubseqCtlPoolCounter, 0, kSubFinalMaxPools * sizeof(uint32_t), stream);
+            if (e != hipSuccess) return e;
+        }
+        const size_t lds_pool = (size_t)n_slots * kK2TabBytes + (size_t)kSubFinalPoolWaves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
+        const hipError_t ea = allow_dynamic_lds(reinterpret_cast<const void *>(&subseq_final_kernel<true>), 160 * 1024, configured_pool);
+        if (ea != hipSuccess) return ea;
+        for (int p = 0; p < n_pools; p++) {
+            const int groups = std::min(num_cus > 0 ? num_cus : 256, (pools[p].count + kSubFinalPoolWaves - 1) / kSubFinalPoolWaves);
+            hipLaunchKernelGGL(subseq_final_kernel<true>, dim3(groups), dim3(64 * kSubFinalPoolWaves), lds_pool, stream, udata, scans,
+                               pool_work + pools[p].first, ends_u, status, huff_pool, lut_pool, final_state, first_block, (const int4 *)dc_entry, coefs,
+                               n_slots, (uint32_t)pools[p].count, changed_dev + kSubseqCtlPoolCounter + p);
+        }
+    }
     return hipGetLastError();
 }
 

@@ -43,6 +43,14 @@ hipError_t launch_idct(hipStream_t stream, const int16_t *coefs, const DevScan *
 hipError_t launch_dispose_pass(hipStream_t stream, int16_t *coefs, const DisposeJob *jobs, int n_jobs, uint32_t max_blocks, const DevQuantTable *quant_pool);
 hipError_t launch_ycc_to_rgb(hipStream_t stream, const uint8_t *src, uint8_t *dst, uint64_t n_pixels, int comps, int bpp, const YccRgbFactors &kf);
 
+// Waves per workgroup of the POOLED form of the K2S final pass (k2s_subseq.hip: runs of scans that stage the same tables; one workgroup per CU, every wave takes the
+// next 64 lanes from a counter): 10 waves + 4 tables fill a CU's LDS.  Runs shorter than kSubFinalPoolMinChunks waves, and runs
+// beyond the kSubFinalMaxPools-th, take the plain form.
+constexpr int kSubFinalPoolWaves = 10, kSubFinalPoolMinChunks = 40, kSubFinalMaxPools = 8;
+constexpr int kSubseqCtlPoolCounter = 72;  // changed_dev words [72, 72 + kSubFinalMaxPools): the pools' counters (cleared by every launch)
+struct SubseqPool {
+    int first, count;  // entries of the pooled work list (one per wave of 64 lanes)
+};
 // DRI = 0 scans (K2S): self-synchronising subsequence decode into the coefficient buffer (device_rounds: see launch_subseq_sync).
 constexpr uint32_t kSubseqBits = 1024;  // smallest subsequence (DevScan::sub_shift = 10); large batches use 2048 / 4096 bits
 hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
@@ -50,10 +58,12 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
                                 int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work,
-                                uint32_t *same_dist, bool *same_valid, int device_rounds);
+                                uint32_t *same_dist, bool *same_valid, int device_rounds, const HuffWork *gather_work, int n_gather,
+                                const HuffWork *pool_work, const SubseqPool *pools, int n_pools, int num_cus);
 // changed_dev: kSubseqCtlWords uint32 (exits changed per round, the device-driven rounds' state; word kSubseqCtlSameDone is
 // cleared once per upload, the rest by every launch).  device_rounds > 0: that many rounds enqueued, nothing read back, the
 // caller checks changed_dev when it next waits for the stream (k2s_subseq.hip); 0: the host checks between rounds.
+constexpr uint32_t kSubseqGatherSpan = 1024;
 constexpr int kSubseqCtlWords = 128, kSubseqCtlSameDone = 96, kSubseqFirstBudget = 16;
 // waves (of 64 subsequences) per workgroup of the K2S final pass.  4 = two workgroups per CU; one workgroup of 10 waves (K2's
 // shape, 25 % more waves per CU) was measured slower: 21.1 vs 19.6 ms K2S per 1024 x 4K -- a workgroup waits for its slowest wave
@@ -101,7 +111,8 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
                               const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                               uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int n_slots, int max_rounds,
                               int *rounds_used, const uint8_t *lut_pool, const uint32_t **final_state_out, uint32_t *same_dist, bool *same_valid,
-                              int device_rounds);
+                              int device_rounds, const HuffWork *gather_work, int n_gather);
+// gather_work: (scan, first subsequence) per kSubseqGatherSpan subsequences -- the work list of the rounds behind round 1
 // (same_dist: one uint32 per subsequence, *same_valid: "filled for this upload" -- the flat-region twins, k2s_subseq.hip)
 hipError_t launch_subseq_transcode(hipStream_t stream, int mode, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,
                                    const uint32_t *ends_u, DevScanStatus *status, const DevHuffTable *huff_pool, const uint32_t *exit_state,
