@@ -71,3 +71,23 @@ def test_two_rank_sharding_and_aggregation():
     assert sorted(idx0 + idx1) == list(range(10)) and set(idx0).isdisjoint(idx1)
     assert emax0 == emax1 == 1.5
     assert v0 == v1 == pytest.approx(3 * 64 * 48 * 2 * 2 / 1.5 / 1e6)
+
+
+def test_bench_launches_its_own_ranks_when_started_without_torchrun():
+    """`python bench.py --gpus 2` (the form the driver uses for --gpus 1) used to measure ONE GPU and print n_gpus: 1 when no
+    torchrun had set WORLD_SIZE.  It now starts `python -m torch.distributed.run --nproc-per-node 2 bench.py ...` as a child before
+    touching any device and relays rank 0's line.  --dry-run keeps the launch's plumbing (rendezvous, barrier, MAX-reduce of the
+    slowest rank's time, one line from rank 0) and leaves the device work out, which is all a box without GPUs can run."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--dry-run"], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["value"] is None
+    assert out["slowest_rank_s"] == 0.75  # rank 1 pretends to be the slower one: the MAX over the ranks
+    assert "self-spawned" in out["launch"]
