@@ -100,9 +100,15 @@ struct alignas(16) DevScan {
     uint32_t dep[3];           // pipelined launch: scan jobs this scan follows (kNoDep = none), see progressive_stream_kernel
     uint32_t last_interval;    // progressive_scan_kernel: restart intervals behind this one are not decoded (0xFFFFFFFF: all; the
                                // replay of a failed file stops where the reference threw)
-    uint32_t pad2[3];
+    uint32_t first_scan;       // sequential scans: the image's first scan job (K3: a scan behind a failed one was never started)
+    uint32_t pad2[2];
 };
 constexpr uint32_t kNoDep = 0xFFFFFFFFu;
+// Sequential scans: DevScanStatus::pad[1] = kFailBlockBase - (index, in scan order, of the block the reference threw in), 0 = the
+// scan did not fail.  Written with atomicMax by the Huffman kernels (the LOWEST failing block wins), read by K3: the reference
+// has called WriteBlock for every block in front of it and for none behind it (JpegHuffmanBaselineScanDecoder.cs:99-134, 153).
+constexpr uint32_t kFailBlockBase = 0xFFFFFFFFu;
+constexpr uint32_t kIdctPartialMcu = 0xFFFFFFFFu;  // IdctWork::first_mcu: "the MCU the scan failed in" (the caller's canvas under a fast layout)
 constexpr uint64_t kScanStoreHoldsSamples = 1;
 // The reference's Dispose() taken literally for one progressive frame (dispose_pass_kernel): component c of the frame is
 // transformed n[c] times in place, with the quantisation tables of the decoder's component slots that point at it, in slot order.
@@ -126,7 +132,8 @@ struct alignas(16) DevScanStatus {
     uint32_t first_error;   // (interval << 8) | detail of the lowest failing interval, 0xFFFFFFFF = none
     uint32_t decoded_mcus;  // MCUs decoded (limits the IDCT pass when EOI came early)
     uint32_t end_pos;       // byte offset (from data_off) of the terminating marker / end of data
-    uint32_t pad[3];        // [0] unstuffed length; [1] progressive scans: restart units completed (0xFFFFFFFF = finished);
+    uint32_t pad[3];        // [0] unstuffed length; [1] progressive scans: restart units completed (0xFFFFFFFF = finished); sequential
+                            // scans: kFailBlockBase - the failing block, 0 = none;
                             // [2] optimizer walk: bits of the stream left unread behind the scan's last block
 };
 

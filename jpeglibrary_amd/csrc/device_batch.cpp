@@ -1181,6 +1181,9 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     dispose_max_blocks_ = 0;
     std::vector<IdctWork> idct_work;
     std::vector<IdctWork> idct_work_by_class[kNumIdctLayoutClasses];
+    std::vector<std::vector<IdctWork>> idct_later_levels;  // scans ordered behind earlier scans of their image: one launch per level
+    std::vector<IdctWork> idct_partial;                     // "the MCU the scan failed in", bytewise (the caller's canvas)
+    std::vector<int> scan_level(jobs_.size(), 0);
     const bool tile_align = !(getenv("JPGPU_TILE_ALIGN") && atoi(getenv("JPGPU_TILE_ALIGN")) == 0);  // A/B switch, default on
     uint64_t out_off = 0, coef_off = 0, planes_off = 0;
     uint32_t ends_off = 0, total_chunks = 0;
@@ -1232,6 +1235,19 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         out_off = align_up(out_off + img.out_bytes, 256);
         planes_off = align_up(planes_off + img.planes_bytes, 256);
         if (!img.jobs.empty()) total_pixels_ += (uint64_t)img.width * img.height;
+        // sequential scans of this image that write a component an earlier scan of it has written (ordered launches, see below)
+        bool overlapping_scans = false;
+        {
+            uint32_t seen = 0;
+            for (int j : img.jobs) {
+                const ScanJob &job = jobs_[j];
+                if (job.kind != kScanSequential || job.disabled) continue;
+                uint32_t mine = 0;
+                for (int c = 0; c < job.scan_components; c++) mine |= 1u << (job.comp[c].component_index & 31);
+                overlapping_scans |= (mine & seen) != 0;
+                seen |= mine;
+            }
+        }
         for (int j : img.jobs) {
             const ScanJob &job = jobs_[j];
             DevScan &s = h_scans_[j];
@@ -1276,6 +1292,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             for (uint32_t c = 0; c < s.n_chunks; c += kMarkerChunksPerWg) chunk_work.push_back({(uint32_t)j, c});
             total_chunks += s.n_chunks;
             s.image_index = (uint32_t)ii;
+            s.first_scan = (uint32_t)img.jobs.front();
             s.level_shift = (uint32_t)g.level_shift;
             s.width = g.frame.samples_per_line;
             s.height = g.frame.lines;
@@ -1412,37 +1429,58 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                     }
             }
             const bool holds_samples = (s.reserved0 & kScanStoreHoldsSamples) != 0;
-            const int cls = holds_samples ? kIdctClassStoreHoldsSamples : (fmt_is_interleaved(format_) ? idct_layout_class(s) : 0);
+            int cls = holds_samples ? kIdctClassStoreHoldsSamples : (fmt_is_interleaved(format_) ? idct_layout_class(s) : 0);
+            // RGB / RGBA of a frame with overlapping scans (below): every scan's samples go to the scratch image in file order and
+            // are converted at the end -- a fused conversion of one scan would be overwritten by the scratch image's
+            if (!holds_samples && overlapping_scans && (format_ == JPGPU_FMT_RGB_U8 || format_ == JPGPU_FMT_RGBA_U8)) cls = 0;
             if ((cls == 0 || holds_samples) && (format_ == JPGPU_FMT_RGB_U8 || format_ == JPGPU_FMT_RGBA_U8)) {
                 // no fused conversion for this layout: samples go to the scratch image, then ycc_to_rgb_kernel
                 bool listed = false;
                 for (const RgbConvert &rc : rgb_convert_) listed |= rc.image == (uint32_t)ii;
                 if (!listed) rgb_convert_.push_back({(uint32_t)ii, img.out_offset, (uint64_t)img.width * img.height, img.num_components});
             }
-            // A baseline frame of several scans whose LATER scans cover every component this one covers (a corrupted selector:
-            // one component scanned twice, another never): every sample this scan's blocks would write is written again by a
-            // later WriteBlock -- the later one wins in the reference, and two scans' tiles in one launch have no order.  The
-            // scan is decoded (its errors count) and its transform left out.  (A later scan covering only SOME of an interleaved
-            // scan's components is not ordered: no encoder writes such a frame, and no header bit flip makes one.)
-            bool overwritten = false;
+            // A baseline frame whose LATER scans write a component this one writes too (a corrupted selector: one component
+            // scanned twice, another never): in the reference the later WriteBlock wins -- where the later scan GOT to; a later
+            // scan that fails or ends early leaves this scan's samples behind its last block -- and two scans' tiles in one
+            // launch have no order.  Such a later scan is ORDERED behind the scans it overlaps: its transform goes to a later
+            // launch (level = 1 + the highest level among the earlier scans sharing a component with it), on the bytewise form,
+            // touching nothing it did not reach (kKeepUnreachedMcus).  Round 4 left the earlier scan's transform out when the
+            // later scans covered all its components (wrong when they were truncated) and did not order partial overlaps.
+            int level = 0;
             if (job.kind == kScanSequential && img.jobs.size() > 1) {
-                uint32_t mine = 0, later = 0;
-                for (int c = 0; c < job.scan_components; c++) mine |= 1u << job.comp[c].component_index;
-                bool behind = false;
+                uint32_t mine = 0;
+                for (int c = 0; c < job.scan_components; c++) mine |= 1u << (job.comp[c].component_index & 31);
                 for (int j2 : img.jobs) {
-                    if (j2 == j) {
-                        behind = true;
-                        continue;
-                    }
+                    if (j2 == j) break;
                     const ScanJob &o = jobs_[(size_t)j2];
-                    if (!behind || o.kind != kScanSequential || o.disabled) continue;
-                    for (int c = 0; c < o.scan_components; c++) later |= 1u << o.comp[c].component_index;
+                    if (o.kind != kScanSequential || o.disabled) continue;
+                    uint32_t theirs = 0;
+                    for (int c = 0; c < o.scan_components; c++) theirs |= 1u << (o.comp[c].component_index & 31);
+                    if (mine & theirs) level = std::max(level, scan_level[(size_t)j2] + 1);
                 }
-                overwritten = (mine & ~later) == 0;
             }
+            scan_level[(size_t)j] = level;
             const uint32_t run = mcus_per_wg * (uint32_t)kIdctTilesPerWg;
-            for (uint32_t first = 0; first < s.total_mcus && !overwritten; first += run)
-                idct_work_by_class[cls].push_back({(uint32_t)j, first, std::min(run, s.total_mcus - first), mcus_per_wg});
+            if (level > 0) {
+                h_scans_[j].shadow_mask |= kKeepUnreachedMcus;
+                if ((size_t)level > idct_later_levels.size()) idct_later_levels.resize((size_t)level);
+                const uint32_t generic_per_wg = ((uint32_t)kIdctBlocksPerWg / s.blocks_per_mcu);
+                const uint32_t grun = generic_per_wg * (uint32_t)kIdctTilesPerWg;
+                for (uint32_t first = 0; first < s.total_mcus; first += grun)
+                    idct_later_levels[(size_t)level - 1].push_back({(uint32_t)j, first, std::min(grun, s.total_mcus - first), generic_per_wg});
+                if (format_ == JPGPU_FMT_RGB_U8 || format_ == JPGPU_FMT_RGBA_U8) {  // (bytewise form: samples to the scratch image, then ycc_to_rgb_kernel)
+                    bool listed = false;
+                    for (const RgbConvert &rc : rgb_convert_) listed |= rc.image == (uint32_t)ii;
+                    if (!listed) rgb_convert_.push_back({(uint32_t)ii, img.out_offset, (uint64_t)img.width * img.height, img.num_components});
+                }
+            } else {
+                for (uint32_t first = 0; first < s.total_mcus; first += run)
+                    idct_work_by_class[cls].push_back({(uint32_t)j, first, std::min(run, s.total_mcus - first), mcus_per_wg});
+                // the caller's canvas under a whole-pixel layout: the MCU a failing scan stops in is written block by block
+                if (keep_canvas_ && job.kind == kScanSequential && format_ == JPGPU_FMT_INTERLEAVED_U8 &&
+                    cls >= 1 && cls <= 3)  // (kLayYccH1V1 / H2V1 / H2V2, k3_idct.hip)
+                    idct_partial.push_back({(uint32_t)j, kIdctPartialMcu, 1, ((uint32_t)kIdctBlocksPerWg / s.blocks_per_mcu)});
+            }
         }
     }
     for (DisposeJob &dj : dispose_jobs_) {  // the frames' stores have their places now
@@ -1594,6 +1632,15 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         idct_class_begin_[c + 1] = (int)idct_work.size();
     }
     n_idct_work_ = (int)idct_work.size();
+    idct_later_begin_.assign(1, n_idct_work_);
+    for (const std::vector<IdctWork> &w : idct_later_levels) {
+        idct_work.insert(idct_work.end(), w.begin(), w.end());
+        idct_later_begin_.push_back((int)idct_work.size());
+    }
+    if (!idct_partial.empty()) {
+        idct_work.insert(idct_work.end(), idct_partial.begin(), idct_partial.end());
+        idct_later_begin_.push_back((int)idct_work.size());
+    }
 
     // ---- two halves for decode()'s overlapped issue order (see decode()): images [0, split) and [split, n), balanced by
     // blocks; the Huffman work list is in image order already (one index splits it), the IDCT work gets a second list with
@@ -1616,7 +1663,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         while (huff_split_ < n_huff_work_ && h_scans_[huff_work[huff_split_].scan].image_index < split_image) huff_split_++;
         // worth it for batches that keep the machine busy for milliseconds: the split costs four launches and two events
         if (wanted && !entropy_only_ && sub_work.empty() && prog_work.empty() && total_blocks_ >= (4u << 20) && huff_split_ > 0 &&
-            huff_split_ < n_huff_work_ && rgb_convert_.empty() && format_ != JPGPU_FMT_EXTENDED_U16) {
+            huff_split_ < n_huff_work_ && rgb_convert_.empty() && format_ != JPGPU_FMT_EXTENDED_U16 && idct_later_begin_.size() == 1) {
             for (int half = 0; half < 2; half++) {
                 idct_split_begin_[half][0] = (int)idct_work_split.size();
                 for (int c = 0; c < kNumIdctLayoutClasses; c++) {
@@ -1925,6 +1972,17 @@ int DeviceBatch::run_idct() {
                                extended ? (uint8_t *)d_planes_.ptr : (uint8_t *)d_out_.ptr, extended ? (int)JPGPU_FMT_PLANAR_I16 : format_, kf,
                                (uint8_t *)d_rgb_scratch_.ptr);
     if (e != hipSuccess) return hip_fail(e, "idct_output_kernel");
+    // scans ordered behind earlier scans of their image (and the failing MCU of a caller's canvas): one bytewise launch per level
+    for (size_t lv = 0; lv + 1 < idct_later_begin_.size(); lv++) {
+        int cb[kNumIdctLayoutClasses + 1];
+        cb[0] = idct_later_begin_[lv];
+        for (int c = 1; c <= kNumIdctLayoutClasses; c++) cb[c] = idct_later_begin_[lv + 1];
+        e = launch_idct(ctx_->stream, (const int16_t *)d_coefs_.ptr, (const DevScan *)d_scans_.ptr, (const IdctWork *)d_idct_work_.ptr, cb,
+                        (const DevScanStatus *)d_status_.ptr, (const DevQuantTable *)d_quant_pool_.ptr,
+                        extended ? (uint8_t *)d_planes_.ptr : (uint8_t *)d_out_.ptr, extended ? (int)JPGPU_FMT_PLANAR_I16 : format_, kf,
+                        (uint8_t *)d_rgb_scratch_.ptr);
+        if (e != hipSuccess) return hip_fail(e, "idct_output_kernel (ordered scans)");
+    }
     if (extended) {
         // "O3": the int16 planes (WriteBlock's arguments) through the test writer's clamp + bit expansion: ONE launch for the
         // batch, a descriptor per image (it was a launch per image)

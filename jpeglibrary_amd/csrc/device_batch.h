@@ -209,6 +209,7 @@ class DeviceBatch {
     int n_huff_slots_ = 1;
     int n_huff_work_ = 0, n_idct_work_ = 0;
     int idct_class_begin_[kNumIdctLayoutClasses + 1] = {};
+    std::vector<int> idct_later_begin_;  // d_idct_work_ behind the classes: [k], [k + 1]) = the k-th ordered launch (run_idct)
     uint64_t total_blocks_ = 0, out_bytes_ = 0, planes_bytes_ = 0, input_bytes_ = 0, compressed_bytes_ = 0, total_pixels_ = 0;
     DevBuffer d_planes_;  // EXTENDED_U16: K3's PLANAR_I16 output, converted by extend_u16_kernel
     DevBuffer d_extend_desc_;

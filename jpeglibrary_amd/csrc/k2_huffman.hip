@@ -181,6 +181,9 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
                     const uint32_t at = i2 - 2u < 126u ? i2 - 2u : 126u;
                     *reinterpret_cast<int16_t *>(my_stage + (at ^ swz16)) = (int16_t)v;
                 }
+                // the block the reference throws in: blocks in front of it have reached the writer, this one and the rest have not
+                if (err != 0)
+                    atomicMax(&status[wk.scan].pad[1], fail_block_word(((uint64_t)interval * dri_eff + mcu) * bpm + b));
             }
             // top up the ring HERE: the wait for the prefetched chunk then only covers memory operations issued before this
             // block was decoded (the chunk itself and the previous block's coefficient stores), never fresh ones

@@ -862,6 +862,9 @@ __device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const
                     const uint32_t at = k2i - 2u < 126u ? k2i - 2u : 126u;
                     *reinterpret_cast<int16_t *>(my_stage + (at ^ swz16)) = (int16_t)v;
                 }
+                // the block the reference throws in (see K2): in front of it every block has reached the writer
+                if (err != 0)
+                    atomicMax(&status[wk.scan].pad[1], fail_block_word(((uint64_t)my_first + j) * bpm + b));
             }
             k2_topup(ring, feed, pos.pm1);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

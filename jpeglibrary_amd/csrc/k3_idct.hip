@@ -442,10 +442,32 @@ __device__ __forceinline__ void idct_output_body(
     // buffer held them -- zero in the buffer the batch owns -- so they go through the same output code with zero samples
     uint32_t decoded = status ? status[wk.scan].decoded_mcus : s.total_mcus;
     if (decoded > s.total_mcus) decoded = s.total_mcus;
+    // ... and the same BLOCK by block for a scan that fails (round 5): the reference has called WriteBlock for every block in
+    // front of the one it threw in and for none behind it (:99-134, 153; JpegHuffmanScanDecoder.cs:103-110), and a scan behind a
+    // failed scan of the image was never started (Decode() left with the exception).
+    uint32_t fail_block = 0xFFFFFFFFu;
+    if (status != nullptr && s.kind == kScanSequential) {
+        const uint32_t fb = status[wk.scan].pad[1];
+        if (fb != 0) fail_block = kFailBlockBase - fb;
+        for (uint32_t j = s.first_scan; j < wk.scan; j++)
+            if (scans[j].image_index == s.image_index && status[j].first_error != kNoError) fail_block = 0;
+    }
+    // keep: the caller's canvas (jpgpu_decode_scan), or a scan ordered behind another scan of its image that wrote the same
+    // component -- what this scan does not reach is not touched.  The YCbCr fast layouts assemble whole pixels of whole MCUs:
+    // there the MCU the scan failed in is left to a launch of the bytewise form (first_mcu == kIdctPartialMcu).
+    const bool keep = (s.shadow_mask & kKeepUnreachedMcus) != 0;
+    constexpr bool kPerMcuLayout = fmt_is_interleaved(FMT) && (LAY == kLayYccH1V1 || LAY == kLayYccH2V1 || LAY == kLayYccH2V2);
+    uint32_t first_mcu = wk.first_mcu;
     uint32_t range_end = wk.first_mcu + wk.n_mcus;
-    if ((s.shadow_mask & kKeepUnreachedMcus) != 0) {  // the caller's canvas (jpgpu_decode_scan): unreached MCUs are not touched
+    if (first_mcu == kIdctPartialMcu) {
+        if (fail_block == 0xFFFFFFFFu || fail_block % bpm == 0 || fail_block / bpm >= decoded) return;
+        first_mcu = fail_block / bpm;
+        range_end = first_mcu + 1;
+    } else if (keep) {
+        const uint32_t reach = kPerMcuLayout ? fail_block / bpm : (fail_block == 0xFFFFFFFFu ? fail_block : (fail_block + bpm - 1) / bpm);
         if (range_end > decoded) range_end = decoded;
-        if (wk.first_mcu >= range_end) return;
+        if (range_end > reach) range_end = reach;
+        if (first_mcu >= range_end) return;
     }
 
     // quantisation tables of the scan components
@@ -478,11 +500,11 @@ __device__ __forceinline__ void idct_output_body(
                                                  (jpgpu_lds_void *)(sh + ((uint32_t)k * kIdctThreads + wave * 64) * 16), 16, 0, 0);
     };
 
-    dma_tile(wk.first_mcu);
+    dma_tile(first_mcu);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-  for (uint32_t tile_first = wk.first_mcu; tile_first < range_end; tile_first += mcus_per_tile) {
+  for (uint32_t tile_first = first_mcu; tile_first < range_end; tile_first += mcus_per_tile) {
     const uint32_t n_mcu = tile_mcus(tile_first);
     const uint32_t n_blk = n_mcu * bpm;
     const uint32_t next_first = tile_first + mcus_per_tile;
@@ -492,7 +514,7 @@ __device__ __forceinline__ void idct_output_body(
     const bool have_block = tid < n_blk;
     // a scan component whose frame component a LATER scan component also resolves to: the reference writes its blocks first
     // and the later component's over them (WriteBlock by ComponentIndex, :118-134), so only the later ones reach the output
-    const bool writes = have_block && ((s.shadow_mask >> ci_early) & 1u) == 0;
+    bool writes = have_block && ((s.shadow_mask >> ci_early) & 1u) == 0;
 
     // phase B1: dequantise this lane's block out of the staging into registers
     float f[64];
@@ -524,7 +546,10 @@ __device__ __forceinline__ void idct_output_body(
 
     // phase B2: IDCT entirely in registers
     if (!PRE && have_block) block_idct(f, (int32_t)s.level_shift, px);
-    if (mcu >= decoded) {
+    // (a frame has fewer than 2^32 blocks: 32-bit arithmetic; computed behind the transform, nothing more alive across it)
+    const bool reached = mcu < decoded && mcu * bpm + b < fail_block;
+    writes = writes && (reached || !keep);
+    if (!reached) {
 #pragma unroll
         for (int i = 0; i < 32; i++) px[i] = 0;
     }

@@ -195,6 +195,9 @@ __device__ __forceinline__ uint32_t stage_addr(uint32_t blk, uint32_t coef_index
     return blk * 128 + chunk * 16 + (coef_index & 7) * 2;
 }
 
+// DevScanStatus::pad[1] of a sequential scan that fails in block `block` (scan order); see common.h
+__device__ __forceinline__ uint32_t fail_block_word(uint64_t block) { return kFailBlockBase - (uint32_t)(block < 0xFFFFFFF0ull ? block : 0xFFFFFFF0ull); }
+
 // Restart check after an interval (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:139-163): runs after every completed
 // interval except a final partial one.  AdvanceAlignByte + TryReadMarker: no whole byte may be left before the closing
 // marker, and the marker must be RSTn (continue) or EOI (return early).  Returns the error code word or kNoError.
@@ -208,12 +211,21 @@ __device__ __forceinline__ uint32_t restart_check(const DevScan &s, const DevSca
     if (!needs_check) return kNoError;
     uint32_t closing = 0xD0;  // entries before the last indexed one are RSTn by construction
     if (interval == n_ends - 1) closing = st.terminator;
-    if (rem >= 8) return (interval << 8) | kDetailExpectRestart;
+    // "Expect restart marker." is thrown behind the interval's last MCU: every block of the interval has reached the writer
+    const uint32_t behind = fail_block_word((uint64_t)(interval + 1) * dri_eff * s.blocks_per_mcu);
+    const bool sequential = s.kind == kScanSequential;  // (a progressive scan's pad[1] is its progress word)
+    if (rem >= 8) {
+        if (sequential) atomicMax(&status_out->pad[1], behind);
+        return (interval << 8) | kDetailExpectRestart;
+    }
     if (closing == 0xD9) {
         if (interval < n_intervals - 1) atomicMin(&status_out->decoded_mcus, (interval + 1) * dri_eff);
         return kNoError;
     }
-    if ((closing & 0xF8) != 0xD0) return (interval << 8) | kDetailExpectRestart;
+    if ((closing & 0xF8) != 0xD0) {
+        if (sequential) atomicMax(&status_out->pad[1], behind);
+        return (interval << 8) | kDetailExpectRestart;
+    }
     return kNoError;
 }
 

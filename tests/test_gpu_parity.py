@@ -1424,6 +1424,12 @@ def test_stress_reproducers_match_the_oracle(name):
         ref, ref_kind = po.decode_8bit(data)[0], "OK"
     except po.OracleError as e:
         ref, ref_kind = None, e.kind
+    partial = None  # what a FAILING decode left in the writer (progressive: the disposed store; sequential: the blocks in front of the throw)
+    if ref is None:
+        try:
+            partial = po.decode_8bit_partial(data)[0]
+        except po.OracleError:
+            partial = None
     neighbours = [jpegsynth.encode(64, 48, "420", 75, 2, seed=3), read_jpeg("progress.jpg")]
     files = [data, neighbours[0], data, neighbours[1], data]
     for fmt in (jl.FMT_INTERLEAVED_U8, jl.FMT_RGBA_U8):
@@ -1436,6 +1442,8 @@ def test_stress_reproducers_match_the_oracle(name):
             if ref is not None:
                 want = ref if fmt == jl.FMT_INTERLEAVED_U8 else po.ycbcr8_to_rgb(ref, rgba=True, gray=(ref.shape[2] == 1))
                 assert np.array_equal(b.output(i), want), (name, i, fmt)
+            elif partial is not None and fmt == jl.FMT_INTERLEAVED_U8 and b.image_info(i).status == 0:
+                assert np.array_equal(b.output(i), partial), (name, i, "writer state of the failing decode")
         b.close()
     for strip in (False, True):
         try:
