@@ -365,10 +365,11 @@ int jpgpu_decode_scan(jpgpu_ctx *ctx, const jpgpu_frame *frame, const jpgpu_scan
  *                              (jpgpu_progressive_output_size says how large), or, _to_writer, as WriteBlock calls in Flush's order.
  *                              Scan orders whose slots do not cover every component once are disposed the way the reference does it
  *                              (a component transformed twice, another never: dispose_pass_kernel); a session without any scan
- *                              flushes the zeroed store.  After a FAILING jpgpu_progressive_scan the store of this per-scan session
- *                              holds what the kernels wrote before they stopped: the blocks in front of the failing restart
- *                              interval are the reference's, the rest is not (the batch entry points, which see the whole file,
- *                              do reproduce the reference's partial flush: jpgpu_batch_decode below).
+ *                              flushes the zeroed store.  After a FAILING jpgpu_progressive_scan the store holds what the
+ *                              reference's ProcessScan left when it threw -- every coefficient and correction bit in front of the
+ *                              throw, nothing behind it: the failing scan is issued once more from a device copy of the store taken
+ *                              in front of it, coefficient by coefficient up to the failing restart interval -- so a dispose behind
+ *                              it flushes what Decode()'s `finally` flushes (JpegDecoder.cs:545-549), like the batch entry points.
  */
 typedef struct jpgpu_progressive jpgpu_progressive;
 int jpgpu_progressive_begin(jpgpu_ctx *ctx, const jpgpu_frame *frame, jpgpu_progressive **out);

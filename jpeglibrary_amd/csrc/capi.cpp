@@ -1058,12 +1058,17 @@ int jpgpu_progressive_scan(jpgpu_progressive *p, const jpgpu_scan *scan, const u
         p->frame.scans()[before].entropy = nullptr;
         p->frame.scans()[before].entropy_len = 0;
         if (rc != JPGPU_OK) return rc;
+        const bool first_scan = p->n_scans == 0;
         p->n_scans++;
+        if (!first_scan && (rc = p->batch.snapshot_progressive_store()) != JPGPU_OK) return rc;  // (a device copy: what a failing scan is re-issued from)
         if ((rc = p->batch.run_marker_index()) != JPGPU_OK) return rc;
         if ((rc = p->batch.run_huffman()) != JPGPU_OK) return rc;
         if ((rc = p->batch.sync()) != JPGPU_OK) return rc;
         jpgpu_image_result res;
         if ((rc = p->batch.result(0, &res)) != JPGPU_OK) return rc;
+        // a failing scan leaves the store where the reference's ProcessScan left it: every coefficient in front of the throw, none
+        // behind it (what jpgpu_progressive_dispose then flushes is what Decode()'s `finally` flushes, JpegDecoder.cs:545-549)
+        if (res.status != JPGPU_OK && res.detail != kDetailUnsupportedFrame && (rc = p->batch.rerun_failed_progressive_scan(first_scan)) != JPGPU_OK) return rc;
         if (result) *result = res;
         if (res.status != JPGPU_OK) p->ctx->last_error = jpgpu_detail_string(res.detail);
         return (int)res.status;

@@ -115,6 +115,13 @@ class DeviceBatch {
     // the frame's coefficient store, which lives in d_coefs_ and persists from call to call (same frame, same layout, the
     // buffers only grow); first_scan clears it like JpegBlockAllocator.Allocate does.  Then run_marker_index + run_huffman.
     int upload_progressive_scan(const ProgressiveFrame &frame, int scan_index, bool first_scan);
+    // The store as it is now, kept aside (a device copy): what rerun_failed_progressive_scan() starts again from.
+    int snapshot_progressive_store();
+    // The scan of the last upload_progressive_scan() failed on the device.  The reference's ProcessScan threw at one coefficient
+    // and left the store exactly there (JpegHuffmanProgressiveScanDecoder.cs:92-419; Decode()'s finally then disposes it,
+    // JpegDecoder.cs:545-549): the store is put back (the snapshot; zero behind a first scan) and the scan issued once more on
+    // the kernel that walks and stores coefficient by coefficient, up to the restart interval it failed in.
+    int rerun_failed_progressive_scan(bool first_scan);
     // ... and the Dispose() pass alone over that store: the frame job without entropy scans; then run_idct.
     int upload_progressive_dispose(const ProgressiveFrame &frame, int format);
     // One pre-built scan job whose entropy bytes are `entropy` (level-2 API and the JpegDecoder mirror).
@@ -220,6 +227,8 @@ class DeviceBatch {
     // DRI = 0 scans: self-synchronising subsequence decode (K2S)
     DevBuffer d_lut_pool_;  // fused lookups of every pool table (K2S round kernel)
     DevBuffer d_sub_work_, d_sub_scan_ids_, d_sub_exit_a_, d_sub_exit_b_, d_sub_nblk_, d_sub_first_, d_sub_entry_, d_sub_dcsum_, d_sub_dcentry_, d_sub_changed_, d_sub_same_;
+    DevBuffer d_prog_snapshot_;  // per-scan session: the frame's store in front of the current scan
+    uint64_t prog_snapshot_blocks_ = 0;
     DevBuffer d_dispose_;  // DisposeJob per frame that takes the generic Dispose() pass
     std::vector<DisposeJob> dispose_jobs_;
     uint32_t dispose_max_blocks_ = 0;

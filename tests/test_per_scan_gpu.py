@@ -289,3 +289,67 @@ def test_tiff_style_surface_argument_checks_and_table_replacement():
     with pytest.raises(jl.InvalidDataException):
         dec.ProcessScan(got["entropy"], got["sh"])
     dec.close()
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_a_failing_scan_leaves_the_session_store_as_the_reference_leaves_it(seed):
+    """JpegDecoder.Decode's `finally` disposes the scan decoder (JpegDecoder.cs:545-549) and the progressive one flushes its store
+    exactly as the throwing ProcessScan left it (ScanDecoder/JpegHuffmanProgressiveScanDecoder.cs:421-470).  The caller of the
+    per-scan session does the same: stop at the failing scan, Dispose.  Round 4 reproduced that flush for whole files only; the
+    session now re-issues a failing scan from a device copy of the store, coefficient by coefficient up to the throw, so its Dispose
+    equals the restatement's writer buffer (po.decode_8bit_partial) on the corrupted corpus of tests/test_partial_flush_gpu.py."""
+    from test_partial_flush_gpu import _corrupted_progressive
+
+    files = _corrupted_progressive(70, seed)
+    compared = failing = 0
+    for k, data in enumerate(files):
+        try:
+            px, info, err = po.decode_8bit_partial(data)
+        except po.OracleError:
+            continue  # Identify failed: no scan decoder was ever created
+        w = Walk(data)
+        st = {"dec": None, "err": None, "fh": None}
+
+        def on_frame(marker, fh):
+            if marker != 0xC2:
+                raise jl.NotSupportedException("not a progressive frame")
+            st["fh"] = fh
+            st["dec"] = jl.JpegGpuProgressiveScanDecoder(fh)
+
+        def on_scan(entropy, sh):
+            if st["err"] is not None or st["dec"] is None:
+                return 0
+            try:
+                return st["dec"].ProcessScan(entropy, sh, w.quantization_tables(), w.huffman_tables(), w.dri)
+            except jl.JpegError as e:
+                st["err"] = e
+                return 0
+
+        try:
+            w.run(on_frame, on_scan)
+        except Exception:  # a corrupted header this test's own walk does not read the way the reference does: not the session's business
+            if st["dec"] is not None:
+                st["dec"].close()
+            continue
+        if st["dec"] is None:
+            continue
+        if (st["err"] is None) != (err is None):
+            st["dec"].close()
+            continue  # (the failure is the marker walk's -- a late error of Decode's loop --, not a scan's)
+        if st["err"] is not None and type(st["err"]).__name__ != err.kind:
+            st["dec"].close()
+            continue
+        fh = st["fh"]
+        if fh.NumberOfComponents != info.ncomp or fh.SamplesPerLine != info.width:
+            st["dec"].close()
+            continue
+        try:
+            out = st["dec"].Dispose(fmt=jl.FMT_INTERLEAVED_U8).reshape(fh.NumberOfLines, fh.SamplesPerLine, fh.NumberOfComponents)
+        except jl.NotSupportedException:
+            st["dec"].close()
+            continue
+        st["dec"].close()
+        assert np.array_equal(out, px), (seed, k, None if err is None else err.kind, int((out != px).sum()))
+        compared += 1
+        failing += err is not None
+    assert compared >= 30 and failing >= 15, (compared, failing)
