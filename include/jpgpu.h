@@ -269,7 +269,10 @@ int jpgpu_batch_result(jpgpu_batch *b, int i, jpgpu_image_result *res);
  * decodes over the caller's own samples, leaves them alone.) */
 void *jpgpu_batch_output_device(const jpgpu_batch *b, uint64_t *total_bytes);
 void *jpgpu_batch_coefficients_device(const jpgpu_batch *b, uint64_t *total_blocks);
-/* Copies one image's output / coefficient blocks (int16[blocks][64], zig-zag order, MCU scan order) to the host. */
+/* Copies one image's output / coefficient blocks (int16[blocks][64], zig-zag order, MCU scan order) to the host.  (A progressive
+ * frame whose Dispose() is taken literally -- component slots that do not cover every component once, the partial flush of a
+ * failed file -- is transformed IN its store: behind the output stage its "coefficients" are samples; the pass runs once per
+ * entropy stage, a second jpgpu_batch_run_idct / jpgpu_progressive_dispose flushes the same samples again.) */
 int jpgpu_batch_download_output(jpgpu_batch *b, int i, void *dst, size_t cap);
 int jpgpu_batch_download_coefficients(jpgpu_batch *b, int i, int16_t *dst, size_t cap_blocks);
 /* Overwrites one image's coefficient blocks from the host (IDCT-stage parity tests; config-5 style accumulate-then-IDCT). */
@@ -283,6 +286,14 @@ int jpgpu_batch_stage_ms(jpgpu_batch *b, float ms[4]);
  * are enqueued ahead and checked on the device (jpgpu_batch_decode does not wait for them): valid after jpgpu_batch_sync /
  * _result / _download_*. */
 int jpgpu_batch_subseq_rounds(const jpgpu_batch *b);
+/* The partial flush of FAILING progressive files (the reference's Decode() disposes the scan decoder in its `finally`, which
+ * transforms and flushes the store as the failing scan left it, JpegDecoder.cs:545-549): on by default -- the first call that
+ * needs a status or an output after a decode in which a progressive frame failed issues those frames once more, scan by scan
+ * (the other images of the batch are not touched).  on = 0: callers that only want the statuses and the outputs of the images
+ * that decoded leave it out (also: environment JPGPU_NO_PARTIAL_FLUSH); the failed frames' outputs are then unspecified. */
+int jpgpu_batch_set_partial_flush(jpgpu_batch *b, int on);
+/* Partial-flush replays issued for this batch so far (0: no progressive frame has failed, or the replay is switched off). */
+int jpgpu_batch_progressive_replays(const jpgpu_batch *b);
 /* Times the enqueued rounds did not reach the fixed point (the synchronising call then issued the step again with the host
  * reading the counts between rounds, and the upload's later decodes stay that way).  Valid after jpgpu_batch_sync. */
 int jpgpu_batch_subseq_fallbacks(const jpgpu_batch *b);

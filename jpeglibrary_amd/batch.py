@@ -138,6 +138,15 @@ class Batch:
         """Synchronisation rounds the DRI = 0 subsequence decoder needed in the last decode (0 = not used)."""
         return _lib.jpgpu_batch_subseq_rounds(self._h)
 
+    def set_partial_flush(self, on=True):
+        """Failing progressive files: reproduce the reference's partial flush (default) or leave those frames' outputs unspecified."""
+        self._check(_lib.jpgpu_batch_set_partial_flush(self._h, 1 if on else 0))
+        return self
+
+    def progressive_replays(self):
+        """Times a partial-flush replay was issued for this batch."""
+        return _lib.jpgpu_batch_progressive_replays(self._h)
+
     def subseq_fallbacks(self):
         """Times the enqueued K2S rounds did not converge and the step was issued again with host-checked rounds."""
         return _lib.jpgpu_batch_subseq_fallbacks(self._h)

@@ -440,6 +440,12 @@ int jpgpu_batch_upload_coefficients(jpgpu_batch *b, int i, const int16_t *src, s
 }
 int jpgpu_batch_stage_ms(jpgpu_batch *b, float ms[4]) { JPGPU_GUARD(b, b->impl.stage_ms(ms)); }
 int jpgpu_batch_subseq_rounds(const jpgpu_batch *b) { return b ? b->impl.last_subseq_rounds() : 0; }
+int jpgpu_batch_set_partial_flush(jpgpu_batch *b, int on) {
+    if (!b) return JPGPU_ERR_ARGUMENT;
+    b->impl.set_partial_flush(on != 0);
+    return JPGPU_OK;
+}
+int jpgpu_batch_progressive_replays(const jpgpu_batch *b) { return b ? b->impl.progressive_replays() : 0; }
 int jpgpu_batch_subseq_fallbacks(const jpgpu_batch *b) { return b ? b->impl.subseq_fallbacks() : 0; }
 int jpgpu_batch_progressive_fallbacks(const jpgpu_batch *b) { return b ? b->impl.progressive_fallbacks() : 0; }
 int jpgpu_batch_ingest_stats(const jpgpu_batch *b, jpgpu_ingest_stats *stats) {

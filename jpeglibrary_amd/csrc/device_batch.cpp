@@ -734,8 +734,6 @@ int DeviceBatch::upload_segments(const jpgpu_segment *segments, const int *segme
         if (img.swallow_job >= 0) img.swallow_job += (int)first_job;
     }
     plans.clear();
-    replay_done_ = false;
-    prog_by_scan_ = false;
     files_resident_ = true;
     rc = layout_and_upload(file_ptr, file_len);
     files_resident_ = false;
@@ -1086,7 +1084,9 @@ int DeviceBatch::upload_progressive_dispose(const ProgressiveFrame &frame, int f
     job_entropy_off_.push_back(0);
     std::vector<const uint8_t *> fp(1, nullptr);
     std::vector<size_t> fl(1, 0);
+    const bool store_holds_samples = dispose_done_;  // an earlier Dispose() of this session has transformed the store in place
     const int rc = layout_and_upload(fp, fl);
+    dispose_done_ = store_holds_samples && !dispose_jobs_.empty();
     keep_progressive_store_ = true;
     defer_refusal_ = false;
     return rc;
@@ -1152,6 +1152,17 @@ int DeviceBatch::upload_frames(const jpgpu_frame *frames, const uint16_t *qt, in
 }
 
 int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr, const std::vector<size_t> &file_len) {
+    dispose_done_ = false;
+    if (!in_replay_) {
+        // every upload path starts from the batch's own launch modes (the replay's flags used to be reset by
+        // upload_segments alone); upload_segments says afterwards whether a partial flush can become necessary
+        replay_done_ = false;
+        replay_possible_ = false;
+        prog_by_scan_ = false;
+        replay_layout_active_ = false;
+        replay_saved_jobs_.clear();
+        for (ImagePlan &img : images_) img.replay_skip = false;
+    }
     hipError_t e = hipSetDevice(ctx_->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     {
@@ -1328,7 +1339,8 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             s.n_chunks = (uint32_t)(((uint64_t)s.data_len + (s.data_off & 15u) + kMarkerChunkBytes - 1) / kMarkerChunkBytes);
             if (s.n_chunks == 0) s.n_chunks = 1;
             if (job.kind == kScanFrameOnly) s.n_chunks = 0;  // no entropy data: K1 / K2 skip the job
-            for (uint32_t c = 0; c < s.n_chunks; c += kMarkerChunksPerWg) chunk_work.push_back({(uint32_t)j, c});
+            // (replay_skip: an image the replay of failed progressive frames leaves alone keeps its place in every buffer and gets no work)
+            for (uint32_t c = 0; c < s.n_chunks && !img.replay_skip; c += kMarkerChunksPerWg) chunk_work.push_back({(uint32_t)j, c});
             total_chunks += s.n_chunks;
             s.image_index = (uint32_t)ii;
             s.first_scan = (uint32_t)img.jobs.front();
@@ -1383,7 +1395,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 }
                 dj.n_blocks = 0xFFFFFFFFu;  // (marks "scan index in coef_off": resolved below, once the store's place is known)
                 dj.coef_off = (uint64_t)j;
-                dispose_jobs_.push_back(dj);
+                if (!img.replay_skip) dispose_jobs_.push_back(dj);
             }
 
             if (job.kind == kScanProgressive) {
@@ -1391,7 +1403,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 // own, in file order -- one kernel duration per scan kind of the script (tools/trace/progressive_by_scan.sh)
                 static const bool by_scan_env = getenv("JPGPU_PROG_BY_SCAN") != nullptr;
                 const bool by_scan = by_scan_env || prog_by_scan_;
-                if (job.disabled) continue;  // (replay of a failed file: the reference never got to this scan; K1 still indexes it)
+                if (job.disabled || img.replay_skip) continue;  // (replay of a failed file: the reference never got to this scan; K1 still indexes it)
                 const int ordinal = by_scan ? j - img.jobs[0] - 1 : job.ordinal;
                 if (by_scan) prog_pipelined_ = false;
                 if ((size_t)ordinal >= prog_work_by_ordinal.size()) {
@@ -1429,7 +1441,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 continue;  // no store of its own, no IDCT work
             }
             const uint64_t nblocks = (uint64_t)s.mcus_per_line * s.mcus_per_column * s.blocks_per_mcu;
-            if (job.kind == kScanFrameOnly) prog_clear_.push_back({coef_off, nblocks});
+            if (job.kind == kScanFrameOnly && !img.replay_skip) prog_clear_.push_back({coef_off, nblocks});
             coef_off += nblocks;
             img.total_blocks += nblocks;
             compressed_bytes_ += s.data_len;
@@ -1446,11 +1458,14 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 s.sub_off = total_subs_;
                 total_subs_ += s.n_subs;
                 max_subs_per_scan_ = std::max(max_subs_per_scan_, s.n_subs);
-                sub_scan_ids_.push_back((uint32_t)j);
-                for (uint32_t first = 0; first < s.n_subs; first += 256) sub_work.push_back({(uint32_t)j, first});
+                if (!img.replay_skip) {
+                    sub_scan_ids_.push_back((uint32_t)j);
+                    for (uint32_t first = 0; first < s.n_subs; first += 256) sub_work.push_back({(uint32_t)j, first});
+                }
             } else {
-                for (uint32_t first = 0; first < s.n_intervals; first += huff_intervals_per_wg) huff_work.push_back({(uint32_t)j, first});
+                for (uint32_t first = 0; first < s.n_intervals && !img.replay_skip; first += huff_intervals_per_wg) huff_work.push_back({(uint32_t)j, first});
             }
+            if (img.replay_skip) continue;  // (its samples are in the output buffer already)
             if (s.blocks_per_mcu == 0) continue;  // cannot happen for a resolved scan (sampling factors are checked); no blocks, no work
             uint32_t mcus_per_wg = (uint32_t)kIdctBlocksPerWg / s.blocks_per_mcu;
             if (tile_align) {
@@ -1656,10 +1671,10 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         }
         bool all = true;
         for (int c = 0; c < img.num_components; c++) all &= ((covered[c >> 6] >> (c & 63)) & 1ull) != 0;
-        if (!all) out_clear_.push_back({img.out_offset, img.out_bytes, img.planes_offset, img.planes_bytes});
+        if (!all && !img.replay_skip) out_clear_.push_back({img.out_offset, img.out_bytes, img.planes_offset, img.planes_bytes});
         // RGB / RGBA = the callers' converter applied to the YCbCr8 buffer (DecodeAction.cs:71-74): an image without any scan
         // leaves that buffer as it was (zero here), and the converter still runs over it
-        if (img.jobs.empty() && (format_ == JPGPU_FMT_RGB_U8 || format_ == JPGPU_FMT_RGBA_U8))
+        if (img.jobs.empty() && !img.replay_skip && (format_ == JPGPU_FMT_RGB_U8 || format_ == JPGPU_FMT_RGBA_U8))
             rgb_convert_.push_back({(uint32_t)(&img - images_.data()), img.out_offset, (uint64_t)img.width * img.height, img.num_components});
     }
     idct_class_begin_[0] = 0;
@@ -1818,6 +1833,7 @@ int DeviceBatch::run_marker_index() {
 }
 int DeviceBatch::run_huffman() {
     status_valid_ = false;
+    dispose_done_ = false;  // (the stores hold coefficients again)
     hipError_t e = launch_huffman(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_huff_work_.ptr,
                                   n_huff_work_, (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr,
                                   (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (const uint8_t *)d_lut_pool_.ptr);
@@ -1985,6 +2001,7 @@ int DeviceBatch::clear_partial_outputs() {
 
 // the frames' coefficient stores back to zero (JpegBlockAllocator.Allocate clears it): a Dispose() without any scan before it
 int DeviceBatch::clear_progressive_stores() {
+    dispose_done_ = false;
     for (const auto &c : prog_clear_) {
         hipError_t e = hipMemsetAsync((int16_t *)d_coefs_.ptr + c.first * 64, 0, (size_t)c.second * 128, ctx_->stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(progressive store)");
@@ -1993,7 +2010,8 @@ int DeviceBatch::clear_progressive_stores() {
 }
 
 int DeviceBatch::run_dispose_passes(hipStream_t stream) {
-    if (dispose_jobs_.empty()) return JPGPU_OK;
+    if (dispose_jobs_.empty() || dispose_done_) return JPGPU_OK;
+    dispose_done_ = true;
     const hipError_t e = launch_dispose_pass(stream, (int16_t *)d_coefs_.ptr, (const DisposeJob *)d_dispose_.ptr, (int)dispose_jobs_.size(), dispose_max_blocks_,
                                              (const DevQuantTable *)d_quant_pool_.ptr);
     return e == hipSuccess ? JPGPU_OK : hip_fail(e, "dispose_pass_kernel");
@@ -2084,6 +2102,10 @@ int DeviceBatch::run_idct() {
 int DeviceBatch::decode() {
     hipError_t e = hipSetDevice(ctx_->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    if (replay_layout_active_ && !in_replay_) {  // a decode behind a partial-flush replay: a whole pass again, from the batch's own work lists
+        const int rr = restore_after_replay();
+        if (rr != JPGPU_OK) return rr;
+    }
     if (ev_used_ + 4 > 4 * 256) {  // bound the pool: keep the most recent decodes only
         ev_used_ = 0;
         ev_serial_.clear();
@@ -2247,7 +2269,8 @@ int DeviceBatch::fetch_status() {
         }
     }
     status_valid_ = true;
-    if (replay_possible_ && !replay_done_ && in_decode_request_) return replay_failed_progressive();
+    static const bool no_partial_flush = getenv("JPGPU_NO_PARTIAL_FLUSH") != nullptr;
+    if (replay_possible_ && !replay_done_ && in_decode_request_ && partial_flush_ && !no_partial_flush) return replay_failed_progressive();
     return JPGPU_OK;
 }
 
@@ -2280,6 +2303,16 @@ int DeviceBatch::replay_failed_progressive() {
     }
     replay_done_ = true;
     if (failed.empty()) return JPGPU_OK;
+    // Only the failed frames are issued again: every other image keeps its place in the buffers and what the first pass wrote
+    // there (one corrupt file in a batch of 1024 used to repeat the whole batch, scan by scan).  Their statuses are
+    // the first pass's; the jobs this function rewrites are kept as they were for restore_after_replay().
+    const std::vector<DevScanStatus> first_pass = h_status_;
+    std::vector<uint8_t> is_failed(images_.size(), 0);
+    for (const Failed &f : failed) is_failed[f.image] = 1;
+    for (size_t ii = 0; ii < images_.size(); ii++) images_[ii].replay_skip = !is_failed[ii];
+    replay_saved_jobs_.clear();
+    for (const Failed &f : failed)
+        for (int j : images_[f.image].jobs) replay_saved_jobs_.emplace_back((size_t)j, jobs_[(size_t)j]);
     for (const Failed &f : failed) {
         const ImagePlan &img = images_[f.image];
         const int n_scans = (int)img.jobs.size() - 1;
@@ -2314,12 +2347,31 @@ int DeviceBatch::replay_failed_progressive() {
     std::vector<const uint8_t *> fp(images_.size(), nullptr);
     std::vector<size_t> fl(images_.size(), 0);
     for (size_t ii = 0; ii < images_.size(); ii++) fl[ii] = images_[ii].file_len;
+    in_replay_ = true;
     files_resident_ = true;
     int rc = layout_and_upload(fp, fl);
     files_resident_ = false;
-    if (rc != JPGPU_OK) return rc;
-    if ((rc = decode()) != JPGPU_OK) return rc;
-    return fetch_status();
+    if (rc == JPGPU_OK) rc = decode();
+    if (rc == JPGPU_OK) rc = fetch_status();
+    in_replay_ = false;
+    replay_layout_active_ = true;  // the work lists are the failed frames' alone: the next decode() puts the batch's own back
+    for (size_t ii = 0; ii < images_.size(); ii++)
+        if (!is_failed[ii])
+            for (int j : images_[ii].jobs) h_status_[(size_t)j] = first_pass[(size_t)j];
+    return rc;
+}
+
+// The batch as it was uploaded: the jobs the replay rewrote as they were, every image with work again, the fast launch modes.
+int DeviceBatch::restore_after_replay() {
+    for (auto &kv : replay_saved_jobs_) jobs_[kv.first] = kv.second;
+    std::vector<const uint8_t *> fp(images_.size(), nullptr);
+    std::vector<size_t> fl(images_.size(), 0);
+    for (size_t ii = 0; ii < images_.size(); ii++) fl[ii] = images_[ii].file_len;
+    files_resident_ = true;
+    const int rc = layout_and_upload(fp, fl);  // (resets the replay's flags and the images' replay_skip)
+    files_resident_ = false;
+    replay_possible_ = rc == JPGPU_OK && !entropy_only_;
+    return rc;
 }
 
 int DeviceBatch::result(int i, jpgpu_image_result *res) {
@@ -2393,7 +2445,8 @@ int DeviceBatch::download_output(int i, void *dst, size_t cap) {
     if (!img || !dst) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_download_output: bad argument");
     if (img->status != JPGPU_OK) return fail(img->status, img->error);
     if (cap < img->out_bytes) return fail(JPGPU_ERR_ARGUMENT, "Destination buffer is too small.");
-    int rc = sync();
+    // (a batch with a failed progressive frame owes its caller the partial flush whatever is asked for first: ADVICE r4)
+    int rc = (replay_possible_ && !replay_done_) ? fetch_status() : sync();
     if (rc != JPGPU_OK) return rc;
     hipError_t e = hipMemcpy(dst, (const uint8_t *)d_out_.ptr + img->out_offset, img->out_bytes, hipMemcpyDeviceToHost);
     return e == hipSuccess ? JPGPU_OK : hip_fail(e, "hipMemcpy(output)");
@@ -2404,7 +2457,7 @@ int DeviceBatch::download_coefficients(int i, int16_t *dst, size_t cap_blocks) {
     if (!img || !dst) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_download_coefficients: bad argument");
     if (img->status != JPGPU_OK) return fail(img->status, img->error);
     if (cap_blocks < img->total_blocks) return fail(JPGPU_ERR_ARGUMENT, "Destination buffer is too small.");
-    int rc = sync();
+    int rc = (replay_possible_ && !replay_done_) ? fetch_status() : sync();
     if (rc != JPGPU_OK) return rc;
     hipError_t e = hipMemcpy(dst, (const int16_t *)d_coefs_.ptr + img->coef_offset * 64, img->total_blocks * 128, hipMemcpyDeviceToHost);
     return e == hipSuccess ? JPGPU_OK : hip_fail(e, "hipMemcpy(coefficients)");
@@ -2415,6 +2468,7 @@ int DeviceBatch::upload_coefficients(int i, const int16_t *src, size_t nblocks) 
     if (!img || !src) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_coefficients: bad argument");
     if (img->status != JPGPU_OK) return fail(img->status, img->error);
     if (nblocks != img->total_blocks) return fail(JPGPU_ERR_ARGUMENT, "Block count does not match the image.");
+    dispose_done_ = false;
     int rc = sync();
     if (rc != JPGPU_OK) return rc;
     hipError_t e = hipMemcpy((int16_t *)d_coefs_.ptr + img->coef_offset * 64, src, nblocks * 128, hipMemcpyHostToDevice);

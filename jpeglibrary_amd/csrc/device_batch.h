@@ -75,6 +75,7 @@ struct ImagePlan {
     // if that scan itself decodes (Decode() runs ProcessScan before it reads the next marker), so it is reported after the
     // device-side status of the scans recorded before it
     int late_status = JPGPU_OK, late_detail = 0;
+    bool replay_skip = false;  // replay of the failed progressive frames (replay_failed_progressive): this image is left as it was decoded
     std::string late_error;
     // what the walk ends in instead when scan job `swallow_job` (the file's last sequential scan) leaves exactly one whole
     // byte unread: the reference's reader then resumes one byte INTO the terminating marker (plan_swallowed_terminator)
@@ -159,6 +160,7 @@ class DeviceBatch {
     int progressive_fallbacks() const { return prog_fallbacks_; }
     int subseq_fallbacks() const { return k2s_fallbacks_; }
     int progressive_replays() const { return prog_replays_; }
+    void set_partial_flush(bool on) { partial_flush_ = on; }
     // the optimizer path only needs the files, the scan descriptors and the marker index: no coefficient / sample buffers
     void set_entropy_only(bool on) { entropy_only_ = on; }
     void set_preset_restart_intervals(std::vector<int> v) { preset_dri_ = std::move(v); }
@@ -233,8 +235,15 @@ class DeviceBatch {
     std::vector<DisposeJob> dispose_jobs_;
     uint32_t dispose_max_blocks_ = 0;
     int run_dispose_passes(hipStream_t stream);
+    // dispose_pass_kernel transforms the stores of the generic-Dispose frames IN PLACE: it runs once per entropy stage / store
+    // clear / coefficient upload, a second jpgpu_batch_run_idct (or Dispose of a session) only flushes again
+    bool dispose_done_ = false;
     int replay_failed_progressive();
     bool replay_done_ = false, replay_possible_ = false, prog_by_scan_ = false;
+    bool replay_layout_active_ = false, in_replay_ = false;  // the work lists are the replay's (failed frames only): the next decode() restores the batch's own
+    bool partial_flush_ = true;                               // JPGPU_NO_PARTIAL_FLUSH / jpgpu_batch_set_partial_flush: throughput callers may leave the replay out
+    std::vector<std::pair<size_t, ScanJob>> replay_saved_jobs_;  // the jobs the replay rewrote, as they were
+    int restore_after_replay();
     int prog_replays_ = 0;
   public:
     int clear_progressive_stores();

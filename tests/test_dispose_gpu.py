@@ -122,3 +122,38 @@ def test_dispose_without_any_scan_flushes_the_zeroed_store():
     # (a block of a subsampled component reaches the writer expanded: one WriteBlock per 8 x 8 samples of the frame, per component)
     n_expected = 3 * (fh.SamplesPerLine // 8) * (fh.NumberOfLines // 8)
     assert len(calls) == n_expected and all(c[3] == 0 for c in calls)
+
+
+def test_a_second_dispose_or_output_stage_flushes_the_same_samples():
+    """dispose_pass_kernel transforms the store in place, and it ran in front of EVERY output stage -- a second
+    jpgpu_batch_run_idct, or a second Dispose of a session (first into a device layout, then into a writer), transformed the samples
+    again.  The pass now runs once per entropy stage."""
+    from test_per_scan_gpu import Walk
+
+    data = _progressive(200, 136, "4:2:0", seed=3)
+    units, tail = _units(data)
+    odd = b"".join(units[:7] + [units[9], units[7], units[8]]) + tail  # slots end as {Cb, Cb, Cr}: the literal Dispose()
+    ref = po.decode_8bit(odd)[0]
+    b = jl.Batch().upload([odd], jl.FMT_INTERLEAVED_U8).decode().sync()
+    assert np.array_equal(b.output(0), ref)
+    b.run_idct().sync()
+    assert np.array_equal(b.output(0), ref)
+    b.decode().sync()  # (a whole pass again: coefficients, one transform)
+    assert np.array_equal(b.output(0), ref)
+    b.close()
+    w = Walk(odd)
+    st = {}
+
+    def on_frame(marker, fh):
+        st["fh"] = fh
+        st["dec"] = jl.JpegGpuProgressiveScanDecoder(fh)
+
+    w.run(on_frame, lambda entropy, sh: st["dec"].ProcessScan(entropy, sh, w.quantization_tables(), w.huffman_tables(), w.dri))
+    fh = st["fh"]
+    first = st["dec"].Dispose(fmt=jl.FMT_INTERLEAVED_U8).reshape(fh.NumberOfLines, fh.SamplesPerLine, 3)
+    again = st["dec"].Dispose(fmt=jl.FMT_INTERLEAVED_U8).reshape(fh.NumberOfLines, fh.SamplesPerLine, 3)
+    buf = np.zeros(fh.SamplesPerLine * fh.NumberOfLines * 3, np.uint8)
+    st["dec"].Dispose(outputWriter=jl.JpegBufferOutputWriter8Bit(fh.SamplesPerLine, fh.NumberOfLines, 3, buf))
+    st["dec"].close()
+    assert np.array_equal(first, ref) and np.array_equal(again, ref)
+    assert np.array_equal(buf.reshape(fh.NumberOfLines, fh.SamplesPerLine, 3), ref)

@@ -117,3 +117,51 @@ def test_a_file_that_fails_in_its_first_scan_header_still_flushes():
     assert np.array_equal(b.output(0), ref)
     assert n > 0 and ref.any()  # (not the untouched buffer)
     b.close()
+
+
+def test_the_replay_touches_only_the_failed_frames_whatever_is_asked_for_first(monkeypatch):
+    """the replay used to repeat the WHOLE batch scan by scan, was only triggered by jpgpu_batch_result (a caller
+    that downloaded first got the un-replayed store), left the batch in the slow launch mode, and could not be switched off."""
+    bad = [f for f in _corrupted_progressive(30, 5) if _fails_in_a_scan(f)][:3]
+    assert len(bad) == 3
+    from tools import jpegsynth
+
+    clean = [read_jpeg("progress.jpg"), jpegsynth.encode(320, 200, "420", 75, 4, seed=8), jpegsynth.encode(300, 180, "444", 80, 0, seed=9),
+             read_jpeg("yellowcat_progressive_restart.jpg")]
+    files = [clean[0], bad[0], clean[1], bad[1], clean[2], clean[3], bad[2]]
+    refs = [po.decode_8bit_partial(f)[0] for f in files]
+    # download FIRST (no jpgpu_batch_result before it): the partial flush is there
+    b = jl.Batch().upload(files, jl.FMT_INTERLEAVED_U8).decode()
+    for i in (1, 3, 6, 0, 2, 4, 5):
+        assert np.array_equal(b.output(i), refs[i]), i
+    assert b.progressive_replays() == 1
+    for i, f in enumerate(files):
+        assert (b.result(i).status != 0) == (f in bad), i
+    # a second decode of the same upload: a whole pass from the batch's own work lists again, then one more replay -- same answers
+    b.decode().sync()
+    for i in range(len(files)):
+        assert (b.result(i).status != 0) == (files[i] in bad), i
+        assert np.array_equal(b.output(i), refs[i]), i
+    assert b.progressive_replays() == 2
+    # the same batch object, another upload: nothing of the replay is left behind
+    b.upload(clean, jl.FMT_INTERLEAVED_U8).decode().sync()
+    for i, f in enumerate(clean):
+        assert b.result(i).status == 0 and np.array_equal(b.output(i), po.decode_8bit(f)[0]), i
+    assert b.progressive_fallbacks() == 0
+    b.close()
+    # switched off: statuses as before, the clean images' outputs as before, no replay
+    b2 = jl.Batch().set_partial_flush(False).upload(files, jl.FMT_INTERLEAVED_U8).decode().sync()
+    for i, f in enumerate(files):
+        assert (b2.result(i).status != 0) == (f in bad), i
+        if f not in bad:
+            assert np.array_equal(b2.output(i), refs[i]), i
+    assert b2.progressive_replays() == 0
+    b2.close()
+
+
+def _fails_in_a_scan(f):
+    try:
+        _, _, err = po.decode_8bit_partial(f)
+    except po.OracleError:
+        return False
+    return err is not None
