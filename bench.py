@@ -43,6 +43,9 @@ WORKLOADS = {
     # HETissueSlide.jpg (2048 x 2048, tests/golden) drawn at (0,0), (0,H), (W,0), (W,H), saved as a baseline 4:2:0 Q75 JPEG
     # without restart markers (ImageSharp's defaults; made with Pillow here); timed there: Identify + Decode + RGBA conversion
     "het_8192": (8192, 8192, "420het", 75, 0, 16),
+    # config 5 on REAL content (round 5): 3840 x 2160 crops of that canvas's tissue quarter at distinct offsets, re-encoded by Pillow as
+    # progressive 4:2:0 Q75 -- photographs have the high-frequency coefficients the sinusoid + noise recipe lacks (its scan 5 is empty)
+    "het_progressive": (3840, 2160, "420hetp", 75, 0, 256),
 }
 DEFAULT_FORMAT = {"het_8192": "rgba_u8"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
@@ -85,6 +88,31 @@ def het_canvas(quality):
     out = io.BytesIO()
     canvas.save(out, format="JPEG", quality=quality, subsampling="4:2:0")
     return out.getvalue()
+
+
+def het_progressive_batch(n, width, height, quality, first, nthreads):
+    """`n` progressive frames: crops of the HETissueSlide canvas's content quarter (4096 x 4096: the slide drawn 2 x 2), crop i at an
+    offset of its own."""
+    import io
+
+    from PIL import Image
+
+    base = Image.open(os.path.join(ROOT, "tests", "golden", "HETissueSlide.jpg")).convert("RGB")
+    w, h = base.size
+    quarter = Image.new("RGB", (2 * w, 2 * h))
+    for pos in ((0, 0), (0, h), (w, 0), (w, h)):
+        quarter.paste(base, pos)
+    px = np.asarray(quarter)
+
+    def one(i):
+        k = first + i
+        x0, y0 = (k * 16) % (2 * w - width + 1), (k * 61) % (2 * h - height + 1)
+        out = io.BytesIO()
+        Image.fromarray(px[y0:y0 + height, x0:x0 + width]).save(out, format="JPEG", quality=quality, progressive=True, subsampling="4:2:0")
+        return out.getvalue()
+
+    with ThreadPoolExecutor(max(1, min(nthreads, 64))) as ex:
+        return list(ex.map(one, range(n)))
 
 
 def progressive_batch(n, width, height, quality, seed0, nthreads):
@@ -205,10 +233,12 @@ def ingest_inclusive(jl, ctx, batch, files, fmt, rounds, pinned=False, sync_rank
 def make_inputs(jl_sharding, jpegsynth, workload, n_images, rank, gen_threads, distinct=0):
     """Synthetic input of one workload: `n_images` files (views into one buffer), distinct seed per image and per rank."""
     width, height, ss, quality, dri, _ = WORKLOADS[workload]
-    if ss in ("420p", "420het"):
+    if ss in ("420p", "420het", "420hetp"):
         if ss == "420het":
             files_b = [het_canvas(quality)]  # the reference benchmark decodes ONE input over and over: so does every slot of the batch
             distinct = 1
+        elif ss == "420hetp":
+            files_b = het_progressive_batch(min(n_images, distinct or n_images), width, height, quality, rank * 1009, gen_threads)
         else:
             files_b = progressive_batch(min(n_images, distinct or n_images), width, height, quality, jl_sharding.rank_seed_base(rank), gen_threads)
         ss = "420"
@@ -285,7 +315,7 @@ def measure_config(jl, sharding, jpegsynth, torch, dist, reduce_device, ctx, nam
         idct_bytes = totals["blocks"] * 128 + totals["output_bytes"]
         achieved = idct_bytes / (stage["idct"] / 1e3) / 1e9 if stage["idct"] > 0 else 0.0
         res = {
-            "workload": f"{n_images} x {width}x{height} {ss_eff} Q{quality} DRI={dri}{' progressive (SOF2)' if ss == '420p' else ''}"
+            "workload": f"{n_images} x {width}x{height} {ss_eff} Q{quality} DRI={dri}{' progressive (SOF2)' if ss in ('420p', '420hetp') else ''}"
                         f"{' (HETissueSlide canvas, DecoderBenchmark.cs)' if ss == '420het' else ''} per GPU, output {fmt_name} resident in HBM",
             "value": round(sharding.aggregate_throughput(n_images * width * height, world, steps, elapsed), 1),
             "unit": "Mpixels/s", "n_gpus": world, "steps": steps, "warmup": max(1, warmup),
@@ -295,7 +325,7 @@ def measure_config(jl, sharding, jpegsynth, torch, dist, reduce_device, ctx, nam
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes": idct_bytes},
             "gen_s": round(t_gen, 1),
         }
-        if dri == 0 and ss != "420p":
+        if dri == 0 and ss not in ("420p", "420hetp"):
             res["subseq_rounds"] = batch.subseq_rounds()
             res["subseq_fallbacks"] = batch.subseq_fallbacks()
         if rank == 0:
@@ -307,7 +337,7 @@ def measure_config(jl, sharding, jpegsynth, torch, dist, reduce_device, ctx, nam
                     one.decode().sync()
                 res["single_image_decode_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
                 one.close()
-            if ss == "420p" and world == 1:
+            if ss in ("420p", "420hetp") and world == 1:
                 ctx2 = jl.Context(ctx.device)
                 other = jl.Batch(ctx2).upload(files, fmt)
                 for b in (batch, other):
@@ -527,7 +557,7 @@ def main():
     from tools import jpegsynth
 
     width, height, ss, quality, dri, default_images = WORKLOADS[args.workload]
-    kind = "progressive (SOF2, 10 scans)" if ss == "420p" else ("baseline (HETissueSlide canvas, DecoderBenchmark.cs)" if ss == "420het" else "baseline")
+    kind = "progressive (SOF2, 10 scans)" if ss in ("420p", "420hetp") else ("baseline (HETissueSlide canvas, DecoderBenchmark.cs)" if ss == "420het" else "baseline")
     n_images = args.images or default_images
     fmt = {"interleaved_u8": jl.FMT_INTERLEAVED_U8, "planar_u8": jl.FMT_PLANAR_U8, "rgb_u8": jl.FMT_RGB_U8, "rgba_u8": jl.FMT_RGBA_U8}[args.format]
 
@@ -627,7 +657,7 @@ def main():
     # Two batches in flight (two contexts = two streams, inputs of both resident) is what a caller who has more than one
     # batch does about it; reported beside `value`, never as `value`
     two_in_flight = None
-    if rank == 0 and args.workload == "4k_progressive" and not os.environ.get("JPGPU_PROG_BY_SCAN"):  # (not under the per-scan profiling switch)
+    if rank == 0 and args.workload in ("4k_progressive", "het_progressive") and not os.environ.get("JPGPU_PROG_BY_SCAN"):  # (not under the per-scan profiling switch)
         try:
             ctx2 = jl.Context(local_rank)
             other = jl.Batch(ctx2).upload(files, fmt)
@@ -767,6 +797,8 @@ def main():
             },
             "stage_ms": {k: round(v, 4) for k, v in stage.items()},
             **({"subseq_rounds": batch.subseq_rounds()} if dri == 0 and "prog" not in args.workload else {}),
+            **({"content": "crops of tests/golden/HETissueSlide.jpg (the reference benchmark's image), progressive re-encode by Pillow"}
+               if args.workload == "het_progressive" else {}),
             "roofline": {
                 "kernel": f"idct_output_kernel<{kfmt},{klay}>",
                 "bound": "hbm",

@@ -1881,9 +1881,12 @@ int DeviceBatch::run_progressive() {
     if (prog_begin_.size() <= 1 && prog_clear_.empty()) return JPGPU_OK;
     status_valid_ = false;
     // every frame's store starts from zero (JpegBlockAllocator.Allocate clears it, JpegBlockAllocator.cs:81-83)
-    for (const auto &c : prog_clear_) {
-        if (keep_progressive_store_) break;  // per-scan boundary: the store holds the scans of earlier calls
-        hipError_t e = hipMemsetAsync((int16_t *)d_coefs_.ptr + c.first * 64, 0, (size_t)c.second * 128, ctx_->stream);
+    // (the stores of consecutive frames lie back to back: one fill per run of them, not one per frame -- 257 fills, 3.8 ms of
+    // a 180 ms step of 256 frames, in round 4)
+    for (size_t k = 0; k < prog_clear_.size() && !keep_progressive_store_;) {  // (per-scan boundary: the store holds the scans of earlier calls)
+        uint64_t first = prog_clear_[k].first, blocks = prog_clear_[k].second;
+        for (k++; k < prog_clear_.size() && prog_clear_[k].first == first + blocks; k++) blocks += prog_clear_[k].second;
+        hipError_t e = hipMemsetAsync((int16_t *)d_coefs_.ptr + first * 64, 0, (size_t)blocks * 128, ctx_->stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(progressive store)");
     }
     if (prog_begin_.size() <= 1) return JPGPU_OK;  // (frames without a single scan to run: their stores are zero now, that is all)

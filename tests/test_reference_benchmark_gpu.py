@@ -75,3 +75,18 @@ def test_flat_regions_do_not_cost_a_round_per_subsequence(subsampling, optimize,
     assert b.subseq_rounds() <= 48, b.subseq_rounds()
     # the optimizer's symbol transcode rides on the same synchronisation
     assert jl.optimize_batch([data], strip=False)[0] == po.optimize(data, False)
+
+
+def test_progressive_crops_of_the_benchmark_image_match_the_oracle():
+    """bench.py --workload het_progressive: config 5 on real content (crops of the reference benchmark's image re-encoded as
+    progressive 4:2:0 by Pillow: coefficients in every band, long refinement scans) -- three frames against the restatement."""
+    files = bench.het_progressive_batch(3, 3840, 2160, 75, 7, 3)
+    info, _ = po.identify(files[0])
+    assert (info.width, info.height, info.sof) == (3840, 2160, 0xC2)
+    b = jl.Batch().upload(files, jl.FMT_INTERLEAVED_U8).decode().sync()
+    for i, f in enumerate(files):
+        assert b.result(i).status == 0, i
+        assert np.array_equal(b.output(i), po.decode_8bit(f)[0]), i
+    assert b.progressive_fallbacks() == 0
+    assert files[0] != files[1] != files[2]
+    b.close()
