@@ -228,7 +228,7 @@ class DeviceBatch {
 
     // DRI = 0 scans: self-synchronising subsequence decode (K2S)
     DevBuffer d_lut_pool_;  // fused lookups of every pool table (K2S round kernel)
-    DevBuffer d_sub_work_, d_sub_scan_ids_, d_sub_exit_a_, d_sub_exit_b_, d_sub_nblk_, d_sub_first_, d_sub_entry_, d_sub_dcsum_, d_sub_dcentry_, d_sub_changed_, d_sub_same_;
+    DevBuffer d_sub_work_, d_sub_scan_ids_, d_sub_exit_a_, d_sub_exit_b_, d_sub_nblk_, d_sub_first_, d_sub_entry_, d_sub_dcsum_, d_sub_dcentry_, d_sub_changed_, d_sub_same_, d_sub_perm_;
     DevBuffer d_prog_snapshot_;  // per-scan session: the frame's store in front of the current scan
     uint64_t prog_snapshot_blocks_ = 0;
     DevBuffer d_dispose_;  // DisposeJob per frame that takes the generic Dispose() pass

@@ -720,42 +720,33 @@ __global__ __launch_bounds__(1024) void subseq_scan_kernel(const DevScan *__rest
 // (First version: the generic word reader and symbol decoder, 11.0 ms per 1024 x 4K against K2's 5.7.  Second, rounds 2-3:
 // K2's ring and symbol step with BLOCK-aligned ownership -- lanes at different blocks of their MCUs, so the tables were
 // picked per lane and a lock-step iteration mixed long luma with short chroma blocks: 8.3 ms.)
-constexpr int kSubFinalMaxWaves = JPGPU_SF_WAVES > kSubFinalPoolWaves ? JPGPU_SF_WAVES : kSubFinalPoolWaves;  // the launch picks subseq_final_waves(n_slots) / the pool's
-constexpr int kSfWaveBytes = kK2WaveBytes + 64 * 2 * (int)sizeof(uint32_t);  // K2's staging + rings, then (first MCU, count) per lane
-// One wave's 64 lanes: subsequences wk.first_interval + lane * kSubFinalSubsPerLane .. of scan wk.scan (tables staged, the wave's
-// coefficient staging zero on entry and on exit).
-__device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const DevScan &s, const DevScanStatus &st, const HuffWork wk,
-                                        const uint32_t *__restrict__ ends_u, DevScanStatus *__restrict__ status,
-                                        const uint32_t *__restrict__ exit_state, const uint32_t *__restrict__ first_block,
-                                        const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs, const uint8_t *tabs,
-                                        const uint32_t *blk_info, uint8_t *stage, uint8_t *ring, uint32_t *meta, uint32_t lane) {
-    const uint32_t ulen = ends_u[s.ends_off];
-    const uint32_t total_bits = ulen * 8;
-    // a lane takes kSubFinalSubsPerLane consecutive subsequences: half the lanes, but half the parsed-not-stored blocks and a
-    // narrower spread of MCU counts inside a wave (the wave iterates to its largest)
-    const uint32_t sub = wk.first_interval + lane * (uint32_t)kSubFinalSubsPerLane;  // (wk: the WAVE's 64 lanes)
+// What a lane of the final pass owns: the whole MCUs that START in its kSubFinalSubsPerLane subsequences (from `sub`).
+struct SfRange {
+    bool live;
+    uint32_t entry, my_first, my_end, skip;
+};
+__device__ __forceinline__ SfRange sf_lane_range(const DevScan &s, const uint32_t *__restrict__ exit_state, const uint32_t *__restrict__ first_block,
+                                                 uint32_t sub) {
     const uint32_t slot = s.sub_off + (sub < s.n_subs ? sub : 0);
-    const uint32_t total_mcus = s.total_mcus;
-    const uint32_t bpm = s.blocks_per_mcu;
-    const uint64_t coef_off = s.coef_off;
-    const bool closed_by_marker = st.terminator != 0;
-
-    bool live = sub < s.n_subs;
-    uint32_t entry = 0;
-    if (live && sub > 0) {
+    const uint32_t total_mcus = s.total_mcus, bpm = s.blocks_per_mcu;
+    SfRange r;
+    r.live = sub < s.n_subs;
+    r.entry = 0;
+    if (r.live && sub > 0) {
         const uint32_t prev = exit_state[slot - 1];
-        if (prev & kSubBad) live = false;  // the stream ended or failed in an earlier subsequence: reported by that lane
-        else entry = prev;
+        if (prev & kSubBad) r.live = false;  // the stream ended or failed in an earlier subsequence: reported by that lane
+        else r.entry = prev;
     }
-    uint32_t b_in_mcu = (entry >> 6) & 31u;
-    uint32_t i2 = ((entry >> 11) & 127u) * 2u;  // 2 x zig-zag position inside the block in progress at the entry
+    const uint32_t i2 = ((r.entry >> 11) & 127u) * 2u;  // 2 x zig-zag position inside the block in progress at the entry
     // first_block = blocks completed before the entry = index of the block in progress (i2 != 0: the previous lane's) or
     // about to start there.  This lane owns the MCUs from the first one that starts at or behind its entry ...
-    uint32_t my_first = total_mcus, my_end = total_mcus, skip = 0;
-    if (live) {
+    r.my_first = total_mcus;
+    r.my_end = total_mcus;
+    r.skip = 0;
+    if (r.live) {
         const uint32_t at = first_block[slot];
-        my_first = (at + (i2 != 0 ? 1u : 0u) + bpm - 1) / bpm;
-        skip = my_first * bpm - at;  // block ends between the entry and that MCU (the first of them may be half a block away)
+        r.my_first = (at + (i2 != 0 ? 1u : 0u) + bpm - 1) / bpm;
+        r.skip = r.my_first * bpm - at;  // block ends between the entry and that MCU (the first of them may be half a block away)
         // ... up to the first one that starts at or behind the next lane's entry (a stream that failed or ran out inside this
         // lane's subsequences leaves it everything that remains)
         const uint32_t n_mine = s.n_subs - sub < (uint32_t)kSubFinalSubsPerLane ? s.n_subs - sub : (uint32_t)kSubFinalSubsPerLane;
@@ -765,10 +756,82 @@ __device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const
             ex = exit_state[slot + q];
             open_end |= (ex & kSubBad) != 0;
         }
-        if (!open_end) my_end = (first_block[slot + n_mine] + ((((ex >> 11) & 127u) != 0) ? 1u : 0u) + bpm - 1) / bpm;
-        if (my_end > total_mcus) my_end = total_mcus;  // the reference stops after the last MCU
-        if (my_first > my_end) my_first = my_end;
+        if (!open_end) r.my_end = (first_block[slot + n_mine] + ((((ex >> 11) & 127u) != 0) ? 1u : 0u) + bpm - 1) / bpm;
+        if (r.my_end > total_mcus) r.my_end = total_mcus;  // the reference stops after the last MCU
+        if (r.my_first > r.my_end) r.my_first = r.my_end;
     }
+    return r;
+}
+
+// The lanes of a scan ORDERED by the number of MCUs they own (round 5).  A wave of the final pass iterates to the largest count
+// among its 64 lanes -- 35 where the mean is 31 on the benchmark's 4K frames: a tenth of the pass spent on lanes that have
+// finished.  Per group of kSubseqGatherSpan subsequences (512 lanes, one workgroup; the rounds' gather list) the lanes are
+// counting-sorted by their count: perm[sub_off + k] = the lane that takes place k.  Ownership does not change, only which 64
+// lanes share a wave; a lane's stream and its coefficient range were never its neighbours' anyway.
+__global__ __launch_bounds__(512) void subseq_order_kernel(const DevScan *__restrict__ scans, const HuffWork *__restrict__ work,
+                                                           const DevScanStatus *__restrict__ status, const uint32_t *__restrict__ exit_state,
+                                                           const uint32_t *__restrict__ first_block, uint32_t *__restrict__ perm) {
+    constexpr uint32_t kLanes = kSubseqGatherSpan / (uint32_t)kSubFinalSubsPerLane, kKeys = 256;
+    static_assert(kLanes == 512, "one thread per lane of the group");
+    __shared__ uint32_t hist[kKeys];
+    const HuffWork wk = work[blockIdx.x];
+    const DevScan &s = scans[wk.scan];
+    if (status[wk.scan].n_ends == 0) return;
+    const uint32_t tid = threadIdx.x;
+    if (tid < kKeys) hist[tid] = 0;
+    __syncthreads();
+    const uint32_t lane_index = wk.first_interval / (uint32_t)kSubFinalSubsPerLane + tid;
+    const uint32_t n_lanes = (s.n_subs + (uint32_t)kSubFinalSubsPerLane - 1) / (uint32_t)kSubFinalSubsPerLane;
+    const bool in_range = lane_index < n_lanes;
+    uint32_t key = 0;
+    if (in_range) {
+        const SfRange r = sf_lane_range(s, exit_state, first_block, lane_index * (uint32_t)kSubFinalSubsPerLane);
+        const uint32_t count = r.my_end - r.my_first;
+        key = count < kKeys - 1 ? count : kKeys - 1;
+    }
+    uint32_t rank_in_key = 0;
+    if (in_range) rank_in_key = atomicAdd(&hist[key], 1u);
+    __syncthreads();
+    // exclusive prefix over the keys (256 entries: one wave's worth of work, done by every lane's own walk over LDS would be 256
+    // reads; four threads per ... keep it simple: thread k sums the keys below k)
+    __shared__ uint32_t base[kKeys];
+    if (tid < kKeys) {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < tid; k++) acc += hist[k];
+        base[tid] = acc;
+    }
+    __syncthreads();
+    if (in_range) perm[s.sub_off + wk.first_interval / (uint32_t)kSubFinalSubsPerLane + base[key] + rank_in_key] = lane_index;
+}
+
+constexpr int kSubFinalMaxWaves = JPGPU_SF_WAVES > kSubFinalPoolWaves ? JPGPU_SF_WAVES : kSubFinalPoolWaves;  // the launch picks subseq_final_waves(n_slots) / the pool's
+constexpr int kSfWaveBytes = kK2WaveBytes + 64 * 2 * (int)sizeof(uint32_t);  // K2's staging + rings, then (first MCU, count) per lane
+// One wave's 64 lanes: subsequences wk.first_interval + lane * kSubFinalSubsPerLane .. of scan wk.scan (tables staged, the wave's
+// coefficient staging zero on entry and on exit).
+__device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const DevScan &s, const DevScanStatus &st, const HuffWork wk,
+                                        const uint32_t *__restrict__ ends_u, DevScanStatus *__restrict__ status,
+                                        const uint32_t *__restrict__ exit_state, const uint32_t *__restrict__ first_block,
+                                        const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs, const uint8_t *tabs,
+                                        const uint32_t *blk_info, uint8_t *stage, uint8_t *ring, uint32_t *meta, uint32_t lane,
+                                        const uint32_t *__restrict__ perm) {
+    const uint32_t ulen = ends_u[s.ends_off];
+    const uint32_t total_bits = ulen * 8;
+    // a lane takes kSubFinalSubsPerLane consecutive subsequences: half the lanes, but half the parsed-not-stored blocks and a
+    // narrower spread of MCU counts inside a wave (the wave iterates to its largest)
+    // (perm: the lanes of a scan in the order subseq_order_kernel put them in -- waves of lanes that own about as many MCUs)
+    const uint32_t lane_index = wk.first_interval / (uint32_t)kSubFinalSubsPerLane + lane;
+    const uint32_t n_lanes = (s.n_subs + (uint32_t)kSubFinalSubsPerLane - 1) / (uint32_t)kSubFinalSubsPerLane;
+    const uint32_t sub = (perm != nullptr && lane_index < n_lanes ? perm[s.sub_off + lane_index] : lane_index) * (uint32_t)kSubFinalSubsPerLane;
+    const uint32_t slot = s.sub_off + (sub < s.n_subs ? sub : 0);
+    const uint32_t total_mcus = s.total_mcus;
+    const uint32_t bpm = s.blocks_per_mcu;
+    const uint64_t coef_off = s.coef_off;
+    const bool closed_by_marker = st.terminator != 0;
+    const SfRange rg = sf_lane_range(s, exit_state, first_block, sub);
+    const bool live = rg.live;
+    const uint32_t entry = rg.entry, my_first = rg.my_first, my_end = rg.my_end, skip = rg.skip;
+    uint32_t b_in_mcu = (entry >> 6) & 31u;
+    uint32_t i2 = ((entry >> 11) & 127u) * 2u;  // 2 x zig-zag position inside the block in progress at the entry
     const uint32_t count = my_end - my_first;
     meta[lane * 2] = my_first;
     meta[lane * 2 + 1] = count;
@@ -912,7 +975,8 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
                                                                            const uint32_t *__restrict__ exit_state,
                                                                            const uint32_t *__restrict__ first_block,
                                                                            const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs,
-                                                                           int n_slots, uint32_t n_chunks, uint32_t *__restrict__ counter) {
+                                                                           int n_slots, uint32_t n_chunks, uint32_t *__restrict__ counter,
+                                                                           const uint32_t *__restrict__ perm) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t n_waves = blockDim.x >> 6;
     uint8_t *tabs = smem;                                                    // n_slots * kK2TabBytes
@@ -933,7 +997,7 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
     __syncthreads();
     if (!POOL) {
         const HuffWork wk = {wk0.scan, wk0.first_interval + wave * 64u * (uint32_t)kSubFinalSubsPerLane};
-        sf_wave(udata, scans[wk.scan], status[wk.scan], wk, ends_u, status, exit_state, first_block, dc_entry, coefs, tabs, blk_info, stage, ring, meta, lane);
+        sf_wave(udata, scans[wk.scan], status[wk.scan], wk, ends_u, status, exit_state, first_block, dc_entry, coefs, tabs, blk_info, stage, ring, meta, lane, perm);
     } else {
         for (;;) {
             uint32_t c = 0;
@@ -943,7 +1007,7 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
             const HuffWork wk = work[c];
             const DevScanStatus st = status[wk.scan];
             if (st.n_ends == 0) continue;
-            sf_wave(udata, scans[wk.scan], st, wk, ends_u, status, exit_state, first_block, dc_entry, coefs, tabs, blk_info, stage, ring, meta, lane);
+            sf_wave(udata, scans[wk.scan], st, wk, ends_u, status, exit_state, first_block, dc_entry, coefs, tabs, blk_info, stage, ring, meta, lane, perm);
         }
     }
 }
@@ -1071,7 +1135,7 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
                                 int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work,
                                 uint32_t *same_dist, bool *same_valid, int device_rounds, const HuffWork *gather_work, int n_gather,
-                                const HuffWork *pool_work, const SubseqPool *pools, int n_pools, int num_cus) {
+                                const HuffWork *pool_work, const SubseqPool *pools, int n_pools, int num_cus, uint32_t *lane_perm) {
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const uint32_t *final_state = nullptr;
     hipError_t e = launch_subseq_sync(stream, udata, scans, work, n_work, scan_ids, n_scans, ends_u, status, huff_pool, exit_a, exit_b, nblk,
@@ -1079,6 +1143,12 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                       &final_state, same_dist, same_valid, device_rounds, gather_work, n_gather);
     if (e != hipSuccess) return e;
     static std::atomic<uint64_t> configured{0}, configured_pool{0};
+    static const bool no_order = getenv("JPGPU_SF_NO_ORDER") != nullptr;  // A/B switch
+    const uint32_t *perm = nullptr;
+    if (lane_perm != nullptr && gather_work != nullptr && n_gather > 0 && !no_order) {
+        hipLaunchKernelGGL(subseq_order_kernel, dim3(n_gather), dim3(512), 0, stream, scans, gather_work, status, final_state, first_block, lane_perm);
+        perm = lane_perm;
+    }
     if (n_final_work > 0) {
         const int waves = subseq_final_waves(n_slots);
         const size_t lds_final = (size_t)n_slots * kK2TabBytes + (size_t)waves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
@@ -1086,7 +1156,7 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
         if (ea != hipSuccess) return ea;
         // final_work: (scan, first subsequence) per workgroup of waves * 64 lanes (the rounds' work list is per 256)
         hipLaunchKernelGGL(subseq_final_kernel<false>, dim3(n_final_work), dim3(64 * waves), lds_final, stream, udata, scans, final_work, ends_u, status,
-                           huff_pool, lut_pool, final_state, first_block, (const int4 *)dc_entry, coefs, n_slots, 0u, (uint32_t *)nullptr);
+                           huff_pool, lut_pool, final_state, first_block, (const int4 *)dc_entry, coefs, n_slots, 0u, (uint32_t *)nullptr, perm);
     }
     if (n_pools > 0) {
         // (the counters live in the control words every launch_subseq_sync clears; a host-checked launch clears the first 64 only)
@@ -1101,7 +1171,7 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
             const int groups = std::min(num_cus > 0 ? num_cus : 256, (pools[p].count + kSubFinalPoolWaves - 1) / kSubFinalPoolWaves);
             hipLaunchKernelGGL(subseq_final_kernel<true>, dim3(groups), dim3(64 * kSubFinalPoolWaves), lds_pool, stream, udata, scans,
                                pool_work + pools[p].first, ends_u, status, huff_pool, lut_pool, final_state, first_block, (const int4 *)dc_entry, coefs,
-                               n_slots, (uint32_t)pools[p].count, changed_dev + kSubseqCtlPoolCounter + p);
+                               n_slots, (uint32_t)pools[p].count, changed_dev + kSubseqCtlPoolCounter + p, perm);
         }
     }
     return hipGetLastError();

@@ -52,6 +52,8 @@ def _compare(files, fmt=jl.FMT_INTERLEAVED_U8):
             continue
         res = b.result(i)
         kind = "OK" if err is None else err.kind
+        if NAMES.get(res.status) == "NotSupportedException" and res.detail == 6 and kind != "NotSupportedException":
+            continue  # one of the fences of DESIGN.md 5 (a middle scan that leaves a byte unread in front of its marker, ...): refused by design
         assert NAMES.get(res.status) == kind, (i, kind, res.status, res.detail)
         if b.image_info(i).status == 0:
             got = b.output(i)
@@ -61,9 +63,12 @@ def _compare(files, fmt=jl.FMT_INTERLEAVED_U8):
     return failing
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
 @pytest.mark.parametrize("sub,dri,non", [("420", 4, False), ("420", 0, False), ("444", 1, False), ("422", 3, False), ("444", 0, True), ("444", 5, True), ("420", 7, False)])
-def test_failing_baseline_files_leave_the_writer_as_the_reference_does(sub, dri, non):
-    rng = np.random.default_rng(hash((sub, dri, non)) & 0xFFFF)
+def test_failing_baseline_files_leave_the_writer_as_the_reference_does(sub, dri, non, seed):
+    import zlib
+
+    rng = np.random.default_rng(zlib.crc32(repr((sub, dri, non, seed)).encode()))  # (not hash(): that differs from process to process)
     base = [jpegsynth.encode(int(rng.integers(40, 300)), int(rng.integers(40, 220)), sub, int(rng.integers(30, 95)), dri, seed=int(rng.integers(1, 1 << 20)),
                              noninterleaved=non) for _ in range(6)]
     files = [_corrupt(base[k % len(base)], rng) for k in range(60)] + base[:2]
