@@ -1566,7 +1566,9 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                    a.blocks_per_mcu == b.blocks_per_mcu && memcmp(a.blk_comp, b.blk_comp, sizeof a.blk_comp) == 0 &&
                    memcmp(a.comp, b.comp, sizeof a.comp) == 0;
         };
-        const uint32_t lanes_subs = 64u * (uint32_t)kSubFinalSubsPerLane;
+        // (a batch that cannot fill the machine with two subsequences per lane takes one: twice the waves, half as long each)
+        sub_final_spl_ = (kSubFinalSubsPerLane >= 2 && total_subs_ >= kSubFinalFewSubs && getenv("JPGPU_SF_ONE_SUB") == nullptr) ? 2 : 1;
+        const uint32_t lanes_subs = 64u * (uint32_t)sub_final_spl_;
         std::vector<HuffWork> pooled;
         size_t i = 0;
         while (i < sub_scan_ids_.size()) {
@@ -1856,7 +1858,7 @@ int DeviceBatch::run_huffman() {
                                  &last_subseq_rounds_, (const uint8_t *)d_lut_pool_.ptr, (const HuffWork *)d_sub_final_work_.ptr, n_sub_final_work_,
                                  (uint32_t *)d_sub_same_.ptr, &sub_same_valid_, device_rounds, (const HuffWork *)d_sub_work_.ptr + n_sub_work_, n_sub_gather_,
                                  (const HuffWork *)d_sub_final_work_.ptr + n_sub_final_work_, sub_pools_.data(), (int)sub_pools_.size(), ctx_->num_cus,
-                                 (uint32_t *)d_sub_perm_.ptr);
+                                 (uint32_t *)d_sub_perm_.ptr, sub_final_spl_);
         if (e != hipSuccess) return hip_fail(e, "subsequence decode");
     }
     const int rc = run_progressive();

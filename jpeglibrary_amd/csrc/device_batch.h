@@ -249,7 +249,7 @@ class DeviceBatch {
     int clear_progressive_stores();
   private:
     bool sub_same_valid_ = false;  // d_sub_same_ holds the twins of this upload's subsequences (subseq_same_kernel)
-    int n_sub_work_ = 0, n_sub_gather_ = 0, n_sub_scans_ = 0, n_sub_final_work_ = 0;
+    int n_sub_work_ = 0, n_sub_gather_ = 0, n_sub_scans_ = 0, n_sub_final_work_ = 0, sub_final_spl_ = 2;
     DevBuffer d_sub_final_work_;
     std::vector<SubseqPool> sub_pools_;  // pooled runs of the final pass: entries of d_sub_final_work_ behind the first n_sub_final_work_
     uint32_t total_subs_ = 0, max_subs_per_scan_ = 0;

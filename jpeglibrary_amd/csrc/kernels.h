@@ -59,7 +59,10 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
                                 int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work,
                                 uint32_t *same_dist, bool *same_valid, int device_rounds, const HuffWork *gather_work, int n_gather,
-                                const HuffWork *pool_work, const SubseqPool *pools, int n_pools, int num_cus, uint32_t *lane_perm);
+                                const HuffWork *pool_work, const SubseqPool *pools, int n_pools, int num_cus, uint32_t *lane_perm, int subs_per_lane);
+// subs_per_lane: subsequences a lane of the final pass takes (the work lists are built for it): kSubFinalSubsPerLane for batches that
+// fill the machine, 1 below kSubFinalFewSubs subsequences in the batch (a lone 67-Mpixel canvas: twice the waves, half as long each)
+constexpr uint64_t kSubFinalFewSubs = 1u << 20;
 // lane_perm: one uint32 per subsequence -- the final pass's lanes of every scan ordered by the MCUs they own (subseq_order_kernel)
 // changed_dev: kSubseqCtlWords uint32 (exits changed per round, the device-driven rounds' state; word kSubseqCtlSameDone is
 // cleared once per upload, the rest by every launch).  device_rounds > 0: that many rounds enqueued, nothing read back, the
