@@ -2129,14 +2129,16 @@ int DeviceBatch::decode() {
     decodes_since_query_++;
     int rc;
     hipStream_t s1 = ctx_->stream, s2 = ctx_->stream2;
-    (void)hipEventRecord(ev[0], s1);
+    // (a stage event that could not be recorded would turn jpgpu_batch_stage_ms -- bench.py's roofline -- into a silent lie: checked)
+    auto mark = [&](int k, hipStream_t st) { return hipEventRecord(ev[k], st) == hipSuccess ? JPGPU_OK : hip_fail(hipGetLastError(), "hipEventRecord(stage)"); };
+    if ((rc = mark(0, s1)) != JPGPU_OK) return rc;
     if (serial) {
         if ((rc = run_marker_index()) != JPGPU_OK) return rc;
-        (void)hipEventRecord(ev[1], s1);
+        if ((rc = mark(1, s1)) != JPGPU_OK) return rc;
         if ((rc = run_huffman()) != JPGPU_OK) return rc;
-        (void)hipEventRecord(ev[2], s1);
+        if ((rc = mark(2, s1)) != JPGPU_OK) return rc;
         if ((rc = run_idct()) != JPGPU_OK) return rc;
-        (void)hipEventRecord(ev[3], s1);
+        if ((rc = mark(3, s1)) != JPGPU_OK) return rc;
     } else {
         status_valid_ = false;
         const YccRgbFactors kf = ycc_rgb_factors();
@@ -2152,17 +2154,15 @@ int DeviceBatch::decode() {
                                idct_split_begin_[half], (const DevScanStatus *)d_status_.ptr, (const DevQuantTable *)d_quant_pool_.ptr,
                                (uint8_t *)d_out_.ptr, format_, kf, (uint8_t *)d_rgb_scratch_.ptr);
         };
-        static const int mode = getenv("JPGPU_OVERLAP_MODE") ? atoi(getenv("JPGPU_OVERLAP_MODE")) : 1;
-        if (mode == 2) (void)hipEventRecord(ev[1], s1);  // experiment: the second half starts right behind K1
         if ((e = k2(s1, 0, huff_split_)) != hipSuccess) return hip_fail(e, "huffman_decode_kernel");
-        if (mode != 2) (void)hipEventRecord(ev[1], s1);  // K1 and K2(A) are done: the second half may start
+        if ((rc = mark(1, s1)) != JPGPU_OK) return rc;  // K1 and K2(A) are done: the second half may start
         if ((e = hipStreamWaitEvent(s2, ev[1], 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
         if ((e = k2(s2, huff_split_, n_huff_work_ - huff_split_)) != hipSuccess) return hip_fail(e, "huffman_decode_kernel");
         if ((e = k3(s1, 0)) != hipSuccess) return hip_fail(e, "idct_output_kernel");
         if ((e = k3(s2, 1)) != hipSuccess) return hip_fail(e, "idct_output_kernel");
-        (void)hipEventRecord(ev[2], s2);
+        if ((rc = mark(2, s2)) != JPGPU_OK) return rc;
         if ((e = hipStreamWaitEvent(s1, ev[2], 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");  // join
-        (void)hipEventRecord(ev[3], s1);
+        if ((rc = mark(3, s1)) != JPGPU_OK) return rc;
     }
     ev_serial_.push_back(serial);
     ev_used_ += 4;
