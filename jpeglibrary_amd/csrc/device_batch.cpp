@@ -1226,7 +1226,10 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     sub_same_valid_ = false;
     k2s_budget_ = 0;
     k2s_unchecked_ = k2s_idct_behind_ = false;
-    k2s_host_checked_ = getenv("JPGPU_SUBSEQ_HOST_CHECK") != nullptr;  // A/B switch: the host reads the counts between rounds
+    // (A/B switch: the host reads the counts between rounds.  Always so over a CALLER'S CANVAS: the device-driven rounds let the
+    // output stage run before anybody knows whether they sufficed, and what that stage writes from unconverged states a second,
+    // correct pass does not take back where it leaves the canvas alone -- tests/golden/stress/baseline_failing_422_canvas_54.jpg)
+    k2s_host_checked_ = getenv("JPGPU_SUBSEQ_HOST_CHECK") != nullptr || keep_canvas_;
     dispose_jobs_.clear();
     dispose_max_blocks_ = 0;
     std::vector<IdctWork> idct_work;
@@ -2401,9 +2404,9 @@ int DeviceBatch::result(int i, jpgpu_image_result *res) {
         res->terminator = st.terminator;
         res->bytes_consumed = st.end_pos;
         if (st.first_error != kNoError && getenv("JPGPU_DEBUG_STATUS"))
-            fprintf(stderr, "[jpgpu] image %d job %d kind %d Ss %d Se %d Ah %d Al %d comps %d: first_error %08x decoded %u of %u end_pos %u\n", i, j,
+            fprintf(stderr, "[jpgpu] image %d job %d kind %d Ss %d Se %d Ah %d Al %d comps %d: first_error %08x decoded %u of %u end_pos %u fail_block %u (bpm %u) shadow %02x\n", i, j,
                     (int)jobs_[j].kind, jobs_[j].ss, jobs_[j].se, jobs_[j].ah, jobs_[j].al, jobs_[j].scan_components, st.first_error, st.decoded_mcus,
-                    h_scans_[j].total_mcus, st.end_pos);
+                    h_scans_[j].total_mcus, st.end_pos, st.pad[1] ? kFailBlockBase - st.pad[1] : 0xFFFFFFFFu, (unsigned)h_scans_[j].blocks_per_mcu, (unsigned)h_scans_[j].shadow_mask);
         if (st.first_error != kNoError) {
             const uint32_t detail = st.first_error & 0xFF;
             res->detail = (int32_t)detail;

@@ -149,3 +149,24 @@ def test_decoder_mirror_leaves_the_callers_buffer_like_the_reference():
             assert np.array_equal(got, px), (sub, dri, int((got != px).sum()))
             done += err is not None
     assert done >= 8
+
+
+def test_a_failing_dri0_scan_over_the_callers_canvas_that_needs_many_rounds():
+    """tools/stress_parity.py, session mode, seed 7: a 4:2:2 DRI = 0 scan that fails near its end and whose subsequence states take
+    more rounds than the device-driven budget.  The optimistic output stage then ran on unconverged states and wrote chroma blocks
+    of MCUs the scan never reached into the caller's buffer; the correct second pass leaves a canvas alone where the scan did not
+    get to, so they stayed.  Over a caller's canvas the rounds are host-checked now."""
+    data = read_jpeg(os.path.join("stress", "baseline_failing_422_canvas_54.jpg"))
+    px, _, err = po.decode_8bit_partial(data)
+    assert err is not None
+    d = jl.JpegDecoder()
+    d.SetInput(data)
+    d.Identify()
+    out = np.zeros(d.Width * d.Height * 3, np.uint8)
+    d.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(d.Width, d.Height, 3, out))
+    with pytest.raises(jl.InvalidDataException):
+        d.Decode()
+    assert np.array_equal(out.reshape(px.shape), px)
+    b = jl.Batch().upload([data], jl.FMT_INTERLEAVED_U8).decode().sync()  # (the batch's own buffer: the second pass rewrites everything)
+    assert np.array_equal(b.output(0), px) and b.subseq_fallbacks() == 1
+    b.close()

@@ -336,9 +336,9 @@ def test_a_failing_scan_leaves_the_session_store_as_the_reference_leaves_it(seed
         if (st["err"] is None) != (err is None):
             st["dec"].close()
             continue  # (the failure is the marker walk's -- a late error of Decode's loop --, not a scan's)
-        if st["err"] is not None and type(st["err"]).__name__ != err.kind:
+        if st["err"] is not None and (type(st["err"]).__name__ != err.kind or "at offset" in str(err)):
             st["dec"].close()
-            continue
+            continue  # ("... at offset N ...": the reference's marker walk gave up, not a scan)
         fh = st["fh"]
         if fh.NumberOfComponents != info.ncomp or fh.SamplesPerLine != info.width:
             st["dec"].close()

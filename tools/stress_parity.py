@@ -290,6 +290,93 @@ for i, ((kind, px), out, res) in enumerate(zip(prefs, outs, results)):
         keep("pdecpx", i, pmut[i])
     n_partial += kind != "OK" and px is not None and out is not None
 
+# ---- the per-scan boundaries (round 5): the same corrupted files through the entry points a caller with its own marker loop
+# uses -- JpegDecoder.Decode() into a JpegBufferOutputWriter8Bit over the caller's buffer (one device call per scan over that
+# canvas), and for progressive files jpgpu_progressive_begin / _scan / _dispose driven by the marker walk of
+# tests/test_per_scan_gpu.py -- against the restatement's writer buffer, failing files included
+n_session = 0
+if os.environ.get("STRESS_NO_SESSION") is None:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from test_per_scan_gpu import Walk
+
+    for i, f in enumerate(mut[:120]):
+        try:
+            px, info, err = po.decode_8bit_partial(f)
+        except po.OracleError:
+            continue
+        d = jl.JpegDecoder()
+        try:
+            d.SetInput(f)
+            d.Identify()
+            if d.NumberOfComponents != info.ncomp or d.Width != info.width or d.Height != info.height:
+                continue
+            buf = np.zeros(d.Width * d.Height * d.NumberOfComponents, np.uint8)
+            d.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(d.Width, d.Height, d.NumberOfComponents, buf))
+            kind = "OK"
+            try:
+                d.Decode()
+            except jl.JpegError as e:
+                kind = type(e).__name__
+                if kind == "NotSupportedException" and (err is None or err.kind != kind):
+                    continue  # a documented fence
+            want = "OK" if err is None else err.kind
+            n_session += 1
+            if kind != want:
+                bad += 1
+                print("session decode status", i, want, kind)
+                keep("sdec", i, f)
+            elif not np.array_equal(buf.reshape(px.shape), px):
+                bad += 1
+                print("session decode pixels", i, want)
+                keep("sdecpx", i, f)
+        except jl.JpegError:
+            continue
+        finally:
+            d.close()
+    for i, f in enumerate(pmut[:80]):
+        try:
+            px, info, err = po.decode_8bit_partial(f)
+        except po.OracleError:
+            continue
+        w = Walk(f)
+        st = {"dec": None, "err": None, "fh": None}
+
+        def on_frame(marker, fh):
+            if marker != 0xC2:
+                raise jl.NotSupportedException("not a progressive frame")
+            st["fh"], st["dec"] = fh, jl.JpegGpuProgressiveScanDecoder(fh)
+
+        def on_scan(entropy, sh):
+            if st["err"] is not None or st["dec"] is None:
+                return 0
+            try:
+                return st["dec"].ProcessScan(entropy, sh, w.quantization_tables(), w.huffman_tables(), w.dri)
+            except jl.JpegError as e:
+                st["err"] = e
+                return 0
+
+        try:
+            w.run(on_frame, on_scan)
+        except Exception:
+            pass  # a header this walk does not read the way the reference does: the batch entry points cover those files
+        else:
+            fh = st["fh"]
+            # (only where the failure is a SCAN's: "... at offset N. ..." is the reference's marker walk giving up -- a table that
+            # does not parse, a segment that runs past the file -- and this tool's own walk is not that walk)
+            same_failure = (st["err"] is None) == (err is None) and (st["err"] is None or (type(st["err"]).__name__ == err.kind and "at offset" not in str(err)))
+            if st["dec"] is not None and same_failure and fh.NumberOfComponents == info.ncomp and fh.SamplesPerLine == info.width:
+                try:
+                    out = st["dec"].Dispose(fmt=jl.FMT_INTERLEAVED_U8).reshape(fh.NumberOfLines, fh.SamplesPerLine, fh.NumberOfComponents)
+                    n_session += 1
+                    if not np.array_equal(out, px):
+                        bad += 1
+                        print("session progressive pixels", i, None if err is None else err.kind)
+                        keep("spdecpx", i, f)
+                except jl.NotSupportedException:
+                    pass
+        if st["dec"] is not None:
+            st["dec"].close()
+
 # ---- encoder: random images / samplings / qualities / table modes, grouped by the parameters one batch shares
 n_enc = 0
 groups = {}
@@ -322,5 +409,5 @@ for (luma, q, mode, rgb, ri), imgs in groups.items():
             bad += 1
             print("encode", luma, q, mode, rgb, ri, im.shape, None if got is None else len(got), None if ref is None else len(ref))
     e.close()
-print(f"stress: {n} files, {sum(k[3] for k in kinds)} progressive, {n_opt} optimizer outputs compared, {n_enc} encoder outputs compared, {n_mut} corrupted files ({n_partial_baseline} failing baseline writers + {n_partial} partial progressive flushes compared), mismatches: {bad}")
+print(f"stress: {n} files, {sum(k[3] for k in kinds)} progressive, {n_opt} optimizer outputs compared, {n_enc} encoder outputs compared, {n_mut} corrupted files ({n_partial_baseline} failing baseline writers + {n_partial} partial progressive flushes compared), {n_session} per-scan sessions compared, mismatches: {bad}")
 sys.exit(1 if bad else 0)
