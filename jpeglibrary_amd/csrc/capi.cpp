@@ -742,10 +742,9 @@ class GpuScanHandler final : public ScanHandler {
         reader.try_advance((int)oc.reader_advance);
     }
     void on_dispose(HostDecoder &dec) override {
-        if (std::current_exception()) {  // Decode() is failing: the reference flushes a partial store, we flush nothing
-            prog_.reset();
-            return;
-        }
+        // (Decode() failing in its marker walk: the reference's `finally` still disposes the scan decoder, which transforms and
+        // flushes what the scans in front of the failure left in the store -- JpegDecoder.cs:545-549; so does this.  The
+        // failure that ended the walk is the one the caller sees: HostDecoder::decode swallows what this throws then.)
         dispose_progressive(dec);
     }
 
@@ -772,18 +771,23 @@ class GpuScanHandler final : public ScanHandler {
         memset(&res, 0, sizeof res);
         if (rc == JPGPU_OK) rc = batch.result(0, &res);
         if (rc != JPGPU_OK) throw DecodeError(rc, "GPU progressive decode failed (see jpgpu_last_error)");
-        if (res.status != JPGPU_OK) throw_for_result(res);
+        // A scan that failed: the writer still receives the flush of the store as that scan left it (the batch has issued the failed
+        // frame again in file order up to the throw: DeviceBatch::replay_failed_progressive), THEN the exception leaves.
+        const bool unsupported = res.status == JPGPU_ERR_NOT_SUPPORTED;
         const ImagePlan &img = *batch.image(0);
-        if (direct) {
-            if (batch.download_output(0, d_->sink8.out, (size_t)fh.samples_per_line * fh.lines * fh.num_components) != JPGPU_OK)
-                throw DecodeError(JPGPU_ERR_DEVICE, "output download failed");
-            return;
+        if (!unsupported && img.status == JPGPU_OK) {
+            if (direct) {
+                if (batch.download_output(0, d_->sink8.out, (size_t)fh.samples_per_line * fh.lines * fh.num_components) != JPGPU_OK)
+                    throw DecodeError(JPGPU_ERR_DEVICE, "output download failed");
+            } else {
+                std::vector<uint8_t> planes(img.out_bytes);
+                if (batch.download_output(0, planes.data(), planes.size()) != JPGPU_OK) throw DecodeError(JPGPU_ERR_DEVICE, "output download failed");
+                jpgpu_write_block_fn fn = d_->writer == jpgpu_decoder::kBuffer8 ? HostSink8::write : d_->fn;
+                void *user = d_->writer == jpgpu_decoder::kBuffer8 ? (void *)&d_->sink8 : d_->user;
+                flush_planes_to_writer(frame.geo(), img, planes.data(), fn, user);
+            }
         }
-        std::vector<uint8_t> planes(img.out_bytes);
-        if (batch.download_output(0, planes.data(), planes.size()) != JPGPU_OK) throw DecodeError(JPGPU_ERR_DEVICE, "output download failed");
-        jpgpu_write_block_fn fn = d_->writer == jpgpu_decoder::kBuffer8 ? HostSink8::write : d_->fn;
-        void *user = d_->writer == jpgpu_decoder::kBuffer8 ? (void *)&d_->sink8 : d_->user;
-        flush_planes_to_writer(frame.geo(), img, planes.data(), fn, user);
+        if (res.status != JPGPU_OK) throw_for_result(res);
     }
 
     jpgpu_decoder *d_;

@@ -992,7 +992,9 @@ int DeviceBatch::upload_progressive_frame(const ProgressiveFrame &frame, const u
     }
     std::vector<const uint8_t *> fp(1, file);
     std::vector<size_t> fl(1, file_len);
-    return layout_and_upload(fp, fl);
+    const int rc = layout_and_upload(fp, fl);
+    replay_possible_ = rc == JPGPU_OK;  // (a scan that fails: the frame is issued again in file order up to the throw, like a file of a batch)
+    return rc;
 }
 
 int DeviceBatch::upload_progressive_scan(const ProgressiveFrame &frame, int scan_index, bool first_scan) {

@@ -165,3 +165,34 @@ def _fails_in_a_scan(f):
     except po.OracleError:
         return False
     return err is not None
+
+
+def test_the_decoder_mirror_flushes_the_partial_store_before_the_exception_leaves():
+    """JpegDecoder.Decode() of a failing progressive file (level 3, one image): the mirror collects the scans during the walk and
+    decodes them at Dispose; when one fails -- or the walk itself fails behind some scans -- the writer now receives the flush the
+    reference's `finally` makes (JpegDecoder.cs:545-549) and then the exception leaves (round 4: "we flush nothing")."""
+    done = 0
+    for f in _corrupted_progressive(60, 21):
+        try:
+            px, info, err = po.decode_8bit_partial(f)
+        except po.OracleError:
+            continue
+        if err is None or "at offset" in str(err):
+            continue  # (clean, or the walk's own failures: their order against a later scan's is the batch entry points' business)
+        d = jl.JpegDecoder()
+        d.SetInput(f)
+        d.Identify()
+        buf = np.zeros(d.Width * d.Height * d.NumberOfComponents, np.uint8)
+        d.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(d.Width, d.Height, d.NumberOfComponents, buf))
+        try:
+            d.Decode()
+            raised = None
+        except jl.JpegError as e:
+            raised = type(e).__name__
+        d.close()
+        if raised == "NotSupportedException" and err.kind != raised:
+            continue
+        assert raised == err.kind, (raised, err)
+        assert np.array_equal(buf.reshape(px.shape), px), (str(err), int((buf.reshape(px.shape) != px).sum()))
+        done += 1
+    assert done >= 12, done
