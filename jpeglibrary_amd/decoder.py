@@ -169,14 +169,19 @@ def _tables_c(quantizationTables, huffmanTables):  # noqa: N803
     """(qt[4][64], qt_present[4], dht[2][4]) for the per-scan entry points, from the decoder-registry-style lists."""
     qt = np.zeros((4, 64), np.uint16)
     present = np.zeros(4, np.uint8)
+    # (the reference finds a table by its EXACT class and identifier -- GetHuffmanTable / GetQuantizationTable, JpegDecoder.cs:869-884,
+    # 910-925 --, so a registry entry a corrupted DHT left under class 9 or identifier 7 is never the one a scan uses: such entries
+    # are not handed over; folding them into [class & 1][identifier & 3] replaced live tables: tools/stress_parity.py, session mode)
     for q in quantizationTables or []:
-        if q is None or q.IsEmpty:
+        if q is None or q.IsEmpty or not 0 <= q.Identifier <= 3:
             continue
-        qt[q.Identifier & 3] = np.asarray(q.Elements, np.uint16)
-        present[q.Identifier & 3] = 1
+        qt[q.Identifier] = np.asarray(q.Elements, np.uint16)
+        present[q.Identifier] = 1
     dht = ((_capi.Dht * 4) * 2)()
     for t in huffmanTables or []:
-        d = dht[t.TableClass & 1][t.Identifier & 3]
+        if t.TableClass not in (0, 1) or not 0 <= t.Identifier <= 3:
+            continue
+        d = dht[t.TableClass][t.Identifier]
         d.present = 1
         for i in range(16):
             d.bits[i] = t.bits[i]

@@ -353,3 +353,34 @@ def test_a_failing_scan_leaves_the_session_store_as_the_reference_leaves_it(seed
         compared += 1
         failing += err is not None
     assert compared >= 30 and failing >= 15, (compared, failing)
+
+
+def test_a_registry_entry_under_an_unknown_table_class_is_never_the_table_a_scan_uses():
+    """tools/stress_parity.py (session mode, header corruptions), seed 52: a DHT whose class / identifier byte has a flipped bit (0x90:
+    class 9) is registered but never FOUND by GetHuffmanTable(isDc, identifier) (JpegDecoder.cs:869-884, exact match) -- the scan
+    behind it decodes with the OLD AC table and fails in its first restart interval.  The Python mirror of the C# twin's MarshalTables
+    folded the entry into dht[class & 1][identifier & 3] and replaced the live table: the scan "succeeded"."""
+    data = read_jpeg("stress/progressive_session_header_16.jpg")
+    px, info, err = po.decode_8bit_partial(data)
+    assert err is not None and err.kind == "InvalidOperationException"
+    w = Walk(data)
+    st = {"dec": None, "err": None, "n": 0}
+
+    def on_frame(marker, fh):
+        st["fh"], st["dec"] = fh, jl.JpegGpuProgressiveScanDecoder(fh)
+
+    def on_scan(entropy, sh):
+        if st["err"] is None:
+            try:
+                st["dec"].ProcessScan(entropy, sh, w.quantization_tables(), w.huffman_tables(), w.dri)
+                st["n"] += 1
+            except jl.JpegError as e:
+                st["err"] = e
+        return 0
+
+    w.run(on_frame, on_scan)
+    assert st["n"] == 3 and type(st["err"]).__name__ == "InvalidOperationException"  # the fourth scan, like the whole-file decode
+    fh = st["fh"]
+    out = st["dec"].Dispose(fmt=jl.FMT_INTERLEAVED_U8).reshape(fh.NumberOfLines, fh.SamplesPerLine, fh.NumberOfComponents)
+    st["dec"].close()
+    assert np.array_equal(out, px)

@@ -12,8 +12,11 @@ from oracle import pyoracle as po  # noqa: E402
 from test_partial_flush_gpu import _corrupted_progressive  # noqa: E402
 from test_per_scan_gpu import Walk  # noqa: E402
 
-seed = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-files = _corrupted_progressive(int(sys.argv[2]) if len(sys.argv) > 2 else 30, seed)
+if len(sys.argv) > 1 and os.path.exists(sys.argv[1]):
+    files = [open(sys.argv[1], "rb").read()]
+else:
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    files = _corrupted_progressive(int(sys.argv[2]) if len(sys.argv) > 2 else 30, seed)
 for k, data in enumerate(files):
     try:
         px, info, err = po.decode_8bit_partial(data)
@@ -31,8 +34,11 @@ for k, data in enumerate(files):
             return 0
         st["scans"].append((sh.NumberOfComponents, sh.StartOfSpectralSelection, sh.EndOfSpectralSelection, sh.SuccessiveApproximationBitPositionHigh, sh.SuccessiveApproximationBitPositionLow, w.dri))
         try:
-            return st["dec"].ProcessScan(entropy, sh, w.quantization_tables(), w.huffman_tables(), w.dri)
+            r = st["dec"].ProcessScan(entropy, sh, w.quantization_tables(), w.huffman_tables(), w.dri)
+            print("   scan", len(st["scans"]) - 1, st["scans"][-1], "OK", len(entropy))
+            return r
         except jl.JpegError as e:
+            print("   scan", len(st["scans"]) - 1, st["scans"][-1], type(e).__name__, e)
             st["err"] = e
             return 0
     try:
@@ -46,5 +52,8 @@ for k, data in enumerate(files):
     whole, res = jl.decode_batch([data])
     d_or = int((out != px).sum()) if out.shape == px.shape else -1
     d_wh = int((np.asarray(whole[0]) != px).sum()) if whole[0] is not None and np.asarray(whole[0]).shape == px.shape else -1
+    if out.shape == px.shape and d_or:
+        bad = np.argwhere((out != px).any(axis=2))
+        print("  first / last differing pixel:", bad[0].tolist(), bad[-1].tolist(), "rows", sorted(set(bad[:, 0].tolist()))[:12])
     print(k, "oracle:", None if err is None else err.kind, "session:", None if st["err"] is None else type(st["err"]).__name__, "failing scan", len(st["scans"]) - 1,
           st["scans"][-1] if st["scans"] else None, "| session != oracle:", d_or, "whole-file != oracle:", d_wh)
