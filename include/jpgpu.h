@@ -172,6 +172,9 @@ typedef struct jpgpu_image_result {
     uint32_t bytes_consumed;  /* entropy bytes up to the terminating marker; same meaning as the reader advance in
                                  ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:167-176 for well-formed streams */
     uint32_t terminator;      /* marker byte that ended the entropy segment (0xD9 = EOI), 0 if the data ran out */
+    uint32_t error_block;     /* a sequential scan that failed: index, in scan order, of the block the reference threw in -- it has
+                                 called WriteBlock for every block in front of it and for none behind it
+                                 (JpegHuffmanBaselineScanDecoder.cs:99-134, 153); 0xFFFFFFFF otherwise */
 } jpgpu_image_result;
 
 /* ------------------------------------------------------------------------------------------------ (1) batch

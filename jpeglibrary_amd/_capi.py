@@ -53,7 +53,7 @@ class ImageInfo(C.Structure):
 
 class ImageResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("detail", C.c_int32), ("error_interval", C.c_uint32), ("decoded_mcus", C.c_uint32),
-                ("bytes_consumed", C.c_uint32), ("terminator", C.c_uint32)]
+                ("bytes_consumed", C.c_uint32), ("terminator", C.c_uint32), ("error_block", C.c_uint32)]
 
 
 class EncodeParams(C.Structure):

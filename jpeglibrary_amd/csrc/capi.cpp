@@ -501,8 +501,10 @@ void write_block_expanded(jpgpu_write_block_fn fn, void *user, const int16_t *bl
 }
 
 // Replays the WriteBlock call sequence of ProcessScan (:99-134) from PLANAR_I16 planes, for the first `mcus` MCUs.
-void replay_blocks(const ScanJob &job, const ImagePlan &img, const uint8_t *planes, uint32_t mcus, jpgpu_write_block_fn fn, void *user) {
+// (max_blocks: a failing scan has written the blocks in front of the one it threw in, inside the failing MCU too)
+void replay_blocks(const ScanJob &job, const ImagePlan &img, const uint8_t *planes, uint32_t mcus, uint64_t max_blocks, jpgpu_write_block_fn fn, void *user) {
     const BaselineGeometry &g = job.geo;
+    uint64_t n_block = 0;
     for (uint32_t m = 0; m < mcus; m++) {
         const int row_mcu = (int)(m / (uint32_t)g.mcus_per_line), col_mcu = (int)(m % (uint32_t)g.mcus_per_line);
         const int offset_x = col_mcu * g.max_h, offset_y = row_mcu * g.max_v;
@@ -513,6 +515,7 @@ void replay_blocks(const ScanJob &job, const ImagePlan &img, const uint8_t *plan
             const int16_t *plane = reinterpret_cast<const int16_t *>(planes + pl.offset);
             for (int y = 0; y < rc.v; y++)
                 for (int x = 0; x < rc.h; x++) {
+                    if (n_block++ >= max_blocks) return;
                     int16_t blk[64];
                     const size_t px = (size_t)(col_mcu * rc.h + x) * 8, py = (size_t)(row_mcu * rc.v + y) * 8;
                     for (int i = 0; i < 8; i++) memcpy(blk + 8 * i, plane + (py + i) * pl.pitch + px, 16);
@@ -586,13 +589,20 @@ ScanOutcome run_scan_on_gpu(DeviceBatch &batch, const ScanJob &job, uint8_t *dir
     const uint32_t total = (uint32_t)(job.geo.mcus_per_line * job.geo.mcus_per_column);
     const uint32_t dri_eff = job.geo.restart_interval ? job.geo.restart_interval : total;
     uint32_t good_mcus = std::min(oc.result.decoded_mcus, total);
-    if (oc.result.status != JPGPU_OK) good_mcus = std::min<uint64_t>((uint64_t)oc.result.error_interval * dri_eff, total);
+    uint64_t good_blocks = ~0ull;
+    if (oc.result.status != JPGPU_OK) {
+        good_mcus = std::min<uint64_t>((uint64_t)oc.result.error_interval * dri_eff, total);
+        if (oc.result.error_block != 0xFFFFFFFFu && job.blocks_per_mcu > 0) {  // block by block up to the throw, inside the failing interval too
+            good_blocks = oc.result.error_block;
+            good_mcus = (uint32_t)std::min<uint64_t>((good_blocks + (uint64_t)job.blocks_per_mcu - 1) / (uint64_t)job.blocks_per_mcu, total);
+        }
+    }
     if (direct8) {
         if (batch.download_output(0, direct8, direct8_bytes) != JPGPU_OK) throw DecodeError(JPGPU_ERR_DEVICE, "output download failed");
     } else if (fn) {
         std::vector<uint8_t> planes(img.out_bytes);
         if (batch.download_output(0, planes.data(), planes.size()) != JPGPU_OK) throw DecodeError(JPGPU_ERR_DEVICE, "output download failed");
-        replay_blocks(job, img, planes.data(), good_mcus, fn, user);
+        replay_blocks(job, img, planes.data(), good_mcus, good_blocks, fn, user);
     }
     // where ProcessScan leaves the outer reader (:145-149, :167-176)
     const uint32_t term = oc.result.terminator;

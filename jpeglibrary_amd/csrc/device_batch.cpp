@@ -2399,10 +2399,12 @@ int DeviceBatch::result(int i, jpgpu_image_result *res) {
     int rc = fetch_status();
     if (rc != JPGPU_OK) return rc;
     res->status = JPGPU_OK;
+    res->error_block = 0xFFFFFFFFu;
     bool swallowed = false;
     for (int j : img->jobs) {
         const DevScanStatus &st = h_status_[j];
         res->decoded_mcus = st.decoded_mcus;
+        if (jobs_[j].kind == kScanSequential && st.first_error != kNoError && st.pad[1] != 0) res->error_block = kFailBlockBase - st.pad[1];
         res->terminator = st.terminator;
         res->bytes_consumed = st.end_pos;
         if (st.first_error != kNoError && getenv("JPGPU_DEBUG_STATUS"))

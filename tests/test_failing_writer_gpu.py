@@ -170,3 +170,50 @@ def test_a_failing_dri0_scan_over_the_callers_canvas_that_needs_many_rounds():
     b = jl.Batch().upload([data], jl.FMT_INTERLEAVED_U8).decode().sync()  # (the batch's own buffer: the second pass rewrites everything)
     assert np.array_equal(b.output(0), px) and b.subseq_fallbacks() == 1
     b.close()
+
+
+def test_an_arbitrary_writer_receives_the_blocks_in_front_of_the_throw_and_no_others():
+    """JpegDecoder.Decode() into a caller's own JpegBlockOutputWriter (WriteBlock calls replayed on the host from the device's int16
+    planes): for a failing scan the calls stop at the block the reference threw in -- inside the failing restart interval and the
+    failing MCU too (jpgpu_image_result.error_block; round 4 replayed whole restart intervals only)."""
+
+    class Sink(jl.JpegBlockOutputWriter):
+        def __init__(self, w, h, c):
+            self.px = np.zeros((h, w, c), np.uint8)
+            self.calls = 0
+
+        def WriteBlock(self, blockRef, componentIndex, x, y):  # noqa: N802,N803
+            self.calls += 1
+            h, w, _ = self.px.shape
+            if x >= w or y >= h:
+                return
+            ww, wh = min(w - x, 8), min(h - y, 8)
+            self.px[y:y + wh, x:x + ww, componentIndex] = np.clip(np.asarray(blockRef, np.int16).reshape(8, 8)[:wh, :ww], 0, 255)
+
+    rng = np.random.default_rng(17)
+    done = 0
+    for sub, dri in (("420", 5), ("444", 0), ("422", 3)):
+        base = jpegsynth.encode(120, 88, sub, 80, dri, seed=31)
+        for _ in range(10):
+            f = _corrupt(base, rng)
+            try:
+                px, _, err = po.decode_8bit_partial(f)
+            except po.OracleError:
+                continue
+            d = jl.JpegDecoder()
+            d.SetInput(f)
+            d.Identify()
+            sink = Sink(d.Width, d.Height, 3)
+            d.SetOutputWriter(sink)
+            try:
+                d.Decode()
+                assert err is None
+            except jl.JpegError as e:
+                if type(e).__name__ == "NotSupportedException" and (err is None or err.kind != "NotSupportedException"):
+                    d.close()
+                    continue
+                assert err is not None and type(e).__name__ == err.kind
+            d.close()
+            assert np.array_equal(sink.px, px), (sub, dri, int((sink.px != px).sum()))
+            done += err is not None
+    assert done >= 8
