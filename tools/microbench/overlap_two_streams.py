@@ -11,8 +11,9 @@ import jpeglibrary_amd as jl
 from tools import jpegsynth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+dri = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 steps = 10
-buf, sizes, stride = jpegsynth.encode_batch(n, 3840, 2160, "420", 75, 4, seed0=1, nthreads=os.cpu_count())
+buf, sizes, stride = jpegsynth.encode_batch(n, 3840, 2160, "420", 75, dri, seed0=1, nthreads=os.cpu_count())
 files = [buf[i * stride:i * stride + int(sizes[i])] for i in range(n)]
 ctx_a, ctx_b = jl.Context(0), jl.Context(0)
 
@@ -60,5 +61,5 @@ for parts, streams in ((4, 2), (4, 4), (8, 2), (3, 3)):
     for x in bs:
         x.close()
 print("parts x streams:", {k: round(v, 2) for k, v in more.items()})
-print(f"{n} x 4K DRI=4: one batch {t_whole:.2f} ms; two halves on two streams {t_halves:.2f} ms (staged issue {t_staged:.2f} ms); "
+print(f"{n} x 4K DRI={dri}: one batch {t_whole:.2f} ms; two halves on two streams {t_halves:.2f} ms (staged issue {t_staged:.2f} ms); "
       f"two halves on one stream {t_serial:.2f} ms")
