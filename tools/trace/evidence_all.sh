@@ -10,8 +10,8 @@ mkdir -p $OUT
 cd $R
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 cut -c1-300 $OUT/bench.json
-( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ingest --no-planar-pass > $OUT/kernel_stats.log 2>&1; cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_1024img.csv )
-bash tools/profile_pmc.sh $TAG --images 128 --steps 2 --warmup 1 --no-cpu-baseline --no-ingest --no-planar-pass > $OUT/pmc.log 2>&1
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ingest --no-planar-pass --no-configs > $OUT/kernel_stats.log 2>&1; cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_1024img.csv )
+bash tools/profile_pmc.sh $TAG --images 128 --steps 2 --warmup 1 --no-cpu-baseline --no-ingest --no-planar-pass --no-configs > $OUT/pmc.log 2>&1
 cp gpurun_out/pmc_$TAG/summary.txt $OUT/pmc_summary_128img.txt; cp gpurun_out/pmc_$TAG/idct_traffic_entry.json $OUT/ 2>/dev/null
 bash tools/trace/evidence.sh $TAG > $OUT/evidence.log 2>&1
 cp gpurun_out/evidence_$TAG/* $OUT/

@@ -6,7 +6,7 @@ cd "$R" || exit 1
 mkdir -p gpurun_out
 run() {  # name, env...
   local name=$1; shift
-  env "$@" python3 bench.py --workload ${WORKLOAD:-4k_dri0} --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline --no-ingest > gpurun_out/r05_k2s_$name.json 2> gpurun_out/r05_k2s_$name.log
+  env "$@" timeout 300 python3 bench.py --workload ${WORKLOAD:-4k_dri0} --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline --no-ingest > gpurun_out/r05_k2s_$name.json 2> gpurun_out/r05_k2s_$name.log
   python3 - "$name" <<PY
 import json,sys
 d=json.loads(open("gpurun_out/r05_k2s_%s.json" % sys.argv[1]).read().strip().splitlines()[-1])
@@ -16,5 +16,6 @@ PY
 run default JPGPU_NOP=1
 run no_gather JPGPU_SUBSEQ_NO_GATHER=1
 run no_pool JPGPU_SF_NO_POOL=1
-run neither JPGPU_SUBSEQ_NO_GATHER=1 JPGPU_SF_NO_POOL=1
+run no_order JPGPU_SF_NO_ORDER=1
+run none_of_them JPGPU_SUBSEQ_NO_GATHER=1 JPGPU_SF_NO_POOL=1 JPGPU_SF_NO_ORDER=1
 run host_checked JPGPU_SUBSEQ_HOST_CHECK=1
