@@ -460,14 +460,16 @@ void jpgpu_decoder_reset_output_writer(jpgpu_decoder *d);                       
  *   SetHuffmanTable(DC/AC, 0/1, standard tables), AddComponent(1, 0, 0, 0, luma_h, luma_v) [, AddComponent(2 | 3, 1, 1, 1, 1, 1)],
  *   SetInputReader(JpegBufferInputReader(width, height, components, pixels)), Encode().
  * The output is the byte stream the reference writes (SOI, DQT, SOF0, DHT, SOS, entropy data, EOI).
- * input_rgb != 0: pixels are R,G,B and JpegRgbToYCbCrConverter.ConvertRgb24ToYCbCr8 (apps/JpegEncode/
- * JpegRgbToYCbCrConverter.cs:64-96) is applied first, like EncodeAction.cs:31-36 does. */
+ * input_rgb == 1: pixels are R,G,B and JpegRgbToYCbCrConverter.ConvertRgb24ToYCbCr8 (apps/JpegEncode/
+ * JpegRgbToYCbCrConverter.cs:64-96) is applied first, like EncodeAction.cs:31-36 does.  input_rgb == 2: pixels are Rgba32
+ * (four bytes each, the alpha byte stepped over) and ConvertRgba32ToYCbCr8 is applied, like the reference's EncoderBenchmark does
+ * (tests/JpegLibrary.Benchmarks/EncoderBenchmark.cs:93, ColorConverters/JpegRgbToYCbCrConverter.cs:95-124): same tables. */
 typedef struct jpgpu_encode_params {
     int32_t width, height;
-    int32_t components;      /* samples per pixel of the input buffer == encoded components: 1 or 3 */
+    int32_t components;      /* encoded components: 1 or 3 == samples per pixel of the input buffer (input_rgb == 2: four bytes per pixel) */
     int32_t luma_h, luma_v;  /* sampling factors of the first component (1, 2 or 4); the others are 1 x 1 */
     int32_t quality;         /* 1..100, JpegStandardQuantizationTable.ScaleByQuality */
-    int32_t input_rgb;
+    int32_t input_rgb;       /* 0, 1 or 2, see above */
     int32_t optimize_coding; /* 1 = EncodeAction's optimizeCoding (EncodeAction.cs:40-46): Huffman tables built from the image's own
                                 statistics (TransformBlocks / BuildHuffmanTables / WritePreparedScanData, JpegEncoder.cs:264-274);
                                 2 = the same with JpegEncoder.MostOptimalCoding (:43) */

@@ -164,6 +164,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         if (p.width <= 0 || p.height <= 0 || p.width > 65535 || p.height > 65535) return fail(JPGPU_ERR_ARGUMENT, "image dimensions out of range");
         if (p.components != 1 && p.components != 3) return fail(JPGPU_ERR_NOT_SUPPORTED, "1 or 3 components are supported.");
         if (p.input_rgb && p.components != 3) return fail(JPGPU_ERR_ARGUMENT, "RGB input needs 3 components.");
+        if (p.input_rgb < 0 || p.input_rgb > 2) return fail(JPGPU_ERR_ARGUMENT, "input_rgb is 0 (samples), 1 (R,G,B) or 2 (R,G,B,A).");
         if (p.restart_interval < 0 || p.restart_interval > 65535) return fail(JPGPU_ERR_ARGUMENT, "restart interval out of range (0..65535)");
         DevEncImage &im = images_[i];
         memset(&im, 0, sizeof im);
@@ -171,7 +172,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         im.coef_off = coef_off;
         im.width = (uint32_t)p.width;
         im.height = (uint32_t)p.height;
-        im.in_components = (uint32_t)p.components;
+        im.in_components = p.input_rgb == 2 ? 4u : (uint32_t)p.components;  // (2: Rgba32 pixels, the alpha byte stepped over)
         im.components = (uint32_t)p.components;
         im.luma_h = (uint32_t)p.luma_h;
         im.luma_v = (uint32_t)p.luma_v;

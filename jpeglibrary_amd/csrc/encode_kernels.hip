@@ -82,12 +82,14 @@ __device__ __forceinline__ void block_fdct(float (&f)[64]) {
 }
 
 // The shapes fdct_fused_kernel takes (E1 as one kernel: three components from three-sample pixels, luma 2 x 2, 2 x 1 or
-// 1 x 1 -> instance 1, 2, 3); every other shape (0) goes through E1a + E1b.
+// 1 x 1 -> instance 1, 2, 3; from R,G,B,A pixels -> 4, 5, 6); every other shape (0) goes through E1a + E1b.
 __host__ __device__ inline int enc_fused_shape(const DevEncImage &im) {
-    if (im.components != 3 || im.in_components != 3) return 0;
-    if (im.luma_h == 2 && im.luma_v == 2) return 1;
-    if (im.luma_h == 2 && im.luma_v == 1) return 2;
-    if (im.luma_h == 1 && im.luma_v == 1) return 3;
+    // (four-byte pixels: R, G, B, A with the alpha ignored -- ConvertRgba32ToYCbCr8, instances 4, 5, 6)
+    if (im.components != 3 || !(im.in_components == 3 || (im.in_components == 4 && im.input_rgb != 0))) return 0;
+    const int wide = im.in_components == 4 ? 3 : 0;
+    if (im.luma_h == 2 && im.luma_v == 2) return 1 + wide;
+    if (im.luma_h == 2 && im.luma_v == 1) return 2 + wide;
+    if (im.luma_h == 1 && im.luma_v == 1) return 3 + wide;
     return 0;
 }
 __host__ __device__ inline bool enc_fused_ok(const DevEncImage &im) { return enc_fused_shape(im) != 0; }
@@ -114,8 +116,8 @@ __device__ __forceinline__ int32_t enc_convert(const EncSrc &s, uint32_t c, int3
 __device__ __forceinline__ int32_t enc_sample(const EncSrc &s, uint32_t c, uint32_t x, uint32_t y) {
     if (x >= s.width || y >= s.height) return 0;
     const uint8_t *p = s.px + ((size_t)y * s.width + x) * s.comps;
-    if (s.comps != 3) return p[0];
-    return enc_convert(s, c, p[0], p[1], p[2]);
+    if (s.comps < 3) return p[0];
+    return enc_convert(s, c, p[0], p[1], p[2]);  // (a fourth byte per pixel is alpha: ConvertRgba32ToYCbCr8 steps over it)
 }
 
 // Component c of P consecutive pixels of one row, all inside the image, the row address dword aligned.
@@ -565,8 +567,8 @@ struct EfConvert {
 // One pixel row of an MCU (8 H pixels in w): luma row through pass 1 into the transpose buffer (block tblk, and tblk + 1 for
 // the right half when H = 2), chroma sums into the sums buffer -- pairs summed in the lane when H = 2, the row below (above)
 // added from the neighbour lane when V = 2.  EDGE: pixels outside the image (`inside`: one bit per pixel).
-template <int H, int V, bool EDGE>
-__device__ __forceinline__ void ef_row(uint8_t *sh, const uint32_t (&w)[6 * H], uint32_t inside, const EfConvert &cv, uint32_t mloc, uint32_t gk,
+template <int H, int V, int BPP, bool EDGE>
+__device__ __forceinline__ void ef_row(uint8_t *sh, const uint32_t (&w)[2 * BPP * H], uint32_t inside, const EfConvert &cv, uint32_t mloc, uint32_t gk,
                                        uint32_t tblk, uint32_t gdy, uint32_t ry) {
     float sb[8], sr[8];
     EncF2 v[8];  // H = 2: left block in .x, right block in .y; H = 1: .x
@@ -575,7 +577,7 @@ __device__ __forceinline__ void ef_row(uint8_t *sh, const uint32_t (&w)[6 * H], 
         EncF2 c[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            const int b0 = 3 * i + ch, b1 = 3 * (i + 1) + ch;
+            const int b0 = BPP * i + ch, b1 = BPP * (i + 1) + ch;
             c[ch] = EncF2{(float)((w[b0 >> 2] >> (8 * (b0 & 3))) & 0xFFu), (float)((w[b1 >> 2] >> (8 * (b1 & 3))) & 0xFFu)};
         }
         const EncF2 yv = ef_floor(__builtin_elementwise_fma(EncF2{cv.y[0], cv.y[0]}, c[0],
@@ -655,7 +657,9 @@ __device__ __forceinline__ void ef_row(uint8_t *sh, const uint32_t (&w)[6 * H], 
 }
 
 // H x V = the luma sampling factors: 2 x 2 (4:2:0), 2 x 1 (4:2:2), 1 x 1 (4:4:4); enc_fused_shape() names the instance.
-template <int H, int V>
+// BPP = bytes per input pixel: 3, or 4 = R, G, B and an alpha byte nobody reads (the reference's EncoderBenchmark hands Rgba32
+// pixels to ConvertRgba32ToYCbCr8, tests/JpegLibrary.Benchmarks/ColorConverters/JpegRgbToYCbCrConverter.cs:95-124).
+template <int H, int V, int BPP>
 __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restrict__ pixels, const DevEncImage *__restrict__ images,
                                                         const EncWork *__restrict__ work, int16_t *__restrict__ coefs) {
     constexpr uint32_t kRows = 8 * V;                    // pixel rows of an MCU
@@ -663,13 +667,13 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
     constexpr uint32_t kRounds = kEfMcus / kPerRound;
     constexpr uint32_t kNY = H * V, kBpm = kNY + 2;      // luma blocks / blocks per MCU
     constexpr uint32_t kRoundsPerPass = 16 / (kPerRound * kNY);  // gather rounds that fill the transpose buffer's 16 blocks
-    constexpr uint32_t kMcuW = 8 * H, kMcuH = 8 * V, kWords = 6 * H;
+    constexpr uint32_t kMcuW = 8 * H, kMcuH = 8 * V, kWords = 2 * BPP * H;
     constexpr int kShift = (H == 2 ? 1 : 0) + (V == 2 ? 1 : 0);  // pixels per chroma sample = 1 << kShift
     __shared__ __attribute__((aligned(16))) uint8_t sh[kEfLdsBytes];
     constexpr uint32_t kPerItem = kEncMcusPerWg / kEfMcus;
     const EncWork wk = work[blockIdx.x / kPerItem];
     const DevEncImage &im = images[wk.image];
-    if (enc_fused_shape(im) != (H == 2 ? (V == 2 ? 1 : 2) : 3)) return;  // (another instance, or E1a + E1b, takes the image)
+    if (enc_fused_shape(im) != (H == 2 ? (V == 2 ? 1 : 2) : 3) + (BPP == 4 ? 3 : 0)) return;  // (another instance, or E1a + E1b, takes the image)
     const uint32_t mcus_per_line = im.mcus_per_line;
     const uint32_t n_mcus = mcus_per_line * im.mcus_per_column;
     const uint32_t base = wk.first + (blockIdx.x % kPerItem) * kEfMcus;
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
         cv.r[0] = 0.0f, cv.r[1] = 0.0f, cv.r[2] = 1.0f;
         cv.oy = -128.0f, cv.oc = 0.0f;
     }
-    const uint32_t row_bytes = width * 3u;
+    const uint32_t row_bytes = width * (uint32_t)BPP;
     const bool rows4 = (row_bytes & 3u) == 0;
 
     // ---- luma: rounds of gather + pass 1; pass 2 and out whenever the transpose buffer holds 16 blocks
@@ -722,16 +726,16 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
         uint32_t x0 = (mcu % mcus_per_line) * kMcuW, y = (mcu / mcus_per_line) * kMcuH + ry;
         x0 = x0 + kMcuW <= width ? x0 : width - kMcuW;
         y = y < height ? y : height - 1;
-        const uint8_t *rowp = px + ((size_t)y * width + x0) * 3;
+        const uint8_t *rowp = px + ((size_t)y * width + x0) * BPP;
         if constexpr (H == 2) {
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
+            for (int j = 0; j < BPP; j++) {
                 const uint4 t = reinterpret_cast<const uint4 *>(rowp)[j];
                 w[4 * j] = t.x, w[4 * j + 1] = t.y, w[4 * j + 2] = t.z, w[4 * j + 3] = t.w;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
+            for (int j = 0; j < BPP; j++) {
                 const uint2 t = reinterpret_cast<const uint2 *>(rowp)[j];
                 w[2 * j] = t.x, w[2 * j + 1] = t.y;
             }
@@ -747,11 +751,11 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
             const uint32_t tblk = (g % kRoundsPerPass) * (kPerRound * kNY) + gm * kNY + (V == 2 ? (ry >> 3) * H : 0u);
             const bool whole = x0 + kMcuW <= width && y < height;
             if (ahead && __builtin_amdgcn_ballot_w64(!whole) == 0) {
-                ef_row<H, V, false>(sh, w, 0xFFFFu, cv, mloc, gk, tblk, gdy, ry);
+                ef_row<H, V, BPP, false>(sh, w, 0xFFFFu, cv, mloc, gk, tblk, gdy, ry);
             } else {
                 // the edge of the image (outside it the reader leaves zeros, JpegBufferInputReader.cs:27-52), or rows that do
                 // not start where the wide loads want them
-                const uint8_t *rowp = px + ((size_t)y * width + x0) * 3;
+                const uint8_t *rowp = px + ((size_t)y * width + x0) * BPP;
                 uint32_t we[kWords];
                 uint32_t inside = 0xFFFFu;  // the row's pixels that lie inside the image
                 if (whole && rows4) {
@@ -761,7 +765,7 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
                     for (uint32_t j = 0; j < kWords; j++) we[j] = 0;
                     inside = 0;
                     if (y < height) {
-                        const uint32_t np = x0 >= width ? 0u : (width - x0 < kMcuW ? width - x0 : kMcuW), nb = np * 3u;
+                        const uint32_t np = x0 >= width ? 0u : (width - x0 < kMcuW ? width - x0 : kMcuW), nb = np * (uint32_t)BPP;
                         inside = (1u << np) - 1u;
                         for (uint32_t j = 0; j < nb; j++) {
                             const uint32_t bv = (uint32_t)rowp[j] << (8u * (j & 3u));
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(64) void fdct_fused_kernel(const uint8_t *__restric
                         }
                     }
                 }
-                ef_row<H, V, true>(sh, we, inside, cv, mloc, gk, tblk, gdy, ry);
+                ef_row<H, V, BPP, true>(sh, we, inside, cv, mloc, gk, tblk, gdy, ry);
             }
             if (ahead && g + 1 < kRounds) fetch(g + 1);
         }
@@ -1311,9 +1315,12 @@ hipError_t launch_fdct_quant(hipStream_t stream, const uint8_t *pixels, const De
                              uint8_t *samples, int16_t *coefs, size_t max_record_bytes, uint32_t fused_shapes, bool any_other) {
     if (n_work <= 0) return hipSuccess;
     const dim3 grid(n_work * (kEncMcusPerWg / kEfMcus));
-    if (fused_shapes & 2u) hipLaunchKernelGGL((fdct_fused_kernel<2, 2>), grid, dim3(64), 0, stream, pixels, images, work, coefs);
-    if (fused_shapes & 4u) hipLaunchKernelGGL((fdct_fused_kernel<2, 1>), grid, dim3(64), 0, stream, pixels, images, work, coefs);
-    if (fused_shapes & 8u) hipLaunchKernelGGL((fdct_fused_kernel<1, 1>), grid, dim3(64), 0, stream, pixels, images, work, coefs);
+    if (fused_shapes & 2u) hipLaunchKernelGGL((fdct_fused_kernel<2, 2, 3>), grid, dim3(64), 0, stream, pixels, images, work, coefs);
+    if (fused_shapes & 4u) hipLaunchKernelGGL((fdct_fused_kernel<2, 1, 3>), grid, dim3(64), 0, stream, pixels, images, work, coefs);
+    if (fused_shapes & 8u) hipLaunchKernelGGL((fdct_fused_kernel<1, 1, 3>), grid, dim3(64), 0, stream, pixels, images, work, coefs);
+    if (fused_shapes & 16u) hipLaunchKernelGGL((fdct_fused_kernel<2, 2, 4>), grid, dim3(64), 0, stream, pixels, images, work, coefs);
+    if (fused_shapes & 32u) hipLaunchKernelGGL((fdct_fused_kernel<2, 1, 4>), grid, dim3(64), 0, stream, pixels, images, work, coefs);
+    if (fused_shapes & 64u) hipLaunchKernelGGL((fdct_fused_kernel<1, 1, 4>), grid, dim3(64), 0, stream, pixels, images, work, coefs);
     if (any_other) {
         const bool skip = fused_shapes != 0;
         const size_t lds = max_record_bytes * (size_t)kEncMcusPerWg;

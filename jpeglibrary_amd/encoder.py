@@ -28,7 +28,8 @@ class EncodeBatch:
         raise_for_status(rc, _lib.jpgpu_last_error(self.ctx._h))
 
     def upload(self, images, luma=(2, 2), quality=75, rgb=False, optimize_coding=False, restart_interval=0):
-        """images: list of uint8 arrays (H, W, 3) or (H, W) / (H, W, 1).  luma = sampling factors of the first component.
+        """images: list of uint8 arrays (H, W, 3) or (H, W) / (H, W, 1); with rgb=True also (H, W, 4) = Rgba32 pixels, the alpha byte
+        stepped over like ConvertRgba32ToYCbCr8 does (the reference's EncoderBenchmark).  luma = sampling factors of the first component.
         optimize_coding = EncodeAction's switch: Huffman tables built from each image's own statistics.
         restart_interval = MCUs between restart markers (0 = none, as the reference's encoder; an extension, see jpgpu.h)."""
         n = len(images)
@@ -43,7 +44,12 @@ class EncodeBatch:
             keep.append(a)
             ptrs[i] = a.ctypes.data
             h, w, c = a.shape
-            params[i] = _capi.EncodeParams(w, h, c, luma[0], luma[1], quality, 1 if rgb else 0, int(optimize_coding), int(restart_interval))
+            mode = 1 if rgb else 0
+            if c == 4:
+                if not rgb:
+                    raise ValueError("four bytes per pixel are Rgba32 pixels: rgb=True")
+                c, mode = 3, 2
+            params[i] = _capi.EncodeParams(w, h, c, luma[0], luma[1], quality, mode, int(optimize_coding), int(restart_interval))
             mcus = (-(-w // (8 * luma[0]))) * (-(-h // (8 * luma[1])))
             self._blocks.append(mcus * (luma[0] * luma[1] + (2 if c == 3 else 0)))
         self._check(_lib.jpgpu_encoder_upload(self._h, ptrs, params, n))

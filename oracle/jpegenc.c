@@ -706,7 +706,10 @@ int jref_encode_8bit_tables(const uint8_t *pixels, int width, int height, int co
 #define R2Y_SCALE_BITS 16
 static int r2y_fix(float x) { return (int)((x * (float)(1L << R2Y_SCALE_BITS)) + 0.5F); } /* ref: :59-62 */
 
-void jref_rgb_to_ycbcr8(const uint8_t *rgb, uint8_t *ycbcr, size_t count) {
+/* stride = bytes per source pixel: 3 = ConvertRgb24ToYCbCr8 (:64-96); 4 = ConvertRgba32ToYCbCr8, the benchmark project's copy of the
+ * converter (tests/JpegLibrary.Benchmarks/ColorConverters/JpegRgbToYCbCrConverter.cs:95-124): the same tables, the source stepping
+ * over a fourth byte per pixel. */
+static void r2y_convert(const uint8_t *rgb, uint8_t *ycbcr, size_t count, int stride) {
     static int y_r[256], y_g[256], y_b[256], cb_r[256], cb_g[256], cb_b[256], cr_g[256], cr_b[256];
     static int ready = 0;
     if (!ready) { /* constructor :26-57 */
@@ -728,7 +731,9 @@ void jref_rgb_to_ycbcr8(const uint8_t *rgb, uint8_t *ycbcr, size_t count) {
         ycbcr[0] = (uint8_t)((y_r[r] + y_g[g] + y_b[b]) >> R2Y_SCALE_BITS);
         ycbcr[1] = (uint8_t)((cb_r[r] + cb_g[g] + cb_b[b]) >> R2Y_SCALE_BITS);
         ycbcr[2] = (uint8_t)((cb_b[r] + cr_g[g] + cr_b[b]) >> R2Y_SCALE_BITS);
-        rgb += 3;
+        rgb += stride;
         ycbcr += 3;
     }
 }
+void jref_rgb_to_ycbcr8(const uint8_t *rgb, uint8_t *ycbcr, size_t count) { r2y_convert(rgb, ycbcr, count, 3); }
+void jref_rgba_to_ycbcr8(const uint8_t *rgba, uint8_t *ycbcr, size_t count) { r2y_convert(rgba, ycbcr, count, 4); }

@@ -179,5 +179,6 @@ int jref_encode_8bit_ex(const uint8_t *pixels, int width, int height, int compon
                         int optimize_coding, uint8_t *out, size_t cap, size_t *out_len, int16_t *coef_tap);
 /* apps/JpegEncode/JpegRgbToYCbCrConverter.ConvertRgb24ToYCbCr8 */
 void jref_rgb_to_ycbcr8(const uint8_t *rgb, uint8_t *ycbcr, size_t count);
+void jref_rgba_to_ycbcr8(const uint8_t *rgba, uint8_t *ycbcr, size_t count); /* Rgba32 source, three bytes per pixel out */
 
 #endif

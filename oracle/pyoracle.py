@@ -292,6 +292,18 @@ def rgb_to_ycbcr8(rgb: np.ndarray) -> np.ndarray:
     return out
 
 
+def rgba_to_ycbcr8(rgba: np.ndarray) -> np.ndarray:
+    """ConvertRgba32ToYCbCr8 (the reference's EncoderBenchmark): (H, W, 4) -> (H, W, 3)."""
+    L = lib()
+    L.jref_rgba_to_ycbcr8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.jref_rgba_to_ycbcr8.restype = None
+    a = np.ascontiguousarray(rgba, dtype=np.uint8)
+    assert a.ndim == 3 and a.shape[2] == 4
+    out = np.empty((a.shape[0], a.shape[1], 3), dtype=np.uint8)
+    L.jref_rgba_to_ycbcr8(a.ctypes.data, out.ctypes.data, a.shape[0] * a.shape[1])
+    return out
+
+
 def decode_blocks(data: bytes):
     """All WriteBlock calls in order: list of (component_index, x, y, block[64] int16)."""
     calls = []

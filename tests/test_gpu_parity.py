@@ -907,6 +907,15 @@ def _enc_image(w, h, seed):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
+def _rgba(rgb, seed):
+    """Rgba32 pixels as the reference's EncoderBenchmark hands them over (ConvertRgba32ToYCbCr8 reads R, G, B): the alpha bytes are
+    noise here, so that a reader that looked at them would show."""
+    a = np.random.default_rng(seed).integers(0, 256, rgb.shape[:2] + (1,), dtype=np.uint8)
+    out = np.ascontiguousarray(np.concatenate([rgb, a], axis=-1))
+    assert np.array_equal(po.rgba_to_ycbcr8(out), po.rgb_to_ycbcr8(rgb))
+    return out
+
+
 ENC_CASES = [(64, 48, (2, 2), 75), (333, 211, (2, 2), 75), (333, 211, (2, 1), 90), (100, 75, (1, 1), 50), (17, 9, (2, 2), 30),
              (1, 1, (2, 2), 75), (640, 368, (2, 2), 100), (1024, 768, (2, 2), 85), (31, 65, (4, 1), 60)]
 
@@ -922,6 +931,7 @@ def test_encoder_matches_the_reference_restatement_byte_for_byte(w, h, luma, q):
     assert np.array_equal(b.coefficients(0), ref_coefs)
     assert b.output(0) == ref
     assert jl.encode_batch([rgb], luma, q, rgb=True)[0] == ref
+    assert jl.encode_batch([_rgba(rgb, w)], luma, q, rgb=True)[0] == ref  # Rgba32 pixels: the alpha byte is stepped over
     # and it is a JPEG the decoder path reads back: pixels equal to the oracle decode of the oracle stream
     outs, results = jl.decode_batch([b.output(0)])
     assert results[0].status == 0 and np.array_equal(outs[0], po.decode_8bit(ref)[0])
@@ -945,6 +955,25 @@ def test_encoder_fused_e1_row_alignments_and_edges(w, h, opt, luma):
     assert np.array_equal(b.coefficients(0), ref_coefs)
     assert b.output(0) == ref
     assert jl.encode_batch([rgb], luma, 77, rgb=True, optimize_coding=opt)[0] == ref
+    # fdct_fused_kernel<H, V, 4>: the same rows at four bytes per pixel (16-byte row starts when the width is a multiple of four)
+    assert jl.encode_batch([_rgba(rgb, w)], luma, 77, rgb=True, optimize_coding=opt)[0] == ref
+
+
+def test_encoder_rgba_pixels_in_a_mixed_batch():
+    """One batch holding Rgba32, RGB and YCbCr images of fused and two-kernel shapes: every instance of E1 leaves the others'
+    images alone, and the four-byte reader of the two-kernel path (luma 4 x 1, 1 x 2) steps over the alpha byte too."""
+    rgbs = [_enc_image(w, h, w * 3 + h) for (w, h) in [(160, 96), (33, 47), (640, 64), (75, 50), (50, 70)]]
+    lumas = [(2, 2), (2, 2), (2, 2), (4, 1), (1, 2)]
+    for luma in set(lumas):
+        idx = [i for i, l in enumerate(lumas) if l == luma]
+        imgs = []
+        for n, i in enumerate(idx):
+            imgs.append(_rgba(rgbs[i], i) if n % 2 == 0 else rgbs[i])
+        outs = jl.encode_batch(imgs, luma, 70, rgb=True)
+        for i, o in zip(idx, outs):
+            assert o == po.encode_8bit(po.rgb_to_ycbcr8(rgbs[i]), luma[0], luma[1], 70)
+    with pytest.raises(ValueError):
+        jl.EncodeBatch().upload([_rgba(rgbs[0], 0)], (2, 2), 70, rgb=False)
 
 
 def test_encoder_fused_and_two_kernel_images_in_one_batch():

@@ -29,6 +29,14 @@ def test_rgb_to_ycbcr_matches_the_fixed_point_closed_form():
     assert np.array_equal(out[..., 0], y) and np.array_equal(out[..., 1], cb) and np.array_equal(out[..., 2], cr)
 
 
+def test_rgba_pixels_convert_like_rgb_pixels_with_the_alpha_stepped_over():
+    """ConvertRgba32ToYCbCr8 (the benchmark project's copy of the converter, JpegRgbToYCbCrConverter.cs:95-124): the Rgb24 tables,
+    the source advancing four bytes per pixel."""
+    rng = np.random.default_rng(11)
+    rgba = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    assert np.array_equal(po.rgba_to_ycbcr8(rgba), po.rgb_to_ycbcr8(np.ascontiguousarray(rgba[..., :3])))
+
+
 def test_fdct_of_constant_and_basis_blocks():
     q = np.ones(64, np.uint16)
     flat = po.fdct_quantize_block(np.full(64, 200, np.int16), q)[0]

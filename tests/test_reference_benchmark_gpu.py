@@ -97,8 +97,11 @@ def test_the_encoder_benchmarks_canvas_encodes_byte_exact(canvas, luma, optimize
     """tests/JpegLibrary.Benchmarks/EncoderBenchmark.cs:21-58, 77-135: the decoded 8192 x 8192 canvas through the encoder, 4:2:0 and
     4:4:4, Q75, standard tables (and EncodeAction's optimizeCoding): the finished stream equals the restatement's byte for byte --
     real content at the reference's own size (268 MB of pixels, a million MCUs, three quarters of them black)."""
-    rgb = np.ascontiguousarray(jl.decode_batch([canvas], jl.FMT_RGB_U8)[0][0])
-    assert rgb.shape == (8192, 8192, 3)
-    got = jl.encode_batch([rgb], luma, 75, rgb=True, optimize_coding=optimize)[0]
-    ref = po.encode_8bit(po.rgb_to_ycbcr8(rgb), luma[0], luma[1], 75, optimize_coding=optimize)
+    # Setup(): decode + ConvertYCbCr8ToRgba32 -> Rgba32 pixels; the benchmark: ConvertRgba32ToYCbCr8 + Encode()
+    rgba = np.ascontiguousarray(jl.decode_batch([canvas], jl.FMT_RGBA_U8)[0][0])
+    assert rgba.shape == (8192, 8192, 4)
+    got = jl.encode_batch([rgba], luma, 75, rgb=True, optimize_coding=optimize)[0]
+    ref = po.encode_8bit(po.rgba_to_ycbcr8(rgba), luma[0], luma[1], 75, optimize_coding=optimize)
     assert len(got) == len(ref) and got == ref
+    if luma == (2, 2) and not optimize:  # three-byte pixels of the same image: the same stream
+        assert jl.encode_batch([np.ascontiguousarray(rgba[..., :3])], luma, 75, rgb=True)[0] == ref

@@ -6,10 +6,10 @@ restatement on the host cores.  Not the headline benchmark (that is bench.py); p
     python tools/bench_encode.py --workload het_8192 [--subsampling 420|444] [--optimize-coding] [--images 8]
 
 --workload het_8192 = the reference's OWN encoder benchmark (tests/JpegLibrary.Benchmarks/EncoderBenchmark.cs:21-58, 77-135): the
-8192 x 8192 canvas of HETissueSlide.jpg (drawn 2 x 2 into the top-left quarter, the rest black), decoded to RGB, encoded as
-baseline Q75 with the standard tables, 4:4:4 or 4:2:0.  The reference times ConvertRgba32ToYCbCr8 + Encode of ONE image per
-call; here: the colour conversion fused into E1, a batch of canvases per call AND one canvas per call (`latency`).  The alpha
-channel of the reference's Rgba32 pixels is dropped by the caller before the clock starts (the encoder takes 3-byte pixels).
+8192 x 8192 canvas of HETissueSlide.jpg (drawn 2 x 2 into the top-left quarter, the rest black), decoded to Rgba32 pixels, encoded
+as baseline Q75 with the standard tables, 4:4:4 or 4:2:0.  The reference times ConvertRgba32ToYCbCr8 + Encode of ONE image per
+call; here: the same Rgba32 pixels in (input_rgb = 2: four bytes per pixel, the alpha byte stepped over), the colour conversion
+fused into E1, a batch of canvases per call AND one canvas per call (`latency`).  --pixels rgb: three-byte pixels instead.
 """
 import argparse
 import json
@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--workload", default="synthetic_4k", choices=["synthetic_4k", "het_8192"])
     ap.add_argument("--subsampling", default="420", choices=["420", "444"])
     ap.add_argument("--optimize-coding", action="store_true", help="Huffman tables from each image's own statistics (EncodeAction's switch)")
+    ap.add_argument("--pixels", default=None, choices=["rgb", "rgba"], help="input pixels (default: rgba for het_8192 like the reference's benchmark, rgb otherwise)")
     args = ap.parse_args()
     import jpeglibrary_amd as jl
     from oracle import pyoracle as po
@@ -57,13 +58,20 @@ def main():
         args.width = args.height = 8192
         if args.images == 64:
             args.images = 8
-        rgb = jl.decode_batch([bench.het_canvas(75)], jl.FMT_RGB_U8)[0][0]  # EncoderBenchmark.Setup: decode + ConvertYCbCr8ToRgba32 (alpha dropped)
-        base = [np.ascontiguousarray(rgb)]
+        rgba = jl.decode_batch([bench.het_canvas(75)], jl.FMT_RGBA_U8)[0][0]  # EncoderBenchmark.Setup: decode + ConvertYCbCr8ToRgba32
+        base = [np.ascontiguousarray(rgba)]
         distinct = 1
     else:
         distinct = min(args.images, 16)
         with ThreadPoolExecutor(16) as ex:
             base = list(ex.map(lambda s: image(args.width, args.height, s), range(distinct)))
+    pixels = args.pixels or ("rgba" if het else "rgb")
+    if pixels == "rgba" and base[0].shape[2] == 3:
+        base = [np.ascontiguousarray(np.concatenate([im, np.full(im.shape[:2] + (1,), 255, np.uint8)], axis=-1)) for im in base]
+    elif pixels == "rgb" and base[0].shape[2] == 4:
+        base = [np.ascontiguousarray(im[..., :3]) for im in base]
+    bpp = 4 if pixels == "rgba" else 3
+    to_ycc = po.rgba_to_ycbcr8 if pixels == "rgba" else po.rgb_to_ycbcr8
     imgs = [base[i % distinct] for i in range(args.images)]
     b = jl.EncodeBatch().upload(imgs, luma, args.quality, rgb=True, restart_interval=args.dri, optimize_coding=args.optimize_coding)
     b.encode()
@@ -74,7 +82,7 @@ def main():
     px = args.images * args.width * args.height
     stage = b.stage_ms()
     out0 = b.output(0)
-    ref = po.encode_8bit(po.rgb_to_ycbcr8(imgs[0]), luma[0], luma[1], args.quality, restart_interval=args.dri, optimize_coding=args.optimize_coding)
+    ref = po.encode_8bit(to_ycc(imgs[0]), luma[0], luma[1], args.quality, restart_interval=args.dri, optimize_coding=args.optimize_coding)
     latency = None
     if het:  # the reference encodes ONE image per call
         one = jl.EncodeBatch().upload(imgs[:1], luma, args.quality, rgb=True, optimize_coding=args.optimize_coding)
@@ -90,7 +98,7 @@ def main():
     from bench import granted_cpus, host_cpu_budget
     budget = host_cpu_budget()
     cores = granted_cpus(budget)
-    ycc = [po.rgb_to_ycbcr8(im) for im in base[:min(distinct, 4)]]
+    ycc = [to_ycc(im) for im in base[:min(distinct, 4)]]
     t1 = time.perf_counter()
     po.encode_8bit(ycc[0], luma[0], luma[1], args.quality, optimize_coding=args.optimize_coding)
     single = args.width * args.height / (time.perf_counter() - t1) / 1e6
@@ -105,14 +113,14 @@ def main():
     # and writes the finished one.
     n_blocks = sum(b._blocks)
     out_bytes = sum(len(b.output(i)) for i in range(min(args.images, distinct))) / min(args.images, distinct) * args.images
-    algo = {"fdct_quant": px * 3 + n_blocks * 128, "block_bits": n_blocks * 128 + n_blocks * 4, "emit": n_blocks * 128 + out_bytes, "stuff": 2 * out_bytes}
+    algo = {"fdct_quant": px * bpp + n_blocks * 128, "block_bits": n_blocks * 128 + n_blocks * 4, "emit": n_blocks * 128 + out_bytes, "stuff": 2 * out_bytes}
     dom = max(("fdct_quant", "block_bits", "emit", "stuff"), key=lambda k: stage[k])
     achieved = algo[dom] / (stage[dom] / 1e3) / 1e9
-    metric = (f"Mpixels/s encoded (the reference's EncoderBenchmark canvas: 8192 x 8192 RGB, 4:{args.subsampling[1]}:{args.subsampling[2]} baseline Q75, "
+    metric = (f"Mpixels/s encoded (the reference's EncoderBenchmark canvas: 8192 x 8192 {'Rgba32' if bpp == 4 else 'RGB'}, 4:{args.subsampling[1]}:{args.subsampling[2]} baseline Q75, "
               f"{'optimised' if args.optimize_coding else 'standard'} tables)" if het else
-              f"Mpixels/s encoded (RGB 4:{args.subsampling[1]}:{args.subsampling[2]} baseline, {'optimised' if args.optimize_coding else 'standard'} tables)")
+              f"Mpixels/s encoded ({'Rgba32' if bpp == 4 else 'RGB'} 4:{args.subsampling[1]}:{args.subsampling[2]} baseline, {'optimised' if args.optimize_coding else 'standard'} tables)")
     print(json.dumps({"metric": metric, **({"latency": latency} if latency else {}), "value": round(px / dt / 1e6, 1), "unit": "Mpixels/s",
-                      "ms_per_step": round(dt * 1e3, 2), "images": args.images, "restart_interval": args.dri, "bytes_per_image": len(out0),
+                      "ms_per_step": round(dt * 1e3, 2), "images": args.images, "bytes_per_pixel_in": bpp, "restart_interval": args.dri, "bytes_per_image": len(out0),
                       "byte_exact_vs_oracle": out0 == ref, "stage_ms": {k: round(v, 3) for k, v in stage.items()},
                       "roofline": {"kernel": {"fdct_quant": "enc_gather_kernel + fdct_quant_kernel" if os.environ.get("JPGPU_ENC_NO_FUSED") else "fdct_fused_kernel", "block_bits": "block_bits_kernel", "emit": "emit_kernel",
                                               "stuff": "stuff_count_kernel + stuff_write_kernel"}[dom], "bound": "hbm", "achieved": round(achieved, 1),
