@@ -386,16 +386,19 @@ for i in range(max(60, n // 4)):
     luma = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (4, 2)][int(rng.integers(0, 6))] if not gray else (1, 1)
     q = int(rng.integers(1, 101))
     mode = int(rng.integers(0, 3))
-    rgb = (not gray) and rng.random() < 0.5
+    rgb = int((not gray) and rng.random() < 0.5)
     ri = int(rng.integers(1, 40)) if rng.random() < 0.4 else 0  # restart interval (the encoder's extension)
     img = rng.integers(0, 256, (h, w) if gray else (h, w, 3)).astype(np.uint8)
     if rng.random() < 0.5:
         img = (img.astype(np.int32) // int(rng.integers(1, 40)) * int(rng.integers(1, 8))).clip(0, 255).astype(np.uint8)
+    if rgb and i % 2 == 1:  # Rgba32 pixels (the reference's EncoderBenchmark input): an alpha byte of noise that nobody may read
+        rgb = 2
+        img = np.ascontiguousarray(np.concatenate([img, np.random.default_rng(i).integers(0, 256, (h, w, 1), dtype=np.uint8)], axis=-1))
     groups.setdefault((luma, q, mode, rgb, ri), []).append(img)
 for (luma, q, mode, rgb, ri), imgs in groups.items():
-    e = jl.EncodeBatch().upload(imgs, luma, q, rgb=rgb, optimize_coding=mode, restart_interval=ri).encode()
+    e = jl.EncodeBatch().upload(imgs, luma, q, rgb=bool(rgb), optimize_coding=mode, restart_interval=ri).encode()
     for k, im in enumerate(imgs):
-        src = po.rgb_to_ycbcr8(im) if rgb else im
+        src = po.rgba_to_ycbcr8(im) if rgb == 2 else (po.rgb_to_ycbcr8(im) if rgb else im)
         try:
             ref = po.encode_8bit(src, luma[0], luma[1], q, optimize_coding=mode, restart_interval=ri)
         except po.OracleError:
