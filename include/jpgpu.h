@@ -496,6 +496,11 @@ int jpgpu_encoder_encode(jpgpu_encoder *e);
  * ZigZagAndQuantizeBlock: JpegEncoder.cs:662-741, 812-826; with optimize_coding also GatherBlockStatistics :552-597), ms[1] code lengths
  * and bit offsets, ms[2] bit emission (EncodeBlock :828-925), ms[3] byte stuffing (JpegWriter.cs:133-232), ms[4] their sum. */
 int jpgpu_encoder_stage_ms(jpgpu_encoder *e, float ms[5]);
+/* How the entropy stage of this encoder's jpgpu_encoder_encode calls ran: *one_pass = calls that counted and emitted the bits in ONE
+ * pass over the blocks (uploads of two or more images without restart intervals: EncodeBlock, JpegEncoder.cs:828-925, run once per
+ * block instead of twice), *fell_back = those of them that had to issue the two-kernel form behind it (a workgroup's stretch of the
+ * stream beyond the on-chip buffer: noise at quality 100).  The streams are the same bytes either way.  Either pointer may be NULL. */
+int jpgpu_encoder_emit_passes(const jpgpu_encoder *e, int *one_pass, int *fell_back);
 int jpgpu_encoder_encoded_size(const jpgpu_encoder *e, int i, size_t *bytes);
 int jpgpu_encoder_download(jpgpu_encoder *e, int i, void *dst, size_t cap);                       /* the IBufferWriter's content */
 void *jpgpu_encoder_output_device(const jpgpu_encoder *e, int i, size_t *bytes);                  /* stream i, resident in HBM */

@@ -179,6 +179,7 @@ SYMBOLS = [
     ("jpgpu_encoder_set_quantization_table", C.c_int, [_P, C.c_int, C.c_int, C.c_void_p]),
     ("jpgpu_encoder_encode", C.c_int, [_P]),
     ("jpgpu_encoder_stage_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("jpgpu_encoder_emit_passes", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("jpgpu_encoder_encoded_size", C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
     ("jpgpu_encoder_download", C.c_int, [_P, C.c_int, C.c_void_p, C.c_size_t]),
     ("jpgpu_encoder_output_device", C.c_void_p, [_P, C.c_int, C.POINTER(C.c_size_t)]),

@@ -1266,6 +1266,11 @@ int jpgpu_encoder_set_quantization_table(jpgpu_encoder *enc, int i, int identifi
 }
 int jpgpu_encoder_encode(jpgpu_encoder *enc) { JPGPU_GUARD(enc, enc->impl.encode()); }
 int jpgpu_encoder_stage_ms(jpgpu_encoder *enc, float ms[5]) { JPGPU_GUARD(enc, enc->impl.stage_ms(ms)); }
+int jpgpu_encoder_emit_passes(const jpgpu_encoder *enc, int *one_pass, int *fell_back) {
+    if (!enc) return JPGPU_ERR_ARGUMENT;
+    enc->impl.emit_counters(one_pass, fell_back);
+    return JPGPU_OK;
+}
 int jpgpu_encoder_encoded_size(const jpgpu_encoder *enc, int i, size_t *bytes) { return enc ? enc->impl.encoded_size(i, bytes) : JPGPU_ERR_ARGUMENT; }
 int jpgpu_encoder_download(jpgpu_encoder *enc, int i, void *dst, size_t cap) { JPGPU_GUARD(enc, enc->impl.download(i, dst, cap)); }
 void *jpgpu_encoder_output_device(const jpgpu_encoder *enc, int i, size_t *bytes) { return enc ? enc->impl.output_device(i, bytes) : nullptr; }

@@ -16,6 +16,11 @@ static bool enc_fused_enabled() {
     static const bool on = getenv("JPGPU_ENC_NO_FUSED") == nullptr;
     return on;
 }
+// JPGPU_ENC_TWO_PASS_EMIT (measurement): E2 and E3 as their two kernels for every upload (bits_emit_kernel never used)
+static bool enc_fused_emit_enabled() {
+    static const bool on = getenv("JPGPU_ENC_TWO_PASS_EMIT") == nullptr;
+    return on;
+}
 
 
 namespace {
@@ -128,7 +133,7 @@ EncodeBatch::~EncodeBatch() {
     for (hipEvent_t ev : ev_)
         if (ev) (void)hipEventDestroy(ev);
     for (DevBuffer *b : {&d_samples_, &d_pixels_, &d_images_, &d_tables_, &d_work_mcu_, &d_work_blk_, &d_work_stat_, &d_work_chunk_, &d_coefs_, &d_bits_, &d_bit_off_,
-                         &d_raw_bits_, &d_raw_, &d_marks_, &d_chunk_ff_, &d_out_, &d_out_len_, &d_hist_, &d_headers_})
+                         &d_raw_bits_, &d_raw_, &d_marks_, &d_chunk_ff_, &d_out_, &d_out_len_, &d_hist_, &d_headers_, &d_chain_, &d_work_order_})
         b->release();
 }
 
@@ -153,6 +158,8 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
     most_optimal_.assign((size_t)n, 0);
     status_.assign((size_t)n, JPGPU_OK);
     encoded_ = false;
+    any_restart_ = false;
+    emit_hint_ = 0;
     std::vector<EncWork> work_mcu, work_blk, work_stat;  // per 128 MCUs | per 256 units (blocks or restart intervals) | per 256 blocks
     uint64_t px_off = 0, coef_off = 0, smp_off = 0;
     for (int i = 0; i < n; i++) {
@@ -183,6 +190,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         im.input_rgb = p.input_rgb ? 1 : 0;
         // restart intervals (an extension, see jpgpu_encode_params): block_bits / emit then take one lane per INTERVAL
         im.restart_interval = (uint32_t)p.restart_interval;
+        any_restart_ = any_restart_ || p.restart_interval != 0;
         im.n_units = im.restart_interval ? (im.mcus_per_line * im.mcus_per_column + im.restart_interval - 1) / im.restart_interval : im.total_blocks;
         if (p.optimize_coding) {
             most_optimal_[i] = p.optimize_coding == 2;  // JpegEncoder.MostOptimalCoding
@@ -266,6 +274,11 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
     n_work_blk_ = (int)work_blk.size();
     n_work_stat_ = (int)work_stat.size();
 
+    // bits_emit_kernel's issue order: the work list's entries by (place inside the image, image)
+    std::vector<uint32_t> work_order(work_blk.size());
+    for (size_t k = 0; k < work_order.size(); k++) work_order[k] = (uint32_t)k;
+    std::stable_sort(work_order.begin(), work_order.end(), [&](uint32_t a, uint32_t b) { return work_blk[a].first < work_blk[b].first; });
+
     std::vector<EncHuffTable> tables(4 + 4 * optimized_.size());
     memset(tables.data(), 0, tables.size() * sizeof(EncHuffTable));
     for (int t = 0; t < 4; t++) build_enc_table(kStd[t], &tables[t]);
@@ -280,6 +293,7 @@ int EncodeBatch::upload(const uint8_t *const *pixels, const jpgpu_encode_params 
         {&d_hist_, nullptr, 0, (size_t)n * 4 * 256 * sizeof(uint32_t) + 256},
         {&d_work_mcu_, work_mcu.data(), work_mcu.size() * sizeof(EncWork), 0},
         {&d_work_blk_, work_blk.data(), work_blk.size() * sizeof(EncWork), 0},
+        {&d_work_order_, work_order.data(), work_order.size() * sizeof(uint32_t), 16},
         {&d_work_stat_, work_stat.data(), work_stat.size() * sizeof(EncWork), 16},
         {&d_pixels_, nullptr, 0, (size_t)px_off + 256},
         {&d_coefs_, nullptr, 0, (size_t)total_blocks_ * 128 + 256},
@@ -401,6 +415,50 @@ int EncodeBatch::encode() {
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(built tables)");
     }
     (void)hipEventRecord(ev_[1], ctx_->stream);
+    std::vector<uint64_t> raw_bits((size_t)n);
+    // E2 + E3 as one pass (bits_emit_kernel): the raw streams are placed BEFORE their sizes are known -- a slot of the worst case
+    // per image (every coefficient a 32-bit field: 256 bytes per block), of which only the stream itself is ever touched
+    // The chains are per image: a batch of ONE image is one chain, as long as the image has workgroups, and runs at the speed the
+    // look-back travels (one 8192 x 8192 canvas: 0.13 ms against the two kernels' 0.107); from two images on the one pass wins.
+    bool fused_emit = false;
+    bool try_fused = enc_fused_emit_enabled() && !any_restart_ && emit_hint_ != 0xFFFFFFFFu && n >= 2;
+    uint64_t slot = 0;
+    const size_t chain_bytes = 256 + enc_chain_bytes(n_work_blk_);  // control words | one record per workgroup
+    if (try_fused) {
+        for (DevEncImage &im : images_) {
+            im.raw_off = slot;
+            slot = align_up64(slot + (uint64_t)im.total_blocks * 256 + 64, 256);
+        }
+        e = d_raw_.reserve((size_t)slot + 256);
+        if (e == hipSuccess) e = d_chain_.reserve(chain_bytes + 256);
+        if (e != hipSuccess) {  // no room for the worst-case slots: the two kernels size the raw streams from the counts
+            (void)hipGetLastError();
+            emit_hint_ = 0xFFFFFFFFu;
+            try_fused = false;
+        }
+    }
+    if (try_fused) {
+        one_pass_emits_++;
+        e = hipMemsetAsync(d_chain_.ptr, 0, chain_bytes, ctx_->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_images_.ptr, images_.data(), (size_t)n * sizeof(DevEncImage), hipMemcpyHostToDevice, ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(images)");
+        e = launch_bits_emit(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_blk_.ptr, n_work_blk_, (const EncHuffTable *)d_tables_.ptr,
+                             (const int16_t *)d_coefs_.ptr, (uint8_t *)d_chain_.ptr + 256, (uint32_t *)d_chain_.ptr, (uint8_t *)d_raw_.ptr, (uint64_t *)d_raw_bits_.ptr,
+                             emit_hint_ ? emit_hint_ : 4096u, (const uint32_t *)d_work_order_.ptr);
+        if (e != hipSuccess) return hip_fail(e, "bits_emit_kernel");
+        (void)hipEventRecord(ev_[2], ctx_->stream);
+        uint32_t ctl[2] = {0, 0};
+        e = hipMemcpyAsync(raw_bits.data(), d_raw_bits_.ptr, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx_->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctl, d_chain_.ptr, sizeof ctl, hipMemcpyDeviceToHost, ctx_->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpy(bit counts)");
+        fused_emit = ctl[1] == 0;
+        if (!fused_emit) {  // a stretch beyond the LDS buffer, or a wait that ran out: this upload takes the two kernels from here on
+            emit_hint_ = 0xFFFFFFFFu;
+            fused_emit_fallbacks_++;
+        }
+    }
+    if (!fused_emit) {
     uint32_t *wg_bits = reinterpret_cast<uint32_t *>((uint8_t *)d_bit_off_.ptr + (((size_t)n_work_blk_ * sizeof(uint64_t) + 255) & ~(size_t)255));
     e = launch_block_bits(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_blk_.ptr, n_work_blk_,
                           (const EncHuffTable *)d_tables_.ptr, (const int16_t *)d_coefs_.ptr, (uint32_t *)d_bits_.ptr, n, wg_bits, (uint64_t *)d_bit_off_.ptr,
@@ -408,10 +466,10 @@ int EncodeBatch::encode() {
     if (e != hipSuccess) return hip_fail(e, "block_bits_kernel");
     (void)hipEventRecord(ev_[2], ctx_->stream);
     // the sizes of the raw and finished streams depend on the data: one host round trip
-    std::vector<uint64_t> raw_bits((size_t)n);
     e = hipMemcpyAsync(raw_bits.data(), d_raw_bits_.ptr, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx_->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpy(bit counts)");
+    }
     std::vector<EncWork> work_chunk;
     uint64_t raw_off = 0, out_off = 0;
     uint32_t chunk_off = 0;
@@ -427,7 +485,7 @@ int EncodeBatch::encode() {
         const uint64_t wgs = ((uint64_t)im.n_units + 255) / 256;
         const uint64_t avg_words = raw_bits[i] / 32 / std::max<uint64_t>(wgs, 1) + 1;
         if (avg_words <= kEmitLdsWordsMax) emit_words = std::max<uint64_t>(emit_words, 2 * avg_words);
-        im.raw_off = raw_off;
+        if (!fused_emit) im.raw_off = raw_off;  // (the one-pass form has placed and written the raw streams already)
         im.out_off = out_off;
         im.chunk_off = chunk_off;
         const uint32_t chunks = (uint32_t)((raw_len + kEncStuffChunk - 1) / kEncStuffChunk);
@@ -437,20 +495,24 @@ int EncodeBatch::encode() {
         // every byte may need stuffing; two marker bytes per restart interval
         out_off = align_up64(out_off + im.header_len + 2 * raw_len + 2 + 64 + (im.restart_interval ? 2 * (uint64_t)im.n_units : 0), 256);
     }
+    // the next encode() of this upload sizes bits_emit_kernel's LDS buffer like emit_kernel's (no stretch would fit: never again)
+    if (emit_hint_ != 0xFFFFFFFFu) emit_hint_ = emit_words == 0 ? 0xFFFFFFFFu : (uint32_t)std::min<uint64_t>((emit_words + 1023) & ~1023ull, kEmitLdsWordsMax);
     n_work_chunk_ = (int)work_chunk.size();
     out_cap_ = out_off;
     const struct {
         DevBuffer *buf;
         size_t bytes;
-    } grow[] = {{&d_raw_, (size_t)raw_off + 256}, {&d_marks_, (size_t)raw_off / 8 + 256}, {&d_out_, (size_t)out_off + 256}, {&d_chunk_ff_, (size_t)chunk_off * sizeof(uint32_t) + 256},
-                {&d_work_chunk_, work_chunk.size() * sizeof(EncWork) + 16}};
+    } grow[] = {{&d_raw_, fused_emit ? 0 : (size_t)raw_off + 256}, {&d_marks_, fused_emit ? 0 : (size_t)raw_off / 8 + 256}, {&d_out_, (size_t)out_off + 256},
+                {&d_chunk_ff_, (size_t)chunk_off * sizeof(uint32_t) + 256}, {&d_work_chunk_, work_chunk.size() * sizeof(EncWork) + 16}};
     for (const auto &g : grow) {
         e = g.buf->reserve(g.bytes);
         if (e != hipSuccess) return hip_fail(e, "hipMalloc");
     }
-    e = hipMemsetAsync(d_raw_.ptr, 0, (size_t)raw_off + 256, ctx_->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_marks_.ptr, 0, (size_t)raw_off / 8 + 256, ctx_->stream);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(raw)");
+    if (!fused_emit) {  // (emit_kernel ORs into zeroed words; the one-pass form has one writer per word and no restart marks)
+        e = hipMemsetAsync(d_raw_.ptr, 0, (size_t)raw_off + 256, ctx_->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_marks_.ptr, 0, (size_t)raw_off / 8 + 256, ctx_->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(raw)");
+    }
     // the headers: one upload for the batch, put in front of the streams on the device
     header_bytes_.clear();
     for (int i = 0; i < n; i++) {
@@ -465,10 +527,12 @@ int EncodeBatch::encode() {
     if (e == hipSuccess) e = launch_place_headers(ctx_->stream, (const DevEncImage *)d_images_.ptr, n, (const uint8_t *)d_headers_.ptr, (uint8_t *)d_out_.ptr);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(headers)");
     (void)hipEventRecord(ev_[3], ctx_->stream);
-    e = launch_emit(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_blk_.ptr, n_work_blk_, (const EncHuffTable *)d_tables_.ptr,
-                    (const int16_t *)d_coefs_.ptr, (const uint32_t *)d_bits_.ptr, (const uint64_t *)d_bit_off_.ptr, (const uint64_t *)d_raw_bits_.ptr,
-                    (uint8_t *)d_raw_.ptr, (uint32_t *)d_marks_.ptr, (uint32_t)std::min<uint64_t>((emit_words + 1023) & ~1023ull, kEmitLdsWordsMax));
-    if (e != hipSuccess) return hip_fail(e, "emit_kernel");
+    if (!fused_emit) {
+        e = launch_emit(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_blk_.ptr, n_work_blk_, (const EncHuffTable *)d_tables_.ptr,
+                        (const int16_t *)d_coefs_.ptr, (const uint32_t *)d_bits_.ptr, (const uint64_t *)d_bit_off_.ptr, (const uint64_t *)d_raw_bits_.ptr,
+                        (uint8_t *)d_raw_.ptr, (uint32_t *)d_marks_.ptr, (uint32_t)std::min<uint64_t>((emit_words + 1023) & ~1023ull, kEmitLdsWordsMax));
+        if (e != hipSuccess) return hip_fail(e, "emit_kernel");
+    }
     (void)hipEventRecord(ev_[4], ctx_->stream);
     e = launch_stuff(ctx_->stream, (const DevEncImage *)d_images_.ptr, (const EncWork *)d_work_chunk_.ptr, n_work_chunk_, (const uint64_t *)d_raw_bits_.ptr,
                      (const uint8_t *)d_raw_.ptr, (const uint32_t *)d_marks_.ptr, (uint32_t *)d_chunk_ff_.ptr, (uint8_t *)d_out_.ptr,

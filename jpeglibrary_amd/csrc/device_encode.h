@@ -54,6 +54,18 @@ class EncodeBatch {
     DevBuffer d_pixels_, d_images_, d_tables_, d_work_mcu_, d_work_blk_, d_work_stat_, d_work_chunk_, d_coefs_, d_bits_, d_bit_off_, d_raw_bits_, d_raw_, d_marks_,
         d_chunk_ff_, d_out_, d_out_len_, d_headers_;
     std::vector<uint8_t> header_bytes_;  // every image's SOI..SOS, concatenated (one upload per encode)
+    // E2 + E3 as one pass (bits_emit_kernel): restart-free uploads only; the LDS stretch buffer is sized from the previous encode()
+    // of this upload (0: not known yet; 0xFFFFFFFF: a stretch did not fit or a wait ran out -- the two-kernel path from then on)
+    DevBuffer d_chain_, d_work_order_;
+    bool any_restart_ = false;
+    uint32_t emit_hint_ = 0;
+    int one_pass_emits_ = 0, fused_emit_fallbacks_ = 0;  // encode() calls that issued bits_emit_kernel / of those, the ones that had to issue the two kernels after it
+
+  public:
+    void emit_counters(int *one_pass, int *fell_back) const {
+        if (one_pass) *one_pass = one_pass_emits_;
+        if (fell_back) *fell_back = fused_emit_fallbacks_;
+    }
 };
 
 }  // namespace jpgpu

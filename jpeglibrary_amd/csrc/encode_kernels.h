@@ -64,6 +64,11 @@ hipError_t launch_block_stats(hipStream_t stream, const DevEncImage *images, con
 hipError_t launch_emit(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
                        const int16_t *coefs, const uint32_t *bits, const uint64_t *wg_base, const uint64_t *raw_bits, uint8_t *raw,
                        uint32_t *marks, uint32_t lds_words);
+// E2 + E3 as one pass over the blocks (round 5; images without restart intervals): see bits_emit_kernel
+size_t enc_chain_bytes(int n_work);
+hipError_t launch_bits_emit(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
+                            const int16_t *coefs, void *chain, uint32_t *ctl, uint8_t *raw, uint64_t *raw_bits, uint32_t lds_words,
+                            const uint32_t *order /* the work list's entries by (place inside the image, image) */);
 // the LDS buffer a workgroup of emit_kernel assembles its stretch of the stream in, in 32-bit words (launch_emit clamps to these)
 constexpr uint32_t kEmitLdsWordsMin = 2048, kEmitLdsWordsMax = 8192;
 constexpr uint32_t kEncStuffChunk = 4096;

@@ -1177,6 +1177,185 @@ __global__ __launch_bounds__(256) void emit_kernel(const DevEncImage *__restrict
     }
 }
 
+// E2 + E3 as ONE pass over the blocks (round 5; restart-free images -- everything the reference's encoder can write): a workgroup
+// counts the bits of its 256 blocks, assembles its stretch of the stream in LDS at offsets RELATIVE to its own first bit (nothing
+// but the workgroup's own scan is needed for that), learns its base from its predecessors through a decoupled look-back and
+// writes the stretch out shifted by the base's bit phase -- one read of the quantised blocks instead of two, no per-block offsets
+// in HBM, no image-wide scan kernel, and no zeroed raw buffer: every stream word has ONE writer (a word that straddles two
+// workgroups is written by the later one, which takes the earlier one's last bits from the chain record), so the raw streams can
+// be placed before their sizes are known (a worst-case slot per image that is never touched beyond the stream's end).
+//   chain[t] = {head, tail}: head = flag << 62 | bits (1: this workgroup's own total; 2: the image's total up to and including
+//   it), tail = the last 32 bits of its stretch.  A workgroup with a successor holds >= 256 blocks x >= 2 bits, i.e. its own tail
+//   IS the stream's tail in front of the successor.  Tickets (ctl[0]) give the workgroups their place in the work list in the
+//   order they START, so whatever a workgroup waits for belongs to a workgroup that is running or done; the wait is bounded and
+//   a stretch that does not fit the LDS buffer is not emitted: either sets ctl[1] and the host issues the two-kernel path.
+struct EncChain {
+    unsigned long long head, tail;
+};
+constexpr unsigned long long kChainFlagShift = 62, kChainValueMask = (1ull << 62) - 1ull;
+__global__ __launch_bounds__(256) void bits_emit_kernel(const DevEncImage *__restrict__ images, const EncWork *__restrict__ work,
+                                                        const EncHuffTable *__restrict__ tables, const int16_t *__restrict__ coefs,
+                                                        EncChain *__restrict__ chain, uint32_t *__restrict__ ctl, uint8_t *__restrict__ raw,
+                                                        uint64_t *__restrict__ raw_bits, uint32_t lds_words, const uint32_t *__restrict__ order) {
+    extern __shared__ uint32_t sh_words[];
+    __shared__ EncHuffTable sh_tab[4];
+    __shared__ uint32_t sh_wave[4], sh_ticket, sh_prev_tail;
+    __shared__ unsigned long long sh_base;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) sh_ticket = atomicAdd(&ctl[0], 1u);
+    __syncthreads();
+    // order[]: the work list's entries by (place inside the image, image) -- the workgroups that run side by side then belong to
+    // as many images as the batch has, and an image's chain is a handful of records long at any time.  (In work-list order all
+    // ~1 500 resident workgroups sat in ONE image's chain and each walked back over all of them: 24 ms per 256 x 4K.)  An image's
+    // workgroups still start in the image's order, and their records (indexed by work-list position) are consecutive.
+    const uint32_t t = order[sh_ticket];
+    const EncWork wk = work[t];
+    const DevEncImage &im = images[wk.image];
+    enc_stage_tables(tables, im.table_base, sh_tab);
+    const uint32_t blk = wk.first + tid;
+    const bool active = blk < im.total_blocks;
+    const int16_t *img_coefs = coefs + im.coef_off * 64;
+    uint4 cv[8];
+    int32_t pred = 0;
+    uint32_t comp = 0, n = 0;
+    if (active) {
+        const uint32_t mcu = blk / im.bpm, b = blk - mcu * im.bpm;
+        pred = enc_dc_predictor(im, img_coefs, mcu, b, comp);
+        const uint4 *src = reinterpret_cast<const uint4 *>(img_coefs + (size_t)enc_source_block(im, blk) * 64);
+#pragma unroll
+        for (int i = 0; i < 8; i++) cv[i] = src[i];
+        enc_block_symbols(cv, pred, sh_tab[comp == 0 ? 0 : 2], sh_tab[comp == 0 ? 1 : 3], [&](uint32_t, uint32_t len) { n += len; });
+    }
+    // the block's offset inside the workgroup's stretch, the stretch's length
+    uint32_t incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= (uint32_t)o) incl += v;
+    }
+    if ((tid & 63) == 63) sh_wave[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (k < (tid >> 6)) before += sh_wave[k];
+        total += sh_wave[k];
+    }
+    const uint32_t n_rel_words = (total + 31u) >> 5;
+    const bool fits = n_rel_words + 1u <= lds_words;  // (one word of slack: the shifted read of the last, partial word)
+    if (fits)
+        for (uint32_t w = tid; w <= n_rel_words; w += 256u) sh_words[w] = 0;
+    __syncthreads();
+    if (fits && active) {
+        const uint32_t start = before + incl - n;
+        uint32_t wi = start >> 5, fill = start & 31u, cur = 0;
+        auto put = [&](uint32_t code, uint32_t len) {  // as emit_kernel's
+            if (len == 0) return;
+            const uint32_t left = code << (32u - len);
+            cur |= left >> fill;
+            const uint32_t was = fill;
+            fill += len;
+            if (fill >= 32u) {
+                atomicOr(&sh_words[wi], cur);
+                wi++;
+                cur = __builtin_amdgcn_alignbit(left, 0u, was);
+                fill -= 32u;
+            }
+        };
+        enc_block_symbols(cv, pred, sh_tab[comp == 0 ? 0 : 2], sh_tab[comp == 0 ? 1 : 3], put);
+        if (fill) atomicOr(&sh_words[wi], cur);
+    }
+    __syncthreads();
+    const bool first_wg = wk.first == 0, last_wg = wk.first + 256u >= im.total_blocks;
+    if (tid < 64u) {  // wave 0: publish, look back 64 records at a time, publish again
+        const uint32_t lane = tid;
+        if (lane == 0) {
+            uint32_t tail = 0;
+            if (fits && total != 0) {
+                const uint32_t w = (total - 1u) >> 5, r = total & 31u;
+                tail = r == 0 ? sh_words[w] : ((w != 0 ? sh_words[w - 1u] << r : 0u) | (sh_words[w] >> (32u - r)));
+            }
+            if (!fits) atomicOr(&ctl[1], 1u);
+            // Relaxed device-scope atomics throughout: they are performed where all XCDs see them, and NOTHING else is handed from
+            // one workgroup to another -- a release / acquire pair would write back / invalidate the whole L2 of the XCD (every
+            // other workgroup's stream words) twice per workgroup and once per poll.  The tail is in memory before the head says so.
+            __hip_atomic_store(&chain[t].tail, (unsigned long long)tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!first_wg) __hip_atomic_store(&chain[t].head, (1ull << kChainFlagShift) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned long long base = 0;
+        if (!first_wg) {
+            // the image's workgroups hold consecutive tickets' records (the work list is in image order): the first one's is the
+            // lowest this walk may read, and it is an inclusive one
+            const int64_t lowest = (int64_t)t - (int64_t)(wk.first >> 8);
+            int64_t pos = (int64_t)t - 1;
+            uint32_t polls = 0;
+            for (;;) {
+                const int64_t j = pos - (int64_t)lane;
+                const bool valid = j >= lowest;
+                unsigned long long v = 0;
+                if (valid) v = __hip_atomic_load(&chain[j].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t flag = (uint32_t)(v >> kChainFlagShift);
+                const uint64_t inclusive = __ballot(valid && flag == 2u), empty = __ballot(valid && flag == 0u);
+                uint64_t take;  // the records this step adds up: up to the nearest inclusive one, or all 64
+                bool done;
+                if (inclusive != 0) {
+                    const uint32_t k = (uint32_t)__builtin_ctzll(inclusive);
+                    take = k == 63u ? ~0ull : ((2ull << k) - 1ull);
+                    done = true;
+                } else {
+                    take = ~0ull;
+                    done = false;
+                }
+                if ((empty & take) != 0) {  // a record the sum needs has not been published yet
+                    if (++polls > (1u << 18)) {  // ~a second: something is wrong; the host issues the two-kernel path
+                        if (lane == 0) atomicOr(&ctl[1], 2u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                unsigned long long part = (valid && ((take >> lane) & 1ull)) ? (v & kChainValueMask) : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                base += part;
+                if (done) break;
+                pos -= 64;
+            }
+        }
+        if (lane == 0) {
+            uint32_t prev_tail = 0;
+            asm volatile("" ::: "memory");  // (behind the walk that has seen record t - 1 published: its tail was in memory before its head)
+            if (!first_wg) prev_tail = (uint32_t)__hip_atomic_load(&chain[t - 1u].tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&chain[t].head, (2ull << kChainFlagShift) | (base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_base = base;
+            sh_prev_tail = prev_tail;
+            if (last_wg) raw_bits[wk.image] = base + total;
+        }
+    }
+    __syncthreads();
+    if (!fits) return;
+    const unsigned long long base = sh_base, end = base + total;
+    const uint32_t p = (uint32_t)(base & 31ull), prev_tail = sh_prev_tail;
+    uint32_t *words = reinterpret_cast<uint32_t *>(raw + im.raw_off) + (base >> 5);
+    auto abs_word = [&](uint32_t w) -> uint32_t {  // stream word (base >> 5) + w out of the relative stretch
+        if (p == 0) return sh_words[w];
+        const uint32_t hi = (w == 0 ? prev_tail : sh_words[w - 1u]) << (32u - p);
+        return hi | (sh_words[w] >> p);
+    };
+    const uint32_t n_full = (uint32_t)((end >> 5) - (base >> 5));  // words this workgroup completes
+    for (uint32_t w = tid; w < n_full; w += 256u) words[w] = __builtin_bswap32(abs_word(w));
+    if (last_wg && tid == 0) {
+        // the stream's last, partial word: the bits left over, ExitBitMode's one-bits up to the byte boundary (ref: JpegWriter.cs:123-147)
+        const uint32_t r = (uint32_t)(end & 31ull), rem = (8u - (uint32_t)(end & 7ull)) & 7u;
+        if (r != 0) {
+            uint32_t a = abs_word(n_full);
+            if (rem) a |= ((1u << rem) - 1u) << (32u - r - rem);
+            words[n_full] = __builtin_bswap32(a);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ E4: byte stuffing
 
 constexpr uint32_t kStuffChunk = 4096;  // raw bytes per workgroup (256 lanes x 16)
@@ -1351,6 +1530,17 @@ hipError_t launch_emit(hipStream_t stream, const DevEncImage *images, const EncW
     if (lds_words != 0) lds_words = std::min(std::max(lds_words, kEmitLdsWordsMin), kEmitLdsWordsMax);  // 0: no workgroup's stretch would fit
     hipLaunchKernelGGL(emit_kernel, dim3(n_work), dim3(256), (size_t)lds_words * 4, stream, images, work, tables, coefs, bits, wg_base, raw_bits, raw,
                        marks, lds_words);
+    return hipGetLastError();
+}
+// E2 + E3 in one pass (restart-free batches): chain = n_work x 16 bytes and ctl = 2 words, both zeroed by the caller; ctl[1] != 0
+// afterwards = not every workgroup emitted (a stretch beyond lds_words, a wait that ran out): issue launch_block_bits + launch_emit
+size_t enc_chain_bytes(int n_work) { return (size_t)n_work * sizeof(EncChain); }
+hipError_t launch_bits_emit(hipStream_t stream, const DevEncImage *images, const EncWork *work, int n_work, const EncHuffTable *tables,
+                            const int16_t *coefs, void *chain, uint32_t *ctl, uint8_t *raw, uint64_t *raw_bits, uint32_t lds_words, const uint32_t *order) {
+    if (n_work <= 0) return hipSuccess;
+    lds_words = std::min(std::max(lds_words, kEmitLdsWordsMin), kEmitLdsWordsMax);
+    hipLaunchKernelGGL(bits_emit_kernel, dim3(n_work), dim3(256), (size_t)lds_words * 4, stream, images, work, tables, coefs, (EncChain *)chain, ctl, raw,
+                       raw_bits, lds_words, order);
     return hipGetLastError();
 }
 hipError_t launch_place_headers(hipStream_t stream, const DevEncImage *images, int n_images, const uint8_t *headers, uint8_t *out) {

@@ -69,6 +69,12 @@ class EncodeBatch:
     def __len__(self):
         return self._n
 
+    def emit_passes(self):
+        """(calls of encode() whose entropy stage ran as ONE pass over the blocks, those of them that fell back to the two kernels)."""
+        a, b = C.c_int(0), C.c_int(0)
+        self._check(_lib.jpgpu_encoder_emit_passes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def stage_ms(self):
         """Device time of the last encode() by stage (HIP events)."""
         ms = (C.c_float * 5)()

@@ -1021,6 +1021,48 @@ def test_encoder_adversarial_content():
     assert b"\xff\x00" in jl.encode_batch([imgs[0]], (1, 1), 100)[0]
 
 
+def test_encoder_counts_and_emits_the_bits_in_one_pass_and_falls_back_when_a_stretch_does_not_fit():
+    """bits_emit_kernel (E2 + E3 as one pass, round 5): uploads of two or more images without restart intervals take it -- the
+    first encode() with a default on-chip buffer, the next ones with a buffer sized from the one before -- and the streams are the
+    checker's byte for byte whichever way they were made: images of one workgroup and of hundreds in one batch, gray, optimizeCoding,
+    a one-pixel image (a chain of one record whose only word is the padded partial one).  A stretch that does not fit the buffer
+    (white noise at quality 100: ~700 bits per block) makes the host issue the two kernels behind it, once; single images and
+    restart intervals never take the one pass."""
+    rng = np.random.default_rng(77)
+    sizes = [(640, 480), (1, 1), (17, 9), (256, 256), (1000, 31), (8, 8)]
+    imgs = [_enc_image(w, h, w + 3 * h) for (w, h) in sizes]
+    ycc = [po.rgb_to_ycbcr8(im) for im in imgs]
+    for luma, opt in (((2, 2), False), ((1, 1), False), ((2, 1), True)):
+        b = jl.EncodeBatch().upload(imgs, luma, 75, rgb=True, optimize_coding=opt)
+        for rep in range(3):  # (the second and third encode() size the buffer from the one before)
+            b.encode()
+            assert b.emit_passes() == (rep + 1, 0)
+            for k, y in enumerate(ycc):
+                assert b.output(k) == po.encode_8bit(y, luma[0], luma[1], 75, optimize_coding=opt), (luma, opt, rep, sizes[k])
+        b.close()
+    gray = [y[..., 0].copy() for y in ycc[:3]]
+    b = jl.EncodeBatch().upload(gray, (1, 1), 60).encode()
+    assert b.emit_passes() == (1, 0)
+    for k, g in enumerate(gray):
+        assert b.output(k) == po.encode_8bit(g, 1, 1, 60)
+    b.close()
+    # a stretch beyond the buffer: the two kernels behind the one pass, and no second attempt for this upload
+    noise = [rng.integers(0, 256, (264, 520, 3)).astype(np.uint8) for _ in range(3)]
+    b = jl.EncodeBatch().upload(noise + [imgs[0]], (1, 1), 100)
+    for rep in range(2):
+        b.encode()
+        assert b.emit_passes() == (1, 1)
+        for k, im in enumerate(noise + [imgs[0]]):
+            assert b.output(k) == po.encode_8bit(im, 1, 1, 100)
+    b.close()
+    one = jl.EncodeBatch().upload(imgs[:1], (2, 2), 75, rgb=True).encode()
+    assert one.emit_passes() == (0, 0) and one.output(0) == po.encode_8bit(ycc[0], 2, 2, 75)
+    one.close()
+    ri = jl.EncodeBatch().upload(imgs[:2], (2, 2), 75, rgb=True, restart_interval=5).encode()
+    assert ri.emit_passes() == (0, 0) and ri.output(1) == po.encode_8bit(ycc[1], 2, 2, 75, restart_interval=5)
+    ri.close()
+
+
 @pytest.mark.parametrize("env", [
     {"JPGPU_PROG_NO_PIPELINE": "1"},                    # wave-per-stream kernel, chain launches (a stream per chain of scans)
     {"JPGPU_PROG_NO_PIPELINE": "1", "JPGPU_PROG_NO_CHAINS": "1"},  # ... one launch per dependency level

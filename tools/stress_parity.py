@@ -379,12 +379,15 @@ if os.environ.get("STRESS_NO_SESSION") is None:
 
 # ---- encoder: random images / samplings / qualities / table modes, grouped by the parameters one batch shares
 n_enc = 0
+n_one_pass = n_fell_back = 0
 groups = {}
 for i in range(max(60, n // 4)):
     w, h = int(rng.integers(1, 200)), int(rng.integers(1, 200))
     gray = rng.random() < 0.15
     luma = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (4, 2)][int(rng.integers(0, 6))] if not gray else (1, 1)
-    q = int(rng.integers(1, 101))
+    # (mostly a few qualities: images that share sampling / quality / tables / pixel form go up as ONE batch, and batches of two or
+    # more restart-free images are what takes the encoder's one-pass entropy stage)
+    q = int(rng.integers(1, 101)) if rng.random() < 0.3 else int([1, 30, 75, 90, 100][int(rng.integers(0, 5))])
     mode = int(rng.integers(0, 3))
     rgb = int((not gray) and rng.random() < 0.5)
     ri = int(rng.integers(1, 40)) if rng.random() < 0.4 else 0  # restart interval (the encoder's extension)
@@ -411,6 +414,9 @@ for (luma, q, mode, rgb, ri), imgs in groups.items():
         if got != ref:
             bad += 1
             print("encode", luma, q, mode, rgb, ri, im.shape, None if got is None else len(got), None if ref is None else len(ref))
+    a, b_ = e.emit_passes()
+    n_one_pass += a
+    n_fell_back += b_
     e.close()
-print(f"stress: {n} files, {sum(k[3] for k in kinds)} progressive, {n_opt} optimizer outputs compared, {n_enc} encoder outputs compared, {n_mut} corrupted files ({n_partial_baseline} failing baseline writers + {n_partial} partial progressive flushes compared), {n_session} per-scan sessions compared, mismatches: {bad}")
+print(f"stress: {n} files, {sum(k[3] for k in kinds)} progressive, {n_opt} optimizer outputs compared, {n_enc} encoder outputs compared ({n_one_pass} batches through the one-pass entropy stage, {n_fell_back} of them fell back), {n_mut} corrupted files ({n_partial_baseline} failing baseline writers + {n_partial} partial progressive flushes compared), {n_session} per-scan sessions compared, mismatches: {bad}")
 sys.exit(1 if bad else 0)
