@@ -297,6 +297,11 @@ int jpgpu_batch_subseq_rounds(const jpgpu_batch *b);
 int jpgpu_batch_set_partial_flush(jpgpu_batch *b, int on);
 /* Partial-flush replays issued for this batch so far (0: no progressive frame has failed, or the replay is switched off). */
 int jpgpu_batch_progressive_replays(const jpgpu_batch *b);
+/* Waits of this batch's jpgpu_batch_sync calls behind which a workgroup of the one-pass marker index (a workgroup per 16 KiB of
+ * entropy data that finds the running sums of the data in front of it by looking back at what the workgroups there have published)
+ * had run out of patience and counted the data in front of it itself.  Not expected to be anything but 0 -- the wait is bounded so
+ * that nothing can hang -- and of no consequence for the results.  Valid after jpgpu_batch_sync. */
+int jpgpu_batch_marker_fallbacks(const jpgpu_batch *b);
 /* Times the enqueued rounds did not reach the fixed point (the synchronising call then issued the step again with the host
  * reading the counts between rounds, and the upload's later decodes stay that way).  Valid after jpgpu_batch_sync. */
 int jpgpu_batch_subseq_fallbacks(const jpgpu_batch *b);

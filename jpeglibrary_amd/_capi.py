@@ -129,6 +129,7 @@ SYMBOLS = [
     ("jpgpu_batch_subseq_fallbacks", C.c_int, [_P]),
     ("jpgpu_batch_set_partial_flush", C.c_int, [_P, C.c_int]),
     ("jpgpu_batch_progressive_replays", C.c_int, [_P]),
+    ("jpgpu_batch_marker_fallbacks", C.c_int, [_P]),
     ("jpgpu_batch_totals", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("jpgpu_decode_scan", C.c_int, [_P, C.POINTER(Frame), C.POINTER(Scan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint16,
                                     C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(ImageResult),

@@ -147,6 +147,10 @@ class Batch:
         """Times a partial-flush replay was issued for this batch."""
         return _lib.jpgpu_batch_progressive_replays(self._h)
 
+    def marker_fallbacks(self):
+        """Waits behind which a group of the one-pass marker index had run out of patience and counted its predecessors itself (expected: 0)."""
+        return _lib.jpgpu_batch_marker_fallbacks(self._h)
+
     def subseq_fallbacks(self):
         """Times the enqueued K2S rounds did not converge and the step was issued again with host-checked rounds."""
         return _lib.jpgpu_batch_subseq_fallbacks(self._h)

@@ -445,6 +445,7 @@ int jpgpu_batch_set_partial_flush(jpgpu_batch *b, int on) {
     b->impl.set_partial_flush(on != 0);
     return JPGPU_OK;
 }
+int jpgpu_batch_marker_fallbacks(const jpgpu_batch *b) { return b ? b->impl.marker_fallbacks() : 0; }
 int jpgpu_batch_progressive_replays(const jpgpu_batch *b) { return b ? b->impl.progressive_replays() : 0; }
 int jpgpu_batch_subseq_fallbacks(const jpgpu_batch *b) { return b ? b->impl.subseq_fallbacks() : 0; }
 int jpgpu_batch_progressive_fallbacks(const jpgpu_batch *b) { return b ? b->impl.progressive_fallbacks() : 0; }

@@ -46,11 +46,12 @@ void DevBuffer::release() {
 
 DeviceBatch::~DeviceBatch() {
     if (ctx_) (void)hipSetDevice(ctx_->device);
-    for (DevBuffer *b : {&d_sub_work_, &d_sub_final_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_sub_same_, &d_sub_perm_, &d_prog_snapshot_, &d_dispose_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_prog_sync_, &d_planes_, &d_extend_desc_, &d_gather_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
+    for (DevBuffer *b : {&d_sub_work_, &d_sub_final_work_, &d_sub_scan_ids_, &d_sub_exit_a_, &d_sub_exit_b_, &d_sub_nblk_, &d_sub_first_, &d_sub_entry_, &d_sub_dcsum_, &d_sub_dcentry_, &d_sub_changed_, &d_sub_same_, &d_sub_perm_, &d_k1_desc_, &d_k1_tickets_, &d_k1_order_, &d_prog_snapshot_, &d_dispose_, &d_verify_, &d_lut_pool_, &d_prog_work_, &d_prog_sync_, &d_planes_, &d_extend_desc_, &d_gather_, &d_rgb_scratch_, &d_chunk_work_, &d_chunk_sums_, &d_unstuffed_, &d_ends_u_, &d_input_, &d_scans_, &d_status_, &d_ends_, &d_huff_pool_, &d_quant_pool_, &d_huff_work_, &d_idct_work_, &d_idct_work_split_, &d_coefs_, &d_out_})
         b->release();
     for (hipEvent_t &e : ev_pool_)
         if (e) (void)hipEventDestroy(e);
     if (done_ev_) (void)hipEventDestroy(done_ev_);
+    if (h_k1_giveup_) (void)hipHostFree(h_k1_giveup_);
 }
 
 int DeviceBatch::fail(int status, const std::string &msg) {
@@ -1199,6 +1200,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     h_scans_.assign(jobs_.size(), DevScan());
     std::vector<HuffWork> huff_work;
     std::vector<ChunkWork> chunk_work;
+    std::vector<ChunkWork> k1_order;  // the one-pass marker index: (scan, first chunk) per group of kMarkerGroupChunks chunks, by (group, scan)
     std::vector<HuffWork> sub_work;
     // DRI = 0 scans are cut into subsequences of 1024 bits; when that gives more lanes than the machine can use anyway the
     // subsequences grow (2048, 4096 bits): a longer one re-synchronises inside itself more often, so fewer rounds
@@ -1346,6 +1348,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             if (job.kind == kScanFrameOnly) s.n_chunks = 0;  // no entropy data: K1 / K2 skip the job
             // (replay_skip: an image the replay of failed progressive frames leaves alone keeps its place in every buffer and gets no work)
             for (uint32_t c = 0; c < s.n_chunks && !img.replay_skip; c += kMarkerChunksPerWg) chunk_work.push_back({(uint32_t)j, c});
+            for (uint32_t c = 0; c < s.n_chunks && !img.replay_skip; c += kMarkerGroupChunks) k1_order.push_back({(uint32_t)j, c});
             total_chunks += s.n_chunks;
             s.image_index = (uint32_t)ii;
             s.first_scan = (uint32_t)img.jobs.front();
@@ -1554,6 +1557,8 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     total_ends_ = ends_off;
     n_huff_work_ = (int)huff_work.size();
     n_chunk_work_ = (int)chunk_work.size();
+    std::stable_sort(k1_order.begin(), k1_order.end(), [](const ChunkWork &a, const ChunkWork &b) { return a.chunk < b.chunk; });
+    n_k1_groups_ = (int)k1_order.size();
     n_sub_work_ = (int)sub_work.size();
     // ... and the list of the rounds behind round 1 (a workgroup per kSubseqGatherSpan subsequences), behind it in the same buffer
     for (uint32_t j : sub_scan_ids_)
@@ -1765,6 +1770,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_quant_pool_, quant_pool_.data(), quant_pool_.size() * sizeof(DevQuantTable), 0},
         {&d_huff_work_, huff_work.data(), huff_work.size() * sizeof(HuffWork), 0},
         {&d_chunk_work_, chunk_work.data(), chunk_work.size() * sizeof(ChunkWork), 0},
+        {&d_k1_order_, k1_order.data(), k1_order.size() * sizeof(ChunkWork), 16},
         {&d_sub_work_, sub_work.data(), sub_work.size() * sizeof(HuffWork), 0},
         {&d_sub_final_work_, sub_final_work.data(), sub_final_work.size() * sizeof(HuffWork), 0},
         {&d_prog_work_, prog_work.data(), prog_work.size() * sizeof(HuffWork), 0},
@@ -1783,6 +1789,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_sub_perm_, nullptr, 0, (size_t)total_subs_ * sizeof(uint32_t) + 256},
         {&d_lut_pool_, nullptr, 0, huff_pool_.size() * kLutPoolBytesPerTable},
         {&d_chunk_sums_, nullptr, 0, (size_t)total_chunks * sizeof(ChunkSum) + 256},
+        {&d_k1_tickets_, nullptr, 0, 256},  // [0] the ticket counter, [1] the device's give-up word
         {&d_idct_work_, idct_work.data(), idct_work.size() * sizeof(IdctWork), 0},
         {&d_idct_work_split_, idct_work_split.data(), idct_work_split.size() * sizeof(IdctWork), 0},
         {&d_ends_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},
@@ -1801,6 +1808,26 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             e = hipMemcpyAsync(u.buf->ptr, u.src, u.bytes, hipMemcpyHostToDevice, up);
             if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(descriptors)");
         }
+    }
+    {
+        // K1 in one pass: descriptors cleared when (re)allocated only (their tags are never reused), tickets + the give-up word per upload
+        const size_t want = (size_t)total_chunks * kMarkerDescBytes + 256;
+        if (want > d_k1_desc_.cap) {
+            e = d_k1_desc_.reserve(want);
+            if (e != hipSuccess) return hip_fail(e, "hipMalloc(K1 descriptors)");
+            e = hipMemsetAsync(d_k1_desc_.ptr, 0, d_k1_desc_.cap, up);
+            if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(K1 descriptors)");
+        }
+        e = hipMemsetAsync(d_k1_tickets_.ptr, 0, 2 * sizeof(uint32_t), up);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(K1 tickets)");
+        if (!h_k1_giveup_) {
+            e = hipHostMalloc((void **)&h_k1_giveup_, 64, hipHostMallocMapped);
+            if (e != hipSuccess) return hip_fail(e, "hipHostMalloc(K1 give-up word)");
+        }
+        *h_k1_giveup_ = 0;
+        k1_epoch_ = 0;
+        static const bool three_pass = getenv("JPGPU_K1_THREE_PASS") != nullptr;  // A/B switch: count + prefix + write kernels
+        k1_onepass_ = !three_pass;
     }
     e = hipMemsetAsync(d_sub_changed_.ptr, 0, kSubseqCtlWords * sizeof(uint32_t), up);  // (word kSubseqCtlSameDone: no twins found for this upload yet)
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(K2S control)");
@@ -1833,6 +1860,19 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
 
 int DeviceBatch::run_marker_index() {
     status_valid_ = false;
+    if (k1_onepass_) {
+        // one pass with a decoupled look-back (k1_markers.hip: groups of four chunks, handed out scan-interleaved, classified once);
+        // a group that runs out of patience counts its predecessors itself and says so in *h_k1_giveup_ (a count for the tests)
+        const char *bev = getenv("JPGPU_K1_SPIN_BUDGET");  // (read per call: the tests force the give-up with 0)
+        const uint32_t budget = bev ? (uint32_t)strtoul(bev, nullptr, 10) : (1u << 20);
+        uint32_t *tickets = (uint32_t *)d_k1_tickets_.ptr;
+        hipError_t e1 = launch_marker_onepass(ctx_->stream, (const uint8_t *)d_input_.ptr, (const DevScan *)d_scans_.ptr, (const ChunkWork *)d_k1_order_.ptr,
+                                              n_k1_groups_, d_k1_desc_.ptr, tickets, k1_epoch_, ++k1_tag_ ? k1_tag_ : ++k1_tag_, budget,
+                                              tickets + 1, h_k1_giveup_, (uint32_t *)d_ends_.ptr, (DevScanStatus *)d_status_.ptr,
+                                              (uint8_t *)d_unstuffed_.ptr, (uint32_t *)d_ends_u_.ptr);
+        k1_epoch_++;
+        return e1 == hipSuccess ? mark_work() : hip_fail(e1, "marker_onepass_kernel");
+    }
     hipError_t e = launch_marker_index(ctx_->stream, (const uint8_t *)d_input_.ptr, (const DevScan *)d_scans_.ptr, (int)h_scans_.size(),
                                        (const ChunkWork *)d_chunk_work_.ptr, n_chunk_work_, (ChunkSum *)d_chunk_sums_.ptr,
                                        (uint32_t *)d_ends_.ptr, (DevScanStatus *)d_status_.ptr, (uint8_t *)d_unstuffed_.ptr,
@@ -2180,6 +2220,10 @@ int DeviceBatch::sync() {
     hipError_t e = work_in_flight_ && done_ev_ ? hipEventSynchronize(done_ev_) : hipStreamSynchronize(ctx_->stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
     work_in_flight_ = false;
+    if (k1_onepass_ && h_k1_giveup_ && *h_k1_giveup_ != 0) {  // a group ran out of patience and counted its predecessors itself (tests: budget 0)
+        *h_k1_giveup_ = 0;
+        k1_fallbacks_++;
+    }
     return k2s_unchecked_ ? check_subseq_rounds() : JPGPU_OK;
 }
 

@@ -159,6 +159,7 @@ class DeviceBatch {
     int last_subseq_rounds() const { return last_subseq_rounds_; }
     int progressive_fallbacks() const { return prog_fallbacks_; }
     int subseq_fallbacks() const { return k2s_fallbacks_; }
+    int marker_fallbacks() const { return k1_fallbacks_; }
     int progressive_replays() const { return prog_replays_; }
     void set_partial_flush(bool on) { partial_flush_ = on; }
     // the optimizer path only needs the files, the scan descriptors and the marker index: no coefficient / sample buffers
@@ -248,6 +249,14 @@ class DeviceBatch {
   public:
     int clear_progressive_stores();
   private:
+    // K1 in one pass (launch_marker_onepass): the look-back descriptors (tagged, never cleared between decodes), a ticket counter
+    // per scan job + the device's give-up word behind them, the host's give-up word in page-locked memory
+    DevBuffer d_k1_desc_, d_k1_tickets_, d_k1_order_;
+    int n_k1_groups_ = 0;
+    uint32_t *h_k1_giveup_ = nullptr;
+    uint32_t k1_epoch_ = 0, k1_tag_ = 0;
+    bool k1_onepass_ = true;
+    int k1_fallbacks_ = 0;
     bool sub_same_valid_ = false;  // d_sub_same_ holds the twins of this upload's subsequences (subseq_same_kernel)
     int n_sub_work_ = 0, n_sub_gather_ = 0, n_sub_scans_ = 0, n_sub_final_work_ = 0, sub_final_spl_ = 2;
     DevBuffer d_sub_final_work_;

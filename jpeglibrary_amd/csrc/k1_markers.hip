@@ -292,35 +292,31 @@ __global__ __launch_bounds__(kScanThreads) void marker_prefix_kernel(const DevSc
 struct ChunkRef {
     uint32_t scan, chunk;
 };
-__device__ __forceinline__ void marker_write_chunk(const uint8_t *__restrict__ data, const DevScan &s, const ChunkRef wk,
-                                                   const ChunkSum *__restrict__ sums, uint32_t *__restrict__ ends,
-                                                   DevScanStatus *__restrict__ status, uint8_t *__restrict__ udata,
-                                                   uint32_t *__restrict__ ends_u) {
+// `mine`: RSTs / udata bytes of the chunks BEFORE this one, and (pad) the earliest terminator among this chunk and the ones before it
+// (the three-kernel form hands over the earliest of the whole scan: a terminator in a LATER chunk changes nothing here).
+// `c`: the chunk's bytes, 16 per lane, classified (classify16 of what load16 returned for them).
+__device__ __forceinline__ void marker_write_chunk(const uint8_t *__restrict__ data, const DevScan &s, const ChunkRef wk, const ChunkSum mine,
+                                                   ByteClass c, uint32_t *__restrict__ ends, DevScanStatus *__restrict__ status,
+                                                   uint8_t *__restrict__ udata, uint32_t *__restrict__ ends_u) {
     const uint8_t *p = data + s.data_off;
     uint8_t *up = udata + s.data_off;
     const uint32_t len = s.data_len;
     const uint32_t cap = s.n_intervals;
     uint32_t *out = ends + s.ends_off;
     uint32_t *out_u = ends_u + s.ends_off;
-    const ChunkSum *cs = sums + s.chunk_off;
     const uint32_t tid = threadIdx.x;
 
     __shared__ uint32_t sh_a[kScanThreads / 64], sh_b[kScanThreads / 64];
     __shared__ __attribute__((aligned(16))) uint8_t sh_tile[kChunkBytes + 2 * kScanThreads + 16];
 
-    // the tile's bytes are asked for BEFORE the chunk's summary is waited for: two load latencies side by side instead of in a row
     const int32_t misalign = (int32_t)(s.data_off & 15u);
     const int64_t chunk_first = -(int64_t)misalign + (int64_t)wk.chunk * kChunkBytes;
     const int64_t off = chunk_first + (int64_t)tid * 16;
-    const Raw16 raw = load16(p, off, len);
-    // RSTs / udata bytes of the chunks before this one, earliest terminator of the whole scan (marker_prefix_kernel)
-    const ChunkSum mine = cs[wk.chunk];
     const uint32_t rst_base = mine.rst_cnt, ubase = mine.keep_cnt, term = mine.pad;
     if (term != kInf && (int64_t)term < chunk_first) return;  // the scan's data ended in an earlier chunk
     if (rst_base >= cap && cap > 0) return;                    // every interval was closed in an earlier chunk
     if (cap == 0) return;
 
-    ByteClass c = classify16(raw, off, len, s.dri == 0);
     const bool term_here = term != kInf && (int64_t)term < chunk_first + (int64_t)kChunkBytes;
     if (term_here) {  // RST markers behind the terminator do not count
 #pragma unroll
@@ -449,7 +445,205 @@ __global__ __launch_bounds__(kScanThreads) void marker_write_kernel(const uint8_
     // kMarkerChunksPerWg consecutive chunks per workgroup (see marker_count_kernel)
     for (uint32_t chunk = wk0.chunk; chunk < wk0.chunk + kMarkerChunksPerWg && chunk < s.n_chunks; chunk++) {
         __syncthreads();  // the shared tile / scan scratch of the previous chunk is free
-        marker_write_chunk(data, s, ChunkRef{wk0.scan, chunk}, sums, ends, status, udata, ends_u);
+        // the tile's bytes are asked for BEFORE the chunk's summary is waited for: two load latencies side by side instead of in a row
+        const int64_t off = -(int64_t)(s.data_off & 15u) + (int64_t)chunk * kChunkBytes + (int64_t)threadIdx.x * 16;
+        const Raw16 raw = load16(data + s.data_off, off, s.data_len);
+        const ChunkSum mine = sums[s.chunk_off + chunk];
+        marker_write_chunk(data, s, ChunkRef{wk0.scan, chunk}, mine, classify16(raw, off, s.data_len, s.dri == 0), ends, status, udata, ends_u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 in ONE pass (round 5).  The three-kernel form reads the entropy segments twice: marker_count_kernel for the chunk summaries,
+// marker_prefix_kernel for their running sums, marker_write_kernel -- which classifies the same bytes again -- for the writing.
+// Here a workgroup takes a GROUP of consecutive chunks of a scan, classifies their tiles once, publishes the group's summary, finds
+// the running sums of the groups in front of it by looking BACK (decoupled look-back: Merrill & Garland) and writes.  Per group two
+// descriptors of three 8-byte granules {value, tag}: AGGREGATE (this group alone: RSTs, udata bytes, first terminator) and
+// INCLUSIVE (everything up to and including it).  A granule is one agent-scope 8-byte store and is read by one agent-scope 8-byte
+// load: it arrives whole or not at all, no fence on either side (the per-XCD L2s are not coherent: sc1 traffic goes past them, and a
+// release / acquire pair would write back / invalidate the whole L2 at every publish and poll); tag = a number no earlier decode of
+// the batch object has used, so nothing is cleared between decodes.  Wave 0 of the workgroup looks at 64 predecessors at a time: the
+// nearest INCLUSIVE one ends the walk, AGGREGATEs in front of it are summed, a predecessor that has published neither is waited for.
+// No workgroup waits for one that has not started: the group a workgroup takes is a TICKET into the order list (one atomic counter),
+// in which a scan's groups stand in the scan's order, so every group in front of it has been taken by a workgroup that is running
+// or done.  The wait is bounded all the same: a workgroup that runs out of patience counts the chunks in front of its group itself.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kK1DescWords = 8;  // uint64 per chunk: [0..2] aggregate {rst, keep, term}, [3..5] inclusive, [6..7] unused (64-byte stride)
+__device__ __forceinline__ void k1_publish(unsigned long long *d, uint32_t rst, uint32_t keep, uint32_t term, uint32_t tag) {
+    __hip_atomic_store(d + 0, ((unsigned long long)tag << 32) | rst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 1, ((unsigned long long)tag << 32) | keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 2, ((unsigned long long)tag << 32) | term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool k1_read(const unsigned long long *d, uint32_t tag, uint32_t &rst, uint32_t &keep, uint32_t &term) {
+    const unsigned long long a = __hip_atomic_load(d + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long c = __hip_atomic_load(d + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rst = (uint32_t)a;
+    keep = (uint32_t)b;
+    term = (uint32_t)c;
+    return (uint32_t)(a >> 32) == tag && (uint32_t)(b >> 32) == tag && (uint32_t)(c >> 32) == tag;
+}
+
+// Second form (round 5, behind the encoder's bits_emit_kernel): the first one gave every 4 KiB chunk a workgroup of its own that
+// lived ~2 us, polled for about as long, and classified its tile twice (for the summary, and again in the writer): 2.39 ms against
+// the three kernels' 1.03.  Here a workgroup takes kK1Group consecutive chunks of a scan (all their loads in flight together),
+// keeps their classification in registers for the writer -- so the bytes are classified ONCE, and these kernels are bound by
+// instruction issue -- publishes ONE summary for the group, and the groups are handed out (a global ticket into `order`) by
+// (place inside the scan, scan): the workgroups that run side by side belong to as many scans as the batch has, a scan's chain
+// is a record or two long at any time, and a scan's groups still start in the scan's order.
+constexpr uint32_t kK1Group = kMarkerGroupChunks;
+__global__ __launch_bounds__(kScanThreads) void marker_onepass_kernel(const uint8_t *__restrict__ data, const DevScan *__restrict__ scans,
+                                                                       const ChunkWork *__restrict__ order, uint32_t n_groups,
+                                                                       unsigned long long *__restrict__ desc, uint32_t *__restrict__ tickets, uint32_t epoch,
+                                                                       uint32_t tag, uint32_t spin_budget, uint32_t *__restrict__ giveup,
+                                                                       uint32_t *__restrict__ host_giveup, uint32_t *__restrict__ ends,
+                                                                       DevScanStatus *__restrict__ status, uint8_t *__restrict__ udata,
+                                                                       uint32_t *__restrict__ ends_u) {
+    __shared__ uint32_t sh_ticket, sh_cnt[kK1Group][kScanThreads / 64], sh_term[kK1Group][kScanThreads / 64], sh_mine[3], sh_ok;
+    const uint32_t tid = threadIdx.x;
+    // the group: a ticket into the order list (tickets[0] has counted n_groups per earlier decode of this upload)
+    if (tid == 0) sh_ticket = atomicAdd(&tickets[0], 1u) - epoch * n_groups;
+    __syncthreads();
+    if (sh_ticket >= n_groups) return;  // (cannot happen: one workgroup per listed group)
+    const ChunkWork wk = order[sh_ticket];
+    const uint32_t scan = wk.scan, first_chunk = wk.chunk;
+    const DevScan &s = scans[scan];
+    const uint32_t len = s.data_len;
+    const bool any_marker = s.dri == 0;
+    // ---- the group's tiles: every load issued before the first is classified (a chunk behind the scan's last holds nothing)
+    Raw16 raw[kK1Group];
+    int64_t off[kK1Group];
+#pragma unroll
+    for (uint32_t i = 0; i < kK1Group; i++) {
+        off[i] = -(int64_t)(s.data_off & 15u) + (int64_t)(first_chunk + i) * kChunkBytes + (int64_t)tid * 16;
+        raw[i] = load16(data + s.data_off, off[i], len);
+    }
+    ByteClass c[kK1Group];
+#pragma unroll
+    for (uint32_t i = 0; i < kK1Group; i++) {
+        c[i] = classify16(raw[i], off[i], len, any_marker);
+        // the chunk's summary (what marker_count_kernel computes)
+        const uint32_t cnt = wave_sum((uint32_t)__builtin_popcount(c[i].rst) | ((uint32_t)(__builtin_popcount(c[i].keep) + __builtin_popcount(c[i].rst | c[i].term)) << 16));
+        const uint64_t has_term = __ballot(c[i].term != 0);
+        uint32_t tpos = kInf;
+        if (has_term != 0) tpos = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off[i] + __builtin_ctz(c[i].term | 0x10000u)), (int)__builtin_ctzll(has_term));
+        if (lane_id() == 0) {
+            sh_cnt[i][tid >> 6] = cnt;
+            sh_term[i][tid >> 6] = tpos;
+        }
+    }
+    __syncthreads();
+    // per chunk: RSTs / udata bytes of the group's chunks in front of it, earliest terminator up to and including it
+    uint32_t pre_rst[kK1Group], pre_keep[kK1Group], upto_term[kK1Group];
+    uint32_t a_rst = 0, a_keep = 0, a_term = kInf;
+#pragma unroll
+    for (uint32_t i = 0; i < kK1Group; i++) {
+        uint32_t total = 0, t = kInf;
+#pragma unroll
+        for (int w = 0; w < kScanThreads / 64; w++) {
+            total += sh_cnt[i][w];
+            t = sh_term[i][w] < t ? sh_term[i][w] : t;
+        }
+        pre_rst[i] = a_rst;
+        pre_keep[i] = a_keep;
+        a_rst += total & 0xFFFFu;
+        a_keep += total >> 16;
+        a_term = t < a_term ? t : a_term;
+        upto_term[i] = a_term;
+    }
+    const uint32_t group = first_chunk / kK1Group;
+    unsigned long long *my = desc + (size_t)(s.chunk_off + first_chunk) * kK1DescWords;  // (the record of the group's first chunk)
+    // ---- publish, look back, publish (wave 0; the others wait at the barrier below)
+    if (tid < 64) {
+        uint32_t x_rst = 0, x_keep = 0, x_term = kInf;  // exclusive: the groups in front of this one
+        bool ok = true;
+        if (group == 0) {
+            if (tid == 0) k1_publish(my + 3, a_rst, a_keep, a_term, tag);
+        } else {
+            if (tid == 0) k1_publish(my, a_rst, a_keep, a_term, tag);
+            int64_t window_first = (int64_t)group - 1;  // lane l looks at group window_first - l
+            uint32_t polls = 0;
+            for (;;) {
+                const int64_t pg = window_first - (int64_t)tid;
+                uint32_t r = 0, k = 0, t = kInf;
+                uint32_t state = 3;  // 0 nothing yet, 1 aggregate, 2 inclusive, 3 in front of the scan's first group
+                if (pg >= 0) {
+                    const unsigned long long *pd = desc + (size_t)(s.chunk_off + (uint32_t)pg * kK1Group) * kK1DescWords;
+                    if (k1_read(pd + 3, tag, r, k, t)) state = 2;
+                    else if (k1_read(pd, tag, r, k, t)) state = 1;
+                    else state = 0;
+                }
+                const uint64_t inc = __ballot(state == 2), none = __ballot(state == 0);
+                // the lanes that count: the ones in front of (and including) the nearest inclusive predecessor
+                const uint32_t stop = inc != 0 ? (uint32_t)__builtin_ctzll(inc) : 63u;
+                const uint64_t upto = stop >= 63u ? ~0ull : ((2ull << stop) - 1ull);
+                if ((none & upto) != 0) {  // somebody there has not published yet
+                    if (++polls > spin_budget) {
+                        ok = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                    continue;
+                }
+                const bool counts = tid <= stop && state != 3;
+                x_rst += wave_sum(counts ? r : 0u);
+                x_keep += wave_sum(counts ? k : 0u);
+                x_term = min(x_term, wave_reduce_min(counts ? t : kInf));
+                if (inc != 0 || window_first - 63 <= 0) break;  // an inclusive prefix, or the scan's first group, was inside the window
+                window_first -= 64;
+            }
+            if (ok && tid == 0) k1_publish(my + 3, x_rst + a_rst, x_keep + a_keep, min(x_term, a_term), tag);
+        }
+        if (tid == 0) {
+            sh_mine[0] = x_rst;
+            sh_mine[1] = x_keep;
+            sh_mine[2] = x_term;
+            sh_ok = ok ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    uint32_t x_rst = sh_mine[0], x_keep = sh_mine[1], x_term = sh_mine[2];
+    if (sh_ok == 0) {
+        // Out of patience (it cannot happen while the groups are handed out by ticket; the bound is there so that nothing can hang,
+        // and the tests set it to zero): the group counts the chunks in front of it ITSELF -- slow, and dependent on nobody -- and
+        // goes on as if it had been told.  (The first form left here and had the host issue the three kernels: the kernels
+        // enqueued behind this one ran on a half-written index in the meantime.)
+        x_rst = 0, x_keep = 0, x_term = kInf;
+        for (uint32_t ch = 0; ch < first_chunk; ch++) {
+            const int64_t o = -(int64_t)(s.data_off & 15u) + (int64_t)ch * kChunkBytes + (int64_t)tid * 16;
+            const ByteClass cc = classify16(load16(data + s.data_off, o, len), o, len, any_marker);
+            const uint32_t cnt = wave_sum((uint32_t)__builtin_popcount(cc.rst) | ((uint32_t)(__builtin_popcount(cc.keep) + __builtin_popcount(cc.rst | cc.term)) << 16));
+            const uint64_t has_term = __ballot(cc.term != 0);
+            uint32_t tpos = kInf;
+            if (has_term != 0) tpos = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o + __builtin_ctz(cc.term | 0x10000u)), (int)__builtin_ctzll(has_term));
+            __syncthreads();
+            if (lane_id() == 0) {
+                sh_cnt[0][tid >> 6] = cnt;
+                sh_term[0][tid >> 6] = tpos;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < kScanThreads / 64; w++) {
+                x_rst += sh_cnt[0][w] & 0xFFFFu;
+                x_keep += sh_cnt[0][w] >> 16;
+                x_term = sh_term[0][w] < x_term ? sh_term[0][w] : x_term;
+            }
+        }
+        if (tid == 0) {
+            k1_publish(my + 3, x_rst + a_rst, x_keep + a_keep, min(x_term, a_term), tag);
+            __hip_atomic_store(host_giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (page-locked host memory: a count for the tests)
+        }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kK1Group; i++) {
+        if (first_chunk + i >= s.n_chunks) break;  // (uniform)
+        __syncthreads();  // the shared tile / scan scratch of the previous chunk is free
+        ChunkSum mine;
+        mine.rst_cnt = x_rst + pre_rst[i];
+        mine.keep_cnt = x_keep + pre_keep[i];
+        mine.first_term = 0;
+        mine.pad = x_term < upto_term[i] ? x_term : upto_term[i];
+        marker_write_chunk(data, s, ChunkRef{scan, first_chunk + i}, mine, c[i], ends, status, udata, ends_u);
     }
 }
 
@@ -469,6 +663,15 @@ hipError_t launch_first_marker(hipStream_t stream, const uint8_t *data, const vo
         hipLaunchKernelGGL(first_marker_kernel, dim3(chunks, n), dim3(kScanThreads), 0, stream, data, (const uint2 *)segs + base, seg_hi + base,
                            first + base);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_marker_onepass(hipStream_t stream, const uint8_t *data, const DevScan *scans, const ChunkWork *order, int n_groups,
+                                 void *desc, uint32_t *tickets, uint32_t epoch, uint32_t tag, uint32_t spin_budget, uint32_t *giveup,
+                                 uint32_t *host_giveup, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u) {
+    if (n_groups <= 0) return hipSuccess;
+    hipLaunchKernelGGL(marker_onepass_kernel, dim3(n_groups), dim3(kScanThreads), 0, stream, data, scans, order, (uint32_t)n_groups, (unsigned long long *)desc,
+                       tickets, epoch, tag, spin_budget, giveup, host_giveup, ends, status, udata, ends_u);
     return hipGetLastError();
 }
 

@@ -548,7 +548,32 @@ __device__ __forceinline__ void idct_output_body(
     if (!PRE && have_block) block_idct(f, (int32_t)s.level_shift, px);
     // (a frame has fewer than 2^32 blocks: 32-bit arithmetic; computed behind the transform, nothing more alive across it)
     const bool reached = mcu < decoded && mcu * bpm + b < fail_block;
-    writes = writes && (reached || !keep);
+    if ((s.shadow_mask & 0xFu) == 0) {
+        writes = writes && (reached || !keep);
+    } else {
+        // A scan that names a frame component twice (a corrupted selector; uniform branch): the reference writes the blocks in scan
+        // order, so at every place the LAST block that reached the writer stands -- the later duplicate's wherever the scan got to
+        // it, the earlier one's in the MCU the scan failed in BETWEEN the two (:118-134), zeros (in the batch's own buffer) where
+        // neither got.  Exactly one lane writes each place: a reached block unless the later duplicate's block at its place is
+        // reached too; an unreached block only if it is the last duplicate and no earlier duplicate's block is there either.
+        const uint32_t bb = b < kMaxBlocksPerMcu ? b : 0u, me = s.blk_comp[bb], fc = s.comp[me & 3u].component_index;
+        uint32_t later = 0xFFu, earlier = 0xFFu;  // scan components: the nearest duplicates of this block's
+        for (uint32_t cc = 0; cc < s.scan_components && cc < (uint32_t)kMaxScanComponents; cc++) {
+            if (cc == me || s.comp[cc].component_index != fc) continue;
+            if (cc > me && later == 0xFFu) later = cc;
+            if (cc < me) earlier = cc;
+        }
+        uint32_t first_me = 0xFFu, first_later = 0xFFu, first_earlier = 0xFFu;  // their first blocks in the MCU
+        for (uint32_t k = 0; k < bpm && k < (uint32_t)kMaxBlocksPerMcu; k++) {
+            const uint32_t ck = s.blk_comp[k];
+            if (ck == me && first_me == 0xFFu) first_me = k;
+            if (ck == later && first_later == 0xFFu) first_later = k;
+            if (ck == earlier && first_earlier == 0xFFu) first_earlier = k;
+        }
+        const bool later_reached = later != 0xFFu && mcu < decoded && mcu * bpm + (b - first_me + first_later) < fail_block;
+        const bool earlier_reached = earlier != 0xFFu && mcu < decoded && mcu * bpm + (b - first_me + first_earlier) < fail_block;
+        writes = have_block && (reached ? !later_reached : (!keep && later == 0xFFu && !earlier_reached));
+    }
     if (!reached) {
 #pragma unroll
         for (int i = 0; i < 32; i++) px[i] = 0;

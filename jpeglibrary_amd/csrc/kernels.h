@@ -24,6 +24,19 @@ constexpr uint32_t kMarkerChunkBytes = 4096;  // K1 chunk size (256 lanes x 16 b
 constexpr uint32_t kMarkerChunksPerWg = 1;  // marker_count_kernel takes several work entries per workgroup and relies on 1 here
 hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const DevScan *scans, int n_scans, const ChunkWork *work,
                                int n_chunks, ChunkSum *sums, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u);
+// K1 in one pass (k1_markers.hip): desc = kMarkerDescBytes per chunk (cleared when allocated), tickets = one uint32 per scan job
+// (cleared once per upload), epoch = decodes of this upload issued before this one, tag = a non-zero number no earlier launch over
+// `desc` has used; spin_budget = polls a workgroup may spend waiting for a predecessor.  *giveup (device, cleared once per upload) and
+// *host_giveup (page-locked host memory) != 0 afterwards: a workgroup gave up, ends / udata / statuses are incomplete -- issue
+// launch_marker_index instead.
+constexpr size_t kMarkerDescBytes = 64;
+#ifndef JPGPU_K1_GROUP
+#define JPGPU_K1_GROUP 4
+#endif
+constexpr uint32_t kMarkerGroupChunks = JPGPU_K1_GROUP;  // chunks a workgroup of the one-pass index takes; `order`: (scan, first chunk) per group, by (group, scan)
+hipError_t launch_marker_onepass(hipStream_t stream, const uint8_t *data, const DevScan *scans, const ChunkWork *order, int n_groups,
+                                 void *desc, uint32_t *tickets, uint32_t epoch, uint32_t tag, uint32_t spin_budget, uint32_t *giveup,
+                                 uint32_t *host_giveup, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u);
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                           const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
                           int n_slots, const uint8_t *lut_pool);

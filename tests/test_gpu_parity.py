@@ -438,6 +438,47 @@ def test_dri0_rounds_are_enqueued_ahead_and_checked_when_the_caller_waits(monkey
         assert np.array_equal(b4.output(i), r), i
 
 
+def test_marker_index_in_one_pass_and_its_bounded_wait(monkeypatch):
+    """Round 5: K1 reads and classifies the entropy segments once -- a workgroup per four 4 KiB chunks publishes its summary and finds the
+    running sums of the groups in front of it by looking back (marker_onepass_kernel) -- where round 4 counted, prefixed and wrote in
+    three kernels that read them twice.  Same ends / unstuffed data / statuses (ref: JpegBitReader.cs:95-138, the restart hand-off of
+    JpegHuffmanBaselineScanDecoder.cs:139-163): every case below against the restatement, in one batch and decode after decode.
+    A spin budget of zero makes any wait a give-up: the group then counts its predecessors itself -- same results."""
+    files = [jpegsynth.encode(1024, 768, "420", 75, 4, seed=31), jpegsynth.encode(640, 368, "444", 90, 1, seed=32), jpegsynth.encode(800, 600, "422", 60, 0, seed=33),
+             jpegsynth.encode(333, 211, "444", 60, 8, seed=10, noninterleaved=True), read_jpeg("progress.jpg"), read_jpeg("yellowcat_progressive_restart.jpg"),
+             jpegsynth.encode(1920, 1080, "420", 90, 4, seed=34)]
+    files.append(files[0][:len(files[0]) // 2] + b"\xff\xd9")  # truncated: the terminator in the middle of the scan
+    refs = []
+    for f in files:
+        px, _, err = po.decode_8bit_partial(f)
+        refs.append((px, err))
+    b = jl.Batch().upload(files, jl.FMT_INTERLEAVED_U8)
+    for _ in range(3):  # (the descriptors are not cleared between decodes: tags)
+        b.decode().sync()
+        for i, (px, err) in enumerate(refs):
+            assert (b.result(i).status != 0) == (err is not None), i
+            assert np.array_equal(b.output(i), px), i
+    assert b.marker_fallbacks() == 0
+    b.close()
+    # no patience at all: a group that finds a predecessor's record missing counts the data in front of it itself and goes on
+    # (whether any group HAD to wait is the machine's business: the counter says how many waits saw it happen)
+    monkeypatch.setenv("JPGPU_K1_SPIN_BUDGET", "0")
+    b = jl.Batch().upload(files * 4, jl.FMT_INTERLEAVED_U8)
+    for rep in range(3):
+        b.decode().sync()
+        assert 0 <= b.marker_fallbacks() <= rep + 1
+        for i in range(len(files) * 4):
+            px, err = refs[i % len(files)]
+            assert (b.result(i).status != 0) == (err is not None), i
+            assert np.array_equal(b.output(i), px), i
+    b.close()
+    monkeypatch.delenv("JPGPU_K1_SPIN_BUDGET")
+    monkeypatch.setenv("JPGPU_K1_THREE_PASS", "1")
+    outs, res = jl.decode_batch(files)
+    for i, (px, err) in enumerate(refs):
+        assert np.array_equal(outs[i], px), i
+
+
 def test_full_size_properties_4k():
     """BASELINE config-2 geometry at full size: every image of a small 4K batch is bit-exact vs the oracle, and the
     DRI=4 and DRI=0 encodings of the same pixels decode to identical output (restart markers carry no information)."""
