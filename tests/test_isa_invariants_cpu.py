@@ -119,3 +119,23 @@ def test_the_fused_encoder_kernel_keeps_the_fdct_in_ieee_steps(enc_isa):
     n = next(x for x in names if "fdct_fused_kernel" in x)
     assert int(vgprs[n]) <= 168 and spills[n] == "0" and sspills[n] == "0" and scratch[n] == "0"
     assert int(lds[n]) * 12 <= 160 * 1024  # twelve waves per CU
+
+
+@pytest.mark.timeout(600)
+def test_the_look_back_chains_neither_write_back_nor_invalidate_the_l2(isa, enc_isa):
+    """bits_emit_kernel (encoder, E2 + E3 in one pass) and marker_onepass_kernel (K1 in one pass) hand their chain records from
+    workgroup to workgroup as RELAXED device-scope atomics.  A release / acquire pair at that scope is `buffer_wbl2` / `buffer_inv` on
+    this part -- the XCD's whole L2 written back at every publish and invalidated at every poll, with every other workgroup's output
+    in it: the first versions of bits_emit_kernel took 18-57 ms instead of 2.5 (LAB_NOTEBOOK 8).  Neither instruction may appear;
+    the records must travel as device-scope (sc1) accesses, and neither kernel may spill."""
+    for text, prefix, name in ((enc_isa, "_ZN5jpgpu16bits_emit_kernel", "bits_emit_kernel"), (isa, "_ZN5jpgpu21marker_onepass_kernel", "marker_onepass_kernel")):
+        body = _body(text, prefix)
+        ops = [ln.split()[0] for ln in body]
+        assert not any(o.startswith("buffer_wbl2") or o.startswith("buffer_inv") for o in ops), name
+        assert any(("global_load" in ln or "global_atomic" in ln) and "sc1" in ln for ln in body), name   # the polls
+        assert any("global_store" in ln and "sc1" in ln for ln in body), name                              # the publishes
+        names = re.findall(r"\.name:\s+(\S+)", text)
+        spills = dict(zip(names, re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)))
+        scratch = dict(zip(names, re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text)))
+        n = next(x for x in names if name in x)
+        assert spills[n] == "0" and scratch[n] == "0", name
