@@ -360,6 +360,53 @@ def measure_config(jl, sharding, jpegsynth, torch, dist, reduce_device, ctx, nam
         batch.close()
 
 
+def measure_next_rows(jl, jpegsynth, gen_threads, images=128):
+    """SURVEY 8(f)'s rows either side of the path, briefly, for the driver's one run: the encoder (tools/bench_encode.py's workload:
+    4K RGB -> 4:2:0 Q75, standard tables) and the optimizer (tools/bench_optimize.py's: 4K 4:2:0 Q75 DRI = 7, strip), `images` each,
+    pixels / files resident in HBM, one output of each against the checker."""
+    from concurrent.futures import ThreadPoolExecutor
+    from tools.bench_encode import image
+    w, h = 3840, 2160
+    out = {}
+    with ThreadPoolExecutor(max(1, min(gen_threads, 16))) as ex:
+        base = list(ex.map(lambda k: image(w, h, k), range(min(images, 8))))
+    b = jl.EncodeBatch().upload([base[i % len(base)] for i in range(images)], (2, 2), 75, rgb=True)
+    b.encode()
+    b.encode()  # (the second encode of an upload sizes the one-pass entropy stage's buffer from the first)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        b.encode()
+    dt = (time.perf_counter() - t0) / 5
+    check = "not checked"
+    try:
+        from oracle import pyoracle as po
+        check = "byte-exact vs oracle" if b.output(0) == po.encode_8bit(po.rgb_to_ycbcr8(base[0]), 2, 2, 75) else "MISMATCH vs oracle"
+    except Exception as e:  # pragma: no cover
+        check = f"not checked ({e})"[:120]
+    out["encode_4k_420"] = {"value": round(images * w * h / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3, 3), "images": images,
+                            "stage_ms": {k: round(v, 3) for k, v in b.stage_ms().items()}, "entropy_stage_one_pass": b.emit_passes()[0] > 0,
+                            "parity_spot_check": check}
+    b.close()
+    buf, sizes, stride = jpegsynth.encode_batch(images, w, h, "420", 75, 7, seed0=1, nthreads=gen_threads)
+    files = [bytes(buf[i * stride:i * stride + int(sizes[i])]) for i in range(images)]
+    ob = jl.OptimizeBatch().upload(files, True)
+    ob.run()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ob.run()
+    dt = (time.perf_counter() - t0) / 5
+    check = "not checked"
+    try:
+        from oracle import pyoracle as po
+        check = "byte-exact vs oracle" if ob.output(0) == po.optimize(files[0], True) else "MISMATCH vs oracle"
+    except Exception as e:  # pragma: no cover
+        check = f"not checked ({e})"[:120]
+    out["optimize_4k_420"] = {"value": round(images * w * h / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3, 3), "images": images,
+                              "parity_spot_check": check}
+    ob.close()
+    return out
+
+
 def free_port():
     import socket
 
@@ -740,6 +787,12 @@ def main():
                     raise  # (the other ranks are inside the same barriers)
                 configs[name] = {"error": str(e)[:200]}
             log(f"[rank {rank}] config {name}: {json.dumps(configs[name])[:300]}")
+        if world == 1 and time.perf_counter() - t_cfg <= 150.0:
+            try:
+                configs.update(measure_next_rows(jl, jpegsynth, gen_threads, images=max(2, 128 // max(1, args.config_scale))))
+                log(f"[rank {rank}] next rows: {json.dumps({k: configs[k] for k in ('encode_4k_420', 'optimize_4k_420')})[:400]}")
+            except Exception as e:  # pragma: no cover
+                configs["encode_4k_420"] = {"error": str(e)[:200]}
         if rank == 0:
             configs["note"] = ("short passes of the other BASELINE.json configurations, run after the headline's timed region with the same step "
                                "definition (inputs resident in HBM, output left in HBM); roofline = K3's algorithmic bytes / its HIP-event time; "

@@ -322,6 +322,10 @@ def test_bench_line_carries_every_baseline_config_and_the_in_process_driver():
         assert c["stage_ms"]["idct"] > 0 and 0 < c["roofline"]["frac"] < 1, (name, c)
     assert cfg["4k_dri0"]["subseq_rounds"] >= 2 and cfg["4k_dri0"]["subseq_fallbacks"] == 0
     assert cfg["het_8192"]["single_image_decode_ms"] > 0 and cfg["4k_progressive"]["value_two_in_flight"] > 0
+    # ... and the rows either side of the path: encoder and optimizer, each with one output against the checker
+    for name in ("encode_4k_420", "optimize_4k_420"):
+        assert cfg[name]["value"] > 0 and cfg[name]["parity_spot_check"] == "byte-exact vs oracle", (name, cfg[name])
+    assert cfg["encode_4k_420"]["entropy_stage_one_pass"] is True
     assert out["value_multi_inprocess"] > 0 and out["multi_inprocess"]["parity_spot_check"] == "bit-exact vs oracle"
 
 
