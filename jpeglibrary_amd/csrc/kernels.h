@@ -24,11 +24,11 @@ constexpr uint32_t kMarkerChunkBytes = 4096;  // K1 chunk size (256 lanes x 16 b
 constexpr uint32_t kMarkerChunksPerWg = 1;  // marker_count_kernel takes several work entries per workgroup and relies on 1 here
 hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const DevScan *scans, int n_scans, const ChunkWork *work,
                                int n_chunks, ChunkSum *sums, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u);
-// K1 in one pass (k1_markers.hip): desc = kMarkerDescBytes per chunk (cleared when allocated), tickets = one uint32 per scan job
-// (cleared once per upload), epoch = decodes of this upload issued before this one, tag = a non-zero number no earlier launch over
-// `desc` has used; spin_budget = polls a workgroup may spend waiting for a predecessor.  *giveup (device, cleared once per upload) and
-// *host_giveup (page-locked host memory) != 0 afterwards: a workgroup gave up, ends / udata / statuses are incomplete -- issue
-// launch_marker_index instead.
+// K1 in one pass (k1_markers.hip): desc = kMarkerDescBytes per chunk (cleared when allocated; a group uses its first chunk's),
+// tickets[0] = the ticket counter (cleared once per upload), epoch = decodes of this upload issued before this one, tag = a non-zero
+// number no earlier launch over `desc` has used; spin_budget = polls a workgroup may spend waiting for a predecessor before it counts
+// the chunks in front of its group itself -- *host_giveup (page-locked host memory) != 0 afterwards says that happened (the results
+// are complete either way); `giveup` is not used any more.
 constexpr size_t kMarkerDescBytes = 64;
 #ifndef JPGPU_K1_GROUP
 #define JPGPU_K1_GROUP 4
