@@ -173,6 +173,8 @@ struct ExtendPlanes {
     uint32_t pitch[4];      // samples
     uint32_t hshift[4], vshift[4];
     uint32_t width, height, ncomp, precision;
+    uint32_t hcnt[4], vcnt[4];  // the components' sampling factors H, V (blocks per MCU in x / y) ...
+    uint32_t max_h, max_v;      // ... and the frame's maxima: the (offsetX + x) * 8 placement of a factor that is neither (round 6)
 };
 
 constexpr uint32_t kNoError = 0xFFFFFFFFu;

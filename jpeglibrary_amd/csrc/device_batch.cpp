@@ -1682,6 +1682,13 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             for (int c = 0; c < s.scan_components; c++) covered[s.comp[c].component_index >> 6] |= 1ull << (s.comp[c].component_index & 63);
         }
         bool all = true;
+        // ... and a component whose sampling factor is neither the frame's maximum nor 1 (round 6): the decoder's (offsetX + x) * 8
+        // placement leaves the last columns / rows of every MCU unwritten (k3_idct.hip, interleaved_output_from_tile)
+        for (int j : img.jobs) {
+            const DevScan &s = h_scans_[j];
+            if (jobs_[j].kind == kScanProgressive) continue;
+            for (int c = 0; c < s.scan_components; c++) all &= !((s.comp[c].h > 1 && s.comp[c].hs > 1) || (s.comp[c].v > 1 && s.comp[c].vs > 1));
+        }
         for (int c = 0; c < img.num_components; c++) all &= ((covered[c >> 6] >> (c & 63)) & 1ull) != 0;
         if (!all && !img.replay_skip) out_clear_.push_back({img.out_offset, img.out_bytes, img.planes_offset, img.planes_bytes});
         // RGB / RGBA = the callers' converter applied to the YCbCr8 buffer (DecodeAction.cs:71-74): an image without any scan
@@ -2109,7 +2116,11 @@ int DeviceBatch::run_idct() {
                 const int hs = geo.max_h / std::max<int>(1, geo.frame.components[c].h), vs = geo.max_v / std::max<int>(1, geo.frame.components[c].v);
                 while ((1 << (g.hshift[c] + 1)) <= hs) g.hshift[c]++;
                 while ((1 << (g.vshift[c] + 1)) <= vs) g.vshift[c]++;
+                g.hcnt[c] = std::max<int>(1, geo.frame.components[c].h);
+                g.vcnt[c] = std::max<int>(1, geo.frame.components[c].v);
             }
+            g.max_h = (uint32_t)geo.max_h;
+            g.max_v = (uint32_t)geo.max_v;
             g.out_off = img.out_offset;
             g.width = img.width;
             g.height = img.height;

@@ -257,8 +257,12 @@ __global__ __launch_bounds__(256) void ycc_to_rgb_kernel(const uint8_t *__restri
 // "O3", the xunit tests' sink (ref: tests/JpegLibrary.Tests/Utils/JpegExtendingOutputWriter.cs:30-112) as a device format:
 // out[(y * W + x) * 4 + c] (componentCount = 4, the way every test constructs it), uint16.  Input: the PLANAR_I16 planes K3
 // wrote = WriteBlock's arguments before chroma expansion.  WriteBlockSlow replicates with shifts (:238-268), so pixel (x, y)
-// of component c is plane_c[y >> vshift][x >> hshift]; the writer then takes (ushort)sample -- a negative sample becomes a
-// large value -- clamps to 2^P - 1 and spreads the P bits over 16 (FastExpandBits for P >= 8, ExpandBits below).
+// of component c is plane_c[y >> vshift][x >> hshift] -- for a sampling factor that is the frame's maximum or 1.  Any other
+// factor (round 6: H = 2 under a maximum of 4 ...) meets the decoder's `(offsetX + x) * 8` placement (...BaselineScanDecoder.cs:104,
+// 134): block x of the MCU lands 8 pixels behind block x - 1 and is hs * 8 wide, so the blocks of one MCU overlap, the later call
+// winning, and the MCU's last (hs - 1) * (h - 1) * 8 columns are never written (they keep the buffer's zero); the same downwards.
+// The writer then takes (ushort)sample -- a negative sample becomes a large value -- clamps to 2^P - 1 and spreads the P bits
+// over 16 (FastExpandBits for P >= 8, ExpandBits below).
 // One launch for the whole batch: blockIdx.y = image (its descriptor in HBM), blockIdx.x strides over the image's pixels.
 __global__ __launch_bounds__(256) void extend_u16_kernel(const uint8_t *__restrict__ planes, uint8_t *__restrict__ out_base,
                                                          const ExtendPlanes *__restrict__ images) {
@@ -272,7 +276,13 @@ __global__ __launch_bounds__(256) void extend_u16_kernel(const uint8_t *__restri
     for (uint32_t c = 0; c < 4u; c++) {
         if (c >= g.ncomp) continue;
         const int16_t *pl = reinterpret_cast<const int16_t *>(planes + g.plane_off[c]);
-        const uint32_t s = (uint32_t)(uint16_t)pl[(uint64_t)(y >> g.vshift[c]) * g.pitch[c] + (x >> g.hshift[c])];
+        // the LAST block of the MCU whose replicated samples cover the pixel: x* = min(px >> 3, h - 1), covered while px < 8 x* + 8 hs
+        const uint32_t mw = 8u * g.max_h, mh = 8u * g.max_v;
+        const uint32_t mcx = x / mw, pxm = x - mcx * mw, mcy = y / mh, pym = y - mcy * mh;
+        const uint32_t bx = (pxm >> 3) < g.hcnt[c] - 1u ? (pxm >> 3) : g.hcnt[c] - 1u, by = (pym >> 3) < g.vcnt[c] - 1u ? (pym >> 3) : g.vcnt[c] - 1u;
+        const uint32_t dx = pxm - 8u * bx, dy = pym - 8u * by;
+        if (dx >= (8u << g.hshift[c]) || dy >= (8u << g.vshift[c])) continue;  // never written: the fresh buffer's zero
+        const uint32_t s = (uint32_t)(uint16_t)pl[(uint64_t)((mcy * g.vcnt[c] + by) * 8u + (dy >> g.vshift[c])) * g.pitch[c] + (mcx * g.hcnt[c] + bx) * 8u + (dx >> g.hshift[c])];
         uint32_t bits = s < mx ? s : mx;  // Clamp((ushort)sample, max)
         if (p >= 8u) {
             const uint32_t rem = 16u - p;
@@ -302,7 +312,8 @@ __global__ __launch_bounds__(256) void extend_u16_kernel(const uint8_t *__restri
 template <int LAY, int CONV>
 __device__ __forceinline__ void interleaved_output_from_tile(const uint8_t *sh_px, const DevScan &s, uint32_t tile_first, uint32_t n_mcu,
                                                              uint32_t tid, bool have_block, const DevScanComponent &comp, uint32_t mcu_x,
-                                                             uint32_t mcu_y, uint32_t b, uint8_t *out, const YccRgbFactors &kf) {
+                                                             uint32_t mcu_y, uint32_t b, uint8_t *out, const YccRgbFactors &kf, bool reached,
+                                                             uint32_t mcu, uint32_t fail_block) {
     const uint32_t W = s.width, H = s.height, C = s.frame_components;
     uint8_t *img = out + s.out_off;
 
@@ -313,16 +324,35 @@ __device__ __forceinline__ void interleaved_output_from_tile(const uint8_t *sh_p
             const uint32_t hs = comp.hs, vs = comp.vs;
             const uint32_t x0 = (mcu_x * s.max_h + s.blk_x[b]) * 8, y0 = (mcu_y * s.max_v + s.blk_y[b]) * 8;
             const uint32_t hshift = 31 - __builtin_clz(hs | 1), vshift = 31 - __builtin_clz(vs | 1);
+            // A sampling factor that is neither the frame's maximum nor 1 (round 6): the decoder places block x of the MCU at
+            // (offsetX + x) * 8 (:104, 134) whatever the block's replicated width hs * 8 is, so the blocks of one MCU OVERLAP and the
+            // later WriteBlock wins: a block owns a replicated pixel unless the next block that covers it -- block x + 1 of its
+            // row from column 8 on, else from row 8 on the first covering block of the row below -- has reached the writer too.
+            // (What no block covers keeps the buffer's content: the host clears the outputs of such frames, plan_work.)
+            const uint32_t bx = s.blk_x[b], by = s.blk_y[b];
+            const bool overlap_h = comp.h > 1 && hs > 1, overlap_v = comp.v > 1 && vs > 1;
+            const uint32_t base = b - (by * comp.h + bx);  // the component's first block in the MCU
+            if ((overlap_h || overlap_v) && !reached) return;
             for (uint32_t v = 0; v < vs; v++)
                 for (uint32_t i = 0; i < 8; i++) {
                     const uint32_t y = y0 + 8 * v + i;
                     if (y >= H) continue;
                     const uint8_t *srow = sh_px + ((8 * v + i) >> vshift) * kPxRowStride + tid * 8;
-                    for (uint32_t h = 0; h < hs; h++)
+                    for (uint32_t h = 0; h < hs; h++) {
+                        if (overlap_h || overlap_v) {
+                            uint32_t later = 0xFFFFFFFFu;  // the earliest later block that covers these eight pixels
+                            if (overlap_h && bx + 1 < comp.h && h >= 1) later = base + by * comp.h + bx + 1;
+                            else if (overlap_v && by + 1 < comp.v && v >= 1) {
+                                const int32_t xf = (int32_t)bx + (int32_t)h - (int32_t)hs + 1;
+                                later = base + (by + 1) * comp.h + (uint32_t)(xf < 0 ? 0 : xf);
+                            }
+                            if (later != 0xFFFFFFFFu && (uint64_t)mcu * s.blocks_per_mcu + later < fail_block) continue;
+                        }
                         for (uint32_t j = 0; j < 8; j++) {
                             const uint32_t x = x0 + 8 * h + j;
                             if (x < W) img[((size_t)y * W + x) * C + comp.component_index] = srow[(8 * h + j) >> hshift];
                         }
+                    }
                 }
         }
     } else {
@@ -647,7 +677,7 @@ __device__ __forceinline__ void idct_output_body(
     __builtin_amdgcn_s_barrier();
     synced = true;
 
-    interleaved_output_from_tile<LAY, CONV>(sh_px, s, tile_first, n_mcu, tid, writes, comp, mcu_x, mcu_y, b, out, kf);
+    interleaved_output_from_tile<LAY, CONV>(sh_px, s, tile_first, n_mcu, tid, writes, comp, mcu_x, mcu_y, b, out, kf, reached, mcu, fail_block);
     }  // interleaved
     }  // u8 formats
 

@@ -3,8 +3,9 @@
  *
  * The reference's encoder (JpegEncoder.cs) has no restart-interval support, so it cannot produce the
  * benchmark's DRI=4 inputs.  This is the build's own minimal baseline encoder:
- *   synthetic RGB (SURVEY 8d recipe) -> JFIF YCbCr -> 4:4:4 / 4:2:2 / 4:2:0 / gray -> float AAN FDCT ->
- *   Annex-K tables scaled libjpeg-style -> standard Huffman tables (one 418-byte DHT) -> DRI/RSTn -> EOI.
+ *   synthetic RGB (SURVEY 8d recipe) -> JFIF YCbCr -> 4:4:4 / 4:2:2 / 4:2:0 / gray, or any per-component sampling factors
+ *   (H, V) in 1..4 (round 6: 4:1:1, 4:4:0, 1x4, luma BELOW chroma, factors that are neither the maximum nor 1 ...) -> float AAN
+ *   FDCT -> Annex-K tables scaled libjpeg-style -> standard Huffman tables (one 418-byte DHT) -> DRI/RSTn -> EOI.
  * It is NOT on the decode path and NOT an oracle; files it writes are ordinary JFIF files (Pillow decodes them).
  * All segment lengths have a low byte >= 2, so the reference's length quirk (JpegReader.cs:174) is never hit.
  */
@@ -20,7 +21,13 @@ typedef struct jsynth_params {
     int quality;          /* 1..100, libjpeg scaling */
     int restart_interval; /* MCUs, 0 = none */
     uint64_t seed;
-    int noninterleaved;   /* 4:4:4 only: three single-component scans instead of one interleaved scan */
+    int noninterleaved;   /* three single-component scans instead of one interleaved scan.  The blocks of a scan go out in the
+                             order the REFERENCE reads them -- h x v blocks of the component per frame MCU
+                             (JpegHuffmanBaselineScanDecoder.cs:99-134 treats every scan as interleaved) -- which is T.81's order
+                             only for 4:4:4; noninterleaved = 2: T.81's order (one block per MCU, the component's own block
+                             raster), which the reference reads as something else */
+    int samp[3][2];       /* per component {H, V}; all zero = take `subsampling`.  A component is the box average over
+                             (Hmax / H) x (Vmax / V) pixels (ratios must be whole) */
 } jsynth_params;
 
 static const uint8_t k_zigzag_to_natural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
@@ -306,6 +313,19 @@ long jsynth_encode(const jsynth_params *prm, uint8_t *out, size_t cap) {
     if (w <= 0 || h <= 0 || w > 65535 || h > 65535 || ss < 0 || ss > 3) return -1;
     int hmax = (ss == 1 || ss == 2) ? 2 : 1, vmax = (ss == 2) ? 2 : 1;
     int ncomp = ss == 3 ? 1 : 3;
+    int ch[3] = {hmax, 1, 1}, cv[3] = {vmax, 1, 1};
+    if (prm->samp[0][0] != 0) {
+        hmax = vmax = 1;
+        for (int c = 0; c < ncomp; c++) {
+            ch[c] = prm->samp[c][0];
+            cv[c] = prm->samp[c][1];
+            if (ch[c] < 1 || ch[c] > 4 || cv[c] < 1 || cv[c] > 4) return -1;
+            if (ch[c] > hmax) hmax = ch[c];
+            if (cv[c] > vmax) vmax = cv[c];
+        }
+        for (int c = 0; c < ncomp; c++)
+            if (hmax % ch[c] != 0 || vmax % cv[c] != 0) return -1;
+    }
     int mcuw = 8 * hmax, mcuh = 8 * vmax;
     int mcus_x = (w + mcuw - 1) / mcuw, mcus_y = (h + mcuh - 1) / mcuh;
     int wpad = mcus_x * mcuw;
@@ -350,14 +370,14 @@ long jsynth_encode(const jsynth_params *prm, uint8_t *out, size_t cap) {
     seg[4] = (uint8_t)w;
     seg[5] = (uint8_t)ncomp;
     seg[6] = 1;
-    seg[7] = (uint8_t)((hmax << 4) | vmax);
+    seg[7] = (uint8_t)((ch[0] << 4) | cv[0]);
     seg[8] = 0;
     if (ncomp == 3) {
         seg[9] = 2;
-        seg[10] = 0x11;
+        seg[10] = (uint8_t)((ch[1] << 4) | cv[1]);
         seg[11] = 1;
         seg[12] = 3;
-        seg[13] = 0x11;
+        seg[13] = (uint8_t)((ch[2] << 4) | cv[2]);
         seg[14] = 1;
     }
     p = put_marker_seg(p, 0xC0, seg, 6 + 3 * ncomp);
@@ -394,7 +414,8 @@ long jsynth_encode(const jsynth_params *prm, uint8_t *out, size_t cap) {
         seg[1] = (uint8_t)prm->restart_interval;
         p = put_marker_seg(p, 0xDD, seg, 2);
     }
-    const int nscans = (prm->noninterleaved && ss == 0 && ncomp == 3) ? 3 : 1;
+    const int nscans = (prm->noninterleaved && ncomp == 3) ? 3 : 1;
+    const int t81_order = prm->noninterleaved == 2 && nscans == 3;
     synth_ctx sc;
     synth_init(&sc, w, h, prm->seed);
     size_t rowsz = (size_t)wpad;
@@ -433,34 +454,60 @@ long jsynth_encode(const jsynth_params *prm, uint8_t *out, size_t cap) {
         bw.nbits = 0;
         int pred[3] = {0, 0, 0};
         int mcus_before_restart = prm->restart_interval, rst_index = 0;
+        /* T.81's non-interleaved order: an MCU is ONE block, the scan walks the component's own block raster (A.2.3) */
+        const int sc_c = nscans == 3 ? scan : 0;
+        const int t81_bx = t81_order ? ((w * ch[sc_c] + hmax - 1) / hmax + 7) / 8 : 0;
+        const int t81_by = t81_order ? ((h * cv[sc_c] + vmax - 1) / vmax + 7) / 8 : 0;
+        const long n_units = t81_order ? (long)t81_bx * t81_by : (long)mcus_x * mcus_y;
+        long unit = 0;
         for (int my = 0; my < mcus_y && !bw.overflow; my++) {
             for (int r = 0; r < mcuh; r++) synth_row(&sc, my * mcuh + r, wpad, Y + r * rowsz, Cb + r * rowsz, Cr + r * rowsz);
             for (int mx = 0; mx < mcus_x; mx++) {
-                if (nscans == 1 || scan == 0)
-                    for (int by = 0; by < vmax; by++)
-                        for (int bx = 0; bx < hmax; bx++) {
-                            const float *src = Y + (size_t)(by * 8) * rowsz + (size_t)mx * mcuw + bx * 8;
+                for (int c = 0; c < ncomp; c++) {
+                    if (nscans == 3 && scan != c) continue;
+                    const float *pl = c == 0 ? Y : (c == 1 ? Cb : Cr);
+                    const int fx = hmax / ch[c], fy = vmax / cv[c];
+                    const float *ql = c == 0 ? qdiv_l : qdiv_c;
+                    const enc_table *tdc = c == 0 ? &dcl : &dcc, *tac = c == 0 ? &acl : &acc;
+                    for (int by = 0; by < cv[c]; by++)
+                        for (int bx = 0; bx < ch[c]; bx++) {
+                            if (t81_order && (mx * ch[c] + bx >= t81_bx || my * cv[c] + by >= t81_by)) continue;
+                            const float *src = pl + (size_t)(by * 8 * fy) * rowsz + (size_t)mx * mcuw + bx * 8 * fx;
                             for (int i = 0; i < 8; i++)
-                                for (int j = 0; j < 8; j++) blk[i * 8 + j] = src[i * rowsz + j] - 128.f;
-                            encode_block(&bw, blk, qdiv_l, &dcl, &acl, &pred[0]);
-                        }
-                if (ncomp == 3) {
-                    for (int c = 0; c < 2; c++) {
-                        if (nscans == 3 && scan != c + 1) continue;
-                        const float *pl = c == 0 ? Cb : Cr;
-                        const float *src = pl + (size_t)mx * mcuw;
-                        for (int i = 0; i < 8; i++)
-                            for (int j = 0; j < 8; j++) {
-                                float acc_ = 0.f;
-                                for (int vy = 0; vy < vmax; vy++)
-                                    for (int vx = 0; vx < hmax; vx++) acc_ += src[(size_t)(i * vmax + vy) * rowsz + j * hmax + vx];
-                                float v = acc_ / (float)(hmax * vmax);
-                                blk[i * 8 + j] = floorf(v + 0.5f) - 128.f;
+                                for (int j = 0; j < 8; j++) {
+                                    if (fx == 1 && fy == 1) {
+                                        blk[i * 8 + j] = src[i * rowsz + j] - 128.f;
+                                        continue;
+                                    }
+                                    float acc_ = 0.f;
+                                    for (int vy = 0; vy < fy; vy++)
+                                        for (int vx = 0; vx < fx; vx++) acc_ += src[(size_t)(i * fy + vy) * rowsz + j * fx + vx];
+                                    float v = acc_ / (float)(fx * fy);
+                                    blk[i * 8 + j] = floorf(v + 0.5f) - 128.f;
+                                }
+                            /* (T.81 order with more than one block row per MCU row would need the blocks of a whole MCU row
+                               reordered: block rows of one MCU row are emitted MCU by MCU here, which is T.81's order only
+                               for V = 1 -- good enough for a file the reference misreads anyway) */
+                            encode_block(&bw, blk, ql, tdc, tac, &pred[c]);
+                            if (t81_order) {
+                                unit++;
+                                if (prm->restart_interval > 0 && --mcus_before_restart == 0) {
+                                    if (unit != n_units) {
+                                        bw_flush_ones(&bw);
+                                        if (bw.p + 2 <= bw.end) {
+                                            *bw.p++ = 0xFF;
+                                            *bw.p++ = (uint8_t)(0xD0 + (rst_index & 7));
+                                        } else
+                                            bw.overflow = 1;
+                                        rst_index++;
+                                        pred[0] = pred[1] = pred[2] = 0;
+                                    }
+                                    mcus_before_restart = prm->restart_interval;
+                                }
                             }
-                        encode_block(&bw, blk, qdiv_c, &dcc, &acc, &pred[1 + c]);
-                    }
+                        }
                 }
-                if (prm->restart_interval > 0 && --mcus_before_restart == 0) {
+                if (!t81_order && prm->restart_interval > 0 && --mcus_before_restart == 0) {
                     int last = (my == mcus_y - 1 && mx == mcus_x - 1);
                     if (!last) {
                         bw_flush_ones(&bw);
