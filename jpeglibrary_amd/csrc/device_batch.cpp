@@ -1686,7 +1686,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         // placement leaves the last columns / rows of every MCU unwritten (k3_idct.hip, interleaved_output_from_tile)
         for (int j : img.jobs) {
             const DevScan &s = h_scans_[j];
-            if (jobs_[j].kind == kScanProgressive) continue;
+            if (jobs_[j].kind != kScanSequential) continue;  // (a progressive frame's Flush places the blocks side by side)
             for (int c = 0; c < s.scan_components; c++) all &= !((s.comp[c].h > 1 && s.comp[c].hs > 1) || (s.comp[c].v > 1 && s.comp[c].vs > 1));
         }
         for (int c = 0; c < img.num_components; c++) all &= ((covered[c >> 6] >> (c & 63)) & 1ull) != 0;
@@ -2119,8 +2119,11 @@ int DeviceBatch::run_idct() {
                 g.hcnt[c] = std::max<int>(1, geo.frame.components[c].h);
                 g.vcnt[c] = std::max<int>(1, geo.frame.components[c].v);
             }
-            g.max_h = (uint32_t)geo.max_h;
-            g.max_v = (uint32_t)geo.max_v;
+            // (0, 0: a progressive frame -- the allocator's Flush places the replicated blocks side by side)
+            bool flush = false;
+            for (int j : img.jobs) flush |= jobs_[j].kind != kScanSequential;
+            g.max_h = flush ? 0u : (uint32_t)geo.max_h;
+            g.max_v = flush ? 0u : (uint32_t)geo.max_v;
             g.out_off = img.out_offset;
             g.width = img.width;
             g.height = img.height;

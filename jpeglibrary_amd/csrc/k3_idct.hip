@@ -277,12 +277,13 @@ __global__ __launch_bounds__(256) void extend_u16_kernel(const uint8_t *__restri
         if (c >= g.ncomp) continue;
         const int16_t *pl = reinterpret_cast<const int16_t *>(planes + g.plane_off[c]);
         // the LAST block of the MCU whose replicated samples cover the pixel: x* = min(px >> 3, h - 1), covered while px < 8 x* + 8 hs
-        const uint32_t mw = 8u * g.max_h, mh = 8u * g.max_v;
+        const uint32_t mw = 8u * (g.max_h | (g.max_h == 0)), mh = 8u * (g.max_v | (g.max_v == 0));
         const uint32_t mcx = x / mw, pxm = x - mcx * mw, mcy = y / mh, pym = y - mcy * mh;
         const uint32_t bx = (pxm >> 3) < g.hcnt[c] - 1u ? (pxm >> 3) : g.hcnt[c] - 1u, by = (pym >> 3) < g.vcnt[c] - 1u ? (pym >> 3) : g.vcnt[c] - 1u;
         const uint32_t dx = pxm - 8u * bx, dy = pym - 8u * by;
-        if (dx >= (8u << g.hshift[c]) || dy >= (8u << g.vshift[c])) continue;  // never written: the fresh buffer's zero
-        const uint32_t s = (uint32_t)(uint16_t)pl[(uint64_t)((mcy * g.vcnt[c] + by) * 8u + (dy >> g.vshift[c])) * g.pitch[c] + (mcx * g.hcnt[c] + bx) * 8u + (dx >> g.hshift[c])];
+        if (g.max_h != 0 && (dx >= (8u << g.hshift[c]) || dy >= (8u << g.vshift[c]))) continue;  // never written: the fresh buffer's zero
+        const uint32_t s = g.max_h == 0 ? (uint32_t)(uint16_t)pl[(uint64_t)(y >> g.vshift[c]) * g.pitch[c] + (x >> g.hshift[c])]  // (a progressive frame: the allocator's Flush)
+                                        : (uint32_t)(uint16_t)pl[(uint64_t)((mcy * g.vcnt[c] + by) * 8u + (dy >> g.vshift[c])) * g.pitch[c] + (mcx * g.hcnt[c] + bx) * 8u + (dx >> g.hshift[c])];
         uint32_t bits = s < mx ? s : mx;  // Clamp((ushort)sample, max)
         if (p >= 8u) {
             const uint32_t rem = 16u - p;
@@ -322,7 +323,11 @@ __device__ __forceinline__ void interleaved_output_from_tile(const uint8_t *sh_p
         // (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:238-268) and the sink's clipping (x < W, y < H)
         if (have_block) {
             const uint32_t hs = comp.hs, vs = comp.vs;
-            const uint32_t x0 = (mcu_x * s.max_h + s.blk_x[b]) * 8, y0 = (mcu_y * s.max_v + s.blk_y[b]) * 8;
+            // (a progressive frame's Dispose(): JpegBlockAllocator.Flush places block (col, row) of the component's own grid at
+            // (col * hs * 8, row * vs * 8), JpegBlockAllocator.cs:120-149 -- the same place for a factor that is the maximum or 1)
+            const bool flush = s.kind == kScanFrameOnly;
+            const uint32_t x0 = flush ? (mcu_x * comp.h + s.blk_x[b]) * hs * 8 : (mcu_x * s.max_h + s.blk_x[b]) * 8;
+            const uint32_t y0 = flush ? (mcu_y * comp.v + s.blk_y[b]) * vs * 8 : (mcu_y * s.max_v + s.blk_y[b]) * 8;
             const uint32_t hshift = 31 - __builtin_clz(hs | 1), vshift = 31 - __builtin_clz(vs | 1);
             // A sampling factor that is neither the frame's maximum nor 1 (round 6): the decoder places block x of the MCU at
             // (offsetX + x) * 8 (:104, 134) whatever the block's replicated width hs * 8 is, so the blocks of one MCU OVERLAP and the
@@ -330,7 +335,7 @@ __device__ __forceinline__ void interleaved_output_from_tile(const uint8_t *sh_p
             // row from column 8 on, else from row 8 on the first covering block of the row below -- has reached the writer too.
             // (What no block covers keeps the buffer's content: the host clears the outputs of such frames, plan_work.)
             const uint32_t bx = s.blk_x[b], by = s.blk_y[b];
-            const bool overlap_h = comp.h > 1 && hs > 1, overlap_v = comp.v > 1 && vs > 1;
+            const bool overlap_h = !flush && comp.h > 1 && hs > 1, overlap_v = !flush && comp.v > 1 && vs > 1;
             const uint32_t base = b - (by * comp.h + bx);  // the component's first block in the MCU
             if ((overlap_h || overlap_v) && !reached) return;
             for (uint32_t v = 0; v < vs; v++)

@@ -167,6 +167,37 @@ def test_decoder_mirror_replays_writeblock_calls_of_unusual_layouts(layout):
     assert np.array_equal(out.reshape(d2.Height, d2.Width, 3), po.decode_8bit(f)[0])
 
 
+PROG_LAYOUTS = [l for l in LAYOUTS if _blocks_per_mcu(l) <= 16] + [((3, 1), (3, 1), (3, 1)), ((1, 3), (1, 3), (1, 3))]
+
+
+@pytest.mark.parametrize("layout", PROG_LAYOUTS, ids=lambda l: "_".join(f"{h}x{v}" for h, v in l))
+def test_progressive_frames_of_every_layout(layout):
+    """The same layouts as SOF2 frames: JpegHuffmanProgressiveScanDecoder addresses the blocks of an interleaved scan as
+    (colMcu * h + x, rowMcu * v + y) (:112-126) and JpegBlockAllocator.Flush places block (col, row) at (col * hs * 8, row * vs * 8)
+    (JpegBlockAllocator.cs:120-149): no overlap here, whatever the factors.  A restart interval that divides a scan's unit count
+    makes the reference expect a restart marker where the next SOS stands: the same exception from both."""
+    files = [bytes(jpegsynth.encode(w, h, quality=80, restart_interval=dri, seed=w + dri, sampling=layout, progressive=True))
+             for (w, h) in SIZES for dri in (0, 7, 11)]
+    names = {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException", 4: "ArgumentException"}
+    n_ok = 0
+    for fmt in (jl.FMT_INTERLEAVED_U8, jl.FMT_RGBA_U8, jl.FMT_EXTENDED_U16):
+        b = jl.Batch().upload(files, fmt).decode().sync()
+        for i, f in enumerate(files):
+            try:
+                ref, kind = (po.decode_16bit(f, component_count=4)[0] if fmt == jl.FMT_EXTENDED_U16 else po.decode_8bit(f)[0]), "OK"
+            except po.OracleError as e:
+                ref, kind = None, e.kind
+            assert names[b.result(i).status] == kind, (i, b.result(i).detail)
+            if ref is None:
+                continue
+            n_ok += 1
+            if fmt == jl.FMT_RGBA_U8:
+                ref = po.ycbcr8_to_rgb(ref, rgba=True)
+            assert np.array_equal(b.output(i), ref), (fmt, i)
+        b.close()
+    assert n_ok >= 9
+
+
 def test_gpu_encoder_luma_shapes_decode_back():
     """The GPU encoder's (4,1) / (1,2) / (1,4) / (4,2) luma shapes (tests/test_gpu_parity.py: byte-exact against the encoder
     restatement) read back by the GPU decoder = by the decoder restatement."""

@@ -28,6 +28,11 @@ typedef struct jsynth_params {
                              raster), which the reference reads as something else */
     int samp[3][2];       /* per component {H, V}; all zero = take `subsampling`.  A component is the box average over
                              (Hmax / H) x (Vmax / V) pixels (ratios must be whole) */
+    int progressive;      /* SOF2 with a fixed script (round 6: the layouts above through the progressive scan decoder): DC of all
+                             components interleaved with Al = 1, the DC refinement, then per component the AC bands 1..5 and 6..63
+                             (Al = 0; EOB per block, no EOB runs: the standard tables carry no EOBn symbols) in T.81's
+                             non-interleaved order = the order JpegHuffmanProgressiveScanDecoder reads
+                             (DecodeProgressiveDataNonInterleaved, :140-194).  restart_interval counts each scan's own MCUs */
 } jsynth_params;
 
 static const uint8_t k_zigzag_to_natural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
@@ -298,6 +303,30 @@ static void encode_block(bitwriter *w, const float *samples /*64, level-shifted*
     if (run > 0) bw_put(w, ac->code[0], ac->size[0]);
 }
 
+/* FDCT + quantisation alone: zig-zag order */
+static void quantize_block(const float *samples, const float *qdiv, int16_t zz[64]) {
+    float d[64];
+    memcpy(d, samples, sizeof d);
+    fdct_aan(d);
+    for (int k = 0; k < 64; k++) zz[k] = (int16_t)lrintf(d[k_zigzag_to_natural[k]] * qdiv[k_zigzag_to_natural[k]]);
+}
+
+/* restart bookkeeping shared by the progressive scans: called after every MCU of the scan */
+static void prog_restart(bitwriter *bw, int dri, int *before, int *rst_index, int last, int *pred) {
+    if (dri <= 0 || --*before != 0) return;
+    if (!last) {
+        bw_flush_ones(bw);
+        if (bw->p + 2 <= bw->end) {
+            *bw->p++ = 0xFF;
+            *bw->p++ = (uint8_t)(0xD0 + (*rst_index & 7));
+        } else
+            bw->overflow = 1;
+        (*rst_index)++;
+        pred[0] = pred[1] = pred[2] = 0;
+    }
+    *before = dri;
+}
+
 static uint8_t *put_marker_seg(uint8_t *p, int marker, const uint8_t *payload, int n) {
     *p++ = 0xFF;
     *p++ = (uint8_t)marker;
@@ -380,7 +409,7 @@ long jsynth_encode(const jsynth_params *prm, uint8_t *out, size_t cap) {
         seg[13] = (uint8_t)((ch[2] << 4) | cv[2]);
         seg[14] = 1;
     }
-    p = put_marker_seg(p, 0xC0, seg, 6 + 3 * ncomp);
+    p = put_marker_seg(p, prm->progressive ? 0xC2 : 0xC0, seg, 6 + 3 * ncomp);
     /* DHT: all tables in one segment (4 tables -> length 418 = 0x01A2; gray: 2 tables -> 210 = 0xD2) */
     {
         uint8_t *q = seg;
@@ -423,6 +452,125 @@ long jsynth_encode(const jsynth_params *prm, uint8_t *out, size_t cap) {
     float *Cb = Y + rowsz * mcuh, *Cr = Cb + rowsz * mcuh;
     bitwriter bw = {p, out + cap - 4, 0, 0, 0};
     float blk[64];
+    if (prm->progressive) {
+        /* quantised blocks of the whole frame, per component on its MCU-padded grid */
+        int gw[3], gh[3];
+        int16_t *store[3] = {NULL, NULL, NULL};
+        for (int c = 0; c < ncomp; c++) {
+            gw[c] = mcus_x * ch[c];
+            gh[c] = mcus_y * cv[c];
+            store[c] = (int16_t *)malloc((size_t)gw[c] * gh[c] * 64 * sizeof(int16_t));
+        }
+        for (int my = 0; my < mcus_y; my++) {
+            for (int r = 0; r < mcuh; r++) synth_row(&sc, my * mcuh + r, wpad, Y + r * rowsz, Cb + r * rowsz, Cr + r * rowsz);
+            for (int mx = 0; mx < mcus_x; mx++)
+                for (int c = 0; c < ncomp; c++) {
+                    const float *pl = c == 0 ? Y : (c == 1 ? Cb : Cr);
+                    const int fx = hmax / ch[c], fy = vmax / cv[c];
+                    for (int by = 0; by < cv[c]; by++)
+                        for (int bx = 0; bx < ch[c]; bx++) {
+                            const float *src = pl + (size_t)(by * 8 * fy) * rowsz + (size_t)mx * mcuw + bx * 8 * fx;
+                            for (int i = 0; i < 8; i++)
+                                for (int j = 0; j < 8; j++) {
+                                    float acc_ = 0.f;
+                                    for (int vy = 0; vy < fy; vy++)
+                                        for (int vx = 0; vx < fx; vx++) acc_ += src[(size_t)(i * fy + vy) * rowsz + j * fx + vx];
+                                    blk[i * 8 + j] = floorf(acc_ / (float)(fx * fy) + 0.5f) - 128.f;
+                                }
+                            quantize_block(blk, c == 0 ? qdiv_l : qdiv_c, store[c] + ((size_t)(my * cv[c] + by) * gw[c] + mx * ch[c] + bx) * 64);
+                        }
+                }
+        }
+        const int dri = prm->restart_interval;
+        /* scans 0, 1: DC first (Al = 1) and DC refinement, every component interleaved */
+        for (int pass = 0; pass < 2 && !bw.overflow; pass++) {
+            uint8_t *hp = bw.p;
+            seg[0] = (uint8_t)ncomp;
+            for (int c = 0; c < ncomp; c++) {
+                seg[1 + 2 * c] = (uint8_t)(c + 1);
+                seg[2 + 2 * c] = c == 0 ? 0x00 : 0x11;
+            }
+            seg[1 + 2 * ncomp] = 0;
+            seg[2 + 2 * ncomp] = 0;
+            seg[3 + 2 * ncomp] = pass == 0 ? 0x01 : 0x10;
+            bw.p = put_marker_seg(hp, 0xDA, seg, 4 + 2 * ncomp);
+            bw.acc = 0;
+            bw.nbits = 0;
+            int pred[3] = {0, 0, 0}, before = dri, rst_index = 0;
+            for (int my = 0; my < mcus_y; my++)
+                for (int mx = 0; mx < mcus_x; mx++) {
+                    for (int c = 0; c < ncomp; c++)
+                        for (int by = 0; by < cv[c]; by++)
+                            for (int bx = 0; bx < ch[c]; bx++) {
+                                const int dcv = store[c][((size_t)(my * cv[c] + by) * gw[c] + mx * ch[c] + bx) * 64];
+                                if (pass == 0) {
+                                    const int t = dcv >> 1, diff = t - pred[c];  /* point transform: arithmetic shift (T.81 G.1.2.1) */
+                                    pred[c] = t;
+                                    const int sz = bit_size(diff);
+                                    const enc_table *tdc = c == 0 ? &dcl : &dcc;
+                                    bw_put(&bw, tdc->code[sz], tdc->size[sz]);
+                                    if (sz) bw_put(&bw, (uint32_t)(diff < 0 ? diff - 1 : diff), sz);
+                                } else
+                                    bw_put(&bw, (uint32_t)(dcv & 1), 1);
+                            }
+                    prog_restart(&bw, dri, &before, &rst_index, my == mcus_y - 1 && mx == mcus_x - 1, pred);
+                }
+            bw_flush_ones(&bw);
+        }
+        /* AC bands per component, the component's own block raster: ceil(W / (8 hs)) x ceil(H / (8 vs)) blocks */
+        static const int band[2][2] = {{1, 5}, {6, 63}};
+        /* (the luma LAST: the reference's Dispose() transforms the components its decoder slots name when the file ends, and a
+           single-component scan always takes slot 0 -- SURVEY 3.4-11; libjpeg's script ends with the luma too) */
+        for (int cc = 0; cc < ncomp && !bw.overflow; cc++)
+            for (int bnd = 0; bnd < 2 && !bw.overflow; bnd++) {
+                const int c = (cc + 1) % ncomp;
+                const int hsf = hmax / ch[c], vsf = vmax / cv[c];
+                const int nbx = (w + 8 * hsf - 1) / (8 * hsf), nby = (h + 8 * vsf - 1) / (8 * vsf);
+                uint8_t *hp = bw.p;
+                seg[0] = 1;
+                seg[1] = (uint8_t)(c + 1);
+                seg[2] = c == 0 ? 0x00 : 0x11;
+                seg[3] = (uint8_t)band[bnd][0];
+                seg[4] = (uint8_t)band[bnd][1];
+                seg[5] = 0;
+                bw.p = put_marker_seg(hp, 0xDA, seg, 6);
+                bw.acc = 0;
+                bw.nbits = 0;
+                const enc_table *tac = c == 0 ? &acl : &acc;
+                int pred[3] = {0, 0, 0}, before = dri, rst_index = 0;
+                for (int by = 0; by < nby; by++)
+                    for (int bx = 0; bx < nbx; bx++) {
+                        const int16_t *zz = store[c] + ((size_t)by * gw[c] + bx) * 64;
+                        int run = 0;
+                        for (int k = band[bnd][0]; k <= band[bnd][1]; k++) {
+                            const int v = zz[k];
+                            if (v == 0) {
+                                run++;
+                                continue;
+                            }
+                            while (run > 15) {
+                                bw_put(&bw, tac->code[0xF0], tac->size[0xF0]);
+                                run -= 16;
+                            }
+                            const int sz = bit_size(v);
+                            bw_put(&bw, tac->code[(run << 4) | sz], tac->size[(run << 4) | sz]);
+                            bw_put(&bw, (uint32_t)(v < 0 ? v - 1 : v), sz);
+                            run = 0;
+                        }
+                        if (run > 0) bw_put(&bw, tac->code[0], tac->size[0]);
+                        prog_restart(&bw, dri, &before, &rst_index, by == nby - 1 && bx == nbx - 1, pred);
+                    }
+                bw_flush_ones(&bw);
+            }
+        for (int c = 0; c < ncomp; c++) free(store[c]);
+        free(Y);
+        synth_free(&sc);
+        if (bw.overflow) return -2;
+        p = bw.p;
+        *p++ = 0xFF;
+        *p++ = 0xD9;
+        return (long)(p - out);
+    }
     for (int scan = 0; scan < nscans && !bw.overflow; scan++) {
         /* SOS */
         uint8_t *hp = bw.p;

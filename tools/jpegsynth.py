@@ -16,7 +16,7 @@ SUBSAMPLING = {"444": 0, "4:4:4": 0, "422": 1, "4:2:2": 1, "420": 2, "4:2:0": 2,
 class Params(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("subsampling", C.c_int), ("quality", C.c_int),
                 ("restart_interval", C.c_int), ("seed", C.c_uint64), ("noninterleaved", C.c_int),
-                ("samp", (C.c_int * 2) * 3)]
+                ("samp", (C.c_int * 2) * 3), ("progressive", C.c_int)]
 
 
 def build(force=False):
@@ -47,15 +47,18 @@ def _cap(width, height):
     return int(width * height * 3 + (1 << 16))
 
 
-def encode(width, height, subsampling="420", quality=75, restart_interval=0, seed=0, noninterleaved=False, sampling=None) -> bytes:
+def encode(width, height, subsampling="420", quality=75, restart_interval=0, seed=0, noninterleaved=False, sampling=None,
+           progressive=False) -> bytes:
     """noninterleaved=True: three single-component scans instead of one interleaved scan, blocks in the order the reference
     reads them (h x v per frame MCU: T.81's order only for 4:4:4); noninterleaved=2: T.81's own order.
-    sampling=((Hy, Vy), (Hcb, Vcb), (Hcr, Vcr)), factors 1..4 with whole ratios to the maximum, overrides `subsampling`."""
+    sampling=((Hy, Vy), (Hcb, Vcb), (Hcr, Vcr)), factors 1..4 with whole ratios to the maximum, overrides `subsampling`.
+    progressive=True: SOF2, fixed script (DC with Al = 1 + refinement, two AC bands per component, spectral selection only)."""
     L = _get()
     p = Params(width, height, SUBSAMPLING[str(subsampling)] if sampling is None else 0, quality, restart_interval, seed, int(noninterleaved))
     if sampling is not None:
         for c in range(3):
             p.samp[c][0], p.samp[c][1] = sampling[c]
+    p.progressive = int(progressive)
     buf = np.empty(_cap(width, height), dtype=np.uint8)
     n = L.jsynth_encode(C.byref(p), buf.ctypes.data, buf.size)
     if n < 0:

@@ -4,7 +4,9 @@
 Pillow / libjpeg-turbo files of random size, quality, sampling, restart interval, progressive / optimize flags:
 decode (YCbCr8 + RGBA) and, for the single-scan baseline ones, the optimizer (both strip settings).  Prints a summary;
 exit code 1 on any mismatch.  Not part of the test suite (it takes minutes with large n).  STRESS_SCALE=k multiplies the image
-dimensions (1..300 -> k..300k pixels a side).  STRESS_HEADER=1: every corrupted file has its flipped bit(s) in a header."""
+dimensions (1..300 -> k..300k pixels a side).  STRESS_HEADER=1: every corrupted file has its flipped bit(s) in a header.
+STRESS_SAMPLING=1 (round 6): every second file comes from tools/jpegsynth with per-component sampling factors drawn from 1..4
+(whole power-of-two ratios, at most 16 blocks per MCU), interleaved, as three single-component scans or as a progressive frame."""
 import io
 import os
 import sys
@@ -64,6 +66,27 @@ if os.environ.get("STRESS_SYNTH") is not None:
         files[i] = jpegsynth.encode(w, h, sub, int(rng.integers(5, 101)), int(rng.integers(0, 40)) if rng.random() < 0.6 else 0,
                                     seed=int(rng.integers(0, 1 << 30)), noninterleaved=non)
         kinds[i] = (w, h, False, False, {"synth": sub, "noninterleaved": non})
+
+if os.environ.get("STRESS_SAMPLING") is not None:
+    from tools import jpegsynth
+
+    def draw_layout():
+        while True:
+            lay = tuple((int(rng.choice([1, 1, 2, 2, 4, 3])), int(rng.choice([1, 1, 2, 2, 4, 3]))) for _ in range(3))
+            mh, mv = max(l[0] for l in lay), max(l[1] for l in lay)
+            if any(mh % l[0] or mv % l[1] or (mh // l[0]) not in (1, 2, 4) or (mv // l[1]) not in (1, 2, 4) for l in lay):
+                continue
+            if sum(l[0] * l[1] for l in lay) <= 16:
+                return lay
+
+    for i in range(0, n, 2):
+        lay = draw_layout()
+        w, h = int(rng.integers(1, 260)) * scale, int(rng.integers(1, 260)) * scale
+        mode = int(rng.integers(0, 4))  # 0, 1: interleaved baseline; 2: three scans; 3: progressive
+        files[i] = jpegsynth.encode(w, h, quality=int(rng.integers(5, 101)), restart_interval=int(rng.integers(1, 40)) if rng.random() < 0.5 else 0,
+                                    seed=int(rng.integers(0, 1 << 30)), sampling=lay, noninterleaved=(int(rng.integers(1, 3)) if mode == 2 else 0),
+                                    progressive=(mode == 3))
+        kinds[i] = (w, h, False, mode == 3, {"sampling": lay, "mode": mode})
 
 bad = 0
 names = {0: "OK", 1: "InvalidDataException", 2: "InvalidOperationException", 3: "NotSupportedException", 4: "ArgumentException"}
