@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define JPGPU_VERSION 100
+/* 101: jpgpu_image_result gained error_block (28 bytes, 24 before) and the library writes all of it: a binding compiled against
+ * an older header must refuse to run -- compare jpgpu_version() / jpgpu_sizeof_image_result() with its own at load time. */
+#define JPGPU_VERSION 101
 
 /* ---- status codes.  1..4 mirror the reference's exception classes so a shim can rethrow them. ---- */
 typedef enum jpgpu_status {
@@ -87,6 +89,8 @@ typedef struct jpgpu_decoder jpgpu_decoder;
 /* ------------------------------------------------------------------------------------------------ context */
 
 int jpgpu_version(void);
+/* sizeof(jpgpu_image_result) as THIS library writes it (the struct every *_result call fills in whole). */
+size_t jpgpu_sizeof_image_result(void);
 /* Number of visible HIP devices (0 when none; never initialises a context). */
 int jpgpu_device_count(void);
 /* Creates a context on `device`.  Fails with JPGPU_ERR_NO_DEVICE when no GPU is present. */

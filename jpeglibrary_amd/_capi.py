@@ -81,6 +81,7 @@ WRITE_BLOCK_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int16), C.c_int, C.
 _P = C.c_void_p
 SYMBOLS = [
     ("jpgpu_version", C.c_int, []),
+    ("jpgpu_sizeof_image_result", C.c_size_t, []),
     ("jpgpu_device_count", C.c_int, []),
     ("jpgpu_create", C.c_int, [C.c_int, C.POINTER(_P)]),
     ("jpgpu_destroy", None, [_P]),
@@ -235,6 +236,10 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
+    # the library fills jpgpu_image_result in whole: a mirror of another size would be overrun
+    if lib.jpgpu_version() < 101 or lib.jpgpu_sizeof_image_result() != C.sizeof(ImageResult):
+        raise ImportError(f"{LIB_PATH} (version {lib.jpgpu_version()}, jpgpu_image_result of {lib.jpgpu_sizeof_image_result()} bytes) does not "
+                          f"match this binding (101, {C.sizeof(ImageResult)} bytes): rebuild it")
     return lib
 
 

@@ -29,6 +29,7 @@ static thread_local std::string g_create_error;
 extern "C" {
 
 int jpgpu_version(void) { return JPGPU_VERSION; }
+size_t jpgpu_sizeof_image_result(void) { return sizeof(jpgpu_image_result); }
 
 int jpgpu_device_count(void) {
     int n = 0;
@@ -763,6 +764,7 @@ class GpuScanHandler final : public ScanHandler {
     // JpegHuffmanProgressiveScanDecoder.Dispose (:421-470): every scan of the frame on the GPU, in file order, then
     // the dequantise + IDCT pass, then JpegBlockAllocator.Flush (JpegBlockAllocator.cs:120-149) into the writer.
     void dispose_progressive(HostDecoder &dec) {
+        deferred_scan_failed_ = false;
         if (!prog_.active()) return;
         ProgressiveFrame frame = std::move(prog_);
         prog_.reset();
@@ -798,9 +800,14 @@ class GpuScanHandler final : public ScanHandler {
                 flush_planes_to_writer(frame.geo(), img, planes.data(), fn, user);
             }
         }
-        if (res.status != JPGPU_OK) throw_for_result(res);
+        if (res.status != JPGPU_OK) {
+            deferred_scan_failed_ = !unsupported;
+            throw_for_result(res);
+        }
     }
+    bool dispose_failure_is_a_deferred_scan() const override { return deferred_scan_failed_; }
 
+    bool deferred_scan_failed_ = false;
     jpgpu_decoder *d_;
     BaselineGeometry geo_;
     ProgressiveFrame prog_;

@@ -1875,10 +1875,12 @@ int DeviceBatch::run_marker_index() {
         uint32_t *tickets = (uint32_t *)d_k1_tickets_.ptr;
         hipError_t e1 = launch_marker_onepass(ctx_->stream, (const uint8_t *)d_input_.ptr, (const DevScan *)d_scans_.ptr, (const ChunkWork *)d_k1_order_.ptr,
                                               n_k1_groups_, d_k1_desc_.ptr, tickets, k1_epoch_, ++k1_tag_ ? k1_tag_ : ++k1_tag_, budget,
-                                              tickets + 1, h_k1_giveup_, (uint32_t *)d_ends_.ptr, (DevScanStatus *)d_status_.ptr,
+                                              h_k1_giveup_, (uint32_t *)d_ends_.ptr, (DevScanStatus *)d_status_.ptr,
                                               (uint8_t *)d_unstuffed_.ptr, (uint32_t *)d_ends_u_.ptr);
+        // (the device's ticket counter has advanced by one launch's worth only if the launch happened: ADVICE r5)
+        if (e1 != hipSuccess) return hip_fail(e1, "marker_onepass_kernel");
         k1_epoch_++;
-        return e1 == hipSuccess ? mark_work() : hip_fail(e1, "marker_onepass_kernel");
+        return mark_work();
     }
     hipError_t e = launch_marker_index(ctx_->stream, (const uint8_t *)d_input_.ptr, (const DevScan *)d_scans_.ptr, (int)h_scans_.size(),
                                        (const ChunkWork *)d_chunk_work_.ptr, n_chunk_work_, (ChunkSum *)d_chunk_sums_.ptr,
@@ -1899,7 +1901,7 @@ int DeviceBatch::run_huffman() {
         const int max_rounds = (int)max_subs_per_scan_ + 2;
         const int first_budget = getenv("JPGPU_SUBSEQ_BUDGET") ? std::max(2, atoi(getenv("JPGPU_SUBSEQ_BUDGET"))) : kSubseqFirstBudget;  // (tests: force the fallback)
         const int device_rounds = k2s_host_checked_ ? 0 : std::min(max_rounds, k2s_budget_ > 0 ? k2s_budget_ : first_budget);
-        k2s_issued_ = device_rounds;
+        k2s_issued_ = std::min(device_rounds, kSubseqMaxDeviceRounds);  // (what launch_subseq_decode really enqueues: ADVICE r5)
         k2s_unchecked_ = device_rounds > 0;
         k2s_idct_behind_ = false;
         e = launch_subseq_decode(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_sub_work_.ptr,

@@ -429,7 +429,14 @@ int EncodeBatch::encode() {
             im.raw_off = slot;
             slot = align_up64(slot + (uint64_t)im.total_blocks * 256 + 64, 256);
         }
-        e = d_raw_.reserve((size_t)slot + 256);
+        // The worst case is ~50 x the streams themselves (51 GB per 1024 x 4K 4:2:0 where the two kernels size ~1 GB from the counts)
+        // and d_raw_ never shrinks: the slots may take a third of what the device has free, no more -- the finished streams, the
+        // chunk counts and the next upload's buffers are reserved behind them, and a batch that used to encode must not fail there
+        // because this one grabbed the rest.  Beyond that the two kernels run.
+        size_t free_b = 0, total_b = 0;
+        e = (size_t)slot + 256 <= d_raw_.cap ? hipSuccess : hipMemGetInfo(&free_b, &total_b);
+        if (e == hipSuccess && (size_t)slot + 256 > d_raw_.cap && (size_t)slot + 256 > free_b / 3) e = hipErrorOutOfMemory;
+        if (e == hipSuccess) e = d_raw_.reserve((size_t)slot + 256);
         if (e == hipSuccess) e = d_chain_.reserve(chain_bytes + 256);
         if (e != hipSuccess) {  // no room for the worst-case slots: the two kernels size the raw streams from the counts
             (void)hipGetLastError();

@@ -125,6 +125,10 @@ class ScanHandler {
     virtual void on_scan(HostDecoder &dec, MarkerReader &reader, const ScanHeader &scan) = 0;
     // ref: _scanDecoder.Dispose() in Decode's finally (JpegDecoder.cs:545-549)
     virtual void on_dispose(HostDecoder &dec) = 0;
+    // A handler that DEFERS its scans to on_dispose (the decoder mirror collects a progressive frame's scans during the walk and
+    // decodes them in one device pass): true when what on_dispose threw is the failure of such a scan.  The reference decoded that
+    // scan at its SOS, in front of whatever ended the walk behind it, so that failure is the one the caller sees (round 6).
+    virtual bool dispose_failure_is_a_deferred_scan() const { return false; }
 };
 
 // ref: JpegDecoder.cs -- the public decoder's state (input, frame header, DRI, table registry).

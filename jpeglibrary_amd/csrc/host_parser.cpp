@@ -582,8 +582,14 @@ void HostDecoder::decode(ScanHandler &handler, bool have_output_writer) {
     } catch (...) {
         try {
             handler.on_dispose(*this);  // finally { _scanDecoder?.Dispose(); }
+        } catch (const DecodeError &) {
+            // the failure that ended the decode is the one the caller sees -- unless the handler decodes its scans HERE and one of
+            // them failed: the reference ran that scan at its SOS, in front of the marker the walk failed at (JpegDecoder.cs:592-599)
+            if (handler.dispose_failure_is_a_deferred_scan()) {
+                scan_decoder_created_ = false;
+                throw;
+            }
         } catch (...) {
-            // the failure that ended the decode is the one the caller sees
         }
         scan_decoder_created_ = false;
         throw;

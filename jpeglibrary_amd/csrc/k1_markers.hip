@@ -495,7 +495,7 @@ constexpr uint32_t kK1Group = kMarkerGroupChunks;
 __global__ __launch_bounds__(kScanThreads) void marker_onepass_kernel(const uint8_t *__restrict__ data, const DevScan *__restrict__ scans,
                                                                        const ChunkWork *__restrict__ order, uint32_t n_groups,
                                                                        unsigned long long *__restrict__ desc, uint32_t *__restrict__ tickets, uint32_t epoch,
-                                                                       uint32_t tag, uint32_t spin_budget, uint32_t *__restrict__ giveup,
+                                                                       uint32_t tag, uint32_t spin_budget,
                                                                        uint32_t *__restrict__ host_giveup, uint32_t *__restrict__ ends,
                                                                        DevScanStatus *__restrict__ status, uint8_t *__restrict__ udata,
                                                                        uint32_t *__restrict__ ends_u) {
@@ -667,11 +667,11 @@ hipError_t launch_first_marker(hipStream_t stream, const uint8_t *data, const vo
 }
 
 hipError_t launch_marker_onepass(hipStream_t stream, const uint8_t *data, const DevScan *scans, const ChunkWork *order, int n_groups,
-                                 void *desc, uint32_t *tickets, uint32_t epoch, uint32_t tag, uint32_t spin_budget, uint32_t *giveup,
+                                 void *desc, uint32_t *tickets, uint32_t epoch, uint32_t tag, uint32_t spin_budget,
                                  uint32_t *host_giveup, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u) {
     if (n_groups <= 0) return hipSuccess;
     hipLaunchKernelGGL(marker_onepass_kernel, dim3(n_groups), dim3(kScanThreads), 0, stream, data, scans, order, (uint32_t)n_groups, (unsigned long long *)desc,
-                       tickets, epoch, tag, spin_budget, giveup, host_giveup, ends, status, udata, ends_u);
+                       tickets, epoch, tag, spin_budget, host_giveup, ends, status, udata, ends_u);
     return hipGetLastError();
 }
 

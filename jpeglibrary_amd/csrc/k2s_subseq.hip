@@ -1111,7 +1111,7 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
     };
     int round = 0;
     if (device_rounds > 0) {
-        const int n_rounds = device_rounds < 62 ? device_rounds : 61;
+        const int n_rounds = device_rounds < kSubseqMaxDeviceRounds ? device_rounds : kSubseqMaxDeviceRounds;
         for (; round < n_rounds; round++) {
             launch_round(round, changed_dev + round, round >= 2 ? changed_dev + (round - 1) : nullptr);
             const int n = round + 1;  // rounds issued so far

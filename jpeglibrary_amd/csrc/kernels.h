@@ -28,14 +28,14 @@ hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const De
 // tickets[0] = the ticket counter (cleared once per upload), epoch = decodes of this upload issued before this one, tag = a non-zero
 // number no earlier launch over `desc` has used; spin_budget = polls a workgroup may spend waiting for a predecessor before it counts
 // the chunks in front of its group itself -- *host_giveup (page-locked host memory) != 0 afterwards says that happened (the results
-// are complete either way); `giveup` is not used any more.
+// are complete either way).
 constexpr size_t kMarkerDescBytes = 64;
 #ifndef JPGPU_K1_GROUP
 #define JPGPU_K1_GROUP 4
 #endif
 constexpr uint32_t kMarkerGroupChunks = JPGPU_K1_GROUP;  // chunks a workgroup of the one-pass index takes; `order`: (scan, first chunk) per group, by (group, scan)
 hipError_t launch_marker_onepass(hipStream_t stream, const uint8_t *data, const DevScan *scans, const ChunkWork *order, int n_groups,
-                                 void *desc, uint32_t *tickets, uint32_t epoch, uint32_t tag, uint32_t spin_budget, uint32_t *giveup,
+                                 void *desc, uint32_t *tickets, uint32_t epoch, uint32_t tag, uint32_t spin_budget,
                                  uint32_t *host_giveup, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u);
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                           const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
@@ -82,6 +82,7 @@ constexpr uint64_t kSubFinalFewSubs = 1u << 20;
 // caller checks changed_dev when it next waits for the stream (k2s_subseq.hip); 0: the host checks between rounds.
 constexpr uint32_t kSubseqGatherSpan = 1024;
 constexpr int kSubseqCtlWords = 128, kSubseqCtlSameDone = 96, kSubseqFirstBudget = 16;
+constexpr int kSubseqMaxDeviceRounds = 61;  // rounds launch_subseq_decode enqueues at most without the host looking (control words [0, 62))
 // waves (of 64 subsequences) per workgroup of the K2S final pass.  4 = two workgroups per CU; one workgroup of 10 waves (K2's
 // shape, 25 % more waves per CU) was measured slower: 21.1 vs 19.6 ms K2S per 1024 x 4K -- a workgroup waits for its slowest wave
 #ifndef JPGPU_SF_WAVES

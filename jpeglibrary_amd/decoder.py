@@ -165,23 +165,37 @@ class JpegHuffmanDecodingTable:
             raise ArgumentException("BITS must hold 16 counts.")
 
 
-def _tables_c(quantizationTables, huffmanTables):  # noqa: N803
-    """(qt[4][64], qt_present[4], dht[2][4]) for the per-scan entry points, from the decoder-registry-style lists."""
+def _tables_c(quantizationTables, huffmanTables, scan_c=None, tq_slots=None):  # noqa: N803
+    """(qt[4][64], qt_present[4], dht[2][4]) for the per-scan entry points, from the decoder-registry-style lists.
+
+    The reference finds a table by its EXACT class and identifier (GetHuffmanTable / GetQuantizationTable, JpegDecoder.cs:869-884,
+    910-925), identifiers being whatever byte the DHT / DQT / SOS / SOF carried (0..15 for well-formed files): a file that defines
+    and selects table 5 decodes.  The C arrays have four slots per class -- as many as a scan of four components can select --, so
+    with `scan_c` (a _capi.Scan, rewritten in place) every identifier the scan SELECTS is given a slot of its own and the scan's
+    selectors are pointed at the slots (round 6; ADVICE r5: identifiers above 3 used to be dropped, and before that folded onto
+    [identifier & 3] over live tables).  tq_slots: {quantisation table identifier: slot} fixed by the frame header
+    (_frame_tq_slots).  A registry entry under a class other than 0 / 1 is never the one a scan uses and is not handed over."""
     qt = np.zeros((4, 64), np.uint16)
     present = np.zeros(4, np.uint8)
-    # (the reference finds a table by its EXACT class and identifier -- GetHuffmanTable / GetQuantizationTable, JpegDecoder.cs:869-884,
-    # 910-925 --, so a registry entry a corrupted DHT left under class 9 or identifier 7 is never the one a scan uses: such entries
-    # are not handed over; folding them into [class & 1][identifier & 3] replaced live tables: tools/stress_parity.py, session mode)
+    if tq_slots is None:
+        tq_slots = {i: i for i in range(4)}
     for q in quantizationTables or []:
-        if q is None or q.IsEmpty or not 0 <= q.Identifier <= 3:
+        if q is None or q.IsEmpty or q.Identifier not in tq_slots:
             continue
-        qt[q.Identifier] = np.asarray(q.Elements, np.uint16)
-        present[q.Identifier] = 1
+        qt[tq_slots[q.Identifier]] = np.asarray(q.Elements, np.uint16)
+        present[tq_slots[q.Identifier]] = 1
+    slots = ({i: i for i in range(4)}, {i: i for i in range(4)})
+    if scan_c is not None:
+        slots = ({}, {})
+        for i in range(min(int(scan_c.num_components), 4)):
+            c = scan_c.comp[i]
+            c.td = slots[0].setdefault(int(c.td), len(slots[0]))
+            c.ta = slots[1].setdefault(int(c.ta), len(slots[1]))
     dht = ((_capi.Dht * 4) * 2)()
     for t in huffmanTables or []:
-        if t.TableClass not in (0, 1) or not 0 <= t.Identifier <= 3:
+        if t.TableClass not in (0, 1) or t.Identifier not in slots[t.TableClass]:
             continue
-        d = dht[t.TableClass][t.Identifier]
+        d = dht[t.TableClass][slots[t.TableClass][t.Identifier]]
         d.present = 1
         for i in range(16):
             d.bits[i] = t.bits[i]
@@ -189,6 +203,16 @@ def _tables_c(quantizationTables, huffmanTables):  # noqa: N803
         for i, v in enumerate(t.values[:256]):
             d.values[i] = v
     return qt, present, dht
+
+
+def _frame_tq_slots(frame_c):
+    """{quantisation table identifier: slot 0..3} for the identifiers a frame's (at most four) components select; the frame's
+    selectors are rewritten to the slots."""
+    slots = {}
+    for i in range(min(int(frame_c.num_components), 4)):
+        c = frame_c.comp[i]
+        c.tq = slots.setdefault(int(c.tq), len(slots))
+    return slots
 
 
 class JpegGpuProgressiveScanDecoder:
@@ -201,13 +225,14 @@ class JpegGpuProgressiveScanDecoder:
         self._ctx = ctx or default_context()
         self._h = C.c_void_p()
         f = frameHeader._c(0xC2)
+        self._tq_slots = _frame_tq_slots(f)
         raise_for_status(_lib.jpgpu_progressive_begin(self._ctx._h, C.byref(f), C.byref(self._h)), _lib.jpgpu_last_error(self._ctx._h))
 
     def ProcessScan(self, entropy, scanHeader, quantizationTables, huffmanTables, restartInterval=0):  # noqa: N802,N803
         """Decodes one scan into the store; raises the reference's exception for this scan.  Returns the reader advance (0)."""
         a = np.frombuffer(entropy, dtype=np.uint8) if not isinstance(entropy, np.ndarray) else np.ascontiguousarray(entropy, dtype=np.uint8)
-        qt, present, dht = _tables_c(quantizationTables, huffmanTables)
         sc = scanHeader._c()
+        qt, present, dht = _tables_c(quantizationTables, huffmanTables, sc, self._tq_slots)
         res = _capi.ImageResult()
         consumed = C.c_size_t()
         rc = _lib.jpgpu_progressive_scan(self._h, C.byref(sc), qt.ctypes.data, present.ctypes.data, C.cast(dht, C.c_void_p), int(restartInterval),

@@ -32,7 +32,10 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_strings():
     from jpeglibrary_amd import _capi
 
-    assert _capi.lib.jpgpu_version() == 100
+    assert _capi.lib.jpgpu_version() == 101
+    # the struct every *_result call fills in whole: the binding's mirror must have the library's size
+    import ctypes
+    assert _capi.lib.jpgpu_sizeof_image_result() == ctypes.sizeof(_capi.ImageResult) == 28
     assert _capi.lib.jpgpu_status_string(1) == b"InvalidDataException"
     assert _capi.lib.jpgpu_detail_string(4) == b"Expect restart marker."
 

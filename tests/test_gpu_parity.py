@@ -1403,6 +1403,45 @@ def test_progressive_scan_failures_come_before_later_walk_failures():
     assert kinds["broken_first_scan_no_tables_for_second"] != kinds["no_tables_for_second"], kinds
 
 
+def test_decoder_mirror_reports_a_bad_progressive_scan_before_a_walk_failure_behind_it():
+    """The same order through JpegDecoder.Decode() (level 3, jpgpu_decoder_decode): the mirror collects a progressive frame's scans
+    during the walk and decodes them in one device pass at Dispose; a failure of the walk BEHIND a bad scan used to be reported in
+    the scan's place (DESIGN.md 5 until round 6).  The reference ran the scan at its SOS (JpegDecoder.cs:592-599): the scan's
+    exception -- class and message -- is the one that leaves Decode(), and the writer holds the partial flush of the store."""
+    good = read_jpeg("yellowcat_progressive_restart.jpg")
+    sos = [i for i in range(len(good) - 1) if good[i] == 0xFF and good[i + 1] == 0xDA]
+    rst = good.index(b"\xff\xd0", sos[0])
+    broken_scan = good[:rst] + b"\x12\x34" + good[rst + 2:]
+    cases = {
+        "broken_first_scan_no_tables_for_second": broken_scan[:sos[0]] + broken_scan[sos[0]:sos[1]].replace(b"\xff\xc4", b"\xff\xe9") + broken_scan[sos[1]:],
+        "no_tables_for_second": good[:sos[0]] + good[sos[0]:sos[1]].replace(b"\xff\xc4", b"\xff\xe9") + good[sos[1]:],
+        # a Huffman table segment too short for its counts in front of the third scan: Identify() steps over it, Decode() parses it
+        "broken_first_scan_bad_dht_before_third": broken_scan[:sos[2]] + b"\xff\xc4\x00\x05\x00\xff\xff" + broken_scan[sos[2]:],
+        "bad_dht_before_third": good[:sos[2]] + b"\xff\xc4\x00\x05\x00\xff\xff" + good[sos[2]:],
+        "broken_first_scan": broken_scan,
+    }
+    seen = {}
+    for k, data in cases.items():
+        ref, info, err = po.decode_8bit_partial(data)
+        d = jl.JpegDecoder()
+        d.SetInput(data)
+        d.Identify()
+        out = np.zeros(d.Width * d.Height * d.NumberOfComponents, np.uint8)
+        d.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(d.Width, d.Height, d.NumberOfComponents, out))
+        try:
+            d.Decode()
+            mine = None
+        except jl.JpegError as e:
+            mine = e
+        assert (mine is None) == (err is None), (k, mine, err)
+        if err is not None:
+            assert type(mine).__name__ == err.kind, (k, mine, err)
+            assert err.message in str(mine) or str(mine) in err.message, (k, str(mine), err.message)
+            seen[k] = (err.kind, err.message)
+        assert np.array_equal(out.reshape(ref.shape), ref), k
+    assert seen["broken_first_scan_bad_dht_before_third"] == seen["broken_first_scan"] != seen["bad_dht_before_third"], seen
+
+
 def test_progressive_band_overrun_is_ordered_like_the_file():
     """A corrupted first-pass AC scan (band 1-5) stores a coefficient behind its band, where the 6-63 scan of the same
     component also stores: file order decides.  The two scans used to share a dependency level, and which store won

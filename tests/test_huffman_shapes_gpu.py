@@ -176,3 +176,31 @@ def test_gray_444_and_a_batch_of_shapes():
     for f, o, r in zip(files, outs, res):
         assert r.status == 0
         assert np.array_equal(o, po.decode_8bit(f)[0])
+
+
+def test_dc_categories_above_16_are_a_fence_with_a_stated_behaviour():
+    """A DHT that assigns a DC code a category of 17..255 (a corrupted table; T.81 allows 0..11 / 0..15).  The reference has no
+    check: ReceiveAndExtend asks TryReadBits for that many bits (ScanDecoder/JpegHuffmanScanDecoder.cs:100-115,
+    JpegBitReader.cs:190-204) -- 17..32 succeed with C#'s masked shifts ((1 << n) with n mod 32), 33..39 depend on how many
+    whole bytes the 64-bit buffer happens to hold at that symbol, more can never be loaded ("The bit stream ended prematurely").
+    The HIP path does NOT follow it there: every table kind fails the scan at the FIRST symbol of such a category
+    with the reference's "Invalid Huffman code" verdict (InvalidDataException, detail 1).  Same exception class as the reference
+    whenever the reference fails too; where the reference decodes on (category 17 here), the classes differ -- pinned so that a
+    change of either side shows."""
+    from tools import jpegsynth
+    base = bytearray(jpegsynth.encode(64, 64, "444", 75, 0, seed=3))
+    vals = base.index(b"\xff\xc4") + 4 + 1 + 16  # the luma DC table's values: categories 0..11
+    verdicts = {}
+    for cat in (17, 20, 32, 33, 64, 255):
+        f = bytearray(base)
+        f[vals + 2] = cat  # the code of category 2 now means `cat`
+        try:
+            po.decode_8bit(bytes(f))
+            ref = "OK"
+        except po.OracleError as e:
+            ref = e.kind
+        _, results = jl.decode_batch([bytes(f)], jl.FMT_INTERLEAVED_U8)
+        assert (results[0].status, results[0].detail) == (1, 1), cat
+        verdicts[cat] = ref
+    assert verdicts == {17: "OK", 20: "InvalidDataException", 32: "InvalidDataException", 33: "InvalidDataException", 64: "InvalidDataException",
+                        255: "InvalidDataException"}, verdicts

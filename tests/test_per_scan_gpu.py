@@ -384,3 +384,67 @@ def test_a_registry_entry_under_an_unknown_table_class_is_never_the_table_a_scan
     out = st["dec"].Dispose(fmt=jl.FMT_INTERLEAVED_U8).reshape(fh.NumberOfLines, fh.SamplesPerLine, fh.NumberOfComponents)
     st["dec"].close()
     assert np.array_equal(out, px)
+
+
+def _retag_tables(data, q_id, h_id):
+    """The chroma tables of a tools/jpegsynth file moved from identifier 1 to `q_id` (DQT + SOF Tq) and `h_id` (DHT + SOS
+    Td / Ta): identifiers are 4-bit fields, the reference matches them exactly and has no upper bound of 3
+    (JpegDecoder.cs:869-884, 910-925; JpegHuffmanDecodingTable.cs:249-291, JpegQuantizationTable.cs:192-232)."""
+    b = bytearray(data)
+    p = 2
+    while p + 4 <= len(b):
+        assert b[p] == 0xFF
+        m, ln = b[p + 1], (b[p + 2] << 8) | b[p + 3]
+        body = p + 4
+        if m == 0xDB and b[body] == 0x01:
+            b[body] = q_id
+        elif m in (0xC0, 0xC2):
+            for i in range(b[body + 5]):
+                if b[body + 8 + 3 * i] == 1:
+                    b[body + 8 + 3 * i] = q_id
+        elif m == 0xC4:
+            q = body
+            while q < p + 2 + ln:
+                n = sum(b[q + 1:q + 17])
+                if b[q] & 15 == 1:
+                    b[q] = (b[q] & 0xF0) | h_id
+                q += 17 + n
+        elif m == 0xDA:
+            for i in range(b[body]):
+                if b[body + 2 + 2 * i] == 0x11:
+                    b[body + 2 + 2 * i] = (h_id << 4) | h_id
+            p += 2 + ln
+            while p + 1 < len(b) and not (b[p] == 0xFF and b[p + 1] not in (0x00, 0xFF) and not 0xD0 <= b[p + 1] <= 0xD7):
+                p += 1
+            continue
+        elif m == 0xD9:
+            break
+        p += 2 + ln
+    return bytes(b)
+
+
+def test_table_identifiers_above_3_through_every_entry_level():
+    """the per-scan mirror handed over identifiers 0..3 only.  A file that defines and selects Huffman tables 5 / 12 and
+    quantisation table 7 / 15: whole-file batch (level 1), JpegDecoder.Decode() (level 3), the progressive per-scan session
+    (level 2b: the selected identifiers are given slots of their own) -- all equal to the checker."""
+    for q_id, h_id in ((7, 5), (15, 12)):
+        base = _retag_tables(jpegsynth.encode(120, 88, "420", 80, 5, seed=21), q_id, h_id)
+        prog = _retag_tables(jpegsynth.encode(120, 88, "420", 80, 7, seed=22, progressive=True), q_id, h_id)
+        for data in (base, prog):
+            ref = po.decode_8bit(data)[0]
+            assert ref[..., 1].std() > 1  # the chroma really was decoded with its tables
+            outs, results = jl.decode_batch([data], jl.FMT_INTERLEAVED_U8)
+            assert results[0].status == 0 and np.array_equal(outs[0], ref)
+            d = jl.JpegDecoder()
+            d.SetInput(data)
+            d.Identify()
+            out = np.zeros(d.Width * d.Height * 3, np.uint8)
+            d.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(d.Width, d.Height, 3, out))
+            d.Decode()
+            assert np.array_equal(out.reshape(ref.shape), ref)
+
+        def deliver(dec, fh):
+            return dec.Dispose(fmt=jl.FMT_INTERLEAVED_U8).reshape(fh.NumberOfLines, fh.SamplesPerLine, 3)
+
+        out, _ = _decode_progressive_scan_by_scan(prog, deliver)
+        assert np.array_equal(out, po.decode_8bit(prog)[0])
