@@ -1249,7 +1249,20 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     n_huff_slots_ = 1;
     // (known before any work list is cut: the Huffman workgroup's size -- intervals per work entry -- follows from it)
     for (const ScanJob &job : jobs_) n_huff_slots_ = std::max(n_huff_slots_, job.n_huff);
-    const uint32_t huff_intervals_per_wg = 64u * (uint32_t)huffman_waves(n_huff_slots_);
+    // LDS the K2 family stages its tables in: the largest set among the sequential scans (an AC table 9 040 bytes, a DC table
+    // 2 896: kernels.h); the waves per workgroup are what it leaves room for
+    k2_tab_bytes_ = kK2AcTabBytes + kK2DcTabBytes;
+    for (const ScanJob &job : jobs_) {
+        if (job.kind != kScanSequential) continue;
+        uint32_t bytes = 0;
+        for (int k = 0; k < job.n_huff; k++) {
+            bool is_dc = false;
+            for (int c = 0; c < job.scan_components; c++) is_dc |= job.dc_slot[c] == k;
+            bytes += is_dc ? kK2DcTabBytes : kK2AcTabBytes;
+        }
+        k2_tab_bytes_ = std::max(k2_tab_bytes_, bytes);
+    }
+    const uint32_t huff_intervals_per_wg = 64u * (uint32_t)huffman_waves(k2_tab_bytes_);
     // the device image of a table depends on BITS / HUFFVAL alone: look those up before building it (a batch of
     // camera files carries the same four tables a thousand times)
     struct HuffKey {
@@ -1570,7 +1583,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     std::vector<HuffWork> sub_final_work;
     sub_pools_.clear();
     {
-        const bool no_pool = getenv("JPGPU_SF_NO_POOL") != nullptr || n_huff_slots_ > 4;  // (A/B switch; ten waves + more than four tables do not fit a CU)
+        const bool no_pool = getenv("JPGPU_SF_NO_POOL") != nullptr || !subseq_pool_fits(k2_tab_bytes_);  // (A/B switch; ten waves + the tables must fit a CU)
         auto same_tables = [&](const DevScan &a, const DevScan &b) {
             return memcmp(a.huff_pool, b.huff_pool, sizeof a.huff_pool) == 0 && a.scan_components == b.scan_components &&
                    a.blocks_per_mcu == b.blocks_per_mcu && memcmp(a.blk_comp, b.blk_comp, sizeof a.blk_comp) == 0 &&
@@ -1592,7 +1605,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             if (pool) sub_pools_.push_back({(int)pooled.size(), (int)waves});
             for (size_t q = i; q < k; q++) {
                 const uint32_t j = sub_scan_ids_[q];
-                const uint32_t step = pool ? lanes_subs : lanes_subs * (uint32_t)subseq_final_waves(n_huff_slots_);
+                const uint32_t step = pool ? lanes_subs : lanes_subs * (uint32_t)subseq_final_waves();
                 for (uint32_t first = 0; first < h_scans_[j].n_subs; first += step) (pool ? pooled : sub_final_work).push_back({j, first});
             }
             i = k;
@@ -1893,7 +1906,7 @@ int DeviceBatch::run_huffman() {
     dispose_done_ = false;  // (the stores hold coefficients again)
     hipError_t e = launch_huffman(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_huff_work_.ptr,
                                   n_huff_work_, (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr,
-                                  (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (const uint8_t *)d_lut_pool_.ptr);
+                                  (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (const uint8_t *)d_lut_pool_.ptr, k2_tab_bytes_);
     if (e != hipSuccess) return hip_fail(e, "huffman_decode_kernel");
     if (n_sub_work_ > 0) {
         // DRI = 0 scans: the final pass writes every block of the scan as whole lines (nothing to clear).  The rounds are
@@ -1912,7 +1925,7 @@ int DeviceBatch::run_huffman() {
                                  &last_subseq_rounds_, (const uint8_t *)d_lut_pool_.ptr, (const HuffWork *)d_sub_final_work_.ptr, n_sub_final_work_,
                                  (uint32_t *)d_sub_same_.ptr, &sub_same_valid_, device_rounds, (const HuffWork *)d_sub_work_.ptr + n_sub_work_, n_sub_gather_,
                                  (const HuffWork *)d_sub_final_work_.ptr + n_sub_final_work_, sub_pools_.data(), (int)sub_pools_.size(), ctx_->num_cus,
-                                 (uint32_t *)d_sub_perm_.ptr, sub_final_spl_);
+                                 (uint32_t *)d_sub_perm_.ptr, sub_final_spl_, k2_tab_bytes_);
         if (e != hipSuccess) return hip_fail(e, "subsequence decode");
     }
     const int rc = run_progressive();
@@ -2208,7 +2221,7 @@ int DeviceBatch::decode() {
         auto k2 = [&](hipStream_t st, int first, int n) {
             return launch_huffman(st, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr, (const HuffWork *)d_huff_work_.ptr + first, n,
                                   (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr, (const DevHuffTable *)d_huff_pool_.ptr,
-                                  (int16_t *)d_coefs_.ptr, n_huff_slots_, (const uint8_t *)d_lut_pool_.ptr);
+                                  (int16_t *)d_coefs_.ptr, n_huff_slots_, (const uint8_t *)d_lut_pool_.ptr, k2_tab_bytes_);
         };
         auto k3 = [&](hipStream_t st, int half) {
             return launch_idct(st, (const int16_t *)d_coefs_.ptr, (const DevScan *)d_scans_.ptr, (const IdctWork *)d_idct_work_split_.ptr,

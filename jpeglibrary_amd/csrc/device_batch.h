@@ -217,6 +217,7 @@ class DeviceBatch {
     std::vector<DevHuffTable> huff_pool_;
     std::vector<DevQuantTable> quant_pool_;
     int n_huff_slots_ = 1;
+    uint32_t k2_tab_bytes_ = 0;  // LDS of the largest table set a sequential scan of the upload stages (K2, the K2S final pass)
     int n_huff_work_ = 0, n_idct_work_ = 0;
     int idct_class_begin_[kNumIdctLayoutClasses + 1] = {};
     std::vector<int> idct_later_begin_;  // d_idct_work_ behind the classes: [k], [k + 1]) = the k-th ordered launch (run_idct)

@@ -24,11 +24,17 @@ namespace jpgpu {
 __global__ __launch_bounds__(256) void lut_pool_kernel(const DevHuffTable *__restrict__ pool, uint8_t *__restrict__ lut_pool) {
     const DevHuffTable &h = pool[blockIdx.x >> 1];
     const bool is_dc = (blockIdx.x & 1) != 0;
-    uint8_t *img = lut_pool + (size_t)blockIdx.x * kK2TabBytes;
+    uint8_t *tab = lut_pool + (size_t)(blockIdx.x >> 1) * kLutPoolBytesPerTable;
+    uint8_t *img = tab + (is_dc ? kK2TabBytes : 0u);  // the u16 image (the K2S round kernel's source)
     uint16_t *l1 = reinterpret_cast<uint16_t *>(img);
     uint16_t *l2 = reinterpret_cast<uint16_t *>(img + kK2L1Bytes);
-    __shared__ uint32_t first_miss;
-    if (threadIdx.x == 0) first_miss = 1u << kK2LutBits;
+    // the u32 image (K2, the K2S final pass): first level with values and pairs | the same second level, header and arrays
+    const uint32_t lb = is_dc ? kK2DcBits : kK2AcBits;
+    uint8_t *img32 = tab + (is_dc ? kPoolNewDc : kPoolNewAc);
+    uint32_t *f1 = reinterpret_cast<uint32_t *>(img32);
+    uint16_t *f2 = reinterpret_cast<uint16_t *>(img32 + (4u << lb));
+    __shared__ uint32_t first_miss, first_miss32;
+    if (threadIdx.x == 0) first_miss = 1u << kK2LutBits, first_miss32 = 1u << lb;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < (1u << kK2LutBits); i += 256) {
         // a code of at most 11 bits is decided by the prefix alone (maxcode[l] has its low 16 - l bits set): evaluate with ones behind it
@@ -36,14 +42,30 @@ __global__ __launch_bounds__(256) void lut_pool_kernel(const DevHuffTable *__res
         l1[i] = (uint16_t)e;
         if (e == 0) atomicMin(&first_miss, i);  // (a bad category is an answer, not a miss)
     }
+    for (uint32_t i = threadIdx.x; i < (1u << lb); i += 256) {
+        const uint32_t e = k2_fast_entry(h, i, is_dc, lb);
+        f1[i] = e;
+        if (e == 0) atomicMin(&first_miss32, i);
+    }
     __syncthreads();
-    const uint32_t lo = first_miss << (16 - kK2LutBits);
-    const uint32_t t16 = lo > 65536u - kK2L2Entries ? lo : 65536u - kK2L2Entries;
-    for (uint32_t j = threadIdx.x; j < kK2L2Entries; j += 256) l2[j] = t16 + j < 65536u ? (uint16_t)k2_entry_of(h, t16 + j, is_dc, 16) : (uint16_t)0;
-    if (threadIdx.x < 4) reinterpret_cast<uint32_t *>(img + kK2L1Bytes + 2u * kK2L2Entries)[threadIdx.x] = threadIdx.x == 0 ? t16 : 0u;
-    if (threadIdx.x < kK2SmallBytes / 16)
-        reinterpret_cast<uint4 *>(img + kK2L1Bytes + 2u * kK2L2Entries + 16u)[threadIdx.x] =
-            reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&h) + offsetof(DevHuffTable, maxcode))[threadIdx.x];
+    {
+        const uint32_t lo = first_miss << (16 - kK2LutBits);
+        const uint32_t t16 = lo > 65536u - kK2L2Entries ? lo : 65536u - kK2L2Entries;
+        for (uint32_t j = threadIdx.x; j < kK2L2Entries; j += 256) l2[j] = t16 + j < 65536u ? (uint16_t)k2_entry_of(h, t16 + j, is_dc, 16) : (uint16_t)0;
+        if (threadIdx.x < 4) reinterpret_cast<uint32_t *>(img + kK2L1Bytes + 2u * kK2L2Entries)[threadIdx.x] = threadIdx.x == 0 ? t16 : 0u;
+        if (threadIdx.x < kK2SmallBytes / 16)
+            reinterpret_cast<uint4 *>(img + kK2L1Bytes + 2u * kK2L2Entries + 16u)[threadIdx.x] =
+                reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&h) + offsetof(DevHuffTable, maxcode))[threadIdx.x];
+    }
+    {
+        const uint32_t lo = first_miss32 << (16 - lb);
+        const uint32_t t16 = lo > 65536u - kK2L2Entries ? lo : 65536u - kK2L2Entries;
+        for (uint32_t j = threadIdx.x; j < kK2L2Entries; j += 256) f2[j] = t16 + j < 65536u ? (uint16_t)k2_entry_of(h, t16 + j, is_dc, 16) : (uint16_t)0;
+        if (threadIdx.x < 4) reinterpret_cast<uint32_t *>(img32 + (4u << lb) + 2u * kK2L2Entries)[threadIdx.x] = threadIdx.x == 0 ? t16 : 0u;
+        if (threadIdx.x < kK2SmallBytes / 16)
+            reinterpret_cast<uint4 *>(img32 + (4u << lb) + 2u * kK2L2Entries + 16u)[threadIdx.x] =
+                reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&h) + offsetof(DevHuffTable, maxcode))[threadIdx.x];
+    }
 }
 
 #ifdef JPGPU_K2_PROFILE
@@ -52,7 +74,7 @@ __device__ unsigned long long k2_prof[8];
 #define K2_PROF_ADD(i, v) do { if (lane == 0) atomicAdd(&k2_prof[i], (unsigned long long)(v)); } while (0)
 extern "C" int jpgpu_debug_k2_profile(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(k2_prof), sizeof(k2_prof)) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(k2_prof), z, sizeof z) != hipSuccess) return 1; }
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(k2_prof), z, sizeof z) != hipSuccess) return 1; }
     return 0;
 }
 #else
@@ -68,10 +90,10 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
                                                                     DevScanStatus *__restrict__ status,
                                                                     const DevHuffTable *__restrict__ huff_pool,
                                                                     int16_t *__restrict__ coefs, int n_slots,
-                                                                    const uint8_t *__restrict__ lut_pool) {
+                                                                    const uint8_t *__restrict__ lut_pool, uint32_t tab_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *tabs = smem;                                      // n_slots * kK2TabBytes
-    uint8_t *wave_all = smem + (size_t)n_slots * kK2TabBytes;  // WAVES * kK2WaveBytes
+    uint8_t *tabs = smem;                  // tab_bytes: the batch's largest set of staged tables
+    uint8_t *wave_all = smem + tab_bytes;  // WAVES * kK2WaveBytes
     uint32_t *blk_info = reinterpret_cast<uint32_t *>(wave_all + WAVES * kK2WaveBytes);  // [kMaxBlocksPerMcu]
 
     const HuffWork wk = work[blockIdx.x];
@@ -156,15 +178,15 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
         for (uint32_t b = 0; b < bpm; b++) {
             const uint32_t bi = __builtin_amdgcn_readfirstlane(blk_info[b]);  // wave-uniform
             const uint32_t ci = bi & 0xFFu;
-            const K2Tab hdc = k2_tab(tabs, (bi >> 8) & 0xFFu);
-            const K2Tab hac = k2_tab(tabs, bi >> 16);
+            const K2Tab hdc = k2_tab_dc(tabs, bi);
+            const K2Tab hac = k2_tab_ac(tabs, bi);
             const unsigned long long k2_a = K2_TICK();
             int32_t lim = k2_limit(endpos, feed.wr);
             if (active && err == 0 && mcu < my_mcus) {
                 // ReadBlockBaseline (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:179-222)
-                int32_t v;
-                uint32_t adv = 0;
-                err = k2_symbol<true>(ring, feed, pos, endpos, lim, hdc, closed_by_marker, v, adv);
+                int32_t v, vb;
+                uint32_t adv = 0, adv_b = 0;
+                err = k2_symbol<true>(ring, feed, pos, endpos, lim, hdc, closed_by_marker, 0u, v, vb, adv, adv_b);
                 const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
                 v += pred;
                 if (ci == 0) pred0 = v;
@@ -174,12 +196,16 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
                 *reinterpret_cast<int16_t *>(my_stage + swz16) = (int16_t)v;  // zig-zag index 0
                 uint32_t i2 = err == 0 ? 2u : 128u;  // 2 x zig-zag index of the next coefficient
                 while (i2 < 128u) {
-                    const uint32_t e2 = k2_symbol<false>(ring, feed, pos, endpos, lim, hac, closed_by_marker, v, adv);
+                    // one step = one symbol or, where the lookup held two, both (round 6): Math.Min(i++, 63) for a coefficient; EOB /
+                    // ZRL store a zero at a position nothing was written to yet; a step of one symbol stores it twice
+                    const uint32_t e2 = k2_symbol<false>(ring, feed, pos, endpos, lim, hac, closed_by_marker, i2, v, vb, adv, adv_b);
                     err |= e2;
-                    i2 += adv;
-                    // Math.Min(i++, 63) for a coefficient; EOB / ZRL store a zero at a position nothing was written to yet
-                    const uint32_t at = i2 - 2u < 126u ? i2 - 2u : 126u;
+                    const uint32_t ia = i2 + adv;
+                    const uint32_t at = ia - 2u < 126u ? ia - 2u : 126u;
                     *reinterpret_cast<int16_t *>(my_stage + (at ^ swz16)) = (int16_t)v;
+                    i2 = ia + adv_b;
+                    const uint32_t at_b = i2 - 2u < 126u ? i2 - 2u : 126u;
+                    *reinterpret_cast<int16_t *>(my_stage + (at_b ^ swz16)) = (int16_t)vb;
                 }
                 // the block the reference throws in: blocks in front of it have reached the writer, this one and the rest have not
                 if (err != 0)
@@ -237,37 +263,40 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
 }
 
 
-// K2 lookup width: 11 bits when the scan stages at most 4 tables, 10 bits for up to 8 (LDS budget: 160 KB per CU)
-static size_t k2_lds_bytes(int n_slots, int waves) {
-    return (size_t)n_slots * kK2TabBytes + (size_t)waves * kK2WaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
-}
-size_t huffman_lds_bytes(int n_slots) { return k2_lds_bytes(n_slots, huffman_waves(n_slots)); }
-
+static size_t k2_lds_bytes(uint32_t tab_bytes, int waves) { return (size_t)tab_bytes + (size_t)waves * kK2WaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t); }
 
 template <int WAVES>
 static hipError_t launch_huffman_w(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                                    const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
-                                   int n_slots, const uint8_t *lut_pool) {
-    const size_t lds = k2_lds_bytes(n_slots, WAVES);
+                                   int n_slots, const uint8_t *lut_pool, uint32_t tab_bytes) {
+    const size_t lds = k2_lds_bytes(tab_bytes, WAVES);
     static std::atomic<uint64_t> configured{0};
     const hipError_t ea = allow_dynamic_lds(reinterpret_cast<const void *>(&huffman_decode_kernel<WAVES>), 160 * 1024, configured);
     if (ea != hipSuccess) return ea;
     hipLaunchKernelGGL((huffman_decode_kernel<WAVES>), dim3(n_work), dim3(64 * WAVES), lds, stream, data, scans, work, ends, status, huff_pool, coefs,
-                       n_slots, lut_pool);
+                       n_slots, lut_pool, tab_bytes);
     return hipGetLastError();
 }
 
-// `work` holds one entry per huffman_waves(n_slots) * 64 restart intervals (DeviceBatch builds it with the same function)
+// `work` holds one entry per huffman_waves(tab_bytes) * 64 restart intervals (DeviceBatch builds it with the same function);
+// tab_bytes = the largest k2_scan_tab_bytes() among the batch's scans
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                           const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
-                          int n_slots, const uint8_t *lut_pool) {
+                          int n_slots, const uint8_t *lut_pool, uint32_t tab_bytes) {
     if (n_work <= 0) return hipSuccess;
-    if (huffman_waves(n_slots) == kHuffWaves)
-        return launch_huffman_w<kHuffWaves>(stream, data, scans, work, n_work, ends, status, huff_pool, coefs, n_slots, lut_pool);
-    return launch_huffman_w<kHuffWavesManyTables>(stream, data, scans, work, n_work, ends, status, huff_pool, coefs, n_slots, lut_pool);
+#define JPGPU_K2_CASE(W) case W: return launch_huffman_w<W>(stream, data, scans, work, n_work, ends, status, huff_pool, coefs, n_slots, lut_pool, tab_bytes)
+    switch (huffman_waves(tab_bytes)) {
+        JPGPU_K2_CASE(11);
+        JPGPU_K2_CASE(10);
+        JPGPU_K2_CASE(9);
+        JPGPU_K2_CASE(8);
+    default:
+        JPGPU_K2_CASE(7);  // (eight AC tables)
+    }
+#undef JPGPU_K2_CASE
 }
 
-// Fused lookups of every table of the pool (once per upload: the tables of a batch do not change between decodes).
+// Lookups of every table of the pool (once per upload: the tables of a batch do not change between decodes).
 hipError_t launch_lut_pool(hipStream_t stream, const DevHuffTable *huff_pool, int n_tables, uint8_t *lut_pool) {
     if (n_tables <= 0) return hipSuccess;
     hipLaunchKernelGGL(lut_pool_kernel, dim3(2 * n_tables), dim3(256), 0, stream, huff_pool, lut_pool);

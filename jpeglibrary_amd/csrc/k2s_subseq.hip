@@ -439,8 +439,9 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
         if (pi == 0xFFFF) continue;
         bool is_dc = false;
         for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
-        const uint16_t *src = reinterpret_cast<const uint16_t *>(lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * kK2TabBytes);
-        if (tid == 0) pool_off[sl] = (uint32_t)(((size_t)pi * 2 + (is_dc ? 1 : 0)) * kK2TabBytes);
+        // (the pool's u16 images: AC at the table's base, DC behind it; the u32 images of K2 / the final pass follow)
+        const uint16_t *src = reinterpret_cast<const uint16_t *>(lut_pool + (size_t)pi * kLutPoolBytesPerTable + (is_dc ? kK2TabBytes : 0u));
+        if (tid == 0) pool_off[sl] = (uint32_t)((size_t)pi * kLutPoolBytesPerTable + (is_dc ? kK2TabBytes : 0u));
         uint32_t *dst = reinterpret_cast<uint32_t *>(smem) + ((size_t)sl << LB);
         for (uint32_t i = tid; i < (1u << LB); i += 256) dst[i] = sr_entry<LB>(src, i, is_dc);
         const uint4 *ssrc = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&huff_pool[pi]) + offsetof(DevHuffTable, maxcode));
@@ -851,7 +852,8 @@ __global__ __launch_bounds__(1024) void subseq_order_kernel(const DevScan *__res
 }
 
 constexpr int kSubFinalMaxWaves = JPGPU_SF_WAVES > kSubFinalPoolWaves ? JPGPU_SF_WAVES : kSubFinalPoolWaves;  // the launch picks subseq_final_waves(n_slots) / the pool's
-constexpr int kSfWaveBytes = kK2WaveBytes + 64 * 2 * (int)sizeof(uint32_t);  // K2's staging + rings, then (first MCU, count) per lane
+constexpr int kSfWaveBytes = kK2WaveBytes + 64 * 2 * (int)sizeof(uint32_t);
+static_assert(kSfWaveBytes == (int)kSfWaveLdsBytes && kSubFinalPoolWaves == 10, "kernels.h: subseq_pool_fits");  // K2's staging + rings, then (first MCU, count) per lane
 // One wave's 64 lanes: subsequences wk.first_interval + lane * kSubFinalSubsPerLane .. of scan wk.scan (tables staged, the wave's
 // coefficient staging zero on entry and on exit).
 __device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const DevScan &s, const DevScanStatus &st, const HuffWork wk,
@@ -915,8 +917,8 @@ __device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const
                 const bool is_dc = i2 == 0;
                 int32_t v;
                 uint32_t adv;
-                err = k2_symbol_any(ring, feed, pos, endpos, lim, k2_tab(tabs, is_dc ? ((info >> 8) & 0xFFu) : (info >> 16)), is_dc, closed_by_marker,
-                                    v, adv);
+                err = k2_symbol_any(ring, feed, pos, endpos, lim, k2_tab_at(tabs, is_dc ? ((info >> 8) & 0xFFFu) : (info >> 20), is_dc), is_dc,
+                                    closed_by_marker, v, adv);
                 if (is_dc) {
                     const uint32_t ci = info & 0xFFu;
                     if (ci == 0) pred0 += v;
@@ -947,14 +949,14 @@ __device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const
         for (uint32_t b = 0; b < bpm; b++) {
             const uint32_t bi = __builtin_amdgcn_readfirstlane(blk_info[b]);  // wave-uniform
             const uint32_t ci = bi & 0xFFu;
-            const K2Tab hdc = k2_tab(tabs, (bi >> 8) & 0xFFu);
-            const K2Tab hac = k2_tab(tabs, bi >> 16);
+            const K2Tab hdc = k2_tab_dc(tabs, bi);
+            const K2Tab hac = k2_tab_ac(tabs, bi);
             lim = k2_limit(endpos, feed.wr);
             if (j < count && err == 0) {
                 // ReadBlockBaseline (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:179-222)
-                int32_t v;
-                uint32_t adv = 0;
-                err = k2_symbol<true>(ring, feed, pos, endpos, lim, hdc, closed_by_marker, v, adv);
+                int32_t v, vb;
+                uint32_t adv = 0, adv_b = 0;
+                err = k2_symbol<true>(ring, feed, pos, endpos, lim, hdc, closed_by_marker, 0u, v, vb, adv, adv_b);
                 const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
                 v += pred;
                 if (ci == 0) pred0 = v;
@@ -964,12 +966,15 @@ __device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const
                 *reinterpret_cast<int16_t *>(my_stage + swz16) = (int16_t)v;  // zig-zag index 0
                 uint32_t k2i = err == 0 ? 2u : 128u;
                 while (k2i < 128u) {
-                    const uint32_t e2 = k2_symbol<false>(ring, feed, pos, endpos, lim, hac, closed_by_marker, v, adv);
+                    // one step = one symbol or the two of a pair entry (see K2): a step of one symbol stores it twice
+                    const uint32_t e2 = k2_symbol<false>(ring, feed, pos, endpos, lim, hac, closed_by_marker, k2i, v, vb, adv, adv_b);
                     err |= e2;
-                    k2i += adv;
-                    // Math.Min(i++, 63) for a coefficient; EOB / ZRL store a zero at a position nothing was written to yet
-                    const uint32_t at = k2i - 2u < 126u ? k2i - 2u : 126u;
+                    const uint32_t ia = k2i + adv;
+                    const uint32_t at = ia - 2u < 126u ? ia - 2u : 126u;
                     *reinterpret_cast<int16_t *>(my_stage + (at ^ swz16)) = (int16_t)v;
+                    k2i = ia + adv_b;
+                    const uint32_t at_b = k2i - 2u < 126u ? k2i - 2u : 126u;
+                    *reinterpret_cast<int16_t *>(my_stage + (at_b ^ swz16)) = (int16_t)vb;
                 }
                 // the block the reference throws in (see K2): in front of it every block has reached the writer
                 if (err != 0)
@@ -1022,11 +1027,11 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
                                                                            const uint32_t *__restrict__ first_block,
                                                                            const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs,
                                                                            int n_slots, uint32_t n_chunks, uint32_t *__restrict__ counter,
-                                                                           const uint32_t *__restrict__ perm, uint32_t spl) {
+                                                                           const uint32_t *__restrict__ perm, uint32_t spl, uint32_t tab_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t n_waves = blockDim.x >> 6;
-    uint8_t *tabs = smem;                                                    // n_slots * kK2TabBytes
-    uint8_t *wave_all = smem + (size_t)n_slots * kK2TabBytes;                // n_waves * kSfWaveBytes
+    uint8_t *tabs = smem;                                                    // tab_bytes: the batch's largest set of staged tables
+    uint8_t *wave_all = smem + tab_bytes;                                    // n_waves * kSfWaveBytes
     uint32_t *blk_info = reinterpret_cast<uint32_t *>(wave_all + n_waves * kSfWaveBytes);  // [kMaxBlocksPerMcu]
     const HuffWork wk0 = work[POOL ? 0u : blockIdx.x];  // POOL: `work` lists the run's waves (scan, first subsequence), all with one set of tables
     if (!POOL && status[wk0.scan].n_ends == 0) return;
@@ -1181,7 +1186,8 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
                                 int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work,
                                 uint32_t *same_dist, bool *same_valid, int device_rounds, const HuffWork *gather_work, int n_gather,
-                                const HuffWork *pool_work, const SubseqPool *pools, int n_pools, int num_cus, uint32_t *lane_perm, int subs_per_lane) {
+                                const HuffWork *pool_work, const SubseqPool *pools, int n_pools, int num_cus, uint32_t *lane_perm, int subs_per_lane,
+                                uint32_t tab_bytes) {
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const uint32_t spl = subs_per_lane >= 2 ? 2u : 1u;
     const uint32_t *final_state = nullptr;
@@ -1198,13 +1204,13 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
         perm = lane_perm;
     }
     if (n_final_work > 0) {
-        const int waves = subseq_final_waves(n_slots);
-        const size_t lds_final = (size_t)n_slots * kK2TabBytes + (size_t)waves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
+        const int waves = subseq_final_waves();
+        const size_t lds_final = (size_t)tab_bytes + (size_t)waves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
         const hipError_t ea = allow_dynamic_lds(reinterpret_cast<const void *>(&subseq_final_kernel<false>), 160 * 1024, configured);
         if (ea != hipSuccess) return ea;
         // final_work: (scan, first subsequence) per workgroup of waves * 64 lanes (the rounds' work list is per 256)
         hipLaunchKernelGGL(subseq_final_kernel<false>, dim3(n_final_work), dim3(64 * waves), lds_final, stream, udata, scans, final_work, ends_u, status,
-                           huff_pool, lut_pool, final_state, first_block, (const int4 *)dc_entry, coefs, n_slots, 0u, (uint32_t *)nullptr, perm, spl);
+                           huff_pool, lut_pool, final_state, first_block, (const int4 *)dc_entry, coefs, n_slots, 0u, (uint32_t *)nullptr, perm, spl, tab_bytes);
     }
     if (n_pools > 0) {
         // (the counters live in the control words every launch_subseq_sync clears; a host-checked launch clears the first 64 only)
@@ -1212,14 +1218,14 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
             e = hipMemsetAsync(changed_dev + kSubseqCtlPoolCounter, 0, kSubFinalMaxPools * sizeof(uint32_t), stream);
             if (e != hipSuccess) return e;
         }
-        const size_t lds_pool = (size_t)n_slots * kK2TabBytes + (size_t)kSubFinalPoolWaves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
+        const size_t lds_pool = (size_t)tab_bytes + (size_t)kSubFinalPoolWaves * kSfWaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t);
         const hipError_t ea = allow_dynamic_lds(reinterpret_cast<const void *>(&subseq_final_kernel<true>), 160 * 1024, configured_pool);
         if (ea != hipSuccess) return ea;
         for (int p = 0; p < n_pools; p++) {
             const int groups = std::min(num_cus > 0 ? num_cus : 256, (pools[p].count + kSubFinalPoolWaves - 1) / kSubFinalPoolWaves);
             hipLaunchKernelGGL(subseq_final_kernel<true>, dim3(groups), dim3(64 * kSubFinalPoolWaves), lds_pool, stream, udata, scans,
                                pool_work + pools[p].first, ends_u, status, huff_pool, lut_pool, final_state, first_block, (const int4 *)dc_entry, coefs,
-                               n_slots, (uint32_t)pools[p].count, changed_dev + kSubseqCtlPoolCounter + p, perm, spl);
+                               n_slots, (uint32_t)pools[p].count, changed_dev + kSubseqCtlPoolCounter + p, perm, spl, tab_bytes);
         }
     }
     return hipGetLastError();

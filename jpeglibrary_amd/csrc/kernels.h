@@ -8,14 +8,30 @@
 
 namespace jpgpu {
 
-constexpr int kHuffWaves = 11;                // wavefronts per Huffman workgroup (scans that stage up to 5 tables)
-constexpr int kHuffWavesManyTables = 9;       // ... with 6-8 tables staged (4.8 KB of LDS each)
-constexpr int huffman_waves(int n_slots) { return n_slots <= 5 ? kHuffWaves : kHuffWavesManyTables; }
+constexpr int kHuffWaves = 11;                // wavefronts per Huffman workgroup at most (what the standard four tables leave room for)
+// LDS of the K2 family (k2_huffman.hip, the K2S final pass): the scan's staged tables -- u32 first levels that carry values and
+// pairs, round 6: an AC table 2^11 entries, a DC table 2^9, + second level, header and the reference's arrays each -- then
+// kK2WaveLdsBytes per wave (64 staged blocks + 64 stream rings) and the block info.
+constexpr uint32_t kK2AcTabBytes = 8192 + 512 + 16 + 320, kK2DcTabBytes = 2048 + 512 + 16 + 320, kK2WaveLdsBytes = 8192 + 64 * 68;
+constexpr uint32_t kK2LdsBudget = 160 * 1024 - 64;
+inline uint32_t k2_scan_tab_bytes(const DevScan &s) {  // a DC table = one that some component decodes its DC symbols with
+    uint32_t bytes = 0;
+    for (int sl = 0; sl < kMaxHuffSlots; sl++) {
+        if (s.huff_pool[sl] == 0xFFFF) continue;
+        bool is_dc = false;
+        for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
+        bytes += is_dc ? kK2DcTabBytes : kK2AcTabBytes;
+    }
+    return bytes;
+}
+// waves per K2 workgroup for a batch whose largest table set takes tab_bytes (eight AC tables still leave seven)
+constexpr int huffman_waves(uint32_t tab_bytes) {
+    return (int)((kK2LdsBudget - tab_bytes) / kK2WaveLdsBytes) < kHuffWaves ? (int)((kK2LdsBudget - tab_bytes) / kK2WaveLdsBytes) : kHuffWaves;
+}
 // restart intervals per Huffman workgroup (one per lane): 64 * huffman_waves(table slots of the batch)
 constexpr int kIdctBlocksPerWg = 256;         // 8x8 blocks per IDCT tile (one per lane)
 constexpr int kIdctTilesPerWg = 16;           // consecutive tiles walked by one IDCT workgroup (prefetch pipeline)
 
-size_t huffman_lds_bytes(int n_slots);
 
 constexpr uint32_t kMarkerChunkBytes = 4096;  // K1 chunk size (256 lanes x 16 bytes)
 // consecutive chunks of one scan handled by one K1 workgroup (one work-list entry).  4 was measured in round 2: K1 1.53 ms
@@ -39,7 +55,7 @@ hipError_t launch_marker_onepass(hipStream_t stream, const uint8_t *data, const 
                                  uint32_t *host_giveup, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u);
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                           const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
-                          int n_slots, const uint8_t *lut_pool);
+                          int n_slots, const uint8_t *lut_pool, uint32_t tab_bytes);
 // lut_pool: kLutPoolBytesPerTable per pool table, filled by launch_lut_pool (K2 and the K2S round kernel copy from it)
 hipError_t launch_lut_pool(hipStream_t stream, const DevHuffTable *huff_pool, int n_tables, uint8_t *lut_pool);
 constexpr int kNumIdctLayoutClasses = 6;
@@ -72,7 +88,8 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int16_t *coefs, int n_slots,
                                 int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work,
                                 uint32_t *same_dist, bool *same_valid, int device_rounds, const HuffWork *gather_work, int n_gather,
-                                const HuffWork *pool_work, const SubseqPool *pools, int n_pools, int num_cus, uint32_t *lane_perm, int subs_per_lane);
+                                const HuffWork *pool_work, const SubseqPool *pools, int n_pools, int num_cus, uint32_t *lane_perm, int subs_per_lane,
+                                uint32_t tab_bytes);
 // subs_per_lane: subsequences a lane of the final pass takes (the work lists are built for it): kSubFinalSubsPerLane for batches that
 // fill the machine, 1 below kSubFinalFewSubs subsequences in the batch (a lone 67-Mpixel canvas: twice the waves, half as long each)
 constexpr uint64_t kSubFinalFewSubs = 1u << 20;
@@ -88,13 +105,18 @@ constexpr int kSubseqMaxDeviceRounds = 61;  // rounds launch_subseq_decode enque
 #ifndef JPGPU_SF_WAVES
 #define JPGPU_SF_WAVES 4
 #endif
-constexpr int subseq_final_waves(int n_slots) { return n_slots <= 5 ? JPGPU_SF_WAVES : 4; }
+constexpr int subseq_final_waves() { return JPGPU_SF_WAVES; }
+// the pooled form (ten waves per workgroup) fits while the staged tables leave room for them
+constexpr uint32_t kSfWaveLdsBytes = kK2WaveLdsBytes + 64 * 2 * 4;
+constexpr bool subseq_pool_fits(uint32_t tab_bytes) { return tab_bytes + 10u * kSfWaveLdsBytes <= kK2LdsBudget; }
 // subsequences per lane of the K2S final pass (1: 8.1 ms per 1024 x 4K; 2: see DESIGN.md)
 #ifndef JPGPU_SF_SUBS
 #define JPGPU_SF_SUBS 2
 #endif
 constexpr int kSubFinalSubsPerLane = JPGPU_SF_SUBS;
-constexpr size_t kLutPoolBytesPerTable = 2 * (4096 + 512 + 16 + 320);  // DC + AC images of one pool table: 2^11 + 256 u16 entries, header, the reference's arrays (lut_pool_kernel)
+// per pool table (lut_pool_kernel): the u16 images as an AC and as a DC table (2^11 + 256 u16 entries, header, the reference's arrays:
+// what the K2S round kernel derives its lookups from), then the u32 images of round 6 (2^11 / 2^9 entries that carry values and pairs: K2, K2S final pass)
+constexpr size_t kLutPoolBytesPerTable = 2 * (4096 + 512 + 16 + 320) + (8192 + 512 + 16 + 320) + (2048 + 512 + 16 + 320);
 
 // progressive frames (K2P): the scans of one ordinal (position inside their frame) of every progressive frame in the batch
 hipError_t launch_progressive(hipStream_t stream, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,

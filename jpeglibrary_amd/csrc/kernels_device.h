@@ -268,24 +268,54 @@ constexpr int kK2LutBits = 11;
 constexpr uint32_t kK2L1Bytes = 2u << kK2LutBits;
 constexpr uint32_t kK2L2Entries = 256;
 constexpr uint32_t kK2BadCat = 0x8000u;
-constexpr uint32_t kK2TabBytes = kK2L1Bytes + 2u * kK2L2Entries + 16u + kK2SmallBytes;  // == kLutPoolBytesPerTable / 2 (kernels.h)
+constexpr uint32_t kK2TailBytes = 2u * kK2L2Entries + 16u + kK2SmallBytes;  // L2 | header | the reference's arrays
+constexpr uint32_t kK2TabBytes = kK2L1Bytes + kK2TailBytes;  // the u16 image above (round 4-5 K2; still what the K2S ROUND kernel derives its lookups from)
+
+// Round 6: the first level K2 and the K2S final pass keep in LDS carries the VALUES, and two symbols where two fit.
+//   AC: 2^11 x u32, the next 11 bits;  DC: 2^9 x u32, the next 9 bits (the standard luminance DC codes end at 9 bits).
+//   fast entry    n | nA << 4 | advA << 8 | advB << 14 | valA << 20 | valB << 26
+//                 n = bits of everything the entry decodes (1..11), nA = bits of its FIRST symbol (code + magnitude), advA / advB =
+//                 zig-zag advance of the first / second symbol in coefficients (r + 1; 16 for ZRL; 63 for EOB; advB = 0: the entry
+//                 holds ONE symbol and valB = valA), valA / valB = the Extend()ed coefficients, six signed bits (categories 0..5:
+//                 with the standard tables no longer symbol fits the index anyway).  A second symbol is only ever an AC symbol of the
+//                 same table behind a first symbol that is not EOB; the lane checks that the first did not end the block.
+//   medium entry  n = 0:  advA << 8 | category << 14 | (code + magnitude bits) << 19 -- the code fits the index, the magnitude does
+//                 not (or is wider than six bits): one exec-masked stretch takes the value from the stream.
+//   0x80000000    DC: a category above 16 (the exact path reports it);   0 = not decided by the index (a longer code: L2 / the walk).
+// Image in the pool and in LDS: L1 | L2 (256 x u16, the old format: long codes) | header | the reference's arrays.
+// Measured on the CPU before it was built (tools/microbench/k2_pairs/price_pairs_r06.txt): the wave's steps per block -- the
+// longest of its 64 lanes' -- fall from 12.7 to 8.0 (Q75) and from 24.7 to 15.5 (Q90).
+constexpr int kK2AcBits = 11, kK2DcBits = 9;
+static_assert(kK2AcTabBytes == (4u << kK2AcBits) + kK2TailBytes && kK2DcTabBytes == (4u << kK2DcBits) + kK2TailBytes, "kernels.h holds the sizes for the host");
+static_assert(kK2WaveLdsBytes == (uint32_t)kK2WaveBytes, "kernels.h holds the size for the host");
+// pool, per table: the u16 images as an AC and as a DC table (round kernel), then the u32 images
+constexpr uint32_t kPoolNewAc = 2u * kK2TabBytes, kPoolNewDc = kPoolNewAc + kK2AcTabBytes;
+static_assert(kPoolNewDc + kK2DcTabBytes == kLutPoolBytesPerTable, "kernels.h sizes the pool");
+constexpr uint32_t kK2MediumMask = 0xFFu;  // n | nA of an entry: zero = not a fast entry
 
 struct K2Tab {
-    const uint16_t *lut;
+    const uint32_t *lut;
     const uint16_t *l2;
     const uint32_t *hdr;  // {t16, 0, 0, 0}
     const uint8_t *small;  // maxcode[18] | valoffset[20] | values[256]
+    uint32_t shift;        // 32 - index bits
 };
 
-__device__ __forceinline__ K2Tab k2_tab(const uint8_t *tabs, uint32_t slot) {
-    const uint8_t *t = tabs + slot * kK2TabBytes;
+// off16: the table's LDS offset in 16-byte units (blk_info carries it: the images of a scan differ in size)
+__device__ __forceinline__ K2Tab k2_tab_at(const uint8_t *tabs, uint32_t off16, bool is_dc) {
+    const uint8_t *t = tabs + off16 * 16u;
+    const uint32_t l1 = is_dc ? (4u << kK2DcBits) : (4u << kK2AcBits);
     K2Tab h;
-    h.lut = reinterpret_cast<const uint16_t *>(t);
-    h.l2 = reinterpret_cast<const uint16_t *>(t + kK2L1Bytes);
-    h.hdr = reinterpret_cast<const uint32_t *>(t + kK2L1Bytes + 2u * kK2L2Entries);
-    h.small = t + kK2L1Bytes + 2u * kK2L2Entries + 16u;
+    h.lut = reinterpret_cast<const uint32_t *>(t);
+    h.l2 = reinterpret_cast<const uint16_t *>(t + l1);
+    h.hdr = reinterpret_cast<const uint32_t *>(t + l1 + 2u * kK2L2Entries);
+    h.small = t + l1 + 2u * kK2L2Entries + 16u;
+    h.shift = is_dc ? 32u - kK2DcBits : 32u - kK2AcBits;
     return h;
 }
+// blk_info word: scan component | DC table offset << 8 | AC table offset << 20 (offsets in 16-byte units, 12 bits each)
+__device__ __forceinline__ K2Tab k2_tab_dc(const uint8_t *tabs, uint32_t bi) { return k2_tab_at(tabs, (bi >> 8) & 0xFFFu, true); }
+__device__ __forceinline__ K2Tab k2_tab_ac(const uint8_t *tabs, uint32_t bi) { return k2_tab_at(tabs, bi >> 20, false); }
 
 // zig-zag advance (in int16 BYTES, i.e. 2 x coefficients) of an AC symbol: r + 1 coefficients for a non-zero category,
 // 16 for ANY r != 0 with category 0 (ref: ...BaselineScanDecoder.cs:212-220), and "past the end" for EOB.
@@ -338,7 +368,8 @@ __device__ __forceinline__ int32_t k2_limit(int32_t endpos, uint32_t wr) {
 }
 
 // Exact symbol decode: DecodeHuffmanCode + ReceiveAndExtend with the reference's "bits available" rules (same decisions
-// as ub_symbol).  Returns 0 or the failure detail; n = bits consumed, value, adv = zig-zag advance (AC, in coefficients).
+// as ub_symbol).  ONE symbol, whatever the first-level entry holds.  Returns 0 or the failure detail; n = bits consumed, value,
+// adv = zig-zag advance (AC, in coefficients).
 __device__ __forceinline__ uint32_t k2_slow_symbol(uint8_t *ring, K2Feed &f, int32_t pm1, int32_t endpos, const K2Tab &h, bool is_dc,
                                                 bool closed_by_marker, uint32_t &n, int32_t &value, uint32_t &adv) {
     const int32_t pos = pm1 + 1;
@@ -347,29 +378,44 @@ __device__ __forceinline__ uint32_t k2_slow_symbol(uint8_t *ring, K2Feed &f, int
     int32_t rem = endpos - pos;
     if (rem < 0) rem = 0;
     const uint32_t code16 = rem > 0 ? (hi >> 16) : 0xFFFFu;
-    uint32_t e = h.lut[code16 >> (16 - kK2LutBits)];
-    if (is_dc && (e & kK2BadCat) != 0) return kDetailInvalidHuffmanCode;  // categories above 16 are outside the verified envelope
-    const uint32_t t16 = h.hdr[0];
-    if (e == 0 && code16 >= t16) {  // a long code: the second level (t16 >= 65536 - 256)
-        e = h.l2[code16 - t16];
-        if (is_dc && (e & kK2BadCat) != 0) return kDetailInvalidHuffmanCode;
-    }
+    const uint32_t e = h.lut[code16 >> (h.shift - 16u)];
     uint32_t size, s;
-    if (e == 0) {
-        // longer than the first level decides and not in the second: the reference's walk (an entry of the first level is empty
-        // exactly when the code has more than 11 bits, so the walk may start there)
-        const uint16_t *maxcode = reinterpret_cast<const uint16_t *>(h.small);
-        size = kK2LutBits + 1;
-        while (code16 > maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
-        if (size > 16) return kDetailInvalidHuffmanCode;
-        const uint32_t sym = h.small[56 + ((h.small[36 + size] + (code16 >> (16 - size))) & 0xFF)];
-        s = is_dc ? sym : (sym & 15u);
-        adv = (sym & 15u) ? (sym >> 4) + 1u : ((sym >> 4) ? 16u : 63u);
-        if (s > 16u) return kDetailInvalidHuffmanCode;
+    adv = 0;
+    if ((e & 15u) != 0) {
+        // a fast entry: its FIRST symbol.  The category of an Extend()ed value is the length of its magnitude.
+        const int32_t va = (int32_t)__builtin_amdgcn_sbfe(e, 20, 6);
+        s = va == 0 ? 0u : 32u - (uint32_t)__builtin_clz((uint32_t)(va < 0 ? -va : va));
+        size = ((e >> 4) & 15u) - s;
+        adv = (e >> 8) & 63u;
+    } else if (e != 0 && (e >> 31) == 0) {  // the code fits the index, the magnitude does not
+        s = (e >> 14) & 31u;
+        size = ((e >> 19) & 63u) - s;
+        adv = (e >> 8) & 63u;
+    } else if (e != 0) {
+        return kDetailInvalidHuffmanCode;  // DC categories above 16 are outside the verified envelope
     } else {
-        s = is_dc ? ((e >> 6) & 31u) : (e >> 12);
-        size = (e & 63u) - s;
-        adv = (e >> 6) & 63u;
+        uint32_t e2 = 0;
+        const uint32_t t16 = h.hdr[0];
+        if (code16 >= t16) {  // a long code: the second level (t16 >= 65536 - 256)
+            e2 = h.l2[code16 - t16];
+            if (is_dc && (e2 & kK2BadCat) != 0) return kDetailInvalidHuffmanCode;
+        }
+        if (e2 == 0) {
+            // longer than the first level decides and not in the second: the reference's walk (an entry of the first level is empty
+            // exactly when the code has more bits than the index, so the walk may start there)
+            const uint16_t *maxcode = reinterpret_cast<const uint16_t *>(h.small);
+            size = 33u - h.shift;
+            while (code16 > maxcode[size]) size++;  // maxcode[17] = 0xFFFF terminates
+            if (size > 16) return kDetailInvalidHuffmanCode;
+            const uint32_t sym = h.small[56 + ((h.small[36 + size] + (code16 >> (16 - size))) & 0xFF)];
+            s = is_dc ? sym : (sym & 15u);
+            adv = (sym & 15u) ? (sym >> 4) + 1u : ((sym >> 4) ? 16u : 63u);
+            if (s > 16u) return kDetailInvalidHuffmanCode;
+        } else {
+            s = is_dc ? ((e2 >> 6) & 31u) : (e2 >> 12);
+            size = (e2 & 63u) - s;
+            adv = (e2 >> 6) & 63u;
+        }
     }
     rem = rem > (int32_t)size ? rem - (int32_t)size : 0;  // advance Math.Min(entry.CodeSize, bitsRead)
     value = 0;
@@ -399,34 +445,50 @@ __device__ __forceinline__ void k2_pos_init(K2Pos &p, const uint8_t *ring, int32
     p.w2 = r[(q + 2) & 15];
 }
 
-// One symbol, fast path for every lane, then ONE branch the wave skips unless some lane needs more: a long code (second
-// level), the last bits of the interval, a ring that ran dry (exact path); advances the position.
-// adv2 = zig-zag advance in int16 BYTES (2 x coefficients; 126 = EOB: past the end from any AC position).
-// On failure the lane gets adv2 = 254 (leaves the AC loop), n = 0, value = 0 and the detail code is returned.
+// One STEP of a lane -- one symbol, or the two symbols of a pair entry --, fast path for every lane, then ONE branch the wave skips
+// unless some lane needs more: a magnitude the index does not hold (medium), a long code (second level), the last bits of the
+// interval, a ring that ran dry, a pair whose first symbol ended the block (exact path, one symbol); advances the position.
+// i2 = 2 x zig-zag index of the next coefficient (the pair test).  adv_a2 / adv_b2 = zig-zag advance in int16 BYTES of the first /
+// second symbol (126 = EOB: past the end from any AC position; adv_b2 = 0 and vb = va: one symbol).
+// On failure the lane gets adv_a2 = 254 (leaves the AC loop), n = 0, values 0 and the detail code is returned.
 template <bool IS_DC>
 __device__ __forceinline__ uint32_t k2_symbol(uint8_t *ring, K2Feed &f, K2Pos &p, int32_t endpos, int32_t &lim, const K2Tab &h, bool closed_by_marker,
-                                              int32_t &value, uint32_t &adv2) {
+                                              uint32_t i2, int32_t &va, int32_t &vb, uint32_t &adv_a2, uint32_t &adv_b2) {
     const uint32_t nxt = *reinterpret_cast<const uint32_t *>(ring + __builtin_amdgcn_ubfe((uint32_t)(p.pm1 + 96), 5, 4) * 4);
     const uint32_t hi = __builtin_amdgcn_alignbit(p.w0, p.w1, ~(uint32_t)p.pm1);
-    const uint32_t e = h.lut[hi >> (32 - kK2LutBits)];
-    uint32_t n = e & 63u;
-    const uint32_t cat = IS_DC ? ((e >> 6) & 31u) : (e >> 12);
-    const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - n, cat);
-    value = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));  // Extend(v, nbits)
-    adv2 = (e >> 5) & 0x7Eu;
+    const uint32_t e = h.lut[hi >> h.shift];
+    uint32_t n = e & 15u;
+    va = (int32_t)__builtin_amdgcn_sbfe(e, 20, 6);
+    vb = (int32_t)e >> 26;
+    adv_a2 = IS_DC ? 0u : ((e >> 7) & 0x7Eu);
+    adv_b2 = IS_DC ? 0u : ((e >> 13) & 0x7Eu);
     uint32_t err = 0;
-    // slow: the entry is empty (e - 1 is negative), a DC category above 16 (bit 15), or the symbol does not fit below the
-    // limit -- one signed test
-    const bool slow = (int32_t)((e - 1u) | (IS_DC ? e << 16 : 0u) | (uint32_t)(lim - (p.pm1 + 1) - (int32_t)n)) < 0;
+    // slow: not a fast entry (n - 1 is negative), the step does not fit below the limit, or a pair whose first symbol ends the
+    // block (i2 + adv_a2 >= 128 with a second symbol behind it: that symbol is the next block's) -- one signed test
+    const int32_t room = lim - (p.pm1 + 1) - (int32_t)n;
+    const uint32_t pair_end = IS_DC ? 0u : ((127u - (i2 + adv_a2)) & (0u - adv_b2));
+    const bool slow = (int32_t)((n - 1u) | (uint32_t)room | pair_end) < 0;
     if (slow) {  // exec-masked; the wave skips it when no lane is flagged
-        uint32_t adv = 0;
-        err = k2_slow_symbol(ring, f, p.pm1, endpos, h, IS_DC, closed_by_marker, n, value, adv);
-        adv2 = adv * 2u;
-        lim = k2_limit(endpos, f.wr);
-        if (err != 0) {
-            n = 0;
-            value = 0;
-            adv2 = 254;
+        const uint32_t ntot = (e >> 19) & 63u;
+        if (n == 0 && (int32_t)e > 0 && lim - (p.pm1 + 1) - (int32_t)ntot >= 0) {
+            // medium: the code fits the index, the magnitude comes from the stream (Extend(v, nbits))
+            const uint32_t cat = (e >> 14) & 31u;
+            const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - ntot, cat);
+            va = vb = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));
+            n = ntot;
+            adv_b2 = 0;
+        } else {
+            uint32_t adv = 0;
+            err = k2_slow_symbol(ring, f, p.pm1, endpos, h, IS_DC, closed_by_marker, n, va, adv);
+            vb = va;
+            adv_a2 = adv * 2u;
+            adv_b2 = 0;
+            lim = k2_limit(endpos, f.wr);
+            if (err != 0) {
+                n = 0;
+                va = vb = 0;
+                adv_a2 = 254;
+            }
         }
     }
     const int32_t np = p.pm1 + (int32_t)n;
@@ -437,19 +499,17 @@ __device__ __forceinline__ uint32_t k2_symbol(uint8_t *ring, K2Feed &f, K2Pos &p
     p.w2 = step ? nxt : p.w2;
     return err;
 }
-// (the same with the table kind known only per lane: the K2S final pass on its way to its first MCU)
+// (ONE symbol, the table kind known only per lane: the K2S final pass on its way to its first MCU)
 __device__ __forceinline__ uint32_t k2_symbol_any(uint8_t *ring, K2Feed &f, K2Pos &p, int32_t endpos, int32_t &lim, const K2Tab &h, bool is_dc,
                                                   bool closed_by_marker, int32_t &value, uint32_t &adv2) {
     const uint32_t nxt = *reinterpret_cast<const uint32_t *>(ring + __builtin_amdgcn_ubfe((uint32_t)(p.pm1 + 96), 5, 4) * 4);
     const uint32_t hi = __builtin_amdgcn_alignbit(p.w0, p.w1, ~(uint32_t)p.pm1);
-    const uint32_t e = h.lut[hi >> (32 - kK2LutBits)];
-    uint32_t n = e & 63u;
-    const uint32_t cat = is_dc ? ((e >> 6) & 31u) : (e >> 12);
-    const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - n, cat);
-    value = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));
-    adv2 = is_dc ? 0u : ((e >> 5) & 0x7Eu);
+    const uint32_t e = h.lut[hi >> h.shift];
+    uint32_t n = (e & 15u) != 0 ? ((e >> 4) & 15u) : 0u;  // the entry's first symbol
+    value = (int32_t)__builtin_amdgcn_sbfe(e, 20, 6);
+    adv2 = is_dc ? 0u : ((e >> 7) & 0x7Eu);
     uint32_t err = 0;
-    const bool slow = (int32_t)((e - 1u) | (is_dc ? e << 16 : 0u) | (uint32_t)(lim - (p.pm1 + 1) - (int32_t)n)) < 0;
+    const bool slow = (int32_t)((n - 1u) | (uint32_t)(lim - (p.pm1 + 1) - (int32_t)n)) < 0;
     if (slow) {
         uint32_t adv = 0;
         err = k2_slow_symbol(ring, f, p.pm1, endpos, h, is_dc, closed_by_marker, n, value, adv);
@@ -494,24 +554,65 @@ __device__ __forceinline__ uint32_t k2_entry_of(const DevHuffTable &h, uint32_t 
     const uint32_t adv = (sym & 15u) ? (sym >> 4) + 1u : ((sym >> 4) ? 16u : 63u);
     return (size + cat) | (adv << 6) | (cat << 12);
 }
-// the scan's tables as the K2 family keeps them in LDS: the pooled images (lut_pool_kernel) copied as they are
+// First-level entry `idx` of the u32 lookup (format at kK2AcBits): the reference's Lookup on the index bits with ones behind them,
+// then -- AC, first symbol not EOB -- once more on what the first symbol left of the index.
+__device__ __forceinline__ uint32_t k2_fast_entry(const DevHuffTable &h, uint32_t idx, bool is_dc, uint32_t lb) {
+    const uint32_t ones = (1u << (16u - lb)) - 1u;
+    const uint32_t a = k2_entry_of(h, (idx << (16u - lb)) | ones, is_dc, lb);
+    if (a == 0) return 0;
+    if (is_dc && (a & kK2BadCat) != 0) return 0x80000000u;
+    const uint32_t na = a & 63u, cat_a = is_dc ? ((a >> 6) & 31u) : (a >> 12), adv_a = is_dc ? 0u : ((a >> 6) & 63u);
+    if (na > lb || cat_a > 5u) return (adv_a << 8) | (cat_a << 14) | (na << 19);  // medium
+    const int32_t raw_a = (int32_t)((idx >> (lb - na)) & ((1u << cat_a) - 1u));
+    const int32_t va = cat_a ? raw_a - ((((raw_a + raw_a) >> cat_a) - 1) & ((1 << cat_a) - 1)) : 0;
+    uint32_t n = na, adv_b = 0;
+    int32_t vb = va;
+    if (!is_dc && adv_a != 63u && na < lb) {
+        const uint32_t rem = lb - na;
+        const uint32_t idx_b = ((idx << na) | ((1u << na) - 1u)) & ((1u << lb) - 1u);
+        const uint32_t b = k2_entry_of(h, (idx_b << (16u - lb)) | ones, false, rem);
+        if (b != 0) {
+            const uint32_t nb = b & 63u, cat_b = b >> 12;
+            if (nb <= rem && cat_b <= 5u) {
+                const int32_t raw_b = (int32_t)((idx_b >> (lb - nb)) & ((1u << cat_b) - 1u));
+                vb = cat_b ? raw_b - ((((raw_b + raw_b) >> cat_b) - 1) & ((1 << cat_b) - 1)) : 0;
+                adv_b = (b >> 6) & 63u;
+                n = na + nb;
+            }
+        }
+    }
+    return n | (na << 4) | (adv_a << 8) | (adv_b << 14) | (((uint32_t)va & 63u) << 20) | (((uint32_t)vb & 63u) << 26);
+}
+// the scan's tables as the K2 family keeps them in LDS: the pooled u32 images (lut_pool_kernel) copied as they are, one behind the other
 __device__ __forceinline__ void k2_stage_scan_tables(const DevScan &s, const uint8_t *lut_pool, uint8_t *tabs, uint32_t *blk_info, int n_slots,
                                                      uint32_t nthreads) {
     const uint32_t tid = threadIdx.x;
-    for (int sl = 0; sl < kMaxHuffSlots && sl < n_slots; sl++) {
+    uint32_t off = 0, off16[kMaxHuffSlots];
+#pragma unroll
+    for (int sl = 0; sl < kMaxHuffSlots; sl++) {
+        off16[sl] = off >> 4;
+        if (sl >= n_slots) continue;
         const uint32_t pi = s.huff_pool[sl];
         if (pi == 0xFFFF) continue;
         bool is_dc = false;
         for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
-        const uint4 *src = reinterpret_cast<const uint4 *>(lut_pool + ((size_t)pi * 2 + (is_dc ? 1 : 0)) * kK2TabBytes);
-        uint4 *dst = reinterpret_cast<uint4 *>(tabs + sl * kK2TabBytes);
-        for (uint32_t i = tid; i < kK2TabBytes / 16; i += nthreads) dst[i] = src[i];
+        const uint32_t bytes = is_dc ? kK2DcTabBytes : kK2AcTabBytes;
+        const uint4 *src = reinterpret_cast<const uint4 *>(lut_pool + (size_t)pi * kLutPoolBytesPerTable + (is_dc ? kPoolNewDc : kPoolNewAc));
+        uint4 *dst = reinterpret_cast<uint4 *>(tabs + off);
+        for (uint32_t i = tid; i < bytes / 16; i += nthreads) dst[i] = src[i];
+        off += bytes;
     }
-    // per block-in-MCU: scan component | DC slot << 8 | AC slot << 16 (kept in LDS: the block loop must not touch global
-    // memory for it, a vector load there would wait for the coefficient stores of the previous block)
+    // per block-in-MCU: scan component | DC table offset << 8 | AC table offset << 20 (kept in LDS: the block loop must not touch
+    // global memory for it, a vector load there would wait for the coefficient stores of the previous block)
     if (tid < kMaxBlocksPerMcu) {
         const uint32_t ci = s.blk_comp[tid];
-        blk_info[tid] = ci | ((uint32_t)s.comp[ci].dc_slot << 8) | ((uint32_t)s.comp[ci].ac_slot << 16);
+        uint32_t dc = 0, ac = 0;
+#pragma unroll
+        for (int sl = 0; sl < kMaxHuffSlots; sl++) {
+            dc = s.comp[ci].dc_slot == sl ? off16[sl] : dc;
+            ac = s.comp[ci].ac_slot == sl ? off16[sl] : ac;
+        }
+        blk_info[tid] = ci | (dc << 8) | (ac << 20);
     }
 }
 
