@@ -360,6 +360,73 @@ def measure_config(jl, sharding, jpegsynth, torch, dist, reduce_device, ctx, nam
         batch.close()
 
 
+LATENCY_CASES = {
+    # the reference's own call pattern: ONE image per Decode() (DecoderBenchmark.cs:51-73, apps/JpegDecode/DecodeAction.cs:26-56)
+    "512_444": (512, 512, "444", 75, 0),
+    "1080p_q90": (1920, 1080, "420", 90, 4),
+    "4k_dri4": (3840, 2160, "420", 75, 4),
+    "4k_dri0": (3840, 2160, "420", 75, 0),
+}
+
+
+def measure_latency(jl, ctx, jpegsynth, reps=20):
+    """One image per call, four shapes, median of `reps` calls each:
+      decode_resident_ms   jpgpu_batch_decode + sync of an uploaded one-image batch: file in HBM, pixels left in HBM
+      from_host_ms         jpgpu_batch_upload (SetInput + Identify + header parse + H2D from pageable memory) + decode + sync
+      with_pixels_back_ms  the reference caller's whole sequence through the decoder mirror (jpgpu_decoder_*): SetInput, Identify,
+                           SetOutputWriter(JpegBufferOutputWriter8Bit over a host buffer), Decode() -- pixels in host memory at the end
+      cpu_single_core_ms   the same sequence in the CPU restatement (checker), one core -- what one call costs without the GPU"""
+    from oracle import pyoracle as po
+
+    def med(f, n):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2] * 1e3
+
+    out = {}
+    for name, (w, h, ss, q, dri) in LATENCY_CASES.items():
+        data = bytes(jpegsynth.encode(w, h, ss, q, dri, seed=4242))
+        one = jl.Batch(ctx).upload([data], jl.FMT_INTERLEAVED_U8)
+        one.decode().sync()
+        one.decode().sync()
+        resident = med(lambda: one.decode().sync(), reps)
+
+        def from_host():
+            one.upload([data], jl.FMT_INTERLEAVED_U8)
+            one.decode().sync()
+
+        from_host()
+        t_host = med(from_host, reps)
+        ok = one.result(0).status == 0
+        one.close()
+        buf = np.zeros(w * h * 3, np.uint8)
+        dec = jl.JpegDecoder(ctx)
+
+        def mirror():
+            dec.SetInput(data)
+            dec.Identify()
+            dec.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(w, h, 3, buf))
+            dec.Decode()
+
+        mirror()
+        mirror()
+        t_mirror = med(mirror, max(5, reps // 2))
+        ref = po.decode_8bit(data)[0]
+        ok = ok and bool(np.array_equal(buf.reshape(ref.shape), ref))
+        dec.close()
+        arr = np.frombuffer(data, np.uint8)
+        sec, _ = po.decode_batch_mt([arr] * 3, 3, 1)
+        out[name] = {"decode_resident_ms": round(resident, 3), "from_host_ms": round(t_host, 3), "with_pixels_back_ms": round(t_mirror, 3),
+                     "cpu_single_core_ms": round(sec / 3 * 1e3, 2), "equal_to_checker": ok, "compressed_KB": round(len(data) / 1e3, 1)}
+    out["note"] = ("one image per call (the reference's DecoderBenchmark / DecodeAction pattern), median of %d calls; with_pixels_back = SetInput + "
+                   "Identify + SetOutputWriter + Decode through jpgpu_decoder_* into a host buffer, compared with the checker" % reps)
+    return out
+
+
 def measure_next_rows(jl, jpegsynth, gen_threads, images=128):
     """SURVEY 8(f)'s rows either side of the path, briefly, for the driver's one run: the encoder (tools/bench_encode.py's workload:
     4K RGB -> 4:2:0 Q75, standard tables) and the optimizer (tools/bench_optimize.py's: 4K 4:2:0 Q75 DRI = 7, strip), `images` each,
@@ -525,6 +592,7 @@ def main():
     ap.add_argument("--no-ingest", action="store_true", help="skip the ingest-inclusive (upload beside decode) measurement")
     ap.add_argument("--no-planar-pass", action="store_true", help="skip the short PLANAR_U8 pass behind roofline.read_frac_planar")
     ap.add_argument("--latency", action="store_true", help="also time one image per call (always on for het_8192)")
+    ap.add_argument("--latency-only", action="store_true", help="print the one-image-per-call table (configs.latency of the default line) and exit")
     ap.add_argument("--gen-threads", type=int, default=0)
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed (RCCL) even for a single rank: runs the barrier / "
                                                          "MAX-reduce path of the multi-GPU launch on a one-GPU box")
@@ -602,6 +670,10 @@ def main():
     import jpeglibrary_amd as jl
     from jpeglibrary_amd import sharding
     from tools import jpegsynth
+
+    if args.latency_only:
+        print(json.dumps({"latency": measure_latency(jl, jl.Context(local_rank), jpegsynth)}), flush=True)
+        return
 
     width, height, ss, quality, dri, default_images = WORKLOADS[args.workload]
     kind = "progressive (SOF2, 10 scans)" if ss in ("420p", "420hetp") else ("baseline (HETissueSlide canvas, DecoderBenchmark.cs)" if ss == "420het" else "baseline")
@@ -793,6 +865,14 @@ def main():
                 log(f"[rank {rank}] next rows: {json.dumps({k: configs[k] for k in ('encode_4k_420', 'optimize_4k_420')})[:400]}")
             except Exception as e:  # pragma: no cover
                 configs["encode_4k_420"] = {"error": str(e)[:200]}
+        if rank == 0 and world == 1:
+            try:
+                t_lat = time.perf_counter()
+                configs["latency"] = measure_latency(jl, ctx, jpegsynth)
+                configs["latency"]["seconds"] = round(time.perf_counter() - t_lat, 1)
+                log(f"[rank {rank}] latency: {json.dumps(configs['latency'])[:600]}")
+            except Exception as e:  # pragma: no cover
+                configs["latency"] = {"error": str(e)[:200]}
         if rank == 0:
             configs["note"] = ("short passes of the other BASELINE.json configurations, run after the headline's timed region with the same step "
                                "definition (inputs resident in HBM, output left in HBM); roofline = K3's algorithmic bytes / its HIP-event time; "

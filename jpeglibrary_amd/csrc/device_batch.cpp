@@ -1210,7 +1210,22 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         for (size_t j = 0; j < jobs_.size(); j++)
             if (jobs_[j].kind == kScanSequential && jobs_[j].geo.restart_interval == 0) dri0_bits += (uint64_t)jobs_[j].entropy_len * 8;
         while (subseq_shift < 12 && (dri0_bits >> subseq_shift) >= 500000u) subseq_shift++;
-        if (const char *ev = getenv("JPGPU_SUBSEQ_SHIFT")) subseq_shift = (uint32_t)std::min(14, std::max(10, atoi(ev)));
+        // ... and shrink when the batch is ONE small image (round 6: the reference's callers decode one image per call): a round and the
+        // final pass last as long as one lane's subsequence, and 1024-bit lanes of a 48 KB scan fill six waves of a 256-CU machine.
+        // (512 bits, not 256: the 6-block MCU phase of a 4:2:0 stream re-synchronises over a few hundred bits, and every subsequence
+        // it spans is another round -- a 640 x 368 image took 27 rounds of 256-bit lanes, 9 of 512-bit ones)
+        while (subseq_shift > 9 && (dri0_bits >> subseq_shift) < 4096u) subseq_shift--;
+        if (const char *ev = getenv("JPGPU_SUBSEQ_SHIFT")) subseq_shift = (uint32_t)std::min(14, std::max(8, atoi(ev)));
+    }
+    // K3 walks runs of consecutive tiles per workgroup (the next tile's coefficients fetched under the current one's transform).
+    // A batch of few tiles -- one image per call -- is cut into shorter runs: every CU gets work at once (round 6).
+    uint32_t idct_tiles_per_wg = (uint32_t)kIdctTilesPerWg;
+    {
+        uint64_t blocks = 0;
+        for (const ScanJob &job : jobs_)
+            if (job.kind != kScanProgressive) blocks += (uint64_t)job.geo.mcus_per_line * job.geo.mcus_per_column * (uint64_t)std::max(1, job.blocks_per_mcu);
+        const uint64_t tiles = blocks / (uint64_t)kIdctBlocksPerWg + 1, want_wgs = 3ull * (uint64_t)(ctx_->num_cus > 0 ? ctx_->num_cus : 256);
+        while (idct_tiles_per_wg > 1 && tiles / idct_tiles_per_wg < want_wgs) idct_tiles_per_wg /= 2;
     }
     std::vector<std::vector<HuffWork>> prog_work_by_ordinal, prog_streams_by_ordinal;
     std::vector<std::vector<HuffWork>> prog_chain_work[jpgpu_ctx::kProgChains];  // [chain][ordinal in the frame's chain]
@@ -1535,12 +1550,12 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
                 }
             }
             scan_level[(size_t)j] = level;
-            const uint32_t run = mcus_per_wg * (uint32_t)kIdctTilesPerWg;
+            const uint32_t run = mcus_per_wg * idct_tiles_per_wg;
             if (level > 0) {
                 h_scans_[j].shadow_mask |= kKeepUnreachedMcus;
                 if ((size_t)level > idct_later_levels.size()) idct_later_levels.resize((size_t)level);
                 const uint32_t generic_per_wg = ((uint32_t)kIdctBlocksPerWg / s.blocks_per_mcu);
-                const uint32_t grun = generic_per_wg * (uint32_t)kIdctTilesPerWg;
+                const uint32_t grun = generic_per_wg * idct_tiles_per_wg;
                 for (uint32_t first = 0; first < s.total_mcus; first += grun)
                     idct_later_levels[(size_t)level - 1].push_back({(uint32_t)j, first, std::min(grun, s.total_mcus - first), generic_per_wg});
                 if (format_ == JPGPU_FMT_RGB_U8 || format_ == JPGPU_FMT_RGBA_U8) {  // (bytewise form: samples to the scratch image, then ycc_to_rgb_kernel)
@@ -2191,11 +2206,13 @@ int DeviceBatch::decode() {
         ev_used_ = 0;
         ev_serial_.clear();
     }
-    while (ev_pool_.size() < ev_used_ + 4) {
-        hipEvent_t ev = nullptr;
-        e = hipEventCreate(&ev);
-        if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
-        ev_pool_.push_back(ev);
+    if (ev_pool_.size() < ev_used_ + 4) {  // sixteen decodes' worth at a time: no event is created on the way of a later call
+        for (int k = 0; k < 64; k++) {
+            hipEvent_t ev = nullptr;
+            e = hipEventCreate(&ev);
+            if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+            ev_pool_.push_back(ev);
+        }
     }
     hipEvent_t *ev = &ev_pool_[ev_used_];
     in_decode_request_ = true;
@@ -2206,11 +2223,15 @@ int DeviceBatch::decode() {
     // (a stage event that could not be recorded would turn jpgpu_batch_stage_ms -- bench.py's roofline -- into a silent lie: checked)
     auto mark = [&](int k, hipStream_t st) { return hipEventRecord(ev[k], st) == hipSuccess ? JPGPU_OK : hip_fail(hipGetLastError(), "hipEventRecord(stage)"); };
     if ((rc = mark(0, s1)) != JPGPU_OK) return rc;
+    // One image per call (the reference's callers): an event between two stages is a barrier packet, ~10 us of an idle machine each
+    // -- a tenth of such a call.  Batches of up to four images record them on the first decode behind an upload or a
+    // jpgpu_batch_stage_ms query and on every 8th after it (the rule of the overlapped mode); the stage times come from those.
+    const bool staged = serial && (images_.size() > 4 || ((decodes_since_query_ - 1) % kSerialEvery) == 0);
     if (serial) {
         if ((rc = run_marker_index()) != JPGPU_OK) return rc;
-        if ((rc = mark(1, s1)) != JPGPU_OK) return rc;
+        if (staged && (rc = mark(1, s1)) != JPGPU_OK) return rc;
         if ((rc = run_huffman()) != JPGPU_OK) return rc;
-        if ((rc = mark(2, s1)) != JPGPU_OK) return rc;
+        if (staged && (rc = mark(2, s1)) != JPGPU_OK) return rc;
         if ((rc = run_idct()) != JPGPU_OK) return rc;
         if ((rc = mark(3, s1)) != JPGPU_OK) return rc;
     } else {
@@ -2238,7 +2259,7 @@ int DeviceBatch::decode() {
         if ((e = hipStreamWaitEvent(s1, ev[2], 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");  // join
         if ((rc = mark(3, s1)) != JPGPU_OK) return rc;
     }
-    ev_serial_.push_back(serial);
+    ev_serial_.push_back(staged);
     ev_used_ += 4;
     return mark_work();
 }
