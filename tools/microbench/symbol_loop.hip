@@ -203,6 +203,73 @@ __device__ __forceinline__ uint32_t run_scalar(uint32_t lane, uint32_t ent2, uin
     return cur + zq + symbits + bits + cv + stop + kprev;
 }
 
+// Round 6: the chain ENTIRELY on the scalar unit with its tables in SGPRs -- no v_readlane result is consumed on
+// the chain.  The Huffman lookup is a static table in an SGPR block read with s_movrels_b32 (M0 = the next bits of the stream window,
+// an s[2] pair shifted with s_lshl_b64); the block's history is an s[2] mask: the zero the symbol's run ends on by s_ff1_i32_b64 on
+// the inverted mask behind the position, the correction bits owed for the non-zero coefficients passed by s_bfm_b64 + s_and_b64 +
+// s_bcnt1_i32_b64; the new coefficient and its sign recorded with s_bitset1_b64 / s_lshl_b64 + s_or_b64 into a new-mask / sign-mask pair
+// that the vector unit would apply once per block.  As in the other variants every entry is a plain symbol with run 0 (so the run
+// loop -- one s_ff1 + s_bitset0 per skipped zero in a real stream -- makes no trip) and the window is never refilled: the FLOOR of
+// such a chain.  The table here is 16 entries (one s[16] operand): a wave has 102 SGPRs in all, a 64-entry table would take 64 of them.
+// (fixed registers: inline asm cannot name the halves of a 64-bit operand.  s[36:37] window, s[38:39] history, s[40:41] its
+// inverse, s[42:43] new mask, s[44:45] sign mask, s[46:47] / s[48:49] / s[50:51] scratch pairs, s52.. scalars, s[64:79] the table)
+__device__ __forceinline__ uint32_t run_sgpr_tables(uint32_t zq0, uint32_t se, uint32_t &trips, uint32_t seed) {
+    uint32_t ntrips, res;
+    asm volatile(
+        "s_mov_b32 s36, 0x9abcdef0\n\ts_mov_b32 s37, 0x12345678\n\t"
+        "s_mov_b32 s38, 0\n\ts_mov_b32 s39, 0x0f0f0000\n\t"
+        "s_not_b64 s[40:41], s[38:39]\n\t"
+        "s_mov_b64 s[42:43], 0\n\ts_mov_b64 s[44:45], 0\n\t"
+        "s_add_u32 s52, %[zq0], 1\n\t"                    // k
+        "s_mov_b32 s53, 0\n\t"                             // trips
+        "s_mov_b32 s64, %[ent]\n\ts_mov_b32 s65, %[ent]\n\ts_mov_b32 s66, %[ent]\n\ts_mov_b32 s67, %[ent]\n\t"
+        "s_mov_b32 s68, %[ent]\n\ts_mov_b32 s69, %[ent]\n\ts_mov_b32 s70, %[ent]\n\ts_mov_b32 s71, %[ent]\n\t"
+        "s_mov_b32 s72, %[ent]\n\ts_mov_b32 s73, %[ent]\n\ts_mov_b32 s74, %[ent]\n\ts_mov_b32 s75, %[ent]\n\t"
+        "s_mov_b32 s76, %[ent]\n\ts_mov_b32 s77, %[ent]\n\ts_mov_b32 s78, %[ent]\n\ts_mov_b32 s79, %[ent]\n\t"
+        "1:\n\t"
+        "s_add_u32 s53, s53, 1\n\t"
+        "s_lshr_b32 s54, s37, 28\n\t"                      // the next 4 bits of the stream
+        "s_mov_b32 m0, s54\n\t"
+        "s_nop 0\n\t"
+        "s_movrels_b32 s55, s64\n\t"                       // lut[m0]
+        "s_and_b32 s56, s55, 31\n\t"                       // code length
+        "s_bfe_u32 s57, s55, 0x40008\n\t"                  // run
+        "s_lshl_b64 s[36:37], s[36:37], s56\n\t"           // the code is consumed
+        "s_lshr_b64 s[46:47], s[40:41], s52\n\t"           // zeros at and behind the position
+        "s_cmp_eq_u32 s57, 0\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "2:\n\t"                                           // skip r zeros (no trip here: run 0)
+        "s_ff1_i32_b64 s58, s[46:47]\n\t"
+        "s_bitset0_b64 s[46:47], s58\n\t"
+        "s_sub_u32 s57, s57, 1\n\t"
+        "s_cmp_lg_u32 s57, 0\n\t"
+        "s_cbranch_scc1 2b\n\t"
+        "3:\n\t"
+        "s_ff1_i32_b64 s58, s[46:47]\n\t"                  // the zero the run ends on, relative to k
+        "s_add_u32 s59, s52, s58\n\t"                      // pos
+        "s_bfm_b64 s[48:49], s58, s52\n\t"                 // coefficients k .. pos - 1
+        "s_and_b64 s[48:49], s[48:49], s[38:39]\n\t"
+        "s_bcnt1_i32_b64 s60, s[48:49]\n\t"                // correction bits owed
+        "s_lshl_b64 s[36:37], s[36:37], s60\n\t"
+        "s_lshr_b64 s[50:51], s[36:37], 63\n\t"            // the new coefficient's sign
+        "s_lshl_b64 s[36:37], s[36:37], 1\n\t"
+        "s_bitset1_b64 s[42:43], s59\n\t"
+        "s_lshl_b64 s[50:51], s[50:51], s59\n\t"
+        "s_or_b64 s[44:45], s[44:45], s[50:51]\n\t"
+        "s_add_u32 s52, s59, 1\n\t"
+        "s_cmp_lt_u32 s52, 63\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_mov_b32 %[ntrips], s53\n\t"
+        "s_add_u32 %[res], s42, s45\n\t"
+        : [ntrips] "=s"(ntrips), [res] "=s"(res)
+        : [zq0] "s"(zq0), [ent] "s"(1u | (seed & 0u))
+        : "scc", "m0", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52",
+          "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76",
+          "s77", "s78", "s79");
+    trips += ntrips;
+    return res;
+}
+
 template <int kVariant>
 __global__ void k(uint64_t *out, uint32_t seed) {
     const uint32_t lane = threadIdx.x;
@@ -215,8 +282,10 @@ __global__ void k(uint64_t *out, uint32_t seed) {
         for (int which = 0; which < 2; which++) {
             const uint32_t zq0 = which == 0 ? 31u : 0xFFFFFFFFu;  // 32 trips or 64
             const uint64_t t0 = tick();
-            for (int rep = 0; rep < 64; rep++) sink += kVariant == 3 ? run_scalar(lane, ent2, ntab, __builtin_amdgcn_readfirstlane(zq0), 200u, trips[which])
-                                                                   : run<kVariant>(lane, ent2, ntab, zq0 + (sink & 0u), 200u, trips[which]);
+            for (int rep = 0; rep < 64; rep++)
+                sink += kVariant == 4   ? run_sgpr_tables(__builtin_amdgcn_readfirstlane(zq0), 200u, trips[which], seed)
+                        : kVariant == 3 ? run_scalar(lane, ent2, ntab, __builtin_amdgcn_readfirstlane(zq0), 200u, trips[which])
+                                        : run<kVariant>(lane, ent2, ntab, zq0 + (sink & 0u), 200u, trips[which]);
             dt[which] = tick() - t0;
         }
     if (lane == 0) {
@@ -231,12 +300,14 @@ __global__ void k(uint64_t *out, uint32_t seed) {
 int main() {
     uint64_t *d, h[5];
     hipMalloc(&d, sizeof h);
-    const char *names[4] = {"full loop (as shipped)", "chain only, gaps as s_nop", "chain through ds_bpermute", "chain on the scalar unit"};
-    for (int v = 0; v < 4; v++) {
+    const char *names[5] = {"full loop (as shipped)", "chain only, gaps as s_nop", "chain through ds_bpermute", "chain on the scalar unit",
+                            "scalar chain, tables in SGPRs"};
+    for (int v = 0; v < 5; v++) {
         if (v == 0) k<0><<<1, 64>>>(d, 5);
         if (v == 1) k<1><<<1, 64>>>(d, 5);
         if (v == 2) k<2><<<1, 64>>>(d, 5);
         if (v == 3) k<3><<<1, 64>>>(d, 5);
+        if (v == 4) k<4><<<1, 64>>>(d, 5);
         hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
         // 64 entries of (fixed cost + n trips); the trip counts differ by 32 (+ the one that fails: the same in both)
         // two timed passes of 64 loop entries each (the counters run over both)
