@@ -176,12 +176,12 @@ __device__ __forceinline__ void sr_service(SrLane &L, const uint8_t *smem, uint3
     const uint32_t hi = sr_peek(L, ring_off);
     const bool is_dc = L.k == 0;
     const uint32_t tab = is_dc ? L.tabdc : L.tabac;
-    const uint32_t e = sr_ld32(tab + (hi >> (32 - LB)) * 4u);
+    uint32_t e = sr_ld32(tab + (hi >> (32 - LB)) * 4u);
     const int32_t rem = endpos - pos;
     if ((e & 63u) != 0 && L.pm1 < L.slim) return;  // it was the ring: the next fast step takes it
     uint32_t n, adv;
     int32_t v;
-    if ((e & 63u) != 0) {  // decided by the lookup, but inside the last 32 bits of the data
+    if ((e & 63u) != 0 && !(is_dc && __builtin_amdgcn_ubfe(e, 6, 7) != 1u)) {  // decided by the lookup, but inside the last 32 bits of the data
         n = e & 63u;
         adv = __builtin_amdgcn_ubfe(e, 6, 7);
         v = (int32_t)e >> 16;
@@ -189,6 +189,7 @@ __device__ __forceinline__ void sr_service(SrLane &L, const uint8_t *smem, uint3
         const uint32_t sl = (tab - lut0) >> (LB + 2);
         const uint32_t code16 = hi >> 16;
         uint32_t size, cat;
+        if ((e & 63u) != 0) e = kSrStandDcWide;  // a DC entry that took the first AC symbol along: the DC symbol alone, from the pooled first level
         if (e == kSrStandBadCat) {  // categories above 16 are outside the verified envelope
             bad = 1;
             L.slim = kSrParked;
@@ -237,8 +238,12 @@ __device__ __forceinline__ void sr_service(SrLane &L, const uint8_t *smem, uint3
 
 // lookups of the round kernel out of the pooled 11-bit ones (lut_pool_kernel): entry i of an LB-bit lookup covers pooled
 // prefixes i << (11 - LB) ..; it is decided when the code has at most LB bits (and, for a DC symbol, the magnitude fits too)
+// l1ac (DC tables): the pooled AC lookup of the table every component that decodes its DC symbols with this table decodes its AC
+// symbols with, or null -- the DC entry then takes the block's FIRST AC symbol along when both fit the index (round 6: a block
+// of a flat region is "DC difference 0, EOB", six bits under the standard tables: one step instead of two; no lane can be at a
+// position where that is wrong -- a DC symbol never ends a block)
 template <int LB>
-__device__ __forceinline__ uint32_t sr_entry(const uint16_t *l1, uint32_t i, bool is_dc) {
+__device__ __forceinline__ uint32_t sr_entry(const uint16_t *l1, uint32_t i, bool is_dc, const uint16_t *l1ac = nullptr) {
     const uint32_t e = l1[i << (kLutPoolBits - LB)];
     if (e == 0) return kSrStandMiss;
     if (is_dc && (e & kK2BadCat) != 0) {  // (the pooled entry does not say how long the code is: every pooled prefix under i must agree)
@@ -252,9 +257,21 @@ __device__ __forceinline__ uint32_t sr_entry(const uint16_t *l1, uint32_t i, boo
         if (n > (uint32_t)LB) return kSrStandDcWide;
         const int32_t raw = (int32_t)((i >> (LB - n)) & ((1u << cat) - 1u));
         const int32_t v = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));
+        if (l1ac != nullptr && n < (uint32_t)LB) {
+            const uint32_t rem = (uint32_t)LB - n;
+            const uint32_t ib = ((i << n) | ((1u << n) - 1u)) & ((1u << LB) - 1u);
+            const uint32_t eb = l1ac[(ib << (kLutPoolBits - LB)) | ((1u << (kLutPoolBits - LB)) - 1u)];
+            if (eb != 0 && (eb & 63u) <= rem) {
+                const uint32_t advb = (eb >> 6) & 63u;
+                return (n + (eb & 63u)) | ((1u + (advb == 63u ? 64u : advb)) << 6) | ((uint32_t)v << 16);
+            }
+        }
         return n | (1u << 6) | ((uint32_t)v << 16);
     }
     const uint32_t adv = (e >> 6) & 63u;
+    // (round 6: AC + AC pairs as in K2's lookup were built and measured here too -- the blocked-pair test costs the step five
+    // instructions, 27 -> 32: 4k_dri0 rounds -0.15 ms per 1024 images, the reference's benchmark canvas, three quarters flat, +0.09 ms
+    // per canvas: not kept; patch and table in tools/microbench/k2_pairs/)
     return n | ((adv == 63u ? 64u : adv) << 6);
 }
 
@@ -442,8 +459,21 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
         // (the pool's u16 images: AC at the table's base, DC behind it; the u32 images of K2 / the final pass follow)
         const uint16_t *src = reinterpret_cast<const uint16_t *>(lut_pool + (size_t)pi * kLutPoolBytesPerTable + (is_dc ? kK2TabBytes : 0u));
         if (tid == 0) pool_off[sl] = (uint32_t)((size_t)pi * kLutPoolBytesPerTable + (is_dc ? kK2TabBytes : 0u));
+        // (a DC table's partner: the one AC table of every component that uses it)
+        const uint16_t *src_ac = nullptr;
+        if (is_dc) {
+            uint32_t ac_pi = 0xFFFFFFFFu;
+            bool one = true;
+            for (int c = 0; c < s.scan_components; c++)
+                if (s.comp[c].dc_slot == sl) {
+                    const uint32_t a = s.comp[c].ac_slot < kMaxHuffSlots ? s.huff_pool[s.comp[c].ac_slot] : 0xFFFFu;
+                    one &= ac_pi == 0xFFFFFFFFu || ac_pi == a;
+                    ac_pi = a;
+                }
+            if (one && ac_pi < 0xFFFFu) src_ac = reinterpret_cast<const uint16_t *>(lut_pool + (size_t)ac_pi * kLutPoolBytesPerTable);
+        }
         uint32_t *dst = reinterpret_cast<uint32_t *>(smem) + ((size_t)sl << LB);
-        for (uint32_t i = tid; i < (1u << LB); i += 256) dst[i] = sr_entry<LB>(src, i, is_dc);
+        for (uint32_t i = tid; i < (1u << LB); i += 256) dst[i] = sr_entry<LB>(src, i, is_dc, src_ac);
         const uint4 *ssrc = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&huff_pool[pi]) + offsetof(DevHuffTable, maxcode));
         uint4 *sdst = reinterpret_cast<uint4 *>(smem + small_off + sl * kK2SmallBytes);
         if (tid < kK2SmallBytes / 16) sdst[tid] = ssrc[tid];
