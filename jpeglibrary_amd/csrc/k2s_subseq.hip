@@ -257,14 +257,20 @@ __device__ __forceinline__ uint32_t sr_entry(const uint16_t *l1, uint32_t i, boo
         if (n > (uint32_t)LB) return kSrStandDcWide;
         const int32_t raw = (int32_t)((i >> (LB - n)) & ((1u << cat) - 1u));
         const int32_t v = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));
-        if (l1ac != nullptr && n < (uint32_t)LB) {
-            const uint32_t rem = (uint32_t)LB - n;
-            const uint32_t ib = ((i << n) | ((1u << n) - 1u)) & ((1u << LB) - 1u);
-            const uint32_t eb = l1ac[(ib << (kLutPoolBits - LB)) | ((1u << (kLutPoolBits - LB)) - 1u)];
-            if (eb != 0 && (eb & 63u) <= rem) {
+        if (l1ac != nullptr) {
+            // ... and every AC symbol behind it that still fits: behind a DC symbol the zig-zag position is 1, ten bits of AC symbols
+            // cannot take it to 64 unless the last of them is EOB, so no lane can be where the chain is wrong
+            uint32_t nn = n, adv = 1u;
+            while (nn < (uint32_t)LB && adv < 64u) {
+                const uint32_t rem = (uint32_t)LB - nn;
+                const uint32_t ib = ((i << nn) | ((1u << nn) - 1u)) & ((1u << LB) - 1u);
+                const uint32_t eb = l1ac[(ib << (kLutPoolBits - LB)) | ((1u << (kLutPoolBits - LB)) - 1u)];
+                if (eb == 0 || (eb & 63u) > rem) break;
                 const uint32_t advb = (eb >> 6) & 63u;
-                return (n + (eb & 63u)) | ((1u + (advb == 63u ? 64u : advb)) << 6) | ((uint32_t)v << 16);
+                nn += eb & 63u;
+                adv += advb == 63u ? 64u : advb;
             }
+            return nn | ((adv < 127u ? adv : 127u) << 6) | ((uint32_t)v << 16);
         }
         return n | (1u << 6) | ((uint32_t)v << 16);
     }
