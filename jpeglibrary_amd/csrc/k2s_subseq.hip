@@ -1141,7 +1141,11 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
     hipError_t e = hipMemsetAsync(changed_dev, 0, (device_rounds > 0 ? (size_t)kSubCtlPerDecode : 64) * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     // round r reads the exits round r - 1 wrote; rounds behind round 1 gather their few lanes (subseq_round_kernel<true>)
-    static const bool no_gather = getenv("JPGPU_SUBSEQ_NO_GATHER") != nullptr;  // A/B switch
+#ifdef JPGPU_SUBSEQ_NO_GATHER  // (A/B build variants since round 6: tools/trace/ab_build.sh "-DJPGPU_SUBSEQ_NO_GATHER" ...)
+    constexpr bool no_gather = true;
+#else
+    constexpr bool no_gather = false;
+#endif
     auto launch_round = [&](int r, uint32_t *count, const uint32_t *prev) {
         if (r >= 2 && gather_work != nullptr && n_gather > 0 && !no_gather)
             hipLaunchKernelGGL(subseq_round_kernel<true>, dim3(n_gather), dim3(256), lds_round, stream, udata, scans, gather_work, ends_u, status, huff_pool,
@@ -1232,7 +1236,11 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                       &final_state, same_dist, same_valid, device_rounds, gather_work, n_gather);
     if (e != hipSuccess) return e;
     static std::atomic<uint64_t> configured{0}, configured_pool{0};
-    static const bool no_order = getenv("JPGPU_SF_NO_ORDER") != nullptr;  // A/B switch
+#ifdef JPGPU_SF_NO_ORDER  // (A/B build variant)
+    constexpr bool no_order = true;
+#else
+    constexpr bool no_order = false;
+#endif
     const uint32_t *perm = nullptr;
     if (lane_perm != nullptr && gather_work != nullptr && n_gather > 0 && !no_order) {
         hipLaunchKernelGGL(subseq_order_kernel, dim3(n_gather), dim3(kSubseqGatherSpan / spl), 0, stream, scans, gather_work, status, final_state, first_block,
