@@ -326,6 +326,12 @@ def test_bench_line_carries_every_baseline_config_and_the_in_process_driver():
     for name in ("encode_4k_420", "optimize_4k_420"):
         assert cfg[name]["value"] > 0 and cfg[name]["parity_spot_check"] == "byte-exact vs oracle", (name, cfg[name])
     assert cfg["encode_4k_420"]["entropy_stage_one_pass"] is True
+    # ... and the reference's OWN call pattern (round 6): one image per call, four shapes, each equal to the checker
+    lat = cfg["latency"]
+    for name in ("512_444", "1080p_q90", "4k_dri4", "4k_dri0"):
+        row = lat[name]
+        assert row["equal_to_checker"] is True, (name, row)
+        assert 0 < row["decode_resident_ms"] <= row["from_host_ms"] * 1.5 and row["with_pixels_back_ms"] > 0 and row["cpu_single_core_ms"] > 0, (name, row)
     assert out["value_multi_inprocess"] > 0 and out["multi_inprocess"]["parity_spot_check"] == "bit-exact vs oracle"
 
 

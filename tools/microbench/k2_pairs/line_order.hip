@@ -54,7 +54,7 @@ int main(int argc, char **argv) {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int wg_per_img = (kIntervals + 64 * kWaves - 1) / (64 * kWaves);
-    const int lds = 150 * 1024;
+    const int lds = argc > 3 ? atoi(argv[3]) * 1024 : 150 * 1024;  // (150 KB: one workgroup per CU, K2's occupancy)
     hipFuncSetAttribute(reinterpret_cast<const void *>(&writer<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&writer<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&writer<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -20,8 +20,8 @@ if [ "${1:-}" = "headline" ]; then
   cut -c1-200 gpurun_out/${TAG}_headline/bench_het_8192.json
   ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kh && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kh -- python3 $R/bench.py --workload het_8192 --steps 5 --warmup 2 --no-cpu-baseline --no-ingest > /tmp/kh.log 2>&1; cp $(find /tmp/kh -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_headline/kernel_stats_het_8192.csv )
   # random corpora through every GPU path against the checker (decode incl. failing writers / partial flushes / per-scan sessions,
-  # optimizer, encoder): ONE summary, 3 seeds x 1500 files per corpus switch (tools/trace/r05_stress.sh)
-  bash tools/trace/r05_stress.sh > /dev/null 2>&1; cp gpurun_out/r05_stress.txt gpurun_out/${TAG}_headline/stress.txt
+  # optimizer, encoder): ONE summary, 3 seeds x 1500 files per corpus switch (tools/trace/round_stress.sh)
+  TAG=$TAG bash tools/trace/round_stress.sh > /dev/null 2>&1; cp gpurun_out/${TAG}_stress.txt gpurun_out/${TAG}_headline/stress.txt
   cat gpurun_out/${TAG}_headline/stress.txt
   exit 0
 fi
@@ -43,4 +43,9 @@ for a in "420" "444"; do python3 tools/bench_encode.py --workload het_8192 --sub
 python3 tools/bench_encode.py --workload het_8192 --subsampling 420 --optimize-coding > gpurun_out/all_$TAG/bench_encode_het_8192_420_optimize.json 2>/dev/null
 bash tools/trace/timeline.sh ${TAG}het1 het_8192 1 > /dev/null 2>&1; cp gpurun_out/timeline_${TAG}het1.txt gpurun_out/all_$TAG/timeline_het_8192_one_canvas.txt
 bash tools/trace/r05_k2s_ab.sh > gpurun_out/all_$TAG/k2s_ab_4k_dri0.txt 2>&1
+# round 6: the reference's call pattern (one image per call) and its kernel timelines; where a K2 wave spends its cycles; K2's stores alone
+python3 bench.py --latency-only > gpurun_out/all_$TAG/latency.json 2>/dev/null
+for w in 512_444 4k_dri4 4k_dri0; do bash tools/trace/one_image_timeline.sh $w; done > gpurun_out/all_$TAG/one_image_timeline.txt 2>&1
+( bash tools/trace/ab_build.sh "-DJPGPU_K2_PROFILE" python3 tools/trace/k2_phases.py 128; bash tools/trace/ab_build.sh "-DJPGPU_K2_PROFILE" python3 tools/trace/k2_phases.py 256 q90 ) > gpurun_out/all_$TAG/k2_phases.txt 2>&1
+( cd tools/microbench/k2_pairs && for d in 0 200; do ./line_order $d 512; done ) > gpurun_out/all_$TAG/line_order.txt 2>&1
 sha256sum jpeglibrary_amd/libjpgpu.so

@@ -14,7 +14,7 @@ for f in bench_4k_dri0.json bench_1080p_q90.json bench_planar_u8.json bench_rgb_
          progressive_by_scan_256.txt progressive_by_scan_2048.txt progressive_pmc_64.txt symbol_loop.txt fetch_rate.txt issue_latency.txt \
          kernel_stats_rgb_u8.csv kernel_stats_rgba_u8.csv multi_slots.jsonl multi_slots.txt encoder_pmc_summary_64img.txt library.sha256 \
          bench_het_progressive.json progressive_by_scan_256_het.txt bench_encode_het_8192_420.json bench_encode_het_8192_444.json \
-         bench_encode_het_8192_420_optimize.json timeline_het_8192_one_canvas.txt k2s_ab_4k_dri0.txt; do
+         bench_encode_het_8192_420_optimize.json timeline_het_8192_one_canvas.txt k2s_ab_4k_dri0.txt latency.json one_image_timeline.txt k2_phases.txt line_order.txt; do
   [ -e $S/$f ] && cp $S/$f $R/profiles/${TAG}_$f
 done
 # the headline line and its kernel statistics inside the long evidence call (a box under load for minutes) ...
