@@ -217,6 +217,8 @@ class DeviceBatch {
     std::vector<DevHuffTable> huff_pool_;
     std::vector<DevQuantTable> quant_pool_;
     int n_huff_slots_ = 1;
+    std::vector<SubseqPool> k2_pools_;          // pooled runs of K2 (round 6): entries of d_huff_work_ behind the first n_huff_work_
+    uint32_t k2_ticket_base_[kK2MaxPools] = {};  // tickets the earlier launches of this upload drew from each pool's counter (d_k2_tickets_)
     uint32_t k2_tab_bytes_ = 0;  // LDS of the largest table set a sequential scan of the upload stages (K2, the K2S final pass)
     int n_huff_work_ = 0, n_idct_work_ = 0;
     int idct_class_begin_[kNumIdctLayoutClasses + 1] = {};
@@ -300,7 +302,7 @@ class DeviceBatch {
     DevBuffer d_chunk_work_, d_chunk_sums_;
     int n_chunk_work_ = 0;
     DevBuffer d_unstuffed_, d_ends_u_;  // K1 output: entropy data as the bit reader sees it + interval ends in it
-    DevBuffer d_input_, d_scans_, d_status_, d_ends_, d_huff_pool_, d_quant_pool_, d_huff_work_, d_idct_work_, d_coefs_, d_out_;
+    DevBuffer d_input_, d_scans_, d_status_, d_ends_, d_huff_pool_, d_quant_pool_, d_huff_work_, d_idct_work_, d_coefs_, d_out_, d_k2_tickets_;
     // stage events of every decode() since the last stage_ms() query (4 events per decode)
     std::vector<hipEvent_t> ev_pool_;
     size_t ev_used_ = 0;

@@ -47,6 +47,17 @@ int DeviceBatch::run_huffman() {
                                   n_huff_work_, (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr,
                                   (const DevHuffTable *)d_huff_pool_.ptr, (int16_t *)d_coefs_.ptr, n_huff_slots_, (const uint8_t *)d_lut_pool_.ptr, k2_tab_bytes_);
     if (e != hipSuccess) return hip_fail(e, "huffman_decode_kernel");
+    for (size_t p = 0; p < k2_pools_.size(); p++) {
+        // pooled runs: one workgroup per CU at most, every wave takes 64 intervals at a time from the run's counter
+        const int waves = huffman_waves(k2_tab_bytes_);
+        const int groups = std::min(ctx_->num_cus > 0 ? ctx_->num_cus : 256, (k2_pools_[p].count + waves - 1) / waves);
+        e = launch_huffman_pool(ctx_->stream, (const uint8_t *)d_unstuffed_.ptr, (const DevScan *)d_scans_.ptr,
+                                (const HuffWork *)d_huff_work_.ptr + n_huff_work_ + k2_pools_[p].first, k2_pools_[p].count, (uint32_t *)d_k2_tickets_.ptr + p,
+                                k2_ticket_base_[p], groups, (const uint32_t *)d_ends_u_.ptr, (DevScanStatus *)d_status_.ptr, (int16_t *)d_coefs_.ptr,
+                                n_huff_slots_, (const uint8_t *)d_lut_pool_.ptr, k2_tab_bytes_);
+        if (e != hipSuccess) return hip_fail(e, "huffman_pool_kernel");
+        k2_ticket_base_[p] += (uint32_t)k2_pools_[p].count + (uint32_t)(groups * waves);
+    }
     if (n_sub_work_ > 0) {
         // DRI = 0 scans: the final pass writes every block of the scan as whole lines (nothing to clear).  The rounds are
         // enqueued ahead, as many as the last decode of this upload used (16 the first time); sync() reads whether they sufficed.

@@ -468,7 +468,46 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     out_bytes_ = out_off;
     planes_bytes_ = planes_off;
     total_ends_ = ends_off;
-    n_huff_work_ = (int)huff_work.size();
+    // K2's work.  Runs of consecutive scans that stage the same tables in the same slots (all of a batch of files from one encoder,
+    // typically) are POOLED (round 6; the K2S final pass below has had it since round 5): one entry per WAVE of 64 restart intervals,
+    // taken from a counter by the waves of one workgroup per CU (huffman_pool_kernel).  Everything else keeps a workgroup per
+    // huffman_waves() * 64 intervals of one scan.  (JPGPU_OVERLAP, the opt-in two-stream issue order, splits the plain list: no pools then.)
+    auto same_tables = [&](const DevScan &a, const DevScan &b) {
+        return memcmp(a.huff_pool, b.huff_pool, sizeof a.huff_pool) == 0 && a.scan_components == b.scan_components &&
+               a.blocks_per_mcu == b.blocks_per_mcu && memcmp(a.blk_comp, b.blk_comp, sizeof a.blk_comp) == 0 &&
+               memcmp(a.comp, b.comp, sizeof a.comp) == 0;
+    };
+    k2_pools_.clear();
+    {
+        std::vector<HuffWork> plain, pooled;
+#ifdef JPGPU_K2_NO_POOL  // (A/B build variant: tools/trace/ab_build.sh "-DJPGPU_K2_NO_POOL" ...)
+        const bool no_pool = true;
+#else
+        const bool no_pool = getenv("JPGPU_OVERLAP") != nullptr && atoi(getenv("JPGPU_OVERLAP")) != 0;
+#endif
+        size_t i = 0;
+        while (i < huff_work.size() && !no_pool) {
+            size_t k = i;
+            uint64_t chunks = 0;
+            const DevScan &a = h_scans_[huff_work[i].scan];
+            while (k < huff_work.size() && same_tables(a, h_scans_[huff_work[k].scan])) {
+                if (huff_work[k].first_interval == 0) chunks += (h_scans_[huff_work[k].scan].n_intervals + 63u) / 64u;
+                k++;
+            }
+            const bool pool = (int)k2_pools_.size() < kK2MaxPools && chunks >= 2 && chunks < 0x7FFFFFFFu;
+            if (pool) k2_pools_.push_back({(int)pooled.size(), (int)chunks});
+            for (size_t q = i; q < k; q++) {
+                if (!pool) plain.push_back(huff_work[q]);
+                else if (huff_work[q].first_interval == 0)
+                    for (uint32_t first = 0; first < h_scans_[huff_work[q].scan].n_intervals; first += 64u) pooled.push_back({huff_work[q].scan, first});
+            }
+            i = k;
+        }
+        if (!no_pool) huff_work.swap(plain);
+        n_huff_work_ = (int)huff_work.size();
+        huff_work.insert(huff_work.end(), pooled.begin(), pooled.end());  // (one buffer: the pooled list behind the plain one)
+    }
+    for (uint32_t &b : k2_ticket_base_) b = 0;
     n_chunk_work_ = (int)chunk_work.size();
     std::stable_sort(k1_order.begin(), k1_order.end(), [](const ChunkWork &a, const ChunkWork &b) { return a.chunk < b.chunk; });
     n_k1_groups_ = (int)k1_order.size();
@@ -488,11 +527,6 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
 #else
         const bool no_pool = !subseq_pool_fits(k2_tab_bytes_);  // (ten waves + the tables must fit a CU)
 #endif
-        auto same_tables = [&](const DevScan &a, const DevScan &b) {
-            return memcmp(a.huff_pool, b.huff_pool, sizeof a.huff_pool) == 0 && a.scan_components == b.scan_components &&
-                   a.blocks_per_mcu == b.blocks_per_mcu && memcmp(a.blk_comp, b.blk_comp, sizeof a.blk_comp) == 0 &&
-                   memcmp(a.comp, b.comp, sizeof a.comp) == 0;
-        };
         // (a batch that cannot fill the machine with two subsequences per lane takes one: twice the waves, half as long each)
 #ifdef JPGPU_SF_ONE_SUB  // (A/B build variant)
         sub_final_spl_ = 1;
@@ -718,6 +752,7 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_lut_pool_, nullptr, 0, huff_pool_.size() * kLutPoolBytesPerTable},
         {&d_chunk_sums_, nullptr, 0, (size_t)total_chunks * sizeof(ChunkSum) + 256},
         {&d_k1_tickets_, nullptr, 0, 256},  // [0] the ticket counter, [1] the device's give-up word
+        {&d_k2_tickets_, nullptr, 0, 256},  // K2's pooled runs: a ticket counter each (cleared per upload, never between decodes)
         {&d_idct_work_, idct_work.data(), idct_work.size() * sizeof(IdctWork), 0},
         {&d_idct_work_split_, idct_work_split.data(), idct_work_split.size() * sizeof(IdctWork), 0},
         {&d_ends_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},
@@ -737,6 +772,8 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
             if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(descriptors)");
         }
     }
+    e = hipMemsetAsync(d_k2_tickets_.ptr, 0, kK2MaxPools * sizeof(uint32_t), up);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(K2 tickets)");
     {
         // K1 in one pass: descriptors cleared when (re)allocated only (their tags are never reused), tickets + the give-up word per upload
         const size_t want = (size_t)total_chunks * kMarkerDescBytes + 256;

@@ -82,38 +82,13 @@ extern "C" int jpgpu_debug_k2_profile(unsigned long long *out, int reset) {
 #define K2_PROF_ADD(i, v) do { (void)(v); } while (0)
 #endif
 
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_t *__restrict__ udata,
-                                                                    const DevScan *__restrict__ scans,
-                                                                    const HuffWork *__restrict__ work,
-                                                                    const uint32_t *__restrict__ ends_u,
-                                                                    DevScanStatus *__restrict__ status,
-                                                                    const DevHuffTable *__restrict__ huff_pool,
-                                                                    int16_t *__restrict__ coefs, int n_slots,
-                                                                    const uint8_t *__restrict__ lut_pool, uint32_t tab_bytes) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *tabs = smem;                  // tab_bytes: the batch's largest set of staged tables
-    uint8_t *wave_all = smem + tab_bytes;  // WAVES * kK2WaveBytes
-    uint32_t *blk_info = reinterpret_cast<uint32_t *>(wave_all + WAVES * kK2WaveBytes);  // [kMaxBlocksPerMcu]
-
-    const HuffWork wk = work[blockIdx.x];
-    const DevScan &s = scans[wk.scan];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63;
-    const uint32_t wave = tid >> 6;
-    const unsigned long long k2_t0 = K2_TICK();
-
-    // stage this scan's Huffman tables (ref: InitDecodeComponents resolves them per scan, JpegHuffmanScanDecoder.cs:63-64)
-    k2_stage_scan_tables(s, lut_pool, tabs, blk_info, n_slots, 64 * WAVES);
-    uint8_t *stage = wave_all + wave * kK2WaveBytes;
-    uint8_t *ring = stage + 8192 + lane * kK2RingStride;
-    {
-        const uint4 z = {0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(stage)[i * 64 + lane] = z;
-    }
-    __syncthreads();
-
+// One wave's 64 restart intervals wave_first .. wave_first + 63 of scan `scan_index` (tables staged, the wave's coefficient staging zero on
+// entry and on exit).
+__device__ __forceinline__ void k2_wave(const uint8_t *__restrict__ udata, const DevScan &s, uint32_t scan_index, uint32_t wave_first,
+                                        const uint32_t *__restrict__ ends_u, DevScanStatus *__restrict__ status, int16_t *__restrict__ coefs,
+                                        const uint8_t *tabs, const uint32_t *blk_info, uint8_t *stage, uint8_t *ring, uint32_t lane,
+                                        unsigned long long k2_t0) {
+    struct { uint32_t scan; } wk = {scan_index};
     const unsigned long long k2_t1 = K2_TICK();
     const DevScanStatus st = status[wk.scan];
     const uint32_t n_ends = st.n_ends;
@@ -121,7 +96,6 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
     const uint32_t total_mcus = s.total_mcus;
     const uint32_t dri_eff = s.dri ? s.dri : total_mcus;
     const uint32_t bpm = s.blocks_per_mcu;
-    const uint32_t wave_first = wk.first_interval + wave * 64;
     const uint32_t interval = wave_first + lane;
     const bool active = interval < n_ends;
     const uint32_t *eu = ends_u + s.ends_off;
@@ -262,6 +236,74 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_
     }
 }
 
+// K2 proper: a workgroup per WAVES * 64 consecutive restart intervals of one scan.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void huffman_decode_kernel(const uint8_t *__restrict__ udata,
+                                                                    const DevScan *__restrict__ scans,
+                                                                    const HuffWork *__restrict__ work,
+                                                                    const uint32_t *__restrict__ ends_u,
+                                                                    DevScanStatus *__restrict__ status,
+                                                                    const DevHuffTable *__restrict__ huff_pool,
+                                                                    int16_t *__restrict__ coefs, int n_slots,
+                                                                    const uint8_t *__restrict__ lut_pool, uint32_t tab_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *tabs = smem;                  // tab_bytes: the batch's largest set of staged tables
+    uint8_t *wave_all = smem + tab_bytes;  // WAVES * kK2WaveBytes
+    uint32_t *blk_info = reinterpret_cast<uint32_t *>(wave_all + WAVES * kK2WaveBytes);  // [kMaxBlocksPerMcu]
+    const HuffWork wk = work[blockIdx.x];
+    const DevScan &s = scans[wk.scan];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long k2_t0 = K2_TICK();
+    // stage this scan's Huffman tables (ref: InitDecodeComponents resolves them per scan, JpegHuffmanScanDecoder.cs:63-64)
+    k2_stage_scan_tables(s, lut_pool, tabs, blk_info, n_slots, 64 * WAVES);
+    uint8_t *stage = wave_all + wave * kK2WaveBytes;
+    uint8_t *ring = stage + 8192 + lane * kK2RingStride;
+    {
+        const uint4 z = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(stage)[i * 64 + lane] = z;
+    }
+    __syncthreads();
+    k2_wave(udata, s, wk.scan, wk.first_interval + wave * 64, ends_u, status, coefs, tabs, blk_info, stage, ring, lane, k2_t0);
+}
+
+// POOL (round 6; the K2S final pass has had it since round 5).  Runs of consecutive scans that stage the same tables in the same slots
+// -- every batch of files from one encoder -- need no workgroup per WAVES * 64 intervals of ONE scan: one workgroup per CU stages the
+// tables once and every WAVE takes the next 64 intervals of the run from a counter until there are none.  No wave waits for a slower one
+// of its workgroup before the CU gets new work, nothing is restaged (a workgroup of the plain form lives for 24 block steps), and the
+// last workgroup of a scan is no longer half empty (8 100 intervals = 11.5 workgroups of 704).  The counter is never cleared: a launch
+// draws n_chunks + (waves launched) tickets -- every wave exactly one beyond the end -- and the host passes the sum of the launches before.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void huffman_pool_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
+                                                                  const HuffWork *__restrict__ work, uint32_t n_chunks,
+                                                                  uint32_t *__restrict__ counter, uint32_t ticket_base,
+                                                                  const uint32_t *__restrict__ ends_u, DevScanStatus *__restrict__ status,
+                                                                  int16_t *__restrict__ coefs, int n_slots, const uint8_t *__restrict__ lut_pool,
+                                                                  uint32_t tab_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *tabs = smem;
+    uint8_t *wave_all = smem + tab_bytes;
+    uint32_t *blk_info = reinterpret_cast<uint32_t *>(wave_all + WAVES * kK2WaveBytes);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long k2_t0 = K2_TICK();
+    k2_stage_scan_tables(scans[work[0].scan], lut_pool, tabs, blk_info, n_slots, 64 * WAVES);  // (every entry of `work` stages the same)
+    uint8_t *stage = wave_all + wave * kK2WaveBytes;
+    uint8_t *ring = stage + 8192 + lane * kK2RingStride;
+    {
+        const uint4 z = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(stage)[i * 64 + lane] = z;
+    }
+    __syncthreads();
+    for (;;) {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(counter, 1u) - ticket_base;
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        if (c >= n_chunks) break;
+        const HuffWork wk = work[c];
+        k2_wave(udata, scans[wk.scan], wk.scan, wk.first_interval, ends_u, status, coefs, tabs, blk_info, stage, ring, lane, k2_t0);
+    }
+}
 
 static size_t k2_lds_bytes(uint32_t tab_bytes, int waves) { return (size_t)tab_bytes + (size_t)waves * kK2WaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t); }
 
@@ -292,6 +334,36 @@ hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan
         JPGPU_K2_CASE(8);
     default:
         JPGPU_K2_CASE(7);  // (eight AC tables)
+    }
+#undef JPGPU_K2_CASE
+}
+
+template <int WAVES>
+static hipError_t launch_huffman_pool_w(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_chunks, uint32_t *counter,
+                                        uint32_t ticket_base, int groups, const uint32_t *ends, DevScanStatus *status, int16_t *coefs, int n_slots,
+                                        const uint8_t *lut_pool, uint32_t tab_bytes) {
+    const size_t lds = k2_lds_bytes(tab_bytes, WAVES);
+    static std::atomic<uint64_t> configured{0};
+    const hipError_t ea = allow_dynamic_lds(reinterpret_cast<const void *>(&huffman_pool_kernel<WAVES>), 160 * 1024, configured);
+    if (ea != hipSuccess) return ea;
+    hipLaunchKernelGGL((huffman_pool_kernel<WAVES>), dim3(groups), dim3(64 * WAVES), lds, stream, data, scans, work, (uint32_t)n_chunks, counter, ticket_base,
+                       ends, status, coefs, n_slots, lut_pool, tab_bytes);
+    return hipGetLastError();
+}
+// One pooled run: `work` = its n_chunks entries (scan, first interval) of 64 intervals each, all staging the same tables; `groups`
+// workgroups of huffman_waves(tab_bytes) waves; draws n_chunks + groups * waves tickets from *counter, the first of them ticket_base.
+hipError_t launch_huffman_pool(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_chunks, uint32_t *counter,
+                               uint32_t ticket_base, int groups, const uint32_t *ends, DevScanStatus *status, int16_t *coefs, int n_slots,
+                               const uint8_t *lut_pool, uint32_t tab_bytes) {
+    if (n_chunks <= 0 || groups <= 0) return hipSuccess;
+#define JPGPU_K2_CASE(W) case W: return launch_huffman_pool_w<W>(stream, data, scans, work, n_chunks, counter, ticket_base, groups, ends, status, coefs, n_slots, lut_pool, tab_bytes)
+    switch (huffman_waves(tab_bytes)) {
+        JPGPU_K2_CASE(11);
+        JPGPU_K2_CASE(10);
+        JPGPU_K2_CASE(9);
+        JPGPU_K2_CASE(8);
+    default:
+        JPGPU_K2_CASE(7);
     }
 #undef JPGPU_K2_CASE
 }

@@ -56,6 +56,13 @@ hipError_t launch_marker_onepass(hipStream_t stream, const uint8_t *data, const 
 hipError_t launch_huffman(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_work,
                           const uint32_t *ends, DevScanStatus *status, const DevHuffTable *huff_pool, int16_t *coefs,
                           int n_slots, const uint8_t *lut_pool, uint32_t tab_bytes);
+// One pooled run of K2 (huffman_pool_kernel): `work` = its n_chunks entries (scan, first interval) of 64 intervals each, all staging the
+// same tables; `groups` workgroups of huffman_waves(tab_bytes) waves each draw from *counter, which is never cleared: the launch takes
+// n_chunks + groups * waves tickets, the first of them ticket_base (the sum of the earlier launches' draws).
+constexpr int kK2MaxPools = 8;
+hipError_t launch_huffman_pool(hipStream_t stream, const uint8_t *data, const DevScan *scans, const HuffWork *work, int n_chunks, uint32_t *counter,
+                               uint32_t ticket_base, int groups, const uint32_t *ends, DevScanStatus *status, int16_t *coefs, int n_slots,
+                               const uint8_t *lut_pool, uint32_t tab_bytes);
 // lut_pool: kLutPoolBytesPerTable per pool table, filled by launch_lut_pool (K2 and the K2S round kernel copy from it)
 hipError_t launch_lut_pool(hipStream_t stream, const DevHuffTable *huff_pool, int n_tables, uint8_t *lut_pool);
 constexpr int kNumIdctLayoutClasses = 6;
