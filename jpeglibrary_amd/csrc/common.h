@@ -101,7 +101,8 @@ struct alignas(16) DevScan {
     uint32_t last_interval;    // progressive_scan_kernel: restart intervals behind this one are not decoded (0xFFFFFFFF: all; the
                                // replay of a failed file stops where the reference threw)
     uint32_t first_scan;       // sequential scans: the image's first scan job (K3: a scan behind a failed one was never started)
-    uint32_t pad2[2];
+    uint32_t sr_set;           // DRI = 0 scans: index of the scan's set of round-kernel lookups (built once per upload: sr_lut_build_kernel)
+    uint32_t pad2;
 };
 constexpr uint32_t kNoDep = 0xFFFFFFFFu;
 // Sequential scans: DevScanStatus::pad[1] = kFailBlockBase - (index, in scan order, of the block the reference threw in), 0 = the

@@ -303,6 +303,7 @@ class DeviceBatch {
     int n_chunk_work_ = 0;
     DevBuffer d_unstuffed_, d_ends_u_;  // K1 output: entropy data as the bit reader sees it + interval ends in it
     DevBuffer d_input_, d_scans_, d_status_, d_ends_, d_huff_pool_, d_quant_pool_, d_huff_work_, d_idct_work_, d_coefs_, d_out_, d_k2_tickets_;
+    DevBuffer d_sr_luts_, d_sr_set_scan_;  // K2S round kernel: its lookups per distinct set of tables (kSrLutSetBytes each), and a scan that stages each set
     // stage events of every decode() since the last stage_ms() query (4 events per decode)
     std::vector<hipEvent_t> ev_pool_;
     size_t ev_used_ = 0;

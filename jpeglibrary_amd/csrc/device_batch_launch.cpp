@@ -75,7 +75,7 @@ int DeviceBatch::run_huffman() {
                                  &last_subseq_rounds_, (const uint8_t *)d_lut_pool_.ptr, (const HuffWork *)d_sub_final_work_.ptr, n_sub_final_work_,
                                  (uint32_t *)d_sub_same_.ptr, &sub_same_valid_, device_rounds, (const HuffWork *)d_sub_work_.ptr + n_sub_work_, n_sub_gather_,
                                  (const HuffWork *)d_sub_final_work_.ptr + n_sub_final_work_, sub_pools_.data(), (int)sub_pools_.size(), ctx_->num_cus,
-                                 (uint32_t *)d_sub_perm_.ptr, sub_final_spl_, k2_tab_bytes_);
+                                 (uint32_t *)d_sub_perm_.ptr, sub_final_spl_, k2_tab_bytes_, (const uint8_t *)d_sr_luts_.ptr);
         if (e != hipSuccess) return hip_fail(e, "subsequence decode");
     }
     const int rc = run_progressive();
@@ -94,7 +94,7 @@ int DeviceBatch::run_subseq_sync(const uint32_t **final_state, const uint32_t **
                                       (uint32_t *)d_sub_entry_.ptr, d_sub_dcsum_.ptr, d_sub_dcentry_.ptr, (uint32_t *)d_sub_changed_.ptr,
                                       n_huff_slots_, (int)max_subs_per_scan_ + 2, &last_subseq_rounds_, (const uint8_t *)d_lut_pool_.ptr,
                                       final_state, (uint32_t *)d_sub_same_.ptr, &sub_same_valid_, 0 /* host-checked: the optimizer waits for the host's table build anyway */,
-                                      (const HuffWork *)d_sub_work_.ptr + n_sub_work_, n_sub_gather_);
+                                      (const HuffWork *)d_sub_work_.ptr + n_sub_work_, n_sub_gather_, (const uint8_t *)d_sr_luts_.ptr);
     if (e != hipSuccess) return hip_fail(e, "subsequence synchronisation");
     return mark_work();
 }

@@ -508,6 +508,15 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         huff_work.insert(huff_work.end(), pooled.begin(), pooled.end());  // (one buffer: the pooled list behind the plain one)
     }
     for (uint32_t &b : k2_ticket_base_) b = 0;
+    // The K2S round kernel's lookups: one set per distinct set of tables among the DRI = 0 scans (one for a batch from one encoder),
+    // built once per upload (sr_lut_build_kernel) -- the workgroups of every round built them themselves until round 6.
+    std::vector<uint32_t> sr_set_scan;
+    for (uint32_t j : sub_scan_ids_) {
+        uint32_t k = 0;
+        while (k < sr_set_scan.size() && !same_tables(h_scans_[sr_set_scan[k]], h_scans_[j])) k++;
+        if (k == sr_set_scan.size()) sr_set_scan.push_back(j);
+        h_scans_[j].sr_set = k;
+    }
     n_chunk_work_ = (int)chunk_work.size();
     std::stable_sort(k1_order.begin(), k1_order.end(), [](const ChunkWork &a, const ChunkWork &b) { return a.chunk < b.chunk; });
     n_k1_groups_ = (int)k1_order.size();
@@ -752,7 +761,9 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
         {&d_lut_pool_, nullptr, 0, huff_pool_.size() * kLutPoolBytesPerTable},
         {&d_chunk_sums_, nullptr, 0, (size_t)total_chunks * sizeof(ChunkSum) + 256},
         {&d_k1_tickets_, nullptr, 0, 256},  // [0] the ticket counter, [1] the device's give-up word
-        {&d_k2_tickets_, nullptr, 0, 256},  // K2's pooled runs: a ticket counter each (cleared per upload, never between decodes)
+        {&d_k2_tickets_, nullptr, 0, 256},
+        {&d_sr_set_scan_, sr_set_scan.data(), sr_set_scan.size() * sizeof(uint32_t), 16},
+        {&d_sr_luts_, nullptr, 0, sr_set_scan.size() * kSrLutSetBytes + 16},  // K2's pooled runs: a ticket counter each (cleared per upload, never between decodes)
         {&d_idct_work_, idct_work.data(), idct_work.size() * sizeof(IdctWork), 0},
         {&d_idct_work_split_, idct_work_split.data(), idct_work_split.size() * sizeof(IdctWork), 0},
         {&d_ends_, nullptr, 0, (size_t)total_ends_ * sizeof(uint32_t) + 256},
@@ -798,6 +809,9 @@ int DeviceBatch::layout_and_upload(const std::vector<const uint8_t *> &file_ptr,
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(K2S control)");
     e = launch_lut_pool(up, (const DevHuffTable *)d_huff_pool_.ptr, (int)huff_pool_.size(), (uint8_t *)d_lut_pool_.ptr);
     if (e != hipSuccess) return hip_fail(e, "lut_pool_kernel");
+    e = launch_sr_luts(up, (const DevScan *)d_scans_.ptr, (const uint32_t *)d_sr_set_scan_.ptr, (int)sr_set_scan.size(), (const uint8_t *)d_lut_pool_.ptr,
+                       (uint8_t *)d_sr_luts_.ptr);
+    if (e != hipSuccess) return hip_fail(e, "sr_lut_build_kernel");
     if (!files_resident_) {
         // single scan jobs / frames handed over by the decoder mirror: small, copied as they are
         // slack before the first file and after the last one is read by the kernels' wide loads: keep it defined

@@ -379,6 +379,41 @@ __device__ __forceinline__ void sr_decode_lane(const uint8_t *__restrict__ udata
 // lanes and decodes those: a tenth of the waves, dense ones, and waves without a lane leave.  (Per-scan work LISTS built by
 // the round before, tried in round 4, were slower: the lists' atomics and a second launch shape; here nothing leaves the
 // workgroup.)  1.46 + 0.73 + 0.20 + 0.14 ms per 1024 x 4K for rounds 2-5 before.
+// The round kernel's lookups of ONE set of tables (a DRI = 0 scan's: `set_scan[blockIdx.y]` is a scan that stages the set), slot
+// blockIdx.x: kSrLutBits-bit u32 entries out of the pooled 11-bit ones (sr_entry), once per upload.
+__global__ __launch_bounds__(256) void sr_lut_build_kernel(const DevScan *__restrict__ scans, const uint32_t *__restrict__ set_scan,
+                                                           const uint8_t *__restrict__ lut_pool, uint8_t *__restrict__ sr_luts) {
+    constexpr int LB = kSrLutBits;
+    const DevScan &s = scans[set_scan[blockIdx.y]];
+    const int sl = (int)blockIdx.x;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(sr_luts + (((size_t)blockIdx.y * kMaxHuffSlots + sl) << (LB + 2)));
+    const uint32_t pi = s.huff_pool[sl];
+    if (pi == 0xFFFF) return;
+    bool is_dc = false;
+    for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
+    // (the pool's u16 images: AC at the table's base, DC behind it; the u32 images of K2 / the final pass follow)
+    const uint16_t *src = reinterpret_cast<const uint16_t *>(lut_pool + (size_t)pi * kLutPoolBytesPerTable + (is_dc ? kK2TabBytes : 0u));
+    // (a DC table's partner: the one AC table of every component that uses it)
+    const uint16_t *src_ac = nullptr;
+    if (is_dc) {
+        uint32_t ac_pi = 0xFFFFFFFFu;
+        bool one = true;
+        for (int c = 0; c < s.scan_components; c++)
+            if (s.comp[c].dc_slot == sl) {
+                const uint32_t a = s.comp[c].ac_slot < kMaxHuffSlots ? s.huff_pool[s.comp[c].ac_slot] : 0xFFFFu;
+                one &= ac_pi == 0xFFFFFFFFu || ac_pi == a;
+                ac_pi = a;
+            }
+        if (one && ac_pi < 0xFFFFu) src_ac = reinterpret_cast<const uint16_t *>(lut_pool + (size_t)ac_pi * kLutPoolBytesPerTable);
+    }
+    for (uint32_t i = threadIdx.x; i < (1u << LB); i += 256) dst[i] = sr_entry<LB>(src, i, is_dc, src_ac);
+}
+hipError_t launch_sr_luts(hipStream_t stream, const DevScan *scans, const uint32_t *set_scan, int n_sets, const uint8_t *lut_pool, uint8_t *sr_luts) {
+    if (n_sets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sr_lut_build_kernel, dim3(kMaxHuffSlots, n_sets), dim3(256), 0, stream, scans, set_scan, lut_pool, sr_luts);
+    return hipGetLastError();
+}
+
 constexpr uint32_t kSrGatherSpan = kSubseqGatherSpan;
 template <bool GATHER>
 __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__restrict__ udata, const DevScan *__restrict__ scans,
@@ -388,7 +423,8 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
                                                             const uint32_t *__restrict__ exit_in, uint32_t *__restrict__ exit_out,
                                                             uint32_t *__restrict__ nblk_out, uint32_t *__restrict__ entry_used,
                                                             int4 *__restrict__ dcsum_out, uint32_t *__restrict__ changed, int round,
-                                                            int n_slots, uint32_t warm_bits, const uint32_t *__restrict__ prev_changed) {
+                                                            int n_slots, uint32_t warm_bits, const uint32_t *__restrict__ prev_changed,
+                                                            const uint8_t *__restrict__ sr_luts) {
     constexpr int LB = kSrLutBits;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // Device-side convergence (round 5): the rounds are enqueued ahead without the host looking at anything; once a round
@@ -456,30 +492,20 @@ __global__ __launch_bounds__(256) void subseq_round_kernel(const uint8_t *__rest
         need = false;
     }
 
-    // ---- stage: lookups, the reference's small arrays (long codes), block info
+    // ---- stage: lookups (round 6: built once per upload for every distinct set of tables -- sr_lut_build_kernel -- and copied here; the
+    // workgroups of a round built them themselves before, 4 096 entries each, a chain of dependent loads per DC entry: a fifth to two
+    // fifths of a round kernel's time), the reference's small arrays (long codes), block info
+    {
+        const uint4 *set = reinterpret_cast<const uint4 *>(sr_luts + ((size_t)s.sr_set * kMaxHuffSlots << (LB + 2)));
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = tid; i < ((uint32_t)n_slots << (LB + 2)) / 16u; i += 256) dst[i] = set[i];
+    }
     for (int sl = 0; sl < kMaxHuffSlots && sl < n_slots; sl++) {
         const uint32_t pi = s.huff_pool[sl];
         if (pi == 0xFFFF) continue;
         bool is_dc = false;
         for (int c = 0; c < s.scan_components; c++) is_dc |= s.comp[c].dc_slot == sl;
-        // (the pool's u16 images: AC at the table's base, DC behind it; the u32 images of K2 / the final pass follow)
-        const uint16_t *src = reinterpret_cast<const uint16_t *>(lut_pool + (size_t)pi * kLutPoolBytesPerTable + (is_dc ? kK2TabBytes : 0u));
         if (tid == 0) pool_off[sl] = (uint32_t)((size_t)pi * kLutPoolBytesPerTable + (is_dc ? kK2TabBytes : 0u));
-        // (a DC table's partner: the one AC table of every component that uses it)
-        const uint16_t *src_ac = nullptr;
-        if (is_dc) {
-            uint32_t ac_pi = 0xFFFFFFFFu;
-            bool one = true;
-            for (int c = 0; c < s.scan_components; c++)
-                if (s.comp[c].dc_slot == sl) {
-                    const uint32_t a = s.comp[c].ac_slot < kMaxHuffSlots ? s.huff_pool[s.comp[c].ac_slot] : 0xFFFFu;
-                    one &= ac_pi == 0xFFFFFFFFu || ac_pi == a;
-                    ac_pi = a;
-                }
-            if (one && ac_pi < 0xFFFFu) src_ac = reinterpret_cast<const uint16_t *>(lut_pool + (size_t)ac_pi * kLutPoolBytesPerTable);
-        }
-        uint32_t *dst = reinterpret_cast<uint32_t *>(smem) + ((size_t)sl << LB);
-        for (uint32_t i = tid; i < (1u << LB); i += 256) dst[i] = sr_entry<LB>(src, i, is_dc, src_ac);
         const uint4 *ssrc = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(&huff_pool[pi]) + offsetof(DevHuffTable, maxcode));
         uint4 *sdst = reinterpret_cast<uint4 *>(smem + small_off + sl * kK2SmallBytes);
         if (tid < kK2SmallBytes / 16) sdst[tid] = ssrc[tid];
@@ -1118,7 +1144,7 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
                               const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                               uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int n_slots, int max_rounds,
                               int *rounds_used, const uint8_t *lut_pool, const uint32_t **final_state_out, uint32_t *same_dist,
-                              bool *same_valid, int device_rounds, const HuffWork *gather_work, int n_gather) {
+                              bool *same_valid, int device_rounds, const HuffWork *gather_work, int n_gather, const uint8_t *sr_luts) {
     *final_state_out = exit_a;
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const size_t lds_round = ((size_t)n_slots << (kSrLutBits + 2)) + (size_t)n_slots * kK2SmallBytes + kMaxBlocksPerMcu * 16 + 256 * (kSrRingStride + 16) +
@@ -1149,10 +1175,10 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
     auto launch_round = [&](int r, uint32_t *count, const uint32_t *prev) {
         if (r >= 2 && gather_work != nullptr && n_gather > 0 && !no_gather)
             hipLaunchKernelGGL(subseq_round_kernel<true>, dim3(n_gather), dim3(256), lds_round, stream, udata, scans, gather_work, ends_u, status, huff_pool,
-                               lut_pool, bufs[(r + 1) & 1], bufs[r & 1], nblk, entry_used, (int4 *)dcsum, count, r, n_slots, warm_bits, prev);
+                               lut_pool, bufs[(r + 1) & 1], bufs[r & 1], nblk, entry_used, (int4 *)dcsum, count, r, n_slots, warm_bits, prev, sr_luts);
         else
             hipLaunchKernelGGL(subseq_round_kernel<false>, dim3(n_work), dim3(256), lds_round, stream, udata, scans, work, ends_u, status, huff_pool,
-                               lut_pool, bufs[(r + 1) & 1], bufs[r & 1], nblk, entry_used, (int4 *)dcsum, count, r, n_slots, warm_bits, prev);
+                               lut_pool, bufs[(r + 1) & 1], bufs[r & 1], nblk, entry_used, (int4 *)dcsum, count, r, n_slots, warm_bits, prev, sr_luts);
     };
     int round = 0;
     if (device_rounds > 0) {
@@ -1227,13 +1253,13 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work,
                                 uint32_t *same_dist, bool *same_valid, int device_rounds, const HuffWork *gather_work, int n_gather,
                                 const HuffWork *pool_work, const SubseqPool *pools, int n_pools, int num_cus, uint32_t *lane_perm, int subs_per_lane,
-                                uint32_t tab_bytes) {
+                                uint32_t tab_bytes, const uint8_t *sr_luts) {
     if (n_work <= 0 || n_scans <= 0) return hipSuccess;
     const uint32_t spl = subs_per_lane >= 2 ? 2u : 1u;
     const uint32_t *final_state = nullptr;
     hipError_t e = launch_subseq_sync(stream, udata, scans, work, n_work, scan_ids, n_scans, ends_u, status, huff_pool, exit_a, exit_b, nblk,
                                       first_block, entry_used, dcsum, dc_entry, changed_dev, n_slots, max_rounds, rounds_used, lut_pool,
-                                      &final_state, same_dist, same_valid, device_rounds, gather_work, n_gather);
+                                      &final_state, same_dist, same_valid, device_rounds, gather_work, n_gather, sr_luts);
     if (e != hipSuccess) return e;
     static std::atomic<uint64_t> configured{0}, configured_pool{0};
 #ifdef JPGPU_SF_NO_ORDER  // (A/B build variant)

@@ -96,7 +96,15 @@ hipError_t launch_subseq_decode(hipStream_t stream, const uint8_t *udata, const 
                                 int max_rounds, int *rounds_used, const uint8_t *lut_pool, const HuffWork *final_work, int n_final_work,
                                 uint32_t *same_dist, bool *same_valid, int device_rounds, const HuffWork *gather_work, int n_gather,
                                 const HuffWork *pool_work, const SubseqPool *pools, int n_pools, int num_cus, uint32_t *lane_perm, int subs_per_lane,
-                                uint32_t tab_bytes);
+                                uint32_t tab_bytes, const uint8_t *sr_luts);
+#ifndef JPGPU_SR_LB
+#define JPGPU_SR_LB 10
+#endif
+constexpr int kSrLutBits = JPGPU_SR_LB;  // lookup width of the K2S round kernel (a 10-bit prefix decides codes of up to 10 bits)
+constexpr size_t kSrLutSetBytes = (size_t)kMaxHuffSlots << (kSrLutBits + 2);
+// sr_luts: the round kernel's lookups, kMaxHuffSlots << (kSrLutBits + 2) bytes per distinct set of tables among the DRI = 0 scans
+// (DevScan::sr_set), built once per upload behind launch_lut_pool; set_scan[k] = a scan that stages set k
+hipError_t launch_sr_luts(hipStream_t stream, const DevScan *scans, const uint32_t *set_scan, int n_sets, const uint8_t *lut_pool, uint8_t *sr_luts);
 // subs_per_lane: subsequences a lane of the final pass takes (the work lists are built for it): kSubFinalSubsPerLane for batches that
 // fill the machine, 1 below kSubFinalFewSubs subsequences in the batch (a lone 67-Mpixel canvas: twice the waves, half as long each)
 constexpr uint64_t kSubFinalFewSubs = 1u << 20;
@@ -158,7 +166,7 @@ hipError_t launch_subseq_sync(hipStream_t stream, const uint8_t *udata, const De
                               const DevHuffTable *huff_pool, uint32_t *exit_a, uint32_t *exit_b, uint32_t *nblk, uint32_t *first_block,
                               uint32_t *entry_used, void *dcsum, void *dc_entry, uint32_t *changed_dev, int n_slots, int max_rounds,
                               int *rounds_used, const uint8_t *lut_pool, const uint32_t **final_state_out, uint32_t *same_dist, bool *same_valid,
-                              int device_rounds, const HuffWork *gather_work, int n_gather);
+                              int device_rounds, const HuffWork *gather_work, int n_gather, const uint8_t *sr_luts);
 // gather_work: (scan, first subsequence) per kSubseqGatherSpan subsequences -- the work list of the rounds behind round 1
 // (same_dist: one uint32 per subsequence, *same_valid: "filled for this upload" -- the flat-region twins, k2s_subseq.hip)
 hipError_t launch_subseq_transcode(hipStream_t stream, int mode, const uint8_t *udata, const DevScan *scans, const HuffWork *work, int n_work,

@@ -533,10 +533,6 @@ __device__ __forceinline__ uint32_t k2_symbol_any(uint8_t *ring, K2Feed &f, K2Po
 // The K2 family's lookups (format above) for every table of the pool, as a DC table (odd blocks) and as an AC table.
 // Image (table * 2 + is_dc) * kK2TabBytes: L1 | L2 | header.
 constexpr int kLutPoolBits = kK2LutBits;
-#ifndef JPGPU_SR_LB
-#define JPGPU_SR_LB 10
-#endif
-constexpr int kSrLutBits = JPGPU_SR_LB;  // lookup width of the round kernel (a 10-bit prefix decides codes of up to 10 bits)
 __device__ __forceinline__ uint32_t k2_entry_of(const DevHuffTable &h, uint32_t code16, bool is_dc, uint32_t max_size) {
     // the reference's Lookup on these 16 bits (JpegHuffmanDecodingTable.cs:73-113): first-level table, then the maxcode walk
     const uint32_t e9 = h.lut[code16 >> (16 - kHuffLutBits)];
