@@ -913,17 +913,32 @@ __global__ __launch_bounds__(1024) void subseq_order_kernel(const DevScan *__res
     if (in_range) perm[s.sub_off + wk.first_interval / spl + base[key] + rank_in_key] = lane_index;
 }
 
+#ifdef JPGPU_K2_PROFILE  // per-wave cycle counters of the final pass (tools/trace/k2_phases.py dri0): [0] waves, [1] open + skip, [2] decode, [3] top-up, [4] flush, [5] total, [6] block steps, [7] lane-blocks
+__device__ unsigned long long sf_prof[8];
+#define SF_TICK() __builtin_readcyclecounter()
+#define SF_PROF_ADD(i, v) do { if (lane == 0) atomicAdd(&sf_prof[i], (unsigned long long)(v)); } while (0)
+extern "C" int jpgpu_debug_sf_profile(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sf_prof), sizeof(sf_prof)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(sf_prof), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
+}
+#else
+#define SF_TICK() 0ull
+#define SF_PROF_ADD(i, v) do { (void)(v); } while (0)
+#endif
 constexpr int kSubFinalMaxWaves = JPGPU_SF_WAVES > kSubFinalPoolWaves ? JPGPU_SF_WAVES : kSubFinalPoolWaves;  // the launch picks subseq_final_waves(n_slots) / the pool's
-constexpr int kSfWaveBytes = kK2WaveBytes + 64 * 2 * (int)sizeof(uint32_t);
-static_assert(kSfWaveBytes == (int)kSfWaveLdsBytes && kSubFinalPoolWaves == 10, "kernels.h: subseq_pool_fits");  // K2's staging + rings, then (first MCU, count) per lane
+constexpr int kSfWaveBytes = kK2WaveBytes;
+static_assert(kSfWaveBytes == (int)kSfWaveLdsBytes && kSubFinalPoolWaves == 11, "kernels.h: subseq_pool_fits");  // K2's staging + rings
 // One wave's 64 lanes: subsequences wk.first_interval + lane * kSubFinalSubsPerLane .. of scan wk.scan (tables staged, the wave's
 // coefficient staging zero on entry and on exit).
 __device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const DevScan &s, const DevScanStatus &st, const HuffWork wk,
                                         const uint32_t *__restrict__ ends_u, DevScanStatus *__restrict__ status,
                                         const uint32_t *__restrict__ exit_state, const uint32_t *__restrict__ first_block,
                                         const int4 *__restrict__ dc_entry, int16_t *__restrict__ coefs, const uint8_t *tabs,
-                                        const uint32_t *blk_info, uint8_t *stage, uint8_t *ring, uint32_t *meta, uint32_t lane,
+                                        const uint32_t *blk_info, uint8_t *stage, uint8_t *ring, uint32_t lane,
                                         const uint32_t *__restrict__ perm, uint32_t spl) {
+    const unsigned long long sf_t0 = SF_TICK();
+    unsigned long long sf_dec = 0, sf_top = 0, sf_fl = 0;
     const uint32_t ulen = ends_u[s.ends_off];
     const uint32_t total_bits = ulen * 8;
     // a lane takes kSubFinalSubsPerLane consecutive subsequences: half the lanes, but half the parsed-not-stored blocks and a
@@ -943,8 +958,6 @@ __device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const
     uint32_t b_in_mcu = (entry >> 6) & 31u;
     uint32_t i2 = ((entry >> 11) & 127u) * 2u;  // 2 x zig-zag position inside the block in progress at the entry
     const uint32_t count = my_end - my_first;
-    meta[lane * 2] = my_first;
-    meta[lane * 2 + 1] = count;
     const uint32_t wave_count = wave_reduce_max_i((int32_t)count);
 
     const bool decodes = live && count != 0;
@@ -1006,9 +1019,11 @@ __device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const
     k2_topup(ring, feed, pos.pm1);
     uint8_t *my_stage = stage + lane * 128;
     const uint32_t swz16 = ((lane >> 1) & 7u) << 4;
+    const unsigned long long sf_t1 = SF_TICK();
 
     for (uint32_t j = 0; j < wave_count; j++) {
         for (uint32_t b = 0; b < bpm; b++) {
+            const unsigned long long sf_a = SF_TICK();
             const uint32_t bi = __builtin_amdgcn_readfirstlane(blk_info[b]);  // wave-uniform
             const uint32_t ci = bi & 0xFFu;
             const K2Tab hdc = k2_tab_dc(tabs, bi);
@@ -1042,7 +1057,9 @@ __device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const
                 if (err != 0)
                     atomicMax(&status[wk.scan].pad[1], fail_block_word(((uint64_t)my_first + j) * bpm + b));
             }
+            const unsigned long long sf_b = SF_TICK();
             k2_topup(ring, feed, pos.pm1);
+            const unsigned long long sf_c = SF_TICK();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1054,14 +1071,29 @@ __device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const
                 const uint4 v = *src;
                 const uint4 z = {0, 0, 0, 0};
                 *src = z;
-                const uint32_t owner_first = meta[blk * 2], owner_count = meta[blk * 2 + 1];
+                // (round 6: the owner's first MCU and count come through the lane crossbar -- ds_bpermute, no storage -- where an LDS table of
+                // 512 bytes per wave held them: the eleventh wave of the pooled workgroup fits)
+                const uint32_t owner_first = (uint32_t)__shfl((int)my_first, (int)blk, 64), owner_count = (uint32_t)__shfl((int)count, (int)blk, 64);
                 if (j < owner_count) *reinterpret_cast<uint4 *>(coefs + (coef_off + ((uint64_t)owner_first + j) * bpm + b) * 64 + chunk * 8) = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned long long sf_d = SF_TICK();
+            sf_dec += sf_b - sf_a;
+            sf_top += sf_c - sf_b;
+            sf_fl += sf_d - sf_c;
         }
     }
+    SF_PROF_ADD(0, 1);
+    SF_PROF_ADD(1, sf_t1 - sf_t0);
+    SF_PROF_ADD(2, sf_dec);
+    SF_PROF_ADD(3, sf_top);
+    SF_PROF_ADD(4, sf_fl);
+    SF_PROF_ADD(5, SF_TICK() - sf_t0);
+    SF_PROF_ADD(6, (unsigned long long)wave_count * bpm);
+    const uint32_t sf_lane_blocks = wave_sum(count) * bpm;
+    SF_PROF_ADD(7, sf_lane_blocks);
     if (live && err != 0) {
         // failure on the true path: same detail codes as the interval decoder; "interval" field carries the subsequence
         atomicMin(&status[wk.scan].first_error, (sub << 8) | err);
@@ -1101,7 +1133,6 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t *stage = wave_all + wave * kSfWaveBytes;
     uint8_t *ring = stage + 8192 + lane * kK2RingStride;
-    uint32_t *meta = reinterpret_cast<uint32_t *>(stage + kK2WaveBytes);
     {
         const uint4 z = {0, 0, 0, 0};
 #pragma unroll
@@ -1110,7 +1141,7 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
     __syncthreads();
     if (!POOL) {
         const HuffWork wk = {wk0.scan, wk0.first_interval + wave * 64u * spl};
-        sf_wave(udata, scans[wk.scan], status[wk.scan], wk, ends_u, status, exit_state, first_block, dc_entry, coefs, tabs, blk_info, stage, ring, meta, lane, perm, spl);
+        sf_wave(udata, scans[wk.scan], status[wk.scan], wk, ends_u, status, exit_state, first_block, dc_entry, coefs, tabs, blk_info, stage, ring, lane, perm, spl);
     } else {
         for (;;) {
             uint32_t c = 0;
@@ -1120,7 +1151,7 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
             const HuffWork wk = work[c];
             const DevScanStatus st = status[wk.scan];
             if (st.n_ends == 0) continue;
-            sf_wave(udata, scans[wk.scan], st, wk, ends_u, status, exit_state, first_block, dc_entry, coefs, tabs, blk_info, stage, ring, meta, lane, perm, spl);
+            sf_wave(udata, scans[wk.scan], st, wk, ends_u, status, exit_state, first_block, dc_entry, coefs, tabs, blk_info, stage, ring, lane, perm, spl);
         }
     }
 }

@@ -82,7 +82,7 @@ hipError_t launch_ycc_to_rgb(hipStream_t stream, const uint8_t *src, uint8_t *ds
 // Waves per workgroup of the POOLED form of the K2S final pass (k2s_subseq.hip: runs of scans that stage the same tables; one workgroup per CU, every wave takes the
 // next 64 lanes from a counter): 10 waves + 4 tables fill a CU's LDS.  Runs shorter than kSubFinalPoolMinChunks waves, and runs
 // beyond the kSubFinalMaxPools-th, take the plain form.
-constexpr int kSubFinalPoolWaves = 10, kSubFinalPoolMinChunks = 40, kSubFinalMaxPools = 8;
+constexpr int kSubFinalPoolWaves = 11, kSubFinalPoolMinChunks = 40, kSubFinalMaxPools = 8;
 constexpr int kSubseqCtlPoolCounter = 72;  // changed_dev words [72, 72 + kSubFinalMaxPools): the pools' counters (cleared by every launch)
 struct SubseqPool {
     int first, count;  // entries of the pooled work list (one per wave of 64 lanes)
@@ -121,9 +121,9 @@ constexpr int kSubseqMaxDeviceRounds = 61;  // rounds launch_subseq_decode enque
 #define JPGPU_SF_WAVES 4
 #endif
 constexpr int subseq_final_waves() { return JPGPU_SF_WAVES; }
-// the pooled form (ten waves per workgroup) fits while the staged tables leave room for them
-constexpr uint32_t kSfWaveLdsBytes = kK2WaveLdsBytes + 64 * 2 * 4;
-constexpr bool subseq_pool_fits(uint32_t tab_bytes) { return tab_bytes + 10u * kSfWaveLdsBytes <= kK2LdsBudget; }
+// the pooled form (eleven waves per workgroup since round 6) fits while the staged tables leave room for them
+constexpr uint32_t kSfWaveLdsBytes = kK2WaveLdsBytes;
+constexpr bool subseq_pool_fits(uint32_t tab_bytes) { return tab_bytes + (uint32_t)kSubFinalPoolWaves * kSfWaveLdsBytes <= kK2LdsBudget; }
 // subsequences per lane of the K2S final pass (1: 8.1 ms per 1024 x 4K; 2: see DESIGN.md)
 #ifndef JPGPU_SF_SUBS
 #define JPGPU_SF_SUBS 2
