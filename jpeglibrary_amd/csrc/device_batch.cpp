@@ -69,7 +69,8 @@ namespace {
 
 class PlanHandler final : public ScanHandler {
   public:
-    explicit PlanHandler(std::vector<ScanJob> *jobs, bool first_scan_only = false) : jobs_(jobs), first_scan_only_(first_scan_only) {}
+    explicit PlanHandler(std::vector<ScanJob> *jobs, bool first_scan_only = false, const std::vector<int> *forced = nullptr)
+        : jobs_(jobs), first_scan_only_(first_scan_only), forced_(forced) {}
     // Second walk of a file whose sequential scans are already planned (`ends` = where each one's data stops): nothing is
     // recorded, and scan number `swallow` leaves the reader ONE byte into its terminating marker.  That is where the
     // reference's reader stands when exactly one whole byte was left in the bit reader behind the last block: the marker
@@ -121,8 +122,12 @@ class PlanHandler final : public ScanHandler {
         }
         jobs_->push_back(make_scan_job(dec, geo_, scan, entropy, len, first_scan_only_));
         if (!first_scan_only_) {
+            // (a scan KNOWN to leave one whole byte unread -- the device said so in the batch this plan is made for -- hands the
+            // reader back one byte into its terminating marker, the way the reference's does: DeviceBatch::redo_swallowed)
+            const bool forced = forced_ != nullptr && std::find(forced_->begin(), forced_->end(), (int)ends_.size()) != forced_->end();
             ends_.push_back(find_scan_end(entropy, len));
-            reader.try_advance((int)ends_.back());
+            jobs_->back().forced_swallow = forced && ends_.back() < len;
+            reader.try_advance((int)ends_.back() + (jobs_->back().forced_swallow ? 1 : 0));
             return;
         }
         // leave the reader just before the next non-RST marker, like ProcessScan does (:167-176); the optimizer path only
@@ -150,6 +155,7 @@ class PlanHandler final : public ScanHandler {
     const std::vector<size_t> *replay_ends_ = nullptr;
     int swallow_ = -1, replayed_ = 0;
     bool first_scan_only_ = false;
+    const std::vector<int> *forced_ = nullptr;  // sequential scans (by ordinal) known to leave one byte unread: DeviceBatch::redo_swallowed
     BaselineGeometry geo_, prog_geo_;
     bool prog_geo_valid_ = false;
     ProgressiveFrame prog_;
@@ -262,7 +268,7 @@ void DeviceBatch::plan_file_full(const uint8_t *file, size_t len, int index, Fil
     img.file_len = len;
     bool decoding = false;  // Identify() is over, Decode()'s marker loop is running
     HostDecoder dec;
-    PlanHandler handler(&fp.jobs, entropy_only_);
+    PlanHandler handler(&fp.jobs, entropy_only_, forced_swallow_.empty() ? nullptr : &forced_swallow_);
     try {
         if (len > 0x7FFFFFF0u) throw DecodeError(JPGPU_ERR_NOT_SUPPORTED, "JPEG streams of 2 GiB or more are not supported.");
         dec.set_input(file, len);
@@ -333,8 +339,8 @@ void DeviceBatch::plan_file_headers(const uint8_t *file, size_t len, FilePlan &f
     fp.img = ImagePlan();
     ImagePlan &img = fp.img;
     img.file_len = len;
-    if (entropy_only_ || len > 0x7FFFFFF0u) {
-        fp.need_full = true;  // optimizer walks have rules of their own; oversize files are refused by the full path
+    if (entropy_only_ || len > 0x7FFFFFF0u || !forced_swallow_.empty()) {
+        fp.need_full = true;  // optimizer walks have rules of their own; oversize files are refused by the full path; a re-plan walks the file
         return;
     }
     HostDecoder dec;
@@ -726,6 +732,7 @@ int DeviceBatch::upload_segments(const jpgpu_segment *segments, const int *segme
     rc = layout_and_upload(file_ptr, file_len);
     files_resident_ = false;
     replay_possible_ = rc == JPGPU_OK && !entropy_only_;
+    whole_files_ = rc == JPGPU_OK;  // (redo_swallowed: the files are in d_input_ as they came)
     ingest_.layout_ms = ms_since(t0);
     ingest_.total_ms = ms_since(t_begin);
     return rc;
@@ -931,6 +938,7 @@ int DeviceBatch::verify_plans(const std::vector<FilePlan> &plans, const std::vec
 }
 
 int DeviceBatch::upload_single_job(const ScanJob &job, int format, const void *initial_output, size_t initial_output_bytes) {
+    whole_files_ = false;
     if (format < 0 || format >= kNumOutputFormats) return fail(JPGPU_ERR_ARGUMENT, "unknown format");
     format_ = format;
     images_.assign(1, ImagePlan());
@@ -960,6 +968,7 @@ int DeviceBatch::upload_single_job(const ScanJob &job, int format, const void *i
 }
 
 int DeviceBatch::upload_progressive_frame(const ProgressiveFrame &frame, const uint8_t *file, size_t file_len, int sof, int format) {
+    whole_files_ = false;
     if (format < 0 || format >= kNumOutputFormats) return fail(JPGPU_ERR_ARGUMENT, "unknown format");
     format_ = format;
     images_.assign(1, ImagePlan());
@@ -986,6 +995,7 @@ int DeviceBatch::upload_progressive_frame(const ProgressiveFrame &frame, const u
 }
 
 int DeviceBatch::upload_progressive_scan(const ProgressiveFrame &frame, int scan_index, bool first_scan) {
+    whole_files_ = false;
     if (scan_index < 0 || scan_index >= (int)frame.scans().size()) return fail(JPGPU_ERR_ARGUMENT, "progressive scan index out of range");
     format_ = JPGPU_FMT_INTERLEAVED_U8;  // no samples are produced by a scan; the smallest output layout
     images_.assign(1, ImagePlan());
@@ -1058,6 +1068,7 @@ int DeviceBatch::rerun_failed_progressive_scan(bool first_scan) {
 }
 
 int DeviceBatch::upload_progressive_dispose(const ProgressiveFrame &frame, int format) {
+    whole_files_ = false;
     if (format < 0 || format >= kNumOutputFormats) return fail(JPGPU_ERR_ARGUMENT, "unknown format");
     format_ = format;
     images_.assign(1, ImagePlan());
@@ -1083,6 +1094,7 @@ int DeviceBatch::upload_progressive_dispose(const ProgressiveFrame &frame, int f
 }
 
 int DeviceBatch::upload_frames(const jpgpu_frame *frames, const uint16_t *qt, int n, int format) {
+    whole_files_ = false;
     if (n < 0 || (n > 0 && (!frames || !qt))) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_frames: null argument");
     if (format < 0 || format >= kNumOutputFormats) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_upload_frames: unknown format");
     format_ = format;

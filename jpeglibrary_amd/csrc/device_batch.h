@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -105,6 +106,8 @@ class DeviceBatch {
 
     // Whole files: host parse (Identify + Decode's marker loop) -> plans/jobs -> HBM.
     int upload_files(const uint8_t *const *jpeg, const size_t *len, int n, int format);
+    // (the planner of a one-file batch: sequential scans, by ordinal, that leave their reader one byte into the terminating marker)
+    void set_forced_swallow(const std::vector<int> &ordinals) { forced_swallow_ = ordinals; }
     // The same for files handed over as lists of segments (the ReadOnlySequence<byte> a reference caller passes to SetInput,
     // JpegDecoder.cs:56-62; multi-segment: apps/JpegDecode/MemoryPoolBufferWriter.cs:166-174): file i is the next
     // segments_per_file[i] entries of `segments`.  flags & JPGPU_UPLOAD_PINNED: every segment lies in page-locked memory
@@ -191,6 +194,7 @@ class DeviceBatch {
     hipEvent_t done_ev_ = nullptr;
     bool work_in_flight_ = false;
     int verify_plans(const std::vector<FilePlan> &plans, const std::vector<int> &spec, std::vector<uint32_t> &first);
+    bool whole_files_ = false;     // the last upload was whole files (upload_files / upload_segments): d_input_ holds them as they came
     bool files_resident_ = false;  // layout_and_upload: the files are in d_input_ already (staged by upload_files)
     IngestStats ingest_;
     DevBuffer d_verify_;
@@ -217,6 +221,16 @@ class DeviceBatch {
     std::vector<DevHuffTable> huff_pool_;
     std::vector<DevQuantTable> quant_pool_;
     int n_huff_slots_ = 1;
+    // A MIDDLE sequential scan that left one whole byte unread (round 6): the reference resumes its marker walk one byte into the
+    // terminating marker, so WHICH scans exist behind it depends on the decode.  The file is planned again with that knowledge and decoded
+    // by a batch of its own; its output and result replace the image's (redo_swallowed; cached per image).
+    int redo_swallowed(int i, int job, jpgpu_image_result *res);
+    std::vector<int> forced_swallow_;
+    struct Redo {
+        jpgpu_image_result res;
+        std::string error;
+    };
+    std::map<int, Redo> redo_;
     std::vector<SubseqPool> k2_pools_;          // pooled runs of K2 (round 6): entries of d_huff_work_ behind the first n_huff_work_
     uint32_t k2_ticket_base_[kK2MaxPools] = {};  // tickets the earlier launches of this upload drew from each pool's counter (d_k2_tickets_)
     uint32_t k2_tab_bytes_ = 0;  // LDS of the largest table set a sequential scan of the upload stages (K2, the K2S final pass)

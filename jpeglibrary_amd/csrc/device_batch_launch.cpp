@@ -350,6 +350,7 @@ int DeviceBatch::decode() {
         }
     }
     hipEvent_t *ev = &ev_pool_[ev_used_];
+    redo_.clear();  // (a re-planned image's output is this batch's own plan's again behind this decode)
     in_decode_request_ = true;
     const bool serial = !overlap_ok_ || (decodes_since_query_ % kSerialEvery) == 0;
     decodes_since_query_++;

@@ -188,7 +188,11 @@ int DeviceBatch::result(int i, jpgpu_image_result *res) {
         if (st.decoded_mcus < h_scans_[j].total_mcus) res->detail = kDetailEarlyEoi;
         if (!entropy_only_ && jobs_[j].kind == kScanSequential && st.terminator != 0 && (st.terminator & 0xF8u) != 0xD0u && (st.pad[2] >> 3) == 1 && st.decoded_mcus >= h_scans_[j].total_mcus) {
             // one whole byte left behind the last block: the reference resumes its walk inside the terminating marker
+            if (jobs_[j].forced_swallow) continue;  // (this batch IS the re-plan: the walk behind the scan started there)
             if (j != img->swallow_job) {
+                // a middle scan: which scans exist behind it depends on this.  A batch of whole files plans the file again; the
+                // per-scan entries (one job, no file: the CALLER walks the markers) still refuse
+                if (whole_files_ && img->file_len != 0) return redo_swallowed(i, j, res);
                 res->status = JPGPU_ERR_NOT_SUPPORTED;
                 res->detail = kDetailUnsupportedFrame;
                 ctx_->last_error = "A scan that leaves one byte unread in front of its terminating marker is only supported as the last scan.";
@@ -220,11 +224,67 @@ int DeviceBatch::result(int i, jpgpu_image_result *res) {
     return JPGPU_OK;
 }
 
+// A middle sequential scan of image i (scan job `job`) left one whole byte unread in front of its terminating marker: the reference's
+// reader resumes ONE BYTE INTO that marker (ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:167-176: the marker sits in the bit reader,
+// TryPeekMarker() shows it only when the buffer is empty, the two bytes are not given back), typically steps over the next scan's
+// header and entropy data as fill, and goes on with whatever marker follows.  The plan this batch was laid out from does not hold
+// then.  The file comes back from HBM, is planned again with the scan marked (PlanHandler: the walk continues where the reference's
+// does) and decoded by a batch of its own -- which may find the same of a later scan and do the same --; its output replaces the
+// image's, its result is the image's.  Rare (a corrupted multi-scan baseline file), and decided once per image.
+int DeviceBatch::redo_swallowed(int i, int job, jpgpu_image_result *res) {
+    auto hit = redo_.find(i);
+    if (hit == redo_.end()) {
+        const ImagePlan &img = images_[(size_t)i];
+        int ordinal = 0;
+        for (int j : img.jobs) {
+            if (j == job) break;
+            ordinal += jobs_[j].kind == kScanSequential ? 1 : 0;
+        }
+        std::vector<uint8_t> file(img.file_len);
+        hipError_t e = hipMemcpy(file.data(), (const uint8_t *)d_input_.ptr + img.file_offset, img.file_len, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpy(file of a re-planned image)");
+        Redo r;
+        memset(&r.res, 0, sizeof r.res);
+        {
+            DeviceBatch sub(ctx_);
+            std::vector<int> forced = forced_swallow_;
+            forced.push_back(ordinal);
+            sub.set_forced_swallow(forced);
+            const uint8_t *fptr = file.data();
+            const size_t flen = file.size();
+            int rc = sub.upload_files(&fptr, &flen, 1, format_);
+            if (rc == JPGPU_OK) rc = sub.decode();
+            if (rc == JPGPU_OK) rc = sub.result(0, &r.res);
+            if (rc != JPGPU_OK) return rc;  // (ctx_->last_error says what)
+            r.error = ctx_->last_error;
+            const ImagePlan *si = sub.image(0);
+            if (si && si->status == JPGPU_OK && si->out_bytes == img.out_bytes && img.out_bytes != 0) {
+                e = hipMemcpy((uint8_t *)d_out_.ptr + img.out_offset, (const uint8_t *)sub.d_out_.ptr + si->out_offset, img.out_bytes, hipMemcpyDeviceToDevice);
+                if (e != hipSuccess) return hip_fail(e, "hipMemcpy(output of a re-planned image)");
+            } else if (si && si->status != JPGPU_OK) {  // the re-plan's own host-side verdict (a walk failure in front of any scan cannot happen: scan 0 was planned)
+                r.res.status = si->status;
+                r.res.detail = si->detail;
+                r.error = si->error;
+            }
+        }
+        hit = redo_.emplace(i, std::move(r)).first;
+    }
+    *res = hit->second.res;
+    ctx_->last_error = hit->second.error;
+    return JPGPU_OK;
+}
+
 int DeviceBatch::download_output(int i, void *dst, size_t cap) {
     const ImagePlan *img = image(i);
     if (!img || !dst) return fail(JPGPU_ERR_ARGUMENT, "jpgpu_batch_download_output: bad argument");
     if (img->status != JPGPU_OK) return fail(img->status, img->error);
     if (cap < img->out_bytes) return fail(JPGPU_ERR_ARGUMENT, "Destination buffer is too small.");
+    if (img->jobs.size() > 1 && !entropy_only_ && redo_.find(i) == redo_.end()) {
+        // (several scans: the image's result decides whether its plan held -- redo_swallowed -- whatever the caller asks for first)
+        jpgpu_image_result tmp;
+        const int rr = result(i, &tmp);
+        if (rr != JPGPU_OK) return rr;
+    }
     // (a batch with a failed progressive frame owes its caller the partial flush whatever is asked for first: ADVICE r4)
     int rc = (replay_possible_ && !replay_done_) ? fetch_status() : sync();
     if (rc != JPGPU_OK) return rc;

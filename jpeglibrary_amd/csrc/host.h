@@ -228,6 +228,9 @@ struct ScanJob {
     // the partial flush of a progressive file that failed (DeviceBatch::replay_failed_progressive): scans behind the failing one
     // never ran in the reference (disabled); the failing one runs on the kernel that walks and stores the way the reference does
     bool disabled = false, force_lane = false;
+    // planned as a scan that leaves one whole byte unread in front of its terminating marker (DeviceBatch::redo_swallowed, round 6): the
+    // walk behind it started one byte into that marker
+    bool forced_swallow = false;
     uint32_t last_interval = 0xFFFFFFFFu;  // ... and not behind the restart interval in which it threw
     uint16_t scan_dri = 0;        // DRI as read at ProcessScan time (ref: ...ProgressiveScanDecoder.cs:78), not at SOF
     uint8_t frame_bpm = 0;
