@@ -193,10 +193,10 @@ int DeviceBatch::result(int i, jpgpu_image_result *res) {
                 // a middle scan: which scans exist behind it depends on this.  A batch of whole files plans the file again; the
                 // per-scan entries (one job, no file: the CALLER walks the markers) still refuse
                 if (whole_files_ && img->file_len != 0) return redo_swallowed(i, j, res);
-                res->status = JPGPU_ERR_NOT_SUPPORTED;
-                res->detail = kDetailUnsupportedFrame;
-                ctx_->last_error = "A scan that leaves one byte unread in front of its terminating marker is only supported as the last scan.";
-                return JPGPU_OK;
+                // (one scan handed over by a caller that walks the markers itself -- jpgpu_decode_scan, the decoder mirror: the reader
+                // advance says it, one byte into the terminating marker, and the caller's walk goes on from there like the reference's)
+                res->bytes_consumed = st.end_pos + 1;
+                continue;
             }
             swallowed = true;
         }

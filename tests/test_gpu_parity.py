@@ -1416,6 +1416,23 @@ def test_a_middle_scan_that_leaves_one_byte_unread_is_planned_again():
             assert names[b.result(i).status] == refs[i][0] and np.array_equal(np.asarray(b.output(i)), refs[i][1]), tags[i]
         b.close()
     assert any(t[1] == 1 and t[2] != "eoi" and r[0] == "OK" for t, r in zip(tags, refs))  # (the case exists: the reference decodes on)
+    # ... and through JpegDecoder.Decode() (level 3: one device call per scan, the mirror's own marker walk): the scan's reader advance
+    # ends one byte into the marker, the walk goes on from there
+    for f, t, (kind, px) in zip(files, tags, refs):
+        if t[1] != 1:
+            continue
+        d = jl.JpegDecoder()
+        d.SetInput(f)
+        d.Identify()
+        out = np.zeros(d.Width * d.Height * 3, np.uint8)
+        d.SetOutputWriter(jl.JpegBufferOutputWriter8Bit(d.Width, d.Height, 3, out))
+        try:
+            d.Decode()
+            mine = "OK"
+        except jl.JpegError as e:
+            mine = type(e).__name__
+        assert mine == kind, (t, mine, kind)
+        assert np.array_equal(out.reshape(px.shape), px), t
 
 
 def test_progressive_scan_failures_come_before_later_walk_failures():
