@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_pool_kernel(const uint8_t 
         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
         if (c >= n_chunks) break;
         const HuffWork wk = work[c];
-        k2_wave(udata, scans[wk.scan], wk.scan, wk.first_interval, ends_u, status, coefs, tabs, blk_info, stage, ring, lane, k2_t0);
+        k2_wave(udata, scans[wk.scan], wk.scan, wk.first_interval, ends_u, status, coefs, tabs, blk_info, stage, ring, lane, c == 0 ? k2_t0 : K2_TICK());
     }
 }
 
