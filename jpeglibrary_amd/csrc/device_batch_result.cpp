@@ -235,6 +235,12 @@ int DeviceBatch::redo_swallowed(int i, int job, jpgpu_image_result *res) {
     auto hit = redo_.find(i);
     if (hit == redo_.end()) {
         const ImagePlan &img = images_[(size_t)i];
+        if (forced_swallow_.size() >= 64) {  // (a re-plan of a re-plan of ...: one level per scan of the file; bounded all the same)
+            res->status = JPGPU_ERR_NOT_SUPPORTED;
+            res->detail = kDetailUnsupportedFrame;
+            ctx_->last_error = "More than 64 scans of one file leave a byte unread in front of their terminating markers.";
+            return JPGPU_OK;
+        }
         int ordinal = 0;
         for (int j : img.jobs) {
             if (j == job) break;

@@ -159,8 +159,8 @@ __device__ __forceinline__ void k2_wave(const uint8_t *__restrict__ udata, const
             if (active && err == 0 && mcu < my_mcus) {
                 // ReadBlockBaseline (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:179-222)
                 int32_t v, vb;
-                uint32_t adv = 0, adv_b = 0;
-                err = k2_symbol<true>(ring, feed, pos, endpos, lim, hdc, closed_by_marker, 0u, v, vb, adv, adv_b);
+                uint32_t ia = 0, adv_b = 0;
+                k2_symbol<true>(ring, feed, pos, endpos, lim, hdc, closed_by_marker, 0u, v, vb, ia, adv_b, err);
                 const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
                 v += pred;
                 if (ci == 0) pred0 = v;
@@ -172,12 +172,10 @@ __device__ __forceinline__ void k2_wave(const uint8_t *__restrict__ udata, const
                 while (i2 < 128u) {
                     // one step = one symbol or, where the lookup held two, both (round 6): Math.Min(i++, 63) for a coefficient; EOB /
                     // ZRL store a zero at a position nothing was written to yet; a step of one symbol stores it twice
-                    const uint32_t e2 = k2_symbol<false>(ring, feed, pos, endpos, lim, hac, closed_by_marker, i2, v, vb, adv, adv_b);
-                    err |= e2;
-                    const uint32_t ia = i2 + adv;
+                    k2_symbol<false>(ring, feed, pos, endpos, lim, hac, closed_by_marker, i2, v, vb, ia, adv_b, err);
                     const uint32_t at = ia - 2u < 126u ? ia - 2u : 126u;
                     *reinterpret_cast<int16_t *>(my_stage + (at ^ swz16)) = (int16_t)v;
-                    i2 = ia + adv_b;
+                    i2 = ia + 2u * adv_b;
                     const uint32_t at_b = i2 - 2u < 126u ? i2 - 2u : 126u;
                     *reinterpret_cast<int16_t *>(my_stage + (at_b ^ swz16)) = (int16_t)vb;
                 }

@@ -1032,8 +1032,8 @@ __device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const
             if (j < count && err == 0) {
                 // ReadBlockBaseline (ref: ScanDecoder/JpegHuffmanBaselineScanDecoder.cs:179-222)
                 int32_t v, vb;
-                uint32_t adv = 0, adv_b = 0;
-                err = k2_symbol<true>(ring, feed, pos, endpos, lim, hdc, closed_by_marker, 0u, v, vb, adv, adv_b);
+                uint32_t ia = 0, adv_b = 0;
+                k2_symbol<true>(ring, feed, pos, endpos, lim, hdc, closed_by_marker, 0u, v, vb, ia, adv_b, err);
                 const int32_t pred = ci == 0 ? pred0 : (ci == 1 ? pred1 : (ci == 2 ? pred2 : pred3));
                 v += pred;
                 if (ci == 0) pred0 = v;
@@ -1044,12 +1044,10 @@ __device__ __forceinline__ void sf_wave(const uint8_t *__restrict__ udata, const
                 uint32_t k2i = err == 0 ? 2u : 128u;
                 while (k2i < 128u) {
                     // one step = one symbol or the two of a pair entry (see K2): a step of one symbol stores it twice
-                    const uint32_t e2 = k2_symbol<false>(ring, feed, pos, endpos, lim, hac, closed_by_marker, k2i, v, vb, adv, adv_b);
-                    err |= e2;
-                    const uint32_t ia = k2i + adv;
+                    k2_symbol<false>(ring, feed, pos, endpos, lim, hac, closed_by_marker, k2i, v, vb, ia, adv_b, err);
                     const uint32_t at = ia - 2u < 126u ? ia - 2u : 126u;
                     *reinterpret_cast<int16_t *>(my_stage + (at ^ swz16)) = (int16_t)v;
-                    k2i = ia + adv_b;
+                    k2i = ia + 2u * adv_b;
                     const uint32_t at_b = k2i - 2u < 126u ? k2i - 2u : 126u;
                     *reinterpret_cast<int16_t *>(my_stage + (at_b ^ swz16)) = (int16_t)vb;
                 }

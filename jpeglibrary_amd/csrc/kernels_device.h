@@ -448,46 +448,51 @@ __device__ __forceinline__ void k2_pos_init(K2Pos &p, const uint8_t *ring, int32
 // One STEP of a lane -- one symbol, or the two symbols of a pair entry --, fast path for every lane, then ONE branch the wave skips
 // unless some lane needs more: a magnitude the index does not hold (medium), a long code (second level), the last bits of the
 // interval, a ring that ran dry, a pair whose first symbol ended the block (exact path, one symbol); advances the position.
-// i2 = 2 x zig-zag index of the next coefficient (the pair test).  adv_a2 / adv_b2 = zig-zag advance in int16 BYTES of the first /
-// second symbol (126 = EOB: past the end from any AC position; adv_b2 = 0 and vb = va: one symbol).
-// On failure the lane gets adv_a2 = 254 (leaves the AC loop), n = 0, values 0 and the detail code is returned.
+// i2 = 2 x zig-zag index of the next coefficient.  Out: ia = i2 + 2 x the first symbol's advance (the position behind it, in int16
+// BYTES; EOB: past the end from any AC position), adv_b = the second symbol's advance in coefficients (0 and vb = va: one symbol).
+// On failure the lane gets ia = i2 + 254 (leaves the AC loop), n = 0, values 0 and the detail code is ORed into `err` (touched on
+// the exact path only: the fast path carries no instruction for it).
 template <bool IS_DC>
-__device__ __forceinline__ uint32_t k2_symbol(uint8_t *ring, K2Feed &f, K2Pos &p, int32_t endpos, int32_t &lim, const K2Tab &h, bool closed_by_marker,
-                                              uint32_t i2, int32_t &va, int32_t &vb, uint32_t &adv_a2, uint32_t &adv_b2) {
+__device__ __forceinline__ void k2_symbol(uint8_t *ring, K2Feed &f, K2Pos &p, int32_t endpos, int32_t &lim, const K2Tab &h, bool closed_by_marker,
+                                          uint32_t i2, int32_t &va, int32_t &vb, uint32_t &ia, uint32_t &adv_b, uint32_t &err) {
     const uint32_t nxt = *reinterpret_cast<const uint32_t *>(ring + __builtin_amdgcn_ubfe((uint32_t)(p.pm1 + 96), 5, 4) * 4);
     const uint32_t hi = __builtin_amdgcn_alignbit(p.w0, p.w1, ~(uint32_t)p.pm1);
-    const uint32_t e = h.lut[hi >> h.shift];
+    // (the index as a shift by the table kind's constant and one shift-add for the address: hipcc's own form -- shift, mask, add --
+    // is one instruction longer; the empty asm keeps it from folding the two shifts)
+    uint32_t idx = hi >> (IS_DC ? 32u - kK2DcBits : 32u - kK2AcBits);
+    asm volatile("" : "+v"(idx));
+    const uint32_t e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(h.lut) + idx * 4u);
     uint32_t n = e & 15u;
     va = (int32_t)__builtin_amdgcn_sbfe(e, 20, 6);
     vb = (int32_t)e >> 26;
-    adv_a2 = IS_DC ? 0u : ((e >> 7) & 0x7Eu);
-    adv_b2 = IS_DC ? 0u : ((e >> 13) & 0x7Eu);
-    uint32_t err = 0;
+    ia = IS_DC ? i2 : i2 + 2u * __builtin_amdgcn_ubfe(e, 8, 6);
+    adv_b = IS_DC ? 0u : __builtin_amdgcn_ubfe(e, 14, 6);
     // slow: not a fast entry (n - 1 is negative), the step does not fit below the limit, or a pair whose first symbol ends the
-    // block (i2 + adv_a2 >= 128 with a second symbol behind it: that symbol is the next block's) -- one signed test
+    // block (ia >= 128 with a second symbol behind it: that symbol is the next block's) -- one signed test
     const int32_t room = lim - (p.pm1 + 1) - (int32_t)n;
-    const uint32_t pair_end = IS_DC ? 0u : ((127u - (i2 + adv_a2)) & (0u - adv_b2));
+    const uint32_t pair_end = IS_DC ? 0u : ((127u - ia) & (0u - adv_b));
     const bool slow = (int32_t)((n - 1u) | (uint32_t)room | pair_end) < 0;
     if (slow) {  // exec-masked; the wave skips it when no lane is flagged
         const uint32_t ntot = (e >> 19) & 63u;
         if (n == 0 && (int32_t)e > 0 && lim - (p.pm1 + 1) - (int32_t)ntot >= 0) {
-            // medium: the code fits the index, the magnitude comes from the stream (Extend(v, nbits))
+            // medium: the code fits the index, the magnitude comes from the stream (Extend(v, nbits)); its advance is where a fast entry's is
             const uint32_t cat = (e >> 14) & 31u;
             const int32_t raw = (int32_t)__builtin_amdgcn_ubfe(hi, 32u - ntot, cat);
             va = vb = raw - ((((raw + raw) >> cat) - 1) & ((1 << cat) - 1));
             n = ntot;
-            adv_b2 = 0;
+            adv_b = 0;
         } else {
             uint32_t adv = 0;
-            err = k2_slow_symbol(ring, f, p.pm1, endpos, h, IS_DC, closed_by_marker, n, va, adv);
+            const uint32_t e1 = k2_slow_symbol(ring, f, p.pm1, endpos, h, IS_DC, closed_by_marker, n, va, adv);
             vb = va;
-            adv_a2 = adv * 2u;
-            adv_b2 = 0;
+            ia = i2 + adv * 2u;
+            adv_b = 0;
             lim = k2_limit(endpos, f.wr);
-            if (err != 0) {
+            if (e1 != 0) {
+                err |= e1;
                 n = 0;
                 va = vb = 0;
-                adv_a2 = 254;
+                ia = i2 + 254u;
             }
         }
     }
@@ -497,7 +502,6 @@ __device__ __forceinline__ uint32_t k2_symbol(uint8_t *ring, K2Feed &f, K2Pos &p
     p.w0 = step ? p.w1 : p.w0;
     p.w1 = step ? p.w2 : p.w1;
     p.w2 = step ? nxt : p.w2;
-    return err;
 }
 // (ONE symbol, the table kind known only per lane: the K2S final pass on its way to its first MCU)
 __device__ __forceinline__ uint32_t k2_symbol_any(uint8_t *ring, K2Feed &f, K2Pos &p, int32_t endpos, int32_t &lim, const K2Tab &h, bool is_dc,
