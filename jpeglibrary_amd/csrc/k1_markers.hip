@@ -363,6 +363,11 @@ __device__ __forceinline__ void marker_write_chunk(const uint8_t *__restrict__ d
         if (term_here && !cap_here && (int64_t)term >= off && (int64_t)term < off + 16) markers |= 1u << (uint32_t)((int64_t)term - off);
         keep_excl = block_exclusive_scan(__builtin_popcount(c.keep) + __builtin_popcount(markers), sh_b, keep_total);
     }
+#if defined(JPGPU_K1_PRICE)
+    // (pricing build only: the compaction loop left out -- wrong output, the time of everything else)
+    *reinterpret_cast<uint4 *>(sh_tile + tid * 16) = uint4{c.w[0], c.w[1], c.w[2], c.w[3] ^ keep_excl ^ rst_excl};
+    if (false)
+#endif
     {
         uint32_t dst = keep_excl;  // chunk-relative udata position
         uint32_t idx = rst_base + rst_excl;
@@ -522,6 +527,12 @@ __global__ __launch_bounds__(kScanThreads) void marker_onepass_kernel(const uint
 #pragma unroll
     for (uint32_t i = 0; i < kK1Group; i++) {
         c[i] = classify16(raw[i], off[i], len, any_marker);
+#if defined(JPGPU_K1_PRICE) && JPGPU_K1_PRICE >= 2
+        // (pricing build only: no classification either)
+        c[i].keep = off[i] < (int64_t)len && off[i] + 16 > 0 ? 0xFFFFu : 0u;
+        c[i].rst = (c[i].w[1] & c[i].w[2] & 0x10101u) == 0x10101u ? 1u : 0u;
+        c[i].term = 0;
+#endif
         // the chunk's summary (what marker_count_kernel computes)
         const uint32_t cnt = wave_sum((uint32_t)__builtin_popcount(c[i].rst) | ((uint32_t)(__builtin_popcount(c[i].keep) + __builtin_popcount(c[i].rst | c[i].term)) << 16));
         const uint64_t has_term = __ballot(c[i].term != 0);
