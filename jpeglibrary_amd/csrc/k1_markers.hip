@@ -402,7 +402,11 @@ __device__ __forceinline__ void marker_write_chunk(const uint8_t *__restrict__ d
         for (uint32_t cbeg = c0; cbeg < keep_total; cbeg += kScanThreads * 16) {
             if (cbeg + 16 <= keep_total) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(sh_tile + cbeg);
+#if defined(JPGPU_K1_PRICE) && JPGPU_K1_PRICE == 3
+                *reinterpret_cast<uint4 *>(up + ((ubase + cbeg) & ~15u)) = v;  // (pricing build only: aligned)
+#else
                 __builtin_memcpy(up + ubase + cbeg, &v, 16);  // unaligned 16-byte global store
+#endif
             } else {
                 for (uint32_t i = cbeg; i < keep_total; i++) up[ubase + i] = sh_tile[i];
             }
@@ -492,12 +496,16 @@ __device__ __forceinline__ bool k1_read(const unsigned long long *d, uint32_t ta
 // Second form (round 5, behind the encoder's bits_emit_kernel): the first one gave every 4 KiB chunk a workgroup of its own that
 // lived ~2 us, polled for about as long, and classified its tile twice (for the summary, and again in the writer): 2.39 ms against
 // the three kernels' 1.03.  Here a workgroup takes kK1Group consecutive chunks of a scan (all their loads in flight together),
-// keeps their classification in registers for the writer -- so the bytes are classified ONCE, and these kernels are bound by
-// instruction issue -- publishes ONE summary for the group, and the groups are handed out (a global ticket into `order`) by
+// keeps their classification in registers for the writer -- so the bytes are classified ONCE -- publishes ONE summary for the group, and the groups are handed out (a global ticket into `order`) by
 // (place inside the scan, scan): the workgroups that run side by side belong to as many scans as the batch has, a scan's chain
 // is a record or two long at any time, and a scan's groups still start in the scan's order.
+// Round 6 priced the kernel (-DJPGPU_K1_PRICE=1..4, profiles/r06_k1_price.txt): neither the two byte loops nor the look-back's
+// wait bound it, the life of its 65 536 workgroups per 1024 x 4K does -- hence the group tile below and five waves per SIMD.
 constexpr uint32_t kK1Group = kMarkerGroupChunks;
-__global__ __launch_bounds__(kScanThreads) void marker_onepass_kernel(const uint8_t *__restrict__ data, const DevScan *__restrict__ scans,
+#ifndef JPGPU_K1_WAVES
+#define JPGPU_K1_WAVES 5
+#endif
+__global__ __launch_bounds__(kScanThreads, JPGPU_K1_WAVES) void marker_onepass_kernel(const uint8_t *__restrict__ data, const DevScan *__restrict__ scans,
                                                                        const ChunkWork *__restrict__ order, uint32_t n_groups,
                                                                        unsigned long long *__restrict__ desc, uint32_t *__restrict__ tickets, uint32_t epoch,
                                                                        uint32_t tag, uint32_t spin_budget,
@@ -534,7 +542,8 @@ __global__ __launch_bounds__(kScanThreads) void marker_onepass_kernel(const uint
         c[i].term = 0;
 #endif
         // the chunk's summary (what marker_count_kernel computes)
-        const uint32_t cnt = wave_sum((uint32_t)__builtin_popcount(c[i].rst) | ((uint32_t)(__builtin_popcount(c[i].keep) + __builtin_popcount(c[i].rst | c[i].term)) << 16));
+        const uint32_t own = (uint32_t)__builtin_popcount(c[i].rst) | ((uint32_t)(__builtin_popcount(c[i].keep) + __builtin_popcount(c[i].rst | c[i].term)) << 16);
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(own), 63);
         const uint64_t has_term = __ballot(c[i].term != 0);
         uint32_t tpos = kInf;
         if (has_term != 0) tpos = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off[i] + __builtin_ctz(c[i].term | 0x10000u)), (int)__builtin_ctzll(has_term));
@@ -588,7 +597,11 @@ __global__ __launch_bounds__(kScanThreads) void marker_onepass_kernel(const uint
                 // the lanes that count: the ones in front of (and including) the nearest inclusive predecessor
                 const uint32_t stop = inc != 0 ? (uint32_t)__builtin_ctzll(inc) : 63u;
                 const uint64_t upto = stop >= 63u ? ~0ull : ((2ull << stop) - 1ull);
+#if defined(JPGPU_K1_PRICE) && JPGPU_K1_PRICE == 4
+                if (false) {  // (pricing build only: nobody waits)
+#else
                 if ((none & upto) != 0) {  // somebody there has not published yet
+#endif
                     if (++polls > spin_budget) {
                         ok = false;
                         break;
@@ -645,6 +658,65 @@ __global__ __launch_bounds__(kScanThreads) void marker_onepass_kernel(const uint
             __hip_atomic_store(host_giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (page-locked host memory: a count for the tests)
         }
     }
+#if !defined(JPGPU_K1_NO_GROUP_TILE)
+    // ---- a group in the middle of its scan (nearly all of them): every chunk interior, no terminator up to and including it, the scan's
+    // last interval not closed inside it.  Nothing of the per-chunk writer's special cases can apply, the places of its bytes follow from
+    // what the summary left behind (the waves' counts in sh_cnt, the lane's place inside its wave): ONE tile of the group's udata bytes,
+    // one barrier, one copy -- the per-chunk writer below pays two block-wide scans and four barriers per chunk.
+    {
+        const int64_t g_first = -(int64_t)(s.data_off & 15u) + (int64_t)first_chunk * kChunkBytes;
+        const bool plain = g_first >= 1 && g_first + (int64_t)(kK1Group * kChunkBytes) + 1 <= (int64_t)len && x_term == kInf && a_term == kInf &&
+                           x_rst + a_rst < s.n_intervals && sh_ok != 0;  // (a group that gave up waiting has used sh_cnt[0] as its scratch)
+        if (plain) {  // (uniform)
+            __shared__ __attribute__((aligned(16))) uint8_t sh_group[kK1Group * kChunkBytes + 32];
+            uint32_t *out = ends + s.ends_off, *out_u = ends_u + s.ends_off;
+            uint8_t *up = udata + s.data_off;
+            const uint32_t wave = tid >> 6;
+#pragma unroll
+            for (uint32_t i = 0; i < kK1Group; i++) {
+                uint32_t before = 0;  // the chunk's waves in front of this one
+#pragma unroll
+                for (uint32_t w = 0; w < kScanThreads / 64; w++)
+                    if (w < wave) before += sh_cnt[i][w];
+                // (the lane's place inside its wave: the summary's scan once more -- four registers less across the look-back)
+                const uint32_t own = (uint32_t)__builtin_popcount(c[i].rst) | ((uint32_t)(__builtin_popcount(c[i].keep) + __builtin_popcount(c[i].rst)) << 16);
+                const uint32_t packed_excl = before + wave_inclusive_scan(own) - own;
+                uint32_t dst = pre_keep[i] + (packed_excl >> 16);  // place in the group's udata bytes
+                uint32_t idx = x_rst + pre_rst[i] + (packed_excl & 0xFFFFu);
+#if defined(JPGPU_K1_PRICE)
+                // (pricing build only: the compaction loop left out -- wrong output, the time of everything else)
+                *reinterpret_cast<uint4 *>(sh_group + i * kChunkBytes + tid * 16) = uint4{c[i].w[0], c[i].w[1], c[i].w[2], c[i].w[3] ^ dst ^ idx};
+                if (false)
+#endif
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if (c[i].keep & (1u << j)) {
+                        sh_group[dst] = (uint8_t)((c[i].w[j >> 2] >> ((j & 3) * 8)) & 0xFF);
+                        if (c[i].rst & (1u << j)) {  // interval end: FF FF in udata
+                            out[idx] = (uint32_t)(off[i] + j);
+                            out_u[idx] = x_keep + dst;
+                            idx++;
+                            sh_group[dst + 1] = 0xFF;
+                            dst += 2;
+                        } else {
+                            dst += 1;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            for (uint32_t cbeg = tid * 16; cbeg < a_keep; cbeg += kScanThreads * 16) {
+                if (cbeg + 16 <= a_keep) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(sh_group + cbeg);
+                    __builtin_memcpy(up + x_keep + cbeg, &v, 16);  // unaligned 16-byte global store
+                } else {
+                    for (uint32_t k = cbeg; k < a_keep; k++) up[x_keep + k] = sh_group[k];
+                }
+            }
+            return;
+        }
+    }
+#endif
 #pragma unroll
     for (uint32_t i = 0; i < kK1Group; i++) {
         if (first_chunk + i >= s.n_chunks) break;  // (uniform)

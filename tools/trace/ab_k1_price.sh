@@ -1,9 +1,10 @@
 #!/bin/bash
 # Pricing of K1's phases on ONE box (round 6): the tree as it is against copies built with -DJPGPU_K1_PRICE=1 (no compaction loop) and
-# =2 (no classification either).  The priced builds produce WRONG output: only `stage_ms.marker_index` of their lines means anything.
+# =2 (no classification either), =3 (the copy-out stores aligned), =4 (nobody waits in the look-back); K1_PRICE_VARIANTS="3 4 0" picks.  The priced builds produce WRONG output: only `stage_ms.marker_index` of their lines means anything.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R" || exit 1
-for flags in "-DJPGPU_K1_PRICE=1" "-DJPGPU_K1_PRICE=2" ""; do
+for v in ${K1_PRICE_VARIANTS:-1 2 0}; do
+  flags=""; [ "$v" != 0 ] && flags="-DJPGPU_K1_PRICE=$v"
   echo "== build flags: [$flags]"
   bash tools/trace/ab_build.sh "$flags" python3 - <<'PY'
 import json, subprocess, sys
