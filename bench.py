@@ -324,6 +324,7 @@ def measure_config(jl, sharding, jpegsynth, torch, dist, reduce_device, ctx, nam
             "roofline": {"kernel": "idct_output_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes": idct_bytes},
             "gen_s": round(t_gen, 1),
+            "marker_fallbacks": batch.marker_fallbacks(),  # groups of K1 that gave up waiting for a predecessor (expected: 0)
         }
         if dri == 0 and ss not in ("420p", "420hetp"):
             res["subseq_rounds"] = batch.subseq_rounds()
@@ -929,6 +930,7 @@ def main():
                 "sharding": "image-per-GPU, no collective",
             },
             "stage_ms": {k: round(v, 4) for k, v in stage.items()},
+            "marker_fallbacks": batch.marker_fallbacks(),  # groups of K1 that gave up waiting for a predecessor (expected: 0)
             **({"subseq_rounds": batch.subseq_rounds()} if dri == 0 and "prog" not in args.workload else {}),
             **({"content": "crops of tests/golden/HETissueSlide.jpg (the reference benchmark's image), progressive re-encode by Pillow"}
                if args.workload == "het_progressive" else {}),

@@ -496,11 +496,12 @@ __device__ __forceinline__ bool k1_read(const unsigned long long *d, uint32_t ta
 // Second form (round 5, behind the encoder's bits_emit_kernel): the first one gave every 4 KiB chunk a workgroup of its own that
 // lived ~2 us, polled for about as long, and classified its tile twice (for the summary, and again in the writer): 2.39 ms against
 // the three kernels' 1.03.  Here a workgroup takes kK1Group consecutive chunks of a scan (all their loads in flight together),
-// keeps their classification in registers for the writer -- so the bytes are classified ONCE -- publishes ONE summary for the group, and the groups are handed out (a global ticket into `order`) by
+// keeps their classification in registers for the writer -- so the bytes are classified ONCE -- publishes ONE summary for the group,
+// and the groups are handed out (round 5: a global ticket into `order`; round 6: the workgroup's own index) by
 // (place inside the scan, scan): the workgroups that run side by side belong to as many scans as the batch has, a scan's chain
 // is a record or two long at any time, and a scan's groups still start in the scan's order.
 // Round 6 priced the kernel (-DJPGPU_K1_PRICE=1..4, profiles/r06_k1_price.txt): neither the two byte loops nor the look-back's
-// wait bound it, the life of its 65 536 workgroups per 1024 x 4K does -- hence the group tile below and five waves per SIMD.
+// wait bound it, the life of its 65 536 workgroups per 1024 x 4K does -- hence the group tile below, five waves per SIMD, no ticket.
 constexpr uint32_t kK1Group = kMarkerGroupChunks;
 #ifndef JPGPU_K1_WAVES
 #define JPGPU_K1_WAVES 5
@@ -512,13 +513,27 @@ __global__ __launch_bounds__(kScanThreads, JPGPU_K1_WAVES) void marker_onepass_k
                                                                        uint32_t *__restrict__ host_giveup, uint32_t *__restrict__ ends,
                                                                        DevScanStatus *__restrict__ status, uint8_t *__restrict__ udata,
                                                                        uint32_t *__restrict__ ends_u) {
-    __shared__ uint32_t sh_ticket, sh_cnt[kK1Group][kScanThreads / 64], sh_term[kK1Group][kScanThreads / 64], sh_mine[3], sh_ok;
+    __shared__ uint32_t sh_cnt[kK1Group][kScanThreads / 64], sh_term[kK1Group][kScanThreads / 64], sh_mine[3], sh_ok;
+#if defined(JPGPU_K1_TICKETS)
+    __shared__ uint32_t sh_ticket;
+#endif
     const uint32_t tid = threadIdx.x;
-    // the group: a ticket into the order list (tickets[0] has counted n_groups per earlier decode of this upload)
+    // (-DJPGPU_K1_TICKETS: a ticket into the order list; tickets[0] has counted n_groups per earlier decode of this upload)
+#if !defined(JPGPU_K1_TICKETS)
+    // The group: the workgroup's own index into the order list.  A group only ever waits for groups in FRONT of it in that list, and the
+    // dispatcher hands workgroups out in index order (round-robin over the XCDs, in order on each): the lowest unfinished group is
+    // always resident, so somebody always makes progress.  That is an observation about this part, not a promise of the programming
+    // model -- which is why the wait below is bounded and a group that runs out of patience counts for itself: were the order ever
+    // different, the index would be slow, never wrong or stuck (jpgpu_batch_marker_fallbacks says whether it happened; the tests
+    // assert 0).  The promise costs a device-scope atomic on ONE address per workgroup and a barrier in front of the first load:
+    // 0.84 -> 0.76 ms per 1024 x 4K, 0.50 -> 0.42 at 1080p Q90, 0.82 -> 0.68 DRI = 0 (-DJPGPU_K1_TICKETS, profiles/r06_k1_group_tile_ab.txt).
+    const ChunkWork wk = order[blockIdx.x];
+#else
     if (tid == 0) sh_ticket = atomicAdd(&tickets[0], 1u) - epoch * n_groups;
     __syncthreads();
     if (sh_ticket >= n_groups) return;  // (cannot happen: one workgroup per listed group)
     const ChunkWork wk = order[sh_ticket];
+#endif
     const uint32_t scan = wk.scan, first_chunk = wk.chunk;
     const DevScan &s = scans[scan];
     const uint32_t len = s.data_len;
