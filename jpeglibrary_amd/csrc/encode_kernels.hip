@@ -1219,16 +1219,26 @@ __global__ __launch_bounds__(256) void bits_emit_kernel(const DevEncImage *__res
                                                         uint64_t *__restrict__ raw_bits, uint32_t lds_words, const uint32_t *__restrict__ order) {
     extern __shared__ uint32_t sh_words[];
     __shared__ EncHuffTable sh_tab[4];
-    __shared__ uint32_t sh_wave[4], sh_ticket, sh_prev_tail;
+    __shared__ uint32_t sh_wave[4], sh_prev_tail;
     __shared__ unsigned long long sh_base;
     const uint32_t tid = threadIdx.x;
+#if defined(JPGPU_ENC_TICKETS)
+    // (round 5: a ticket -- the place in the list in the order the workgroups START, whatever the dispatcher does)
+    __shared__ uint32_t sh_ticket;
     if (tid == 0) sh_ticket = atomicAdd(&ctl[0], 1u);
     __syncthreads();
+    const uint32_t place = sh_ticket;
+#else
+    // Round 6, as in K1 (k1_markers.hip, marker_onepass_kernel): the workgroup's own index.  Workgroups are handed out in index order,
+    // so the lowest unfinished one is always resident; the wait stays bounded and ctl[1] still sends the batch to the two-kernel
+    // path if it ever ran out -- slow then, never wrong.  Saves a device-scope atomic on one address and a barrier per workgroup.
+    const uint32_t place = blockIdx.x;
+#endif
     // order[]: the work list's entries by (place inside the image, image) -- the workgroups that run side by side then belong to
     // as many images as the batch has, and an image's chain is a handful of records long at any time.  (In work-list order all
     // ~1 500 resident workgroups sat in ONE image's chain and each walked back over all of them: 24 ms per 256 x 4K.)  An image's
     // workgroups still start in the image's order, and their records (indexed by work-list position) are consecutive.
-    const uint32_t t = order[sh_ticket];
+    const uint32_t t = order[place];
     const EncWork wk = work[t];
     const DevEncImage &im = images[wk.image];
     enc_stage_tables(tables, im.table_base, sh_tab);
