@@ -518,6 +518,19 @@ __global__ __launch_bounds__(kScanThreads, JPGPU_K1_WAVES) void marker_onepass_k
     __shared__ uint32_t sh_ticket;
 #endif
     const uint32_t tid = threadIdx.x;
+#if !defined(JPGPU_K1_NO_GROUP_TILE)
+    // the tile a group in the middle of its scan assembles its udata bytes in (below): 16 bytes in front of them, room behind them for
+    // the last lane's fifth word.  Its lanes OR their bytes into it, so it starts as zeros -- written here, in front of everything the
+    // kernel waits for; the barriers behind the summary and the look-back are in between.
+    constexpr uint32_t kTileFront = 16, kTileBytes = kTileFront + kK1Group * kChunkBytes + 48;
+    __shared__ __attribute__((aligned(16))) uint32_t sh_group_w[kTileBytes / 4];
+    uint8_t *const sh_group = reinterpret_cast<uint8_t *>(sh_group_w);
+#if !defined(JPGPU_K1_TILE_BYTE_LOOP)
+#pragma unroll
+    for (uint32_t i = 0; i < kK1Group; i++) *reinterpret_cast<uint4 *>(sh_group + i * kChunkBytes + tid * 16) = uint4{0, 0, 0, 0};
+    if (tid < (kTileBytes - kK1Group * kChunkBytes) / 16) *reinterpret_cast<uint4 *>(sh_group + kK1Group * kChunkBytes + tid * 16) = uint4{0, 0, 0, 0};
+#endif
+#endif
     // (-DJPGPU_K1_TICKETS: a ticket into the order list; tickets[0] has counted n_groups per earlier decode of this upload)
 #if !defined(JPGPU_K1_TICKETS)
     // The group: the workgroup's own index into the order list.  A group only ever waits for groups in FRONT of it in that list, and the
@@ -683,7 +696,6 @@ __global__ __launch_bounds__(kScanThreads, JPGPU_K1_WAVES) void marker_onepass_k
         const bool plain = g_first >= 1 && g_first + (int64_t)(kK1Group * kChunkBytes) + 1 <= (int64_t)len && x_term == kInf && a_term == kInf &&
                            x_rst + a_rst < s.n_intervals && sh_ok != 0;  // (a group that gave up waiting has used sh_cnt[0] as its scratch)
         if (plain) {  // (uniform)
-            __shared__ __attribute__((aligned(16))) uint8_t sh_group[kK1Group * kChunkBytes + 32];
             uint32_t *out = ends + s.ends_off, *out_u = ends_u + s.ends_off;
             uint8_t *up = udata + s.data_off;
             const uint32_t wave = tid >> 6;
@@ -699,33 +711,86 @@ __global__ __launch_bounds__(kScanThreads, JPGPU_K1_WAVES) void marker_onepass_k
                 uint32_t dst = pre_keep[i] + (packed_excl >> 16);  // place in the group's udata bytes
                 uint32_t idx = x_rst + pre_rst[i] + (packed_excl & 0xFFFFu);
 #if defined(JPGPU_K1_PRICE)
-                // (pricing build only: the compaction loop left out -- wrong output, the time of everything else)
-                *reinterpret_cast<uint4 *>(sh_group + i * kChunkBytes + tid * 16) = uint4{c[i].w[0], c[i].w[1], c[i].w[2], c[i].w[3] ^ dst ^ idx};
-                if (false)
-#endif
+                // (pricing build only: the compaction left out -- wrong output, the time of everything else)
+                *reinterpret_cast<uint4 *>(sh_group + kTileFront + i * kChunkBytes + tid * 16) = uint4{c[i].w[0], c[i].w[1], c[i].w[2], c[i].w[3] ^ dst ^ idx};
+#elif defined(JPGPU_K1_TILE_BYTE_LOOP)
+                // (the first form of the tile's writer: byte by byte, 16 single-byte LDS stores and their branches per lane)
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     if (c[i].keep & (1u << j)) {
-                        sh_group[dst] = (uint8_t)((c[i].w[j >> 2] >> ((j & 3) * 8)) & 0xFF);
+                        sh_group[kTileFront + dst] = (uint8_t)((c[i].w[j >> 2] >> ((j & 3) * 8)) & 0xFF);
                         if (c[i].rst & (1u << j)) {  // interval end: FF FF in udata
                             out[idx] = (uint32_t)(off[i] + j);
                             out_u[idx] = x_keep + dst;
                             idx++;
-                            sh_group[dst + 1] = 0xFF;
+                            sh_group[kTileFront + dst + 1] = 0xFF;
                             dst += 2;
                         } else {
                             dst += 1;
                         }
                     }
                 }
+#else
+                // The lane's 16 bytes as four words.  What udata does not take -- a stuffed zero, a fill FF, the code byte of a marker whose
+                // FF is the lane in front's last byte -- is rare per lane (one lane in sixteen) and present in nearly every wave: taken out
+                // of the words one byte per trip, lowest first, the bytes above it moving down (the wave makes as many trips as its
+                // worst lane has such bytes: one or two).  A marker's code byte inside the lane keeps its place: the second FF of the
+                // pair is ORed over it below.  Then the words go into the tile at the lane's byte offset: five aligned words, the outer
+                // two shared with the neighbours, all by OR into zeros -- no single-byte stores, no branch per byte.
+                const uint32_t rst = c[i].rst;
+                const uint32_t kept = c[i].keep | ((rst << 1) & 0xFFFFu);
+                uint32_t drop = ~kept & 0xFFFFu;
+                uint32_t w0 = c[i].w[0], w1 = c[i].w[1], w2 = c[i].w[2], w3 = c[i].w[3];
+                while (__ballot(drop != 0) != 0) {  // (uniform)
+                    if (drop != 0) {
+                        const int32_t k8 = 8 * (int32_t)__builtin_ctz(drop);  // bit position of the byte that goes
+                        const uint32_t s0 = __builtin_amdgcn_alignbit(w1, w0, 8), s1 = __builtin_amdgcn_alignbit(w2, w1, 8),
+                                       s2 = __builtin_amdgcn_alignbit(w3, w2, 8), s3 = w3 >> 8;
+                        // bits of word d at and above the byte: they take the word moved down one byte
+                        const uint32_t h0 = (uint32_t)(~0ull << (uint32_t)min(max(k8, 0), 32)), h1 = (uint32_t)(~0ull << (uint32_t)min(max(k8 - 32, 0), 32)),
+                                       h2 = (uint32_t)(~0ull << (uint32_t)min(max(k8 - 64, 0), 32)), h3 = (uint32_t)(~0ull << (uint32_t)min(max(k8 - 96, 0), 32));
+                        w0 = (w0 & ~h0) | (s0 & h0);
+                        w1 = (w1 & ~h1) | (s1 & h1);
+                        w2 = (w2 & ~h2) | (s2 & h2);
+                        w3 = (w3 & ~h3) | (s3 & h3);
+                        drop = (drop & (drop - 1u)) >> 1;  // (the bytes above it have moved down one place)
+                    }
+                }
+                {
+                    // byte offset dst of the tile's data = byte t + 1 counted from the tile's first word: the words move up by
+                    // ((t & 3) + 1) bytes from the word t lies in (1 .. 4: a funnel shift by 24, 16, 8 or 0 bits takes the right halves)
+                    const uint32_t t = dst + (kTileFront - 1), r = 24u - 8u * (t & 3u);
+                    uint32_t *q = sh_group_w + (t >> 2);
+                    __hip_atomic_fetch_or(q + 0, __builtin_amdgcn_alignbit(w0, 0u, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_or(q + 1, __builtin_amdgcn_alignbit(w1, w0, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_or(q + 2, __builtin_amdgcn_alignbit(w2, w1, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_or(q + 3, __builtin_amdgcn_alignbit(w3, w2, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_or(q + 4, __builtin_amdgcn_alignbit(0u, w3, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                // interval ends: the index entries, and FF over the place behind the marker's FF (its code byte, or -- the marker in the
+                // lane's last byte -- the place the lane's count has reserved behind its bytes)
+                uint32_t m = rst;
+                while (__ballot(m != 0) != 0) {  // (uniform)
+                    if (m != 0) {
+                        const uint32_t j = (uint32_t)__builtin_ctz(m);
+                        m &= m - 1u;
+                        const uint32_t pos = dst + (uint32_t)__builtin_popcount(kept & ((1u << j) - 1u));
+                        out[idx] = (uint32_t)(off[i] + j);
+                        out_u[idx] = x_keep + pos;
+                        idx++;
+                        const uint32_t a = pos + 1u + kTileFront;
+                        __hip_atomic_fetch_or(sh_group_w + (a >> 2), 0xFFu << (8u * (a & 3u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+#endif
             }
             __syncthreads();
             for (uint32_t cbeg = tid * 16; cbeg < a_keep; cbeg += kScanThreads * 16) {
                 if (cbeg + 16 <= a_keep) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(sh_group + cbeg);
+                    const uint4 v = *reinterpret_cast<const uint4 *>(sh_group + kTileFront + cbeg);
                     __builtin_memcpy(up + x_keep + cbeg, &v, 16);  // unaligned 16-byte global store
                 } else {
-                    for (uint32_t k = cbeg; k < a_keep; k++) up[x_keep + k] = sh_group[k];
+                    for (uint32_t k = cbeg; k < a_keep; k++) up[x_keep + k] = sh_group[kTileFront + k];
                 }
             }
             return;
