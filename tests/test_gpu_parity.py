@@ -479,6 +479,31 @@ def test_marker_index_in_one_pass_and_its_bounded_wait(monkeypatch):
         assert np.array_equal(outs[i], px), i
 
 
+def test_marker_index_tile_writer_on_dense_markers_at_every_alignment():
+    """Round 6: a group of the one-pass marker index in the middle of its scan assembles its udata bytes in one 16 KiB tile -- dropped bytes
+    taken out of the lane's four words, five aligned LDS ORs per lane, the second FF of a marker pair ORed over the code byte's place
+    (k1_markers.hip).  Its corner cases are places: a marker's FF in the last byte of a lane / a wave's 1 KiB / a chunk / a group, a
+    stuffed zero in a lane's first byte, two dropped bytes in one lane.  Files with a restart marker every MCU (tens of thousands of them
+    over ~1 MB of noisy entropy data, i.e. at every phase of 16 / 1024 / 4096 / 16384 many times over), shifted through all 16 byte
+    alignments of the segment by a comment in front -- every sample against the restatement (ref: JpegBitReader.cs:95-138, the restart
+    hand-off of JpegHuffmanBaselineScanDecoder.cs:139-163)."""
+    files = []
+    for k, (w, h, ss, q, dri) in enumerate(((2048, 1536, "444", 95, 1), (1920, 1080, "420", 98, 1), (2048, 1024, "422", 92, 2), (1600, 1200, "444", 97, 0))):
+        f = jpegsynth.encode(w, h, ss, q, dri, seed=600 + k)
+        for pad in (0, 5, 10, 15) if k == 0 else ((k * 3) % 16, (k * 7 + 1) % 16):
+            com = b"\xff\xfe" + (pad + 2).to_bytes(2, "big") + bytes(pad)
+            files.append(f[:2] + com + f[2:])
+    b = jl.Batch().upload(files, jl.FMT_INTERLEAVED_U8)
+    for _ in range(2):
+        b.decode().sync()
+        for i, f in enumerate(files):
+            ref, _ = po.decode_8bit(f)
+            assert b.result(i).status == 0, i
+            assert np.array_equal(b.output(i), ref), i
+    assert b.marker_fallbacks() == 0
+    b.close()
+
+
 def test_full_size_properties_4k():
     """BASELINE config-2 geometry at full size: every image of a small 4K batch is bit-exact vs the oracle, and the
     DRI=4 and DRI=0 encodings of the same pixels decode to identical output (restart markers carry no information)."""
