@@ -41,7 +41,8 @@ constexpr uint32_t kMarkerChunksPerWg = 1;  // marker_count_kernel takes several
 hipError_t launch_marker_index(hipStream_t stream, const uint8_t *data, const DevScan *scans, int n_scans, const ChunkWork *work,
                                int n_chunks, ChunkSum *sums, uint32_t *ends, DevScanStatus *status, uint8_t *udata, uint32_t *ends_u);
 // K1 in one pass (k1_markers.hip): desc = kMarkerDescBytes per chunk (cleared when allocated; a group uses its first chunk's),
-// tickets[0] = the ticket counter (cleared once per upload), epoch = decodes of this upload issued before this one, tag = a non-zero
+// tickets[0] = the ticket counter (cleared once per upload; read by -DJPGPU_K1_TICKETS builds only since round 6: a group takes its place
+// in `order` from its workgroup index), epoch = decodes of this upload issued before this one, tag = a non-zero
 // number no earlier launch over `desc` has used; spin_budget = polls a workgroup may spend waiting for a predecessor before it counts
 // the chunks in front of its group itself -- *host_giveup (page-locked host memory) != 0 afterwards says that happened (the results
 // are complete either way).
