@@ -293,6 +293,7 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_pool_kernel(const uint8_t 
         for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(stage)[i * 64 + lane] = z;
     }
     __syncthreads();
+#if !defined(JPGPU_K2_TICKET_AHEAD)
     for (;;) {
         uint32_t c = 0;
         if (lane == 0) c = atomicAdd(counter, 1u) - ticket_base;
@@ -301,6 +302,22 @@ __global__ __launch_bounds__(64 * WAVES) void huffman_pool_kernel(const uint8_t 
         const HuffWork wk = work[c];
         k2_wave(udata, scans[wk.scan], wk.scan, wk.first_interval, ends_u, status, coefs, tabs, blk_info, stage, ring, lane, c == 0 ? k2_t0 : K2_TICK());
     }
+#else
+    // (measured and NOT adopted, round 6: a wave drawing the ticket of its NEXT chunk before it starts on the one it holds, so that the
+    // counter's round trip lies under the chunk's first loads.  K2 4.93 -> 5.10 ms per 1024 x 4K, the benchmark canvases' Huffman stage
+    // 2.26 -> 2.48, DRI = 0 unchanged (profiles/r06_ticket_ahead_ab.txt): the loads of the chunk then queue behind the atomic in the
+    // wave's in-order counter, and a chunk waits for ITS wave.)
+    uint32_t c = 0;
+    if (lane == 0) c = atomicAdd(counter, 1u) - ticket_base;
+    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    while (c < n_chunks) {
+        uint32_t ahead = 0;
+        if (lane == 0) ahead = atomicAdd(counter, 1u) - ticket_base;
+        const HuffWork wk = work[c];
+        k2_wave(udata, scans[wk.scan], wk.scan, wk.first_interval, ends_u, status, coefs, tabs, blk_info, stage, ring, lane, c == 0 ? k2_t0 : K2_TICK());
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)ahead);
+    }
+#endif
 }
 
 static size_t k2_lds_bytes(uint32_t tab_bytes, int waves) { return (size_t)tab_bytes + (size_t)waves * kK2WaveBytes + kMaxBlocksPerMcu * sizeof(uint32_t); }

@@ -1141,6 +1141,7 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
         const HuffWork wk = {wk0.scan, wk0.first_interval + wave * 64u * spl};
         sf_wave(udata, scans[wk.scan], status[wk.scan], wk, ends_u, status, exit_state, first_block, dc_entry, coefs, tabs, blk_info, stage, ring, lane, perm, spl);
     } else {
+#if !defined(JPGPU_K2_TICKET_AHEAD)
         for (;;) {
             uint32_t c = 0;
             if (lane == 0) c = atomicAdd(counter, 1u);
@@ -1151,6 +1152,21 @@ __global__ __launch_bounds__(64 * kSubFinalMaxWaves) void subseq_final_kernel(co
             if (st.n_ends == 0) continue;
             sf_wave(udata, scans[wk.scan], st, wk, ends_u, status, exit_state, first_block, dc_entry, coefs, tabs, blk_info, stage, ring, lane, perm, spl);
         }
+#else
+        // (-DJPGPU_K2_TICKET_AHEAD: measured and not adopted, see huffman_pool_kernel in k2_huffman.hip)
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(counter, 1u);
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        while (c < n_chunks) {
+            uint32_t ahead = 0;
+            if (lane == 0) ahead = atomicAdd(counter, 1u);
+            const HuffWork wk = work[c];
+            const DevScanStatus st = status[wk.scan];
+            if (st.n_ends != 0)
+                sf_wave(udata, scans[wk.scan], st, wk, ends_u, status, exit_state, first_block, dc_entry, coefs, tabs, blk_info, stage, ring, lane, perm, spl);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)ahead);
+        }
+#endif
     }
 }
 
