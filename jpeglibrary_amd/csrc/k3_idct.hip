@@ -127,6 +127,12 @@ __device__ __forceinline__ void idct8(T &y0, T &y1, T &y2, T &y3, T &y4, T &y5, 
 // dequantised block held in registers, two lanes of the butterfly per instruction.
 // out[r * 4 + c2] = samples (r, 2*c2) | (r, 2*c2 + 1) << 16 as int16: (short)(Round(v) + levelShift), unclamped.
 __device__ __forceinline__ void block_idct(const float (&f)[64], int32_t level_shift, uint32_t (&out)[32]) {
+#if defined(JPGPU_K3_PRICE)
+    // (pricing build only, tools/trace/ab_k3_price.sh: the transform left out -- wrong samples, the time of everything else)
+#pragma unroll
+    for (int i = 0; i < 32; i++) out[i] = (__builtin_bit_cast(uint32_t, f[2 * i]) >> 16) | (__builtin_bit_cast(uint32_t, f[2 * i + 1]) & 0xFFFF0000u) | (uint32_t)level_shift;
+    return;
+#endif
     // pass 1: 1-D IDCT along each ROW (the reference transposes, runs the column butterfly, transposes back);
     // a[r2][c] holds rows 2*r2 and 2*r2+1 of column c
     float2v a[4][8];
